@@ -1,0 +1,172 @@
+/*
+ * ramp_hip.h -- C ABI of libramp_hip.so, the MI355X (gfx950) implementation of
+ * the RAMP-VO tracking hot path.
+ *
+ * Every entry point replaces one native entry point (or one fused group of
+ * ATen calls) of the reference; the reference interface it stands in for is
+ * cited as file:line (paths relative to the upstream repository).  The
+ * reference binds its natives through pybind11/torch::Tensor; this boundary is
+ * plain C: device pointers, sizes, a hipStream_t (passed as void*), int status.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless the name ends in _host
+ *   - index arrays are int64 (torch.long), like the reference
+ *   - return value: RAMP_OK (0) or a negative RAMP_E* code; kernels are
+ *     enqueued on `stream` and NOT synchronised
+ *   - no entry point allocates device memory: scratch is supplied by the
+ *     caller (`ws`, sized by the matching *_workspace_bytes query)
+ *   - poses are [tx ty tz qx qy qz qw] float32 (lietorch SE3 embedding)
+ *   - feature maps come in two layouts: RAMP_NCHW (the reference's) and
+ *     RAMP_NHWC (channels-last, this library's native layout: one pixel's
+ *     channels are contiguous so a wavefront reads whole 512 B rows)
+ */
+#ifndef RAMP_HIP_H
+#define RAMP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RAMP_OK 0
+#define RAMP_EINVAL -1      /* bad argument (null pointer, unsupported size) */
+#define RAMP_ELAUNCH -2     /* HIP reported a launch/runtime error            */
+#define RAMP_EWORKSPACE -3  /* workspace too small                            */
+#define RAMP_EUNSUPPORTED -4
+
+#define RAMP_F32 0
+#define RAMP_F16 1
+
+#define RAMP_NCHW 0
+#define RAMP_NHWC 1
+
+/* library / build identification: returns a static string */
+const char *ramp_version(void);
+
+/* ------------------------------------------------------------------ altcorr */
+
+/* cuda_corr.patchify_forward + the bilinear blend of altcorr.patchify
+ * (ramp/altcorr/correlation.cpp:47-50, correlation_kernel.cu:16-47,288-307,
+ *  ramp/altcorr/correlation.py:51-68).
+ *   net    [n][C][H][W] (NCHW) or [n][H][W][C] (NHWC), dtype
+ *   coords [n][M][2] float32 (x, y)
+ *   out    bilinear=1: [n][M][C][2R+1][2R+1]   (altcorr.patchify, fused)
+ *          bilinear=0: [n][M][C][2R+2][2R+2]   (raw cuda_corr.patchify_forward)
+ *   out_layout RAMP_NCHW: as above;  RAMP_NHWC: [n][M][d][d][C]                */
+int ramp_patchify_fwd(const void *net, const float *coords, void *out, int n, int C, int H,
+                      int W, int M, int radius, int bilinear, int dtype, int layout,
+                      int out_layout, void *stream);
+
+/* cuda_corr.forward (ramp/altcorr/correlation.cpp:28-35,
+ * correlation_kernel.cu:82-136 + host blend/permute 193-233), fused over the
+ * levels of the feature pyramid and with the torch.stack(..., -1) of
+ * ramp/Ramp_vo.py:175-182 folded into the store.
+ *   fmap1   patch features: NCHW [N1][C][P][P] or NHWC [N1][P][P][C]
+ *   level l target features: NCHW [N2][C][H2_l][W2_l] or NHWC [N2][H2_l][W2_l][C]
+ *   coords  [E][2][P][P] float32, divided by coord_div_l inside the kernel
+ *   ii[E]   index into fmap1,  jj[E] index into the level's fmap
+ *   out     [E][2R+1 (x off)][2R+1 (y off)][P][P][nlevels], dtype
+ * nlevels==1 reproduces cuda_corr.forward's (permuted, contiguous) result.   */
+typedef struct {
+  const void *fmap;
+  int H2, W2;
+  float coord_div;
+} ramp_corr_level;
+
+int ramp_corr_fwd(const void *fmap1, const ramp_corr_level *levels_host, int nlevels,
+                  const float *coords, const int64_t *ii, const int64_t *jj, void *out, int E,
+                  int N1, int N2, int C, int P, int radius, int dtype, int layout,
+                  void *stream);
+
+/* ----------------------------------------------------------------- lietorch */
+/* lietorch_backends.{expm,logm,inv,mul,act4,adj,adjT} for group_id 3 (SE3),
+ * float32, forward only (ramp/lietorch/src/lietorch.cpp:286-316; math from
+ * ramp/lietorch/include/se3.h:30-142, so3.h:31-208).  n = batch elements.   */
+int ramp_se3_exp(const float *a, float *X, int n, void *stream);
+int ramp_se3_log(const float *X, float *a, int n, void *stream);
+int ramp_se3_inv(const float *X, float *Y, int n, void *stream);
+int ramp_se3_mul(const float *X, const float *Y, float *Z, int n, void *stream);
+int ramp_se3_act4(const float *X, const float *p, float *q, int n, void *stream);
+int ramp_se3_adj(const float *X, const float *a, float *b, int n, void *stream);
+int ramp_se3_adjT(const float *X, const float *a, float *b, int n, void *stream);
+
+/* ---------------------------------------------------------- projective ops */
+/* pops.transform(SE3(poses), patches, intrinsics, ii, jj, kk[, tonly])
+ * followed by .permute(0,1,4,2,3).contiguous(), i.e. Ramp_vo.reproject
+ * (ramp/projective_ops.py:16-101 jacobian=False path, ramp/Ramp_vo.py:184-192;
+ * ~10 torch kernels + 3 lietorch launches upstream).
+ *   poses [Np][7], patches [Nk][3][P][P], intrinsics [Np][4] (per frame)
+ *   out   [E][2][P][P]                                                        */
+int ramp_transform(const float *poses, const float *patches, const float *intrinsics,
+                   const int64_t *ii, const int64_t *jj, const int64_t *kk, float *out, int E,
+                   int P, int tonly, void *stream);
+
+/* cuda_ba.reproject (ramp/fastba/ba.cpp:48-56, ba_cuda.cu:379-429,585-617):
+ * frame-0 intrinsics, no depth clamp.  out [E][2][P][P]                      */
+int ramp_reproject(const float *poses, const float *patches, const float *intrinsics,
+                   const int64_t *ii, const int64_t *jj, const int64_t *kk, float *out, int E,
+                   int P, void *stream);
+
+/* pops.point_cloud (ramp/projective_ops.py:103-105) reduced to what
+ * Ramp_vo.update keeps (ramp/Ramp_vo.py:308-310): the 3-D point of each patch
+ * centre.  ix[m] = source frame of patch m.  out [m][3]                      */
+int ramp_point_cloud(const float *poses, const float *patches, const float *intrinsics,
+                     const int64_t *ix, float *out, int m, int P, void *stream);
+
+/* ------------------------------------------------------------------- graph */
+/* group the E edges by an int64 key (device-side replacement of the
+ * torch.unique / torch::_unique / std::stable_sort host round trips at
+ * ramp/blocks.py:43, ramp/fastba/ba_cuda.cu:447, ramp/fastba/ba.cpp:59-97).
+ *   key_bound : exclusive upper bound of the keys (0 = unknown: full 63 bits)
+ *   order[E]      edge indices sorted by (key, edge index)  (stable)
+ *   gid[E]        dense rank of the edge's key among the sorted unique keys
+ *                 (== the `inverse` of torch.unique(sorted=True))
+ *   seg_start[E+1] first sorted position of every group, seg_start[G] = E
+ *   ukeys[E]      the sorted unique keys (first G entries valid), may be NULL
+ *   ngroups       device int: G                                              */
+size_t ramp_group_by_workspace_bytes(int E);
+int ramp_group_by(const int64_t *keys, int E, int64_t key_bound, int32_t *order, int32_t *gid,
+                  int32_t *seg_start, int64_t *ukeys, int32_t *ngroups, void *ws,
+                  size_t ws_bytes, void *stream);
+
+/* cuda_ba.neighbors(kk, jj) (ramp/fastba/ba.cpp:59-97): previous / next edge
+ * of the same kk ordered by jj (stable), -1 at either end.  Entirely on the
+ * device (the reference copies to the host, sorts, copies back).
+ * kk_bound / jj_bound: exclusive upper bounds (0 = unknown).                 */
+size_t ramp_neighbors_workspace_bytes(int E);
+int ramp_neighbors(const int64_t *kk, const int64_t *jj, int64_t *ix, int64_t *jx, int E,
+                   int64_t kk_bound, int64_t jj_bound, void *ws, size_t ws_bytes,
+                   void *stream);
+
+/* SoftAgg core (ramp/blocks.py:44-45; torch_scatter.scatter_softmax +
+ * scatter_sum): y[g][c] = sum_{e in g} softmax_e(gx[e][c]) * fx[e][c]
+ * with the groups given by ramp_group_by's (order, seg_start, ngroups).
+ *   fx, gx [E][C] dtype;  y [>=G][C] dtype (rows >= G untouched)             */
+int ramp_segment_softmax_sum(const void *fx, const void *gx, const int32_t *order,
+                             const int32_t *seg_start, const int32_t *ngroups, void *y, int E,
+                             int C, int max_groups, int dtype, void *stream);
+
+/* ------------------------------------------------------------------ fastba */
+/* cuda_ba.forward (ramp/fastba/ba.cpp:32-45, ba_cuda.cu:433-582): `iterations`
+ * damped Gauss-Newton steps on the reprojection error of the patch centres,
+ * poses t0..t1-1 free.  poses [n_poses][7] and patches [n_patches][3][P][P]
+ * are updated IN PLACE (rows t0..t1-1 / depth channel of the patches that
+ * appear in kk), exactly as the reference mutates its arguments.
+ *   target, weight [E][2]; lmbda [1]; intrinsics [>=1][4] (row 0 is used,
+ *   ba_cuda.cu:253-258)
+ *   info: optional device int, set to 1 if the Cholesky factorisation hit a
+ *         non-positive pivot (the reference discards cholesky_ex's info)
+ * Deterministic: all reductions are ordered segment sums, no float atomics.  */
+size_t ramp_ba_workspace_bytes(int E, int n_poses, int n_patches, int t0, int t1);
+int ramp_ba_forward(float *poses, float *patches, const float *intrinsics, const float *target,
+                    const float *weight, const float *lmbda, const int64_t *ii,
+                    const int64_t *jj, const int64_t *kk, int E, int P, int n_poses,
+                    int n_patches, int t0, int t1, int iterations, void *ws, size_t ws_bytes,
+                    int32_t *info, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAMP_HIP_H */

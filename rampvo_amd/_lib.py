@@ -1,0 +1,129 @@
+"""ctypes binding of libramp_hip.so (C ABI declared in include/ramp_hip.h).
+
+There is no CPU fallback: every operator of this package runs its HIP kernel
+or raises.  ``lib()`` raises ``RuntimeError`` if the shared library has not been
+built (``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C rampvo_amd/csrc``).
+"""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libramp_hip.so")
+
+RAMP_F32, RAMP_F16 = 0, 1
+RAMP_NCHW, RAMP_NHWC = 0, 1
+
+_ERR = {-1: "RAMP_EINVAL (bad argument)", -2: "RAMP_ELAUNCH (HIP launch/runtime error)",
+        -3: "RAMP_EWORKSPACE (workspace too small)", -4: "RAMP_EUNSUPPORTED (size/shape not supported)"}
+
+c_p, c_i, c_i64, c_sz, c_f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float
+
+
+class CorrLevel(ctypes.Structure):
+    _fields_ = [("fmap", c_p), ("H2", c_i), ("W2", c_i), ("coord_div", c_f)]
+
+
+# name -> (restype, argtypes); also the list the CPU test checks for export
+SIGNATURES = {
+    "ramp_version": (ctypes.c_char_p, []),
+    "ramp_patchify_fwd": (c_i, [c_p, c_p, c_p] + [c_i] * 10 + [c_p]),
+    "ramp_corr_fwd": (c_i, [c_p, ctypes.POINTER(CorrLevel), c_i, c_p, c_p, c_p, c_p] + [c_i] * 8 + [c_p]),
+    "ramp_se3_exp": (c_i, [c_p, c_p, c_i, c_p]),
+    "ramp_se3_log": (c_i, [c_p, c_p, c_i, c_p]),
+    "ramp_se3_inv": (c_i, [c_p, c_p, c_i, c_p]),
+    "ramp_se3_mul": (c_i, [c_p, c_p, c_p, c_i, c_p]),
+    "ramp_se3_act4": (c_i, [c_p, c_p, c_p, c_i, c_p]),
+    "ramp_se3_adj": (c_i, [c_p, c_p, c_p, c_i, c_p]),
+    "ramp_se3_adjT": (c_i, [c_p, c_p, c_p, c_i, c_p]),
+    "ramp_transform": (c_i, [c_p] * 7 + [c_i, c_i, c_i, c_p]),
+    "ramp_reproject": (c_i, [c_p] * 7 + [c_i, c_i, c_p]),
+    "ramp_point_cloud": (c_i, [c_p] * 5 + [c_i, c_i, c_p]),
+    "ramp_group_by_workspace_bytes": (c_sz, [c_i]),
+    "ramp_group_by": (c_i, [c_p, c_i, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
+    "ramp_neighbors_workspace_bytes": (c_sz, [c_i]),
+    "ramp_neighbors": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i64, c_i64, c_p, c_sz, c_p]),
+    "ramp_segment_softmax_sum": (c_i, [c_p] * 6 + [c_i, c_i, c_i, c_i, c_p]),
+    "ramp_ba_workspace_bytes": (c_sz, [c_i] * 5),
+    "ramp_ba_forward": (c_i, [c_p] * 9 + [c_i] * 7 + [c_p, c_sz, c_p, c_p]),
+}
+
+_lib = None
+
+
+def build(force=False, jobs=8):
+    """compile every HIP source for gfx950 into csrc/libramp_hip.so"""
+    cmd = ["make", "-s", "-C", CSRC, "-j%d" % jobs]
+    if force:
+        cmd.append("-B")
+    subprocess.check_call(cmd + ["libramp_hip.so"])
+    return LIB_PATH
+
+
+def register_optional(extra):
+    """late registration of signatures for optional translation units"""
+    SIGNATURES.update(extra)
+    if _lib is not None:
+        for name, (res, args) in extra.items():
+            fn = getattr(_lib, name)
+            fn.restype, fn.argtypes = res, args
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "rampvo_amd: %s is missing -- the HIP extension is not built and there is no "
+                "CPU fallback (run __graft_entry__.build())" % LIB_PATH)
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if a declared symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed: %s" % (what, _ERR.get(rc, "status %d" % rc)))
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("rampvo_amd operators run on the GPU only (got a %s tensor); "
+                               "there is no CPU fallback" % t.device)
+
+
+def dtype_code(t):
+    if t.dtype == torch.float32:
+        return RAMP_F32
+    if t.dtype == torch.float16:
+        return RAMP_F16
+    raise RuntimeError("unsupported dtype %s (float32 / float16 only)" % t.dtype)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device, tag="ws"):
+    """grow-only scratch buffer per (device, tag); contents are never reused across calls"""
+    key = (device, tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf

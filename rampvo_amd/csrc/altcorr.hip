@@ -1,0 +1,358 @@
+// altcorr: patch gather (patchify) and the fused sparse patch correlation.
+//
+// corr design (gfx950):
+//   one wavefront (64 lanes) per edge, both pyramid levels in the same block.
+//   The 9 patch pixels of an edge look up 8x8 windows that overlap almost
+//   entirely, so instead of 9*64 independent 128-long dot products the block
+//   forms the UNION of the 9 windows (typically 10x10 at level 0, 9x9 at level
+//   1), gives every union pixel to a lane (2 per lane), streams that pixel's
+//   128 channels ONCE from HBM (channels-last: 512 contiguous bytes) and
+//   accumulates it against all 9 patch pixels (held in LDS, read as wave-wide
+//   broadcasts).  The 9 x T dot-product matrix goes to LDS, the bilinear blend
+//   + permute + level interleave of the reference's host code is applied from
+//   there and the edge's 882 outputs leave as one contiguous 3.5 KB store.
+//   Edges whose reprojected patch is so distorted that the union exceeds 128
+//   pixels fall back to one 8x8 window per patch pixel (same code, 9 groups).
+//   Dots are a channel-ordered fmaf chain == the reference kernel's
+//   accumulation (correlation_kernel.cu:121-131) in fp32.
+#include "ramp_device.h"
+
+// ---------------------------------------------------------------- patchify
+template <typename T>
+__device__ __forceinline__ float ld_as_float(const T *p) { return (float)(*p); }
+template <>
+__device__ __forceinline__ float ld_as_float<__half>(const __half *p) { return __half2float(*p); }
+template <typename T>
+__device__ __forceinline__ void st_from_float(T *p, float v) { *p = (T)v; }
+template <>
+__device__ __forceinline__ void st_from_float<__half>(__half *p, float v) { *p = __float2half(v); }
+
+// reference: correlation_kernel.cu:16-47 (gather) + correlation.py:51-68 (blend)
+template <typename T>
+__global__ void __launch_bounds__(256)
+    patchify_kernel(const T *__restrict__ net, const float *__restrict__ coords,
+                    T *__restrict__ out, int C, int H, int W, int M, int R, int bilinear,
+                    int layout, int out_layout) {
+  const int bm = blockIdx.x;  // n*M + m
+  const int b = bm / M;
+  const float x = coords[2 * (size_t)bm + 0];
+  const float y = coords[2 * (size_t)bm + 1];
+  const float flx = floorf(x), fly = floorf(y);
+  const int fx = ramp_f2i(flx), fy = ramp_f2i(fly);
+  const int d = bilinear ? 2 * R + 1 : 2 * R + 2;
+  const float dx = x - flx, dy = y - fly;
+  const float w00 = (1 - dy) * (1 - dx), w01 = (1 - dy) * dx, w10 = dy * (1 - dx),
+              w11 = dy * dx;
+  const int total = C * d * d;
+  const T *nb = net + (size_t)b * C * H * W;
+  for (int o = threadIdx.x; o < total; o += blockDim.x) {
+    int k, a, c;
+    if (out_layout == RAMP_NHWC) { k = o % C; c = (o / C) % d; a = o / (C * d); }
+    else { c = o % d; a = (o / d) % d; k = o / (d * d); }
+    auto tap = [&](int aa, int cc) -> float {
+      const long i = (long)fy + (aa - R), j = (long)fx + (cc - R);
+      if (i < 0 || i >= H || j < 0 || j >= W) return 0.0f;
+      const size_t off = (layout == RAMP_NHWC) ? ((size_t)i * W + j) * C + k
+                                               : ((size_t)k * H + i) * W + j;
+      return ld_as_float(nb + off);
+    };
+    float s;
+    if (bilinear) {
+      s = w00 * tap(a, c);
+      s = s + w01 * tap(a, c + 1);
+      s = s + w10 * tap(a + 1, c);
+      s = s + w11 * tap(a + 1, c + 1);
+    } else {
+      s = tap(a, c);
+    }
+    st_from_float(out + (size_t)bm * total + o, s);
+  }
+}
+
+// -------------------------------------------------------------------- corr
+#define CORR_MAXLEV 2
+#define CORR_T 128  // union pixels handled per group (2 per lane)
+
+struct CorrParams {
+  const void *fmap1;
+  const void *fmap2[CORR_MAXLEV];
+  int H2[CORR_MAXLEV], W2[CORR_MAXLEV];
+  float cdiv[CORR_MAXLEV];
+  int nlevels;
+  const float *coords;
+  const int64_t *ii, *jj;
+  void *out;
+  int E, N1, N2;
+};
+
+template <typename T> struct Vec4;
+template <> struct Vec4<float> {
+  static __device__ __forceinline__ void load(const float *p, float *o) {
+    const float4 v = *reinterpret_cast<const float4 *>(p);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+  }
+};
+template <> struct Vec4<__half> {
+  static __device__ __forceinline__ void load(const __half *p, float *o) {
+    const uint2 v = *reinterpret_cast<const uint2 *>(p);
+    const __half2 a = *reinterpret_cast<const __half2 *>(&v.x);
+    const __half2 b = *reinterpret_cast<const __half2 *>(&v.y);
+    const float2 fa = __half22float2(a), fb = __half22float2(b);
+    o[0] = fa.x; o[1] = fa.y; o[2] = fb.x; o[3] = fb.y;
+  }
+};
+
+template <typename T, int LAYOUT>
+__global__ void __launch_bounds__(64)
+    corr_kernel(const CorrParams prm) {
+  constexpr int C = 128, P = 3, PP = 9, R = 3, D = 8, d = 7;
+  constexpr int NOUT = d * d * PP;  // 441
+  __shared__ __attribute__((aligned(16))) float f1s[PP * C];     // [p][c]
+  __shared__ __attribute__((aligned(16))) float Cs[PP * CORR_T];  // [p][t]
+  __shared__ float outs[NOUT * CORR_MAXLEV];
+  __shared__ int s_ox[PP], s_oy[PP], s_live[PP];
+  __shared__ float s_dx[PP], s_dy[PP];
+
+  const int e = blockIdx.x;
+  const int lane = threadIdx.x;
+  const long i1 = prm.ii[e], j2 = prm.jj[e];
+  const int L = prm.nlevels;
+
+  // ---- stage the patch features as fp32 [p][c]
+  {
+    const T *src = reinterpret_cast<const T *>(prm.fmap1) + (size_t)i1 * C * PP;
+    if (LAYOUT == RAMP_NHWC) {
+      for (int q = lane; q < PP * C / 4; q += 64) {
+        float v[4];
+        Vec4<T>::load(src + 4 * q, v);
+        *reinterpret_cast<float4 *>(&f1s[4 * q]) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    } else {
+      for (int q = lane; q < PP * C; q += 64) {  // src index q = c*9 + p
+        const int c = q / PP, p = q - c * PP;
+        f1s[p * C + c] = ld_as_float(src + q);
+      }
+    }
+  }
+
+  for (int lvl = 0; lvl < L; lvl++) {
+    const int H2 = prm.H2[lvl], W2 = prm.W2[lvl];
+    const T *f2 = reinterpret_cast<const T *>(prm.fmap2[lvl]) + (size_t)j2 * C * H2 * W2;
+    if (lane < PP) {
+      const float cdv = prm.cdiv[lvl];
+      const float x = prm.coords[((size_t)e * 2 + 0) * PP + lane] / cdv;
+      const float y = prm.coords[((size_t)e * 2 + 1) * PP + lane] / cdv;
+      const float flx = floorf(x), fly = floorf(y);
+      const int ox = ramp_f2i(flx), oy = ramp_f2i(fly);
+      s_dx[lane] = x - flx;
+      s_dy[lane] = y - fly;
+      // window [o-R, o-R+D) x [o-R, o-R+D) intersects the image?
+      const bool live = ((long)ox - R < W2) && ((long)ox - R + D > 0) &&
+                        ((long)oy - R < H2) && ((long)oy - R + D > 0);
+      s_live[lane] = live ? 1 : 0;
+      s_ox[lane] = live ? ox - R : 0;
+      s_oy[lane] = live ? oy - R : 0;
+    }
+    __syncthreads();
+    int minx = 1 << 30, miny = 1 << 30, maxx = -(1 << 30), maxy = -(1 << 30), nlive = 0;
+#pragma unroll
+    for (int p = 0; p < PP; p++) {
+      if (s_live[p]) {
+        nlive++;
+        minx = min(minx, s_ox[p]); maxx = max(maxx, s_ox[p]);
+        miny = min(miny, s_oy[p]); maxy = max(maxy, s_oy[p]);
+      }
+    }
+    const long bw = (long)maxx - minx + D, bh = (long)maxy - miny + D;
+    const bool uni = (nlive > 0) && (bw * bh <= CORR_T);
+    const int ngroups = (nlive == 0) ? 0 : (uni ? 1 : PP);
+
+    if (nlive == 0) {
+      // every window is outside the image: the raw correlations are all zero,
+      // the blend still multiplies them by the (possibly NaN) weights
+      for (int o = lane; o < NOUT; o += 64) {
+        const int p = o % PP;
+        const float dx = s_dx[p], dy = s_dy[p];
+        float s = ((1 - dx) * (1 - dy)) * 0.0f;
+        s = s + (dx * (1 - dy)) * 0.0f;
+        s = s + ((1 - dx) * dy) * 0.0f;
+        s = s + (dx * dy) * 0.0f;
+        outs[o * L + lvl] = s;
+      }
+    }
+
+    for (int g = 0; g < ngroups; g++) {
+      if (!uni && !s_live[g]) {
+        for (int ab = lane; ab < d * d; ab += 64) {
+          const float dx = s_dx[g], dy = s_dy[g];
+          float s = ((1 - dx) * (1 - dy)) * 0.0f;
+          s = s + (dx * (1 - dy)) * 0.0f;
+          s = s + ((1 - dx) * dy) * 0.0f;
+          s = s + (dx * dy) * 0.0f;
+          outs[(ab * PP + g) * L + lvl] = s;
+        }
+        continue;
+      }
+      const int gx0 = uni ? minx : s_ox[g], gy0 = uni ? miny : s_oy[g];
+      const int gw = uni ? (int)bw : D, gh = uni ? (int)bh : D;
+      const int Tn = gw * gh;
+
+      float acc[2][PP];
+#pragma unroll
+      for (int s = 0; s < 2; s++)
+#pragma unroll
+        for (int p = 0; p < PP; p++) acc[s][p] = 0.0f;
+      bool inb[2];
+      size_t poff[2];
+#pragma unroll
+      for (int s = 0; s < 2; s++) {
+        const int t = lane + 64 * s;
+        const int ty = t / gw, tx = t - ty * gw;
+        const int px = gx0 + tx, py = gy0 + ty;
+        inb[s] = (t < Tn) && px >= 0 && px < W2 && py >= 0 && py < H2;
+        poff[s] = (LAYOUT == RAMP_NHWC) ? ((size_t)py * W2 + px) * C : ((size_t)py * W2 + px);
+      }
+      if (LAYOUT == RAMP_NHWC) {
+#pragma unroll 2
+        for (int c4 = 0; c4 < C / 4; c4++) {
+          float v[2][4];
+#pragma unroll
+          for (int s = 0; s < 2; s++) {
+            if (inb[s]) Vec4<T>::load(f2 + poff[s] + 4 * c4, v[s]);
+            else { v[s][0] = v[s][1] = v[s][2] = v[s][3] = 0.0f; }
+          }
+#pragma unroll
+          for (int p = 0; p < PP; p++) {
+            const float4 a = *reinterpret_cast<const float4 *>(&f1s[p * C + 4 * c4]);
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+              float r = acc[s][p];
+              r = __builtin_fmaf(a.x, v[s][0], r);
+              r = __builtin_fmaf(a.y, v[s][1], r);
+              r = __builtin_fmaf(a.z, v[s][2], r);
+              r = __builtin_fmaf(a.w, v[s][3], r);
+              acc[s][p] = r;
+            }
+          }
+        }
+      } else {
+        const size_t cstride = (size_t)H2 * W2;
+#pragma unroll 4
+        for (int c = 0; c < C; c++) {
+          float v[2];
+#pragma unroll
+          for (int s = 0; s < 2; s++) v[s] = inb[s] ? ld_as_float(f2 + c * cstride + poff[s]) : 0.0f;
+#pragma unroll
+          for (int p = 0; p < PP; p++) {
+            const float a = f1s[p * C + c];
+            acc[0][p] = __builtin_fmaf(a, v[0], acc[0][p]);
+            acc[1][p] = __builtin_fmaf(a, v[1], acc[1][p]);
+          }
+        }
+      }
+      // out-of-image pixels contribute exact zeros (reference: s = 0)
+#pragma unroll
+      for (int s = 0; s < 2; s++) {
+        const int t = lane + 64 * s;
+        if (t < Tn) {
+#pragma unroll
+          for (int p = 0; p < PP; p++) Cs[p * CORR_T + t] = inb[s] ? acc[s][p] : 0.0f;
+        }
+      }
+      __syncthreads();
+      // blend 8x8 -> 7x7 and apply the reference's permute
+      const int nout = uni ? NOUT : d * d;
+      for (int o = lane; o < nout; o += 64) {
+        const int p = uni ? (o % PP) : g;
+        const int ab = uni ? (o / PP) : o;
+        const int b = ab / d, a = ab - b * d;  // b: x offset, a: y offset
+        float c00 = 0, c01 = 0, c10 = 0, c11 = 0;
+        if (s_live[p]) {
+          const int wx = s_ox[p] - gx0 + b, wy = s_oy[p] - gy0 + a;
+          const float *row = &Cs[p * CORR_T + wy * gw + wx];
+          c00 = row[0]; c01 = row[1]; c10 = row[gw]; c11 = row[gw + 1];
+        }
+        const float dx = s_dx[p], dy = s_dy[p];
+        float s = ((1 - dx) * (1 - dy)) * c00;
+        s = s + (dx * (1 - dy)) * c01;
+        s = s + ((1 - dx) * dy) * c10;
+        s = s + (dx * dy) * c11;
+        outs[(ab * PP + p) * L + lvl] = s;
+      }
+      __syncthreads();
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  T *o = reinterpret_cast<T *>(prm.out) + (size_t)e * NOUT * L;
+  for (int q = lane; q < NOUT * L; q += 64) st_from_float(o + q, outs[q]);
+}
+
+extern "C" {
+
+int ramp_patchify_fwd(const void *net, const float *coords, void *out, int n, int C, int H,
+                      int W, int M, int radius, int bilinear, int dtype, int layout,
+                      int out_layout, void *stream) {
+  if (n < 0 || M < 0 || C <= 0 || H <= 0 || W <= 0 || radius < 0) return RAMP_EINVAL;
+  if (n * M == 0) return RAMP_OK;
+  if (!net || !coords || !out) return RAMP_EINVAL;
+  if (layout != RAMP_NCHW && layout != RAMP_NHWC) return RAMP_EINVAL;
+  const int d = bilinear ? 2 * radius + 1 : 2 * radius + 2;
+  const int total = C * d * d;
+  const int threads = total >= 256 ? 256 : (total > 64 ? 128 : 64);
+  if (dtype == RAMP_F32)
+    hipLaunchKernelGGL(patchify_kernel<float>, dim3(n * M), dim3(threads), 0, (hipStream_t)stream,
+                       (const float *)net, coords, (float *)out, C, H, W, M, radius, bilinear,
+                       layout, out_layout);
+  else if (dtype == RAMP_F16)
+    hipLaunchKernelGGL(patchify_kernel<__half>, dim3(n * M), dim3(threads), 0,
+                       (hipStream_t)stream, (const __half *)net, coords, (__half *)out, C, H, W,
+                       M, radius, bilinear, layout, out_layout);
+  else
+    return RAMP_EINVAL;
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+
+int ramp_corr_fwd(const void *fmap1, const ramp_corr_level *levels, int nlevels,
+                  const float *coords, const int64_t *ii, const int64_t *jj, void *out, int E,
+                  int N1, int N2, int C, int P, int radius, int dtype, int layout,
+                  void *stream) {
+  if (E < 0 || nlevels < 1 || nlevels > CORR_MAXLEV || !levels) return RAMP_EINVAL;
+  if (C != 128 || P != 3 || radius != 3) return RAMP_EUNSUPPORTED;
+  if (E == 0) return RAMP_OK;
+  if (!fmap1 || !coords || !ii || !jj || !out) return RAMP_EINVAL;
+  CorrParams prm;
+  prm.fmap1 = fmap1;
+  for (int l = 0; l < CORR_MAXLEV; l++) {
+    const int s = l < nlevels ? l : 0;
+    if (!levels[s].fmap || levels[s].H2 <= 0 || levels[s].W2 <= 0) return RAMP_EINVAL;
+    prm.fmap2[l] = levels[s].fmap;
+    prm.H2[l] = levels[s].H2;
+    prm.W2[l] = levels[s].W2;
+    prm.cdiv[l] = levels[s].coord_div;
+  }
+  prm.nlevels = nlevels;
+  prm.coords = coords;
+  prm.ii = ii;
+  prm.jj = jj;
+  prm.out = out;
+  prm.E = E;
+  prm.N1 = N1;
+  prm.N2 = N2;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == RAMP_F32 && layout == RAMP_NHWC)
+    hipLaunchKernelGGL((corr_kernel<float, RAMP_NHWC>), dim3(E), dim3(64), 0, st, prm);
+  else if (dtype == RAMP_F32 && layout == RAMP_NCHW)
+    hipLaunchKernelGGL((corr_kernel<float, RAMP_NCHW>), dim3(E), dim3(64), 0, st, prm);
+  else if (dtype == RAMP_F16 && layout == RAMP_NHWC)
+    hipLaunchKernelGGL((corr_kernel<__half, RAMP_NHWC>), dim3(E), dim3(64), 0, st, prm);
+  else if (dtype == RAMP_F16 && layout == RAMP_NCHW)
+    hipLaunchKernelGGL((corr_kernel<__half, RAMP_NCHW>), dim3(E), dim3(64), 0, st, prm);
+  else
+    return RAMP_EINVAL;
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,513 @@
+// fastba.BA on gfx950: Gauss-Newton bundle adjustment of the sliding window.
+//
+// The reference accumulates the normal equations with ~340 float atomics per
+// edge into a 60x60 matrix and then runs ~25 ATen launches per iteration.  Here
+// every reduction is an ORDERED SEGMENT SUM (deterministic, no float atomics):
+//
+//   prep   group the edges by patch (kk) and by pose pair (ii,jj)  [graph.hip]
+//   K1     edge kernel: residual, validity, Jacobians -> 128 B record / edge
+//   K2     patch kernel: one workgroup per patch walks its edge segment and
+//          emits the dense E row [6N], C, u, Q = 1/(C+lambda)
+//   K3     pair kernel: one workgroup per (i,j) segment emits the 6x6 blocks
+//          w*Ji*Ji', w*Jj*Jj', -w*Ji*Jj', -w*Jj*Ji' and the gradient parts
+//   K4     split-K SYRK: partial  E' diag(Q) E  and  E' diag(Q) u
+//   K5     assemble  S = B - sum(partials),  y = v - ..., damping
+//   K6     single-workgroup LDS Cholesky + triangular solves -> dX
+//   K7     dZ = Q (u - E dX), depth retraction, SE3 pose retraction
+//
+// Math restates ramp/fastba/ba_cuda.cu:232-376 (kernel), 433-582 (host loop),
+// 178-229 (retractions).  Everything is fp32 like the reference (mtype=float).
+#include "ramp_device.h"
+#include "ramp_internal.h"
+
+#define BA_REC 32     // floats per edge record
+#define BA_PAIR 160   // floats per pair record (156 used)
+#define BA_TS 64      // SYRK tile
+#define BA_KB 8       // SYRK k batch
+
+static inline size_t al(size_t x) { return (x + 255) / 256 * 256; }
+
+// ------------------------------------------------------------------ K1
+__global__ void __launch_bounds__(256)
+    ba_edge_kernel(const float *__restrict__ poses, const float *__restrict__ patches,
+                   const float *__restrict__ intr, const float *__restrict__ target,
+                   const float *__restrict__ weight, const int64_t *__restrict__ ii,
+                   const int64_t *__restrict__ jj, const int64_t *__restrict__ kk,
+                   float *__restrict__ rec, int E, int PP, int c11, int t0, int N) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= E) return;
+  const float fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];
+  int ix = (int)ii[n], jx = (int)jj[n];
+  const long kx = kk[n];
+  float pi[7], pj[7];
+#pragma unroll
+  for (int c = 0; c < 7; c++) { pi[c] = poses[7 * (size_t)ix + c]; pj[c] = poses[7 * (size_t)jx + c]; }
+  float Xi[4], Xj[4];
+  Xi[0] = (patches[((size_t)kx * 3 + 0) * PP + c11] - cx) / fx;
+  Xi[1] = (patches[((size_t)kx * 3 + 1) * PP + c11] - cy) / fy;
+  Xi[2] = 1.0f;
+  Xi[3] = patches[((size_t)kx * 3 + 2) * PP + c11];
+  float tij[3], qij[4];
+  fb_relSE3(pi, pi + 3, pj, pj + 3, tij, qij);
+  fb_actSE3(tij, qij, Xi, Xj);
+  const float X = Xj[0], Y = Xj[1], Z = Xj[2], W = Xj[3];
+  const float d = (Z >= 0.2f) ? 1.0f / Z : 0.0f;
+  const float d2 = d * d;
+  const float x1 = fx * (X / Z) + cx;
+  const float y1 = fy * (Y / Z) + cy;
+  const float tx_ = target[2 * (size_t)n + 0], ty_ = target[2 * (size_t)n + 1];
+  const float rx = tx_ - x1, ry = ty_ - y1;
+  const bool in_bounds = (sqrtf(rx * rx + ry * ry) < 128) && (Z > 0.2f) && (x1 > -64) &&
+                         (y1 > -64) && (x1 < 2 * cx + 64) && (y1 < 2 * cy + 64);
+  const float mask = in_bounds ? 1.0f : 0.0f;
+  ix -= t0;
+  jx -= t0;
+  if (ix >= N) ix = -1;  // poses >= t1 are not free (out of B in the reference)
+  if (jx >= N) jx = -1;
+  if (ix < 0) ix = -1;
+  if (jx < 0) jx = -1;
+  float Jj0[6] = {fx * W * d, 0, fx * -X * W * d2, fx * -X * Y * d2, fx * (1 + X * X * d2),
+                  fx * -Y * d};
+  float Jj1[6] = {0, fy * W * d, fy * -Y * W * d2, fy * (-1 - Y * Y * d2), fy * (X * Y * d2),
+                  fy * X * d};
+  float Ji0[6], Ji1[6];
+  fb_adjSE3(tij, qij, Jj0, Ji0);
+  fb_adjSE3(tij, qij, Jj1, Ji1);
+  const float Jz0 = fx * (tij[0] * d - tij[2] * (X * d2));
+  const float Jz1 = fy * (tij[1] * d - tij[2] * (Y * d2));
+  const float w0 = mask * weight[2 * (size_t)n + 0], w1 = mask * weight[2 * (size_t)n + 1];
+  float4 *r4 = reinterpret_cast<float4 *>(rec + (size_t)n * BA_REC);
+  r4[0] = make_float4(Ji0[0], Ji0[1], Ji0[2], Ji0[3]);
+  r4[1] = make_float4(Ji0[4], Ji0[5], Ji1[0], Ji1[1]);
+  r4[2] = make_float4(Ji1[2], Ji1[3], Ji1[4], Ji1[5]);
+  r4[3] = make_float4(Jj0[0], Jj0[1], Jj0[2], Jj0[3]);
+  r4[4] = make_float4(Jj0[4], Jj0[5], Jj1[0], Jj1[1]);
+  r4[5] = make_float4(Jj1[2], Jj1[3], Jj1[4], Jj1[5]);
+  r4[6] = make_float4(w0, w1, rx, ry);
+  r4[7] = make_float4(Jz0, Jz1, __int_as_float(ix), __int_as_float(jx));
+}
+// record field offsets
+#define R_JI0 0
+#define R_JI1 6
+#define R_JJ0 12
+#define R_JJ1 18
+#define R_W0 24
+#define R_W1 25
+#define R_R0 26
+#define R_R1 27
+#define R_JZ0 28
+#define R_JZ1 29
+#define R_I 30
+#define R_J 31
+
+// ------------------------------------------------------------------ K2
+__global__ void __launch_bounds__(256)
+    ba_patch_kernel(const float *__restrict__ rec, const int32_t *__restrict__ order,
+                    const int32_t *__restrict__ seg, const int32_t *__restrict__ ngroups,
+                    const float *__restrict__ lmbda, float *__restrict__ Erow,
+                    float *__restrict__ Cv, float *__restrict__ uv, float *__restrict__ Qv,
+                    int n6) {
+  const int g = blockIdx.x;
+  if (g >= *ngroups) return;
+  const int tid = threadIdx.x;
+  if (tid >= n6 + 2) return;
+  const int s0 = seg[g], s1 = seg[g + 1];
+  float acc = 0.0f;
+  if (tid < n6) {
+    const int a = tid / 6, c = tid - a * 6;
+    for (int p = s0; p < s1; p++) {
+      const float *r = rec + (size_t)order[p] * BA_REC;
+      const int i = __float_as_int(r[R_I]), j = __float_as_int(r[R_J]);
+      if (i == a) acc += (-r[R_W0] * r[R_JZ0]) * r[R_JI0 + c];
+      if (j == a) acc += (r[R_W0] * r[R_JZ0]) * r[R_JJ0 + c];
+      if (i == a) acc += (-r[R_W1] * r[R_JZ1]) * r[R_JI1 + c];
+      if (j == a) acc += (r[R_W1] * r[R_JZ1]) * r[R_JJ1 + c];
+    }
+    Erow[(size_t)g * n6 + tid] = acc;
+  } else if (tid == n6) {
+    for (int p = s0; p < s1; p++) {
+      const float *r = rec + (size_t)order[p] * BA_REC;
+      acc += (r[R_W0] * r[R_JZ0]) * r[R_JZ0];
+      acc += (r[R_W1] * r[R_JZ1]) * r[R_JZ1];
+    }
+    Cv[g] = acc;
+    Qv[g] = 1.0f / (acc + lmbda[0]);
+  } else {
+    for (int p = s0; p < s1; p++) {
+      const float *r = rec + (size_t)order[p] * BA_REC;
+      acc += (r[R_W0] * r[R_R0]) * r[R_JZ0];
+      acc += (r[R_W1] * r[R_R1]) * r[R_JZ1];
+    }
+    uv[g] = acc;
+  }
+}
+
+// ------------------------------------------------------------------ K3
+// pair record: [0,36) w Ji Ji', [36,72) w Jj Jj', [72,108) -w Ji Jj',
+// [108,144) -w Jj Ji', [144,150) -w r Ji, [150,156) w r Jj
+__global__ void __launch_bounds__(192)
+    ba_pair_kernel(const float *__restrict__ rec, const int32_t *__restrict__ order,
+                   const int32_t *__restrict__ seg, const int32_t *__restrict__ ngroups,
+                   float *__restrict__ pairs, int32_t *__restrict__ pair_ij) {
+  const int g = blockIdx.x;
+  if (g >= *ngroups) return;
+  const int tid = threadIdx.x;
+  const int s0 = seg[g], s1 = seg[g + 1];
+  if (tid == 0) {
+    const float *r = rec + (size_t)order[s0] * BA_REC;
+    pair_ij[2 * g + 0] = __float_as_int(r[R_I]);
+    pair_ij[2 * g + 1] = __float_as_int(r[R_J]);
+  }
+  if (tid >= 156) return;
+  float acc = 0.0f;
+  if (tid < 144) {
+    const int blk = tid / 36, q = tid - blk * 36, x = q / 6, y = q - x * 6;
+    const int oa = (blk == 0 || blk == 2) ? R_JI0 : R_JJ0;  // left factor
+    const int ob = (blk == 0 || blk == 3) ? R_JI0 : R_JJ0;  // right factor
+    const float sgn = (blk >= 2) ? -1.0f : 1.0f;
+    for (int p = s0; p < s1; p++) {
+      const float *r = rec + (size_t)order[p] * BA_REC;
+      acc += ((sgn * r[R_W0]) * r[oa + x]) * r[ob + y];
+      acc += ((sgn * r[R_W1]) * r[oa + 6 + x]) * r[ob + 6 + y];
+    }
+  } else {
+    const int q = tid - 144;
+    const bool isj = q >= 6;
+    const int x = isj ? q - 6 : q;
+    const int oa = isj ? R_JJ0 : R_JI0;
+    const float sgn = isj ? 1.0f : -1.0f;
+    for (int p = s0; p < s1; p++) {
+      const float *r = rec + (size_t)order[p] * BA_REC;
+      acc += ((sgn * r[R_W0]) * r[R_R0]) * r[oa + x];
+      acc += ((sgn * r[R_W1]) * r[R_R1]) * r[oa + 6 + x];
+    }
+  }
+  pairs[(size_t)g * BA_PAIR + tid] = acc;
+}
+
+// ------------------------------------------------------------------ K4
+// S_part[z] = sum_{k in chunk z} Q_k E_k E_k' (64x64 tile per block),
+// y_part[z] = sum Q_k u_k E_k
+__global__ void __launch_bounds__(256)
+    ba_schur_kernel(const float *__restrict__ Erow, const float *__restrict__ Qv,
+                    const float *__restrict__ uv, const int32_t *__restrict__ ngroups,
+                    float *__restrict__ S_part, float *__restrict__ y_part, int n6, int KS) {
+  __shared__ float Ea[BA_KB][BA_TS];  // scaled by Q
+  __shared__ float Eb[BA_KB][BA_TS];
+  __shared__ float us[BA_KB];
+  const int nk = *ngroups;
+  const int z = blockIdx.z;
+  const int per = (nk + KS - 1) / KS;
+  const int k0 = z * per, k1 = min(nk, k0 + per);
+  const int r0 = blockIdx.x * BA_TS, c0 = blockIdx.y * BA_TS;
+  const int tid = threadIdx.x, ty = tid / 16, tx = tid % 16;
+  float acc[4][4];
+  float yacc[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int b = 0; b < 4; b++) acc[a][b] = 0.0f;
+  for (int kb = k0; kb < k1; kb += BA_KB) {
+    __syncthreads();
+    for (int q = tid; q < BA_KB * BA_TS; q += 256) {
+      const int kq = q / BA_TS, col = q - kq * BA_TS;
+      const int k = kb + kq;
+      float va = 0.0f, vb = 0.0f;
+      if (k < k1) {
+        if (r0 + col < n6) va = Erow[(size_t)k * n6 + r0 + col] * Qv[k];
+        if (c0 + col < n6) vb = Erow[(size_t)k * n6 + c0 + col];
+      }
+      Ea[kq][col] = va;
+      Eb[kq][col] = vb;
+    }
+    if (tid < BA_KB) us[tid] = (kb + tid < k1) ? uv[kb + tid] : 0.0f;
+    __syncthreads();
+#pragma unroll
+    for (int kq = 0; kq < BA_KB; kq++) {
+      float a[4], b[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) { a[q] = Ea[kq][ty * 4 + q]; b[q] = Eb[kq][tx * 4 + q]; }
+#pragma unroll
+      for (int x = 0; x < 4; x++)
+#pragma unroll
+        for (int y = 0; y < 4; y++) acc[x][y] = __builtin_fmaf(a[x], b[y], acc[x][y]);
+      if (blockIdx.y == 0 && tx == 0) {
+        const float u = us[kq];
+#pragma unroll
+        for (int x = 0; x < 4; x++) yacc[x] = __builtin_fmaf(a[x], u, yacc[x]);
+      }
+    }
+  }
+#pragma unroll
+  for (int x = 0; x < 4; x++) {
+    const int r = r0 + ty * 4 + x;
+    if (r >= n6) continue;
+#pragma unroll
+    for (int y = 0; y < 4; y++) {
+      const int c = c0 + tx * 4 + y;
+      if (c < n6) S_part[((size_t)z * n6 + r) * n6 + c] = acc[x][y];
+    }
+    if (blockIdx.y == 0 && tx == 0) y_part[(size_t)z * n6 + r] = yacc[x];
+  }
+}
+
+// ------------------------------------------------------------------ K5
+__global__ void __launch_bounds__(256)
+    ba_assemble_kernel(const float *__restrict__ pairs, const int32_t *__restrict__ pair_ij,
+                       const int32_t *__restrict__ npairs, const float *__restrict__ S_part,
+                       const float *__restrict__ y_part, float *__restrict__ S,
+                       float *__restrict__ yv, int n6, int KS) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n6 * n6) return;
+  const int r = idx / n6, c = idx - r * n6;
+  const int a = r / 6, x = r - a * 6, b = c / 6, y = c - b * 6;
+  const int np = *npairs;
+  float bsum = 0.0f, vsum = 0.0f;
+  for (int g = 0; g < np; g++) {
+    const int i = pair_ij[2 * g], j = pair_ij[2 * g + 1];
+    const float *pr = pairs + (size_t)g * BA_PAIR;
+    if (i == a && i == b) bsum += pr[x * 6 + y];
+    if (j == a && j == b) bsum += pr[36 + x * 6 + y];
+    if (i == a && j == b) bsum += pr[72 + x * 6 + y];
+    if (j == a && i == b) bsum += pr[108 + x * 6 + y];
+    if (c == 0) {
+      if (i == a) vsum += pr[144 + x];
+      if (j == a) vsum += pr[150 + x];
+    }
+  }
+  float sp = 0.0f;
+  for (int z = 0; z < KS; z++) sp += S_part[((size_t)z * n6 + r) * n6 + c];
+  float s = bsum - sp;
+  if (r == c) s += (1e-4f * s + 1.0f);
+  S[(size_t)r * n6 + c] = s;
+  if (c == 0) {
+    float yp = 0.0f;
+    for (int z = 0; z < KS; z++) yp += y_part[(size_t)z * n6 + r];
+    yv[r] = vsum - yp;
+  }
+}
+
+// ------------------------------------------------------------------ K6
+// single workgroup, matrix in LDS (row stride n6+1), right-looking Cholesky
+// whose per-element update order (k ascending, separate mul/sub) equals the
+// textbook left-looking loop, then column-oriented forward/back substitution.
+__global__ void __launch_bounds__(1024)
+    ba_chol_kernel(const float *__restrict__ S, const float *__restrict__ yv,
+                   float *__restrict__ dX, int32_t *__restrict__ info, int n6) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int ld = n6 + 1;
+  float *A = sm;             // n6 x ld
+  float *t = sm + n6 * ld;   // n6
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int q = tid; q < n6 * n6; q += nt) {
+    const int r = q / n6, c = q - r * n6;
+    A[r * ld + c] = S[q];
+  }
+  for (int q = tid; q < n6; q += nt) t[q] = yv[q];
+  __syncthreads();
+  for (int j = 0; j < n6; j++) {
+    if (tid == 0) {
+      const float dgn = A[j * ld + j];
+      if (!(dgn > 0.0f) && info) *info = 1;
+      A[j * ld + j] = sqrtf(dgn);
+    }
+    __syncthreads();
+    const float ljj = A[j * ld + j];
+    for (int i = j + 1 + tid; i < n6; i += nt) A[i * ld + j] = A[i * ld + j] / ljj;
+    __syncthreads();
+    // trailing lower triangle: (i,k), j < k <= i < n6
+    const int m = n6 - j - 1;
+    for (int q = tid; q < m * m; q += nt) {
+      const int ri = q / m, ck = q - ri * m;
+      if (ck <= ri) {
+        const int i = j + 1 + ri, k = j + 1 + ck;
+        A[i * ld + k] = A[i * ld + k] - A[i * ld + j] * A[k * ld + j];
+      }
+    }
+    __syncthreads();
+  }
+  // forward: L z = y
+  for (int k = 0; k < n6; k++) {
+    if (tid == 0) t[k] = t[k] / A[k * ld + k];
+    __syncthreads();
+    const float xk = t[k];
+    for (int i = k + 1 + tid; i < n6; i += nt) t[i] = t[i] - A[i * ld + k] * xk;
+    __syncthreads();
+  }
+  // backward: L' x = z
+  for (int k = n6 - 1; k >= 0; k--) {
+    if (tid == 0) t[k] = t[k] / A[k * ld + k];
+    __syncthreads();
+    const float xk = t[k];
+    for (int i = tid; i < k; i += nt) t[i] = t[i] - A[k * ld + i] * xk;
+    __syncthreads();
+  }
+  for (int q = tid; q < n6; q += nt) dX[q] = t[q];
+}
+
+// ------------------------------------------------------------------ K7
+__global__ void __launch_bounds__(256)
+    ba_retract_kernel(float *__restrict__ poses, float *__restrict__ patches,
+                      const float *__restrict__ Erow, const float *__restrict__ Qv,
+                      const float *__restrict__ uv, const float *__restrict__ dX,
+                      const int64_t *__restrict__ kx, const int32_t *__restrict__ ngroups,
+                      int n6, int PP, int t0, int N, int depth_blocks) {
+  if ((int)blockIdx.x >= depth_blocks) {
+    // pose retraction (ba_cuda.cu:178-206)
+    const int i = (blockIdx.x - depth_blocks) * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float *p = poses + 7 * (size_t)(t0 + i);
+    float xi[6], to[3] = {p[0], p[1], p[2]}, qo[4] = {p[3], p[4], p[5], p[6]}, tn[3], qn[4];
+#pragma unroll
+    for (int c = 0; c < 6; c++) xi[c] = dX[6 * i + c];
+    fb_retrSE3(xi, to, qo, tn, qn);
+    p[0] = tn[0]; p[1] = tn[1]; p[2] = tn[2];
+    p[3] = qn[0]; p[4] = qn[1]; p[5] = qn[2]; p[6] = qn[3];
+    return;
+  }
+  // depth retraction (ba_cuda.cu:209-229), one wavefront per patch
+  const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
+  const int g = blockIdx.x * (blockDim.x / 64) + wave;
+  if (g >= *ngroups) return;
+  float s = 0.0f;
+  for (int a = lane; a < n6; a += 64) s += Erow[(size_t)g * n6 + a] * dX[a];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  s = __shfl(s, 0, 64);
+  const float dz = Qv[g] * (uv[g] - s);
+  float *pt = patches + ((size_t)kx[g] * 3 + 2) * PP;
+  float dd = pt[0];
+  dd = dd + dz;
+  dd = (dd > 20) ? 1.0f : dd;
+  dd = fmaxf(dd, 1e-4f);
+  // every lane has read pt[0] (same address) before any lane stores
+  if (lane < PP) pt[lane] = dd;
+}
+
+__global__ void ba_pairkey_kernel(const int64_t *__restrict__ ii, const int64_t *__restrict__ jj,
+                                  int64_t *__restrict__ keys, int E, long long np) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n < E) keys[n] = ii[n] * np + jj[n];
+}
+
+// ------------------------------------------------------------- host driver
+struct BaWs {
+  void *gb; size_t gb_bytes;
+  int64_t *pkeys, *kx, *pukeys;
+  int32_t *order_k, *seg_k, *order_p, *seg_p, *pair_ij, *counters;
+  float *rec, *Erow, *Cv, *uv, *Qv, *pairs, *S_part, *y_part, *S, *yv, *dX;
+  int Mu_b, Gp_b, KS, tiles;
+};
+static size_t ba_carve(void *ws, int E, int n_poses, int n_patches, int N, BaWs *w) {
+  const size_t e = (size_t)(E > 0 ? E : 1);
+  const int n6 = 6 * N;
+  size_t off = 0;
+  char *base = (char *)ws;
+  auto take = [&](size_t bytes) { char *p = base ? base + off : nullptr; off += al(bytes); return (void *)p; };
+  w->Mu_b = (int)((size_t)n_patches < e ? (size_t)n_patches : e);
+  if (w->Mu_b < 1) w->Mu_b = 1;
+  const size_t pp = (size_t)n_poses * (size_t)n_poses;
+  w->Gp_b = (int)(pp < e ? pp : e);
+  if (w->Gp_b < 1) w->Gp_b = 1;
+  w->tiles = (n6 + BA_TS - 1) / BA_TS;
+  if (w->tiles < 1) w->tiles = 1;
+  int ks = 256 / (w->tiles * w->tiles);
+  w->KS = ks < 4 ? 4 : (ks > 64 ? 64 : ks);
+  w->gb_bytes = ramp_internal_group_by_ws(E);
+  w->gb = take(w->gb_bytes);
+  w->pkeys = (int64_t *)take(e * 8);
+  w->kx = (int64_t *)take(e * 8);
+  w->pukeys = (int64_t *)take(e * 8);
+  w->order_k = (int32_t *)take(e * 4);
+  w->seg_k = (int32_t *)take((e + 1) * 4);
+  w->order_p = (int32_t *)take(e * 4);
+  w->seg_p = (int32_t *)take((e + 1) * 4);
+  w->pair_ij = (int32_t *)take((size_t)w->Gp_b * 8);
+  w->counters = (int32_t *)take(64);
+  w->rec = (float *)take(e * BA_REC * 4);
+  w->Erow = (float *)take((size_t)w->Mu_b * (n6 > 0 ? n6 : 1) * 4);
+  w->Cv = (float *)take((size_t)w->Mu_b * 4);
+  w->uv = (float *)take((size_t)w->Mu_b * 4);
+  w->Qv = (float *)take((size_t)w->Mu_b * 4);
+  w->pairs = (float *)take((size_t)w->Gp_b * BA_PAIR * 4);
+  w->S_part = (float *)take((size_t)w->KS * (n6 * n6 + 1) * 4);
+  w->y_part = (float *)take((size_t)w->KS * (n6 + 1) * 4);
+  w->S = (float *)take((size_t)(n6 * n6 + 1) * 4);
+  w->yv = (float *)take((size_t)(n6 + 1) * 4);
+  w->dX = (float *)take((size_t)(n6 + 1) * 4);
+  return off;
+}
+
+extern "C" {
+
+size_t ramp_ba_workspace_bytes(int E, int n_poses, int n_patches, int t0, int t1) {
+  BaWs w;
+  const int N = t1 - t0 > 0 ? t1 - t0 : 0;
+  return ba_carve(nullptr, E, n_poses, n_patches, N, &w);
+}
+
+int ramp_ba_forward(float *poses, float *patches, const float *intrinsics, const float *target,
+                    const float *weight, const float *lmbda, const int64_t *ii,
+                    const int64_t *jj, const int64_t *kk, int E, int P, int n_poses,
+                    int n_patches, int t0, int t1, int iterations, void *ws, size_t ws_bytes,
+                    int32_t *info, void *stream) {
+  if (E < 0 || P < 2 || n_poses <= 0 || n_patches <= 0 || iterations < 0) return RAMP_EINVAL;
+  if (t0 < 0 || t1 < t0 || t1 > n_poses) return RAMP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (info) hipMemsetAsync(info, 0, sizeof(int32_t), st);
+  if (E == 0 || iterations == 0) return RAMP_OK;
+  if (!poses || !patches || !intrinsics || !target || !weight || !lmbda || !ii || !jj || !kk ||
+      !ws)
+    return RAMP_EINVAL;
+  const int N = t1 - t0, n6 = 6 * N;
+  const size_t lds = (size_t)(n6 * (n6 + 1) + n6) * sizeof(float);
+  if (lds > 160 * 1024) return RAMP_EUNSUPPORTED;  // > 32 free poses: S does not fit one LDS
+  BaWs w;
+  if (ba_carve(ws, E, n_poses, n_patches, N, &w) > ws_bytes) return RAMP_EWORKSPACE;
+  int32_t *nk = w.counters, *np = w.counters + 1;
+  const int PP = P * P, c11 = 1 * P + 1;
+  int rc;
+  // ---- prep: group by patch, group by pose pair
+  rc = ramp_internal_group_by(kk, E, n_patches, w.order_k, nullptr, w.seg_k, w.kx, nk, w.gb,
+                              w.gb_bytes, st);
+  if (rc != RAMP_OK) return rc;
+  if (N > 0) {
+    hipLaunchKernelGGL(ba_pairkey_kernel, dim3(ramp_cdiv(E, 256)), dim3(256), 0, st, ii, jj,
+                       w.pkeys, E, (long long)n_poses);
+    rc = ramp_internal_group_by(w.pkeys, E, (int64_t)n_poses * n_poses, w.order_p, nullptr,
+                                w.seg_p, w.pukeys, np, w.gb, w.gb_bytes, st);
+    if (rc != RAMP_OK) return rc;
+    if (lds > 64 * 1024) {
+      if (hipFuncSetAttribute((const void *)ba_chol_kernel,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return RAMP_ELAUNCH;
+    }
+  }
+  const int pthreads = ((n6 + 2 + 63) / 64) * 64;
+  if (pthreads > 256) return RAMP_EUNSUPPORTED;
+  const int depth_blocks = ramp_cdiv(w.Mu_b, 4);
+  const int pose_blocks = N > 0 ? ramp_cdiv(N, 256) : 0;
+  for (int itr = 0; itr < iterations; itr++) {
+    hipLaunchKernelGGL(ba_edge_kernel, dim3(ramp_cdiv(E, 256)), dim3(256), 0, st, poses, patches,
+                       intrinsics, target, weight, ii, jj, kk, w.rec, E, PP, c11, t0, N);
+    hipLaunchKernelGGL(ba_patch_kernel, dim3(w.Mu_b), dim3(pthreads), 0, st, w.rec, w.order_k,
+                       w.seg_k, nk, lmbda, w.Erow, w.Cv, w.uv, w.Qv, n6);
+    if (N > 0) {
+      hipLaunchKernelGGL(ba_pair_kernel, dim3(w.Gp_b), dim3(192), 0, st, w.rec, w.order_p, w.seg_p,
+                         np, w.pairs, w.pair_ij);
+      hipLaunchKernelGGL(ba_schur_kernel, dim3(w.tiles, w.tiles, w.KS), dim3(256), 0, st, w.Erow,
+                         w.Qv, w.uv, nk, w.S_part, w.y_part, n6, w.KS);
+      hipLaunchKernelGGL(ba_assemble_kernel, dim3(ramp_cdiv(n6 * n6, 256)), dim3(256), 0, st,
+                         w.pairs, w.pair_ij, np, w.S_part, w.y_part, w.S, w.yv, n6, w.KS);
+      hipLaunchKernelGGL(ba_chol_kernel, dim3(1), dim3(n6 <= 64 ? 256 : 1024), lds, st, w.S, w.yv,
+                         w.dX, info, n6);
+    }
+    hipLaunchKernelGGL(ba_retract_kernel, dim3(depth_blocks + pose_blocks), dim3(256), 0, st,
+                       poses, patches, w.Erow, w.Qv, w.uv, w.dX, w.kx, nk, n6, PP, t0, N,
+                       depth_blocks);
+    RAMP_CHECK_LAUNCH();
+  }
+  return RAMP_OK;
+}
+
+}  // extern "C"

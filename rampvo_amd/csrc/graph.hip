@@ -1,0 +1,263 @@
+// Edge-graph primitives: group-by-key (stable radix sort + segment heads),
+// temporal neighbours and the SoftAgg segment softmax/sum -- the device-side
+// replacements of the reference's torch.unique syncs and its host std::stable_sort.
+#include "ramp_device.h"
+#include "ramp_internal.h"
+#include <hipcub/hipcub.hpp>
+
+#define GR_THREADS 256
+
+static inline int key_bits(int64_t bound) {
+  if (bound <= 0) return 63;
+  int b = 1;
+  while (b < 63 && ((int64_t)1 << b) < bound) b++;
+  return b;
+}
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+__global__ void __launch_bounds__(GR_THREADS)
+    gb_init_kernel(const int64_t *__restrict__ keys, unsigned long long *__restrict__ k64,
+                   int32_t *__restrict__ iota, int E) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= E) return;
+  k64[i] = (unsigned long long)keys[i];
+  iota[i] = i;
+}
+__global__ void __launch_bounds__(GR_THREADS)
+    gb_heads_kernel(const unsigned long long *__restrict__ ks, int32_t *__restrict__ heads, int E) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= E) return;
+  heads[p] = (p == 0 || ks[p] != ks[p - 1]) ? 1 : 0;
+}
+__global__ void __launch_bounds__(GR_THREADS)
+    gb_finish_kernel(const unsigned long long *__restrict__ ks, const int32_t *__restrict__ order,
+                     const int32_t *__restrict__ heads, const int32_t *__restrict__ incl,
+                     int32_t *__restrict__ gid, int32_t *__restrict__ seg_start,
+                     int64_t *__restrict__ ukeys, int32_t *__restrict__ ngroups, int E) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= E) return;
+  const int g = incl[p] - 1;
+  if (gid) gid[order[p]] = g;
+  if (heads[p]) {
+    seg_start[g] = p;
+    if (ukeys) ukeys[g] = (int64_t)ks[p];
+  }
+  if (p == E - 1) {
+    seg_start[g + 1] = E;
+    *ngroups = g + 1;
+  }
+}
+
+// workspace carve for group_by
+struct GbWs {
+  unsigned long long *k_in, *k_out;
+  int32_t *iota, *heads, *incl;
+  void *cub;
+  size_t cub_bytes;
+};
+static size_t gb_cub_bytes(int E) {
+  size_t a = 0, b = 0;
+  unsigned long long *k = nullptr;
+  int32_t *v = nullptr;
+  hipcub::DeviceRadixSort::SortPairs(nullptr, a, k, k, v, v, E > 0 ? E : 1, 0, 64, (hipStream_t)0);
+  hipcub::DeviceScan::InclusiveSum(nullptr, b, v, v, E > 0 ? E : 1, (hipStream_t)0);
+  return align_up((a > b ? a : b) + 256, 256);
+}
+static size_t gb_carve(void *ws, int E, GbWs *w) {
+  const size_t n = (size_t)(E > 0 ? E : 1);
+  size_t off = 0;
+  char *base = (char *)ws;
+  auto take = [&](size_t bytes) { char *p = base ? base + off : nullptr; off += align_up(bytes, 256); return p; };
+  w->k_in = (unsigned long long *)take(n * 8);
+  w->k_out = (unsigned long long *)take(n * 8);
+  w->iota = (int32_t *)take(n * 4);
+  w->heads = (int32_t *)take(n * 4);
+  w->incl = (int32_t *)take(n * 4);
+  w->cub_bytes = gb_cub_bytes(E);
+  w->cub = take(w->cub_bytes);
+  return off;
+}
+
+// keys already prepared in w.k_in / w.iota
+static int gb_run_sorted(GbWs &w, int E, int bits, int32_t *order, int32_t *gid,
+                         int32_t *seg_start, int64_t *ukeys, int32_t *ngroups, hipStream_t st) {
+  size_t cb = w.cub_bytes;
+  if (hipcub::DeviceRadixSort::SortPairs(w.cub, cb, w.k_in, w.k_out, w.iota, order, E, 0, bits,
+                                         st) != hipSuccess)
+    return RAMP_ELAUNCH;
+  const int nb = ramp_cdiv(E, GR_THREADS);
+  hipLaunchKernelGGL(gb_heads_kernel, dim3(nb), dim3(GR_THREADS), 0, st, w.k_out, w.heads, E);
+  cb = w.cub_bytes;
+  if (hipcub::DeviceScan::InclusiveSum(w.cub, cb, w.heads, w.incl, E, st) != hipSuccess)
+    return RAMP_ELAUNCH;
+  hipLaunchKernelGGL(gb_finish_kernel, dim3(nb), dim3(GR_THREADS), 0, st, w.k_out, order, w.heads,
+                     w.incl, gid, seg_start, ukeys, ngroups, E);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+
+size_t ramp_internal_group_by_ws(int E) {
+  GbWs w;
+  return gb_carve(nullptr, E, &w);
+}
+
+int ramp_internal_group_by(const int64_t *keys, int E, int64_t key_bound, int32_t *order,
+                           int32_t *gid, int32_t *seg_start, int64_t *ukeys, int32_t *ngroups,
+                           void *ws, size_t ws_bytes, hipStream_t st) {
+  if (E < 0 || !ngroups || !seg_start) return RAMP_EINVAL;
+  if (E == 0) {
+    hipMemsetAsync(ngroups, 0, sizeof(int32_t), st);
+    hipMemsetAsync(seg_start, 0, sizeof(int32_t), st);
+    return RAMP_OK;
+  }
+  if (!keys || !order || !ws) return RAMP_EINVAL;
+  GbWs w;
+  if (gb_carve(ws, E, &w) > ws_bytes) return RAMP_EWORKSPACE;
+  hipLaunchKernelGGL(gb_init_kernel, dim3(ramp_cdiv(E, GR_THREADS)), dim3(GR_THREADS), 0, st, keys,
+                     w.k_in, w.iota, E);
+  return gb_run_sorted(w, E, key_bits(key_bound), order, gid, seg_start, ukeys, ngroups, st);
+}
+
+// ---------------------------------------------------------------- neighbors
+__global__ void __launch_bounds__(GR_THREADS)
+    nb_key_kernel(const int64_t *__restrict__ kk, const int64_t *__restrict__ jj,
+                  unsigned long long *__restrict__ k64, int32_t *__restrict__ iota, int E,
+                  long long jmul) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= E) return;
+  k64[i] = (unsigned long long)(kk[i] * jmul + jj[i]);
+  iota[i] = i;
+}
+__global__ void __launch_bounds__(GR_THREADS)
+    nb_gather_key_kernel(const int64_t *__restrict__ kk, const int32_t *__restrict__ order_in,
+                         unsigned long long *__restrict__ k64, int E) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= E) return;
+  k64[i] = (unsigned long long)kk[order_in[i]];
+}
+__global__ void __launch_bounds__(GR_THREADS)
+    nb_link_kernel(const int64_t *__restrict__ kk, const int32_t *__restrict__ order,
+                   int64_t *__restrict__ ix, int64_t *__restrict__ jx, int E) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= E) return;
+  const int e = order[p];
+  const int64_t k = kk[e];
+  int64_t prev = -1, next = -1;
+  if (p > 0) { const int q = order[p - 1]; if (kk[q] == k) prev = q; }
+  if (p + 1 < E) { const int q = order[p + 1]; if (kk[q] == k) next = q; }
+  ix[e] = prev;
+  jx[e] = next;
+}
+
+// ---------------------------------------------------- segment softmax + sum
+// one workgroup per group, lanes over channels; three ordered passes over the
+// group's rows (max, sum of exp, weighted sum) == torch_scatter's composite
+// scatter_softmax followed by scatter_sum, in sorted (= ascending edge) order.
+template <typename T>
+__global__ void __launch_bounds__(128)
+    seg_softmax_sum_kernel(const T *__restrict__ fx, const T *__restrict__ gx,
+                           const int32_t *__restrict__ order, const int32_t *__restrict__ seg_start,
+                           const int32_t *__restrict__ ngroups, T *__restrict__ y, int C) {
+  const int g = blockIdx.x;
+  if (g >= *ngroups) return;
+  const int s0 = seg_start[g], s1 = seg_start[g + 1];
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float m = -INFINITY;
+    for (int p = s0; p < s1; p++) {
+      const float v = (float)gx[(size_t)order[p] * C + c];
+      m = v > m ? v : m;
+    }
+    float s = 0.0f;
+    for (int p = s0; p < s1; p++) s += expf((float)gx[(size_t)order[p] * C + c] - m);
+    float acc = 0.0f;
+    for (int p = s0; p < s1; p++) {
+      const size_t r = (size_t)order[p] * C + c;
+      const float w = expf((float)gx[r] - m) / s;
+      acc += (float)fx[r] * w;
+    }
+    y[(size_t)g * C + c] = (T)acc;
+  }
+}
+
+extern "C" {
+
+size_t ramp_group_by_workspace_bytes(int E) { return ramp_internal_group_by_ws(E); }
+
+int ramp_group_by(const int64_t *keys, int E, int64_t key_bound, int32_t *order, int32_t *gid,
+                  int32_t *seg_start, int64_t *ukeys, int32_t *ngroups, void *ws,
+                  size_t ws_bytes, void *stream) {
+  return ramp_internal_group_by(keys, E, key_bound, order, gid, seg_start, ukeys, ngroups, ws,
+                                ws_bytes, (hipStream_t)stream);
+}
+
+size_t ramp_neighbors_workspace_bytes(int E) {
+  const size_t n = (size_t)(E > 0 ? E : 1);
+  return ramp_internal_group_by_ws(E) + 2 * align_up(n * 4, 256);
+}
+
+int ramp_neighbors(const int64_t *kk, const int64_t *jj, int64_t *ix, int64_t *jx, int E,
+                   int64_t kk_bound, int64_t jj_bound, void *ws, size_t ws_bytes,
+                   void *stream) {
+  if (E < 0) return RAMP_EINVAL;
+  if (E == 0) return RAMP_OK;
+  if (!kk || !jj || !ix || !jx || !ws) return RAMP_EINVAL;
+  if (ws_bytes < ramp_neighbors_workspace_bytes(E)) return RAMP_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  GbWs w;
+  const size_t used = gb_carve(ws, E, &w);
+  int32_t *order1 = (int32_t *)((char *)ws + used);
+  int32_t *order2 = (int32_t *)((char *)ws + used + align_up((size_t)E * 4, 256));
+  const int nb = ramp_cdiv(E, GR_THREADS);
+  size_t cb;
+  const int bk = key_bits(kk_bound), bj = key_bits(jj_bound);
+  if (kk_bound > 0 && jj_bound > 0 && bk + bj <= 62) {
+    // one pass: composite key (kk, jj); radix sort is stable in the edge index
+    hipLaunchKernelGGL(nb_key_kernel, dim3(nb), dim3(GR_THREADS), 0, st, kk, jj, w.k_in, w.iota, E,
+                       (long long)jj_bound);
+    cb = w.cub_bytes;
+    // kk*jj_bound + jj < kk_bound*jj_bound <= 2^(bk+bj)
+    if (hipcub::DeviceRadixSort::SortPairs(w.cub, cb, w.k_in, w.k_out, w.iota, order2, E, 0,
+                                           bk + bj, st) != hipSuccess)
+      return RAMP_ELAUNCH;
+  } else {
+    // two stable passes: by jj, then by kk
+    hipLaunchKernelGGL(gb_init_kernel, dim3(nb), dim3(GR_THREADS), 0, st, jj, w.k_in, w.iota, E);
+    cb = w.cub_bytes;
+    if (hipcub::DeviceRadixSort::SortPairs(w.cub, cb, w.k_in, w.k_out, w.iota, order1, E, 0, bj,
+                                           st) != hipSuccess)
+      return RAMP_ELAUNCH;
+    hipLaunchKernelGGL(nb_gather_key_kernel, dim3(nb), dim3(GR_THREADS), 0, st, kk, order1, w.k_in,
+                       E);
+    cb = w.cub_bytes;
+    if (hipcub::DeviceRadixSort::SortPairs(w.cub, cb, w.k_in, w.k_out, order1, order2, E, 0, bk,
+                                           st) != hipSuccess)
+      return RAMP_ELAUNCH;
+  }
+  hipLaunchKernelGGL(nb_link_kernel, dim3(nb), dim3(GR_THREADS), 0, st, kk, order2, ix, jx, E);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+
+int ramp_segment_softmax_sum(const void *fx, const void *gx, const int32_t *order,
+                             const int32_t *seg_start, const int32_t *ngroups, void *y, int E,
+                             int C, int max_groups, int dtype, void *stream) {
+  if (E < 0 || C <= 0 || max_groups < 0) return RAMP_EINVAL;
+  if (E == 0 || max_groups == 0) return RAMP_OK;
+  if (!fx || !gx || !order || !seg_start || !ngroups || !y) return RAMP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == RAMP_F32)
+    hipLaunchKernelGGL(seg_softmax_sum_kernel<float>, dim3(max_groups), dim3(128), 0, st,
+                       (const float *)fx, (const float *)gx, order, seg_start, ngroups, (float *)y,
+                       C);
+  else if (dtype == RAMP_F16)
+    hipLaunchKernelGGL(seg_softmax_sum_kernel<_Float16>, dim3(max_groups), dim3(128), 0, st,
+                       (const _Float16 *)fx, (const _Float16 *)gx, order, seg_start, ngroups,
+                       (_Float16 *)y, C);
+  else
+    return RAMP_EINVAL;
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,248 @@
+// SE3 batched forward ops, the fused projective transform and the fastba
+// reprojection kernel.  One lane per group element / edge: these are pure
+// latency kernels (a few hundred bytes per element), the win over the
+// reference is fusing ~13 launches (inv, mul, 9x broadcast act4, iproj, proj)
+// of pops.transform into one.
+#include "ramp_device.h"
+
+#define LIE_THREADS 256
+
+// ------------------------------------------------------------------ SE3 ops
+// reference: lietorch_gpu.cu forward kernels (one thread per element),
+// math from se3.h / so3.h (see ramp_device.h)
+__global__ void __launch_bounds__(LIE_THREADS) se3_exp_kernel(const float *a, float *X, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float xi[6], o[7];
+  for (int k = 0; k < 6; k++) xi[k] = a[6 * (size_t)i + k];
+  lt_exp(xi, o);
+  for (int k = 0; k < 7; k++) X[7 * (size_t)i + k] = o[k];
+}
+__global__ void __launch_bounds__(LIE_THREADS) se3_log_kernel(const float *X, float *a, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float x[7], o[6];
+  for (int k = 0; k < 7; k++) x[k] = X[7 * (size_t)i + k];
+  lt_log(x, o);
+  for (int k = 0; k < 6; k++) a[6 * (size_t)i + k] = o[k];
+}
+__global__ void __launch_bounds__(LIE_THREADS) se3_inv_kernel(const float *X, float *Y, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float x[7], o[7];
+  for (int k = 0; k < 7; k++) x[k] = X[7 * (size_t)i + k];
+  lt_inv(x, o);
+  for (int k = 0; k < 7; k++) Y[7 * (size_t)i + k] = o[k];
+}
+__global__ void __launch_bounds__(LIE_THREADS)
+    se3_mul_kernel(const float *X, const float *Y, float *Z, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float x[7], y[7], o[7];
+  for (int k = 0; k < 7; k++) { x[k] = X[7 * (size_t)i + k]; y[k] = Y[7 * (size_t)i + k]; }
+  lt_mul(x, y, o);
+  for (int k = 0; k < 7; k++) Z[7 * (size_t)i + k] = o[k];
+}
+__global__ void __launch_bounds__(LIE_THREADS)
+    se3_act4_kernel(const float *X, const float *p, float *q, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float x[7], t[3], r[4], pp[4], o[4];
+  for (int k = 0; k < 7; k++) x[k] = X[7 * (size_t)i + k];
+  for (int k = 0; k < 4; k++) pp[k] = p[4 * (size_t)i + k];
+  lt_load(x, t, r);
+  lt_act4_tq(t, r, pp, o);
+  for (int k = 0; k < 4; k++) q[4 * (size_t)i + k] = o[k];
+}
+template <bool TRANSPOSE>
+__global__ void __launch_bounds__(LIE_THREADS)
+    se3_adj_kernel(const float *X, const float *a, float *b, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float x[7], Ad[36], v[6];
+  for (int k = 0; k < 7; k++) x[k] = X[7 * (size_t)i + k];
+  for (int k = 0; k < 6; k++) v[k] = a[6 * (size_t)i + k];
+  lt_Adj(x, Ad);
+#pragma unroll
+  for (int r = 0; r < 6; r++) {
+    float s = 0;
+#pragma unroll
+    for (int c = 0; c < 6; c++) s += (TRANSPOSE ? Ad[c * 6 + r] : Ad[r * 6 + c]) * v[c];
+    b[6 * (size_t)i + r] = s;
+  }
+}
+
+#define LIE_LAUNCH(kern, n, ...)                                                        \
+  do {                                                                                  \
+    if ((n) < 0) return RAMP_EINVAL;                                                    \
+    if ((n) == 0) return RAMP_OK;                                                       \
+    hipLaunchKernelGGL(kern, dim3(ramp_cdiv((n), LIE_THREADS)), dim3(LIE_THREADS), 0,   \
+                       (hipStream_t)stream, __VA_ARGS__);                               \
+    RAMP_CHECK_LAUNCH();                                                                \
+    return RAMP_OK;                                                                     \
+  } while (0)
+
+extern "C" {
+int ramp_se3_exp(const float *a, float *X, int n, void *stream) {
+  if (n > 0 && (!a || !X)) return RAMP_EINVAL;
+  LIE_LAUNCH(se3_exp_kernel, n, a, X, n);
+}
+int ramp_se3_log(const float *X, float *a, int n, void *stream) {
+  if (n > 0 && (!a || !X)) return RAMP_EINVAL;
+  LIE_LAUNCH(se3_log_kernel, n, X, a, n);
+}
+int ramp_se3_inv(const float *X, float *Y, int n, void *stream) {
+  if (n > 0 && (!Y || !X)) return RAMP_EINVAL;
+  LIE_LAUNCH(se3_inv_kernel, n, X, Y, n);
+}
+int ramp_se3_mul(const float *X, const float *Y, float *Z, int n, void *stream) {
+  if (n > 0 && (!X || !Y || !Z)) return RAMP_EINVAL;
+  LIE_LAUNCH(se3_mul_kernel, n, X, Y, Z, n);
+}
+int ramp_se3_act4(const float *X, const float *p, float *q, int n, void *stream) {
+  if (n > 0 && (!X || !p || !q)) return RAMP_EINVAL;
+  LIE_LAUNCH(se3_act4_kernel, n, X, p, q, n);
+}
+int ramp_se3_adj(const float *X, const float *a, float *b, int n, void *stream) {
+  if (n > 0 && (!X || !a || !b)) return RAMP_EINVAL;
+  LIE_LAUNCH(se3_adj_kernel<false>, n, X, a, b, n);
+}
+int ramp_se3_adjT(const float *X, const float *a, float *b, int n, void *stream) {
+  if (n > 0 && (!X || !a || !b)) return RAMP_EINVAL;
+  LIE_LAUNCH(se3_adj_kernel<true>, n, X, a, b, n);
+}
+}  // extern "C"
+
+// ----------------------------------------------------- pops.transform fused
+// reference: ramp/projective_ops.py:16-101 (iproj, Gij = Tj * Ti^-1 through
+// lietorch inv/mul, act4 broadcast over the patch, proj with Z clamped at 0.1)
+template <int P>
+__global__ void __launch_bounds__(LIE_THREADS)
+    transform_kernel(const float *__restrict__ poses, const float *__restrict__ patches,
+                     const float *__restrict__ intr, const int64_t *__restrict__ ii,
+                     const int64_t *__restrict__ jj, const int64_t *__restrict__ kk,
+                     float *__restrict__ out, int E, int tonly) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const long i = ii[e], j = jj[e], k = kk[e];
+  float Ti[7], Tj[7], Tinv[7], G[7];
+#pragma unroll
+  for (int c = 0; c < 7; c++) { Ti[c] = poses[7 * i + c]; Tj[c] = poses[7 * j + c]; }
+  lt_inv(Ti, Tinv);
+  lt_mul(Tj, Tinv, G);
+  if (tonly) { G[3] = 0; G[4] = 0; G[5] = 0; G[6] = 1; }
+  float t[3], q[4];
+  lt_load(G, t, q);
+  const float fxi = intr[4 * i + 0], fyi = intr[4 * i + 1], cxi = intr[4 * i + 2],
+              cyi = intr[4 * i + 3];
+  const float fxj = intr[4 * j + 0], fyj = intr[4 * j + 1], cxj = intr[4 * j + 2],
+              cyj = intr[4 * j + 3];
+  const float *pt = patches + (size_t)k * 3 * P * P;
+  float *o = out + (size_t)e * 2 * P * P;
+#pragma unroll
+  for (int a = 0; a < P * P; a++) {
+    float X0[4], X1[4];
+    X0[0] = (pt[a] - cxi) / fxi;
+    X0[1] = (pt[P * P + a] - cyi) / fyi;
+    X0[2] = 1.0f;
+    X0[3] = pt[2 * P * P + a];
+    lt_act4_tq(t, q, X0, X1);
+    const float Z = X1[2] < 0.1f ? 0.1f : X1[2];
+    const float d = 1.0f / Z;
+    o[a] = fxj * (d * X1[0]) + cxj;
+    o[P * P + a] = fyj * (d * X1[1]) + cyj;
+  }
+}
+
+// reference: ramp/fastba/ba_cuda.cu:379-429
+template <int P>
+__global__ void __launch_bounds__(LIE_THREADS)
+    reproject_kernel(const float *__restrict__ poses, const float *__restrict__ patches,
+                     const float *__restrict__ intr, const int64_t *__restrict__ ii,
+                     const int64_t *__restrict__ jj, const int64_t *__restrict__ kk,
+                     float *__restrict__ out, int E) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const float fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];
+  const long i = ii[e], j = jj[e], k = kk[e];
+  float pi[7], pj[7], tij[3], qij[4];
+#pragma unroll
+  for (int c = 0; c < 7; c++) { pi[c] = poses[7 * i + c]; pj[c] = poses[7 * j + c]; }
+  fb_relSE3(pi, pi + 3, pj, pj + 3, tij, qij);
+  const float *pt = patches + (size_t)k * 3 * P * P;
+  float *o = out + (size_t)e * 2 * P * P;
+#pragma unroll
+  for (int a = 0; a < P * P; a++) {
+    float Xi[4] = {(pt[a] - cx) / fx, (pt[P * P + a] - cy) / fy, 1.0f, pt[2 * P * P + a]};
+    float Xj[4];
+    fb_actSE3(tij, qij, Xi, Xj);
+    o[a] = fx * (Xj[0] / Xj[2]) + cx;
+    o[P * P + a] = fy * (Xj[1] / Xj[2]) + cy;
+  }
+}
+
+// reference: ramp/projective_ops.py:103-105 + ramp/Ramp_vo.py:308-310
+template <int P>
+__global__ void __launch_bounds__(LIE_THREADS)
+    point_cloud_kernel(const float *__restrict__ poses, const float *__restrict__ patches,
+                       const float *__restrict__ intr, const int64_t *__restrict__ ix,
+                       float *__restrict__ out, int m) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= m) return;
+  const long f = ix[n];
+  float T[7], Tinv[7], t[3], q[4];
+#pragma unroll
+  for (int c = 0; c < 7; c++) T[c] = poses[7 * f + c];
+  lt_inv(T, Tinv);
+  lt_load(Tinv, t, q);
+  const float *pt = patches + (size_t)n * 3 * P * P;
+  const int a = (P / 2) * P + (P / 2);
+  float X0[4], X1[4];
+  X0[0] = (pt[a] - intr[4 * f + 2]) / intr[4 * f + 0];
+  X0[1] = (pt[P * P + a] - intr[4 * f + 3]) / intr[4 * f + 1];
+  X0[2] = 1.0f;
+  X0[3] = pt[2 * P * P + a];
+  lt_act4_tq(t, q, X0, X1);
+  out[3 * (size_t)n + 0] = X1[0] / X1[3];
+  out[3 * (size_t)n + 1] = X1[1] / X1[3];
+  out[3 * (size_t)n + 2] = X1[2] / X1[3];
+}
+
+extern "C" {
+int ramp_transform(const float *poses, const float *patches, const float *intrinsics,
+                   const int64_t *ii, const int64_t *jj, const int64_t *kk, float *out, int E,
+                   int P, int tonly, void *stream) {
+  if (E < 0) return RAMP_EINVAL;
+  if (E == 0) return RAMP_OK;
+  if (!poses || !patches || !intrinsics || !ii || !jj || !kk || !out) return RAMP_EINVAL;
+  if (P != 3) return RAMP_EUNSUPPORTED;
+  hipLaunchKernelGGL(transform_kernel<3>, dim3(ramp_cdiv(E, LIE_THREADS)), dim3(LIE_THREADS), 0,
+                     (hipStream_t)stream, poses, patches, intrinsics, ii, jj, kk, out, E, tonly);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+int ramp_reproject(const float *poses, const float *patches, const float *intrinsics,
+                   const int64_t *ii, const int64_t *jj, const int64_t *kk, float *out, int E,
+                   int P, void *stream) {
+  if (E < 0) return RAMP_EINVAL;
+  if (E == 0) return RAMP_OK;
+  if (!poses || !patches || !intrinsics || !ii || !jj || !kk || !out) return RAMP_EINVAL;
+  if (P != 3) return RAMP_EUNSUPPORTED;
+  hipLaunchKernelGGL(reproject_kernel<3>, dim3(ramp_cdiv(E, LIE_THREADS)), dim3(LIE_THREADS), 0,
+                     (hipStream_t)stream, poses, patches, intrinsics, ii, jj, kk, out, E);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+int ramp_point_cloud(const float *poses, const float *patches, const float *intrinsics,
+                     const int64_t *ix, float *out, int m, int P, void *stream) {
+  if (m < 0) return RAMP_EINVAL;
+  if (m == 0) return RAMP_OK;
+  if (!poses || !patches || !intrinsics || !ix || !out) return RAMP_EINVAL;
+  if (P != 3) return RAMP_EUNSUPPORTED;
+  hipLaunchKernelGGL(point_cloud_kernel<3>, dim3(ramp_cdiv(m, LIE_THREADS)), dim3(LIE_THREADS), 0,
+                     (hipStream_t)stream, poses, patches, intrinsics, ix, out, m);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+const char *ramp_version(void) { return "rampvo-mi355x libramp_hip 0.1 (gfx950)"; }
+}  // extern "C"

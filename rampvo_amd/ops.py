@@ -1,0 +1,224 @@
+"""Tensor-level wrappers over the C ABI (include/ramp_hip.h).
+
+Each function takes/returns torch CUDA tensors and enqueues one HIP kernel (or a
+short fixed pipeline) on torch's current stream.  No CPU fallbacks.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import RAMP_NCHW, RAMP_NHWC, CorrLevel, check, dtype_code, lib, ptr, require_cuda, stream
+
+
+# ------------------------------------------------------------------- altcorr
+def patchify(net, coords, radius, bilinear=True, layout=RAMP_NCHW, out_layout=RAMP_NCHW):
+    """net [n,C,H,W] (NCHW) or [n,H,W,C] (NHWC); coords [n,M,2] -> [n,M,C,d,d] (or [n,M,d,d,C])"""
+    require_cuda(net, coords)
+    net = net.contiguous()
+    coords = coords.contiguous().float()
+    if layout == RAMP_NCHW:
+        n, C, H, W = net.shape
+    else:
+        n, H, W, C = net.shape
+    M = coords.shape[1]
+    d = 2 * radius + 1 if bilinear else 2 * radius + 2
+    shape = (n, M, C, d, d) if out_layout == RAMP_NCHW else (n, M, d, d, C)
+    out = torch.empty(shape, dtype=net.dtype, device=net.device)
+    check(lib().ramp_patchify_fwd(ptr(net), ptr(coords), ptr(out), n, C, H, W, M, radius,
+                                  int(bilinear), dtype_code(net), layout, out_layout, stream()),
+          "ramp_patchify_fwd")
+    return out
+
+
+def corr(fmap1, fmaps2, coords, ii, jj, radius=3, coord_divs=(1.0,), layout=RAMP_NCHW):
+    """fused multi-level patch correlation.
+
+    fmap1  [N1,C,P,P] (NCHW) / [N1,P,P,C] (NHWC) patch features
+    fmaps2 list of per-level target maps [N2,C,H,W] / [N2,H,W,C]
+    coords [E,2,P,P] float32;  ii,jj [E] int64
+    -> [E, 2r+1, 2r+1, P, P, nlevels]
+    """
+    require_cuda(fmap1, coords, ii, jj, *fmaps2)
+    fmap1 = fmap1.contiguous()
+    fmaps2 = [f.contiguous() for f in fmaps2]
+    coords = coords.contiguous().float()
+    ii = ii.contiguous()
+    jj = jj.contiguous()
+    assert ii.dtype == torch.int64 and jj.dtype == torch.int64
+    if layout == RAMP_NCHW:
+        N1, C, P, _ = fmap1.shape
+    else:
+        N1, P, _, C = fmap1.shape
+    E = coords.shape[0]
+    L = len(fmaps2)
+    levels = (CorrLevel * L)()
+    N2 = fmaps2[0].shape[0]
+    for l, f in enumerate(fmaps2):
+        assert f.dtype == fmap1.dtype and f.shape[0] == N2
+        H2, W2 = (f.shape[2], f.shape[3]) if layout == RAMP_NCHW else (f.shape[1], f.shape[2])
+        levels[l] = CorrLevel(f.data_ptr(), H2, W2, float(coord_divs[l]))
+    d = 2 * radius + 1
+    out = torch.empty((E, d, d, P, P, L), dtype=fmap1.dtype, device=fmap1.device)
+    check(lib().ramp_corr_fwd(ptr(fmap1), levels, L, ptr(coords), ptr(ii), ptr(jj), ptr(out), E,
+                              N1, N2, C, P, radius, dtype_code(fmap1), layout, stream()),
+          "ramp_corr_fwd")
+    return out
+
+
+# ------------------------------------------------------------------ lietorch
+def _flat(x, dim):
+    return x.reshape(-1, dim).contiguous().float()
+
+
+def se3_unary(name, x, din, dout):
+    require_cuda(x)
+    shp = x.shape[:-1]
+    x2 = _flat(x, din)
+    out = torch.empty((x2.shape[0], dout), dtype=torch.float32, device=x.device)
+    check(getattr(lib(), name)(ptr(x2), ptr(out), x2.shape[0], stream()), name)
+    return out.view(shp + (dout,))
+
+
+def se3_binary(name, x, y, dx, dy, dout):
+    require_cuda(x, y)
+    bs = torch.broadcast_shapes(x.shape[:-1], y.shape[:-1])
+    x2 = x.float().expand(bs + (dx,)).reshape(-1, dx).contiguous()
+    y2 = y.float().expand(bs + (dy,)).reshape(-1, dy).contiguous()
+    out = torch.empty((x2.shape[0], dout), dtype=torch.float32, device=x.device)
+    check(getattr(lib(), name)(ptr(x2), ptr(y2), ptr(out), x2.shape[0], stream()), name)
+    return out.view(bs + (dout,))
+
+
+# ----------------------------------------------------------- projective ops
+def _idx(t):
+    assert t.dtype == torch.int64
+    return t.contiguous()
+
+
+def transform(poses, patches, intrinsics, ii, jj, kk, tonly=False):
+    """Ramp_vo.reproject: poses [..,7], patches [..,3,P,P], intrinsics [..,4] -> [1,E,2,P,P]"""
+    require_cuda(poses, patches, intrinsics, ii, jj, kk)
+    P = patches.shape[-1]
+    poses = poses.reshape(-1, 7).contiguous().float()
+    patches = patches.reshape(-1, 3, P, P).contiguous().float()
+    intrinsics = intrinsics.reshape(-1, 4).contiguous().float()
+    E = ii.shape[0]
+    out = torch.empty((1, E, 2, P, P), dtype=torch.float32, device=poses.device)
+    check(lib().ramp_transform(ptr(poses), ptr(patches), ptr(intrinsics), ptr(_idx(ii)),
+                               ptr(_idx(jj)), ptr(_idx(kk)), ptr(out), E, P, int(bool(tonly)),
+                               stream()), "ramp_transform")
+    return out
+
+
+def reproject(poses, patches, intrinsics, ii, jj, kk):
+    """cuda_ba.reproject -> [1,E,2,P,P]"""
+    require_cuda(poses, patches, intrinsics, ii, jj, kk)
+    P = patches.shape[-1]
+    poses = poses.reshape(-1, 7).contiguous().float()
+    patches = patches.reshape(-1, 3, P, P).contiguous().float()
+    intrinsics = intrinsics.reshape(-1, 4).contiguous().float()
+    E = ii.shape[0]
+    out = torch.empty((1, E, 2, P, P), dtype=torch.float32, device=poses.device)
+    check(lib().ramp_reproject(ptr(poses), ptr(patches), ptr(intrinsics), ptr(_idx(ii)),
+                               ptr(_idx(jj)), ptr(_idx(kk)), ptr(out), E, P, stream()),
+          "ramp_reproject")
+    return out
+
+
+def point_cloud(poses, patches, intrinsics, ix):
+    """3-D point of every patch centre: patches [m,3,P,P] (or [1,m,..]), ix [m] -> [m,3]"""
+    require_cuda(poses, patches, intrinsics, ix)
+    P = patches.shape[-1]
+    poses = poses.reshape(-1, 7).contiguous().float()
+    patches = patches.reshape(-1, 3, P, P).contiguous().float()
+    intrinsics = intrinsics.reshape(-1, 4).contiguous().float()
+    m = ix.shape[0]
+    assert patches.shape[0] >= m
+    out = torch.empty((m, 3), dtype=torch.float32, device=poses.device)
+    check(lib().ramp_point_cloud(ptr(poses), ptr(patches), ptr(intrinsics), ptr(_idx(ix)),
+                                 ptr(out), m, P, stream()), "ramp_point_cloud")
+    return out
+
+
+# --------------------------------------------------------------------- graph
+class Groups:
+    """result of group_by: order/gid/seg_start/ukeys/ngroups (device tensors)"""
+    __slots__ = ("order", "gid", "seg_start", "ukeys", "ngroups", "E")
+
+
+def group_by(keys, key_bound=0):
+    require_cuda(keys)
+    keys = _idx(keys)
+    E = keys.shape[0]
+    dev = keys.device
+    g = Groups()
+    g.E = E
+    g.order = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+    g.gid = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+    g.seg_start = torch.empty(E + 1, dtype=torch.int32, device=dev)
+    g.ukeys = torch.empty(max(E, 1), dtype=torch.int64, device=dev)
+    g.ngroups = torch.empty(1, dtype=torch.int32, device=dev)
+    nbytes = lib().ramp_group_by_workspace_bytes(E)
+    ws = _lib.workspace(nbytes, dev, "graph")
+    check(lib().ramp_group_by(ptr(keys), E, int(key_bound), ptr(g.order), ptr(g.gid),
+                              ptr(g.seg_start), ptr(g.ukeys), ptr(g.ngroups), ptr(ws),
+                              ws.numel(), stream()), "ramp_group_by")
+    return g
+
+
+def neighbors(kk, jj, kk_bound=0, jj_bound=0):
+    require_cuda(kk, jj)
+    kk, jj = _idx(kk), _idx(jj)
+    E = kk.shape[0]
+    ix = torch.empty(E, dtype=torch.int64, device=kk.device)
+    jx = torch.empty(E, dtype=torch.int64, device=kk.device)
+    if E == 0:
+        return ix, jx
+    nbytes = lib().ramp_neighbors_workspace_bytes(E)
+    ws = _lib.workspace(nbytes, kk.device, "graph")
+    check(lib().ramp_neighbors(ptr(kk), ptr(jj), ptr(ix), ptr(jx), E, int(kk_bound),
+                               int(jj_bound), ptr(ws), ws.numel(), stream()), "ramp_neighbors")
+    return ix, jx
+
+
+def segment_softmax_sum(fx, gx, groups, max_groups):
+    """y[g] = sum_{e in g} softmax_e(gx[e]) * fx[e];  fx,gx [E,C] -> y [max_groups,C]"""
+    require_cuda(fx, gx)
+    fx = fx.contiguous()
+    gx = gx.contiguous()
+    assert fx.dtype == gx.dtype and fx.shape == gx.shape
+    E, C = fx.shape
+    y = torch.zeros((max_groups, C), dtype=fx.dtype, device=fx.device)
+    check(lib().ramp_segment_softmax_sum(ptr(fx), ptr(gx), ptr(groups.order),
+                                         ptr(groups.seg_start), ptr(groups.ngroups), ptr(y), E, C,
+                                         int(max_groups), dtype_code(fx), stream()),
+          "ramp_segment_softmax_sum")
+    return y
+
+
+# -------------------------------------------------------------------- fastba
+def ba(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t1, iterations=2,
+       info=None):
+    """in-place bundle adjustment (cuda_ba.forward).  poses [..,7] and patches
+    [..,3,P,P] must be contiguous float32 views of the caller's storage."""
+    require_cuda(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk)
+    for t in (poses, patches):
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise RuntimeError("BA mutates poses/patches in place: contiguous float32 required")
+    P = patches.shape[-1]
+    n_poses = poses.numel() // 7
+    n_patches = patches.numel() // (3 * P * P)
+    intrinsics = intrinsics.reshape(-1, 4).contiguous().float()
+    target = target.reshape(-1, 2).contiguous().float()
+    weight = weight.reshape(-1, 2).contiguous().float()
+    lmbda = lmbda.reshape(-1).contiguous().float()
+    E = ii.shape[0]
+    assert target.shape[0] == E and weight.shape[0] == E
+    nbytes = lib().ramp_ba_workspace_bytes(E, n_poses, n_patches, int(t0), int(t1))
+    ws = _lib.workspace(nbytes, poses.device, "ba")
+    check(lib().ramp_ba_forward(ptr(poses), ptr(patches), ptr(intrinsics), ptr(target),
+                                ptr(weight), ptr(lmbda), ptr(_idx(ii)), ptr(_idx(jj)),
+                                ptr(_idx(kk)), E, P, n_poses, n_patches, int(t0), int(t1),
+                                int(iterations), ptr(ws), ws.numel(), ptr(info), stream()),
+          "ramp_ba_forward")

@@ -1,0 +1,70 @@
+"""Seeded synthetic problem instances shared by the CPU (oracle) and GPU (parity) tests."""
+import numpy as np
+
+
+def se3_exp_np(xi):
+    """tiny numpy SE3 exp (tests only) -> [tx ty tz qx qy qz qw]"""
+    import oracle as orc
+    return orc.se3_exp(np.asarray(xi, np.float32))
+
+
+def ba_scene(seed=0, n_frames=8, M=12, lifetime=5, H=120, W=160, noise=1.5, n_total_frames=None,
+             far=False):
+    """A small sliding-window graph shaped like Ramp_vo's: every patch of frame i is
+    connected to the frames within `lifetime` of i (both directions, incl. i itself)."""
+    rng = np.random.default_rng(seed)
+    N = n_total_frames or n_frames
+    xi = np.zeros((N, 6), np.float32)
+    xi[:n_frames] = np.cumsum(rng.normal(0, [0.05, 0.03, 0.02, 0.01, 0.01, 0.01], (n_frames, 6)), 0)
+    import oracle as orc
+    poses = orc.se3_exp(xi).astype(np.float32)
+    poses[n_frames:] = [0, 0, 0, 0, 0, 0, 1]
+    fx = fy = W * 0.5
+    cx, cy = W * 0.5, H * 0.5
+    intr = np.tile(np.array([fx, fy, cx, cy], np.float32), (N, 1))
+    patches = np.zeros((N * M, 3, 3, 3), np.float32)
+    for f in range(n_frames):
+        for m in range(M):
+            x = rng.uniform(8, W - 8) + rng.uniform(0, 1)
+            y = rng.uniform(8, H - 8)
+            gx, gy = np.meshgrid(np.arange(-1, 2), np.arange(-1, 2))
+            patches[f * M + m, 0] = x + gx
+            patches[f * M + m, 1] = y + gy
+            patches[f * M + m, 2] = rng.uniform(0.15, 1.2)
+    ii, jj, kk = [], [], []
+    for f in range(n_frames):
+        for m in range(M):
+            for j in range(max(0, f - lifetime), min(n_frames, f + lifetime + 1)):
+                ii.append(f); jj.append(j); kk.append(f * M + m)
+    ii, jj, kk = (np.asarray(a, np.int64) for a in (ii, jj, kk))
+    perm = rng.permutation(len(ii)) if far else np.arange(len(ii))
+    ii, jj, kk = ii[perm], jj[perm], kk[perm]
+    coords = orc.transform(poses, patches, intr, ii, jj, kk)[0]          # [E,2,3,3]
+    target = coords[:, :, 1, 1] + rng.normal(0, noise, (len(ii), 2)).astype(np.float32)
+    weight = rng.uniform(0.0, 1.0, (len(ii), 2)).astype(np.float32)
+    # a few gross outliers / out-of-image targets exercise the validity mask
+    bad = rng.choice(len(ii), size=max(1, len(ii) // 40), replace=False)
+    target[bad] += rng.normal(0, 300, (len(bad), 2)).astype(np.float32)
+    return dict(poses=poses, patches=patches, intr=intr, ii=ii, jj=jj, kk=kk,
+                target=target.astype(np.float32), weight=weight,
+                lmbda=np.array([1e-4], np.float32), n_frames=n_frames, M=M)
+
+
+def corr_case(seed=0, E=48, N1=40, N2=6, H=30, W=40, C=128, distort=True):
+    rng = np.random.default_rng(seed)
+    fmap1 = rng.normal(0, 1, (1, N1, C, 3, 3)).astype(np.float32)
+    fmap2 = rng.normal(0, 1, (1, N2, C, H, W)).astype(np.float32)
+    cx = rng.uniform(-6, W + 6, (E, 1, 1, 1)).astype(np.float32)
+    cy = rng.uniform(-6, H + 6, (E, 1, 1, 1)).astype(np.float32)
+    gy, gx = np.meshgrid(np.arange(-1, 2), np.arange(-1, 2), indexing="ij")
+    scale = rng.uniform(0.6, 1.6, (E, 1, 1)).astype(np.float32)
+    if distort:
+        scale[::7] *= 6.0          # union of windows > 128 px -> per-pixel fallback path
+    x = cx[:, 0] + gx[None] * scale + rng.normal(0, 0.05, (E, 3, 3))
+    y = cy[:, 0] + gy[None] * scale + rng.normal(0, 0.05, (E, 3, 3))
+    coords = np.stack([x, y], 1).astype(np.float32)[None]          # [1,E,2,3,3]
+    coords[0, 3] = 1e9            # absurd coordinates: every window off-image
+    coords[0, 5, :, 0, 0] = -40.0  # one dead pixel inside an otherwise live patch
+    ii = rng.integers(0, N1, E).astype(np.int64)
+    jj = rng.integers(0, N2, E).astype(np.int64)
+    return fmap1, fmap2, coords, ii, jj

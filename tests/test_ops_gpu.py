@@ -1,0 +1,261 @@
+"""GPU parity tests: every HIP operator (called through the C ABI) against the CPU
+oracle on the same seeded inputs.  Tolerances are stated per test; integer /
+index outputs must match exactly."""
+import numpy as np
+import pytest
+import torch
+
+import oracle as orc
+from scenes import ba_scene, corr_case
+
+pytestmark = pytest.mark.gpu
+
+
+def cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+# ---------------------------------------------------------------------- lietorch
+def test_se3_ops_match_oracle():
+    from rampvo_amd import ops
+    rng = np.random.default_rng(0)
+    a = (0.4 * rng.normal(size=(257, 6))).astype(np.float32)
+    a[0] = 0  # identity / small-angle branches
+    a[1, 3:] = 1e-7
+    X = orc.se3_exp(a)
+    Xg = ops.se3_unary("ramp_se3_exp", cu(a), 6, 7).cpu().numpy()
+    assert np.abs(Xg - X).max() < 2e-6
+    Y = orc.se3_exp((0.3 * rng.normal(size=(257, 6))).astype(np.float32))
+    p = rng.normal(size=(257, 4)).astype(np.float32)
+    b = rng.normal(size=(257, 6)).astype(np.float32)
+    assert np.abs(ops.se3_unary("ramp_se3_log", cu(X), 7, 6).cpu().numpy() - orc.se3_log(X)).max() < 5e-6
+    assert np.abs(ops.se3_unary("ramp_se3_inv", cu(X), 7, 7).cpu().numpy() - orc.se3_inv(X)).max() < 2e-6
+    assert np.abs(ops.se3_binary("ramp_se3_mul", cu(X), cu(Y), 7, 7, 7).cpu().numpy() - orc.se3_mul(X, Y)).max() < 2e-6
+    assert np.abs(ops.se3_binary("ramp_se3_act4", cu(X), cu(p), 7, 4, 4).cpu().numpy() - orc.se3_act4(X, p)).max() < 5e-6
+    assert np.abs(ops.se3_binary("ramp_se3_adj", cu(X), cu(b), 7, 6, 6).cpu().numpy() - orc.se3_adj(X, b)).max() < 1e-5
+    assert np.abs(ops.se3_binary("ramp_se3_adjT", cu(X), cu(b), 7, 6, 6).cpu().numpy() - orc.se3_adjT(X, b)).max() < 1e-5
+
+
+def test_se3_class_identities():
+    """the identities of the reference's ramp/lietorch/run_tests.py:16-52 at fp32"""
+    from rampvo_amd.lietorch import SE3
+    g = torch.Generator().manual_seed(1)
+    a = (0.2 * torch.randn(2, 3, 4, 6, generator=g)).cuda()
+    X = SE3.exp(a)
+    assert (X.log() - a).abs().max() < 1e-5
+    assert (X * X.inv()).log().abs().max() < 1e-5
+    c = torch.randn(2, 3, 4, 6, generator=g).cuda()
+    Y1 = X * SE3.exp(c)
+    Y2 = SE3.exp(X.adj(c)) * X
+    assert (Y1 * Y2.inv()).log().abs().max() < 2e-5
+    Xs = SE3.exp(torch.randn(1, 6, generator=g).cuda())
+    p = torch.randn(1, 3, generator=g).cuda()
+    p1 = Xs.act(p)
+    ph = torch.cat([p, torch.ones_like(p[..., :1])], -1)
+    p2 = torch.matmul(Xs.matrix(), ph[..., None])[..., 0]
+    assert (p1 - p2[..., :3]).abs().max() < 1e-5
+
+
+# ----------------------------------------------------------------------- altcorr
+@pytest.mark.parametrize("C,R,HW", [(128, 1, (30, 40)), (384, 0, (30, 40)), (3, 1, (30, 40)), (3, 0, (120, 160))])
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+def test_patchify_matches_oracle(C, R, HW, layout):
+    from rampvo_amd import ops
+    from rampvo_amd._lib import RAMP_NCHW, RAMP_NHWC
+    rng = np.random.default_rng(C + R)
+    H, W = HW
+    M = 37
+    net = rng.normal(size=(2, C, H, W)).astype(np.float32)
+    coords = np.stack([rng.uniform(-3, W + 3, (2, M)), rng.uniform(-3, H + 3, (2, M))], -1).astype(np.float32)
+    coords[0, 0] = [0.0, 0.0]
+    coords[0, 1] = [W - 1, H - 1]
+    coords[0, 2] = [5.0, 7.0]  # integral coordinates: dx = dy = 0
+    ref = orc.patchify(net, coords, R)
+    raw = orc.patchify_raw(net, coords, R)
+    if layout == "nchw":
+        out = ops.patchify(cu(net), cu(coords), R, True, RAMP_NCHW, RAMP_NCHW).cpu().numpy()
+        outr = ops.patchify(cu(net), cu(coords), R, False, RAMP_NCHW, RAMP_NCHW).cpu().numpy()
+    else:
+        nh = cu(net.transpose(0, 2, 3, 1))
+        out = ops.patchify(nh, cu(coords), R, True, RAMP_NHWC, RAMP_NHWC).permute(0, 1, 4, 2, 3).cpu().numpy()
+        outr = ops.patchify(nh, cu(coords), R, False, RAMP_NHWC, RAMP_NCHW).cpu().numpy()
+    assert np.array_equal(outr, raw)            # a gather: bit exact
+    assert np.abs(out - ref).max() <= 1e-6     # same expression order; fp32 rounding only
+
+
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+def test_corr_matches_oracle(layout):
+    from rampvo_amd import ops
+    from rampvo_amd._lib import RAMP_NCHW, RAMP_NHWC
+    fmap1, fmap2, coords, ii, jj = corr_case(seed=3)
+    fmap2b = np.ascontiguousarray(fmap2[:, :, :, ::2, ::2])  # a second, coarser level
+    ref0 = orc.corr(fmap1, fmap2, coords / 1, ii, jj, 3)[0]
+    ref1 = orc.corr(fmap1, fmap2b, coords / 4, ii, jj, 3)[0]
+    if layout == "nchw":
+        out = ops.corr(cu(fmap1[0]), [cu(fmap2[0]), cu(fmap2b[0])], cu(coords[0]), cu(ii), cu(jj), 3,
+                       (1.0, 4.0), RAMP_NCHW)
+    else:
+        out = ops.corr(cu(fmap1[0].transpose(0, 2, 3, 1)),
+                       [cu(fmap2[0].transpose(0, 2, 3, 1)), cu(fmap2b[0].transpose(0, 2, 3, 1))],
+                       cu(coords[0]), cu(ii), cu(jj), 3, (1.0, 4.0), RAMP_NHWC)
+    out = out.cpu().numpy()
+    assert out.shape == (coords.shape[1], 7, 7, 3, 3, 2)
+    # dots are the same channel-ordered fmaf chain, the blend the same expression
+    for lvl, ref in ((0, ref0), (1, ref1)):
+        diff = np.abs(out[..., lvl] - ref)
+        assert np.nanmax(diff) <= 1e-5, (lvl, np.nanmax(diff))
+        assert np.array_equal(np.isnan(out[..., lvl]), np.isnan(ref))
+
+
+def test_corr_reference_signature_and_half():
+    from rampvo_amd import altcorr
+    fmap1, fmap2, coords, ii, jj = corr_case(seed=5, E=32, distort=False)
+    ref = orc.corr(fmap1, fmap2, coords, ii, jj, 3)
+    out = altcorr.corr(cu(fmap1), cu(fmap2), cu(coords), cu(ii), cu(jj), 3)
+    assert out.shape == ref.shape
+    assert np.nanmax(np.abs(out.cpu().numpy() - ref)) <= 1e-5
+    # fp16 storage, fp32 accumulation (the reference accumulates in half: looser tolerance)
+    outh = altcorr.corr(cu(fmap1).half(), cu(fmap2).half(), cu(coords), cu(ii), cu(jj), 3)
+    assert outh.dtype == torch.float16
+    refh = orc.corr(fmap1.astype(np.float16).astype(np.float32), fmap2.astype(np.float16).astype(np.float32),
+                    coords, ii, jj, 3)
+    ok = np.isfinite(refh)
+    assert np.abs(outh.float().cpu().numpy()[ok] - refh[ok]).max() <= 2e-2 * np.abs(refh[ok]).max()
+
+
+# ---------------------------------------------------------------- projective ops
+def test_transform_reproject_point_cloud():
+    from rampvo_amd import ops
+    s = ba_scene(seed=2, n_frames=7, M=9)
+    s["patches"][5, 2] = 1e-3      # far point
+    s["poses"][3, :3] += [0, 0, 9]  # pushes some points behind the camera -> Z clamp
+    for tonly in (False, True):
+        ref = orc.transform(s["poses"], s["patches"], s["intr"], s["ii"], s["jj"], s["kk"], tonly)
+        out = ops.transform(cu(s["poses"]), cu(s["patches"]), cu(s["intr"]), cu(s["ii"]), cu(s["jj"]),
+                            cu(s["kk"]), tonly).cpu().numpy()
+        assert rel_err(out, ref) < 1e-5
+    ref = orc.reproject(s["poses"], s["patches"], s["intr"], s["ii"], s["jj"], s["kk"])
+    out = ops.reproject(cu(s["poses"]), cu(s["patches"]), cu(s["intr"]), cu(s["ii"]), cu(s["jj"]),
+                        cu(s["kk"])).cpu().numpy()
+    fin = np.isfinite(ref) & (np.abs(ref) < 1e6)
+    assert np.abs(out[fin] - ref[fin]).max() / np.abs(ref[fin]).max() < 1e-5
+    m = s["n_frames"] * s["M"]
+    ix = np.repeat(np.arange(s["n_frames"]), s["M"]).astype(np.int64)
+    Tinv = orc.se3_inv(s["poses"][ix])
+    K = s["intr"][ix]
+    c = s["patches"][:m, :, 1, 1]
+    X0 = np.stack([(c[:, 0] - K[:, 2]) / K[:, 0], (c[:, 1] - K[:, 3]) / K[:, 1], np.ones(m), c[:, 2]], -1)
+    Pw = orc.se3_act4(Tinv, X0.astype(np.float32))
+    refpc = Pw[:, :3] / Pw[:, 3:]
+    out = ops.point_cloud(cu(s["poses"]), cu(s["patches"][:m]), cu(s["intr"]), cu(ix)).cpu().numpy()
+    assert rel_err(out, refpc) < 1e-5
+
+
+# ------------------------------------------------------------------------- graph
+def test_group_by_and_neighbors_exact():
+    from rampvo_amd import ops
+    rng = np.random.default_rng(4)
+    E = 5000
+    kk = rng.integers(0, 300, E).astype(np.int64)
+    jj = rng.integers(0, 40, E).astype(np.int64)
+    for bound in (0, 300):
+        g = ops.group_by(cu(kk), bound)
+        G = int(g.ngroups.item())
+        uk, inv = np.unique(kk, return_inverse=True)
+        assert G == len(uk)
+        assert np.array_equal(g.ukeys[:G].cpu().numpy(), uk)
+        assert np.array_equal(g.gid[:E].cpu().numpy(), inv)
+        order = g.order[:E].cpu().numpy()
+        assert np.array_equal(order, np.argsort(kk, kind="stable"))
+        seg = g.seg_start[:G + 1].cpu().numpy()
+        assert seg[0] == 0 and seg[-1] == E and np.all(np.diff(seg) == np.bincount(inv))
+    rix, rjx = orc.neighbors(kk, jj)
+    for kb, jb in ((0, 0), (300, 40)):
+        ix, jx = ops.neighbors(cu(kk), cu(jj), kb, jb)
+        assert np.array_equal(ix.cpu().numpy(), rix) and np.array_equal(jx.cpu().numpy(), rjx)
+
+
+def test_group_by_empty_and_single():
+    from rampvo_amd import ops
+    g = ops.group_by(torch.zeros(0, dtype=torch.int64, device="cuda"))
+    assert int(g.ngroups.item()) == 0
+    g = ops.group_by(torch.full((17,), 5, dtype=torch.int64, device="cuda"), 6)
+    assert int(g.ngroups.item()) == 1 and g.seg_start[:2].tolist() == [0, 17]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_segment_softmax_sum(dtype):
+    from rampvo_amd import ops
+    rng = np.random.default_rng(6)
+    E, C = 3000, 384
+    keys = rng.integers(0, 90, E).astype(np.int64) * 12345 + rng.integers(0, 3, E)
+    fx = rng.normal(size=(E, C)).astype(np.float32)
+    gx = (3 * rng.normal(size=(E, C))).astype(np.float32)
+    if dtype == torch.float16:
+        fx = fx.astype(np.float16).astype(np.float32)
+        gx = gx.astype(np.float16).astype(np.float32)
+    uk, inv = np.unique(keys, return_inverse=True)
+    ref = orc.segment_softmax_sum(fx, gx, inv, len(uk))
+    g = ops.group_by(cu(keys))
+    y = ops.segment_softmax_sum(cu(fx).to(dtype), cu(gx).to(dtype), g, len(uk) + 5)
+    out = y[:len(uk)].float().cpu().numpy()
+    tol = 2e-6 if dtype == torch.float32 else 2e-3
+    assert np.abs(out - ref).max() <= tol * max(1.0, np.abs(ref).max())
+    assert torch.all(y[len(uk):] == 0)
+
+
+# ---------------------------------------------------------------------------- BA
+@pytest.mark.parametrize("case", ["window", "all_free", "structure_only", "shuffled", "big_window"])
+def test_ba_matches_oracle(case):
+    from rampvo_amd import ops
+    kw = dict(seed=11, n_frames=9, M=14, lifetime=4, n_total_frames=16)
+    if case == "shuffled":
+        kw["far"] = True
+    if case == "big_window":
+        kw.update(n_frames=34, M=6, lifetime=33, n_total_frames=40)
+    s = ba_scene(**kw)
+    nf = s["n_frames"]
+    t0, t1 = {"window": (nf - 5, nf), "all_free": (1, nf), "structure_only": (nf, nf),
+              "shuffled": (2, nf), "big_window": (nf - 30, nf)}[case]
+    p_ref, pt_ref = s["poses"].copy(), s["patches"].copy()
+    st = orc.ba(p_ref, pt_ref, s["intr"], s["target"], s["weight"], s["lmbda"], s["ii"], s["jj"], s["kk"], t0, t1, 2)
+    assert st == 0
+    poses, patches = cu(s["poses"]), cu(s["patches"])
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ops.ba(poses, patches, cu(s["intr"]), cu(s["target"]), cu(s["weight"]), cu(s["lmbda"]), cu(s["ii"]),
+           cu(s["jj"]), cu(s["kk"]), t0, t1, 2, info)
+    assert int(info.item()) == 0
+    p, pt = poses.cpu().numpy(), patches.cpu().numpy()
+    assert np.array_equal(p[:t0], s["poses"][:t0]) and np.array_equal(p[t1:], s["poses"][t1:])  # fixed poses untouched
+    moved = np.abs(p_ref - s["poses"]).max()
+    if t1 > t0:
+        assert moved > 1e-4                                  # the problem is not degenerate
+    # north-star tolerance: 1e-4 relative on fp32 poses / depths
+    assert np.abs(p - p_ref).max() <= 1e-4 * max(1.0, np.abs(p_ref).max())
+    assert np.abs(pt - pt_ref).max() <= 1e-4 * max(1.0, np.abs(pt_ref[:, 2]).max())
+    # x,y channels of the patches are never written
+    assert np.array_equal(pt[:, :2], s["patches"][:, :2])
+
+
+def test_ba_is_deterministic():
+    from rampvo_amd import ops
+    s = ba_scene(seed=12, n_frames=9, M=14, lifetime=4, n_total_frames=16, far=True)
+    outs = []
+    for _ in range(3):
+        poses, patches = cu(s["poses"]), cu(s["patches"])
+        ops.ba(poses, patches, cu(s["intr"]), cu(s["target"]), cu(s["weight"]), cu(s["lmbda"]), cu(s["ii"]),
+               cu(s["jj"]), cu(s["kk"]), 2, 9, 2)
+        outs.append((poses.cpu().numpy(), patches.cpu().numpy()))
+    for p, pt in outs[1:]:
+        assert np.array_equal(p, outs[0][0]) and np.array_equal(pt, outs[0][1])
+
+
+def test_ops_refuse_cpu_tensors():
+    from rampvo_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.se3_unary("ramp_se3_inv", torch.zeros(1, 7), 7, 7)
