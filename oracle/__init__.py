@@ -29,8 +29,36 @@ def build(force=False):
     if (not force and os.path.exists(_LIB_PATH)
             and os.path.getmtime(_LIB_PATH) >= os.path.getmtime(src)):
         return _LIB_PATH
-    subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libramp_oracle.so"])
+    subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "all"])
     return _LIB_PATH
+
+
+_lib64 = None
+
+
+def lib64():
+    """fp64 diagnostic build of the same source (rounding-envelope measurements only)"""
+    global _lib64
+    if _lib64 is None:
+        path = os.path.join(_HERE, "libramp_oracle_f64.so")
+        src = os.path.join(_HERE, "ramp_oracle.c")
+        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-s", "-C", _HERE, "libramp_oracle_f64.so"])
+        _lib64 = ctypes.CDLL(path)
+        _lib64.orc_ba.restype = ctypes.c_int
+    return _lib64
+
+
+def ba_f64(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t1, iterations=2):
+    """fp64 evaluation of orc_ba; returns (poses, patches) as float64 copies"""
+    d = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    P = patches.shape[-1]
+    p, pt = d(poses).reshape(-1, 7).copy(), d(patches).reshape(-1, 3, P, P).copy()
+    intrinsics, target, weight, lmbda = d(intrinsics).reshape(-1, 4), d(target).reshape(-1, 2), d(weight).reshape(-1, 2), d(lmbda).reshape(-1)
+    ii, jj, kk = _i(ii), _i(jj), _i(kk)
+    lib64().orc_ba(_p(p), _p(pt), _p(intrinsics), _p(target), _p(weight), _p(lmbda), _p(ii), _p(jj),
+                   _p(kk), ii.shape[0], P, int(t0), int(t1), int(iterations))
+    return p, pt
 
 
 def lib():

@@ -31,6 +31,14 @@
 
 #define ORC_API __attribute__((visibility("default")))
 
+/* Diagnostic build (oracle/Makefile target libramp_oracle_f64.so): the same
+ * source with every `float` promoted to double, used by tests to measure the
+ * fp32 rounding envelope of ill-conditioned problems.  Never a parity target. */
+#ifdef ORC_F64
+#define float double
+#define __builtin_fmaf __builtin_fma
+#endif
+
 /* float -> int with the saturating semantics of the GPU conversion the
  * reference relies on (static_cast<int>(floor(x)) in device code). */
 static inline int f2i_sat(float f) {

@@ -1,0 +1,412 @@
+"""Sliding-window visual-odometry front-end (reference: ramp/Ramp_vo.py:27-410).
+
+Same plugin surface as the reference class -- ``Ramp_vo(cfg, network, train_cfg,
+ht, wd)``, ``slam(t, input_tensor=(events, image, mask), intrinsics=K)``,
+``slam.update()``, ``slam.terminate()``, attributes ``points_ / colors_ / m / n /
+poses_ / patches_`` -- so ``evaluate.py::run`` drives it unchanged.  The
+pose-prediction mode (reference :414-534) is off in every shipped config and not
+provided.
+
+MI355X-first differences that do not change results:
+  * feature ring buffers are channels-last (one pixel's 128 channels contiguous);
+  * reproject / corr(+pyramid stack) / BA / point cloud are one fused HIP launch
+    each (reference: ~13 / ~26 / ~50 / 4 launches);
+  * the factor graph (ii, jj, kk) is mirrored on the host, so edge generation,
+    factor removal and the keyframe shuffle need no device->host size reads; the
+    only sync per frame is the keyframe decision itself;
+  * neighbour / group index structures are built once per graph change and
+    shared by the update operator and BA.
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import altcorr, fastba, lietorch, ops
+from . import projective_ops as pops
+from ._lib import RAMP_NHWC
+from .lietorch import SE3
+from .net import GraphPlan, VONet
+from .utils import Timer, filter_features, preprocess_input
+
+
+class Ramp_vo:
+    def __init__(self, cfg, network, train_cfg, ht=480, wd=640, device="cuda"):
+        self.cfg = cfg
+        self.event_bias = train_cfg["event_bias"]
+        self.train_cfg = train_cfg
+        self.device = torch.device(device)
+        dev = self.device
+
+        self.lmbda = torch.as_tensor([1e-4], device=dev)
+        self.load_weights(network)
+        self.is_initialized = False
+        self.enable_timing = False
+
+        self.n = 0      # number of keyframes
+        self.m = 0      # number of patches
+        self.M = self.cfg.PATCHES_PER_FRAME
+        self.N = self.cfg.BUFFER_SIZE
+        self.ht, self.wd = ht, wd
+        DIM, RES = self.DIM, self.RES
+
+        self.tlist = []
+        self.counter = 0
+
+        self.tstamps_ = torch.zeros(self.N, dtype=torch.long, device=dev)
+        self.poses_ = torch.zeros(self.N, 7, dtype=torch.float, device=dev)
+        self.patches_ = torch.zeros(self.N, self.M, 3, self.P, self.P, dtype=torch.float, device=dev)
+        self.intrinsics_ = torch.zeros(self.N, 4, dtype=torch.float, device=dev)
+        self.points_ = torch.zeros(self.N * self.M, 3, dtype=torch.float, device=dev)
+        self.colors_ = torch.zeros(self.N, self.M, 3, dtype=torch.uint8, device=dev)
+        self.index_ = torch.arange(self.N, device=dev).view(-1, 1).repeat(1, self.M)
+        self.index_[0] = 0
+        self.index_map_ = torch.zeros(self.N, dtype=torch.long, device=dev)
+
+        self.mem = 32
+        self.dtype = torch.half if self.cfg.MIXED_PRECISION else torch.float
+        self.kwargs = kwargs = {"device": dev, "dtype": self.dtype}
+        h, w = ht // RES, wd // RES
+        # channels-last ring buffers (reference: [mem,M,DIM], [mem,M,128,P,P], [1,mem,128,h,w])
+        self.imap_ = torch.zeros(self.mem, self.M, DIM, **kwargs)
+        self.gmap_ = torch.zeros(self.mem, self.M, self.P, self.P, 128, **kwargs)
+        self.fmap1_ = torch.zeros(self.mem, h, w, 128, **kwargs)
+        self.fmap2_ = torch.zeros(self.mem, h // 4, w // 4, 128, **kwargs)
+        self.pyramid = (self.fmap1_, self.fmap2_)
+
+        self.net = torch.zeros(1, 0, DIM, **kwargs)
+        self.ii = torch.zeros(0, dtype=torch.long, device=dev)
+        self.jj = torch.zeros(0, dtype=torch.long, device=dev)
+        self.kk = torch.zeros(0, dtype=torch.long, device=dev)
+        # host mirror of the factor graph
+        self._ii = np.zeros(0, np.int64)
+        self._jj = np.zeros(0, np.int64)
+        self._kk = np.zeros(0, np.int64)
+        self._plan = None
+
+        self.poses_[:, 6] = 1.0
+        self.delta = {}
+        self._ba_info = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    # ------------------------------------------------------------------ weights
+    def load_weights(self, network):
+        if isinstance(network, str):
+            checkpoint = torch.load(network, map_location="cpu")
+            state_dict = checkpoint['model_state_dict'] if checkpoint.get('model_state_dict') else checkpoint
+            new_state_dict = OrderedDict()
+            for k, v in state_dict.items():
+                if "update.lmbda" not in k:
+                    new_state_dict[k.replace('module.', '')] = v
+            self.network = VONet(cfg=self.train_cfg)
+            self.network.load_state_dict(new_state_dict)
+        else:
+            self.network = network
+        self.DIM, self.RES, self.P = self.network.DIM, self.network.RES, self.network.P
+        self.network.to(self.device)
+        self.network.eval()
+
+    # -------------------------------------------------------------------- views
+    @property
+    def poses(self):
+        return self.poses_.view(1, self.N, 7)
+
+    @property
+    def patches(self):
+        return self.patches_.view(1, self.N * self.M, 3, 3, 3)
+
+    @property
+    def intrinsics(self):
+        return self.intrinsics_.view(1, self.N, 4)
+
+    @property
+    def ix(self):
+        return self.index_.view(-1)
+
+    @property
+    def imap(self):
+        return self.imap_.view(1, self.mem * self.M, self.DIM)
+
+    @property
+    def gmap(self):
+        """reference shape [1, mem*M, 128, 3, 3] (a channels-last view)"""
+        return self.gmap_.view(1, self.mem * self.M, 3, 3, 128).permute(0, 1, 4, 2, 3)
+
+    # ----------------------------------------------------------------- snapshot
+    def state_dict(self):
+        """VO state as CPU tensors in the REFERENCE's layouts (NCHW feature buffers), so a
+        snapshot can move between devices / implementations.  (The reference's VO state
+        is not checkpointable; this is what bench.py uses to hand the steady state to
+        the CPU baseline and what the teacher-forced parity tests inject.)"""
+        n = self.n
+        c = lambda t: t.detach().cpu().clone()
+        return dict(
+            n=n, m=self.m, counter=self.counter, is_initialized=self.is_initialized, tlist=list(self.tlist),
+            tstamps=c(self.tstamps_[:n + 1]), poses=c(self.poses_[:n + 1]), patches=c(self.patches_[:n + 1]),
+            intrinsics=c(self.intrinsics_[:n + 1]), colors=c(self.colors_[:n + 1]),
+            imap=c(self.imap_), gmap=c(self.gmap_.permute(0, 1, 4, 2, 3)),
+            fmap1=c(self.fmap1_.permute(0, 3, 1, 2)), fmap2=c(self.fmap2_.permute(0, 3, 1, 2)),
+            net=c(self.net), ii=c(self.ii), jj=c(self.jj), kk=c(self.kk),
+            delta={k: (v[0], c(v[1].data)) for k, v in self.delta.items()})
+
+    def load_state_dict(self, sd):
+        dev = self.device
+        n = int(sd["n"])
+        self.n, self.m, self.counter = n, int(sd["m"]), int(sd["counter"])
+        self.is_initialized = bool(sd["is_initialized"])
+        self.tlist = list(sd.get("tlist", []))
+        k = sd["poses"].shape[0]
+        self.tstamps_[:k] = sd["tstamps"].to(dev)
+        self.poses_[:k] = sd["poses"].to(dev)
+        self.patches_[:k] = sd["patches"].to(dev)
+        self.intrinsics_[:k] = sd["intrinsics"].to(dev)
+        if "colors" in sd:
+            self.colors_[:k] = sd["colors"].to(dev)
+        self.imap_.copy_(sd["imap"].to(dev))
+        self.gmap_.copy_(sd["gmap"].to(dev).permute(0, 1, 3, 4, 2))
+        self.fmap1_.copy_(sd["fmap1"].to(dev).permute(0, 2, 3, 1))
+        self.fmap2_.copy_(sd["fmap2"].to(dev).permute(0, 2, 3, 1))
+        self.net = sd["net"].to(dev)
+        self.ii, self.jj, self.kk = (sd[x].to(dev).long() for x in ("ii", "jj", "kk"))
+        self._ii, self._jj, self._kk = (sd[x].cpu().numpy().astype(np.int64) for x in ("ii", "jj", "kk"))
+        self.delta = {k: (v[0], SE3(v[1].to(dev))) for k, v in sd.get("delta", {}).items()}
+        self._plan = None
+
+    # --------------------------------------------------------------- trajectory
+    def get_pose(self, t):
+        if t in self.traj:
+            return SE3(self.traj[t])
+        t0, dP = self.delta[t]
+        return dP * self.get_pose(t0)
+
+    def terminate(self):
+        """interpolate the poses of dropped frames; returns (inverse poses [T,7], tstamps)"""
+        self.traj = {}
+        ts = self.tstamps_[:self.n].tolist()
+        for i in range(self.n):
+            self.traj[ts[i]] = self.poses_[i]
+        poses = [self.get_pose(t) for t in range(self.counter)]
+        poses = lietorch.stack(poses, dim=0)
+        poses = poses.inv().data.cpu().numpy()
+        return poses, np.array(self.tlist, dtype=float)
+
+    # ------------------------------------------------------------------ kernels
+    def corr(self, coords, indicies=None):
+        """local correlation volume, both pyramid levels fused: [1, E, 882]"""
+        ii, jj = indicies if indicies is not None else (self.kk, self.jj)
+        ii1 = ii % (self.M * self.mem)
+        jj1 = jj % self.mem
+        return altcorr.corr_pyramid(self.gmap_.view(-1, 3, 3, 128), self.pyramid, coords[0], ii1, jj1, 3,
+                                    (1, 4), RAMP_NHWC)
+
+    def reproject(self, indicies=None, poses=None, patches=None, intrinsics=None):
+        (ii, jj, kk) = indicies if indicies is not None else (self.ii, self.jj, self.kk)
+        poses = poses if poses is not None else self.poses
+        patches = patches if patches is not None else self.patches
+        intrinsics = intrinsics if intrinsics is not None else self.intrinsics
+        return pops.reproject(poses, patches, intrinsics, ii, jj, kk)      # [1,E,2,3,3]
+
+    # -------------------------------------------------------------------- graph
+    def _upload(self, a):
+        return torch.from_numpy(a).to(self.device)
+
+    def append_factors(self, ii, jj):
+        """ii: patch indices, jj: frame indices (host arrays) -- reference :194-201"""
+        ii = np.asarray(ii, np.int64)
+        jj = np.asarray(jj, np.int64)
+        src = ii // self.M                      # == self.ix[ii]: index_[r] = r for every frame row
+        self._jj = np.concatenate([self._jj, jj])
+        self._kk = np.concatenate([self._kk, ii])
+        self._ii = np.concatenate([self._ii, src])
+        self.jj = torch.cat([self.jj, self._upload(jj)])
+        self.kk = torch.cat([self.kk, self._upload(ii)])
+        self.ii = torch.cat([self.ii, self._upload(src)])
+        net = torch.zeros(1, len(ii), self.DIM, **self.kwargs)
+        self.net = torch.cat([self.net, net], dim=1)
+        self._plan = None
+
+    def remove_factors(self, m):
+        """m: host boolean mask of factors to drop -- reference :203-208"""
+        m = np.asarray(m, bool)
+        if not m.any():
+            return
+        keep = np.nonzero(~m)[0]
+        self._ii, self._jj, self._kk = self._ii[keep], self._jj[keep], self._kk[keep]
+        kd = self._upload(keep)
+        self.ii, self.jj, self.kk = self.ii[kd], self.jj[kd], self.kk[kd]
+        self.net = self.net[:, kd]
+        self._plan = None
+
+    def _graph_plan(self):
+        if self._plan is None or self._plan.E != len(self._ii):
+            nfr = len(np.unique(self._kk // self.M)) if len(self._kk) else 0
+            pairs = len(np.unique(self._ii * 12345 + self._jj)) if len(self._ii) else 0
+            self._plan = GraphPlan.build(self.ii, self.jj, self.kk, kk_bound=self.N * self.M, jj_bound=self.N,
+                                         max_kk=nfr * self.M, max_ij=pairs)
+        return self._plan
+
+    def __edges_forw(self):
+        r = self.cfg.PATCH_LIFETIME
+        t0 = self.M * max((self.n - r), 0)
+        t1 = self.M * max((self.n - 1), 0)
+        kk, jj = np.meshgrid(np.arange(t0, t1), np.arange(self.n - 1, self.n), indexing='ij')
+        return kk.reshape(-1), jj.reshape(-1)
+
+    def __edges_back(self):
+        r = self.cfg.PATCH_LIFETIME
+        t0 = self.M * max((self.n - 1), 0)
+        t1 = self.M * max((self.n - 0), 0)
+        kk, jj = np.meshgrid(np.arange(t0, t1), np.arange(max(self.n - r, 0), self.n), indexing='ij')
+        return kk.reshape(-1), jj.reshape(-1)
+
+    # ------------------------------------------------------------------- motion
+    def motion_probe(self):
+        """median update magnitude of the newest patches against the newest frame (reference :210-225)"""
+        kk = torch.arange(self.m - self.M, self.m, device=self.device)
+        jj = self.n * torch.ones_like(kk)
+        ii = kk // self.M
+        net = torch.zeros(1, len(ii), self.DIM, **self.kwargs)
+        coords = self.reproject(indicies=(ii, jj, kk))
+        corr = self.corr(coords, indicies=(kk, jj)).to(self.dtype)
+        ctx = self.imap[:, kk % (self.M * self.mem)]
+        with torch.autocast("cuda", dtype=torch.half, enabled=self.cfg.MIXED_PRECISION):
+            net, (delta, weight, _) = self.network.update(net, ctx, corr, None, ii, jj, kk)
+        return torch.quantile(delta.norm(dim=-1).float(), 0.5)
+
+    def _motionmag_pair(self, i, j):
+        """mean patch flow i->j and j->i in one device pass: 0.5*(mag(i,j)+mag(j,i)) (reference :227-243)"""
+        sel_f = np.nonzero((self._ii == i) & (self._jj == j))[0]
+        sel_b = np.nonzero((self._ii == j) & (self._jj == i))[0]
+        mags = []
+        for sel in (sel_f, sel_b):
+            if len(sel) == 0:
+                mags.append(torch.full((), float("nan"), device=self.device))
+                continue
+            s = self._upload(sel)
+            flow = pops.flow_mag(self.poses, self.patches, self.intrinsics, self.ii[s], self.jj[s], self.kk[s],
+                                 beta=0.5)
+            mags.append(flow.mean())
+        return float(((mags[0] + mags[1]) / 2).item())
+
+    def keyframe(self):
+        """drop keyframe n-KEYFRAME_INDEX if the motion around it is small (reference :237-274)"""
+        i = self.n - self.cfg.KEYFRAME_INDEX - 1
+        j = self.n - self.cfg.KEYFRAME_INDEX + 1
+        m = self._motionmag_pair(i, j)
+        if m < self.cfg.KEYFRAME_THRESH:
+            k = self.n - self.cfg.KEYFRAME_INDEX
+            ts = self.tstamps_[k - 1:k + 1].tolist()
+            t0, t1 = ts[0], ts[1]
+            dP = SE3(self.poses_[k]) * SE3(self.poses_[k - 1]).inv()
+            self.delta[t1] = (t0, dP)
+            self.remove_factors((self._ii == k) | (self._jj == k))
+            self._kk[self._ii > k] -= self.M
+            self._ii[self._ii > k] -= 1
+            self._jj[self._jj > k] -= 1
+            self.kk, self.ii, self.jj = self._upload(self._kk), self._upload(self._ii), self._upload(self._jj)
+            self._plan = None
+            # shift the per-frame state down by one row (reference: python loop of row copies)
+            n = self.n
+            for buf in (self.tstamps_, self.colors_, self.poses_, self.patches_, self.intrinsics_):
+                buf[k:n - 1] = buf[k + 1:n].clone()
+            dst = torch.arange(k, n - 1, device=self.device) % self.mem
+            src = torch.arange(k + 1, n, device=self.device) % self.mem
+            for buf in (self.imap_, self.gmap_, self.fmap1_, self.fmap2_):
+                buf[dst] = buf[src]
+            self.n -= 1
+            self.m -= self.M
+        self.remove_factors((self._kk // self.M) < self.n - self.cfg.REMOVAL_WINDOW)
+
+    # ------------------------------------------------------------------- update
+    def update(self):
+        with Timer("other", enabled=self.enable_timing):
+            coords = self.reproject()
+            corr = self.corr(coords).to(self.dtype)
+            ctx = self.imap[:, self.kk % (self.M * self.mem)]
+            plan = self._graph_plan()
+            with torch.autocast("cuda", dtype=torch.half, enabled=self.cfg.MIXED_PRECISION):
+                self.net, (delta, weight, _) = self.network.update(self.net, ctx, corr, None, self.ii, self.jj,
+                                                                   self.kk, plan=plan)
+            weight = weight.float()
+            target = coords[..., self.P // 2, self.P // 2] + delta.float()
+            weight = filter_features(confidences=weight, target=target, data_shape=(self.ht // 4, self.wd // 4))
+            self.last_weight = weight
+        with Timer("BA", enabled=self.enable_timing):
+            t0 = self.n - self.cfg.OPTIMIZATION_WINDOW if self.is_initialized else 1
+            t0 = max(t0, 1)
+            try:
+                fastba.BA(self.poses, self.patches, self.intrinsics, target, weight, self.lmbda, self.ii, self.jj,
+                          self.kk, t0, self.n, M=self.M, iterations=2, eff_impl=False, info=self._ba_info)
+            except Exception as e:  # same recovery as the reference (:302-306)
+                print(f"WARNING: BA failed...{e}")
+            ixm = torch.arange(self.m, device=self.device) // self.M
+            self.points_[:self.m] = pops.point_cloud(self.poses, self.patches_.view(-1, 3, 3, 3)[:self.m],
+                                                     self.intrinsics, ixm)
+
+    # --------------------------------------------------------------------- call
+    def __call__(self, tstamp, input_tensor, intrinsics):
+        """track a new frame"""
+        input_ = preprocess_input(input_tensor=input_tensor)
+        with torch.no_grad():
+            return self._track(tstamp, input_, intrinsics)
+
+    def _track(self, tstamp, input_, intrinsics):
+        fmap, gmap, imap, patches, _, clr = self.network.patchify(
+            input_=input_, patches_per_image=self.cfg.PATCHES_PER_FRAME, event_bias=self.event_bias,
+            reinit_hidden=True if tstamp == 0 else False)
+        mask = input_[2]
+        if mask is not None and not mask:
+            return      # events only: the encoder state has advanced, the VO has not
+
+        n = self.n
+        self.tlist.append(tstamp)
+        self.tstamps_[n] = self.counter
+        self.intrinsics_[n] = intrinsics.to(self.device) / self.RES
+        self.index_map_[n + 1] = self.m + self.M
+        clr = (clr[0][:, [2, 1, 0]] + 0.5) * (255.0 / 2)
+        self.colors_[n] = clr.to(torch.uint8)
+
+        if n > 1:
+            if self.cfg.MOTION_MODEL == 'DAMPED_LINEAR':
+                P1 = SE3(self.poses_[n - 1])
+                P2 = SE3(self.poses_[n - 2])
+                xi = self.cfg.MOTION_DAMPING * (P1 * P2.inv()).log()
+                self.poses_[n] = (SE3.exp(xi) * P1).data
+            else:
+                self.poses_[n] = self.poses_[n - 1]
+
+        patches[:, :, 2] = self._initial_depth(patches)
+        if self.is_initialized:
+            patches[:, :, 2] = torch.median(self.patches_[n - 3:n, :, 2])
+        self.patches_[n] = patches
+
+        slot = n % self.mem
+        self.imap_[slot] = imap.reshape(self.M, self.DIM).to(self.dtype)
+        self.gmap_[slot] = gmap[0].permute(0, 2, 3, 1).to(self.dtype)
+        f = fmap[0]                                                  # [1,128,h,w], channels-last storage
+        self.fmap1_[slot] = f[0].permute(1, 2, 0).to(self.dtype)
+        self.fmap2_[slot] = F.avg_pool2d(f, 4, 4)[0].permute(1, 2, 0).to(self.dtype)
+
+        self.counter += 1
+        if n > 0 and not self.is_initialized:
+            if self.motion_probe() < 2.0:
+                self.delta[self.counter - 1] = (self.counter - 2, SE3.Identity(1, device=self.device)[0])
+                return
+
+        self.n += 1
+        self.m += self.M
+        self.append_factors(*self.__edges_forw())
+        self.append_factors(*self.__edges_back())
+
+        if self.n == 8 and not self.is_initialized:
+            self.is_initialized = True
+            for _ in range(12):
+                self.update()
+        elif self.is_initialized:
+            self.update()
+            self.keyframe()
+
+    def _initial_depth(self, patches):
+        """reference :369 -- torch.rand_like; overridable so parity tests can inject the
+        oracle's draw"""
+        return torch.rand_like(patches[:, :, 2, 0, 0, None, None])

@@ -1,0 +1,275 @@
+"""RAMP encoders (reference: ramp/extractor.py).
+
+The module tree and parameter names mirror the reference so its checkpoints load
+with ``strict=True`` (104 keys SingleScale / 116 MultiScale); the forward passes
+are this package's own:
+
+  * everything is channels-last: a pixel's channels are contiguous, so the
+    per-pixel recurrent cells are plain [H*W, C] row-major GEMV batches and the
+    conv towers feed the correlation kernels without a layout change;
+  * the per-pixel LSTM + super-state 1x1 convolutions are evaluated as fused
+    pointwise math on [H*W, C] matrices (the reference calls cuDNN's LSTM on
+    307,200 length-1 sequences and syncs on ``torch.any`` per modality);
+  * the conv towers go through ``conv.conv2d`` / ``conv.instance_norm_relu``
+    (HIP implicit-GEMM MFMA kernels when built, see csrc/conv.hip).
+"""
+import torch
+import torch.nn as nn
+
+from . import conv as C
+
+DIM = 32
+
+
+def _norm(kind, planes):
+    if kind == 'instance':
+        return nn.InstanceNorm2d(planes)
+    if kind == 'none':
+        return nn.Sequential()
+    if kind == 'batch':
+        return nn.BatchNorm2d(planes)
+    if kind == 'group':
+        return nn.GroupNorm(num_groups=planes // 8, num_channels=planes)
+    raise ValueError(kind)
+
+
+class ResidualBlock(nn.Module):
+    """two 3x3 convs + skip (1x1 strided conv when downsampling); reference :8-57"""
+
+    def __init__(self, in_planes, planes, norm_fn='group', stride=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_planes, planes, kernel_size=3, padding=1, stride=stride)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, padding=1)
+        self.relu = nn.ReLU(inplace=True)
+        self.norm_fn = norm_fn
+        self.norm1 = _norm(norm_fn, planes)
+        self.norm2 = _norm(norm_fn, planes)
+        self.downsample = None
+        if stride != 1:
+            self.norm3 = _norm(norm_fn, planes)
+            self.downsample = nn.Sequential(nn.Conv2d(in_planes, planes, kernel_size=1, stride=stride), self.norm3)
+
+    def forward(self, x):
+        y = C.conv_norm_relu(x, self.conv1, self.norm1, relu=True)
+        y = C.conv_norm_relu(y, self.conv2, self.norm2, relu=True)
+        if self.downsample is not None:
+            x = C.conv_norm_relu(x, self.downsample[0], self.norm3, relu=False)
+        return C.add_relu(x, y)
+
+
+class BasicEncoder4(nn.Module):
+    """conv7x7/2 -> 2xRes(32) -> Res(32->64,/2)+Res(64) -> conv1x1; reference :60-130"""
+
+    def __init__(self, output_dim=128, norm_fn='batch', dropout=0.0, multidim=False, channel_dim=5):
+        super().__init__()
+        self.norm_fn = norm_fn
+        self.channel_dim = channel_dim
+        self.norm1 = _norm(norm_fn, DIM)
+        self.conv1 = nn.Conv2d(channel_dim, DIM, kernel_size=7, stride=2, padding=3)
+        self.relu1 = nn.ReLU(inplace=True)
+        self.in_planes = DIM
+        self.layer1 = self._make_layer(DIM, stride=1)
+        self.in_planes_layer1 = self.in_planes
+        self.layer2 = self._make_layer(2 * DIM, stride=2)
+        self.conv2 = nn.Conv2d(2 * DIM, output_dim, kernel_size=1)
+        self.dropout = None
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+
+    def _make_layer(self, output_dim, stride=1):
+        layers = (ResidualBlock(self.in_planes, output_dim, self.norm_fn, stride=stride),
+                  ResidualBlock(output_dim, output_dim, self.norm_fn, stride=1))
+        self.in_planes = output_dim
+        return nn.Sequential(*layers)
+
+    def forward(self, x, out_scale=1.0):
+        """x [b,n,c,h,w] (any strides) -> [b,n,out,h/4,w/4], channels-last storage.
+        ``out_scale`` folds the Patchifier's ``fmap / 4`` into the last conv's epilogue."""
+        b, n, c1, h1, w1 = x.shape
+        x = x.reshape(b * n, c1, h1, w1)
+        x = C.conv_norm_relu(x, self.conv1, self.norm1, relu=True)
+        x = self.layer1(x)
+        x = self.layer2(x)
+        x = C.conv_norm_relu(x, self.conv2, None, relu=False, out_scale=out_scale)
+        return x.view(b, n, *x.shape[1:])
+
+
+class MultiScaleBasicEncoder4(BasicEncoder4):
+    """three-scale tower: the 1/2 and 1/4 super-states are concatenated in;
+    reference :274-311.  ``layer2`` / ``conv2`` exist (and are loaded) but unused,
+    as upstream."""
+
+    def __init__(self, output_dim=128, internal_input_dimensions=None, **kwargs):
+        super().__init__(**kwargs)
+        if internal_input_dimensions is None:
+            internal_input_dimensions = [self.channel_dim] * 3
+        self.internal_input_dimensions = internal_input_dimensions
+        self.in_planes = self.in_planes_layer1 + internal_input_dimensions[1]
+        self.layer3 = self._make_layer(output_dim=2 * DIM, stride=2)
+        self.conv3 = nn.Conv2d(2 * DIM + internal_input_dimensions[2], output_dim, kernel_size=1)
+
+    def forward(self, x, x_down2, x_down4, out_scale=1.0):
+        b, n = x.shape[:2]
+        x = x.reshape(b * n, *x.shape[2:])
+        x_down2 = x_down2.reshape(b * n, *x_down2.shape[2:])
+        x_down4 = x_down4.reshape(b * n, *x_down4.shape[2:])
+        x = C.conv_norm_relu(x, self.conv1, self.norm1, relu=True)
+        x = self.layer1(x)
+        x = C.cat_channels(x, x_down2)
+        x = self.layer3(x)
+        x = C.cat_channels(x, x_down4)
+        x = C.conv_norm_relu(x, self.conv3, None, relu=False, out_scale=out_scale)
+        return x.view(b, n, *x.shape[1:])
+
+
+def _pixel_lstm(lstm, x2d, state):
+    """one step of nn.LSTM (gate order i,f,g,o) for every pixel row of x2d [HW,Cin].
+    state = (h, c) [HW,hid] or None (zeros)."""
+    gates = torch.addmm(lstm.bias_ih_l0 + lstm.bias_hh_l0, x2d, lstm.weight_ih_l0.t())
+    if state is not None:
+        gates = gates + state[0] @ lstm.weight_hh_l0.t()
+    i, f, g, o = gates.chunk(4, dim=1)
+    i, f, o = torch.sigmoid(i), torch.sigmoid(f), torch.sigmoid(o)
+    g = torch.tanh(g)
+    c = i * g if state is None else f * state[1] + i * g
+    h = o * torch.tanh(c)
+    return h, c
+
+
+def _pixel_mix(conv, s2d, e2d):
+    """1x1 conv on the channel concat [s ; e] as two [HW,C] GEMMs"""
+    w = conv.weight.view(conv.out_channels, -1)
+    k = s2d.shape[1]
+    return torch.addmm(conv.bias, s2d, w[:, :k].t()) + e2d @ w[:, k:].t()
+
+
+def _to_rows(x):
+    """[C,H,W] (any strides) -> [H*W, C] contiguous"""
+    return x.permute(1, 2, 0).reshape(-1, x.shape[0]).contiguous()
+
+
+class MergerLSTMsceneEncoder(nn.Module):
+    """SingleScale RAMP encoder; reference :187-269"""
+
+    def __init__(self, evs_ch_dim=5, img_ch_dim=3, output_lstm_dim=15, output_dim_f=128, output_dim_i=DIM,
+                 norm_fn_fmap="instance", norm_fn_imap="none", kernel_size_superstate=1):
+        super().__init__()
+        assert kernel_size_superstate == 1
+        self.hidden_size = output_lstm_dim
+        self.events_convlstm = nn.LSTM(input_size=evs_ch_dim, hidden_size=output_lstm_dim, batch_first=True)
+        self.image_convlstm = nn.LSTM(input_size=img_ch_dim, hidden_size=output_lstm_dim, batch_first=True)
+        self.superstate_encoder = nn.Conv2d(2 * output_lstm_dim, output_lstm_dim, kernel_size=1)
+        self.fmap_encoder = BasicEncoder4(output_dim=output_dim_f, norm_fn=norm_fn_fmap, channel_dim=output_lstm_dim)
+        self.imap_encoder = BasicEncoder4(output_dim=output_dim_i, norm_fn=norm_fn_imap, channel_dim=output_lstm_dim)
+        self.states_events, self.states_image, self.super_state = None, None, None
+
+    def forward(self, events, images, reinit_hidden=False, out_scale=1.0):
+        if reinit_hidden:
+            self.states_events, self.states_image, self.super_state = None, None, None
+        B, T, Ce, H, W = events.shape
+        assert B == 1 and images.shape[1] == T
+        super_states = []
+        for t in range(T):
+            ev, im = events[0, t], images[0, t]
+            e_rows, i_rows = _to_rows(ev.float()), _to_rows(im.float())
+            self.states_events = _pixel_lstm(self.events_convlstm, e_rows, self.states_events)
+            self.states_image = _pixel_lstm(self.image_convlstm, i_rows, self.states_image)
+            s = self.super_state if self.super_state is not None else torch.zeros_like(self.states_events[0])
+            # reference gates each update on torch.any(x != 0) with a host sync; here the
+            # flag stays on the device and selects the result
+            s_ev = _pixel_mix(self.superstate_encoder, s, self.states_events[0])
+            s = torch.where((ev != 0).any(), s_ev, s)
+            s_im = _pixel_mix(self.superstate_encoder, s, self.states_image[0])
+            s = torch.where((im != 0).any(), s_im, s)
+            self.super_state = s
+            super_states.append(s.view(H, W, -1))
+        ss = torch.stack(super_states, 0).permute(0, 3, 1, 2)[None]       # [1,T,15,H,W], NHWC storage
+        fmap = self.fmap_encoder(ss, out_scale=out_scale)
+        imap = self.imap_encoder(ss, out_scale=out_scale)
+        return fmap, imap, None
+
+
+class LSTMEncoder(nn.Module):
+    """strided conv + per-pixel LSTM with NO state carry; reference :314-390"""
+
+    def __init__(self, in_channels, downsample_scale=0, out_channels=15, batch_norm_momentum=0.1,
+                 activation_fn=None, normalization_type=None):
+        super().__init__()
+        assert activation_fn is None and normalization_type is None
+        k, stride, pad = downsample_scale + 1, downsample_scale, 1
+        if downsample_scale <= 1:
+            k, stride, pad = 1, 1, 0
+        self.conv_1 = nn.Conv2d(in_channels, in_channels, kernel_size=k, stride=stride, padding=pad)
+        self.convlstm = nn.LSTM(input_size=in_channels, hidden_size=out_channels, batch_first=True)
+        self.norm_layer = nn.Sequential()
+
+    def forward(self, x):
+        """x [1,T,C,H,W] -> list over T of hidden rows [H'*W', hid] and (H', W')"""
+        y = C.conv_norm_relu(x[0].float(), self.conv_1, None, relu=False)     # [T,C,H',W']
+        Hs, Ws = y.shape[-2:]
+        return [_pixel_lstm(self.convlstm, _to_rows(y[t]), None)[0] for t in range(y.shape[0])], (Hs, Ws)
+
+
+class SuperStateEncoder(nn.Module):
+    """1x1 conv over [state ; embedding]; reference :393-463"""
+
+    def __init__(self, kernel_size, out_channels=15, norm_superstate=False):
+        super().__init__()
+        assert kernel_size == 1 and not norm_superstate
+        self.encoder = nn.Conv2d(2 * out_channels, out_channels, kernel_size=1)
+        self.instance_norm_layer = nn.InstanceNorm2d(num_features=out_channels)
+        self.norm_superstate = norm_superstate
+
+
+class MultiScaleMergerDoubleNet(nn.Module):
+    """MultiScale RAMP encoder; reference :468-566"""
+
+    def __init__(self, evs_ch_dim, img_ch_dim, lstm_dim=16, output_dim_f=128, output_dim_i=DIM,
+                 norm_fn_fmap="instance", norm_fn_imap="none", kernel_size_superstate=1, activation_fn=None,
+                 normalization_type=None, norm_superstate=False):
+        super().__init__()
+        self.scales = [1, 2, 4]
+        self.ev_encoders, self.im_encoders = nn.ModuleList(), nn.ModuleList()
+        self.super_state_ev_encoder, self.super_state_im_encoders = nn.ModuleList(), nn.ModuleList()
+        self.internal_dimensions = []
+        self.super_states = []
+        for s in self.scales:
+            d = lstm_dim * s
+            self.internal_dimensions.append(d)
+            self.ev_encoders.append(LSTMEncoder(evs_ch_dim, downsample_scale=s, out_channels=d))
+            self.im_encoders.append(LSTMEncoder(img_ch_dim, downsample_scale=s, out_channels=d))
+            self.super_state_ev_encoder.append(SuperStateEncoder(kernel_size_superstate, d, norm_superstate))
+            self.super_state_im_encoders.append(SuperStateEncoder(kernel_size_superstate, d, norm_superstate))
+            self.super_states.append(None)
+        self.fmap_encoder = MultiScaleBasicEncoder4(output_dim=output_dim_f, norm_fn=norm_fn_fmap,
+                                                    channel_dim=lstm_dim,
+                                                    internal_input_dimensions=self.internal_dimensions)
+        self.imap_encoder = MultiScaleBasicEncoder4(output_dim=output_dim_i, norm_fn=norm_fn_imap,
+                                                    channel_dim=lstm_dim,
+                                                    internal_input_dimensions=self.internal_dimensions)
+
+    def forward(self, events, images, mask, reinit_hidden=False, out_scale=1.0):
+        mask_list = [bool(m) for m in mask.reshape(-1).tolist()]
+        outs = []
+        for k in range(len(self.scales)):
+            if reinit_hidden:
+                self.super_states[k] = None
+            ev_rows, (Hs, Ws) = self.ev_encoders[k](events)
+            im_rows, _ = self.im_encoders[k](images)
+            s = self.super_states[k]
+            collected, ind_im = [], 0
+            for t, e in enumerate(ev_rows):
+                if s is None:
+                    s = torch.zeros_like(e)
+                s = _pixel_mix(self.super_state_ev_encoder[k].encoder, s, e)
+                if mask_list[t] if len(mask_list) > 1 else mask_list[0]:
+                    s = _pixel_mix(self.super_state_im_encoders[k].encoder, s, im_rows[ind_im])
+                    ind_im += 1
+                    collected.append(s)
+            self.super_states[k] = s
+            stack = collected if collected else [s]
+            outs.append(torch.stack([r.view(Hs, Ws, -1) for r in stack], 0).permute(0, 3, 1, 2)[None])
+        fmap = self.fmap_encoder(outs[0], outs[1], outs[2], out_scale=out_scale)
+        imap = self.imap_encoder(outs[0], outs[1], outs[2], out_scale=out_scale)
+        return fmap, imap

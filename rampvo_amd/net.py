@@ -1,0 +1,166 @@
+"""Network operators of the tracking loop (reference: ramp/net.py).
+
+``VONet`` keeps the surface ``Ramp_vo`` consumes -- ``patchify(...)``,
+``update(net, inp, corr, flow, ii, jj, kk)`` and the attributes ``DIM, RES, P`` --
+and the reference's parameter names (checkpoints load with strict=True).  The
+training unroll ``VONet.forward`` is outside the hot path and not provided.
+"""
+import torch
+import torch.nn as nn
+
+from . import altcorr, fastba, ops
+from ._lib import RAMP_NCHW, RAMP_NHWC
+from .blocks import GatedResidual, SoftAgg
+from .extractor import MergerLSTMsceneEncoder, MultiScaleMergerDoubleNet
+from .utils import coords_grid_with_index, get_channel_dim, get_coords_from_topk_events, preprocess_input
+
+DIM = 384
+
+
+class GradientClip(nn.Module):
+    """identity in the forward pass (reference blocks.py:76-90 clips gradients only);
+    kept so the Sequential indices -- and checkpoint keys -- match"""
+
+    def forward(self, x):
+        return x
+
+
+class GraphPlan:
+    """Per-graph index structures shared by the Update operator and BA: temporal
+    neighbours and the two SoftAgg groupings.  Built on the device in one go
+    (``build``); ``Ramp_vo`` rebuilds it only when the factor graph changes."""
+    __slots__ = ("ix", "jx", "mask_ix", "mask_jx", "g_kk", "g_ij", "max_kk", "max_ij", "E")
+
+    @staticmethod
+    def build(ii, jj, kk, kk_bound=0, jj_bound=0, max_kk=None, max_ij=None):
+        p = GraphPlan()
+        p.E = ii.shape[0]
+        p.ix, p.jx = ops.neighbors(kk, jj, kk_bound, jj_bound)
+        p.mask_ix = (p.ix >= 0).reshape(1, -1, 1)
+        p.mask_jx = (p.jx >= 0).reshape(1, -1, 1)
+        p.ix = p.ix.clamp(min=0)
+        p.jx = p.jx.clamp(min=0)
+        p.g_kk = ops.group_by(kk, kk_bound)
+        p.g_ij = ops.group_by(ii * 12345 + jj, 0 if not jj_bound else int(jj_bound) * 12346)
+        # group counts: caller-supplied upper bounds avoid a device->host read-back
+        p.max_kk = int(max_kk) if max_kk is not None else int(p.g_kk.ngroups.item())
+        p.max_ij = int(max_ij) if max_ij is not None else int(p.g_ij.ngroups.item())
+        return p
+
+
+class Update(nn.Module):
+    """recurrent update operator; reference ramp/net.py:34-90"""
+
+    def __init__(self, p):
+        super().__init__()
+        self.c1 = nn.Sequential(nn.Linear(DIM, DIM), nn.ReLU(inplace=True), nn.Linear(DIM, DIM))
+        self.c2 = nn.Sequential(nn.Linear(DIM, DIM), nn.ReLU(inplace=True), nn.Linear(DIM, DIM))
+        self.norm = nn.LayerNorm(DIM, eps=1e-3)
+        self.agg_kk = SoftAgg(DIM)
+        self.agg_ij = SoftAgg(DIM)
+        self.gru = nn.Sequential(nn.LayerNorm(DIM, eps=1e-3), GatedResidual(DIM),
+                                 nn.LayerNorm(DIM, eps=1e-3), GatedResidual(DIM))
+        self.corr = nn.Sequential(nn.Linear(2 * 49 * p * p, DIM), nn.ReLU(inplace=True), nn.Linear(DIM, DIM),
+                                  nn.LayerNorm(DIM, eps=1e-3), nn.ReLU(inplace=True), nn.Linear(DIM, DIM))
+        self.d = nn.Sequential(nn.ReLU(inplace=False), nn.Linear(DIM, 2), GradientClip())
+        self.w = nn.Sequential(nn.ReLU(inplace=False), nn.Linear(DIM, 2), GradientClip(), nn.Sigmoid())
+
+    def forward(self, net, inp, corr, flow, ii, jj, kk, plan=None):
+        if plan is None:
+            plan = GraphPlan.build(ii, jj, kk)
+        net = net + inp + self.corr(corr)
+        net = self.norm(net)
+        net = net + self.c1(plan.mask_ix.to(net.dtype) * net[:, plan.ix])
+        net = net + self.c2(plan.mask_jx.to(net.dtype) * net[:, plan.jx])
+        net = net + self.agg_kk(net, kk, plan.g_kk, plan.max_kk)
+        net = net + self.agg_ij(net, None, plan.g_ij, plan.max_ij)
+        net = self.gru(net)
+        return net, (self.d(net), self.w(net), None)
+
+
+class Patchifier(nn.Module):
+    """encoder + patch selection + patch extraction; reference ramp/net.py:93-203"""
+
+    def __init__(self, channels_dim, patch_size=3, input_mode="MultiScale"):
+        super().__init__()
+        self.input_mode = input_mode
+        self.P = patch_size
+        evs_ch_dim, img_ch_dim = channels_dim
+        if input_mode == "SingleScale":
+            self.encoder = MergerLSTMsceneEncoder(evs_ch_dim=evs_ch_dim, img_ch_dim=img_ch_dim, output_lstm_dim=15,
+                                                  output_dim_f=128, output_dim_i=DIM, norm_fn_fmap="instance",
+                                                  norm_fn_imap="none", kernel_size_superstate=1)
+        elif input_mode == "MultiScale":
+            self.encoder = MultiScaleMergerDoubleNet(evs_ch_dim=evs_ch_dim, img_ch_dim=img_ch_dim, lstm_dim=16,
+                                                     output_dim_f=128, output_dim_i=DIM, norm_fn_fmap="instance",
+                                                     norm_fn_imap="none", norm_superstate=False)
+        else:
+            raise ValueError(f"Invalid input mode: {input_mode}")
+        self._grid = None
+
+    def _coord_grid(self, h, w, device):
+        if self._grid is None or self._grid.shape[-2:] != (h, w) or self._grid.device != device:
+            disps = torch.ones(1, 1, h, w, device=device)
+            grid, _ = coords_grid_with_index(disps, device=device)
+            self._grid = grid[0].contiguous()       # [1,3,h,w]
+        return self._grid
+
+    def forward(self, input_, patches_per_image=80, reinit_hidden=False, disps=None, event_bias=False,
+                gradient_bias=False):
+        events, images, mask = input_
+        if self.input_mode == "SingleScale":
+            fmap, imap, _ = self.encoder(events=events, images=images, reinit_hidden=reinit_hidden,
+                                         out_scale=0.25)           # fmap / 4.0, imap / 4.0 folded in
+            mask = None
+        else:
+            fmap, imap = self.encoder(events=events, images=images, mask=mask, reinit_hidden=reinit_hidden,
+                                      out_scale=0.25)
+            events = events[mask]
+        if mask is not None and not mask.any():
+            return None, None, None, None, None, None
+        b, n, c, h, w = fmap.shape
+        if event_bias:
+            coords = get_coords_from_topk_events(events=events, patches_per_image=patches_per_image,
+                                                 border_suppression_size=0, non_max_supp_rad=11)
+        else:
+            if gradient_bias:
+                raise NotImplementedError("gradient-biased sampling is a training-time option")
+            x = torch.randint(1, w - 1, size=[n, patches_per_image], device=fmap.device)
+            y = torch.randint(1, h - 1, size=[n, patches_per_image], device=fmap.device)
+            coords = torch.stack([x, y], dim=-1).float()
+        coords = coords.float().contiguous()
+        # channels-last storage -> NHWC kernels; results are handed out in the reference's shapes
+        f_nhwc = fmap[0].permute(0, 2, 3, 1)
+        i_nhwc = imap[0].permute(0, 2, 3, 1)
+        gmap = ops.patchify(f_nhwc, coords, 1, True, RAMP_NHWC, RAMP_NHWC)           # [n,M,3,3,128]
+        gmap = gmap.permute(0, 1, 4, 2, 3).reshape(b, -1, 128, self.P, self.P)   # a view when n == 1
+        imap_p = ops.patchify(i_nhwc, coords, 0, True, RAMP_NHWC, RAMP_NHWC)         # [n,M,1,1,384]
+        imap_p = imap_p.view(b, -1, DIM, 1, 1)
+        if disps is None:
+            grid = self._coord_grid(h, w, fmap.device).expand(n, 3, h, w).contiguous()
+        else:
+            grid, _ = coords_grid_with_index(disps, device=fmap.device)
+            grid = grid[0].contiguous()
+        patches = altcorr.patchify(grid, coords, self.P // 2).view(b, -1, 3, self.P, self.P)
+        index = torch.arange(n, device=fmap.device).view(n, 1).repeat(1, patches_per_image).reshape(-1)
+        clr = altcorr.patchify(images[0].float(), 4 * (coords + 0.5), 0).view(b, -1, 3)
+        return fmap, gmap, imap_p, patches, index, clr
+
+
+class VONet(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.P = 3
+        self.RES = 4
+        self.DIM = DIM
+        self.EVENT_BIAS = cfg["event_bias"]
+        self.MOTION_MODEL = "DAMPED_LINEAR"
+        self.MOTION_DAMPING = 0.5
+        self.inp_channel_dims = get_channel_dim(cfg)
+        self.input_mode = cfg["input_mode"]
+        self.patchify = Patchifier(channels_dim=self.inp_channel_dims, patch_size=self.P, input_mode=self.input_mode)
+        self.update = Update(self.P)
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError("the training unroll (reference net.py:252-378) is outside the tracking hot "
+                                  "path; use Ramp_vo for inference")
