@@ -1,0 +1,241 @@
+#!/usr/bin/env python
+"""bench.py -- keyframes/sec of the RAMP-VO tracking hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): SingleScale encoder, 640x480 synthetic
+event+frame stream, 96 patches/frame, default.yaml windows (lifetime 13, removal
+22, optimisation 10), 2 BA iterations per keyframe.  One *step* = one
+``Ramp_vo.__call__`` on an initialised tracker = encoder + patchify + reproject +
+corr + update operator + 2 GN iterations + keyframe management.  The tracker is
+first primed (untimed) until its sliding window is full, so the timed steps run at
+the steady-state graph size (E ~ 45k edges).  Inputs for all steps are generated
+and resident in HBM before the timed region.
+
+N > 1: one process per GPU (torchrun), every rank tracks its own independent
+sequence (different seed) -- the path shards by sequence only; the single
+collective is an all_gather of per-rank metrics.  value = total steps of all ranks
+/ max-over-ranks time.
+
+Prints ONE JSON line on rank 0, including
+  roofline     the fused correlation kernel: algorithmic bytes per launch / mean launch
+               time (HIP events on the launch stream, inside the timed region)
+  cpu_baseline the same steady-state step on the host cores through the CPU oracle
+               ("port"), a bounded sample from the identical state
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--prime", type=int, default=70, help="untimed frames to fill the sliding window")
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--patches", type=int, default=96)
+    ap.add_argument("--mode", default="SingleScale")
+    ap.add_argument("--mixed", type=int, default=0, help="1: fp16 features/update operator like default.yaml")
+    ap.add_argument("--cpu-steps", type=int, default=3, help="steps of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+class CorrTimer:
+    """HIP event pairs around every fused-correlation launch (torch's current stream is the
+    stream the C ABI launches on)"""
+
+    def __init__(self):
+        self.pairs = []
+        self.edges = []
+        self.enabled = False
+
+    def install(self):
+        from rampvo_amd import altcorr
+        inner = altcorr.corr_pyramid
+        timer = self
+
+        def timed(gmap, pyramid, coords, ii, jj, *a, **k):
+            if not timer.enabled:
+                return inner(gmap, pyramid, coords, ii, jj, *a, **k)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = inner(gmap, pyramid, coords, ii, jj, *a, **k)
+            e.record()
+            timer.pairs.append((s, e))
+            timer.edges.append(int(ii.shape[0]))
+            return out
+
+        altcorr.corr_pyramid = timed
+
+    def summary(self, elem_bytes):
+        if not self.pairs:
+            return None
+        ms = np.array([s.elapsed_time(e) for s, e in self.pairs])
+        edges = np.array(self.edges, dtype=np.float64)
+        # per edge per level: 128*9*s (patch) + 128*100*s (union of the 9 8x8 windows)
+        # + 72 (coords) + 16 (indices) + 441*s (output); two levels per launch
+        per_edge_level = 128 * 9 * elem_bytes + 128 * 100 * elem_bytes + 72 + 16 + 441 * elem_bytes
+        big = edges > 0.5 * edges.max()          # the per-update launches (motion-probe launches are tiny)
+        bytes_per_launch = float((edges[big] * 2 * per_edge_level).mean())
+        mean_ms = float(ms[big].mean())
+        achieved = bytes_per_launch / (mean_ms * 1e-3) / 1e9
+        return dict(kernel="corr_kernel", bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None, launches=int(big.sum()),
+                    mean_launch_us=round(mean_ms * 1e3, 1), bytes_per_launch=int(bytes_per_launch),
+                    edges_per_launch=int(edges[big].mean()))
+
+
+def cpu_baseline(state, args, cfg_kwargs, frames, steps):
+    """time `steps` tracker steps on the host cores from the same steady-state snapshot, through
+    the CPU oracle backend (torch CPU for the encoder / update GEMMs, oracle C for the natives)"""
+    from oracle.backend_cpu import cpu_oracle_ops
+    from rampvo_amd.config import make_cfg
+    from rampvo_amd.Ramp_vo import Ramp_vo
+    from rampvo_amd.synthetic import make_network
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg_kwargs = dict(cfg_kwargs, MIXED_PRECISION=False)       # the host path is fp32 throughout
+    state = dict(state)
+    for k in ("net", "imap", "gmap", "fmap1", "fmap2"):
+        state[k] = state[k].float()
+    with cpu_oracle_ops():
+        net = make_network(args.mode, device="cpu")
+        slam = Ramp_vo(make_cfg("default", **cfg_kwargs), net, {"event_bias": True}, ht=args.height, wd=args.width,
+                       device="cpu")
+        slam.load_state_dict(state)
+        # encoder recurrent state is not part of the VO snapshot: one untimed step re-seeds it
+        t0 = state["counter"]
+        im, ev, K, mask = frames[0]
+        slam(t0, input_tensor=(ev, im, mask), intrinsics=K)
+        tic = time.perf_counter()
+        for i in range(steps):
+            im, ev, K, mask = frames[1 + i]
+            slam(t0 + 1 + i, input_tensor=(ev, im, mask), intrinsics=K)
+        dt = time.perf_counter() - tic
+    return dict(value=round(steps / dt, 4), unit="keyframes/s", cores=cores, kind="port",
+                sample="%d steady-state steps (E~%d edges) from the GPU run's state snapshot; torch-CPU fp32 "
+                       "encoder/update GEMMs on %d threads + oracle C natives" % (steps, len(slam._ii), cores),
+                s_per_step=round(dt / steps, 3))
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl")
+    assert torch.cuda.is_available(), "bench.py measures the HIP path: a GPU is required"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from rampvo_amd.config import make_cfg
+    from rampvo_amd.Ramp_vo import Ramp_vo
+    from rampvo_amd.synthetic import SyntheticStream, make_network
+
+    cfg_kwargs = dict(PATCHES_PER_FRAME=args.patches, MIXED_PRECISION=bool(args.mixed))
+    cfg = make_cfg("default", **cfg_kwargs)
+    torch.manual_seed(1234 + rank)
+    net = make_network(args.mode, device=dev)
+    slam = Ramp_vo(cfg, net, {"event_bias": True}, ht=args.height, wd=args.width, device=dev)
+    total = args.prime + args.warmup + args.steps
+    n_cpu = args.cpu_steps + 1 if (rank == 0 and world == 1 and args.cpu_steps > 0) else 0
+    stream = SyntheticStream(args.height, args.width, total + n_cpu + 1, seed=1234 + rank, device=dev)
+    frames = [tuple(x.to(dev) if i < 2 else x for i, x in enumerate(stream.frame(t))) for t in range(total)]
+
+    ctimer = CorrTimer()
+    if not args.no_kernel_timing:
+        ctimer.install()
+
+    def step(t):
+        im, ev, K, mask = frames[t]
+        slam(t, input_tensor=(ev, im, mask), intrinsics=K)
+
+    t = 0
+    for _ in range(args.prime):
+        step(t); t += 1
+    assert slam.is_initialized, "tracker did not initialise during priming"
+    for _ in range(args.warmup):
+        step(t); t += 1
+    E0, n0 = len(slam._ii), slam.n
+
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ctimer.enabled = True
+    tic = time.perf_counter()
+    for _ in range(args.steps):
+        step(t); t += 1
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - tic
+    ctimer.enabled = False
+
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt_all = float(tmax.item())
+        mine = torch.tensor([args.steps / dt, float(len(slam._ii)), float(slam.n),
+                             float(slam.poses_[:slam.n].double().sum())], device=dev, dtype=torch.float64)
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)              # the path's single collective: per-sequence metrics
+        per_rank = [[round(float(v), 4) for v in g.tolist()] for g in gathered]
+    else:
+        dt_all = dt
+        per_rank = None
+
+    if rank == 0:
+        value = world * args.steps / dt_all
+        out = {
+            "metric": "keyframes/sec (BA iters/sec) SingleScale 640x480; ATE vs reference",
+            "value": round(value, 3), "unit": "keyframes/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * dt_all / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16/f32" if args.mixed else "f32",
+            "data": "synthetic (seeded 640x480 event+frame stream, seeded random-init weights)",
+            "config": {"workload": "%s %dx%d, %d patches/frame, default.yaml windows, 2 BA iters/keyframe, "
+                                   "steady-state sliding window" % (args.mode, args.width, args.height, args.patches),
+                       "ba_iters_per_s": round(2 * value, 2), "edges": E0, "edges_end": len(slam._ii),
+                       "keyframes_in_window": n0, "prime_frames": args.prime,
+                       "sharding": "independent sequences, 1 per GPU" if world > 1 else "single sequence"},
+        }
+        if per_rank is not None:
+            out["config"]["per_rank_kfps_E_n_chk"] = per_rank
+        rl = ctimer.summary(2 if args.mixed else 4)
+        if rl is not None:
+            out["roofline"] = rl
+        if n_cpu:
+            state = slam.state_dict()
+            cpu_frames = [stream.frame(total + i) for i in range(n_cpu)]
+            cpu_frames = [tuple(x.cpu() for x in f) for f in cpu_frames]
+            try:
+                out["cpu_baseline"] = cpu_baseline(state, args, cfg_kwargs, cpu_frames, args.cpu_steps)
+                out["config"]["speedup_vs_cpu_port"] = round(value / out["cpu_baseline"]["value"], 1)
+            except Exception as e:  # the baseline must never take the GPU number down with it
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -37,8 +37,8 @@ OUT = os.path.join(ROOT, "tests", "golden")
 NET_CFG = lambda mode: {"event_bias": True, "num_event_bins": 5, "input_mode": mode}   # noqa: E731
 
 # shared problem definitions (the tests rebuild the same inputs from these)
-PATCHIFY = dict(H=96, W=128, T=3, M=16, seed=1234)
-RAMPVO = dict(H=128, W=160, T=20, M=16, seed=1234)
+PATCHIFY = dict(H=128, W=160, T=3, M=8, seed=1234)
+RAMPVO = dict(H=128, W=160, T=20, M=8, seed=1234)
 DEPTH_SEED = 4321
 
 
@@ -53,6 +53,17 @@ def ref_network(ns, mode, seed=1234):
 def sample_idx(shape, k=256, seed=0):
     rng = np.random.default_rng(seed)
     return rng.integers(0, int(np.prod(shape)), k)
+
+
+def assert_tie_free(events, M):
+    """top-k patch selection is only well defined without ties (torch.topk's order among equal
+    values is backend specific): require M strictly positive, well separated NMS maxima"""
+    import torch.nn.functional as F
+    from rampvo_amd.utils import nms_image
+    e = F.avg_pool2d(torch.abs(events.squeeze(0)), 4, 4).transpose(3, 2).mean(dim=1)
+    v = torch.sort(nms_image(e, 11).flatten(), descending=True).values[:M + 1]
+    assert v[M - 1] > 0, "fewer than M positive maxima: selection would tie at zero"
+    assert ((v[:-1] - v[1:]) / v[:-1])[:M].min() > 1e-4, "near-tie among the selected maxima"
 
 
 def depth_draw(frame, M):
@@ -71,6 +82,7 @@ def gen_patchify(ns, mode):
         for t in range(p["T"]):
             image, events, K, _ = stream.frame(t)
             mask = torch.tensor([not (mode == "MultiScale" and t == 1)])   # MS: an events-only step
+            assert_tie_free(events, p["M"])
             res = net.patchify(input_=(events, image, mask), patches_per_image=p["M"], event_bias=True,
                                reinit_hidden=(t == 0))
             fmap, gmap, imap, patches, index, clr = res
@@ -170,6 +182,7 @@ def gen_ramp_vo(ns):
         try:
             for t in range(p["T"]):
                 image, events, K, mask = stream.frame(t)
+                assert_tie_free(events, p["M"])
                 frame_no[0] = t
                 slam(t, input_tensor=(events, image, mask), intrinsics=K)
                 rec["n"].append(slam.n); rec["m"].append(slam.m); rec["E"].append(len(slam.ii))

@@ -7,8 +7,8 @@ import numpy as np
 import torch
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-PATCHIFY = dict(H=96, W=128, T=3, M=16, seed=1234)
-RAMPVO = dict(H=128, W=160, T=20, M=16, seed=1234)
+PATCHIFY = dict(H=128, W=160, T=3, M=8, seed=1234)
+RAMPVO = dict(H=128, W=160, T=20, M=8, seed=1234)
 DEPTH_SEED = 4321
 NET_CFG = lambda mode: {"event_bias": True, "num_event_bins": 5, "input_mode": mode}   # noqa: E731
 
