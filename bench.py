@@ -191,18 +191,14 @@ def main():
     dt = time.perf_counter() - tic
     ctimer.enabled = False
 
+    from rampvo_amd.shard import gather_metrics, max_over_ranks
+    dt_all = max_over_ranks(dt, dev)
+    per_rank = None
     if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt_all = float(tmax.item())
-        mine = torch.tensor([args.steps / dt, float(len(slam._ii)), float(slam.n),
-                             float(slam.poses_[:slam.n].double().sum())], device=dev, dtype=torch.float64)
-        gathered = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(gathered, mine)              # the path's single collective: per-sequence metrics
-        per_rank = [[round(float(v), 4) for v in g.tolist()] for g in gathered]
-    else:
-        dt_all = dt
-        per_rank = None
+        # the path's single collective: per-sequence metrics (kf/s, E, n, pose checksum)
+        g = gather_metrics([args.steps / dt, float(len(slam._ii)), float(slam.n),
+                            float(slam.poses_[:slam.n].double().sum())], dev)
+        per_rank = [[round(float(v), 4) for v in row] for row in g.tolist()]
 
     if rank == 0:
         value = world * args.steps / dt_all
