@@ -166,6 +166,49 @@ int ramp_ba_forward(float *poses, float *patches, const float *intrinsics, const
                     int n_patches, int t0, int t1, int iterations, void *ws, size_t ws_bytes,
                     int32_t *info, void *stream);
 
+/* ------------------------------------------------------------------ encoder */
+/* flags[0] = any(a != 0), flags[1] = any(b != 0): the "events / image present" tests of
+ * ramp/extractor.py:253-254, kept on the device (the reference syncs the host on each).       */
+int ramp_any_nonzero(const float *a, long na, const float *b, long nb, int32_t *flags, void *stream);
+
+/* The two per-pixel LSTM cells and the super-state 1x1 convolution of the SingleScale encoder,
+ * fused (ramp/extractor.py:239-259: nn.LSTM x2 on [H*W,1,C] sequences + Conv2d(30->15) x2).
+ *   ev [5][HW], im [3][HW] planar float32; h_ev,c_ev,h_im,c_im [15][HW] planar recurrent state (in/out);
+ *   ss [HW][16] channels-last super-state (in/out, channel 15 = 0);
+ *   wpacked: LSTM + conv weights packed by rampvo_amd/conv_hip.py::pack_lstm;
+ *   has_state / has_ss: 0 on the first call after reinit_hidden (zero initial state)         */
+int ramp_lstm_superstate(const float *ev, const float *im, float *h_ev, float *c_ev, float *h_im,
+                         float *c_im, float *ss, const float *wpacked, const int32_t *flags, int HW,
+                         int has_state, int has_ss, void *stream);
+
+/* nn.Conv2d (+ fused neighbours) of the encoder towers as an implicit GEMM on MFMA
+ * (ramp/extractor.py:8-57, 60-130; reference: cuDNN).  NHWC activations, padding = K/2.
+ *   x [H][W][Cin] (Cin % 16 == 0), y [OH][OW][Cout] (Cout % 32 == 0)
+ *   wpk: weights in MFMA fragment order (rampvo_amd/conv_hip.py::pack_conv_weight)
+ *   pre_scale/pre_shift [Cin] (optional): x <- relu(x*scale + shift) while loading, i.e. the
+ *       producer's InstanceNorm + ReLU fused into this conv
+ *   y = [relu]( conv + bias );  if res: y = relu(y + res);  y *= out_scale
+ *   stats (optional) [ceil(OH*OW/128)][Cout][2]: per-block partial sum / sum of squares of
+ *       (conv + bias), reduced by ramp_in_stats_finalize                                       */
+int ramp_conv2d_nhwc(const void *x, const void *wpk, const float *bias, const float *pre_scale,
+                     const float *pre_shift, const void *res, void *y, float *stats, int H, int W,
+                     int Cin, int Cout, int KH, int KW, int stride, int relu, float out_scale,
+                     int dtype, void *stream);
+
+/* InstanceNorm2d statistics (affine=False, biased variance): scale = rsqrt(var+eps),
+ * shift = -mean*scale, from the per-block partials of ramp_conv2d_nhwc                         */
+int ramp_in_stats_finalize(const float *partial, int nblk, int C, float count, float eps, float *scale,
+                           float *shift, void *stream);
+
+/* out = relu(x*s + h)   (InstanceNorm + ReLU materialised where a skip connection needs it)    */
+int ramp_affine_relu(const float *x, const float *s, const float *h, float *out, long n, int C,
+                     void *stream);
+
+/* residual-block tail: out = relu( skip' + relu(y*sy + hy) ), skip' = skip*ss + hs if ss else skip
+ * (ramp/extractor.py:49-57 with the norms folded in)                                           */
+int ramp_norm_add_relu(const float *y, const float *sy, const float *hy, const float *skip,
+                       const float *ss, const float *hs, float *out, long n, int C, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

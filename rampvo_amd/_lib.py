@@ -50,6 +50,12 @@ SIGNATURES = {
     "ramp_segment_softmax_sum": (c_i, [c_p] * 6 + [c_i, c_i, c_i, c_i, c_p]),
     "ramp_ba_workspace_bytes": (c_sz, [c_i] * 5),
     "ramp_ba_forward": (c_i, [c_p] * 9 + [c_i] * 7 + [c_p, c_sz, c_p, c_p]),
+    "ramp_any_nonzero": (c_i, [c_p, ctypes.c_long, c_p, ctypes.c_long, c_p, c_p]),
+    "ramp_lstm_superstate": (c_i, [c_p] * 9 + [c_i, c_i, c_i, c_p]),
+    "ramp_conv2d_nhwc": (c_i, [c_p] * 8 + [c_i] * 8 + [c_f, c_i, c_p]),
+    "ramp_in_stats_finalize": (c_i, [c_p, c_i, c_i, c_f, c_f, c_p, c_p, c_p]),
+    "ramp_affine_relu": (c_i, [c_p, c_p, c_p, c_p, ctypes.c_long, c_i, c_p]),
+    "ramp_norm_add_relu": (c_i, [c_p] * 7 + [ctypes.c_long, c_i, c_p]),
 }
 
 _lib = None

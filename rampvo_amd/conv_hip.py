@@ -1,0 +1,167 @@
+"""HIP back-end of the RAMP encoder: fused per-pixel LSTM / super-state kernel and the
+implicit-GEMM MFMA conv towers (csrc/conv.hip).  Activations are NHWC float32 tensors
+[H, W, C]; InstanceNorm + ReLU are never materialised on their own -- they ride on the
+consumer conv's load path (``pre``) or on the residual-block tail kernel.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import RAMP_F32, check, lib, ptr, stream
+
+_pack_cache = {}
+
+
+def available():
+    try:
+        return hasattr(lib(), "ramp_conv2d_nhwc")
+    except Exception:
+        return False
+
+
+# ------------------------------------------------------------------ weight packing
+def pack_conv_weight(conv):
+    """[Cout,Cin,KH,KW] -> MFMA fragment order [tap][Cin/16][Cout/16][64 lanes][4]:
+    lane (q = lane>>4, j = lane&15) holds W[16*nt + j][16*ch + 4*q + s] for s = 0..3"""
+    w = conv.weight
+    key = (id(conv), w._version, w.device, w.data_ptr())
+    hit = _pack_cache.get(id(conv))
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
+    cout, cin, kh, kw = w.shape
+    cin_p = (cin + 15) // 16 * 16
+    wp = torch.zeros(cout, cin_p, kh, kw, dtype=torch.float32, device=w.device)
+    wp[:, :cin] = w.detach().float()
+    t = wp.permute(2, 3, 1, 0).reshape(kh * kw, cin_p // 16, 4, 4, cout // 16, 16)   # tap, ch, q, s, nt, j
+    t = t.permute(0, 1, 4, 2, 5, 3).contiguous()                                       # tap, ch, nt, q, j, s
+    bias = conv.bias.detach().float().contiguous() if conv.bias is not None else None
+    _pack_cache[id(conv)] = (key, t, bias)
+    return t, bias
+
+
+def pack_lstm(enc):
+    """weights of the fused LSTM/super-state kernel (offsets LW_* in csrc/conv.hip)"""
+    key = tuple((p.data_ptr(), p._version) for p in enc.events_convlstm.parameters()) + \
+        tuple((p.data_ptr(), p._version) for p in enc.image_convlstm.parameters()) + \
+        tuple((p.data_ptr(), p._version) for p in enc.superstate_encoder.parameters())
+    hit = _pack_cache.get(("lstm", id(enc)))
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    e, i, s = enc.events_convlstm, enc.image_convlstm, enc.superstate_encoder
+    parts = [e.weight_ih_l0, e.weight_hh_l0, e.bias_ih_l0 + e.bias_hh_l0,
+             i.weight_ih_l0, i.weight_hh_l0, i.bias_ih_l0 + i.bias_hh_l0,
+             s.weight.view(15, 30), s.bias]
+    w = torch.cat([p.detach().float().reshape(-1) for p in parts]).contiguous()
+    assert w.numel() == 60 * 5 + 60 * 15 + 60 + 60 * 3 + 60 * 15 + 60 + 15 * 30 + 15
+    _pack_cache[("lstm", id(enc))] = (key, w)
+    return w
+
+
+# ------------------------------------------------------------------------ primitives
+class Pending:
+    """a raw conv output whose InstanceNorm(+ReLU) has not been applied yet"""
+    __slots__ = ("raw", "scale", "shift")
+
+    def __init__(self, raw, scale, shift):
+        self.raw, self.scale, self.shift = raw, scale, shift
+
+
+def conv2d(x, conv, pre=None, res=None, relu=False, want_stats=False, out_scale=1.0, eps=1e-5):
+    """x [H,W,Cin] NHWC fp32 (or a Pending: normalise+ReLU on load).  Returns y [OH,OW,Cout],
+    or Pending(y, scale, shift) when want_stats (InstanceNorm statistics of y)."""
+    if isinstance(x, Pending):
+        pre, x = (x.scale, x.shift), x.raw
+    H, W, Cin = x.shape
+    wpk, bias = pack_conv_weight(conv)
+    cout, _, kh, kw = conv.weight.shape
+    stride = conv.stride[0]
+    assert Cin == wpk.shape[1] * 16 and conv.padding[0] == kh // 2 and x.is_contiguous()
+    OH = (H + 2 * (kh // 2) - kh) // stride + 1
+    OW = (W + 2 * (kw // 2) - kw) // stride + 1
+    y = torch.empty(OH, OW, cout, dtype=torch.float32, device=x.device)
+    nblk = (OH * OW + 127) // 128
+    stats = torch.empty(nblk, cout, 2, dtype=torch.float32, device=x.device) if want_stats else None
+    check(lib().ramp_conv2d_nhwc(ptr(x), ptr(wpk), ptr(bias), ptr(pre[0]) if pre else None,
+                                 ptr(pre[1]) if pre else None, ptr(res), ptr(y), ptr(stats), H, W, Cin, cout,
+                                 kh, kw, stride, int(relu), float(out_scale), RAMP_F32, stream()),
+          "ramp_conv2d_nhwc")
+    if not want_stats:
+        return y
+    scale = torch.empty(cout, dtype=torch.float32, device=x.device)
+    shift = torch.empty(cout, dtype=torch.float32, device=x.device)
+    check(lib().ramp_in_stats_finalize(ptr(stats), nblk, cout, float(OH * OW), float(eps), ptr(scale), ptr(shift),
+                                       stream()), "ramp_in_stats_finalize")
+    return Pending(y, scale, shift)
+
+
+def materialize(p):
+    """relu(norm(raw))"""
+    out = torch.empty_like(p.raw)
+    check(lib().ramp_affine_relu(ptr(p.raw), ptr(p.scale), ptr(p.shift), ptr(out), p.raw.numel(), p.raw.shape[-1],
+                                 stream()), "ramp_affine_relu")
+    return out
+
+
+def norm_add_relu(y, skip):
+    """relu(skip' + relu(norm(y)));  skip is a tensor or a Pending (norm, no ReLU)"""
+    out = torch.empty_like(y.raw)
+    s_raw, ss, hs = (skip.raw, skip.scale, skip.shift) if isinstance(skip, Pending) else (skip, None, None)
+    check(lib().ramp_norm_add_relu(ptr(y.raw), ptr(y.scale), ptr(y.shift), ptr(s_raw), ptr(ss), ptr(hs), ptr(out),
+                                   y.raw.numel(), y.raw.shape[-1], stream()), "ramp_norm_add_relu")
+    return out
+
+
+# --------------------------------------------------------------------------- towers
+def _res_block(blk, x, norm):
+    """reference ResidualBlock.forward (extractor.py:49-57)"""
+    if norm:
+        y = conv2d(x, blk.conv1, want_stats=True)
+        y = conv2d(y, blk.conv2, want_stats=True)
+        skip = x if blk.downsample is None else conv2d(x, blk.downsample[0], want_stats=True)
+        return norm_add_relu(y, skip)
+    y = conv2d(x, blk.conv1, relu=True)
+    skip = x if blk.downsample is None else conv2d(x, blk.downsample[0])
+    return conv2d(y, blk.conv2, res=skip, relu=True)       # relu(skip + relu(conv2(y)))
+
+
+def basic_encoder4(enc, x, out_scale=1.0):
+    """BasicEncoder4._forward on one NHWC image x [H,W,Cin_padded] -> [H/4,W/4,out]"""
+    norm = isinstance(enc.norm1, nn.InstanceNorm2d)
+    if norm:
+        x = materialize(conv2d(x, enc.conv1, want_stats=True, eps=enc.norm1.eps))
+    else:
+        assert isinstance(enc.norm1, nn.Sequential) and len(enc.norm1) == 0
+        x = conv2d(x, enc.conv1, relu=True)
+    for blk in enc.layer1:
+        x = _res_block(blk, x, norm)
+    for blk in enc.layer2:
+        x = _res_block(blk, x, norm)
+    return conv2d(x, enc.conv2, out_scale=out_scale)
+
+
+# ------------------------------------------------------------------ LSTM / super-state
+class LstmState:
+    __slots__ = ("h_ev", "c_ev", "h_im", "c_im", "ss", "flags", "fresh", "HW")
+
+    def __init__(self, HW, device):
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=device)
+        self.h_ev, self.c_ev, self.h_im, self.c_im = z(15, HW), z(15, HW), z(15, HW), z(15, HW)
+        self.ss = z(HW, 16)
+        self.flags = torch.zeros(2, dtype=torch.int32, device=device)
+        self.fresh = True
+        self.HW = HW
+
+
+def lstm_superstate_step(enc, ev, im, st):
+    """ev [5,H,W], im [3,H,W] contiguous fp32; updates st in place, returns the super-state
+    as an NHWC16 tensor [H,W,16] (a view of st.ss)"""
+    w = pack_lstm(enc)
+    H, W = ev.shape[-2:]
+    check(lib().ramp_any_nonzero(ptr(ev), ev.numel(), ptr(im), im.numel(), ptr(st.flags), stream()),
+          "ramp_any_nonzero")
+    has = 0 if st.fresh else 1
+    check(lib().ramp_lstm_superstate(ptr(ev), ptr(im), ptr(st.h_ev), ptr(st.c_ev), ptr(st.h_im), ptr(st.c_im),
+                                     ptr(st.ss), ptr(w), ptr(st.flags), H * W, has, has, stream()),
+          "ramp_lstm_superstate")
+    st.fresh = False
+    return st.ss.view(H, W, 16)

@@ -1,0 +1,425 @@
+// RAMP encoder kernels for gfx950.
+//
+//  1. lstm_superstate_kernel: the two per-pixel LSTM cells (events 5->15, image 3->15, state
+//     carried) and the shared super-state 1x1 convolution, fused into ONE pointwise kernel
+//     (reference: cuDNN LSTM over 307,200 length-1 sequences + two conv launches + host syncs on
+//     torch.any; ramp/extractor.py:233-259).  Weights are read through uniform (scalar) loads and
+//     enter the FMAs as SGPR operands; recurrent state is planar [15][H*W] (coalesced), the
+//     super-state leaves as channels-last [H*W][16] (channel 15 = 0) for the conv towers.
+//
+//  2. conv_mfma_kernel: implicit-GEMM convolution on the matrix cores.  NHWC activations, one
+//     wavefront = 32 output pixels x 32 output channels = 2x2 tiles of v_mfma_f32_16x16x4_f32
+//     (exact fp32, k-ordered fmaf chain) or v_mfma_f32_16x16x32_f16.  No LDS: the K axis is
+//     permuted so that every lane's A fragment for 4 (fp32) / 1 (f16) MFMA steps is ONE 16-byte
+//     channels-last load of its own pixel, and the weights are pre-packed host-side in fragment
+//     order so B is one coalesced 16-byte load per lane (L2-resident, shared by all blocks).
+//     Prologue (optional): per-channel affine + ReLU applied while loading the input, i.e. the
+//     previous layer's InstanceNorm + ReLU are never materialised.  Epilogue: bias, optional ReLU,
+//     optional residual add + ReLU, output scale, and per-block partial sums / sums of squares
+//     per channel for the next InstanceNorm (deterministic two-stage reduction, no atomics).
+//
+//  3. in_stats_finalize_kernel, norm_add_relu_kernel: InstanceNorm statistics -> (scale, shift),
+//     and the residual-block tail relu(skip' + relu(norm(y))).
+#include "ramp_device.h"
+
+// ------------------------------------------------------------------ any != 0
+__global__ void __launch_bounds__(256)
+    any_nonzero_kernel(const float *__restrict__ a, long na, const float *__restrict__ b, long nb,
+                       int *__restrict__ flags) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  bool fa = false, fb = false;
+  for (long k = i; k < na; k += stride) fa |= (a[k] != 0.0f);
+  for (long k = i; k < nb; k += stride) fb |= (b[k] != 0.0f);
+  if (__any(fa) && (threadIdx.x & 63) == 0) atomicOr(&flags[0], 1);
+  if (__any(fb) && (threadIdx.x & 63) == 0) atomicOr(&flags[1], 1);
+}
+
+// ------------------------------------------------------- LSTM + super-state
+// packed weights (floats): see rampvo_amd/conv_hip.py::pack_lstm
+#define LW_IH_E 0                    // [60][5]
+#define LW_HH_E (LW_IH_E + 60 * 5)   // [60][15]
+#define LW_B_E (LW_HH_E + 60 * 15)   // [60]   (b_ih + b_hh)
+#define LW_IH_I (LW_B_E + 60)        // [60][3]
+#define LW_HH_I (LW_IH_I + 60 * 3)   // [60][15]
+#define LW_B_I (LW_HH_I + 60 * 15)   // [60]
+#define LW_SS (LW_B_I + 60)          // [15][30]
+#define LW_SB (LW_SS + 15 * 30)      // [15]
+#define LW_TOTAL (LW_SB + 15)
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <int CIN>
+__device__ __forceinline__ void lstm_cell(const float *__restrict__ Wih, const float *__restrict__ Whh,
+                                          const float *__restrict__ B, const float *x, float *h,
+                                          float *c, bool has_state) {
+  float g[60];
+#pragma unroll
+  for (int r = 0; r < 60; r++) {
+    float s = B[r];
+#pragma unroll
+    for (int k = 0; k < CIN; k++) s = __builtin_fmaf(Wih[r * CIN + k], x[k], s);
+    g[r] = s;
+  }
+  if (has_state) {
+#pragma unroll
+    for (int r = 0; r < 60; r++) {
+      float s = g[r];
+#pragma unroll
+      for (int k = 0; k < 15; k++) s = __builtin_fmaf(Whh[r * 15 + k], h[k], s);
+      g[r] = s;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 15; k++) {  // torch gate order: i, f, g, o
+    const float ig = sigmoidf_(g[k]), fg = sigmoidf_(g[15 + k]), gg = tanhf(g[30 + k]),
+                og = sigmoidf_(g[45 + k]);
+    const float cn = has_state ? fg * c[k] + ig * gg : ig * gg;
+    c[k] = cn;
+    h[k] = og * tanhf(cn);
+  }
+}
+
+__global__ void __launch_bounds__(128)
+    lstm_superstate_kernel(const float *__restrict__ ev, const float *__restrict__ im,
+                           float *__restrict__ h_ev, float *__restrict__ c_ev,
+                           float *__restrict__ h_im, float *__restrict__ c_im,
+                           float *__restrict__ ss, const float *__restrict__ W,
+                           const int *__restrict__ flags, int HW, int has_state, int has_ss) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= HW) return;
+  float x[5], y[3], he[15], ce[15], hi[15], ci[15], s[15];
+#pragma unroll
+  for (int k = 0; k < 5; k++) x[k] = ev[(size_t)k * HW + p];
+#pragma unroll
+  for (int k = 0; k < 3; k++) y[k] = im[(size_t)k * HW + p];
+  if (has_state) {
+#pragma unroll
+    for (int k = 0; k < 15; k++) {
+      he[k] = h_ev[(size_t)k * HW + p]; ce[k] = c_ev[(size_t)k * HW + p];
+      hi[k] = h_im[(size_t)k * HW + p]; ci[k] = c_im[(size_t)k * HW + p];
+    }
+  }
+  lstm_cell<5>(W + LW_IH_E, W + LW_HH_E, W + LW_B_E, x, he, ce, has_state);
+  lstm_cell<3>(W + LW_IH_I, W + LW_HH_I, W + LW_B_I, y, hi, ci, has_state);
+#pragma unroll
+  for (int k = 0; k < 15; k++) {
+    h_ev[(size_t)k * HW + p] = he[k]; c_ev[(size_t)k * HW + p] = ce[k];
+    h_im[(size_t)k * HW + p] = hi[k]; c_im[(size_t)k * HW + p] = ci[k];
+  }
+  float4 *sp = reinterpret_cast<float4 *>(ss + (size_t)p * 16);
+  if (has_ss) {
+    const float4 a = sp[0], b = sp[1], c = sp[2], d = sp[3];
+    s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
+    s[8] = c.x; s[9] = c.y; s[10] = c.z; s[11] = c.w; s[12] = d.x; s[13] = d.y; s[14] = d.z;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 15; k++) s[k] = 0.0f;
+  }
+  // super_state <- Conv1x1([super_state ; embedding]) per present modality (extractor.py:251-259)
+#pragma unroll
+  for (int pass = 0; pass < 2; pass++) {
+    if (!flags[pass]) continue;
+    const float *e = pass == 0 ? he : hi;
+    float t[15];
+#pragma unroll
+    for (int r = 0; r < 15; r++) {
+      float a = W[LW_SB + r];
+#pragma unroll
+      for (int k = 0; k < 15; k++) a = __builtin_fmaf(W[LW_SS + r * 30 + k], s[k], a);
+#pragma unroll
+      for (int k = 0; k < 15; k++) a = __builtin_fmaf(W[LW_SS + r * 30 + 15 + k], e[k], a);
+      t[r] = a;
+    }
+#pragma unroll
+    for (int r = 0; r < 15; r++) s[r] = t[r];
+  }
+  sp[0] = make_float4(s[0], s[1], s[2], s[3]);
+  sp[1] = make_float4(s[4], s[5], s[6], s[7]);
+  sp[2] = make_float4(s[8], s[9], s[10], s[11]);
+  sp[3] = make_float4(s[12], s[13], s[14], 0.0f);
+}
+
+// --------------------------------------------------------- implicit GEMM conv
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+struct ConvParams {
+  const void *x;        // NHWC [H][W][Cin]
+  const void *wpk;      // packed weights (fragment order)
+  const float *bias;    // [Cout] or null
+  const float *pre_scale, *pre_shift;  // [Cin] or null: x <- relu(x*scale+shift) on load
+  const void *res;      // NHWC [OH][OW][Cout] residual (added before the final ReLU) or null
+  void *y;              // NHWC [OH][OW][Cout]
+  float *stats;         // [nblk_m][Cout][2] partial (sum, sumsq) of the raw (bias-added) output or null
+  int H, W, Cin, OH, OW, Cout;
+  int relu;             // ReLU on the conv output (before the residual add; the add is followed by its own ReLU)
+  float out_scale;
+};
+
+// fp32: wave tile 32 px x 32 ch, K chunk = 16 input channels per tap.
+// A fragment (v_mfma_f32_16x16x4_f32): lane l supplies A[i=l&15][k=l>>4]; with the channel
+// permutation c = 4*(l>>4) + step one float4 load feeds 4 MFMA steps.
+template <int KH, int KW, int STRIDE>
+__global__ void __launch_bounds__(256)
+    conv_mfma_f32_kernel(const ConvParams p) {
+  constexpr int PAD = KH / 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane >> 4, j = lane & 15;
+  const int M = p.OH * p.OW;
+  const int m_wave = (blockIdx.x * 4 + wave) * 32;
+  const int n0 = blockIdx.y * 32;
+  const float *x = reinterpret_cast<const float *>(p.x);
+  const float *wpk = reinterpret_cast<const float *>(p.wpk);
+  const int nchunk = p.Cin / 16;
+
+  // the two pixels (one per m-tile) whose activations this lane loads
+  int oy[2], ox[2];
+  bool mval[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; mt++) {
+    const int m = m_wave + mt * 16 + j;
+    mval[mt] = m < M;
+    const int mm = mval[mt] ? m : 0;
+    oy[mt] = mm / p.OW;
+    ox[mt] = mm - oy[mt] * p.OW;
+  }
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // packed weights: [tap][chunk][ntile(Cout/16)][lane(64)][4]
+  const int ntiles = p.Cout / 16;
+  for (int ky = 0; ky < KH; ky++) {
+    for (int kx = 0; kx < KW; kx++) {
+      const int tap = ky * KW + kx;
+      size_t aoff[2];
+      bool aval[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; mt++) {
+        const int iy = oy[mt] * STRIDE + ky - PAD, ix = ox[mt] * STRIDE + kx - PAD;
+        aval[mt] = mval[mt] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        aoff[mt] = ((size_t)(aval[mt] ? iy : 0) * p.W + (aval[mt] ? ix : 0)) * p.Cin + 4 * q;
+      }
+      for (int ch = 0; ch < nchunk; ch++) {
+        float4 a[2], b[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++) {
+          a[mt] = aval[mt] ? *reinterpret_cast<const float4 *>(x + aoff[mt] + ch * 16)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (p.pre_scale) {
+          const float4 sc = *reinterpret_cast<const float4 *>(p.pre_scale + ch * 16 + 4 * q);
+          const float4 sh = *reinterpret_cast<const float4 *>(p.pre_shift + ch * 16 + 4 * q);
+#pragma unroll
+          for (int mt = 0; mt < 2; mt++) {
+            if (aval[mt]) {
+              a[mt].x = fmaxf(a[mt].x * sc.x + sh.x, 0.f);
+              a[mt].y = fmaxf(a[mt].y * sc.y + sh.y, 0.f);
+              a[mt].z = fmaxf(a[mt].z * sc.z + sh.z, 0.f);
+              a[mt].w = fmaxf(a[mt].w * sc.w + sh.w, 0.f);
+            }
+          }
+        }
+        const float *wb = wpk + (((size_t)(tap * nchunk + ch) * ntiles + (n0 / 16)) * 64 + lane) * 4;
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++) b[nt] = *reinterpret_cast<const float4 *>(wb + nt * 256);
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+          for (int nt = 0; nt < 2; nt++) {
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, b[nt].x, acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, b[nt].y, acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].z, b[nt].z, acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, b[nt].w, acc[mt][nt], 0, 0, 0);
+          }
+      }
+    }
+  }
+  // ---- epilogue.  D layout: lane holds rows 4q..4q+3 (pixels) of column j (channel)
+  __shared__ float s_stat[4][32][2];
+  float *y = reinterpret_cast<float *>(p.y);
+  const float *res = reinterpret_cast<const float *>(p.res);
+#pragma unroll
+  for (int nt = 0; nt < 2; nt++) {
+    const int c = n0 + nt * 16 + j;
+    const float bv = p.bias ? p.bias[c] : 0.0f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int m = m_wave + mt * 16 + 4 * q + r;
+        if (m < M) {
+          float v = acc[mt][nt][r] + bv;
+          s1 += v;
+          s2 += v * v;
+          if (p.relu) v = fmaxf(v, 0.f);
+          if (res) v = fmaxf(v + res[(size_t)m * p.Cout + c], 0.f);
+          y[(size_t)m * p.Cout + c] = v * p.out_scale;
+        }
+      }
+    }
+    if (p.stats) {
+      s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+      if (q == 0) { s_stat[wave][nt * 16 + j][0] = s1; s_stat[wave][nt * 16 + j][1] = s2; }
+    }
+  }
+  if (p.stats) {
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const int c = threadIdx.x >> 1, k = threadIdx.x & 1;
+      const float v = ((s_stat[0][c][k] + s_stat[1][c][k]) + s_stat[2][c][k]) + s_stat[3][c][k];
+      p.stats[((size_t)blockIdx.x * p.Cout + n0 + c) * 2 + k] = v;
+    }
+  }
+}
+
+// InstanceNorm statistics: partial[nblk][C][2] -> scale = rstd, shift = -mean*rstd (biased variance)
+__global__ void __launch_bounds__(64)
+    in_stats_finalize_kernel(const float *__restrict__ partial, int nblk, int C, float count, float eps,
+                             float *__restrict__ scale, float *__restrict__ shift) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  float s1 = 0.f, s2 = 0.f;
+  for (int b = lane; b < nblk; b += 64) {
+    s1 += partial[((size_t)b * C + c) * 2 + 0];
+    s2 += partial[((size_t)b * C + c) * 2 + 1];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_down(s1, off, 64); s2 += __shfl_down(s2, off, 64); }
+  if (lane == 0) {
+    const float mean = s1 / count;
+    float var = s2 / count - mean * mean;
+    var = var < 0.f ? 0.f : var;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    scale[c] = rstd;
+    shift[c] = -mean * rstd;
+  }
+}
+
+// out = relu( f(skip) + relu(y*sy + hy) ),  f(skip) = skip*ss + hs when given (norm3 of the
+// downsample path, no ReLU) else skip.  NHWC, C multiple of 4.
+__global__ void __launch_bounds__(256)
+    norm_add_relu_kernel(const float *__restrict__ y, const float *__restrict__ sy,
+                         const float *__restrict__ hy, const float *__restrict__ skip,
+                         const float *__restrict__ ss, const float *__restrict__ hs,
+                         float *__restrict__ out, long n4, int C) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const int c = (int)((i * 4) % C);
+  float4 v = reinterpret_cast<const float4 *>(y)[i];
+  const float4 a = *reinterpret_cast<const float4 *>(sy + c), b = *reinterpret_cast<const float4 *>(hy + c);
+  v.x = fmaxf(v.x * a.x + b.x, 0.f); v.y = fmaxf(v.y * a.y + b.y, 0.f);
+  v.z = fmaxf(v.z * a.z + b.z, 0.f); v.w = fmaxf(v.w * a.w + b.w, 0.f);
+  float4 k = reinterpret_cast<const float4 *>(skip)[i];
+  if (ss) {
+    const float4 e = *reinterpret_cast<const float4 *>(ss + c), f = *reinterpret_cast<const float4 *>(hs + c);
+    k.x = k.x * e.x + f.x; k.y = k.y * e.y + f.y; k.z = k.z * e.z + f.z; k.w = k.w * e.w + f.w;
+  }
+  v.x = fmaxf(v.x + k.x, 0.f); v.y = fmaxf(v.y + k.y, 0.f);
+  v.z = fmaxf(v.z + k.z, 0.f); v.w = fmaxf(v.w + k.w, 0.f);
+  reinterpret_cast<float4 *>(out)[i] = v;
+}
+
+// out = relu(x*s + h), NHWC, C multiple of 4
+__global__ void __launch_bounds__(256)
+    affine_relu_kernel(const float *__restrict__ x, const float *__restrict__ s,
+                       const float *__restrict__ h, float *__restrict__ out, long n4, int C) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const int c = (int)((i * 4) % C);
+  float4 v = reinterpret_cast<const float4 *>(x)[i];
+  const float4 a = *reinterpret_cast<const float4 *>(s + c), b = *reinterpret_cast<const float4 *>(h + c);
+  v.x = fmaxf(v.x * a.x + b.x, 0.f); v.y = fmaxf(v.y * a.y + b.y, 0.f);
+  v.z = fmaxf(v.z * a.z + b.z, 0.f); v.w = fmaxf(v.w * a.w + b.w, 0.f);
+  reinterpret_cast<float4 *>(out)[i] = v;
+}
+
+extern "C" {
+
+int ramp_affine_relu(const float *x, const float *s, const float *h, float *out, long n, int C,
+                     void *stream) {
+  if (!x || !s || !h || !out || n <= 0 || C % 4 || n % 4) return RAMP_EINVAL;
+  const long n4 = n / 4;
+  hipLaunchKernelGGL(affine_relu_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, x, s, h, out, n4, C);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+
+int ramp_any_nonzero(const float *a, long na, const float *b, long nb, int32_t *flags, void *stream) {
+  if (!flags) return RAMP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(flags, 0, 2 * sizeof(int32_t), st) != hipSuccess) return RAMP_ELAUNCH;
+  const long n = na > nb ? na : nb;
+  if (n <= 0) return RAMP_OK;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(any_nonzero_kernel, dim3(blocks), dim3(256), 0, st, a, na, b, nb, flags);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+
+int ramp_lstm_superstate(const float *ev, const float *im, float *h_ev, float *c_ev, float *h_im,
+                         float *c_im, float *ss, const float *wpacked, const int32_t *flags, int HW,
+                         int has_state, int has_ss, void *stream) {
+  if (HW <= 0 || !ev || !im || !h_ev || !c_ev || !h_im || !c_im || !ss || !wpacked || !flags)
+    return RAMP_EINVAL;
+  hipLaunchKernelGGL(lstm_superstate_kernel, dim3(ramp_cdiv(HW, 128)), dim3(128), 0,
+                     (hipStream_t)stream, ev, im, h_ev, c_ev, h_im, c_im, ss, wpacked, flags, HW,
+                     has_state, has_ss);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+
+int ramp_conv2d_nhwc(const void *x, const void *wpk, const float *bias, const float *pre_scale,
+                     const float *pre_shift, const void *res, void *y, float *stats, int H, int W,
+                     int Cin, int Cout, int KH, int KW, int stride, int relu, float out_scale,
+                     int dtype, void *stream) {
+  if (!x || !wpk || !y || H <= 0 || W <= 0) return RAMP_EINVAL;
+  if (Cin % 16 || Cout % 32 || KH != KW) return RAMP_EUNSUPPORTED;
+  if (dtype != RAMP_F32) return RAMP_EUNSUPPORTED;
+  ConvParams p;
+  p.x = x; p.wpk = wpk; p.bias = bias; p.pre_scale = pre_scale; p.pre_shift = pre_shift;
+  p.res = res; p.y = y; p.stats = stats;
+  p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+  const int pad = KH / 2;
+  p.OH = (H + 2 * pad - KH) / stride + 1;
+  p.OW = (W + 2 * pad - KW) / stride + 1;
+  p.relu = relu; p.out_scale = out_scale;
+  const int M = p.OH * p.OW;
+  dim3 grid(ramp_cdiv(M, 128), Cout / 32), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (KH == 7 && stride == 2) hipLaunchKernelGGL((conv_mfma_f32_kernel<7, 7, 2>), grid, block, 0, st, p);
+  else if (KH == 3 && stride == 1) hipLaunchKernelGGL((conv_mfma_f32_kernel<3, 3, 1>), grid, block, 0, st, p);
+  else if (KH == 3 && stride == 2) hipLaunchKernelGGL((conv_mfma_f32_kernel<3, 3, 2>), grid, block, 0, st, p);
+  else if (KH == 1 && stride == 1) hipLaunchKernelGGL((conv_mfma_f32_kernel<1, 1, 1>), grid, block, 0, st, p);
+  else if (KH == 1 && stride == 2) hipLaunchKernelGGL((conv_mfma_f32_kernel<1, 1, 2>), grid, block, 0, st, p);
+  else return RAMP_EUNSUPPORTED;
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+
+int ramp_in_stats_finalize(const float *partial, int nblk, int C, float count, float eps, float *scale,
+                           float *shift, void *stream) {
+  if (!partial || !scale || !shift || nblk <= 0 || C <= 0) return RAMP_EINVAL;
+  hipLaunchKernelGGL(in_stats_finalize_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, partial, nblk,
+                     C, count, eps, scale, shift);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+
+int ramp_norm_add_relu(const float *y, const float *sy, const float *hy, const float *skip,
+                       const float *ss, const float *hs, float *out, long n, int C, void *stream) {
+  if (!y || !sy || !hy || !skip || !out || n <= 0 || C % 4 || n % 4) return RAMP_EINVAL;
+  const long n4 = n / 4;
+  hipLaunchKernelGGL(norm_add_relu_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, y, sy, hy, skip, ss, hs, out, n4, C);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+
+}  // extern "C"
