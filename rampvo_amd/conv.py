@@ -27,7 +27,7 @@ def set_backend(name):
     _backend = name
 
 
-def _use_hip(x):
+def use_hip(x):
     if _backend == "torch" or not x.is_cuda:
         return False
     try:
@@ -50,10 +50,6 @@ def _is_identity(norm):
 
 def conv_norm_relu(x, conv, norm, relu, out_scale=1.0):
     """y = [relu]([instance_norm](conv(x) + b)) * out_scale, channels-last in and out"""
-    if _use_hip(x) and (_is_instance(norm) or _is_identity(norm)):
-        from . import conv_hip
-        return conv_hip.conv_norm_relu(x, conv, _is_instance(norm), norm.eps if _is_instance(norm) else 0.0,
-                                       relu, out_scale)
     x = x.contiguous(memory_format=torch.channels_last)
     y = F.conv2d(x.to(conv.weight.dtype), conv.weight, conv.bias, conv.stride, conv.padding)
     if _is_instance(norm):

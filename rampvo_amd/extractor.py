@@ -163,12 +163,30 @@ class MergerLSTMsceneEncoder(nn.Module):
         self.fmap_encoder = BasicEncoder4(output_dim=output_dim_f, norm_fn=norm_fn_fmap, channel_dim=output_lstm_dim)
         self.imap_encoder = BasicEncoder4(output_dim=output_dim_i, norm_fn=norm_fn_imap, channel_dim=output_lstm_dim)
         self.states_events, self.states_image, self.super_state = None, None, None
+        self._hip_state = None
+
+    def _forward_hip(self, events, images, reinit_hidden, out_scale):
+        """fused LSTM/super-state kernel + MFMA conv towers (csrc/conv.hip)"""
+        from . import conv_hip
+        H, W = events.shape[-2:]
+        st = self._hip_state
+        if st is None or st.HW != H * W or st.ss.device != events.device:
+            st = self._hip_state = conv_hip.LstmState(H * W, events.device)
+        if reinit_hidden:
+            st.fresh = True
+        s16 = conv_hip.lstm_superstate_step(self, events[0, 0].float().contiguous(),
+                                            images[0, 0].float().contiguous(), st)
+        f = conv_hip.basic_encoder4(self.fmap_encoder, s16, out_scale)        # [h,w,128]
+        i = conv_hip.basic_encoder4(self.imap_encoder, s16, out_scale)        # [h,w,384]
+        return f.permute(2, 0, 1)[None, None], i.permute(2, 0, 1)[None, None], None
 
     def forward(self, events, images, reinit_hidden=False, out_scale=1.0):
-        if reinit_hidden:
-            self.states_events, self.states_image, self.super_state = None, None, None
         B, T, Ce, H, W = events.shape
         assert B == 1 and images.shape[1] == T
+        if T == 1 and C.use_hip(events):
+            return self._forward_hip(events, images, reinit_hidden, out_scale)
+        if reinit_hidden:
+            self.states_events, self.states_image, self.super_state = None, None, None
         super_states = []
         for t in range(T):
             ev, im = events[0, t], images[0, t]
