@@ -76,6 +76,7 @@ def conv2d(x, conv, pre=None, res=None, relu=False, want_stats=False, out_scale=
     cout, _, kh, kw = conv.weight.shape
     stride = conv.stride[0]
     assert Cin == wpk.shape[1] * 16 and conv.padding[0] == kh // 2 and x.is_contiguous()
+    assert res is None or res.is_contiguous()
     OH = (H + 2 * (kh // 2) - kh) // stride + 1
     OW = (W + 2 * (kw // 2) - kw) // stride + 1
     y = torch.empty(OH, OW, cout, dtype=torch.float32, device=x.device)

@@ -42,7 +42,7 @@ def test_conv_mfma_matches_torch(cin, cout, k, stride, hw):
         xin = F.relu(x * sc + sh)
         if cin == 16:
             xin[..., 15] = 0
-        res = torch.randn_like(ref)
+        res = torch.randn(ref.shape, device="cuda")      # contiguous NHWC
         ref2 = F.relu(res + F.relu(_ref_conv(xin, conv))) * 0.25
         y2 = conv_hip.conv2d(x, conv, pre=(sc, sh), res=res, relu=True, out_scale=0.25)
         assert float((y2 - ref2).abs().max()) <= tol
