@@ -288,6 +288,147 @@ __global__ void __launch_bounds__(64)
   for (int q = lane; q < NOUT * L; q += 64) st_from_float(o + q, outs[q]);
 }
 
+
+// ---------------------------------------------------------------- fp16 / MFMA
+// Mixed-precision path (fp16 features, the reference's default MIXED_PRECISION): the 9 x T
+// dot-product matrix of an edge is a [16(9 used) x 128] x [128 x 16] product per group of 16
+// union pixels -> v_mfma_f32_16x16x32_f16, fp32 accumulation (the reference accumulates in
+// half).  A (patch features) lives in 16 VGPRs for the whole edge; B is one 16-byte
+// channels-last load per lane per MFMA; no LDS in the main loop.
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(64)
+    corr_mfma_f16_kernel(const CorrParams prm) {
+  constexpr int C = 128, PP = 9, R = 3, D = 8, d = 7;
+  constexpr int NOUT = d * d * PP;
+  __shared__ __attribute__((aligned(16))) float Cs[PP * CORR_T];
+  __shared__ float outs[NOUT * CORR_MAXLEV];
+  __shared__ int s_ox[PP], s_oy[PP], s_live[PP];
+  __shared__ float s_dx[PP], s_dy[PP];
+
+  const int e = blockIdx.x;
+  const int lane = threadIdx.x, q = lane >> 4, j = lane & 15;
+  const long i1 = prm.ii[e], j2 = prm.jj[e];
+  const int L = prm.nlevels;
+
+  f16x8_t afrag[4];
+  {
+    const _Float16 *src = reinterpret_cast<const _Float16 *>(prm.fmap1) + (size_t)i1 * C * PP;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      if (j < PP) afrag[s] = *reinterpret_cast<const f16x8_t *>(src + j * C + 32 * s + 8 * q);
+      else afrag[s] = (f16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  }
+
+  for (int lvl = 0; lvl < L; lvl++) {
+    const int H2 = prm.H2[lvl], W2 = prm.W2[lvl];
+    const _Float16 *f2 = reinterpret_cast<const _Float16 *>(prm.fmap2[lvl]) + (size_t)j2 * C * H2 * W2;
+    if (lane < PP) {
+      const float cdv = prm.cdiv[lvl];
+      const float x = prm.coords[((size_t)e * 2 + 0) * PP + lane] / cdv;
+      const float y = prm.coords[((size_t)e * 2 + 1) * PP + lane] / cdv;
+      const float flx = floorf(x), fly = floorf(y);
+      const int ox = ramp_f2i(flx), oy = ramp_f2i(fly);
+      s_dx[lane] = x - flx;
+      s_dy[lane] = y - fly;
+      const bool live = ((long)ox - R < W2) && ((long)ox - R + D > 0) &&
+                        ((long)oy - R < H2) && ((long)oy - R + D > 0);
+      s_live[lane] = live ? 1 : 0;
+      s_ox[lane] = live ? ox - R : 0;
+      s_oy[lane] = live ? oy - R : 0;
+    }
+    __syncthreads();
+    int minx = 1 << 30, miny = 1 << 30, maxx = -(1 << 30), maxy = -(1 << 30), nlive = 0;
+#pragma unroll
+    for (int p = 0; p < PP; p++) {
+      if (s_live[p]) {
+        nlive++;
+        minx = min(minx, s_ox[p]); maxx = max(maxx, s_ox[p]);
+        miny = min(miny, s_oy[p]); maxy = max(maxy, s_oy[p]);
+      }
+    }
+    const long bw = (long)maxx - minx + D, bh = (long)maxy - miny + D;
+    const bool uni = (nlive > 0) && (bw * bh <= CORR_T);
+    const int ngroups = (nlive == 0) ? 0 : (uni ? 1 : PP);
+    if (nlive == 0) {
+      for (int o = lane; o < NOUT; o += 64) {
+        const int p = o % PP;
+        const float dx = s_dx[p], dy = s_dy[p];
+        float s = ((1 - dx) * (1 - dy)) * 0.0f;
+        s = s + (dx * (1 - dy)) * 0.0f;
+        s = s + ((1 - dx) * dy) * 0.0f;
+        s = s + (dx * dy) * 0.0f;
+        outs[o * L + lvl] = s;
+      }
+    }
+    for (int g = 0; g < ngroups; g++) {
+      if (!uni && !s_live[g]) {
+        for (int ab = lane; ab < d * d; ab += 64) {
+          const float dx = s_dx[g], dy = s_dy[g];
+          float s = ((1 - dx) * (1 - dy)) * 0.0f;
+          s = s + (dx * (1 - dy)) * 0.0f;
+          s = s + ((1 - dx) * dy) * 0.0f;
+          s = s + (dx * dy) * 0.0f;
+          outs[(ab * PP + g) * L + lvl] = s;
+        }
+        continue;
+      }
+      const int gx0 = uni ? minx : s_ox[g], gy0 = uni ? miny : s_oy[g];
+      const int gw = uni ? (int)bw : D, gh = uni ? (int)bh : D;
+      const int Tn = gw * gh;
+      const int npg = (Tn + 15) / 16;
+      for (int pg = 0; pg < npg; pg++) {
+        const int t = pg * 16 + j;
+        const int ty = t / gw, tx = t - ty * gw;
+        const int px = gx0 + tx, py = gy0 + ty;
+        const bool inb = (t < Tn) && px >= 0 && px < W2 && py >= 0 && py < H2;
+        const _Float16 *pp = f2 + ((size_t)(inb ? py : 0) * W2 + (inb ? px : 0)) * C + 8 * q;
+        f16x8_t b[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+          b[s] = inb ? *reinterpret_cast<const f16x8_t *>(pp + 32 * s) : (f16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
+        f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag[s], b[s], acc, 0, 0, 0);
+        // D: rows 4q..4q+3 = patch pixels, column j = union pixel t
+        if (t < Tn) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int p = 4 * q + r;
+            if (p < PP) Cs[p * CORR_T + t] = acc[r];
+          }
+        }
+      }
+      __syncthreads();
+      const int nout = uni ? NOUT : d * d;
+      for (int o = lane; o < nout; o += 64) {
+        const int p = uni ? (o % PP) : g;
+        const int ab = uni ? (o / PP) : o;
+        const int b = ab / d, a = ab - b * d;
+        float c00 = 0, c01 = 0, c10 = 0, c11 = 0;
+        if (s_live[p]) {
+          const int wx = s_ox[p] - gx0 + b, wy = s_oy[p] - gy0 + a;
+          const float *row = &Cs[p * CORR_T + wy * gw + wx];
+          c00 = row[0]; c01 = row[1]; c10 = row[gw]; c11 = row[gw + 1];
+        }
+        const float dx = s_dx[p], dy = s_dy[p];
+        float s = ((1 - dx) * (1 - dy)) * c00;
+        s = s + (dx * (1 - dy)) * c01;
+        s = s + ((1 - dx) * dy) * c10;
+        s = s + (dx * dy) * c11;
+        outs[(ab * PP + p) * L + lvl] = s;
+      }
+      __syncthreads();
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  __half *o = reinterpret_cast<__half *>(prm.out) + (size_t)e * NOUT * L;
+  for (int k = lane; k < NOUT * L; k += 64) o[k] = __float2half(outs[k]);
+}
+
 extern "C" {
 
 int ramp_patchify_fwd(const void *net, const float *coords, void *out, int n, int C, int H,
@@ -346,7 +487,7 @@ int ramp_corr_fwd(const void *fmap1, const ramp_corr_level *levels, int nlevels,
   else if (dtype == RAMP_F32 && layout == RAMP_NCHW)
     hipLaunchKernelGGL((corr_kernel<float, RAMP_NCHW>), dim3(E), dim3(64), 0, st, prm);
   else if (dtype == RAMP_F16 && layout == RAMP_NHWC)
-    hipLaunchKernelGGL((corr_kernel<__half, RAMP_NHWC>), dim3(E), dim3(64), 0, st, prm);
+    hipLaunchKernelGGL(corr_mfma_f16_kernel, dim3(E), dim3(64), 0, st, prm);
   else if (dtype == RAMP_F16 && layout == RAMP_NCHW)
     hipLaunchKernelGGL((corr_kernel<__half, RAMP_NCHW>), dim3(E), dim3(64), 0, st, prm);
   else

@@ -128,6 +128,28 @@ def test_corr_reference_signature_and_half():
     assert np.abs(outh.float().cpu().numpy()[ok] - refh[ok]).max() <= 2e-2 * np.abs(refh[ok]).max()
 
 
+def test_corr_half_mfma_path_matches_oracle():
+    """fp16 channels-last features -> v_mfma_f32_16x16x32_f16 kernel (fp32 accumulation; the reference
+    accumulates in half, so the oracle on fp16-rounded inputs is the tighter target): only the final
+    rounding of the output to half separates the two"""
+    from rampvo_amd import ops
+    from rampvo_amd._lib import RAMP_NHWC
+    fmap1, fmap2, coords, ii, jj = corr_case(seed=8, E=64)
+    fmap2b = np.ascontiguousarray(fmap2[:, :, :, ::2, ::2])
+    h = lambda a: a.astype(np.float16).astype(np.float32)
+    ref0 = orc.corr(h(fmap1), h(fmap2), coords / 1, ii, jj, 3)[0]
+    ref1 = orc.corr(h(fmap1), h(fmap2b), coords / 4, ii, jj, 3)[0]
+    out = ops.corr(cu(fmap1[0].transpose(0, 2, 3, 1)).half(),
+                   [cu(fmap2[0].transpose(0, 2, 3, 1)).half(), cu(fmap2b[0].transpose(0, 2, 3, 1)).half()],
+                   cu(coords[0]), cu(ii), cu(jj), 3, (1.0, 4.0), RAMP_NHWC)
+    assert out.dtype == torch.float16
+    out = out.float().cpu().numpy()
+    for lvl, ref in ((0, ref0), (1, ref1)):
+        ok = np.isfinite(ref)
+        assert np.array_equal(np.isnan(out[..., lvl]), np.isnan(ref))
+        assert np.abs(out[..., lvl][ok] - ref[ok]).max() <= 1.5e-3 * np.abs(ref[ok]).max()
+
+
 # ---------------------------------------------------------------- projective ops
 def test_transform_reproject_point_cloud():
     from rampvo_amd import ops
