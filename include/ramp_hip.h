@@ -209,6 +209,36 @@ int ramp_affine_relu(const float *x, const float *s, const float *h, float *out,
 int ramp_norm_add_relu(const float *y, const float *sy, const float *hy, const float *skip,
                        const float *ss, const float *hs, float *out, long n, int C, void *stream);
 
+/* ---------------------------------------------------------- update operator */
+/* Row-fused glue of the update operator (ramp/net.py:69-90, ramp/blocks.py:15-50); rows are
+ * [E][384].  `dtype` is the GEMM I/O dtype T (RAMP_F16 under MIXED_PRECISION); the hidden state
+ * is fp32 as under the reference's autocast.
+ *
+ * ramp_upd_row_fuse: t = A[e] + B[rowB(e)] + C[rowC(e)]; optional LayerNorm(ln_w, ln_b, eps)
+ *   (nn.LayerNorm(384, eps=1e-3), net.py:45,49-52,60) and ReLU; written as fp32 (out_f32) and/or
+ *   T (out_t).  rowB(e) = idxB[e] (int64) or idxB32[e] or e, taken modulo modB when modB > 0
+ *   (the `kk % (M*mem)` ring-buffer gather of Ramp_vo.py:282); rowC likewise.  A fp32, B/C of T. */
+int ramp_upd_row_fuse(const float *A, const void *B, const void *C, const int64_t *idxB,
+                      const int32_t *idxB32, long modB, const int64_t *idxC, const int32_t *idxC32,
+                      const float *ln_w, const float *ln_b, float eps, int relu, float *out_f32,
+                      void *out_t, int E, int dtype, void *stream);
+/* out[e] = idx[e] >= 0 ? X[idx[e]] : 0  -- `mask_ix * net[:, ix]` of net.py:78-82 (X fp32, out T) */
+int ramp_upd_gather_mask(const float *X, const int64_t *idx, void *out, int E, int dtype, void *stream);
+/* GatedResidual tail (blocks.py:30-31): t = X + sigmoid(G) * R, optional LayerNorm; written as
+ * fp32, T and ReLU(T) (each optional) */
+int ramp_upd_gated(const float *X, const void *G, const void *R, const float *ln_w, const float *ln_b,
+                   float eps, float *out_f32, void *out_t, void *out_relu_t, int E, int dtype,
+                   void *stream);
+/* heads + Ramp_vo.update's target / filter_features (net.py:64-67, Ramp_vo.py:288-294,
+ * utils.py:557-570): hw [E][4] = (delta_x, delta_y, w_x, w_y) pre-sigmoid, coords [E][2][P][P];
+ * target = centre + delta, weight = sigmoid(w) zeroed outside [0,wd]x[0,ht]; delta optional    */
+int ramp_upd_heads(const void *hw, const float *coords, float *target, float *weight, float *delta,
+                   int E, int P, float wd, float ht, int dtype, void *stream);
+/* SoftAgg core over the stacked [f | g] GEMM output fg [E][768] (single-pass online softmax):
+ * y[g] = sum_{e in g} softmax_e(g[e]) * f[e]  (blocks.py:44-45)                                */
+int ramp_upd_segment_softmax(const void *fg, const int32_t *order, const int32_t *seg_start,
+                             const int32_t *ngroups, void *y, int max_groups, int dtype, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -75,7 +75,7 @@ class Ramp_vo:
         self.fmap2_ = torch.zeros(self.mem, h // 4, w // 4, 128, **kwargs)
         self.pyramid = (self.fmap1_, self.fmap2_)
 
-        self.net = torch.zeros(1, 0, DIM, **kwargs)
+        self.net = torch.zeros(1, 0, DIM, dtype=torch.float, device=dev)   # hidden state is fp32 (as under autocast)
         self.ii = torch.zeros(0, dtype=torch.long, device=dev)
         self.jj = torch.zeros(0, dtype=torch.long, device=dev)
         self.kk = torch.zeros(0, dtype=torch.long, device=dev)
@@ -221,7 +221,7 @@ class Ramp_vo:
         self.jj = torch.cat([self.jj, self._upload(jj)])
         self.kk = torch.cat([self.kk, self._upload(ii)])
         self.ii = torch.cat([self.ii, self._upload(src)])
-        net = torch.zeros(1, len(ii), self.DIM, **self.kwargs)
+        net = torch.zeros(1, len(ii), self.DIM, dtype=torch.float, device=self.device)
         self.net = torch.cat([self.net, net], dim=1)
         self._plan = None
 
@@ -265,11 +265,17 @@ class Ramp_vo:
         kk = torch.arange(self.m - self.M, self.m, device=self.device)
         jj = self.n * torch.ones_like(kk)
         ii = kk // self.M
-        net = torch.zeros(1, len(ii), self.DIM, **self.kwargs)
         coords = self.reproject(indicies=(ii, jj, kk))
         corr = self.corr(coords, indicies=(kk, jj)).to(self.dtype)
-        ctx = self.imap[:, kk % (self.M * self.mem)]
-        with torch.autocast("cuda", dtype=torch.half, enabled=self.cfg.MIXED_PRECISION):
+        if self.device.type == "cuda":
+            fu = self.network.update.fused(self.dtype)
+            from .net import GraphPlan
+            plan = GraphPlan.build(ii, jj, kk, kk_bound=self.N * self.M, jj_bound=self.N, max_kk=self.M, max_ij=1)
+            _, relu_t = fu.hidden(None, self.imap_.view(-1, self.DIM), kk, self.M * self.mem, corr[0], plan)
+            delta = fu.heads(relu_t)[None, :, :2]
+        else:
+            net = torch.zeros(1, len(ii), self.DIM, dtype=torch.float, device=self.device)
+            ctx = self.imap[:, kk % (self.M * self.mem)]
             net, (delta, weight, _) = self.network.update(net, ctx, corr, None, ii, jj, kk)
         return torch.quantile(delta.norm(dim=-1).float(), 0.5)
 
@@ -322,14 +328,22 @@ class Ramp_vo:
         with Timer("other", enabled=self.enable_timing):
             coords = self.reproject()
             corr = self.corr(coords).to(self.dtype)
-            ctx = self.imap[:, self.kk % (self.M * self.mem)]
             plan = self._graph_plan()
-            with torch.autocast("cuda", dtype=torch.half, enabled=self.cfg.MIXED_PRECISION):
+            if self.device.type == "cuda":
+                # GEMMs + row-fused glue (csrc/update.hip); the context gather, the heads' activations,
+                # `target = centre + delta` and filter_features are folded into those kernels
+                fu = self.network.update.fused(self.dtype)
+                out32, relu_t = fu.hidden(self.net[0], self.imap_.view(-1, self.DIM), self.kk, self.M * self.mem,
+                                          corr[0], plan)
+                self.net = out32[None]
+                target, weight, _ = fu.target_weight(fu.heads(relu_t), coords[0], self.wd // 4, self.ht // 4)
+            else:
+                ctx = self.imap[:, self.kk % (self.M * self.mem)]
                 self.net, (delta, weight, _) = self.network.update(self.net, ctx, corr, None, self.ii, self.jj,
                                                                    self.kk, plan=plan)
-            weight = weight.float()
-            target = coords[..., self.P // 2, self.P // 2] + delta.float()
-            weight = filter_features(confidences=weight, target=target, data_shape=(self.ht // 4, self.wd // 4))
+                weight = weight.float()
+                target = coords[..., self.P // 2, self.P // 2] + delta.float()
+                weight = filter_features(confidences=weight, target=target, data_shape=(self.ht // 4, self.wd // 4))
             self.last_weight = weight
         with Timer("BA", enabled=self.enable_timing):
             t0 = self.n - self.cfg.OPTIMIZATION_WINDOW if self.is_initialized else 1

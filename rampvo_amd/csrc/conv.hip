@@ -26,13 +26,33 @@
 __global__ void __launch_bounds__(256)
     any_nonzero_kernel(const float *__restrict__ a, long na, const float *__restrict__ b, long nb,
                        int *__restrict__ flags) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long stride = (long)gridDim.x * blockDim.x;
+  __shared__ int s_any[2];
+  if (threadIdx.x < 2) s_any[threadIdx.x] = 0;
+  __syncthreads();
+  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const long stride = (long)gridDim.x * blockDim.x * 4;
   bool fa = false, fb = false;
-  for (long k = i; k < na; k += stride) fa |= (a[k] != 0.0f);
-  for (long k = i; k < nb; k += stride) fb |= (b[k] != 0.0f);
-  if (__any(fa) && (threadIdx.x & 63) == 0) atomicOr(&flags[0], 1);
-  if (__any(fb) && (threadIdx.x & 63) == 0) atomicOr(&flags[1], 1);
+  for (long k = i; k < na; k += stride) {
+    if (k + 3 < na) {
+      const float4 v = *reinterpret_cast<const float4 *>(a + k);
+      fa |= (v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f);
+    } else {
+      for (long t = k; t < na; t++) fa |= (a[t] != 0.0f);
+    }
+  }
+  for (long k = i; k < nb; k += stride) {
+    if (k + 3 < nb) {
+      const float4 v = *reinterpret_cast<const float4 *>(b + k);
+      fb |= (v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f);
+    } else {
+      for (long t = k; t < nb; t++) fb |= (b[t] != 0.0f);
+    }
+  }
+  // one (benign, idempotent) plain store per workgroup instead of an atomic per wavefront
+  if (__any(fa) && (threadIdx.x & 63) == 0) s_any[0] = 1;
+  if (__any(fb) && (threadIdx.x & 63) == 0) s_any[1] = 1;
+  __syncthreads();
+  if (threadIdx.x < 2 && s_any[threadIdx.x]) flags[threadIdx.x] = 1;
 }
 
 // ------------------------------------------------------- LSTM + super-state
@@ -356,8 +376,9 @@ int ramp_any_nonzero(const float *a, long na, const float *b, long nb, int32_t *
   if (hipMemsetAsync(flags, 0, 2 * sizeof(int32_t), st) != hipSuccess) return RAMP_ELAUNCH;
   const long n = na > nb ? na : nb;
   if (n <= 0) return RAMP_OK;
-  int blocks = (int)((n + 255) / 256);
+  int blocks = (int)((n / 4 + 255) / 256);
   if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(any_nonzero_kernel, dim3(blocks), dim3(256), 0, st, a, na, b, nb, flags);
   RAMP_CHECK_LAUNCH();
   return RAMP_OK;

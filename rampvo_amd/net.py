@@ -29,13 +29,14 @@ class GraphPlan:
     """Per-graph index structures shared by the Update operator and BA: temporal
     neighbours and the two SoftAgg groupings.  Built on the device in one go
     (``build``); ``Ramp_vo`` rebuilds it only when the factor graph changes."""
-    __slots__ = ("ix", "jx", "mask_ix", "mask_jx", "g_kk", "g_ij", "max_kk", "max_ij", "E")
+    __slots__ = ("ix", "jx", "ix_raw", "jx_raw", "mask_ix", "mask_jx", "g_kk", "g_ij", "max_kk", "max_ij", "E")
 
     @staticmethod
     def build(ii, jj, kk, kk_bound=0, jj_bound=0, max_kk=None, max_ij=None):
         p = GraphPlan()
         p.E = ii.shape[0]
         p.ix, p.jx = ops.neighbors(kk, jj, kk_bound, jj_bound)
+        p.ix_raw, p.jx_raw = p.ix, p.jx
         p.mask_ix = (p.ix >= 0).reshape(1, -1, 1)
         p.mask_jx = (p.jx >= 0).reshape(1, -1, 1)
         p.ix = p.ix.clamp(min=0)
@@ -65,9 +66,25 @@ class Update(nn.Module):
         self.d = nn.Sequential(nn.ReLU(inplace=False), nn.Linear(DIM, 2), GradientClip())
         self.w = nn.Sequential(nn.ReLU(inplace=False), nn.Linear(DIM, 2), GradientClip(), nn.Sigmoid())
 
+    def fused(self, dtype):
+        """row-fused HIP implementation (csrc/update.hip), one instance per GEMM dtype"""
+        from .update_fused import FusedUpdate
+        if not hasattr(self, "_fused_impl"):
+            object.__setattr__(self, "_fused_impl", {})
+        if dtype not in self._fused_impl:
+            self._fused_impl[dtype] = FusedUpdate(self, dtype)
+        return self._fused_impl[dtype]
+
     def forward(self, net, inp, corr, flow, ii, jj, kk, plan=None):
         if plan is None:
             plan = GraphPlan.build(ii, jj, kk)
+        if corr.is_cuda:
+            # GPU: GEMMs + row-fused glue kernels; dtype = the caller's feature dtype
+            fu = self.fused(corr.dtype)
+            out32, relu_t = fu.hidden(net[0].float().contiguous(), inp[0].to(corr.dtype).contiguous(), None, 0,
+                                      corr[0].contiguous(), plan)
+            hw = fu.heads(relu_t)
+            return out32[None], (hw[None, :, :2], torch.sigmoid(hw[None, :, 2:]), None)
         net = net + inp + self.corr(corr)
         net = self.norm(net)
         net = net + self.c1(plan.mask_ix.to(net.dtype) * net[:, plan.ix])

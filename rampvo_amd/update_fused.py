@@ -1,0 +1,151 @@
+"""Fused forward of the update operator (reference: ramp/net.py:69-90).
+
+~19 GEMMs (hipBLASLt through torch, bias / bias+ReLU epilogues) stitched by the row-fused HIP
+kernels of csrc/update.hip: every gather, residual add, LayerNorm, gate and dtype cast between
+two GEMMs is ONE kernel.  The hidden state stays fp32; GEMM inputs/outputs are ``dtype`` (half
+under MIXED_PRECISION -- what the reference's autocast does -- or float).  Weight copies in
+``dtype`` (f|g and the two heads stacked) are cached per module.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from ._lib import check, lib, ptr, stream
+
+_code = {torch.float32: _lib.RAMP_F32, torch.float16: _lib.RAMP_F16}
+
+
+class FusedUpdate:
+    def __init__(self, update, dtype):
+        self.m = update
+        self.dtype = dtype
+        self._w = None
+        self._key = None
+        self._act_ok = True
+
+    # ------------------------------------------------------------------ weights
+    def weights(self):
+        key = tuple((p.data_ptr(), p._version) for p in self.m.parameters())
+        if self._w is not None and key == self._key:
+            return self._w
+        m, T = self.m, self.dtype
+        c = lambda t: t.detach().to(T).contiguous()
+        f = lambda t: t.detach().float().contiguous()
+        w = dict(
+            corr0=(c(m.corr[0].weight), c(m.corr[0].bias)), corr2=(c(m.corr[2].weight), c(m.corr[2].bias)),
+            corr_ln=(f(m.corr[3].weight), f(m.corr[3].bias), m.corr[3].eps),
+            corr5=(c(m.corr[5].weight), c(m.corr[5].bias)),
+            norm=(f(m.norm.weight), f(m.norm.bias), m.norm.eps),
+            c1a=(c(m.c1[0].weight), c(m.c1[0].bias)), c1b=(c(m.c1[2].weight), c(m.c1[2].bias)),
+            c2a=(c(m.c2[0].weight), c(m.c2[0].bias)), c2b=(c(m.c2[2].weight), c(m.c2[2].bias)),
+            kk_fg=(c(torch.cat([m.agg_kk.f.weight, m.agg_kk.g.weight], 0)),
+                   c(torch.cat([m.agg_kk.f.bias, m.agg_kk.g.bias], 0))),
+            kk_h=(c(m.agg_kk.h.weight), c(m.agg_kk.h.bias)),
+            ij_fg=(c(torch.cat([m.agg_ij.f.weight, m.agg_ij.g.weight], 0)),
+                   c(torch.cat([m.agg_ij.f.bias, m.agg_ij.g.bias], 0))),
+            ij_h=(c(m.agg_ij.h.weight), c(m.agg_ij.h.bias)),
+            ln1=(f(m.gru[0].weight), f(m.gru[0].bias), m.gru[0].eps),
+            g1_gate=(c(m.gru[1].gate[0].weight), c(m.gru[1].gate[0].bias)),
+            g1_r1=(c(m.gru[1].res[0].weight), c(m.gru[1].res[0].bias)),
+            g1_r2=(c(m.gru[1].res[2].weight), c(m.gru[1].res[2].bias)),
+            ln2=(f(m.gru[2].weight), f(m.gru[2].bias), m.gru[2].eps),
+            g2_gate=(c(m.gru[3].gate[0].weight), c(m.gru[3].gate[0].bias)),
+            g2_r1=(c(m.gru[3].res[0].weight), c(m.gru[3].res[0].bias)),
+            g2_r2=(c(m.gru[3].res[2].weight), c(m.gru[3].res[2].bias)),
+            heads=(c(torch.cat([m.d[1].weight, m.w[1].weight], 0)), c(torch.cat([m.d[1].bias, m.w[1].bias], 0))),
+        )
+        self._w, self._key = w, key
+        return w
+
+    # --------------------------------------------------------------- primitives
+    def lin(self, x, wb):
+        return F.linear(x, wb[0], wb[1])
+
+    def lin_relu(self, x, wb):
+        if self._act_ok:
+            try:
+                return torch._addmm_activation(wb[1], x, wb[0].t(), use_gelu=False)
+            except Exception:
+                self._act_ok = False
+        return F.relu_(F.linear(x, wb[0], wb[1]))
+
+    def row_fuse(self, E, A=None, B=None, C=None, idxB=None, idxB32=None, modB=0, idxC32=None, ln=None, relu=False,
+                 want_f32=False, want_t=False, out_f32=None):
+        dev = (A if A is not None else B).device
+        if want_f32 and out_f32 is None:
+            out_f32 = torch.empty(E, 384, dtype=torch.float32, device=dev)
+        out_t = torch.empty(E, 384, dtype=self.dtype, device=dev) if want_t else None
+        check(lib().ramp_upd_row_fuse(ptr(A), ptr(B), ptr(C), ptr(idxB), ptr(idxB32), int(modB), None, ptr(idxC32),
+                                      ptr(ln[0]) if ln else None, ptr(ln[1]) if ln else None,
+                                      float(ln[2]) if ln else 0.0, int(relu), ptr(out_f32), ptr(out_t), E,
+                                      _code[self.dtype], stream()), "ramp_upd_row_fuse")
+        return out_f32, out_t
+
+    def gather_mask(self, X, idx, E):
+        out = torch.empty(E, 384, dtype=self.dtype, device=X.device)
+        check(lib().ramp_upd_gather_mask(ptr(X), ptr(idx), ptr(out), E, _code[self.dtype], stream()),
+              "ramp_upd_gather_mask")
+        return out
+
+    def gated(self, X, G, R, E, ln=None, want_f32=True, want_t=False, want_relu=False):
+        dev = X.device
+        o32 = torch.empty(E, 384, dtype=torch.float32, device=dev) if want_f32 else None
+        ot = torch.empty(E, 384, dtype=self.dtype, device=dev) if want_t else None
+        orl = torch.empty(E, 384, dtype=self.dtype, device=dev) if want_relu else None
+        check(lib().ramp_upd_gated(ptr(X), ptr(G), ptr(R), ptr(ln[0]) if ln else None, ptr(ln[1]) if ln else None,
+                                   float(ln[2]) if ln else 0.0, ptr(o32), ptr(ot), ptr(orl), E, _code[self.dtype],
+                                   stream()), "ramp_upd_gated")
+        return o32, ot, orl
+
+    def seg(self, fg, groups, max_groups):
+        y = torch.zeros(max(max_groups, 1), 384, dtype=self.dtype, device=fg.device)
+        check(lib().ramp_upd_segment_softmax(ptr(fg), ptr(groups.order), ptr(groups.seg_start), ptr(groups.ngroups),
+                                             ptr(y), int(max_groups), _code[self.dtype], stream()),
+              "ramp_upd_segment_softmax")
+        return y
+
+    # ------------------------------------------------------------------ forward
+    def hidden(self, net, inp_table, inp_idx, inp_mod, corr, plan):
+        """net [E,384] fp32 or None (zeros); inp = inp_table[inp_idx % inp_mod] (or inp_table rows when
+        inp_idx is None); corr [E,882] in self.dtype.  Returns (net_out fp32 [E,384], relu copy T)."""
+        w = self.weights()
+        E = corr.shape[0]
+        c = self.lin_relu(corr, w["corr0"])
+        c = self.lin(c, w["corr2"])
+        _, c = self.row_fuse(E, B=c, ln=w["corr_ln"], relu=True, want_t=True)
+        c = self.lin(c, w["corr5"])
+        net32, _ = self.row_fuse(E, A=net, B=inp_table, idxB=inp_idx, modB=inp_mod, C=c, ln=w["norm"], want_f32=True)
+        # temporal neighbours (net.py:77-82); plan.ix_raw / jx_raw keep the -1 markers
+        g = self.gather_mask(net32, plan.ix_raw, E)
+        y = self.lin(self.lin_relu(g, w["c1a"]), w["c1b"])
+        self.row_fuse(E, A=net32, B=y, out_f32=net32)
+        g = self.gather_mask(net32, plan.jx_raw, E)
+        y = self.lin(self.lin_relu(g, w["c2a"]), w["c2b"])
+        _, net_t = self.row_fuse(E, A=net32, B=y, out_f32=net32, want_t=True)
+        # SoftAgg over patches, then over (i, j) pairs (net.py:84-85)
+        hy = self.lin(self.seg(self.lin(net_t, w["kk_fg"]), plan.g_kk, plan.max_kk), w["kk_h"])
+        _, net_t = self.row_fuse(E, A=net32, B=hy, idxB32=plan.g_kk.gid, out_f32=net32, want_t=True)
+        hy = self.lin(self.seg(self.lin(net_t, w["ij_fg"]), plan.g_ij, plan.max_ij), w["ij_h"])
+        x32, x_t = self.row_fuse(E, A=net32, B=hy, idxB32=plan.g_ij.gid, ln=w["ln1"], out_f32=net32, want_t=True)
+        # gru = LN, GatedResidual, LN, GatedResidual (net.py:49-54)
+        gate = self.lin(x_t, w["g1_gate"])
+        r = self.lin(self.lin_relu(x_t, w["g1_r1"]), w["g1_r2"])
+        x32, x_t, _ = self.gated(x32, gate, r, E, ln=w["ln2"], want_t=True)
+        gate = self.lin(x_t, w["g2_gate"])
+        r = self.lin(self.lin_relu(x_t, w["g2_r1"]), w["g2_r2"])
+        out32, _, relu_t = self.gated(x32, gate, r, E, want_relu=True)
+        return out32, relu_t
+
+    def heads(self, relu_t):
+        return self.lin(relu_t, self.weights()["heads"])          # [E,4]
+
+    def target_weight(self, hw, coords, wd, ht, want_delta=False):
+        E = hw.shape[0]
+        P = coords.shape[-1]
+        dev = hw.device
+        target = torch.empty(1, E, 2, dtype=torch.float32, device=dev)
+        weight = torch.empty(1, E, 2, dtype=torch.float32, device=dev)
+        delta = torch.empty(1, E, 2, dtype=torch.float32, device=dev) if want_delta else None
+        check(lib().ramp_upd_heads(ptr(hw), ptr(coords), ptr(target), ptr(weight), ptr(delta), E, P, float(wd),
+                                   float(ht), _code[self.dtype], stream()), "ramp_upd_heads")
+        return target, weight, delta
