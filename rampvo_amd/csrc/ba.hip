@@ -252,38 +252,65 @@ __global__ void __launch_bounds__(256)
 }
 
 // ------------------------------------------------------------------ K5
+// One workgroup per free pose a (block row of S).  The pair records that touch pose a are first
+// compacted IN ORDER into LDS (ballot prefix), then every thread sums its entries of the 6 x 6N
+// row block over that short list -- fixed order, no atomics.
+#define BA_MAXLIST 1024
 __global__ void __launch_bounds__(256)
     ba_assemble_kernel(const float *__restrict__ pairs, const int32_t *__restrict__ pair_ij,
                        const int32_t *__restrict__ npairs, const float *__restrict__ S_part,
                        const float *__restrict__ y_part, float *__restrict__ S,
                        float *__restrict__ yv, int n6, int KS) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= n6 * n6) return;
-  const int r = idx / n6, c = idx - r * n6;
-  const int a = r / 6, x = r - a * 6, b = c / 6, y = c - b * 6;
+  __shared__ int s_list[BA_MAXLIST];
+  __shared__ int s_wcnt[4];
+  __shared__ int s_base;
+  const int a = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int np = *npairs;
-  float bsum = 0.0f, vsum = 0.0f;
-  for (int g = 0; g < np; g++) {
-    const int i = pair_ij[2 * g], j = pair_ij[2 * g + 1];
-    const float *pr = pairs + (size_t)g * BA_PAIR;
-    if (i == a && i == b) bsum += pr[x * 6 + y];
-    if (j == a && j == b) bsum += pr[36 + x * 6 + y];
-    if (i == a && j == b) bsum += pr[72 + x * 6 + y];
-    if (j == a && i == b) bsum += pr[108 + x * 6 + y];
-    if (c == 0) {
-      if (i == a) vsum += pr[144 + x];
-      if (j == a) vsum += pr[150 + x];
-    }
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int g0 = 0; g0 < np; g0 += 256) {
+    const int g = g0 + tid;
+    const bool hit = g < np && (pair_ij[2 * g] == a || pair_ij[2 * g + 1] == a);
+    const unsigned long long m = __ballot(hit);
+    if (lane == 0) s_wcnt[wave] = __popcll(m);
+    __syncthreads();
+    int off = s_base;
+    for (int w = 0; w < wave; w++) off += s_wcnt[w];
+    off += __popcll(m & ((1ull << lane) - 1ull));
+    if (hit && off < BA_MAXLIST) s_list[off] = g;
+    __syncthreads();
+    if (tid == 0) s_base += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+    __syncthreads();
   }
-  float sp = 0.0f;
-  for (int z = 0; z < KS; z++) sp += S_part[((size_t)z * n6 + r) * n6 + c];
-  float s = bsum - sp;
-  if (r == c) s += (1e-4f * s + 1.0f);
-  S[(size_t)r * n6 + c] = s;
-  if (c == 0) {
-    float yp = 0.0f;
-    for (int z = 0; z < KS; z++) yp += y_part[(size_t)z * n6 + r];
-    yv[r] = vsum - yp;
+  const int nl = min(s_base, BA_MAXLIST);
+  for (int q = tid; q < 6 * n6; q += 256) {
+    const int x = q / n6, c = q - x * n6;
+    const int b = c / 6, y = c - b * 6;
+    const int r = 6 * a + x;
+    float bsum = 0.0f, vsum = 0.0f;
+    for (int l = 0; l < nl; l++) {
+      const int g = s_list[l];
+      const int i = pair_ij[2 * g], j = pair_ij[2 * g + 1];
+      const float *pr = pairs + (size_t)g * BA_PAIR;
+      if (i == a && i == b) bsum += pr[x * 6 + y];
+      if (j == a && j == b) bsum += pr[36 + x * 6 + y];
+      if (i == a && j == b) bsum += pr[72 + x * 6 + y];
+      if (j == a && i == b) bsum += pr[108 + x * 6 + y];
+      if (c == 0) {
+        if (i == a) vsum += pr[144 + x];
+        if (j == a) vsum += pr[150 + x];
+      }
+    }
+    float sp = 0.0f;
+    for (int z = 0; z < KS; z++) sp += S_part[((size_t)z * n6 + r) * n6 + c];
+    float s = bsum - sp;
+    if (r == c) s += (1e-4f * s + 1.0f);
+    S[(size_t)r * n6 + c] = s;
+    if (c == 0) {
+      float yp = 0.0f;
+      for (int z = 0; z < KS; z++) yp += y_part[(size_t)z * n6 + r];
+      yv[r] = vsum - yp;
+    }
   }
 }
 
@@ -343,6 +370,51 @@ __global__ void __launch_bounds__(1024)
     __syncthreads();
   }
   for (int q = tid; q < n6; q += nt) dX[q] = t[q];
+}
+
+// single-wavefront variant for 6N <= 64 (default.yaml: 60): lane i owns row i, no multi-wave
+// barriers; the per-element operation order is the same as in ba_chol_kernel.
+__global__ void __launch_bounds__(64)
+    ba_chol64_kernel(const float *__restrict__ S, const float *__restrict__ yv,
+                     float *__restrict__ dX, int32_t *__restrict__ info, int n6) {
+  __shared__ float A[64 * 65];
+  __shared__ float t[64];
+  const int i = threadIdx.x;
+  const int ld = 65;
+  if (i < n6) {
+    for (int c = 0; c < n6; c++) A[i * ld + c] = S[(size_t)i * n6 + c];
+    t[i] = yv[i];
+  }
+  __syncthreads();
+  for (int j = 0; j < n6; j++) {
+    if (i == j) {
+      const float dgn = A[j * ld + j];
+      if (!(dgn > 0.0f) && info) *info = 1;
+      A[j * ld + j] = sqrtf(dgn);
+    }
+    __syncthreads();
+    const float ljj = A[j * ld + j];
+    if (i > j && i < n6) A[i * ld + j] = A[i * ld + j] / ljj;
+    __syncthreads();
+    if (i > j && i < n6) {
+      const float lij = A[i * ld + j];
+      for (int k = j + 1; k <= i; k++) A[i * ld + k] = A[i * ld + k] - lij * A[k * ld + j];
+    }
+    __syncthreads();
+  }
+  for (int k = 0; k < n6; k++) {
+    if (i == k) t[k] = t[k] / A[k * ld + k];
+    __syncthreads();
+    if (i > k && i < n6) t[i] = t[i] - A[i * ld + k] * t[k];
+    __syncthreads();
+  }
+  for (int k = n6 - 1; k >= 0; k--) {
+    if (i == k) t[k] = t[k] / A[k * ld + k];
+    __syncthreads();
+    if (i < k) t[i] = t[i] - A[k * ld + i] * t[k];
+    __syncthreads();
+  }
+  if (i < n6) dX[i] = t[i];
 }
 
 // ------------------------------------------------------------------ K7
@@ -497,10 +569,12 @@ int ramp_ba_forward(float *poses, float *patches, const float *intrinsics, const
                          np, w.pairs, w.pair_ij);
       hipLaunchKernelGGL(ba_schur_kernel, dim3(w.tiles, w.tiles, w.KS), dim3(256), 0, st, w.Erow,
                          w.Qv, w.uv, nk, w.S_part, w.y_part, n6, w.KS);
-      hipLaunchKernelGGL(ba_assemble_kernel, dim3(ramp_cdiv(n6 * n6, 256)), dim3(256), 0, st,
-                         w.pairs, w.pair_ij, np, w.S_part, w.y_part, w.S, w.yv, n6, w.KS);
-      hipLaunchKernelGGL(ba_chol_kernel, dim3(1), dim3(n6 <= 64 ? 256 : 1024), lds, st, w.S, w.yv,
-                         w.dX, info, n6);
+      hipLaunchKernelGGL(ba_assemble_kernel, dim3(N), dim3(256), 0, st, w.pairs, w.pair_ij, np,
+                         w.S_part, w.y_part, w.S, w.yv, n6, w.KS);
+      if (n6 <= 64)
+        hipLaunchKernelGGL(ba_chol64_kernel, dim3(1), dim3(64), 0, st, w.S, w.yv, w.dX, info, n6);
+      else
+        hipLaunchKernelGGL(ba_chol_kernel, dim3(1), dim3(1024), lds, st, w.S, w.yv, w.dX, info, n6);
     }
     hipLaunchKernelGGL(ba_retract_kernel, dim3(depth_blocks + pose_blocks), dim3(256), 0, st,
                        poses, patches, w.Erow, w.Qv, w.uv, w.dX, w.kx, nk, n6, PP, t0, N,
