@@ -166,6 +166,37 @@ int ramp_ba_forward(float *poses, float *patches, const float *intrinsics, const
                     int n_patches, int t0, int t1, int iterations, void *ws, size_t ws_bytes,
                     int32_t *info, void *stream);
 
+/* ramp_ba_forward with the two edge groupings supplied by the caller (the tracker builds them once
+ * per graph change and shares them with the update operator's SoftAgg): by patch kk
+ * (order_k / seg_k / ngroups_k / ukeys_k = sorted unique kk) and by pose pair (ii, jj) in
+ * lexicographic order (order_p / seg_p / ngroups_p), as produced by ramp_group_by[_small].
+ * max_patches / max_pairs: upper bounds of the group counts (grid sizes, workspace).          */
+size_t ramp_ba_planned_workspace_bytes(int E, int n_poses, int n_patches, int t0, int t1,
+                                       int max_patches, int max_pairs);
+int ramp_ba_forward_planned(float *poses, float *patches, const float *intrinsics, const float *target,
+                            const float *weight, const float *lmbda, const int64_t *ii,
+                            const int64_t *jj, const int64_t *kk, int E, int P, int n_poses,
+                            int n_patches, int t0, int t1, int iterations, const int32_t *order_k,
+                            const int32_t *seg_k, const int32_t *ngroups_k, const int64_t *ukeys_k,
+                            int max_patches, const int32_t *order_p, const int32_t *seg_p,
+                            const int32_t *ngroups_p, int max_pairs, void *ws, size_t ws_bytes,
+                            int32_t *info, void *stream);
+
+/* group-by for a SMALL key range known to the caller: key = a[e]*mul + (b ? b[e] : 0) - sub must lie
+ * in [0, K).  Histogram + one-workgroup scan + scatter + per-segment rank sort (5 short kernels vs a
+ * radix sort); same outputs and the same (stable) ordering as ramp_group_by.  ukeys = key + sub.  */
+size_t ramp_group_by_small_workspace_bytes(int E, int K);
+int ramp_group_by_small(const int64_t *a, const int64_t *b, int64_t mul, int64_t sub, int K, int E,
+                        int32_t *order, int32_t *gid, int32_t *seg_start, int64_t *ukeys,
+                        int32_t *ngroups, int max_groups, void *ws, size_t ws_bytes, void *stream);
+
+/* cuda_ba.neighbors derived from the per-kk groups (no second sort): every group's edges are
+ * ranked by (jj, edge index).  Groups longer than 1024 edges are left untouched (use
+ * ramp_neighbors for such graphs).                                                              */
+int ramp_neighbors_from_groups(const int32_t *order, const int32_t *seg_start, const int32_t *ngroups,
+                               const int64_t *jj, int64_t *ix, int64_t *jx, int E, int max_groups,
+                               void *stream);
+
 /* ------------------------------------------------------------------ encoder */
 /* flags[0] = any(a != 0), flags[1] = any(b != 0): the "events / image present" tests of
  * ramp/extractor.py:253-254, kept on the device (the reference syncs the host on each).       */
@@ -195,6 +226,11 @@ int ramp_conv2d_nhwc(const void *x, const void *wpk, const float *bias, const fl
                      int Cin, int Cout, int KH, int KW, int stride, int relu, float out_scale,
                      int dtype, void *stream);
 
+/* dtype of ramp_conv2d_nhwc: RAMP_F32 (fp32 in/out, exact fp32 MFMA), RAMP_F16 (half in/out, fp16
+ * MFMA, fp32 accumulation / bias / statistics; Cin % 32 == 0) or RAMP_F16|RAMP_IN_F32 (fp32 in,
+ * half out: the first layer of the mixed-precision tower, Cin == 16)                            */
+#define RAMP_IN_F32 0x10
+
 /* InstanceNorm2d statistics (affine=False, biased variance): scale = rsqrt(var+eps),
  * shift = -mean*scale, from the per-block partials of ramp_conv2d_nhwc                         */
 int ramp_in_stats_finalize(const float *partial, int nblk, int C, float count, float eps, float *scale,
@@ -203,6 +239,12 @@ int ramp_in_stats_finalize(const float *partial, int nblk, int C, float count, f
 /* out = relu(x*s + h)   (InstanceNorm + ReLU materialised where a skip connection needs it)    */
 int ramp_affine_relu(const float *x, const float *s, const float *h, float *out, long n, int C,
                      void *stream);
+
+/* half-storage variants (x, y, skip, out are half; scale/shift stay fp32) */
+int ramp_affine_relu_f16(const void *x, const float *s, const float *h, void *out, long n, int C,
+                         void *stream);
+int ramp_norm_add_relu_f16(const void *y, const float *sy, const float *hy, const void *skip,
+                           const float *ss, const float *hs, void *out, long n, int C, void *stream);
 
 /* residual-block tail: out = relu( skip' + relu(y*sy + hy) ), skip' = skip*ss + hs if ss else skip
  * (ramp/extractor.py:49-57 with the norms folded in)                                           */

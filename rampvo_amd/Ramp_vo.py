@@ -105,6 +105,9 @@ class Ramp_vo:
         self.DIM, self.RES, self.P = self.network.DIM, self.network.RES, self.network.P
         self.network.to(self.device)
         self.network.eval()
+        enc = getattr(self.network.patchify, "encoder", None)
+        if hasattr(enc, "mixed_precision"):
+            enc.mixed_precision = bool(self.cfg.MIXED_PRECISION)
 
     # -------------------------------------------------------------------- views
     @property
@@ -239,10 +242,15 @@ class Ramp_vo:
 
     def _graph_plan(self):
         if self._plan is None or self._plan.E != len(self._ii):
-            nfr = len(np.unique(self._kk // self.M)) if len(self._kk) else 0
-            pairs = len(np.unique(self._ii * 12345 + self._jj)) if len(self._ii) else 0
+            fr = self._kk // self.M
+            nfr = len(np.unique(fr)) if len(fr) else 0
+            pairs = len(np.unique(self._ii * self.N + self._jj)) if len(self._ii) else 0
+            f_lo = int(min(self._ii.min(), self._jj.min()))
+            f_hi = int(max(self._ii.max(), self._jj.max())) + 1
             self._plan = GraphPlan.build(self.ii, self.jj, self.kk, kk_bound=self.N * self.M, jj_bound=self.N,
-                                         max_kk=nfr * self.M, max_ij=pairs)
+                                         max_kk=nfr * self.M, max_ij=pairs,
+                                         kk_range=(int(self._kk.min()), int(self._kk.max()) + 1),
+                                         frame_range=(f_lo, f_hi))
         return self._plan
 
     def __edges_forw(self):
@@ -350,7 +358,8 @@ class Ramp_vo:
             t0 = max(t0, 1)
             try:
                 fastba.BA(self.poses, self.patches, self.intrinsics, target, weight, self.lmbda, self.ii, self.jj,
-                          self.kk, t0, self.n, M=self.M, iterations=2, eff_impl=False, info=self._ba_info)
+                          self.kk, t0, self.n, M=self.M, iterations=2, eff_impl=False, info=self._ba_info,
+                          plan=plan if self.device.type == "cuda" else None)
             except Exception as e:  # same recovery as the reference (:302-306)
                 print(f"WARNING: BA failed...{e}")
             ixm = torch.arange(self.m, device=self.device) // self.M

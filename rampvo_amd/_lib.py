@@ -50,12 +50,19 @@ SIGNATURES = {
     "ramp_segment_softmax_sum": (c_i, [c_p] * 6 + [c_i, c_i, c_i, c_i, c_p]),
     "ramp_ba_workspace_bytes": (c_sz, [c_i] * 5),
     "ramp_ba_forward": (c_i, [c_p] * 9 + [c_i] * 7 + [c_p, c_sz, c_p, c_p]),
+    "ramp_ba_planned_workspace_bytes": (c_sz, [c_i] * 7),
+    "ramp_ba_forward_planned": (c_i, [c_p] * 9 + [c_i] * 7 + [c_p] * 4 + [c_i] + [c_p] * 3 + [c_i, c_p, c_sz, c_p, c_p]),
+    "ramp_group_by_small_workspace_bytes": (c_sz, [c_i, c_i]),
+    "ramp_group_by_small": (c_i, [c_p, c_p, c_i64, c_i64, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_sz, c_p]),
+    "ramp_neighbors_from_groups": (c_i, [c_p] * 6 + [c_i, c_i, c_p]),
     "ramp_any_nonzero": (c_i, [c_p, ctypes.c_long, c_p, ctypes.c_long, c_p, c_p]),
     "ramp_lstm_superstate": (c_i, [c_p] * 9 + [c_i, c_i, c_i, c_p]),
     "ramp_conv2d_nhwc": (c_i, [c_p] * 8 + [c_i] * 8 + [c_f, c_i, c_p]),
     "ramp_in_stats_finalize": (c_i, [c_p, c_i, c_i, c_f, c_f, c_p, c_p, c_p]),
     "ramp_affine_relu": (c_i, [c_p, c_p, c_p, c_p, ctypes.c_long, c_i, c_p]),
     "ramp_norm_add_relu": (c_i, [c_p] * 7 + [ctypes.c_long, c_i, c_p]),
+    "ramp_affine_relu_f16": (c_i, [c_p, c_p, c_p, c_p, ctypes.c_long, c_i, c_p]),
+    "ramp_norm_add_relu_f16": (c_i, [c_p] * 7 + [ctypes.c_long, c_i, c_p]),
     "ramp_upd_row_fuse": (c_i, [c_p] * 5 + [ctypes.c_long, c_p, c_p, c_p, c_p, c_f, c_i, c_p, c_p, c_i, c_i, c_p]),
     "ramp_upd_gather_mask": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p]),
     "ramp_upd_gated": (c_i, [c_p] * 5 + [c_f, c_p, c_p, c_p, c_i, c_i, c_p]),

@@ -20,22 +20,26 @@ def available():
 
 
 # ------------------------------------------------------------------ weight packing
-def pack_conv_weight(conv):
-    """[Cout,Cin,KH,KW] -> MFMA fragment order [tap][Cin/16][Cout/16][64 lanes][4]:
-    lane (q = lane>>4, j = lane&15) holds W[16*nt + j][16*ch + 4*q + s] for s = 0..3"""
+def pack_conv_weight(conv, mode="f32"):
+    """[Cout,Cin,KH,KW] -> MFMA fragment order [tap][Cin/KC][Cout/16][64 lanes][CPL]:
+    lane (q = lane>>4, j = lane&15) holds W[16*nt + j][KC*ch + CPL*q + s], s < CPL.
+    mode "f32": KC=16, CPL=4 fp32;  "f16": KC=32, CPL=8 half;  "f16_first": KC=16, CPL=4 half"""
     w = conv.weight
-    key = (id(conv), w._version, w.device, w.data_ptr())
-    hit = _pack_cache.get(id(conv))
+    key = (id(conv), mode, w._version, w.device, w.data_ptr())
+    hit = _pack_cache.get((id(conv), mode))
     if hit is not None and hit[0] == key:
         return hit[1], hit[2]
+    kc, cpl = (32, 8) if mode == "f16" else (16, 4)
     cout, cin, kh, kw = w.shape
-    cin_p = (cin + 15) // 16 * 16
+    cin_p = (cin + kc - 1) // kc * kc
     wp = torch.zeros(cout, cin_p, kh, kw, dtype=torch.float32, device=w.device)
     wp[:, :cin] = w.detach().float()
-    t = wp.permute(2, 3, 1, 0).reshape(kh * kw, cin_p // 16, 4, 4, cout // 16, 16)   # tap, ch, q, s, nt, j
-    t = t.permute(0, 1, 4, 2, 5, 3).contiguous()                                       # tap, ch, nt, q, j, s
+    t = wp.permute(2, 3, 1, 0).reshape(kh * kw, cin_p // kc, 4, cpl, cout // 16, 16)   # tap, ch, q, s, nt, j
+    t = t.permute(0, 1, 4, 2, 5, 3).contiguous()                                        # tap, ch, nt, q, j, s
+    if mode != "f32":
+        t = t.half()
     bias = conv.bias.detach().float().contiguous() if conv.bias is not None else None
-    _pack_cache[id(conv)] = (key, t, bias)
+    _pack_cache[(id(conv), mode)] = (key, t, bias)
     return t, bias
 
 
@@ -66,25 +70,33 @@ class Pending:
         self.raw, self.scale, self.shift = raw, scale, shift
 
 
-def conv2d(x, conv, pre=None, res=None, relu=False, want_stats=False, out_scale=1.0, eps=1e-5):
-    """x [H,W,Cin] NHWC fp32 (or a Pending: normalise+ReLU on load).  Returns y [OH,OW,Cout],
-    or Pending(y, scale, shift) when want_stats (InstanceNorm statistics of y)."""
+def conv2d(x, conv, pre=None, res=None, relu=False, want_stats=False, out_scale=1.0, eps=1e-5, half=False):
+    """x [H,W,Cin] NHWC (or a Pending: normalise+ReLU on load).  fp32 in/out, or with ``half``:
+    half out and half in (fp32 in allowed for the 16-channel first layer).  Returns y [OH,OW,Cout],
+    or Pending(y, scale, shift) when want_stats (InstanceNorm statistics of y, always fp32)."""
     if isinstance(x, Pending):
         pre, x = (x.scale, x.shift), x.raw
     H, W, Cin = x.shape
-    wpk, bias = pack_conv_weight(conv)
+    if not half:
+        mode, code, odt = "f32", RAMP_F32, torch.float32
+    elif x.dtype == torch.float32:
+        mode, code, odt = "f16_first", _lib.RAMP_F16 | 0x10, torch.float16
+    else:
+        mode, code, odt = "f16", _lib.RAMP_F16, torch.float16
+    wpk, bias = pack_conv_weight(conv, mode)
     cout, _, kh, kw = conv.weight.shape
     stride = conv.stride[0]
-    assert Cin == wpk.shape[1] * 16 and conv.padding[0] == kh // 2 and x.is_contiguous()
-    assert res is None or res.is_contiguous()
+    kc = 32 if mode == "f16" else 16
+    assert Cin == wpk.shape[1] * kc and conv.padding[0] == kh // 2 and x.is_contiguous()
+    assert res is None or (res.is_contiguous() and res.dtype == odt)
     OH = (H + 2 * (kh // 2) - kh) // stride + 1
     OW = (W + 2 * (kw // 2) - kw) // stride + 1
-    y = torch.empty(OH, OW, cout, dtype=torch.float32, device=x.device)
+    y = torch.empty(OH, OW, cout, dtype=odt, device=x.device)
     nblk = (OH * OW + 127) // 128
     stats = torch.empty(nblk, cout, 2, dtype=torch.float32, device=x.device) if want_stats else None
     check(lib().ramp_conv2d_nhwc(ptr(x), ptr(wpk), ptr(bias), ptr(pre[0]) if pre else None,
                                  ptr(pre[1]) if pre else None, ptr(res), ptr(y), ptr(stats), H, W, Cin, cout,
-                                 kh, kw, stride, int(relu), float(out_scale), RAMP_F32, stream()),
+                                 kh, kw, stride, int(relu), float(out_scale), code, stream()),
           "ramp_conv2d_nhwc")
     if not want_stats:
         return y
@@ -98,8 +110,9 @@ def conv2d(x, conv, pre=None, res=None, relu=False, want_stats=False, out_scale=
 def materialize(p):
     """relu(norm(raw))"""
     out = torch.empty_like(p.raw)
-    check(lib().ramp_affine_relu(ptr(p.raw), ptr(p.scale), ptr(p.shift), ptr(out), p.raw.numel(), p.raw.shape[-1],
-                                 stream()), "ramp_affine_relu")
+    fn = lib().ramp_affine_relu_f16 if p.raw.dtype == torch.float16 else lib().ramp_affine_relu
+    check(fn(ptr(p.raw), ptr(p.scale), ptr(p.shift), ptr(out), p.raw.numel(), p.raw.shape[-1], stream()),
+          "ramp_affine_relu")
     return out
 
 
@@ -107,37 +120,39 @@ def norm_add_relu(y, skip):
     """relu(skip' + relu(norm(y)));  skip is a tensor or a Pending (norm, no ReLU)"""
     out = torch.empty_like(y.raw)
     s_raw, ss, hs = (skip.raw, skip.scale, skip.shift) if isinstance(skip, Pending) else (skip, None, None)
-    check(lib().ramp_norm_add_relu(ptr(y.raw), ptr(y.scale), ptr(y.shift), ptr(s_raw), ptr(ss), ptr(hs), ptr(out),
-                                   y.raw.numel(), y.raw.shape[-1], stream()), "ramp_norm_add_relu")
+    fn = lib().ramp_norm_add_relu_f16 if y.raw.dtype == torch.float16 else lib().ramp_norm_add_relu
+    check(fn(ptr(y.raw), ptr(y.scale), ptr(y.shift), ptr(s_raw), ptr(ss), ptr(hs), ptr(out), y.raw.numel(),
+             y.raw.shape[-1], stream()), "ramp_norm_add_relu")
     return out
 
 
 # --------------------------------------------------------------------------- towers
-def _res_block(blk, x, norm):
+def _res_block(blk, x, norm, half):
     """reference ResidualBlock.forward (extractor.py:49-57)"""
     if norm:
-        y = conv2d(x, blk.conv1, want_stats=True)
-        y = conv2d(y, blk.conv2, want_stats=True)
-        skip = x if blk.downsample is None else conv2d(x, blk.downsample[0], want_stats=True)
+        y = conv2d(x, blk.conv1, want_stats=True, half=half)
+        y = conv2d(y, blk.conv2, want_stats=True, half=half)
+        skip = x if blk.downsample is None else conv2d(x, blk.downsample[0], want_stats=True, half=half)
         return norm_add_relu(y, skip)
-    y = conv2d(x, blk.conv1, relu=True)
-    skip = x if blk.downsample is None else conv2d(x, blk.downsample[0])
-    return conv2d(y, blk.conv2, res=skip, relu=True)       # relu(skip + relu(conv2(y)))
+    y = conv2d(x, blk.conv1, relu=True, half=half)
+    skip = x if blk.downsample is None else conv2d(x, blk.downsample[0], half=half)
+    return conv2d(y, blk.conv2, res=skip, relu=True, half=half)       # relu(skip + relu(conv2(y)))
 
 
-def basic_encoder4(enc, x, out_scale=1.0):
-    """BasicEncoder4._forward on one NHWC image x [H,W,Cin_padded] -> [H/4,W/4,out]"""
+def basic_encoder4(enc, x, out_scale=1.0, half=False):
+    """BasicEncoder4._forward on one NHWC image x [H,W,Cin_padded] -> [H/4,W/4,out]
+    (``half``: fp16 storage + fp16 MFMA after the first layer's fp32 input)"""
     norm = isinstance(enc.norm1, nn.InstanceNorm2d)
     if norm:
-        x = materialize(conv2d(x, enc.conv1, want_stats=True, eps=enc.norm1.eps))
+        x = materialize(conv2d(x, enc.conv1, want_stats=True, eps=enc.norm1.eps, half=half))
     else:
         assert isinstance(enc.norm1, nn.Sequential) and len(enc.norm1) == 0
-        x = conv2d(x, enc.conv1, relu=True)
+        x = conv2d(x, enc.conv1, relu=True, half=half)
     for blk in enc.layer1:
-        x = _res_block(blk, x, norm)
+        x = _res_block(blk, x, norm, half)
     for blk in enc.layer2:
-        x = _res_block(blk, x, norm)
-    return conv2d(x, enc.conv2, out_scale=out_scale)
+        x = _res_block(blk, x, norm, half)
+    return conv2d(x, enc.conv2, out_scale=out_scale, half=half)
 
 
 # ------------------------------------------------------------------ LSTM / super-state

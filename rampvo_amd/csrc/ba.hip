@@ -470,30 +470,40 @@ struct BaWs {
   float *rec, *Erow, *Cv, *uv, *Qv, *pairs, *S_part, *y_part, *S, *yv, *dX;
   int Mu_b, Gp_b, KS, tiles;
 };
-static size_t ba_carve(void *ws, int E, int n_poses, int n_patches, int N, BaWs *w) {
+// own_groups: carve room for this call's own group-by (ramp_ba_forward); otherwise the groups
+// come from the caller's plan (ramp_ba_forward_planned) and Mu_b / Gp_b are the caller's bounds.
+static size_t ba_carve(void *ws, int E, int n_poses, int n_patches, int N, int own_groups,
+                       int max_patches, int max_pairs, BaWs *w) {
   const size_t e = (size_t)(E > 0 ? E : 1);
   const int n6 = 6 * N;
   size_t off = 0;
   char *base = (char *)ws;
   auto take = [&](size_t bytes) { char *p = base ? base + off : nullptr; off += al(bytes); return (void *)p; };
   w->Mu_b = (int)((size_t)n_patches < e ? (size_t)n_patches : e);
+  if (max_patches > 0 && max_patches < w->Mu_b) w->Mu_b = max_patches;
   if (w->Mu_b < 1) w->Mu_b = 1;
   const size_t pp = (size_t)n_poses * (size_t)n_poses;
   w->Gp_b = (int)(pp < e ? pp : e);
+  if (max_pairs > 0 && max_pairs < w->Gp_b) w->Gp_b = max_pairs;
   if (w->Gp_b < 1) w->Gp_b = 1;
   w->tiles = (n6 + BA_TS - 1) / BA_TS;
   if (w->tiles < 1) w->tiles = 1;
   int ks = 256 / (w->tiles * w->tiles);
   w->KS = ks < 4 ? 4 : (ks > 64 ? 64 : ks);
-  w->gb_bytes = ramp_internal_group_by_ws(E);
-  w->gb = take(w->gb_bytes);
-  w->pkeys = (int64_t *)take(e * 8);
-  w->kx = (int64_t *)take(e * 8);
-  w->pukeys = (int64_t *)take(e * 8);
-  w->order_k = (int32_t *)take(e * 4);
-  w->seg_k = (int32_t *)take((e + 1) * 4);
-  w->order_p = (int32_t *)take(e * 4);
-  w->seg_p = (int32_t *)take((e + 1) * 4);
+  w->gb = nullptr; w->gb_bytes = 0;
+  w->pkeys = w->kx = w->pukeys = nullptr;
+  w->order_k = w->seg_k = w->order_p = w->seg_p = nullptr;
+  if (own_groups) {
+    w->gb_bytes = ramp_internal_group_by_ws(E);
+    w->gb = take(w->gb_bytes);
+    w->pkeys = (int64_t *)take(e * 8);
+    w->kx = (int64_t *)take(e * 8);
+    w->pukeys = (int64_t *)take(e * 8);
+    w->order_k = (int32_t *)take(e * 4);
+    w->seg_k = (int32_t *)take((e + 1) * 4);
+    w->order_p = (int32_t *)take(e * 4);
+    w->seg_p = (int32_t *)take((e + 1) * 4);
+  }
   w->pair_ij = (int32_t *)take((size_t)w->Gp_b * 8);
   w->counters = (int32_t *)take(64);
   w->rec = (float *)take(e * BA_REC * 4);
@@ -510,50 +520,20 @@ static size_t ba_carve(void *ws, int E, int n_poses, int n_patches, int N, BaWs 
   return off;
 }
 
-extern "C" {
-
-size_t ramp_ba_workspace_bytes(int E, int n_poses, int n_patches, int t0, int t1) {
-  BaWs w;
-  const int N = t1 - t0 > 0 ? t1 - t0 : 0;
-  return ba_carve(nullptr, E, n_poses, n_patches, N, &w);
-}
-
-int ramp_ba_forward(float *poses, float *patches, const float *intrinsics, const float *target,
-                    const float *weight, const float *lmbda, const int64_t *ii,
-                    const int64_t *jj, const int64_t *kk, int E, int P, int n_poses,
-                    int n_patches, int t0, int t1, int iterations, void *ws, size_t ws_bytes,
-                    int32_t *info, void *stream) {
-  if (E < 0 || P < 2 || n_poses <= 0 || n_patches <= 0 || iterations < 0) return RAMP_EINVAL;
-  if (t0 < 0 || t1 < t0 || t1 > n_poses) return RAMP_EINVAL;
-  hipStream_t st = (hipStream_t)stream;
-  if (info) hipMemsetAsync(info, 0, sizeof(int32_t), st);
-  if (E == 0 || iterations == 0) return RAMP_OK;
-  if (!poses || !patches || !intrinsics || !target || !weight || !lmbda || !ii || !jj || !kk ||
-      !ws)
-    return RAMP_EINVAL;
+// the GN iterations, given the two groupings
+static int ba_iterate(float *poses, float *patches, const float *intrinsics, const float *target,
+                      const float *weight, const float *lmbda, const int64_t *ii, const int64_t *jj,
+                      const int64_t *kk, int E, int P, int t0, int t1, int iterations, BaWs &w,
+                      const int32_t *order_k, const int32_t *seg_k, const int32_t *nk, const int64_t *kx,
+                      const int32_t *order_p, const int32_t *seg_p, const int32_t *np, int32_t *info,
+                      hipStream_t st) {
   const int N = t1 - t0, n6 = 6 * N;
   const size_t lds = (size_t)(n6 * (n6 + 1) + n6) * sizeof(float);
-  if (lds > 160 * 1024) return RAMP_EUNSUPPORTED;  // > 32 free poses: S does not fit one LDS
-  BaWs w;
-  if (ba_carve(ws, E, n_poses, n_patches, N, &w) > ws_bytes) return RAMP_EWORKSPACE;
-  int32_t *nk = w.counters, *np = w.counters + 1;
   const int PP = P * P, c11 = 1 * P + 1;
-  int rc;
-  // ---- prep: group by patch, group by pose pair
-  rc = ramp_internal_group_by(kk, E, n_patches, w.order_k, nullptr, w.seg_k, w.kx, nk, w.gb,
-                              w.gb_bytes, st);
-  if (rc != RAMP_OK) return rc;
-  if (N > 0) {
-    hipLaunchKernelGGL(ba_pairkey_kernel, dim3(ramp_cdiv(E, 256)), dim3(256), 0, st, ii, jj,
-                       w.pkeys, E, (long long)n_poses);
-    rc = ramp_internal_group_by(w.pkeys, E, (int64_t)n_poses * n_poses, w.order_p, nullptr,
-                                w.seg_p, w.pukeys, np, w.gb, w.gb_bytes, st);
-    if (rc != RAMP_OK) return rc;
-    if (lds > 64 * 1024) {
-      if (hipFuncSetAttribute((const void *)ba_chol_kernel,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return RAMP_ELAUNCH;
-    }
+  if (N > 0 && n6 > 64 && lds > 64 * 1024) {
+    if (hipFuncSetAttribute((const void *)ba_chol_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return RAMP_ELAUNCH;
   }
   const int pthreads = ((n6 + 2 + 63) / 64) * 64;
   if (pthreads > 256) return RAMP_EUNSUPPORTED;
@@ -562,11 +542,11 @@ int ramp_ba_forward(float *poses, float *patches, const float *intrinsics, const
   for (int itr = 0; itr < iterations; itr++) {
     hipLaunchKernelGGL(ba_edge_kernel, dim3(ramp_cdiv(E, 256)), dim3(256), 0, st, poses, patches,
                        intrinsics, target, weight, ii, jj, kk, w.rec, E, PP, c11, t0, N);
-    hipLaunchKernelGGL(ba_patch_kernel, dim3(w.Mu_b), dim3(pthreads), 0, st, w.rec, w.order_k,
-                       w.seg_k, nk, lmbda, w.Erow, w.Cv, w.uv, w.Qv, n6);
+    hipLaunchKernelGGL(ba_patch_kernel, dim3(w.Mu_b), dim3(pthreads), 0, st, w.rec, order_k, seg_k, nk,
+                       lmbda, w.Erow, w.Cv, w.uv, w.Qv, n6);
     if (N > 0) {
-      hipLaunchKernelGGL(ba_pair_kernel, dim3(w.Gp_b), dim3(192), 0, st, w.rec, w.order_p, w.seg_p,
-                         np, w.pairs, w.pair_ij);
+      hipLaunchKernelGGL(ba_pair_kernel, dim3(w.Gp_b), dim3(192), 0, st, w.rec, order_p, seg_p, np,
+                         w.pairs, w.pair_ij);
       hipLaunchKernelGGL(ba_schur_kernel, dim3(w.tiles, w.tiles, w.KS), dim3(256), 0, st, w.Erow,
                          w.Qv, w.uv, nk, w.S_part, w.y_part, n6, w.KS);
       hipLaunchKernelGGL(ba_assemble_kernel, dim3(N), dim3(256), 0, st, w.pairs, w.pair_ij, np,
@@ -577,11 +557,87 @@ int ramp_ba_forward(float *poses, float *patches, const float *intrinsics, const
         hipLaunchKernelGGL(ba_chol_kernel, dim3(1), dim3(1024), lds, st, w.S, w.yv, w.dX, info, n6);
     }
     hipLaunchKernelGGL(ba_retract_kernel, dim3(depth_blocks + pose_blocks), dim3(256), 0, st,
-                       poses, patches, w.Erow, w.Qv, w.uv, w.dX, w.kx, nk, n6, PP, t0, N,
-                       depth_blocks);
+                       poses, patches, w.Erow, w.Qv, w.uv, w.dX, kx, nk, n6, PP, t0, N, depth_blocks);
     RAMP_CHECK_LAUNCH();
   }
   return RAMP_OK;
+}
+
+static int ba_check_args(int E, int P, int n_poses, int n_patches, int t0, int t1, int iterations) {
+  if (E < 0 || P < 2 || n_poses <= 0 || n_patches <= 0 || iterations < 0) return RAMP_EINVAL;
+  if (t0 < 0 || t1 < t0 || t1 > n_poses) return RAMP_EINVAL;
+  const int n6 = 6 * (t1 - t0);
+  if ((size_t)(n6 * (n6 + 1) + n6) * sizeof(float) > 160 * 1024) return RAMP_EUNSUPPORTED;  // > 32 free poses
+  return RAMP_OK;
+}
+
+extern "C" {
+
+size_t ramp_ba_workspace_bytes(int E, int n_poses, int n_patches, int t0, int t1) {
+  BaWs w;
+  const int N = t1 - t0 > 0 ? t1 - t0 : 0;
+  return ba_carve(nullptr, E, n_poses, n_patches, N, 1, 0, 0, &w);
+}
+
+int ramp_ba_forward(float *poses, float *patches, const float *intrinsics, const float *target,
+                    const float *weight, const float *lmbda, const int64_t *ii,
+                    const int64_t *jj, const int64_t *kk, int E, int P, int n_poses,
+                    int n_patches, int t0, int t1, int iterations, void *ws, size_t ws_bytes,
+                    int32_t *info, void *stream) {
+  int rc = ba_check_args(E, P, n_poses, n_patches, t0, t1, iterations);
+  if (rc != RAMP_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (info) (void)hipMemsetAsync(info, 0, sizeof(int32_t), st);
+  if (E == 0 || iterations == 0) return RAMP_OK;
+  if (!poses || !patches || !intrinsics || !target || !weight || !lmbda || !ii || !jj || !kk || !ws)
+    return RAMP_EINVAL;
+  const int N = t1 - t0;
+  BaWs w;
+  if (ba_carve(ws, E, n_poses, n_patches, N, 1, 0, 0, &w) > ws_bytes) return RAMP_EWORKSPACE;
+  int32_t *nk = w.counters, *np = w.counters + 1;
+  // ---- prep: group by patch, group by pose pair
+  rc = ramp_internal_group_by(kk, E, n_patches, w.order_k, nullptr, w.seg_k, w.kx, nk, w.gb, w.gb_bytes, st);
+  if (rc != RAMP_OK) return rc;
+  if (N > 0) {
+    hipLaunchKernelGGL(ba_pairkey_kernel, dim3(ramp_cdiv(E, 256)), dim3(256), 0, st, ii, jj, w.pkeys, E,
+                       (long long)n_poses);
+    rc = ramp_internal_group_by(w.pkeys, E, (int64_t)n_poses * n_poses, w.order_p, nullptr, w.seg_p,
+                                w.pukeys, np, w.gb, w.gb_bytes, st);
+    if (rc != RAMP_OK) return rc;
+  }
+  return ba_iterate(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, E, P, t0, t1, iterations,
+                    w, w.order_k, w.seg_k, nk, w.kx, w.order_p, w.seg_p, np, info, st);
+}
+
+size_t ramp_ba_planned_workspace_bytes(int E, int n_poses, int n_patches, int t0, int t1,
+                                       int max_patches, int max_pairs) {
+  BaWs w;
+  const int N = t1 - t0 > 0 ? t1 - t0 : 0;
+  return ba_carve(nullptr, E, n_poses, n_patches, N, 0, max_patches, max_pairs, &w);
+}
+
+int ramp_ba_forward_planned(float *poses, float *patches, const float *intrinsics, const float *target,
+                            const float *weight, const float *lmbda, const int64_t *ii,
+                            const int64_t *jj, const int64_t *kk, int E, int P, int n_poses,
+                            int n_patches, int t0, int t1, int iterations, const int32_t *order_k,
+                            const int32_t *seg_k, const int32_t *ngroups_k, const int64_t *ukeys_k,
+                            int max_patches, const int32_t *order_p, const int32_t *seg_p,
+                            const int32_t *ngroups_p, int max_pairs, void *ws, size_t ws_bytes,
+                            int32_t *info, void *stream) {
+  int rc = ba_check_args(E, P, n_poses, n_patches, t0, t1, iterations);
+  if (rc != RAMP_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (info) (void)hipMemsetAsync(info, 0, sizeof(int32_t), st);
+  if (E == 0 || iterations == 0) return RAMP_OK;
+  if (!poses || !patches || !intrinsics || !target || !weight || !lmbda || !ii || !jj || !kk || !ws ||
+      !order_k || !seg_k || !ngroups_k || !ukeys_k || !order_p || !seg_p || !ngroups_p)
+    return RAMP_EINVAL;
+  if (max_patches <= 0 || max_pairs <= 0) return RAMP_EINVAL;
+  BaWs w;
+  if (ba_carve(ws, E, n_poses, n_patches, t1 - t0, 0, max_patches, max_pairs, &w) > ws_bytes)
+    return RAMP_EWORKSPACE;
+  return ba_iterate(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, E, P, t0, t1, iterations,
+                    w, order_k, seg_k, ngroups_k, ukeys_k, order_p, seg_p, ngroups_p, info, st);
 }
 
 }  // extern "C"

@@ -298,6 +298,150 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// fp16 storage / fp16 MFMA variant (MIXED_PRECISION): activations and weights are half, the
+// accumulators, bias, InstanceNorm statistics and the prologue affine are fp32.
+//   IN_F32 = true : first layer (Cin = 16, fp32 super-state in): one tap per
+//                   v_mfma_f32_16x16x16_f16, lane loads float4 -> 4 halves
+//   IN_F32 = false: Cin % 32 == 0, half in: one (tap, 32-channel chunk) per
+//                   v_mfma_f32_16x16x32_f16, lane loads 8 halves (16 B)
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+template <int KH, int KW, int STRIDE, bool IN_F32>
+__global__ void __launch_bounds__(256)
+    conv_mfma_f16_kernel(const ConvParams p) {
+  constexpr int PAD = KH / 2;
+  constexpr int KC = IN_F32 ? 16 : 32;   // channels consumed per MFMA
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane >> 4, j = lane & 15;
+  const int M = p.OH * p.OW;
+  const int m_wave = (blockIdx.x * 4 + wave) * 32;
+  const int n0 = blockIdx.y * 32;
+  const int nchunk = p.Cin / KC;
+  const int ntiles = p.Cout / 16;
+  int oy[2], ox[2];
+  bool mval[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; mt++) {
+    const int m = m_wave + mt * 16 + j;
+    mval[mt] = m < M;
+    const int mm = mval[mt] ? m : 0;
+    oy[mt] = mm / p.OW;
+    ox[mt] = mm - oy[mt] * p.OW;
+  }
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  constexpr int CPL = KC / 4;   // channels per lane per MFMA (4 or 8)
+
+  for (int ky = 0; ky < KH; ky++) {
+    for (int kx = 0; kx < KW; kx++) {
+      const int tap = ky * KW + kx;
+      size_t aoff[2];
+      bool aval[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; mt++) {
+        const int iy = oy[mt] * STRIDE + ky - PAD, ix = ox[mt] * STRIDE + kx - PAD;
+        aval[mt] = mval[mt] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        aoff[mt] = ((size_t)(aval[mt] ? iy : 0) * p.W + (aval[mt] ? ix : 0)) * p.Cin + CPL * q;
+      }
+      for (int ch = 0; ch < nchunk; ch++) {
+        float av[2][CPL];
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++) {
+          if (!aval[mt]) {
+#pragma unroll
+            for (int c = 0; c < CPL; c++) av[mt][c] = 0.f;
+          } else if (IN_F32) {
+            const float4 v = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(p.x) + aoff[mt] + ch * KC);
+            av[mt][0] = v.x; av[mt][1] = v.y; av[mt][2] = v.z; av[mt][3] = v.w;
+          } else {
+            const f16x8 v = *reinterpret_cast<const f16x8 *>(reinterpret_cast<const _Float16 *>(p.x) + aoff[mt] + ch * KC);
+#pragma unroll
+            for (int c = 0; c < CPL; c++) av[mt][c] = (float)v[c];
+          }
+        }
+        if (p.pre_scale) {
+#pragma unroll
+          for (int c = 0; c < CPL; c++) {
+            const float sc = p.pre_scale[ch * KC + CPL * q + c], sh = p.pre_shift[ch * KC + CPL * q + c];
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++)
+              if (aval[mt]) av[mt][c] = fmaxf(av[mt][c] * sc + sh, 0.f);
+          }
+        }
+        const _Float16 *wb = reinterpret_cast<const _Float16 *>(p.wpk) +
+                             (((size_t)(tap * nchunk + ch) * ntiles + (n0 / 16)) * 64 + lane) * CPL;
+        if (IN_F32) {
+          f16x4 a[2], b[2];
+#pragma unroll
+          for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) a[mt][c] = (_Float16)av[mt][c];
+#pragma unroll
+          for (int nt = 0; nt < 2; nt++) b[nt] = *reinterpret_cast<const f16x4 *>(wb + nt * 64 * CPL);
+#pragma unroll
+          for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+        } else {
+          f16x8 a[2], b[2];
+#pragma unroll
+          for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int c = 0; c < 8; c++) a[mt][c] = (_Float16)av[mt][c < CPL ? c : 0];
+#pragma unroll
+          for (int nt = 0; nt < 2; nt++) b[nt] = *reinterpret_cast<const f16x8 *>(wb + nt * 64 * CPL);
+#pragma unroll
+          for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  __shared__ float s_stat[4][32][2];
+  _Float16 *y = reinterpret_cast<_Float16 *>(p.y);
+  const _Float16 *res = reinterpret_cast<const _Float16 *>(p.res);
+#pragma unroll
+  for (int nt = 0; nt < 2; nt++) {
+    const int c = n0 + nt * 16 + j;
+    const float bv = p.bias ? p.bias[c] : 0.0f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int m = m_wave + mt * 16 + 4 * q + r;
+        if (m < M) {
+          float v = acc[mt][nt][r] + bv;
+          s1 += v;
+          s2 += v * v;
+          if (p.relu) v = fmaxf(v, 0.f);
+          if (res) v = fmaxf(v + (float)res[(size_t)m * p.Cout + c], 0.f);
+          y[(size_t)m * p.Cout + c] = (_Float16)(v * p.out_scale);
+        }
+      }
+    }
+    if (p.stats) {
+      s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+      if (q == 0) { s_stat[wave][nt * 16 + j][0] = s1; s_stat[wave][nt * 16 + j][1] = s2; }
+    }
+  }
+  if (p.stats) {
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const int c = threadIdx.x >> 1, k = threadIdx.x & 1;
+      const float v = ((s_stat[0][c][k] + s_stat[1][c][k]) + s_stat[2][c][k]) + s_stat[3][c][k];
+      p.stats[((size_t)blockIdx.x * p.Cout + n0 + c) * 2 + k] = v;
+    }
+  }
+}
+
 // InstanceNorm statistics: partial[nblk][C][2] -> scale = rstd, shift = -mean*rstd (biased variance)
 __global__ void __launch_bounds__(64)
     in_stats_finalize_kernel(const float *__restrict__ partial, int nblk, int C, float count, float eps,
@@ -344,6 +488,40 @@ __global__ void __launch_bounds__(256)
   reinterpret_cast<float4 *>(out)[i] = v;
 }
 
+// half-storage variants of the two tail kernels (8 channels / 16 B per lane)
+__global__ void __launch_bounds__(256)
+    norm_add_relu_f16_kernel(const _Float16 *__restrict__ y, const float *__restrict__ sy,
+                             const float *__restrict__ hy, const _Float16 *__restrict__ skip,
+                             const float *__restrict__ ss, const float *__restrict__ hs,
+                             _Float16 *__restrict__ out, long n8, int C) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const int c = (int)((i * 8) % C);
+  const f16x8 v = reinterpret_cast<const f16x8 *>(y)[i];
+  const f16x8 k = reinterpret_cast<const f16x8 *>(skip)[i];
+  f16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; e++) {
+    float a = fmaxf((float)v[e] * sy[c + e] + hy[c + e], 0.f);
+    float b = (float)k[e];
+    if (ss) b = b * ss[c + e] + hs[c + e];
+    o[e] = (_Float16)fmaxf(a + b, 0.f);
+  }
+  reinterpret_cast<f16x8 *>(out)[i] = o;
+}
+__global__ void __launch_bounds__(256)
+    affine_relu_f16_kernel(const _Float16 *__restrict__ x, const float *__restrict__ s,
+                           const float *__restrict__ h, _Float16 *__restrict__ out, long n8, int C) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const int c = (int)((i * 8) % C);
+  const f16x8 v = reinterpret_cast<const f16x8 *>(x)[i];
+  f16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; e++) o[e] = (_Float16)fmaxf((float)v[e] * s[c + e] + h[c + e], 0.f);
+  reinterpret_cast<f16x8 *>(out)[i] = o;
+}
+
 // out = relu(x*s + h), NHWC, C multiple of 4
 __global__ void __launch_bounds__(256)
     affine_relu_kernel(const float *__restrict__ x, const float *__restrict__ s,
@@ -366,6 +544,27 @@ int ramp_affine_relu(const float *x, const float *s, const float *h, float *out,
   const long n4 = n / 4;
   hipLaunchKernelGGL(affine_relu_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, x, s, h, out, n4, C);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+
+int ramp_affine_relu_f16(const void *x, const float *s, const float *h, void *out, long n, int C,
+                         void *stream) {
+  if (!x || !s || !h || !out || n <= 0 || C % 8 || n % 8) return RAMP_EINVAL;
+  const long n8 = n / 8;
+  hipLaunchKernelGGL(affine_relu_f16_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, (const _Float16 *)x, s, h, (_Float16 *)out, n8, C);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+
+int ramp_norm_add_relu_f16(const void *y, const float *sy, const float *hy, const void *skip,
+                           const float *ss, const float *hs, void *out, long n, int C, void *stream) {
+  if (!y || !sy || !hy || !skip || !out || n <= 0 || C % 8 || n % 8) return RAMP_EINVAL;
+  const long n8 = n / 8;
+  hipLaunchKernelGGL(norm_add_relu_f16_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, (const _Float16 *)y, sy, hy, (const _Float16 *)skip, ss, hs,
+                     (_Float16 *)out, n8, C);
   RAMP_CHECK_LAUNCH();
   return RAMP_OK;
 }
@@ -402,7 +601,12 @@ int ramp_conv2d_nhwc(const void *x, const void *wpk, const float *bias, const fl
                      int dtype, void *stream) {
   if (!x || !wpk || !y || H <= 0 || W <= 0) return RAMP_EINVAL;
   if (Cin % 16 || Cout % 32 || KH != KW) return RAMP_EUNSUPPORTED;
-  if (dtype != RAMP_F32) return RAMP_EUNSUPPORTED;
+  // dtype: RAMP_F32 = fp32 in/out (exact fp32 MFMA); RAMP_F16 = half in/out;
+  //        RAMP_F16 | 0x10 = fp32 in, half out (first layer of the mixed-precision tower)
+  const bool f16 = (dtype & 0xf) == RAMP_F16, in_f32 = f16 && (dtype & 0x10);
+  if (!f16 && dtype != RAMP_F32) return RAMP_EINVAL;
+  if (f16 && !in_f32 && Cin % 32) return RAMP_EUNSUPPORTED;
+  if (in_f32 && Cin != 16) return RAMP_EUNSUPPORTED;
   ConvParams p;
   p.x = x; p.wpk = wpk; p.bias = bias; p.pre_scale = pre_scale; p.pre_shift = pre_shift;
   p.res = res; p.y = y; p.stats = stats;
@@ -414,14 +618,21 @@ int ramp_conv2d_nhwc(const void *x, const void *wpk, const float *bias, const fl
   const int M = p.OH * p.OW;
   dim3 grid(ramp_cdiv(M, 128), Cout / 32), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (KH == 7 && stride == 2) hipLaunchKernelGGL((conv_mfma_f32_kernel<7, 7, 2>), grid, block, 0, st, p);
-  else if (KH == 3 && stride == 1) hipLaunchKernelGGL((conv_mfma_f32_kernel<3, 3, 1>), grid, block, 0, st, p);
-  else if (KH == 3 && stride == 2) hipLaunchKernelGGL((conv_mfma_f32_kernel<3, 3, 2>), grid, block, 0, st, p);
-  else if (KH == 1 && stride == 1) hipLaunchKernelGGL((conv_mfma_f32_kernel<1, 1, 1>), grid, block, 0, st, p);
-  else if (KH == 1 && stride == 2) hipLaunchKernelGGL((conv_mfma_f32_kernel<1, 1, 2>), grid, block, 0, st, p);
-  else return RAMP_EUNSUPPORTED;
-  RAMP_CHECK_LAUNCH();
-  return RAMP_OK;
+#define CONV_CASE(K, S)                                                                              \
+  if (KH == K && stride == S) {                                                                      \
+    if (!f16) hipLaunchKernelGGL((conv_mfma_f32_kernel<K, K, S>), grid, block, 0, st, p);            \
+    else if (in_f32) hipLaunchKernelGGL((conv_mfma_f16_kernel<K, K, S, true>), grid, block, 0, st, p); \
+    else hipLaunchKernelGGL((conv_mfma_f16_kernel<K, K, S, false>), grid, block, 0, st, p);          \
+    RAMP_CHECK_LAUNCH();                                                                             \
+    return RAMP_OK;                                                                                  \
+  }
+  CONV_CASE(7, 2)
+  CONV_CASE(3, 1)
+  CONV_CASE(3, 2)
+  CONV_CASE(1, 1)
+  CONV_CASE(1, 2)
+#undef CONV_CASE
+  return RAMP_EUNSUPPORTED;
 }
 
 int ramp_in_stats_finalize(const float *partial, int nblk, int C, float count, float eps, float *scale,

@@ -60,8 +60,8 @@ static size_t gb_cub_bytes(int E) {
   size_t a = 0, b = 0;
   unsigned long long *k = nullptr;
   int32_t *v = nullptr;
-  hipcub::DeviceRadixSort::SortPairs(nullptr, a, k, k, v, v, E > 0 ? E : 1, 0, 64, (hipStream_t)0);
-  hipcub::DeviceScan::InclusiveSum(nullptr, b, v, v, E > 0 ? E : 1, (hipStream_t)0);
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, a, k, k, v, v, E > 0 ? E : 1, 0, 64, (hipStream_t)0);
+  (void)hipcub::DeviceScan::InclusiveSum(nullptr, b, v, v, E > 0 ? E : 1, (hipStream_t)0);
   return align_up((a > b ? a : b) + 256, 256);
 }
 static size_t gb_carve(void *ws, int E, GbWs *w) {
@@ -107,8 +107,8 @@ int ramp_internal_group_by(const int64_t *keys, int E, int64_t key_bound, int32_
                            void *ws, size_t ws_bytes, hipStream_t st) {
   if (E < 0 || !ngroups || !seg_start) return RAMP_EINVAL;
   if (E == 0) {
-    hipMemsetAsync(ngroups, 0, sizeof(int32_t), st);
-    hipMemsetAsync(seg_start, 0, sizeof(int32_t), st);
+    (void)hipMemsetAsync(ngroups, 0, sizeof(int32_t), st);
+    (void)hipMemsetAsync(seg_start, 0, sizeof(int32_t), st);
     return RAMP_OK;
   }
   if (!keys || !order || !ws) return RAMP_EINVAL;
@@ -180,7 +180,161 @@ __global__ void __launch_bounds__(128)
   }
 }
 
+// ------------------------------------------------- counting group-by (small key range)
+// key = a[e]*mul + (b ? b[e] : 0) - sub in [0, K).  histogram -> single-workgroup scan ->
+// scatter -> per-group rank sort by edge index (restores the stable order).  5 short kernels
+// instead of a radix sort's ~12; used when the caller knows a tight key range (the tracker does).
+__device__ __forceinline__ long gbc_key(const int64_t *a, const int64_t *b, long mul, long sub, int e) {
+  return a[e] * mul + (b ? b[e] : 0) - sub;
+}
+__global__ void __launch_bounds__(256)
+    gbc_hist_kernel(const int64_t *__restrict__ a, const int64_t *__restrict__ b, long mul, long sub,
+                    int32_t *__restrict__ hist, int E, int K, int32_t *__restrict__ bad) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const long k = gbc_key(a, b, mul, sub, e);
+  if (k < 0 || k >= K) { *bad = 1; return; }
+  atomicAdd(&hist[k], 1);
+}
+// one workgroup: exclusive scan of the counts (-> cursor/offset) and of (count > 0) (-> group id)
+__global__ void __launch_bounds__(1024)
+    gbc_scan_kernel(int32_t *__restrict__ hist, int32_t *__restrict__ gidmap, int32_t *__restrict__ seg_start,
+                    int64_t *__restrict__ ukeys, int32_t *__restrict__ ngroups, int K, int E, long sub,
+                    long mul_is_pair) {
+  __shared__ int s_cnt[1024], s_grp[1024];
+  const int tid = threadIdx.x;
+  const int per = (K + 1023) / 1024;
+  const int k0 = tid * per, k1 = min(K, k0 + per);
+  int c = 0, g = 0;
+  for (int k = k0; k < k1; k++) { const int h = hist[k]; c += h; g += (h > 0); }
+  s_cnt[tid] = c; s_grp[tid] = g;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan
+    int vc = 0, vg = 0;
+    if (tid >= off) { vc = s_cnt[tid - off]; vg = s_grp[tid - off]; }
+    __syncthreads();
+    s_cnt[tid] += vc; s_grp[tid] += vg;
+    __syncthreads();
+  }
+  int oc = s_cnt[tid] - c, og = s_grp[tid] - g;   // exclusive prefixes of this thread's chunk
+  for (int k = k0; k < k1; k++) {
+    const int h = hist[k];
+    hist[k] = oc;               // becomes the scatter cursor
+    if (h > 0) {
+      gidmap[k] = og;
+      seg_start[og] = oc;
+      if (ukeys) ukeys[og] = (int64_t)k + sub;
+      og++;
+    } else {
+      gidmap[k] = -1;
+    }
+    oc += h;
+  }
+  if (tid == 1023) { *ngroups = s_grp[1023]; seg_start[s_grp[1023]] = E; }
+}
+__global__ void __launch_bounds__(256)
+    gbc_scatter_kernel(const int64_t *__restrict__ a, const int64_t *__restrict__ b, long mul, long sub,
+                       int32_t *__restrict__ cursor, const int32_t *__restrict__ gidmap,
+                       int32_t *__restrict__ tmp_order, int32_t *__restrict__ gid, int E, int K) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const long k = gbc_key(a, b, mul, sub, e);
+  if (k < 0 || k >= K) return;
+  const int pos = atomicAdd(&cursor[k], 1);
+  tmp_order[pos] = e;
+  if (gid) gid[e] = gidmap[k];
+}
+// restore ascending edge order inside every segment (rank by counting; segments are short)
+__global__ void __launch_bounds__(64)
+    gbc_segsort_kernel(const int32_t *__restrict__ tmp_order, const int32_t *__restrict__ seg_start,
+                       const int32_t *__restrict__ ngroups, int32_t *__restrict__ order) {
+  const int g = blockIdx.x;
+  if (g >= *ngroups) return;
+  const int s0 = seg_start[g], n = seg_start[g + 1] - s0;
+  for (int p = threadIdx.x; p < n; p += 64) {
+    const int v = tmp_order[s0 + p];
+    int r = 0;
+    for (int q = 0; q < n; q++) r += (tmp_order[s0 + q] < v);
+    order[s0 + r] = v;
+  }
+}
+// temporal neighbours from the per-patch groups: rank each edge of a group by (jj, edge index)
+__global__ void __launch_bounds__(64)
+    nb_from_groups_kernel(const int32_t *__restrict__ order, const int32_t *__restrict__ seg_start,
+                          const int32_t *__restrict__ ngroups, const int64_t *__restrict__ jj,
+                          int64_t *__restrict__ ix, int64_t *__restrict__ jx) {
+  __shared__ int s_sorted[1024];
+  const int g = blockIdx.x;
+  if (g >= *ngroups) return;
+  const int s0 = seg_start[g], n = seg_start[g + 1] - s0;
+  if (n > 1024) return;   // host falls back to the sort-based path for such graphs
+  for (int p = threadIdx.x; p < n; p += 64) {
+    const int e = order[s0 + p];
+    const long j = jj[e];
+    int r = 0;
+    for (int q = 0; q < n; q++) {
+      const int f = order[s0 + q];
+      const long jf = jj[f];
+      r += (jf < j) || (jf == j && f < e);
+    }
+    s_sorted[r] = e;
+  }
+  __syncthreads();
+  for (int r = threadIdx.x; r < n; r += 64) {
+    const int e = s_sorted[r];
+    ix[e] = r > 0 ? s_sorted[r - 1] : -1;
+    jx[e] = r + 1 < n ? s_sorted[r + 1] : -1;
+  }
+}
+
 extern "C" {
+
+size_t ramp_group_by_small_workspace_bytes(int E, int K) {
+  return align_up((size_t)(K + 1) * 4, 256) * 2 + align_up((size_t)(E > 0 ? E : 1) * 4, 256) + 256;
+}
+
+int ramp_group_by_small(const int64_t *a, const int64_t *b, int64_t mul, int64_t sub, int K, int E,
+                        int32_t *order, int32_t *gid, int32_t *seg_start, int64_t *ukeys,
+                        int32_t *ngroups, int max_groups, void *ws, size_t ws_bytes, void *stream) {
+  if (E < 0 || K <= 0 || !ngroups || !seg_start) return RAMP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (E == 0) {
+    (void)hipMemsetAsync(ngroups, 0, sizeof(int32_t), st);
+    (void)hipMemsetAsync(seg_start, 0, sizeof(int32_t), st);
+    return RAMP_OK;
+  }
+  if (!a || !order || !ws) return RAMP_EINVAL;
+  if (ws_bytes < ramp_group_by_small_workspace_bytes(E, K)) return RAMP_EWORKSPACE;
+  char *base = (char *)ws;
+  int32_t *hist = (int32_t *)base;
+  int32_t *gidmap = (int32_t *)(base + align_up((size_t)(K + 1) * 4, 256));
+  int32_t *tmp = (int32_t *)(base + 2 * align_up((size_t)(K + 1) * 4, 256));
+  int32_t *bad = (int32_t *)(base + 2 * align_up((size_t)(K + 1) * 4, 256) + align_up((size_t)E * 4, 256));
+  (void)hipMemsetAsync(hist, 0, (size_t)(K + 1) * 4, st);
+  (void)hipMemsetAsync(bad, 0, 4, st);
+  const int nb = ramp_cdiv(E, 256);
+  hipLaunchKernelGGL(gbc_hist_kernel, dim3(nb), dim3(256), 0, st, a, b, (long)mul, (long)sub, hist, E, K, bad);
+  hipLaunchKernelGGL(gbc_scan_kernel, dim3(1), dim3(1024), 0, st, hist, gidmap, seg_start, ukeys, ngroups, K, E,
+                     (long)sub, 0L);
+  hipLaunchKernelGGL(gbc_scatter_kernel, dim3(nb), dim3(256), 0, st, a, b, (long)mul, (long)sub, hist, gidmap,
+                     tmp, gid, E, K);
+  const int ng = max_groups > 0 ? (max_groups < E ? max_groups : E) : (K < E ? K : E);
+  hipLaunchKernelGGL(gbc_segsort_kernel, dim3(ng), dim3(64), 0, st, tmp, seg_start, ngroups, order);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+
+int ramp_neighbors_from_groups(const int32_t *order, const int32_t *seg_start, const int32_t *ngroups,
+                               const int64_t *jj, int64_t *ix, int64_t *jx, int E, int max_groups,
+                               void *stream) {
+  if (E < 0 || max_groups < 0) return RAMP_EINVAL;
+  if (E == 0 || max_groups == 0) return RAMP_OK;
+  if (!order || !seg_start || !ngroups || !jj || !ix || !jx) return RAMP_EINVAL;
+  hipLaunchKernelGGL(nb_from_groups_kernel, dim3(max_groups), dim3(64), 0, (hipStream_t)stream, order,
+                     seg_start, ngroups, jj, ix, jx);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
 
 size_t ramp_group_by_workspace_bytes(int E) { return ramp_internal_group_by_ws(E); }
 

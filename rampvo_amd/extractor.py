@@ -164,6 +164,7 @@ class MergerLSTMsceneEncoder(nn.Module):
         self.imap_encoder = BasicEncoder4(output_dim=output_dim_i, norm_fn=norm_fn_imap, channel_dim=output_lstm_dim)
         self.states_events, self.states_image, self.super_state = None, None, None
         self._hip_state = None
+        self.mixed_precision = False      # fp16 storage / fp16 MFMA conv towers (set by Ramp_vo from cfg)
 
     def _forward_hip(self, events, images, reinit_hidden, out_scale):
         """fused LSTM/super-state kernel + MFMA conv towers (csrc/conv.hip)"""
@@ -176,8 +177,8 @@ class MergerLSTMsceneEncoder(nn.Module):
             st.fresh = True
         s16 = conv_hip.lstm_superstate_step(self, events[0, 0].float().contiguous(),
                                             images[0, 0].float().contiguous(), st)
-        f = conv_hip.basic_encoder4(self.fmap_encoder, s16, out_scale)        # [h,w,128]
-        i = conv_hip.basic_encoder4(self.imap_encoder, s16, out_scale)        # [h,w,384]
+        f = conv_hip.basic_encoder4(self.fmap_encoder, s16, out_scale, half=self.mixed_precision)   # [h,w,128]
+        i = conv_hip.basic_encoder4(self.imap_encoder, s16, out_scale, half=self.mixed_precision)   # [h,w,384]
         return f.permute(2, 0, 1)[None, None], i.permute(2, 0, 1)[None, None], None
 
     def forward(self, events, images, reinit_hidden=False, out_scale=1.0):

@@ -32,17 +32,32 @@ class GraphPlan:
     __slots__ = ("ix", "jx", "ix_raw", "jx_raw", "mask_ix", "mask_jx", "g_kk", "g_ij", "max_kk", "max_ij", "E")
 
     @staticmethod
-    def build(ii, jj, kk, kk_bound=0, jj_bound=0, max_kk=None, max_ij=None):
+    def build(ii, jj, kk, kk_bound=0, jj_bound=0, max_kk=None, max_ij=None, kk_range=None, frame_range=None):
+        """kk_range=(lo, hi) / frame_range=(lo, hi): tight half-open ranges of kk and of the frame
+        indices in ii, jj when the caller knows them (the tracker does): the groupings then come
+        from the counting group-by and the neighbours from the kk groups, no radix sort."""
         p = GraphPlan()
         p.E = ii.shape[0]
-        p.ix, p.jx = ops.neighbors(kk, jj, kk_bound, jj_bound)
+        small = (kk_range is not None and frame_range is not None and max_kk is not None and max_ij is not None
+                 and ii.is_cuda and hasattr(ops, "group_by_small"))
+        if small:
+            k_lo, k_hi = int(kk_range[0]), int(kk_range[1])
+            f_lo, f_hi = int(frame_range[0]), int(frame_range[1])
+            W = max(f_hi - f_lo, 1)
+            p.g_kk = ops.group_by_small(kk, None, 1, k_lo, max(k_hi - k_lo, 1), max_kk)
+            p.g_ij = ops.group_by_small(ii, jj, W, f_lo * W + f_lo, W * W, max_ij)
+            p.ix, p.jx = ops.neighbors_from_groups(p.g_kk, jj, max_kk)
+        else:
+            p.ix, p.jx = ops.neighbors(kk, jj, kk_bound, jj_bound)
+            p.g_kk = ops.group_by(kk, kk_bound)
+            # keyed by (ii, jj) lexicographically -- the same partition / order as ii*12345+jj
+            nb = int(jj_bound) if jj_bound else 0
+            p.g_ij = ops.group_by(ii * (nb if nb else 12345) + jj, nb * nb if nb else 0)
         p.ix_raw, p.jx_raw = p.ix, p.jx
         p.mask_ix = (p.ix >= 0).reshape(1, -1, 1)
         p.mask_jx = (p.jx >= 0).reshape(1, -1, 1)
         p.ix = p.ix.clamp(min=0)
         p.jx = p.jx.clamp(min=0)
-        p.g_kk = ops.group_by(kk, kk_bound)
-        p.g_ij = ops.group_by(ii * 12345 + jj, 0 if not jj_bound else int(jj_bound) * 12346)
         # group counts: caller-supplied upper bounds avoid a device->host read-back
         p.max_kk = int(max_kk) if max_kk is not None else int(p.g_kk.ngroups.item())
         p.max_ij = int(max_ij) if max_ij is not None else int(p.g_ij.ngroups.item())

@@ -167,6 +167,41 @@ def group_by(keys, key_bound=0):
     return g
 
 
+def group_by_small(a, b, mul, sub, K, max_groups=0):
+    """group_by for keys a*mul + b - sub known to lie in [0, K) (counting sort, 5 short kernels)"""
+    require_cuda(a)
+    a = _idx(a)
+    b = _idx(b) if b is not None else None
+    E = a.shape[0]
+    dev = a.device
+    g = Groups()
+    g.E = E
+    g.order = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+    g.gid = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+    g.seg_start = torch.empty(E + 1, dtype=torch.int32, device=dev)
+    g.ukeys = torch.empty(max(E, 1), dtype=torch.int64, device=dev)
+    g.ngroups = torch.empty(1, dtype=torch.int32, device=dev)
+    nbytes = lib().ramp_group_by_small_workspace_bytes(E, int(K))
+    ws = _lib.workspace(nbytes, dev, "graph")
+    check(lib().ramp_group_by_small(ptr(a), ptr(b), int(mul), int(sub), int(K), E, ptr(g.order), ptr(g.gid),
+                                    ptr(g.seg_start), ptr(g.ukeys), ptr(g.ngroups), int(max_groups), ptr(ws),
+                                    ws.numel(), stream()), "ramp_group_by_small")
+    return g
+
+
+def neighbors_from_groups(groups, jj, max_groups):
+    """cuda_ba.neighbors(kk, jj) from the per-kk groups (no extra sort)"""
+    require_cuda(jj)
+    jj = _idx(jj)
+    E = jj.shape[0]
+    ix = torch.empty(E, dtype=torch.int64, device=jj.device)
+    jx = torch.empty(E, dtype=torch.int64, device=jj.device)
+    check(lib().ramp_neighbors_from_groups(ptr(groups.order), ptr(groups.seg_start), ptr(groups.ngroups), ptr(jj),
+                                           ptr(ix), ptr(jx), E, int(max_groups), stream()),
+          "ramp_neighbors_from_groups")
+    return ix, jx
+
+
 def neighbors(kk, jj, kk_bound=0, jj_bound=0):
     require_cuda(kk, jj)
     kk, jj = _idx(kk), _idx(jj)
@@ -199,7 +234,7 @@ def segment_softmax_sum(fx, gx, groups, max_groups):
 
 # -------------------------------------------------------------------- fastba
 def ba(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t1, iterations=2,
-       info=None):
+       info=None, plan=None):
     """in-place bundle adjustment (cuda_ba.forward).  poses [..,7] and patches
     [..,3,P,P] must be contiguous float32 views of the caller's storage."""
     require_cuda(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk)
@@ -215,6 +250,19 @@ def ba(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t1, it
     lmbda = lmbda.reshape(-1).contiguous().float()
     E = ii.shape[0]
     assert target.shape[0] == E and weight.shape[0] == E
+    if plan is not None:
+        # groupings shared with the update operator (GraphPlan): no sort inside BA
+        gk, gp = plan.g_kk, plan.g_ij
+        mk, mp = max(int(plan.max_kk), 1), max(int(plan.max_ij), 1)
+        nbytes = lib().ramp_ba_planned_workspace_bytes(E, n_poses, n_patches, int(t0), int(t1), mk, mp)
+        ws = _lib.workspace(nbytes, poses.device, "ba")
+        check(lib().ramp_ba_forward_planned(ptr(poses), ptr(patches), ptr(intrinsics), ptr(target), ptr(weight),
+                                            ptr(lmbda), ptr(_idx(ii)), ptr(_idx(jj)), ptr(_idx(kk)), E, P, n_poses,
+                                            n_patches, int(t0), int(t1), int(iterations), ptr(gk.order),
+                                            ptr(gk.seg_start), ptr(gk.ngroups), ptr(gk.ukeys), mk, ptr(gp.order),
+                                            ptr(gp.seg_start), ptr(gp.ngroups), mp, ptr(ws), ws.numel(), ptr(info),
+                                            stream()), "ramp_ba_forward_planned")
+        return
     nbytes = lib().ramp_ba_workspace_bytes(E, n_poses, n_patches, int(t0), int(t1))
     ws = _lib.workspace(nbytes, poses.device, "ba")
     check(lib().ramp_ba_forward(ptr(poses), ptr(patches), ptr(intrinsics), ptr(target),

@@ -55,6 +55,61 @@ def test_conv_mfma_matches_torch(cin, cout, k, stride, hw):
         assert float((conv_hip.materialize(p) - refn).abs().max()) <= 2e-3
 
 
+@pytest.mark.parametrize("cin,cout,k,stride,hw,first", [(16, 32, 7, 2, (48, 64), True), (32, 32, 3, 1, (37, 53), False),
+                                                         (32, 64, 3, 2, (40, 56), False), (64, 64, 3, 1, (20, 28), False),
+                                                         (32, 64, 1, 2, (40, 56), False), (64, 384, 1, 1, (21, 29), False)])
+def test_conv_mfma_f16_matches_torch(cin, cout, k, stride, hw, first):
+    """fp16 storage / fp16 MFMA (fp32 accumulate) against fp32 torch on the fp16-rounded operands"""
+    from rampvo_amd import conv_hip
+    torch.manual_seed(2)
+    real_cin = 15 if cin == 16 else cin
+    conv = nn.Conv2d(real_cin, cout, k, stride=stride, padding=k // 2).cuda()
+    with torch.no_grad():
+        conv.weight.copy_(conv.weight.half().float())
+        x = torch.randn(hw[0], hw[1], cin, device="cuda").half().float()
+        if cin == 16:
+            x[..., 15] = 0
+        xin = x if first else x.half()
+        ref = _ref_conv(x, conv)
+        y = conv_hip.conv2d(xin, conv, half=True)
+        assert y.dtype == torch.float16 and y.shape == ref.shape
+        tol = 2e-3 * float(ref.abs().max())
+        assert float((y.float() - ref).abs().max()) <= tol
+        sc, sh = torch.rand(cin, device="cuda") + 0.5, torch.randn(cin, device="cuda") * 0.1
+        xq = F.relu(x * sc + sh).half().float()           # the kernel rounds the normalised input to half
+        if cin == 16:
+            xq[..., 15] = 0
+        res = torch.randn(ref.shape, device="cuda").half()
+        ref2 = F.relu(res.float() + F.relu(_ref_conv(xq, conv))) * 0.25
+        y2 = conv_hip.conv2d(xin, conv, pre=(sc, sh), res=res, relu=True, out_scale=0.25, half=True)
+        assert float((y2.float() - ref2).abs().max()) <= 2 * tol
+        p = conv_hip.conv2d(xin, conv, want_stats=True, half=True)
+        refn = F.relu(F.instance_norm(ref.permute(2, 0, 1)[None], eps=1e-5))[0].permute(1, 2, 0)
+        assert float((conv_hip.materialize(p).float() - refn).abs().max()) <= 1e-2
+
+
+def test_singlescale_encoder_half_vs_fp32():
+    from rampvo_amd import conv
+    from rampvo_amd.synthetic import SyntheticStream, make_network
+    net = make_network("SingleScale")
+    enc = net.patchify.encoder
+    stream = SyntheticStream(96, 128, 3, seed=6)
+    outs = {}
+    with torch.no_grad():
+        for half in (False, True):
+            enc.mixed_precision = half
+            res = []
+            for t in range(3):
+                im, ev, _, _ = stream.frame(t)
+                f, i, _ = enc(events=ev.cuda(), images=im.cuda(), reinit_hidden=(t == 0), out_scale=0.25)
+                res.append((f.float().clone(), i.float().clone()))
+            outs[half] = res
+    enc.mixed_precision = False
+    for (f0, i0), (f1, i1) in zip(outs[False], outs[True]):
+        assert float((f0 - f1).abs().max()) <= 3e-2 * float(f0.abs().max())
+        assert float((i0 - i1).abs().max()) <= 3e-2 * float(i0.abs().max())
+
+
 def test_lstm_superstate_kernel_matches_torch():
     from rampvo_amd import conv_hip
     from rampvo_amd.extractor import MergerLSTMsceneEncoder

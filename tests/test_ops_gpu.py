@@ -202,6 +202,50 @@ def test_group_by_and_neighbors_exact():
         assert np.array_equal(ix.cpu().numpy(), rix) and np.array_equal(jx.cpu().numpy(), rjx)
 
 
+def test_group_by_small_and_neighbors_from_groups_exact():
+    from rampvo_amd import ops
+    rng = np.random.default_rng(14)
+    E = 6000
+    kk = (rng.integers(0, 260, E) + 1000).astype(np.int64)
+    ii = kk // 13
+    jj = (rng.integers(0, 30, E) + 70).astype(np.int64)
+    g = ops.group_by_small(cu(kk), None, 1, 1000, 260, 300)
+    uk, inv = np.unique(kk, return_inverse=True)
+    G = int(g.ngroups.item())
+    assert G == len(uk) and np.array_equal(g.ukeys[:G].cpu().numpy(), uk)
+    assert np.array_equal(g.gid[:E].cpu().numpy(), inv)
+    assert np.array_equal(g.order[:E].cpu().numpy(), np.argsort(kk, kind="stable"))
+    seg = g.seg_start[:G + 1].cpu().numpy()
+    assert seg[0] == 0 and seg[-1] == E and np.all(np.diff(seg) == np.bincount(inv))
+    f_lo, f_hi = int(min(ii.min(), jj.min())), int(max(ii.max(), jj.max())) + 1
+    W = f_hi - f_lo
+    gp = ops.group_by_small(cu(ii), cu(jj), W, f_lo * W + f_lo, W * W, 0)
+    key = ii * 4096 + jj
+    uk2, inv2 = np.unique(key, return_inverse=True)
+    assert int(gp.ngroups.item()) == len(uk2) and np.array_equal(gp.gid[:E].cpu().numpy(), inv2)
+    assert np.array_equal(gp.order[:E].cpu().numpy(), np.argsort(key, kind="stable"))
+    rix, rjx = orc.neighbors(kk, jj)
+    ix, jx = ops.neighbors_from_groups(g, cu(jj), 300)
+    assert np.array_equal(ix.cpu().numpy(), rix) and np.array_equal(jx.cpu().numpy(), rjx)
+
+
+def test_ba_with_shared_plan_equals_self_grouped():
+    from rampvo_amd import ops
+    from rampvo_amd.net import GraphPlan
+    s = ba_scene(seed=17, n_frames=9, M=14, lifetime=4, n_total_frames=16, far=True)
+    outs = []
+    for use_plan in (False, True):
+        poses, patches = cu(s["poses"]), cu(s["patches"])
+        plan = None
+        if use_plan:
+            plan = GraphPlan.build(cu(s["ii"]), cu(s["jj"]), cu(s["kk"]), max_kk=9 * 14, max_ij=81,
+                                   kk_range=(0, 9 * 14), frame_range=(0, 9))
+        ops.ba(poses, patches, cu(s["intr"]), cu(s["target"]), cu(s["weight"]), cu(s["lmbda"]), cu(s["ii"]),
+               cu(s["jj"]), cu(s["kk"]), 3, 9, 2, plan=plan)
+        outs.append((poses.cpu().numpy(), patches.cpu().numpy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
 def test_group_by_empty_and_single():
     from rampvo_amd import ops
     g = ops.group_by(torch.zeros(0, dtype=torch.int64, device="cuda"))
