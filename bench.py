@@ -50,7 +50,9 @@ def parse():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--patches", type=int, default=96)
     ap.add_argument("--mode", default="SingleScale")
-    ap.add_argument("--mixed", type=int, default=0, help="1: fp16 features/update operator like default.yaml")
+    ap.add_argument("--mixed", type=int, default=1,
+                    help="1 (default.yaml's MIXED_PRECISION: True): fp16 features / conv + GEMM I/O with fp32 "
+                         "accumulation, fp32 hidden state, BA and geometry; 0: fp32 everywhere")
     ap.add_argument("--cpu-steps", type=int, default=3, help="steps of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
@@ -108,8 +110,8 @@ def cpu_baseline(state, args, cfg_kwargs, frames, steps):
     from rampvo_amd.config import make_cfg
     from rampvo_amd.Ramp_vo import Ramp_vo
     from rampvo_amd.synthetic import make_network
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    cores = min(os.cpu_count() or 1, int(os.environ.get("RAMP_CPU_THREADS", "64")))
+    torch.set_num_threads(cores)      # also the OpenMP team of the oracle's edge-parallel loops
     cfg_kwargs = dict(cfg_kwargs, MIXED_PRECISION=False)       # the host path is fp32 throughout
     state = dict(state)
     for k in ("net", "imap", "gmap", "fmap1", "fmap2"):
@@ -130,7 +132,8 @@ def cpu_baseline(state, args, cfg_kwargs, frames, steps):
         dt = time.perf_counter() - tic
     return dict(value=round(steps / dt, 4), unit="keyframes/s", cores=cores, kind="port",
                 sample="%d steady-state steps (E~%d edges) from the GPU run's state snapshot; torch-CPU fp32 "
-                       "encoder/update GEMMs on %d threads + oracle C natives" % (steps, len(slam._ii), cores),
+                       "encoder/update GEMMs + OpenMP oracle C natives on %d threads (host has %d logical cores)"
+                       % (steps, len(slam._ii), cores, os.cpu_count() or 1),
                 s_per_step=round(dt / steps, 3))
 
 
@@ -206,7 +209,7 @@ def main():
             "metric": "keyframes/sec (BA iters/sec) SingleScale 640x480; ATE vs reference",
             "value": round(value, 3), "unit": "keyframes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt_all / args.steps, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f16/f32" if args.mixed else "f32",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16 storage+MFMA inputs / f32 accumulate, state, BA (default.yaml MIXED_PRECISION)" if args.mixed else "f32",
             "data": "synthetic (seeded 640x480 event+frame stream, seeded random-init weights)",
             "config": {"workload": "%s %dx%d, %d patches/frame, default.yaml windows, 2 BA iters/keyframe, "
                                    "steady-state sliding window" % (args.mode, args.width, args.height, args.patches),

@@ -116,7 +116,7 @@ STEP = dict(H=64, W=96, T=11, M=8, seed=99, OPTIMIZATION_WINDOW=5)
 
 
 @torch.no_grad()
-def check_update_step(device):
+def check_update_step(device, mixed=False):
     """teacher-forced: inject the reference's captured state, run ONE update(), compare with what the
     reference's update() produced from the same state (fixture update_step.npz)"""
     from rampvo_amd.config import make_cfg
@@ -125,7 +125,7 @@ def check_update_step(device):
     p = STEP
     g = gold("update_step.npz")
     net = make_network("SingleScale", device=device)
-    cfg = make_cfg("default", PATCHES_PER_FRAME=p["M"], MIXED_PRECISION=False,
+    cfg = make_cfg("default", PATCHES_PER_FRAME=p["M"], MIXED_PRECISION=mixed,
                    OPTIMIZATION_WINDOW=p["OPTIMIZATION_WINDOW"])
     slam = Ramp_vo(cfg, net, {"event_bias": True}, ht=p["H"], wd=p["W"], device=device)
     k = g["in_poses"].shape[0]
