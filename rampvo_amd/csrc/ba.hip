@@ -149,40 +149,56 @@ __global__ void __launch_bounds__(192)
     ba_pair_kernel(const float *__restrict__ rec, const int32_t *__restrict__ order,
                    const int32_t *__restrict__ seg, const int32_t *__restrict__ ngroups,
                    float *__restrict__ pairs, int32_t *__restrict__ pair_ij) {
+  __shared__ __attribute__((aligned(16))) float s_rec[48 * BA_REC];   // 48 records per batch
   const int g = blockIdx.x;
   if (g >= *ngroups) return;
   const int tid = threadIdx.x;
   const int s0 = seg[g], s1 = seg[g + 1];
-  if (tid == 0) {
-    const float *r = rec + (size_t)order[s0] * BA_REC;
-    pair_ij[2 * g + 0] = __float_as_int(r[R_I]);
-    pair_ij[2 * g + 1] = __float_as_int(r[R_J]);
-  }
-  if (tid >= 156) return;
-  float acc = 0.0f;
+  int blk = 0, x = 0, y = 0, oa = 0, ob = 0;
+  float sgn = 1.0f;
   if (tid < 144) {
-    const int blk = tid / 36, q = tid - blk * 36, x = q / 6, y = q - x * 6;
-    const int oa = (blk == 0 || blk == 2) ? R_JI0 : R_JJ0;  // left factor
-    const int ob = (blk == 0 || blk == 3) ? R_JI0 : R_JJ0;  // right factor
-    const float sgn = (blk >= 2) ? -1.0f : 1.0f;
-    for (int p = s0; p < s1; p++) {
-      const float *r = rec + (size_t)order[p] * BA_REC;
-      acc += ((sgn * r[R_W0]) * r[oa + x]) * r[ob + y];
-      acc += ((sgn * r[R_W1]) * r[oa + 6 + x]) * r[ob + 6 + y];
-    }
-  } else {
+    blk = tid / 36;
+    const int q = tid - blk * 36;
+    x = q / 6; y = q - x * 6;
+    oa = (blk == 0 || blk == 2) ? R_JI0 : R_JJ0;  // left factor
+    ob = (blk == 0 || blk == 3) ? R_JI0 : R_JJ0;  // right factor
+    sgn = (blk >= 2) ? -1.0f : 1.0f;
+  } else if (tid < 156) {
     const int q = tid - 144;
     const bool isj = q >= 6;
-    const int x = isj ? q - 6 : q;
-    const int oa = isj ? R_JJ0 : R_JI0;
-    const float sgn = isj ? 1.0f : -1.0f;
-    for (int p = s0; p < s1; p++) {
-      const float *r = rec + (size_t)order[p] * BA_REC;
-      acc += ((sgn * r[R_W0]) * r[R_R0]) * r[oa + x];
-      acc += ((sgn * r[R_W1]) * r[R_R1]) * r[oa + 6 + x];
+    x = isj ? q - 6 : q;
+    oa = isj ? R_JJ0 : R_JI0;
+    sgn = isj ? 1.0f : -1.0f;
+  }
+  float acc = 0.0f;
+  for (int b0 = s0; b0 < s1; b0 += 48) {
+    const int nb = min(48, s1 - b0);
+    __syncthreads();
+    for (int q = tid; q < nb * (BA_REC / 4); q += 192) {      // coalesced 16-byte loads of whole records
+      const int rr = q / (BA_REC / 4), cc = q - rr * (BA_REC / 4);
+      reinterpret_cast<float4 *>(s_rec)[q] =
+          reinterpret_cast<const float4 *>(rec + (size_t)order[b0 + rr] * BA_REC)[cc];
+    }
+    __syncthreads();
+    if (tid < 144) {
+      for (int p = 0; p < nb; p++) {
+        const float *r = s_rec + p * BA_REC;
+        acc += ((sgn * r[R_W0]) * r[oa + x]) * r[ob + y];
+        acc += ((sgn * r[R_W1]) * r[oa + 6 + x]) * r[ob + 6 + y];
+      }
+    } else if (tid < 156) {
+      for (int p = 0; p < nb; p++) {
+        const float *r = s_rec + p * BA_REC;
+        acc += ((sgn * r[R_W0]) * r[R_R0]) * r[oa + x];
+        acc += ((sgn * r[R_W1]) * r[R_R1]) * r[oa + 6 + x];
+      }
+    }
+    if (b0 == s0 && tid == 0) {
+      pair_ij[2 * g + 0] = __float_as_int(s_rec[R_I]);
+      pair_ij[2 * g + 1] = __float_as_int(s_rec[R_J]);
     }
   }
-  pairs[(size_t)g * BA_PAIR + tid] = acc;
+  if (tid < 156) pairs[(size_t)g * BA_PAIR + tid] = acc;
 }
 
 // ------------------------------------------------------------------ K4
@@ -302,6 +318,7 @@ __global__ void __launch_bounds__(256)
       }
     }
     float sp = 0.0f;
+#pragma unroll 8
     for (int z = 0; z < KS; z++) sp += S_part[((size_t)z * n6 + r) * n6 + c];
     float s = bsum - sp;
     if (r == c) s += (1e-4f * s + 1.0f);
@@ -372,49 +389,53 @@ __global__ void __launch_bounds__(1024)
   for (int q = tid; q < n6; q += nt) dX[q] = t[q];
 }
 
-// single-wavefront variant for 6N <= 64 (default.yaml: 60): lane i owns row i, no multi-wave
-// barriers; the per-element operation order is the same as in ba_chol_kernel.
+// single-wavefront variant for 6N <= 64 (default.yaml: 60).  Lane i keeps ROW i of the matrix in
+// 64 registers; column values are broadcast with v_readlane (constant lane index after full
+// unrolling), so the factorisation is ~2000 straight-line readlane+fma pairs, no LDS, no barriers.
+// Per-element update order (j ascending, separate mul/sub) is that of the textbook loop.
+__device__ __forceinline__ float bcast_lane(float v, int lane_const) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_const));
+}
+
 __global__ void __launch_bounds__(64)
     ba_chol64_kernel(const float *__restrict__ S, const float *__restrict__ yv,
                      float *__restrict__ dX, int32_t *__restrict__ info, int n6) {
-  __shared__ float A[64 * 65];
-  __shared__ float t[64];
   const int i = threadIdx.x;
-  const int ld = 65;
-  if (i < n6) {
-    for (int c = 0; c < n6; c++) A[i * ld + c] = S[(size_t)i * n6 + c];
-    t[i] = yv[i];
-  }
-  __syncthreads();
-  for (int j = 0; j < n6; j++) {
-    if (i == j) {
-      const float dgn = A[j * ld + j];
-      if (!(dgn > 0.0f) && info) *info = 1;
-      A[j * ld + j] = sqrtf(dgn);
+  float a[64];
+#pragma unroll
+  for (int k = 0; k < 64; k++)
+    a[k] = (i < n6 && k < n6) ? (k <= i ? S[(size_t)i * n6 + k] : 0.0f) : (k == i ? 1.0f : 0.0f);
+  float t = i < n6 ? yv[i] : 0.0f;
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < 64; j++) {
+    const float dgn = bcast_lane(a[j], j);
+    bad |= !(dgn > 0.0f);
+    const float ljj = sqrtf(dgn);
+    a[j] = (i > j) ? a[j] / ljj : (i == j ? ljj : a[j]);
+#pragma unroll
+    for (int k = j + 1; k < 64; k++) {
+      const float lkj = bcast_lane(a[j], k);
+      if (i >= k) a[k] = a[k] - a[j] * lkj;
     }
-    __syncthreads();
-    const float ljj = A[j * ld + j];
-    if (i > j && i < n6) A[i * ld + j] = A[i * ld + j] / ljj;
-    __syncthreads();
-    if (i > j && i < n6) {
-      const float lij = A[i * ld + j];
-      for (int k = j + 1; k <= i; k++) A[i * ld + k] = A[i * ld + k] - lij * A[k * ld + j];
-    }
-    __syncthreads();
   }
-  for (int k = 0; k < n6; k++) {
-    if (i == k) t[k] = t[k] / A[k * ld + k];
-    __syncthreads();
-    if (i > k && i < n6) t[i] = t[i] - A[i * ld + k] * t[k];
-    __syncthreads();
+  if (bad && i == 0 && info) *info = 1;
+  // forward substitution  L z = y
+#pragma unroll
+  for (int k = 0; k < 64; k++) {
+    const float zk = bcast_lane(t, k) / bcast_lane(a[k], k);
+    t = (i == k) ? zk : (i > k ? t - a[k] * zk : t);
   }
-  for (int k = n6 - 1; k >= 0; k--) {
-    if (i == k) t[k] = t[k] / A[k * ld + k];
-    __syncthreads();
-    if (i < k) t[i] = t[i] - A[k * ld + i] * t[k];
-    __syncthreads();
+  // backward substitution  L' x = z :  x_i = (z_i - sum_{k>i} L[k][i] x_k) / L[i][i]
+  float x = 0.0f;
+#pragma unroll
+  for (int r = 63; r >= 0; r--) {
+    float part = (i > r) ? a[r] * x : 0.0f;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+    if (i == r) x = (t - part) / a[r];
   }
-  if (i < n6) dX[i] = t[i];
+  if (i < n6) dX[i] = x;
 }
 
 // ------------------------------------------------------------------ K7
@@ -489,7 +510,7 @@ static size_t ba_carve(void *ws, int E, int n_poses, int n_patches, int N, int o
   w->tiles = (n6 + BA_TS - 1) / BA_TS;
   if (w->tiles < 1) w->tiles = 1;
   int ks = 256 / (w->tiles * w->tiles);
-  w->KS = ks < 4 ? 4 : (ks > 64 ? 64 : ks);
+  w->KS = ks < 4 ? 4 : (ks > 16 ? 16 : ks);
   w->gb = nullptr; w->gb_bytes = 0;
   w->pkeys = w->kx = w->pukeys = nullptr;
   w->order_k = w->seg_k = w->order_p = w->seg_p = nullptr;
