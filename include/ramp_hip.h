@@ -115,6 +115,20 @@ int ramp_reproject(const float *poses, const float *patches, const float *intrin
 int ramp_point_cloud(const float *poses, const float *patches, const float *intrinsics,
                      const int64_t *ix, float *out, int m, int P, void *stream);
 
+/* Ramp_vo.motionmag(i, j) and motionmag(j, i) in one launch (ramp/Ramp_vo.py:227-243 over
+ * pops.flow_mag, projective_ops.py:108-118, beta-weighted full / translation-only flow).  The
+ * edges of each direction are located through the (ii, jj) grouping of ramp_group_by[_small]
+ * (order / seg / sorted unique keys / ngroups); key_ij, key_ji are the two pair keys in that
+ * grouping's key space.  out2[0] = mean flow i->j, out2[1] = j->i (NaN when a direction has no edge). */
+int ramp_motionmag(const float *poses, const float *patches, const float *intrinsics,
+                   const int64_t *ii, const int64_t *jj, const int64_t *kk, const int32_t *order,
+                   const int32_t *seg, const int64_t *ukeys, const int32_t *ngroups, int64_t key_ij,
+                   int64_t key_ji, float beta, float *out2, int P, void *stream);
+
+/* DAMPED_LINEAR motion model (ramp/Ramp_vo.py:356-363; 5 lietorch launches upstream):
+ * poses[n] = Exp(damping * Log(poses[n-1] * poses[n-2]^-1)) * poses[n-1]                      */
+int ramp_motion_model(float *poses, int n, float damping, void *stream);
+
 /* ------------------------------------------------------------------- graph */
 /* group the E edges by an int64 key (device-side replacement of the
  * torch.unique / torch::_unique / std::stable_sort host round trips at

@@ -242,14 +242,14 @@ class Ramp_vo:
 
     def _graph_plan(self):
         if self._plan is None or self._plan.E != len(self._ii):
-            fr = self._kk // self.M
-            nfr = len(np.unique(fr)) if len(fr) else 0
-            pairs = len(np.unique(self._ii * self.N + self._jj)) if len(self._ii) else 0
+            k_lo, k_hi = int(self._kk.min()), int(self._kk.max()) + 1
             f_lo = int(min(self._ii.min(), self._jj.min()))
             f_hi = int(max(self._ii.max(), self._jj.max())) + 1
+            # group-count upper bounds from the ranges (no host-side unique, no device read-back)
+            max_kk = (k_hi // self.M - k_lo // self.M + 1) * self.M
+            max_ij = min((f_hi - f_lo) ** 2, len(self._ii))
             self._plan = GraphPlan.build(self.ii, self.jj, self.kk, kk_bound=self.N * self.M, jj_bound=self.N,
-                                         max_kk=nfr * self.M, max_ij=pairs,
-                                         kk_range=(int(self._kk.min()), int(self._kk.max()) + 1),
+                                         max_kk=max_kk, max_ij=max_ij, kk_range=(k_lo, k_hi),
                                          frame_range=(f_lo, f_hi))
         return self._plan
 
@@ -288,11 +288,16 @@ class Ramp_vo:
         return torch.quantile(delta.norm(dim=-1).float(), 0.5)
 
     def _motionmag_pair(self, i, j):
-        """mean patch flow i->j and j->i in one device pass: 0.5*(mag(i,j)+mag(j,i)) (reference :227-243)"""
-        sel_f = np.nonzero((self._ii == i) & (self._jj == j))[0]
-        sel_b = np.nonzero((self._ii == j) & (self._jj == i))[0]
+        """0.5*(motionmag(i,j) + motionmag(j,i)) (reference :227-243).  GPU: one fused kernel over the
+        pair grouping of the current graph plan + one read-back (the frame's only sync)."""
+        if self.device.type == "cuda":
+            plan = self._graph_plan()
+            mm = ops.motionmag(self.poses, self.patches, self.intrinsics, self.ii, self.jj, self.kk, plan.g_ij,
+                               i * plan.pair_mul + j, j * plan.pair_mul + i, beta=0.5)
+            return float(mm.mean().item())
         mags = []
-        for sel in (sel_f, sel_b):
+        for a, b in ((i, j), (j, i)):
+            sel = np.nonzero((self._ii == a) & (self._jj == b))[0]
             if len(sel) == 0:
                 mags.append(torch.full((), float("nan"), device=self.device))
                 continue
@@ -303,22 +308,25 @@ class Ramp_vo:
         return float(((mags[0] + mags[1]) / 2).item())
 
     def keyframe(self):
-        """drop keyframe n-KEYFRAME_INDEX if the motion around it is small (reference :237-274)"""
+        """drop keyframe n-KEYFRAME_INDEX if the motion around it is small, then cull factors older
+        than REMOVAL_WINDOW (reference :237-274).  Both removals are decided on the host mirror and
+        applied to the device state as ONE compaction."""
         i = self.n - self.cfg.KEYFRAME_INDEX - 1
         j = self.n - self.cfg.KEYFRAME_INDEX + 1
         m = self._motionmag_pair(i, j)
+        keep = np.ones(len(self._ii), bool)
+        ii, jj, kk = self._ii, self._jj, self._kk
         if m < self.cfg.KEYFRAME_THRESH:
             k = self.n - self.cfg.KEYFRAME_INDEX
             ts = self.tstamps_[k - 1:k + 1].tolist()
             t0, t1 = ts[0], ts[1]
             dP = SE3(self.poses_[k]) * SE3(self.poses_[k - 1]).inv()
             self.delta[t1] = (t0, dP)
-            self.remove_factors((self._ii == k) | (self._jj == k))
-            self._kk[self._ii > k] -= self.M
-            self._ii[self._ii > k] -= 1
-            self._jj[self._jj > k] -= 1
-            self.kk, self.ii, self.jj = self._upload(self._kk), self._upload(self._ii), self._upload(self._jj)
-            self._plan = None
+            keep &= ~((ii == k) | (jj == k))
+            ii, jj, kk = ii.copy(), jj.copy(), kk.copy()
+            kk[ii > k] -= self.M
+            ii[ii > k] -= 1
+            jj[jj > k] -= 1
             # shift the per-frame state down by one row (reference: python loop of row copies)
             n = self.n
             for buf in (self.tstamps_, self.colors_, self.poses_, self.patches_, self.intrinsics_):
@@ -329,7 +337,16 @@ class Ramp_vo:
                 buf[dst] = buf[src]
             self.n -= 1
             self.m -= self.M
-        self.remove_factors((self._kk // self.M) < self.n - self.cfg.REMOVAL_WINDOW)
+        keep &= ~((kk // self.M) < self.n - self.cfg.REMOVAL_WINDOW)
+        changed = (ii is not self._ii) or not keep.all()
+        if not changed:
+            return
+        idx = np.nonzero(keep)[0]
+        self._ii, self._jj, self._kk = ii[idx], jj[idx], kk[idx]
+        self.ii, self.jj, self.kk = self._upload(self._ii), self._upload(self._jj), self._upload(self._kk)
+        if len(idx) != self.net.shape[1]:
+            self.net = self.net[:, self._upload(idx)]
+        self._plan = None
 
     # ------------------------------------------------------------------- update
     def update(self):
@@ -390,7 +407,9 @@ class Ramp_vo:
         self.colors_[n] = clr.to(torch.uint8)
 
         if n > 1:
-            if self.cfg.MOTION_MODEL == 'DAMPED_LINEAR':
+            if self.cfg.MOTION_MODEL == 'DAMPED_LINEAR' and self.device.type == "cuda":
+                ops.motion_model(self.poses_, n, self.cfg.MOTION_DAMPING)     # one fused kernel
+            elif self.cfg.MOTION_MODEL == 'DAMPED_LINEAR':
                 P1 = SE3(self.poses_[n - 1])
                 P2 = SE3(self.poses_[n - 2])
                 xi = self.cfg.MOTION_DAMPING * (P1 * P2.inv()).log()
@@ -418,8 +437,9 @@ class Ramp_vo:
 
         self.n += 1
         self.m += self.M
-        self.append_factors(*self.__edges_forw())
-        self.append_factors(*self.__edges_back())
+        kf, jf = self.__edges_forw()
+        kb, jb = self.__edges_back()
+        self.append_factors(np.concatenate([kf, kb]), np.concatenate([jf, jb]))    # one upload for both
 
         if self.n == 8 and not self.is_initialized:
             self.is_initialized = True

@@ -208,7 +208,121 @@ __global__ void __launch_bounds__(LIE_THREADS)
   out[3 * (size_t)n + 2] = X1[2] / X1[3];
 }
 
+// Ramp_vo.motionmag both ways in one launch (ramp/Ramp_vo.py:227-243, pops.flow_mag :108-118):
+// block b (0: i->j, 1: j->i) finds its (ii,jj) segment in the pair grouping by binary search on
+// the sorted unique pair keys and reduces mean(beta*|x_full - x_0| + (1-beta)*|x_tonly - x_0|)
+// over the segment's edges x 9 patch pixels in a fixed order.
+template <int P>
+__device__ __forceinline__ void mm_project(const float *t, const float *q, const float *pt, int a,
+                                           const float *Ki, const float *Kj, float *xy) {
+  float X0[4], X1[4];
+  X0[0] = (pt[a] - Ki[2]) / Ki[0];
+  X0[1] = (pt[P * P + a] - Ki[3]) / Ki[1];
+  X0[2] = 1.0f;
+  X0[3] = pt[2 * P * P + a];
+  lt_act4_tq(t, q, X0, X1);
+  const float Z = X1[2] < 0.1f ? 0.1f : X1[2];
+  const float d = 1.0f / Z;
+  xy[0] = Kj[0] * (d * X1[0]) + Kj[2];
+  xy[1] = Kj[1] * (d * X1[1]) + Kj[3];
+}
+
+template <int P>
+__global__ void __launch_bounds__(256)
+    motionmag_kernel(const float *__restrict__ poses, const float *__restrict__ patches,
+                     const float *__restrict__ intr, const int64_t *__restrict__ ii,
+                     const int64_t *__restrict__ jj, const int64_t *__restrict__ kk,
+                     const int32_t *__restrict__ order, const int32_t *__restrict__ seg,
+                     const int64_t *__restrict__ ukeys, const int32_t *__restrict__ ngroups,
+                     long key0, long key1, float beta, float *__restrict__ out) {
+  __shared__ float s_part[256];
+  __shared__ int s_seg[2];
+  const long key = blockIdx.x == 0 ? key0 : key1;
+  if (threadIdx.x == 0) {
+    int lo = 0, hi = *ngroups - 1, g = -1;
+    while (lo <= hi) {
+      const int mid = (lo + hi) >> 1;
+      const long v = ukeys[mid];
+      if (v == key) { g = mid; break; }
+      if (v < key) lo = mid + 1; else hi = mid - 1;
+    }
+    s_seg[0] = g < 0 ? 0 : seg[g];
+    s_seg[1] = g < 0 ? 0 : seg[g + 1];
+  }
+  __syncthreads();
+  const int s0 = s_seg[0], n = s_seg[1] - s0;
+  float acc = 0.0f;
+  for (int p = threadIdx.x; p < n; p += 256) {
+    const int e = order[s0 + p];
+    const long i = ii[e], j = jj[e], k = kk[e];
+    float Ti[7], Tj[7], Tinv[7], G[7], G0[7], t[3], q[4], t0[3], q0[4], tt[3];
+    for (int c = 0; c < 7; c++) { Ti[c] = poses[7 * i + c]; Tj[c] = poses[7 * j + c]; }
+    lt_inv(Ti, Tinv);
+    lt_mul(Tj, Tinv, G);       // i -> j
+    lt_mul(Ti, Tinv, G0);      // i -> i (the reference evaluates this too)
+    lt_load(G, t, q);
+    lt_load(G0, t0, q0);
+    float Gt[7] = {G[0], G[1], G[2], 0.f, 0.f, 0.f, 1.f}, qt[4];
+    lt_load(Gt, tt, qt);
+    const float *pt = patches + (size_t)k * 3 * P * P;
+    const float *Ki = intr + 4 * i, *Kj = intr + 4 * j;
+    float s = 0.0f;
+#pragma unroll
+    for (int a = 0; a < P * P; a++) {
+      float c0[2], c1[2], c2[2];
+      mm_project<P>(t0, q0, pt, a, Ki, Ki, c0);
+      mm_project<P>(t, q, pt, a, Ki, Kj, c1);
+      mm_project<P>(tt, qt, pt, a, Ki, Kj, c2);
+      const float f1 = sqrtf((c1[0] - c0[0]) * (c1[0] - c0[0]) + (c1[1] - c0[1]) * (c1[1] - c0[1]));
+      const float f2 = sqrtf((c2[0] - c0[0]) * (c2[0] - c0[0]) + (c2[1] - c0[1]) * (c2[1] - c0[1]));
+      s += beta * f1 + (1 - beta) * f2;
+    }
+    acc += s;
+  }
+  s_part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) s_part[threadIdx.x] += s_part[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = n > 0 ? s_part[0] / (float)(n * P * P) : __int_as_float(0x7fc00000);
+}
+
+// DAMPED_LINEAR motion model (ramp/Ramp_vo.py:356-363): poses[n] = Exp(d * Log(P1 * P2^-1)) * P1
+__global__ void motion_model_kernel(float *poses, int n, float damping) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float P1[7], P2[7], P2i[7], D[7], xi[6], E[7], Pn[7];
+  for (int c = 0; c < 7; c++) { P1[c] = poses[7 * (n - 1) + c]; P2[c] = poses[7 * (n - 2) + c]; }
+  lt_inv(P2, P2i);
+  lt_mul(P1, P2i, D);
+  lt_log(D, xi);
+  for (int c = 0; c < 6; c++) xi[c] = damping * xi[c];
+  lt_exp(xi, E);
+  lt_mul(E, P1, Pn);
+  for (int c = 0; c < 7; c++) poses[7 * n + c] = Pn[c];
+}
+
 extern "C" {
+int ramp_motionmag(const float *poses, const float *patches, const float *intrinsics,
+                   const int64_t *ii, const int64_t *jj, const int64_t *kk, const int32_t *order,
+                   const int32_t *seg, const int64_t *ukeys, const int32_t *ngroups, int64_t key_ij,
+                   int64_t key_ji, float beta, float *out2, int P, void *stream) {
+  if (!poses || !patches || !intrinsics || !ii || !jj || !kk || !order || !seg || !ukeys || !ngroups ||
+      !out2)
+    return RAMP_EINVAL;
+  if (P != 3) return RAMP_EUNSUPPORTED;
+  hipLaunchKernelGGL(motionmag_kernel<3>, dim3(2), dim3(256), 0, (hipStream_t)stream, poses, patches,
+                     intrinsics, ii, jj, kk, order, seg, ukeys, ngroups, (long)key_ij, (long)key_ji, beta,
+                     out2);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+int ramp_motion_model(float *poses, int n, float damping, void *stream) {
+  if (!poses || n < 2) return RAMP_EINVAL;
+  hipLaunchKernelGGL(motion_model_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, poses, n, damping);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
 int ramp_transform(const float *poses, const float *patches, const float *intrinsics,
                    const int64_t *ii, const int64_t *jj, const int64_t *kk, float *out, int E,
                    int P, int tonly, void *stream) {

@@ -29,7 +29,8 @@ class GraphPlan:
     """Per-graph index structures shared by the Update operator and BA: temporal
     neighbours and the two SoftAgg groupings.  Built on the device in one go
     (``build``); ``Ramp_vo`` rebuilds it only when the factor graph changes."""
-    __slots__ = ("ix", "jx", "ix_raw", "jx_raw", "mask_ix", "mask_jx", "g_kk", "g_ij", "max_kk", "max_ij", "E")
+    __slots__ = ("ix", "jx", "ix_raw", "jx_raw", "mask_ix", "mask_jx", "g_kk", "g_ij", "max_kk", "max_ij", "E",
+                 "pair_mul")
 
     @staticmethod
     def build(ii, jj, kk, kk_bound=0, jj_bound=0, max_kk=None, max_ij=None, kk_range=None, frame_range=None):
@@ -46,18 +47,21 @@ class GraphPlan:
             W = max(f_hi - f_lo, 1)
             p.g_kk = ops.group_by_small(kk, None, 1, k_lo, max(k_hi - k_lo, 1), max_kk)
             p.g_ij = ops.group_by_small(ii, jj, W, f_lo * W + f_lo, W * W, max_ij)
+            p.pair_mul = W                 # g_ij.ukeys = ii * W + jj
             p.ix, p.jx = ops.neighbors_from_groups(p.g_kk, jj, max_kk)
         else:
             p.ix, p.jx = ops.neighbors(kk, jj, kk_bound, jj_bound)
             p.g_kk = ops.group_by(kk, kk_bound)
             # keyed by (ii, jj) lexicographically -- the same partition / order as ii*12345+jj
             nb = int(jj_bound) if jj_bound else 0
-            p.g_ij = ops.group_by(ii * (nb if nb else 12345) + jj, nb * nb if nb else 0)
+            p.pair_mul = nb if nb else 12345
+            p.g_ij = ops.group_by(ii * p.pair_mul + jj, nb * nb if nb else 0)
         p.ix_raw, p.jx_raw = p.ix, p.jx
-        p.mask_ix = (p.ix >= 0).reshape(1, -1, 1)
-        p.mask_jx = (p.jx >= 0).reshape(1, -1, 1)
-        p.ix = p.ix.clamp(min=0)
-        p.jx = p.jx.clamp(min=0)
+        if not ii.is_cuda:               # the ATen path of Update.forward wants masks + clamped indices
+            p.mask_ix = (p.ix >= 0).reshape(1, -1, 1)
+            p.mask_jx = (p.jx >= 0).reshape(1, -1, 1)
+            p.ix = p.ix.clamp(min=0)
+            p.jx = p.jx.clamp(min=0)
         # group counts: caller-supplied upper bounds avoid a device->host read-back
         p.max_kk = int(max_kk) if max_kk is not None else int(p.g_kk.ngroups.item())
         p.max_ij = int(max_ij) if max_ij is not None else int(p.g_ij.ngroups.item())
@@ -129,6 +133,10 @@ class Patchifier(nn.Module):
         else:
             raise ValueError(f"Invalid input mode: {input_mode}")
         self._grid = None
+        import os
+        self.use_graph = os.environ.get("RAMP_NO_GRAPH", "0") != "1"
+        self._graphs = {}
+        self._graph_warm = 0
 
     def _coord_grid(self, h, w, device):
         if self._grid is None or self._grid.shape[-2:] != (h, w) or self._grid.device != device:
@@ -139,6 +147,39 @@ class Patchifier(nn.Module):
 
     def forward(self, input_, patches_per_image=80, reinit_hidden=False, disps=None, event_bias=False,
                 gradient_bias=False):
+        """On the GPU the whole SingleScale front-end (fused LSTM, ~35 conv-tower launches, patch
+        selection, 4 patch gathers: ~60 launches of static shape) is captured into ONE hipGraph
+        after a warm-up call and replayed per frame; results live in the graph's static output
+        buffers until the next call (Ramp_vo copies them into its ring buffers immediately)."""
+        events, images, mask = input_
+        graphable = (self.use_graph and events.is_cuda and self.input_mode == "SingleScale" and event_bias
+                     and disps is None and not reinit_hidden and events.shape[1] == 1 and not torch.is_grad_enabled())
+        if not graphable:
+            self._graph_warm = 0 if reinit_hidden else self._graph_warm
+            return self._forward_impl(input_, patches_per_image, reinit_hidden, disps, event_bias, gradient_bias)
+        key = (tuple(events.shape), tuple(images.shape), patches_per_image, events.dtype, images.dtype,
+               bool(getattr(self.encoder, "mixed_precision", False)), events.device)
+        g = self._graphs.get(key)
+        if g is None:
+            if self._graph_warm < 1:      # one eager call with carried state first (allocator / pack caches warm)
+                self._graph_warm += 1
+                return self._forward_impl(input_, patches_per_image, False, None, event_bias, gradient_bias)
+            ev_s, im_s = events.clone(), images.clone()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                outs = self._forward_impl((ev_s, im_s, mask), patches_per_image, False, None, event_bias,
+                                          gradient_bias)
+            self._graphs[key] = g = (graph, ev_s, im_s, outs)
+            graph.replay()               # capture does not execute: run this frame now (inputs already staged)
+            return outs
+        graph, ev_s, im_s, outs = g
+        ev_s.copy_(events)
+        im_s.copy_(images)
+        graph.replay()
+        return outs
+
+    def _forward_impl(self, input_, patches_per_image=80, reinit_hidden=False, disps=None, event_bias=False,
+                      gradient_bias=False):
         events, images, mask = input_
         if self.input_mode == "SingleScale":
             fmap, imap, _ = self.encoder(events=events, images=images, reinit_hidden=reinit_hidden,

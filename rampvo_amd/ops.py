@@ -141,6 +141,28 @@ def point_cloud(poses, patches, intrinsics, ix):
     return out
 
 
+def motionmag(poses, patches, intrinsics, ii, jj, kk, pair_groups, key_ij, key_ji, beta=0.5):
+    """[mean flow i->j, mean flow j->i] (device tensor [2]); pair_groups: the (ii, jj) grouping"""
+    require_cuda(poses, patches, intrinsics, ii, jj, kk)
+    P = patches.shape[-1]
+    poses = poses.reshape(-1, 7).contiguous().float()
+    patches = patches.reshape(-1, 3, P, P).contiguous().float()
+    intrinsics = intrinsics.reshape(-1, 4).contiguous().float()
+    out = torch.empty(2, dtype=torch.float32, device=poses.device)
+    g = pair_groups
+    check(lib().ramp_motionmag(ptr(poses), ptr(patches), ptr(intrinsics), ptr(_idx(ii)), ptr(_idx(jj)),
+                               ptr(_idx(kk)), ptr(g.order), ptr(g.seg_start), ptr(g.ukeys), ptr(g.ngroups),
+                               int(key_ij), int(key_ji), float(beta), ptr(out), P, stream()), "ramp_motionmag")
+    return out
+
+
+def motion_model(poses, n, damping):
+    """in place: poses[n] = Exp(damping * Log(poses[n-1] * poses[n-2]^-1)) * poses[n-1]"""
+    require_cuda(poses)
+    assert poses.dtype == torch.float32 and poses.is_contiguous()
+    check(lib().ramp_motion_model(ptr(poses), int(n), float(damping), stream()), "ramp_motion_model")
+
+
 # --------------------------------------------------------------------- graph
 class Groups:
     """result of group_by: order/gid/seg_start/ukeys/ngroups (device tensors)"""
