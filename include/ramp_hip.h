@@ -129,6 +129,16 @@ int ramp_motionmag(const float *poses, const float *patches, const float *intrin
  * poses[n] = Exp(damping * Log(poses[n-1] * poses[n-2]^-1)) * poses[n-1]                      */
 int ramp_motion_model(float *poses, int n, float damping, void *stream);
 
+/* Tracker bookkeeping helpers (host-side pointer arrays, <= 10 buffers per call).
+ * ramp_multi_copy: dst[b][0:bytes[b]) = src[b][...] -- the per-frame stores of imap/gmap/fmap1/fmap2/
+ *   patches/colors into the state buffers (ramp/Ramp_vo.py:345-381) in one launch.
+ * ramp_shift_rows: rows k+1..nrows-1 of every buffer move down by one -- the keyframe-removal loop of
+ *   ramp/Ramp_vo.py:258-268; mod[b] > 0 marks a ring buffer (row r lives at slot r % mod[b]).        */
+int ramp_multi_copy(const void *const *src_host, void *const *dst_host, const long *bytes_host, int n,
+                    void *stream);
+int ramp_shift_rows(void *const *base_host, const long *row_bytes_host, const int *mod_host, int n, int k,
+                    int nrows, void *stream);
+
 /* ------------------------------------------------------------------- graph */
 /* group the E edges by an int64 key (device-side replacement of the
  * torch.unique / torch::_unique / std::stable_sort host round trips at

@@ -53,6 +53,7 @@ class Ramp_vo:
 
         self.tlist = []
         self.counter = 0
+        self._tstamps = []          # host mirror of tstamps_[:n]
 
         self.tstamps_ = torch.zeros(self.N, dtype=torch.long, device=dev)
         self.poses_ = torch.zeros(self.N, 7, dtype=torch.float, device=dev)
@@ -160,6 +161,7 @@ class Ramp_vo:
         self.tlist = list(sd.get("tlist", []))
         k = sd["poses"].shape[0]
         self.tstamps_[:k] = sd["tstamps"].to(dev)
+        self._tstamps = [int(v) for v in sd["tstamps"][:n].tolist()]
         self.poses_[:k] = sd["poses"].to(dev)
         self.patches_[:k] = sd["patches"].to(dev)
         self.intrinsics_[:k] = sd["intrinsics"].to(dev)
@@ -185,7 +187,7 @@ class Ramp_vo:
     def terminate(self):
         """interpolate the poses of dropped frames; returns (inverse poses [T,7], tstamps)"""
         self.traj = {}
-        ts = self.tstamps_[:self.n].tolist()
+        ts = self._tstamps[:self.n] if len(self._tstamps) >= self.n else self.tstamps_[:self.n].tolist()
         for i in range(self.n):
             self.traj[ts[i]] = self.poses_[i]
         poses = [self.get_pose(t) for t in range(self.counter)]
@@ -318,8 +320,7 @@ class Ramp_vo:
         ii, jj, kk = self._ii, self._jj, self._kk
         if m < self.cfg.KEYFRAME_THRESH:
             k = self.n - self.cfg.KEYFRAME_INDEX
-            ts = self.tstamps_[k - 1:k + 1].tolist()
-            t0, t1 = ts[0], ts[1]
+            t0, t1 = self._tstamps[k - 1], self._tstamps[k]
             dP = SE3(self.poses_[k]) * SE3(self.poses_[k - 1]).inv()
             self.delta[t1] = (t0, dP)
             keep &= ~((ii == k) | (jj == k))
@@ -329,12 +330,18 @@ class Ramp_vo:
             jj[jj > k] -= 1
             # shift the per-frame state down by one row (reference: python loop of row copies)
             n = self.n
-            for buf in (self.tstamps_, self.colors_, self.poses_, self.patches_, self.intrinsics_):
-                buf[k:n - 1] = buf[k + 1:n].clone()
-            dst = torch.arange(k, n - 1, device=self.device) % self.mem
-            src = torch.arange(k + 1, n, device=self.device) % self.mem
-            for buf in (self.imap_, self.gmap_, self.fmap1_, self.fmap2_):
-                buf[dst] = buf[src]
+            del self._tstamps[k]
+            if self.device.type == "cuda" and (self.M * 3) % 4 == 0:
+                ops.shift_rows([(self.tstamps_, 0), (self.colors_, 0), (self.poses_, 0), (self.patches_, 0),
+                                (self.intrinsics_, 0), (self.imap_, self.mem), (self.gmap_, self.mem),
+                                (self.fmap1_, self.mem), (self.fmap2_, self.mem)], k, n)     # one launch
+            else:
+                for buf in (self.tstamps_, self.colors_, self.poses_, self.patches_, self.intrinsics_):
+                    buf[k:n - 1] = buf[k + 1:n].clone()
+                dst = torch.arange(k, n - 1, device=self.device) % self.mem
+                src = torch.arange(k + 1, n, device=self.device) % self.mem
+                for buf in (self.imap_, self.gmap_, self.fmap1_, self.fmap2_):
+                    buf[dst] = buf[src]
             self.n -= 1
             self.m -= self.M
         keep &= ~((kk // self.M) < self.n - self.cfg.REMOVAL_WINDOW)
@@ -400,11 +407,11 @@ class Ramp_vo:
 
         n = self.n
         self.tlist.append(tstamp)
+        del self._tstamps[n:]
+        self._tstamps.append(self.counter)
         self.tstamps_[n] = self.counter
-        self.intrinsics_[n] = intrinsics.to(self.device) / self.RES
+        self.intrinsics_[n] = (intrinsics.detach().cpu().float() / self.RES).to(self.device)
         self.index_map_[n + 1] = self.m + self.M
-        clr = (clr[0][:, [2, 1, 0]] + 0.5) * (255.0 / 2)
-        self.colors_[n] = clr.to(torch.uint8)
 
         if n > 1:
             if self.cfg.MOTION_MODEL == 'DAMPED_LINEAR' and self.device.type == "cuda":
@@ -420,14 +427,24 @@ class Ramp_vo:
         patches[:, :, 2] = self._initial_depth(patches)
         if self.is_initialized:
             patches[:, :, 2] = torch.median(self.patches_[n - 3:n, :, 2])
-        self.patches_[n] = patches
 
         slot = n % self.mem
-        self.imap_[slot] = imap.reshape(self.M, self.DIM).to(self.dtype)
-        self.gmap_[slot] = gmap[0].permute(0, 2, 3, 1).to(self.dtype)
-        f = fmap[0]                                                  # [1,128,h,w], channels-last storage
-        self.fmap1_[slot] = f[0].permute(1, 2, 0).to(self.dtype)
-        self.fmap2_[slot] = F.avg_pool2d(f, 4, 4)[0].permute(1, 2, 0).to(self.dtype)
+        ex = getattr(self.network.patchify, "_extra", None)
+        if (ex is not None and self.device.type == "cuda" and ex["fmap"].dtype == self.dtype
+                and (self.M * 3) % 4 == 0 and patches.is_contiguous()):
+            # one launch: patches, colours and the four feature tensors into their state rows / ring slots
+            ops.multi_copy([(patches, self.patches_[n]), (ex["colors"], self.colors_[n]),
+                            (ex["imap"], self.imap_[slot]), (ex["gmap"], self.gmap_[slot]),
+                            (ex["fmap"], self.fmap1_[slot]), (ex["fmap2"], self.fmap2_[slot])])
+        else:
+            clr = (clr[0][:, [2, 1, 0]] + 0.5) * (255.0 / 2)
+            self.colors_[n] = clr.to(torch.uint8)
+            self.patches_[n] = patches
+            self.imap_[slot] = imap.reshape(self.M, self.DIM).to(self.dtype)
+            self.gmap_[slot] = gmap[0].permute(0, 2, 3, 1).to(self.dtype)
+            f = fmap[0]                                                  # [1,128,h,w], channels-last storage
+            self.fmap1_[slot] = f[0].permute(1, 2, 0).to(self.dtype)
+            self.fmap2_[slot] = F.avg_pool2d(f, 4, 4)[0].permute(1, 2, 0).to(self.dtype)
 
         self.counter += 1
         if n > 0 and not self.is_initialized:

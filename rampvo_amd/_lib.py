@@ -43,6 +43,8 @@ SIGNATURES = {
     "ramp_transform": (c_i, [c_p] * 7 + [c_i, c_i, c_i, c_p]),
     "ramp_reproject": (c_i, [c_p] * 7 + [c_i, c_i, c_p]),
     "ramp_point_cloud": (c_i, [c_p] * 5 + [c_i, c_i, c_p]),
+    "ramp_multi_copy": (c_i, [c_p, c_p, c_p, c_i, c_p]),
+    "ramp_shift_rows": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "ramp_motionmag": (c_i, [c_p] * 10 + [c_i64, c_i64, c_f, c_p, c_i, c_p]),
     "ramp_motion_model": (c_i, [c_p, c_i, c_f, c_p]),
     "ramp_group_by_workspace_bytes": (c_sz, [c_i]),

@@ -302,7 +302,91 @@ __global__ void motion_model_kernel(float *poses, int n, float damping) {
   for (int c = 0; c < 7; c++) poses[7 * n + c] = Pn[c];
 }
 
+// ---- small multi-buffer copies (tracker bookkeeping: one launch instead of ~10-20 tiny ATen ops)
+#define RAMP_MAXBUF 10
+struct CopyDesc {
+  const char *src[RAMP_MAXBUF];
+  char *dst[RAMP_MAXBUF];
+  long bytes[RAMP_MAXBUF];   // multiples of 4
+  int n;
+};
+// dst[b][0:bytes[b]) = src[b][0:bytes[b]) for every buffer b (disjoint src/dst)
+__global__ void __launch_bounds__(256) multi_copy_kernel(const CopyDesc d) {
+  const int b = blockIdx.y;
+  if (b >= d.n) return;
+  const long n4 = d.bytes[b] / 4;
+  const uint32_t *s = reinterpret_cast<const uint32_t *>(d.src[b]);
+  uint32_t *o = reinterpret_cast<uint32_t *>(d.dst[b]);
+  if ((((uintptr_t)s | (uintptr_t)o) & 15) == 0 && (n4 & 3) == 0) {
+    const long n16 = n4 / 4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x)
+      reinterpret_cast<uint4 *>(o)[i] = reinterpret_cast<const uint4 *>(s)[i];
+  } else {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x)
+      o[i] = s[i];
+  }
+}
+// keyframe removal: rows k+1..n-1 move down by one in every buffer.  Plain buffers are
+// [rows][row_bytes]; ring buffers hold row r at slot r % mod.  Rows are moved in ascending order by
+// ONE workgroup per (buffer, column chunk), so a chunk is read before it is overwritten.
+struct ShiftDesc {
+  char *base[RAMP_MAXBUF];
+  long row_bytes[RAMP_MAXBUF];
+  int mod[RAMP_MAXBUF];      // 0: plain
+  int n;
+};
+__global__ void __launch_bounds__(256) shift_rows_kernel(const ShiftDesc d, int k, int nrows) {
+  const int b = blockIdx.y;
+  if (b >= d.n) return;
+  const long n4 = d.row_bytes[b] / 4;
+  const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  // each thread owns columns c, c + stride, ... and walks the rows itself: no cross-thread hazard
+  for (long col = c; col < n4; col += (long)gridDim.x * blockDim.x) {
+    for (int r = k; r < nrows - 1; r++) {
+      const int sd = d.mod[b] ? r % d.mod[b] : r, ss = d.mod[b] ? (r + 1) % d.mod[b] : r + 1;
+      reinterpret_cast<uint32_t *>(d.base[b] + (size_t)sd * d.row_bytes[b])[col] =
+          reinterpret_cast<const uint32_t *>(d.base[b] + (size_t)ss * d.row_bytes[b])[col];
+    }
+  }
+}
+
 extern "C" {
+int ramp_multi_copy(const void *const *src_host, void *const *dst_host, const long *bytes_host, int n,
+                    void *stream) {
+  if (n < 0 || n > RAMP_MAXBUF) return RAMP_EINVAL;
+  if (n == 0) return RAMP_OK;
+  CopyDesc d;
+  long mx = 0;
+  for (int i = 0; i < n; i++) {
+    if (!src_host[i] || !dst_host[i] || bytes_host[i] < 0 || (bytes_host[i] & 3)) return RAMP_EINVAL;
+    d.src[i] = (const char *)src_host[i]; d.dst[i] = (char *)dst_host[i]; d.bytes[i] = bytes_host[i];
+    if (bytes_host[i] > mx) mx = bytes_host[i];
+  }
+  d.n = n;
+  int bx = (int)((mx / 16 + 255) / 256);
+  bx = bx < 1 ? 1 : (bx > 512 ? 512 : bx);
+  hipLaunchKernelGGL(multi_copy_kernel, dim3(bx, n), dim3(256), 0, (hipStream_t)stream, d);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+int ramp_shift_rows(void *const *base_host, const long *row_bytes_host, const int *mod_host, int n, int k,
+                    int nrows, void *stream) {
+  if (n < 0 || n > RAMP_MAXBUF || k < 0) return RAMP_EINVAL;
+  if (n == 0 || k >= nrows - 1) return RAMP_OK;
+  ShiftDesc d;
+  long mx = 0;
+  for (int i = 0; i < n; i++) {
+    if (!base_host[i] || row_bytes_host[i] <= 0 || (row_bytes_host[i] & 3) || mod_host[i] < 0) return RAMP_EINVAL;
+    d.base[i] = (char *)base_host[i]; d.row_bytes[i] = row_bytes_host[i]; d.mod[i] = mod_host[i];
+    if (row_bytes_host[i] > mx) mx = row_bytes_host[i];
+  }
+  d.n = n;
+  int bx = (int)((mx / 4 + 255) / 256);
+  bx = bx < 1 ? 1 : (bx > 1024 ? 1024 : bx);
+  hipLaunchKernelGGL(shift_rows_kernel, dim3(bx, n), dim3(256), 0, (hipStream_t)stream, d, k, nrows);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
 int ramp_motionmag(const float *poses, const float *patches, const float *intrinsics,
                    const int64_t *ii, const int64_t *jj, const int64_t *kk, const int32_t *order,
                    const int32_t *seg, const int64_t *ukeys, const int32_t *ngroups, int64_t key_ij,

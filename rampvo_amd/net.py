@@ -137,6 +137,7 @@ class Patchifier(nn.Module):
         self.use_graph = os.environ.get("RAMP_NO_GRAPH", "0") != "1"
         self._graphs = {}
         self._graph_warm = 0
+        self._extra = None
 
     def _coord_grid(self, h, w, device):
         if self._grid is None or self._grid.shape[-2:] != (h, w) or self._grid.device != device:
@@ -169,10 +170,10 @@ class Patchifier(nn.Module):
             with torch.cuda.graph(graph):
                 outs = self._forward_impl((ev_s, im_s, mask), patches_per_image, False, None, event_bias,
                                           gradient_bias)
-            self._graphs[key] = g = (graph, ev_s, im_s, outs)
+            self._graphs[key] = g = (graph, ev_s, im_s, outs, self._extra)
             graph.replay()               # capture does not execute: run this frame now (inputs already staged)
             return outs
-        graph, ev_s, im_s, outs = g
+        graph, ev_s, im_s, outs, self._extra = g
         ev_s.copy_(events)
         im_s.copy_(images)
         graph.replay()
@@ -217,6 +218,16 @@ class Patchifier(nn.Module):
         patches = altcorr.patchify(grid, coords, self.P // 2).view(b, -1, 3, self.P, self.P)
         index = torch.arange(n, device=fmap.device).view(n, 1).repeat(1, patches_per_image).reshape(-1)
         clr = altcorr.patchify(images[0].float(), 4 * (coords + 0.5), 0).view(b, -1, 3)
+        if fmap.is_cuda and n == 1:
+            # extras for the tracker's one-launch state store (channels-last sources, the 1/4 pyramid
+            # level and the uint8 BGR colours of Ramp_vo.py:353-354, 381), produced inside the graph
+            import torch.nn.functional as F
+            f2 = F.avg_pool2d(fmap[0], 4, 4).permute(0, 2, 3, 1).contiguous()
+            col = ((clr[0].flip(-1) + 0.5) * (255.0 / 2)).to(torch.uint8)       # BGR, no host index tensor
+            self._extra = dict(gmap=gmap.permute(0, 1, 3, 4, 2), imap=imap_p.view(-1, DIM), fmap=f_nhwc[0],
+                               fmap2=f2[0], colors=col)
+        else:
+            self._extra = None
         return fmap, gmap, imap_p, patches, index, clr
 
 

@@ -156,6 +156,28 @@ def motionmag(poses, patches, intrinsics, ii, jj, kk, pair_groups, key_ij, key_j
     return out
 
 
+def multi_copy(pairs):
+    """pairs: list of (src_tensor, dst_tensor) with equal byte sizes, both contiguous; one launch"""
+    n = len(pairs)
+    src = (ctypes.c_void_p * n)(*[s.data_ptr() for s, _ in pairs])
+    dst = (ctypes.c_void_p * n)(*[d.data_ptr() for _, d in pairs])
+    nbytes = (ctypes.c_long * n)(*[s.numel() * s.element_size() for s, _ in pairs])
+    for s, d in pairs:
+        assert s.is_contiguous() and d.is_contiguous() and s.numel() * s.element_size() == d.numel() * d.element_size()
+    check(lib().ramp_multi_copy(src, dst, nbytes, n, stream()), "ramp_multi_copy")
+
+
+def shift_rows(bufs, k, nrows):
+    """bufs: list of (tensor [rows, ...], ring_modulus or 0); rows k+1..nrows-1 move down by one"""
+    n = len(bufs)
+    base = (ctypes.c_void_p * n)(*[t.data_ptr() for t, _ in bufs])
+    rb = (ctypes.c_long * n)(*[t[0].numel() * t.element_size() for t, _ in bufs])
+    mod = (ctypes.c_int * n)(*[int(m) for _, m in bufs])
+    for t, _ in bufs:
+        assert t.is_contiguous()
+    check(lib().ramp_shift_rows(base, rb, mod, n, int(k), int(nrows), stream()), "ramp_shift_rows")
+
+
 def motion_model(poses, n, damping):
     """in place: poses[n] = Exp(damping * Log(poses[n-1] * poses[n-2]^-1)) * poses[n-1]"""
     require_cuda(poses)

@@ -10,15 +10,18 @@ from rampvo_amd.synthetic import SyntheticStream, make_network
 from rampvo_amd import Ramp_vo as RV, ops, altcorr, fastba, projective_ops as pops, net as NET
 
 mixed = int(os.environ.get("MIXED", "1"))
+SYNC = int(os.environ.get("SYNC", "1"))     # SYNC=0: host-side (enqueue) time per section only
 acc = collections.defaultdict(float); cnt = collections.defaultdict(int)
 enabled = [False]
 def timed(name, fn):
     def w(*a, **k):
         if not enabled[0]:
             return fn(*a, **k)
-        torch.cuda.synchronize(); t = time.perf_counter()
+        if SYNC: torch.cuda.synchronize()
+        t = time.perf_counter()
         r = fn(*a, **k)
-        torch.cuda.synchronize(); acc[name] += time.perf_counter() - t; cnt[name] += 1
+        if SYNC: torch.cuda.synchronize()
+        acc[name] += time.perf_counter() - t; cnt[name] += 1
         return r
     return w
 
@@ -36,7 +39,8 @@ slam.corr = timed("  corr", slam.corr)
 RV.fastba.BA = timed("  BA", RV.fastba.BA)
 RV.pops.point_cloud = timed("  point_cloud", RV.pops.point_cloud)
 RV.pops.flow_mag = timed("  flow_mag", RV.pops.flow_mag)
-slam.remove_factors = timed("  remove_factors", slam.remove_factors)
+slam._motionmag_pair = timed("  motionmag+sync", slam._motionmag_pair)
+slam._track = timed("track(total)", slam._track)
 import rampvo_amd.update_fused as UF
 UF.FusedUpdate.hidden = timed("  fused_hidden", UF.FusedUpdate.hidden)
 import rampvo_amd.utils as U
@@ -52,6 +56,6 @@ for t in range(T):
     slam(t, input_tensor=(ev, im, mask), intrinsics=K)
 torch.cuda.synchronize(); total = time.perf_counter() - t0
 n = T - 80
-print("steps %d, E=%d, synchronised step time %.3f ms" % (n, len(slam._ii), 1e3 * total / n))
+print("steps %d, E=%d, %s step time %.3f ms" % (n, len(slam._ii), "synchronised" if SYNC else "pipelined (host enqueue times below)", 1e3 * total / n))
 for k in sorted(acc, key=lambda k: -acc[k]):
     print("%-22s %7.3f ms/step  (%d calls)" % (k, 1e3 * acc[k] / n, cnt[k]))
