@@ -213,19 +213,41 @@ class Ramp_vo:
 
     # -------------------------------------------------------------------- graph
     def _upload(self, a):
-        return torch.from_numpy(a).to(self.device)
+        """host array -> device.  A pageable host->device copy blocks the host until everything queued
+        before it has run, so the tracker issues its uploads only where the stream is known to be
+        (nearly) empty: at the top of a frame (_prefetch_edges) and right after keyframe()'s read-back."""
+        return torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
 
-    def append_factors(self, ii, jj):
-        """ii: patch indices, jj: frame indices (host arrays) -- reference :194-201"""
-        ii = np.asarray(ii, np.int64)
-        jj = np.asarray(jj, np.int64)
-        src = ii // self.M                      # == self.ix[ii]: index_[r] = r for every frame row
+    def _prefetch_edges(self):
+        """the factors this frame will add if it is accepted (reference :312-325, :394-395) depend only on
+        (n, M, lifetime): build and upload them BEFORE the encoder is enqueued, while the GPU is idle."""
+        n1 = self.n + 1                       # value of self.n when the edges are generated
+        r, M = self.cfg.PATCH_LIFETIME, self.M
+        kf, jf = np.meshgrid(np.arange(M * max(n1 - r, 0), M * max(n1 - 1, 0)), np.arange(n1 - 1, n1), indexing='ij')
+        kb, jb = np.meshgrid(np.arange(M * max(n1 - 1, 0), M * n1), np.arange(max(n1 - r, 0), n1), indexing='ij')
+        kk = np.concatenate([kf.reshape(-1), kb.reshape(-1)]).astype(np.int64)
+        jj = np.concatenate([jf.reshape(-1), jb.reshape(-1)]).astype(np.int64)
+        ii = kk // M
+        dev = self._upload(np.stack([ii, jj, kk]))            # one copy for the three arrays
+        return (n1, ii, jj, kk, dev)
+
+    def append_factors(self, ii, jj, pre=None):
+        """ii: patch indices, jj: frame indices (host arrays) -- reference :194-201.  ``pre``: the same
+        edges already uploaded by _prefetch_edges"""
+        if pre is not None:
+            _, src, jj, ii, dev = pre
+            d_ii, d_jj, d_kk = dev[0], dev[1], dev[2]
+        else:
+            ii = np.asarray(ii, np.int64)
+            jj = np.asarray(jj, np.int64)
+            src = ii // self.M                      # == self.ix[ii]: index_[r] = r for every frame row
+            d_ii, d_jj, d_kk = self._upload(src), self._upload(jj), self._upload(ii)
         self._jj = np.concatenate([self._jj, jj])
         self._kk = np.concatenate([self._kk, ii])
         self._ii = np.concatenate([self._ii, src])
-        self.jj = torch.cat([self.jj, self._upload(jj)])
-        self.kk = torch.cat([self.kk, self._upload(ii)])
-        self.ii = torch.cat([self.ii, self._upload(src)])
+        self.jj = torch.cat([self.jj, d_jj])
+        self.kk = torch.cat([self.kk, d_kk])
+        self.ii = torch.cat([self.ii, d_ii])
         net = torch.zeros(1, len(ii), self.DIM, dtype=torch.float, device=self.device)
         self.net = torch.cat([self.net, net], dim=1)
         self._plan = None
@@ -398,6 +420,13 @@ class Ramp_vo:
             return self._track(tstamp, input_, intrinsics)
 
     def _track(self, tstamp, input_, intrinsics):
+        mask = input_[2]
+        accepts = mask is None or bool(mask)
+        pre = self._prefetch_edges() if (accepts and self.device.type == "cuda") else None
+        kq = intrinsics.detach().cpu().float().numpy() / self.RES
+        k_dev = None
+        if accepts and not (getattr(self, "_last_K", None) is not None and np.array_equal(kq, self._last_K)):
+            k_dev = self._upload(kq.astype(np.float32))
         fmap, gmap, imap, patches, _, clr = self.network.patchify(
             input_=input_, patches_per_image=self.cfg.PATCHES_PER_FRAME, event_bias=self.event_bias,
             reinit_hidden=True if tstamp == 0 else False)
@@ -409,9 +438,13 @@ class Ramp_vo:
         self.tlist.append(tstamp)
         del self._tstamps[n:]
         self._tstamps.append(self.counter)
-        self.tstamps_[n] = self.counter
-        self.intrinsics_[n] = (intrinsics.detach().cpu().float() / self.RES).to(self.device)
-        self.index_map_[n + 1] = self.m + self.M
+        self.tstamps_[n].fill_(self.counter)              # fill kernels: no blocking host->device copy
+        self.index_map_[n + 1].fill_(self.m + self.M)
+        if k_dev is None and n > 0:
+            self.intrinsics_[n] = self.intrinsics_[n - 1]     # unchanged intrinsics: device-side row copy
+        else:
+            self.intrinsics_[n] = k_dev if k_dev is not None else self._upload(kq.astype(np.float32))
+            self._last_K = kq
 
         if n > 1:
             if self.cfg.MOTION_MODEL == 'DAMPED_LINEAR' and self.device.type == "cuda":
@@ -454,9 +487,12 @@ class Ramp_vo:
 
         self.n += 1
         self.m += self.M
-        kf, jf = self.__edges_forw()
-        kb, jb = self.__edges_back()
-        self.append_factors(np.concatenate([kf, kb]), np.concatenate([jf, jb]))    # one upload for both
+        if pre is not None and pre[0] == self.n:
+            self.append_factors(None, None, pre=pre)
+        else:
+            kf, jf = self.__edges_forw()
+            kb, jb = self.__edges_back()
+            self.append_factors(np.concatenate([kf, kb]), np.concatenate([jf, jb]))
 
         if self.n == 8 and not self.is_initialized:
             self.is_initialized = True
