@@ -41,6 +41,7 @@ extern "C" {
 
 #define RAMP_NCHW 0
 #define RAMP_NHWC 1
+#define RAMP_NHWC8 2  /* [H][C/8][W][8]: correlation target maps only (ramp_pyramid_pack) */
 
 /* library / build identification: returns a static string */
 const char *ramp_version(void);
@@ -79,6 +80,26 @@ int ramp_corr_fwd(const void *fmap1, const ramp_corr_level *levels_host, int nle
                   const float *coords, const int64_t *ii, const int64_t *jj, void *out, int E,
                   int N1, int N2, int C, int P, int radius, int dtype, int layout,
                   void *stream);
+
+/* Same result as ramp_corr_fwd (every edge is computed independently, so the
+ * schedule cannot change a value).  order[E] (int32, device; NULL = identity)
+ * is the order in which edges are handed to workgroups: consecutive positions
+ * run on the same XCD, so a target-frame-major order keeps each frame's
+ * feature plane in one L2.  The tracker passes the (jj, ii) pair grouping of
+ * its graph plan.                                                           */
+int ramp_corr_fwd_ordered(const void *fmap1, const ramp_corr_level *levels_host, int nlevels,
+                          const float *coords, const int64_t *ii, const int64_t *jj,
+                          const int32_t *order, void *out, int E, int N1, int N2, int C, int P,
+                          int radius, int dtype, int layout, void *stream);
+
+/* Ramp_vo.__call__'s pyramid store (ramp/Ramp_vo.py:378-381: fmap1_[slot] =
+ * fmap, fmap2_[slot] = avg_pool2d(fmap, 4, 4)) for fp16 channels-last features:
+ * fmap [H][W][C] -> level1 [H][C/8][W][8] (same values) and level4
+ * [H/4][C/8][W/4][8] (4x4 mean, fp32 sum, one rounding).  These are the
+ * RAMP_NHWC8 target maps of ramp_corr_fwd (fp16 only; fmap1 stays RAMP_NHWC).
+ * C == 128, W % 16 == 0, H % 4 == 0, else RAMP_EUNSUPPORTED.                 */
+int ramp_pyramid_pack(const void *fmap, void *level1, void *level4, int H, int W, int C, int dtype,
+                      void *stream);
 
 /* ----------------------------------------------------------------- lietorch */
 /* lietorch_backends.{expm,logm,inv,mul,act4,adj,adjT} for group_id 3 (SE3),

@@ -19,13 +19,14 @@ MI355X-first differences that do not change results:
 """
 from collections import OrderedDict
 
+import os
 import numpy as np
 import torch
 import torch.nn.functional as F
 
 from . import altcorr, fastba, lietorch, ops
 from . import projective_ops as pops
-from ._lib import RAMP_NHWC
+from ._lib import RAMP_NHWC, RAMP_NHWC8
 from .lietorch import SE3
 from .net import GraphPlan, VONet
 from .utils import Timer, filter_features, preprocess_input
@@ -72,8 +73,16 @@ class Ramp_vo:
         # channels-last ring buffers (reference: [mem,M,DIM], [mem,M,128,P,P], [1,mem,128,h,w])
         self.imap_ = torch.zeros(self.mem, self.M, DIM, **kwargs)
         self.gmap_ = torch.zeros(self.mem, self.M, self.P, self.P, 128, **kwargs)
-        self.fmap1_ = torch.zeros(self.mem, h, w, 128, **kwargs)
-        self.fmap2_ = torch.zeros(self.mem, h // 4, w // 4, 128, **kwargs)
+        # fp16 pyramid on the GPU: [h][C/8][w][8] slots (csrc/altcorr.hip, the MFMA kernel's target
+        # layout); otherwise plain channels-last
+        self._chunked = (dev.type == "cuda" and self.dtype == torch.half and ops.pyramid_pack_supported(h, w)
+                         and (h // 4) > 0 and (w // 4) > 0)
+        if self._chunked:
+            self.fmap1_ = torch.zeros(self.mem, h, 16, w, 8, **kwargs)
+            self.fmap2_ = torch.zeros(self.mem, h // 4, 16, w // 4, 8, **kwargs)
+        else:
+            self.fmap1_ = torch.zeros(self.mem, h, w, 128, **kwargs)
+            self.fmap2_ = torch.zeros(self.mem, h // 4, w // 4, 128, **kwargs)
         self.pyramid = (self.fmap1_, self.fmap2_)
 
         self.net = torch.zeros(1, 0, DIM, dtype=torch.float, device=dev)   # hidden state is fp32 (as under autocast)
@@ -149,9 +158,14 @@ class Ramp_vo:
             tstamps=c(self.tstamps_[:n + 1]), poses=c(self.poses_[:n + 1]), patches=c(self.patches_[:n + 1]),
             intrinsics=c(self.intrinsics_[:n + 1]), colors=c(self.colors_[:n + 1]),
             imap=c(self.imap_), gmap=c(self.gmap_.permute(0, 1, 4, 2, 3)),
-            fmap1=c(self.fmap1_.permute(0, 3, 1, 2)), fmap2=c(self.fmap2_.permute(0, 3, 1, 2)),
+            fmap1=c(self._fmap_nchw(self.fmap1_)), fmap2=c(self._fmap_nchw(self.fmap2_)),
             net=c(self.net), ii=c(self.ii), jj=c(self.jj), kk=c(self.kk),
             delta={k: (v[0], c(v[1].data)) for k, v in self.delta.items()})
+
+    def _fmap_nchw(self, buf):
+        if self._chunked:                                              # [mem, h, 16, w, 8] -> [mem, 128, h, w]
+            return buf.permute(0, 2, 4, 1, 3).reshape(buf.shape[0], 128, buf.shape[1], buf.shape[3])
+        return buf.permute(0, 3, 1, 2)
 
     def load_state_dict(self, sd):
         dev = self.device
@@ -169,8 +183,13 @@ class Ramp_vo:
             self.colors_[:k] = sd["colors"].to(dev)
         self.imap_.copy_(sd["imap"].to(dev))
         self.gmap_.copy_(sd["gmap"].to(dev).permute(0, 1, 3, 4, 2))
-        self.fmap1_.copy_(sd["fmap1"].to(dev).permute(0, 2, 3, 1))
-        self.fmap2_.copy_(sd["fmap2"].to(dev).permute(0, 2, 3, 1))
+        for buf, key in ((self.fmap1_, "fmap1"), (self.fmap2_, "fmap2")):
+            src = sd[key].to(dev)                                      # [mem, 128, h, w]
+            if self._chunked:
+                src = src.reshape(src.shape[0], 16, 8, src.shape[2], src.shape[3]).permute(0, 3, 1, 4, 2)
+            else:
+                src = src.permute(0, 2, 3, 1)
+            buf.copy_(src)
         self.net = sd["net"].to(dev)
         self.ii, self.jj, self.kk = (sd[x].to(dev).long() for x in ("ii", "jj", "kk"))
         self._ii, self._jj, self._kk = (sd[x].cpu().numpy().astype(np.int64) for x in ("ii", "jj", "kk"))
@@ -196,13 +215,14 @@ class Ramp_vo:
         return poses, np.array(self.tlist, dtype=float)
 
     # ------------------------------------------------------------------ kernels
-    def corr(self, coords, indicies=None):
-        """local correlation volume, both pyramid levels fused: [1, E, 882]"""
+    def corr(self, coords, indicies=None, order=None):
+        """local correlation volume, both pyramid levels fused: [1, E, 882].  order: the graph
+        plan's target-frame-major edge permutation (scheduling only)"""
         ii, jj = indicies if indicies is not None else (self.kk, self.jj)
         ii1 = ii % (self.M * self.mem)
         jj1 = jj % self.mem
         return altcorr.corr_pyramid(self.gmap_.view(-1, 3, 3, 128), self.pyramid, coords[0], ii1, jj1, 3,
-                                    (1, 4), RAMP_NHWC)
+                                    (1, 4), RAMP_NHWC8 if self._chunked else RAMP_NHWC, order=order)
 
     def reproject(self, indicies=None, poses=None, patches=None, intrinsics=None):
         (ii, jj, kk) = indicies if indicies is not None else (self.ii, self.jj, self.kk)
@@ -317,7 +337,7 @@ class Ramp_vo:
         if self.device.type == "cuda":
             plan = self._graph_plan()
             mm = ops.motionmag(self.poses, self.patches, self.intrinsics, self.ii, self.jj, self.kk, plan.g_ij,
-                               i * plan.pair_mul + j, j * plan.pair_mul + i, beta=0.5)
+                               j * plan.pair_mul + i, i * plan.pair_mul + j, beta=0.5)   # keys are jj*mul+ii
             return float(mm.mean().item())
         mags = []
         for a, b in ((i, j), (j, i)):
@@ -380,9 +400,10 @@ class Ramp_vo:
     # ------------------------------------------------------------------- update
     def update(self):
         with Timer("other", enabled=self.enable_timing):
-            coords = self.reproject()
-            corr = self.corr(coords).to(self.dtype)
             plan = self._graph_plan()
+            coords = self.reproject()
+            order = plan.g_ij.order if (self.device.type == "cuda" and os.environ.get("RAMP_CORR_ORDER", "1") == "1") else None
+            corr = self.corr(coords, order=order).to(self.dtype)
             if self.device.type == "cuda":
                 # GEMMs + row-fused glue (csrc/update.hip); the context gather, the heads' activations,
                 # `target = centre + delta` and filter_features are folded into those kernels
@@ -464,7 +485,7 @@ class Ramp_vo:
         slot = n % self.mem
         ex = getattr(self.network.patchify, "_extra", None)
         if (ex is not None and self.device.type == "cuda" and ex["fmap"].dtype == self.dtype
-                and (self.M * 3) % 4 == 0 and patches.is_contiguous()):
+                and (self.M * 3) % 4 == 0 and patches.is_contiguous() and ex["chunked"] == self._chunked):
             # one launch: patches, colours and the four feature tensors into their state rows / ring slots
             ops.multi_copy([(patches, self.patches_[n]), (ex["colors"], self.colors_[n]),
                             (ex["imap"], self.imap_[slot]), (ex["gmap"], self.gmap_[slot]),
@@ -476,8 +497,12 @@ class Ramp_vo:
             self.imap_[slot] = imap.reshape(self.M, self.DIM).to(self.dtype)
             self.gmap_[slot] = gmap[0].permute(0, 2, 3, 1).to(self.dtype)
             f = fmap[0]                                                  # [1,128,h,w], channels-last storage
-            self.fmap1_[slot] = f[0].permute(1, 2, 0).to(self.dtype)
-            self.fmap2_[slot] = F.avg_pool2d(f, 4, 4)[0].permute(1, 2, 0).to(self.dtype)
+            if self._chunked:
+                ops.pyramid_pack(f[0].permute(1, 2, 0).to(self.dtype).contiguous(), self.fmap1_[slot],
+                                 self.fmap2_[slot])
+            else:
+                self.fmap1_[slot] = f[0].permute(1, 2, 0).to(self.dtype)
+                self.fmap2_[slot] = F.avg_pool2d(f, 4, 4)[0].permute(1, 2, 0).to(self.dtype)
 
         self.counter += 1
         if n > 0 and not self.is_initialized:

@@ -13,10 +13,10 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libramp_hip.so")
+LIB_PATH = os.environ.get("RAMP_HIP_LIB") or os.path.join(CSRC, "libramp_hip.so")   # env: kernel A/B builds
 
 RAMP_F32, RAMP_F16 = 0, 1
-RAMP_NCHW, RAMP_NHWC = 0, 1
+RAMP_NCHW, RAMP_NHWC, RAMP_NHWC8 = 0, 1, 2
 
 _ERR = {-1: "RAMP_EINVAL (bad argument)", -2: "RAMP_ELAUNCH (HIP launch/runtime error)",
         -3: "RAMP_EWORKSPACE (workspace too small)", -4: "RAMP_EUNSUPPORTED (size/shape not supported)"}
@@ -33,6 +33,9 @@ SIGNATURES = {
     "ramp_version": (ctypes.c_char_p, []),
     "ramp_patchify_fwd": (c_i, [c_p, c_p, c_p] + [c_i] * 10 + [c_p]),
     "ramp_corr_fwd": (c_i, [c_p, ctypes.POINTER(CorrLevel), c_i, c_p, c_p, c_p, c_p] + [c_i] * 8 + [c_p]),
+    "ramp_pyramid_pack": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "ramp_corr_fwd_ordered": (c_i, [c_p, ctypes.POINTER(CorrLevel), c_i, c_p, c_p, c_p, c_p, c_p] + [c_i] * 8
+                              + [c_p]),
     "ramp_se3_exp": (c_i, [c_p, c_p, c_i, c_p]),
     "ramp_se3_log": (c_i, [c_p, c_p, c_i, c_p]),
     "ramp_se3_inv": (c_i, [c_p, c_p, c_i, c_p]),

@@ -71,6 +71,10 @@ __global__ void __launch_bounds__(256)
 
 // -------------------------------------------------------------------- corr
 #define CORR_MAXLEV 2
+#ifndef CORR_PGB
+#define CORR_PGB 4    // pixel groups (of 16) whose loads are in flight together, MFMA kernel
+#define CORR_WAVES 4  // waves per SIMD the MFMA kernel is register-budgeted for
+#endif
 #define CORR_T 128  // union pixels handled per group (2 per lane)
 
 struct CorrParams {
@@ -83,7 +87,21 @@ struct CorrParams {
   const int64_t *ii, *jj;
   void *out;
   int E, N1, N2;
+  const int32_t *order;   // optional schedule: position -> edge (any permutation of 0..E-1)
+  int chunk;              // ceil(E / CORR_XCDS)
 };
+
+// Workgroup ids are dealt round-robin to the 8 XCDs, each with a private L2.  Position p of the
+// schedule is given to XCD p / chunk, so that a run of consecutive positions -- edges that look at
+// the same target frame when the caller passes a jj-major `order` -- shares one L2 instead of
+// pulling the frame's feature plane into all eight.
+constexpr int CORR_XCDS = 8;
+static __device__ __forceinline__ int corr_edge_of_block(const CorrParams &prm) {
+  const int b = blockIdx.x;
+  const int pos = (b % CORR_XCDS) * prm.chunk + b / CORR_XCDS;
+  if (pos >= prm.E) return -1;
+  return prm.order ? prm.order[pos] : pos;
+}
 
 template <typename T> struct Vec4;
 template <> struct Vec4<float> {
@@ -113,7 +131,8 @@ __global__ void __launch_bounds__(64)
   __shared__ int s_ox[PP], s_oy[PP], s_live[PP];
   __shared__ float s_dx[PP], s_dy[PP];
 
-  const int e = blockIdx.x;
+  const int e = corr_edge_of_block(prm);
+  if (e < 0) return;
   const int lane = threadIdx.x;
   const long i1 = prm.ii[e], j2 = prm.jj[e];
   const int L = prm.nlevels;
@@ -298,16 +317,25 @@ __global__ void __launch_bounds__(64)
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-__global__ void __launch_bounds__(64)
+//
+// Target maps come either as plain NHWC or (CHUNKED) as [H][C/8][W][8]: there the 16 lanes of a
+// quarter-wave -- 16 neighbouring window pixels, same 8-channel chunk -- read one or two
+// contiguous runs instead of 16 cache lines 256 B apart.  The vector L1 looks up one line per
+// cycle, and with NHWC those lookups (64 per load instruction) were what the kernel waited on.
+template <bool CHUNKED>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CORR_WAVES, 8)))
     corr_mfma_f16_kernel(const CorrParams prm) {
   constexpr int C = 128, PP = 9, R = 3, D = 8, d = 7;
-  constexpr int NOUT = d * d * PP;
+  constexpr int NOUT = d * d * PP;           // 441 values per level
+  constexpr int KOUT = d;                    // 7 per lane (lanes 0..62), held until both levels are done
+  constexpr int PGB = CORR_PGB;                   // pixel groups whose loads are in flight together
   __shared__ __attribute__((aligned(16))) float Cs[PP * CORR_T];
-  __shared__ float outs[NOUT * CORR_MAXLEV];
+  __shared__ float outs[NOUT];               // staging for the ragged (non-union) paths only
   __shared__ int s_ox[PP], s_oy[PP], s_live[PP];
   __shared__ float s_dx[PP], s_dy[PP];
 
-  const int e = blockIdx.x;
+  const int e = corr_edge_of_block(prm);
+  if (e < 0) return;
   const int lane = threadIdx.x, q = lane >> 4, j = lane & 15;
   const long i1 = prm.ii[e], j2 = prm.jj[e];
   const int L = prm.nlevels;
@@ -322,7 +350,11 @@ __global__ void __launch_bounds__(64)
     }
   }
 
-  for (int lvl = 0; lvl < L; lvl++) {
+  float res[CORR_MAXLEV][KOUT];
+  const int op_p = lane % PP, op_a = lane / PP;   // output ownership, see the union epilogue
+#pragma unroll
+  for (int lvl = 0; lvl < CORR_MAXLEV; lvl++) {
+    if (lvl >= L) break;
     const int H2 = prm.H2[lvl], W2 = prm.W2[lvl];
     const _Float16 *f2 = reinterpret_cast<const _Float16 *>(prm.fmap2[lvl]) + (size_t)j2 * C * H2 * W2;
     if (lane < PP) {
@@ -360,7 +392,7 @@ __global__ void __launch_bounds__(64)
         s = s + (dx * (1 - dy)) * 0.0f;
         s = s + ((1 - dx) * dy) * 0.0f;
         s = s + (dx * dy) * 0.0f;
-        outs[o * L + lvl] = s;
+        outs[o] = s;
       }
     }
     for (int g = 0; g < ngroups; g++) {
@@ -371,65 +403,171 @@ __global__ void __launch_bounds__(64)
           s = s + (dx * (1 - dy)) * 0.0f;
           s = s + ((1 - dx) * dy) * 0.0f;
           s = s + (dx * dy) * 0.0f;
-          outs[(ab * PP + g) * L + lvl] = s;
+          outs[ab * PP + g] = s;
         }
         continue;
       }
       const int gx0 = uni ? minx : s_ox[g], gy0 = uni ? miny : s_oy[g];
       const int gw = uni ? (int)bw : D, gh = uni ? (int)bh : D;
-      const int Tn = gw * gh;
+      const int Tn = gw * gh;                      // <= CORR_T = 128
       const int npg = (Tn + 15) / 16;
-      for (int pg = 0; pg < npg; pg++) {
-        const int t = pg * 16 + j;
-        const int ty = t / gw, tx = t - ty * gw;
-        const int px = gx0 + tx, py = gy0 + ty;
-        const bool inb = (t < Tn) && px >= 0 && px < W2 && py >= 0 && py < H2;
-        const _Float16 *pp = f2 + ((size_t)(inb ? py : 0) * W2 + (inb ? px : 0)) * C + 8 * q;
-        f16x8_t b[4];
+      const int inv_gw = (65536 + gw - 1) / gw;    // t / gw == (t * inv_gw) >> 16 for t < 128, gw <= 128
+      for (int pg0 = 0; pg0 < npg; pg0 += PGB) {
+        // all PGB x 4 sixteen-byte loads of the batch are issued before the first MFMA waits on
+        // one: the address is always a valid pixel, out-of-window lanes are zeroed afterwards
+        f16x8_t bfr[PGB][4];
+        bool inb[PGB];
 #pragma unroll
-        for (int s = 0; s < 4; s++)
-          b[s] = inb ? *reinterpret_cast<const f16x8_t *>(pp + 32 * s) : (f16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
-        f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < PGB; u++) {
+          const int t = (pg0 + u) * 16 + j;
+          const int ty = (t * inv_gw) >> 16, tx = t - ty * gw;
+          const int px = gx0 + tx, py = gy0 + ty;
+          inb[u] = (t < Tn) && px >= 0 && px < W2 && py >= 0 && py < H2;
+          const int cy = inb[u] ? py : 0, cx = inb[u] ? px : 0;
+          // MFMA step s, quarter q <-> channels [32 s + 8 q, +8) = chunk 4 s + q
+          const _Float16 *pp = CHUNKED ? f2 + (((size_t)cy * (C / 8) + q) * W2 + cx) * 8
+                                       : f2 + ((size_t)cy * W2 + cx) * C + 8 * q;
+          const size_t sstride = CHUNKED ? (size_t)4 * W2 * 8 : 32;
 #pragma unroll
-        for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag[s], b[s], acc, 0, 0, 0);
-        // D: rows 4q..4q+3 = patch pixels, column j = union pixel t
-        if (t < Tn) {
+          for (int s = 0; s < 4; s++) bfr[u][s] = *reinterpret_cast<const f16x8_t *>(pp + s * sstride);
+        }
 #pragma unroll
-          for (int r = 0; r < 4; r++) {
-            const int p = 4 * q + r;
-            if (p < PP) Cs[p * CORR_T + t] = acc[r];
+        for (int u = 0; u < PGB; u++) {
+          const int t = (pg0 + u) * 16 + j;
+          f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s = 0; s < 4; s++)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag[s], bfr[u][s], acc, 0, 0, 0);
+          // D: rows 4q..4q+3 = patch pixels, column j = union pixel t; an out-of-map pixel
+          // contributes zeros (the loads above fetched a valid stand-in pixel for it)
+          if (t < Tn) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              const int p = 4 * q + r;
+              if (p < PP) Cs[p * CORR_T + t] = inb[u] ? acc[r] : 0.0f;
+            }
           }
         }
       }
       __syncthreads();
-      const int nout = uni ? NOUT : d * d;
-      for (int o = lane; o < nout; o += 64) {
-        const int p = uni ? (o % PP) : g;
-        const int ab = uni ? (o / PP) : o;
-        const int b = ab / d, a = ab - b * d;
-        float c00 = 0, c01 = 0, c10 = 0, c11 = 0;
-        if (s_live[p]) {
-          const int wx = s_ox[p] - gx0 + b, wy = s_oy[p] - gy0 + a;
-          const float *row = &Cs[p * CORR_T + wy * gw + wx];
-          c00 = row[0]; c01 = row[1]; c10 = row[gw]; c11 = row[gw + 1];
+      if (uni) {
+        // lane = 9 a + p owns output row a of patch pixel p; its 7 outputs (b = 0..6) are
+        // o = (7 b + a) 9 + p = lane + 63 b and need two 8-wide rows of Cs
+        if (lane < 63) {
+          float r0[D], r1[D];
+          if (s_live[op_p]) {
+            const float *row = &Cs[op_p * CORR_T + (s_oy[op_p] - gy0 + op_a) * gw + (s_ox[op_p] - gx0)];
+#pragma unroll
+            for (int b = 0; b < D; b++) { r0[b] = row[b]; r1[b] = row[gw + b]; }
+          } else {
+#pragma unroll
+            for (int b = 0; b < D; b++) { r0[b] = 0.f; r1[b] = 0.f; }
+          }
+          const float dx = s_dx[op_p], dy = s_dy[op_p];
+#pragma unroll
+          for (int b = 0; b < d; b++) {
+            float s = ((1 - dx) * (1 - dy)) * r0[b];
+            s = s + (dx * (1 - dy)) * r0[b + 1];
+            s = s + ((1 - dx) * dy) * r1[b];
+            s = s + (dx * dy) * r1[b + 1];
+            res[lvl][b] = s;
+          }
         }
-        const float dx = s_dx[p], dy = s_dy[p];
-        float s = ((1 - dx) * (1 - dy)) * c00;
-        s = s + (dx * (1 - dy)) * c01;
-        s = s + ((1 - dx) * dy) * c10;
-        s = s + (dx * dy) * c11;
-        outs[(ab * PP + p) * L + lvl] = s;
+      } else {
+        for (int ab = lane; ab < d * d; ab += 64) {
+          const int b = ab / d, a = ab - b * d;
+          const int wx = s_ox[g] - gx0 + b, wy = s_oy[g] - gy0 + a;
+          const float *row = &Cs[g * CORR_T + wy * gw + wx];
+          const float c00 = row[0], c01 = row[1], c10 = row[gw], c11 = row[gw + 1];
+          const float dx = s_dx[g], dy = s_dy[g];
+          float s = ((1 - dx) * (1 - dy)) * c00;
+          s = s + (dx * (1 - dy)) * c01;
+          s = s + ((1 - dx) * dy) * c10;
+          s = s + (dx * dy) * c11;
+          outs[ab * PP + g] = s;
+        }
       }
       __syncthreads();
     }
+    if (!uni) {
+      __syncthreads();
+      if (lane < 63) {
+#pragma unroll
+        for (int k = 0; k < KOUT; k++) res[lvl][k] = outs[lane + 63 * k];
+      }
+    }
     __syncthreads();
   }
-  __syncthreads();
-  __half *o = reinterpret_cast<__half *>(prm.out) + (size_t)e * NOUT * L;
-  for (int k = lane; k < NOUT * L; k += 64) o[k] = __float2half(outs[k]);
+  // out[e][o][lvl]: with two levels a lane's pair is one 4-byte store, consecutive over lanes
+  __half *op = reinterpret_cast<__half *>(prm.out) + (size_t)e * NOUT * L;
+  if (lane < 63) {
+    if (L == 2) {
+#pragma unroll
+      for (int k = 0; k < KOUT; k++)
+        reinterpret_cast<__half2 *>(op)[lane + 63 * k] =
+            __halves2half2(__float2half(res[0][k]), __float2half(res[1][k]));
+    } else {
+#pragma unroll
+      for (int k = 0; k < KOUT; k++) op[lane + 63 * k] = __float2half(res[0][k]);
+    }
+  }
+}
+
+// ------------------------------------------------------------- pyramid pack
+// One frame's fp16 NHWC feature map [H][W][128] -> the two correlation levels in the chunked
+// layout: level 1 = the map itself as [H][16][W][8]; level 4 = its 4x4 average (fp32 sum / 16,
+// rounded once; Ramp_vo.py:378-381's avg_pool2d) as [H/4][16][W/4][8].  A workgroup owns a 4-row x
+// 16-pixel tile; thread (xl, c8) moves 16 bytes per row through an LDS transpose so that both the
+// reads (pixel-major) and the writes (chunk-major) are contiguous.
+__global__ void __launch_bounds__(256) pyramid_pack_kernel(const uint4 *__restrict__ in, uint4 *__restrict__ out1,
+                                                           uint4 *__restrict__ out4, int H, int W) {
+  __shared__ uint4 tile[16][17];
+  const int t = threadIdx.x;
+  const int x0 = blockIdx.x * 16, y0 = blockIdx.y * 4;
+  const int xl = t >> 4, c8 = t & 15;      // read role
+  const int wc = t >> 4, wx = t & 15;      // write role: chunk wc, pixel wx
+  float sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int r = 0; r < 4; r++) {
+    const int y = y0 + r;
+    const uint4 v = in[((size_t)y * W + x0 + xl) * 16 + c8];
+    const __half2 *h = reinterpret_cast<const __half2 *>(&v);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const float2 f = __half22float2(h[k]);
+      sum[2 * k] += f.x;
+      sum[2 * k + 1] += f.y;
+    }
+    __syncthreads();
+    tile[c8][xl] = v;
+    __syncthreads();
+    out1[((size_t)y * 16 + wc) * W + x0 + wx] = tile[wc][wx];
+  }
+  // 4 neighbouring pixels = lanes t, t^16, t^32, t^48 of one wave
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    sum[k] += __shfl_xor(sum[k], 16);
+    sum[k] += __shfl_xor(sum[k], 32);
+  }
+  if ((xl & 3) == 0) {
+    uint4 o;
+    __half2 *h = reinterpret_cast<__half2 *>(&o);
+#pragma unroll
+    for (int k = 0; k < 4; k++) h[k] = __floats2half2_rn(sum[2 * k] * 0.0625f, sum[2 * k + 1] * 0.0625f);
+    out4[((size_t)blockIdx.y * 16 + c8) * (W / 4) + (x0 + xl) / 4] = o;
+  }
 }
 
 extern "C" {
+
+int ramp_pyramid_pack(const void *fmap, void *level1, void *level4, int H, int W, int C, int dtype,
+                      void *stream) {
+  if (!fmap || !level1 || !level4 || H <= 0 || W <= 0) return RAMP_EINVAL;
+  if (C != 128 || dtype != RAMP_F16 || (W % 16) || (H % 4)) return RAMP_EUNSUPPORTED;
+  hipLaunchKernelGGL(pyramid_pack_kernel, dim3(W / 16, H / 4), dim3(256), 0, (hipStream_t)stream,
+                     (const uint4 *)fmap, (uint4 *)level1, (uint4 *)level4, H, W);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
 
 int ramp_patchify_fwd(const void *net, const float *coords, void *out, int n, int C, int H,
                       int W, int M, int radius, int bilinear, int dtype, int layout,
@@ -455,10 +593,10 @@ int ramp_patchify_fwd(const void *net, const float *coords, void *out, int n, in
   return RAMP_OK;
 }
 
-int ramp_corr_fwd(const void *fmap1, const ramp_corr_level *levels, int nlevels,
-                  const float *coords, const int64_t *ii, const int64_t *jj, void *out, int E,
-                  int N1, int N2, int C, int P, int radius, int dtype, int layout,
-                  void *stream) {
+int ramp_corr_fwd_ordered(const void *fmap1, const ramp_corr_level *levels, int nlevels,
+                          const float *coords, const int64_t *ii, const int64_t *jj,
+                          const int32_t *order, void *out, int E, int N1, int N2, int C, int P,
+                          int radius, int dtype, int layout, void *stream) {
   if (E < 0 || nlevels < 1 || nlevels > CORR_MAXLEV || !levels) return RAMP_EINVAL;
   if (C != 128 || P != 3 || radius != 3) return RAMP_EUNSUPPORTED;
   if (E == 0) return RAMP_OK;
@@ -481,19 +619,32 @@ int ramp_corr_fwd(const void *fmap1, const ramp_corr_level *levels, int nlevels,
   prm.E = E;
   prm.N1 = N1;
   prm.N2 = N2;
+  prm.order = order;
+  prm.chunk = (E + CORR_XCDS - 1) / CORR_XCDS;
+  const dim3 grid(prm.chunk * CORR_XCDS);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == RAMP_F32 && layout == RAMP_NHWC)
-    hipLaunchKernelGGL((corr_kernel<float, RAMP_NHWC>), dim3(E), dim3(64), 0, st, prm);
+    hipLaunchKernelGGL((corr_kernel<float, RAMP_NHWC>), grid, dim3(64), 0, st, prm);
   else if (dtype == RAMP_F32 && layout == RAMP_NCHW)
-    hipLaunchKernelGGL((corr_kernel<float, RAMP_NCHW>), dim3(E), dim3(64), 0, st, prm);
+    hipLaunchKernelGGL((corr_kernel<float, RAMP_NCHW>), grid, dim3(64), 0, st, prm);
   else if (dtype == RAMP_F16 && layout == RAMP_NHWC)
-    hipLaunchKernelGGL(corr_mfma_f16_kernel, dim3(E), dim3(64), 0, st, prm);
+    hipLaunchKernelGGL(corr_mfma_f16_kernel<false>, grid, dim3(64), 0, st, prm);
+  else if (dtype == RAMP_F16 && layout == RAMP_NHWC8)
+    hipLaunchKernelGGL(corr_mfma_f16_kernel<true>, grid, dim3(64), 0, st, prm);
   else if (dtype == RAMP_F16 && layout == RAMP_NCHW)
-    hipLaunchKernelGGL((corr_kernel<__half, RAMP_NCHW>), dim3(E), dim3(64), 0, st, prm);
+    hipLaunchKernelGGL((corr_kernel<__half, RAMP_NCHW>), grid, dim3(64), 0, st, prm);
   else
     return RAMP_EINVAL;
   RAMP_CHECK_LAUNCH();
   return RAMP_OK;
+}
+
+int ramp_corr_fwd(const void *fmap1, const ramp_corr_level *levels, int nlevels,
+                  const float *coords, const int64_t *ii, const int64_t *jj, void *out, int E,
+                  int N1, int N2, int C, int P, int radius, int dtype, int layout,
+                  void *stream) {
+  return ramp_corr_fwd_ordered(fmap1, levels, nlevels, coords, ii, jj, nullptr, out, E, N1, N2, C,
+                               P, radius, dtype, layout, stream);
 }
 
 }  // extern "C"

@@ -480,7 +480,7 @@ __global__ void __launch_bounds__(256)
 __global__ void ba_pairkey_kernel(const int64_t *__restrict__ ii, const int64_t *__restrict__ jj,
                                   int64_t *__restrict__ keys, int E, long long np) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n < E) keys[n] = ii[n] * np + jj[n];
+  if (n < E) keys[n] = jj[n] * np + ii[n];   // target-frame-major, as the tracker's graph plan
 }
 
 // ------------------------------------------------------------- host driver

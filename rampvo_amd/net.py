@@ -46,16 +46,18 @@ class GraphPlan:
             f_lo, f_hi = int(frame_range[0]), int(frame_range[1])
             W = max(f_hi - f_lo, 1)
             p.g_kk = ops.group_by_small(kk, None, 1, k_lo, max(k_hi - k_lo, 1), max_kk)
-            p.g_ij = ops.group_by_small(ii, jj, W, f_lo * W + f_lo, W * W, max_ij)
-            p.pair_mul = W                 # g_ij.ukeys = ii * W + jj
+            # (jj, ii) lexicographic: g_ij.order is target-frame-major, which is also the schedule
+            # the correlation kernel wants (ops.corr(order=))
+            p.g_ij = ops.group_by_small(jj, ii, W, f_lo * W + f_lo, W * W, max_ij)
+            p.pair_mul = W                 # g_ij.ukeys = jj * W + ii
             p.ix, p.jx = ops.neighbors_from_groups(p.g_kk, jj, max_kk)
         else:
             p.ix, p.jx = ops.neighbors(kk, jj, kk_bound, jj_bound)
             p.g_kk = ops.group_by(kk, kk_bound)
-            # keyed by (ii, jj) lexicographically -- the same partition / order as ii*12345+jj
+            # keyed by (jj, ii) lexicographically -- the same partition as the reference's ii*12345+jj
             nb = int(jj_bound) if jj_bound else 0
             p.pair_mul = nb if nb else 12345
-            p.g_ij = ops.group_by(ii * p.pair_mul + jj, nb * nb if nb else 0)
+            p.g_ij = ops.group_by(jj * p.pair_mul + ii, nb * nb if nb else 0)
         p.ix_raw, p.jx_raw = p.ix, p.jx
         if not ii.is_cuda:               # the ATen path of Update.forward wants masks + clamped indices
             p.mask_ix = (p.ix >= 0).reshape(1, -1, 1)
@@ -221,11 +223,18 @@ class Patchifier(nn.Module):
         if fmap.is_cuda and n == 1:
             # extras for the tracker's one-launch state store (channels-last sources, the 1/4 pyramid
             # level and the uint8 BGR colours of Ramp_vo.py:353-354, 381), produced inside the graph
-            import torch.nn.functional as F
-            f2 = F.avg_pool2d(fmap[0], 4, 4).permute(0, 2, 3, 1).contiguous()
             col = ((clr[0].flip(-1) + 0.5) * (255.0 / 2)).to(torch.uint8)       # BGR, no host index tensor
-            self._extra = dict(gmap=gmap.permute(0, 1, 3, 4, 2), imap=imap_p.view(-1, DIM), fmap=f_nhwc[0],
-                               fmap2=f2[0], colors=col)
+            chunked = (fmap.dtype == torch.float16 and ops.pyramid_pack_supported(h, w)
+                       and f_nhwc[0].is_contiguous())
+            if chunked:
+                # both correlation levels in the MFMA kernel's [h][C/8][w][8] target layout
+                f1, f2 = ops.pyramid_pack(f_nhwc[0])
+            else:
+                import torch.nn.functional as F
+                f1 = f_nhwc[0]
+                f2 = F.avg_pool2d(fmap[0], 4, 4).permute(0, 2, 3, 1).contiguous()[0]
+            self._extra = dict(gmap=gmap.permute(0, 1, 3, 4, 2), imap=imap_p.view(-1, DIM), fmap=f1,
+                               fmap2=f2, colors=col, chunked=chunked)
         else:
             self._extra = None
         return fmap, gmap, imap_p, patches, index, clr

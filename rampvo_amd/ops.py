@@ -8,7 +8,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import RAMP_NCHW, RAMP_NHWC, CorrLevel, check, dtype_code, lib, ptr, require_cuda, stream
+from ._lib import RAMP_NHWC8, RAMP_NCHW, RAMP_NHWC, CorrLevel, check, dtype_code, lib, ptr, require_cuda, stream
 
 
 # ------------------------------------------------------------------- altcorr
@@ -31,8 +31,9 @@ def patchify(net, coords, radius, bilinear=True, layout=RAMP_NCHW, out_layout=RA
     return out
 
 
-def corr(fmap1, fmaps2, coords, ii, jj, radius=3, coord_divs=(1.0,), layout=RAMP_NCHW):
-    """fused multi-level patch correlation.
+def corr(fmap1, fmaps2, coords, ii, jj, radius=3, coord_divs=(1.0,), layout=RAMP_NCHW, order=None):
+    """fused multi-level patch correlation.  order: optional int32 [E] schedule (a permutation of
+    the edges, e.g. target-frame-major) -- affects which XCD computes an edge, never a value.
 
     fmap1  [N1,C,P,P] (NCHW) / [N1,P,P,C] (NHWC) patch features
     fmaps2 list of per-level target maps [N2,C,H,W] / [N2,H,W,C]
@@ -50,20 +51,46 @@ def corr(fmap1, fmaps2, coords, ii, jj, radius=3, coord_divs=(1.0,), layout=RAMP
         N1, C, P, _ = fmap1.shape
     else:
         N1, P, _, C = fmap1.shape
+    if layout == RAMP_NHWC8:     # fp16 target maps [N2][H][C/8][W][8] (pyramid_pack); fmap1 stays NHWC
+        assert fmap1.dtype == torch.float16 and all(f.dim() == 5 and f.shape[2] * 8 == C and f.shape[4] == 8
+                                                    for f in fmaps2)
     E = coords.shape[0]
     L = len(fmaps2)
     levels = (CorrLevel * L)()
     N2 = fmaps2[0].shape[0]
     for l, f in enumerate(fmaps2):
         assert f.dtype == fmap1.dtype and f.shape[0] == N2
-        H2, W2 = (f.shape[2], f.shape[3]) if layout == RAMP_NCHW else (f.shape[1], f.shape[2])
+        H2, W2 = ((f.shape[2], f.shape[3]) if layout == RAMP_NCHW else
+                  (f.shape[1], f.shape[3]) if layout == RAMP_NHWC8 else (f.shape[1], f.shape[2]))
         levels[l] = CorrLevel(f.data_ptr(), H2, W2, float(coord_divs[l]))
     d = 2 * radius + 1
     out = torch.empty((E, d, d, P, P, L), dtype=fmap1.dtype, device=fmap1.device)
-    check(lib().ramp_corr_fwd(ptr(fmap1), levels, L, ptr(coords), ptr(ii), ptr(jj), ptr(out), E,
-                              N1, N2, C, P, radius, dtype_code(fmap1), layout, stream()),
-          "ramp_corr_fwd")
+    if order is not None:
+        assert order.dtype == torch.int32 and order.is_contiguous() and order.shape[0] == E
+    check(lib().ramp_corr_fwd_ordered(ptr(fmap1), levels, L, ptr(coords), ptr(ii), ptr(jj),
+                                      ptr(order) if order is not None else None, ptr(out), E,
+                                      N1, N2, C, P, radius, dtype_code(fmap1), layout, stream()),
+          "ramp_corr_fwd_ordered")
     return out
+
+
+def pyramid_pack(fmap, out1=None, out4=None):
+    """fp16 NHWC map [H,W,128] -> (level1 [H,16,W,8], level4 [H/4,16,W/4,8]) in the correlation
+    kernel's chunked target layout (RAMP_NHWC8); level4 is the 4x4 mean (Ramp_vo.py:378-381)"""
+    require_cuda(fmap)
+    H, W, C = fmap.shape
+    assert fmap.dtype == torch.float16 and fmap.is_contiguous()
+    if out1 is None:
+        out1 = torch.empty((H, C // 8, W, 8), dtype=fmap.dtype, device=fmap.device)
+    if out4 is None:
+        out4 = torch.empty((H // 4, C // 8, W // 4, 8), dtype=fmap.dtype, device=fmap.device)
+    check(lib().ramp_pyramid_pack(ptr(fmap), ptr(out1), ptr(out4), H, W, C, dtype_code(fmap), stream()),
+          "ramp_pyramid_pack")
+    return out1, out4
+
+
+def pyramid_pack_supported(H, W, C=128):
+    return C == 128 and W % 16 == 0 and H % 4 == 0
 
 
 # ------------------------------------------------------------------ lietorch

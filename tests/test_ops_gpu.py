@@ -150,6 +150,58 @@ def test_corr_half_mfma_path_matches_oracle():
         assert np.abs(out[..., lvl][ok] - ref[ok]).max() <= 1.5e-3 * np.abs(ref[ok]).max()
 
 
+@pytest.mark.parametrize("half", [False, True])
+def test_corr_schedule_does_not_change_values(half):
+    """ramp_corr_fwd_ordered: any edge permutation as the XCD schedule (E not a multiple of 8, so the
+    padded tail of the grid is exercised) gives bit-identical output"""
+    from rampvo_amd import ops
+    from rampvo_amd._lib import RAMP_NHWC
+    fmap1, fmap2, coords, ii, jj = corr_case(seed=11, E=61)
+    fmap2b = np.ascontiguousarray(fmap2[:, :, :, ::2, ::2])
+    t = (lambda a: cu(a).half()) if half else cu
+    args = (t(fmap1[0].transpose(0, 2, 3, 1)), [t(fmap2[0].transpose(0, 2, 3, 1)), t(fmap2b[0].transpose(0, 2, 3, 1))],
+            cu(coords[0]), cu(ii), cu(jj), 3, (1.0, 4.0), RAMP_NHWC)
+    base = ops.corr(*args)
+    perm = torch.from_numpy(np.random.default_rng(0).permutation(61).astype(np.int32)).cuda()
+    byjj = torch.argsort(cu(jj), stable=True).int()
+    for order in (perm, byjj):
+        out = ops.corr(*args, order=order)
+        assert torch.equal(torch.nan_to_num(out.float(), nan=-7.0), torch.nan_to_num(base.float(), nan=-7.0))
+
+
+def test_pyramid_pack_and_chunked_corr():
+    """ramp_pyramid_pack: level 1 is a pure re-layout, level 4 the 4x4 mean (Ramp_vo.py:378-381);
+    the MFMA correlation over the chunked maps is bit-identical to the NHWC one"""
+    import torch.nn.functional as F
+    from rampvo_amd import ops
+    from rampvo_amd._lib import RAMP_NHWC, RAMP_NHWC8
+    g = torch.Generator().manual_seed(5)
+    N2, H, W, C = 3, 24, 32, 128
+    maps = (torch.randn(N2, H, W, C, generator=g) * 0.5).half().cuda()
+    l1 = torch.empty(N2, H, C // 8, W, 8, dtype=torch.half, device="cuda")
+    l4 = torch.empty(N2, H // 4, C // 8, W // 4, 8, dtype=torch.half, device="cuda")
+    for n in range(N2):
+        ops.pyramid_pack(maps[n], l1[n], l4[n])
+    unchunk = lambda t: t.permute(0, 1, 3, 2, 4).reshape(t.shape[0], t.shape[1], t.shape[3], C)
+    assert torch.equal(unchunk(l1), maps)
+    pooled = F.avg_pool2d(maps.float().permute(0, 3, 1, 2), 4, 4).permute(0, 2, 3, 1)
+    got = unchunk(l4).float()
+    assert (got - pooled).abs().max() <= 2.0 ** -11 * pooled.abs().max() * 1.01       # one fp16 rounding
+    # correlation: same edges over both layouts
+    rng = np.random.default_rng(4)
+    E, M = 61, 12
+    fmap1 = (torch.randn(M, 3, 3, C, generator=g) * 0.5).half().cuda()
+    coords = np.stack([rng.uniform(-6, W + 6, (E, 3, 3)), rng.uniform(-6, H + 6, (E, 3, 3))], 1).astype(np.float32)
+    coords[:20] = coords[:20, :, :1, :1] + np.arange(3, dtype=np.float32)[None, None, None, :]   # compact windows
+    ii = torch.from_numpy(rng.integers(0, M, E)).cuda()
+    jj = torch.from_numpy(rng.integers(0, N2, E)).cuda()
+    pooled_h = unchunk(l4).contiguous()
+    a = ops.corr(fmap1, [maps, pooled_h], cu(coords), ii, jj, 3, (1.0, 4.0), RAMP_NHWC)
+    b = ops.corr(fmap1, [l1, l4], cu(coords), ii, jj, 3, (1.0, 4.0), RAMP_NHWC8)
+    assert torch.equal(torch.nan_to_num(a.float(), nan=-7.0), torch.nan_to_num(b.float(), nan=-7.0))
+    assert a.float().abs().max() > 0
+
+
 # ---------------------------------------------------------------- projective ops
 def test_transform_reproject_point_cloud():
     from rampvo_amd import ops
