@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--patches", type=int, default=96)
     ap.add_argument("--mode", default="SingleScale")
+    ap.add_argument("--preset", default="default", choices=("default", "precise", "fast"),
+                    help="config_vo preset for the BA / lifetime windows (configs[2] uses precise)")
     ap.add_argument("--mixed", type=int, default=1,
                     help="1 (default.yaml's MIXED_PRECISION: True): fp16 features / conv + GEMM I/O with fp32 "
                          "accumulation, fp32 hidden state, BA and geometry; 0: fp32 everywhere")
@@ -118,7 +120,7 @@ def cpu_baseline(state, args, cfg_kwargs, frames, steps):
         state[k] = state[k].float()
     with cpu_oracle_ops():
         net = make_network(args.mode, device="cpu")
-        slam = Ramp_vo(make_cfg("default", **cfg_kwargs), net, {"event_bias": True}, ht=args.height, wd=args.width,
+        slam = Ramp_vo(make_cfg(args.preset, **cfg_kwargs), net, {"event_bias": True}, ht=args.height, wd=args.width,
                        device="cpu")
         slam.load_state_dict(state)
         # encoder recurrent state is not part of the VO snapshot: one untimed step re-seeds it
@@ -154,7 +156,7 @@ def main():
     from rampvo_amd.synthetic import SyntheticStream, make_network
 
     cfg_kwargs = dict(PATCHES_PER_FRAME=args.patches, MIXED_PRECISION=bool(args.mixed))
-    cfg = make_cfg("default", **cfg_kwargs)
+    cfg = make_cfg(args.preset, **cfg_kwargs)
     torch.manual_seed(1234 + rank)
     net = make_network(args.mode, device=dev)
     slam = Ramp_vo(cfg, net, {"event_bias": True}, ht=args.height, wd=args.width, device=dev)
@@ -206,13 +208,14 @@ def main():
     if rank == 0:
         value = world * args.steps / dt_all
         out = {
-            "metric": "keyframes/sec (BA iters/sec) SingleScale 640x480; ATE vs reference",
+            "metric": "keyframes/sec (BA iters/sec) %s %dx%d; ATE vs reference" % (args.mode, args.width, args.height),
             "value": round(value, 3), "unit": "keyframes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt_all / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16 storage+MFMA inputs / f32 accumulate, state, BA (default.yaml MIXED_PRECISION)" if args.mixed else "f32",
-            "data": "synthetic (seeded 640x480 event+frame stream, seeded random-init weights)",
-            "config": {"workload": "%s %dx%d, %d patches/frame, default.yaml windows, 2 BA iters/keyframe, "
-                                   "steady-state sliding window" % (args.mode, args.width, args.height, args.patches),
+            "data": "synthetic (seeded %dx%d event+frame stream, seeded random-init weights)" % (args.width, args.height),
+            "config": {"workload": "%s %dx%d, %d patches/frame, %s.yaml windows, 2 BA iters/keyframe, "
+                                   "steady-state sliding window" % (args.mode, args.width, args.height, args.patches,
+                                                                    args.preset),
                        "ba_iters_per_s": round(2 * value, 2), "edges": E0, "edges_end": len(slam._ii),
                        "keyframes_in_window": n0, "prime_frames": args.prime,
                        "sharding": "independent sequences, 1 per GPU" if world > 1 else "single sequence"},

@@ -257,6 +257,19 @@ int ramp_lstm_superstate(const float *ev, const float *im, float *h_ev, float *c
                          float *c_im, float *ss, const float *wpacked, const int32_t *flags, int HW,
                          int has_state, int has_ss, void *stream);
 
+/* One scale (1, 2 or 4) of the MultiScale encoder's recurrent front end for one time step
+ * (ramp/extractor.py:540-566 with LSTMEncoder :376-385 and SuperStateEncoder :432-463): strided
+ * conv_1 on events / image, a per-pixel LSTM step from the zero state (hidden size D = 16*scale),
+ * then s <- mix_ev([s ; h_ev]) and, if use_im (the frame's mask), s <- mix_im([s ; h_im]).
+ *   ev [5][H][W], im [3][H][W] float32;  state [Hs*Ws][D] channels-last super-state, in/out
+ *   weights_host: 12 device pointers (a host array): conv_1 ev W [5][5][K][K], b; conv_1 im W
+ *   [3][3][K][K], b; LSTM ev W_ih [4D][5], b_ih+b_hh [4D]; LSTM im W_ih [4D][3], b [4D]; mix ev W^T
+ *   [2D][D], b [D]; mix im W^T [2D][D], b [D]    (packed by rampvo_amd/conv_hip.py::pack_ms_scale)
+ *   has_state: 0 on the first call after reinit_hidden (zero super-state)                        */
+int ramp_ms_lstm_superstate(const float *ev, const float *im, const float *const *weights_host,
+                            float *state, int H, int W, int scale, int has_state, int use_im,
+                            void *stream);
+
 /* nn.Conv2d (+ fused neighbours) of the encoder towers as an implicit GEMM on MFMA
  * (ramp/extractor.py:8-57, 60-130; reference: cuDNN).  NHWC activations, padding = K/2.
  *   x [H][W][Cin] (Cin % 16 == 0), y [OH][OW][Cout] (Cout % 32 == 0)

@@ -33,6 +33,7 @@ SIGNATURES = {
     "ramp_version": (ctypes.c_char_p, []),
     "ramp_patchify_fwd": (c_i, [c_p, c_p, c_p] + [c_i] * 10 + [c_p]),
     "ramp_corr_fwd": (c_i, [c_p, ctypes.POINTER(CorrLevel), c_i, c_p, c_p, c_p, c_p] + [c_i] * 8 + [c_p]),
+    "ramp_ms_lstm_superstate": (c_i, [c_p, c_p, ctypes.POINTER(c_p), c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "ramp_pyramid_pack": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "ramp_corr_fwd_ordered": (c_i, [c_p, ctypes.POINTER(CorrLevel), c_i, c_p, c_p, c_p, c_p, c_p] + [c_i] * 8
                               + [c_p]),

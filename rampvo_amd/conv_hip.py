@@ -155,6 +155,25 @@ def basic_encoder4(enc, x, out_scale=1.0, half=False):
     return conv2d(x, enc.conv2, out_scale=out_scale, half=half)
 
 
+def multiscale_encoder4(enc, x, x2, x4, out_scale=1.0, half=False):
+    """MultiScaleBasicEncoder4.forward (reference extractor.py:288-311) on NHWC inputs: x [H,W,16],
+    x2 [H/2,W/2,32] and x4 [H/4,W/4,64] (the three super-states) -> [H/4,W/4,out].  The channel
+    concatenations are the only non-conv steps; layer2/conv2 are unused, as upstream."""
+    norm = isinstance(enc.norm1, nn.InstanceNorm2d)
+    if norm:
+        x = materialize(conv2d(x, enc.conv1, want_stats=True, eps=enc.norm1.eps, half=half))
+    else:
+        assert isinstance(enc.norm1, nn.Sequential) and len(enc.norm1) == 0
+        x = conv2d(x, enc.conv1, relu=True, half=half)
+    for blk in enc.layer1:
+        x = _res_block(blk, x, norm, half)
+    x = torch.cat((x, x2.to(x.dtype)), dim=-1)
+    for blk in enc.layer3:
+        x = _res_block(blk, x, norm, half)
+    x = torch.cat((x, x4.to(x.dtype)), dim=-1)
+    return conv2d(x, enc.conv3, out_scale=out_scale, half=half)
+
+
 # ------------------------------------------------------------------ LSTM / super-state
 class LstmState:
     __slots__ = ("h_ev", "c_ev", "h_im", "c_im", "ss", "flags", "fresh", "HW")
@@ -181,3 +200,51 @@ def lstm_superstate_step(enc, ev, im, st):
           "ramp_lstm_superstate")
     st.fresh = False
     return st.ss.view(H, W, 16)
+
+
+# ----------------------------------------------------------- MultiScale front end
+class MsState:
+    """super-state of one scale: [Hs*Ws, D] channels-last rows"""
+    __slots__ = ("s", "fresh", "Hs", "Ws", "D")
+
+    def __init__(self, H, W, scale, device):
+        k, pad = (scale + 1, 1) if scale > 1 else (1, 0)
+        self.Hs, self.Ws, self.D = (H + 2 * pad - k) // scale + 1, (W + 2 * pad - k) // scale + 1, 16 * scale
+        self.s = torch.zeros(self.Hs * self.Ws, self.D, dtype=torch.float32, device=device)
+        self.fresh = True
+
+
+def pack_ms_scale(enc, k):
+    """the 12 weight arrays of ramp_ms_lstm_superstate for scale index k (see include/ramp_hip.h)"""
+    ev, im = enc.ev_encoders[k], enc.im_encoders[k]
+    me, mi = enc.super_state_ev_encoder[k].encoder, enc.super_state_im_encoders[k].encoder
+    params = [ev.conv_1.weight, ev.conv_1.bias, im.conv_1.weight, im.conv_1.bias,
+              ev.convlstm.weight_ih_l0, ev.convlstm.bias_ih_l0, ev.convlstm.bias_hh_l0,
+              im.convlstm.weight_ih_l0, im.convlstm.bias_ih_l0, im.convlstm.bias_hh_l0,
+              me.weight, me.bias, mi.weight, mi.bias]
+    key = tuple((q.data_ptr(), q._version) for q in params)
+    hit = _pack_cache.get(("ms", id(enc), k))
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    f = lambda t: t.detach().float().contiguous()
+    d = me.out_channels
+    arrs = [f(ev.conv_1.weight), f(ev.conv_1.bias), f(im.conv_1.weight), f(im.conv_1.bias),
+            f(ev.convlstm.weight_ih_l0), f(ev.convlstm.bias_ih_l0 + ev.convlstm.bias_hh_l0),
+            f(im.convlstm.weight_ih_l0), f(im.convlstm.bias_ih_l0 + im.convlstm.bias_hh_l0),
+            f(me.weight.view(d, 2 * d).t()), f(me.bias), f(mi.weight.view(d, 2 * d).t()), f(mi.bias)]
+    import ctypes
+    ptrs = (ctypes.c_void_p * 12)(*[a.data_ptr() for a in arrs])
+    _pack_cache[("ms", id(enc), k)] = (key, (arrs, ptrs))
+    return arrs, ptrs
+
+
+def ms_lstm_superstate_step(enc, k, ev, im, st, use_im):
+    """ev [5,H,W], im [3,H,W] contiguous fp32; advances scale k's super-state in place and returns
+    it as an NHWC tensor [Hs, Ws, D] (a view of st.s)"""
+    _, ptrs = pack_ms_scale(enc, k)
+    H, W = ev.shape[-2:]
+    check(lib().ramp_ms_lstm_superstate(ptr(ev), ptr(im), ptrs, ptr(st.s), H, W, enc.scales[k],
+                                        0 if st.fresh else 1, int(bool(use_im)), stream()),
+          "ramp_ms_lstm_superstate")
+    st.fresh = False
+    return st.s.view(st.Hs, st.Ws, st.D)

@@ -536,6 +536,116 @@ __global__ void __launch_bounds__(256)
   reinterpret_cast<float4 *>(out)[i] = v;
 }
 
+// ------------------------------------------------- MultiScale LSTM / super-state
+// One scale of MultiScaleMergerDoubleNet.forward for one time step (ramp/extractor.py:540-566):
+//   LSTMEncoder x2 (:376-385): conv_1 (k = S+1, stride S, pad 1; 1x1 for S = 1) on the 5 event /
+//   3 image channels, then ONE per-pixel LSTM step from a zero state (no state carry: c = i*g,
+//   h = o*tanh(c); the forget gate never acts), hidden size D = 16 S;
+//   SuperStateEncoder x2 (:432-463): s <- Conv1x1(2D -> D)([s ; h_ev]), and, when the frame is
+//   present (mask), s <- Conv1x1_im([s ; h_im]).
+// Thread (group g, unit u) produces unit u for PB pixels; the mix weights are transposed
+// ([2D][D]) so a wave reads one 256-byte row per input channel and re-uses it for its PB pixels.
+struct MsLstmParams {
+  const float *ev, *im;                 // [5][H][W], [3][H][W]
+  const float *wce, *bce, *wci, *bci;   // conv_1 weight [C][C][K][K], bias [C]
+  const float *wle, *ble, *wli, *bli;   // LSTM W_ih [4D][C], b_ih + b_hh [4D]
+  const float *wme, *bme, *wmi, *bmi;   // mixes, transposed [2D][D], bias [D]
+  float *state;                         // [Hs*Ws][D] super-state, in/out
+  int H, W, Hs, Ws, has_state, use_im;
+};
+
+template <int D, int S>
+__global__ void __launch_bounds__(256) ms_lstm_superstate_kernel(const MsLstmParams p) {
+  constexpr int K = S > 1 ? S + 1 : 1, PAD = S > 1 ? 1 : 0;
+  constexpr int G = 256 / D, PB = 4, NP = G * PB;
+  __shared__ float y_e[NP][5], y_i[NP][3];
+  __shared__ float vin[NP][2 * D];
+  __shared__ float h_im[NP][D];
+  const int u = threadIdx.x % D, g = threadIdx.x / D;
+  const int pix0 = blockIdx.x * NP, HWs = p.Hs * p.Ws;
+
+  // conv_1: NP pixels x (5 + 3) output channels
+  for (int v = threadIdx.x; v < NP * 8; v += 256) {
+    const int lp = v >> 3, c = v & 7, pix = pix0 + lp;
+    const bool isev = c < 5;
+    const int co = isev ? c : c - 5, C = isev ? 5 : 3;
+    float acc = 0.f;
+    if (pix < HWs) {
+      const int oy = pix / p.Ws, ox = pix - oy * p.Ws;
+      const float *x = isev ? p.ev : p.im;
+      const float *w = (isev ? p.wce : p.wci) + (size_t)co * C * K * K;
+      acc = (isev ? p.bce : p.bci)[co];
+      for (int ci = 0; ci < C; ci++)
+        for (int ky = 0; ky < K; ky++) {
+          const int iy = oy * S - PAD + ky;
+          if (iy < 0 || iy >= p.H) continue;
+          for (int kx = 0; kx < K; kx++) {
+            const int ix = ox * S - PAD + kx;
+            if (ix < 0 || ix >= p.W) continue;
+            acc = __builtin_fmaf(w[(ci * K + ky) * K + kx], x[((size_t)ci * p.H + iy) * p.W + ix], acc);
+          }
+        }
+    }
+    if (isev) y_e[lp][co] = acc; else y_i[lp][co] = acc;
+  }
+  __syncthreads();
+
+  // LSTM step from the zero state, both modalities; stage [s ; h_ev]
+#pragma unroll
+  for (int b = 0; b < PB; b++) {
+    const int lp = g * PB + b, pix = pix0 + lp;
+    float gi = p.ble[u], gg = p.ble[2 * D + u], go = p.ble[3 * D + u];
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+      const float y = y_e[lp][c];
+      gi = __builtin_fmaf(p.wle[u * 5 + c], y, gi);
+      gg = __builtin_fmaf(p.wle[(2 * D + u) * 5 + c], y, gg);
+      go = __builtin_fmaf(p.wle[(3 * D + u) * 5 + c], y, go);
+    }
+    vin[lp][D + u] = sigmoidf_(go) * tanhf(sigmoidf_(gi) * tanhf(gg));
+    gi = p.bli[u]; gg = p.bli[2 * D + u]; go = p.bli[3 * D + u];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const float y = y_i[lp][c];
+      gi = __builtin_fmaf(p.wli[u * 3 + c], y, gi);
+      gg = __builtin_fmaf(p.wli[(2 * D + u) * 3 + c], y, gg);
+      go = __builtin_fmaf(p.wli[(3 * D + u) * 3 + c], y, go);
+    }
+    h_im[lp][u] = sigmoidf_(go) * tanhf(sigmoidf_(gi) * tanhf(gg));
+    vin[lp][u] = (p.has_state && pix < HWs) ? p.state[(size_t)pix * D + u] : 0.f;
+  }
+  __syncthreads();
+
+  float acc[PB];
+#pragma unroll
+  for (int b = 0; b < PB; b++) acc[b] = p.bme[u];
+  for (int k = 0; k < 2 * D; k++) {
+    const float w = p.wme[k * D + u];
+#pragma unroll
+    for (int b = 0; b < PB; b++) acc[b] = __builtin_fmaf(w, vin[g * PB + b][k], acc[b]);
+  }
+  if (p.use_im) {
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < PB; b++) {
+      vin[g * PB + b][u] = acc[b];
+      vin[g * PB + b][D + u] = h_im[g * PB + b][u];
+      acc[b] = p.bmi[u];
+    }
+    __syncthreads();
+    for (int k = 0; k < 2 * D; k++) {
+      const float w = p.wmi[k * D + u];
+#pragma unroll
+      for (int b = 0; b < PB; b++) acc[b] = __builtin_fmaf(w, vin[g * PB + b][k], acc[b]);
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < PB; b++) {
+    const int pix = pix0 + g * PB + b;
+    if (pix < HWs) p.state[(size_t)pix * D + u] = acc[b];
+  }
+}
+
 extern "C" {
 
 int ramp_affine_relu(const float *x, const float *s, const float *h, float *out, long n, int C,
@@ -650,6 +760,35 @@ int ramp_norm_add_relu(const float *y, const float *sy, const float *hy, const f
   const long n4 = n / 4;
   hipLaunchKernelGGL(norm_add_relu_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, y, sy, hy, skip, ss, hs, out, n4, C);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+
+int ramp_ms_lstm_superstate(const float *ev, const float *im, const float *const *weights_host,
+                            float *state, int H, int W, int scale, int has_state, int use_im,
+                            void *stream) {
+  if (!ev || !im || !weights_host || !state || H <= 0 || W <= 0) return RAMP_EINVAL;
+  for (int i = 0; i < 12; i++)
+    if (!weights_host[i]) return RAMP_EINVAL;
+  if (scale != 1 && scale != 2 && scale != 4) return RAMP_EUNSUPPORTED;
+  MsLstmParams p;
+  p.ev = ev; p.im = im;
+  p.wce = weights_host[0]; p.bce = weights_host[1]; p.wci = weights_host[2]; p.bci = weights_host[3];
+  p.wle = weights_host[4]; p.ble = weights_host[5]; p.wli = weights_host[6]; p.bli = weights_host[7];
+  p.wme = weights_host[8]; p.bme = weights_host[9]; p.wmi = weights_host[10]; p.bmi = weights_host[11];
+  p.state = state;
+  p.H = H; p.W = W;
+  const int k = scale > 1 ? scale + 1 : 1, pad = scale > 1 ? 1 : 0;
+  p.Hs = (H + 2 * pad - k) / scale + 1;
+  p.Ws = (W + 2 * pad - k) / scale + 1;
+  if (p.Hs <= 0 || p.Ws <= 0) return RAMP_EINVAL;
+  p.has_state = has_state; p.use_im = use_im;
+  const int D = 16 * scale, np = (256 / D) * 4;
+  const dim3 grid(ramp_cdiv(p.Hs * p.Ws, np));
+  hipStream_t st = (hipStream_t)stream;
+  if (scale == 1) hipLaunchKernelGGL((ms_lstm_superstate_kernel<16, 1>), grid, dim3(256), 0, st, p);
+  else if (scale == 2) hipLaunchKernelGGL((ms_lstm_superstate_kernel<32, 2>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((ms_lstm_superstate_kernel<64, 4>), grid, dim3(256), 0, st, p);
   RAMP_CHECK_LAUNCH();
   return RAMP_OK;
 }

@@ -267,9 +267,35 @@ class MultiScaleMergerDoubleNet(nn.Module):
         self.imap_encoder = MultiScaleBasicEncoder4(output_dim=output_dim_i, norm_fn=norm_fn_imap,
                                                     channel_dim=lstm_dim,
                                                     internal_input_dimensions=self.internal_dimensions)
+        self._hip_state = None
+        self.mixed_precision = False      # fp16 storage / fp16 MFMA conv towers (set by Ramp_vo from cfg)
+
+    def _forward_hip(self, events, images, present, reinit_hidden, out_scale):
+        """one time step on the GPU: fused conv_1 + LSTM + super-state kernel per scale, then the MFMA
+        conv towers (csrc/conv.hip).  ``present``: the frame's mask (events-only steps advance the
+        super-states and produce no maps)."""
+        from . import conv_hip
+        H, W = events.shape[-2:]
+        ev, im = events[0, 0].float().contiguous(), images[0, 0].float().contiguous()
+        st = self._hip_state
+        if st is None or st[0].s.device != events.device or (st[0].Hs, st[0].Ws) != (H, W):
+            st = self._hip_state = [conv_hip.MsState(H, W, s, events.device) for s in self.scales]
+        xs = []
+        for k in range(len(self.scales)):
+            if reinit_hidden:
+                st[k].fresh = True
+            xs.append(conv_hip.ms_lstm_superstate_step(self, k, ev, im, st[k], present))
+        if not present:
+            return None, None
+        half = self.mixed_precision
+        f = conv_hip.multiscale_encoder4(self.fmap_encoder, xs[0], xs[1], xs[2], out_scale, half=half)
+        i = conv_hip.multiscale_encoder4(self.imap_encoder, xs[0], xs[1], xs[2], out_scale, half=half)
+        return f.permute(2, 0, 1)[None, None], i.permute(2, 0, 1)[None, None]
 
     def forward(self, events, images, mask, reinit_hidden=False, out_scale=1.0):
         mask_list = [bool(m) for m in mask.reshape(-1).tolist()]
+        if events.shape[1] == 1 and len(mask_list) == 1 and C.use_hip(events):
+            return self._forward_hip(events, images, mask_list[0], reinit_hidden, out_scale)
         outs = []
         for k in range(len(self.scales)):
             if reinit_hidden:

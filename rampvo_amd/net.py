@@ -150,18 +150,21 @@ class Patchifier(nn.Module):
 
     def forward(self, input_, patches_per_image=80, reinit_hidden=False, disps=None, event_bias=False,
                 gradient_bias=False):
-        """On the GPU the whole SingleScale front-end (fused LSTM, ~35 conv-tower launches, patch
+        """On the GPU the whole front-end (fused LSTM, ~35 conv-tower launches, patch
         selection, 4 patch gathers: ~60 launches of static shape) is captured into ONE hipGraph
         after a warm-up call and replayed per frame; results live in the graph's static output
         buffers until the next call (Ramp_vo copies them into its ring buffers immediately)."""
         events, images, mask = input_
-        graphable = (self.use_graph and events.is_cuda and self.input_mode == "SingleScale" and event_bias
+        graphable = (self.use_graph and events.is_cuda and event_bias
                      and disps is None and not reinit_hidden and events.shape[1] == 1 and not torch.is_grad_enabled())
+        if graphable and self.input_mode != "SingleScale":
+            # MultiScale: only frames that are present (host-side mask) share one static graph
+            graphable = mask is not None and mask.device.type == "cpu" and mask.numel() == 1 and bool(mask.all())
         if not graphable:
             self._graph_warm = 0 if reinit_hidden else self._graph_warm
             return self._forward_impl(input_, patches_per_image, reinit_hidden, disps, event_bias, gradient_bias)
-        key = (tuple(events.shape), tuple(images.shape), patches_per_image, events.dtype, images.dtype,
-               bool(getattr(self.encoder, "mixed_precision", False)), events.device)
+        key = (self.input_mode, tuple(events.shape), tuple(images.shape), patches_per_image, events.dtype,
+               images.dtype, bool(getattr(self.encoder, "mixed_precision", False)), events.device)
         g = self._graphs.get(key)
         if g is None:
             if self._graph_warm < 1:      # one eager call with carried state first (allocator / pack caches warm)
@@ -191,7 +194,8 @@ class Patchifier(nn.Module):
         else:
             fmap, imap = self.encoder(events=events, images=images, mask=mask, reinit_hidden=reinit_hidden,
                                       out_scale=0.25)
-            events = events[mask]
+            if not bool(mask.all()):
+                events = events[mask]
         if mask is not None and not mask.any():
             return None, None, None, None, None, None
         b, n, c, h, w = fmap.shape

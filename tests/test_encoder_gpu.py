@@ -160,3 +160,63 @@ def test_singlescale_encoder_hip_vs_aten():
         assert f0.shape == f1.shape and i0.shape == i1.shape
         assert float((f0 - f1).abs().max()) <= 2e-3 * float(f0.abs().max())
         assert float((i0 - i1).abs().max()) <= 2e-3 * float(i0.abs().max())
+
+
+def test_multiscale_encoder_hip_vs_aten():
+    """MultiScale front end: fused conv_1 + zero-state LSTM + super-state kernel per scale and the
+    MFMA towers against the ATen path, including an events-only step (mask False)"""
+    from rampvo_amd import conv
+    from rampvo_amd.synthetic import SyntheticStream, make_network
+    net = make_network("MultiScale")
+    enc = net.patchify.encoder
+    stream = SyntheticStream(96, 128, 4, seed=6)
+    masks = [True, True, False, True]
+    outs = {}
+    with torch.no_grad():
+        for backend in ("torch", "hip"):
+            conv.set_backend(backend)
+            res = []
+            for t in range(4):
+                im, ev, _, _ = stream.frame(t)
+                f, i = enc(events=ev.cuda(), images=im.cuda(), mask=torch.tensor([masks[t]]), reinit_hidden=(t == 0),
+                           out_scale=0.25)
+                if masks[t]:
+                    res.append((f.float().clone(), i.float().clone()))
+            outs[backend] = res
+            if backend == "hip":
+                states = [s.s.clone() for s in enc._hip_state]
+            else:
+                ref_states = [s.clone() for s in enc.super_states]
+    conv.set_backend("auto")
+    for a, b in zip(ref_states, states):
+        assert a.shape == b.shape and float((a - b).abs().max()) <= 2e-5 * max(1.0, float(a.abs().max()))
+    assert len(outs["hip"]) == 3
+    for (f0, i0), (f1, i1) in zip(outs["torch"], outs["hip"]):
+        assert f0.shape == f1.shape and i0.shape == i1.shape
+        assert float((f0 - f1).abs().max()) <= 2e-3 * float(f0.abs().max())
+        assert float((i0 - i1).abs().max()) <= 2e-3 * float(i0.abs().max())
+
+
+@pytest.mark.parametrize("mode", ["SingleScale", "MultiScale"])
+def test_front_end_graph_replay_equals_eager(mode):
+    """the hipGraph-captured front end (encoder + patch selection + gathers) replays to exactly what
+    the eager launches produce, frame after frame (recurrent state carried through the graph)"""
+    from rampvo_amd.synthetic import SyntheticStream, make_network
+    stream = SyntheticStream(96, 128, 6, seed=9)
+    res = {}
+    for use_graph in (False, True):
+        net = make_network(mode)
+        net.patchify.use_graph = use_graph
+        out = []
+        with torch.no_grad():
+            for t in range(6):
+                im, ev, _, _ = stream.frame(t)
+                r = net.patchify(input_=(ev.cuda(), im.cuda(), torch.tensor([True])), patches_per_image=8,
+                                 event_bias=True, reinit_hidden=(t == 0))
+                out.append([x.float().clone() for x in r])
+        res[use_graph] = out
+        if use_graph:
+            assert len(net.patchify._graphs) == 1      # frames 2.. ran as replays
+    for a, b in zip(res[False], res[True]):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
