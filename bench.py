@@ -87,6 +87,20 @@ class CorrTimer:
 
         altcorr.corr_pyramid = timed
 
+    @staticmethod
+    def pmc_traffic_per_edge(elem_bytes):
+        """HBM-side bytes per edge of the fp16 kernel from the committed rocprofv3 PMC passes
+        (FETCH_SIZE x2 per the guide's gfx950 correction + WRITE_SIZE; profiles/pmc/r01_corr_traffic.json).
+        Counters cannot be read inside this process, so the per-edge figure of the PMC run of the same
+        workload is scaled by this run's edges per launch.  None for the fp32 kernel (not measured)."""
+        if elem_bytes != 2:
+            return None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc", "r01_corr_traffic.json")) as f:
+                return float(json.load(f)["bytes_per_edge"])
+        except Exception:
+            return None
+
     def summary(self, elem_bytes):
         if not self.pairs:
             return None
@@ -99,10 +113,78 @@ class CorrTimer:
         bytes_per_launch = float((edges[big] * 2 * per_edge_level).mean())
         mean_ms = float(ms[big].mean())
         achieved = bytes_per_launch / (mean_ms * 1e-3) / 1e9
-        return dict(kernel="corr_kernel", bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None, launches=int(big.sum()),
-                    mean_launch_us=round(mean_ms * 1e3, 1), bytes_per_launch=int(bytes_per_launch),
-                    edges_per_launch=int(edges[big].mean()))
+        per_edge = self.pmc_traffic_per_edge(elem_bytes)
+        traffic = int(per_edge * edges[big].mean()) if per_edge else None
+        out = dict(kernel="corr_mfma_f16_kernel" if elem_bytes == 2 else "corr_kernel<float>", bound="hbm",
+                   achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                   frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, launches=int(big.sum()),
+                   mean_launch_us=round(mean_ms * 1e3, 1), bytes_per_launch=int(bytes_per_launch),
+                   edges_per_launch=int(edges[big].mean()))
+        if traffic:
+            # the algorithmic model counts every edge's window privately; overlapping windows are served
+            # from L2 / the XCD-local schedule, so measured traffic is well below it and frac can exceed 1
+            out["traffic_gbps"] = round(traffic / (mean_ms * 1e-3) / 1e9, 1)
+            out["traffic_frac_of_peak"] = round(traffic / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        return out
+
+
+MFMA_F16_PEAK_TFLOPS = 2500.0   # dense f16 MFMA, MI355X_MICROARCH.md
+MFMA_F32_PEAK_TFLOPS = 157.0    # fp32 MFMA (the --mixed 0 towers)
+
+
+class EncoderTimer:
+    """HIP events around the encoder front end (one hipGraph replay per frame: fused LSTM + conv towers
+    + patch selection + gathers) and the conv FLOPs of one frame, counted from the shapes of the
+    ramp_conv2d_nhwc calls of an eager (un-captured) frame."""
+
+    def __init__(self):
+        self.pairs, self.enabled = [], False
+        self.flops_frame, self._acc = 0, 0
+
+    def install(self, net):
+        from rampvo_amd import conv_hip
+        timer, conv_inner = self, conv_hip.conv2d
+
+        def counted(x, conv, *a, **k):
+            y = conv_inner(x, conv, *a, **k)
+            o = y.raw if isinstance(y, conv_hip.Pending) else y
+            cout, cin, kh, kw = conv.weight.shape
+            timer._acc += 2 * o.shape[0] * o.shape[1] * cout * cin * kh * kw
+            return y
+
+        conv_hip.conv2d = counted
+        pat = net.patchify
+        impl_inner, fwd_inner = pat._forward_impl, pat.forward
+
+        def impl(*a, **k):
+            timer._acc = 0
+            r = impl_inner(*a, **k)
+            timer.flops_frame = max(timer.flops_frame, timer._acc)
+            return r
+
+        def fwd(*a, **k):
+            if not timer.enabled:
+                return fwd_inner(*a, **k)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = fwd_inner(*a, **k)
+            e.record()
+            timer.pairs.append((s, e))
+            return r
+
+        pat._forward_impl, pat.forward = impl, fwd
+
+    def summary(self, mixed):
+        if not self.pairs or not self.flops_frame:
+            return None
+        ms = float(np.mean([s.elapsed_time(e) for s, e in self.pairs]))
+        peak = MFMA_F16_PEAK_TFLOPS if mixed else MFMA_F32_PEAK_TFLOPS
+        ach = self.flops_frame / (ms * 1e-3) / 1e12
+        return dict(kernel="encoder front end (conv_mfma_* towers + fused LSTM + patch selection, 1 hipGraph)",
+                    bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 5),
+                    conv_gflop_per_frame=round(self.flops_frame / 1e9, 2), mean_front_end_us=round(ms * 1e3, 1),
+                    note="32/64-channel layers: arithmetic intensity is below the machine balance, the towers are "
+                         "latency/HBM bound; MFMA busy from PMC: profiles/pmc/r01_g_MFMA_BUSY_per_kernel.txt")
 
 
 def cpu_baseline(state, args, cfg_kwargs, frames, steps):
@@ -165,9 +247,10 @@ def main():
     stream = SyntheticStream(args.height, args.width, total + n_cpu + 1, seed=1234 + rank, device=dev)
     frames = [tuple(x.to(dev) if i < 2 else x for i, x in enumerate(stream.frame(t))) for t in range(total)]
 
-    ctimer = CorrTimer()
+    ctimer, etimer = CorrTimer(), EncoderTimer()
     if not args.no_kernel_timing:
         ctimer.install()
+        etimer.install(net)
 
     def step(t):
         im, ev, K, mask = frames[t]
@@ -185,7 +268,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ctimer.enabled = True
+    ctimer.enabled = etimer.enabled = True
     tic = time.perf_counter()
     for _ in range(args.steps):
         step(t); t += 1
@@ -194,7 +277,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - tic
-    ctimer.enabled = False
+    ctimer.enabled = etimer.enabled = False
 
     from rampvo_amd.shard import gather_metrics, max_over_ranks
     dt_all = max_over_ranks(dt, dev)
@@ -225,6 +308,9 @@ def main():
         rl = ctimer.summary(2 if args.mixed else 4)
         if rl is not None:
             out["roofline"] = rl
+        el = etimer.summary(bool(args.mixed))
+        if el is not None:
+            out["roofline_encoder"] = el
         if n_cpu:
             state = slam.state_dict()
             cpu_frames = [stream.frame(total + i) for i in range(n_cpu)]
