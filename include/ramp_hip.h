@@ -277,8 +277,8 @@ int ramp_ms_lstm_superstate(const float *ev, const float *im, const float *const
  *   pre_scale/pre_shift [Cin] (optional): x <- relu(x*scale + shift) while loading, i.e. the
  *       producer's InstanceNorm + ReLU fused into this conv
  *   y = [relu]( conv + bias );  if res: y = relu(y + res);  y *= out_scale
- *   stats (optional) [ceil(OH*OW/128)][Cout][2]: per-block partial sum / sum of squares of
- *       (conv + bias), reduced by ramp_in_stats_finalize                                       */
+ *   stats (optional) [ramp_conv2d_stats_blocks(...)][Cout][2]: per-block partial sum / sum of
+ *       squares of (conv + bias), reduced by ramp_in_stats_finalize                                     */
 int ramp_conv2d_nhwc(const void *x, const void *wpk, const float *bias, const float *pre_scale,
                      const float *pre_shift, const void *res, void *y, float *stats, int H, int W,
                      int Cin, int Cout, int KH, int KW, int stride, int relu, float out_scale,
@@ -288,6 +288,12 @@ int ramp_conv2d_nhwc(const void *x, const void *wpk, const float *bias, const fl
  * MFMA, fp32 accumulation / bias / statistics; Cin % 32 == 0) or RAMP_F16|RAMP_IN_F32 (fp32 in,
  * half out: the first layer of the mixed-precision tower, Cin == 16)                            */
 #define RAMP_IN_F32 0x10
+/* fp16 only: use the direct (one global round trip per tap) kernel instead of the LDS-tiled one;
+ * both give identical results (kept for the A/B test)                                          */
+#define RAMP_CONV_DIRECT 0x20
+
+/* number of per-block partials ramp_conv2d_nhwc writes to `stats` for this layer shape / dtype   */
+int ramp_conv2d_stats_blocks(int H, int W, int Cin, int Cout, int KH, int stride, int dtype);
 
 /* InstanceNorm2d statistics (affine=False, biased variance): scale = rsqrt(var+eps),
  * shift = -mean*scale, from the per-block partials of ramp_conv2d_nhwc                         */

@@ -16,6 +16,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("RAMP_HIP_LIB") or os.path.join(CSRC, "libramp_hip.so")   # env: kernel A/B builds
 
 RAMP_F32, RAMP_F16 = 0, 1
+RAMP_IN_F32, RAMP_CONV_DIRECT = 0x10, 0x20
 RAMP_NCHW, RAMP_NHWC, RAMP_NHWC8 = 0, 1, 2
 
 _ERR = {-1: "RAMP_EINVAL (bad argument)", -2: "RAMP_ELAUNCH (HIP launch/runtime error)",
@@ -34,6 +35,7 @@ SIGNATURES = {
     "ramp_patchify_fwd": (c_i, [c_p, c_p, c_p] + [c_i] * 10 + [c_p]),
     "ramp_corr_fwd": (c_i, [c_p, ctypes.POINTER(CorrLevel), c_i, c_p, c_p, c_p, c_p] + [c_i] * 8 + [c_p]),
     "ramp_ms_lstm_superstate": (c_i, [c_p, c_p, ctypes.POINTER(c_p), c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "ramp_conv2d_stats_blocks": (c_i, [c_i] * 7),
     "ramp_pyramid_pack": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "ramp_corr_fwd_ordered": (c_i, [c_p, ctypes.POINTER(CorrLevel), c_i, c_p, c_p, c_p, c_p, c_p] + [c_i] * 8
                               + [c_p]),

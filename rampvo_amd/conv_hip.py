@@ -70,7 +70,8 @@ class Pending:
         self.raw, self.scale, self.shift = raw, scale, shift
 
 
-def conv2d(x, conv, pre=None, res=None, relu=False, want_stats=False, out_scale=1.0, eps=1e-5, half=False):
+def conv2d(x, conv, pre=None, res=None, relu=False, want_stats=False, out_scale=1.0, eps=1e-5, half=False,
+           direct=False):
     """x [H,W,Cin] NHWC (or a Pending: normalise+ReLU on load).  fp32 in/out, or with ``half``:
     half out and half in (fp32 in allowed for the 16-channel first layer).  Returns y [OH,OW,Cout],
     or Pending(y, scale, shift) when want_stats (InstanceNorm statistics of y, always fp32)."""
@@ -80,9 +81,11 @@ def conv2d(x, conv, pre=None, res=None, relu=False, want_stats=False, out_scale=
     if not half:
         mode, code, odt = "f32", RAMP_F32, torch.float32
     elif x.dtype == torch.float32:
-        mode, code, odt = "f16_first", _lib.RAMP_F16 | 0x10, torch.float16
+        mode, code, odt = "f16_first", _lib.RAMP_F16 | _lib.RAMP_IN_F32, torch.float16
     else:
         mode, code, odt = "f16", _lib.RAMP_F16, torch.float16
+    if direct and half:
+        code |= _lib.RAMP_CONV_DIRECT        # the one-round-trip-per-tap kernel (A/B test of the LDS-tiled one)
     wpk, bias = pack_conv_weight(conv, mode)
     cout, _, kh, kw = conv.weight.shape
     stride = conv.stride[0]
@@ -92,7 +95,8 @@ def conv2d(x, conv, pre=None, res=None, relu=False, want_stats=False, out_scale=
     OH = (H + 2 * (kh // 2) - kh) // stride + 1
     OW = (W + 2 * (kw // 2) - kw) // stride + 1
     y = torch.empty(OH, OW, cout, dtype=odt, device=x.device)
-    nblk = (OH * OW + 127) // 128
+    nblk = lib().ramp_conv2d_stats_blocks(H, W, Cin, cout, kh, stride, code)
+    assert nblk > 0
     stats = torch.empty(nblk, cout, 2, dtype=torch.float32, device=x.device) if want_stats else None
     check(lib().ramp_conv2d_nhwc(ptr(x), ptr(wpk), ptr(bias), ptr(pre[0]) if pre else None,
                                  ptr(pre[1]) if pre else None, ptr(res), ptr(y), ptr(stats), H, W, Cin, cout,

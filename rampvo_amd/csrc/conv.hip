@@ -442,6 +442,207 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// LDS-tiled fp16 variant: the layers of these towers are tiny (32/64 channels, <= 77k pixels), so
+// the direct kernel above spends its time on one global round trip per tap and on re-applying
+// the InstanceNorm prologue 9 (49) times per input value.  Here a workgroup owns an 8 x 16 output
+// tile:
+//   1. every thread issues ALL its 16-byte loads of the (halo) input tile and of the weight
+//      fragments at once, applies relu(x*scale+shift) once per value and parks them in LDS;
+//   2. the K*K*Cin/32 MFMA steps then run from LDS only (wave w = output rows 2w, 2w+1; the A
+//      fragment of lane (q, j) is pixel (row, j), channels 8q.. of the chunk: one ds_read_b128;
+//      pixel stride Cin*2+16 bytes keeps the 16 lanes of a quarter-wave on distinct banks);
+//   3. bias / statistics / ReLU in registers, then the tile goes through LDS once more (fp32) so
+//      the residual is read and the result written as contiguous 16-byte pieces.
+// Same accumulation order as the direct kernel => identical results.
+template <int K, int S, bool IN_F32, int CIN, int NT>
+__global__ void __launch_bounds__(256) conv_tile_f16_kernel(const ConvParams p) {
+  constexpr int PAD = K / 2, TH = 8, TW = 16;
+  constexpr int SP = K == 1 ? 1 : S;                  // tile-pixel step between output neighbours
+  constexpr int STEP = K == 1 ? S : 1;                // image-pixel step between tile pixels
+  constexpr int IH = (TH - 1) * SP + K, IW = (TW - 1) * SP + K;
+  constexpr int PSTR = CIN * 2 + 16;                  // LDS bytes per tile pixel
+  constexpr int KC = IN_F32 ? 16 : 32, NCH = CIN / KC;
+  constexpr int FRAG = IN_F32 ? 8 : 16;               // bytes per lane per B fragment
+  constexpr int CPI = IN_F32 ? 4 : 8;                 // channels per 16-byte global item
+  constexpr int CH8 = CIN / CPI;                      // items per pixel
+  constexpr int NITEM = IH * IW * CH8, NI = (NITEM + 255) / 256;
+  constexpr int WBYTES = K * K * NCH * NT * 64 * FRAG, NW = (WBYTES / 16 + 255) / 256;
+  constexpr int IBYTES = IH * IW * PSTR;
+  constexpr int OSTR = NT * 16 + 4;                   // fp32 staging row (floats), 16-byte aligned
+  constexpr int OBYTES = TH * TW * OSTR * 4;
+  constexpr int SMB = (WBYTES + IBYTES) > OBYTES ? (WBYTES + IBYTES) : OBYTES;
+  static_assert(256 % CH8 == 0, "a thread keeps one channel slot");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMB];
+  __shared__ float s_stat[4][NT * 16][2];
+  unsigned char *s_w = smem, *s_in = smem + WBYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, j = lane & 15;
+  const int tiles_x = (p.OW + TW - 1) / TW;
+  const int ty0 = blockIdx.x / tiles_x, tx0 = blockIdx.x - ty0 * tiles_x;
+  const int oy0 = ty0 * TH, ox0 = tx0 * TW;
+  const int n0 = blockIdx.y * NT * 16, ntiles = p.Cout / 16;
+
+  // ---- 1. all global loads first (native vector types: the arrays must stay in registers)
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 wbuf[NW];
+#pragma unroll
+  for (int n = 0; n < NW; n++) {
+    const int i = tid + n * 256;
+    constexpr int SEG = NT * 64 * FRAG / 16;        // 16-byte pieces per (tap, chunk) of this n-block
+    const int ic = i < WBYTES / 16 ? i : 0;
+    const int seg = ic / SEG, within = ic - seg * SEG;
+    wbuf[n] = reinterpret_cast<const u32x4 *>(p.wpk)[((size_t)seg * ntiles + n0 / 16) * (64 * FRAG / 16) + within];
+  }
+  u32x4 ibuf[NI];
+  bool iok[NI];
+  const int cslot = tid % CH8;
+#pragma unroll
+  for (int n = 0; n < NI; n++) {
+    const int i = tid + n * 256;
+    const int pix = i / CH8, ty = pix / IW, tx = pix - ty * IW;
+    const int gy = oy0 * S + ty * STEP - PAD, gx = ox0 * S + tx * STEP - PAD;
+    iok[n] = i < NITEM && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+    const int cy = iok[n] ? gy : 0, cx = iok[n] ? gx : 0;      // always a valid address; masked below
+    ibuf[n] = reinterpret_cast<const u32x4 *>(p.x)[((size_t)cy * p.W + cx) * CH8 + cslot];
+  }
+  float sc[8], sh[8];
+  const bool pre = p.pre_scale != nullptr;
+  if (pre) {
+#pragma unroll
+    for (int c = 0; c < CPI; c++) { sc[c] = p.pre_scale[cslot * CPI + c]; sh[c] = p.pre_shift[cslot * CPI + c]; }
+  }
+#pragma unroll
+  for (int n = 0; n < NW; n++) {
+    const int i = tid + n * 256;
+    if (i < WBYTES / 16) reinterpret_cast<u32x4 *>(s_w)[i] = wbuf[n];
+  }
+#pragma unroll
+  for (int n = 0; n < NI; n++) {
+    const int i = tid + n * 256;
+    const int pix = i / CH8;
+    if (IN_F32) {
+      const f32x4 f = __builtin_bit_cast(f32x4, ibuf[n]);
+      f16x4 h;
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const float v = pre ? fmaxf(f[c] * sc[c] + sh[c], 0.f) : f[c];
+        h[c] = iok[n] ? (_Float16)v : (_Float16)0.f;
+      }
+      if (i < NITEM) *reinterpret_cast<f16x4 *>(s_in + pix * PSTR + cslot * 8) = h;
+    } else {
+      f16x8 h = __builtin_bit_cast(f16x8, ibuf[n]);
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        const float v = pre ? fmaxf((float)h[c] * sc[c] + sh[c], 0.f) : (float)h[c];
+        h[c] = iok[n] ? (_Float16)v : (_Float16)0.f;
+      }
+      if (i < NITEM) *reinterpret_cast<f16x8 *>(s_in + pix * PSTR + cslot * 16) = h;
+    }
+  }
+  __syncthreads();
+
+  // ---- 2. MFMA from LDS
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < NT; b++) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const unsigned char *a_base = s_in + ((2 * wave) * SP * IW + j * SP) * PSTR + q * (IN_F32 ? 8 : 16);
+  const unsigned char *b_base = s_w + lane * FRAG;
+#pragma unroll
+  for (int ky = 0; ky < K; ky++) {
+#pragma unroll
+    for (int kx = 0; kx < K; kx++) {
+#pragma unroll
+      for (int ch = 0; ch < NCH; ch++) {
+        const int tap = ky * K + kx;
+        if (IN_F32) {
+          f16x4 a[2], b[NT];
+#pragma unroll
+          for (int mt = 0; mt < 2; mt++)
+            a[mt] = *reinterpret_cast<const f16x4 *>(a_base + ((mt * SP + ky) * IW + kx) * PSTR + ch * KC * 2);
+#pragma unroll
+          for (int nt = 0; nt < NT; nt++)
+            b[nt] = *reinterpret_cast<const f16x4 *>(b_base + ((tap * NCH + ch) * NT + nt) * 64 * FRAG);
+#pragma unroll
+          for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+        } else {
+          f16x8 a[2], b[NT];
+#pragma unroll
+          for (int mt = 0; mt < 2; mt++)
+            a[mt] = *reinterpret_cast<const f16x8 *>(a_base + ((mt * SP + ky) * IW + kx) * PSTR + ch * KC * 2);
+#pragma unroll
+          for (int nt = 0; nt < NT; nt++)
+            b[nt] = *reinterpret_cast<const f16x8 *>(b_base + ((tap * NCH + ch) * NT + nt) * 64 * FRAG);
+#pragma unroll
+          for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  __syncthreads();          // every wave is done with the input / weight tiles
+
+  // ---- 3. epilogue: bias, statistics, ReLU -> fp32 tile in LDS
+  float *s_out = reinterpret_cast<float *>(smem);
+#pragma unroll
+  for (int nt = 0; nt < NT; nt++) {
+    const int c = n0 + nt * 16 + j;
+    const float bv = p.bias ? p.bias[c] : 0.0f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++) {
+      const int r = 2 * wave + mt;
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++) {
+        const int xx = 4 * q + rr;
+        float v = acc[mt][nt][rr] + bv;
+        if (oy0 + r < p.OH && ox0 + xx < p.OW) { s1 += v; s2 += v * v; }
+        if (p.relu) v = fmaxf(v, 0.f);
+        s_out[(r * TW + xx) * OSTR + nt * 16 + j] = v;
+      }
+    }
+    if (p.stats) {
+      s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+      if (q == 0) { s_stat[wave][nt * 16 + j][0] = s1; s_stat[wave][nt * 16 + j][1] = s2; }
+    }
+  }
+  __syncthreads();
+  if (p.stats && tid < NT * 32) {
+    const int c = tid >> 1, k = tid & 1;
+    const float v = ((s_stat[0][c][k] + s_stat[1][c][k]) + s_stat[2][c][k]) + s_stat[3][c][k];
+    p.stats[((size_t)blockIdx.x * p.Cout + n0 + c) * 2 + k] = v;
+  }
+  // 16-byte pieces: pixel-major, 8 channels each
+  constexpr int PPP = NT * 2;                         // pieces per pixel
+  for (int i = tid; i < TH * TW * PPP; i += 256) {
+    const int pix = i / PPP, piece = i - pix * PPP;
+    const int r = pix / TW, xx = pix - r * TW;
+    const int oy = oy0 + r, ox = ox0 + xx;
+    if (oy >= p.OH || ox >= p.OW) continue;
+    const float *sv = s_out + pix * OSTR + piece * 8;
+    const size_t go = ((size_t)oy * p.OW + ox) * p.Cout + n0 + piece * 8;
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) v[c] = sv[c];
+    if (p.res) {
+      const f16x8 rv = *reinterpret_cast<const f16x8 *>(reinterpret_cast<const _Float16 *>(p.res) + go);
+#pragma unroll
+      for (int c = 0; c < 8; c++) v[c] = fmaxf(v[c] + (float)rv[c], 0.f);
+    }
+    f16x8 h;
+#pragma unroll
+    for (int c = 0; c < 8; c++) h[c] = (_Float16)(v[c] * p.out_scale);
+    *reinterpret_cast<f16x8 *>(reinterpret_cast<_Float16 *>(p.y) + go) = h;
+  }
+}
+
 // InstanceNorm statistics: partial[nblk][C][2] -> scale = rstd, shift = -mean*rstd (biased variance)
 __global__ void __launch_bounds__(64)
     in_stats_finalize_kernel(const float *__restrict__ partial, int nblk, int C, float count, float eps,
@@ -728,6 +929,26 @@ int ramp_conv2d_nhwc(const void *x, const void *wpk, const float *bias, const fl
   const int M = p.OH * p.OW;
   dim3 grid(ramp_cdiv(M, 128), Cout / 32), block(256);
   hipStream_t st = (hipStream_t)stream;
+  // fp16: LDS-tiled kernel for the layer shapes of the towers (RAMP_CONV_DIRECT forces the direct one)
+  if (f16 && !(dtype & RAMP_CONV_DIRECT)) {
+    const dim3 tg(ramp_cdiv(p.OH, 8) * ramp_cdiv(p.OW, 16), 1);
+#define TILE_CASE(K, S, INF32, CIN, NT)                                                              \
+  if (KH == K && stride == S && in_f32 == INF32 && Cin == CIN && Cout % (NT * 16) == 0) {             \
+    hipLaunchKernelGGL((conv_tile_f16_kernel<K, S, INF32, CIN, NT>), dim3(tg.x, Cout / (NT * 16)),     \
+                       block, 0, st, p);                                                              \
+    RAMP_CHECK_LAUNCH();                                                                              \
+    return RAMP_OK;                                                                                   \
+  }
+    TILE_CASE(7, 2, true, 16, 2)
+    TILE_CASE(3, 1, false, 32, 2)
+    TILE_CASE(3, 2, false, 32, 2)
+    TILE_CASE(3, 1, false, 64, 2)
+    TILE_CASE(1, 2, false, 32, 4)
+    TILE_CASE(1, 2, false, 64, 4)
+    TILE_CASE(1, 1, false, 64, 4)
+    TILE_CASE(1, 1, false, 128, 4)
+#undef TILE_CASE
+  }
 #define CONV_CASE(K, S)                                                                              \
   if (KH == K && stride == S) {                                                                      \
     if (!f16) hipLaunchKernelGGL((conv_mfma_f32_kernel<K, K, S>), grid, block, 0, st, p);            \
@@ -743,6 +964,22 @@ int ramp_conv2d_nhwc(const void *x, const void *wpk, const float *bias, const fl
   CONV_CASE(1, 2)
 #undef CONV_CASE
   return RAMP_EUNSUPPORTED;
+}
+
+int ramp_conv2d_stats_blocks(int H, int W, int Cin, int Cout, int KH, int stride, int dtype) {
+  const int pad = KH / 2;
+  const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KH) / stride + 1;
+  if (OH <= 0 || OW <= 0) return RAMP_EINVAL;
+  const bool f16 = (dtype & 0xf) == RAMP_F16, in_f32 = f16 && (dtype & RAMP_IN_F32);
+  bool tiled = false;
+  if (f16 && !(dtype & RAMP_CONV_DIRECT)) {
+    tiled = (KH == 7 && stride == 2 && in_f32 && Cin == 16 && Cout % 32 == 0) ||
+            (!in_f32 && KH == 3 && stride == 1 && (Cin == 32 || Cin == 64) && Cout % 32 == 0) ||
+            (!in_f32 && KH == 3 && stride == 2 && Cin == 32 && Cout % 32 == 0) ||
+            (!in_f32 && KH == 1 && stride == 2 && (Cin == 32 || Cin == 64) && Cout % 64 == 0) ||
+            (!in_f32 && KH == 1 && stride == 1 && (Cin == 64 || Cin == 128) && Cout % 64 == 0);
+  }
+  return tiled ? ramp_cdiv(OH, 8) * ramp_cdiv(OW, 16) : ramp_cdiv(OH * OW, 128);
 }
 
 int ramp_in_stats_finalize(const float *partial, int nblk, int C, float count, float eps, float *scale,

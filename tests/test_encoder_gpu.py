@@ -88,6 +88,34 @@ def test_conv_mfma_f16_matches_torch(cin, cout, k, stride, hw, first):
         assert float((conv_hip.materialize(p).float() - refn).abs().max()) <= 1e-2
 
 
+@pytest.mark.parametrize("cin,cout,k,stride,hw,first", [(16, 32, 7, 2, (48, 64), True), (32, 32, 3, 1, (37, 53), False),
+                                                         (32, 64, 3, 2, (40, 56), False), (64, 64, 3, 1, (20, 28), False),
+                                                         (32, 64, 1, 2, (40, 56), False), (64, 384, 1, 1, (21, 29), False),
+                                                         (64, 64, 1, 2, (33, 47), False), (128, 128, 1, 1, (19, 35), False),
+                                                         (32, 32, 3, 1, (240, 320), False)])
+def test_conv_tiled_equals_direct(cin, cout, k, stride, hw, first):
+    """the LDS-tiled fp16 kernel accumulates in the same order as the direct one: bit-identical
+    outputs, and InstanceNorm statistics equal up to the (different) block partition of the sum"""
+    from rampvo_amd import conv_hip
+    torch.manual_seed(3)
+    conv = nn.Conv2d(cin, cout, k, stride=stride, padding=k // 2).cuda()
+    with torch.no_grad():
+        x = torch.randn(hw[0], hw[1], cin, device="cuda")
+        xin = x if first else x.half()
+        sc, sh = torch.rand(cin, device="cuda") + 0.5, torch.randn(cin, device="cuda") * 0.1
+        oh, ow = (hw[0] + 2 * (k // 2) - k) // stride + 1, (hw[1] + 2 * (k // 2) - k) // stride + 1
+        res = torch.randn(oh, ow, cout, device="cuda").half()
+        for kw in (dict(), dict(relu=True), dict(pre=(sc, sh), res=res, relu=True, out_scale=0.25)):
+            a = conv_hip.conv2d(xin, conv, half=True, direct=True, **kw)
+            b = conv_hip.conv2d(xin, conv, half=True, **kw)
+            assert torch.equal(a, b), kw.keys()
+        pa = conv_hip.conv2d(xin, conv, want_stats=True, half=True, direct=True)
+        pb = conv_hip.conv2d(xin, conv, want_stats=True, half=True)
+        assert torch.equal(pa.raw, pb.raw)
+        assert float((pa.scale - pb.scale).abs().max()) <= 1e-5 * float(pa.scale.abs().max())
+        assert float((pa.shift - pb.shift).abs().max()) <= 1e-5 * max(1.0, float(pa.shift.abs().max()))
+
+
 def test_singlescale_encoder_half_vs_fp32():
     from rampvo_amd import conv
     from rampvo_amd.synthetic import SyntheticStream, make_network
