@@ -248,14 +248,18 @@ int ramp_neighbors_from_groups(const int32_t *order, const int32_t *seg_start, c
 int ramp_any_nonzero(const float *a, long na, const float *b, long nb, int32_t *flags, void *stream);
 
 /* The two per-pixel LSTM cells and the super-state 1x1 convolution of the SingleScale encoder,
- * fused (ramp/extractor.py:239-259: nn.LSTM x2 on [H*W,1,C] sequences + Conv2d(30->15) x2).
- *   ev [5][HW], im [3][HW] planar float32; h_ev,c_ev,h_im,c_im [15][HW] planar recurrent state (in/out);
- *   ss [HW][16] channels-last super-state (in/out, channel 15 = 0);
- *   wpacked: LSTM + conv weights packed by rampvo_amd/conv_hip.py::pack_lstm;
- *   has_state / has_ss: 0 on the first call after reinit_hidden (zero initial state)         */
-int ramp_lstm_superstate(const float *ev, const float *im, float *h_ev, float *c_ev, float *h_im,
-                         float *c_im, float *ss, const float *wpacked, const int32_t *flags, int HW,
-                         int has_state, int has_ss, void *stream);
+ * fused (ramp/extractor.py:239-259: nn.LSTM x2 on [H*W,1,C] sequences + Conv2d(30->15) x2), on the
+ * matrix cores (v_mfma_f32_16x16x4_f32, exact fp32 products): the three matrix-vector products per
+ * pixel are batched over 16-pixel tiles.
+ *   ev [5][HW], im [3][HW] planar float32
+ *   h_ev,c_ev,h_im,c_im [ceil(HW/16)][16 units][16 px] tile-major recurrent state (in/out, unit 15 = 0)
+ *   ss [HW][16] channels-last super-state (in/out, channel 15 = 0)
+ *   wfrag: per-lane MFMA fragments of the weights, rampvo_amd/conv_hip.py::pack_lstm_mfma
+ *   flags[2]: events / image present (ramp_any_nonzero)
+ *   has_state / has_ss: 0 on the first call after reinit_hidden (zero initial state)            */
+int ramp_lstm_superstate_tiled(const float *ev, const float *im, float *h_ev, float *c_ev, float *h_im,
+                               float *c_im, float *ss, const float *wfrag, const int32_t *flags, int HW,
+                               int has_state, int has_ss, void *stream);
 
 /* One scale (1, 2 or 4) of the MultiScale encoder's recurrent front end for one time step
  * (ramp/extractor.py:540-566 with LSTMEncoder :376-385 and SuperStateEncoder :432-463): strided

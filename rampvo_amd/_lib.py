@@ -66,7 +66,7 @@ SIGNATURES = {
     "ramp_group_by_small": (c_i, [c_p, c_p, c_i64, c_i64, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_sz, c_p]),
     "ramp_neighbors_from_groups": (c_i, [c_p] * 6 + [c_i, c_i, c_p]),
     "ramp_any_nonzero": (c_i, [c_p, ctypes.c_long, c_p, ctypes.c_long, c_p, c_p]),
-    "ramp_lstm_superstate": (c_i, [c_p] * 9 + [c_i, c_i, c_i, c_p]),
+    "ramp_lstm_superstate_tiled": (c_i, [c_p] * 9 + [c_i, c_i, c_i, c_p]),
     "ramp_conv2d_nhwc": (c_i, [c_p] * 8 + [c_i] * 8 + [c_f, c_i, c_p]),
     "ramp_in_stats_finalize": (c_i, [c_p, c_i, c_i, c_f, c_f, c_p, c_p, c_p]),
     "ramp_affine_relu": (c_i, [c_p, c_p, c_p, c_p, ctypes.c_long, c_i, c_p]),

@@ -43,22 +43,55 @@ def pack_conv_weight(conv, mode="f32"):
     return t, bias
 
 
-def pack_lstm(enc):
-    """weights of the fused LSTM/super-state kernel (offsets LW_* in csrc/conv.hip)"""
+def pack_lstm_mfma(enc):
+    """per-lane A fragments / accumulator-init biases of lstm_superstate_mfma_kernel (layout LM_* in
+    csrc/conv.hip): [fragment][64 lanes] float32.  MFMA 16x16x4: lane l supplies A[row l&15][k l>>4]."""
     key = tuple((p.data_ptr(), p._version) for p in enc.events_convlstm.parameters()) + \
         tuple((p.data_ptr(), p._version) for p in enc.image_convlstm.parameters()) + \
         tuple((p.data_ptr(), p._version) for p in enc.superstate_encoder.parameters())
-    hit = _pack_cache.get(("lstm", id(enc)))
+    hit = _pack_cache.get(("lstm_mfma", id(enc)))
     if hit is not None and hit[0] == key:
         return hit[1]
-    e, i, s = enc.events_convlstm, enc.image_convlstm, enc.superstate_encoder
-    parts = [e.weight_ih_l0, e.weight_hh_l0, e.bias_ih_l0 + e.bias_hh_l0,
-             i.weight_ih_l0, i.weight_hh_l0, i.bias_ih_l0 + i.bias_hh_l0,
-             s.weight.view(15, 30), s.bias]
-    w = torch.cat([p.detach().float().reshape(-1) for p in parts]).contiguous()
-    assert w.numel() == 60 * 5 + 60 * 15 + 60 + 60 * 3 + 60 * 15 + 60 + 15 * 30 + 15
-    _pack_cache[("lstm", id(enc))] = (key, w)
-    return w
+    dev = enc.superstate_encoder.weight.device
+    lane = torch.arange(64)
+    i, q = lane & 15, lane >> 4
+    frags = []
+
+    def lstm_frags(lstm, cin, ksteps):
+        w_ih, w_hh = lstm.weight_ih_l0.detach().float().cpu(), lstm.weight_hh_l0.detach().float().cpu()
+        b = (lstm.bias_ih_l0 + lstm.bias_hh_l0).detach().float().cpu()
+        # full K matrix [60 rows][16 (h, unit 15 = 0) + 8 (x, zero padded)]
+        wk = torch.zeros(60, 24)
+        wk[:, :15] = w_hh
+        wk[:, 16:16 + cin] = w_ih
+        out, bias = [], []
+        for t in range(4):
+            unit, gate = 4 * t + (i >> 2), i & 3
+            row = gate * 15 + unit.clamp(max=14)
+            ok = (unit < 15).float()
+            for s4 in range(ksteps):
+                out.append(wk[row, 4 * s4 + q] * ok)
+        for t in range(4):
+            for r in range(4):                     # accumulator register r of lane (q, j): row 4q+r of tile t
+                unit = 4 * t + q
+                bias.append(b[r * 15 + unit.clamp(max=14)] * (unit < 15).float())
+        return out, bias
+
+    ev_f, ev_b = lstm_frags(enc.events_convlstm, 5, 6)
+    im_f, im_b = lstm_frags(enc.image_convlstm, 3, 5)
+    wss = torch.zeros(16, 32)
+    w = enc.superstate_encoder.weight.detach().float().cpu().view(15, 30)
+    wss[:15, :15] = w[:, :15]          # columns 0..15: previous super-state channels
+    wss[:15, 16:31] = w[:, 15:]        # columns 16..31: embedding units
+    ss_f = [wss[i, 4 * q + st] for st in range(4)] + [wss[i, 16 + 4 * t + q] for t in range(4)]
+    bs = torch.zeros(16)
+    bs[:15] = enc.superstate_encoder.bias.detach().float().cpu()
+    ss_b = [bs[4 * q + r] for r in range(4)]
+    frags = ev_f + im_f + ss_f + ev_b + im_b + ss_b
+    assert len(frags) == 24 + 20 + 8 + 16 + 16 + 4
+    wf = torch.stack(frags).contiguous().to(dev)
+    _pack_cache[("lstm_mfma", id(enc))] = (key, wf)
+    return wf
 
 
 # ------------------------------------------------------------------------ primitives
@@ -180,28 +213,36 @@ def multiscale_encoder4(enc, x, x2, x4, out_scale=1.0, half=False):
 
 # ------------------------------------------------------------------ LSTM / super-state
 class LstmState:
+    """recurrent state of the SingleScale front end.  h_*, c_*: tile-major [ceil(HW/16), 16 units,
+    16 px] (the MFMA kernel's layout; unit 15 is padding); ss: channels-last [HW, 16]."""
     __slots__ = ("h_ev", "c_ev", "h_im", "c_im", "ss", "flags", "fresh", "HW")
 
     def __init__(self, HW, device):
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=device)
-        self.h_ev, self.c_ev, self.h_im, self.c_im = z(15, HW), z(15, HW), z(15, HW), z(15, HW)
+        nt = (HW + 15) // 16
+        self.h_ev, self.c_ev, self.h_im, self.c_im = z(nt, 16, 16), z(nt, 16, 16), z(nt, 16, 16), z(nt, 16, 16)
         self.ss = z(HW, 16)
         self.flags = torch.zeros(2, dtype=torch.int32, device=device)
         self.fresh = True
         self.HW = HW
 
+    def rows(self, name):
+        """state `name` as [HW, 15] rows (pixel-major), for inspection / tests"""
+        t = getattr(self, name)
+        return t.permute(0, 2, 1).reshape(-1, 16)[:self.HW, :15]
+
 
 def lstm_superstate_step(enc, ev, im, st):
     """ev [5,H,W], im [3,H,W] contiguous fp32; updates st in place, returns the super-state
     as an NHWC16 tensor [H,W,16] (a view of st.ss)"""
-    w = pack_lstm(enc)
+    w = pack_lstm_mfma(enc)
     H, W = ev.shape[-2:]
     check(lib().ramp_any_nonzero(ptr(ev), ev.numel(), ptr(im), im.numel(), ptr(st.flags), stream()),
           "ramp_any_nonzero")
     has = 0 if st.fresh else 1
-    check(lib().ramp_lstm_superstate(ptr(ev), ptr(im), ptr(st.h_ev), ptr(st.c_ev), ptr(st.h_im), ptr(st.c_im),
-                                     ptr(st.ss), ptr(w), ptr(st.flags), H * W, has, has, stream()),
-          "ramp_lstm_superstate")
+    check(lib().ramp_lstm_superstate_tiled(ptr(ev), ptr(im), ptr(st.h_ev), ptr(st.c_ev), ptr(st.h_im),
+                                           ptr(st.c_im), ptr(st.ss), ptr(w), ptr(st.flags), H * W, has, has,
+                                           stream()), "ramp_lstm_superstate_tiled")
     st.fresh = False
     return st.ss.view(H, W, 16)
 

@@ -1,10 +1,9 @@
 // RAMP encoder kernels for gfx950.
 //
-//  1. lstm_superstate_kernel: the two per-pixel LSTM cells (events 5->15, image 3->15, state
-//     carried) and the shared super-state 1x1 convolution, fused into ONE pointwise kernel
+//  1. lstm_superstate_mfma_kernel: the two per-pixel LSTM cells (events 5->15, image 3->15, state
+//     carried) and the shared super-state 1x1 convolution, fused into ONE kernel on fp32 MFMA
 //     (reference: cuDNN LSTM over 307,200 length-1 sequences + two conv launches + host syncs on
-//     torch.any; ramp/extractor.py:233-259).  Weights are read through uniform (scalar) loads and
-//     enter the FMAs as SGPR operands; recurrent state is planar [15][H*W] (coalesced), the
+//     torch.any; ramp/extractor.py:233-259).  Recurrent state is tile-major [HW/16][16][16], the
 //     super-state leaves as channels-last [H*W][16] (channel 15 = 0) for the conv towers.
 //
 //  2. conv_mfma_kernel: implicit-GEMM convolution on the matrix cores.  NHWC activations, one
@@ -55,112 +54,8 @@ __global__ void __launch_bounds__(256)
   if (threadIdx.x < 2 && s_any[threadIdx.x]) flags[threadIdx.x] = 1;
 }
 
-// ------------------------------------------------------- LSTM + super-state
-// packed weights (floats): see rampvo_amd/conv_hip.py::pack_lstm
-#define LW_IH_E 0                    // [60][5]
-#define LW_HH_E (LW_IH_E + 60 * 5)   // [60][15]
-#define LW_B_E (LW_HH_E + 60 * 15)   // [60]   (b_ih + b_hh)
-#define LW_IH_I (LW_B_E + 60)        // [60][3]
-#define LW_HH_I (LW_IH_I + 60 * 3)   // [60][15]
-#define LW_B_I (LW_HH_I + 60 * 15)   // [60]
-#define LW_SS (LW_B_I + 60)          // [15][30]
-#define LW_SB (LW_SS + 15 * 30)      // [15]
-#define LW_TOTAL (LW_SB + 15)
-
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-template <int CIN>
-__device__ __forceinline__ void lstm_cell(const float *__restrict__ Wih, const float *__restrict__ Whh,
-                                          const float *__restrict__ B, const float *x, float *h,
-                                          float *c, bool has_state) {
-  float g[60];
-#pragma unroll
-  for (int r = 0; r < 60; r++) {
-    float s = B[r];
-#pragma unroll
-    for (int k = 0; k < CIN; k++) s = __builtin_fmaf(Wih[r * CIN + k], x[k], s);
-    g[r] = s;
-  }
-  if (has_state) {
-#pragma unroll
-    for (int r = 0; r < 60; r++) {
-      float s = g[r];
-#pragma unroll
-      for (int k = 0; k < 15; k++) s = __builtin_fmaf(Whh[r * 15 + k], h[k], s);
-      g[r] = s;
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < 15; k++) {  // torch gate order: i, f, g, o
-    const float ig = sigmoidf_(g[k]), fg = sigmoidf_(g[15 + k]), gg = tanhf(g[30 + k]),
-                og = sigmoidf_(g[45 + k]);
-    const float cn = has_state ? fg * c[k] + ig * gg : ig * gg;
-    c[k] = cn;
-    h[k] = og * tanhf(cn);
-  }
-}
-
-__global__ void __launch_bounds__(128)
-    lstm_superstate_kernel(const float *__restrict__ ev, const float *__restrict__ im,
-                           float *__restrict__ h_ev, float *__restrict__ c_ev,
-                           float *__restrict__ h_im, float *__restrict__ c_im,
-                           float *__restrict__ ss, const float *__restrict__ W,
-                           const int *__restrict__ flags, int HW, int has_state, int has_ss) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= HW) return;
-  float x[5], y[3], he[15], ce[15], hi[15], ci[15], s[15];
-#pragma unroll
-  for (int k = 0; k < 5; k++) x[k] = ev[(size_t)k * HW + p];
-#pragma unroll
-  for (int k = 0; k < 3; k++) y[k] = im[(size_t)k * HW + p];
-  if (has_state) {
-#pragma unroll
-    for (int k = 0; k < 15; k++) {
-      he[k] = h_ev[(size_t)k * HW + p]; ce[k] = c_ev[(size_t)k * HW + p];
-      hi[k] = h_im[(size_t)k * HW + p]; ci[k] = c_im[(size_t)k * HW + p];
-    }
-  }
-  lstm_cell<5>(W + LW_IH_E, W + LW_HH_E, W + LW_B_E, x, he, ce, has_state);
-  lstm_cell<3>(W + LW_IH_I, W + LW_HH_I, W + LW_B_I, y, hi, ci, has_state);
-#pragma unroll
-  for (int k = 0; k < 15; k++) {
-    h_ev[(size_t)k * HW + p] = he[k]; c_ev[(size_t)k * HW + p] = ce[k];
-    h_im[(size_t)k * HW + p] = hi[k]; c_im[(size_t)k * HW + p] = ci[k];
-  }
-  float4 *sp = reinterpret_cast<float4 *>(ss + (size_t)p * 16);
-  if (has_ss) {
-    const float4 a = sp[0], b = sp[1], c = sp[2], d = sp[3];
-    s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
-    s[8] = c.x; s[9] = c.y; s[10] = c.z; s[11] = c.w; s[12] = d.x; s[13] = d.y; s[14] = d.z;
-  } else {
-#pragma unroll
-    for (int k = 0; k < 15; k++) s[k] = 0.0f;
-  }
-  // super_state <- Conv1x1([super_state ; embedding]) per present modality (extractor.py:251-259)
-#pragma unroll
-  for (int pass = 0; pass < 2; pass++) {
-    if (!flags[pass]) continue;
-    const float *e = pass == 0 ? he : hi;
-    float t[15];
-#pragma unroll
-    for (int r = 0; r < 15; r++) {
-      float a = W[LW_SB + r];
-#pragma unroll
-      for (int k = 0; k < 15; k++) a = __builtin_fmaf(W[LW_SS + r * 30 + k], s[k], a);
-#pragma unroll
-      for (int k = 0; k < 15; k++) a = __builtin_fmaf(W[LW_SS + r * 30 + 15 + k], e[k], a);
-      t[r] = a;
-    }
-#pragma unroll
-    for (int r = 0; r < 15; r++) s[r] = t[r];
-  }
-  sp[0] = make_float4(s[0], s[1], s[2], s[3]);
-  sp[1] = make_float4(s[4], s[5], s[6], s[7]);
-  sp[2] = make_float4(s[8], s[9], s[10], s[11]);
-  sp[3] = make_float4(s[12], s[13], s[14], 0.0f);
-}
-
-// --------------------------------------------------------- implicit GEMM conv
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
@@ -737,6 +632,125 @@ __global__ void __launch_bounds__(256)
   reinterpret_cast<float4 *>(out)[i] = v;
 }
 
+// ----------------------------------------------- LSTM + super-state on MFMA
+// The two per-pixel LSTM cells (events 5->15, image 3->15, state carried) and the shared
+// super-state 1x1 convolution of the SingleScale encoder (ramp/extractor.py:233-259; reference:
+// cuDNN LSTM over 307,200 length-1 sequences + two conv launches + host syncs on torch.any), fused
+// into one kernel, with the three matrix-vector products per pixel batched over 16 pixels on v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulate):
+//   gates[64 x 16 px] = Wg[64 x K] * [h ; x][K x 16 px]      (per modality, K = 24 / 20)
+//   s'   [16 x 16 px] = Wss[16 x 32] * [s ; h][32 x 16 px]   (per present modality)
+// The freedom in ordering rows and K columns is used so that nothing is ever shuffled:
+//   * gate rows are permuted so that output tile t, lane (q, j) holds (i, f, g, o) of unit 4t+q
+//     for pixel j in its four accumulator registers -> the cell update is lane-local;
+//   * the recurrent state is stored tile-major, [HW/16][16 units][16 px]: for a fixed t the wave
+//     reads / writes one contiguous 256-byte run, and the same registers are the B operand of
+//     K-step t of the next gate product and of K-step 4+t of the super-state product;
+//   * the super-state K order is channel 4q+step, i.e. lane (q, j) feeds component `step` of the
+//     float4 it loaded (channels 4q..4q+3 of pixel j) -- and that is also the accumulator layout
+//     the product leaves, so the second modality's product takes the first one's output as is.
+// Weights arrive pre-arranged as per-lane A fragments (rampvo_amd/conv_hip.py::pack_lstm_mfma).
+#define LM_EV 0                         // 4 tiles x 6 K-steps
+#define LM_IM (LM_EV + 24)              // 4 tiles x 5 K-steps
+#define LM_SS (LM_IM + 20)              // 8 K-steps
+#define LM_BEV (LM_SS + 8)              // bias as accumulator init: 4 tiles x 4 regs
+#define LM_BIM (LM_BEV + 16)
+#define LM_BSS (LM_BIM + 16)            // 4 regs
+#define LM_TOTAL (LM_BSS + 4)           // x 64 lanes floats
+
+__device__ __forceinline__ float lm_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ void __launch_bounds__(256)
+    lstm_superstate_mfma_kernel(const float *__restrict__ ev, const float *__restrict__ im,
+                                float *__restrict__ h_ev, float *__restrict__ c_ev,
+                                float *__restrict__ h_im, float *__restrict__ c_im,
+                                float *__restrict__ ss, const float *__restrict__ Wf,
+                                const int *__restrict__ flags, int HW, int has_state, int has_ss,
+                                int tiles_per_wave) {
+  const int lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
+  const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int ntile = (HW + 15) / 16;
+  // weights: one float per lane per fragment, held for every tile of this wave
+  float a_ev[24], a_im[20], a_ss[8], b_ev[16], b_im[16], b_ss[4];
+#pragma unroll
+  for (int f = 0; f < 24; f++) a_ev[f] = Wf[(LM_EV + f) * 64 + lane];
+#pragma unroll
+  for (int f = 0; f < 20; f++) a_im[f] = Wf[(LM_IM + f) * 64 + lane];
+#pragma unroll
+  for (int f = 0; f < 8; f++) a_ss[f] = Wf[(LM_SS + f) * 64 + lane];
+#pragma unroll
+  for (int f = 0; f < 16; f++) { b_ev[f] = Wf[(LM_BEV + f) * 64 + lane]; b_im[f] = Wf[(LM_BIM + f) * 64 + lane]; }
+#pragma unroll
+  for (int f = 0; f < 4; f++) b_ss[f] = Wf[(LM_BSS + f) * 64 + lane];
+  const int f_ev = flags[0], f_im = flags[1];
+
+  for (int it = 0; it < tiles_per_wave; it++) {
+    const int tile = gw * tiles_per_wave + it;
+    if (tile >= ntile) break;
+    const int p = tile * 16 + j;
+    const bool pv = p < HW;
+    const size_t sbase = (size_t)tile * 256 + lane;      // + 64 t : unit 4t+q, pixel j
+    float hn[2][4];                                       // new h of both modalities, per tile t
+#pragma unroll
+    for (int mod = 0; mod < 2; mod++) {
+      const float *xin = mod == 0 ? ev : im;
+      float *hs = mod == 0 ? h_ev : h_im, *cs = mod == 0 ? c_ev : c_im;
+      const int CIN = mod == 0 ? 5 : 3;
+      // B operand: K-steps 0..3 = h (unit 4s+q), then the input channels
+      float bk[6];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; s4++) bk[s4] = has_state ? hs[sbase + 64 * s4] : 0.0f;
+#pragma unroll
+      for (int s4 = 4; s4 < 6; s4++) {
+        const int ch = 4 * (s4 - 4) + q;
+        bk[s4] = (ch < CIN && pv) ? xin[(size_t)ch * HW + p] : 0.0f;
+      }
+      float cold[4];
+#pragma unroll
+      for (int t = 0; t < 4; t++) cold[t] = has_state ? cs[sbase + 64 * t] : 0.0f;
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        f32x4 acc;
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[r] = mod == 0 ? b_ev[t * 4 + r] : b_im[t * 4 + r];
+        if (mod == 0) {
+#pragma unroll
+          for (int s4 = 0; s4 < 6; s4++)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_ev[t * 6 + s4], bk[s4], acc, 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int s4 = 0; s4 < 5; s4++)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_im[t * 5 + s4], bk[s4], acc, 0, 0, 0);
+        }
+        // acc = (i, f, g, o) pre-activations of unit 4t+q, pixel j (torch gate order i, f, g, o)
+        const float ig = lm_sigmoid(acc[0]), fg = lm_sigmoid(acc[1]), gg = tanhf(acc[2]), og = lm_sigmoid(acc[3]);
+        const float cn = has_state ? fg * cold[t] + ig * gg : ig * gg;
+        const float hv = og * tanhf(cn);
+        const bool unit_ok = 4 * t + q < 15;
+        hn[mod][t] = unit_ok ? hv : 0.0f;
+        cs[sbase + 64 * t] = unit_ok ? cn : 0.0f;
+        hs[sbase + 64 * t] = hn[mod][t];
+      }
+    }
+    // super-state: channels 4q..4q+3 of pixel j
+    float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 *sp = reinterpret_cast<float4 *>(ss + (size_t)p * 16) + q;
+    if (has_ss && pv) sv = *sp;
+    f32x4 sreg = (f32x4){sv.x, sv.y, sv.z, sv.w};
+#pragma unroll
+    for (int mod = 0; mod < 2; mod++) {
+      if (!(mod == 0 ? f_ev : f_im)) continue;       // uniform
+      f32x4 acc = (f32x4){b_ss[0], b_ss[1], b_ss[2], b_ss[3]};
+#pragma unroll
+      for (int s4 = 0; s4 < 4; s4++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_ss[s4], sreg[s4], acc, 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 4; t++)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_ss[4 + t], hn[mod][t], acc, 0, 0, 0);
+      sreg = acc;
+    }
+    if (pv) *sp = make_float4(sreg[0], sreg[1], sreg[2], q == 3 ? 0.0f : sreg[3]);
+  }
+}
+
 // ------------------------------------------------- MultiScale LSTM / super-state
 // One scale of MultiScaleMergerDoubleNet.forward for one time step (ramp/extractor.py:540-566):
 //   LSTMEncoder x2 (:376-385): conv_1 (k = S+1, stride S, pad 1; 1x1 for S = 1) on the 5 event /
@@ -894,14 +908,16 @@ int ramp_any_nonzero(const float *a, long na, const float *b, long nb, int32_t *
   return RAMP_OK;
 }
 
-int ramp_lstm_superstate(const float *ev, const float *im, float *h_ev, float *c_ev, float *h_im,
-                         float *c_im, float *ss, const float *wpacked, const int32_t *flags, int HW,
-                         int has_state, int has_ss, void *stream) {
-  if (HW <= 0 || !ev || !im || !h_ev || !c_ev || !h_im || !c_im || !ss || !wpacked || !flags)
+int ramp_lstm_superstate_tiled(const float *ev, const float *im, float *h_ev, float *c_ev, float *h_im,
+                               float *c_im, float *ss, const float *wfrag, const int32_t *flags, int HW,
+                               int has_state, int has_ss, void *stream) {
+  if (HW <= 0 || !ev || !im || !h_ev || !c_ev || !h_im || !c_im || !ss || !wfrag || !flags)
     return RAMP_EINVAL;
-  hipLaunchKernelGGL(lstm_superstate_kernel, dim3(ramp_cdiv(HW, 128)), dim3(128), 0,
-                     (hipStream_t)stream, ev, im, h_ev, c_ev, h_im, c_im, ss, wpacked, flags, HW,
-                     has_state, has_ss);
+  const int ntile = ramp_cdiv(HW, 16);
+  const int tpw = ntile >= 8192 ? 4 : 1;           // tiles per wave: amortise the 104 weight registers
+  hipLaunchKernelGGL(lstm_superstate_mfma_kernel, dim3(ramp_cdiv(ntile, 4 * tpw)), dim3(256), 0,
+                     (hipStream_t)stream, ev, im, h_ev, c_ev, h_im, c_im, ss, wfrag, flags, HW, has_state,
+                     has_ss, tpw);
   RAMP_CHECK_LAUNCH();
   return RAMP_OK;
 }

@@ -21,11 +21,12 @@ class FusedUpdate:
         self.dtype = dtype
         self._w = None
         self._key = None
+        self._params = list(update.parameters())     # module structure is fixed; values are tracked by key
         self._act_ok = True
 
     # ------------------------------------------------------------------ weights
     def weights(self):
-        key = tuple((p.data_ptr(), p._version) for p in self.m.parameters())
+        key = tuple([(p.data_ptr(), p._version) for p in self._params])
         if self._w is not None and key == self._key:
             return self._w
         m, T = self.m, self.dtype

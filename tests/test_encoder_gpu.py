@@ -143,7 +143,7 @@ def test_lstm_superstate_kernel_matches_torch():
     from rampvo_amd.extractor import MergerLSTMsceneEncoder
     torch.manual_seed(1)
     enc = MergerLSTMsceneEncoder().cuda().eval()
-    H, W = 24, 40
+    H, W = 23, 41          # H*W not a multiple of the 16-pixel MFMA tile
     st = conv_hip.LstmState(H * W, "cuda")
     h_e = c_e = h_i = c_i = s = None
     with torch.no_grad():
@@ -164,7 +164,8 @@ def test_lstm_superstate_kernel_matches_torch():
                     s = enc.superstate_encoder(torch.cat((s, e), 0))
             assert float((out[..., :15] - s.permute(1, 2, 0)).abs().max()) <= 2e-5
             assert float(out[..., 15].abs().max()) == 0.0
-            assert float((st.h_ev.t() - h_e[0]).abs().max()) <= 2e-5 and float((st.c_im.t() - c_i[0]).abs().max()) <= 2e-5
+            assert float((st.rows("h_ev") - h_e[0]).abs().max()) <= 2e-5
+            assert float((st.rows("c_im") - c_i[0]).abs().max()) <= 2e-5
 
 
 def test_singlescale_encoder_hip_vs_aten():
