@@ -101,6 +101,18 @@ int ramp_corr_fwd_ordered(const void *fmap1, const ramp_corr_level *levels_host,
 int ramp_pyramid_pack(const void *fmap, void *level1, void *level4, int H, int W, int C, int dtype,
                       void *stream);
 
+/* Event-biased patch-centre selection: get_coords_from_topk_events + nms_image
+ * (ramp/utils.py:186-226, 157-183; upstream ~20 ATen launches) for one frame.
+ *   events [bins][H][W] float32 (W % 4 == 0); score = mean over bins of the 4x4 average of |events|,
+ *   laid out [W/4][H/4]; local maxima of an nms_kernel_size^2 window kept (0 = no NMS);
+ *   the k largest cells in descending order (ties: lowest flat index first)
+ *   coords [k][2] float32 = (flat_index / (H/4) as a TRUE division -- x carries y/h, as upstream --,
+ *   flat_index % (H/4));  indices [k] int64 flat indices (optional, may be NULL)
+ *   ws: ramp_event_topk_workspace_bytes(H, W);  k <= 512                                          */
+size_t ramp_event_topk_workspace_bytes(int H, int W);
+int ramp_event_topk(const float *events, int bins, int H, int W, int k, int nms_kernel_size, float *coords,
+                    int64_t *indices, void *ws, size_t ws_bytes, void *stream);
+
 /* ----------------------------------------------------------------- lietorch */
 /* lietorch_backends.{expm,logm,inv,mul,act4,adj,adjT} for group_id 3 (SE3),
  * float32, forward only (ramp/lietorch/src/lietorch.cpp:286-316; math from

@@ -9,7 +9,14 @@ import torch.nn as nn
 from . import _lib
 from ._lib import RAMP_F32, check, lib, ptr, stream
 
-_pack_cache = {}
+def _cache(module):
+    """packed-weight cache living ON the module (a process-wide dict keyed by id() would hand a new
+    module the packs of a dead one whose id and storage addresses got recycled)"""
+    c = module.__dict__.get("_ramp_pack")
+    if c is None:
+        c = {}
+        object.__setattr__(module, "_ramp_pack", c)
+    return c
 
 
 def available():
@@ -25,8 +32,8 @@ def pack_conv_weight(conv, mode="f32"):
     lane (q = lane>>4, j = lane&15) holds W[16*nt + j][KC*ch + CPL*q + s], s < CPL.
     mode "f32": KC=16, CPL=4 fp32;  "f16": KC=32, CPL=8 half;  "f16_first": KC=16, CPL=4 half"""
     w = conv.weight
-    key = (id(conv), mode, w._version, w.device, w.data_ptr())
-    hit = _pack_cache.get((id(conv), mode))
+    key = (mode, w._version, w.device, w.data_ptr())
+    hit = _cache(conv).get(mode)
     if hit is not None and hit[0] == key:
         return hit[1], hit[2]
     kc, cpl = (32, 8) if mode == "f16" else (16, 4)
@@ -39,7 +46,7 @@ def pack_conv_weight(conv, mode="f32"):
     if mode != "f32":
         t = t.half()
     bias = conv.bias.detach().float().contiguous() if conv.bias is not None else None
-    _pack_cache[(id(conv), mode)] = (key, t, bias)
+    _cache(conv)[mode] = (key, t, bias)
     return t, bias
 
 
@@ -49,7 +56,7 @@ def pack_lstm_mfma(enc):
     key = tuple((p.data_ptr(), p._version) for p in enc.events_convlstm.parameters()) + \
         tuple((p.data_ptr(), p._version) for p in enc.image_convlstm.parameters()) + \
         tuple((p.data_ptr(), p._version) for p in enc.superstate_encoder.parameters())
-    hit = _pack_cache.get(("lstm_mfma", id(enc)))
+    hit = _cache(enc).get("lstm_mfma")
     if hit is not None and hit[0] == key:
         return hit[1]
     dev = enc.superstate_encoder.weight.device
@@ -90,7 +97,7 @@ def pack_lstm_mfma(enc):
     frags = ev_f + im_f + ss_f + ev_b + im_b + ss_b
     assert len(frags) == 24 + 20 + 8 + 16 + 16 + 4
     wf = torch.stack(frags).contiguous().to(dev)
-    _pack_cache[("lstm_mfma", id(enc))] = (key, wf)
+    _cache(enc)["lstm_mfma"] = (key, wf)
     return wf
 
 
@@ -268,7 +275,7 @@ def pack_ms_scale(enc, k):
               im.convlstm.weight_ih_l0, im.convlstm.bias_ih_l0, im.convlstm.bias_hh_l0,
               me.weight, me.bias, mi.weight, mi.bias]
     key = tuple((q.data_ptr(), q._version) for q in params)
-    hit = _pack_cache.get(("ms", id(enc), k))
+    hit = _cache(enc).get(("ms", k))
     if hit is not None and hit[0] == key:
         return hit[1]
     f = lambda t: t.detach().float().contiguous()
@@ -279,7 +286,7 @@ def pack_ms_scale(enc, k):
             f(me.weight.view(d, 2 * d).t()), f(me.bias), f(mi.weight.view(d, 2 * d).t()), f(mi.bias)]
     import ctypes
     ptrs = (ctypes.c_void_p * 12)(*[a.data_ptr() for a in arrs])
-    _pack_cache[("ms", id(enc), k)] = (key, (arrs, ptrs))
+    _cache(enc)[("ms", k)] = (key, (arrs, ptrs))
     return arrs, ptrs
 
 

@@ -1,0 +1,232 @@
+// Event-biased patch selection for gfx950 (reference ramp/utils.py:186-226 + 157-183):
+//   score[X][Y] = mean over bins of avgpool4x4(|events|), laid out [w][h] (transposed)
+//   keep local maxima of an 11x11 neighbourhood (x * (maxpool(x) == x))
+//   top-k cells, sorted by value; x = flat_index / h (TRUE division, so x carries y/h), y = index % h
+// upstream: abs, avg_pool2d, transpose, mean, max_pool2d, eq, mul, topk (radix sort + merges), div,
+// remainder, stack = ~20 launches.  Here: score kernel, NMS kernel, one-workgroup radix select.
+#include "ramp_device.h"
+#include "ramp_internal.h"
+
+// thread per 1/4-resolution cell, X fastest: a thread reads 16 contiguous bytes per row per bin
+__global__ void __launch_bounds__(256)
+    event_score_kernel(const float *__restrict__ ev, float *__restrict__ score, int bins, int H, int W, int h,
+                       int w) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= h * w) return;
+  const int Y = c / w, X = c - Y * w;
+  float tot = 0.0f;
+  for (int b = 0; b < bins; b++) {
+    float acc = 0.0f;      // avg_pool2d: running sum over the window in (ky, kx) order, then / 16
+#pragma unroll
+    for (int ky = 0; ky < 4; ky++) {
+      const float4 v = *reinterpret_cast<const float4 *>(ev + ((size_t)b * H + 4 * Y + ky) * W + 4 * X);
+      acc += fabsf(v.x); acc += fabsf(v.y); acc += fabsf(v.z); acc += fabsf(v.w);
+    }
+    tot += acc / 16.0f;
+  }
+  score[(size_t)X * h + Y] = tot / (float)bins;
+}
+
+// x * (max over the (2r+1)^2 window == x), window clipped at the border (-inf padding).
+// A workgroup stages its 16 x 16 cells plus the halo in LDS; max == x  <=>  no neighbour is larger,
+// so a cell stops at the first larger neighbour.
+#define NMS_T 16
+#define NMS_RMAX 8
+__global__ void __launch_bounds__(NMS_T * NMS_T)
+    nms_kernel(const float *__restrict__ score, float *__restrict__ out, int w, int h, int r) {
+  __shared__ float tile[(NMS_T + 2 * NMS_RMAX) * (NMS_T + 2 * NMS_RMAX)];
+  const int tw = NMS_T + 2 * r;
+  const int X0 = blockIdx.y * NMS_T, Y0 = blockIdx.x * NMS_T;          // Y (fast axis of score) on x
+  for (int i = threadIdx.x; i < tw * tw; i += NMS_T * NMS_T) {
+    const int tx = i / tw, ty = i - tx * tw;
+    const int xx = X0 - r + tx, yy = Y0 - r + ty;
+    tile[i] = (xx >= 0 && xx < w && yy >= 0 && yy < h) ? score[(size_t)xx * h + yy] : -INFINITY;
+  }
+  __syncthreads();
+  const int lx = threadIdx.x / NMS_T, ly = threadIdx.x - lx * NMS_T;
+  const int X = X0 + lx, Y = Y0 + ly;
+  if (X >= w || Y >= h) return;
+  const float v = tile[(lx + r) * tw + ly + r];
+  bool keep = true;
+  for (int dx = 0; dx <= 2 * r && keep; dx++)
+    for (int dy = 0; dy <= 2 * r; dy++)
+      if (tile[(lx + dx) * tw + ly + dy] > v) { keep = false; break; }
+  out[(size_t)X * h + Y] = v * (keep ? 1.0f : 0.0f);
+}
+
+// One workgroup: the k largest cells, sorted by (value desc, index asc).
+//   1. one pass over the map compacts the non-zero cells (after NMS: a few hundred local maxima) into
+//      an LDS candidate list; zeros are only counted;
+//   2. the exact k-th largest value is found by 4 x 8-bit MSB radix passes over the float bit
+//      patterns of the candidates (values are >= 0, so the patterns order like the values); the bin
+//      search is a wave-wide suffix sum over the 256 counters;
+//   3. everything >= the threshold is gathered and bitonic-sorted; if fewer than k cells are
+//      positive the remaining slots take the zero cells of lowest index.
+// A map with more non-zero cells than the list holds (no NMS, dense events) streams the map from
+// memory in every pass instead.
+#define TOPK_THREADS 1024
+#define TOPK_MAXK 512
+#define TOPK_CAP 6144
+__global__ void __launch_bounds__(TOPK_THREADS)
+    topk_coords_kernel(const float *__restrict__ vals, int N, int k, int hh, float *__restrict__ coords,
+                       int64_t *__restrict__ idx_out) {
+  __shared__ unsigned hist[256];
+  __shared__ unsigned s_prefix, s_remaining, s_count, s_ncand;
+  __shared__ unsigned cand_key[TOPK_CAP], cand_idx[TOPK_CAP];
+  __shared__ unsigned long long sel[2 * TOPK_MAXK];
+  __shared__ unsigned s_scan[TOPK_THREADS];
+  const int tid = threadIdx.x;
+  const unsigned *keys = reinterpret_cast<const unsigned *>(vals);
+  if (tid == 0) { s_prefix = 0; s_remaining = (unsigned)k; s_count = 0; s_ncand = 0; }
+  for (int i = tid; i < 2 * TOPK_MAXK; i += TOPK_THREADS) sel[i] = 0ull;
+  __syncthreads();
+  for (int i0 = tid; i0 < N; i0 += 4 * TOPK_THREADS) {
+    unsigned kv[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) kv[u] = (i0 + u * TOPK_THREADS < N) ? keys[i0 + u * TOPK_THREADS] : 0u;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (kv[u] != 0) {
+        const unsigned pos = atomicAdd(&s_ncand, 1u);
+        if (pos < TOPK_CAP) { cand_key[pos] = kv[u]; cand_idx[pos] = (unsigned)(i0 + u * TOPK_THREADS); }
+      }
+    }
+  }
+  __syncthreads();
+  const unsigned nnz = s_ncand;
+  const bool in_lds = nnz <= TOPK_CAP;
+  const int M = in_lds ? (int)nnz : N;           // items the passes below walk over
+  const unsigned zeros = (unsigned)N - nnz;
+#define TOPK_ITEM(i, key, idx)                                   \
+  const unsigned key = in_lds ? cand_key[i] : keys[i];           \
+  const unsigned idx = in_lds ? cand_idx[i] : (unsigned)(i);
+  unsigned mask = 0;
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    const unsigned prefix = s_prefix;
+    for (int i = tid; i < M; i += TOPK_THREADS) {
+      TOPK_ITEM(i, key, idx)
+      (void)idx;
+      if (key != 0 && (key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (tid < 64) {
+      // which bin holds the rem-th largest: suffix sums over the 256 bins, 4 bins per lane of wave 0
+      unsigned c[4];
+#pragma unroll
+      for (int b = 0; b < 4; b++) c[b] = hist[4 * tid + b];
+      if (prefix == 0 && tid == 0) c[0] += zeros;
+      const unsigned tot = c[0] + c[1] + c[2] + c[3];
+      unsigned suf = tot;
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned v = __shfl_down(suf, o, 64);
+        if (tid + o < 64) suf += v;
+      }
+      const unsigned rem = s_remaining, above = suf - tot;
+      if (above < rem && suf >= rem) {
+        unsigned rr = rem - above;
+        int bin = 4 * tid;
+#pragma unroll
+        for (int b = 3; b >= 0; b--) {
+          if (c[b] >= rr) { bin = 4 * tid + b; break; }
+          rr -= c[b];
+        }
+        s_remaining = rr;
+        s_prefix = prefix | ((unsigned)bin << shift);
+      }
+    }
+    mask |= 255u << shift;
+    __syncthreads();
+  }
+  const unsigned T = s_prefix;
+  // gather: T > 0: everything >= T (ties are ordered by the sort); T == 0: every positive cell
+  for (int i = tid; i < M; i += TOPK_THREADS) {
+    TOPK_ITEM(i, key, idx)
+    if (key != 0 && key >= T) {
+      const unsigned pos = atomicAdd(&s_count, 1u);
+      if (pos < 2u * TOPK_MAXK) sel[pos] = ((unsigned long long)key << 32) | (0xffffffffu - idx);
+    }
+  }
+  __syncthreads();
+  if (T == 0) {
+    // fewer than k positive cells: the zero cells of lowest index fill up (index-ordered scan of the map)
+    const unsigned ngt = s_count, need = (unsigned)k - min((unsigned)k, ngt);
+    const int chunk = (N + TOPK_THREADS - 1) / TOPK_THREADS;
+    const int i0 = tid * chunk, i1 = min(N, i0 + chunk);
+    unsigned cnt = 0;
+    for (int i = i0; i < i1; i++) cnt += (keys[i] == 0);
+    s_scan[tid] = cnt;
+    __syncthreads();
+    for (int off = 1; off < TOPK_THREADS; off <<= 1) {
+      const unsigned v = tid >= off ? s_scan[tid - off] : 0;
+      __syncthreads();
+      s_scan[tid] += v;
+      __syncthreads();
+    }
+    unsigned rank = s_scan[tid] - cnt;
+    for (int i = i0; i < i1 && rank < need; i++) {
+      if (keys[i] == 0) {
+        const unsigned pos = ngt + rank;
+        if (pos < 2u * TOPK_MAXK) sel[pos] = (unsigned long long)(0xffffffffu - (unsigned)i);
+        rank++;
+      }
+    }
+    __syncthreads();
+  }
+  // bitonic sort, descending, of the gathered composite keys (unused slots are 0 = smallest)
+  const unsigned gathered = T == 0 ? (unsigned)k : min(s_count, 2u * TOPK_MAXK);
+  int KP = 64;
+  while (KP < (int)gathered) KP <<= 1;
+  for (int size = 2; size <= KP; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < KP / 2; t += TOPK_THREADS) {
+        const int lo = (t / stride) * stride * 2 + (t % stride), hi = lo + stride;
+        const bool desc = ((lo / size) & 1) == 0;
+        const unsigned long long a = sel[lo], b = sel[hi];
+        if ((a < b) == desc) { sel[lo] = b; sel[hi] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  for (int t = tid; t < k; t += TOPK_THREADS) {
+    const unsigned idx = 0xffffffffu - (unsigned)(sel[t] & 0xffffffffull);
+    // `indices / h` upstream runs on the GPU, where ATen turns a true division by a host scalar into
+    // a multiplication by its float reciprocal (BinaryDivTrueKernel.cu); same arithmetic here
+    coords[2 * t + 0] = (float)idx * (1.0f / (float)hh);
+    coords[2 * t + 1] = (float)(idx % (unsigned)hh);
+    if (idx_out) idx_out[t] = (int64_t)idx;
+  }
+#undef TOPK_ITEM
+}
+
+extern "C" {
+
+size_t ramp_event_topk_workspace_bytes(int H, int W) {
+  return (size_t)2 * (H / 4) * (W / 4) * sizeof(float);
+}
+
+int ramp_event_topk(const float *events, int bins, int H, int W, int k, int nms_kernel_size, float *coords,
+                    int64_t *indices, void *ws, size_t ws_bytes, void *stream) {
+  if (!events || !coords || !ws || bins <= 0 || H < 4 || W < 4 || k <= 0) return RAMP_EINVAL;
+  const int h = H / 4, w = W / 4, N = h * w;
+  if (k > TOPK_MAXK || k > N || (W % 4) || nms_kernel_size < 0 || (nms_kernel_size && !(nms_kernel_size & 1)) ||
+      nms_kernel_size > 2 * NMS_RMAX + 1)
+    return RAMP_EUNSUPPORTED;
+  if (ws_bytes < ramp_event_topk_workspace_bytes(H, W)) return RAMP_EWORKSPACE;
+  float *score = (float *)ws, *kept = score + N;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(event_score_kernel, dim3(ramp_cdiv(N, 256)), dim3(256), 0, st, events, score, bins, H, W, h,
+                     w);
+  const float *src = score;
+  if (nms_kernel_size > 1) {
+    hipLaunchKernelGGL(nms_kernel, dim3(ramp_cdiv(h, NMS_T), ramp_cdiv(w, NMS_T)), dim3(NMS_T * NMS_T), 0, st,
+                       score, kept, w, h, (nms_kernel_size - 1) / 2);
+    src = kept;
+  }
+  hipLaunchKernelGGL(topk_coords_kernel, dim3(1), dim3(TOPK_THREADS), 0, st, src, N, k, h, coords, indices);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+
+}  // extern "C"

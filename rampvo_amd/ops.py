@@ -8,6 +8,7 @@ import ctypes
 import torch
 
 from . import _lib
+from ._lib import workspace as _lib_workspace
 from ._lib import RAMP_NHWC8, RAMP_NCHW, RAMP_NHWC, CorrLevel, check, dtype_code, lib, ptr, require_cuda, stream
 
 
@@ -72,6 +73,28 @@ def corr(fmap1, fmaps2, coords, ii, jj, radius=3, coord_divs=(1.0,), layout=RAMP
                                       N1, N2, C, P, radius, dtype_code(fmap1), layout, stream()),
           "ramp_corr_fwd_ordered")
     return out
+
+
+def event_topk(events, k, nms_kernel_size=11, want_indices=False):
+    """patch centres of one frame: events [bins,H,W] float32 -> coords [k,2] float32 (x + y/h, y) at the
+    top-k cells of the NMS'ed mean |event| map (reference utils.py:186-226), one score kernel + one NMS
+    kernel + a one-workgroup radix select"""
+    require_cuda(events)
+    bins, H, W = events.shape
+    events = events.contiguous().float()
+    coords = torch.empty((k, 2), dtype=torch.float32, device=events.device)
+    idx = torch.empty(k, dtype=torch.int64, device=events.device) if want_indices else None
+    nbytes = lib().ramp_event_topk_workspace_bytes(H, W)
+    ws = _lib_workspace(nbytes, events.device, "topk")
+    check(lib().ramp_event_topk(ptr(events), bins, H, W, int(k), int(nms_kernel_size), ptr(coords),
+                                ptr(idx) if idx is not None else None, ptr(ws), nbytes, stream()),
+          "ramp_event_topk")
+    return (coords, idx) if want_indices else coords
+
+
+def event_topk_supported(events, k, nms_kernel_size):
+    return (events.dim() == 3 and events.shape[2] % 4 == 0 and events.shape[1] >= 4 and k <= 512
+            and k <= (events.shape[1] // 4) * (events.shape[2] // 4) and (nms_kernel_size == 0 or (nms_kernel_size % 2 == 1 and nms_kernel_size <= 17)))
 
 
 def pyramid_pack(fmap, out1=None, out4=None):

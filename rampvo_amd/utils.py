@@ -57,7 +57,13 @@ def get_coords_from_topk_events(events, patches_per_image, border_suppression_si
     resolution (reference utils.py:186-226).  The map is laid out [w, h] and the
     reference derives x by TRUE division of the flat index by h, so x carries the
     fraction y/h -- reproduced because every later bilinear lookup depends on it."""
-    ev = torch.abs(events.squeeze(0))
+    e4 = events.squeeze(0)                                        # [T, bins, H, W]
+    if e4.is_cuda and e4.shape[0] == 1 and border_suppression_size == 0:
+        from . import ops
+        if ops.event_topk_supported(e4[0], patches_per_image, non_max_supp_rad):
+            # GPU: score + NMS + radix select in three HIP launches (csrc/select.hip)
+            return ops.event_topk(e4[0], patches_per_image, non_max_supp_rad)[None]
+    ev = torch.abs(e4)
     ev = F.avg_pool2d(ev, 4, 4).transpose(3, 2).mean(dim=1)      # [T, w, h]
     if border_suppression_size != 0:
         b = border_suppression_size

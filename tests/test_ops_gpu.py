@@ -387,3 +387,46 @@ def test_ops_refuse_cpu_tensors():
     from rampvo_amd import ops
     with pytest.raises(RuntimeError):
         ops.se3_unary("ramp_se3_inv", torch.zeros(1, 7), 7, 7)
+
+
+@pytest.mark.parametrize("shape,k", [((5, 96, 128), 6), ((5, 480, 640), 96), ((5, 260, 348), 40)])
+def test_event_topk_matches_aten_pipeline(shape, k):
+    """ramp_event_topk against the reference's ATen pipeline (ramp/utils.py:186-226): identical cell
+    indices in identical order, and x = index / h as a true division"""
+    import torch.nn.functional as F
+    from rampvo_amd import ops
+    g = torch.Generator().manual_seed(17)
+    ev = (torch.randn(*shape, generator=g) * 20).cuda()
+    ev[:, :8] = 0                                                   # a dead band: NMS zeros / ties at 0 stay below the top-k
+    coords, idx = ops.event_topk(ev, k, 11, want_indices=True)
+    s = F.avg_pool2d(ev.abs()[None], 4, 4).transpose(3, 2).mean(dim=1)          # [1, w, h]
+    mx = F.max_pool2d(s.unsqueeze(0), 11, stride=1, padding=5).squeeze(0)
+    s = s * (mx == s).float()
+    hh = s.shape[-1]
+    val, ref = torch.topk(s.flatten(1), k=k, dim=-1)
+    assert float(val.min()) > 0                                     # tie-free fixture
+    assert torch.equal(idx, ref[0])
+    assert torch.equal(coords[:, 0], (ref[0] / hh).float()) and torch.equal(coords[:, 1], (ref[0] % hh).float())
+
+
+def test_event_topk_ties_take_lowest_index():
+    from rampvo_amd import ops
+    ev = torch.zeros(1, 64, 64, device="cuda")
+    ev[0, 8:12, 8:12] = 3.0           # one cell with score 3
+    ev[0, 40:44, 20:24] = 5.0         # one cell with score 5
+    coords, idx = ops.event_topk(ev, 5, 0, want_indices=True)
+    h = 16
+    assert idx[:2].tolist() == [5 * h + 10, 2 * h + 2]               # (X=5,Y=10) then (X=2,Y=2)
+    assert idx[2:].tolist() == [0, 1, 2]                              # zeros: lowest flat indices
+
+
+def test_event_topk_dense_map_without_nms():
+    """no NMS: every cell is a candidate (more than the LDS list holds) -> the streaming passes"""
+    import torch.nn.functional as F
+    from rampvo_amd import ops
+    g = torch.Generator().manual_seed(23)
+    ev = (torch.randn(5, 480, 640, generator=g) * 20).cuda()
+    coords, idx = ops.event_topk(ev, 200, 0, want_indices=True)
+    s = F.avg_pool2d(ev.abs()[None], 4, 4).transpose(3, 2).mean(dim=1)
+    val, ref = torch.topk(s.flatten(1), k=200, dim=-1)
+    assert torch.equal(idx, ref[0])
