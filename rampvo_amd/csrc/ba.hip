@@ -389,10 +389,15 @@ __global__ void __launch_bounds__(1024)
   for (int q = tid; q < n6; q += nt) dX[q] = t[q];
 }
 
-// single-wavefront variant for 6N <= 64 (default.yaml: 60).  Lane i keeps ROW i of the matrix in
-// 64 registers; column values are broadcast with v_readlane (constant lane index after full
-// unrolling), so the factorisation is ~2000 straight-line readlane+fma pairs, no LDS, no barriers.
-// Per-element update order (j ascending, separate mul/sub) is that of the textbook loop.
+// single-wavefront variant for 6N <= 63 (default.yaml: 60).  Lane i keeps ROW i of the matrix in 64
+// registers; column values are broadcast with v_readlane (constant lane index after full
+// unrolling): straight-line readlane + fma pairs, no barriers.
+//   * the right-hand side rides along as row n6 of the lower triangle, so the factorisation leaves
+//     z = L^-1 y in that row (no separate forward substitution);
+//   * 1/L[j][j] is computed once per column (uniform) and kept by lane j, so neither the column
+//     scaling nor the back substitution divides;
+//   * the back substitution is column oriented: lane i reads L[r][i] from an LDS transpose and
+//     subtracts L[r][i] x_r -- one readlane pair + fma per step instead of a wave reduction.
 __device__ __forceinline__ float bcast_lane(float v, int lane_const) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_const));
 }
@@ -400,40 +405,43 @@ __device__ __forceinline__ float bcast_lane(float v, int lane_const) {
 __global__ void __launch_bounds__(64)
     ba_chol64_kernel(const float *__restrict__ S, const float *__restrict__ yv,
                      float *__restrict__ dX, int32_t *__restrict__ info, int n6) {
+  __shared__ float Lt[64 * 65];          // Lt[c * 65 + i] = L[i][c]
   const int i = threadIdx.x;
   float a[64];
 #pragma unroll
-  for (int k = 0; k < 64; k++)
-    a[k] = (i < n6 && k < n6) ? (k <= i ? S[(size_t)i * n6 + k] : 0.0f) : (k == i ? 1.0f : 0.0f);
-  float t = i < n6 ? yv[i] : 0.0f;
+  for (int k = 0; k < 64; k++) {
+    float v = (k == i) ? 1.0f : 0.0f;                       // identity padding keeps unused columns inert
+    if (i < n6 && k < n6) v = (k <= i) ? S[(size_t)i * n6 + k] : 0.0f;
+    if (i == n6 && k < n6) v = yv[k];                       // right-hand side as row n6
+    a[k] = v;
+  }
   bool bad = false;
+  float rdiag = 1.0f;                                       // lane j: 1 / L[j][j]
 #pragma unroll
-  for (int j = 0; j < 64; j++) {
+  for (int j = 0; j < 63; j++) {
     const float dgn = bcast_lane(a[j], j);
-    bad |= !(dgn > 0.0f);
-    const float ljj = sqrtf(dgn);
-    a[j] = (i > j) ? a[j] / ljj : (i == j ? ljj : a[j]);
+    bad |= (j < n6) && !(dgn > 0.0f);
+    const float rinv = 1.0f / sqrtf(dgn);
+    if (i == j) rdiag = rinv;
+    a[j] = (i == j) ? sqrtf(dgn) : a[j] * rinv;             // rows above j hold don't-care values
 #pragma unroll
     for (int k = j + 1; k < 64; k++) {
       const float lkj = bcast_lane(a[j], k);
-      if (i >= k) a[k] = a[k] - a[j] * lkj;
+      a[k] = __builtin_fmaf(-a[j], lkj, a[k]);              // only rows i >= k are ever read
     }
   }
   if (bad && i == 0 && info) *info = 1;
-  // forward substitution  L z = y
+  // z = row n6;  L' x = z, column oriented
 #pragma unroll
-  for (int k = 0; k < 64; k++) {
-    const float zk = bcast_lane(t, k) / bcast_lane(a[k], k);
-    t = (i == k) ? zk : (i > k ? t - a[k] * zk : t);
-  }
-  // backward substitution  L' x = z :  x_i = (z_i - sum_{k>i} L[k][i] x_k) / L[i][i]
+  for (int c = 0; c < 64; c++) Lt[c * 65 + i] = a[c];
+  __syncthreads();
+  float z = (i < n6) ? Lt[i * 65 + n6] : 0.0f;             // z_i = L[n6][i]
   float x = 0.0f;
-#pragma unroll
-  for (int r = 63; r >= 0; r--) {
-    float part = (i > r) ? a[r] * x : 0.0f;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
-    if (i == r) x = (t - part) / a[r];
+  for (int r = n6 - 1; r >= 0; r--) {
+    const float xr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(z), r)) *
+                     __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rdiag), r));
+    if (i == r) x = xr;
+    z = __builtin_fmaf(-Lt[i * 65 + r], xr, z);             // L[r][i]; lanes i >= r are no longer needed
   }
   if (i < n6) dX[i] = x;
 }
@@ -572,7 +580,7 @@ static int ba_iterate(float *poses, float *patches, const float *intrinsics, con
                          w.Qv, w.uv, nk, w.S_part, w.y_part, n6, w.KS);
       hipLaunchKernelGGL(ba_assemble_kernel, dim3(N), dim3(256), 0, st, w.pairs, w.pair_ij, np,
                          w.S_part, w.y_part, w.S, w.yv, n6, w.KS);
-      if (n6 <= 64)
+      if (n6 <= 63)
         hipLaunchKernelGGL(ba_chol64_kernel, dim3(1), dim3(64), 0, st, w.S, w.yv, w.dX, info, n6);
       else
         hipLaunchKernelGGL(ba_chol_kernel, dim3(1), dim3(1024), lds, st, w.S, w.yv, w.dX, info, n6);
