@@ -101,43 +101,60 @@ __global__ void __launch_bounds__(256)
 #define R_J 31
 
 // ------------------------------------------------------------------ K2
+// One workgroup per patch (group of edges with the same kk).  The group's records are staged in LDS
+// with all loads in flight at once (walking them from memory is one dependent round trip per edge);
+// the sums run over the staged records in segment order.
+#define BA_PCHUNK 32
 __global__ void __launch_bounds__(256)
     ba_patch_kernel(const float *__restrict__ rec, const int32_t *__restrict__ order,
                     const int32_t *__restrict__ seg, const int32_t *__restrict__ ngroups,
                     const float *__restrict__ lmbda, float *__restrict__ Erow,
                     float *__restrict__ Cv, float *__restrict__ uv, float *__restrict__ Qv,
                     int n6) {
+  __shared__ float s_rec[BA_PCHUNK][BA_REC + 1];
   const int g = blockIdx.x;
   if (g >= *ngroups) return;
-  const int tid = threadIdx.x;
-  if (tid >= n6 + 2) return;
+  const int tid = threadIdx.x, nthr = blockDim.x;
   const int s0 = seg[g], s1 = seg[g + 1];
+  const int a = tid / 6, c = tid - a * 6;
   float acc = 0.0f;
-  if (tid < n6) {
-    const int a = tid / 6, c = tid - a * 6;
-    for (int p = s0; p < s1; p++) {
-      const float *r = rec + (size_t)order[p] * BA_REC;
-      const int i = __float_as_int(r[R_I]), j = __float_as_int(r[R_J]);
-      if (i == a) acc += (-r[R_W0] * r[R_JZ0]) * r[R_JI0 + c];
-      if (j == a) acc += (r[R_W0] * r[R_JZ0]) * r[R_JJ0 + c];
-      if (i == a) acc += (-r[R_W1] * r[R_JZ1]) * r[R_JI1 + c];
-      if (j == a) acc += (r[R_W1] * r[R_JZ1]) * r[R_JJ1 + c];
+  for (int b0 = s0; b0 < s1; b0 += BA_PCHUNK) {
+    const int nb = min(BA_PCHUNK, s1 - b0);
+    __syncthreads();
+    for (int e = tid; e < nb * BA_REC; e += nthr) {
+      const int l = e / BA_REC, k = e - l * BA_REC;
+      s_rec[l][k] = rec[(size_t)order[b0 + l] * BA_REC + k];
     }
+    __syncthreads();
+    if (tid < n6) {
+      for (int l = 0; l < nb; l++) {
+        const float *r = s_rec[l];
+        const int i = __float_as_int(r[R_I]), j = __float_as_int(r[R_J]);
+        if (i == a) acc += (-r[R_W0] * r[R_JZ0]) * r[R_JI0 + c];
+        if (j == a) acc += (r[R_W0] * r[R_JZ0]) * r[R_JJ0 + c];
+        if (i == a) acc += (-r[R_W1] * r[R_JZ1]) * r[R_JI1 + c];
+        if (j == a) acc += (r[R_W1] * r[R_JZ1]) * r[R_JJ1 + c];
+      }
+    } else if (tid == n6) {
+      for (int l = 0; l < nb; l++) {
+        const float *r = s_rec[l];
+        acc += (r[R_W0] * r[R_JZ0]) * r[R_JZ0];
+        acc += (r[R_W1] * r[R_JZ1]) * r[R_JZ1];
+      }
+    } else if (tid == n6 + 1) {
+      for (int l = 0; l < nb; l++) {
+        const float *r = s_rec[l];
+        acc += (r[R_W0] * r[R_R0]) * r[R_JZ0];
+        acc += (r[R_W1] * r[R_R1]) * r[R_JZ1];
+      }
+    }
+  }
+  if (tid < n6) {
     Erow[(size_t)g * n6 + tid] = acc;
   } else if (tid == n6) {
-    for (int p = s0; p < s1; p++) {
-      const float *r = rec + (size_t)order[p] * BA_REC;
-      acc += (r[R_W0] * r[R_JZ0]) * r[R_JZ0];
-      acc += (r[R_W1] * r[R_JZ1]) * r[R_JZ1];
-    }
     Cv[g] = acc;
     Qv[g] = 1.0f / (acc + lmbda[0]);
-  } else {
-    for (int p = s0; p < s1; p++) {
-      const float *r = rec + (size_t)order[p] * BA_REC;
-      acc += (r[R_W0] * r[R_R0]) * r[R_JZ0];
-      acc += (r[R_W1] * r[R_R1]) * r[R_JZ1];
-    }
+  } else if (tid == n6 + 1) {
     uv[g] = acc;
   }
 }
@@ -272,6 +289,7 @@ __global__ void __launch_bounds__(256)
 // compacted IN ORDER into LDS (ballot prefix), then every thread sums its entries of the 6 x 6N
 // row block over that short list -- fixed order, no atomics.
 #define BA_MAXLIST 1024
+#define BA_CHUNK 48
 __global__ void __launch_bounds__(256)
     ba_assemble_kernel(const float *__restrict__ pairs, const int32_t *__restrict__ pair_ij,
                        const int32_t *__restrict__ npairs, const float *__restrict__ S_part,
@@ -299,34 +317,89 @@ __global__ void __launch_bounds__(256)
     __syncthreads();
   }
   const int nl = min(s_base, BA_MAXLIST);
-  for (int q = tid; q < 6 * n6; q += 256) {
-    const int x = q / n6, c = q - x * n6;
-    const int b = c / 6, y = c - b * 6;
-    const int r = 6 * a + x;
-    float bsum = 0.0f, vsum = 0.0f;
-    for (int l = 0; l < nl; l++) {
-      const int g = s_list[l];
-      const int i = pair_ij[2 * g], j = pair_ij[2 * g + 1];
-      const float *pr = pairs + (size_t)g * BA_PAIR;
-      if (i == a && i == b) bsum += pr[x * 6 + y];
-      if (j == a && j == b) bsum += pr[36 + x * 6 + y];
-      if (i == a && j == b) bsum += pr[72 + x * 6 + y];
-      if (j == a && i == b) bsum += pr[108 + x * 6 + y];
-      if (c == 0) {
-        if (i == a) vsum += pr[144 + x];
-        if (j == a) vsum += pr[150 + x];
+  // The listed pair records are staged through LDS in chunks (coalesced, all loads in flight at
+  // once) -- walking them straight from memory costs one dependent global round trip per record.
+  __shared__ __attribute__((aligned(16))) float s_pr[BA_CHUNK][BA_PAIR];
+  __shared__ int s_i[BA_CHUNK], s_j[BA_CHUNK];
+  // the 6 x 6N row block is split over gridDim.y workgroups
+  const int epb = (6 * n6 + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int q_lo = blockIdx.y * epb, q_hi = min(6 * n6, q_lo + epb);
+  constexpr int QMAX = 5;                    // entries per thread (epb <= 1280)
+  float bsum[QMAX], vsum[QMAX];
+#pragma unroll
+  for (int t = 0; t < QMAX; t++) { bsum[t] = 0.0f; vsum[t] = 0.0f; }
+  for (int l0 = 0; l0 < nl; l0 += BA_CHUNK) {
+    const int cnt = min(BA_CHUNK, nl - l0);
+    __syncthreads();
+    constexpr int V4 = BA_PAIR / 4;            // float4 pieces per record
+    for (int e0 = 0; e0 < cnt * V4; e0 += 4 * 256) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {              // 4 independent 16-byte loads per thread in flight
+        const int e = e0 + u * 256 + tid;
+        const int l = min(e / V4, cnt - 1), k = e % V4;
+        v[u] = reinterpret_cast<const float4 *>(pairs + (size_t)s_list[l0 + l] * BA_PAIR)[k];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int e = e0 + u * 256 + tid;
+        if (e < cnt * V4) reinterpret_cast<float4 *>(&s_pr[e / V4][0])[e % V4] = v[u];
       }
     }
+    if (tid < cnt) {
+      const int g = s_list[l0 + tid];
+      s_i[tid] = pair_ij[2 * g];
+      s_j[tid] = pair_ij[2 * g + 1];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < QMAX; t++) {
+      const int q = q_lo + tid + t * 256;
+      if (q >= q_hi) break;
+      const int x = q / n6, c = q - x * n6;
+      const int b = c / 6, y = c - b * 6;
+      for (int l = 0; l < cnt; l++) {          // ascending list order: the fixed summation order
+        const int i = s_i[l], j = s_j[l];
+        const float *pr = s_pr[l];
+        if (i == a && i == b) bsum[t] += pr[x * 6 + y];
+        if (j == a && j == b) bsum[t] += pr[36 + x * 6 + y];
+        if (i == a && j == b) bsum[t] += pr[72 + x * 6 + y];
+        if (j == a && i == b) bsum[t] += pr[108 + x * 6 + y];
+        if (c == 0) {
+          if (i == a) vsum[t] += pr[144 + x];
+          if (j == a) vsum[t] += pr[150 + x];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < QMAX; t++) {
+    const int q = q_lo + tid + t * 256;
+    if (q >= q_hi) break;
+    const int x = q / n6, c = q - x * n6;
+    const int r = 6 * a + x;
+    // split-K partials in z order; 16 loads in flight at a time
     float sp = 0.0f;
-#pragma unroll 8
-    for (int z = 0; z < KS; z++) sp += S_part[((size_t)z * n6 + r) * n6 + c];
-    float s = bsum - sp;
+    for (int z0 = 0; z0 < KS; z0 += 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) v[u] = (z0 + u < KS) ? S_part[((size_t)(z0 + u) * n6 + r) * n6 + c] : 0.0f;
+#pragma unroll
+      for (int u = 0; u < 16; u++) if (z0 + u < KS) sp += v[u];
+    }
+    float s = bsum[t] - sp;
     if (r == c) s += (1e-4f * s + 1.0f);
     S[(size_t)r * n6 + c] = s;
     if (c == 0) {
       float yp = 0.0f;
-      for (int z = 0; z < KS; z++) yp += y_part[(size_t)z * n6 + r];
-      yv[r] = vsum - yp;
+      for (int z0 = 0; z0 < KS; z0 += 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) v[u] = (z0 + u < KS) ? y_part[(size_t)(z0 + u) * n6 + r] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 16; u++) if (z0 + u < KS) yp += v[u];
+      }
+      yv[r] = vsum[t] - yp;
     }
   }
 }
@@ -518,7 +591,7 @@ static size_t ba_carve(void *ws, int E, int n_poses, int n_patches, int N, int o
   w->tiles = (n6 + BA_TS - 1) / BA_TS;
   if (w->tiles < 1) w->tiles = 1;
   int ks = 256 / (w->tiles * w->tiles);
-  w->KS = ks < 4 ? 4 : (ks > 16 ? 16 : ks);
+  w->KS = ks < 4 ? 4 : (ks > 64 ? 64 : ks);   // split-K partials, summed in fixed order by K5
   w->gb = nullptr; w->gb_bytes = 0;
   w->pkeys = w->kx = w->pukeys = nullptr;
   w->order_k = w->seg_k = w->order_p = w->seg_p = nullptr;
@@ -578,7 +651,7 @@ static int ba_iterate(float *poses, float *patches, const float *intrinsics, con
                          w.pairs, w.pair_ij);
       hipLaunchKernelGGL(ba_schur_kernel, dim3(w.tiles, w.tiles, w.KS), dim3(256), 0, st, w.Erow,
                          w.Qv, w.uv, nk, w.S_part, w.y_part, n6, w.KS);
-      hipLaunchKernelGGL(ba_assemble_kernel, dim3(N), dim3(256), 0, st, w.pairs, w.pair_ij, np,
+      hipLaunchKernelGGL(ba_assemble_kernel, dim3(N, ramp_cdiv(6 * n6, 192)), dim3(256), 0, st, w.pairs, w.pair_ij, np,
                          w.S_part, w.y_part, w.S, w.yv, n6, w.KS);
       if (n6 <= 63)
         hipLaunchKernelGGL(ba_chol64_kernel, dim3(1), dim3(64), 0, st, w.S, w.yv, w.dX, info, n6);
