@@ -361,6 +361,19 @@ int ramp_upd_heads(const void *hw, const float *coords, float *target, float *we
 int ramp_upd_segment_softmax(const void *fg, const int32_t *order, const int32_t *seg_start,
                              const int32_t *ngroups, void *y, int max_groups, int dtype, void *stream);
 
+/* ------------------------------------------------ fused update-operator GEMM chains (fp16) */
+/* gru[1..3] of the update operator (ramp/net.py:49-54; GatedResidual: ramp/blocks.py:15-31) as ONE
+ * launch: x -> x + sigmoid(Wg x) * W2 relu(W1 x) -> LayerNorm -> the same again, 6 Linear layers with the
+ * 64-row activation tile resident in LDS, fp16 MFMA / fp32 accumulate.
+ *   x32 [E][384] fp32 (output of gru[0], the caller's LayerNorm);  out32 [E][384] fp32;
+ *   relu_t [E][384] fp16 = relu(out32), the heads' input
+ *   wp_host[6]: fp16 weights of (g1.gate, g1.res[0], g1.res[2], g2.gate, g2.res[0], g2.res[2]) packed in
+ *   MFMA fragment order [K/32][N/16][64 lanes][8] (lane (q, j): W[16 nt + j][32 ks + 8 q ..]);
+ *   bias_host[6]: fp32 [384] each (host arrays of device pointers); ln_w, ln_b, eps: gru[2]          */
+int ramp_upd_gru(const float *x32, const void *const *wp_host, const float *const *bias_host, const float *ln_w,
+                 const float *ln_b, float eps, float *out32, void *relu_t, int E, void *stream);
+size_t ramp_upd_mlp_lds_bytes(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,254 @@
+// Fused GEMM chains of the update operator on the matrix cores (fp16 in, fp32 accumulate).
+//
+// The per-edge MLPs of the operator (ramp/net.py:49-54 `gru`, :43-46 `c1`/`c2`, ramp/blocks.py:15-31
+// GatedResidual) are chains of [E,384]x[384,384] Linear layers with row-local glue between them.  As
+// separate library GEMMs every layer reads and writes the full [E,384] activation (2 x 30 MB) and
+// every glue step is another pass; at N = K = 384 a GEMM is neither compute nor bandwidth bound but
+// tile-quantised and launch-latency bound.  Here a workgroup owns 64 rows for the WHOLE chain:
+//   * the activation tile lives in LDS (fp16, [64][384+8]); the A fragment of lane (q, j) is row j,
+//     channels 8q..8q+7 of a 32-channel K step: one ds_read_b128, conflict free with the +8 pad;
+//   * 8 waves, wave w owns output columns [48w, 48w+48): 4 x 3 accumulator tiles of
+//     v_mfma_f32_16x16x32_f16; weights are pre-packed in fragment order (one contiguous KB per load
+//     instruction) and streamed from L2 -- a wave never re-reads a fragment;
+//   * bias / ReLU / sigmoid gate / residual / LayerNorm run on the accumulator registers; only the
+//     next layer's fp16 input goes back to LDS.  Linear outputs are rounded to fp16 where the
+//     reference's autocast would (they are half tensors there).
+#include "ramp_device.h"
+
+#define MD 384                 // feature width
+#define MBM 64                 // rows per workgroup
+#define MXS (MD + 8)           // LDS row stride (halfs)
+#define MKS (MD / 32)          // K steps per 384-wide layer
+#define MNTW 3                 // 16-column tiles per wave
+#define MWAVES 8
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float h_round(float v) { return (float)(_Float16)v; }
+__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// acc[mt][nt] += Xs[64 x 384] * W^T for this wave's 48 columns; NB weight matrices share the A reads
+template <int NB>
+__device__ __forceinline__ void mlp_gemm(const _Float16 *Xs, const _Float16 *const (&wp)[NB], int wave, int lane,
+                                         f4 (&acc)[NB][4][MNTW]) {
+  const int q = lane >> 4, j = lane & 15;
+#pragma unroll
+  for (int b = 0; b < NB; b++)
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+      for (int nt = 0; nt < MNTW; nt++) acc[b][mt][nt] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+  for (int ks = 0; ks < MKS; ks++) {
+    h8 a[4], bw[NB][MNTW];
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+#pragma unroll
+      for (int nt = 0; nt < MNTW; nt++)
+        bw[b][nt] = *reinterpret_cast<const h8 *>(wp[b] + (((size_t)ks * (MD / 16) + wave * MNTW + nt) * 64 + lane) * 8);
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++) a[mt] = *reinterpret_cast<const h8 *>(Xs + (mt * 16 + j) * MXS + ks * 32 + 8 * q);
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+#pragma unroll
+      for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+        for (int nt = 0; nt < MNTW; nt++)
+          acc[b][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mt], bw[b][nt], acc[b][mt][nt], 0, 0, 0);
+  }
+}
+
+// sum over the 384 columns of each of the 64 rows of a value held in accumulator layout:
+// lane (q, j) holds rows 16 mt + 4 q + r, columns 48 wave + 16 nt + j.  Returns the row totals for
+// this lane's 16 (mt, r) rows.  Fixed order: nt, then the 16 lanes (xor butterfly), then waves 0..7.
+__device__ __forceinline__ void row_totals(const float (&part)[4][4], float *s_red, int wave, int lane,
+                                           float (&tot)[4][4]) {
+  const int q = lane >> 4, j = lane & 15;
+  __syncthreads();                                   // s_red is reused
+#pragma unroll
+  for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      float v = part[mt][r];
+      v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+      if (j == 0) s_red[wave * MBM + mt * 16 + 4 * q + r] = v;
+    }
+  __syncthreads();
+#pragma unroll
+  for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < MWAVES; w++) t += s_red[w * MBM + mt * 16 + 4 * q + r];
+      tot[mt][r] = t;
+    }
+}
+
+struct GruParams {
+  const float *x32;            // [E][384] fp32: the LayerNorm'ed residual stream entering gru[1]
+  const _Float16 *wp[6];       // packed weights: g1_gate, g1_r1, g1_r2, g2_gate, g2_r1, g2_r2
+  const float *bias[6];        // biases (fp16-rounded values as fp32)
+  const float *ln_w, *ln_b;    // gru[2] LayerNorm
+  float eps;
+  float *out32;                // [E][384] fp32 result of gru[3]
+  _Float16 *relu_t;            // [E][384] relu(result) in fp16 (input of the heads)
+  int E;
+};
+
+// gru = LayerNorm (done by the caller's row kernel), GatedResidual, LayerNorm, GatedResidual
+__global__ void __launch_bounds__(64 * MWAVES) upd_gru_kernel(const GruParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  _Float16 *Xs = reinterpret_cast<_Float16 *>(smem_raw);            // [64][MXS]
+  _Float16 *Hs = Xs + MBM * MXS;                                    // [64][MXS]
+  float *s_red = reinterpret_cast<float *>(Hs + MBM * MXS);         // [8][64]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
+  const int row0 = blockIdx.x * MBM;
+  const int col0 = wave * (16 * MNTW);
+
+  // ---- stage the input tile (fp32 -> fp16) and keep this lane's residual entries in fp32
+  for (int i = tid; i < MBM * (MD / 4); i += 64 * MWAVES) {
+    const int r = i / (MD / 4), c4 = i - r * (MD / 4);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row0 + r < p.E) v = *reinterpret_cast<const float4 *>(p.x32 + (size_t)(row0 + r) * MD + 4 * c4);
+    _Float16 *d = Xs + r * MXS + 4 * c4;
+    d[0] = (_Float16)v.x; d[1] = (_Float16)v.y; d[2] = (_Float16)v.z; d[3] = (_Float16)v.w;
+  }
+  float xres[4][MNTW][4];
+#pragma unroll
+  for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+    for (int nt = 0; nt < MNTW; nt++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = row0 + mt * 16 + 4 * q + r;
+        xres[mt][nt][r] = row < p.E ? p.x32[(size_t)row * MD + col0 + nt * 16 + j] : 0.0f;
+      }
+  __syncthreads();
+
+#pragma unroll 1
+  for (int stage = 0; stage < 2; stage++) {
+    const int wb = 3 * stage;
+    // gate pre-activation and first residual layer share the A operand
+    f4 acc2[2][4][MNTW];
+    {
+      const _Float16 *const w2[2] = {p.wp[wb + 0], p.wp[wb + 1]};
+      mlp_gemm<2>(Xs, w2, wave, lane, acc2);
+    }
+    // h = relu(L1 x + b1) -> Hs (fp16)
+#pragma unroll
+    for (int nt = 0; nt < MNTW; nt++) {
+      const float b1 = p.bias[wb + 1][col0 + nt * 16 + j];
+#pragma unroll
+      for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          Hs[(mt * 16 + 4 * q + r) * MXS + col0 + nt * 16 + j] = (_Float16)fmaxf(acc2[1][mt][nt][r] + b1, 0.f);
+    }
+    __syncthreads();
+    f4 accr[1][4][MNTW];
+    {
+      const _Float16 *const w1[1] = {p.wp[wb + 2]};
+      mlp_gemm<1>(Hs, w1, wave, lane, accr);
+    }
+    // v = x + sigmoid(gate) * r     (gate and r are half tensors under the reference's autocast)
+    float v[4][MNTW][4];
+#pragma unroll
+    for (int nt = 0; nt < MNTW; nt++) {
+      const float bg = p.bias[wb + 0][col0 + nt * 16 + j], b2 = p.bias[wb + 2][col0 + nt * 16 + j];
+#pragma unroll
+      for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const float g = h_round(acc2[0][mt][nt][r] + bg), rr = h_round(accr[0][mt][nt][r] + b2);
+          v[mt][nt][r] = xres[mt][nt][r] + sigm(g) * rr;
+        }
+    }
+    if (stage == 0) {
+      // gru[2]: LayerNorm over the row (two-pass, fp32), result = next stage's residual + fp16 input
+      float part[4][4], tot[4][4], mean[4][4];
+#pragma unroll
+      for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) part[mt][r] = (v[mt][0][r] + v[mt][1][r]) + v[mt][2][r];
+      row_totals(part, s_red, wave, lane, tot);
+#pragma unroll
+      for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          mean[mt][r] = tot[mt][r] * (1.0f / MD);
+          float s = 0.f;
+#pragma unroll
+          for (int nt = 0; nt < MNTW; nt++) { const float d = v[mt][nt][r] - mean[mt][r]; s += d * d; }
+          part[mt][r] = s;
+        }
+      row_totals(part, s_red, wave, lane, tot);
+#pragma unroll
+      for (int nt = 0; nt < MNTW; nt++) {
+        const float lw = p.ln_w[col0 + nt * 16 + j], lb = p.ln_b[col0 + nt * 16 + j];
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const float rstd = 1.0f / sqrtf(tot[mt][r] * (1.0f / MD) + p.eps);
+            const float y = (v[mt][nt][r] - mean[mt][r]) * rstd * lw + lb;
+            xres[mt][nt][r] = y;
+            Xs[(mt * 16 + 4 * q + r) * MXS + col0 + nt * 16 + j] = (_Float16)y;    // every wave is past its X reads
+          }
+      }
+      __syncthreads();
+    } else {
+      // result: fp32 state straight from the registers, ReLU copy through LDS for 16-byte stores
+#pragma unroll
+      for (int nt = 0; nt < MNTW; nt++)
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int row = row0 + mt * 16 + 4 * q + r;
+            if (row < p.E) p.out32[(size_t)row * MD + col0 + nt * 16 + j] = v[mt][nt][r];
+            Xs[(mt * 16 + 4 * q + r) * MXS + col0 + nt * 16 + j] = (_Float16)fmaxf(v[mt][nt][r], 0.f);
+          }
+      __syncthreads();
+      for (int i = tid; i < MBM * (MD / 8); i += 64 * MWAVES) {
+        const int r = i / (MD / 8), c8 = i - r * (MD / 8);
+        if (row0 + r < p.E)
+          *reinterpret_cast<h8 *>(p.relu_t + (size_t)(row0 + r) * MD + 8 * c8) =
+              *reinterpret_cast<const h8 *>(Xs + r * MXS + 8 * c8);
+      }
+    }
+  }
+}
+
+extern "C" {
+
+size_t ramp_upd_mlp_lds_bytes(void) { return (size_t)2 * MBM * MXS * 2 + MWAVES * MBM * 4; }
+
+int ramp_upd_gru(const float *x32, const void *const *wp_host, const float *const *bias_host, const float *ln_w,
+                 const float *ln_b, float eps, float *out32, void *relu_t, int E, void *stream) {
+  if (E < 0) return RAMP_EINVAL;
+  if (E == 0) return RAMP_OK;
+  if (!x32 || !wp_host || !bias_host || !ln_w || !ln_b || !out32 || !relu_t) return RAMP_EINVAL;
+  GruParams p;
+  p.x32 = x32;
+  for (int i = 0; i < 6; i++) {
+    if (!wp_host[i] || !bias_host[i]) return RAMP_EINVAL;
+    p.wp[i] = (const _Float16 *)wp_host[i];
+    p.bias[i] = bias_host[i];
+  }
+  p.ln_w = ln_w; p.ln_b = ln_b; p.eps = eps; p.out32 = out32; p.relu_t = (_Float16 *)relu_t; p.E = E;
+  const size_t lds = ramp_upd_mlp_lds_bytes();
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void *)upd_gru_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+        hipSuccess)
+      return RAMP_ELAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(upd_gru_kernel, dim3(ramp_cdiv(E, MBM)), dim3(64 * MWAVES), lds, (hipStream_t)stream, p);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+
+}  // extern "C"

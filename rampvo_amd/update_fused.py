@@ -6,6 +6,8 @@ two GEMMs is ONE kernel.  The hidden state stays fp32; GEMM inputs/outputs are `
 under MIXED_PRECISION -- what the reference's autocast does -- or float).  Weight copies in
 ``dtype`` (f|g and the two heads stacked) are cached per module.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -13,6 +15,15 @@ from . import _lib
 from ._lib import check, lib, ptr, stream
 
 _code = {torch.float32: _lib.RAMP_F32, torch.float16: _lib.RAMP_F16}
+
+
+def pack_linear_f16(weight):
+    """nn.Linear weight [N, K] -> fp16 MFMA B fragments [K/32][N/16][64 lanes][8]:
+    lane (q = lane >> 4, j = lane & 15) of fragment (ks, nt) holds W[16 nt + j][32 ks + 8 q .. + 8]"""
+    w = weight.detach().half()
+    N, K = w.shape
+    assert N % 16 == 0 and K % 32 == 0
+    return w.view(N // 16, 16, K // 32, 4, 8).permute(2, 0, 3, 1, 4).contiguous()
 
 
 class FusedUpdate:
@@ -23,6 +34,7 @@ class FusedUpdate:
         self._key = None
         self._params = list(update.parameters())     # module structure is fixed; values are tracked by key
         self._act_ok = True
+        self.use_mlp = os.environ.get("RAMP_UPD_MLP", "1") == "1"    # fused GEMM-chain kernels (fp16 only)
 
     # ------------------------------------------------------------------ weights
     def weights(self):
@@ -55,6 +67,15 @@ class FusedUpdate:
             g2_r2=(c(m.gru[3].res[2].weight), c(m.gru[3].res[2].bias)),
             heads=(c(torch.cat([m.d[1].weight, m.w[1].weight], 0)), c(torch.cat([m.d[1].bias, m.w[1].bias], 0))),
         )
+        if T == torch.float16:
+            # fused GEMM chains (csrc/update_mlp.hip): weights in MFMA fragment order, biases as the fp32
+            # values of their fp16 roundings (they are half tensors under the reference's autocast)
+            import ctypes
+            gru = [m.gru[1].gate[0], m.gru[1].res[0], m.gru[1].res[2], m.gru[3].gate[0], m.gru[3].res[0], m.gru[3].res[2]]
+            wp = [pack_linear_f16(l.weight) for l in gru]
+            bs = [l.bias.detach().half().float().contiguous() for l in gru]
+            w["gru_pack"] = (wp, bs, (ctypes.c_void_p * 6)(*[t.data_ptr() for t in wp]),
+                             (ctypes.c_void_p * 6)(*[t.data_ptr() for t in bs]))
         self._w, self._key = w, key
         return w
 
@@ -129,6 +150,13 @@ class FusedUpdate:
         hy = self.lin(self.seg(self.lin(net_t, w["ij_fg"]), plan.g_ij, plan.max_ij), w["ij_h"])
         x32, x_t = self.row_fuse(E, A=net32, B=hy, idxB32=plan.g_ij.gid, ln=w["ln1"], out_f32=net32, want_t=True)
         # gru = LN, GatedResidual, LN, GatedResidual (net.py:49-54)
+        if "gru_pack" in w and self.use_mlp:
+            _, _, wptr, bptr = w["gru_pack"]
+            out32 = torch.empty(E, 384, dtype=torch.float32, device=x32.device)
+            relu_t = torch.empty(E, 384, dtype=self.dtype, device=x32.device)
+            check(lib().ramp_upd_gru(ptr(x32), wptr, bptr, ptr(w["ln2"][0]), ptr(w["ln2"][1]), float(w["ln2"][2]),
+                                     ptr(out32), ptr(relu_t), E, stream()), "ramp_upd_gru")
+            return out32, relu_t
         gate = self.lin(x_t, w["g1_gate"])
         r = self.lin(self.lin_relu(x_t, w["g1_r1"]), w["g1_r2"])
         x32, x_t, _ = self.gated(x32, gate, r, E, ln=w["ln2"], want_t=True)

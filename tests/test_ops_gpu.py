@@ -430,3 +430,32 @@ def test_event_topk_dense_map_without_nms():
     s = F.avg_pool2d(ev.abs()[None], 4, 4).transpose(3, 2).mean(dim=1)
     val, ref = torch.topk(s.flatten(1), k=200, dim=-1)
     assert torch.equal(idx, ref[0])
+
+
+def test_fused_gru_chain_matches_gemm_path():
+    """csrc/update_mlp.hip::upd_gru_kernel (6 Linear layers + gates + LayerNorm in one launch) against
+    the same operator stitched from library GEMMs and the row kernels; E not a multiple of the 64-row tile"""
+    from rampvo_amd.synthetic import make_network
+    from rampvo_amd.net import GraphPlan
+    net = make_network("SingleScale")
+    fu = net.update.fused(torch.float16)
+    g = torch.Generator().manual_seed(3)
+    E, M = 1000, 40
+    kk = torch.sort(torch.randint(0, M * 6, (E,), generator=g)).values.cuda()
+    ii = kk // M
+    jj = torch.randint(0, 8, (E,), generator=g).cuda()
+    plan = GraphPlan.build(ii, jj, kk)
+    netst = (torch.randn(E, 384, generator=g) * 0.5).cuda()
+    inp = (torch.randn(E, 384, generator=g) * 0.5).half().cuda()
+    corr = (torch.randn(E, 882, generator=g) * 0.5).half().cuda()
+    outs = {}
+    with torch.no_grad():
+        for mlp in (False, True):
+            fu.use_mlp = mlp
+            o32, rt = fu.hidden(netst.clone(), inp, None, 0, corr, plan)
+            outs[mlp] = (o32.clone(), rt.float().clone())
+    fu.use_mlp = True
+    scale = float(outs[False][0].abs().max())
+    assert float((outs[False][0] - outs[True][0]).abs().max()) <= 4e-3 * scale      # fp16 GEMM inputs on both sides
+    assert float((outs[False][1] - outs[True][1]).abs().max()) <= 4e-3 * scale
+    assert torch.equal(outs[True][1], torch.relu(outs[True][0]).half().float())
