@@ -657,7 +657,10 @@ __global__ void __launch_bounds__(256)
 #define LM_BSS (LM_BIM + 16)            // 4 regs
 #define LM_TOTAL (LM_BSS + 4)           // x 64 lanes floats
 
-__device__ __forceinline__ float lm_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+// v_exp_f32 / v_rcp_f32 based (about 1 ulp each): the IEEE expf + division + tanhf sequences were most
+// of this kernel's VALU time; the LSTM gates are insensitive at that level (test tolerance 2e-5)
+__device__ __forceinline__ float lm_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float lm_tanh(float x) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f; }
 
 __global__ void __launch_bounds__(256)
     lstm_superstate_mfma_kernel(const float *__restrict__ ev, const float *__restrict__ im,
@@ -722,9 +725,9 @@ __global__ void __launch_bounds__(256)
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_im[t * 5 + s4], bk[s4], acc, 0, 0, 0);
         }
         // acc = (i, f, g, o) pre-activations of unit 4t+q, pixel j (torch gate order i, f, g, o)
-        const float ig = lm_sigmoid(acc[0]), fg = lm_sigmoid(acc[1]), gg = tanhf(acc[2]), og = lm_sigmoid(acc[3]);
+        const float ig = lm_sigmoid(acc[0]), fg = lm_sigmoid(acc[1]), gg = lm_tanh(acc[2]), og = lm_sigmoid(acc[3]);
         const float cn = has_state ? fg * cold[t] + ig * gg : ig * gg;
-        const float hv = og * tanhf(cn);
+        const float hv = og * lm_tanh(cn);
         const bool unit_ok = 4 * t + q < 15;
         hn[mod][t] = unit_ok ? hv : 0.0f;
         cs[sbase + 64 * t] = unit_ok ? cn : 0.0f;
