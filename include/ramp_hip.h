@@ -374,6 +374,13 @@ int ramp_upd_gru(const float *x32, const void *const *wp_host, const float *cons
                  const float *ln_b, float eps, float *out32, void *relu_t, int E, void *stream);
 size_t ramp_upd_mlp_lds_bytes(void);
 
+/* net_out[e] = net_in[e] + Lb(relu(La(idx[e] >= 0 ? net_in[idx[e]] : 0)))  -- the temporal-neighbour MLPs
+ * c1 / c2 (ramp/net.py:43-46, 77-82) with the gather, both Linear layers and the residual add in one
+ * launch.  net_in != net_out (other workgroups gather from net_in); out_t: optional fp16 copy of
+ * net_out.  wa / wb packed like ramp_upd_gru's weights, ba / bb fp32 [384].                          */
+int ramp_upd_nbr(const float *net_in, const int64_t *idx, const void *wa, const float *ba, const void *wb,
+                 const float *bb, float *net_out, void *out_t, int E, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

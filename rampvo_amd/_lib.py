@@ -82,6 +82,7 @@ SIGNATURES = {
     "ramp_upd_segment_softmax": (c_i, [c_p] * 5 + [c_i, c_i, c_p]),
     "ramp_upd_gru": (c_i, [c_p, ctypes.POINTER(c_p), ctypes.POINTER(c_p), c_p, c_p, c_f, c_p, c_p, c_i, c_p]),
     "ramp_upd_mlp_lds_bytes": (c_sz, []),
+    "ramp_upd_nbr": (c_i, [c_p] * 8 + [c_i, c_p]),
 }
 
 _lib = None

@@ -223,6 +223,84 @@ __global__ void __launch_bounds__(64 * MWAVES) upd_gru_kernel(const GruParams p)
   }
 }
 
+// ------------------------------------------------------------------ c1 / c2
+// net[e] += Lb(relu(La(mask * net[idx[e]])))   (ramp/net.py:77-82: the temporal-neighbour MLPs; idx = -1
+// marks a missing neighbour).  The gathered rows are staged straight into the LDS tile; the result is
+// written to a SECOND state buffer (other workgroups still gather from the input one).
+struct NbrParams {
+  const float *net_in;         // [E][384] fp32
+  const int64_t *idx;          // [E] neighbour row or -1
+  const _Float16 *wa, *wb;     // packed weights of the two Linear layers
+  const float *ba, *bb;        // biases (fp16-rounded values as fp32)
+  float *net_out;              // [E][384] fp32
+  _Float16 *out_t;             // optional [E][384] fp16 copy of net_out
+  int E;
+};
+
+__global__ void __launch_bounds__(64 * MWAVES) upd_nbr_kernel(const NbrParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  _Float16 *Xs = reinterpret_cast<_Float16 *>(smem_raw);
+  _Float16 *Hs = Xs + MBM * MXS;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
+  const int row0 = blockIdx.x * MBM;
+  const int col0 = wave * (16 * MNTW);
+  for (int i = tid; i < MBM * (MD / 4); i += 64 * MWAVES) {
+    const int r = i / (MD / 4), c4 = i - r * (MD / 4);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row0 + r < p.E) {
+      const long src = p.idx[row0 + r];
+      if (src >= 0) v = *reinterpret_cast<const float4 *>(p.net_in + (size_t)src * MD + 4 * c4);
+    }
+    _Float16 *d = Xs + r * MXS + 4 * c4;
+    d[0] = (_Float16)v.x; d[1] = (_Float16)v.y; d[2] = (_Float16)v.z; d[3] = (_Float16)v.w;
+  }
+  __syncthreads();
+  f4 acc[1][4][MNTW];
+  {
+    const _Float16 *const w1[1] = {p.wa};
+    mlp_gemm<1>(Xs, w1, wave, lane, acc);
+  }
+#pragma unroll
+  for (int nt = 0; nt < MNTW; nt++) {
+    const float b1 = p.ba[col0 + nt * 16 + j];
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+        Hs[(mt * 16 + 4 * q + r) * MXS + col0 + nt * 16 + j] = (_Float16)fmaxf(acc[0][mt][nt][r] + b1, 0.f);
+  }
+  __syncthreads();
+  {
+    const _Float16 *const w1[1] = {p.wb};
+    mlp_gemm<1>(Hs, w1, wave, lane, acc);
+  }
+#pragma unroll
+  for (int nt = 0; nt < MNTW; nt++) {
+    const float b2 = p.bb[col0 + nt * 16 + j];
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = row0 + mt * 16 + 4 * q + r;
+        if (row < p.E) {
+          const size_t o = (size_t)row * MD + col0 + nt * 16 + j;
+          const float v = p.net_in[o] + h_round(acc[0][mt][nt][r] + b2);
+          p.net_out[o] = v;
+          if (p.out_t) Xs[(mt * 16 + 4 * q + r) * MXS + col0 + nt * 16 + j] = (_Float16)v;   // x is dead
+        }
+      }
+  }
+  if (p.out_t) {
+    __syncthreads();
+    for (int i = tid; i < MBM * (MD / 8); i += 64 * MWAVES) {
+      const int r = i / (MD / 8), c8 = i - r * (MD / 8);
+      if (row0 + r < p.E)
+        *reinterpret_cast<h8 *>(p.out_t + (size_t)(row0 + r) * MD + 8 * c8) =
+            *reinterpret_cast<const h8 *>(Xs + r * MXS + 8 * c8);
+    }
+  }
+}
+
 extern "C" {
 
 size_t ramp_upd_mlp_lds_bytes(void) { return (size_t)2 * MBM * MXS * 2 + MWAVES * MBM * 4; }
@@ -249,6 +327,27 @@ int ramp_upd_gru(const float *x32, const void *const *wp_host, const float *cons
     attr_set = true;
   }
   hipLaunchKernelGGL(upd_gru_kernel, dim3(ramp_cdiv(E, MBM)), dim3(64 * MWAVES), lds, (hipStream_t)stream, p);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+
+int ramp_upd_nbr(const float *net_in, const int64_t *idx, const void *wa, const float *ba, const void *wb,
+                 const float *bb, float *net_out, void *out_t, int E, void *stream) {
+  if (E < 0) return RAMP_EINVAL;
+  if (E == 0) return RAMP_OK;
+  if (!net_in || !idx || !wa || !ba || !wb || !bb || !net_out || net_in == net_out) return RAMP_EINVAL;
+  NbrParams p;
+  p.net_in = net_in; p.idx = idx; p.wa = (const _Float16 *)wa; p.wb = (const _Float16 *)wb; p.ba = ba; p.bb = bb;
+  p.net_out = net_out; p.out_t = (_Float16 *)out_t; p.E = E;
+  const size_t lds = ramp_upd_mlp_lds_bytes();
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void *)upd_nbr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+        hipSuccess)
+      return RAMP_ELAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(upd_nbr_kernel, dim3(ramp_cdiv(E, MBM)), dim3(64 * MWAVES), lds, (hipStream_t)stream, p);
   RAMP_CHECK_LAUNCH();
   return RAMP_OK;
 }

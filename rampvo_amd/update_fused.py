@@ -76,6 +76,9 @@ class FusedUpdate:
             bs = [l.bias.detach().half().float().contiguous() for l in gru]
             w["gru_pack"] = (wp, bs, (ctypes.c_void_p * 6)(*[t.data_ptr() for t in wp]),
                              (ctypes.c_void_p * 6)(*[t.data_ptr() for t in bs]))
+            hb = lambda l: l.bias.detach().half().float().contiguous()
+            w["c1_pack"] = (pack_linear_f16(m.c1[0].weight), hb(m.c1[0]), pack_linear_f16(m.c1[2].weight), hb(m.c1[2]))
+            w["c2_pack"] = (pack_linear_f16(m.c2[0].weight), hb(m.c2[0]), pack_linear_f16(m.c2[2].weight), hb(m.c2[2]))
         self._w, self._key = w, key
         return w
 
@@ -138,12 +141,27 @@ class FusedUpdate:
         c = self.lin(c, w["corr5"])
         net32, _ = self.row_fuse(E, A=net, B=inp_table, idxB=inp_idx, modB=inp_mod, C=c, ln=w["norm"], want_f32=True)
         # temporal neighbours (net.py:77-82); plan.ix_raw / jx_raw keep the -1 markers
+        if "c1_pack" in w and self.use_mlp:
+            # gather + 2 Linear + residual add per launch; ping-pong between two state buffers
+            tmp = torch.empty_like(net32)
+            net_t = torch.empty(E, 384, dtype=self.dtype, device=net32.device)
+            wa, ba, wb, bb = w["c1_pack"]
+            check(lib().ramp_upd_nbr(ptr(net32), ptr(plan.ix_raw), ptr(wa), ptr(ba), ptr(wb), ptr(bb), ptr(tmp), None,
+                                     E, stream()), "ramp_upd_nbr")
+            wa, ba, wb, bb = w["c2_pack"]
+            check(lib().ramp_upd_nbr(ptr(tmp), ptr(plan.jx_raw), ptr(wa), ptr(ba), ptr(wb), ptr(bb), ptr(net32),
+                                     ptr(net_t), E, stream()), "ramp_upd_nbr")
+            return self._tail(w, E, net32, net_t, plan)
         g = self.gather_mask(net32, plan.ix_raw, E)
         y = self.lin(self.lin_relu(g, w["c1a"]), w["c1b"])
         self.row_fuse(E, A=net32, B=y, out_f32=net32)
         g = self.gather_mask(net32, plan.jx_raw, E)
         y = self.lin(self.lin_relu(g, w["c2a"]), w["c2b"])
         _, net_t = self.row_fuse(E, A=net32, B=y, out_f32=net32, want_t=True)
+        return self._tail(w, E, net32, net_t, plan)
+
+    def _tail(self, w, E, net32, net_t, plan):
+        """SoftAgg x2 and the gru block, from the state after c1 / c2"""
         # SoftAgg over patches, then over (i, j) pairs (net.py:84-85)
         hy = self.lin(self.seg(self.lin(net_t, w["kk_fg"]), plan.g_kk, plan.max_kk), w["kk_h"])
         _, net_t = self.row_fuse(E, A=net32, B=hy, idxB32=plan.g_kk.gid, out_f32=net32, want_t=True)
