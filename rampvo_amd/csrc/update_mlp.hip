@@ -23,6 +23,7 @@
 #define MWAVES 8
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float h_round(float v) { return (float)(_Float16)v; }
@@ -61,31 +62,50 @@ __device__ __forceinline__ void mlp_gemm(const _Float16 *Xs, const _Float16 *con
   }
 }
 
-// sum over the 384 columns of each of the 64 rows of a value held in accumulator layout:
-// lane (q, j) holds rows 16 mt + 4 q + r, columns 48 wave + 16 nt + j.  Returns the row totals for
-// this lane's 16 (mt, r) rows.  Fixed order: nt, then the 16 lanes (xor butterfly), then waves 0..7.
-__device__ __forceinline__ void row_totals(const float (&part)[4][4], float *s_red, int wave, int lane,
-                                           float (&tot)[4][4]) {
-  const int q = lane >> 4, j = lane & 15;
-  __syncthreads();                                   // s_red is reused
+// Row-wise epilogues run in a second, ROW-MAJOR pass: the accumulator layout (lane (q, j): rows 4q..4q+3
+// of a 16-row tile, one column) would touch global memory in 64-byte pieces and needs cross-wave
+// reductions for a LayerNorm.  Instead the per-element product of the stage is parked in LDS as fp32
+// (32 rows at a time, in the dead h tile) and each wave then owns whole rows -- lane l holds channels
+// 2l + 128k + {0,1}: 512-byte contiguous global accesses and a wave-shuffle LayerNorm.
+#define MPR 32                  // rows per parking pass
+#define MPS (MD + 4)            // parking row stride (floats)
+
+__device__ __forceinline__ float wave_sum64(float v) {
 #pragma unroll
-  for (int mt = 0; mt < 4; mt++)
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// two-pass LayerNorm of a row held as v[3][2] per lane (same arithmetic as csrc/update.hip)
+__device__ __forceinline__ void row_ln(float (&v)[3][2], const float *__restrict__ w, const float *__restrict__ b,
+                                       float eps, int lane) {
+  float s = 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      float v = part[mt][r];
-      v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-      if (j == 0) s_red[wave * MBM + mt * 16 + 4 * q + r] = v;
-    }
-  __syncthreads();
+  for (int k = 0; k < 3; k++) s += v[k][0] + v[k][1];
+  const float mean = wave_sum64(s) * (1.0f / MD);
+  float q = 0.f;
 #pragma unroll
-  for (int mt = 0; mt < 4; mt++)
+  for (int k = 0; k < 3; k++) {
+    const float a = v[k][0] - mean, c = v[k][1] - mean;
+    q += a * a + c * c;
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum64(q) * (1.0f / MD) + eps);
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      float t = 0.f;
+  for (int k = 0; k < 3; k++) {
+    const int c = 2 * lane + 128 * k;
+    v[k][0] = (v[k][0] - mean) * rstd * w[c] + b[c];
+    v[k][1] = (v[k][1] - mean) * rstd * w[c + 1] + b[c + 1];
+  }
+}
+
+// park the two 16-row tiles (2 half, 2 half + 1) of a value in accumulator layout
+__device__ __forceinline__ void park_half(float *P, const float (&val)[4][MNTW][4], int half, int col0, int q, int j) {
 #pragma unroll
-      for (int w = 0; w < MWAVES; w++) t += s_red[w * MBM + mt * 16 + 4 * q + r];
-      tot[mt][r] = t;
-    }
+  for (int m = 0; m < 2; m++)
+#pragma unroll
+    for (int nt = 0; nt < MNTW; nt++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) P[(m * 16 + 4 * q + r) * MPS + col0 + nt * 16 + j] = val[2 * half + m][nt][r];
 }
 
 struct GruParams {
@@ -104,30 +124,31 @@ __global__ void __launch_bounds__(64 * MWAVES) upd_gru_kernel(const GruParams p)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   _Float16 *Xs = reinterpret_cast<_Float16 *>(smem_raw);            // [64][MXS]
   _Float16 *Hs = Xs + MBM * MXS;                                    // [64][MXS]
-  float *s_red = reinterpret_cast<float *>(Hs + MBM * MXS);         // [8][64]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
   const int row0 = blockIdx.x * MBM;
   const int col0 = wave * (16 * MNTW);
 
-  // ---- stage the input tile (fp32 -> fp16) and keep this lane's residual entries in fp32
-  for (int i = tid; i < MBM * (MD / 4); i += 64 * MWAVES) {
-    const int r = i / (MD / 4), c4 = i - r * (MD / 4);
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row0 + r < p.E) v = *reinterpret_cast<const float4 *>(p.x32 + (size_t)(row0 + r) * MD + 4 * c4);
-    _Float16 *d = Xs + r * MXS + 4 * c4;
-    d[0] = (_Float16)v.x; d[1] = (_Float16)v.y; d[2] = (_Float16)v.z; d[3] = (_Float16)v.w;
-  }
-  float xres[4][MNTW][4];
+  // ---- stage the input tile (fp32 -> fp16).  Wave w owns rows 4w..4w+3 of each 32-row half for the
+  // row-major passes and keeps them in fp32 (lane l: channels 2l + 128k + {0,1}): the residual stream is
+  // read from memory once and never parked
+  float xrow[2][MPR / MWAVES][3][2];
 #pragma unroll
-  for (int mt = 0; mt < 4; mt++)
+  for (int half = 0; half < 2; half++)
 #pragma unroll
-    for (int nt = 0; nt < MNTW; nt++)
+    for (int rr = 0; rr < MPR / MWAVES; rr++) {
+      const int rt = half * MPR + wave * (MPR / MWAVES) + rr;
+      const int row = row0 + rt;
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int row = row0 + mt * 16 + 4 * q + r;
-        xres[mt][nt][r] = row < p.E ? p.x32[(size_t)row * MD + col0 + nt * 16 + j] : 0.0f;
+      for (int k = 0; k < 3; k++) {
+        const int c = 2 * lane + 128 * k;
+        float2 v = make_float2(0.f, 0.f);
+        if (row < p.E) v = *reinterpret_cast<const float2 *>(p.x32 + (size_t)row * MD + c);
+        xrow[half][rr][k][0] = v.x; xrow[half][rr][k][1] = v.y;
+        *reinterpret_cast<h2 *>(Xs + rt * MXS + c) = (h2){(_Float16)v.x, (_Float16)v.y};
       }
+    }
   __syncthreads();
+  float *P = reinterpret_cast<float *>(Hs);              // parking tile, aliases h once h is dead
 
 #pragma unroll 1
   for (int stage = 0; stage < 2; stage++) {
@@ -154,71 +175,51 @@ __global__ void __launch_bounds__(64 * MWAVES) upd_gru_kernel(const GruParams p)
       const _Float16 *const w1[1] = {p.wp[wb + 2]};
       mlp_gemm<1>(Hs, w1, wave, lane, accr);
     }
-    // v = x + sigmoid(gate) * r     (gate and r are half tensors under the reference's autocast)
-    float v[4][MNTW][4];
+    // sigmoid(gate) * r     (gate and r are half tensors under the reference's autocast)
+    float pr[4][MNTW][4];
 #pragma unroll
     for (int nt = 0; nt < MNTW; nt++) {
       const float bg = p.bias[wb + 0][col0 + nt * 16 + j], b2 = p.bias[wb + 2][col0 + nt * 16 + j];
 #pragma unroll
       for (int mt = 0; mt < 4; mt++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const float g = h_round(acc2[0][mt][nt][r] + bg), rr = h_round(accr[0][mt][nt][r] + b2);
-          v[mt][nt][r] = xres[mt][nt][r] + sigm(g) * rr;
-        }
+        for (int r = 0; r < 4; r++)
+          pr[mt][nt][r] = sigm(h_round(acc2[0][mt][nt][r] + bg)) * h_round(accr[0][mt][nt][r] + b2);
     }
-    if (stage == 0) {
-      // gru[2]: LayerNorm over the row (two-pass, fp32), result = next stage's residual + fp16 input
-      float part[4][4], tot[4][4], mean[4][4];
+    __syncthreads();                                     // every wave is past its reads of h (and of x)
+    // row pass: residual += product; stage 0: LayerNorm -> next residual (registers) + fp16 x (LDS);
+    // stage 1: the result and its ReLU copy
 #pragma unroll
-      for (int mt = 0; mt < 4; mt++)
+    for (int half = 0; half < 2; half++) {
+      park_half(P, pr, half, col0, q, j);
+      __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 4; r++) part[mt][r] = (v[mt][0][r] + v[mt][1][r]) + v[mt][2][r];
-      row_totals(part, s_red, wave, lane, tot);
+      for (int rr = 0; rr < MPR / MWAVES; rr++) {      // 4 rows per wave
+        const int rl = wave * (MPR / MWAVES) + rr;        // row within the parking pass
+        const int rt = half * MPR + rl;                   // row within the tile
+        const int row = row0 + rt;
+        float (&v)[3][2] = xrow[half][rr];
 #pragma unroll
-      for (int mt = 0; mt < 4; mt++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          mean[mt][r] = tot[mt][r] * (1.0f / MD);
-          float s = 0.f;
-#pragma unroll
-          for (int nt = 0; nt < MNTW; nt++) { const float d = v[mt][nt][r] - mean[mt][r]; s += d * d; }
-          part[mt][r] = s;
+        for (int k = 0; k < 3; k++) {
+          const float2 pv = *reinterpret_cast<const float2 *>(P + rl * MPS + 2 * lane + 128 * k);
+          v[k][0] += pv.x; v[k][1] += pv.y;
         }
-      row_totals(part, s_red, wave, lane, tot);
+        if (stage == 0) {
+          row_ln(v, p.ln_w, p.ln_b, p.eps, lane);
 #pragma unroll
-      for (int nt = 0; nt < MNTW; nt++) {
-        const float lw = p.ln_w[col0 + nt * 16 + j], lb = p.ln_b[col0 + nt * 16 + j];
+          for (int k = 0; k < 3; k++)
+            *reinterpret_cast<h2 *>(Xs + rt * MXS + 2 * lane + 128 * k) = (h2){(_Float16)v[k][0], (_Float16)v[k][1]};
+        } else if (row < p.E) {
 #pragma unroll
-        for (int mt = 0; mt < 4; mt++)
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            const float rstd = 1.0f / sqrtf(tot[mt][r] * (1.0f / MD) + p.eps);
-            const float y = (v[mt][nt][r] - mean[mt][r]) * rstd * lw + lb;
-            xres[mt][nt][r] = y;
-            Xs[(mt * 16 + 4 * q + r) * MXS + col0 + nt * 16 + j] = (_Float16)y;    // every wave is past its X reads
+          for (int k = 0; k < 3; k++) {
+            const int c = 2 * lane + 128 * k;
+            *reinterpret_cast<float2 *>(p.out32 + (size_t)row * MD + c) = make_float2(v[k][0], v[k][1]);
+            *reinterpret_cast<h2 *>(p.relu_t + (size_t)row * MD + c) =
+                (h2){(_Float16)fmaxf(v[k][0], 0.f), (_Float16)fmaxf(v[k][1], 0.f)};
           }
+        }
       }
-      __syncthreads();
-    } else {
-      // result: fp32 state straight from the registers, ReLU copy through LDS for 16-byte stores
-#pragma unroll
-      for (int nt = 0; nt < MNTW; nt++)
-#pragma unroll
-        for (int mt = 0; mt < 4; mt++)
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            const int row = row0 + mt * 16 + 4 * q + r;
-            if (row < p.E) p.out32[(size_t)row * MD + col0 + nt * 16 + j] = v[mt][nt][r];
-            Xs[(mt * 16 + 4 * q + r) * MXS + col0 + nt * 16 + j] = (_Float16)fmaxf(v[mt][nt][r], 0.f);
-          }
-      __syncthreads();
-      for (int i = tid; i < MBM * (MD / 8); i += 64 * MWAVES) {
-        const int r = i / (MD / 8), c8 = i - r * (MD / 8);
-        if (row0 + r < p.E)
-          *reinterpret_cast<h8 *>(p.relu_t + (size_t)(row0 + r) * MD + 8 * c8) =
-              *reinterpret_cast<const h8 *>(Xs + r * MXS + 8 * c8);
-      }
+      __syncthreads();                                   // before the parking tile is overwritten / x is read
     }
   }
 }
@@ -274,36 +275,43 @@ __global__ void __launch_bounds__(64 * MWAVES) upd_nbr_kernel(const NbrParams p)
     const _Float16 *const w1[1] = {p.wb};
     mlp_gemm<1>(Hs, w1, wave, lane, acc);
   }
+  float y[4][MNTW][4];
 #pragma unroll
   for (int nt = 0; nt < MNTW; nt++) {
     const float b2 = p.bb[col0 + nt * 16 + j];
 #pragma unroll
     for (int mt = 0; mt < 4; mt++)
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int row = row0 + mt * 16 + 4 * q + r;
-        if (row < p.E) {
-          const size_t o = (size_t)row * MD + col0 + nt * 16 + j;
-          const float v = p.net_in[o] + h_round(acc[0][mt][nt][r] + b2);
-          p.net_out[o] = v;
-          if (p.out_t) Xs[(mt * 16 + 4 * q + r) * MXS + col0 + nt * 16 + j] = (_Float16)v;   // x is dead
-        }
-      }
+      for (int r = 0; r < 4; r++) y[mt][nt][r] = h_round(acc[0][mt][nt][r] + b2);
   }
-  if (p.out_t) {
+  __syncthreads();                                       // every wave is past its reads of h
+  float *P = reinterpret_cast<float *>(Hs);
+#pragma unroll
+  for (int half = 0; half < 2; half++) {
+    park_half(P, y, half, col0, q, j);
     __syncthreads();
-    for (int i = tid; i < MBM * (MD / 8); i += 64 * MWAVES) {
-      const int r = i / (MD / 8), c8 = i - r * (MD / 8);
-      if (row0 + r < p.E)
-        *reinterpret_cast<h8 *>(p.out_t + (size_t)(row0 + r) * MD + 8 * c8) =
-            *reinterpret_cast<const h8 *>(Xs + r * MXS + 8 * c8);
+#pragma unroll
+    for (int rr = 0; rr < MPR / MWAVES; rr++) {
+      const int rl = wave * (MPR / MWAVES) + rr;
+      const int row = row0 + half * MPR + rl;
+      if (row >= p.E) continue;
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const int c = 2 * lane + 128 * k;
+        const float2 x = *reinterpret_cast<const float2 *>(p.net_in + (size_t)row * MD + c);
+        const float2 pv = *reinterpret_cast<const float2 *>(P + rl * MPS + c);
+        const float v0 = x.x + pv.x, v1 = x.y + pv.y;
+        *reinterpret_cast<float2 *>(p.net_out + (size_t)row * MD + c) = make_float2(v0, v1);
+        if (p.out_t) *reinterpret_cast<h2 *>(p.out_t + (size_t)row * MD + c) = (h2){(_Float16)v0, (_Float16)v1};
+      }
     }
+    __syncthreads();
   }
 }
 
 extern "C" {
 
-size_t ramp_upd_mlp_lds_bytes(void) { return (size_t)2 * MBM * MXS * 2 + MWAVES * MBM * 4; }
+size_t ramp_upd_mlp_lds_bytes(void) { return (size_t)2 * MBM * MXS * 2; }
 
 int ramp_upd_gru(const float *x32, const void *const *wp_host, const float *const *bias_host, const float *ln_w,
                  const float *ln_b, float eps, float *out32, void *relu_t, int E, void *stream) {
