@@ -101,6 +101,15 @@ int ramp_corr_fwd_ordered(const void *fmap1, const ramp_corr_level *levels_host,
 int ramp_pyramid_pack(const void *fmap, void *level1, void *level4, int H, int W, int C, int dtype,
                       void *stream);
 
+/* Event list -> int8 bin stack, the encoder's event input (reference utils/transformers.py:128-161,
+ * EventToStack_Numpy; upstream a host-side np.add.at).  Event i goes to bin
+ * int32(float32(bins * i) / N); polarities p[i] (+-1) are accumulated per (bin, y, x) and the sum is cast to
+ * int8 (wraps).  Integer pixel coordinates only (the reference's uint16 path; its sub-pixel bilinear path is
+ * not provided).  out_i8 and/or out_f32 [bins][H][W]; ws: ramp_event_stack_workspace_bytes.          */
+size_t ramp_event_stack_workspace_bytes(int bins, int H, int W);
+int ramp_event_stack(const int32_t *x, const int32_t *y, const int8_t *p, int N, int bins, int H, int W,
+                     int8_t *out_i8, float *out_f32, void *ws, size_t ws_bytes, void *stream);
+
 /* Event-biased patch-centre selection: get_coords_from_topk_events + nms_image
  * (ramp/utils.py:186-226, 157-183; upstream ~20 ATen launches) for one frame.
  *   events [bins][H][W] float32 (W % 4 == 0); score = mean over bins of the 4x4 average of |events|,

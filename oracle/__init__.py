@@ -217,3 +217,20 @@ def segment_softmax_sum(fx, gx, group, G):
     y = np.empty((G, C), np.float32)
     lib().orc_segment_softmax_sum(_p(fx), _p(gx), _p(group), _p(y), E, G, C)
     return y
+
+
+def event_stack(x, y, p, height, width, num_bins):
+    """EventToStack_Numpy.__call__ for integer pixel coordinates (reference utils/transformers.py:128-161):
+    event i goes to bin int32(float32(num_bins * i) / N) -- by INDEX, not by time stamp --, the bin images
+    accumulate the polarities (+-1) and the float32 grid is cast to int8 (C cast: wraps modulo 256).
+    x, y integer arrays, p int8 (+-1).  -> int8 [num_bins, height, width]"""
+    x, y, p = np.asarray(x), np.asarray(y), np.asarray(p)
+    n = len(x)
+    grid = np.zeros((num_bins, height, width), np.float32)
+    if n < 2:
+        return grid.astype(np.int8)
+    b = (num_bins * np.arange(n, dtype=np.float32) / n).astype(np.int32)
+    xi, yi = x.astype(np.int64), y.astype(np.int64)
+    m = (xi >= 0) & (yi >= 0) & (xi < width) & (yi < height)
+    np.add.at(grid, (b[m], yi[m], xi[m]), p[m])
+    return grid.astype(np.int32).astype(np.int8)      # wrap, as numpy's float32 -> int8 cast does on x86

@@ -275,9 +275,29 @@ def gen_update_step(ns):
                         **out)
 
 
+def gen_event_stack(ns):
+    """the reference's EventToStack_Numpy (utils/transformers.py:128-161) on a seeded event list, including
+    one pixel hot enough to overflow int8"""
+    import importlib
+    tr = importlib.import_module("utils.transformers")
+    ev_mod = importlib.import_module("data.events")
+    rng = np.random.default_rng(77)
+    H, W, N, B = 48, 64, 30000, 5
+    x = rng.integers(0, W, N).astype(np.uint16)
+    y = rng.integers(0, H, N).astype(np.uint16)
+    pol = rng.integers(0, 2, N).astype(np.int8)
+    x[100:400], y[100:400], pol[100:400] = 7, 9, 1           # 300 positive events on one pixel of bin 0
+    events = ev_mod.Events(x=x.copy(), y=y.copy(), t=np.arange(N, dtype=np.int64), p=pol.copy(), width=W, height=H)
+    out = tr.EventToStack_Numpy(B)(events)
+    assert out.dtype == np.int8 and out.shape == (B, H, W)
+    np.savez_compressed(os.path.join(OUT, "event_stack.npz"), x=x, y=y, p=events.p, height=H, width=W, bins=B, out=out)
+    print("event_stack: hot pixel ->", out[0, 9, 7], " range", out.min(), out.max())
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = rh.load()
+    gen_event_stack(ns)
     gen_patchify(ns, "SingleScale")
     gen_patchify(ns, "MultiScale")
     gen_update(ns)

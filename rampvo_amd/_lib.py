@@ -36,6 +36,8 @@ SIGNATURES = {
     "ramp_corr_fwd": (c_i, [c_p, ctypes.POINTER(CorrLevel), c_i, c_p, c_p, c_p, c_p] + [c_i] * 8 + [c_p]),
     "ramp_ms_lstm_superstate": (c_i, [c_p, c_p, ctypes.POINTER(c_p), c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "ramp_conv2d_stats_blocks": (c_i, [c_i] * 7),
+    "ramp_event_stack_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
+    "ramp_event_stack": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_sz, c_p]),
     "ramp_event_topk_workspace_bytes": (c_sz, [c_i, c_i]),
     "ramp_event_topk": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_sz, c_p]),
     "ramp_pyramid_pack": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),

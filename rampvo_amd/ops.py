@@ -75,6 +75,24 @@ def corr(fmap1, fmaps2, coords, ii, jj, radius=3, coord_divs=(1.0,), layout=RAMP
     return out
 
 
+def event_stack(x, y, p, height, width, num_bins=5, as_float=True):
+    """EventToStack_Numpy on the device (reference utils/transformers.py:128-161): integer pixel
+    coordinates x, y [N] and polarities p [N] (int8, +-1; 0 is read as -1 like data/events.py:29) ->
+    the [num_bins, height, width] stack (float32 values of the int8 stack, or int8 with as_float=False)"""
+    require_cuda(x, y, p)
+    N = x.shape[0]
+    xi, yi = x.to(torch.int32).contiguous(), y.to(torch.int32).contiguous()
+    pi = p.to(torch.int8)
+    pi = torch.where(pi == 0, torch.full_like(pi, -1), pi).contiguous()
+    out = torch.empty((num_bins, height, width), dtype=torch.float32 if as_float else torch.int8, device=x.device)
+    nbytes = lib().ramp_event_stack_workspace_bytes(num_bins, height, width)
+    ws = _lib_workspace(nbytes, x.device, "evstack")
+    check(lib().ramp_event_stack(ptr(xi), ptr(yi), ptr(pi), N, num_bins, height, width,
+                                 None if as_float else ptr(out), ptr(out) if as_float else None, ptr(ws), nbytes,
+                                 stream()), "ramp_event_stack")
+    return out
+
+
 def event_topk(events, k, nms_kernel_size=11, want_indices=False):
     """patch centres of one frame: events [bins,H,W] float32 -> coords [k,2] float32 (x + y/h, y) at the
     top-k cells of the NMS'ed mean |event| map (reference utils.py:186-226), one score kernel + one NMS

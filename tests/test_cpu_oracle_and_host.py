@@ -113,6 +113,14 @@ def test_oracle_ba_crosscheck_with_reference_python_ba():
     assert np.array_equal(p, g["poses_oracle"]) and np.array_equal(pt, g["patches_oracle"])
 
 
+def test_oracle_event_stack_against_reference_golden():
+    """oracle.event_stack == the reference's EventToStack_Numpy output frozen by oracle/make_golden.py"""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "event_stack.npz"))
+    out = orc.event_stack(g["x"], g["y"], g["p"], int(g["height"]), int(g["width"]), int(g["bins"]))
+    assert out.dtype == np.int8 and np.array_equal(out, g["out"])
+    assert out[0, 9, 7] == 45          # 301 events on one pixel wrap to 45, as upstream
+
+
 def test_oracle_ba_properties():
     s = ba_scene(seed=5, n_frames=8, M=10, lifetime=4)
     p, pt = s["poses"].copy(), s["patches"].copy()

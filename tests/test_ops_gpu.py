@@ -459,3 +459,22 @@ def test_fused_gru_chain_matches_gemm_path():
     assert float((outs[False][0] - outs[True][0]).abs().max()) <= 4e-3 * scale      # fp16 GEMM inputs on both sides
     assert float((outs[False][1] - outs[True][1]).abs().max()) <= 4e-3 * scale
     assert torch.equal(outs[True][1], torch.relu(outs[True][0]).half().float())
+
+
+def test_event_stack_matches_reference_golden_and_oracle():
+    """ramp_event_stack against the reference's EventToStack_Numpy output (tests/golden/event_stack.npz,
+    incl. an int8 overflow) and against the oracle on a larger random list"""
+    import os
+    from rampvo_amd import ops
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "event_stack.npz"))
+    H, W, B = int(g["height"]), int(g["width"]), int(g["bins"])
+    out = ops.event_stack(cu(g["x"].astype(np.int32)), cu(g["y"].astype(np.int32)), cu(g["p"]), H, W, B, as_float=False)
+    assert np.array_equal(out.cpu().numpy(), g["out"])
+    rng = np.random.default_rng(5)
+    N, H, W = 300001, 480, 640
+    x, y = rng.integers(-2, W + 2, N).astype(np.int32), rng.integers(-2, H + 2, N).astype(np.int32)   # some outside
+    p = rng.integers(0, 2, N).astype(np.int8) * 2 - 1
+    ref = orc.event_stack(x, y, p, H, W, 5)
+    outf = ops.event_stack(cu(x), cu(y), cu(p), H, W, 5)
+    assert outf.dtype == torch.float32 and np.array_equal(outf.cpu().numpy(), ref.astype(np.float32))
+    assert float(ops.event_stack(cu(x[:1]), cu(y[:1]), cu(p[:1]), H, W, 5).abs().sum()) == 0.0     # < 2 events
