@@ -405,61 +405,56 @@ __global__ void __launch_bounds__(256)
 }
 
 // ------------------------------------------------------------------ K6
-// single workgroup, matrix in LDS (row stride n6+1), right-looking Cholesky
-// whose per-element update order (k ascending, separate mul/sub) equals the
-// textbook left-looking loop, then column-oriented forward/back substitution.
+// Single workgroup, matrix in LDS, right-looking Cholesky with ONE barrier per column:
+//   * the pivot d = A[j][j] is read by every thread (no broadcast step); the trailing update uses the
+//     UNSCALED column, A[i][k] -= A[i][j] A[k][j] / d, so it does not wait for a scaling pass;
+//   * the scaled column L[i][j] = A[i][j] / sqrt(d) goes to the unused upper triangle (A[j][i]) in the same
+//     phase -- which is also the layout the back substitution wants (row j of L');
+//   * the right-hand side rides along as row n6, so z = L^-1 y falls out of the factorisation
+//     (column n6 of the upper triangle) and there is no forward substitution;
+//   * 1/L[j][j] is kept per column: the back substitution multiplies, one barrier per step.
 __global__ void __launch_bounds__(1024)
     ba_chol_kernel(const float *__restrict__ S, const float *__restrict__ yv,
                    float *__restrict__ dX, int32_t *__restrict__ info, int n6) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int ld = n6 + 1;
-  float *A = sm;             // n6 x ld
-  float *t = sm + n6 * ld;   // n6
+  float *A = sm;                  // (n6 + 1) x ld: rows 0..n6-1 = S, row n6 = y
+  float *t = sm + (n6 + 1) * ld;  // n6: back-substitution vector
+  float *rd = t + n6;             // n6: 1 / L[j][j]
   const int tid = threadIdx.x, nt = blockDim.x;
+  const int ty = tid >> 5, tx = tid & 31, nty = nt >> 5;
   for (int q = tid; q < n6 * n6; q += nt) {
     const int r = q / n6, c = q - r * n6;
     A[r * ld + c] = S[q];
   }
-  for (int q = tid; q < n6; q += nt) t[q] = yv[q];
+  for (int q = tid; q < n6; q += nt) A[n6 * ld + q] = yv[q];
   __syncthreads();
+  bool bad = false;
   for (int j = 0; j < n6; j++) {
-    if (tid == 0) {
-      const float dgn = A[j * ld + j];
-      if (!(dgn > 0.0f) && info) *info = 1;
-      A[j * ld + j] = sqrtf(dgn);
-    }
-    __syncthreads();
-    const float ljj = A[j * ld + j];
-    for (int i = j + 1 + tid; i < n6; i += nt) A[i * ld + j] = A[i * ld + j] / ljj;
-    __syncthreads();
-    // trailing lower triangle: (i,k), j < k <= i < n6
-    const int m = n6 - j - 1;
-    for (int q = tid; q < m * m; q += nt) {
-      const int ri = q / m, ck = q - ri * m;
-      if (ck <= ri) {
-        const int i = j + 1 + ri, k = j + 1 + ck;
-        A[i * ld + k] = A[i * ld + k] - A[i * ld + j] * A[k * ld + j];
-      }
+    const float d = A[j * ld + j];
+    bad |= !(d > 0.0f);
+    const float rinv = 1.0f / sqrtf(d), dinv = 1.0f / d;
+    if (tid == 0) rd[j] = rinv;
+    // scaled column -> upper triangle (rows j+1..n6 of column j)
+    for (int i = j + 1 + tid; i <= n6; i += nt) A[j * ld + i] = A[i * ld + j] * rinv;
+    // trailing lower triangle incl. the rhs row: (i, k), j < k <= i <= n6, k < n6
+    for (int i = j + 1 + ty; i <= n6; i += nty) {
+      const float aij = A[i * ld + j] * dinv;
+      const int kmax = i < n6 ? i : n6 - 1;
+      for (int k = j + 1 + tx; k <= kmax; k += 32) A[i * ld + k] = A[i * ld + k] - aij * A[k * ld + j];
     }
     __syncthreads();
   }
-  // forward: L z = y
-  for (int k = 0; k < n6; k++) {
-    if (tid == 0) t[k] = t[k] / A[k * ld + k];
-    __syncthreads();
-    const float xk = t[k];
-    for (int i = k + 1 + tid; i < n6; i += nt) t[i] = t[i] - A[i * ld + k] * xk;
-    __syncthreads();
-  }
-  // backward: L' x = z
+  if (bad && tid == 0 && info) *info = 1;
+  // z = column n6 of the upper triangle;  L' x = z, column oriented; L[k][i] sits at A[i][k]
+  for (int q = tid; q < n6; q += nt) t[q] = A[q * ld + n6];
+  __syncthreads();
   for (int k = n6 - 1; k >= 0; k--) {
-    if (tid == 0) t[k] = t[k] / A[k * ld + k];
-    __syncthreads();
-    const float xk = t[k];
-    for (int i = tid; i < k; i += nt) t[i] = t[i] - A[k * ld + i] * xk;
+    const float xk = t[k] * rd[k];
+    if (tid == 0) dX[k] = xk;
+    for (int i = tid; i < k; i += nt) t[i] = t[i] - A[i * ld + k] * xk;
     __syncthreads();
   }
-  for (int q = tid; q < n6; q += nt) dX[q] = t[q];
 }
 
 // single-wavefront variant for 6N <= 63 (default.yaml: 60).  Lane i keeps ROW i of the matrix in 64
@@ -630,7 +625,7 @@ static int ba_iterate(float *poses, float *patches, const float *intrinsics, con
                       const int32_t *order_p, const int32_t *seg_p, const int32_t *np, int32_t *info,
                       hipStream_t st) {
   const int N = t1 - t0, n6 = 6 * N;
-  const size_t lds = (size_t)(n6 * (n6 + 1) + n6) * sizeof(float);
+  const size_t lds = (size_t)((n6 + 1) * (n6 + 1) + 2 * n6) * sizeof(float);
   const int PP = P * P, c11 = 1 * P + 1;
   if (N > 0 && n6 > 64 && lds > 64 * 1024) {
     if (hipFuncSetAttribute((const void *)ba_chol_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -669,7 +664,7 @@ static int ba_check_args(int E, int P, int n_poses, int n_patches, int t0, int t
   if (E < 0 || P < 2 || n_poses <= 0 || n_patches <= 0 || iterations < 0) return RAMP_EINVAL;
   if (t0 < 0 || t1 < t0 || t1 > n_poses) return RAMP_EINVAL;
   const int n6 = 6 * (t1 - t0);
-  if ((size_t)(n6 * (n6 + 1) + n6) * sizeof(float) > 160 * 1024) return RAMP_EUNSUPPORTED;  // > 32 free poses
+  if ((size_t)((n6 + 1) * (n6 + 1) + 2 * n6) * sizeof(float) > 160 * 1024) return RAMP_EUNSUPPORTED;  // > 32 free poses
   return RAMP_OK;
 }
 
