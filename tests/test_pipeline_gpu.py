@@ -56,3 +56,48 @@ def test_hip_library_is_the_code_that_ran():
     """the native library is loaded in this process (no silent fallback)"""
     maps = open("/proc/self/maps").read()
     assert "libramp_hip.so" in maps
+
+
+@torch.no_grad()
+def test_full_size_update_step_against_cpu_oracle():
+    """BASELINE.json configs[1] size (SingleScale 640x480, 96 patches, default.yaml windows, fp32): track the
+    synthetic stream on the GPU until the window holds > 20k edges, then run ONE update() twice from the
+    same snapshot -- HIP kernels vs the CPU oracle backend (torch-CPU encoder/GEMMs + oracle C natives)."""
+    from oracle.backend_cpu import cpu_oracle_ops
+    from rampvo_amd.config import make_cfg
+    from rampvo_amd.Ramp_vo import Ramp_vo
+    from rampvo_amd.synthetic import SyntheticStream, make_network
+    cfgk = dict(PATCHES_PER_FRAME=96, MIXED_PRECISION=False)
+    slam = Ramp_vo(make_cfg("default", **cfgk), make_network("SingleScale"), {"event_bias": True})
+    stream = SyntheticStream(480, 640, 40, seed=4321, device="cuda")
+    for t in range(34):
+        im, ev, K, mask = stream.frame(t)
+        slam(t, input_tensor=(ev, im, mask), intrinsics=K)
+    assert slam.is_initialized and len(slam._ii) > 20000
+    sd = slam.state_dict()
+    n, m = slam.n, slam.m
+    before = slam.poses_[:n].cpu().numpy().copy()
+    slam.update()
+    g_poses = slam.poses_[:n].cpu().numpy()
+    g_depth = slam.patches_[:n, :, 2, 1, 1].cpu().numpy()
+    g_net = slam.net[0].float().cpu().numpy()
+    g_w = slam.last_weight.cpu().numpy()
+    with cpu_oracle_ops():
+        ref = Ramp_vo(make_cfg("default", **cfgk), make_network("SingleScale", device="cpu"), {"event_bias": True},
+                      device="cpu")
+        ref.load_state_dict(sd)
+        ref.update()
+        r_poses = ref.poses_[:n].numpy()
+        r_depth = ref.patches_[:n, :, 2, 1, 1].numpy()
+        r_net = ref.net[0].float().numpy()
+        r_w = ref.last_weight.numpy()
+    assert np.array_equal(slam._ii, ref._ii) and np.array_equal(slam._kk, ref._kk)
+    step = float(np.abs(r_poses - before).max())
+    scale = max(1.0, step)
+    e = dict(E=len(slam._ii), step=step, net=float(np.abs(g_net - r_net).max() / np.abs(r_net).max()),
+             weight=float(np.abs(g_w - r_w).max()), poses=float(np.abs(g_poses - r_poses).max()),
+             depths=float((np.abs(g_depth - r_depth) / np.maximum(np.abs(r_depth), 1.0)).max()),
+             depth_range=(float(r_depth.min()), float(r_depth.max())))
+    print(e)
+    assert e["net"] <= 1e-4 and e["weight"] <= 1e-4, e
+    assert e["poses"] <= 1e-4 * scale and e["depths"] <= 1e-4 * scale, e
