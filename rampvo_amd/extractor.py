@@ -123,6 +123,27 @@ class MultiScaleBasicEncoder4(BasicEncoder4):
         return x.view(b, n, *x.shape[1:])
 
 
+def _two_towers(owner, fmap_fn, imap_fn):
+    """the two conv towers share only their input: the imap tower runs on a side HIP stream (fork / join
+    around it, also inside the front end's hipGraph capture), so its ~20 small launches fill the CUs the
+    fmap tower's leave idle.  RAMP_TOWER_STREAMS=0 keeps everything on one stream."""
+    import os
+    if os.environ.get("RAMP_TOWER_STREAMS", "1") != "1":
+        return fmap_fn(), imap_fn()
+    cur = torch.cuda.current_stream()
+    side = owner.__dict__.get("_side_stream")
+    if side is None or side.device != cur.device:
+        side = torch.cuda.Stream(device=cur.device)
+        object.__setattr__(owner, "_side_stream", side)
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        i = imap_fn()
+    f = fmap_fn()
+    cur.wait_stream(side)
+    i.record_stream(cur)
+    return f, i
+
+
 def _pixel_lstm(lstm, x2d, state):
     """one step of nn.LSTM (gate order i,f,g,o) for every pixel row of x2d [HW,Cin].
     state = (h, c) [HW,hid] or None (zeros)."""
@@ -177,8 +198,10 @@ class MergerLSTMsceneEncoder(nn.Module):
             st.fresh = True
         s16 = conv_hip.lstm_superstate_step(self, events[0, 0].float().contiguous(),
                                             images[0, 0].float().contiguous(), st)
-        f = conv_hip.basic_encoder4(self.fmap_encoder, s16, out_scale, half=self.mixed_precision)   # [h,w,128]
-        i = conv_hip.basic_encoder4(self.imap_encoder, s16, out_scale, half=self.mixed_precision)   # [h,w,384]
+        f, i = _two_towers(self, lambda: conv_hip.basic_encoder4(self.fmap_encoder, s16, out_scale,
+                                                                  half=self.mixed_precision),      # [h,w,128]
+                           lambda: conv_hip.basic_encoder4(self.imap_encoder, s16, out_scale,
+                                                           half=self.mixed_precision))             # [h,w,384]
         return f.permute(2, 0, 1)[None, None], i.permute(2, 0, 1)[None, None], None
 
     def forward(self, events, images, reinit_hidden=False, out_scale=1.0):
@@ -288,8 +311,10 @@ class MultiScaleMergerDoubleNet(nn.Module):
         if not present:
             return None, None
         half = self.mixed_precision
-        f = conv_hip.multiscale_encoder4(self.fmap_encoder, xs[0], xs[1], xs[2], out_scale, half=half)
-        i = conv_hip.multiscale_encoder4(self.imap_encoder, xs[0], xs[1], xs[2], out_scale, half=half)
+        f, i = _two_towers(self, lambda: conv_hip.multiscale_encoder4(self.fmap_encoder, xs[0], xs[1], xs[2],
+                                                                       out_scale, half=half),
+                           lambda: conv_hip.multiscale_encoder4(self.imap_encoder, xs[0], xs[1], xs[2],
+                                                                out_scale, half=half))
         return f.permute(2, 0, 1)[None, None], i.permute(2, 0, 1)[None, None]
 
     def forward(self, events, images, mask, reinit_hidden=False, out_scale=1.0):
