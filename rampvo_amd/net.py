@@ -140,6 +140,7 @@ class Patchifier(nn.Module):
         self._graphs = {}
         self._graph_warm = 0
         self._extra = None
+        self._sel_stream = None
 
     def _coord_grid(self, h, w, device):
         if self._grid is None or self._grid.shape[-2:] != (h, w) or self._grid.device != device:
@@ -187,6 +188,17 @@ class Patchifier(nn.Module):
     def _forward_impl(self, input_, patches_per_image=80, reinit_hidden=False, disps=None, event_bias=False,
                       gradient_bias=False):
         events, images, mask = input_
+        # patch selection only reads the events: on the GPU it runs on a side stream next to the encoder
+        early = None
+        if (event_bias and events.is_cuda and events.shape[1] == 1
+                and (self.input_mode == "SingleScale" or (mask is not None and bool(mask.all())))):
+            cur = torch.cuda.current_stream()
+            if self._sel_stream is None or self._sel_stream.device != cur.device:
+                self._sel_stream = torch.cuda.Stream(device=cur.device)
+            self._sel_stream.wait_stream(cur)
+            with torch.cuda.stream(self._sel_stream):
+                early = get_coords_from_topk_events(events=events, patches_per_image=patches_per_image,
+                                                    border_suppression_size=0, non_max_supp_rad=11)
         if self.input_mode == "SingleScale":
             fmap, imap, _ = self.encoder(events=events, images=images, reinit_hidden=reinit_hidden,
                                          out_scale=0.25)           # fmap / 4.0, imap / 4.0 folded in
@@ -199,7 +211,11 @@ class Patchifier(nn.Module):
         if mask is not None and not mask.any():
             return None, None, None, None, None, None
         b, n, c, h, w = fmap.shape
-        if event_bias:
+        if early is not None:
+            torch.cuda.current_stream().wait_stream(self._sel_stream)
+            early.record_stream(torch.cuda.current_stream())
+            coords = early
+        elif event_bias:
             coords = get_coords_from_topk_events(events=events, patches_per_image=patches_per_image,
                                                  border_suppression_size=0, non_max_supp_rad=11)
         else:
