@@ -345,11 +345,14 @@ int ramp_norm_add_relu(const float *y, const float *sy, const float *hy, const f
  * [E][384].  `dtype` is the GEMM I/O dtype T (RAMP_F16 under MIXED_PRECISION); the hidden state
  * is fp32 as under the reference's autocast.
  *
- * ramp_upd_row_fuse: t = A[e] + B[rowB(e)] + C[rowC(e)]; optional LayerNorm(ln_w, ln_b, eps)
+ * ramp_upd_row_fuse: t = A[rowA(e)] + B[rowB(e)] + C[rowC(e)]; optional LayerNorm(ln_w, ln_b, eps)
  *   (nn.LayerNorm(384, eps=1e-3), net.py:45,49-52,60) and ReLU; written as fp32 (out_f32) and/or
  *   T (out_t).  rowB(e) = idxB[e] (int64) or idxB32[e] or e, taken modulo modB when modB > 0
- *   (the `kk % (M*mem)` ring-buffer gather of Ramp_vo.py:282); rowC likewise.  A fp32, B/C of T. */
-int ramp_upd_row_fuse(const float *A, const void *B, const void *C, const int64_t *idxB,
+ *   (the `kk % (M*mem)` ring-buffer gather of Ramp_vo.py:282); rowC likewise.  rowA(e) = idxA[e] or e;
+ *   idxA[e] < 0 reads a zero row: the tracker keeps the hidden state of the PREVIOUS graph and maps
+ *   the current edges into it (removed edges drop out, new edges start at zero: Ramp_vo.py:204-205,
+ *   268-270) instead of compacting / growing the [E,384] state every frame.  A fp32, B/C of T. */
+int ramp_upd_row_fuse(const float *A, const int64_t *idxA, const void *B, const void *C, const int64_t *idxB,
                       const int32_t *idxB32, long modB, const int64_t *idxC, const int32_t *idxC32,
                       const float *ln_w, const float *ln_b, float eps, int relu, float *out_f32,
                       void *out_t, int E, int dtype, void *stream);

@@ -85,6 +85,9 @@ class Ramp_vo:
             self.fmap2_ = torch.zeros(self.mem, h // 4, w // 4, 128, **kwargs)
         self.pyramid = (self.fmap1_, self.fmap2_)
 
+        self._lazy_net = dev.type == "cuda"      # GPU: the [E,384] state is re-indexed, not copied, when the graph changes
+        self._net_map = None                     # host int64 [E]: row of _net_buf per current edge (-1: zeros)
+        self._net_map_dev = None
         self.net = torch.zeros(1, 0, DIM, dtype=torch.float, device=dev)   # hidden state is fp32 (as under autocast)
         self.ii = torch.zeros(0, dtype=torch.long, device=dev)
         self.jj = torch.zeros(0, dtype=torch.long, device=dev)
@@ -144,6 +147,26 @@ class Ramp_vo:
     def gmap(self):
         """reference shape [1, mem*M, 128, 3, 3] (a channels-last view)"""
         return self.gmap_.view(1, self.mem * self.M, 3, 3, 128).permute(0, 1, 4, 2, 3)
+
+    # --------------------------------------------------------------- hidden state
+    # Reference: ``self.net`` [1,E,384] is compacted on every factor removal (:203-208) and grown with zero
+    # rows on every append (:194-201) -- two full copies of a 60 MB tensor per frame.  On the GPU the tensor
+    # of the PREVIOUS update is kept as is and a host-side row map follows the graph edits; the update
+    # operator's first row kernel gathers through the map.  Reading ``self.net`` materialises it.
+    @property
+    def net(self):
+        if self._net_map is not None:
+            m = torch.from_numpy(self._net_map).to(self._net_buf.device)
+            rows = self._net_buf[:, m.clamp(min=0)] * (m >= 0).to(self._net_buf.dtype)[None, :, None]
+            self._net_buf, self._net_map, self._net_map_dev = rows, None, None
+        return self._net_buf
+
+    @net.setter
+    def net(self, value):
+        self._net_buf, self._net_map, self._net_map_dev = value, None, None
+
+    def _net_rows(self):
+        return self._net_map if self._net_map is not None else np.arange(self._net_buf.shape[1], dtype=np.int64)
 
     # ----------------------------------------------------------------- snapshot
     def state_dict(self):
@@ -249,13 +272,17 @@ class Ramp_vo:
         jj = np.concatenate([jf.reshape(-1), jb.reshape(-1)]).astype(np.int64)
         ii = kk // M
         dev = self._upload(np.stack([ii, jj, kk]))            # one copy for the three arrays
-        return (n1, ii, jj, kk, dev)
+        map_dev = None
+        if self._lazy_net:                                    # the state row map as it will be after the append
+            map_dev = self._upload(np.concatenate([self._net_rows(), np.full(len(kk), -1, np.int64)]))
+        return (n1, ii, jj, kk, dev, map_dev)
 
     def append_factors(self, ii, jj, pre=None):
         """ii: patch indices, jj: frame indices (host arrays) -- reference :194-201.  ``pre``: the same
         edges already uploaded by _prefetch_edges"""
+        map_dev = None
         if pre is not None:
-            _, src, jj, ii, dev = pre
+            _, src, jj, ii, dev, map_dev = pre
             d_ii, d_jj, d_kk = dev[0], dev[1], dev[2]
         else:
             ii = np.asarray(ii, np.int64)
@@ -268,8 +295,12 @@ class Ramp_vo:
         self.jj = torch.cat([self.jj, d_jj])
         self.kk = torch.cat([self.kk, d_kk])
         self.ii = torch.cat([self.ii, d_ii])
-        net = torch.zeros(1, len(ii), self.DIM, dtype=torch.float, device=self.device)
-        self.net = torch.cat([self.net, net], dim=1)
+        if self._lazy_net:
+            self._net_map = np.concatenate([self._net_rows(), np.full(len(ii), -1, np.int64)])
+            self._net_map_dev = map_dev if (map_dev is not None and map_dev.shape[0] == len(self._net_map)) else None
+        else:
+            net = torch.zeros(1, len(ii), self.DIM, dtype=torch.float, device=self.device)
+            self.net = torch.cat([self.net, net], dim=1)
         self._plan = None
 
     def remove_factors(self, m):
@@ -281,7 +312,10 @@ class Ramp_vo:
         self._ii, self._jj, self._kk = self._ii[keep], self._jj[keep], self._kk[keep]
         kd = self._upload(keep)
         self.ii, self.jj, self.kk = self.ii[kd], self.jj[kd], self.kk[kd]
-        self.net = self.net[:, kd]
+        if self._lazy_net:
+            self._net_map, self._net_map_dev = self._net_rows()[keep], None
+        else:
+            self.net = self.net[:, kd]
         self._plan = None
 
     def _graph_plan(self):
@@ -393,7 +427,9 @@ class Ramp_vo:
         idx = np.nonzero(keep)[0]
         self._ii, self._jj, self._kk = ii[idx], jj[idx], kk[idx]
         self.ii, self.jj, self.kk = self._upload(self._ii), self._upload(self._jj), self._upload(self._kk)
-        if len(idx) != self.net.shape[1]:
+        if self._lazy_net:
+            self._net_map, self._net_map_dev = self._net_rows()[idx], None
+        elif len(idx) != self.net.shape[1]:
             self.net = self.net[:, self._upload(idx)]
         self._plan = None
 
@@ -408,8 +444,11 @@ class Ramp_vo:
                 # GEMMs + row-fused glue (csrc/update.hip); the context gather, the heads' activations,
                 # `target = centre + delta` and filter_features are folded into those kernels
                 fu = self.network.update.fused(self.dtype)
-                out32, relu_t = fu.hidden(self.net[0], self.imap_.view(-1, self.DIM), self.kk, self.M * self.mem,
-                                          corr[0], plan)
+                net_map = None
+                if self._net_map is not None:
+                    net_map = self._net_map_dev if self._net_map_dev is not None else self._upload(self._net_map)
+                out32, relu_t = fu.hidden(self._net_buf[0], self.imap_.view(-1, self.DIM), self.kk, self.M * self.mem,
+                                          corr[0], plan, net_map=net_map)
                 self.net = out32[None]
                 target, weight, _ = fu.target_weight(fu.heads(relu_t), coords[0], self.wd // 4, self.ht // 4)
             else:

@@ -64,7 +64,8 @@ __device__ __forceinline__ void row_layernorm(float v[3][2], const float *__rest
 }
 
 struct RowFuseParams {
-  const float *A;            // [E][384] fp32 or null
+  const float *A;            // [*][384] fp32 or null
+  const int64_t *idxA;       // optional row of A per edge; < 0: a zero row (an edge new in this update)
   const void *B, *C;         // [*][384] T or null
   const int64_t *idxB, *idxC;   // optional int64 row index (null: row e)
   const int32_t *idxB32, *idxC32;  // optional int32 row index
@@ -86,10 +87,13 @@ __global__ void __launch_bounds__(256) upd_row_fuse_kernel(const RowFuseParams p
 #pragma unroll
   for (int k = 0; k < 3; k++) { v[k][0] = 0.f; v[k][1] = 0.f; }
   if (p.A) {
+    const long ra = p.idxA ? p.idxA[e] : (long)e;
+    if (ra >= 0) {
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-      const float2 a = *reinterpret_cast<const float2 *>(p.A + (size_t)e * UD + 2 * lane + 128 * k);
-      v[k][0] = a.x; v[k][1] = a.y;
+      for (int k = 0; k < 3; k++) {
+        const float2 a = *reinterpret_cast<const float2 *>(p.A + (size_t)ra * UD + 2 * lane + 128 * k);
+        v[k][0] = a.x; v[k][1] = a.y;
+      }
     }
   }
   if (p.B) {
@@ -245,7 +249,7 @@ __global__ void __launch_bounds__(192)
 
 extern "C" {
 
-int ramp_upd_row_fuse(const float *A, const void *B, const void *C, const int64_t *idxB,
+int ramp_upd_row_fuse(const float *A, const int64_t *idxA, const void *B, const void *C, const int64_t *idxB,
                       const int32_t *idxB32, long modB, const int64_t *idxC, const int32_t *idxC32,
                       const float *ln_w, const float *ln_b, float eps, int relu, float *out_f32,
                       void *out_t, int E, int dtype, void *stream) {
@@ -253,7 +257,7 @@ int ramp_upd_row_fuse(const float *A, const void *B, const void *C, const int64_
   if (E == 0) return RAMP_OK;
   if ((!A && !B && !C) || (!out_f32 && !out_t) || ((ln_w == nullptr) != (ln_b == nullptr))) return RAMP_EINVAL;
   RowFuseParams p;
-  p.A = A; p.B = B; p.C = C; p.idxB = idxB; p.idxC = idxC; p.idxB32 = idxB32; p.idxC32 = idxC32;
+  p.A = A; p.idxA = idxA; p.B = B; p.C = C; p.idxB = idxB; p.idxC = idxC; p.idxB32 = idxB32; p.idxC32 = idxC32;
   p.modB = modB; p.ln_w = ln_w; p.ln_b = ln_b; p.eps = eps; p.relu = relu;
   p.out_f32 = out_f32; p.out_t = out_t; p.E = E;
   const dim3 grid(ramp_cdiv(E, 4)), block(256);

@@ -95,12 +95,13 @@ class FusedUpdate:
         return F.relu_(F.linear(x, wb[0], wb[1]))
 
     def row_fuse(self, E, A=None, B=None, C=None, idxB=None, idxB32=None, modB=0, idxC32=None, ln=None, relu=False,
-                 want_f32=False, want_t=False, out_f32=None):
+                 want_f32=False, want_t=False, out_f32=None, idxA=None):
         dev = (A if A is not None else B).device
         if want_f32 and out_f32 is None:
             out_f32 = torch.empty(E, 384, dtype=torch.float32, device=dev)
         out_t = torch.empty(E, 384, dtype=self.dtype, device=dev) if want_t else None
-        check(lib().ramp_upd_row_fuse(ptr(A), ptr(B), ptr(C), ptr(idxB), ptr(idxB32), int(modB), None, ptr(idxC32),
+        check(lib().ramp_upd_row_fuse(ptr(A), ptr(idxA), ptr(B), ptr(C), ptr(idxB), ptr(idxB32), int(modB), None,
+                                      ptr(idxC32),
                                       ptr(ln[0]) if ln else None, ptr(ln[1]) if ln else None,
                                       float(ln[2]) if ln else 0.0, int(relu), ptr(out_f32), ptr(out_t), E,
                                       _code[self.dtype], stream()), "ramp_upd_row_fuse")
@@ -130,16 +131,18 @@ class FusedUpdate:
         return y
 
     # ------------------------------------------------------------------ forward
-    def hidden(self, net, inp_table, inp_idx, inp_mod, corr, plan):
-        """net [E,384] fp32 or None (zeros); inp = inp_table[inp_idx % inp_mod] (or inp_table rows when
-        inp_idx is None); corr [E,882] in self.dtype.  Returns (net_out fp32 [E,384], relu copy T)."""
+    def hidden(self, net, inp_table, inp_idx, inp_mod, corr, plan, net_map=None):
+        """net [*,384] fp32 or None (zeros), row net_map[e] of it per edge when net_map is given (-1: zero
+        row); inp = inp_table[inp_idx % inp_mod] (or inp_table rows when inp_idx is None); corr [E,882] in
+        self.dtype.  Returns (net_out fp32 [E,384], relu copy T)."""
         w = self.weights()
         E = corr.shape[0]
         c = self.lin_relu(corr, w["corr0"])
         c = self.lin(c, w["corr2"])
         _, c = self.row_fuse(E, B=c, ln=w["corr_ln"], relu=True, want_t=True)
         c = self.lin(c, w["corr5"])
-        net32, _ = self.row_fuse(E, A=net, B=inp_table, idxB=inp_idx, modB=inp_mod, C=c, ln=w["norm"], want_f32=True)
+        net32, _ = self.row_fuse(E, A=net, idxA=net_map, B=inp_table, idxB=inp_idx, modB=inp_mod, C=c, ln=w["norm"],
+                                 want_f32=True)
         # temporal neighbours (net.py:77-82); plan.ix_raw / jx_raw keep the -1 markers
         if "c1_pack" in w and self.use_mlp:
             # gather + 2 Linear + residual add per launch; ping-pong between two state buffers
