@@ -88,6 +88,9 @@ class Ramp_vo:
         self._lazy_net = dev.type == "cuda"      # GPU: the [E,384] state is re-indexed, not copied, when the graph changes
         self._net_map = None                     # host int64 [E]: row of _net_buf per current edge (-1: zeros)
         self._net_map_dev = None
+        self._pre_cache = None                   # (n1, ii, jj, kk, dev, map_dev, E_base): next frame's edges, uploaded early
+        self._up_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        self._mm_host = torch.empty(1, dtype=torch.float32).pin_memory() if dev.type == "cuda" else None
         self.net = torch.zeros(1, 0, DIM, dtype=torch.float, device=dev)   # hidden state is fp32 (as under autocast)
         self.ii = torch.zeros(0, dtype=torch.long, device=dev)
         self.jj = torch.zeros(0, dtype=torch.long, device=dev)
@@ -261,16 +264,26 @@ class Ramp_vo:
         (nearly) empty: at the top of a frame (_prefetch_edges) and right after keyframe()'s read-back."""
         return torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
 
-    def _prefetch_edges(self):
-        """the factors this frame will add if it is accepted (reference :312-325, :394-395) depend only on
-        (n, M, lifetime): build and upload them BEFORE the encoder is enqueued, while the GPU is idle."""
-        n1 = self.n + 1                       # value of self.n when the edges are generated
+    def _new_edges(self, n1):
+        """the factors frame n1-1 adds when it is accepted (reference :312-325, :394-395); host arrays"""
         r, M = self.cfg.PATCH_LIFETIME, self.M
         kf, jf = np.meshgrid(np.arange(M * max(n1 - r, 0), M * max(n1 - 1, 0)), np.arange(n1 - 1, n1), indexing='ij')
         kb, jb = np.meshgrid(np.arange(M * max(n1 - 1, 0), M * n1), np.arange(max(n1 - r, 0), n1), indexing='ij')
         kk = np.concatenate([kf.reshape(-1), kb.reshape(-1)]).astype(np.int64)
         jj = np.concatenate([jf.reshape(-1), jb.reshape(-1)]).astype(np.int64)
-        ii = kk // M
+        return kk // M, jj, kk
+
+    def _prefetch_edges(self):
+        """the factors this frame will add if it is accepted depend only on (n, M, lifetime): build and
+        upload them BEFORE the encoder is enqueued, while the GPU is idle -- or take the copy the
+        speculative keyframe() of the previous frame already made."""
+        n1 = self.n + 1                       # value of self.n when the edges are generated
+        pre = self._pre_cache
+        self._pre_cache = None
+        if pre is not None and pre[0] == n1 and pre[6] == len(self._ii):
+            torch.cuda.current_stream().wait_stream(self._up_stream)
+            return pre[:6]
+        ii, jj, kk = self._new_edges(n1)
         dev = self._upload(np.stack([ii, jj, kk]))            # one copy for the three arrays
         map_dev = None
         if self._lazy_net:                                    # the state row map as it will be after the append
@@ -385,52 +398,123 @@ class Ramp_vo:
             mags.append(flow.mean())
         return float(((mags[0] + mags[1]) / 2).item())
 
-    def keyframe(self):
-        """drop keyframe n-KEYFRAME_INDEX if the motion around it is small, then cull factors older
-        than REMOVAL_WINDOW (reference :237-274).  Both removals are decided on the host mirror and
-        applied to the device state as ONE compaction."""
-        i = self.n - self.cfg.KEYFRAME_INDEX - 1
-        j = self.n - self.cfg.KEYFRAME_INDEX + 1
-        m = self._motionmag_pair(i, j)
-        keep = np.ones(len(self._ii), bool)
+    def _graph_edit(self, remove_kf):
+        """host-side result of keyframe() for one outcome of the motion test (reference :247-274): the
+        graph after dropping keyframe n-KEYFRAME_INDEX (if remove_kf) and culling factors older than
+        REMOVAL_WINDOW.  Pure function of the host mirror."""
         ii, jj, kk = self._ii, self._jj, self._kk
-        if m < self.cfg.KEYFRAME_THRESH:
+        keep = np.ones(len(ii), bool)
+        n = self.n
+        if remove_kf:
             k = self.n - self.cfg.KEYFRAME_INDEX
-            t0, t1 = self._tstamps[k - 1], self._tstamps[k]
-            dP = SE3(self.poses_[k]) * SE3(self.poses_[k - 1]).inv()
-            self.delta[t1] = (t0, dP)
             keep &= ~((ii == k) | (jj == k))
             ii, jj, kk = ii.copy(), jj.copy(), kk.copy()
             kk[ii > k] -= self.M
             ii[ii > k] -= 1
             jj[jj > k] -= 1
-            # shift the per-frame state down by one row (reference: python loop of row copies)
-            n = self.n
-            del self._tstamps[k]
-            if self.device.type == "cuda" and (self.M * 3) % 4 == 0:
-                ops.shift_rows([(self.tstamps_, 0), (self.colors_, 0), (self.poses_, 0), (self.patches_, 0),
-                                (self.intrinsics_, 0), (self.imap_, self.mem), (self.gmap_, self.mem),
-                                (self.fmap1_, self.mem), (self.fmap2_, self.mem)], k, n)     # one launch
-            else:
-                for buf in (self.tstamps_, self.colors_, self.poses_, self.patches_, self.intrinsics_):
-                    buf[k:n - 1] = buf[k + 1:n].clone()
-                dst = torch.arange(k, n - 1, device=self.device) % self.mem
-                src = torch.arange(k + 1, n, device=self.device) % self.mem
-                for buf in (self.imap_, self.gmap_, self.fmap1_, self.fmap2_):
-                    buf[dst] = buf[src]
-            self.n -= 1
-            self.m -= self.M
-        keep &= ~((kk // self.M) < self.n - self.cfg.REMOVAL_WINDOW)
-        changed = (ii is not self._ii) or not keep.all()
-        if not changed:
+            n -= 1
+        keep &= ~((kk // self.M) < n - self.cfg.REMOVAL_WINDOW)
+        changed = remove_kf or not keep.all()
+        idx = np.nonzero(keep)[0] if changed else None
+        if changed:
+            ii, jj, kk = ii[idx], jj[idx], kk[idx]
+        return dict(changed=changed, ii=ii, jj=jj, kk=kk, idx=idx, n=n)
+
+    def _apply_removal(self, k):
+        """device side of dropping keyframe k: shift the per-frame state down by one row"""
+        n = self.n
+        del self._tstamps[k]
+        if self.device.type == "cuda" and (self.M * 3) % 4 == 0:
+            ops.shift_rows([(self.tstamps_, 0), (self.colors_, 0), (self.poses_, 0), (self.patches_, 0),
+                            (self.intrinsics_, 0), (self.imap_, self.mem), (self.gmap_, self.mem),
+                            (self.fmap1_, self.mem), (self.fmap2_, self.mem)], k, n)     # one launch
+        else:
+            for buf in (self.tstamps_, self.colors_, self.poses_, self.patches_, self.intrinsics_):
+                buf[k:n - 1] = buf[k + 1:n].clone()
+            dst = torch.arange(k, n - 1, device=self.device) % self.mem
+            src = torch.arange(k + 1, n, device=self.device) % self.mem
+            for buf in (self.imap_, self.gmap_, self.fmap1_, self.fmap2_):
+                buf[dst] = buf[src]
+        self.n -= 1
+        self.m -= self.M
+
+    def keyframe(self):
+        """drop keyframe n-KEYFRAME_INDEX if the motion around it is small, then cull factors older
+        than REMOVAL_WINDOW (reference :237-274).  Both removals are decided on the host mirror and
+        applied to the device state as ONE compaction."""
+        if self.device.type == "cuda" and self._lazy_net:
+            return self._keyframe_speculative()
+        i = self.n - self.cfg.KEYFRAME_INDEX - 1
+        j = self.n - self.cfg.KEYFRAME_INDEX + 1
+        m = self._motionmag_pair(i, j)
+        remove = m < self.cfg.KEYFRAME_THRESH
+        if remove:
+            k = self.n - self.cfg.KEYFRAME_INDEX
+            t0, t1 = self._tstamps[k - 1], self._tstamps[k]
+            dP = SE3(self.poses_[k]) * SE3(self.poses_[k - 1]).inv()
+            self.delta[t1] = (t0, dP)
+        ed = self._graph_edit(remove)
+        if remove:
+            self._apply_removal(self.n - self.cfg.KEYFRAME_INDEX)
+        if not ed["changed"]:
             return
-        idx = np.nonzero(keep)[0]
-        self._ii, self._jj, self._kk = ii[idx], jj[idx], kk[idx]
+        idx = ed["idx"]
+        self._ii, self._jj, self._kk = ed["ii"], ed["jj"], ed["kk"]
         self.ii, self.jj, self.kk = self._upload(self._ii), self._upload(self._jj), self._upload(self._kk)
         if self._lazy_net:
             self._net_map, self._net_map_dev = self._net_rows()[idx], None
         elif len(idx) != self.net.shape[1]:
             self.net = self.net[:, self._upload(idx)]
+        self._plan = None
+
+    def _keyframe_speculative(self):
+        """GPU: the motion test is the frame's only device->host read, and at that point the GPU still has
+        most of update() queued.  While it drains, the host prepares BOTH outcomes -- edited graph, hidden-
+        state row map, the next frame's new edges -- and uploads them on a side stream; after the read-back
+        it only picks one.  (Doing this work after the read-back left the GPU idle for ~0.4 ms per frame.)"""
+        cfg = self.cfg
+        i, j = self.n - cfg.KEYFRAME_INDEX - 1, self.n - cfg.KEYFRAME_INDEX + 1
+        k = self.n - cfg.KEYFRAME_INDEX
+        plan = self._graph_plan()
+        mm = ops.motionmag(self.poses, self.patches, self.intrinsics, self.ii, self.jj, self.kk, plan.g_ij,
+                           j * plan.pair_mul + i, i * plan.pair_mul + j, beta=0.5)   # keys are jj*mul+ii
+        self._mm_host.copy_(mm.mean().reshape(1), non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+        dP = SE3(self.poses_[k]) * SE3(self.poses_[k - 1]).inv()      # only used if the keyframe goes
+        base_rows = self._net_rows()
+        spec = {}
+        with torch.cuda.stream(self._up_stream):
+            for remove in (True, False):
+                ed = self._graph_edit(remove)
+                rows = base_rows[ed["idx"]] if ed["changed"] else base_rows
+                g_dev = None
+                if ed["changed"]:
+                    g_dev = self._upload(np.stack([ed["ii"], ed["jj"], ed["kk"]]))
+                # the edges the next frame adds, and the row map after that append
+                n1 = ed["n"] + 1
+                e_ii, e_jj, e_kk = self._new_edges(n1)
+                e_dev = self._upload(np.stack([e_ii, e_jj, e_kk]))
+                m_dev = self._upload(np.concatenate([rows, np.full(len(e_kk), -1, np.int64)]))
+                spec[remove] = (ed, rows, g_dev, (n1, e_ii, e_jj, e_kk, e_dev, m_dev, len(ed["ii"])))
+        done.synchronize()
+        remove = float(self._mm_host[0]) < cfg.KEYFRAME_THRESH
+        ed, rows, g_dev, pre = spec[remove]
+        cur = torch.cuda.current_stream()
+        cur.wait_stream(self._up_stream)
+        for t in (g_dev, pre[4], pre[5]):          # allocated on the side stream, consumed on this one
+            if t is not None:
+                t.record_stream(cur)
+        if remove:
+            t0, t1 = self._tstamps[k - 1], self._tstamps[k]
+            self.delta[t1] = (t0, dP)
+            self._apply_removal(k)
+        self._pre_cache = pre
+        if not ed["changed"]:
+            return
+        self._ii, self._jj, self._kk = ed["ii"], ed["jj"], ed["kk"]
+        self.ii, self.jj, self.kk = g_dev[0], g_dev[1], g_dev[2]
+        self._net_map, self._net_map_dev = rows, None
         self._plan = None
 
     # ------------------------------------------------------------------- update
