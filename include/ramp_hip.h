@@ -373,6 +373,13 @@ int ramp_upd_heads(const void *hw, const float *coords, float *target, float *we
 int ramp_upd_segment_softmax(const void *fg, const int32_t *order, const int32_t *seg_start,
                              const int32_t *ngroups, void *y, int max_groups, int dtype, void *stream);
 
+/* HOST helper (pointers are host memory, nothing is launched): the factor-graph edit of
+ * Ramp_vo.keyframe() (ramp/Ramp_vo.py:247-274 + remove_factors :203-208) for one outcome of the motion
+ * test, one pass over the host mirror.  k_remove < 0: no keyframe is dropped.  out [4][cap] int64 =
+ * (ii, jj, kk, hidden-state row) of the factors kept; rows_in NULL = identity.  Returns their number.  */
+int ramp_graph_edit_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, const int64_t *rows_in, int E,
+                         int M, int k_remove, int n_after, int removal_window, int64_t *out, int cap);
+
 /* ------------------------------------------------ fused update-operator GEMM chains (fp16) */
 /* gru[1..3] of the update operator (ramp/net.py:49-54; GatedResidual: ramp/blocks.py:15-31) as ONE
  * launch: x -> x + sigmoid(Wg x) * W2 relu(W1 x) -> LayerNorm -> the same again, 6 Linear layers with the

@@ -26,6 +26,7 @@ import torch.nn.functional as F
 
 from . import altcorr, fastba, lietorch, ops
 from . import projective_ops as pops
+from . import _lib
 from ._lib import RAMP_NHWC, RAMP_NHWC8
 from .lietorch import SE3
 from .net import GraphPlan, VONet
@@ -482,29 +483,42 @@ class Ramp_vo:
         done = torch.cuda.Event()
         done.record()
         dP = SE3(self.poses_[k]) * SE3(self.poses_[k - 1]).inv()      # only used if the keyframe goes
-        base_rows = self._net_rows()
+        base_rows = self._net_map            # None: identity
+        E, M = len(self._ii), self.M
         spec = {}
         with torch.cuda.stream(self._up_stream):
             for remove in (True, False):
-                ed = self._graph_edit(remove)
-                rows = base_rows[ed["idx"]] if ed["changed"] else base_rows
-                g_dev = None
-                if ed["changed"]:
-                    g_dev = self._upload(np.stack([ed["ii"], ed["jj"], ed["kk"]]))
-                # the edges the next frame adds, and the row map after that append
-                n1 = ed["n"] + 1
+                n_after = self.n - 1 if remove else self.n
+                n1 = n_after + 1
                 e_ii, e_jj, e_kk = self._new_edges(n1)
-                e_dev = self._upload(np.stack([e_ii, e_jj, e_kk]))
-                m_dev = self._upload(np.concatenate([rows, np.full(len(e_kk), -1, np.int64)]))
-                spec[remove] = (ed, rows, g_dev, (n1, e_ii, e_jj, e_kk, e_dev, m_dev, len(ed["ii"])))
+                ne = len(e_kk)
+                # ONE host buffer / one upload per outcome: [ii | jj | kk | rows] of the edited graph (stride
+                # E), then the next frame's new edges [ii | jj | kk], then the row map after that append
+                buf = np.empty(4 * E + 3 * ne + (E + ne), np.int64)
+                Ek = _lib.lib().ramp_graph_edit_host(
+                    self._ii.ctypes.data, self._jj.ctypes.data, self._kk.ctypes.data,
+                    base_rows.ctypes.data if base_rows is not None else None, E, M, k if remove else -1, n_after,
+                    cfg.REMOVAL_WINDOW, buf.ctypes.data, E)
+                assert Ek >= 0
+                g = buf[:4 * E].reshape(4, E)
+                changed = remove or Ek != E
+                o = 4 * E
+                buf[o:o + ne] = e_ii; buf[o + ne:o + 2 * ne] = e_jj; buf[o + 2 * ne:o + 3 * ne] = e_kk
+                o2 = o + 3 * ne
+                buf[o2:o2 + Ek] = g[3, :Ek]
+                buf[o2 + Ek:o2 + Ek + ne] = -1
+                dev = self._upload(buf[:o2 + Ek + ne])
+                g_dev = dev[:4 * E].view(4, E)[:, :Ek]
+                e_dev = dev[o:o2].view(3, ne)
+                m_dev = dev[o2:o2 + Ek + ne]
+                ed = dict(changed=changed, ii=g[0, :Ek], jj=g[1, :Ek], kk=g[2, :Ek], n=n_after)
+                spec[remove] = (ed, g[3, :Ek], g_dev, dev, (n1, e_ii, e_jj, e_kk, e_dev, m_dev, Ek))
         done.synchronize()
         remove = float(self._mm_host[0]) < cfg.KEYFRAME_THRESH
-        ed, rows, g_dev, pre = spec[remove]
+        ed, rows, g_dev, dev, pre = spec[remove]
         cur = torch.cuda.current_stream()
         cur.wait_stream(self._up_stream)
-        for t in (g_dev, pre[4], pre[5]):          # allocated on the side stream, consumed on this one
-            if t is not None:
-                t.record_stream(cur)
+        dev.record_stream(cur)                     # allocated on the side stream, consumed on this one
         if remove:
             t0, t1 = self._tstamps[k - 1], self._tstamps[k]
             self.delta[t1] = (t0, dP)
@@ -512,6 +526,7 @@ class Ramp_vo:
         self._pre_cache = pre
         if not ed["changed"]:
             return
+        # (the host mirrors are views of the staging buffer; the device arrays views of its upload)
         self._ii, self._jj, self._kk = ed["ii"], ed["jj"], ed["kk"]
         self.ii, self.jj, self.kk = g_dev[0], g_dev[1], g_dev[2]
         self._net_map, self._net_map_dev = rows, None

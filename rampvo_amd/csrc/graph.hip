@@ -414,4 +414,29 @@ int ramp_segment_softmax_sum(const void *fx, const void *gx, const int32_t *orde
   return RAMP_OK;
 }
 
+// HOST function (no GPU work): Ramp_vo.keyframe()'s edit of the factor graph for one outcome of the motion
+// test (reference ramp/Ramp_vo.py:247-274, 203-208) in one pass over the host mirror: drop the factors of
+// keyframe k_remove (k_remove < 0: none) and renumber the later frames / patches, then drop factors whose
+// source frame is older than n_after - removal_window.  out = [4][cap] int64 rows (ii, jj, kk, state row),
+// rows_in = the hidden-state row of each factor (NULL: identity).  Returns the number of factors kept.
+int ramp_graph_edit_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, const int64_t *rows_in, int E,
+                         int M, int k_remove, int n_after, int removal_window, int64_t *out, int cap) {
+  if (E < 0 || !out || cap < E || (E > 0 && (!ii || !jj || !kk))) return RAMP_EINVAL;
+  int64_t *oi = out, *oj = out + cap, *ok = out + 2 * (size_t)cap, *orow = out + 3 * (size_t)cap;
+  const int64_t oldest = (int64_t)n_after - removal_window;
+  int m = 0;
+  for (int e = 0; e < E; e++) {
+    int64_t i = ii[e], j = jj[e], q = kk[e];
+    if (k_remove >= 0) {
+      if (i == k_remove || j == k_remove) continue;
+      if (i > k_remove) { i -= 1; q -= M; }
+      if (j > k_remove) j -= 1;
+    }
+    if (q / M < oldest) continue;
+    oi[m] = i; oj[m] = j; ok[m] = q; orow[m] = rows_in ? rows_in[e] : (int64_t)e;
+    m++;
+  }
+  return m;
+}
+
 }  // extern "C"

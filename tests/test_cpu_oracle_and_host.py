@@ -121,6 +121,32 @@ def test_oracle_event_stack_against_reference_golden():
     assert out[0, 9, 7] == 45          # 301 events on one pixel wrap to 45, as upstream
 
 
+def test_host_graph_edit_matches_numpy_logic():
+    """libramp_hip.so's HOST helper ramp_graph_edit_host (one C pass) against Ramp_vo._graph_edit (the numpy
+    restatement of reference Ramp_vo.py:247-274 + :203-208), both outcomes of the motion test"""
+    import ctypes
+    from rampvo_amd import _lib
+    from rampvo_amd.Ramp_vo import Ramp_vo
+    rng = np.random.default_rng(3)
+    M, n, R, KI = 8, 30, 22, 4
+    fake = type("T", (), {})()
+    fake.cfg = type("C", (), dict(KEYFRAME_INDEX=KI, REMOVAL_WINDOW=R))()
+    fake.M, fake.n = M, n
+    kk = np.sort(rng.integers(0, n * M, 5000)).astype(np.int64)
+    fake._kk, fake._ii = kk, kk // M
+    fake._jj = rng.integers(0, n, 5000).astype(np.int64)
+    rows = rng.permutation(5000).astype(np.int64)
+    for remove in (True, False):
+        ref = Ramp_vo._graph_edit(fake, remove)
+        out = np.empty((4, 5000), np.int64)
+        k = n - KI if remove else -1
+        m = _lib.lib().ramp_graph_edit_host(fake._ii.ctypes.data, fake._jj.ctypes.data, fake._kk.ctypes.data,
+                                            rows.ctypes.data, 5000, M, k, ref["n"], R, out.ctypes.data, 5000)
+        assert m == len(ref["ii"]) and ref["changed"]
+        assert np.array_equal(out[0, :m], ref["ii"]) and np.array_equal(out[1, :m], ref["jj"])
+        assert np.array_equal(out[2, :m], ref["kk"]) and np.array_equal(out[3, :m], rows[ref["idx"]])
+
+
 def test_oracle_ba_properties():
     s = ba_scene(seed=5, n_frames=8, M=10, lifetime=4)
     p, pt = s["poses"].copy(), s["patches"].copy()
