@@ -89,7 +89,7 @@ class Ramp_vo:
         self._lazy_net = dev.type == "cuda"      # GPU: the [E,384] state is re-indexed, not copied, when the graph changes
         self._net_map = None                     # host int64 [E]: row of _net_buf per current edge (-1: zeros)
         self._net_map_dev = None
-        self._pre_cache = None                   # (n1, ii, jj, kk, dev, map_dev, E_base): next frame's edges, uploaded early
+        self._pre_cache = None                   # the next frame's graph (host + device arrays, plan), prepared by keyframe()
         self._up_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._mm_host = torch.empty(1, dtype=torch.float32).pin_memory() if dev.type == "cuda" else None
         self.net = torch.zeros(1, 0, DIM, dtype=torch.float, device=dev)   # hidden state is fp32 (as under autocast)
@@ -281,9 +281,8 @@ class Ramp_vo:
         n1 = self.n + 1                       # value of self.n when the edges are generated
         pre = self._pre_cache
         self._pre_cache = None
-        if pre is not None and pre[0] == n1 and pre[6] == len(self._ii):
-            torch.cuda.current_stream().wait_stream(self._up_stream)
-            return pre[:6]
+        if pre is not None and pre["n1"] == n1 and pre["Ek"] == len(self._ii):
+            return pre
         ii, jj, kk = self._new_edges(n1)
         dev = self._upload(np.stack([ii, jj, kk]))            # one copy for the three arrays
         map_dev = None
@@ -295,6 +294,15 @@ class Ramp_vo:
         """ii: patch indices, jj: frame indices (host arrays) -- reference :194-201.  ``pre``: the same
         edges already uploaded by _prefetch_edges"""
         map_dev = None
+        if isinstance(pre, dict):
+            # the speculative keyframe() laid the whole next graph out (host + device) and built its plan:
+            # kept factors [0, Ek) followed by this frame's new ones -- nothing is concatenated or uploaded
+            b4, d4, tot = pre["host"], pre["dev"], pre["Ek"] + pre["ne"]
+            self._ii, self._jj, self._kk = b4[0, :tot], b4[1, :tot], b4[2, :tot]
+            self.ii, self.jj, self.kk = d4[0, :tot], d4[1, :tot], d4[2, :tot]
+            self._net_map, self._net_map_dev = b4[3, :tot], d4[3, :tot]
+            self._plan = pre.get("plan")
+            return
         if pre is not None:
             _, src, jj, ii, dev, map_dev = pre
             d_ii, d_jj, d_kk = dev[0], dev[1], dev[2]
@@ -332,17 +340,19 @@ class Ramp_vo:
             self.net = self.net[:, kd]
         self._plan = None
 
+    def _build_plan(self, h_ii, h_jj, h_kk, d_ii, d_jj, d_kk):
+        k_lo, k_hi = int(h_kk.min()), int(h_kk.max()) + 1
+        f_lo = int(min(h_ii.min(), h_jj.min()))
+        f_hi = int(max(h_ii.max(), h_jj.max())) + 1
+        # group-count upper bounds from the ranges (no host-side unique, no device read-back)
+        max_kk = (k_hi // self.M - k_lo // self.M + 1) * self.M
+        max_ij = min((f_hi - f_lo) ** 2, len(h_ii))
+        return GraphPlan.build(d_ii, d_jj, d_kk, kk_bound=self.N * self.M, jj_bound=self.N,
+                               max_kk=max_kk, max_ij=max_ij, kk_range=(k_lo, k_hi), frame_range=(f_lo, f_hi))
+
     def _graph_plan(self):
         if self._plan is None or self._plan.E != len(self._ii):
-            k_lo, k_hi = int(self._kk.min()), int(self._kk.max()) + 1
-            f_lo = int(min(self._ii.min(), self._jj.min()))
-            f_hi = int(max(self._ii.max(), self._jj.max())) + 1
-            # group-count upper bounds from the ranges (no host-side unique, no device read-back)
-            max_kk = (k_hi // self.M - k_lo // self.M + 1) * self.M
-            max_ij = min((f_hi - f_lo) ** 2, len(self._ii))
-            self._plan = GraphPlan.build(self.ii, self.jj, self.kk, kk_bound=self.N * self.M, jj_bound=self.N,
-                                         max_kk=max_kk, max_ij=max_ij, kk_range=(k_lo, k_hi),
-                                         frame_range=(f_lo, f_hi))
+            self._plan = self._build_plan(self._ii, self._jj, self._kk, self.ii, self.jj, self.kk)
         return self._plan
 
     def __edges_forw(self):
@@ -492,45 +502,42 @@ class Ramp_vo:
                 n1 = n_after + 1
                 e_ii, e_jj, e_kk = self._new_edges(n1)
                 ne = len(e_kk)
-                # ONE host buffer / one upload per outcome: [ii | jj | kk | rows] of the edited graph (stride
-                # E), then the next frame's new edges [ii | jj | kk], then the row map after that append
-                buf = np.empty(4 * E + 3 * ne + (E + ne), np.int64)
+                # ONE host buffer / one upload per outcome: rows (ii, jj, kk, state row) of capacity E + ne;
+                # the factors kept by the edit come first, the next frame's new factors follow -- so the
+                # current graph is the [:Ek] view and the next frame's graph the [:Ek+ne] view of the same
+                # arrays, on the host and on the device
+                cap = E + ne
+                buf = np.empty((4, cap), np.int64)
                 Ek = _lib.lib().ramp_graph_edit_host(
                     self._ii.ctypes.data, self._jj.ctypes.data, self._kk.ctypes.data,
                     base_rows.ctypes.data if base_rows is not None else None, E, M, k if remove else -1, n_after,
-                    cfg.REMOVAL_WINDOW, buf.ctypes.data, E)
+                    cfg.REMOVAL_WINDOW, buf.ctypes.data, cap)
                 assert Ek >= 0
-                g = buf[:4 * E].reshape(4, E)
-                changed = remove or Ek != E
-                o = 4 * E
-                buf[o:o + ne] = e_ii; buf[o + ne:o + 2 * ne] = e_jj; buf[o + 2 * ne:o + 3 * ne] = e_kk
-                o2 = o + 3 * ne
-                buf[o2:o2 + Ek] = g[3, :Ek]
-                buf[o2 + Ek:o2 + Ek + ne] = -1
-                dev = self._upload(buf[:o2 + Ek + ne])
-                g_dev = dev[:4 * E].view(4, E)[:, :Ek]
-                e_dev = dev[o:o2].view(3, ne)
-                m_dev = dev[o2:o2 + Ek + ne]
-                ed = dict(changed=changed, ii=g[0, :Ek], jj=g[1, :Ek], kk=g[2, :Ek], n=n_after)
-                spec[remove] = (ed, g[3, :Ek], g_dev, dev, (n1, e_ii, e_jj, e_kk, e_dev, m_dev, Ek))
+                buf[0, Ek:Ek + ne] = e_ii
+                buf[1, Ek:Ek + ne] = e_jj
+                buf[2, Ek:Ek + ne] = e_kk
+                buf[3, Ek:Ek + ne] = -1
+                dev = self._upload(buf)
+                spec[remove] = dict(n1=n1, n=n_after, Ek=Ek, ne=ne, host=buf, dev=dev)
         done.synchronize()
         remove = float(self._mm_host[0]) < cfg.KEYFRAME_THRESH
-        ed, rows, g_dev, dev, pre = spec[remove]
+        pre = spec[remove]
         cur = torch.cuda.current_stream()
         cur.wait_stream(self._up_stream)
-        dev.record_stream(cur)                     # allocated on the side stream, consumed on this one
+        pre["dev"].record_stream(cur)              # allocated on the side stream, consumed on this one
         if remove:
             t0, t1 = self._tstamps[k - 1], self._tstamps[k]
             self.delta[t1] = (t0, dP)
             self._apply_removal(k)
-        self._pre_cache = pre
-        if not ed["changed"]:
-            return
-        # (the host mirrors are views of the staging buffer; the device arrays views of its upload)
-        self._ii, self._jj, self._kk = ed["ii"], ed["jj"], ed["kk"]
-        self.ii, self.jj, self.kk = g_dev[0], g_dev[1], g_dev[2]
-        self._net_map, self._net_map_dev = rows, None
+        b4, d4, Ek = pre["host"], pre["dev"], pre["Ek"]
+        self._ii, self._jj, self._kk = b4[0, :Ek], b4[1, :Ek], b4[2, :Ek]
+        self.ii, self.jj, self.kk = d4[0, :Ek], d4[1, :Ek], d4[2, :Ek]
+        self._net_map, self._net_map_dev = b4[3, :Ek], None
         self._plan = None
+        # the next frame's graph is known now: build its plan here, in the gap between two frames
+        tot = Ek + pre["ne"]
+        pre["plan"] = self._build_plan(b4[0, :tot], b4[1, :tot], b4[2, :tot], d4[0, :tot], d4[1, :tot], d4[2, :tot])
+        self._pre_cache = pre
 
     # ------------------------------------------------------------------- update
     def update(self):
@@ -650,7 +657,7 @@ class Ramp_vo:
 
         self.n += 1
         self.m += self.M
-        if pre is not None and pre[0] == self.n:
+        if pre is not None and (pre["n1"] if isinstance(pre, dict) else pre[0]) == self.n:
             self.append_factors(None, None, pre=pre)
         else:
             kf, jf = self.__edges_forw()
