@@ -28,6 +28,7 @@ from . import altcorr, fastba, lietorch, ops
 from . import projective_ops as pops
 from . import _lib
 from ._lib import RAMP_NHWC, RAMP_NHWC8
+from .update_fused import CORR_ROW
 from .lietorch import SE3
 from .net import GraphPlan, VONet
 from .utils import Timer, filter_features, preprocess_input
@@ -248,8 +249,11 @@ class Ramp_vo:
         ii, jj = indicies if indicies is not None else (self.kk, self.jj)
         ii1 = ii % (self.M * self.mem)
         jj1 = jj % self.mem
+        # GPU, fp16: rows padded 882 -> 896 (16-byte aligned rows for the first Linear layer, update_fused.py)
         return altcorr.corr_pyramid(self.gmap_.view(-1, 3, 3, 128), self.pyramid, coords[0], ii1, jj1, 3,
-                                    (1, 4), RAMP_NHWC8 if self._chunked else RAMP_NHWC, order=order)
+                                    (1, 4), RAMP_NHWC8 if self._chunked else RAMP_NHWC, order=order,
+                                    row_elems=CORR_ROW if (self.device.type == "cuda" and self.dtype == torch.half)
+                                    else 0)
 
     def reproject(self, indicies=None, poses=None, patches=None, intrinsics=None):
         (ii, jj, kk) = indicies if indicies is not None else (self.ii, self.jj, self.kk)

@@ -87,6 +87,7 @@ struct CorrParams {
   const int64_t *ii, *jj;
   void *out;
   int E, N1, N2;
+  int row_elems;          // elements per edge row of `out` (>= 441 * nlevels; the tail is zero filled)
   const int32_t *order;   // optional schedule: position -> edge (any permutation of 0..E-1)
   int chunk;              // ceil(E / CORR_XCDS)
 };
@@ -303,8 +304,9 @@ __global__ void __launch_bounds__(64)
     __syncthreads();
   }
   __syncthreads();
-  T *o = reinterpret_cast<T *>(prm.out) + (size_t)e * NOUT * L;
+  T *o = reinterpret_cast<T *>(prm.out) + (size_t)e * prm.row_elems;
   for (int q = lane; q < NOUT * L; q += 64) st_from_float(o + q, outs[q]);
+  for (int q = NOUT * L + lane; q < prm.row_elems; q += 64) st_from_float(o + q, 0.0f);
 }
 
 
@@ -499,7 +501,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CORR_WA
     __syncthreads();
   }
   // out[e][o][lvl]: with two levels a lane's pair is one 4-byte store, consecutive over lanes
-  __half *op = reinterpret_cast<__half *>(prm.out) + (size_t)e * NOUT * L;
+  __half *op = reinterpret_cast<__half *>(prm.out) + (size_t)e * prm.row_elems;
+  for (int q = NOUT * L + lane; q < prm.row_elems; q += 64) op[q] = __float2half(0.0f);   // row padding
   if (lane < 63) {
     if (L == 2) {
 #pragma unroll
@@ -595,8 +598,8 @@ int ramp_patchify_fwd(const void *net, const float *coords, void *out, int n, in
 
 int ramp_corr_fwd_ordered(const void *fmap1, const ramp_corr_level *levels, int nlevels,
                           const float *coords, const int64_t *ii, const int64_t *jj,
-                          const int32_t *order, void *out, int E, int N1, int N2, int C, int P,
-                          int radius, int dtype, int layout, void *stream) {
+                          const int32_t *order, void *out, int out_row_elems, int E, int N1, int N2, int C,
+                          int P, int radius, int dtype, int layout, void *stream) {
   if (E < 0 || nlevels < 1 || nlevels > CORR_MAXLEV || !levels) return RAMP_EINVAL;
   if (C != 128 || P != 3 || radius != 3) return RAMP_EUNSUPPORTED;
   if (E == 0) return RAMP_OK;
@@ -620,6 +623,8 @@ int ramp_corr_fwd_ordered(const void *fmap1, const ramp_corr_level *levels, int 
   prm.N1 = N1;
   prm.N2 = N2;
   prm.order = order;
+  prm.row_elems = out_row_elems > 0 ? out_row_elems : 49 * 9 * nlevels;
+  if (prm.row_elems < 49 * 9 * nlevels || (nlevels == 2 && (prm.row_elems & 1))) return RAMP_EINVAL;   // half2 stores
   prm.chunk = (E + CORR_XCDS - 1) / CORR_XCDS;
   const dim3 grid(prm.chunk * CORR_XCDS);
   hipStream_t st = (hipStream_t)stream;
@@ -643,7 +648,7 @@ int ramp_corr_fwd(const void *fmap1, const ramp_corr_level *levels, int nlevels,
                   const float *coords, const int64_t *ii, const int64_t *jj, void *out, int E,
                   int N1, int N2, int C, int P, int radius, int dtype, int layout,
                   void *stream) {
-  return ramp_corr_fwd_ordered(fmap1, levels, nlevels, coords, ii, jj, nullptr, out, E, N1, N2, C,
+  return ramp_corr_fwd_ordered(fmap1, levels, nlevels, coords, ii, jj, nullptr, out, 0, E, N1, N2, C,
                                P, radius, dtype, layout, stream);
 }
 

@@ -32,7 +32,7 @@ def patchify(net, coords, radius, bilinear=True, layout=RAMP_NCHW, out_layout=RA
     return out
 
 
-def corr(fmap1, fmaps2, coords, ii, jj, radius=3, coord_divs=(1.0,), layout=RAMP_NCHW, order=None):
+def corr(fmap1, fmaps2, coords, ii, jj, radius=3, coord_divs=(1.0,), layout=RAMP_NCHW, order=None, row_elems=0):
     """fused multi-level patch correlation.  order: optional int32 [E] schedule (a permutation of
     the edges, e.g. target-frame-major) -- affects which XCD computes an edge, never a value.
 
@@ -65,11 +65,17 @@ def corr(fmap1, fmaps2, coords, ii, jj, radius=3, coord_divs=(1.0,), layout=RAMP
                   (f.shape[1], f.shape[3]) if layout == RAMP_NHWC8 else (f.shape[1], f.shape[2]))
         levels[l] = CorrLevel(f.data_ptr(), H2, W2, float(coord_divs[l]))
     d = 2 * radius + 1
-    out = torch.empty((E, d, d, P, P, L), dtype=fmap1.dtype, device=fmap1.device)
+    dense = d * d * P * P * L
+    if row_elems and row_elems != dense:      # padded rows [E, row_elems] (tail zero filled by the kernel)
+        assert row_elems > dense
+        out = torch.empty((E, row_elems), dtype=fmap1.dtype, device=fmap1.device)
+    else:
+        row_elems = 0
+        out = torch.empty((E, d, d, P, P, L), dtype=fmap1.dtype, device=fmap1.device)
     if order is not None:
         assert order.dtype == torch.int32 and order.is_contiguous() and order.shape[0] == E
     check(lib().ramp_corr_fwd_ordered(ptr(fmap1), levels, L, ptr(coords), ptr(ii), ptr(jj),
-                                      ptr(order) if order is not None else None, ptr(out), E,
+                                      ptr(order) if order is not None else None, ptr(out), int(row_elems), E,
                                       N1, N2, C, P, radius, dtype_code(fmap1), layout, stream()),
           "ramp_corr_fwd_ordered")
     return out

@@ -17,6 +17,9 @@ from ._lib import check, lib, ptr, stream
 _code = {torch.float32: _lib.RAMP_F32, torch.float16: _lib.RAMP_F16}
 
 
+CORR_ROW = 896     # correlation rows are padded from 882 to 896 elements on the GPU (zero tail)
+
+
 def pack_linear_f16(weight):
     """nn.Linear weight [N, K] -> fp16 MFMA B fragments [K/32][N/16][64 lanes][8]:
     lane (q = lane >> 4, j = lane & 15) of fragment (ks, nt) holds W[16 nt + j][32 ks + 8 q .. + 8]"""
@@ -45,7 +48,9 @@ class FusedUpdate:
         c = lambda t: t.detach().to(T).contiguous()
         f = lambda t: t.detach().float().contiguous()
         w = dict(
-            corr0=(c(m.corr[0].weight), c(m.corr[0].bias)), corr2=(c(m.corr[2].weight), c(m.corr[2].bias)),
+            corr0=(c(m.corr[0].weight), c(m.corr[0].bias)),
+            corr0_pad=(c(F.pad(m.corr[0].weight, (0, CORR_ROW - m.corr[0].weight.shape[1]))), c(m.corr[0].bias)),
+            corr2=(c(m.corr[2].weight), c(m.corr[2].bias)),
             corr_ln=(f(m.corr[3].weight), f(m.corr[3].bias), m.corr[3].eps),
             corr5=(c(m.corr[5].weight), c(m.corr[5].bias)),
             norm=(f(m.norm.weight), f(m.norm.bias), m.norm.eps),
@@ -137,7 +142,7 @@ class FusedUpdate:
         self.dtype.  Returns (net_out fp32 [E,384], relu copy T)."""
         w = self.weights()
         E = corr.shape[0]
-        c = self.lin_relu(corr, w["corr0"])
+        c = self.lin_relu(corr, w["corr0_pad"] if corr.shape[1] == CORR_ROW else w["corr0"])
         c = self.lin(c, w["corr2"])
         _, c = self.row_fuse(E, B=c, ln=w["corr_ln"], relu=True, want_t=True)
         c = self.lin(c, w["corr5"])

@@ -167,6 +167,11 @@ def test_corr_schedule_does_not_change_values(half):
     for order in (perm, byjj):
         out = ops.corr(*args, order=order)
         assert torch.equal(torch.nan_to_num(out.float(), nan=-7.0), torch.nan_to_num(base.float(), nan=-7.0))
+    # padded rows (882 -> 896): same values, zero tail
+    pad = ops.corr(*args, order=byjj, row_elems=896)
+    assert pad.shape == (61, 896) and float(pad[:, 882:].abs().max()) == 0.0
+    assert torch.equal(torch.nan_to_num(pad[:, :882].float(), nan=-7.0),
+                       torch.nan_to_num(base.reshape(61, 882).float(), nan=-7.0))
 
 
 def test_pyramid_pack_and_chunked_corr():
