@@ -305,7 +305,7 @@ int ramp_ms_lstm_superstate(const float *ev, const float *im, const float *const
  *   pre_scale/pre_shift [Cin] (optional): x <- relu(x*scale + shift) while loading, i.e. the
  *       producer's InstanceNorm + ReLU fused into this conv
  *   y = [relu]( conv + bias );  if res: y = relu(y + res);  y *= out_scale
- *   stats (optional) [ramp_conv2d_stats_blocks(...)][Cout][2]: per-block partial sum / sum of
+ *   stats (optional) [Cout][2][ramp_conv2d_stats_blocks(...)]: per-block partial sum / sum of
  *       squares of (conv + bias), reduced by ramp_in_stats_finalize                                     */
 int ramp_conv2d_nhwc(const void *x, const void *wpk, const float *bias, const float *pre_scale,
                      const float *pre_shift, const void *res, void *y, float *stats, int H, int W,

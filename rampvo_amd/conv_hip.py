@@ -137,7 +137,7 @@ def conv2d(x, conv, pre=None, res=None, relu=False, want_stats=False, out_scale=
     y = torch.empty(OH, OW, cout, dtype=odt, device=x.device)
     nblk = lib().ramp_conv2d_stats_blocks(H, W, Cin, cout, kh, stride, code)
     assert nblk > 0
-    stats = torch.empty(nblk, cout, 2, dtype=torch.float32, device=x.device) if want_stats else None
+    stats = torch.empty(cout, 2, nblk, dtype=torch.float32, device=x.device) if want_stats else None
     check(lib().ramp_conv2d_nhwc(ptr(x), ptr(wpk), ptr(bias), ptr(pre[0]) if pre else None,
                                  ptr(pre[1]) if pre else None, ptr(res), ptr(y), ptr(stats), H, W, Cin, cout,
                                  kh, kw, stride, int(relu), float(out_scale), code, stream()),

@@ -66,7 +66,7 @@ struct ConvParams {
   const float *pre_scale, *pre_shift;  // [Cin] or null: x <- relu(x*scale+shift) on load
   const void *res;      // NHWC [OH][OW][Cout] residual (added before the final ReLU) or null
   void *y;              // NHWC [OH][OW][Cout]
-  float *stats;         // [nblk_m][Cout][2] partial (sum, sumsq) of the raw (bias-added) output or null
+  float *stats;         // [Cout][2][nblk] partial (sum, sumsq) of the raw (bias-added) output or null
   int H, W, Cin, OH, OW, Cout;
   int relu;             // ReLU on the conv output (before the residual add; the add is followed by its own ReLU)
   float out_scale;
@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(256)
     if (threadIdx.x < 64) {
       const int c = threadIdx.x >> 1, k = threadIdx.x & 1;
       const float v = ((s_stat[0][c][k] + s_stat[1][c][k]) + s_stat[2][c][k]) + s_stat[3][c][k];
-      p.stats[((size_t)blockIdx.x * p.Cout + n0 + c) * 2 + k] = v;
+      p.stats[((size_t)(n0 + c) * 2 + k) * gridDim.x + blockIdx.x] = v;   // [C][2][nblk]: contiguous per channel
     }
   }
 }
@@ -332,7 +332,7 @@ __global__ void __launch_bounds__(256)
     if (threadIdx.x < 64) {
       const int c = threadIdx.x >> 1, k = threadIdx.x & 1;
       const float v = ((s_stat[0][c][k] + s_stat[1][c][k]) + s_stat[2][c][k]) + s_stat[3][c][k];
-      p.stats[((size_t)blockIdx.x * p.Cout + n0 + c) * 2 + k] = v;
+      p.stats[((size_t)(n0 + c) * 2 + k) * gridDim.x + blockIdx.x] = v;   // [C][2][nblk]: contiguous per channel
     }
   }
 }
@@ -512,7 +512,7 @@ __global__ void __launch_bounds__(256) conv_tile_f16_kernel(const ConvParams p) 
   if (p.stats && tid < NT * 32) {
     const int c = tid >> 1, k = tid & 1;
     const float v = ((s_stat[0][c][k] + s_stat[1][c][k]) + s_stat[2][c][k]) + s_stat[3][c][k];
-    p.stats[((size_t)blockIdx.x * p.Cout + n0 + c) * 2 + k] = v;
+    p.stats[((size_t)(n0 + c) * 2 + k) * gridDim.x + blockIdx.x] = v;   // [C][2][nblk]: contiguous per channel
   }
   // 16-byte pieces: pixel-major, 8 channels each
   constexpr int PPP = NT * 2;                         // pieces per pixel
@@ -543,10 +543,19 @@ __global__ void __launch_bounds__(64)
     in_stats_finalize_kernel(const float *__restrict__ partial, int nblk, int C, float count, float eps,
                              float *__restrict__ scale, float *__restrict__ shift) {
   const int c = blockIdx.x, lane = threadIdx.x;
+  // partial[C][2][nblk]: a channel's partials are contiguous -> coalesced, 4 loads in flight per lane
+  const float *p1 = partial + ((size_t)c * 2 + 0) * nblk, *p2 = partial + ((size_t)c * 2 + 1) * nblk;
   float s1 = 0.f, s2 = 0.f;
-  for (int b = lane; b < nblk; b += 64) {
-    s1 += partial[((size_t)b * C + c) * 2 + 0];
-    s2 += partial[((size_t)b * C + c) * 2 + 1];
+  for (int b0 = 0; b0 < nblk; b0 += 256) {
+    float a[4], q[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int b = b0 + u * 64 + lane;
+      a[u] = b < nblk ? p1[b] : 0.f;
+      q[u] = b < nblk ? p2[b] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) { s1 += a[u]; s2 += q[u]; }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_down(s1, off, 64); s2 += __shfl_down(s2, off, 64); }
