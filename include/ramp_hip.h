@@ -113,6 +113,11 @@ size_t ramp_event_stack_workspace_bytes(int bins, int H, int W);
 int ramp_event_stack(const int32_t *x, const int32_t *y, const int8_t *p, int N, int bins, int H, int W,
                      int8_t *out_i8, float *out_f32, void *ws, size_t ws_bytes, void *stream);
 
+/* Depth initialisation of a new frame (ramp/Ramp_vo.py:370-371): the lower median (torch.median) of the
+ * inverse depths of the last F frames' patches -- patches_src = &patches_[n-F], [F][M][3][P][P] -- written
+ * into channel 2 of the M new patches patches_dst [M][3][P][P].  F*M*P*P <= 4096.                   */
+int ramp_depth_median_fill(const float *patches_src, int F, int M, int P, float *patches_dst, void *stream);
+
 /* Event-biased patch-centre selection: get_coords_from_topk_events + nms_image
  * (ramp/utils.py:186-226, 157-183; upstream ~20 ATen launches) for one frame.
  *   events [bins][H][W] float32 (W % 4 == 0); score = mean over bins of the 4x4 average of |events|,

@@ -90,6 +90,7 @@ class Ramp_vo:
         self._lazy_net = dev.type == "cuda"      # GPU: the [E,384] state is re-indexed, not copied, when the graph changes
         self._net_map = None                     # host int64 [E]: row of _net_buf per current edge (-1: zeros)
         self._net_map_dev = None
+        self._ixm = None
         self._pre_cache = None                   # the next frame's graph (host + device arrays, plan), prepared by keyframe()
         self._up_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._mm_host = torch.empty(1, dtype=torch.float32).pin_memory() if dev.type == "cuda" else None
@@ -578,7 +579,9 @@ class Ramp_vo:
                           plan=plan if self.device.type == "cuda" else None)
             except Exception as e:  # same recovery as the reference (:302-306)
                 print(f"WARNING: BA failed...{e}")
-            ixm = torch.arange(self.m, device=self.device) // self.M
+            if self._ixm is None or self._ixm.shape[0] < self.m:
+                self._ixm = torch.arange(self.N * self.M, device=self.device) // self.M     # patch -> source frame
+            ixm = self._ixm[:self.m]
             self.points_[:self.m] = pops.point_cloud(self.poses, self.patches_.view(-1, 3, 3, 3)[:self.m],
                                                      self.intrinsics, ixm)
 
@@ -629,7 +632,11 @@ class Ramp_vo:
 
         patches[:, :, 2] = self._initial_depth(patches)
         if self.is_initialized:
-            patches[:, :, 2] = torch.median(self.patches_[n - 3:n, :, 2])
+            if (self.device.type == "cuda" and patches.is_contiguous() and patches.dtype == torch.float32
+                    and ops.depth_median_supported(3, self.M, self.P)):
+                ops.depth_median_fill(self.patches_, n, 3, patches[0])       # radix select + fill, one launch
+            else:
+                patches[:, :, 2] = torch.median(self.patches_[n - 3:n, :, 2])
 
         slot = n % self.mem
         ex = getattr(self.network.patchify, "_extra", None)

@@ -39,6 +39,7 @@ SIGNATURES = {
     "ramp_graph_edit_host": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i]),
     "ramp_event_stack_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "ramp_event_stack": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_sz, c_p]),
+    "ramp_depth_median_fill": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p]),
     "ramp_event_topk_workspace_bytes": (c_sz, [c_i, c_i]),
     "ramp_event_topk": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_sz, c_p]),
     "ramp_pyramid_pack": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),

@@ -200,7 +200,86 @@ __global__ void __launch_bounds__(TOPK_THREADS)
 #undef TOPK_ITEM
 }
 
+// Depth initialisation of a new frame's patches (reference ramp/Ramp_vo.py:370-371):
+//   patches[:, :, 2] = torch.median(self.patches_[n-3:n, :, 2])
+// i.e. the lower median of the F*M*PP inverse depths of the last F frames, broadcast into the depth plane
+// of the M new patches.  One workgroup: keys in registers, 4 x 8-bit radix passes (k-th smallest), fill.
+#define MED_THREADS 1024
+#define MED_PER 4               // up to 4096 values
+__global__ void __launch_bounds__(MED_THREADS)
+    depth_median_fill_kernel(const float *__restrict__ src, int F, int M, int PP, float *__restrict__ dst) {
+  __shared__ unsigned hist[256];
+  __shared__ unsigned s_prefix, s_remaining;
+  const int tid = threadIdx.x, n = F * M * PP;
+  unsigned key[MED_PER];
+  bool has[MED_PER];
+#pragma unroll
+  for (int u = 0; u < MED_PER; u++) {
+    const int i = tid + u * MED_THREADS;
+    has[u] = i < n;
+    unsigned b = 0;
+    if (has[u]) {
+      const int fm = i / PP, p = i - fm * PP;               // (frame, patch) pair, pixel
+      b = __float_as_uint(src[((size_t)fm * 3 + 2) * PP + p]);
+      b ^= (b >> 31) ? 0xffffffffu : 0x80000000u;          // order-preserving map of float to uint
+    }
+    key[u] = b;
+  }
+  if (tid == 0) { s_prefix = 0; s_remaining = (unsigned)((n - 1) / 2) + 1; }   // rank of the lower median, 1-based
+  unsigned mask = 0;
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    const unsigned prefix = s_prefix;
+#pragma unroll
+    for (int u = 0; u < MED_PER; u++)
+      if (has[u] && (key[u] & mask) == prefix) atomicAdd(&hist[(key[u] >> shift) & 255u], 1u);
+    __syncthreads();
+    if (tid < 64) {
+      unsigned c[4];
+#pragma unroll
+      for (int b = 0; b < 4; b++) c[b] = hist[4 * tid + b];
+      const unsigned tot = c[0] + c[1] + c[2] + c[3];
+      unsigned pre = tot;                                   // inclusive prefix sum over lanes (ascending bins)
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned v = __shfl_up(pre, o, 64);
+        if (tid >= o) pre += v;
+      }
+      const unsigned rem = s_remaining, below = pre - tot;
+      if (below < rem && pre >= rem) {
+        unsigned rr = rem - below;
+        int bin = 4 * tid + 3;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+          if (c[b] >= rr) { bin = 4 * tid + b; break; }
+          rr -= c[b];
+        }
+        s_remaining = rr;
+        s_prefix = prefix | ((unsigned)bin << shift);
+      }
+    }
+    mask |= 255u << shift;
+    __syncthreads();
+  }
+  unsigned b = s_prefix;
+  b ^= (b >> 31) ? 0x80000000u : 0xffffffffu;             // inverse map
+  const float med = __uint_as_float(b);
+  for (int i = tid; i < M * PP; i += MED_THREADS) {
+    const int m = i / PP, p = i - m * PP;
+    dst[((size_t)m * 3 + 2) * PP + p] = med;
+  }
+}
+
 extern "C" {
+
+int ramp_depth_median_fill(const float *patches_src, int F, int M, int P, float *patches_dst, void *stream) {
+  if (!patches_src || !patches_dst || F <= 0 || M <= 0 || P <= 0) return RAMP_EINVAL;
+  if ((long)F * M * P * P > MED_THREADS * MED_PER) return RAMP_EUNSUPPORTED;
+  hipLaunchKernelGGL(depth_median_fill_kernel, dim3(1), dim3(MED_THREADS), 0, (hipStream_t)stream, patches_src, F,
+                     M, P * P, patches_dst);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
 
 size_t ramp_event_topk_workspace_bytes(int H, int W) {
   return (size_t)2 * (H / 4) * (W / 4) * sizeof(float);

@@ -99,6 +99,20 @@ def event_stack(x, y, p, height, width, num_bins=5, as_float=True):
     return out
 
 
+def depth_median_fill(patches_state, n, F, patches_new):
+    """patches_new[:, 2] = median of patches_state[n-F:n, :, 2] (reference Ramp_vo.py:370-371), one launch.
+    patches_state [N,M,3,P,P], patches_new [M,3,P,P] (both contiguous fp32)"""
+    require_cuda(patches_state, patches_new)
+    _, M, _, P, _ = patches_state.shape
+    assert patches_state.is_contiguous() and patches_new.is_contiguous() and n - F >= 0
+    check(lib().ramp_depth_median_fill(ptr(patches_state[n - F]), F, M, P, ptr(patches_new), stream()),
+          "ramp_depth_median_fill")
+
+
+def depth_median_supported(F, M, P):
+    return F * M * P * P <= 4096
+
+
 def event_topk(events, k, nms_kernel_size=11, want_indices=False):
     """patch centres of one frame: events [bins,H,W] float32 -> coords [k,2] float32 (x + y/h, y) at the
     top-k cells of the NMS'ed mean |event| map (reference utils.py:186-226), one score kernel + one NMS

@@ -483,3 +483,17 @@ def test_event_stack_matches_reference_golden_and_oracle():
     outf = ops.event_stack(cu(x), cu(y), cu(p), H, W, 5)
     assert outf.dtype == torch.float32 and np.array_equal(outf.cpu().numpy(), ref.astype(np.float32))
     assert float(ops.event_stack(cu(x[:1]), cu(y[:1]), cu(p[:1]), H, W, 5).abs().sum()) == 0.0     # < 2 events
+
+
+def test_depth_median_fill_matches_torch_median():
+    from rampvo_amd import ops
+    g = torch.Generator().manual_seed(2)
+    N, M, P = 12, 96, 3
+    state = (torch.rand(N, M, 3, P, P, generator=g) * 19 + 1e-3).cuda()
+    state[5, :7, 2] = -0.25                                     # sign handling of the key map
+    for n in (3, 8, 12):
+        new = torch.rand(M, 3, P, P, generator=g).cuda()
+        keep = new.clone()
+        ops.depth_median_fill(state, n, 3, new)
+        med = torch.median(state[n - 3:n, :, 2])
+        assert torch.equal(new[:, 2], med.expand(M, P, P)) and torch.equal(new[:, :2], keep[:, :2])
