@@ -386,7 +386,8 @@ int ramp_upd_segment_softmax(const void *fg, const int32_t *order, const int32_t
  * test, one pass over the host mirror.  k_remove < 0: no keyframe is dropped.  out [4][cap] int64 =
  * (ii, jj, kk, hidden-state row) of the factors kept; rows_in NULL = identity.  Returns their number.  */
 int ramp_graph_edit_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, const int64_t *rows_in, int E,
-                         int M, int k_remove, int n_after, int removal_window, int64_t *out, int cap);
+                         int M, int k_remove, int n_after, int removal_window, int64_t *out, int cap,
+                         int64_t *ranges /* optional [4]: min/max kk, min/max frame index of the kept factors */);
 
 /* ------------------------------------------------ fused update-operator GEMM chains (fp16) */
 /* gru[1..3] of the update operator (ramp/net.py:49-54; GatedResidual: ramp/blocks.py:15-31) as ONE

@@ -345,10 +345,13 @@ class Ramp_vo:
             self.net = self.net[:, kd]
         self._plan = None
 
-    def _build_plan(self, h_ii, h_jj, h_kk, d_ii, d_jj, d_kk):
-        k_lo, k_hi = int(h_kk.min()), int(h_kk.max()) + 1
-        f_lo = int(min(h_ii.min(), h_jj.min()))
-        f_hi = int(max(h_ii.max(), h_jj.max())) + 1
+    def _build_plan(self, h_ii, h_jj, h_kk, d_ii, d_jj, d_kk, ranges=None):
+        if ranges is not None:
+            k_lo, k_hi, f_lo, f_hi = ranges
+        else:
+            k_lo, k_hi = int(h_kk.min()), int(h_kk.max()) + 1
+            f_lo = int(min(h_ii.min(), h_jj.min()))
+            f_hi = int(max(h_ii.max(), h_jj.max())) + 1
         # group-count upper bounds from the ranges (no host-side unique, no device read-back)
         max_kk = (k_hi // self.M - k_lo // self.M + 1) * self.M
         max_ij = min((f_hi - f_lo) ** 2, len(h_ii))
@@ -513,17 +516,25 @@ class Ramp_vo:
                 # arrays, on the host and on the device
                 cap = E + ne
                 buf = np.empty((4, cap), np.int64)
+                rng = np.empty(4, np.int64)
                 Ek = _lib.lib().ramp_graph_edit_host(
                     self._ii.ctypes.data, self._jj.ctypes.data, self._kk.ctypes.data,
                     base_rows.ctypes.data if base_rows is not None else None, E, M, k if remove else -1, n_after,
-                    cfg.REMOVAL_WINDOW, buf.ctypes.data, cap)
+                    cfg.REMOVAL_WINDOW, buf.ctypes.data, cap, rng.ctypes.data)
                 assert Ek >= 0
+                # index ranges of the next frame's graph: kept factors (from the C pass) + the new ones (closed form)
+                r_ = cfg.PATCH_LIFETIME
+                k_lo, k_hi = M * max(n1 - r_, 0), M * n1
+                f_lo, f_hi = max(n1 - r_, 0), n1
+                if Ek > 0:
+                    k_lo, k_hi = min(k_lo, int(rng[0])), max(k_hi, int(rng[1]) + 1)
+                    f_lo, f_hi = min(f_lo, int(rng[2])), max(f_hi, int(rng[3]) + 1)
                 buf[0, Ek:Ek + ne] = e_ii
                 buf[1, Ek:Ek + ne] = e_jj
                 buf[2, Ek:Ek + ne] = e_kk
                 buf[3, Ek:Ek + ne] = -1
                 dev = self._upload(buf)
-                spec[remove] = dict(n1=n1, n=n_after, Ek=Ek, ne=ne, host=buf, dev=dev)
+                spec[remove] = dict(n1=n1, n=n_after, Ek=Ek, ne=ne, host=buf, dev=dev, ranges=(k_lo, k_hi, f_lo, f_hi))
         done.synchronize()
         remove = float(self._mm_host[0]) < cfg.KEYFRAME_THRESH
         pre = spec[remove]
@@ -541,7 +552,8 @@ class Ramp_vo:
         self._plan = None
         # the next frame's graph is known now: build its plan here, in the gap between two frames
         tot = Ek + pre["ne"]
-        pre["plan"] = self._build_plan(b4[0, :tot], b4[1, :tot], b4[2, :tot], d4[0, :tot], d4[1, :tot], d4[2, :tot])
+        pre["plan"] = self._build_plan(b4[0, :tot], b4[1, :tot], b4[2, :tot], d4[0, :tot], d4[1, :tot], d4[2, :tot],
+                                       ranges=pre["ranges"])
         self._pre_cache = pre
 
     # ------------------------------------------------------------------- update

@@ -36,7 +36,7 @@ SIGNATURES = {
     "ramp_corr_fwd": (c_i, [c_p, ctypes.POINTER(CorrLevel), c_i, c_p, c_p, c_p, c_p] + [c_i] * 8 + [c_p]),
     "ramp_ms_lstm_superstate": (c_i, [c_p, c_p, ctypes.POINTER(c_p), c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "ramp_conv2d_stats_blocks": (c_i, [c_i] * 7),
-    "ramp_graph_edit_host": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i]),
+    "ramp_graph_edit_host": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
     "ramp_event_stack_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "ramp_event_stack": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_sz, c_p]),
     "ramp_depth_median_fill": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p]),

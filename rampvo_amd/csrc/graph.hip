@@ -3,6 +3,7 @@
 // replacements of the reference's torch.unique syncs and its host std::stable_sort.
 #include "ramp_device.h"
 #include "ramp_internal.h"
+#include <cstdint>
 #include <hipcub/hipcub.hpp>
 
 #define GR_THREADS 256
@@ -420,8 +421,10 @@ int ramp_segment_softmax_sum(const void *fx, const void *gx, const int32_t *orde
 // source frame is older than n_after - removal_window.  out = [4][cap] int64 rows (ii, jj, kk, state row),
 // rows_in = the hidden-state row of each factor (NULL: identity).  Returns the number of factors kept.
 int ramp_graph_edit_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, const int64_t *rows_in, int E,
-                         int M, int k_remove, int n_after, int removal_window, int64_t *out, int cap) {
+                         int M, int k_remove, int n_after, int removal_window, int64_t *out, int cap,
+                         int64_t *ranges) {
   if (E < 0 || !out || cap < E || (E > 0 && (!ii || !jj || !kk))) return RAMP_EINVAL;
+  int64_t kmin = INT64_MAX, kmax = INT64_MIN, fmin = INT64_MAX, fmax = INT64_MIN;
   int64_t *oi = out, *oj = out + cap, *ok = out + 2 * (size_t)cap, *orow = out + 3 * (size_t)cap;
   const int64_t oldest = (int64_t)n_after - removal_window;
   int m = 0;
@@ -434,8 +437,12 @@ int ramp_graph_edit_host(const int64_t *ii, const int64_t *jj, const int64_t *kk
     }
     if (q / M < oldest) continue;
     oi[m] = i; oj[m] = j; ok[m] = q; orow[m] = rows_in ? rows_in[e] : (int64_t)e;
+    kmin = q < kmin ? q : kmin; kmax = q > kmax ? q : kmax;
+    const int64_t lo = i < j ? i : j, hi = i < j ? j : i;
+    fmin = lo < fmin ? lo : fmin; fmax = hi > fmax ? hi : fmax;
     m++;
   }
+  if (ranges) { ranges[0] = kmin; ranges[1] = kmax; ranges[2] = fmin; ranges[3] = fmax; }   // of the kept factors
   return m;
 }
 

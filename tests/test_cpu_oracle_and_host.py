@@ -139,10 +139,14 @@ def test_host_graph_edit_matches_numpy_logic():
     for remove in (True, False):
         ref = Ramp_vo._graph_edit(fake, remove)
         out = np.empty((4, 5000), np.int64)
+        rng_out = np.empty(4, np.int64)
         k = n - KI if remove else -1
         m = _lib.lib().ramp_graph_edit_host(fake._ii.ctypes.data, fake._jj.ctypes.data, fake._kk.ctypes.data,
-                                            rows.ctypes.data, 5000, M, k, ref["n"], R, out.ctypes.data, 5000)
+                                            rows.ctypes.data, 5000, M, k, ref["n"], R, out.ctypes.data, 5000,
+                                            rng_out.ctypes.data)
         assert m == len(ref["ii"]) and ref["changed"]
+        assert rng_out.tolist() == [ref["kk"].min(), ref["kk"].max(), min(ref["ii"].min(), ref["jj"].min()),
+                                    max(ref["ii"].max(), ref["jj"].max())]
         assert np.array_equal(out[0, :m], ref["ii"]) and np.array_equal(out[1, :m], ref["jj"])
         assert np.array_equal(out[2, :m], ref["kk"]) and np.array_equal(out[3, :m], rows[ref["idx"]])
 
