@@ -307,6 +307,11 @@ class Ramp_vo:
             self.ii, self.jj, self.kk = d4[0, :tot], d4[1, :tot], d4[2, :tot]
             self._net_map, self._net_map_dev = b4[3, :tot], d4[3, :tot]
             self._plan = pre.get("plan")
+            if self._plan is not None:                 # built on the upload stream: order it before this stream's use
+                cur = torch.cuda.current_stream()
+                cur.wait_stream(self._up_stream)
+                for t in self._plan.tensors():
+                    t.record_stream(cur)
             return
         if pre is not None:
             _, src, jj, ii, dev, map_dev = pre
@@ -550,11 +555,18 @@ class Ramp_vo:
         self.ii, self.jj, self.kk = d4[0, :Ek], d4[1, :Ek], d4[2, :Ek]
         self._net_map, self._net_map_dev = b4[3, :Ek], None
         self._plan = None
-        # the next frame's graph is known now: build its plan here, in the gap between two frames
-        tot = Ek + pre["ne"]
-        pre["plan"] = self._build_plan(b4[0, :tot], b4[1, :tot], b4[2, :tot], d4[0, :tot], d4[1, :tot], d4[2, :tot],
-                                       ranges=pre["ranges"])
+        # the next frame's graph is known now; its plan is built by _track() right after the next front end has
+        # been enqueued (side stream), so nothing but the selection sits between the read-back and that launch
+        pre["plan"] = None
         self._pre_cache = pre
+
+    def _build_next_plan(self, pre):
+        """plan of the graph this frame will have after append_factors, on the upload stream, concurrently with
+        the encoder (the plan kernels are small; the front end leaves most CUs idle)"""
+        b4, d4, tot = pre["host"], pre["dev"], pre["Ek"] + pre["ne"]
+        with torch.cuda.stream(self._up_stream):
+            pre["plan"] = self._build_plan(b4[0, :tot], b4[1, :tot], b4[2, :tot], d4[0, :tot], d4[1, :tot],
+                                           d4[2, :tot], ranges=pre["ranges"])
 
     # ------------------------------------------------------------------- update
     def update(self):
@@ -615,6 +627,8 @@ class Ramp_vo:
         fmap, gmap, imap, patches, _, clr = self.network.patchify(
             input_=input_, patches_per_image=self.cfg.PATCHES_PER_FRAME, event_bias=self.event_bias,
             reinit_hidden=True if tstamp == 0 else False)
+        if isinstance(pre, dict) and pre.get("plan") is None:
+            self._build_next_plan(pre)
         mask = input_[2]
         if mask is not None and not mask:
             return      # events only: the encoder state has advanced, the VO has not

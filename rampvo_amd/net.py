@@ -32,12 +32,22 @@ class GraphPlan:
     __slots__ = ("ix", "jx", "ix_raw", "jx_raw", "mask_ix", "mask_jx", "g_kk", "g_ij", "max_kk", "max_ij", "E",
                  "pair_mul")
 
+    def tensors(self):
+        """every device tensor of the plan (for stream bookkeeping)"""
+        out = [t for t in (self.ix, self.jx, self.ix_raw, self.jx_raw, self.mask_ix, self.mask_jx)
+               if isinstance(t, torch.Tensor)]
+        for g in (self.g_kk, self.g_ij):
+            out += [getattr(g, n) for n in ("order", "gid", "seg_start", "ukeys", "ngroups")
+                    if isinstance(getattr(g, n, None), torch.Tensor)]
+        return out
+
     @staticmethod
     def build(ii, jj, kk, kk_bound=0, jj_bound=0, max_kk=None, max_ij=None, kk_range=None, frame_range=None):
         """kk_range=(lo, hi) / frame_range=(lo, hi): tight half-open ranges of kk and of the frame
         indices in ii, jj when the caller knows them (the tracker does): the groupings then come
         from the counting group-by and the neighbours from the kk groups, no radix sort."""
         p = GraphPlan()
+        p.mask_ix = p.mask_jx = None
         p.E = ii.shape[0]
         small = (kk_range is not None and frame_range is not None and max_kk is not None and max_ij is not None
                  and ii.is_cuda and hasattr(ops, "group_by_small"))
