@@ -16,7 +16,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("RAMP_HIP_LIB") or os.path.join(CSRC, "libramp_hip.so")   # env: kernel A/B builds
 
 RAMP_F32, RAMP_F16 = 0, 1
-RAMP_IN_F32, RAMP_CONV_DIRECT = 0x10, 0x20
+RAMP_IN_F32, RAMP_CONV_DIRECT, RAMP_CORR_MFMA32 = 0x10, 0x20, 0x40
 RAMP_NCHW, RAMP_NHWC, RAMP_NHWC8 = 0, 1, 2
 
 _ERR = {-1: "RAMP_EINVAL (bad argument)", -2: "RAMP_ELAUNCH (HIP launch/runtime error)",

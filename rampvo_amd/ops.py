@@ -5,9 +5,12 @@ short fixed pipeline) on torch's current stream.  No CPU fallbacks.
 """
 import ctypes
 
+import os
+
 import torch
 
 from . import _lib
+from ._lib import RAMP_CORR_MFMA32 as _LIB_CORR_MFMA32
 from ._lib import workspace as _lib_workspace
 from ._lib import RAMP_NHWC8, RAMP_NCHW, RAMP_NHWC, CorrLevel, check, dtype_code, lib, ptr, require_cuda, stream
 
@@ -32,7 +35,8 @@ def patchify(net, coords, radius, bilinear=True, layout=RAMP_NCHW, out_layout=RA
     return out
 
 
-def corr(fmap1, fmaps2, coords, ii, jj, radius=3, coord_divs=(1.0,), layout=RAMP_NCHW, order=None, row_elems=0):
+def corr(fmap1, fmaps2, coords, ii, jj, radius=3, coord_divs=(1.0,), layout=RAMP_NCHW, order=None, row_elems=0,
+         fast_f32=None):
     """fused multi-level patch correlation.  order: optional int32 [E] schedule (a permutation of
     the edges, e.g. target-frame-major) -- affects which XCD computes an edge, never a value.
 
@@ -74,9 +78,14 @@ def corr(fmap1, fmaps2, coords, ii, jj, radius=3, coord_divs=(1.0,), layout=RAMP
         out = torch.empty((E, d, d, P, P, L), dtype=fmap1.dtype, device=fmap1.device)
     if order is not None:
         assert order.dtype == torch.int32 and order.is_contiguous() and order.shape[0] == E
+    code = dtype_code(fmap1)
+    if fast_f32 is None:
+        fast_f32 = os.environ.get("RAMP_CORR_F32_MFMA", "0") == "1"
+    if fast_f32 and fmap1.dtype == torch.float32 and layout == RAMP_NHWC:
+        code |= _LIB_CORR_MFMA32         # opt-in: MFMA accumulation order instead of the reference's fmaf chain
     check(lib().ramp_corr_fwd_ordered(ptr(fmap1), levels, L, ptr(coords), ptr(ii), ptr(jj),
                                       ptr(order) if order is not None else None, ptr(out), int(row_elems), E,
-                                      N1, N2, C, P, radius, dtype_code(fmap1), layout, stream()),
+                                      N1, N2, C, P, radius, code, layout, stream()),
           "ramp_corr_fwd_ordered")
     return out
 

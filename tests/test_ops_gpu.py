@@ -112,6 +112,25 @@ def test_corr_matches_oracle(layout):
         assert np.array_equal(np.isnan(out[..., lvl]), np.isnan(ref))
 
 
+def test_corr_f32_mfma_variant_matches_oracle():
+    """opt-in fp32 MFMA kernel (RAMP_CORR_MFMA32): same values as the oracle to 1e-5 (its accumulation order
+    is the MFMA's; the default fp32 kernel keeps the reference's order)"""
+    from rampvo_amd import ops
+    from rampvo_amd._lib import RAMP_NHWC
+    fmap1, fmap2, coords, ii, jj = corr_case(seed=3)
+    fmap2b = np.ascontiguousarray(fmap2[:, :, :, ::2, ::2])
+    ref0 = orc.corr(fmap1, fmap2, coords / 1, ii, jj, 3)[0]
+    ref1 = orc.corr(fmap1, fmap2b, coords / 4, ii, jj, 3)[0]
+    args = (cu(fmap1[0].transpose(0, 2, 3, 1)), [cu(fmap2[0].transpose(0, 2, 3, 1)), cu(fmap2b[0].transpose(0, 2, 3, 1))],
+            cu(coords[0]), cu(ii), cu(jj), 3, (1.0, 4.0), RAMP_NHWC)
+    out = ops.corr(*args, fast_f32=True).cpu().numpy()
+    for lvl, ref in ((0, ref0), (1, ref1)):
+        assert np.array_equal(np.isnan(out[..., lvl]), np.isnan(ref))
+        assert np.nanmax(np.abs(out[..., lvl] - ref)) <= 1e-5 * max(1.0, np.nanmax(np.abs(ref)))
+    base = ops.corr(*args, fast_f32=False).cpu().numpy()
+    assert np.nanmax(np.abs(base - out)) <= 1e-5 * max(1.0, np.nanmax(np.abs(ref0)))
+
+
 def test_corr_reference_signature_and_half():
     from rampvo_amd import altcorr
     fmap1, fmap2, coords, ii, jj = corr_case(seed=5, E=32, distort=False)
