@@ -93,11 +93,13 @@ int ramp_corr_fwd(const void *fmap1, const ramp_corr_level *levels_host, int nle
  * its graph plan.  out_row_elems (0 = dense, 441 * nlevels): elements per edge
  * row of `out`; the tail of a longer row is zero filled -- 896 instead of 882
  * makes the rows 16-byte aligned for the first Linear layer of the update
- * operator (library GEMM: 49 instead of 88 us at E = 40k).                  */
+ * operator (library GEMM: 49 instead of 88 us at E = 40k).  mod_ii / mod_jj
+ * > 0: ii[e] % mod_ii and jj[e] % mod_jj are used (the `kk % (M*mem)`,
+ * `jj % mem` ring-buffer slots of ramp/Ramp_vo.py:178-179).                 */
 int ramp_corr_fwd_ordered(const void *fmap1, const ramp_corr_level *levels_host, int nlevels,
                           const float *coords, const int64_t *ii, const int64_t *jj,
-                          const int32_t *order, void *out, int out_row_elems, int E, int N1, int N2, int C,
-                          int P, int radius, int dtype, int layout, void *stream);
+                          const int32_t *order, void *out, int out_row_elems, long mod_ii, long mod_jj, int E,
+                          int N1, int N2, int C, int P, int radius, int dtype, int layout, void *stream);
 
 /* Ramp_vo.__call__'s pyramid store (ramp/Ramp_vo.py:378-381: fmap1_[slot] =
  * fmap, fmap2_[slot] = avg_pool2d(fmap, 4, 4)) for fp16 channels-last features:

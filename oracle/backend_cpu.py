@@ -33,7 +33,7 @@ def patchify(net, coords, radius, bilinear=True, layout=RAMP_NCHW, out_layout=RA
     return out if out_layout == RAMP_NCHW else out.permute(0, 1, 3, 4, 2).contiguous()
 
 
-def corr(fmap1, fmaps2, coords, ii, jj, radius=3, coord_divs=(1.0,), layout=RAMP_NCHW, order=None, row_elems=0):
+def corr(fmap1, fmaps2, coords, ii, jj, radius=3, coord_divs=(1.0,), layout=RAMP_NCHW, order=None, row_elems=0, fast_f32=None, mod_ii=0, mod_jj=0):
     f1 = fmap1 if layout == RAMP_NCHW else fmap1.permute(0, 3, 1, 2)
     outs = []
     for f2, dv in zip(fmaps2, coord_divs):

@@ -248,13 +248,17 @@ class Ramp_vo:
         """local correlation volume, both pyramid levels fused: [1, E, 882].  order: the graph
         plan's target-frame-major edge permutation (scheduling only)"""
         ii, jj = indicies if indicies is not None else (self.kk, self.jj)
+        if self.device.type == "cuda":
+            # ring-buffer slots (kk % (M*mem), jj % mem) are taken inside the kernel; fp16: rows padded 882 -> 896
+            # (16-byte aligned rows for the first Linear layer, update_fused.py)
+            return altcorr.corr_pyramid(self.gmap_.view(-1, 3, 3, 128), self.pyramid, coords[0], ii, jj, 3, (1, 4),
+                                        RAMP_NHWC8 if self._chunked else RAMP_NHWC, order=order,
+                                        row_elems=CORR_ROW if self.dtype == torch.half else 0,
+                                        mod_ii=self.M * self.mem, mod_jj=self.mem)
         ii1 = ii % (self.M * self.mem)
         jj1 = jj % self.mem
-        # GPU, fp16: rows padded 882 -> 896 (16-byte aligned rows for the first Linear layer, update_fused.py)
         return altcorr.corr_pyramid(self.gmap_.view(-1, 3, 3, 128), self.pyramid, coords[0], ii1, jj1, 3,
-                                    (1, 4), RAMP_NHWC8 if self._chunked else RAMP_NHWC, order=order,
-                                    row_elems=CORR_ROW if (self.device.type == "cuda" and self.dtype == torch.half)
-                                    else 0)
+                                    (1, 4), RAMP_NHWC, order=order)
 
     def reproject(self, indicies=None, poses=None, patches=None, intrinsics=None):
         (ii, jj, kk) = indicies if indicies is not None else (self.ii, self.jj, self.kk)

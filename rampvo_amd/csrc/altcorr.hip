@@ -87,6 +87,7 @@ struct CorrParams {
   const int64_t *ii, *jj;
   void *out;
   int E, N1, N2;
+  long mod_ii, mod_jj;    // > 0: ii / jj are taken modulo these (the tracker's ring buffers)
   int row_elems;          // elements per edge row of `out` (>= 441 * nlevels; the tail is zero filled)
   const int32_t *order;   // optional schedule: position -> edge (any permutation of 0..E-1)
   int chunk;              // ceil(E / CORR_XCDS)
@@ -135,7 +136,8 @@ __global__ void __launch_bounds__(64)
   const int e = corr_edge_of_block(prm);
   if (e < 0) return;
   const int lane = threadIdx.x;
-  const long i1 = prm.ii[e], j2 = prm.jj[e];
+  const long i1 = prm.mod_ii > 0 ? prm.ii[e] % prm.mod_ii : prm.ii[e];   // ring-buffer slots (Ramp_vo.py:178-179)
+  const long j2 = prm.mod_jj > 0 ? prm.jj[e] % prm.mod_jj : prm.jj[e];
   const int L = prm.nlevels;
 
   // ---- stage the patch features as fp32 [p][c]
@@ -339,7 +341,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CORR_WA
   const int e = corr_edge_of_block(prm);
   if (e < 0) return;
   const int lane = threadIdx.x, q = lane >> 4, j = lane & 15;
-  const long i1 = prm.ii[e], j2 = prm.jj[e];
+  const long i1 = prm.mod_ii > 0 ? prm.ii[e] % prm.mod_ii : prm.ii[e];   // ring-buffer slots (Ramp_vo.py:178-179)
+  const long j2 = prm.mod_jj > 0 ? prm.jj[e] % prm.mod_jj : prm.jj[e];
   const int L = prm.nlevels;
 
   f16x8_t afrag[4];
@@ -538,7 +541,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8)))
   const int e = corr_edge_of_block(prm);
   if (e < 0) return;
   const int lane = threadIdx.x, q = lane >> 4, j = lane & 15;
-  const long i1 = prm.ii[e], j2 = prm.jj[e];
+  const long i1 = prm.mod_ii > 0 ? prm.ii[e] % prm.mod_ii : prm.ii[e];   // ring-buffer slots (Ramp_vo.py:178-179)
+  const long j2 = prm.mod_jj > 0 ? prm.jj[e] % prm.mod_jj : prm.jj[e];
   const int L = prm.nlevels;
 
   f32x4_t afrag[8];
@@ -796,8 +800,8 @@ int ramp_patchify_fwd(const void *net, const float *coords, void *out, int n, in
 
 int ramp_corr_fwd_ordered(const void *fmap1, const ramp_corr_level *levels, int nlevels,
                           const float *coords, const int64_t *ii, const int64_t *jj,
-                          const int32_t *order, void *out, int out_row_elems, int E, int N1, int N2, int C,
-                          int P, int radius, int dtype, int layout, void *stream) {
+                          const int32_t *order, void *out, int out_row_elems, long mod_ii, long mod_jj, int E,
+                          int N1, int N2, int C, int P, int radius, int dtype, int layout, void *stream) {
   if (E < 0 || nlevels < 1 || nlevels > CORR_MAXLEV || !levels) return RAMP_EINVAL;
   if (C != 128 || P != 3 || radius != 3) return RAMP_EUNSUPPORTED;
   if (E == 0) return RAMP_OK;
@@ -821,6 +825,8 @@ int ramp_corr_fwd_ordered(const void *fmap1, const ramp_corr_level *levels, int 
   prm.N1 = N1;
   prm.N2 = N2;
   prm.order = order;
+  prm.mod_ii = mod_ii;
+  prm.mod_jj = mod_jj;
   prm.row_elems = out_row_elems > 0 ? out_row_elems : 49 * 9 * nlevels;
   if (prm.row_elems < 49 * 9 * nlevels || (nlevels == 2 && (prm.row_elems & 1))) return RAMP_EINVAL;   // half2 stores
   prm.chunk = (E + CORR_XCDS - 1) / CORR_XCDS;
@@ -850,7 +856,7 @@ int ramp_corr_fwd(const void *fmap1, const ramp_corr_level *levels, int nlevels,
                   const float *coords, const int64_t *ii, const int64_t *jj, void *out, int E,
                   int N1, int N2, int C, int P, int radius, int dtype, int layout,
                   void *stream) {
-  return ramp_corr_fwd_ordered(fmap1, levels, nlevels, coords, ii, jj, nullptr, out, 0, E, N1, N2, C,
+  return ramp_corr_fwd_ordered(fmap1, levels, nlevels, coords, ii, jj, nullptr, out, 0, 0, 0, E, N1, N2, C,
                                P, radius, dtype, layout, stream);
 }
 

@@ -36,7 +36,7 @@ def patchify(net, coords, radius, bilinear=True, layout=RAMP_NCHW, out_layout=RA
 
 
 def corr(fmap1, fmaps2, coords, ii, jj, radius=3, coord_divs=(1.0,), layout=RAMP_NCHW, order=None, row_elems=0,
-         fast_f32=None):
+         fast_f32=None, mod_ii=0, mod_jj=0):
     """fused multi-level patch correlation.  order: optional int32 [E] schedule (a permutation of
     the edges, e.g. target-frame-major) -- affects which XCD computes an edge, never a value.
 
@@ -84,7 +84,8 @@ def corr(fmap1, fmaps2, coords, ii, jj, radius=3, coord_divs=(1.0,), layout=RAMP
     if fast_f32 and fmap1.dtype == torch.float32 and layout == RAMP_NHWC:
         code |= _LIB_CORR_MFMA32         # opt-in: MFMA accumulation order instead of the reference's fmaf chain
     check(lib().ramp_corr_fwd_ordered(ptr(fmap1), levels, L, ptr(coords), ptr(ii), ptr(jj),
-                                      ptr(order) if order is not None else None, ptr(out), int(row_elems), E,
+                                      ptr(order) if order is not None else None, ptr(out), int(row_elems), int(mod_ii),
+                                      int(mod_jj), E,
                                       N1, N2, C, P, radius, code, layout, stream()),
           "ramp_corr_fwd_ordered")
     return out
