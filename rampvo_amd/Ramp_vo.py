@@ -93,7 +93,7 @@ class Ramp_vo:
         self._ixm = None
         self._pre_cache = None                   # the next frame's graph (host + device arrays, plan), prepared by keyframe()
         self._up_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
-        self._mm_host = torch.empty(1, dtype=torch.float32).pin_memory() if dev.type == "cuda" else None
+        self._mm_host = torch.empty(2, dtype=torch.float32).pin_memory() if dev.type == "cuda" else None
         self.net = torch.zeros(1, 0, DIM, dtype=torch.float, device=dev)   # hidden state is fp32 (as under autocast)
         self.ii = torch.zeros(0, dtype=torch.long, device=dev)
         self.jj = torch.zeros(0, dtype=torch.long, device=dev)
@@ -506,7 +506,7 @@ class Ramp_vo:
         plan = self._graph_plan()
         mm = ops.motionmag(self.poses, self.patches, self.intrinsics, self.ii, self.jj, self.kk, plan.g_ij,
                            j * plan.pair_mul + i, i * plan.pair_mul + j, beta=0.5)   # keys are jj*mul+ii
-        self._mm_host.copy_(mm.mean().reshape(1), non_blocking=True)
+        self._mm_host.copy_(mm.reshape(2), non_blocking=True)       # both directions; averaged on the host
         done = torch.cuda.Event()
         done.record()
         dP = SE3(self.poses_[k]) * SE3(self.poses_[k - 1]).inv()      # only used if the keyframe goes
@@ -545,7 +545,8 @@ class Ramp_vo:
                 dev = self._upload(buf)
                 spec[remove] = dict(n1=n1, n=n_after, Ek=Ek, ne=ne, host=buf, dev=dev, ranges=(k_lo, k_hi, f_lo, f_hi))
         done.synchronize()
-        remove = float(self._mm_host[0]) < cfg.KEYFRAME_THRESH
+        mmh = self._mm_host.numpy()
+        remove = float((mmh[0] + mmh[1]) * np.float32(0.5)) < cfg.KEYFRAME_THRESH      # fp32 mean, as torch's
         pre = spec[remove]
         cur = torch.cuda.current_stream()
         cur.wait_stream(self._up_stream)

@@ -217,8 +217,11 @@ __global__ void __launch_bounds__(192)
                                const int32_t *__restrict__ seg_start, const int32_t *__restrict__ ngroups,
                                T *__restrict__ y) {
   const int g = blockIdx.x;
-  if (g >= *ngroups) return;
   const int c = 2 * threadIdx.x;
+  if (g >= *ngroups) {          // unused tail of the table: defined (zero) rows, no memset launch needed
+    st2<T>(y + (size_t)g * UD + c, 0.f, 0.f);
+    return;
+  }
   const int s0 = seg_start[g], s1 = seg_start[g + 1];
   float m0 = -INFINITY, m1 = -INFINITY, z0 = 0.f, z1 = 0.f, a0 = 0.f, a1 = 0.f;
   int p = s0;

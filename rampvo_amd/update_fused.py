@@ -129,7 +129,7 @@ class FusedUpdate:
         return o32, ot, orl
 
     def seg(self, fg, groups, max_groups):
-        y = torch.zeros(max(max_groups, 1), 384, dtype=self.dtype, device=fg.device)
+        y = torch.empty(max(max_groups, 1), 384, dtype=self.dtype, device=fg.device)     # the kernel writes every row
         check(lib().ramp_upd_segment_softmax(ptr(fg), ptr(groups.order), ptr(groups.seg_start), ptr(groups.ngroups),
                                              ptr(y), int(max_groups), _code[self.dtype], stream()),
               "ramp_upd_segment_softmax")
@@ -174,9 +174,11 @@ class FusedUpdate:
         hy = self.lin(self.seg(self.lin(net_t, w["kk_fg"]), plan.g_kk, plan.max_kk), w["kk_h"])
         _, net_t = self.row_fuse(E, A=net32, B=hy, idxB32=plan.g_kk.gid, out_f32=net32, want_t=True)
         hy = self.lin(self.seg(self.lin(net_t, w["ij_fg"]), plan.g_ij, plan.max_ij), w["ij_h"])
-        x32, x_t = self.row_fuse(E, A=net32, B=hy, idxB32=plan.g_ij.gid, ln=w["ln1"], out_f32=net32, want_t=True)
+        fused_gru = "gru_pack" in w and self.use_mlp          # the chain kernel reads the fp32 stream only
+        x32, x_t = self.row_fuse(E, A=net32, B=hy, idxB32=plan.g_ij.gid, ln=w["ln1"], out_f32=net32,
+                                 want_t=not fused_gru)
         # gru = LN, GatedResidual, LN, GatedResidual (net.py:49-54)
-        if "gru_pack" in w and self.use_mlp:
+        if fused_gru:
             _, _, wptr, bptr = w["gru_pack"]
             out32 = torch.empty(E, 384, dtype=torch.float32, device=x32.device)
             relu_t = torch.empty(E, 384, dtype=self.dtype, device=x32.device)
