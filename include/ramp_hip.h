@@ -185,6 +185,13 @@ int ramp_motionmag(const float *poses, const float *patches, const float *intrin
  * poses[n] = Exp(damping * Log(poses[n-1] * poses[n-2]^-1)) * poses[n-1]                      */
 int ramp_motion_model(float *poses, int n, float damping, void *stream);
 
+/* The per-frame bookkeeping of Ramp_vo.__call__ (ramp/Ramp_vo.py:345-363: tstamps_[n], index_map_[n+1],
+ * intrinsics_[n], motion-model pose) as one launch.  motion: 0 = none, 1 = DAMPED_LINEAR (as above),
+ * 2 = poses[n] = poses[n-1]; copy_k: intrinsics[n] = intrinsics[n-1] (the caller writes the row itself when
+ * the intrinsics changed); tstamps / index_map may be NULL.                                       */
+int ramp_frame_begin(float *poses, int n, int motion, float damping, int64_t *tstamps, int64_t counter,
+                     int64_t *index_map, int64_t index_val, float *intrinsics, int copy_k, void *stream);
+
 /* Tracker bookkeeping helpers (host-side pointer arrays, <= 10 buffers per call).
  * ramp_multi_copy: dst[b][0:bytes[b]) = src[b][...] -- the per-frame stores of imap/gmap/fmap1/fmap2/
  *   patches/colors into the state buffers (ramp/Ramp_vo.py:345-381) in one launch.

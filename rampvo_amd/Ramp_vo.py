@@ -93,6 +93,26 @@ class Ramp_vo:
         self._ixm = None
         self._pre_cache = None                   # the next frame's graph (host + device arrays, plan), prepared by keyframe()
         self._up_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        # Frame pipelining (GPU, opt-in): when the caller guarantees that the tensors it hands to __call__ are
+        # complete (not still being produced on the current stream), the keyframe decision of frame t is left
+        # pending when __call__ returns, and frame t+1's front end -- which depends on nothing but the new input
+        # and the encoder's own recurrent state -- is launched on a side stream BEFORE the host waits for that
+        # decision: it then runs next to frame t's bundle adjustment (a few small blocks on a 256-CU chip).
+        # Results are unchanged; read public state through settle() (update/terminate/state_dict call it).
+        self.inputs_ready = False
+        self._pending = None
+        self._edge_tmpl = None
+        self._spec_ema = 1.0                     # running frequency of "keyframe removed" (see _keyframe_speculative)
+        # pinned host buffers for the speculative graph layouts: the host mirror of the graph is a view of one of
+        # them, the outcome(s) being prepared live in the others (fresh numpy buffers cost ~80 us of page faults
+        # per MB, pageable uploads another ~50 us)
+        self._pool = [None, None, None, None]
+        self._pool_busy = set()
+        self._mirror_pool = None
+        self._keep = (None, None)
+        self._fe_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        self._fe_free = None
+        self._ba_event = None
         self._mm_host = torch.empty(2, dtype=torch.float32).pin_memory() if dev.type == "cuda" else None
         self.net = torch.zeros(1, 0, DIM, dtype=torch.float, device=dev)   # hidden state is fp32 (as under autocast)
         self.ii = torch.zeros(0, dtype=torch.long, device=dev)
@@ -175,11 +195,17 @@ class Ramp_vo:
         return self._net_map if self._net_map is not None else np.arange(self._net_buf.shape[1], dtype=np.int64)
 
     # ----------------------------------------------------------------- snapshot
+    def settle(self):
+        """apply a keyframe decision left pending by the pipelined mode (see ``inputs_ready``)"""
+        if self._pending is not None:
+            self._keyframe_finish()
+
     def state_dict(self):
         """VO state as CPU tensors in the REFERENCE's layouts (NCHW feature buffers), so a
         snapshot can move between devices / implementations.  (The reference's VO state
         is not checkpointable; this is what bench.py uses to hand the steady state to
         the CPU baseline and what the teacher-forced parity tests inject.)"""
+        self.settle()
         n = self.n
         c = lambda t: t.detach().cpu().clone()
         return dict(
@@ -197,6 +223,7 @@ class Ramp_vo:
         return buf.permute(0, 3, 1, 2)
 
     def load_state_dict(self, sd):
+        self.settle()
         dev = self.device
         n = int(sd["n"])
         self.n, self.m, self.counter = n, int(sd["m"]), int(sd["counter"])
@@ -234,6 +261,7 @@ class Ramp_vo:
 
     def terminate(self):
         """interpolate the poses of dropped frames; returns (inverse poses [T,7], tstamps)"""
+        self.settle()
         self.traj = {}
         ts = self._tstamps[:self.n] if len(self._tstamps) >= self.n else self.tstamps_[:self.n].tolist()
         for i in range(self.n):
@@ -277,6 +305,17 @@ class Ramp_vo:
     def _new_edges(self, n1):
         """the factors frame n1-1 adds when it is accepted (reference :312-325, :394-395); host arrays"""
         r, M = self.cfg.PATCH_LIFETIME, self.M
+        if n1 >= r:
+            # steady state: the pattern of frame n1 is the pattern of frame r shifted by n1 - r frames
+            if self._edge_tmpl is None:
+                self._edge_tmpl = self._new_edges_at(r)
+            d = n1 - r
+            t_ii, t_jj, t_kk = self._edge_tmpl
+            return t_ii + d, t_jj + d, t_kk + M * d
+        return self._new_edges_at(n1)
+
+    def _new_edges_at(self, n1):
+        r, M = self.cfg.PATCH_LIFETIME, self.M
         kf, jf = np.meshgrid(np.arange(M * max(n1 - r, 0), M * max(n1 - 1, 0)), np.arange(n1 - 1, n1), indexing='ij')
         kb, jb = np.meshgrid(np.arange(M * max(n1 - 1, 0), M * n1), np.arange(max(n1 - r, 0), n1), indexing='ij')
         kk = np.concatenate([kf.reshape(-1), kb.reshape(-1)]).astype(np.int64)
@@ -312,10 +351,7 @@ class Ramp_vo:
             self._net_map, self._net_map_dev = b4[3, :tot], d4[3, :tot]
             self._plan = pre.get("plan")
             if self._plan is not None:                 # built on the upload stream: order it before this stream's use
-                cur = torch.cuda.current_stream()
-                cur.wait_stream(self._up_stream)
-                for t in self._plan.tensors():
-                    t.record_stream(cur)
+                torch.cuda.current_stream().wait_stream(self._up_stream)
             return
         if pre is not None:
             _, src, jj, ii, dev, map_dev = pre
@@ -470,6 +506,7 @@ class Ramp_vo:
         """drop keyframe n-KEYFRAME_INDEX if the motion around it is small, then cull factors older
         than REMOVAL_WINDOW (reference :237-274).  Both removals are decided on the host mirror and
         applied to the device state as ONE compaction."""
+        self.settle()
         if self.device.type == "cuda" and self._lazy_net:
             return self._keyframe_speculative()
         i = self.n - self.cfg.KEYFRAME_INDEX - 1
@@ -497,9 +534,9 @@ class Ramp_vo:
 
     def _keyframe_speculative(self):
         """GPU: the motion test is the frame's only device->host read, and at that point the GPU still has
-        most of update() queued.  While it drains, the host prepares BOTH outcomes -- edited graph, hidden-
-        state row map, the next frame's new edges -- and uploads them on a side stream; after the read-back
-        it only picks one.  (Doing this work after the read-back left the GPU idle for ~0.4 ms per frame.)"""
+        most of update() queued.  While it drains, the host prepares the outcome -- edited graph, hidden-
+        state row map, the next frame's new edges -- and uploads it on a side stream; after the read-back
+        it only adopts it.  (Doing this work after the read-back left the GPU idle for ~0.4 ms per frame.)"""
         cfg = self.cfg
         i, j = self.n - cfg.KEYFRAME_INDEX - 1, self.n - cfg.KEYFRAME_INDEX + 1
         k = self.n - cfg.KEYFRAME_INDEX
@@ -510,47 +547,87 @@ class Ramp_vo:
         done = torch.cuda.Event()
         done.record()
         dP = SE3(self.poses_[k]) * SE3(self.poses_[k - 1]).inv()      # only used if the keyframe goes
+        # steady motion gives the same answer frame after frame: only the more frequent outcome so far is
+        # prepared ahead; the other one is built after the read-back if the guess was wrong
+        guess = self._spec_ema >= 0.5
+        spec = {guess: self._spec_outcome(guess, k)}
+        self._pending = dict(done=done, spec=spec, k=k, dP=dP)
+        if not (self.inputs_ready and getattr(self.network.patchify, "_graphs", None)):
+            self._keyframe_finish()
+        else:
+            # pipelined: nothing hides host work after the read-back, so the guessed graph's plan is built now too
+            self._build_next_plan(spec[guess])
+
+    def _pool_take(self, nelem):
+        idx = next(i for i in range(len(self._pool)) if i not in self._pool_busy)
+        t = self._pool[idx]
+        if t is None or t.numel() < nelem:
+            t = self._pool[idx] = torch.empty(int(nelem * 1.25) + 1024, dtype=torch.long).pin_memory()
+        self._pool_busy.add(idx)
+        return idx, t
+
+    def _spec_outcome(self, remove, k):
+        """the graph after keyframe() for one outcome of the motion test, laid out together with the next frame's
+        new factors, on the host and (uploaded on the side stream) on the device"""
+        cfg = self.cfg
         base_rows = self._net_map            # None: identity
         E, M = len(self._ii), self.M
-        spec = {}
         with torch.cuda.stream(self._up_stream):
-            for remove in (True, False):
-                n_after = self.n - 1 if remove else self.n
-                n1 = n_after + 1
-                e_ii, e_jj, e_kk = self._new_edges(n1)
-                ne = len(e_kk)
-                # ONE host buffer / one upload per outcome: rows (ii, jj, kk, state row) of capacity E + ne;
-                # the factors kept by the edit come first, the next frame's new factors follow -- so the
-                # current graph is the [:Ek] view and the next frame's graph the [:Ek+ne] view of the same
-                # arrays, on the host and on the device
-                cap = E + ne
-                buf = np.empty((4, cap), np.int64)
-                rng = np.empty(4, np.int64)
-                Ek = _lib.lib().ramp_graph_edit_host(
-                    self._ii.ctypes.data, self._jj.ctypes.data, self._kk.ctypes.data,
-                    base_rows.ctypes.data if base_rows is not None else None, E, M, k if remove else -1, n_after,
-                    cfg.REMOVAL_WINDOW, buf.ctypes.data, cap, rng.ctypes.data)
-                assert Ek >= 0
-                # index ranges of the next frame's graph: kept factors (from the C pass) + the new ones (closed form)
-                r_ = cfg.PATCH_LIFETIME
-                k_lo, k_hi = M * max(n1 - r_, 0), M * n1
-                f_lo, f_hi = max(n1 - r_, 0), n1
-                if Ek > 0:
-                    k_lo, k_hi = min(k_lo, int(rng[0])), max(k_hi, int(rng[1]) + 1)
-                    f_lo, f_hi = min(f_lo, int(rng[2])), max(f_hi, int(rng[3]) + 1)
-                buf[0, Ek:Ek + ne] = e_ii
-                buf[1, Ek:Ek + ne] = e_jj
-                buf[2, Ek:Ek + ne] = e_kk
-                buf[3, Ek:Ek + ne] = -1
-                dev = self._upload(buf)
-                spec[remove] = dict(n1=n1, n=n_after, Ek=Ek, ne=ne, host=buf, dev=dev, ranges=(k_lo, k_hi, f_lo, f_hi))
-        done.synchronize()
+            n_after = self.n - 1 if remove else self.n
+            n1 = n_after + 1
+            e_ii, e_jj, e_kk = self._new_edges(n1)
+            ne = len(e_kk)
+            # ONE host buffer / one upload per outcome: rows (ii, jj, kk, state row) of capacity E + ne;
+            # the factors kept by the edit come first, the next frame's new factors follow -- so the
+            # current graph is the [:Ek] view and the next frame's graph the [:Ek+ne] view of the same
+            # arrays, on the host and on the device
+            cap = E + ne
+            pool, flat = self._pool_take(4 * cap)
+            flat = flat[:4 * cap].view(4, cap)
+            buf = flat.numpy()
+            rng = np.empty(4, np.int64)
+            Ek = _lib.lib().ramp_graph_edit_host(
+                self._ii.ctypes.data, self._jj.ctypes.data, self._kk.ctypes.data,
+                base_rows.ctypes.data if base_rows is not None else None, E, M, k if remove else -1, n_after,
+                cfg.REMOVAL_WINDOW, buf.ctypes.data, cap, rng.ctypes.data)
+            assert Ek >= 0
+            # index ranges of the next frame's graph: kept factors (from the C pass) + the new ones (closed form)
+            r_ = cfg.PATCH_LIFETIME
+            k_lo, k_hi = M * max(n1 - r_, 0), M * n1
+            f_lo, f_hi = max(n1 - r_, 0), n1
+            if Ek > 0:
+                k_lo, k_hi = min(k_lo, int(rng[0])), max(k_hi, int(rng[1]) + 1)
+                f_lo, f_hi = min(f_lo, int(rng[2])), max(f_hi, int(rng[3]) + 1)
+            buf[0, Ek:Ek + ne] = e_ii
+            buf[1, Ek:Ek + ne] = e_jj
+            buf[2, Ek:Ek + ne] = e_kk
+            buf[3, Ek:Ek + ne] = -1
+            dev = torch.empty((4, cap), dtype=torch.long, device=self.device)
+            dev.copy_(flat, non_blocking=True)
+            return dict(n1=n1, n=n_after, Ek=Ek, ne=ne, host=buf, dev=dev, ranges=(k_lo, k_hi, f_lo, f_hi), pool=pool)
+
+    def _keyframe_finish(self):
+        """second half of keyframe(): wait for the motion test, pick the prepared outcome"""
+        cfg = self.cfg
+        pend, self._pending = self._pending, None
+        spec, k, dP = pend["spec"], pend["k"], pend["dP"]
+        pend["done"].synchronize()
         mmh = self._mm_host.numpy()
         remove = float((mmh[0] + mmh[1]) * np.float32(0.5)) < cfg.KEYFRAME_THRESH      # fp32 mean, as torch's
-        pre = spec[remove]
-        cur = torch.cuda.current_stream()
-        cur.wait_stream(self._up_stream)
-        pre["dev"].record_stream(cur)              # allocated on the side stream, consumed on this one
+        pre = spec.get(remove)
+        if pre is None:
+            pre = self._spec_outcome(remove, k)
+        self._spec_ema = 0.9 * self._spec_ema + (0.1 if remove else 0.0)
+        for other in spec.values():               # host buffers: the adopted layout becomes the mirror
+            if other is not pre:
+                self._pool_busy.discard(other["pool"])
+        self._pool_busy.discard(self._mirror_pool)
+        self._mirror_pool = pre["pool"]
+        torch.cuda.current_stream().wait_stream(self._up_stream)
+        # arrays and plan were allocated on the side stream and are consumed on this one: instead of
+        # record_stream() on ~15 tensors they are simply kept alive for two frames -- every consumer of frame t
+        # has finished when frame t+1's motion test has been read back
+        self._keep = (self._keep[1], pre)
         if remove:
             t0, t1 = self._tstamps[k - 1], self._tstamps[k]
             self.delta[t1] = (t0, dP)
@@ -562,7 +639,7 @@ class Ramp_vo:
         self._plan = None
         # the next frame's graph is known now; its plan is built by _track() right after the next front end has
         # been enqueued (side stream), so nothing but the selection sits between the read-back and that launch
-        pre["plan"] = None
+        pre.setdefault("plan", None)
         self._pre_cache = pre
 
     def _build_next_plan(self, pre):
@@ -575,6 +652,7 @@ class Ramp_vo:
 
     # ------------------------------------------------------------------- update
     def update(self):
+        self.settle()
         with Timer("other", enabled=self.enable_timing):
             plan = self._graph_plan()
             coords = self.reproject()
@@ -599,6 +677,11 @@ class Ramp_vo:
                 target = coords[..., self.P // 2, self.P // 2] + delta.float()
                 weight = filter_features(confidences=weight, target=target, data_shape=(self.ht // 4, self.wd // 4))
             self.last_weight = weight
+            if self.inputs_ready and self.device.type == "cuda":
+                # the next frame's front end may start here: next to BA's small kernels, not next to the
+                # bandwidth-bound update operator (starting it earlier slowed those kernels by more than it hid)
+                self._ba_event = torch.cuda.Event()
+                self._ba_event.record()
         with Timer("BA", enabled=self.enable_timing):
             t0 = self.n - self.cfg.OPTIMIZATION_WINDOW if self.is_initialized else 1
             t0 = max(t0, 1)
@@ -624,14 +707,32 @@ class Ramp_vo:
     def _track(self, tstamp, input_, intrinsics):
         mask = input_[2]
         accepts = mask is None or bool(mask)
+        fe_done = None
+        if self._pending is not None:
+            # pipelined: this frame's front end goes out first, on its own stream, next to what is left of the
+            # previous frame; only then does the host wait for the previous frame's keyframe decision
+            cur, fe = torch.cuda.current_stream(), self._fe_stream
+            if self._fe_free is not None:
+                fe.wait_event(self._fe_free)          # the previous frame has copied the static outputs away
+            if self._ba_event is not None:
+                fe.wait_event(self._ba_event)
+            with torch.cuda.stream(fe):
+                fmap, gmap, imap, patches, _, clr = self.network.patchify(
+                    input_=input_, patches_per_image=self.cfg.PATCHES_PER_FRAME, event_bias=self.event_bias,
+                    reinit_hidden=False)
+            fe_done = torch.cuda.Event()
+            fe_done.record(fe)
+            self._keyframe_finish()
+            cur.wait_event(fe_done)
         pre = self._prefetch_edges() if (accepts and self.device.type == "cuda") else None
         kq = intrinsics.detach().cpu().float().numpy() / self.RES
         k_dev = None
         if accepts and not (getattr(self, "_last_K", None) is not None and np.array_equal(kq, self._last_K)):
             k_dev = self._upload(kq.astype(np.float32))
-        fmap, gmap, imap, patches, _, clr = self.network.patchify(
-            input_=input_, patches_per_image=self.cfg.PATCHES_PER_FRAME, event_bias=self.event_bias,
-            reinit_hidden=True if tstamp == 0 else False)
+        if fe_done is None:
+            fmap, gmap, imap, patches, _, clr = self.network.patchify(
+                input_=input_, patches_per_image=self.cfg.PATCHES_PER_FRAME, event_bias=self.event_bias,
+                reinit_hidden=True if tstamp == 0 else False)
         if isinstance(pre, dict) and pre.get("plan") is None:
             self._build_next_plan(pre)
         mask = input_[2]
@@ -642,32 +743,41 @@ class Ramp_vo:
         self.tlist.append(tstamp)
         del self._tstamps[n:]
         self._tstamps.append(self.counter)
-        self.tstamps_[n].fill_(self.counter)              # fill kernels: no blocking host->device copy
-        self.index_map_[n + 1].fill_(self.m + self.M)
-        if k_dev is None and n > 0:
-            self.intrinsics_[n] = self.intrinsics_[n - 1]     # unchanged intrinsics: device-side row copy
+        if self.device.type == "cuda":
+            # time stamp, index map, intrinsics row and motion-model pose: one launch
+            copy_k = k_dev is None and n > 0
+            if not copy_k:
+                self.intrinsics_[n] = k_dev if k_dev is not None else self._upload(kq.astype(np.float32))
+                self._last_K = kq
+            motion = 0 if n <= 1 else (1 if self.cfg.MOTION_MODEL == 'DAMPED_LINEAR' else 2)
+            ops.frame_begin(self.poses_, n, motion, self.cfg.MOTION_DAMPING, self.tstamps_, self.counter,
+                            self.index_map_, self.m + self.M, self.intrinsics_, copy_k)
         else:
-            self.intrinsics_[n] = k_dev if k_dev is not None else self._upload(kq.astype(np.float32))
-            self._last_K = kq
-
-        if n > 1:
-            if self.cfg.MOTION_MODEL == 'DAMPED_LINEAR' and self.device.type == "cuda":
-                ops.motion_model(self.poses_, n, self.cfg.MOTION_DAMPING)     # one fused kernel
-            elif self.cfg.MOTION_MODEL == 'DAMPED_LINEAR':
-                P1 = SE3(self.poses_[n - 1])
-                P2 = SE3(self.poses_[n - 2])
-                xi = self.cfg.MOTION_DAMPING * (P1 * P2.inv()).log()
-                self.poses_[n] = (SE3.exp(xi) * P1).data
+            self.tstamps_[n].fill_(self.counter)
+            self.index_map_[n + 1].fill_(self.m + self.M)
+            if k_dev is None and n > 0:
+                self.intrinsics_[n] = self.intrinsics_[n - 1]     # unchanged intrinsics: device-side row copy
             else:
-                self.poses_[n] = self.poses_[n - 1]
+                self.intrinsics_[n] = k_dev if k_dev is not None else self._upload(kq.astype(np.float32))
+                self._last_K = kq
+            if n > 1:
+                if self.cfg.MOTION_MODEL == 'DAMPED_LINEAR':
+                    P1 = SE3(self.poses_[n - 1])
+                    P2 = SE3(self.poses_[n - 2])
+                    xi = self.cfg.MOTION_DAMPING * (P1 * P2.inv()).log()
+                    self.poses_[n] = (SE3.exp(xi) * P1).data
+                else:
+                    self.poses_[n] = self.poses_[n - 1]
 
-        patches[:, :, 2] = self._initial_depth(patches)
+        draw = self._initial_depth(patches)          # reference :369 (drawn every frame, also when overwritten below)
         if self.is_initialized:
             if (self.device.type == "cuda" and patches.is_contiguous() and patches.dtype == torch.float32
                     and ops.depth_median_supported(3, self.M, self.P)):
                 ops.depth_median_fill(self.patches_, n, 3, patches[0])       # radix select + fill, one launch
             else:
                 patches[:, :, 2] = torch.median(self.patches_[n - 3:n, :, 2])
+        else:
+            patches[:, :, 2] = draw
 
         slot = n % self.mem
         ex = getattr(self.network.patchify, "_extra", None)
@@ -691,6 +801,9 @@ class Ramp_vo:
                 self.fmap1_[slot] = f[0].permute(1, 2, 0).to(self.dtype)
                 self.fmap2_[slot] = F.avg_pool2d(f, 4, 4)[0].permute(1, 2, 0).to(self.dtype)
 
+        if self.inputs_ready and self.device.type == "cuda":
+            self._fe_free = torch.cuda.Event()
+            self._fe_free.record()
         self.counter += 1
         if n > 0 and not self.is_initialized:
             if self.motion_probe() < 2.0:

@@ -427,20 +427,21 @@ int ramp_graph_edit_host(const int64_t *ii, const int64_t *jj, const int64_t *kk
   int64_t kmin = INT64_MAX, kmax = INT64_MIN, fmin = INT64_MAX, fmax = INT64_MIN;
   int64_t *oi = out, *oj = out + cap, *ok = out + 2 * (size_t)cap, *orow = out + 3 * (size_t)cap;
   const int64_t oldest = (int64_t)n_after - removal_window;
+  // kk >= 0: kk / M < oldest  <=>  kk < oldest * M (never when oldest <= 0); no division, no branches in the loop
+  const int64_t kcut = oldest > 0 ? oldest * (int64_t)M : 0;
+  const int64_t kr = k_remove >= 0 ? (int64_t)k_remove : INT64_MAX;
   int m = 0;
   for (int e = 0; e < E; e++) {
     int64_t i = ii[e], j = jj[e], q = kk[e];
-    if (k_remove >= 0) {
-      if (i == k_remove || j == k_remove) continue;
-      if (i > k_remove) { i -= 1; q -= M; }
-      if (j > k_remove) j -= 1;
-    }
-    if (q / M < oldest) continue;
+    const bool hit = (i == kr) | (j == kr);
+    const int64_t gi = i > kr, gj = j > kr;
+    i -= gi; q -= gi * M; j -= gj;
+    const bool keep = !hit & (q >= kcut);
     oi[m] = i; oj[m] = j; ok[m] = q; orow[m] = rows_in ? rows_in[e] : (int64_t)e;
-    kmin = q < kmin ? q : kmin; kmax = q > kmax ? q : kmax;
     const int64_t lo = i < j ? i : j, hi = i < j ? j : i;
-    fmin = lo < fmin ? lo : fmin; fmax = hi > fmax ? hi : fmax;
-    m++;
+    kmin = (keep & (q < kmin)) ? q : kmin; kmax = (keep & (q > kmax)) ? q : kmax;
+    fmin = (keep & (lo < fmin)) ? lo : fmin; fmax = (keep & (hi > fmax)) ? hi : fmax;
+    m += keep;
   }
   if (ranges) { ranges[0] = kmin; ranges[1] = kmax; ranges[2] = fmin; ranges[3] = fmax; }   // of the kept factors
   return m;

@@ -302,6 +302,30 @@ __global__ void motion_model_kernel(float *poses, int n, float damping) {
   for (int c = 0; c < 7; c++) poses[7 * n + c] = Pn[c];
 }
 
+// Per-frame bookkeeping of Ramp_vo.__call__ (ramp/Ramp_vo.py:345-363) as ONE launch: time stamp, patch index
+// map, intrinsics row (copied from the previous frame when unchanged) and the motion-model pose of frame n.
+// motion: 0 = leave poses[n]; 1 = DAMPED_LINEAR; 2 = copy poses[n-1]
+__global__ void frame_begin_kernel(float *poses, int n, int motion, float damping, int64_t *tstamps, int64_t counter,
+                                   int64_t *index_map, int64_t index_val, float *intrinsics, int copy_k) {
+  const int t = threadIdx.x;
+  if (t == 0) {
+    if (tstamps) tstamps[n] = counter;
+    if (index_map) index_map[n + 1] = index_val;
+  }
+  if (copy_k && t < 4) intrinsics[4 * n + t] = intrinsics[4 * (n - 1) + t];
+  if (motion == 2 && t < 7) poses[7 * n + t] = poses[7 * (n - 1) + t];
+  if (motion != 1 || t != 0) return;
+  float P1[7], P2[7], P2i[7], D[7], xi[6], E[7], Pn[7];
+  for (int c = 0; c < 7; c++) { P1[c] = poses[7 * (n - 1) + c]; P2[c] = poses[7 * (n - 2) + c]; }
+  lt_inv(P2, P2i);
+  lt_mul(P1, P2i, D);
+  lt_log(D, xi);
+  for (int c = 0; c < 6; c++) xi[c] = damping * xi[c];
+  lt_exp(xi, E);
+  lt_mul(E, P1, Pn);
+  for (int c = 0; c < 7; c++) poses[7 * n + c] = Pn[c];
+}
+
 // ---- small multi-buffer copies (tracker bookkeeping: one launch instead of ~10-20 tiny ATen ops)
 #define RAMP_MAXBUF 10
 struct CopyDesc {
@@ -398,6 +422,15 @@ int ramp_motionmag(const float *poses, const float *patches, const float *intrin
   hipLaunchKernelGGL(motionmag_kernel<3>, dim3(2), dim3(256), 0, (hipStream_t)stream, poses, patches,
                      intrinsics, ii, jj, kk, order, seg, ukeys, ngroups, (long)key_ij, (long)key_ji, beta,
                      out2);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+int ramp_frame_begin(float *poses, int n, int motion, float damping, int64_t *tstamps, int64_t counter,
+                     int64_t *index_map, int64_t index_val, float *intrinsics, int copy_k, void *stream) {
+  if (!poses || n < 0 || (motion == 1 && n < 2) || ((motion == 2 || copy_k) && n < 1) || (copy_k && !intrinsics))
+    return RAMP_EINVAL;
+  hipLaunchKernelGGL(frame_begin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, poses, n, motion, damping,
+                     tstamps, counter, index_map, index_val, intrinsics, copy_k);
   RAMP_CHECK_LAUNCH();
   return RAMP_OK;
 }

@@ -42,7 +42,35 @@ __device__ __forceinline__ void mlp_gemm(const _Float16 *Xs, const _Float16 *con
     for (int mt = 0; mt < 4; mt++)
 #pragma unroll
       for (int nt = 0; nt < MNTW; nt++) acc[b][mt][nt] = (f4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
+#ifndef MLP_PREFETCH
+#define MLP_PREFETCH 0
+#endif
+#ifndef MLP_UNROLL
+#define MLP_UNROLL 2
+#endif
+#if MLP_PREFETCH
+  // weight fragments of K step ks+1 are in flight while the matrix cores work on step ks
+  h8 bn[NB][MNTW];
+#pragma unroll
+  for (int b = 0; b < NB; b++)
+#pragma unroll
+    for (int nt = 0; nt < MNTW; nt++)
+      bn[b][nt] = *reinterpret_cast<const h8 *>(wp[b] + (((size_t)(wave * MNTW + nt)) * 64 + lane) * 8);
+#pragma unroll MLP_UNROLL
+  for (int ks = 0; ks < MKS; ks++) {
+    h8 a[4], bw[NB][MNTW];
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+#pragma unroll
+      for (int nt = 0; nt < MNTW; nt++) bw[b][nt] = bn[b][nt];
+    const int kn = ks + 1 < MKS ? ks + 1 : ks;
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+#pragma unroll
+      for (int nt = 0; nt < MNTW; nt++)
+        bn[b][nt] = *reinterpret_cast<const h8 *>(wp[b] + (((size_t)kn * (MD / 16) + wave * MNTW + nt) * 64 + lane) * 8);
+#else
+#pragma unroll MLP_UNROLL
   for (int ks = 0; ks < MKS; ks++) {
     h8 a[4], bw[NB][MNTW];
 #pragma unroll
@@ -50,6 +78,7 @@ __device__ __forceinline__ void mlp_gemm(const _Float16 *Xs, const _Float16 *con
 #pragma unroll
       for (int nt = 0; nt < MNTW; nt++)
         bw[b][nt] = *reinterpret_cast<const h8 *>(wp[b] + (((size_t)ks * (MD / 16) + wave * MNTW + nt) * 64 + lane) * 8);
+#endif
 #pragma unroll
     for (int mt = 0; mt < 4; mt++) a[mt] = *reinterpret_cast<const h8 *>(Xs + (mt * 16 + j) * MXS + ks * 32 + 8 * q);
 #pragma unroll

@@ -283,6 +283,16 @@ def motion_model(poses, n, damping):
     check(lib().ramp_motion_model(ptr(poses), int(n), float(damping), stream()), "ramp_motion_model")
 
 
+def frame_begin(poses, n, motion, damping, tstamps, counter, index_map, index_val, intrinsics, copy_k):
+    """one launch for the per-frame bookkeeping (reference Ramp_vo.py:345-363); see include/ramp_hip.h"""
+    require_cuda(poses, tstamps, index_map, intrinsics)
+    assert poses.dtype == torch.float32 and poses.is_contiguous() and intrinsics.is_contiguous()
+    assert tstamps.dtype == torch.long and index_map.dtype == torch.long
+    check(lib().ramp_frame_begin(ptr(poses), int(n), int(motion), float(damping), ptr(tstamps), int(counter),
+                                 ptr(index_map), int(index_val), ptr(intrinsics), int(bool(copy_k)), stream()),
+          "ramp_frame_begin")
+
+
 # --------------------------------------------------------------------- graph
 class Groups:
     """result of group_by: order/gid/seg_start/ukeys/ngroups (device tensors)"""

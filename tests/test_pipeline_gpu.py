@@ -101,3 +101,35 @@ def test_full_size_update_step_against_cpu_oracle():
     print(e)
     assert e["net"] <= 1e-4 and e["weight"] <= 1e-4, e
     assert e["poses"] <= 1e-4 * scale and e["depths"] <= 1e-4 * scale, e
+
+
+@torch.no_grad()
+def test_frame_pipelining_does_not_change_results():
+    """Ramp_vo.inputs_ready (front end of frame t+1 launched before the host waits for frame t's keyframe
+    decision, on its own stream) is scheduling only: same graph, same poses, same depths -- bit for bit."""
+    from rampvo_amd.config import make_cfg
+    from rampvo_amd.Ramp_vo import Ramp_vo
+    from rampvo_amd.synthetic import SyntheticStream, make_network
+    T = 30
+    stream = SyntheticStream(240, 320, T, seed=77, device="cuda")
+    frames = [stream.frame(t) for t in range(T)]
+    torch.cuda.synchronize()
+    out = []
+    for ready in (False, True):
+        torch.manual_seed(5)
+        slam = Ramp_vo(make_cfg("default", PATCHES_PER_FRAME=48, MIXED_PRECISION=True),
+                       make_network("SingleScale"), {"event_bias": True}, ht=240, wd=320)
+        slam.inputs_ready = ready
+        pipelined = 0
+        for t, (im, ev, K, mask) in enumerate(frames):
+            slam(t, input_tensor=(ev, im, mask), intrinsics=K)
+            pipelined += slam._pending is not None
+        assert (pipelined > 5) == ready, pipelined
+        slam.update()                                   # settles the pending decision first
+        traj, ts = slam.terminate()
+        out.append((slam.n, slam._ii.copy(), slam._kk.copy(), slam.poses_[:slam.n].cpu().numpy(),
+                    slam.patches_[:slam.n].cpu().numpy(), traj, ts))
+    a, b = out
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    for x, y in zip(a[3:], b[3:]):
+        assert np.array_equal(x, y)

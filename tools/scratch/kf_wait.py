@@ -1,3 +1,4 @@
+"""host time per frame vs. time spent waiting for the keyframe decision; usage: kf_wait.py [pipeline 0|1]"""
 import sys, time; sys.path.insert(0, '/root/repo')
 import torch
 from rampvo_amd.config import make_cfg
@@ -5,10 +6,11 @@ from rampvo_amd.Ramp_vo import Ramp_vo
 from rampvo_amd.synthetic import SyntheticStream, make_network
 cfg = make_cfg("default", PATCHES_PER_FRAME=96, MIXED_PRECISION=True)
 slam = Ramp_vo(cfg, make_network("SingleScale"), {"event_bias": True})
-T = 120
+slam.inputs_ready = len(sys.argv) > 1 and sys.argv[1] == "1"
+T = 200
 stream = SyntheticStream(480, 640, T + 1, seed=1234, device="cuda")
 frames = [stream.frame(t) for t in range(T)]
-acc = {"wait": 0.0, "n": 0, "spec": 0.0}
+acc = {"wait": 0.0, "n": 0}
 on = [False]
 orig = torch.cuda.Event.synchronize
 def sync(self):
@@ -16,16 +18,11 @@ def sync(self):
     if on[0]: acc["wait"] += time.perf_counter() - t; acc["n"] += 1
     return r
 torch.cuda.Event.synchronize = sync
-ge = slam._graph_edit
-def graph_edit(rem):
-    t = time.perf_counter(); r = ge(rem)
-    if on[0]: acc["spec"] += time.perf_counter() - t
-    return r
-slam._graph_edit = graph_edit
 for t in range(T):
     if t == 80:
         torch.cuda.synchronize(); on[0] = True; t0 = time.perf_counter()
     im, ev, K, mask = frames[t]; slam(t, input_tensor=(ev, im, mask), intrinsics=K)
-torch.cuda.synchronize(); dt = time.perf_counter() - t0
+slam.settle(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
 n = T - 80
-print("step %.3f ms; event wait %.3f ms/step (%d waits); _graph_edit (both branches) %.3f ms/step" % (1e3 * dt / n, 1e3 * acc["wait"] / n, acc["n"], 1e3 * acc["spec"] / n))
+print("pipeline %d: step %.3f ms; event wait %.3f ms/step (%d waits); host busy %.3f ms/step"
+      % (slam.inputs_ready, 1e3 * dt / n, 1e3 * acc["wait"] / n, acc["n"], 1e3 * (dt - acc["wait"]) / n))
