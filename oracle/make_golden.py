@@ -294,10 +294,78 @@ def gen_event_stack(ns):
     print("event_stack: hot pixel ->", out[0, 9, 7], " range", out.min(), out.max())
 
 
+@torch.no_grad()
+def gen_pose_pred(ns):
+    """helpers of the pose-prediction mode (ramp/pose_prediction/pose_pred_utils.py) called in the order
+    Ramp_vo.predict_future_pose (ramp/Ramp_vo.py:450-496) calls them, on the state the reference tracker
+    reaches on the RAMPVO stream.  (predict_future_pose itself is not a usable oracle: it hands the whole
+    [1,E,2,3,3] coords tensor to cuda_ba as ``target``, which views it as [-1,2] and reads the first E rows --
+    fastba/ba_cuda.cu:462 -- so its BA step runs on scrambled targets.)"""
+    import importlib
+    pp = importlib.import_module("ramp.pose_prediction.pose_pred_utils")
+    p = RAMPVO
+    net = ref_network(ns, "SingleScale")
+    cfg = ns.CfgNode(make_cfg("default", PATCHES_PER_FRAME=p["M"], MIXED_PRECISION=False))
+    stream = SyntheticStream(p["H"], p["W"], p["T"], seed=p["seed"])
+    frame_no = [0]
+    orig_rand_like = torch.rand_like
+
+    def fake_rand_like(x, *a, **k):
+        return depth_draw(frame_no[0], x.shape[1]).to(x.dtype).expand_as(x).clone()
+
+    with rh.CudaToCpu():
+        slam = ns.Ramp_vo.Ramp_vo(cfg=cfg, network=net, train_cfg={"event_bias": True}, ht=p["H"], wd=p["W"])
+        torch.rand_like = fake_rand_like
+        try:
+            for t in range(p["T"]):
+                image, events, K, mask = stream.frame(t)
+                frame_no[0] = t
+                slam(t, input_tensor=(events, image, mask), intrinsics=K)
+        finally:
+            torch.rand_like = orig_rand_like
+        n = slam.n
+        next_frame_number, next_frame_index = n + 1, n
+        step, frequency, deg = 2, 30, 3
+        poses = slam.poses.clone()
+        boot = pp.motion_bootstrap(poses=poses[0, ...], n=slam.n, MOTION_MODEL=slam.cfg.MOTION_MODEL,
+                                   MOTION_DAMPING=slam.cfg.MOTION_DAMPING)
+        poses[:, next_frame_index] = boot
+        intrinsics = slam.intrinsics.clone()
+        intrinsics[:, next_frame_index] = intrinsics[:, next_frame_index - 1]
+        inp = dict(n=n, M=slam.M, r=slam.cfg.PATCH_LIFETIME, ii=slam.ii.numpy().copy(), jj=slam.jj.numpy().copy(),
+                   kk=slam.kk.numpy().copy(), ix=slam.ix.numpy().copy(), last_weight=slam.last_weight.numpy().copy(),
+                   tstamps=slam.tstamps_.numpy().copy(), poses_in=slam.poses.numpy().copy(),
+                   step=step, frequency=frequency, deg=deg, ht=slam.ht, wd=slam.wd)
+        ii, jj, kk, w_up = pp.add_forward_elements(frame_num=next_frame_number, patch_extracted_num=slam.M,
+                                                   ii=slam.ii, jj=slam.jj, kk=slam.kk, ix=slam.ix,
+                                                   r=slam.cfg.PATCH_LIFETIME, weights=slam.last_weight.clone())
+        coords = slam.reproject(indicies=(ii, jj, kk), poses=poses, patches=slam.patches.clone(), intrinsics=intrinsics)
+        coords_in = coords.numpy().copy()
+        tracks = pp.compute_patch_track__(coords=coords, ii=ii, jj=jj, kk=kk, image_to_proj=next_frame_index)
+        models = pp.fit_model_patch_track(next_frame_index=next_frame_index, patch_dict=tracks,
+                                          img_to_keyframe_map=slam.tstamps_, ii=ii, jj=jj,
+                                          data_shape=(slam.ht, slam.wd), frequency=frequency, deg=deg)
+        ret = pp.predict_patch_on_model(patch_models=models, step_to_pred_future=step, frequency=frequency,
+                                        next_frame_index=next_frame_index, coords=coords, weights=w_up,
+                                        ii=ii, jj=jj, kk=kk)
+        assert ret[0].data_ptr() == coords.data_ptr() and ret[1].data_ptr() == w_up.data_ptr()   # in place
+    keys = np.array(list(tracks.keys()), np.int64)
+    lens = np.array([len(tracks[tuple(k)]) for k in keys.tolist()], np.int64)
+    flat = np.concatenate([tracks[tuple(k)].numpy() for k in keys.tolist()], 0)
+    np.savez_compressed(os.path.join(OUT, "pose_pred.npz"), **inp, boot=boot.numpy(), ii2=ii.numpy(), jj2=jj.numpy(),
+                        kk2=kk.numpy(), w_up_shape=np.array(w_up.shape), coords_in=coords_in, track_keys=keys,
+                        track_lens=lens, track_xy=flat, coords_out=coords.numpy(), weights_out=w_up.numpy())
+    print("pose_pred ok: n", n, "E", len(inp["ii"]), "->", len(ii), "tracks", len(keys),
+          "changed edges", int((coords_in != coords.numpy()).any(axis=(0, 2, 3, 4)).sum()))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = rh.load()
+    if len(sys.argv) > 1 and sys.argv[1] == "pose_pred":
+        return gen_pose_pred(ns)
     gen_event_stack(ns)
+    gen_pose_pred(ns)
     gen_patchify(ns, "SingleScale")
     gen_patchify(ns, "MultiScale")
     gen_update(ns)

@@ -3,9 +3,9 @@
 Same plugin surface as the reference class -- ``Ramp_vo(cfg, network, train_cfg,
 ht, wd)``, ``slam(t, input_tensor=(events, image, mask), intrinsics=K)``,
 ``slam.update()``, ``slam.terminate()``, attributes ``points_ / colors_ / m / n /
-poses_ / patches_`` -- so ``evaluate.py::run`` drives it unchanged.  The
-pose-prediction mode (reference :414-534) is off in every shipped config and not
-provided.
+poses_ / patches_`` -- so ``evaluate.py::run`` drives it unchanged; the
+pose-prediction mode (reference :414-534, ``evaluate.py::run_pose_pred``) is at the
+end of the class.
 
 MI355X-first differences that do not change results:
   * feature ring buffers are channels-last (one pixel's 128 channels contiguous);
@@ -126,6 +126,8 @@ class Ramp_vo:
 
         self.poses_[:, 6] = 1.0
         self.delta = {}
+        self.patch_dict_ = None          # pose-prediction mode (reference :34-35)
+        self.patches_models = None
         self._ba_info = torch.zeros(1, dtype=torch.int32, device=dev)
 
     # ------------------------------------------------------------------ weights
@@ -826,6 +828,88 @@ class Ramp_vo:
         elif self.is_initialized:
             self.update()
             self.keyframe()
+
+    # -------------------------------------------------------- pose prediction
+    def _virtual_frame(self, last_keyframe_number):
+        """graph, poses and intrinsics extended by a virtual keyframe whose pose is the motion model's
+        (reference :416-444 / :452-479)"""
+        from .pose_prediction.pose_pred_utils import add_forward_elements, motion_bootstrap
+        self.settle()
+        next_frame_number = last_keyframe_number + 1       # number starting from 1
+        next_frame_index = next_frame_number - 1           # index starting from 0
+        poses = self.poses.clone()
+        poses[:, next_frame_index] = motion_bootstrap(poses=poses[0, ...], n=self.n,
+                                                      MOTION_MODEL=self.cfg.MOTION_MODEL,
+                                                      MOTION_DAMPING=self.cfg.MOTION_DAMPING)
+        intrinsics = self.intrinsics.clone()
+        intrinsics[:, next_frame_index] = intrinsics[:, next_frame_index - 1]
+        patches = self.patches.clone()
+        ii, jj, kk, weights_up = add_forward_elements(
+            frame_num=next_frame_number, patch_extracted_num=self.M, ii=self.ii, jj=self.jj, kk=self.kk, ix=self.ix,
+            r=self.cfg.PATCH_LIFETIME, weights=self.last_weight.clone())
+        coords = self.reproject(indicies=(ii, jj, kk), poses=poses, patches=patches, intrinsics=intrinsics)
+        return next_frame_number, next_frame_index, poses, patches, intrinsics, (ii, jj, kk), weights_up, coords
+
+    def efficient_pose_prediction(self, sec_to_pred_future, abs_time, last_keyframe_number, deg=3, frequency=30):
+        """reference :416-444: builds the virtual frame and its reprojections and stops there (returns None)"""
+        self._virtual_frame(last_keyframe_number)
+
+    def predict_future_pose(self, sec_to_pred_future, abs_time, last_keyframe_number, deg=3, frequency=30):
+        """Extrapolate a virtual keyframe ``sec_to_pred_future`` frames past the last real one (reference
+        :447-507, driven by evaluate.py::run_pose_pred): motion-model pose, one extra factor per live patch,
+        per-patch spline models of the past reprojections (fitted once, on the first call), two BA iterations
+        on the predicted targets, then the pose is appended so that terminate() interpolates through it.
+
+        Deviation, on purpose: upstream passes the whole predicted ``coords`` tensor [1,E,2,3,3] as BA's
+        ``target``; cuda_ba views it as [-1,2] and reads its first E rows (fastba/ba_cuda.cu:462), i.e. pairs of
+        neighbouring x values of the first E/9 factors, and the predicted grids are written with x and y
+        exchanged (pose_pred_utils.py:342).  Here BA gets what Ramp_vo.update() gives it -- the patch centres
+        [1,E,2], channel 0 = x -- for the same factors and weights."""
+        from .pose_prediction.pose_pred_utils import (compute_patch_track__, fit_model_patch_track,
+                                                      predict_patch_on_model)
+        (next_frame_number, next_frame_index, poses, patches, intrinsics, (ii, jj, kk), weights_up,
+         coords) = self._virtual_frame(last_keyframe_number)
+        if self.patch_dict_ is None:
+            self.patch_dict_ = compute_patch_track__(coords=coords, ii=ii, jj=jj, kk=kk,
+                                                     image_to_proj=next_frame_index)
+        if self.patches_models is None:
+            self.patches_models = fit_model_patch_track(
+                next_frame_index=next_frame_index, patch_dict=self.patch_dict_, img_to_keyframe_map=self.tstamps_,
+                ii=ii, jj=jj, data_shape=(self.ht, self.wd), frequency=frequency, deg=deg)
+        coords, updated_weight = predict_patch_on_model(
+            patch_models=self.patches_models, step_to_pred_future=sec_to_pred_future, frequency=frequency,
+            next_frame_index=next_frame_index, coords=coords, weights=weights_up, ii=ii, jj=jj, kk=kk,
+            reference_layout=False)
+        target = coords[..., self.P // 2, self.P // 2].contiguous()
+        t0 = max(next_frame_number - self.cfg.OPTIMIZATION_WINDOW if self.is_initialized else 1, 1)
+        t1 = next_frame_number
+        try:
+            fastba.BA(poses, patches, intrinsics, target, updated_weight.contiguous(), self.lmbda, ii, jj, kk, t0, t1,
+                      M=self.M, iterations=2, eff_impl=False, info=self._ba_info)
+        except Exception as e:
+            print(f"WARNING: BA failed...{e}")
+        self.update_attributes(abs_time=abs_time, next_frame_index=next_frame_index, poses=poses)
+
+    def update_attributes(self, abs_time, next_frame_index, poses):
+        """expose the virtual pose to terminate() (reference :510-519)"""
+        assert self._tstamps[self.n - 1] != 0 if self._tstamps else int(self.tstamps_[self.n - 1]) != 0
+        self.tstamps_[self.n] = abs_time
+        del self._tstamps[self.n:]
+        self._tstamps.append(int(abs_time))
+        self.poses_[self.n] = poses[0, next_frame_index]
+        self.tlist.append(abs_time)
+        self.counter += 1
+        self.n += 1
+
+    def remove_attributes(self):
+        """undo update_attributes (reference :521-528; upstream's ``poses_[:,6] = 1.0`` there rewrites the qw of
+        EVERY keyframe -- only the removed row is reset here)"""
+        self.n -= 1
+        self.counter -= 1
+        self.tlist.pop()
+        del self._tstamps[self.n:]
+        self.poses_[self.n] = torch.tensor([0, 0, 0, 0, 0, 0, 1], dtype=torch.float, device=self.device)
+        self.tstamps_[self.n] = 0
 
     def _initial_depth(self, patches):
         """reference :369 -- torch.rand_like; overridable so parity tests can inject the

@@ -205,4 +205,8 @@ def check_ramp_vo(device):
     pre_d = float(np.abs(np.asarray(rec["depth_med"][:first_ba]) - g["depth_med"][:first_ba]).max())
     assert pre == 0.0 and pre_d < 1e-6
     same = sum(int(a == b) for a, b in zip(rec["n"], g["n"]))
-    return dict(frames=len(rec["n"]), frames_with_same_n=same, n_final=slam.n, E_final=rec["E"][-1])
+    from rampvo_amd.evaluate import ate_rmse
+    # informational (random-weight tracker: see the docstring): the reference's own metric between the two runs
+    ate = ate_rmse(traj[:, :3], g["traj"][:, :3])
+    return dict(frames=len(rec["n"]), frames_with_same_n=same, n_final=slam.n, E_final=rec["E"][-1],
+                ate_rmse_vs_reference_run=ate, path_length=float(np.linalg.norm(np.diff(g["traj"][:, :3], axis=0), axis=1).sum()))

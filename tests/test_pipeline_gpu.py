@@ -133,3 +133,66 @@ def test_frame_pipelining_does_not_change_results():
     assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
     for x, y in zip(a[3:], b[3:]):
         assert np.array_equal(x, y)
+
+
+@torch.no_grad()
+def test_pose_prediction_mode():
+    """Ramp_vo.predict_future_pose driven like evaluate.py::run_pose_pred (reference :185-229): track, 12 updates
+    at the hand-over, then virtual keyframes 0, 1, 2 frames ahead.  The predicted factors carry weights of 1e-9
+    (pose_pred_utils.py:310) against a unit damping term, so BA moves the virtual pose by at most ~1e-9 * J * r * #factors
+    (a few 1e-3) away from the damped-linear motion model's pose; terminate() interpolates through the appended poses."""
+    from rampvo_amd.config import make_cfg
+    from rampvo_amd.Ramp_vo import Ramp_vo
+    from rampvo_amd.pose_prediction.pose_pred_utils import motion_bootstrap
+    from rampvo_amd.synthetic import SyntheticStream, make_network
+    T = 22
+    stream = SyntheticStream(240, 320, T, seed=31, device="cuda")
+    slam = Ramp_vo(make_cfg("default", PATCHES_PER_FRAME=32, MIXED_PRECISION=True), make_network("SingleScale"),
+                   {"event_bias": True}, ht=240, wd=320)
+    for t in range(T):
+        im, ev, K, mask = stream.frame(t)
+        slam(t, input_tensor=(ev, im, mask), intrinsics=K)
+    assert slam.is_initialized
+    for _ in range(12):
+        slam.update()
+    last, counter, E = slam.n, slam.counter, len(slam._ii)
+    real = slam.poses_[:last].clone()
+    for step in range(3):
+        boot = motion_bootstrap(n=slam.n, poses=slam.poses_, MOTION_MODEL=slam.cfg.MOTION_MODEL,
+                                MOTION_DAMPING=slam.cfg.MOTION_DAMPING).clone()
+        slam.predict_future_pose(sec_to_pred_future=step, abs_time=T + step, last_keyframe_number=last, deg=3)
+        assert slam.n == last + step + 1 and slam.counter == counter + step + 1
+        got = slam.poses_[slam.n - 1]
+        assert torch.isfinite(got).all()
+        assert (got - boot).abs().max() < 2e-2, (got, boot)
+    assert len(slam._ii) == E and torch.equal(slam.poses_[:last], real)     # the tracker's own state is untouched
+    assert len(slam.patch_dict_) == 32 * min(last, slam.cfg.PATCH_LIFETIME - 1) and len(slam.patches_models) == len(slam.patch_dict_)
+    traj, ts = slam.terminate()
+    assert traj.shape == (counter + 3, 7) and np.isfinite(traj).all() and ts[-1] == T + 2
+    for _ in range(3):
+        slam.remove_attributes()
+    assert slam.n == last and slam.counter == counter and float(slam.poses_[last, 6]) == 1.0
+
+
+@torch.no_grad()
+def test_evaluate_harness_run_and_run_pose_pred():
+    """rampvo_amd.evaluate.run / run_pose_pred make the reference's call sequences (evaluate.py:185-260)"""
+    from rampvo_amd import evaluate as ev
+    from rampvo_amd.config import make_cfg
+    from rampvo_amd.synthetic import SyntheticStream, make_network
+    T = 20
+    stream = SyntheticStream(240, 320, T, seed=8, device="cuda")
+    data = [stream.frame(t) for t in range(T)]
+    cfg = make_cfg("default", PATCHES_PER_FRAME=32, MIXED_PRECISION=True)
+    eval_cfg = {"data_loader": {"train": {"args": {"event_bias": True}}}}
+    poses, ts, points, colors = ev.run(cfg, make_network("SingleScale"), eval_cfg, data, ht=240, wd=320)
+    assert poses.shape == (T, 7) and np.isfinite(poses).all() and len(ts) == T
+    assert points.shape[1] == 3 and points.shape[0] == colors.shape[0] and points.shape[0] % 32 == 0
+    tr = ev.Trajectory.from_terminate(poses, ts)
+    assert ev.ate_rmse(tr.positions_xyz, tr.positions_xyz) < 1e-12
+    p2, ts2 = ev.run_pose_pred(cfg, make_network("SingleScale"), eval_cfg, data, t_horizon_to_pred=3, t_to_pred=16,
+                               deg_approx=4, ht=240, wd=320)
+    assert p2.shape == (16 + 4, 7) and np.isfinite(p2).all()        # 16 tracked frames + predictions for t = 16..19
+    assert list(ts2[-4:]) == [16, 17, 18, 19]
+    # the tracked part: both runs optimise the same 16 frames (the 12 hand-over updates come on top)
+    assert np.abs(p2[:8] - poses[:8]).max() < 0.5
