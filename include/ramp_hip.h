@@ -410,8 +410,12 @@ int ramp_graph_edit_host(const int64_t *ii, const int64_t *jj, const int64_t *kk
  *   relu_t [E][384] fp16 = relu(out32), the heads' input
  *   wp_host[6]: fp16 weights of (g1.gate, g1.res[0], g1.res[2], g2.gate, g2.res[0], g2.res[2]) packed in
  *   MFMA fragment order [K/32][N/16][64 lanes][8] (lane (q, j): W[16 nt + j][32 ks + 8 q ..]);
- *   bias_host[6]: fp32 [384] each (host arrays of device pointers); ln_w, ln_b, eps: gru[2]          */
-int ramp_upd_gru(const float *x32, const void *const *wp_host, const float *const *bias_host, const float *ln_w,
+ *   bias_host[6]: fp32 [384] each (host arrays of device pointers); ln_w, ln_b, eps: gru[2].
+ *   add_t != NULL: the kernel first forms x = LayerNorm(x32 + add_t[add_idx[e]]; pre_w, pre_b, pre_eps) itself
+ *   -- the expand-and-add of the second SoftAgg (ramp/net.py:85) and gru[0] -- add_t [groups][384] fp16,
+ *   add_idx [E] int32; NULL: x32 is already the output of gru[0].                                       */
+int ramp_upd_gru(const float *x32, const void *add_t, const int32_t *add_idx, const float *pre_w, const float *pre_b,
+                 float pre_eps, const void *const *wp_host, const float *const *bias_host, const float *ln_w,
                  const float *ln_b, float eps, float *out32, void *relu_t, int E, void *stream);
 size_t ramp_upd_mlp_lds_bytes(void);
 

@@ -29,7 +29,7 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float h_round(float v) { return (float)(_Float16)v; }
 // the gate's input was rounded to fp16 one line earlier: the fast exp / reciprocal (~1 ulp) are exact
 // enough, and the IEEE expf + division sequence was a quarter of this kernel's time
-__device__ __forceinline__ float sigm(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float sigm(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 // acc[mt][nt] += Xs[64 x 384] * W^T for this wave's 48 columns; NB weight matrices share the A reads
 template <int NB>
@@ -99,10 +99,20 @@ __device__ __forceinline__ void mlp_gemm(const _Float16 *Xs, const _Float16 *con
 #define MPR 32                  // rows per parking pass
 #define MPS (MD + 4)            // parking row stride (floats)
 
+// sum over the 64 lanes on the DPP network (6 VALU adds + one readlane; a ds_bpermute butterfly is 6 dependent
+// trips through the LDS crossbar)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
 __device__ __forceinline__ float wave_sum64(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  v = dpp_add<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
+  v = dpp_add<0x141, 0xF>(v);   // row_half_mirror: 8-lane sums
+  v = dpp_add<0x140, 0xF>(v);   // row_mirror: every lane holds its row's 16-lane sum
+  v = dpp_add<0x142, 0xA>(v);   // row_bcast15 into rows 1, 3
+  v = dpp_add<0x143, 0xC>(v);   // row_bcast31 into rows 2, 3: lane 63 holds the total
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // two-pass LayerNorm of a row held as v[3][2] per lane (same arithmetic as csrc/update.hip)
@@ -145,6 +155,11 @@ struct GruParams {
   float eps;
   float *out32;                // [E][384] fp32 result of gru[3]
   _Float16 *relu_t;            // [E][384] relu(result) in fp16 (input of the heads)
+  // optional prologue: x = LayerNorm_pre(x32 + add_t[add_idx]) -- the last SoftAgg's expand-and-add and gru[0]
+  const _Float16 *add_t;       // [groups][384] fp16 or NULL
+  const int32_t *add_idx;      // [E]
+  const float *pre_w, *pre_b;  // gru[0] LayerNorm
+  float pre_eps;
   int E;
 };
 
@@ -173,8 +188,22 @@ __global__ void __launch_bounds__(64 * MWAVES) upd_gru_kernel(const GruParams p)
         float2 v = make_float2(0.f, 0.f);
         if (row < p.E) v = *reinterpret_cast<const float2 *>(p.x32 + (size_t)row * MD + c);
         xrow[half][rr][k][0] = v.x; xrow[half][rr][k][1] = v.y;
-        *reinterpret_cast<h2 *>(Xs + rt * MXS + c) = (h2){(_Float16)v.x, (_Float16)v.y};
       }
+      if (p.add_t) {             // wave-uniform
+        if (row < p.E) {
+          const _Float16 *a = p.add_t + (size_t)p.add_idx[row] * MD;
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            const h2 b = *reinterpret_cast<const h2 *>(a + 2 * lane + 128 * k);
+            xrow[half][rr][k][0] += (float)b[0]; xrow[half][rr][k][1] += (float)b[1];
+          }
+        }
+        row_ln(xrow[half][rr], p.pre_w, p.pre_b, p.pre_eps, lane);
+      }
+#pragma unroll
+      for (int k = 0; k < 3; k++)
+        *reinterpret_cast<h2 *>(Xs + rt * MXS + 2 * lane + 128 * k) =
+            (h2){(_Float16)xrow[half][rr][k][0], (_Float16)xrow[half][rr][k][1]};
     }
   __syncthreads();
   float *P = reinterpret_cast<float *>(Hs);              // parking tile, aliases h once h is dead
@@ -342,13 +371,16 @@ extern "C" {
 
 size_t ramp_upd_mlp_lds_bytes(void) { return (size_t)2 * MBM * MXS * 2; }
 
-int ramp_upd_gru(const float *x32, const void *const *wp_host, const float *const *bias_host, const float *ln_w,
+int ramp_upd_gru(const float *x32, const void *add_t, const int32_t *add_idx, const float *pre_w, const float *pre_b,
+                 float pre_eps, const void *const *wp_host, const float *const *bias_host, const float *ln_w,
                  const float *ln_b, float eps, float *out32, void *relu_t, int E, void *stream) {
   if (E < 0) return RAMP_EINVAL;
   if (E == 0) return RAMP_OK;
   if (!x32 || !wp_host || !bias_host || !ln_w || !ln_b || !out32 || !relu_t) return RAMP_EINVAL;
+  if (add_t && (!add_idx || !pre_w || !pre_b)) return RAMP_EINVAL;
   GruParams p;
   p.x32 = x32;
+  p.add_t = (const _Float16 *)add_t; p.add_idx = add_idx; p.pre_w = pre_w; p.pre_b = pre_b; p.pre_eps = pre_eps;
   for (int i = 0; i < 6; i++) {
     if (!wp_host[i] || !bias_host[i]) return RAMP_EINVAL;
     p.wp[i] = (const _Float16 *)wp_host[i];

@@ -174,17 +174,18 @@ class FusedUpdate:
         hy = self.lin(self.seg(self.lin(net_t, w["kk_fg"]), plan.g_kk, plan.max_kk), w["kk_h"])
         _, net_t = self.row_fuse(E, A=net32, B=hy, idxB32=plan.g_kk.gid, out_f32=net32, want_t=True)
         hy = self.lin(self.seg(self.lin(net_t, w["ij_fg"]), plan.g_ij, plan.max_ij), w["ij_h"])
-        fused_gru = "gru_pack" in w and self.use_mlp          # the chain kernel reads the fp32 stream only
-        x32, x_t = self.row_fuse(E, A=net32, B=hy, idxB32=plan.g_ij.gid, ln=w["ln1"], out_f32=net32,
-                                 want_t=not fused_gru)
         # gru = LN, GatedResidual, LN, GatedResidual (net.py:49-54)
-        if fused_gru:
+        if "gru_pack" in w and self.use_mlp:
+            # the chain kernel forms LN(net + hy[gid]) itself while it stages its tile: no separate row pass
             _, _, wptr, bptr = w["gru_pack"]
-            out32 = torch.empty(E, 384, dtype=torch.float32, device=x32.device)
-            relu_t = torch.empty(E, 384, dtype=self.dtype, device=x32.device)
-            check(lib().ramp_upd_gru(ptr(x32), wptr, bptr, ptr(w["ln2"][0]), ptr(w["ln2"][1]), float(w["ln2"][2]),
+            out32 = torch.empty(E, 384, dtype=torch.float32, device=net32.device)
+            relu_t = torch.empty(E, 384, dtype=self.dtype, device=net32.device)
+            ln1 = w["ln1"]
+            check(lib().ramp_upd_gru(ptr(net32), ptr(hy), ptr(plan.g_ij.gid), ptr(ln1[0]), ptr(ln1[1]), float(ln1[2]),
+                                     wptr, bptr, ptr(w["ln2"][0]), ptr(w["ln2"][1]), float(w["ln2"][2]),
                                      ptr(out32), ptr(relu_t), E, stream()), "ramp_upd_gru")
             return out32, relu_t
+        x32, x_t = self.row_fuse(E, A=net32, B=hy, idxB32=plan.g_ij.gid, ln=w["ln1"], out_f32=net32, want_t=True)
         gate = self.lin(x_t, w["g1_gate"])
         r = self.lin(self.lin_relu(x_t, w["g1_r1"]), w["g1_r2"])
         x32, x_t, _ = self.gated(x32, gate, r, E, ln=w["ln2"], want_t=True)

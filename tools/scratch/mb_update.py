@@ -26,7 +26,7 @@ def timeit(fn, n=20):
 out32 = torch.empty_like(x32); relu_t = torch.empty(E, 384, dtype=torch.float16, device="cuda"); tmp = torch.empty_like(x32)
 _, _, wptr, bptr = w["gru_pack"]
 def gru():
-    check(lib().ramp_upd_gru(ptr(x32), wptr, bptr, ptr(w["ln2"][0]), ptr(w["ln2"][1]), float(w["ln2"][2]), ptr(out32), ptr(relu_t), E, stream()), "gru")
+    check(lib().ramp_upd_gru(ptr(x32), None, None, None, None, 0.0, wptr, bptr, ptr(w["ln2"][0]), ptr(w["ln2"][1]), float(w["ln2"][2]), ptr(out32), ptr(relu_t), E, stream()), "gru")
 wa, ba, wb, bb = w["c1_pack"]
 def nbr():
     check(lib().ramp_upd_nbr(ptr(x32), ptr(plan.ix_raw), ptr(wa), ptr(ba), ptr(wb), ptr(bb), ptr(tmp), None, E, stream()), "nbr")
