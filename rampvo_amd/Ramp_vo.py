@@ -110,9 +110,15 @@ class Ramp_vo:
         self._pool_busy = set()
         self._mirror_pool = None
         self._keep = (None, None)
+        self._shift_plan = None
+        self._cur_stream = None
+        self._fe_pool = None
         self._fe_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._fe_free = None
         self._ba_event = None
+        # events are re-recorded every frame (creating one costs a hipEventCreate/Destroy pair per use)
+        mk = (lambda: torch.cuda.Event()) if dev.type == "cuda" else (lambda: None)
+        self._ev_done, self._ev_fe_done, self._ev_fe_free, self._ev_ba, self._ev_up = mk(), mk(), mk(), mk(), mk()
         self._mm_host = torch.empty(2, dtype=torch.float32).pin_memory() if dev.type == "cuda" else None
         self.net = torch.zeros(1, 0, DIM, dtype=torch.float, device=dev)   # hidden state is fp32 (as under autocast)
         self.ii = torch.zeros(0, dtype=torch.long, device=dev)
@@ -353,7 +359,7 @@ class Ramp_vo:
             self._net_map, self._net_map_dev = b4[3, :tot], d4[3, :tot]
             self._plan = pre.get("plan")
             if self._plan is not None:                 # built on the upload stream: order it before this stream's use
-                torch.cuda.current_stream().wait_stream(self._up_stream)
+                self._wait_upload_stream()
             return
         if pre is not None:
             _, src, jj, ii, dev, map_dev = pre
@@ -491,9 +497,12 @@ class Ramp_vo:
         n = self.n
         del self._tstamps[k]
         if self.device.type == "cuda" and (self.M * 3) % 4 == 0:
-            ops.shift_rows([(self.tstamps_, 0), (self.colors_, 0), (self.poses_, 0), (self.patches_, 0),
-                            (self.intrinsics_, 0), (self.imap_, self.mem), (self.gmap_, self.mem),
-                            (self.fmap1_, self.mem), (self.fmap2_, self.mem)], k, n)     # one launch
+            if self._shift_plan is None:
+                self._shift_plan = ops.ShiftPlan([(self.tstamps_, 0), (self.colors_, 0), (self.poses_, 0),
+                                                  (self.patches_, 0), (self.intrinsics_, 0), (self.imap_, self.mem),
+                                                  (self.gmap_, self.mem), (self.fmap1_, self.mem),
+                                                  (self.fmap2_, self.mem)])
+            self._shift_plan.run(k, n)                                                    # one launch
         else:
             for buf in (self.tstamps_, self.colors_, self.poses_, self.patches_, self.intrinsics_):
                 buf[k:n - 1] = buf[k + 1:n].clone()
@@ -546,7 +555,7 @@ class Ramp_vo:
         mm = ops.motionmag(self.poses, self.patches, self.intrinsics, self.ii, self.jj, self.kk, plan.g_ij,
                            j * plan.pair_mul + i, i * plan.pair_mul + j, beta=0.5)   # keys are jj*mul+ii
         self._mm_host.copy_(mm.reshape(2), non_blocking=True)       # both directions; averaged on the host
-        done = torch.cuda.Event()
+        done = self._ev_done
         done.record()
         dP = SE3(self.poses_[k]) * SE3(self.poses_[k - 1]).inv()      # only used if the keyframe goes
         # steady motion gives the same answer frame after frame: only the more frequent outcome so far is
@@ -567,6 +576,15 @@ class Ramp_vo:
             t = self._pool[idx] = torch.empty(int(nelem * 1.25) + 1024, dtype=torch.long).pin_memory()
         self._pool_busy.add(idx)
         return idx, t
+
+    def _cur(self):
+        """the caller's stream; looked up once per __call__ (torch.cuda.current_stream() costs ~4 us)"""
+        return self._cur_stream if self._cur_stream is not None else torch.cuda.current_stream()
+
+    def _wait_upload_stream(self):
+        """current stream waits for everything queued on the upload stream (wait_stream without a new event)"""
+        self._ev_up.record(self._up_stream)
+        self._cur().wait_event(self._ev_up)
 
     def _spec_outcome(self, remove, k):
         """the graph after keyframe() for one outcome of the motion test, laid out together with the next frame's
@@ -625,7 +643,7 @@ class Ramp_vo:
                 self._pool_busy.discard(other["pool"])
         self._pool_busy.discard(self._mirror_pool)
         self._mirror_pool = pre["pool"]
-        torch.cuda.current_stream().wait_stream(self._up_stream)
+        self._wait_upload_stream()
         # arrays and plan were allocated on the side stream and are consumed on this one: instead of
         # record_stream() on ~15 tensors they are simply kept alive for two frames -- every consumer of frame t
         # has finished when frame t+1's motion test has been read back
@@ -682,7 +700,7 @@ class Ramp_vo:
             if self.inputs_ready and self.device.type == "cuda":
                 # the next frame's front end may start here: next to BA's small kernels, not next to the
                 # bandwidth-bound update operator (starting it earlier slowed those kernels by more than it hid)
-                self._ba_event = torch.cuda.Event()
+                self._ba_event = self._ev_ba
                 self._ba_event.record()
         with Timer("BA", enabled=self.enable_timing):
             t0 = self.n - self.cfg.OPTIMIZATION_WINDOW if self.is_initialized else 1
@@ -704,7 +722,11 @@ class Ramp_vo:
         """track a new frame"""
         input_ = preprocess_input(input_tensor=input_tensor)
         with torch.no_grad():
-            return self._track(tstamp, input_, intrinsics)
+            self._cur_stream = torch.cuda.current_stream() if self.device.type == "cuda" else None
+            try:
+                return self._track(tstamp, input_, intrinsics)
+            finally:
+                self._cur_stream = None
 
     def _track(self, tstamp, input_, intrinsics):
         mask = input_[2]
@@ -713,18 +735,34 @@ class Ramp_vo:
         if self._pending is not None:
             # pipelined: this frame's front end goes out first, on its own stream, next to what is left of the
             # previous frame; only then does the host wait for the previous frame's keyframe decision
-            cur, fe = torch.cuda.current_stream(), self._fe_stream
-            if self._fe_free is not None:
-                fe.wait_event(self._fe_free)          # the previous frame has copied the static outputs away
-            if self._ba_event is not None:
-                fe.wait_event(self._ba_event)
-            with torch.cuda.stream(fe):
-                fmap, gmap, imap, patches, _, clr = self.network.patchify(
-                    input_=input_, patches_per_image=self.cfg.PATCHES_PER_FRAME, event_bias=self.event_bias,
-                    reinit_hidden=False)
-            fe_done = torch.cuda.Event()
-            fe_done.record(fe)
+            cur, fe = self._cur(), self._fe_stream
+            fe_done = self._ev_fe_done
+
+            def front_end():
+                if self._fe_free is not None:
+                    fe.wait_event(self._fe_free)          # the previous frame has copied the static outputs away
+                if self._ba_event is not None:
+                    fe.wait_event(self._ba_event)
+                with torch.no_grad(), torch.cuda.stream(fe):
+                    out = self.network.patchify(
+                        input_=input_, patches_per_image=self.cfg.PATCHES_PER_FRAME, event_bias=self.event_bias,
+                        reinit_hidden=False)
+                fe_done.record(fe)
+                return out
+
+            # the graph launch (~0.17 ms of host time inside the runtime, GIL released) runs on a helper thread
+            # while this thread waits for the read-back and applies the keyframe decision
+            if self._fe_pool is None and os.environ.get("RAMP_FE_THREAD", "1") == "1":
+                import concurrent.futures
+                self._fe_pool = concurrent.futures.ThreadPoolExecutor(
+                    max_workers=1, initializer=torch.cuda.set_device,
+                    initargs=(self.device.index if self.device.index is not None else torch.cuda.current_device(),))
+            job = self._fe_pool.submit(front_end) if self._fe_pool is not None else None
+            if job is None:
+                fmap, gmap, imap, patches, _, clr = front_end()
             self._keyframe_finish()
+            if job is not None:
+                fmap, gmap, imap, patches, _, clr = job.result()
             cur.wait_event(fe_done)
         pre = self._prefetch_edges() if (accepts and self.device.type == "cuda") else None
         kq = intrinsics.detach().cpu().float().numpy() / self.RES
@@ -771,7 +809,8 @@ class Ramp_vo:
                 else:
                     self.poses_[n] = self.poses_[n - 1]
 
-        draw = self._initial_depth(patches)          # reference :369 (drawn every frame, also when overwritten below)
+        # reference :369-372: random inverse depths, replaced by the median of the last three keyframes once the
+        # tracker is initialised -- the draw is dead then and is not made (nothing else consumes the generator)
         if self.is_initialized:
             if (self.device.type == "cuda" and patches.is_contiguous() and patches.dtype == torch.float32
                     and ops.depth_median_supported(3, self.M, self.P)):
@@ -779,16 +818,16 @@ class Ramp_vo:
             else:
                 patches[:, :, 2] = torch.median(self.patches_[n - 3:n, :, 2])
         else:
-            patches[:, :, 2] = draw
+            patches[:, :, 2] = self._initial_depth(patches)
 
         slot = n % self.mem
         ex = getattr(self.network.patchify, "_extra", None)
         if (ex is not None and self.device.type == "cuda" and ex["fmap"].dtype == self.dtype
                 and (self.M * 3) % 4 == 0 and patches.is_contiguous() and ex["chunked"] == self._chunked):
             # one launch: patches, colours and the four feature tensors into their state rows / ring slots
-            ops.multi_copy([(patches, self.patches_[n]), (ex["colors"], self.colors_[n]),
-                            (ex["imap"], self.imap_[slot]), (ex["gmap"], self.gmap_[slot]),
-                            (ex["fmap"], self.fmap1_[slot]), (ex["fmap2"], self.fmap2_[slot])])
+            ops.store_rows([patches, ex["colors"], ex["imap"], ex["gmap"], ex["fmap"], ex["fmap2"]],
+                           [(self.patches_, n), (self.colors_, n), (self.imap_, slot), (self.gmap_, slot),
+                            (self.fmap1_, slot), (self.fmap2_, slot)])
         else:
             clr = (clr[0][:, [2, 1, 0]] + 0.5) * (255.0 / 2)
             self.colors_[n] = clr.to(torch.uint8)
@@ -804,7 +843,7 @@ class Ramp_vo:
                 self.fmap2_[slot] = F.avg_pool2d(f, 4, 4)[0].permute(1, 2, 0).to(self.dtype)
 
         if self.inputs_ready and self.device.type == "cuda":
-            self._fe_free = torch.cuda.Event()
+            self._fe_free = self._ev_fe_free
             self._fe_free.record()
         self.counter += 1
         if n > 0 and not self.is_initialized:

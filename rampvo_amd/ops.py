@@ -198,9 +198,12 @@ def transform(poses, patches, intrinsics, ii, jj, kk, tonly=False):
     """Ramp_vo.reproject: poses [..,7], patches [..,3,P,P], intrinsics [..,4] -> [1,E,2,P,P]"""
     require_cuda(poses, patches, intrinsics, ii, jj, kk)
     P = patches.shape[-1]
-    poses = poses.reshape(-1, 7).contiguous().float()
-    patches = patches.reshape(-1, 3, P, P).contiguous().float()
-    intrinsics = intrinsics.reshape(-1, 4).contiguous().float()
+    f32 = torch.float32
+    if not (poses.dtype == f32 and patches.dtype == f32 and intrinsics.dtype == f32 and poses.is_contiguous()
+            and patches.is_contiguous() and intrinsics.is_contiguous()):        # (the tracker's buffers are)
+        poses = poses.reshape(-1, 7).contiguous().float()
+        patches = patches.reshape(-1, 3, P, P).contiguous().float()
+        intrinsics = intrinsics.reshape(-1, 4).contiguous().float()
     E = ii.shape[0]
     out = torch.empty((1, E, 2, P, P), dtype=torch.float32, device=poses.device)
     check(lib().ramp_transform(ptr(poses), ptr(patches), ptr(intrinsics), ptr(_idx(ii)),
@@ -263,6 +266,34 @@ def multi_copy(pairs):
     for s, d in pairs:
         assert s.is_contiguous() and d.is_contiguous() and s.numel() * s.element_size() == d.numel() * d.element_size()
     check(lib().ramp_multi_copy(src, dst, nbytes, n, stream()), "ramp_multi_copy")
+
+
+def store_rows(srcs, rows):
+    """one launch: contiguous tensor srcs[i] -> row rows[i][1] of the contiguous buffer rows[i][0] (no view tensors)"""
+    n = len(srcs)
+    rb = [b.stride(0) * b.element_size() for b, _ in rows]
+    for s_, (b, _), nb in zip(srcs, rows, rb):
+        assert s_.numel() * s_.element_size() == nb and s_.is_contiguous() and b.is_contiguous()
+    src = (ctypes.c_void_p * n)(*[s_.data_ptr() for s_ in srcs])
+    dst = (ctypes.c_void_p * n)(*[b.data_ptr() + int(r) * nb for (b, r), nb in zip(rows, rb)])
+    check(lib().ramp_multi_copy(src, dst, (ctypes.c_long * n)(*rb), n, stream()), "ramp_multi_copy")
+
+
+class ShiftPlan:
+    """descriptor arrays of shift_rows for a fixed set of buffers (built once)"""
+
+    def __init__(self, bufs):
+        n = self.n = len(bufs)
+        for t, _ in bufs:
+            assert t.is_contiguous()
+        self.keep = [t for t, _ in bufs]
+        self.base = (ctypes.c_void_p * n)(*[t.data_ptr() for t, _ in bufs])
+        self.rb = (ctypes.c_long * n)(*[t[0].numel() * t.element_size() for t, _ in bufs])
+        self.mod = (ctypes.c_int * n)(*[int(m) for _, m in bufs])
+
+    def run(self, k, nrows):
+        check(lib().ramp_shift_rows(self.base, self.rb, self.mod, self.n, int(k), int(nrows), stream()),
+              "ramp_shift_rows")
 
 
 def shift_rows(bufs, k, nrows):
