@@ -43,8 +43,8 @@ HBM_PEAK_GBS = 8000.0           # MI355X HBM3E peak (MI355X_MICROARCH.md)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--prime", type=int, default=70, help="untimed frames to fill the sliding window")
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
