@@ -298,8 +298,10 @@ struct NbrParams {
 
 __global__ void __launch_bounds__(64 * MWAVES) upd_nbr_kernel(const NbrParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  // ONE 50 KB tile: gathered input, then (after a barrier) the hidden layer, then the fp32 parking tile --
+  // two workgroups per CU, so one's gather / row pass overlaps the other's matrix work
   _Float16 *Xs = reinterpret_cast<_Float16 *>(smem_raw);
-  _Float16 *Hs = Xs + MBM * MXS;
+  _Float16 *Hs = Xs;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
   const int row0 = blockIdx.x * MBM;
   const int col0 = wave * (16 * MNTW);
@@ -319,6 +321,7 @@ __global__ void __launch_bounds__(64 * MWAVES) upd_nbr_kernel(const NbrParams p)
     const _Float16 *const w1[1] = {p.wa};
     mlp_gemm<1>(Xs, w1, wave, lane, acc);
   }
+  __syncthreads();                                       // every wave is past its reads of x
 #pragma unroll
   for (int nt = 0; nt < MNTW; nt++) {
     const float b1 = p.ba[col0 + nt * 16 + j];
@@ -408,7 +411,7 @@ int ramp_upd_nbr(const float *net_in, const int64_t *idx, const void *wa, const 
   NbrParams p;
   p.net_in = net_in; p.idx = idx; p.wa = (const _Float16 *)wa; p.wb = (const _Float16 *)wb; p.ba = ba; p.bb = bb;
   p.net_out = net_out; p.out_t = (_Float16 *)out_t; p.E = E;
-  const size_t lds = ramp_upd_mlp_lds_bytes();
+  const size_t lds = (size_t)MBM * MXS * 2;          // one tile (see the kernel)
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void *)upd_nbr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
