@@ -209,11 +209,62 @@ __global__ void __launch_bounds__(256)
 }
 
 // SoftAgg core over the stacked [f | g] rows (row stride 768): y[g][c] = sum softmax(g) * f.
+// One workgroup per group: SEG_R row lanes x 192 threads x 2 channels.  Row lane w walks rows w, w + R, ... of
+// the group (ascending edge order) with a running max (online softmax); the R partial (max, sum, weighted
+// sum) triples are merged in lane order.  (A single row lane per group left the 96-row pair groups with a
+// 48-step dependent chain on 420 workgroups.)
+// exp: the hardware exponential (v_exp_f32, ~1 ulp) -- with libm's expf this kernel was VALU bound (6 x ~15
+// instructions per row and lane pair); it only runs on the fp16 path, whose inputs carry 11 bits.
+#define SEG_R 4
+template <typename T>
+__global__ void __launch_bounds__(192 * SEG_R)
+    upd_segment_softmax_kernel(const T *__restrict__ fg, const int32_t *__restrict__ order,
+                               const int32_t *__restrict__ seg_start, const int32_t *__restrict__ ngroups,
+                               T *__restrict__ y) {
+  __shared__ float part[SEG_R][6][192];
+  const int g = blockIdx.x;
+  const int t = threadIdx.x % 192, w = threadIdx.x / 192;
+  const int c = 2 * t;
+  if (g >= *ngroups) {          // unused tail of the table: defined (zero) rows, no memset launch needed
+    if (w == 0) st2<T>(y + (size_t)g * UD + c, 0.f, 0.f);
+    return;
+  }
+  const int s0 = seg_start[g], s1 = seg_start[g + 1];
+  float m0 = -INFINITY, m1 = -INFINITY, z0 = 0.f, z1 = 0.f, a0 = 0.f, a1 = 0.f;
+  for (int p = s0 + w; p < s1; p += SEG_R) {
+    const size_t r0 = (size_t)order[p] * (2 * UD);
+    const float2 f0 = ld2<T>(fg + r0 + c), g0 = ld2<T>(fg + r0 + UD + c);
+    const float n0 = fmaxf(m0, g0.x), n1 = fmaxf(m1, g0.y);
+    const float s0_ = __expf(m0 - n0), s1_ = __expf(m1 - n1);
+    const float e0 = __expf(g0.x - n0), e1 = __expf(g0.y - n1);
+    z0 = z0 * s0_ + e0; a0 = a0 * s0_ + f0.x * e0;
+    z1 = z1 * s1_ + e1; a1 = a1 * s1_ + f0.y * e1;
+    m0 = n0; m1 = n1;
+  }
+  part[w][0][t] = m0; part[w][1][t] = m1; part[w][2][t] = z0; part[w][3][t] = z1; part[w][4][t] = a0; part[w][5][t] = a1;
+  __syncthreads();
+  if (w != 0) return;
+#pragma unroll
+  for (int k = 1; k < SEG_R; k++) {
+    const float zk0 = part[k][2][t], zk1 = part[k][3][t];
+    if (zk0 == 0.f) continue;                 // this row lane saw no row (both channels share the rows)
+    const float mk0 = part[k][0][t], mk1 = part[k][1][t];
+    const float n0 = fmaxf(m0, mk0), n1 = fmaxf(m1, mk1);
+    const float s0_ = __expf(m0 - n0), s1_ = __expf(m1 - n1), t0_ = __expf(mk0 - n0), t1_ = __expf(mk1 - n1);
+    z0 = z0 * s0_ + zk0 * t0_; a0 = a0 * s0_ + part[k][4][t] * t0_;
+    z1 = z1 * s1_ + zk1 * t1_; a1 = a1 * s1_ + part[k][5][t] * t1_;
+    m0 = n0; m1 = n1;
+  }
+  st2<T>(y + (size_t)g * UD + c, a0 / z0, a1 / z1);
+}
+
+// Sequential variant (fp32 path): the summation order the fp32 parity fixtures were recorded with.
+// y[g][c] = sum softmax(g) * f over the stacked [f | g] rows (row stride 768).
 // One workgroup (192 lanes x 2 channels) per group, single pass with a running max (online
 // softmax), rows visited in ascending edge order.
 template <typename T>
 __global__ void __launch_bounds__(192)
-    upd_segment_softmax_kernel(const T *__restrict__ fg, const int32_t *__restrict__ order,
+    upd_segment_softmax_seq_kernel(const T *__restrict__ fg, const int32_t *__restrict__ order,
                                const int32_t *__restrict__ seg_start, const int32_t *__restrict__ ngroups,
                                T *__restrict__ y) {
   const int g = blockIdx.x;
@@ -326,10 +377,10 @@ int ramp_upd_segment_softmax(const void *fg, const int32_t *order, const int32_t
   if (max_groups < 0) return RAMP_EINVAL;
   if (max_groups == 0) return RAMP_OK;
   if (!fg || !order || !seg_start || !ngroups || !y) return RAMP_EINVAL;
-  const dim3 grid(max_groups), block(192);
+  const dim3 grid(max_groups), block(192 * SEG_R);
   if (dtype == RAMP_F32)
-    hipLaunchKernelGGL(upd_segment_softmax_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float *)fg,
-                       order, seg_start, ngroups, (float *)y);
+    hipLaunchKernelGGL(upd_segment_softmax_seq_kernel<float>, grid, dim3(192), 0, (hipStream_t)stream,
+                       (const float *)fg, order, seg_start, ngroups, (float *)y);
   else if (dtype == RAMP_F16)
     hipLaunchKernelGGL(upd_segment_softmax_kernel<_Float16>, grid, block, 0, (hipStream_t)stream,
                        (const _Float16 *)fg, order, seg_start, ngroups, (_Float16 *)y);
