@@ -426,6 +426,16 @@ size_t ramp_upd_mlp_lds_bytes(void);
 int ramp_upd_nbr(const float *net_in, const int64_t *idx, const void *wa, const float *ba, const void *wb,
                  const float *bb, float *net_out, void *out_t, int E, void *stream);
 
+/* Tail of the correlation MLP and Update.norm in one launch (ramp/net.py:57-62, 71-74):
+ *   net_out[e] = LayerNorm_norm(net[net_map[e]] + inp[inp_idx[e] % inp_mod] + L3(relu(LayerNorm_ln(L2(c1[e])))))
+ * c1 [E][384] fp16 = relu(L1(corr)) (the K = 896 library GEMM); w2 / w3 packed like ramp_upd_gru's weights,
+ * b2 / b3 fp32 [384]; net NULL = zeros, net_map NULL = identity, -1 = zero row; inp_idx NULL = identity,
+ * inp_mod <= 0 = no modulo.  net_out fp32 [E][384], must not alias net.                              */
+int ramp_upd_corr_tail(const void *c1, const void *w2, const float *b2, const void *w3, const float *b3,
+                       const float *ln_w, const float *ln_b, float ln_eps, const float *net, const int64_t *net_map,
+                       const void *inp, const int64_t *inp_idx, long inp_mod, const float *norm_w,
+                       const float *norm_b, float norm_eps, float *net_out, int E, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -370,6 +370,147 @@ __global__ void __launch_bounds__(64 * MWAVES) upd_nbr_kernel(const NbrParams p)
   }
 }
 
+// Tail of the correlation MLP and the operator's first LayerNorm (ramp/net.py:57-62, 71-74):
+//   c = Linear3(relu(LayerNorm(Linear2(c1))));  net = LayerNorm(net_prev + inp + c)
+// c1 = relu(Linear1(corr)) comes from the library GEMM (K = 896).  One 50 KB LDS tile (input, hidden, fp32
+// parking) -> two workgroups per CU.  Linear outputs are rounded to fp16 where autocast makes them half tensors.
+struct CorrTailParams {
+  const _Float16 *c1;          // [E][384] fp16
+  const _Float16 *w2, *w3;     // packed weights of corr[2], corr[5]
+  const float *b2, *b3;        // biases (fp16-rounded values as fp32)
+  const float *ln_w, *ln_b;    // corr[3] LayerNorm
+  float ln_eps;
+  const float *net;            // [*][384] fp32 previous hidden state or NULL (zeros)
+  const int64_t *net_map;      // [E] row of `net` per edge (-1: zero row) or NULL (identity)
+  const _Float16 *inp;         // context table [*][384] fp16
+  const int64_t *inp_idx;      // [E] row of `inp` (taken modulo inp_mod when inp_mod > 0) or NULL (identity)
+  long inp_mod;
+  const float *norm_w, *norm_b;
+  float norm_eps;
+  float *net_out;              // [E][384] fp32
+  int E;
+};
+
+__global__ void __launch_bounds__(64 * MWAVES) upd_corr_tail_kernel(const CorrTailParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  _Float16 *Xs = reinterpret_cast<_Float16 *>(smem_raw);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
+  const int row0 = blockIdx.x * MBM;
+  const int col0 = wave * (16 * MNTW);
+  for (int i = tid; i < MBM * (MD / 8); i += 64 * MWAVES) {
+    const int r = i / (MD / 8), c8 = i - r * (MD / 8);
+    h8 v = (h8){0, 0, 0, 0, 0, 0, 0, 0};
+    if (row0 + r < p.E) v = *reinterpret_cast<const h8 *>(p.c1 + (size_t)(row0 + r) * MD + 8 * c8);
+    *reinterpret_cast<h8 *>(Xs + r * MXS + 8 * c8) = v;
+  }
+  __syncthreads();
+  f4 acc[1][4][MNTW];
+  {
+    const _Float16 *const w1[1] = {p.w2};
+    mlp_gemm<1>(Xs, w1, wave, lane, acc);
+  }
+  float y[4][MNTW][4];
+#pragma unroll
+  for (int nt = 0; nt < MNTW; nt++) {
+    const float b = p.b2[col0 + nt * 16 + j];
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) y[mt][nt][r] = h_round(acc[0][mt][nt][r] + b);
+  }
+  __syncthreads();                                       // every wave is past its reads of the input tile
+  float *P = reinterpret_cast<float *>(Xs);
+  // row pass 1: LayerNorm + ReLU; the 8 rows of this wave wait in registers until both halves are through
+  // (the parking tile covers the whole LDS tile), then become the hidden tile
+  h2 hrow[2][MPR / MWAVES][3];
+#pragma unroll
+  for (int half = 0; half < 2; half++) {
+    park_half(P, y, half, col0, q, j);
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < MPR / MWAVES; rr++) {
+      const int rl = wave * (MPR / MWAVES) + rr;
+      float v[3][2];
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const float2 pv = *reinterpret_cast<const float2 *>(P + rl * MPS + 2 * lane + 128 * k);
+        v[k][0] = pv.x; v[k][1] = pv.y;
+      }
+      row_ln(v, p.ln_w, p.ln_b, p.ln_eps, lane);
+#pragma unroll
+      for (int k = 0; k < 3; k++) hrow[half][rr][k] = (h2){(_Float16)fmaxf(v[k][0], 0.f), (_Float16)fmaxf(v[k][1], 0.f)};
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int half = 0; half < 2; half++)
+#pragma unroll
+    for (int rr = 0; rr < MPR / MWAVES; rr++) {
+      const int rt = half * MPR + wave * (MPR / MWAVES) + rr;
+#pragma unroll
+      for (int k = 0; k < 3; k++) *reinterpret_cast<h2 *>(Xs + rt * MXS + 2 * lane + 128 * k) = hrow[half][rr][k];
+    }
+  __syncthreads();
+  {
+    const _Float16 *const w1[1] = {p.w3};
+    mlp_gemm<1>(Xs, w1, wave, lane, acc);
+  }
+#pragma unroll
+  for (int nt = 0; nt < MNTW; nt++) {
+    const float b = p.b3[col0 + nt * 16 + j];
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) y[mt][nt][r] = h_round(acc[0][mt][nt][r] + b);
+  }
+  __syncthreads();
+  // row pass 2: net_prev + inp + c (in that order), LayerNorm, fp32 store
+#pragma unroll
+  for (int half = 0; half < 2; half++) {
+    park_half(P, y, half, col0, q, j);
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < MPR / MWAVES; rr++) {
+      const int rl = wave * (MPR / MWAVES) + rr;
+      const int row = row0 + half * MPR + rl;
+      if (row >= p.E) continue;                          // wave-uniform
+      float v[3][2];
+#pragma unroll
+      for (int k = 0; k < 3; k++) { v[k][0] = 0.f; v[k][1] = 0.f; }
+      if (p.net) {
+        const long ra = p.net_map ? p.net_map[row] : (long)row;
+        if (ra >= 0) {
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            const float2 a = *reinterpret_cast<const float2 *>(p.net + (size_t)ra * MD + 2 * lane + 128 * k);
+            v[k][0] = a.x; v[k][1] = a.y;
+          }
+        }
+      }
+      {
+        long rb = p.inp_idx ? p.inp_idx[row] : (long)row;
+        if (p.inp_mod > 0) rb %= p.inp_mod;
+        const _Float16 *b = p.inp + (size_t)rb * MD;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          const h2 t = *reinterpret_cast<const h2 *>(b + 2 * lane + 128 * k);
+          v[k][0] += (float)t[0]; v[k][1] += (float)t[1];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const float2 pv = *reinterpret_cast<const float2 *>(P + rl * MPS + 2 * lane + 128 * k);
+        v[k][0] += pv.x; v[k][1] += pv.y;
+      }
+      row_ln(v, p.norm_w, p.norm_b, p.norm_eps, lane);
+#pragma unroll
+      for (int k = 0; k < 3; k++)
+        *reinterpret_cast<float2 *>(p.net_out + (size_t)row * MD + 2 * lane + 128 * k) = make_float2(v[k][0], v[k][1]);
+    }
+    __syncthreads();
+  }
+}
+
 extern "C" {
 
 size_t ramp_upd_mlp_lds_bytes(void) { return (size_t)2 * MBM * MXS * 2; }
@@ -420,6 +561,25 @@ int ramp_upd_nbr(const float *net_in, const int64_t *idx, const void *wa, const 
     attr_set = true;
   }
   hipLaunchKernelGGL(upd_nbr_kernel, dim3(ramp_cdiv(E, MBM)), dim3(64 * MWAVES), lds, (hipStream_t)stream, p);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+
+int ramp_upd_corr_tail(const void *c1, const void *w2, const float *b2, const void *w3, const float *b3,
+                       const float *ln_w, const float *ln_b, float ln_eps, const float *net, const int64_t *net_map,
+                       const void *inp, const int64_t *inp_idx, long inp_mod, const float *norm_w,
+                       const float *norm_b, float norm_eps, float *net_out, int E, void *stream) {
+  if (E < 0) return RAMP_EINVAL;
+  if (E == 0) return RAMP_OK;
+  if (!c1 || !w2 || !b2 || !w3 || !b3 || !ln_w || !ln_b || !inp || !norm_w || !norm_b || !net_out || net == net_out)
+    return RAMP_EINVAL;
+  CorrTailParams p;
+  p.c1 = (const _Float16 *)c1; p.w2 = (const _Float16 *)w2; p.w3 = (const _Float16 *)w3; p.b2 = b2; p.b3 = b3;
+  p.ln_w = ln_w; p.ln_b = ln_b; p.ln_eps = ln_eps; p.net = net; p.net_map = net_map; p.inp = (const _Float16 *)inp;
+  p.inp_idx = inp_idx; p.inp_mod = inp_mod; p.norm_w = norm_w; p.norm_b = norm_b; p.norm_eps = norm_eps;
+  p.net_out = net_out; p.E = E;
+  const size_t lds = (size_t)MBM * MXS * 2;
+  hipLaunchKernelGGL(upd_corr_tail_kernel, dim3(ramp_cdiv(E, MBM)), dim3(64 * MWAVES), lds, (hipStream_t)stream, p);
   RAMP_CHECK_LAUNCH();
   return RAMP_OK;
 }

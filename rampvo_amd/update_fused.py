@@ -84,6 +84,8 @@ class FusedUpdate:
             hb = lambda l: l.bias.detach().half().float().contiguous()
             w["c1_pack"] = (pack_linear_f16(m.c1[0].weight), hb(m.c1[0]), pack_linear_f16(m.c1[2].weight), hb(m.c1[2]))
             w["c2_pack"] = (pack_linear_f16(m.c2[0].weight), hb(m.c2[0]), pack_linear_f16(m.c2[2].weight), hb(m.c2[2]))
+            w["tail_pack"] = (pack_linear_f16(m.corr[2].weight), hb(m.corr[2]), pack_linear_f16(m.corr[5].weight),
+                              hb(m.corr[5]))
         self._w, self._key = w, key
         return w
 
@@ -143,11 +145,21 @@ class FusedUpdate:
         w = self.weights()
         E = corr.shape[0]
         c = self.lin_relu(corr, w["corr0_pad"] if corr.shape[1] == CORR_ROW else w["corr0"])
-        c = self.lin(c, w["corr2"])
-        _, c = self.row_fuse(E, B=c, ln=w["corr_ln"], relu=True, want_t=True)
-        c = self.lin(c, w["corr5"])
-        net32, _ = self.row_fuse(E, A=net, idxA=net_map, B=inp_table, idxB=inp_idx, modB=inp_mod, C=c, ln=w["norm"],
-                                 want_f32=True)
+        if "tail_pack" in w and self.use_mlp:
+            # Linear, LayerNorm + ReLU, Linear, net + inp + c, LayerNorm: one launch (csrc/update_mlp.hip)
+            w2, b2, w3, b3 = w["tail_pack"]
+            ln, nm = w["corr_ln"], w["norm"]
+            net32 = torch.empty(E, 384, dtype=torch.float32, device=c.device)
+            check(lib().ramp_upd_corr_tail(ptr(c), ptr(w2), ptr(b2), ptr(w3), ptr(b3), ptr(ln[0]), ptr(ln[1]),
+                                           float(ln[2]), ptr(net), ptr(net_map), ptr(inp_table), ptr(inp_idx),
+                                           int(inp_mod or 0), ptr(nm[0]), ptr(nm[1]), float(nm[2]), ptr(net32), E,
+                                           stream()), "ramp_upd_corr_tail")
+        else:
+            c = self.lin(c, w["corr2"])
+            _, c = self.row_fuse(E, B=c, ln=w["corr_ln"], relu=True, want_t=True)
+            c = self.lin(c, w["corr5"])
+            net32, _ = self.row_fuse(E, A=net, idxA=net_map, B=inp_table, idxB=inp_idx, modB=inp_mod, C=c,
+                                     ln=w["norm"], want_f32=True)
         # temporal neighbours (net.py:77-82); plan.ix_raw / jx_raw keep the -1 markers
         if "c1_pack" in w and self.use_mlp:
             # gather + 2 Linear + residual add per launch; ping-pong between two state buffers

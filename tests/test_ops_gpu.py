@@ -483,6 +483,19 @@ def test_fused_gru_chain_matches_gemm_path():
     assert float((outs[False][0] - outs[True][0]).abs().max()) <= 4e-3 * scale      # fp16 GEMM inputs on both sides
     assert float((outs[False][1] - outs[True][1]).abs().max()) <= 4e-3 * scale
     assert torch.equal(outs[True][1], torch.relu(outs[True][0]).half().float())
+    # the tracker's form: state rows through a row map (-1 = new factor), context rows through a ring index
+    net_map = torch.randint(-1, 700, (E,), generator=g).cuda()
+    table = (torch.randn(300, 384, generator=g) * 0.5).half().cuda()
+    inp_idx = torch.randint(0, 5000, (E,), generator=g).cuda()
+    with torch.no_grad():
+        for mlp in (False, True):
+            fu.use_mlp = mlp
+            o32, rt = fu.hidden(netst[:700].contiguous(), table, inp_idx, 300, corr, plan, net_map=net_map)
+            outs[mlp] = (o32.clone(), rt.float().clone())
+    fu.use_mlp = True
+    scale = float(outs[False][0].abs().max())
+    assert float((outs[False][0] - outs[True][0]).abs().max()) <= 4e-3 * scale
+    assert float((outs[False][1] - outs[True][1]).abs().max()) <= 4e-3 * scale
 
 
 def test_event_stack_matches_reference_golden_and_oracle():
