@@ -670,6 +670,10 @@ class Ramp_vo:
             pre["plan"] = self._build_plan(b4[0, :tot], b4[1, :tot], b4[2, :tot], d4[0, :tot], d4[1, :tot],
                                            d4[2, :tot], ranges=pre["ranges"])
 
+    def _mark_fe_start(self):
+        self._ba_event = self._ev_ba
+        self._ba_event.record()
+
     # ------------------------------------------------------------------- update
     def update(self):
         self.settle()
@@ -682,6 +686,9 @@ class Ramp_vo:
                 # GEMMs + row-fused glue (csrc/update.hip); the context gather, the heads' activations,
                 # `target = centre + delta` and filter_features are folded into those kernels
                 fu = self.network.update.fused(self.dtype)
+                fe_at = os.environ.get("RAMP_FE_AT", "gru")    # where the next front end may start (ba|gru|softagg|nbr)
+                fu.before_gru = self._mark_fe_start if (self.inputs_ready and fe_at != "ba") else None
+                fu.hook_at = fe_at
                 net_map = None
                 if self._net_map is not None:
                     net_map = self._net_map_dev if self._net_map_dev is not None else self._upload(self._net_map)
@@ -697,9 +704,10 @@ class Ramp_vo:
                 target = coords[..., self.P // 2, self.P // 2] + delta.float()
                 weight = filter_features(confidences=weight, target=target, data_shape=(self.ht // 4, self.wd // 4))
             self.last_weight = weight
-            if self.inputs_ready and self.device.type == "cuda":
-                # the next frame's front end may start here: next to BA's small kernels, not next to the
-                # bandwidth-bound update operator (starting it earlier slowed those kernels by more than it hid)
+            if self.inputs_ready and self.device.type == "cuda" and fe_at == "ba":
+                # the next frame's front end may start here, next to BA's small kernels (default: one kernel
+                # earlier, at the gru chain -- measured 1.43 vs 1.46 ms per step; earlier than that it costs the
+                # bandwidth-bound update kernels more than it hides)
                 self._ba_event = self._ev_ba
                 self._ba_event.record()
         with Timer("BA", enabled=self.enable_timing):

@@ -38,6 +38,8 @@ class FusedUpdate:
         self._params = list(update.parameters())     # module structure is fixed; values are tracked by key
         self._act_ok = True
         self.use_mlp = os.environ.get("RAMP_UPD_MLP", "1") == "1"    # fused GEMM-chain kernels (fp16 only)
+        self.before_gru = None                   # optional callable run right before a stage is enqueued
+        self.hook_at = "gru"
 
     # ------------------------------------------------------------------ weights
     def weights(self):
@@ -165,6 +167,8 @@ class FusedUpdate:
             # gather + 2 Linear + residual add per launch; ping-pong between two state buffers
             tmp = torch.empty_like(net32)
             net_t = torch.empty(E, 384, dtype=self.dtype, device=net32.device)
+            if self.before_gru is not None and self.hook_at == "nbr":
+                self.before_gru()
             wa, ba, wb, bb = w["c1_pack"]
             check(lib().ramp_upd_nbr(ptr(net32), ptr(plan.ix_raw), ptr(wa), ptr(ba), ptr(wb), ptr(bb), ptr(tmp), None,
                                      E, stream()), "ramp_upd_nbr")
@@ -183,6 +187,8 @@ class FusedUpdate:
     def _tail(self, w, E, net32, net_t, plan):
         """SoftAgg x2 and the gru block, from the state after c1 / c2"""
         # SoftAgg over patches, then over (i, j) pairs (net.py:84-85)
+        if self.before_gru is not None and self.hook_at == "softagg":
+            self.before_gru()
         hy = self.lin(self.seg(self.lin(net_t, w["kk_fg"]), plan.g_kk, plan.max_kk), w["kk_h"])
         _, net_t = self.row_fuse(E, A=net32, B=hy, idxB32=plan.g_kk.gid, out_f32=net32, want_t=True)
         hy = self.lin(self.seg(self.lin(net_t, w["ij_fg"]), plan.g_ij, plan.max_ij), w["ij_h"])
@@ -193,6 +199,8 @@ class FusedUpdate:
             out32 = torch.empty(E, 384, dtype=torch.float32, device=net32.device)
             relu_t = torch.empty(E, 384, dtype=self.dtype, device=net32.device)
             ln1 = w["ln1"]
+            if self.before_gru is not None and self.hook_at == "gru":
+                self.before_gru()
             check(lib().ramp_upd_gru(ptr(net32), ptr(hy), ptr(plan.g_ij.gid), ptr(ln1[0]), ptr(ln1[1]), float(ln1[2]),
                                      wptr, bptr, ptr(w["ln2"][0]), ptr(w["ln2"][1]), float(w["ln2"][2]),
                                      ptr(out32), ptr(relu_t), E, stream()), "ramp_upd_gru")

@@ -23,6 +23,17 @@ def take(n):
     if before != after: reall.append((len(times), n))
     return r
 slam._pool_take = take
+import concurrent.futures as cf
+jw = []
+r0 = cf.Future.result
+def res(self, timeout=None):
+    t0 = time.perf_counter(); r = r0(self, timeout); jw.append(time.perf_counter() - t0); return r
+cf.Future.result = res
+sy = []
+s0 = torch.cuda.Event.synchronize
+def sync(self):
+    t0 = time.perf_counter(); r = s0(self); sy.append(time.perf_counter() - t0); return r
+torch.cuda.Event.synchronize = sync
 times = []
 for t in range(T):
     im, ev, K, mask = frames[t]
@@ -34,3 +45,6 @@ print("frames 100..%d: mean %.3f ms median %.3f  p99 %.3f  max %.3f; sum of (t -
 print("slow frames:", [(int(i) + 100, round(float(v), 2)) for i, v in zip(np.argsort(a)[-8:], np.sort(a)[-8:])])
 print("gc events after frame 100:", [(g[0], g[1], round(1e3 * g[3], 2)) for g in gcs if g[0] >= 100 and len(g) > 3][:20])
 print("pinned reallocations:", reall)
+
+j = np.array(jw[100:]) * 1e3; y = np.array(sy[100:]) * 1e3
+print("job.result wait: mean %.3f ms p99 %.3f; event sync wait: mean %.3f median %.3f p99 %.3f" % (j.mean(), np.percentile(j, 99), y.mean(), np.median(y), np.percentile(y, 99)))
