@@ -209,53 +209,59 @@ __global__ void __launch_bounds__(256)
 }
 
 // SoftAgg core over the stacked [f | g] rows (row stride 768): y[g][c] = sum softmax(g) * f.
-// One workgroup per group: SEG_R row lanes x 192 threads x 2 channels.  Row lane w walks rows w, w + R, ... of
+// One workgroup per group: SEG_R row lanes x 96 threads x 4 channels.  Row lane w walks rows w, w + R, ... of
 // the group (ascending edge order) with a running max (online softmax); the R partial (max, sum, weighted
 // sum) triples are merged in lane order.  (A single row lane per group left the 96-row pair groups with a
 // 48-step dependent chain on 420 workgroups.)
 // exp: the hardware exponential (v_exp_f32, ~1 ulp) -- with libm's expf this kernel was VALU bound (6 x ~15
 // instructions per row and lane pair); it only runs on the fp16 path, whose inputs carry 11 bits.
-#define SEG_R 4
-template <typename T>
-__global__ void __launch_bounds__(192 * SEG_R)
-    upd_segment_softmax_kernel(const T *__restrict__ fg, const int32_t *__restrict__ order,
-                               const int32_t *__restrict__ seg_start, const int32_t *__restrict__ ngroups,
-                               T *__restrict__ y) {
-  __shared__ float part[SEG_R][6][192];
+#define SEG_R 8
+#define SEG_T 96                // threads per row lane: 4 channels (one 8-byte load) each
+typedef _Float16 seg_h4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(SEG_T * SEG_R)
+    upd_segment_softmax_f16_kernel(const _Float16 *__restrict__ fg, const int32_t *__restrict__ order,
+                                   const int32_t *__restrict__ seg_start, const int32_t *__restrict__ ngroups,
+                                   _Float16 *__restrict__ y) {
+  __shared__ float part[SEG_R][12][SEG_T];
   const int g = blockIdx.x;
-  const int t = threadIdx.x % 192, w = threadIdx.x / 192;
-  const int c = 2 * t;
+  const int t = threadIdx.x % SEG_T, w = threadIdx.x / SEG_T;
+  const int c = 4 * t;
   if (g >= *ngroups) {          // unused tail of the table: defined (zero) rows, no memset launch needed
-    if (w == 0) st2<T>(y + (size_t)g * UD + c, 0.f, 0.f);
+    if (w == 0) *reinterpret_cast<seg_h4 *>(y + (size_t)g * UD + c) = (seg_h4){0, 0, 0, 0};
     return;
   }
   const int s0 = seg_start[g], s1 = seg_start[g + 1];
-  float m0 = -INFINITY, m1 = -INFINITY, z0 = 0.f, z1 = 0.f, a0 = 0.f, a1 = 0.f;
+  float m[4], z[4], a[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) { m[k] = -INFINITY; z[k] = 0.f; a[k] = 0.f; }
   for (int p = s0 + w; p < s1; p += SEG_R) {
     const size_t r0 = (size_t)order[p] * (2 * UD);
-    const float2 f0 = ld2<T>(fg + r0 + c), g0 = ld2<T>(fg + r0 + UD + c);
-    const float n0 = fmaxf(m0, g0.x), n1 = fmaxf(m1, g0.y);
-    const float s0_ = __expf(m0 - n0), s1_ = __expf(m1 - n1);
-    const float e0 = __expf(g0.x - n0), e1 = __expf(g0.y - n1);
-    z0 = z0 * s0_ + e0; a0 = a0 * s0_ + f0.x * e0;
-    z1 = z1 * s1_ + e1; a1 = a1 * s1_ + f0.y * e1;
-    m0 = n0; m1 = n1;
+    const seg_h4 fv = *reinterpret_cast<const seg_h4 *>(fg + r0 + c);
+    const seg_h4 gv = *reinterpret_cast<const seg_h4 *>(fg + r0 + UD + c);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const float gk = (float)gv[k], n = fmaxf(m[k], gk);
+      const float sc = __expf(m[k] - n), e = __expf(gk - n);
+      z[k] = z[k] * sc + e; a[k] = a[k] * sc + (float)fv[k] * e;
+      m[k] = n;
+    }
   }
-  part[w][0][t] = m0; part[w][1][t] = m1; part[w][2][t] = z0; part[w][3][t] = z1; part[w][4][t] = a0; part[w][5][t] = a1;
+#pragma unroll
+  for (int k = 0; k < 4; k++) { part[w][k][t] = m[k]; part[w][4 + k][t] = z[k]; part[w][8 + k][t] = a[k]; }
   __syncthreads();
   if (w != 0) return;
+  for (int q = 1; q < SEG_R; q++) {
+    if (part[q][4][t] == 0.f) continue;       // this row lane saw no row (all channels share the rows)
 #pragma unroll
-  for (int k = 1; k < SEG_R; k++) {
-    const float zk0 = part[k][2][t], zk1 = part[k][3][t];
-    if (zk0 == 0.f) continue;                 // this row lane saw no row (both channels share the rows)
-    const float mk0 = part[k][0][t], mk1 = part[k][1][t];
-    const float n0 = fmaxf(m0, mk0), n1 = fmaxf(m1, mk1);
-    const float s0_ = __expf(m0 - n0), s1_ = __expf(m1 - n1), t0_ = __expf(mk0 - n0), t1_ = __expf(mk1 - n1);
-    z0 = z0 * s0_ + zk0 * t0_; a0 = a0 * s0_ + part[k][4][t] * t0_;
-    z1 = z1 * s1_ + zk1 * t1_; a1 = a1 * s1_ + part[k][5][t] * t1_;
-    m0 = n0; m1 = n1;
+    for (int k = 0; k < 4; k++) {
+      const float mk = part[q][k][t], n = fmaxf(m[k], mk);
+      const float sc = __expf(m[k] - n), tc = __expf(mk - n);
+      z[k] = z[k] * sc + part[q][4 + k][t] * tc; a[k] = a[k] * sc + part[q][8 + k][t] * tc;
+      m[k] = n;
+    }
   }
-  st2<T>(y + (size_t)g * UD + c, a0 / z0, a1 / z1);
+  *reinterpret_cast<seg_h4 *>(y + (size_t)g * UD + c) =
+      (seg_h4){(_Float16)(a[0] / z[0]), (_Float16)(a[1] / z[1]), (_Float16)(a[2] / z[2]), (_Float16)(a[3] / z[3])};
 }
 
 // Sequential variant (fp32 path): the summation order the fp32 parity fixtures were recorded with.
@@ -377,12 +383,12 @@ int ramp_upd_segment_softmax(const void *fg, const int32_t *order, const int32_t
   if (max_groups < 0) return RAMP_EINVAL;
   if (max_groups == 0) return RAMP_OK;
   if (!fg || !order || !seg_start || !ngroups || !y) return RAMP_EINVAL;
-  const dim3 grid(max_groups), block(192 * SEG_R);
+  const dim3 grid(max_groups);
   if (dtype == RAMP_F32)
     hipLaunchKernelGGL(upd_segment_softmax_seq_kernel<float>, grid, dim3(192), 0, (hipStream_t)stream,
                        (const float *)fg, order, seg_start, ngroups, (float *)y);
   else if (dtype == RAMP_F16)
-    hipLaunchKernelGGL(upd_segment_softmax_kernel<_Float16>, grid, block, 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(upd_segment_softmax_f16_kernel, grid, dim3(SEG_T * SEG_R), 0, (hipStream_t)stream,
                        (const _Float16 *)fg, order, seg_start, ngroups, (_Float16 *)y);
   else return RAMP_EINVAL;
   RAMP_CHECK_LAUNCH();
