@@ -282,8 +282,10 @@ def main():
     torch.cuda.synchronize()
     ctimer.enabled = etimer.enabled = True
     tic = time.perf_counter()
+    marks = [tic]
     for _ in range(args.steps):
         step(t); t += 1
+        marks.append(time.perf_counter())         # host-side return times (the GPU may lag by less than a step)
     slam.settle()
     torch.cuda.synchronize()
     if world > 1:
@@ -315,6 +317,9 @@ def main():
                        "ba_iters_per_s": round(2 * value, 2), "edges": E0, "edges_end": len(slam._ii),
                        "keyframes_in_window": n0, "prime_frames": args.prime,
                        "frame_pipelining": bool(args.pipeline),
+                       "host_step_ms_p50_p90_max": [round(1e3 * float(v), 3) for v in
+                                                    (np.percentile(np.diff(marks), 50), np.percentile(np.diff(marks), 90),
+                                                     np.max(np.diff(marks)))],
                        "sharding": "independent sequences, 1 per GPU" if world > 1 else "single sequence"},
         }
         if per_rank is not None:
