@@ -296,10 +296,12 @@ struct NbrParams {
   int E;
 };
 
-__global__ void __launch_bounds__(64 * MWAVES) upd_nbr_kernel(const NbrParams p) {
+// waves_per_eu 6: 80 VGPRs -> three workgroups per CU (3 x 50 KB LDS): all ~625 workgroups of an update are
+// resident at once (768 slots) instead of 1.2 rounds of 512
+__global__ void __launch_bounds__(64 * MWAVES) __attribute__((amdgpu_waves_per_eu(6, 6))) upd_nbr_kernel(const NbrParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   // ONE 50 KB tile: gathered input, then (after a barrier) the hidden layer, then the fp32 parking tile --
-  // two workgroups per CU, so one's gather / row pass overlaps the other's matrix work
+  // several workgroups per CU, so one's gather / row pass overlaps the others' matrix work
   _Float16 *Xs = reinterpret_cast<_Float16 *>(smem_raw);
   _Float16 *Hs = Xs;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
@@ -391,7 +393,8 @@ struct CorrTailParams {
   int E;
 };
 
-__global__ void __launch_bounds__(64 * MWAVES) upd_corr_tail_kernel(const CorrTailParams p) {
+__global__ void __launch_bounds__(64 * MWAVES) __attribute__((amdgpu_waves_per_eu(6, 6)))
+    upd_corr_tail_kernel(const CorrTailParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   _Float16 *Xs = reinterpret_cast<_Float16 *>(smem_raw);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
