@@ -113,6 +113,7 @@ class Ramp_vo:
         self._shift_plan = None
         self._cur_stream = None
         self._fe_pool = None
+        self._corr_levels = None
         self._fe_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._fe_free = None
         self._ba_event = None
@@ -284,6 +285,22 @@ class Ramp_vo:
         """local correlation volume, both pyramid levels fused: [1, E, 882].  order: the graph
         plan's target-frame-major edge permutation (scheduling only)"""
         ii, jj = indicies if indicies is not None else (self.kk, self.jj)
+        if (self._chunked and order is not None and coords.shape[1] > 0 and coords.dtype == torch.float32 and coords.is_contiguous()
+                and ii.is_contiguous() and jj.is_contiguous()):
+            # the tracker's own per-frame call: same launch as below without the generic wrapper's checks (the
+            # level descriptors of the fixed pyramid buffers are built once)
+            if self._corr_levels is None:
+                lv = (_lib.CorrLevel * 2)()
+                lv[0] = _lib.CorrLevel(self.fmap1_.data_ptr(), self.fmap1_.shape[1], self.fmap1_.shape[3], 1.0)
+                lv[1] = _lib.CorrLevel(self.fmap2_.data_ptr(), self.fmap2_.shape[1], self.fmap2_.shape[3], 4.0)
+                self._corr_levels = lv
+            E = coords.shape[1]
+            out = torch.empty((E, CORR_ROW), dtype=torch.half, device=self.device)
+            _lib.check(_lib.lib().ramp_corr_fwd_ordered(
+                _lib.ptr(self.gmap_), self._corr_levels, 2, _lib.ptr(coords), _lib.ptr(ii), _lib.ptr(jj),
+                _lib.ptr(order), _lib.ptr(out), CORR_ROW, self.M * self.mem, self.mem, E, self.mem * self.M,
+                self.mem, 128, 3, 3, _lib.RAMP_F16, RAMP_NHWC8, _lib.stream()), "ramp_corr_fwd_ordered")
+            return out.view(1, E, CORR_ROW)
         if self.device.type == "cuda":
             # ring-buffer slots (kk % (M*mem), jj % mem) are taken inside the kernel; fp16: rows padded 882 -> 896
             # (16-byte aligned rows for the first Linear layer, update_fused.py)
@@ -297,6 +314,14 @@ class Ramp_vo:
                                     (1, 4), RAMP_NHWC, order=order)
 
     def reproject(self, indicies=None, poses=None, patches=None, intrinsics=None):
+        if indicies is None and poses is None and patches is None and intrinsics is None and self.device.type == "cuda":
+            # the tracker's own per-frame call on its own (contiguous fp32) buffers and graph
+            E = self.ii.shape[0]
+            out = torch.empty((1, E, 2, self.P, self.P), dtype=torch.float32, device=self.device)
+            _lib.check(_lib.lib().ramp_transform(_lib.ptr(self.poses_), _lib.ptr(self.patches_), _lib.ptr(self.intrinsics_),
+                                                 _lib.ptr(self.ii), _lib.ptr(self.jj), _lib.ptr(self.kk), _lib.ptr(out),
+                                                 E, self.P, 0, _lib.stream()), "ramp_transform")
+            return out
         (ii, jj, kk) = indicies if indicies is not None else (self.ii, self.jj, self.kk)
         poses = poses if poses is not None else self.poses
         patches = patches if patches is not None else self.patches
