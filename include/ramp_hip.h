@@ -436,6 +436,12 @@ int ramp_upd_corr_tail(const void *c1, const void *w2, const float *b2, const vo
                        const void *inp, const int64_t *inp_idx, long inp_mod, const float *norm_w,
                        const float *norm_b, float norm_eps, float *net_out, int E, void *stream);
 
+/* SoftAgg front half (ramp/blocks.py:42-46) in one launch: x = x32[e] (+ add_t[add_idx[e]], written to x32_out
+ * when given; x32_out may be x32);  fg[e] = [ f(x) | g(x) ]  fp16 [E][768].  wf / wg packed like ramp_upd_gru's
+ * weights, bf / bg fp32 [384].                                                                        */
+int ramp_upd_fg(const float *x32, const void *add_t, const int32_t *add_idx, float *x32_out, const void *wf,
+                const float *bf, const void *wg, const float *bg, void *fg, int E, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

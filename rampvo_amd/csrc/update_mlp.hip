@@ -32,7 +32,9 @@ __device__ __forceinline__ float h_round(float v) { return (float)(_Float16)v; }
 __device__ __forceinline__ float sigm(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 // acc[mt][nt] += Xs[64 x 384] * W^T for this wave's 48 columns; NB weight matrices share the A reads
-template <int NB>
+// SWAP: operands exchanged -> the accumulators hold the TRANSPOSED tile (lane (q, j): row j of the 16-row tile,
+// columns 4q..4q+3 of the 16-column tile), i.e. four consecutive output columns per lane for direct row-major stores
+template <int NB, bool SWAP = false>
 __device__ __forceinline__ void mlp_gemm(const _Float16 *Xs, const _Float16 *const (&wp)[NB], int wave, int lane,
                                          f4 (&acc)[NB][4][MNTW]) {
   const int q = lane >> 4, j = lane & 15;
@@ -87,7 +89,8 @@ __device__ __forceinline__ void mlp_gemm(const _Float16 *Xs, const _Float16 *con
       for (int mt = 0; mt < 4; mt++)
 #pragma unroll
         for (int nt = 0; nt < MNTW; nt++)
-          acc[b][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mt], bw[b][nt], acc[b][mt][nt], 0, 0, 0);
+          acc[b][mt][nt] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_f16(bw[b][nt], a[mt], acc[b][mt][nt], 0, 0, 0)
+                                : __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mt], bw[b][nt], acc[b][mt][nt], 0, 0, 0);
   }
 }
 
@@ -514,6 +517,81 @@ __global__ void __launch_bounds__(64 * MWAVES) __attribute__((amdgpu_waves_per_e
   }
 }
 
+// SoftAgg front half (ramp/blocks.py:42-46): fg[e] = [f(x_e) | g(x_e)] for x = x32 (+ add_t[add_idx], the previous
+// SoftAgg's expand-and-add, written back to x32_out) -- the row pass that formed x and the [E,384]x[384,768] GEMM in
+// one launch.  Transposed accumulators: every lane stores four consecutive fp16 outputs, no parking pass, the
+// input tile stays valid for the second matrix.  One 50 KB tile, three workgroups per CU.
+struct FgParams {
+  const float *x32;            // [E][384] fp32
+  const _Float16 *add_t;       // optional [groups][384] fp16
+  const int32_t *add_idx;      // [E]
+  float *x32_out;              // optional [E][384] fp32 (may be x32): x after the add
+  const _Float16 *wf, *wg;     // packed weights of f and g
+  const float *bf, *bg;        // biases (fp16-rounded values as fp32)
+  _Float16 *fg;                // [E][768] fp16
+  int E;
+};
+
+__global__ void __launch_bounds__(64 * MWAVES) __attribute__((amdgpu_waves_per_eu(6, 6))) upd_fg_kernel(const FgParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  _Float16 *Xs = reinterpret_cast<_Float16 *>(smem_raw);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
+  const int row0 = blockIdx.x * MBM;
+  const int col0 = wave * (16 * MNTW);
+#pragma unroll
+  for (int rr = 0; rr < MBM / MWAVES; rr++) {            // 8 whole rows per wave
+    const int rt = wave * (MBM / MWAVES) + rr;
+    const int row = row0 + rt;
+    float v[3][2];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { v[k][0] = 0.f; v[k][1] = 0.f; }
+    if (row < p.E) {                                     // wave-uniform
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const float2 a = *reinterpret_cast<const float2 *>(p.x32 + (size_t)row * MD + 2 * lane + 128 * k);
+        v[k][0] = a.x; v[k][1] = a.y;
+      }
+      if (p.add_t) {
+        const _Float16 *b = p.add_t + (size_t)p.add_idx[row] * MD;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          const h2 t = *reinterpret_cast<const h2 *>(b + 2 * lane + 128 * k);
+          v[k][0] += (float)t[0]; v[k][1] += (float)t[1];
+        }
+      }
+      if (p.x32_out) {
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+          *reinterpret_cast<float2 *>(p.x32_out + (size_t)row * MD + 2 * lane + 128 * k) = make_float2(v[k][0], v[k][1]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+      *reinterpret_cast<h2 *>(Xs + rt * MXS + 2 * lane + 128 * k) = (h2){(_Float16)v[k][0], (_Float16)v[k][1]};
+  }
+  __syncthreads();
+  typedef _Float16 hh4 __attribute__((ext_vector_type(4)));
+#pragma unroll 1
+  for (int part = 0; part < 2; part++) {
+    f4 acc[1][4][MNTW];
+    const _Float16 *const w1[1] = {part ? p.wg : p.wf};
+    mlp_gemm<1, true>(Xs, w1, wave, lane, acc);
+    const float *bias = part ? p.bg : p.bf;
+#pragma unroll
+    for (int nt = 0; nt < MNTW; nt++) {
+      const float4 b = *reinterpret_cast<const float4 *>(bias + col0 + nt * 16 + 4 * q);
+#pragma unroll
+      for (int mt = 0; mt < 4; mt++) {
+        const int row = row0 + mt * 16 + j;
+        if (row < p.E)
+          *reinterpret_cast<hh4 *>(p.fg + (size_t)row * (2 * MD) + part * MD + col0 + nt * 16 + 4 * q) =
+              (hh4){(_Float16)(acc[0][mt][nt][0] + b.x), (_Float16)(acc[0][mt][nt][1] + b.y),
+                    (_Float16)(acc[0][mt][nt][2] + b.z), (_Float16)(acc[0][mt][nt][3] + b.w)};
+      }
+    }
+  }
+}
+
 extern "C" {
 
 size_t ramp_upd_mlp_lds_bytes(void) { return (size_t)2 * MBM * MXS * 2; }
@@ -583,6 +661,20 @@ int ramp_upd_corr_tail(const void *c1, const void *w2, const float *b2, const vo
   p.net_out = net_out; p.E = E;
   const size_t lds = (size_t)MBM * MXS * 2;
   hipLaunchKernelGGL(upd_corr_tail_kernel, dim3(ramp_cdiv(E, MBM)), dim3(64 * MWAVES), lds, (hipStream_t)stream, p);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+
+int ramp_upd_fg(const float *x32, const void *add_t, const int32_t *add_idx, float *x32_out, const void *wf,
+                const float *bf, const void *wg, const float *bg, void *fg, int E, void *stream) {
+  if (E < 0) return RAMP_EINVAL;
+  if (E == 0) return RAMP_OK;
+  if (!x32 || !wf || !bf || !wg || !bg || !fg || (add_t && !add_idx)) return RAMP_EINVAL;
+  FgParams p;
+  p.x32 = x32; p.add_t = (const _Float16 *)add_t; p.add_idx = add_idx; p.x32_out = x32_out;
+  p.wf = (const _Float16 *)wf; p.wg = (const _Float16 *)wg; p.bf = bf; p.bg = bg; p.fg = (_Float16 *)fg; p.E = E;
+  const size_t lds = (size_t)MBM * MXS * 2;
+  hipLaunchKernelGGL(upd_fg_kernel, dim3(ramp_cdiv(E, MBM)), dim3(64 * MWAVES), lds, (hipStream_t)stream, p);
   RAMP_CHECK_LAUNCH();
   return RAMP_OK;
 }

@@ -86,6 +86,8 @@ class FusedUpdate:
             hb = lambda l: l.bias.detach().half().float().contiguous()
             w["c1_pack"] = (pack_linear_f16(m.c1[0].weight), hb(m.c1[0]), pack_linear_f16(m.c1[2].weight), hb(m.c1[2]))
             w["c2_pack"] = (pack_linear_f16(m.c2[0].weight), hb(m.c2[0]), pack_linear_f16(m.c2[2].weight), hb(m.c2[2]))
+            for name, agg in (("kk_fg_pack", m.agg_kk), ("ij_fg_pack", m.agg_ij)):
+                w[name] = (pack_linear_f16(agg.f.weight), hb(agg.f), pack_linear_f16(agg.g.weight), hb(agg.g))
             w["tail_pack"] = (pack_linear_f16(m.corr[2].weight), hb(m.corr[2]), pack_linear_f16(m.corr[5].weight),
                               hb(m.corr[5]))
         self._w, self._key = w, key
@@ -132,6 +134,14 @@ class FusedUpdate:
                                    stream()), "ramp_upd_gated")
         return o32, ot, orl
 
+    def fg(self, net32, add_t, add_idx, pack, E):
+        """[f(x) | g(x)] of x = net32 (+ add_t[add_idx], written back to net32): csrc/update_mlp.hip::upd_fg_kernel"""
+        out = torch.empty(E, 768, dtype=self.dtype, device=net32.device)
+        wf, bf, wg, bg = pack
+        check(lib().ramp_upd_fg(ptr(net32), ptr(add_t), ptr(add_idx), ptr(net32) if add_t is not None else None,
+                                ptr(wf), ptr(bf), ptr(wg), ptr(bg), ptr(out), E, stream()), "ramp_upd_fg")
+        return out
+
     def seg(self, fg, groups, max_groups):
         y = torch.empty(max(max_groups, 1), 384, dtype=self.dtype, device=fg.device)     # the kernel writes every row
         check(lib().ramp_upd_segment_softmax(ptr(fg), ptr(groups.order), ptr(groups.seg_start), ptr(groups.ngroups),
@@ -174,8 +184,8 @@ class FusedUpdate:
                                      E, stream()), "ramp_upd_nbr")
             wa, ba, wb, bb = w["c2_pack"]
             check(lib().ramp_upd_nbr(ptr(tmp), ptr(plan.jx_raw), ptr(wa), ptr(ba), ptr(wb), ptr(bb), ptr(net32),
-                                     ptr(net_t), E, stream()), "ramp_upd_nbr")
-            return self._tail(w, E, net32, net_t, plan)
+                                     None, E, stream()), "ramp_upd_nbr")
+            return self._tail(w, E, net32, None, plan)
         g = self.gather_mask(net32, plan.ix_raw, E)
         y = self.lin(self.lin_relu(g, w["c1a"]), w["c1b"])
         self.row_fuse(E, A=net32, B=y, out_f32=net32)
@@ -189,9 +199,16 @@ class FusedUpdate:
         # SoftAgg over patches, then over (i, j) pairs (net.py:84-85)
         if self.before_gru is not None and self.hook_at == "softagg":
             self.before_gru()
-        hy = self.lin(self.seg(self.lin(net_t, w["kk_fg"]), plan.g_kk, plan.max_kk), w["kk_h"])
-        _, net_t = self.row_fuse(E, A=net32, B=hy, idxB32=plan.g_kk.gid, out_f32=net32, want_t=True)
-        hy = self.lin(self.seg(self.lin(net_t, w["ij_fg"]), plan.g_ij, plan.max_ij), w["ij_h"])
+        if net_t is None:
+            # fused path: the [f | g] GEMM forms its own fp16 input tile from the fp32 state (and applies the
+            # previous SoftAgg's expand-and-add on the way): no fp16 state copy, no separate row pass
+            hy = self.lin(self.seg(self.fg(net32, None, None, w["kk_fg_pack"], E), plan.g_kk, plan.max_kk), w["kk_h"])
+            hy = self.lin(self.seg(self.fg(net32, hy, plan.g_kk.gid, w["ij_fg_pack"], E), plan.g_ij, plan.max_ij),
+                          w["ij_h"])
+        else:
+            hy = self.lin(self.seg(self.lin(net_t, w["kk_fg"]), plan.g_kk, plan.max_kk), w["kk_h"])
+            _, net_t = self.row_fuse(E, A=net32, B=hy, idxB32=plan.g_kk.gid, out_f32=net32, want_t=True)
+            hy = self.lin(self.seg(self.lin(net_t, w["ij_fg"]), plan.g_ij, plan.max_ij), w["ij_h"])
         # gru = LN, GatedResidual, LN, GatedResidual (net.py:49-54)
         if "gru_pack" in w and self.use_mlp:
             # the chain kernel forms LN(net + hy[gid]) itself while it stages its tile: no separate row pass
