@@ -91,6 +91,22 @@ class CorrTimer:
             return out
 
         altcorr.corr_pyramid = timed
+        # the tracker's own per-frame launch goes straight to the C ABI (Ramp_vo._corr_launch)
+        from rampvo_amd.Ramp_vo import Ramp_vo
+        direct = Ramp_vo._corr_launch
+
+        def timed_direct(slam, coords, ii, jj, order):
+            if not timer.enabled:
+                return direct(slam, coords, ii, jj, order)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = direct(slam, coords, ii, jj, order)
+            e.record()
+            timer.pairs.append((s, e))
+            timer.edges.append(int(ii.shape[0]))
+            return out
+
+        Ramp_vo._corr_launch = timed_direct
 
     @staticmethod
     def pmc_traffic_per_edge(elem_bytes):
@@ -332,6 +348,7 @@ def main():
         if per_rank is not None:
             out["config"]["per_rank_kfps_E_n_chk"] = per_rank
         rl = ctimer.summary(2 if args.mixed else 4)
+        assert rl is not None or args.no_kernel_timing, "no correlation launch was timed: the roofline hook is stale"
         if rl is not None:
             out["roofline"] = rl
         el = etimer.summary(bool(args.mixed))

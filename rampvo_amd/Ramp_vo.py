@@ -289,18 +289,7 @@ class Ramp_vo:
                 and ii.is_contiguous() and jj.is_contiguous()):
             # the tracker's own per-frame call: same launch as below without the generic wrapper's checks (the
             # level descriptors of the fixed pyramid buffers are built once)
-            if self._corr_levels is None:
-                lv = (_lib.CorrLevel * 2)()
-                lv[0] = _lib.CorrLevel(self.fmap1_.data_ptr(), self.fmap1_.shape[1], self.fmap1_.shape[3], 1.0)
-                lv[1] = _lib.CorrLevel(self.fmap2_.data_ptr(), self.fmap2_.shape[1], self.fmap2_.shape[3], 4.0)
-                self._corr_levels = lv
-            E = coords.shape[1]
-            out = torch.empty((E, CORR_ROW), dtype=torch.half, device=self.device)
-            _lib.check(_lib.lib().ramp_corr_fwd_ordered(
-                _lib.ptr(self.gmap_), self._corr_levels, 2, _lib.ptr(coords), _lib.ptr(ii), _lib.ptr(jj),
-                _lib.ptr(order), _lib.ptr(out), CORR_ROW, self.M * self.mem, self.mem, E, self.mem * self.M,
-                self.mem, 128, 3, 3, _lib.RAMP_F16, RAMP_NHWC8, _lib.stream()), "ramp_corr_fwd_ordered")
-            return out.view(1, E, CORR_ROW)
+            return self._corr_launch(coords, ii, jj, order)
         if self.device.type == "cuda":
             # ring-buffer slots (kk % (M*mem), jj % mem) are taken inside the kernel; fp16: rows padded 882 -> 896
             # (16-byte aligned rows for the first Linear layer, update_fused.py)
@@ -312,6 +301,21 @@ class Ramp_vo:
         jj1 = jj % self.mem
         return altcorr.corr_pyramid(self.gmap_.view(-1, 3, 3, 128), self.pyramid, coords[0], ii1, jj1, 3,
                                     (1, 4), RAMP_NHWC, order=order)
+
+    def _corr_launch(self, coords, ii, jj, order):
+        """ramp_corr_fwd_ordered on the tracker's own buffers (fp16 chunked pyramid, padded rows)"""
+        if self._corr_levels is None:
+            lv = (_lib.CorrLevel * 2)()
+            lv[0] = _lib.CorrLevel(self.fmap1_.data_ptr(), self.fmap1_.shape[1], self.fmap1_.shape[3], 1.0)
+            lv[1] = _lib.CorrLevel(self.fmap2_.data_ptr(), self.fmap2_.shape[1], self.fmap2_.shape[3], 4.0)
+            self._corr_levels = lv
+        E = coords.shape[1]
+        out = torch.empty((E, CORR_ROW), dtype=torch.half, device=self.device)
+        _lib.check(_lib.lib().ramp_corr_fwd_ordered(
+            _lib.ptr(self.gmap_), self._corr_levels, 2, _lib.ptr(coords), _lib.ptr(ii), _lib.ptr(jj),
+            _lib.ptr(order), _lib.ptr(out), CORR_ROW, self.M * self.mem, self.mem, E, self.mem * self.M,
+            self.mem, 128, 3, 3, _lib.RAMP_F16, RAMP_NHWC8, _lib.stream()), "ramp_corr_fwd_ordered")
+        return out.view(1, E, CORR_ROW)
 
     def reproject(self, indicies=None, poses=None, patches=None, intrinsics=None):
         if indicies is None and poses is None and patches is None and intrinsics is None and self.device.type == "cuda":

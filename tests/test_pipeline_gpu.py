@@ -194,3 +194,30 @@ def test_evaluate_harness_run_and_run_pose_pred():
                                deg_approx=4, ht=240, wd=320)
     assert p2.shape == (16 + 4, 7) and np.isfinite(p2).all()        # 16 tracked frames + predictions for t = 16..19
     assert list(ts2[-4:]) == [16, 17, 18, 19]
+
+
+def test_bench_json_contract():
+    """bench.py prints ONE JSON line with the driver's keys, the roofline of the correlation kernel measured in this
+    run (HIP events on the launch stream) and the CPU baseline -- on a small workload so that it runs in seconds"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--height", "240", "--width", "320",
+                          "--patches", "48", "--prime", "40", "--warmup", "3", "--steps", "12", "--cpu-steps", "1"],
+                         capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "roofline_encoder", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 12 and d["warmup"] == 3 and d["higher_is_better"] is True
+    assert d["unit"] == "keyframes/s" and d["value"] > 0 and d["vs_baseline"] is None and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["launches"] == 12 and r["achieved"] > 0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["unit"] == "keyframes/s"
