@@ -30,6 +30,18 @@ def gru():
 wa, ba, wb, bb = w["c1_pack"]
 def nbr():
     check(lib().ramp_upd_nbr(ptr(x32), ptr(plan.ix_raw), ptr(wa), ptr(ba), ptr(wb), ptr(bb), ptr(tmp), None, E, stream()), "nbr")
+fgo = torch.empty(E, 768, dtype=torch.float16, device="cuda")
+hyk = (torch.randn(2200, 384, generator=g) * 0.1).half().cuda()
+gid = plan.g_kk.gid
+wf, bf, wg, bg = w["kk_fg_pack"]
+def fg_plain():
+    check(lib().ramp_upd_fg(ptr(x32), None, None, None, ptr(wf), ptr(bf), ptr(wg), ptr(bg), ptr(fgo), E, stream()), "fg")
+def fg_add():
+    check(lib().ramp_upd_fg(ptr(x32), ptr(hyk), ptr(gid), ptr(tmp), ptr(wf), ptr(bf), ptr(wg), ptr(bg), ptr(fgo), E, stream()), "fg")
+xh = x32.half()
+def gemm768():
+    return torch.nn.functional.linear(xh, w["kk_fg"][0], w["kk_fg"][1])
+print("fg (no add) %.1f us   fg (+add, state write) %.1f us   hipBLASLt 384->768 GEMM %.1f us" % (timeit(fg_plain), timeit(fg_add), timeit(gemm768)))
 xt = x32.half()
 def gemm():
     return torch.nn.functional.linear(xt, w["c1a"][0], w["c1a"][1])
