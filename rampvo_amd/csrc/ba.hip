@@ -105,14 +105,13 @@ __global__ void __launch_bounds__(256)
 // with all loads in flight at once (walking them from memory is one dependent round trip per edge);
 // the sums run over the staged records in segment order.
 #define BA_PCHUNK 32
-__global__ void __launch_bounds__(256)
-    ba_patch_kernel(const float *__restrict__ rec, const int32_t *__restrict__ order,
-                    const int32_t *__restrict__ seg, const int32_t *__restrict__ ngroups,
-                    const float *__restrict__ lmbda, float *__restrict__ Erow,
-                    float *__restrict__ Cv, float *__restrict__ uv, float *__restrict__ Qv,
-                    int n6) {
+__device__ __forceinline__ void
+    ba_patch_body(int g, const float *__restrict__ rec, const int32_t *__restrict__ order,
+                  const int32_t *__restrict__ seg, const int32_t *__restrict__ ngroups,
+                  const float *__restrict__ lmbda, float *__restrict__ Erow,
+                  float *__restrict__ Cv, float *__restrict__ uv, float *__restrict__ Qv,
+                  int n6) {
   __shared__ float s_rec[BA_PCHUNK][BA_REC + 1];
-  const int g = blockIdx.x;
   if (g >= *ngroups) return;
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int s0 = seg[g], s1 = seg[g + 1];
@@ -159,15 +158,23 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+__global__ void __launch_bounds__(256)
+    ba_patch_kernel(const float *__restrict__ rec, const int32_t *__restrict__ order,
+                    const int32_t *__restrict__ seg, const int32_t *__restrict__ ngroups,
+                    const float *__restrict__ lmbda, float *__restrict__ Erow,
+                    float *__restrict__ Cv, float *__restrict__ uv, float *__restrict__ Qv,
+                    int n6) {
+  ba_patch_body(blockIdx.x, rec, order, seg, ngroups, lmbda, Erow, Cv, uv, Qv, n6);
+}
+
 // ------------------------------------------------------------------ K3
 // pair record: [0,36) w Ji Ji', [36,72) w Jj Jj', [72,108) -w Ji Jj',
-// [108,144) -w Jj Ji', [144,150) -w r Ji, [150,156) w r Jj
-__global__ void __launch_bounds__(192)
-    ba_pair_kernel(const float *__restrict__ rec, const int32_t *__restrict__ order,
-                   const int32_t *__restrict__ seg, const int32_t *__restrict__ ngroups,
-                   float *__restrict__ pairs, int32_t *__restrict__ pair_ij) {
+// [108,144) -w Jj Ji', [144,150) -w r Ji, [150,156) w r Jj.  Threads >= 192 only take part in the barriers.
+__device__ __forceinline__ void
+    ba_pair_body(int g, const float *__restrict__ rec, const int32_t *__restrict__ order,
+                 const int32_t *__restrict__ seg, const int32_t *__restrict__ ngroups,
+                 float *__restrict__ pairs, int32_t *__restrict__ pair_ij) {
   __shared__ __attribute__((aligned(16))) float s_rec[48 * BA_REC];   // 48 records per batch
-  const int g = blockIdx.x;
   if (g >= *ngroups) return;
   const int tid = threadIdx.x;
   const int s0 = seg[g], s1 = seg[g + 1];
@@ -191,7 +198,7 @@ __global__ void __launch_bounds__(192)
   for (int b0 = s0; b0 < s1; b0 += 48) {
     const int nb = min(48, s1 - b0);
     __syncthreads();
-    for (int q = tid; q < nb * (BA_REC / 4); q += 192) {      // coalesced 16-byte loads of whole records
+    for (int q = tid < 192 ? tid : nb * (BA_REC / 4); q < nb * (BA_REC / 4); q += 192) {      // coalesced 16-byte loads of whole records
       const int rr = q / (BA_REC / 4), cc = q - rr * (BA_REC / 4);
       reinterpret_cast<float4 *>(s_rec)[q] =
           reinterpret_cast<const float4 *>(rec + (size_t)order[b0 + rr] * BA_REC)[cc];
@@ -216,6 +223,28 @@ __global__ void __launch_bounds__(192)
     }
   }
   if (tid < 156) pairs[(size_t)g * BA_PAIR + tid] = acc;
+}
+
+__global__ void __launch_bounds__(192)
+    ba_pair_kernel(const float *__restrict__ rec, const int32_t *__restrict__ order,
+                   const int32_t *__restrict__ seg, const int32_t *__restrict__ ngroups,
+                   float *__restrict__ pairs, int32_t *__restrict__ pair_ij) {
+  ba_pair_body(blockIdx.x, rec, order, seg, ngroups, pairs, pair_ij);
+}
+
+// K2 and K3 read the same per-edge records and do not depend on each other: one launch, the first n_patch
+// workgroups take the patch role, the rest the pair role (same arithmetic as the separate kernels)
+__global__ void __launch_bounds__(256)
+    ba_patch_pair_kernel(int n_patch, const float *__restrict__ rec, const int32_t *__restrict__ order_k,
+                         const int32_t *__restrict__ seg_k, const int32_t *__restrict__ nk,
+                         const float *__restrict__ lmbda, float *__restrict__ Erow, float *__restrict__ Cv,
+                         float *__restrict__ uv, float *__restrict__ Qv, int n6,
+                         const int32_t *__restrict__ order_p, const int32_t *__restrict__ seg_p,
+                         const int32_t *__restrict__ np, float *__restrict__ pairs, int32_t *__restrict__ pair_ij) {
+  if ((int)blockIdx.x < n_patch)
+    ba_patch_body(blockIdx.x, rec, order_k, seg_k, nk, lmbda, Erow, Cv, uv, Qv, n6);
+  else
+    ba_pair_body(blockIdx.x - n_patch, rec, order_p, seg_p, np, pairs, pair_ij);
 }
 
 // ------------------------------------------------------------------ K4
@@ -639,11 +668,13 @@ static int ba_iterate(float *poses, float *patches, const float *intrinsics, con
   for (int itr = 0; itr < iterations; itr++) {
     hipLaunchKernelGGL(ba_edge_kernel, dim3(ramp_cdiv(E, 256)), dim3(256), 0, st, poses, patches,
                        intrinsics, target, weight, ii, jj, kk, w.rec, E, PP, c11, t0, N);
-    hipLaunchKernelGGL(ba_patch_kernel, dim3(w.Mu_b), dim3(pthreads), 0, st, w.rec, order_k, seg_k, nk,
-                       lmbda, w.Erow, w.Cv, w.uv, w.Qv, n6);
+    if (N > 0)
+      hipLaunchKernelGGL(ba_patch_pair_kernel, dim3(w.Mu_b + w.Gp_b), dim3(256), 0, st, w.Mu_b, w.rec, order_k,
+                         seg_k, nk, lmbda, w.Erow, w.Cv, w.uv, w.Qv, n6, order_p, seg_p, np, w.pairs, w.pair_ij);
+    else
+      hipLaunchKernelGGL(ba_patch_kernel, dim3(w.Mu_b), dim3(pthreads), 0, st, w.rec, order_k, seg_k, nk,
+                         lmbda, w.Erow, w.Cv, w.uv, w.Qv, n6);
     if (N > 0) {
-      hipLaunchKernelGGL(ba_pair_kernel, dim3(w.Gp_b), dim3(192), 0, st, w.rec, order_p, seg_p, np,
-                         w.pairs, w.pair_ij);
       hipLaunchKernelGGL(ba_schur_kernel, dim3(w.tiles, w.tiles, w.KS), dim3(256), 0, st, w.Erow,
                          w.Qv, w.uv, nk, w.S_part, w.y_part, n6, w.KS);
       hipLaunchKernelGGL(ba_assemble_kernel, dim3(N, ramp_cdiv(6 * n6, 192)), dim3(256), 0, st, w.pairs, w.pair_ij, np,
