@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--mixed", type=int, default=1,
                     help="1 (default.yaml's MIXED_PRECISION: True): fp16 features / conv + GEMM I/O with fp32 "
                          "accumulation, fp32 hidden state, BA and geometry; 0: fp32 everywhere")
-    ap.add_argument("--cpu-steps", type=int, default=3, help="steps of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=6, help="steps of the CPU baseline sample, ~2 s each (0 = skip)")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="1: the synthetic frames are resident in HBM before their step (the bench contract), so the "
                          "tracker may launch frame t+1's front end while frame t's bundle adjustment drains "
