@@ -149,6 +149,45 @@ class CorrTimer:
         return out
 
 
+class BaTimer:
+    """HIP events around fastba.BA (two Gauss-Newton iterations, 6 launches each + one memset)"""
+
+    def __init__(self):
+        self.pairs, self.meta, self.enabled = [], [], False
+
+    def install(self):
+        from rampvo_amd import fastba
+        inner, timer = fastba.BA, self
+
+        def timed(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t1, *a, **k):
+            if not timer.enabled:
+                return inner(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t1, *a, **k)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = inner(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t1, *a, **k)
+            e.record()
+            timer.pairs.append((s, e))
+            timer.meta.append((int(ii.shape[0]), int(t1 - t0), int(k.get("iterations", 2))))
+            return out
+
+        fastba.BA = timed
+
+    def summary(self, patches_per_frame, removal_window):
+        if not self.pairs:
+            return None
+        ms = float(np.mean([s.elapsed_time(e) for s, e in self.pairs]))
+        E, N, it = (float(np.mean([m[i] for m in self.meta])) for i in range(3))
+        mu = patches_per_frame * removal_window
+        # SURVEY 8(d): 116 B per edge per iteration in, + per-iteration outputs (6N)^2 + 6N*Mu + 2*Mu + 6N floats
+        nbytes = it * (116.0 * E + 4.0 * ((6 * N) ** 2 + 6 * N * mu + 2 * mu + 6 * N))
+        ach = nbytes / (ms * 1e-3) / 1e9
+        return dict(kernel="fastba.BA: ba_edge / ba_patch_pair / ba_schur / ba_assemble / ba_chol64 / ba_retract x 2",
+                    bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 5),
+                    traffic=None, mean_call_us=round(ms * 1e3, 1), bytes_per_call=int(nbytes), edges=int(E),
+                    free_poses=int(N), note="a dependent chain of 13 small launches: latency, not bandwidth, bounds it "
+                                            "(time includes the overlap with the next frame's front end when pipelining)")
+
+
 MFMA_F16_PEAK_TFLOPS = 2500.0   # dense f16 MFMA, MI355X_MICROARCH.md
 MFMA_F32_PEAK_TFLOPS = 157.0    # fp32 MFMA (the --mixed 0 towers)
 
@@ -276,10 +315,11 @@ def main():
     stream = SyntheticStream(args.height, args.width, total + n_cpu + 1, seed=1234 + rank, device=dev)
     frames = [tuple(x.to(dev) if i < 2 else x for i, x in enumerate(stream.frame(t))) for t in range(total)]
 
-    ctimer, etimer = CorrTimer(), EncoderTimer()
+    ctimer, etimer, btimer = CorrTimer(), EncoderTimer(), BaTimer()
     if not args.no_kernel_timing:
         ctimer.install()
         etimer.install(net)
+        btimer.install()
 
     def step(t):
         im, ev, K, mask = frames[t]
@@ -303,7 +343,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ctimer.enabled = etimer.enabled = True
+    ctimer.enabled = etimer.enabled = btimer.enabled = True
     tic = time.perf_counter()
     marks = [tic]
     for _ in range(args.steps):
@@ -315,7 +355,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - tic
-    ctimer.enabled = etimer.enabled = False
+    ctimer.enabled = etimer.enabled = btimer.enabled = False
 
     from rampvo_amd.shard import gather_metrics, max_over_ranks
     dt_all = max_over_ranks(dt, dev)
@@ -354,6 +394,9 @@ def main():
         el = etimer.summary(bool(args.mixed))
         if el is not None:
             out["roofline_encoder"] = el
+        bl = btimer.summary(args.patches, cfg.REMOVAL_WINDOW)
+        if bl is not None:
+            out["roofline_ba"] = bl
         if n_cpu:
             state = slam.state_dict()
             cpu_frames = [stream.frame(total + i) for i in range(n_cpu)]

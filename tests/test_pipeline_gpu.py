@@ -212,7 +212,7 @@ def test_bench_json_contract():
     assert len(lines) == 1
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "roofline_encoder", "cpu_baseline"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "roofline_encoder", "roofline_ba", "cpu_baseline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 12 and d["warmup"] == 3 and d["higher_is_better"] is True
     assert d["unit"] == "keyframes/s" and d["value"] > 0 and d["vs_baseline"] is None and "workload" in d["config"]
