@@ -30,15 +30,24 @@ def sync(self):
 torch.cuda.Event.synchronize = sync
 c0 = slam.corr
 def corr(*a, **k):
+    r = c0(*a, **k)
     if on[0] and inwin[0] and k.get("order") is not None:
-        acc["TOTAL sync->corr"] += time.perf_counter() - t_sync[0]; cnt["TOTAL sync->corr"] += 1; inwin[0] = False
-    return c0(*a, **k)
+        acc["TOTAL sync->corr launched"] += time.perf_counter() - t_sync[0]; cnt["TOTAL sync->corr launched"] += 1; inwin[0] = False
+    return r
 slam.corr = corr
 for n in ("_spec_outcome", "_build_next_plan", "_apply_removal", "_prefetch_edges", "append_factors", "reproject",
           "_initial_depth", "_graph_plan", "_upload"):
     wrap(slam, n)
-for n in ("frame_begin", "depth_median_fill", "multi_copy", "shift_rows"):
+for n in ("frame_begin", "depth_median_fill", "store_rows"):
     wrap(ops, n)
+wrap(slam, "_corr_launch"); wrap(slam, "_keyframe_finish"); wrap(slam, "_wait_upload_stream")
+import rampvo_amd.ops as _o
+_sp = _o.ShiftPlan.run
+def _run(self, k, n):
+    t = time.perf_counter(); r = _sp(self, k, n)
+    if on[0] and inwin[0]: acc["shift_rows"] += time.perf_counter() - t; cnt["shift_rows"] += 1
+    return r
+_o.ShiftPlan.run = _run
 wrap(torch.cuda.Stream, "wait_stream"); wrap(torch.cuda.Stream, "wait_event"); wrap(torch.cuda.Event, "record")
 wrap(torch.cuda, "current_stream")
 for t in range(T):
@@ -46,6 +55,6 @@ for t in range(T):
         torch.cuda.synchronize(); on[0] = True
     im, ev, K, mask = frames[t]; slam(t, input_tensor=(ev, im, mask), intrinsics=K)
 slam.settle(); torch.cuda.synchronize()
-n = cnt["TOTAL sync->corr"]
+n = cnt["TOTAL sync->corr launched"]
 for k, v in acc.most_common():
     print("  %-22s %7.1f us/frame  %5.2f calls/frame" % (k, 1e6 * v / n, cnt[k] / n))
