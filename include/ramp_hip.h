@@ -192,6 +192,17 @@ int ramp_motion_model(float *poses, int n, float damping, void *stream);
 int ramp_frame_begin(float *poses, int n, int motion, float damping, int64_t *tstamps, int64_t counter,
                      int64_t *index_map, int64_t index_val, float *intrinsics, int copy_k, void *stream);
 
+/* ramp_frame_begin + ramp_depth_median_fill + ramp_multi_copy of a steady-state Ramp_vo.__call__ as ONE launch
+ * (ramp/Ramp_vo.py:345-381; three dependent tiny launches on the frame's critical path otherwise):
+ *   frame_begin's arguments as above; patches_state [N][M][3][P][P] fp32: the depth channel of patches_new
+ *   [M][3][P][P] becomes the median of rows n - median_frames .. n - 1 (median_frames = 0: left as is) and
+ *   patches_new is stored as row n; then dst[b] = src[b] for n_copy <= 6 further buffers (16-byte aligned,
+ *   16-byte multiples: colours, imap, gmap, fmap1, fmap2 rows).                                          */
+int ramp_frame_commit(float *poses, int n, int motion, float damping, int64_t *tstamps, int64_t counter,
+                      int64_t *index_map, int64_t index_val, float *intrinsics, int copy_k, float *patches_state,
+                      int median_frames, int M, int P, float *patches_new, int n_copy, const void *const *src_host,
+                      void *const *dst_host, const long *bytes_host, void *stream);
+
 /* Tracker bookkeeping helpers (host-side pointer arrays, <= 10 buffers per call).
  * ramp_multi_copy: dst[b][0:bytes[b]) = src[b][...] -- the per-frame stores of imap/gmap/fmap1/fmap2/
  *   patches/colors into the state buffers (ramp/Ramp_vo.py:345-381) in one launch.

@@ -820,65 +820,29 @@ class Ramp_vo:
         self.tlist.append(tstamp)
         del self._tstamps[n:]
         self._tstamps.append(self.counter)
-        if self.device.type == "cuda":
-            # time stamp, index map, intrinsics row and motion-model pose: one launch
+        ex = getattr(self.network.patchify, "_extra", None)
+        slot = n % self.mem
+        if (self.device.type == "cuda" and ex is not None and ex["fmap"].dtype == self.dtype
+                and ex["chunked"] == self._chunked and (self.M * 3) % 16 == 0 and patches.is_contiguous()
+                and patches.dtype == torch.float32 and ops.depth_median_supported(3, self.M, self.P)
+                and (not self.is_initialized or n >= 3)
+                and all(ex[k].data_ptr() % 16 == 0 for k in ("colors", "imap", "gmap", "fmap", "fmap2"))):
+            # bookkeeping writes, depth initialisation and all state stores of the frame: ONE launch
             copy_k = k_dev is None and n > 0
             if not copy_k:
                 self.intrinsics_[n] = k_dev if k_dev is not None else self._upload(kq.astype(np.float32))
                 self._last_K = kq
             motion = 0 if n <= 1 else (1 if self.cfg.MOTION_MODEL == 'DAMPED_LINEAR' else 2)
-            ops.frame_begin(self.poses_, n, motion, self.cfg.MOTION_DAMPING, self.tstamps_, self.counter,
-                            self.index_map_, self.m + self.M, self.intrinsics_, copy_k)
+            if not self.is_initialized:
+                patches[:, :, 2] = self._initial_depth(patches)       # reference :369; replaced by the median later
+            ops.frame_commit(self.poses_, n, motion, self.cfg.MOTION_DAMPING, self.tstamps_, self.counter,
+                             self.index_map_, self.m + self.M, self.intrinsics_, copy_k, self.patches_,
+                             3 if self.is_initialized else 0, patches,
+                             [ex["colors"], ex["imap"], ex["gmap"], ex["fmap"], ex["fmap2"]],
+                             [(self.colors_, n), (self.imap_, slot), (self.gmap_, slot), (self.fmap1_, slot),
+                              (self.fmap2_, slot)])
         else:
-            self.tstamps_[n].fill_(self.counter)
-            self.index_map_[n + 1].fill_(self.m + self.M)
-            if k_dev is None and n > 0:
-                self.intrinsics_[n] = self.intrinsics_[n - 1]     # unchanged intrinsics: device-side row copy
-            else:
-                self.intrinsics_[n] = k_dev if k_dev is not None else self._upload(kq.astype(np.float32))
-                self._last_K = kq
-            if n > 1:
-                if self.cfg.MOTION_MODEL == 'DAMPED_LINEAR':
-                    P1 = SE3(self.poses_[n - 1])
-                    P2 = SE3(self.poses_[n - 2])
-                    xi = self.cfg.MOTION_DAMPING * (P1 * P2.inv()).log()
-                    self.poses_[n] = (SE3.exp(xi) * P1).data
-                else:
-                    self.poses_[n] = self.poses_[n - 1]
-
-        # reference :369-372: random inverse depths, replaced by the median of the last three keyframes once the
-        # tracker is initialised -- the draw is dead then and is not made (nothing else consumes the generator)
-        if self.is_initialized:
-            if (self.device.type == "cuda" and patches.is_contiguous() and patches.dtype == torch.float32
-                    and ops.depth_median_supported(3, self.M, self.P)):
-                ops.depth_median_fill(self.patches_, n, 3, patches[0])       # radix select + fill, one launch
-            else:
-                patches[:, :, 2] = torch.median(self.patches_[n - 3:n, :, 2])
-        else:
-            patches[:, :, 2] = self._initial_depth(patches)
-
-        slot = n % self.mem
-        ex = getattr(self.network.patchify, "_extra", None)
-        if (ex is not None and self.device.type == "cuda" and ex["fmap"].dtype == self.dtype
-                and (self.M * 3) % 4 == 0 and patches.is_contiguous() and ex["chunked"] == self._chunked):
-            # one launch: patches, colours and the four feature tensors into their state rows / ring slots
-            ops.store_rows([patches, ex["colors"], ex["imap"], ex["gmap"], ex["fmap"], ex["fmap2"]],
-                           [(self.patches_, n), (self.colors_, n), (self.imap_, slot), (self.gmap_, slot),
-                            (self.fmap1_, slot), (self.fmap2_, slot)])
-        else:
-            clr = (clr[0][:, [2, 1, 0]] + 0.5) * (255.0 / 2)
-            self.colors_[n] = clr.to(torch.uint8)
-            self.patches_[n] = patches
-            self.imap_[slot] = imap.reshape(self.M, self.DIM).to(self.dtype)
-            self.gmap_[slot] = gmap[0].permute(0, 2, 3, 1).to(self.dtype)
-            f = fmap[0]                                                  # [1,128,h,w], channels-last storage
-            if self._chunked:
-                ops.pyramid_pack(f[0].permute(1, 2, 0).to(self.dtype).contiguous(), self.fmap1_[slot],
-                                 self.fmap2_[slot])
-            else:
-                self.fmap1_[slot] = f[0].permute(1, 2, 0).to(self.dtype)
-                self.fmap2_[slot] = F.avg_pool2d(f, 4, 4)[0].permute(1, 2, 0).to(self.dtype)
-
+            self._frame_stores_stepwise(n, slot, k_dev, kq, patches, imap, gmap, fmap, clr, ex)
         if self.inputs_ready and self.device.type == "cuda":
             self._fe_free = self._ev_fe_free
             self._fe_free.record()
@@ -986,6 +950,66 @@ class Ramp_vo:
         del self._tstamps[self.n:]
         self.poses_[self.n] = torch.tensor([0, 0, 0, 0, 0, 0, 1], dtype=torch.float, device=self.device)
         self.tstamps_[self.n] = 0
+
+    def _frame_stores_stepwise(self, n, slot, k_dev, kq, patches, imap, gmap, fmap, clr, ex):
+        """the same writes as ops.frame_commit, one step at a time (CPU oracle backend, first frames, odd shapes)"""
+        if self.device.type == "cuda":
+            # time stamp, index map, intrinsics row and motion-model pose: one launch
+            copy_k = k_dev is None and n > 0
+            if not copy_k:
+                self.intrinsics_[n] = k_dev if k_dev is not None else self._upload(kq.astype(np.float32))
+                self._last_K = kq
+            motion = 0 if n <= 1 else (1 if self.cfg.MOTION_MODEL == 'DAMPED_LINEAR' else 2)
+            ops.frame_begin(self.poses_, n, motion, self.cfg.MOTION_DAMPING, self.tstamps_, self.counter,
+                            self.index_map_, self.m + self.M, self.intrinsics_, copy_k)
+        else:
+            self.tstamps_[n].fill_(self.counter)
+            self.index_map_[n + 1].fill_(self.m + self.M)
+            if k_dev is None and n > 0:
+                self.intrinsics_[n] = self.intrinsics_[n - 1]     # unchanged intrinsics: device-side row copy
+            else:
+                self.intrinsics_[n] = k_dev if k_dev is not None else self._upload(kq.astype(np.float32))
+                self._last_K = kq
+            if n > 1:
+                if self.cfg.MOTION_MODEL == 'DAMPED_LINEAR':
+                    P1 = SE3(self.poses_[n - 1])
+                    P2 = SE3(self.poses_[n - 2])
+                    xi = self.cfg.MOTION_DAMPING * (P1 * P2.inv()).log()
+                    self.poses_[n] = (SE3.exp(xi) * P1).data
+                else:
+                    self.poses_[n] = self.poses_[n - 1]
+
+        # reference :369-372: random inverse depths, replaced by the median of the last three keyframes once the
+        # tracker is initialised -- the draw is dead then and is not made (nothing else consumes the generator)
+        if self.is_initialized:
+            if (self.device.type == "cuda" and patches.is_contiguous() and patches.dtype == torch.float32
+                    and ops.depth_median_supported(3, self.M, self.P)):
+                ops.depth_median_fill(self.patches_, n, 3, patches[0])       # radix select + fill, one launch
+            else:
+                patches[:, :, 2] = torch.median(self.patches_[n - 3:n, :, 2])
+        else:
+            patches[:, :, 2] = self._initial_depth(patches)
+
+        if (ex is not None and self.device.type == "cuda" and ex["fmap"].dtype == self.dtype
+                and (self.M * 3) % 4 == 0 and patches.is_contiguous() and ex["chunked"] == self._chunked):
+            # one launch: patches, colours and the four feature tensors into their state rows / ring slots
+            ops.store_rows([patches, ex["colors"], ex["imap"], ex["gmap"], ex["fmap"], ex["fmap2"]],
+                           [(self.patches_, n), (self.colors_, n), (self.imap_, slot), (self.gmap_, slot),
+                            (self.fmap1_, slot), (self.fmap2_, slot)])
+        else:
+            clr = (clr[0][:, [2, 1, 0]] + 0.5) * (255.0 / 2)
+            self.colors_[n] = clr.to(torch.uint8)
+            self.patches_[n] = patches
+            self.imap_[slot] = imap.reshape(self.M, self.DIM).to(self.dtype)
+            self.gmap_[slot] = gmap[0].permute(0, 2, 3, 1).to(self.dtype)
+            f = fmap[0]                                                  # [1,128,h,w], channels-last storage
+            if self._chunked:
+                ops.pyramid_pack(f[0].permute(1, 2, 0).to(self.dtype).contiguous(), self.fmap1_[slot],
+                                 self.fmap2_[slot])
+            else:
+                self.fmap1_[slot] = f[0].permute(1, 2, 0).to(self.dtype)
+                self.fmap2_[slot] = F.avg_pool2d(f, 4, 4)[0].permute(1, 2, 0).to(self.dtype)
+
 
     def _initial_depth(self, patches):
         """reference :369 -- torch.rand_like; overridable so parity tests can inject the

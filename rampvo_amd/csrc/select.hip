@@ -206,8 +206,8 @@ __global__ void __launch_bounds__(TOPK_THREADS)
 // of the M new patches.  One workgroup: keys in registers, 4 x 8-bit radix passes (k-th smallest), fill.
 #define MED_THREADS 1024
 #define MED_PER 4               // up to 4096 values
-__global__ void __launch_bounds__(MED_THREADS)
-    depth_median_fill_kernel(const float *__restrict__ src, int F, int M, int PP, float *__restrict__ dst) {
+// lower median of the F*M*PP depth values of src ([F*M][3][PP] rows, channel 2); every thread of the 1024 returns it
+__device__ __forceinline__ float depth_median_block(const float *__restrict__ src, int F, int M, int PP) {
   __shared__ unsigned hist[256];
   __shared__ unsigned s_prefix, s_remaining;
   const int tid = threadIdx.x, n = F * M * PP;
@@ -263,12 +263,69 @@ __global__ void __launch_bounds__(MED_THREADS)
   }
   unsigned b = s_prefix;
   b ^= (b >> 31) ? 0x80000000u : 0xffffffffu;             // inverse map
-  const float med = __uint_as_float(b);
-  for (int i = tid; i < M * PP; i += MED_THREADS) {
+  return __uint_as_float(b);
+}
+
+__global__ void __launch_bounds__(MED_THREADS)
+    depth_median_fill_kernel(const float *__restrict__ src, int F, int M, int PP, float *__restrict__ dst) {
+  const float med = depth_median_block(src, F, M, PP);
+  for (int i = threadIdx.x; i < M * PP; i += MED_THREADS) {
     const int m = i / PP, p = i - m * PP;
     dst[((size_t)m * 3 + 2) * PP + p] = med;
   }
 }
+
+// Everything a steady-state Ramp_vo.__call__ writes before its reprojection (ramp/Ramp_vo.py:345-381) as ONE launch
+// -- these were three dependent tiny launches on the frame's critical path.  Workgroup (0, 0): time stamp, index
+// map, intrinsics row, motion-model pose (ramp_frame_begin), the depth median (ramp_depth_median_fill) and the new
+// row of the patch buffer; workgroups (*, 1 + b): copy of buffer b (ramp_multi_copy).
+#define FC_MAXBUF 6
+struct FrameCommit {
+  float *poses; int n, motion; float damping; int64_t *tstamps; int64_t counter; int64_t *index_map; int64_t index_val;
+  float *intrinsics; int copy_k;
+  const float *median_src; int F, M, PP; float *patches_new; float *patches_row;
+  int n_copy; const char *src[FC_MAXBUF]; char *dst[FC_MAXBUF]; long bytes[FC_MAXBUF];
+};
+__global__ void __launch_bounds__(MED_THREADS) frame_commit_kernel(const FrameCommit a) {
+  const int t = threadIdx.x;
+  if (blockIdx.y > 0) {
+    const int b = blockIdx.y - 1;
+    if (b >= a.n_copy) return;
+    const long n16 = a.bytes[b] / 16;                       // 16-byte multiples, 16-byte aligned (checked on the host)
+    const uint4 *s = reinterpret_cast<const uint4 *>(a.src[b]);
+    uint4 *o = reinterpret_cast<uint4 *>(a.dst[b]);
+    for (long i = (long)blockIdx.x * blockDim.x + t; i < n16; i += (long)gridDim.x * blockDim.x) o[i] = s[i];
+    return;
+  }
+  if (blockIdx.x != 0) return;
+  const int n = a.n;
+  if (t == 0) {
+    if (a.tstamps) a.tstamps[n] = a.counter;
+    if (a.index_map) a.index_map[n + 1] = a.index_val;
+  }
+  if (a.copy_k && t < 4) a.intrinsics[4 * n + t] = a.intrinsics[4 * (n - 1) + t];
+  if (a.motion == 2 && t < 7) a.poses[7 * n + t] = a.poses[7 * (n - 1) + t];
+  if (a.motion == 1 && t == 0) {
+    float P1[7], P2[7], P2i[7], D[7], xi[6], E[7], Pn[7];
+    for (int c = 0; c < 7; c++) { P1[c] = a.poses[7 * (n - 1) + c]; P2[c] = a.poses[7 * (n - 2) + c]; }
+    lt_inv(P2, P2i);
+    lt_mul(P1, P2i, D);
+    lt_log(D, xi);
+    for (int c = 0; c < 6; c++) xi[c] = a.damping * xi[c];
+    lt_exp(xi, E);
+    lt_mul(E, P1, Pn);
+    for (int c = 0; c < 7; c++) a.poses[7 * n + c] = Pn[c];
+  }
+  const bool fill = a.F > 0;
+  const float med = fill ? depth_median_block(a.median_src, a.F, a.M, a.PP) : 0.f;
+  for (int i = t; i < a.M * 3 * a.PP; i += MED_THREADS) {
+    const int ch = (i / a.PP) % 3;
+    float v = a.patches_new[i];
+    if (fill && ch == 2) { v = med; a.patches_new[i] = med; }
+    a.patches_row[i] = v;
+  }
+}
+
 
 extern "C" {
 
@@ -304,6 +361,37 @@ int ramp_event_topk(const float *events, int bins, int H, int W, int k, int nms_
     src = kept;
   }
   hipLaunchKernelGGL(topk_coords_kernel, dim3(1), dim3(TOPK_THREADS), 0, st, src, N, k, h, coords, indices);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+
+int ramp_frame_commit(float *poses, int n, int motion, float damping, int64_t *tstamps, int64_t counter,
+                      int64_t *index_map, int64_t index_val, float *intrinsics, int copy_k, float *patches_state,
+                      int median_frames, int M, int P, float *patches_new, int n_copy, const void *const *src_host,
+                      void *const *dst_host, const long *bytes_host, void *stream) {
+  if (!poses || !patches_state || !patches_new || n < 0 || M <= 0 || P <= 0 || n_copy < 0 || n_copy > FC_MAXBUF)
+    return RAMP_EINVAL;
+  if ((motion == 1 && n < 2) || ((motion == 2 || copy_k) && n < 1) || (copy_k && !intrinsics)) return RAMP_EINVAL;
+  if (median_frames < 0 || n - median_frames < 0) return RAMP_EINVAL;
+  if ((long)median_frames * M * P * P > MED_THREADS * MED_PER) return RAMP_EUNSUPPORTED;
+  FrameCommit a;
+  a.poses = poses; a.n = n; a.motion = motion; a.damping = damping; a.tstamps = tstamps; a.counter = counter;
+  a.index_map = index_map; a.index_val = index_val; a.intrinsics = intrinsics; a.copy_k = copy_k;
+  const size_t row = (size_t)M * 3 * P * P;
+  a.median_src = patches_state + (size_t)(n - median_frames) * row; a.F = median_frames; a.M = M; a.PP = P * P;
+  a.patches_new = patches_new; a.patches_row = patches_state + (size_t)n * row;
+  a.n_copy = n_copy;
+  long mx = 0;
+  for (int i = 0; i < n_copy; i++) {
+    if (!src_host[i] || !dst_host[i] || bytes_host[i] <= 0 || (bytes_host[i] & 15) ||
+        (((uintptr_t)src_host[i] | (uintptr_t)dst_host[i]) & 15))
+      return RAMP_EINVAL;
+    a.src[i] = (const char *)src_host[i]; a.dst[i] = (char *)dst_host[i]; a.bytes[i] = bytes_host[i];
+    if (bytes_host[i] > mx) mx = bytes_host[i];
+  }
+  int bx = (int)((mx / 16 + MED_THREADS - 1) / MED_THREADS);
+  bx = bx < 1 ? 1 : (bx > 256 ? 256 : bx);
+  hipLaunchKernelGGL(frame_commit_kernel, dim3(bx, 1 + n_copy), dim3(MED_THREADS), 0, (hipStream_t)stream, a);
   RAMP_CHECK_LAUNCH();
   return RAMP_OK;
 }

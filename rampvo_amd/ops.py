@@ -279,6 +279,23 @@ def store_rows(srcs, rows):
     check(lib().ramp_multi_copy(src, dst, (ctypes.c_long * n)(*rb), n, stream()), "ramp_multi_copy")
 
 
+def frame_commit(poses, n, motion, damping, tstamps, counter, index_map, index_val, intrinsics, copy_k, patches_state,
+                 median_frames, patches_new, srcs, rows):
+    """ramp_frame_commit: frame_begin + depth_median_fill + the state stores of one frame in one launch;
+    srcs[i] -> row rows[i][1] of buffer rows[i][0] (like store_rows), patches_new -> patches_state[n]"""
+    n_copy = len(srcs)
+    rb = [b.stride(0) * b.element_size() for b, _ in rows]
+    for s_, (b, _), nb in zip(srcs, rows, rb):
+        assert s_.numel() * s_.element_size() == nb and s_.is_contiguous() and b.is_contiguous()
+    src = (ctypes.c_void_p * n_copy)(*[s_.data_ptr() for s_ in srcs])
+    dst = (ctypes.c_void_p * n_copy)(*[b.data_ptr() + int(r) * nb for (b, r), nb in zip(rows, rb)])
+    _, M, _, P, _ = patches_state.shape
+    check(lib().ramp_frame_commit(ptr(poses), int(n), int(motion), float(damping), ptr(tstamps), int(counter),
+                                  ptr(index_map), int(index_val), ptr(intrinsics), int(bool(copy_k)), ptr(patches_state),
+                                  int(median_frames), M, P, ptr(patches_new), n_copy, src, dst,
+                                  (ctypes.c_long * n_copy)(*rb), stream()), "ramp_frame_commit")
+
+
 class ShiftPlan:
     """descriptor arrays of shift_rows for a fixed set of buffers (built once)"""
 
