@@ -802,10 +802,18 @@ class Ramp_vo:
                 fmap, gmap, imap, patches, _, clr = job.result()
             cur.wait_event(fe_done)
         pre = self._prefetch_edges() if (accepts and self.device.type == "cuda") else None
-        kq = intrinsics.detach().cpu().float().numpy() / self.RES
+        # intrinsics at feature resolution; the usual case (same values as the previous frame, CPU fp32 tensor)
+        # is recognised without building new arrays
         k_dev = None
-        if accepts and not (getattr(self, "_last_K", None) is not None and np.array_equal(kq, self._last_K)):
-            k_dev = self._upload(kq.astype(np.float32))
+        raw = getattr(self, "_last_K_raw", None)
+        if (raw is not None and intrinsics.device.type == "cpu" and intrinsics.dtype == torch.float32
+                and torch.equal(intrinsics, raw)):
+            kq = self._last_K
+        else:
+            kq = intrinsics.detach().cpu().float().numpy() / self.RES
+            self._K_raw_now = intrinsics.detach().cpu().float().clone()
+            if accepts and not (getattr(self, "_last_K", None) is not None and np.array_equal(kq, self._last_K)):
+                k_dev = self._upload(kq.astype(np.float32))
         if fe_done is None:
             fmap, gmap, imap, patches, _, clr = self.network.patchify(
                 input_=input_, patches_per_image=self.cfg.PATCHES_PER_FRAME, event_bias=self.event_bias,
@@ -831,7 +839,7 @@ class Ramp_vo:
             copy_k = k_dev is None and n > 0
             if not copy_k:
                 self.intrinsics_[n] = k_dev if k_dev is not None else self._upload(kq.astype(np.float32))
-                self._last_K = kq
+                self._last_K, self._last_K_raw = kq, self._K_raw_now
             motion = 0 if n <= 1 else (1 if self.cfg.MOTION_MODEL == 'DAMPED_LINEAR' else 2)
             if not self.is_initialized:
                 patches[:, :, 2] = self._initial_depth(patches)       # reference :369; replaced by the median later
@@ -958,7 +966,7 @@ class Ramp_vo:
             copy_k = k_dev is None and n > 0
             if not copy_k:
                 self.intrinsics_[n] = k_dev if k_dev is not None else self._upload(kq.astype(np.float32))
-                self._last_K = kq
+                self._last_K, self._last_K_raw = kq, self._K_raw_now
             motion = 0 if n <= 1 else (1 if self.cfg.MOTION_MODEL == 'DAMPED_LINEAR' else 2)
             ops.frame_begin(self.poses_, n, motion, self.cfg.MOTION_DAMPING, self.tstamps_, self.counter,
                             self.index_map_, self.m + self.M, self.intrinsics_, copy_k)
@@ -969,7 +977,7 @@ class Ramp_vo:
                 self.intrinsics_[n] = self.intrinsics_[n - 1]     # unchanged intrinsics: device-side row copy
             else:
                 self.intrinsics_[n] = k_dev if k_dev is not None else self._upload(kq.astype(np.float32))
-                self._last_K = kq
+                self._last_K, self._last_K_raw = kq, self._K_raw_now
             if n > 1:
                 if self.cfg.MOTION_MODEL == 'DAMPED_LINEAR':
                     P1 = SE3(self.poses_[n - 1])

@@ -221,3 +221,30 @@ def test_bench_json_contract():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["unit"] == "keyframes/s"
+
+
+@torch.no_grad()
+def test_intrinsics_rows_follow_the_input():
+    """intrinsics_[n] = K / RES of the frame stored at row n (reference Ramp_vo.py:351), also when K changes between
+    frames, across an events-only frame, and back (the unchanged case is a device-side row copy)"""
+    from rampvo_amd.config import make_cfg
+    from rampvo_amd.Ramp_vo import Ramp_vo
+    from rampvo_amd.synthetic import SyntheticStream, make_network
+    T = 7
+    stream = SyntheticStream(128, 160, T, seed=3, device="cuda")
+    slam = Ramp_vo(make_cfg("default", PATCHES_PER_FRAME=16, MIXED_PRECISION=True), make_network("MultiScale"),
+                   {"event_bias": True}, ht=128, wd=160)
+    Ks = [torch.tensor([80.0, 80.0, 80.0, 64.0]) * s for s in (1.0, 1.0, 1.5, 1.5, 2.0, 1.0, 1.0)]
+    masks = [True, True, True, False, True, True, True]
+    rows = []
+    for t in range(T):
+        im, ev, _, _ = stream.frame(t)
+        n0 = slam.n
+        slam(t, input_tensor=(ev, im, torch.tensor([masks[t]])), intrinsics=Ks[t].clone())
+        if masks[t]:
+            rows.append((n0, Ks[t] / 4.0))
+    kept = {}
+    for n0, k in rows:
+        kept[n0] = k                         # the last frame written to a row wins
+    for n0, k in kept.items():
+        assert torch.equal(slam.intrinsics_[n0].cpu(), k), (n0, slam.intrinsics_[n0], k)
