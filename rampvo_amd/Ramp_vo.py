@@ -103,6 +103,9 @@ class Ramp_vo:
         self._pending = None
         self._edge_tmpl = None
         self._spec_ema = 1.0                     # running frequency of "keyframe removed" (see _keyframe_speculative)
+        self._mm_prev, self._mm_inc = None, 3.0  # previous motion-test value / decision, its typical step
+        self._pred_score, self._pred_last = [0.5, 0.5], (True, True)
+        self._pred_stats = [0, 0]                # motion tests, misses (which outcome was prepared ahead)
         # pinned host buffers for the speculative graph layouts: the host mirror of the graph is a view of one of
         # them, the outcome(s) being prepared live in the others (fresh numpy buffers cost ~80 us of page faults
         # per MB, pageable uploads another ~50 us)
@@ -589,7 +592,15 @@ class Ramp_vo:
         dP = SE3(self.poses_[k]) * SE3(self.poses_[k - 1]).inv()      # only used if the keyframe goes
         # steady motion gives the same answer frame after frame: only the more frequent outcome so far is
         # prepared ahead; the other one is built after the read-back if the guess was wrong
-        guess = self._spec_ema >= 0.5
+        g_freq = self._spec_ema >= 0.5
+        g_saw = g_freq
+        if self._mm_prev is not None:
+            # the test value is a sawtooth under steady motion: it grows by a fairly constant step while keyframes
+            # are being removed (the compared frames drift apart) and drops once one is kept
+            pm, prem = self._mm_prev
+            g_saw = True if not prem else (pm + self._mm_inc < cfg.KEYFRAME_THRESH)
+        guess = g_saw if self._pred_score[1] >= self._pred_score[0] else g_freq
+        self._pred_last = (g_freq, g_saw)
         spec = {guess: self._spec_outcome(guess, k)}
         self._pending = dict(done=done, spec=spec, k=k, dP=dP)
         if not (self.inputs_ready and getattr(self.network.patchify, "_graphs", None)):
@@ -664,9 +675,17 @@ class Ramp_vo:
         mmh = self._mm_host.numpy()
         remove = float((mmh[0] + mmh[1]) * np.float32(0.5)) < cfg.KEYFRAME_THRESH      # fp32 mean, as torch's
         pre = spec.get(remove)
+        self._pred_stats[0] += 1
         if pre is None:
+            self._pred_stats[1] += 1
             pre = self._spec_outcome(remove, k)
         self._spec_ema = 0.9 * self._spec_ema + (0.1 if remove else 0.0)
+        m_now = float((mmh[0] + mmh[1]) * np.float32(0.5))
+        if self._mm_prev is not None and self._mm_prev[1] and m_now > self._mm_prev[0]:
+            self._mm_inc = 0.9 * self._mm_inc + 0.1 * (m_now - self._mm_prev[0])
+        self._mm_prev = (m_now, remove) if m_now == m_now else None          # NaN: no edges between the pair
+        for i, g in enumerate(self._pred_last):                              # running hit rate of both predictors
+            self._pred_score[i] = 0.95 * self._pred_score[i] + (0.05 if g == remove else 0.0)
         for other in spec.values():               # host buffers: the adopted layout becomes the mirror
             if other is not pre:
                 self._pool_busy.discard(other["pool"])

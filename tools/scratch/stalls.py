@@ -48,3 +48,4 @@ print("pinned reallocations:", reall)
 
 j = np.array(jw[100:]) * 1e3; y = np.array(sy[100:]) * 1e3
 print("job.result wait: mean %.3f ms p99 %.3f; event sync wait: mean %.3f median %.3f p99 %.3f" % (j.mean(), np.percentile(j, 99), y.mean(), np.median(y), np.percentile(y, 99)))
+print("motion tests %d, outcome not prepared ahead %d" % tuple(slam._pred_stats))
