@@ -447,6 +447,14 @@ int ramp_upd_corr_tail(const void *c1, const void *w2, const float *b2, const vo
                        const void *inp, const int64_t *inp_idx, long inp_mod, const float *norm_w,
                        const float *norm_b, float norm_eps, float *net_out, int E, void *stream);
 
+/* The whole correlation MLP and Update.norm in one launch: as ramp_upd_corr_tail, with c1 = relu(L1(corr)) formed by
+ * the kernel itself from corr [E][corr_k] fp16 (corr_k a multiple of 32: 896 = 882 + zero padding; w1 packed
+ * [corr_k/32][24][64][8] from the zero-padded weight, b1 fp32 [384]).                                   */
+int ramp_upd_corr_mlp(const void *corr, int corr_k, const void *w1, const float *b1, const void *w2, const float *b2,
+                      const void *w3, const float *b3, const float *ln_w, const float *ln_b, float ln_eps,
+                      const float *net, const int64_t *net_map, const void *inp, const int64_t *inp_idx, long inp_mod,
+                      const float *norm_w, const float *norm_b, float norm_eps, float *net_out, int E, void *stream);
+
 /* SoftAgg front half (ramp/blocks.py:42-46) in one launch: x = x32[e] (+ add_t[add_idx[e]], written to x32_out
  * when given; x32_out may be x32);  fg[e] = [ f(x) | g(x) ]  fp16 [E][768].  wf / wg packed like ramp_upd_gru's
  * weights, bf / bg fp32 [384].                                                                        */

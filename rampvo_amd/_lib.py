@@ -89,6 +89,8 @@ SIGNATURES = {
     "ramp_upd_segment_softmax": (c_i, [c_p] * 5 + [c_i, c_i, c_p]),
     "ramp_upd_corr_tail": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, ctypes.c_long, c_p, c_p,
                                  c_f, c_p, c_i, c_p]),
+    "ramp_upd_corr_mlp": (c_i, [c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, ctypes.c_long,
+                                c_p, c_p, c_f, c_p, c_i, c_p]),
     "ramp_upd_fg": (c_i, [c_p] * 9 + [c_i, c_p]),
     "ramp_upd_gru": (c_i, [c_p, c_p, c_p, c_p, c_p, c_f, ctypes.POINTER(c_p), ctypes.POINTER(c_p), c_p, c_p, c_f, c_p,
                            c_p, c_i, c_p]),

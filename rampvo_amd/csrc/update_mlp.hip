@@ -94,6 +94,27 @@ __device__ __forceinline__ void mlp_gemm(const _Float16 *Xs, const _Float16 *con
   }
 }
 
+// acc += Xs[64 x 32 nks] * W[:, 32 w_ks0 .. 32 (w_ks0 + nks))^T for this wave's 48 columns: one K chunk of a layer whose
+// K does not fit the tile (the activation chunk sits at tile columns 0 .. 32 nks)
+__device__ __forceinline__ void mlp_gemm_chunk(const _Float16 *Xs, const _Float16 *wp, int wave, int lane, int nks,
+                                               int w_ks0, f4 (&acc)[1][4][MNTW]) {
+  const int q = lane >> 4, j = lane & 15;
+#pragma unroll 2
+  for (int ks = 0; ks < nks; ks++) {
+    h8 a[4], bw[MNTW];
+#pragma unroll
+    for (int nt = 0; nt < MNTW; nt++)
+      bw[nt] = *reinterpret_cast<const h8 *>(wp + (((size_t)(w_ks0 + ks) * (MD / 16) + wave * MNTW + nt) * 64 + lane) * 8);
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++) a[mt] = *reinterpret_cast<const h8 *>(Xs + (mt * 16 + j) * MXS + ks * 32 + 8 * q);
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+      for (int nt = 0; nt < MNTW; nt++)
+        acc[0][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mt], bw[nt], acc[0][mt][nt], 0, 0, 0);
+  }
+}
+
 // Row-wise epilogues run in a second, ROW-MAJOR pass: the accumulator layout (lane (q, j): rows 4q..4q+3
 // of a 16-row tile, one column) would touch global memory in 64-byte pieces and needs cross-wave
 // reductions for a LayerNorm.  Instead the per-element product of the stage is parked in LDS as fp32
@@ -380,7 +401,12 @@ __global__ void __launch_bounds__(64 * MWAVES) __attribute__((amdgpu_waves_per_e
 // c1 = relu(Linear1(corr)) comes from the library GEMM (K = 896).  One 50 KB LDS tile (input, hidden, fp32
 // parking) -> two workgroups per CU.  Linear outputs are rounded to fp16 where autocast makes them half tensors.
 struct CorrTailParams {
-  const _Float16 *c1;          // [E][384] fp16
+  // FULL variant: the first Linear (+ReLU) of the MLP on the correlation rows as well
+  const _Float16 *corr;        // [E][corr_k] fp16 (corr_k a multiple of 32, e.g. 896 = 882 + zero padding)
+  const _Float16 *w1;          // packed [corr_k/32][24][64][8]
+  const float *b1;
+  int corr_k;
+  const _Float16 *c1;          // [E][384] fp16 (tail-only variant: relu(Linear1(corr)) from a library GEMM)
   const _Float16 *w2, *w3;     // packed weights of corr[2], corr[5]
   const float *b2, *b3;        // biases (fp16-rounded values as fp32)
   const float *ln_w, *ln_b;    // corr[3] LayerNorm
@@ -396,6 +422,7 @@ struct CorrTailParams {
   int E;
 };
 
+template <bool FULL>
 __global__ void __launch_bounds__(64 * MWAVES) __attribute__((amdgpu_waves_per_eu(6, 6)))
     upd_corr_tail_kernel(const CorrTailParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -403,14 +430,45 @@ __global__ void __launch_bounds__(64 * MWAVES) __attribute__((amdgpu_waves_per_e
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
   const int row0 = blockIdx.x * MBM;
   const int col0 = wave * (16 * MNTW);
-  for (int i = tid; i < MBM * (MD / 8); i += 64 * MWAVES) {
-    const int r = i / (MD / 8), c8 = i - r * (MD / 8);
-    h8 v = (h8){0, 0, 0, 0, 0, 0, 0, 0};
-    if (row0 + r < p.E) v = *reinterpret_cast<const h8 *>(p.c1 + (size_t)(row0 + r) * MD + 8 * c8);
-    *reinterpret_cast<h8 *>(Xs + r * MXS + 8 * c8) = v;
+  f4 acc[1][4][MNTW];
+  if (FULL) {
+    // Linear1 over K = corr_k in chunks of <= 12 K steps (the tile is 384 wide), then relu(+b1) becomes the tile
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+      for (int nt = 0; nt < MNTW; nt++) acc[0][mt][nt] = (f4){0.f, 0.f, 0.f, 0.f};
+    const int nks_total = p.corr_k / 32;
+    for (int ks0 = 0; ks0 < nks_total; ks0 += MKS) {
+      const int nks = min(MKS, nks_total - ks0);
+      const int v8 = nks * 4;                                  // 16-byte vectors per row of this chunk
+      for (int i = tid; i < MBM * v8; i += 64 * MWAVES) {
+        const int r = i / v8, c8 = i - r * v8;
+        h8 v = (h8){0, 0, 0, 0, 0, 0, 0, 0};
+        if (row0 + r < p.E) v = *reinterpret_cast<const h8 *>(p.corr + (size_t)(row0 + r) * p.corr_k + ks0 * 32 + 8 * c8);
+        *reinterpret_cast<h8 *>(Xs + r * MXS + 8 * c8) = v;
+      }
+      __syncthreads();
+      mlp_gemm_chunk(Xs, p.w1, wave, lane, nks, ks0, acc);
+      __syncthreads();                                         // before the tile is overwritten
+    }
+#pragma unroll
+    for (int nt = 0; nt < MNTW; nt++) {
+      const float b = p.b1[col0 + nt * 16 + j];
+#pragma unroll
+      for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          Xs[(mt * 16 + 4 * q + r) * MXS + col0 + nt * 16 + j] = (_Float16)fmaxf(acc[0][mt][nt][r] + b, 0.f);
+    }
+  } else {
+    for (int i = tid; i < MBM * (MD / 8); i += 64 * MWAVES) {
+      const int r = i / (MD / 8), c8 = i - r * (MD / 8);
+      h8 v = (h8){0, 0, 0, 0, 0, 0, 0, 0};
+      if (row0 + r < p.E) v = *reinterpret_cast<const h8 *>(p.c1 + (size_t)(row0 + r) * MD + 8 * c8);
+      *reinterpret_cast<h8 *>(Xs + r * MXS + 8 * c8) = v;
+    }
   }
   __syncthreads();
-  f4 acc[1][4][MNTW];
   {
     const _Float16 *const w1[1] = {p.w2};
     mlp_gemm<1>(Xs, w1, wave, lane, acc);
@@ -660,7 +718,29 @@ int ramp_upd_corr_tail(const void *c1, const void *w2, const float *b2, const vo
   p.inp_idx = inp_idx; p.inp_mod = inp_mod; p.norm_w = norm_w; p.norm_b = norm_b; p.norm_eps = norm_eps;
   p.net_out = net_out; p.E = E;
   const size_t lds = (size_t)MBM * MXS * 2;
-  hipLaunchKernelGGL(upd_corr_tail_kernel, dim3(ramp_cdiv(E, MBM)), dim3(64 * MWAVES), lds, (hipStream_t)stream, p);
+  p.corr = nullptr; p.w1 = nullptr; p.b1 = nullptr; p.corr_k = 0;
+  hipLaunchKernelGGL(upd_corr_tail_kernel<false>, dim3(ramp_cdiv(E, MBM)), dim3(64 * MWAVES), lds, (hipStream_t)stream, p);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+
+int ramp_upd_corr_mlp(const void *corr, int corr_k, const void *w1, const float *b1, const void *w2, const float *b2,
+                      const void *w3, const float *b3, const float *ln_w, const float *ln_b, float ln_eps,
+                      const float *net, const int64_t *net_map, const void *inp, const int64_t *inp_idx, long inp_mod,
+                      const float *norm_w, const float *norm_b, float norm_eps, float *net_out, int E, void *stream) {
+  if (E < 0) return RAMP_EINVAL;
+  if (E == 0) return RAMP_OK;
+  if (!corr || corr_k <= 0 || (corr_k & 31) || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !ln_w || !ln_b || !inp ||
+      !norm_w || !norm_b || !net_out || net == net_out)
+    return RAMP_EINVAL;
+  CorrTailParams p;
+  p.corr = (const _Float16 *)corr; p.w1 = (const _Float16 *)w1; p.b1 = b1; p.corr_k = corr_k; p.c1 = nullptr;
+  p.w2 = (const _Float16 *)w2; p.w3 = (const _Float16 *)w3; p.b2 = b2; p.b3 = b3;
+  p.ln_w = ln_w; p.ln_b = ln_b; p.ln_eps = ln_eps; p.net = net; p.net_map = net_map; p.inp = (const _Float16 *)inp;
+  p.inp_idx = inp_idx; p.inp_mod = inp_mod; p.norm_w = norm_w; p.norm_b = norm_b; p.norm_eps = norm_eps;
+  p.net_out = net_out; p.E = E;
+  const size_t lds = (size_t)MBM * MXS * 2;
+  hipLaunchKernelGGL(upd_corr_tail_kernel<true>, dim3(ramp_cdiv(E, MBM)), dim3(64 * MWAVES), lds, (hipStream_t)stream, p);
   RAMP_CHECK_LAUNCH();
   return RAMP_OK;
 }

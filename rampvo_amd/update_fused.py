@@ -38,6 +38,7 @@ class FusedUpdate:
         self._params = list(update.parameters())     # module structure is fixed; values are tracked by key
         self._act_ok = True
         self.use_mlp = os.environ.get("RAMP_UPD_MLP", "1") == "1"    # fused GEMM-chain kernels (fp16 only)
+        self.use_corr_mlp = os.environ.get("RAMP_CORR_MLP", "1") == "1"
         self.before_gru = None                   # optional callable run right before a stage is enqueued
         self.hook_at = "gru"
 
@@ -88,6 +89,8 @@ class FusedUpdate:
             w["c2_pack"] = (pack_linear_f16(m.c2[0].weight), hb(m.c2[0]), pack_linear_f16(m.c2[2].weight), hb(m.c2[2]))
             for name, agg in (("kk_fg_pack", m.agg_kk), ("ij_fg_pack", m.agg_ij)):
                 w[name] = (pack_linear_f16(agg.f.weight), hb(agg.f), pack_linear_f16(agg.g.weight), hb(agg.g))
+            w["corr1_pack"] = (pack_linear_f16(F.pad(m.corr[0].weight, (0, CORR_ROW - m.corr[0].weight.shape[1]))),
+                               hb(m.corr[0]))
             w["tail_pack"] = (pack_linear_f16(m.corr[2].weight), hb(m.corr[2]), pack_linear_f16(m.corr[5].weight),
                               hb(m.corr[5]))
         self._w, self._key = w, key
@@ -156,8 +159,22 @@ class FusedUpdate:
         self.dtype.  Returns (net_out fp32 [E,384], relu copy T)."""
         w = self.weights()
         E = corr.shape[0]
-        c = self.lin_relu(corr, w["corr0_pad"] if corr.shape[1] == CORR_ROW else w["corr0"])
-        if "tail_pack" in w and self.use_mlp:
+        if "tail_pack" in w and self.use_mlp and corr.shape[1] == CORR_ROW and self.use_corr_mlp:
+            # the whole correlation MLP (3 Linear, LayerNorm, ReLUs) + net + inp + c + LayerNorm: one launch
+            w1, b1 = w["corr1_pack"]
+            w2, b2, w3, b3 = w["tail_pack"]
+            ln, nm = w["corr_ln"], w["norm"]
+            net32 = torch.empty(E, 384, dtype=torch.float32, device=corr.device)
+            check(lib().ramp_upd_corr_mlp(ptr(corr), CORR_ROW, ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3),
+                                          ptr(ln[0]), ptr(ln[1]), float(ln[2]), ptr(net), ptr(net_map), ptr(inp_table),
+                                          ptr(inp_idx), int(inp_mod or 0), ptr(nm[0]), ptr(nm[1]), float(nm[2]),
+                                          ptr(net32), E, stream()), "ramp_upd_corr_mlp")
+            c = None
+        else:
+            c = self.lin_relu(corr, w["corr0_pad"] if corr.shape[1] == CORR_ROW else w["corr0"])
+        if c is None:
+            pass
+        elif "tail_pack" in w and self.use_mlp:
             # Linear, LayerNorm + ReLU, Linear, net + inp + c, LayerNorm: one launch (csrc/update_mlp.hip)
             w2, b2, w3, b3 = w["tail_pack"]
             ln, nm = w["corr_ln"], w["norm"]

@@ -496,6 +496,17 @@ def test_fused_gru_chain_matches_gemm_path():
     scale = float(outs[False][0].abs().max())
     assert float((outs[False][0] - outs[True][0]).abs().max()) <= 4e-3 * scale
     assert float((outs[False][1] - outs[True][1]).abs().max()) <= 4e-3 * scale
+    # padded correlation rows (the tracker's layout): the whole correlation MLP in one launch vs library GEMM + tail
+    corr_pad = torch.nn.functional.pad(corr, (0, 896 - 882)).contiguous()
+    res = {}
+    with torch.no_grad():
+        for one in (False, True):
+            fu.use_corr_mlp = one
+            o32, rt = fu.hidden(netst[:700].contiguous(), table, inp_idx, 300, corr_pad, plan, net_map=net_map)
+            res[one] = (o32.clone(), rt.float().clone())
+    fu.use_corr_mlp = True
+    assert float((res[False][0] - res[True][0]).abs().max()) <= 4e-3 * scale
+    assert float((res[False][0] - outs[True][0]).abs().max()) <= 4e-3 * scale          # padding changes nothing
 
 
 def test_event_stack_matches_reference_golden_and_oracle():
