@@ -455,6 +455,12 @@ int ramp_upd_corr_mlp(const void *corr, int corr_k, const void *w1, const float 
                       const float *net, const int64_t *net_map, const void *inp, const int64_t *inp_idx, long inp_mod,
                       const float *norm_w, const float *norm_b, float norm_eps, float *net_out, int E, void *stream);
 
+/* fp16 path: the two heads' Linear layers (ramp/net.py:64-66) + ramp_upd_heads's epilogue in one launch:
+ * hw = relu_t [E][384] @ heads_w [4][384]^T + heads_b (rounded to fp16 like the GEMM's output), then target = patch
+ * centre of coords + hw[:2], weight = sigmoid(hw[2:]) zeroed where target is outside [0,wd]x[0,ht].     */
+int ramp_upd_heads_linear(const void *relu_t, const void *heads_w, const float *heads_b, const float *coords,
+                          float *target, float *weight, int E, int P, float wd, float ht, void *stream);
+
 /* SoftAgg front half (ramp/blocks.py:42-46) in one launch: x = x32[e] (+ add_t[add_idx[e]], written to x32_out
  * when given; x32_out may be x32);  fg[e] = [ f(x) | g(x) ]  fp16 [E][768].  wf / wg packed like ramp_upd_gru's
  * weights, bf / bg fp32 [384].                                                                        */

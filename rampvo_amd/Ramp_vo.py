@@ -743,7 +743,11 @@ class Ramp_vo:
                 out32, relu_t = fu.hidden(self._net_buf[0], self.imap_.view(-1, self.DIM), self.kk, self.M * self.mem,
                                           corr[0], plan, net_map=net_map)
                 self.net = out32[None]
-                target, weight, _ = fu.target_weight(fu.heads(relu_t), coords[0], self.wd // 4, self.ht // 4)
+                tw = fu.heads_target_weight(relu_t, coords[0], self.wd // 4, self.ht // 4)
+                if tw is not None:
+                    target, weight = tw
+                else:
+                    target, weight, _ = fu.target_weight(fu.heads(relu_t), coords[0], self.wd // 4, self.ht // 4)
             else:
                 ctx = self.imap[:, self.kk % (self.M * self.mem)]
                 self.net, (delta, weight, _) = self.network.update(self.net, ctx, corr, None, self.ii, self.jj,

@@ -91,6 +91,7 @@ SIGNATURES = {
                                  c_f, c_p, c_i, c_p]),
     "ramp_upd_corr_mlp": (c_i, [c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, ctypes.c_long,
                                 c_p, c_p, c_f, c_p, c_i, c_p]),
+    "ramp_upd_heads_linear": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_p]),
     "ramp_upd_fg": (c_i, [c_p] * 9 + [c_i, c_p]),
     "ramp_upd_gru": (c_i, [c_p, c_p, c_p, c_p, c_p, c_f, ctypes.POINTER(c_p), ctypes.POINTER(c_p), c_p, c_p, c_f, c_p,
                            c_p, c_i, c_p]),

@@ -208,6 +208,57 @@ __global__ void __launch_bounds__(256)
   if (delta) { delta[2 * (size_t)e + 0] = dx; delta[2 * (size_t)e + 1] = dy; }
 }
 
+// fp16 path: the two heads' Linear layers (ramp/net.py:64-66; 4 outputs per edge) and the epilogue above in one
+// launch -- a [E,384]x[384,4] GEMM is a row-wise dot product: one wave per edge row (lane l: channels 2l + 128k +
+// {0,1}), DPP wave sums, lane 0 finishes like upd_heads_kernel.  Outputs are rounded to fp16 where the GEMM's are.
+__device__ __forceinline__ float heads_wave_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+typedef _Float16 hd_h2 __attribute__((ext_vector_type(2)));
+__global__ void __launch_bounds__(256)
+    upd_heads_linear_f16_kernel(const _Float16 *__restrict__ relu_t, const _Float16 *__restrict__ hwt,
+                                const float *__restrict__ hb, const float *__restrict__ coords,
+                                float *__restrict__ target, float *__restrict__ weight, int E, int PP, int ctr,
+                                float wd, float ht) {
+  const int lane = threadIdx.x & 63;
+  const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (e >= E) return;
+  float x[6];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const hd_h2 v = *reinterpret_cast<const hd_h2 *>(relu_t + (size_t)e * UD + 2 * lane + 128 * k);
+    x[2 * k] = (float)v[0]; x[2 * k + 1] = (float)v[1];
+  }
+  float o[4];
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const hd_h2 wv = *reinterpret_cast<const hd_h2 *>(hwt + c * UD + 2 * lane + 128 * k);
+      acc += x[2 * k] * (float)wv[0];
+      acc += x[2 * k + 1] * (float)wv[1];
+    }
+    o[c] = (float)(_Float16)(heads_wave_sum(acc) + hb[c]);          // the Linear output is a half tensor
+  }
+  if (lane != 0) return;
+  const float wx = (float)(_Float16)(1.0f / (1.0f + expf(-o[2])));
+  const float wy = (float)(_Float16)(1.0f / (1.0f + expf(-o[3])));
+  const float tx = coords[((size_t)e * 2 + 0) * PP + ctr] + o[0];
+  const float ty = coords[((size_t)e * 2 + 1) * PP + ctr] + o[1];
+  const bool outside = (tx < 0) || (tx > wd) || (ty < 0) || (ty > ht);
+  target[2 * (size_t)e + 0] = tx;
+  target[2 * (size_t)e + 1] = ty;
+  weight[2 * (size_t)e + 0] = outside ? 0.0f : wx;
+  weight[2 * (size_t)e + 1] = outside ? 0.0f : wy;
+}
+
 // SoftAgg core over the stacked [f | g] rows (row stride 768): y[g][c] = sum softmax(g) * f.
 // One workgroup per group: SEG_R row lanes x 96 threads x 4 channels.  Row lane w walks rows w, w + R, ... of
 // the group (ascending edge order) with a running max (online softmax); the R partial (max, sum, weighted
@@ -374,6 +425,19 @@ int ramp_upd_heads(const void *hw, const float *coords, float *target, float *we
     hipLaunchKernelGGL(upd_heads_kernel<_Float16>, grid, block, 0, (hipStream_t)stream, (const _Float16 *)hw,
                        coords, target, weight, delta, E, PP, ctr, wd, ht);
   else return RAMP_EINVAL;
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+
+int ramp_upd_heads_linear(const void *relu_t, const void *heads_w, const float *heads_b, const float *coords,
+                          float *target, float *weight, int E, int P, float wd, float ht, void *stream) {
+  if (E < 0 || P < 1) return RAMP_EINVAL;
+  if (E == 0) return RAMP_OK;
+  if (!relu_t || !heads_w || !heads_b || !coords || !target || !weight) return RAMP_EINVAL;
+  const int PP = P * P, ctr = (P / 2) * P + P / 2;
+  hipLaunchKernelGGL(upd_heads_linear_f16_kernel, dim3(ramp_cdiv(E, 4)), dim3(256), 0, (hipStream_t)stream,
+                     (const _Float16 *)relu_t, (const _Float16 *)heads_w, heads_b, coords, target, weight, E, PP, ctr,
+                     wd, ht);
   RAMP_CHECK_LAUNCH();
   return RAMP_OK;
 }

@@ -91,6 +91,7 @@ class FusedUpdate:
                 w[name] = (pack_linear_f16(agg.f.weight), hb(agg.f), pack_linear_f16(agg.g.weight), hb(agg.g))
             w["corr1_pack"] = (pack_linear_f16(F.pad(m.corr[0].weight, (0, CORR_ROW - m.corr[0].weight.shape[1]))),
                                hb(m.corr[0]))
+            w["heads_pack"] = (w["heads"][0], w["heads"][1].float().contiguous())
             w["tail_pack"] = (pack_linear_f16(m.corr[2].weight), hb(m.corr[2]), pack_linear_f16(m.corr[5].weight),
                               hb(m.corr[5]))
         self._w, self._key = w, key
@@ -250,6 +251,19 @@ class FusedUpdate:
 
     def heads(self, relu_t):
         return self.lin(relu_t, self.weights()["heads"])          # [E,4]
+
+    def heads_target_weight(self, relu_t, coords, wd, ht):
+        """heads(relu_t) followed by target_weight, one launch (fp16 path); None when not available"""
+        w = self.weights()
+        if "heads_pack" not in w or not self.use_mlp or relu_t.dtype != torch.float16:
+            return None
+        E, P, dev = relu_t.shape[0], coords.shape[-1], relu_t.device
+        target = torch.empty(1, E, 2, dtype=torch.float32, device=dev)
+        weight = torch.empty(1, E, 2, dtype=torch.float32, device=dev)
+        hwt, hb = w["heads_pack"]
+        check(lib().ramp_upd_heads_linear(ptr(relu_t), ptr(hwt), ptr(hb), ptr(coords), ptr(target), ptr(weight), E, P,
+                                          float(wd), float(ht), stream()), "ramp_upd_heads_linear")
+        return target, weight
 
     def target_weight(self, hw, coords, wd, ht, want_delta=False):
         E = hw.shape[0]

@@ -505,6 +505,14 @@ def test_fused_gru_chain_matches_gemm_path():
             o32, rt = fu.hidden(netst[:700].contiguous(), table, inp_idx, 300, corr_pad, plan, net_map=net_map)
             res[one] = (o32.clone(), rt.float().clone())
     fu.use_corr_mlp = True
+    # heads: row-wise dot-product kernel (+ target / weight epilogue) vs the [E,384]x[384,4] GEMM + upd_heads
+    coords = (torch.rand(E, 2, 3, 3, generator=g) * 60).cuda()
+    with torch.no_grad():
+        t_ref, w_ref, _ = fu.target_weight(fu.heads(res[True][1].half()), coords, 40.0, 30.0)
+        t_new, w_new = fu.heads_target_weight(res[True][1].half(), coords, 40.0, 30.0)
+    assert float((t_ref - t_new).abs().max()) <= 2e-3 * max(1.0, float(t_ref.abs().max()))
+    near_edge = ((t_ref - torch.tensor([40.0, 30.0], device="cuda")).abs().min(-1).values < 0.1) | (t_ref.abs().min(-1).values < 0.1)
+    assert float(((w_ref - w_new).abs().max(-1).values * (~near_edge)).max()) <= 2e-3
     assert float((res[False][0] - res[True][0]).abs().max()) <= 4e-3 * scale
     assert float((res[False][0] - outs[True][0]).abs().max()) <= 4e-3 * scale          # padding changes nothing
 
