@@ -613,7 +613,11 @@ class Ramp_vo:
         idx = next(i for i in range(len(self._pool)) if i not in self._pool_busy)
         t = self._pool[idx]
         if t is None or t.numel() < nelem:
-            t = self._pool[idx] = torch.empty(int(nelem * 1.25) + 1024, dtype=torch.long).pin_memory()
+            # sized once for the largest graph the windows allow (a pinned allocation in steady state is a
+            # multi-millisecond stall): patches alive x factors per patch, 4 rows
+            cfg = self.cfg
+            bound = 4 * self.M * (cfg.REMOVAL_WINDOW + 2) * (2 * cfg.PATCH_LIFETIME)
+            t = self._pool[idx] = torch.empty(max(int(nelem * 1.25) + 1024, bound), dtype=torch.long).pin_memory()
         self._pool_busy.add(idx)
         return idx, t
 

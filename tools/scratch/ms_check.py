@@ -15,3 +15,6 @@ for t in range(T):
 slam.settle(); torch.cuda.synchronize()
 a = np.array(times[100:]) * 1e3
 print("MS: mean %.3f median %.3f  E=%d n=%d  tests/misses %s" % (a.mean(), np.median(a), len(slam._ii), slam.n, slam._pred_stats))
+idx = np.argsort(a)[-12:]
+print("slowest:", sorted((int(i) + 100, round(float(a[i]), 2)) for i in idx))
+print("p50 %.3f p75 %.3f p90 %.3f p99 %.3f" % tuple(np.percentile(a, [50, 75, 90, 99])))
