@@ -9,8 +9,9 @@ event+frame stream, 96 patches/frame, default.yaml windows (lifetime 13, removal
 ``Ramp_vo.__call__`` on an initialised tracker = encoder + patchify + reproject +
 corr + update operator + 2 GN iterations + keyframe management.  The tracker is
 first primed (untimed) until its sliding window is full, so the timed steps run at
-the steady-state graph size (E ~ 45k edges).  Inputs for all steps are generated
-and resident in HBM before the timed region.
+the steady-state graph size (E ~ 40k edges), then stepped for >= 0.6 s (untimed,
+``--clock-warm-s``) so that even a 20-step timed region runs at settled clocks.
+Inputs for all steps are generated and resident in HBM before the timed region.
 
 N > 1: one process per GPU (torchrun), every rank tracks its own independent
 sequence (different seed) -- the path shards by sequence only; the single
@@ -18,8 +19,16 @@ collective is an all_gather of per-rank metrics.  value = total steps of all ran
 / max-over-ranks time.
 
 Prints ONE JSON line on rank 0, including
-  roofline     the fused correlation kernel: algorithmic bytes per launch / mean launch
-               time (HIP events on the launch stream, inside the timed region)
+  roofline     the fused correlation kernel against the HBM roof: COMPULSORY bytes per launch
+               (every referenced feature plane / patch read once, every output written once:
+               frac <= 1 by construction) / mean launch time (HIP events on the launch stream,
+               inside the timed region); the SURVEY 8(d) per-edge model and the PMC-measured
+               fabric traffic ride along as model_bytes / traffic, its MFMA rate as mfma_*
+  roofline_update / roofline_encoder / roofline_ba   the other three stages, same clock
+  parity       measured in this process after the timed region: ONE teacher-forced update()
+               from the run's own state snapshot -- HIP fp16 (the benchmarked path), HIP fp32
+               and the CPU oracle backend -- and a free-running trajectory (damped weights)
+               against the reference's own run (tests/golden/ramp_vo_traj_ss.npz): ATE + rel
   cpu_baseline the same steady-state step on the host cores through the CPU oracle
                ("port"), a bounded sample from the identical state
 """
@@ -39,6 +48,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E peak (MI355X_MICROARCH.md)
+MFMA_F16_PEAK_TFLOPS = 2500.0   # dense f16 MFMA, MI355X_MICROARCH.md
+MFMA_F32_PEAK_TFLOPS = 157.0    # fp32 MFMA (the --mixed 0 towers)
+UPDATE_FLOP_PER_EDGE = 5.40e6   # 2.70 MMAC / edge in the update operator's 18 Linear layers
+CORR_FLOP_PER_EDGE_LEVEL = 2 * 128 * 576    # 9 px x 64 window positions, 128-long dots
 
 
 def parse():
@@ -53,6 +66,7 @@ def parse():
     ap.add_argument("--mode", default="SingleScale")
     ap.add_argument("--preset", default="default", choices=("default", "precise", "fast"),
                     help="config_vo preset for the BA / lifetime windows (configs[2] uses precise)")
+    ap.add_argument("--opt-window", type=int, default=0, help="override OPTIMIZATION_WINDOW (configs[4]: 32)")
     ap.add_argument("--mixed", type=int, default=1,
                     help="1 (default.yaml's MIXED_PRECISION: True): fp16 features / conv + GEMM I/O with fp32 "
                          "accumulation, fp32 hidden state, BA and geometry; 0: fp32 everywhere")
@@ -62,7 +76,21 @@ def parse():
                          "tracker may launch frame t+1's front end while frame t's bundle adjustment drains "
                          "(Ramp_vo.inputs_ready); 0: strictly one frame at a time")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--clock-warm-s", type=float, default=0.6,
+                    help="untimed steady-state steps for at least this long right before the warm-up steps, so that a "
+                         "short timed region (the driver's --steps 20 is ~30 ms) runs at settled clocks")
+    ap.add_argument("--clock-warm-max", type=int, default=480, help="cap of the clock-warm phase in frames")
+    ap.add_argument("--parity", type=int, default=1,
+                    help="1: after the timed region, one teacher-forced update() from the run's snapshot on HIP fp16 / "
+                         "HIP fp32 / the CPU oracle, and the free-running trajectory check (rank 0, N = 1)")
+    ap.add_argument("--np-steps", type=int, default=40,
+                    help="extra steps with frame pipelining OFF after the timed region, reported as "
+                         "config.non_pipelined_kfps (what evaluate.run's strictly sequential loop gets); 0 = skip")
     return ap.parse_args()
+
+
+def _event_pair():
+    return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
 
 class CorrTimer:
@@ -82,7 +110,7 @@ class CorrTimer:
         def timed(gmap, pyramid, coords, ii, jj, *a, **k):
             if not timer.enabled:
                 return inner(gmap, pyramid, coords, ii, jj, *a, **k)
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s, e = _event_pair()
             s.record()
             out = inner(gmap, pyramid, coords, ii, jj, *a, **k)
             e.record()
@@ -98,7 +126,7 @@ class CorrTimer:
         def timed_direct(slam, coords, ii, jj, order):
             if not timer.enabled:
                 return direct(slam, coords, ii, jj, order)
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s, e = _event_pair()
             s.record()
             out = direct(slam, coords, ii, jj, order)
             e.record()
@@ -110,47 +138,107 @@ class CorrTimer:
 
     @staticmethod
     def pmc_traffic_per_edge(elem_bytes):
-        """HBM-side bytes per edge of the fp16 kernel from the committed rocprofv3 PMC passes
-        (FETCH_SIZE x2 per the guide's gfx950 correction + WRITE_SIZE; profiles/pmc/r01_corr_traffic.json).
-        Counters cannot be read inside this process, so the per-edge figure of the PMC run of the same
-        workload is scaled by this run's edges per launch.  None for the fp32 kernel (not measured)."""
+        """fabric-side bytes per edge of the fp16 kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2
+        per the guide's gfx950 correction + WRITE_SIZE, separate --pmc passes; the newest
+        profiles/pmc/r*_corr_traffic.json, which names its command).  Counters cannot be read inside this process,
+        so the per-edge figure of the PMC run of the same workload is scaled by this run's edges per launch."""
         if elem_bytes != 2:
-            return None
-        try:
-            with open(os.path.join(ROOT, "profiles", "pmc", "r01_corr_traffic.json")) as f:
-                return float(json.load(f)["bytes_per_edge"])
-        except Exception:
-            return None
+            return None, None
+        import glob
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc", "r*_corr_traffic.json")))
+        for f in reversed(files):
+            try:
+                with open(f) as fh:
+                    return float(json.load(fh)["bytes_per_edge"]), os.path.relpath(f, ROOT)
+            except Exception:
+                continue
+        return None, None
 
-    def summary(self, elem_bytes):
+    def summary(self, elem_bytes, slam):
         if not self.pairs:
             return None
         ms = np.array([s.elapsed_time(e) for s, e in self.pairs])
         edges = np.array(self.edges, dtype=np.float64)
-        # SURVEY 8(d): per edge per level: 128*9*s (patch) + 128*100*s (union of the 9 8x8 windows)
-        # + 72 (coords) + 16 (indices) + 441*s (output); two levels per launch
-        per_edge_level = 128 * 9 * elem_bytes + 128 * 100 * elem_bytes + 72 + 16 + 441 * elem_bytes
         big = edges > 0.5 * edges.max()          # the per-update launches (motion-probe launches are tiny)
-        bytes_per_launch = float((edges[big] * 2 * per_edge_level).mean())
+        E = float(edges[big].mean())
         mean_ms = float(ms[big].mean())
-        achieved = bytes_per_launch / (mean_ms * 1e-3) / 1e9
-        per_edge = self.pmc_traffic_per_edge(elem_bytes)
-        traffic = int(per_edge * edges[big].mean()) if per_edge else None
-        out = dict(kernel="corr_mfma_f16_kernel" if elem_bytes == 2 else "corr_kernel<float>", bound="hbm",
+        sec = mean_ms * 1e-3
+        # COMPULSORY bytes of one launch: each referenced target plane (both pyramid levels) and each referenced
+        # 3x3x128 patch once, per-edge coordinates + indices + schedule entry, every output row once.  Distinct
+        # frames / patches are those of the graph at the end of the timed region (the window is in steady state).
+        h, w = slam.ht // slam.RES, slam.wd // slam.RES
+        frames = int(len(np.unique(slam._jj % slam.mem)))
+        patches = int(len(np.unique(slam._kk % (slam.M * slam.mem))))
+        out_row = (896 if elem_bytes == 2 else 882) * elem_bytes
+        compulsory = (frames * 128 * (h * w + (h // 4) * (w // 4)) * elem_bytes + patches * 128 * 9 * elem_bytes
+                      + E * (72 + 16 + 4) + E * out_row)
+        # SURVEY 8(d)'s per-edge model (every edge reads its 10x10 window privately; two levels per launch): counts
+        # re-reads that the (jj, ii)-major XCD schedule serves from L2, which is why it can exceed the HBM peak
+        per_edge_level = 128 * 9 * elem_bytes + 128 * 100 * elem_bytes + 72 + 16 + 441 * elem_bytes
+        model = E * 2 * per_edge_level
+        achieved = compulsory / sec / 1e9
+        per_edge, src = self.pmc_traffic_per_edge(elem_bytes)
+        traffic = int(per_edge * E) if per_edge else None
+        flops = E * 2 * CORR_FLOP_PER_EDGE_LEVEL
+        peak_tf = MFMA_F16_PEAK_TFLOPS if elem_bytes == 2 else MFMA_F32_PEAK_TFLOPS
+        out = dict(kernel="corr_mfma_kernel<half>" if elem_bytes == 2 else "corr_kernel<float>", bound="hbm",
                    achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, launches=int(big.sum()),
-                   mean_launch_us=round(mean_ms * 1e3, 1), bytes_per_launch=int(bytes_per_launch),
-                   edges_per_launch=int(edges[big].mean()))
+                   mean_launch_us=round(mean_ms * 1e3, 1), bytes_per_launch=int(compulsory),
+                   edges_per_launch=int(E), target_frames=frames, patches=patches,
+                   model_bytes=int(model), model_gbps=round(model / sec / 1e9, 1),
+                   mfma_tflops=round(flops / sec / 1e12, 1), mfma_frac=round(flops / sec / 1e12 / peak_tf, 4),
+                   limiter="vector L1 / texture addresser (window gathers: TCP_GATE_EN1 ~80 %, profiles/pmc), neither "
+                           "HBM nor MFMA: achieved = compulsory bytes, model_bytes = SURVEY 8(d) per-edge bytes "
+                           "(L2-served re-reads included), traffic = PMC fabric bytes")
         if traffic:
-            # the algorithmic model counts every edge's window privately; overlapping windows are served
-            # from L2 / the XCD-local schedule, so measured traffic is well below it and frac can exceed 1
-            out["traffic_gbps"] = round(traffic / (mean_ms * 1e-3) / 1e9, 1)
-            out["traffic_frac_of_peak"] = round(traffic / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            out["traffic_gbps"] = round(traffic / sec / 1e9, 1)
+            out["traffic_frac_of_peak"] = round(traffic / sec / 1e9 / HBM_PEAK_GBS, 4)
+            out["traffic_source"] = src
         return out
 
 
+class UpdateTimer:
+    """HIP events around the update operator (FusedUpdate.hidden: correlation MLP, neighbour MLPs, SoftAgg x2, gru)"""
+
+    def __init__(self):
+        self.pairs, self.edges, self.enabled = [], [], False
+
+    def install(self):
+        from rampvo_amd.update_fused import FusedUpdate
+        inner, timer = FusedUpdate.hidden, self
+
+        def timed(fu, net, inp_table, inp_idx, inp_mod, corr, plan, net_map=None):
+            if not timer.enabled:
+                return inner(fu, net, inp_table, inp_idx, inp_mod, corr, plan, net_map=net_map)
+            s, e = _event_pair()
+            s.record()
+            out = inner(fu, net, inp_table, inp_idx, inp_mod, corr, plan, net_map=net_map)
+            e.record()
+            timer.pairs.append((s, e))
+            timer.edges.append(int(corr.shape[0]))
+            return out
+
+        FusedUpdate.hidden = timed
+
+    def summary(self, mixed):
+        if not self.pairs:
+            return None
+        ms = np.array([s.elapsed_time(e) for s, e in self.pairs])
+        edges = np.array(self.edges, dtype=np.float64)
+        big = edges > 0.5 * edges.max()
+        E, mean_ms = float(edges[big].mean()), float(ms[big].mean())
+        peak = MFMA_F16_PEAK_TFLOPS if mixed else MFMA_F32_PEAK_TFLOPS
+        ach = E * UPDATE_FLOP_PER_EDGE / (mean_ms * 1e-3) / 1e12
+        return dict(kernel="update operator: upd_corr_mlp + upd_nbr x2 + (upd_fg + segment softmax + h GEMM) x2 + upd_gru",
+                    bound="mfma", achieved=round(ach, 1), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
+                    mean_call_us=round(mean_ms * 1e3, 1), edges=int(E), flop_per_edge=UPDATE_FLOP_PER_EDGE,
+                    note="18 Linear layers of 384 (one of K = 882) per edge, SURVEY 8(d)'s 5.40 MFLOP/edge; the "
+                         "time is the whole operator incl. its row-wise LayerNorm / gate / softmax passes")
+
+
 class BaTimer:
-    """HIP events around fastba.BA (two Gauss-Newton iterations, 6 launches each + one memset)"""
+    """HIP events around fastba.BA (two Gauss-Newton iterations)"""
 
     def __init__(self):
         self.pairs, self.meta, self.enabled = [], [], False
@@ -162,7 +250,7 @@ class BaTimer:
         def timed(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t1, *a, **k):
             if not timer.enabled:
                 return inner(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t1, *a, **k)
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s, e = _event_pair()
             s.record()
             out = inner(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t1, *a, **k)
             e.record()
@@ -181,15 +269,11 @@ class BaTimer:
         # 116 B per edge per iteration in, + per-iteration outputs (6N)^2 + 6N*Mu + 2*Mu + 6N floats
         nbytes = it * (116.0 * E + 4.0 * ((6 * N) ** 2 + 6 * N * mu + 2 * mu + 6 * N))
         ach = nbytes / (ms * 1e-3) / 1e9
-        return dict(kernel="fastba.BA: ba_edge / ba_patch_pair / ba_schur / ba_assemble / ba_chol64 / ba_retract x 2",
+        return dict(kernel="fastba.BA (2 Gauss-Newton iterations)",
                     bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 5),
                     traffic=None, mean_call_us=round(ms * 1e3, 1), bytes_per_call=int(nbytes), edges=int(E),
-                    free_poses=int(N), note="a dependent chain of 13 small launches: latency, not bandwidth, bounds it "
+                    free_poses=int(N), note="a short dependent chain on ~10 MB: latency, not bandwidth, bounds it "
                                             "(time includes the overlap with the next frame's front end when pipelining)")
-
-
-MFMA_F16_PEAK_TFLOPS = 2500.0   # dense f16 MFMA, MI355X_MICROARCH.md
-MFMA_F32_PEAK_TFLOPS = 157.0    # fp32 MFMA (the --mixed 0 towers)
 
 
 class EncoderTimer:
@@ -225,7 +309,7 @@ class EncoderTimer:
         def fwd(*a, **k):
             if not timer.enabled:
                 return fwd_inner(*a, **k)
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s, e = _event_pair()
             s.record()
             r = fwd_inner(*a, **k)
             e.record()
@@ -240,31 +324,37 @@ class EncoderTimer:
         ms = float(np.mean([s.elapsed_time(e) for s, e in self.pairs]))
         peak = MFMA_F16_PEAK_TFLOPS if mixed else MFMA_F32_PEAK_TFLOPS
         ach = self.flops_frame / (ms * 1e-3) / 1e12
-        return dict(kernel="encoder front end (conv_mfma_* towers + fused LSTM + patch selection, 1 hipGraph)",
+        return dict(kernel="encoder front end (conv towers + fused LSTM + patch selection, 1 hipGraph)",
                     bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 5),
                     conv_gflop_per_frame=round(self.flops_frame / 1e9, 2), mean_front_end_us=round(ms * 1e3, 1),
                     note="32/64-channel layers: arithmetic intensity is below the machine balance, the towers are "
-                         "latency/HBM bound; MFMA busy from PMC: profiles/pmc/r01_g_MFMA_BUSY_per_kernel.txt")
+                         "latency/HBM bound; when pipelining the front end overlaps the previous frame's BA")
+
+
+def _cpu_tracker(state, args, cfg_kwargs):
+    """the CPU oracle backend's tracker loaded with a state snapshot (inside cpu_oracle_ops())"""
+    from rampvo_amd.config import make_cfg
+    from rampvo_amd.Ramp_vo import Ramp_vo
+    from rampvo_amd.synthetic import make_network
+    cfg_kwargs = dict(cfg_kwargs, MIXED_PRECISION=False)       # the host path is fp32 throughout
+    state = dict(state)
+    for k in ("net", "imap", "gmap", "fmap1", "fmap2"):
+        state[k] = state[k].float()
+    net = make_network(args.mode, device="cpu")
+    slam = Ramp_vo(make_cfg(args.preset, **cfg_kwargs), net, {"event_bias": True}, ht=args.height, wd=args.width,
+                   device="cpu")
+    slam.load_state_dict(state)
+    return slam
 
 
 def cpu_baseline(state, args, cfg_kwargs, frames, steps):
     """time `steps` tracker steps on the host cores from the same steady-state snapshot, through
     the CPU oracle backend (torch CPU for the encoder / update GEMMs, oracle C for the natives)"""
     from oracle.backend_cpu import cpu_oracle_ops
-    from rampvo_amd.config import make_cfg
-    from rampvo_amd.Ramp_vo import Ramp_vo
-    from rampvo_amd.synthetic import make_network
     cores = min(os.cpu_count() or 1, int(os.environ.get("RAMP_CPU_THREADS", "64")))
     torch.set_num_threads(cores)      # also the OpenMP team of the oracle's edge-parallel loops
-    cfg_kwargs = dict(cfg_kwargs, MIXED_PRECISION=False)       # the host path is fp32 throughout
-    state = dict(state)
-    for k in ("net", "imap", "gmap", "fmap1", "fmap2"):
-        state[k] = state[k].float()
     with cpu_oracle_ops():
-        net = make_network(args.mode, device="cpu")
-        slam = Ramp_vo(make_cfg(args.preset, **cfg_kwargs), net, {"event_bias": True}, ht=args.height, wd=args.width,
-                       device="cpu")
-        slam.load_state_dict(state)
+        slam = _cpu_tracker(state, args, cfg_kwargs)
         # encoder recurrent state is not part of the VO snapshot: one untimed step re-seeds it
         t0 = state["counter"]
         im, ev, K, mask = frames[0]
@@ -279,6 +369,68 @@ def cpu_baseline(state, args, cfg_kwargs, frames, steps):
                        "encoder/update GEMMs + OpenMP oracle C natives on %d threads (host has %d logical cores)"
                        % (steps, len(slam._ii), cores, os.cpu_count() or 1),
                 s_per_step=round(dt / steps, 3))
+
+
+@torch.no_grad()
+def parity_block(state, args, cfg_kwargs, net, dev):
+    """ONE teacher-forced update() (reproject -> corr -> update operator -> BA x2) from the run's own steady-state
+    snapshot: HIP fp16 (the benchmarked path) and HIP fp32 against the CPU oracle backend (fp32), plus the
+    free-running trajectory of the damped-weight tracker against the reference's own run (committed fixture)."""
+    from oracle.backend_cpu import cpu_oracle_ops
+    from rampvo_amd.config import make_cfg
+    from rampvo_amd.Ramp_vo import Ramp_vo
+    n = int(state["n"])
+    before = state["poses"][:n].numpy().copy()
+    torch.set_num_threads(min(os.cpu_count() or 1, int(os.environ.get("RAMP_CPU_THREADS", "64"))))
+    with cpu_oracle_ops():
+        ref = _cpu_tracker(state, args, cfg_kwargs)
+        ref.update()
+        r = dict(poses=ref.poses_[:n].numpy().copy(), depth=ref.patches_[:n, :, 2, 1, 1].numpy().copy(),
+                 net=ref.net[0].float().numpy().copy(), w=ref.last_weight.numpy().copy())
+    step = float(np.abs(r["poses"] - before).max())
+    scale = max(1.0, step)
+    tf = dict(edges=int(state["ii"].shape[0]), keyframes=n, gn_step=round(step, 6),
+              note="max abs error of one update() vs the CPU oracle (fp32) from the same snapshot; net relative to its "
+                   "largest entry, poses / depths relative to max(1, |GN step|) (depths also to max(1, |depth|))")
+    enc = getattr(net.patchify, "encoder", None)
+    flag = getattr(enc, "mixed_precision", None)
+    try:
+        for name, mixed in (("fp16", True), ("fp32", False)):
+            slam = Ramp_vo(make_cfg(args.preset, **dict(cfg_kwargs, MIXED_PRECISION=mixed)), net, {"event_bias": True},
+                           ht=args.height, wd=args.width, device=dev)
+            slam.load_state_dict(state)
+            slam.update()
+            torch.cuda.synchronize()
+            g_depth = slam.patches_[:n, :, 2, 1, 1].cpu().numpy()
+            leg = dict(
+                net=float(np.abs(slam.net[0].float().cpu().numpy() - r["net"]).max() / np.abs(r["net"]).max()),
+                weight=float(np.abs(slam.last_weight.cpu().numpy() - r["w"]).max()),
+                poses=float(np.abs(slam.poses_[:n].cpu().numpy() - r["poses"]).max() / scale),
+                depths=float((np.abs(g_depth - r["depth"]) / np.maximum(np.abs(r["depth"]), 1.0)).max() / scale))
+            tf[name] = {k: float("%.3g" % v) for k, v in leg.items()}
+            del slam
+    finally:
+        if flag is not None:
+            enc.mixed_precision = flag
+    out = dict(teacher_forced=tf)
+    # trajectory level: tests/pipeline_checks.py::check_trajectory against tests/golden/ramp_vo_traj_ss.npz
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    try:
+        import pipeline_checks as pc
+        tr = {}
+        for name, mixed in (("fp32", False), ("fp16", True)):
+            e = pc.check_trajectory("ss", "cuda", mixed=mixed)
+            tr[name] = dict(ate_vs_reference=float("%.3g" % e["ate_rmse"]), rel=float("%.3g" % e["rel"]),
+                            depths_rel=float("%.3g" % e["depths_rel"]))
+            tr.update(frames=e["frames"], path_length=round(e["path_length"], 4))
+        tr["note"] = ("free-running %s 192x256, 16 patches, default.yaml windows, damped weight profile, against the "
+                      "reference's own CPU run of the same stream (tests/golden/ramp_vo_traj_ss.npz): identical keyframe "
+                      "decisions and graph; ate = Sim(3)-aligned RMSE (evaluate.py:295-304), rel = max abs / "
+                      "max(1, largest translation)" % pc.TRAJ["ss"]["mode"])
+        out["trajectory"] = tr
+    except Exception as e:  # parity is reported, it must not take the throughput number down
+        out["trajectory"] = {"error": repr(e)}
+    return out
 
 
 def main():
@@ -305,32 +457,48 @@ def main():
     from rampvo_amd.synthetic import SyntheticStream, make_network
 
     cfg_kwargs = dict(PATCHES_PER_FRAME=args.patches, MIXED_PRECISION=bool(args.mixed))
+    if args.opt_window:
+        cfg_kwargs["OPTIMIZATION_WINDOW"] = args.opt_window
     cfg = make_cfg(args.preset, **cfg_kwargs)
     torch.manual_seed(1234 + rank)
     net = make_network(args.mode, device=dev)
     slam = Ramp_vo(cfg, net, {"event_bias": True}, ht=args.height, wd=args.width, device=dev)
     slam.inputs_ready = bool(args.pipeline)     # every frame is resident before its __call__ (see parse())
-    total = args.prime + args.warmup + args.steps
-    n_cpu = args.cpu_steps + 1 if (rank == 0 and world == 1 and args.cpu_steps > 0) else 0
+    solo = rank == 0 and world == 1
+    n_warm = args.clock_warm_max if args.clock_warm_s > 0 else 0
+    n_np = args.np_steps if args.pipeline else 0
+    total = args.prime + n_warm + args.warmup + args.steps + n_np
+    n_cpu = args.cpu_steps + 1 if (solo and args.cpu_steps > 0) else 0
     stream = SyntheticStream(args.height, args.width, total + n_cpu + 1, seed=1234 + rank, device=dev)
     frames = [tuple(x.to(dev) if i < 2 else x for i, x in enumerate(stream.frame(t))) for t in range(total)]
 
-    ctimer, etimer, btimer = CorrTimer(), EncoderTimer(), BaTimer()
+    ctimer, etimer, btimer, utimer = CorrTimer(), EncoderTimer(), BaTimer(), UpdateTimer()
     if not args.no_kernel_timing:
         ctimer.install()
         etimer.install(net)
         btimer.install()
+        utimer.install()
 
-    def step(t):
-        im, ev, K, mask = frames[t]
-        slam(t, input_tensor=(ev, im, mask), intrinsics=K)
+    pos = {"t": 0}
 
-    t = 0
+    def step():
+        im, ev, K, mask = frames[pos["t"]]
+        slam(pos["t"], input_tensor=(ev, im, mask), intrinsics=K)
+        pos["t"] += 1
+
     for _ in range(args.prime):
-        step(t); t += 1
+        step()
     assert slam.is_initialized, "tracker did not initialise during priming"
+    # clock warm: the same steady-state steps, untimed, until the GPU has been busy for clock_warm_s (a fresh
+    # box idles at low clocks; a 20-step region is ~30 ms)
+    warm_steps, warm_tic = 0, time.perf_counter()
+    while warm_steps < n_warm and time.perf_counter() - warm_tic < args.clock_warm_s:
+        step()
+        warm_steps += 1
+    torch.cuda.synchronize()
+    warm_s = time.perf_counter() - warm_tic
     for _ in range(args.warmup):
-        step(t); t += 1
+        step()
     E0, n0 = len(slam._ii), slam.n
 
     # A generation-2 pass of CPython's cyclic collector over this process's ~10^6 long-lived objects (modules,
@@ -343,11 +511,11 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ctimer.enabled = etimer.enabled = btimer.enabled = True
+    ctimer.enabled = etimer.enabled = btimer.enabled = utimer.enabled = True
     tic = time.perf_counter()
     marks = [tic]
     for _ in range(args.steps):
-        step(t); t += 1
+        step()
         marks.append(time.perf_counter())         # host-side return times (the GPU may lag by less than a step)
     slam.settle()
     torch.cuda.synchronize()
@@ -355,7 +523,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - tic
-    ctimer.enabled = etimer.enabled = btimer.enabled = False
+    ctimer.enabled = etimer.enabled = btimer.enabled = utimer.enabled = False
 
     from rampvo_amd.shard import gather_metrics, max_over_ranks
     dt_all = max_over_ranks(dt, dev)
@@ -365,6 +533,19 @@ def main():
         g = gather_metrics([args.steps / dt, float(len(slam._ii)), float(slam.n),
                             float(slam.poses_[:slam.n].double().sum())], dev)
         per_rank = [[round(float(v), 4) for v in row] for row in g.tolist()]
+    E1 = len(slam._ii)
+
+    # the strictly sequential rate (no frame pipelining): what evaluate.run's loop gets
+    np_kfps = None
+    if n_np > 0:
+        slam.inputs_ready = False
+        torch.cuda.synchronize()
+        t_np = time.perf_counter()
+        for _ in range(n_np):
+            step()
+        slam.settle()
+        torch.cuda.synchronize()
+        np_kfps = n_np / (time.perf_counter() - t_np)
 
     if rank == 0:
         value = world * args.steps / dt_all
@@ -372,14 +553,19 @@ def main():
             "metric": "keyframes/sec (BA iters/sec) %s %dx%d; ATE vs reference" % (args.mode, args.width, args.height),
             "value": round(value, 3), "unit": "keyframes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt_all / args.steps, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f16 storage+MFMA inputs / f32 accumulate, state, BA (default.yaml MIXED_PRECISION)" if args.mixed else "f32",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16 (features, MFMA inputs; f32 accumulate, hidden state, BA, geometry: default.yaml "
+                     "MIXED_PRECISION)" if args.mixed else "f32",
             "data": "synthetic (seeded %dx%d event+frame stream, seeded random-init weights)" % (args.width, args.height),
             "config": {"workload": "%s %dx%d, %d patches/frame, %s.yaml windows, 2 BA iters/keyframe, "
                                    "steady-state sliding window" % (args.mode, args.width, args.height, args.patches,
                                                                     args.preset),
-                       "ba_iters_per_s": round(2 * value, 2), "edges": E0, "edges_end": len(slam._ii),
+                       "ba_iters_per_s": round(2 * value, 2), "edges": E0, "edges_end": E1,
                        "keyframes_in_window": n0, "prime_frames": args.prime,
+                       "clock_warm": "%d untimed steady-state steps (%.2f s) before the %d warm-up steps"
+                                     % (warm_steps, warm_s, args.warmup),
                        "frame_pipelining": bool(args.pipeline),
+                       "non_pipelined_kfps": round(np_kfps, 1) if np_kfps else None,
                        "host_step_ms_p50_p90_max": [round(1e3 * float(v), 3) for v in
                                                     (np.percentile(np.diff(marks), 50), np.percentile(np.diff(marks), 90),
                                                      np.max(np.diff(marks)))],
@@ -387,22 +573,29 @@ def main():
         }
         if per_rank is not None:
             out["config"]["per_rank_kfps_E_n_chk"] = per_rank
-        rl = ctimer.summary(2 if args.mixed else 4)
+        rl = ctimer.summary(2 if args.mixed else 4, slam)
         assert rl is not None or args.no_kernel_timing, "no correlation launch was timed: the roofline hook is stale"
         if rl is not None:
             out["roofline"] = rl
-        el = etimer.summary(bool(args.mixed))
-        if el is not None:
-            out["roofline_encoder"] = el
-        bl = btimer.summary(args.patches, cfg.REMOVAL_WINDOW)
-        if bl is not None:
-            out["roofline_ba"] = bl
+        for key, val in (("roofline_update", utimer.summary(bool(args.mixed))),
+                         ("roofline_encoder", etimer.summary(bool(args.mixed))),
+                         ("roofline_ba", btimer.summary(args.patches, cfg.REMOVAL_WINDOW))):
+            if val is not None:
+                out[key] = val
+        snapshot = slam.state_dict() if (n_cpu or (solo and args.parity)) else None
+        if solo and args.parity:
+            try:
+                out["parity"] = parity_block(snapshot, args, cfg_kwargs, net, dev)
+                tr = out["parity"].get("trajectory", {})
+                if "fp32" in tr:
+                    out["ate_vs_oracle"] = tr["fp32"]["ate_vs_reference"]
+            except Exception as e:
+                out["parity"] = {"error": repr(e)}
         if n_cpu:
-            state = slam.state_dict()
             cpu_frames = [stream.frame(total + i) for i in range(n_cpu)]
             cpu_frames = [tuple(x.cpu() for x in f) for f in cpu_frames]
             try:
-                out["cpu_baseline"] = cpu_baseline(state, args, cfg_kwargs, cpu_frames, args.cpu_steps)
+                out["cpu_baseline"] = cpu_baseline(snapshot, args, cfg_kwargs, cpu_frames, args.cpu_steps)
                 out["config"]["speedup_vs_cpu_port"] = round(value / out["cpu_baseline"]["value"], 1)
             except Exception as e:  # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"error": repr(e)}

@@ -35,6 +35,10 @@ def patchify(net, coords, radius, bilinear=True, layout=RAMP_NCHW, out_layout=RA
 
 def corr(fmap1, fmaps2, coords, ii, jj, radius=3, coord_divs=(1.0,), layout=RAMP_NCHW, order=None, row_elems=0, fast_f32=None, mod_ii=0, mod_jj=0):
     f1 = fmap1 if layout == RAMP_NCHW else fmap1.permute(0, 3, 1, 2)
+    if mod_ii:                        # the tracker's ring-buffer slots (reference Ramp_vo.py:178-179)
+        ii = ii % int(mod_ii)
+    if mod_jj:
+        jj = jj % int(mod_jj)
     outs = []
     for f2, dv in zip(fmaps2, coord_divs):
         f2 = f2 if layout == RAMP_NCHW else f2.permute(0, 3, 1, 2)

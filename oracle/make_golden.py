@@ -16,6 +16,17 @@ Fixtures:
   G6    ramp_vo_ss.npz        the reference Ramp_vo driven over a 20-frame stream:
                               per-frame (n, m, E, newest pose, median depth),
                               graph after the run, final terminate() trajectory
+  G3    corr.npz              the reference's altcorr.corr call site (CorrLayer ->
+                              cuda_corr.forward, served by the C oracle) on random
+                              features / coords incl. out-of-bounds, E = 64, both
+                              pyramid levels stacked as Ramp_vo.corr does
+  G7    ramp_vo_traj_ss.npz   free-running trajectory of the reference Ramp_vo with the
+                              ``damped`` weight profile (synthetic.py): 40 frames,
+                              default.yaml windows -- the trajectory-parity contract
+  G8    ramp_vo_traj_ms.npz   the same for configs[2]'s structure: MultiScale encoder,
+                              precise.yaml windows (PATCH_LIFETIME 33 > mem 32: the
+                              ring-buffer aliasing of Ramp_vo.py:178-179), 48 frames,
+                              every frame kept as a keyframe (KEYFRAME_THRESH 0)
 """
 import os
 import sys
@@ -42,8 +53,8 @@ RAMPVO = dict(H=128, W=160, T=20, M=8, seed=1234)
 DEPTH_SEED = 4321
 
 
-def ref_network(ns, mode, seed=1234):
-    sd = seeded_state_dict(VONet(NET_CFG(mode)), seed)
+def ref_network(ns, mode, seed=1234, profile="wide"):
+    sd = seeded_state_dict(VONet(NET_CFG(mode)), seed, profile=profile)
     with rh.CudaToCpu():
         net = ns.net.VONet(NET_CFG(mode))
     net.load_state_dict(sd, strict=True)
@@ -199,6 +210,72 @@ def gen_ramp_vo(ns):
     np.savez_compressed(os.path.join(OUT, "ramp_vo_ss.npz"), traj=traj, tstamps=ts,
                         **{k: np.asarray(v) for k, v in rec.items()}, **{"final_" + k: v for k, v in final.items()})
     print("ramp_vo ok: n", rec["n"], "E", rec["E"][-1])
+
+
+TRAJ = {
+    "ss": dict(mode="SingleScale", preset="default", H=192, W=256, T=40, M=16, seed=11, over={}),
+    "ms": dict(mode="MultiScale", preset="precise", H=192, W=256, T=48, M=16, seed=9, over={"KEYFRAME_THRESH": 0.0}),
+}
+
+
+@torch.no_grad()
+def gen_ramp_vo_traj(ns, tag):
+    """free run of the reference tracker with the ``damped`` weights (contractive: see synthetic.py)"""
+    p = TRAJ[tag]
+    net = ref_network(ns, p["mode"], profile="damped")
+    cfg = ns.CfgNode(make_cfg(p["preset"], PATCHES_PER_FRAME=p["M"], MIXED_PRECISION=False, **p["over"]))
+    stream = SyntheticStream(p["H"], p["W"], p["T"], seed=p["seed"])
+    rec = dict(n=[], E=[], pose=[])
+    frame_no = [0]
+    orig_rand_like = torch.rand_like
+
+    def fake_rand_like(x, *a, **k):
+        return depth_draw(frame_no[0], x.shape[1]).to(x.dtype).expand_as(x).clone()
+
+    with rh.CudaToCpu():
+        slam = ns.Ramp_vo.Ramp_vo(cfg=cfg, network=net, train_cfg={"event_bias": True}, ht=p["H"], wd=p["W"])
+        torch.rand_like = fake_rand_like
+        try:
+            for t in range(p["T"]):
+                image, events, K, mask = stream.frame(t)
+                assert_tie_free(events, p["M"])
+                frame_no[0] = t
+                slam(t, input_tensor=(events, image, mask), intrinsics=K)
+                rec["n"].append(slam.n); rec["E"].append(len(slam.ii))
+                rec["pose"].append(slam.poses_[max(slam.n - 1, 0)].numpy().copy())
+            n = slam.n
+            final = dict(ii=slam.ii.numpy().copy(), jj=slam.jj.numpy().copy(), kk=slam.kk.numpy().copy(),
+                         poses=slam.poses_[:n].numpy().copy(), depths=slam.patches_[:n, :, 2, 1, 1].numpy().copy(),
+                         tstamps=slam.tstamps_[:n].numpy().copy())
+            traj, ts = slam.terminate()
+        finally:
+            torch.rand_like = orig_rand_like
+    np.savez_compressed(os.path.join(OUT, f"ramp_vo_traj_{tag}.npz"), traj=traj, tstamps=ts,
+                        **{k: np.asarray(v) for k, v in rec.items()}, **{"final_" + k: v for k, v in final.items()})
+    path = float(np.linalg.norm(np.diff(traj[:, :3], axis=0), axis=1).sum())
+    print("ramp_vo_traj", tag, "ok: n", rec["n"][-1], "E", rec["E"][-1], "path length %.3f" % path,
+          "jj max", int(final["jj"].max()))
+
+
+@torch.no_grad()
+def gen_corr(ns):
+    """G3: the reference's python call site of the correlation op on both pyramid levels
+    (ramp/Ramp_vo.py:175-182: corr(gmap, pyramid[l], coords / 4**l, ii % .., jj % .., 3), stacked last)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from scenes import corr_case
+    import importlib
+    altcorr = importlib.import_module("ramp.altcorr")
+    f1, f2, coords, ii, jj = corr_case(seed=11, E=64)
+    rng = np.random.default_rng(12)
+    f2b = rng.standard_normal((1, f2.shape[1], f2.shape[2], f2.shape[3] // 4, f2.shape[4] // 4)).astype(np.float16).astype(np.float32)
+    t = torch.from_numpy
+    with rh.CudaToCpu():
+        c1 = altcorr.corr(t(f1), t(f2), t(coords) / 1, t(ii), t(jj), 3)
+        c2 = altcorr.corr(t(f1), t(f2b), t(coords) / 4, t(ii), t(jj), 3)
+        out = torch.stack([c1, c2], -1).view(1, len(ii), -1)
+    np.savez_compressed(os.path.join(OUT, "corr.npz"), seed=11, E=64, fmap2_l1=f2b.astype(np.float16),
+                        out=out.numpy())
+    print("corr ok", tuple(out.shape), "nan", int(torch.isnan(out).sum()))
 
 
 STEP = dict(H=64, W=96, T=11, M=8, seed=99, OPTIMIZATION_WINDOW=5)
@@ -362,8 +439,14 @@ def gen_pose_pred(ns):
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = rh.load()
-    if len(sys.argv) > 1 and sys.argv[1] == "pose_pred":
+    only = sys.argv[1] if len(sys.argv) > 1 else None
+    if only == "pose_pred":
         return gen_pose_pred(ns)
+    if only == "traj":
+        gen_ramp_vo_traj(ns, "ss")
+        return gen_ramp_vo_traj(ns, "ms")
+    if only == "corr":
+        return gen_corr(ns)
     gen_event_stack(ns)
     gen_pose_pred(ns)
     gen_patchify(ns, "SingleScale")
@@ -372,6 +455,9 @@ def main():
     gen_ba_crosscheck(ns)
     gen_ramp_vo(ns)
     gen_update_step(ns)
+    gen_corr(ns)
+    gen_ramp_vo_traj(ns, "ss")
+    gen_ramp_vo_traj(ns, "ms")
 
 
 if __name__ == "__main__":

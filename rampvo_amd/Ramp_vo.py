@@ -139,6 +139,8 @@ class Ramp_vo:
         self.patch_dict_ = None          # pose-prediction mode (reference :34-35)
         self.patches_models = None
         self._ba_info = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._last_K = self._last_K_raw = None     # last intrinsics written to a row of intrinsics_, and which row
+        self._last_K_row = -1
 
     # ------------------------------------------------------------------ weights
     def load_weights(self, network):
@@ -263,6 +265,14 @@ class Ramp_vo:
         self._ii, self._jj, self._kk = (sd[x].cpu().numpy().astype(np.int64) for x in ("ii", "jj", "kk"))
         self.delta = {k: (v[0], SE3(v[1].to(dev))) for k, v in sd.get("delta", {}).items()}
         self._plan = None
+        # nothing prepared for the previous state may survive: the speculative next-frame graph (validated only by
+        # its sizes), the keyframe predictor, the intrinsics row cache, the pinned layout buffers' bookkeeping
+        self._pre_cache, self._pending, self._net_map_dev = None, None, None
+        self._mm_prev, self._spec_ema = None, 1.0
+        self._last_K = self._last_K_raw = None
+        self._last_K_row = -1
+        self._pool_busy.clear()
+        self._mirror_pool = None
 
     # --------------------------------------------------------------- trajectory
     def get_pose(self, t):
@@ -528,6 +538,8 @@ class Ramp_vo:
         """device side of dropping keyframe k: shift the per-frame state down by one row"""
         n = self.n
         del self._tstamps[k]
+        if self._last_K_row > k:
+            self._last_K_row -= 1
         if self.device.type == "cuda" and (self.M * 3) % 4 == 0:
             if self._shift_plan is None:
                 self._shift_plan = ops.ShiftPlan([(self.tstamps_, 0), (self.colors_, 0), (self.poses_, 0),
@@ -832,14 +844,17 @@ class Ramp_vo:
         # intrinsics at feature resolution; the usual case (same values as the previous frame, CPU fp32 tensor)
         # is recognised without building new arrays
         k_dev = None
-        raw = getattr(self, "_last_K_raw", None)
-        if (raw is not None and intrinsics.device.type == "cpu" and intrinsics.dtype == torch.float32
+        raw = self._last_K_raw
+        # the row copy (intrinsics_[n] = intrinsics_[n-1]) is only right while row n-1 is the row that holds
+        # _last_K: not after a frame that wrote a new K to row n and was then rejected by the motion probe
+        row_ok = self._last_K_row == self.n - 1
+        if (raw is not None and row_ok and intrinsics.device.type == "cpu" and intrinsics.dtype == torch.float32
                 and torch.equal(intrinsics, raw)):
             kq = self._last_K
         else:
             kq = intrinsics.detach().cpu().float().numpy() / self.RES
             self._K_raw_now = intrinsics.detach().cpu().float().clone()
-            if accepts and not (getattr(self, "_last_K", None) is not None and np.array_equal(kq, self._last_K)):
+            if accepts and not (row_ok and self._last_K is not None and np.array_equal(kq, self._last_K)):
                 k_dev = self._upload(kq.astype(np.float32))
         if fe_done is None:
             fmap, gmap, imap, patches, _, clr = self.network.patchify(
@@ -878,6 +893,7 @@ class Ramp_vo:
                               (self.fmap2_, slot)])
         else:
             self._frame_stores_stepwise(n, slot, k_dev, kq, patches, imap, gmap, fmap, clr, ex)
+        self._last_K_row = n                         # row n now holds _last_K (written or copied from row n-1)
         if self.inputs_ready and self.device.type == "cuda":
             self._fe_free = self._ev_fe_free
             self._fe_free.record()

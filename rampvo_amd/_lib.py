@@ -165,13 +165,20 @@ def ptr(t):
 
 
 _ws_cache = {}
+_ws_retired = []
 
 
 def workspace(nbytes, device, tag="ws"):
-    """grow-only scratch buffer per (device, tag); contents are never reused across calls"""
-    key = (device, tag)
+    """grow-only scratch buffer per (device, stream, tag): two trackers on different streams of one GPU (or one
+    tracker's main and plan-building streams) never share scratch.  Contents are never reused across calls.  A
+    buffer that is outgrown is retired, not freed: launches already queued on its stream (or captured in a
+    hipGraph) may still reference it."""
+    key = (device, torch._C._cuda_getCurrentRawStream(device.index if device.index is not None
+                                                      else torch.cuda.current_device()), tag)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        if buf is not None:
+            _ws_retired.append(buf)
+        buf = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf

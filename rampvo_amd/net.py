@@ -149,8 +149,14 @@ class Patchifier(nn.Module):
         self.use_graph = os.environ.get("RAMP_NO_GRAPH", "0") != "1"
         self._graphs = {}
         self._graph_warm = 0
+        self._plist = None
         self._extra = None
         self._sel_stream = None
+
+    def _apply(self, fn, *a, **k):
+        """.to() / .half() / .cuda() replace the parameter tensors: captured graphs point at the old ones"""
+        self._graphs, self._graph_warm, self._plist = {}, 0, None
+        return super()._apply(fn, *a, **k)
 
     def _coord_grid(self, h, w, device):
         if self._grid is None or self._grid.shape[-2:] != (h, w) or self._grid.device != device:
@@ -176,7 +182,16 @@ class Patchifier(nn.Module):
             return self._forward_impl(input_, patches_per_image, reinit_hidden, disps, event_bias, gradient_bias)
         key = (self.input_mode, tuple(events.shape), tuple(images.shape), patches_per_image, events.dtype,
                images.dtype, bool(getattr(self.encoder, "mixed_precision", False)), events.device)
+        # the captured graph bakes in raw pointers to the packed encoder weights and to the encoder's recurrent
+        # state buffers: it is only valid for the parameter values and the state object it was captured with
+        # (in-place weight updates bump ``_version``; a resolution change reallocates the state)
+        if self._plist is None:
+            self._plist = list(self.encoder.parameters())
+        sig = (sum(p._version for p in self._plist), self._plist[0].data_ptr(), id(getattr(self.encoder, "_hip_state", None)))
         g = self._graphs.get(key)
+        if g is not None and g[5] != sig:
+            del self._graphs[key]              # stale: captured against other weights / another state buffer
+            g, self._graph_warm = None, 0
         if g is None:
             if self._graph_warm < 1:      # one eager call with carried state first (allocator / pack caches warm)
                 self._graph_warm += 1
@@ -186,10 +201,11 @@ class Patchifier(nn.Module):
             with torch.cuda.graph(graph):
                 outs = self._forward_impl((ev_s, im_s, mask), patches_per_image, False, None, event_bias,
                                           gradient_bias)
-            self._graphs[key] = g = (graph, ev_s, im_s, outs, self._extra)
+            sig = (sig[0], sig[1], id(getattr(self.encoder, "_hip_state", None)))
+            self._graphs[key] = g = (graph, ev_s, im_s, outs, self._extra, sig)
             graph.replay()               # capture does not execute: run this frame now (inputs already staged)
             return outs
-        graph, ev_s, im_s, outs, self._extra = g
+        graph, ev_s, im_s, outs, self._extra, _ = g
         ev_s.copy_(events)
         im_s.copy_(images)
         graph.replay()

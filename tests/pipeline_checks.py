@@ -210,3 +210,59 @@ def check_ramp_vo(device):
     ate = ate_rmse(traj[:, :3], g["traj"][:, :3])
     return dict(frames=len(rec["n"]), frames_with_same_n=same, n_final=slam.n, E_final=rec["E"][-1],
                 ate_rmse_vs_reference_run=ate, path_length=float(np.linalg.norm(np.diff(g["traj"][:, :3], axis=0), axis=1).sum()))
+
+
+# free-running trajectory parity (fixtures ramp_vo_traj_{ss,ms}.npz; same definitions as oracle/make_golden.py::TRAJ)
+TRAJ = {
+    "ss": dict(mode="SingleScale", preset="default", H=192, W=256, T=40, M=16, seed=11, over={}),
+    "ms": dict(mode="MultiScale", preset="precise", H=192, W=256, T=48, M=16, seed=9, over={"KEYFRAME_THRESH": 0.0}),
+}
+
+
+@torch.no_grad()
+def run_trajectory(tag, device, mixed=False, pipelined=False):
+    from rampvo_amd.config import make_cfg
+    from rampvo_amd.Ramp_vo import Ramp_vo
+    from rampvo_amd.synthetic import SyntheticStream, make_network
+    p = TRAJ[tag]
+    net = make_network(p["mode"], device=device, profile="damped")
+    cfg = make_cfg(p["preset"], PATCHES_PER_FRAME=p["M"], MIXED_PRECISION=mixed, **p["over"])
+    slam = Ramp_vo(cfg, net, {"event_bias": True}, ht=p["H"], wd=p["W"], device=device)
+    slam.inputs_ready = pipelined
+    stream = SyntheticStream(p["H"], p["W"], p["T"], seed=p["seed"])
+    frame_no = [0]
+    slam._initial_depth = lambda patches: depth_draw(frame_no[0], patches.shape[1]).to(patches.device)
+    rec = dict(n=[], E=[], pose=[])
+    for t in range(p["T"]):
+        image, events, K, mask = stream.frame(t)
+        frame_no[0] = t
+        slam(t, input_tensor=(events.to(device), image.to(device), mask), intrinsics=K)
+        slam.settle()
+        rec["n"].append(slam.n); rec["E"].append(len(slam._ii))
+        rec["pose"].append(slam.poses_[max(slam.n - 1, 0)].cpu().numpy().copy())
+    traj, ts = slam.terminate()
+    return slam, rec, traj, ts
+
+
+def check_trajectory(tag, device, mixed=False, pipelined=False):
+    """N-frame free run (damped weight profile) against the reference's own run of the same stream: structure
+    exact, every float within the returned errors.  ``rel`` = max abs trajectory difference / max(1, largest
+    reference translation) -- the north-star's 'pose trajectory within 1e-4 rel'."""
+    from rampvo_amd.evaluate import ate_rmse
+    g = gold(f"ramp_vo_traj_{tag}.npz")
+    slam, rec, traj, ts = run_trajectory(tag, device, mixed, pipelined)
+    assert rec["n"] == list(g["n"]) and rec["E"] == list(g["E"]), "keyframe decisions / graph sizes"
+    for a, b in ((slam._ii, "ii"), (slam._jj, "jj"), (slam._kk, "kk")):
+        assert np.array_equal(a, g["final_" + b]), b
+    assert np.array_equal(ts, g["tstamps"]) and traj.shape == g["traj"].shape
+    n = slam.n
+    scale = max(1.0, float(np.abs(g["traj"][:, :3]).max()))
+    d_ref = g["final_depths"]
+    d_got = slam.patches_[:n, :, 2, 1, 1].cpu().numpy()
+    return dict(frames=len(rec["n"]), n=n, E=rec["E"][-1], jj_max=int(slam._jj.max()),
+                traj_abs=float(np.abs(traj - g["traj"]).max()), rel=float(np.abs(traj - g["traj"]).max() / scale),
+                per_frame_pose=float(np.abs(np.asarray(rec["pose"]) - g["pose"]).max()),
+                poses=float(np.abs(slam.poses_[:n].cpu().numpy() - g["final_poses"]).max()),
+                depths_rel=float((np.abs(d_got - d_ref) / np.maximum(np.abs(d_ref), 1.0)).max()),
+                ate_rmse=float(ate_rmse(traj[:, :3], g["traj"][:, :3])),
+                path_length=float(np.linalg.norm(np.diff(g["traj"][:, :3], axis=0), axis=1).sum()))

@@ -302,3 +302,27 @@ def test_ate_metric_and_writers(tmp_path):
     assert (c / "cameras.txt").read_text() == "1 PINHOLE 640 480 320 320 320 240"
     assert len((c / "points3D.txt").read_text().splitlines()) == 5
     assert (c / "images.txt").read_text().splitlines()[0].startswith("1 1.0 0.0 0.0 0.0 ")
+
+
+@pytest.mark.parametrize("tag", ["ss", "ms"])
+def test_trajectory_against_reference_run_cpu(tag):
+    """free-running tracker (damped weights) over the oracle backend vs the reference's own run: the host logic
+    (edges, keyframe shuffle, ring-buffer aliasing at n > 32 in "ms") reproduces the reference's trajectory"""
+    with cpu_oracle_ops():
+        e = pc.check_trajectory(tag, "cpu")
+    print(e)
+    assert e["rel"] <= 1e-5 and e["depths_rel"] <= 1e-4, e
+    if tag == "ms":
+        assert e["jj_max"] >= 45      # the frame index wrapped the 32-slot ring
+
+
+def test_oracle_corr_against_reference_call_site_golden():
+    """G3: orc.corr on both pyramid levels, stacked as Ramp_vo.corr stacks them, equals what the reference's
+    altcorr.corr python call site returned in the build container"""
+    from scenes import corr_case
+    g = pc.gold("corr.npz")
+    f1, f2, coords, ii, jj = corr_case(seed=int(g["seed"]), E=int(g["E"]))
+    c1 = orc.corr(f1, f2, coords / 1, ii, jj, 3)
+    c2 = orc.corr(f1, g["fmap2_l1"].astype(np.float32), coords / 4, ii, jj, 3)
+    out = np.stack([c1, c2], -1).reshape(1, len(ii), -1)
+    assert out.shape == g["out"].shape and np.array_equal(out, g["out"])

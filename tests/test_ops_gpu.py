@@ -226,6 +226,59 @@ def test_pyramid_pack_and_chunked_corr():
     assert a.float().abs().max() > 0
 
 
+def test_corr_matches_reference_call_site_golden():
+    """G3 (tests/golden/corr.npz): what the reference's altcorr.corr python call site returned for both pyramid
+    levels, stacked as Ramp_vo.corr stacks them (ramp/Ramp_vo.py:175-182)"""
+    import pipeline_checks as pc
+    from rampvo_amd import altcorr
+    from rampvo_amd._lib import RAMP_NCHW
+    g = pc.gold("corr.npz")
+    f1, f2, coords, ii, jj = corr_case(seed=int(g["seed"]), E=int(g["E"]))
+    f2b = g["fmap2_l1"].astype(np.float32)
+    out = altcorr.corr_pyramid(cu(f1[0]), [cu(f2[0]), cu(f2b[0])], cu(coords[0]), cu(ii), cu(jj), 3, (1, 4), RAMP_NCHW)
+    out = out.cpu().numpy()
+    assert out.shape == g["out"].shape
+    assert np.array_equal(np.isnan(out), np.isnan(g["out"]))
+    assert np.nanmax(np.abs(out - g["out"])) <= 1e-5
+
+
+@pytest.mark.parametrize("half", [False, True])
+def test_corr_ring_buffer_modulo_matches_oracle_on_wrapped_indices(half):
+    """Ramp_vo.corr's ring-buffer aliasing (reference Ramp_vo.py:178-179: ``ii % (M*mem)``, ``jj % mem``) is taken
+    INSIDE the kernel (mod_ii / mod_jj of ramp_corr_fwd_ordered): edge indices beyond the buffers (kk up to 3x the
+    patch slots, jj up to 3x the frame slots, as after > mem keyframes under precise.yaml) must read the wrapped
+    slot -- compared with the oracle on pre-wrapped indices, fp32 (<= 1e-5) and the fp16 MFMA kernel
+    (oracle on fp16-rounded inputs), plain and target-frame-major schedule, both output row formats"""
+    from rampvo_amd import ops
+    from rampvo_amd._lib import RAMP_NHWC
+    N1, N2, E = 40, 6, 93
+    fmap1, fmap2, coords, ii, jj = corr_case(seed=21, E=E, N1=N1, N2=N2)
+    rng = np.random.default_rng(5)
+    ii_raw = (ii + N1 * rng.integers(0, 3, E)).astype(np.int64)
+    jj_raw = (jj + N2 * rng.integers(0, 3, E)).astype(np.int64)
+    assert ii_raw.max() >= N1 and jj_raw.max() >= N2 and np.array_equal(ii_raw % N1, ii)
+    fmap2b = np.ascontiguousarray(fmap2[:, :, :, ::2, ::2])
+    h = (lambda a: a.astype(np.float16).astype(np.float32)) if half else (lambda a: a)
+    ref = np.stack([orc.corr(h(fmap1), h(fmap2), coords / 1, ii, jj, 3)[0],
+                    orc.corr(h(fmap1), h(fmap2b), coords / 4, ii, jj, 3)[0]], -1)
+    t = (lambda a: cu(a).half()) if half else cu
+    args = (t(fmap1[0].transpose(0, 2, 3, 1)), [t(fmap2[0].transpose(0, 2, 3, 1)), t(fmap2b[0].transpose(0, 2, 3, 1))],
+            cu(coords[0]), cu(ii_raw), cu(jj_raw), 3, (1.0, 4.0), RAMP_NHWC)
+    byjj = torch.argsort(cu(jj_raw), stable=True).int()
+    tol = 1.5e-3 * np.nanmax(np.abs(ref)) if half else 1e-5
+    wrapped = ops.corr(*args[:3], cu(ii), cu(jj), *args[5:])           # the same edges, indices wrapped by the caller
+    for order, row in ((None, 0), (byjj, 0), (byjj, 896)):
+        out = ops.corr(*args, order=order, row_elems=row, mod_ii=N1, mod_jj=N2)
+        if row:
+            assert float(out[:, 882:].abs().max()) == 0.0
+            out = out[:, :882]
+        assert torch.equal(torch.nan_to_num(out.reshape(E, -1).float(), nan=-7.0),
+                           torch.nan_to_num(wrapped.reshape(E, -1).float(), nan=-7.0))
+        o = out.reshape(ref.shape).float().cpu().numpy()
+        assert np.array_equal(np.isnan(o), np.isnan(ref))
+        assert np.nanmax(np.abs(o - ref)) <= tol
+
+
 # ---------------------------------------------------------------- projective ops
 def test_transform_reproject_point_cloud():
     from rampvo_amd import ops
@@ -515,6 +568,131 @@ def test_fused_gru_chain_matches_gemm_path():
     assert float(((w_ref - w_new).abs().max(-1).values * (~near_edge)).max()) <= 2e-3
     assert float((res[False][0] - res[True][0]).abs().max()) <= 4e-3 * scale
     assert float((res[False][0] - outs[True][0]).abs().max()) <= 4e-3 * scale          # padding changes nothing
+
+
+FUSED_CHAIN_TOL = 3e-3      # x the output scale; measured worst case is recorded by the test's print
+
+
+@torch.no_grad()
+def test_fused_update_chains_against_fp32_torch():
+    """every fused fp16 MFMA chain of the update operator (csrc/update_mlp.hip, update.hip) on its own against a
+    PLAIN fp32 PyTorch evaluation of the same reference expressions (ramp/net.py:69-90, ramp/blocks.py:15-50) on the
+    fp16-rounded operands the kernels consume (fp16 weights / biases / inputs, fp32 everywhere else): what separates
+    the two is the kernels' fp16 rounding of the activations they park in LDS between layers.  No comparison with
+    this repo's own GEMM path.  E is not a multiple of the 64-row tile."""
+    import copy
+    import torch.nn.functional as F
+    from rampvo_amd import _lib
+    from rampvo_amd._lib import check, lib, ptr, stream
+    from rampvo_amd.synthetic import make_network
+    net = make_network("SingleScale")
+    fu = net.update.fused(torch.float16)
+    w = fu.weights()
+    ref = copy.deepcopy(net.update).float()
+    # the operands the fp16 path consumes: Linear weights / biases rounded to fp16; LayerNorm parameters stay fp32
+    for mod in ref.modules():
+        if isinstance(mod, torch.nn.Linear):
+            mod.weight.copy_(mod.weight.half().float())
+            mod.bias.copy_(mod.bias.half().float())
+    g = torch.Generator().manual_seed(17)
+    E, G = 1003, 57
+    rnd = lambda *s, sc=0.5: (torch.randn(*s, generator=g) * sc).cuda()
+    worst = {}
+
+    def cmp(name, got, exp, tol=FUSED_CHAIN_TOL):
+        scale = float(exp.abs().max())
+        err = float((got.float() - exp).abs().max()) / scale
+        worst[name] = err
+        assert err <= tol, (name, err, worst)
+
+    # --- upd_gru: LN(x + hy[gid]) -> GatedResidual -> LN -> GatedResidual (+ relu copy)
+    x32, hy = rnd(E, 384), rnd(G, 384).half()
+    gid = torch.randint(0, G, (E,), generator=g).int().cuda()
+    out32 = torch.empty(E, 384, device="cuda")
+    relu_t = torch.empty(E, 384, dtype=torch.half, device="cuda")
+    _, _, wptr, bptr = w["gru_pack"]
+    ln1, ln2 = w["ln1"], w["ln2"]
+    check(lib().ramp_upd_gru(ptr(x32), ptr(hy), ptr(gid), ptr(ln1[0]), ptr(ln1[1]), float(ln1[2]), wptr, bptr,
+                             ptr(ln2[0]), ptr(ln2[1]), float(ln2[2]), ptr(out32), ptr(relu_t), E, stream()), "gru")
+    exp = ref.gru(x32 + hy.float()[gid.long()])
+    cmp("gru", out32, exp)
+    cmp("gru_relu", relu_t, torch.relu(exp))
+    # without the prologue: x32 is already gru[0]'s output
+    xin = ref.gru[0](x32)
+    check(lib().ramp_upd_gru(ptr(xin), None, None, None, None, 0.0, wptr, bptr, ptr(ln2[0]), ptr(ln2[1]),
+                             float(ln2[2]), ptr(out32), ptr(relu_t), E, stream()), "gru")
+    cmp("gru_noprologue", out32, ref.gru[3](ref.gru[2](ref.gru[1](xin))))
+
+    # --- upd_nbr: net + Lb(relu(La(mask * net[idx])))
+    net_in = rnd(E, 384)
+    idx = torch.randint(-1, E, (E,), generator=g).cuda()
+    idx[::5] = -1
+    for name, seq in (("c1_pack", ref.c1), ("c2_pack", ref.c2)):
+        wa, ba, wb, bb = w[name]
+        o = torch.empty_like(net_in)
+        ot = torch.empty(E, 384, dtype=torch.half, device="cuda")
+        check(lib().ramp_upd_nbr(ptr(net_in), ptr(idx), ptr(wa), ptr(ba), ptr(wb), ptr(bb), ptr(o), ptr(ot), E, stream()),
+              "nbr")
+        gathered = net_in[idx.clamp(min=0)] * (idx >= 0).float()[:, None]
+        exp = net_in + seq(gathered)
+        cmp("nbr_" + name, o, exp)
+        cmp("nbr_t_" + name, ot, exp)
+
+    # --- upd_corr_mlp: LN_norm(net[map] + inp[idx % mod] + corr-MLP(corr)); upd_corr_tail: the same from c1 = relu(L1 corr)
+    corr = F.pad(rnd(E, 882, sc=2.0).half(), (0, 14)).contiguous()
+    state = rnd(700, 384)
+    net_map = torch.randint(-1, 700, (E,), generator=g).cuda()
+    table = rnd(300, 384).half()
+    inp_idx = torch.randint(0, 5000, (E,), generator=g).cuda()
+    w1, b1 = w["corr1_pack"]
+    w2, b2, w3, b3 = w["tail_pack"]
+    ln, nm = w["corr_ln"], w["norm"]
+    o = torch.empty(E, 384, device="cuda")
+    check(lib().ramp_upd_corr_mlp(ptr(corr), 896, ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3), ptr(ln[0]),
+                                  ptr(ln[1]), float(ln[2]), ptr(state), ptr(net_map), ptr(table), ptr(inp_idx), 300,
+                                  ptr(nm[0]), ptr(nm[1]), float(nm[2]), ptr(o), E, stream()), "corr_mlp")
+    st = state[net_map.clamp(min=0)] * (net_map >= 0).float()[:, None]
+    exp = ref.norm(st + table.float()[inp_idx % 300] + ref.corr(corr[:, :882].float()))
+    cmp("corr_mlp", o, exp)
+    c1 = torch.relu(ref.corr[0](corr[:, :882].float())).half()
+    check(lib().ramp_upd_corr_tail(ptr(c1), ptr(w2), ptr(b2), ptr(w3), ptr(b3), ptr(ln[0]), ptr(ln[1]), float(ln[2]),
+                                   ptr(state), ptr(net_map), ptr(table), ptr(inp_idx), 300, ptr(nm[0]), ptr(nm[1]),
+                                   float(nm[2]), ptr(o), E, stream()), "corr_tail")
+    exp_t = ref.norm(st + table.float()[inp_idx % 300] + ref.corr[5](torch.relu(ref.corr[3](ref.corr[2](c1.float())))))
+    cmp("corr_tail", o, exp_t)
+    # zero state / identity context (the motion probe's form)
+    check(lib().ramp_upd_corr_mlp(ptr(corr), 896, ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3), ptr(ln[0]),
+                                  ptr(ln[1]), float(ln[2]), None, None, ptr(rnd(E, 384).half()), None, 0,
+                                  ptr(nm[0]), ptr(nm[1]), float(nm[2]), ptr(o), E, stream()), "corr_mlp")
+    assert torch.isfinite(o).all()
+
+    # --- upd_fg: x = x32 (+ add[gid], written back); fg = [f(x) | g(x)]; then the segment softmax + h: SoftAgg
+    for name, agg in (("kk_fg_pack", ref.agg_kk), ("ij_fg_pack", ref.agg_ij)):
+        wf, bf, wg, bg = w[name]
+        xs = x32.clone()
+        fg = torch.empty(E, 768, dtype=torch.half, device="cuda")
+        check(lib().ramp_upd_fg(ptr(xs), ptr(hy), ptr(gid), ptr(xs), ptr(wf), ptr(bf), ptr(wg), ptr(bg), ptr(fg), E,
+                                stream()), "fg")
+        xe = x32 + hy.float()[gid.long()]
+        cmp("fg_x_" + name, xs, xe, tol=1e-6)
+        cmp("fg_" + name, fg, torch.cat([agg.f(xe), agg.g(xe)], 1))
+
+    # --- heads: Linear(384 -> 2) x 2 on relu(net), target = centre + delta, weight = sigmoid(.) inside the image
+    relu_in = torch.relu(rnd(E, 384)).half()
+    coords = (torch.rand(E, 2, 3, 3, generator=g) * 60).cuda()
+    target = torch.empty(1, E, 2, device="cuda")
+    weight = torch.empty(1, E, 2, device="cuda")
+    hwt, hb = w["heads_pack"]
+    check(lib().ramp_upd_heads_linear(ptr(relu_in), ptr(hwt), ptr(hb), ptr(coords), ptr(target), ptr(weight), E, 3,
+                                      40.0, 30.0, stream()), "heads")
+    delta = ref.d[1](relu_in.float())
+    t_exp = coords[:, :, 1, 1] + delta
+    w_exp = torch.sigmoid(ref.w[1](relu_in.float()))
+    inside = (t_exp[:, 0] >= 0) & (t_exp[:, 1] >= 0) & (t_exp[:, 0] <= 40.0) & (t_exp[:, 1] <= 30.0)   # utils.py:557-570
+    cmp("heads_target", target[0], t_exp, tol=2e-3)
+    far = ((t_exp - torch.tensor([40.0, 30.0], device="cuda")).abs().min(-1).values > 0.2) & (t_exp.abs().min(-1).values > 0.2)
+    assert float(((weight[0] - w_exp * inside[:, None].float()).abs().max(-1).values * far.float()).max()) <= 2e-3
+    print("fused update chains vs fp32 torch, max err / output scale:", {k: round(v, 6) for k, v in worst.items()})
 
 
 def test_event_stack_matches_reference_golden_and_oracle():

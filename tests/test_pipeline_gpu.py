@@ -58,49 +58,154 @@ def test_hip_library_is_the_code_that_ran():
     assert "libramp_hip.so" in maps
 
 
-@torch.no_grad()
-def test_full_size_update_step_against_cpu_oracle():
-    """BASELINE.json configs[1] size (SingleScale 640x480, 96 patches, default.yaml windows, fp32): track the
-    synthetic stream on the GPU until the window holds > 20k edges, then run ONE update() twice from the
-    same snapshot -- HIP kernels vs the CPU oracle backend (torch-CPU encoder/GEMMs + oracle C natives)."""
-    from oracle.backend_cpu import cpu_oracle_ops
+def _steady_state_snapshot(mode, preset, M, H, W, frames, mixed, seed=4321, **over):
+    """track the synthetic stream on the GPU ("wide" weights: keyframes are kept, the window fills) and return the
+    tracker + its state snapshot (reference layouts, CPU tensors)"""
     from rampvo_amd.config import make_cfg
     from rampvo_amd.Ramp_vo import Ramp_vo
     from rampvo_amd.synthetic import SyntheticStream, make_network
-    cfgk = dict(PATCHES_PER_FRAME=96, MIXED_PRECISION=False)
-    slam = Ramp_vo(make_cfg("default", **cfgk), make_network("SingleScale"), {"event_bias": True})
-    stream = SyntheticStream(480, 640, 40, seed=4321, device="cuda")
-    for t in range(34):
+    cfgk = dict(PATCHES_PER_FRAME=M, MIXED_PRECISION=mixed, **over)
+    slam = Ramp_vo(make_cfg(preset, **cfgk), make_network(mode), {"event_bias": True}, ht=H, wd=W)
+    stream = SyntheticStream(H, W, frames + 1, seed=seed, device="cuda")
+    for t in range(frames):
         im, ev, K, mask = stream.frame(t)
         slam(t, input_tensor=(ev, im, mask), intrinsics=K)
-    assert slam.is_initialized and len(slam._ii) > 20000
-    sd = slam.state_dict()
-    n, m = slam.n, slam.m
-    before = slam.poses_[:n].cpu().numpy().copy()
-    slam.update()
-    g_poses = slam.poses_[:n].cpu().numpy()
-    g_depth = slam.patches_[:n, :, 2, 1, 1].cpu().numpy()
-    g_net = slam.net[0].float().cpu().numpy()
-    g_w = slam.last_weight.cpu().numpy()
+    assert slam.is_initialized
+    return slam, slam.state_dict(), cfgk
+
+
+def _one_update_vs_cpu_oracle(mode, preset, H, W, sd, cfgk, legs=(False,)):
+    """ONE update() (reproject -> corr -> update operator -> BA x2 -> point cloud) from the same snapshot: HIP kernels
+    (a fresh tracker per precision leg) vs the CPU oracle backend in fp32 (torch-CPU GEMMs + oracle C natives).
+    Returns {leg: errors}; errors are max-abs, poses/depths relative to max(1, size of the GN step)."""
+    from oracle.backend_cpu import cpu_oracle_ops
+    from rampvo_amd.config import make_cfg
+    from rampvo_amd.Ramp_vo import Ramp_vo
+    from rampvo_amd.synthetic import make_network
+    n = int(sd["n"])
+    before = sd["poses"][:n].numpy().copy()
+    f32 = dict(sd)
+    for k in ("net", "imap", "gmap", "fmap1", "fmap2"):
+        f32[k] = sd[k].float()
     with cpu_oracle_ops():
-        ref = Ramp_vo(make_cfg("default", **cfgk), make_network("SingleScale", device="cpu"), {"event_bias": True},
-                      device="cpu")
-        ref.load_state_dict(sd)
+        ref = Ramp_vo(make_cfg(preset, **dict(cfgk, MIXED_PRECISION=False)), make_network(mode, device="cpu"),
+                      {"event_bias": True}, ht=H, wd=W, device="cpu")
+        ref.load_state_dict(f32)
         ref.update()
-        r_poses = ref.poses_[:n].numpy()
-        r_depth = ref.patches_[:n, :, 2, 1, 1].numpy()
-        r_net = ref.net[0].float().numpy()
-        r_w = ref.last_weight.numpy()
-    assert np.array_equal(slam._ii, ref._ii) and np.array_equal(slam._kk, ref._kk)
+        r_poses = ref.poses_[:n].numpy().copy()
+        r_depth = ref.patches_[:n, :, 2, 1, 1].numpy().copy()
+        r_net = ref.net[0].float().numpy().copy()
+        r_w = ref.last_weight.numpy().copy()
     step = float(np.abs(r_poses - before).max())
-    scale = max(1.0, step)
-    e = dict(E=len(slam._ii), step=step, net=float(np.abs(g_net - r_net).max() / np.abs(r_net).max()),
-             weight=float(np.abs(g_w - r_w).max()), poses=float(np.abs(g_poses - r_poses).max()),
-             depths=float((np.abs(g_depth - r_depth) / np.maximum(np.abs(r_depth), 1.0)).max()),
-             depth_range=(float(r_depth.min()), float(r_depth.max())))
-    print(e)
+    out = {}
+    net = make_network(mode)
+    for mixed in legs:
+        slam = Ramp_vo(make_cfg(preset, **dict(cfgk, MIXED_PRECISION=mixed)), net, {"event_bias": True}, ht=H, wd=W)
+        slam.load_state_dict(sd)
+        assert np.array_equal(slam._ii, ref._ii) and np.array_equal(slam._kk, ref._kk)
+        slam.update()
+        g_poses = slam.poses_[:n].cpu().numpy()
+        g_depth = slam.patches_[:n, :, 2, 1, 1].cpu().numpy()
+        g_net = slam.net[0].float().cpu().numpy()
+        g_w = slam.last_weight.cpu().numpy()
+        out["fp16" if mixed else "fp32"] = dict(
+            E=len(slam._ii), n=n, jj_max=int(slam._jj.max()), step=step,
+            net=float(np.abs(g_net - r_net).max() / np.abs(r_net).max()), weight=float(np.abs(g_w - r_w).max()),
+            poses=float(np.abs(g_poses - r_poses).max()),
+            depths=float((np.abs(g_depth - r_depth) / np.maximum(np.abs(r_depth), 1.0)).max()),
+            depth_range=(float(r_depth.min()), float(r_depth.max())))
+    return out
+
+
+def _assert_fp32_leg(e):
+    scale = max(1.0, e["step"])
     assert e["net"] <= 1e-4 and e["weight"] <= 1e-4, e
     assert e["poses"] <= 1e-4 * scale and e["depths"] <= 1e-4 * scale, e
+
+
+# stated bounds of the fp16 (MIXED_PRECISION, the benchmarked) leg against the fp32 oracle, "wide" weights:
+# hidden state / confidence weights to fp16 GEMM-I/O accuracy; poses and depths relative to max(1, GN step)
+MIXED_NET, MIXED_WEIGHT, MIXED_POSES, MIXED_DEPTHS = 2e-2, 2e-2, 5e-2, 2.5e-1
+
+
+@torch.no_grad()
+def test_full_size_update_step_against_cpu_oracle():
+    """BASELINE.json configs[1] size (SingleScale 640x480, 96 patches, default.yaml windows): track the synthetic stream
+    on the GPU in the benchmarked precision until the window holds > 20k edges, then run ONE update() from the same
+    snapshot three ways -- HIP fp32, HIP fp16 (the benchmarked path) and the CPU oracle backend (fp32)."""
+    slam, sd, cfgk = _steady_state_snapshot("SingleScale", "default", 96, 480, 640, 34, mixed=True)
+    assert len(slam._ii) > 20000
+    e = _one_update_vs_cpu_oracle("SingleScale", "default", 480, 640, sd, cfgk, legs=(False, True))
+    print(e)
+    _assert_fp32_leg(e["fp32"])
+    m = e["fp16"]
+    scale = max(1.0, m["step"])
+    assert m["net"] <= MIXED_NET and m["weight"] <= MIXED_WEIGHT, m
+    assert m["poses"] <= MIXED_POSES * scale and m["depths"] <= MIXED_DEPTHS * scale, m
+
+
+@torch.no_grad()
+def test_config3_multiscale_precise_windows_update_step_against_cpu_oracle():
+    """BASELINE.json configs[2]: MultiScale encoder, 96 patches, precise.yaml windows (PATCH_LIFETIME 33, REMOVAL 42,
+    OPTIMIZATION 30: a 180x180 Schur system).  More keyframes than ring slots (mem = 32, reference Ramp_vo.py:72), so
+    ``jj % 32`` / ``kk % (M*32)`` alias newer features onto old frames (Ramp_vo.py:178-179) -- reproduced, not fixed.
+    One update() from the GPU-tracked snapshot: HIP fp32 and fp16 vs the CPU oracle backend."""
+    slam, sd, cfgk = _steady_state_snapshot("MultiScale", "precise", 96, 480, 640, 52, mixed=True)
+    assert slam.n > 34 and int(slam._jj.max()) >= 33 and len(slam._ii) > 100000, (slam.n, len(slam._ii))
+    e = _one_update_vs_cpu_oracle("MultiScale", "precise", 480, 640, sd, cfgk, legs=(False, True))
+    print(e)
+    _assert_fp32_leg(e["fp32"])
+    m = e["fp16"]
+    scale = max(1.0, m["step"])
+    assert m["net"] <= MIXED_NET and m["weight"] <= MIXED_WEIGHT, m
+    assert m["poses"] <= MIXED_POSES * scale and m["depths"] <= MIXED_DEPTHS * scale, m
+
+
+@torch.no_grad()
+def test_config5_720p_256_patches_32_keyframe_window_update_step_against_cpu_oracle():
+    """BASELINE.json configs[4]: MultiScale 1280x720, 256 patches, 32-keyframe optimisation window (a 192x192 Schur
+    system over ~10k patch depths), precise.yaml lifetimes: one update() vs the CPU oracle backend, fp32 leg."""
+    over = dict(OPTIMIZATION_WINDOW=32)
+    slam, sd, cfgk = _steady_state_snapshot("MultiScale", "precise", 256, 720, 1280, 40, mixed=True, **over)
+    assert slam.n > 33 and len(slam._ii) > 300000, (slam.n, len(slam._ii))
+    e = _one_update_vs_cpu_oracle("MultiScale", "precise", 720, 1280, sd, cfgk, legs=(False, True))
+    print(e)
+    _assert_fp32_leg(e["fp32"])
+    m = e["fp16"]
+    scale = max(1.0, m["step"])
+    assert m["net"] <= MIXED_NET and m["weight"] <= MIXED_WEIGHT, m
+    assert m["poses"] <= MIXED_POSES * scale and m["depths"] <= MIXED_DEPTHS * scale, m
+
+
+@pytest.mark.parametrize("tag", ["ss", "ms"])
+def test_trajectory_fp32_against_reference_run(tag):
+    """N-frame FREE-RUNNING tracker (fp32, damped weight profile) against the reference's own run of the same stream
+    (tests/golden/ramp_vo_traj_*.npz): identical keyframe decisions and graphs, trajectory within 1e-4 relative
+    (north star), depths within 1e-4 relative.  "ms": MultiScale + precise.yaml windows with every frame kept, so the
+    ring buffers alias (48 keyframes on 32 slots)."""
+    e = pc.check_trajectory(tag, "cuda")
+    print(e)
+    assert e["rel"] <= 1e-4 and e["depths_rel"] <= 1e-4 and e["ate_rmse"] <= 1e-4, e
+    if tag == "ms":
+        assert e["jj_max"] >= 45
+
+
+def test_trajectory_fp32_pipelined_against_reference_run():
+    """the same with frame pipelining on (scheduling only)"""
+    e = pc.check_trajectory("ss", "cuda", pipelined=True)
+    assert e["rel"] <= 1e-4 and e["depths_rel"] <= 1e-4, e
+
+
+TRAJ_MIXED_REL = 2e-2
+
+
+@pytest.mark.parametrize("tag", ["ss", "ms"])
+def test_trajectory_mixed_precision_against_reference_run(tag):
+    """the benchmarked precision (fp16 features / MFMA inputs) free-running against the reference's fp32 run: same
+    keyframe decisions and graphs; the trajectory error is stated, not 1e-4 (fp16 features)."""
+    e = pc.check_trajectory(tag, "cuda", mixed=True)
+    print(e)
+    assert e["rel"] <= TRAJ_MIXED_REL, e
 
 
 @torch.no_grad()
@@ -212,15 +317,27 @@ def test_bench_json_contract():
     assert len(lines) == 1
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "roofline_encoder", "roofline_ba", "cpu_baseline"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "roofline_update", "roofline_encoder", "roofline_ba",
+              "cpu_baseline", "parity", "ate_vs_oracle"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 12 and d["warmup"] == 3 and d["higher_is_better"] is True
     assert d["unit"] == "keyframes/s" and d["value"] > 0 and d["vs_baseline"] is None and "workload" in d["config"]
+    assert "clock_warm" in d["config"] and d["config"]["non_pipelined_kfps"] > 0
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["launches"] == 12 and r["achieved"] > 0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r
+    assert 0 < r["frac"] <= 1.0 and r["model_bytes"] > r["bytes_per_launch"]          # compulsory bytes: <= 1 by construction
+    assert abs(r["achieved"] - r["bytes_per_launch"] / (r["mean_launch_us"] * 1e-6) / 1e9) <= 0.01 * r["achieved"]
+    u = d["roofline_update"]
+    assert u["bound"] == "mfma" and 0 < u["frac"] <= 1.0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["unit"] == "keyframes/s"
+    # parity measured in the same process: the fp32 leg meets the north-star tolerance, the fp16 leg is stated
+    tf = d["parity"]["teacher_forced"]
+    assert tf["fp32"]["poses"] <= 1e-4 and tf["fp32"]["depths"] <= 1e-4 and tf["fp32"]["net"] <= 1e-4, tf
+    assert all(np.isfinite(v) for v in tf["fp16"].values()), tf
+    tr = d["parity"]["trajectory"]
+    assert tr["fp32"]["rel"] <= 1e-4 and tr["fp32"]["ate_vs_reference"] <= 1e-4 and d["ate_vs_oracle"] <= 1e-4, tr
 
 
 @torch.no_grad()
@@ -248,3 +365,60 @@ def test_intrinsics_rows_follow_the_input():
         kept[n0] = k                         # the last frame written to a row wins
     for n0, k in kept.items():
         assert torch.equal(slam.intrinsics_[n0].cpu(), k), (n0, slam.intrinsics_[n0], k)
+
+
+@torch.no_grad()
+def test_intrinsics_row_after_a_rejected_frame():
+    """K changes on a frame the motion probe then rejects (n not advanced); the next frame carries the same new K:
+    row n must hold the NEW intrinsics (the reference always writes intrinsics_[n], Ramp_vo.py:351), not a copy of
+    row n-1.  A zeroed ``d`` head makes the probe reject every frame after the first."""
+    from rampvo_amd.config import make_cfg
+    from rampvo_amd.Ramp_vo import Ramp_vo
+    from rampvo_amd.synthetic import SyntheticStream, make_network
+    stream = SyntheticStream(128, 160, 4, seed=3, device="cuda")
+    slam = Ramp_vo(make_cfg("default", PATCHES_PER_FRAME=16, MIXED_PRECISION=True),
+                   make_network("SingleScale", d_gain=0.0, d_bias=0.0), {"event_bias": True}, ht=128, wd=160)
+    K1, K2 = torch.tensor([80.0, 80.0, 80.0, 64.0]), torch.tensor([120.0, 120.0, 80.0, 64.0])
+    for t, K in enumerate((K1, K2, K2, K2)):
+        im, ev, _, mask = stream.frame(t)
+        slam(t, input_tensor=(ev, im, mask), intrinsics=K.clone())
+    assert slam.n == 1 and not slam.is_initialized            # every later frame was rejected
+    assert torch.equal(slam.intrinsics_[0].cpu(), K1 / 4.0)
+    assert torch.equal(slam.intrinsics_[1].cpu(), K2 / 4.0), slam.intrinsics_[:2]
+
+
+@torch.no_grad()
+def test_front_end_graph_follows_weight_updates_and_state_reloads():
+    """the front end's hipGraph bakes in pointers to the packed weights: after an in-place weight update (or
+    load_state_dict on the same module) the next call must not replay the stale capture"""
+    from rampvo_amd.synthetic import SyntheticStream, make_network
+    net = make_network("SingleScale")
+    net.patchify.encoder.mixed_precision = True
+    stream = SyntheticStream(128, 160, 8, seed=3, device="cuda")
+    frames = [stream.frame(t) for t in range(8)]
+
+    def run(t, reinit=False):
+        im, ev, _, mask = frames[t]
+        out = net.patchify(input_=(ev, im, mask), patches_per_image=16, event_bias=True, reinit_hidden=reinit)
+        return [o.float().clone() for o in out[:4]]
+
+    run(0, True); run(1); run(2)                     # eager, warm, capture
+    assert len(net.patchify._graphs) == 1
+    for p in net.patchify.encoder.fmap_encoder.parameters():
+        p.mul_(1.5)                                  # in place: same storage, new _version
+    got = [run(t) for t in (3, 4, 5)]                # stale graph dropped -> warm (eager), capture, replay
+    assert len(net.patchify._graphs) == 1
+    # the reference history, all eager: frames 0-2 with the original weights, the scaled ones from frame 3 on
+    ref_net = make_network("SingleScale")
+    ref_net.patchify.encoder.mixed_precision = True
+    ref_net.patchify.use_graph = False
+    for t in range(3):
+        im, ev, _, mask = frames[t]
+        ref_net.patchify(input_=(ev, im, mask), patches_per_image=16, event_bias=True, reinit_hidden=(t == 0))
+    for p in ref_net.patchify.encoder.fmap_encoder.parameters():
+        p.mul_(1.5)
+    for k, t in enumerate((3, 4, 5)):
+        im, ev, _, mask = frames[t]
+        exp = ref_net.patchify(input_=(ev, im, mask), patches_per_image=16, event_bias=True, reinit_hidden=False)
+        for a, b in zip(got[k], exp[:4]):
+            assert (a - b.float()).abs().max() <= 2e-3 * max(1.0, float(b.float().abs().max()))
