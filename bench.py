@@ -331,7 +331,10 @@ class EncoderTimer:
                          "latency/HBM bound; when pipelining the front end overlaps the previous frame's BA")
 
 
-def _cpu_tracker(state, args, cfg_kwargs):
+PARITY_W_BIAS = -14.0   # see parity_block()
+
+
+def _cpu_tracker(state, args, cfg_kwargs, **net_kw):
     """the CPU oracle backend's tracker loaded with a state snapshot (inside cpu_oracle_ops())"""
     from rampvo_amd.config import make_cfg
     from rampvo_amd.Ramp_vo import Ramp_vo
@@ -340,7 +343,7 @@ def _cpu_tracker(state, args, cfg_kwargs):
     state = dict(state)
     for k in ("net", "imap", "gmap", "fmap1", "fmap2"):
         state[k] = state[k].float()
-    net = make_network(args.mode, device="cpu")
+    net = make_network(args.mode, device="cpu", **net_kw)
     slam = Ramp_vo(make_cfg(args.preset, **cfg_kwargs), net, {"event_bias": True}, ht=args.height, wd=args.width,
                    device="cpu")
     slam.load_state_dict(state)
@@ -375,26 +378,32 @@ def cpu_baseline(state, args, cfg_kwargs, frames, steps):
 def parity_block(state, args, cfg_kwargs, net, dev):
     """ONE teacher-forced update() (reproject -> corr -> update operator -> BA x2) from the run's own steady-state
     snapshot: HIP fp16 (the benchmarked path) and HIP fp32 against the CPU oracle backend (fp32), plus the
-    free-running trajectory of the damped-weight tracker against the reference's own run (committed fixture)."""
+    free-running trajectory of the damped-weight tracker against the reference's own run (committed fixture).
+
+    The compared step runs on all three legs with the run's weights except for the confidence head's bias, shifted by
+    PARITY_W_BIAS: with the throughput profile's confidences (~0.5) on 2-40 px residuals Gauss-Newton solves depths
+    with Q = 1/(C + 1e-4) up to 1e4 on patches seen over almost no baseline, and a 1e-7 input difference moves such
+    a depth by 1e-3 -- the conditioning of the random-weight problem, not kernel accuracy."""
     from oracle.backend_cpu import cpu_oracle_ops
     from rampvo_amd.config import make_cfg
     from rampvo_amd.Ramp_vo import Ramp_vo
+    from rampvo_amd.synthetic import make_network
+    del net
+    net = make_network(args.mode, device=dev, w_bias=PARITY_W_BIAS)
     n = int(state["n"])
     before = state["poses"][:n].numpy().copy()
     torch.set_num_threads(min(os.cpu_count() or 1, int(os.environ.get("RAMP_CPU_THREADS", "64"))))
     with cpu_oracle_ops():
-        ref = _cpu_tracker(state, args, cfg_kwargs)
+        ref = _cpu_tracker(state, args, cfg_kwargs, w_bias=PARITY_W_BIAS)
         ref.update()
         r = dict(poses=ref.poses_[:n].numpy().copy(), depth=ref.patches_[:n, :, 2, 1, 1].numpy().copy(),
                  net=ref.net[0].float().numpy().copy(), w=ref.last_weight.numpy().copy())
     step = float(np.abs(r["poses"] - before).max())
     scale = max(1.0, step)
-    tf = dict(edges=int(state["ii"].shape[0]), keyframes=n, gn_step=round(step, 6),
+    tf = dict(edges=int(state["ii"].shape[0]), keyframes=n, gn_step=round(step, 6), w_head_bias_shift=PARITY_W_BIAS,
               note="max abs error of one update() vs the CPU oracle (fp32) from the same snapshot; net relative to its "
                    "largest entry, poses / depths relative to max(1, |GN step|) (depths also to max(1, |depth|))")
-    enc = getattr(net.patchify, "encoder", None)
-    flag = getattr(enc, "mixed_precision", None)
-    try:
+    if True:
         for name, mixed in (("fp16", True), ("fp32", False)):
             slam = Ramp_vo(make_cfg(args.preset, **dict(cfg_kwargs, MIXED_PRECISION=mixed)), net, {"event_bias": True},
                            ht=args.height, wd=args.width, device=dev)
@@ -402,16 +411,16 @@ def parity_block(state, args, cfg_kwargs, net, dev):
             slam.update()
             torch.cuda.synchronize()
             g_depth = slam.patches_[:n, :, 2, 1, 1].cpu().numpy()
+            # the d > 20 -> 1 reset (ba_cuda.cu:220) is a step function: depths ending within 0.1 of it are counted, not compared
+            at_reset = (np.abs(r["depth"] - 20.0) < 0.1) | (np.abs(g_depth - 20.0) < 0.1)
+            derr = (np.abs(g_depth - r["depth"]) / np.maximum(np.abs(r["depth"]), 1.0))[~at_reset]
             leg = dict(
                 net=float(np.abs(slam.net[0].float().cpu().numpy() - r["net"]).max() / np.abs(r["net"]).max()),
                 weight=float(np.abs(slam.last_weight.cpu().numpy() - r["w"]).max()),
                 poses=float(np.abs(slam.poses_[:n].cpu().numpy() - r["poses"]).max() / scale),
-                depths=float((np.abs(g_depth - r["depth"]) / np.maximum(np.abs(r["depth"]), 1.0)).max() / scale))
+                depths=float(derr.max() / scale), depths_at_reset_threshold=float(at_reset.sum()))
             tf[name] = {k: float("%.3g" % v) for k, v in leg.items()}
             del slam
-    finally:
-        if flag is not None:
-            enc.mixed_precision = flag
     out = dict(teacher_forced=tf)
     # trajectory level: tests/pipeline_checks.py::check_trajectory against tests/golden/ramp_vo_traj_ss.npz
     sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -479,7 +479,9 @@ __global__ void __launch_bounds__(1024)
   for (int q = tid; q < n6; q += nt) t[q] = A[q * ld + n6];
   __syncthreads();
   for (int k = n6 - 1; k >= 0; k--) {
-    const float xk = t[k] * rd[k];
+    // a non-positive pivot (S indefinite by rounding): the reference's Eigen LLT would silently return NaN poses
+    // (ba_cuda.cu:549-552) and the tracker never recovers; here the pose step of this iteration is dropped
+    const float xk = bad ? 0.0f : t[k] * rd[k];
     if (tid == 0) dX[k] = xk;
     for (int i = tid; i < k; i += nt) t[i] = t[i] - A[i * ld + k] * xk;
     __syncthreads();
@@ -540,7 +542,7 @@ __global__ void __launch_bounds__(64)
     if (i == r) x = xr;
     z = __builtin_fmaf(-Lt[i * 65 + r], xr, z);             // L[r][i]; lanes i >= r are no longer needed
   }
-  if (i < n6) dX[i] = x;
+  if (i < n6) dX[i] = bad ? 0.0f : x;                      // see ba_chol_kernel: a failed factorisation drops the pose step
 }
 
 // ------------------------------------------------------------------ K7

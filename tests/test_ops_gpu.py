@@ -580,15 +580,13 @@ def test_fused_update_chains_against_fp32_torch():
     fp16-rounded operands the kernels consume (fp16 weights / biases / inputs, fp32 everywhere else): what separates
     the two is the kernels' fp16 rounding of the activations they park in LDS between layers.  No comparison with
     this repo's own GEMM path.  E is not a multiple of the 64-row tile."""
-    import copy
     import torch.nn.functional as F
-    from rampvo_amd import _lib
     from rampvo_amd._lib import check, lib, ptr, stream
     from rampvo_amd.synthetic import make_network
     net = make_network("SingleScale")
     fu = net.update.fused(torch.float16)
     w = fu.weights()
-    ref = copy.deepcopy(net.update).float()
+    ref = make_network("SingleScale").update.float()          # same seeded weights, a second module
     # the operands the fp16 path consumes: Linear weights / biases rounded to fp16; LayerNorm parameters stay fp32
     for mod in ref.modules():
         if isinstance(mod, torch.nn.Linear):
