@@ -14,6 +14,7 @@
 //     next layer's fp16 input goes back to LDS.  Linear outputs are rounded to fp16 where the
 //     reference's autocast would (they are half tensors there).
 #include "ramp_device.h"
+#include <stdlib.h>
 
 #define MD 384                 // feature width
 #define MBM 64                 // rows per workgroup
@@ -71,6 +72,9 @@ __device__ __forceinline__ void mlp_gemm(const _Float16 *Xs, const _Float16 *con
 #pragma unroll
       for (int nt = 0; nt < MNTW; nt++)
         bn[b][nt] = *reinterpret_cast<const h8 *>(wp[b] + (((size_t)kn * (MD / 16) + wave * MNTW + nt) * 64 + lane) * 8);
+    // the scheduling barrier keeps the loads ABOVE the matrix work (the compiler sinks them to their first use
+    // otherwise, which exposes their full L2 latency on every K step -- the reason this prefetch once looked useless)
+    __builtin_amdgcn_sched_barrier(0);
 #else
 #pragma unroll MLP_UNROLL
   for (int ks = 0; ks < MKS; ks++) {
@@ -650,6 +654,260 @@ __global__ void __launch_bounds__(64 * MWAVES) __attribute__((amdgpu_waves_per_e
   }
 }
 
+// =====================================================================================================
+// Wider-tile variants of the two chains WITHOUT row statistics (c1 / c2 and SoftAgg's [f | g]): a workgroup owns
+// 16 NMT rows (80 / 96 at the bench size) instead of 64, two workgroups per CU, so each streamed weight fragment
+// feeds 1.25-1.5x the matrix work and one workgroup's gather / store phase overlaps the other's GEMM.
+//   * TRANSPOSED accumulators (weights as the A operand): lane (q, j) holds row j of a 16-row tile and four
+//     consecutive columns -- the epilogue is a 16-byte global access straight from the accumulator registers, no fp32
+//     parking pass through LDS;
+//   * global accesses in that layout use ONE 32-bit byte offset per row tile next to a uniform base pointer; rows
+//     past E are clamped for loads and masked for stores;
+//   * the weight fragments of K step ks + 1 are issued before the MFMAs of step ks (scheduling barrier: the compiler
+//     sinks them to their first use otherwise).
+// Measured on MI355X at E = 40,000 (tools/mb_update.py): c1 / c2 48.9 -> 43.3 us (80 rows), [f | g] 56.1 -> 46.1 us
+// (96 rows).  Both chains move 184 MB of fp32 state per launch (~37-46 us at 4-5 TB/s): they are HBM bound, the matrix
+// work is hidden.  The same treatment of the gru block and the correlation MLP (160 rows per workgroup, one round of
+// 250 workgroups, LayerNorm statistics through an LDS table) was slower than the 64-row kernels (192 vs 162 us,
+// 131 vs 90 us): one workgroup per CU cannot hide its own weight-load latency, and 240+ live accumulator registers
+// spill -- the way forward there is an LDS-DMA weight FIFO with counted vmcnt waits (inline asm), not a bigger tile.
+typedef _Float16 hh4 __attribute__((ext_vector_type(4)));
+
+template <int NMT, int NTW>
+__device__ __forceinline__ void big_zero(f4 (&acc)[NMT][NTW]) {
+#pragma unroll
+  for (int mt = 0; mt < NMT; mt++)
+#pragma unroll
+    for (int nt = 0; nt < NTW; nt++) acc[mt][nt] = (f4){0.f, 0.f, 0.f, 0.f};
+}
+
+// acc[mt][nt] += (Xs[16 NMT x 32 nks] * W[:, 32 w_ks0 ..)^T)^T for this wave's 16 NTW columns (transposed
+// accumulators).  The weight fragments of K step ks + 1 are ISSUED before the matrix work of step ks (the scheduling
+// barrier keeps the compiler from sinking them to their first use, which exposed their full L2 latency every step);
+// the A fragment of row tile mt + 1 is read from LDS while tile mt multiplies.
+template <int NMT, int NTW>
+__device__ __forceinline__ void big_gemm(const _Float16 *Xs, const _Float16 *wp, int nks, int w_ks0, int wave, int lane,
+                                         f4 (&acc)[NMT][NTW]) {
+  const int q = lane >> 4, j = lane & 15;
+  const _Float16 *wb = wp + (((size_t)w_ks0 * (MD / 16) + wave * NTW) * 64 + lane) * 8;
+  const _Float16 *xb = Xs + j * MXS + 8 * q;
+  h8 bn[NTW];
+#pragma unroll
+  for (int nt = 0; nt < NTW; nt++) bn[nt] = *reinterpret_cast<const h8 *>(wb + (size_t)nt * 512);
+#pragma unroll 1
+  for (int ks = 0; ks < nks; ks++) {
+    h8 bw[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; nt++) bw[nt] = bn[nt];
+    const int kn = ks + 1 < nks ? ks + 1 : ks;
+#pragma unroll
+    for (int nt = 0; nt < NTW; nt++)
+      bn[nt] = *reinterpret_cast<const h8 *>(wb + ((size_t)kn * (MD / 16) + nt) * 512);
+    h8 a = *reinterpret_cast<const h8 *>(xb + ks * 32);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mt = 0; mt < NMT; mt++) {
+      h8 an = a;
+      if (mt + 1 < NMT) an = *reinterpret_cast<const h8 *>(xb + (mt + 1) * 16 * MXS + ks * 32);
+#pragma unroll
+      for (int nt = 0; nt < NTW; nt++)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bw[nt], a, acc[mt][nt], 0, 0, 0);
+      a = an;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// h = [relu](acc + bias) as fp16 into the LDS tile (8-byte stores, conflict free with the +8 pad)
+template <int NMT, int NTW, bool RELU>
+__device__ __forceinline__ void big_store_tile(_Float16 *Xs, const f4 (&acc)[NMT][NTW], const float *__restrict__ bias,
+                                               int col0, int q, int j) {
+#pragma unroll
+  for (int nt = 0; nt < NTW; nt++) {
+    const int c = col0 + nt * 16 + 4 * q;
+    const float4 b = *reinterpret_cast<const float4 *>(bias + c);
+#pragma unroll
+    for (int mt = 0; mt < NMT; mt++) {
+      float v0 = acc[mt][nt][0] + b.x, v1 = acc[mt][nt][1] + b.y, v2 = acc[mt][nt][2] + b.z, v3 = acc[mt][nt][3] + b.w;
+      if (RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+      *reinterpret_cast<hh4 *>(Xs + (mt * 16 + j) * MXS + c) = (hh4){(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
+    }
+  }
+}
+
+__device__ __forceinline__ float4 ldg4(const float *base, unsigned off, int nt) {
+  return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + off + nt * 64);
+}
+__device__ __forceinline__ void stg4(float *base, unsigned off, int nt, float4 v) {
+  *reinterpret_cast<float4 *>(reinterpret_cast<char *>(base) + off + nt * 64) = v;
+}
+__device__ __forceinline__ void stg4h(_Float16 *base, unsigned off_f32, int nt, float4 v) {   // fp16 row of the same shape
+  *reinterpret_cast<hh4 *>(reinterpret_cast<char *>(base) + (off_f32 >> 1) + nt * 32) =
+      (hh4){(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+}
+
+// byte offsets (fp32 rows of 384) of this lane's first column in every row tile + the mask of live rows
+template <int NMT>
+__device__ __forceinline__ unsigned big_row_offsets(unsigned (&ro)[NMT], int row0, int col0, int q, int j, int E) {
+  unsigned live = 0;
+#pragma unroll
+  for (int mt = 0; mt < NMT; mt++) {
+    const int row = row0 + mt * 16 + j;
+    ro[mt] = (unsigned)(min(row, E - 1) * MD + col0 + 4 * q) * 4u;
+    if (row < E) live |= 1u << mt;
+  }
+  return live;
+}
+
+// ------------------------------------------------------------------ c1 / c2 (big tile)
+template <int NMT, int NW>
+__global__ void __launch_bounds__(64 * NW, NW / 4) upd_nbr_big_kernel(const NbrParams p) {
+  constexpr int NTW = 24 / NW, ROWS = 16 * NMT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  _Float16 *Xs = reinterpret_cast<_Float16 *>(smem_raw);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
+  const int row0 = blockIdx.x * ROWS;
+  const int col0 = wave * (16 * NTW);
+  // gather: wave w stages rows w, w + NW, ... (lane l: channels 2l + 128k): 512-byte contiguous reads
+  for (int r = wave; r < ROWS; r += NW) {
+    float2 v[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) v[k] = make_float2(0.f, 0.f);
+    if (row0 + r < p.E) {
+      const long src = p.idx[row0 + r];
+      if (src >= 0) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) v[k] = *reinterpret_cast<const float2 *>(p.net_in + (size_t)src * MD + 2 * lane + 128 * k);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+      *reinterpret_cast<h2 *>(Xs + r * MXS + 2 * lane + 128 * k) = (h2){(_Float16)v[k].x, (_Float16)v[k].y};
+  }
+  unsigned ro[NMT];
+  const unsigned live = big_row_offsets<NMT>(ro, row0, col0, q, j, p.E);
+  __syncthreads();
+  f4 acc[NMT][NTW];
+  big_zero<NMT, NTW>(acc);
+  big_gemm<NMT, NTW>(Xs, p.wa, MKS, 0, wave, lane, acc);
+  __syncthreads();                                       // every wave is past its reads of x
+  big_store_tile<NMT, NTW, true>(Xs, acc, p.ba, col0, q, j);
+  __syncthreads();
+  big_zero<NMT, NTW>(acc);
+  big_gemm<NMT, NTW>(Xs, p.wb, MKS, 0, wave, lane, acc);
+  float4 bv[NTW];
+#pragma unroll
+  for (int nt = 0; nt < NTW; nt++) bv[nt] = *reinterpret_cast<const float4 *>(p.bb + col0 + nt * 16 + 4 * q);
+#pragma unroll
+  for (int mt = 0; mt < NMT; mt++) {
+    float4 x[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; nt++) x[nt] = ldg4(p.net_in, ro[mt], nt);
+    if (!((live >> mt) & 1)) continue;
+#pragma unroll
+    for (int nt = 0; nt < NTW; nt++) {
+      const float4 o = make_float4(x[nt].x + h_round(acc[mt][nt][0] + bv[nt].x), x[nt].y + h_round(acc[mt][nt][1] + bv[nt].y),
+                                   x[nt].z + h_round(acc[mt][nt][2] + bv[nt].z), x[nt].w + h_round(acc[mt][nt][3] + bv[nt].w));
+      stg4(p.net_out, ro[mt], nt, o);
+      if (p.out_t) stg4h(p.out_t, ro[mt], nt, o);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ SoftAgg [f | g] (big tile)
+template <int NMT, int NW>
+__global__ void __launch_bounds__(64 * NW, NW / 4) upd_fg_big_kernel(const FgParams p) {
+  constexpr int NTW = 24 / NW, ROWS = 16 * NMT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  _Float16 *Xs = reinterpret_cast<_Float16 *>(smem_raw);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
+  const int row0 = blockIdx.x * ROWS;
+  const int col0 = wave * (16 * NTW);
+  for (int r = wave; r < ROWS; r += NW) {
+    const int row = row0 + r;
+    float v[3][2];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { v[k][0] = 0.f; v[k][1] = 0.f; }
+    if (row < p.E) {                                     // wave-uniform
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const float2 a = *reinterpret_cast<const float2 *>(p.x32 + (size_t)row * MD + 2 * lane + 128 * k);
+        v[k][0] = a.x; v[k][1] = a.y;
+      }
+      if (p.add_t) {
+        const _Float16 *b = p.add_t + (size_t)p.add_idx[row] * MD;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          const h2 t = *reinterpret_cast<const h2 *>(b + 2 * lane + 128 * k);
+          v[k][0] += (float)t[0]; v[k][1] += (float)t[1];
+        }
+      }
+      if (p.x32_out) {
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+          *reinterpret_cast<float2 *>(p.x32_out + (size_t)row * MD + 2 * lane + 128 * k) = make_float2(v[k][0], v[k][1]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+      *reinterpret_cast<h2 *>(Xs + r * MXS + 2 * lane + 128 * k) = (h2){(_Float16)v[k][0], (_Float16)v[k][1]};
+  }
+  unsigned ro[NMT];
+  const unsigned live = big_row_offsets<NMT>(ro, row0, col0, q, j, p.E);
+  __syncthreads();
+#pragma unroll 1
+  for (int part = 0; part < 2; part++) {
+    f4 acc[NMT][NTW];
+    big_zero<NMT, NTW>(acc);
+    big_gemm<NMT, NTW>(Xs, part ? p.wg : p.wf, MKS, 0, wave, lane, acc);
+    const float *bias = part ? p.bg : p.bf;
+    _Float16 *dst = p.fg + part * MD;                      // rows of 768 halfs = 1536 B, like an fp32 row of 384
+    const unsigned cfix = (unsigned)(col0 + 4 * q) * 2u;   // ro counts the lane's first column in fp32 bytes; here halfs
+#pragma unroll
+    for (int nt = 0; nt < NTW; nt++) {
+      const float4 b = *reinterpret_cast<const float4 *>(bias + col0 + nt * 16 + 4 * q);
+#pragma unroll
+      for (int mt = 0; mt < NMT; mt++)
+        if ((live >> mt) & 1)
+          *reinterpret_cast<hh4 *>(reinterpret_cast<char *>(dst) + (ro[mt] - cfix) + nt * 32) =
+              (hh4){(_Float16)(acc[mt][nt][0] + b.x), (_Float16)(acc[mt][nt][1] + b.y),
+                    (_Float16)(acc[mt][nt][2] + b.z), (_Float16)(acc[mt][nt][3] + b.w)};
+    }
+  }
+}
+
+// row tiles per workgroup for E edges (0: the 64-row kernels -- small problems, or RAMP_UPD_BIG=0; 4..8 forces a tile
+// for A/B runs); `best`: the measured optimum of the chain at the bench size
+static int big_pick_nmt(int E, int best) {
+  static int mode = -1;
+  if (mode < 0) {
+    const char *e = getenv("RAMP_UPD_BIG");
+    mode = e ? atoi(e) : 1;
+  }
+  if (mode == 0 || E < 16384 || (long)E * MD * 4 >= (1l << 32)) return 0;
+  if (mode >= 4 && mode <= 8) return mode;
+  return best;
+}
+
+template <typename KernelT, typename ParamsT>
+static int big_launch(KernelT kernel, const ParamsT &p, int E, int nmt, int nw, bool with_red, hipStream_t st) {
+  const size_t lds = (size_t)16 * nmt * MXS * 2 + (with_red ? (size_t)2 * 16 * nmt * nw * 4 : 0);
+  if (hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return RAMP_ELAUNCH;
+  hipLaunchKernelGGL(kernel, dim3(ramp_cdiv(E, 16 * nmt)), dim3(64 * nw), lds, st, p);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+
+#define BIG_DISPATCH(KERNEL, NW, P, E, NMT, RED, ST)                                       \
+  switch (NMT) {                                                                             \
+    case 4: return big_launch(KERNEL<4, NW>, P, E, 4, NW, RED, ST);                          \
+    case 5: return big_launch(KERNEL<5, NW>, P, E, 5, NW, RED, ST);                          \
+    case 6: return big_launch(KERNEL<6, NW>, P, E, 6, NW, RED, ST);                          \
+    case 7: return big_launch(KERNEL<7, NW>, P, E, 7, NW, RED, ST);                          \
+    default: return big_launch(KERNEL<8, NW>, P, E, 8, NW, RED, ST);                         \
+  }
+
 extern "C" {
 
 size_t ramp_upd_mlp_lds_bytes(void) { return (size_t)2 * MBM * MXS * 2; }
@@ -691,6 +949,7 @@ int ramp_upd_nbr(const float *net_in, const int64_t *idx, const void *wa, const 
   NbrParams p;
   p.net_in = net_in; p.idx = idx; p.wa = (const _Float16 *)wa; p.wb = (const _Float16 *)wb; p.ba = ba; p.bb = bb;
   p.net_out = net_out; p.out_t = (_Float16 *)out_t; p.E = E;
+  if (const int nmt = big_pick_nmt(E, 5)) { BIG_DISPATCH(upd_nbr_big_kernel, 8, p, E, nmt, false, (hipStream_t)stream) }
   const size_t lds = (size_t)MBM * MXS * 2;          // one tile (see the kernel)
   static bool attr_set = false;
   if (!attr_set) {
@@ -753,6 +1012,7 @@ int ramp_upd_fg(const float *x32, const void *add_t, const int32_t *add_idx, flo
   FgParams p;
   p.x32 = x32; p.add_t = (const _Float16 *)add_t; p.add_idx = add_idx; p.x32_out = x32_out;
   p.wf = (const _Float16 *)wf; p.wg = (const _Float16 *)wg; p.bf = bf; p.bg = bg; p.fg = (_Float16 *)fg; p.E = E;
+  if (const int nmt = big_pick_nmt(E, 6)) { BIG_DISPATCH(upd_fg_big_kernel, 8, p, E, nmt, false, (hipStream_t)stream) }
   const size_t lds = (size_t)MBM * MXS * 2;
   hipLaunchKernelGGL(upd_fg_kernel, dim3(ramp_cdiv(E, MBM)), dim3(64 * MWAVES), lds, (hipStream_t)stream, p);
   RAMP_CHECK_LAUNCH();
