@@ -336,8 +336,8 @@ PARITY_W_BIAS = -14.0   # see parity_block()
 
 def _cpu_tracker(state, args, cfg_kwargs, **net_kw):
     """the CPU oracle backend's tracker loaded with a state snapshot (inside cpu_oracle_ops())"""
+    from oracle.backend_cpu import Ramp_vo
     from rampvo_amd.config import make_cfg
-    from rampvo_amd.Ramp_vo import Ramp_vo
     from rampvo_amd.synthetic import make_network
     cfg_kwargs = dict(cfg_kwargs, MIXED_PRECISION=False)       # the host path is fp32 throughout
     state = dict(state)

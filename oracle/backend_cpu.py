@@ -123,13 +123,27 @@ _NAMES = ("patchify", "corr", "se3_unary", "se3_binary", "transform", "reproject
 
 @contextlib.contextmanager
 def cpu_oracle_ops():
-    """temporarily serve rampvo_amd.ops from the CPU oracle (tests / cpu_baseline only)"""
+    """temporarily serve rampvo_amd.ops from the CPU oracle and the network modules' forwards from their plain-PyTorch
+    restatements (oracle/host_cpu.py) -- tests / cpu_baseline only"""
     import rampvo_amd.ops as ops
+    from oracle import host_cpu
     saved = {n: getattr(ops, n) for n in _NAMES}
+    patches = host_cpu.module_patches()
+    saved_mod = [(c, a, c.__dict__[a]) for c, a, _ in patches]
     try:
         for n in _NAMES:
             setattr(ops, n, globals()[n])
+        for c, a, f in patches:
+            setattr(c, a, f)
         yield
     finally:
         for n, f in saved.items():
             setattr(ops, n, f)
+        for c, a, f in saved_mod:
+            setattr(c, a, f)
+
+
+def Ramp_vo(cfg, network, train_cfg, ht=480, wd=640, device="cpu"):
+    """the oracle-side tracker (rampvo_amd.Ramp_vo with its device steps served by the oracle)"""
+    from oracle.host_cpu import RampVoCPU
+    return RampVoCPU(cfg, network, train_cfg, ht=ht, wd=wd, device=device)

@@ -31,7 +31,7 @@ from ._lib import RAMP_NHWC, RAMP_NHWC8
 from .update_fused import CORR_ROW
 from .lietorch import SE3
 from .net import GraphPlan, VONet
-from .utils import Timer, filter_features, preprocess_input
+from .utils import Timer, preprocess_input
 
 
 class Ramp_vo:
@@ -41,6 +41,8 @@ class Ramp_vo:
         self.train_cfg = train_cfg
         self.device = torch.device(device)
         dev = self.device
+        if dev.type != "cuda" and not getattr(self, "_allow_cpu", False):
+            raise RuntimeError("rampvo_amd.Ramp_vo runs on the GPU only (HIP kernels, no CPU fallback); got device %s" % dev)
 
         self.lmbda = torch.as_tensor([1e-4], device=dev)
         self.load_weights(network)
@@ -77,8 +79,7 @@ class Ramp_vo:
         self.gmap_ = torch.zeros(self.mem, self.M, self.P, self.P, 128, **kwargs)
         # fp16 pyramid on the GPU: [h][C/8][w][8] slots (csrc/altcorr.hip, the MFMA kernel's target
         # layout); otherwise plain channels-last
-        self._chunked = (dev.type == "cuda" and self.dtype == torch.half and ops.pyramid_pack_supported(h, w)
-                         and (h // 4) > 0 and (w // 4) > 0)
+        self._chunked, self._lazy_net = self._layout_flags(h, w)
         if self._chunked:
             self.fmap1_ = torch.zeros(self.mem, h, 16, w, 8, **kwargs)
             self.fmap2_ = torch.zeros(self.mem, h // 4, 16, w // 4, 8, **kwargs)
@@ -87,12 +88,10 @@ class Ramp_vo:
             self.fmap2_ = torch.zeros(self.mem, h // 4, w // 4, 128, **kwargs)
         self.pyramid = (self.fmap1_, self.fmap2_)
 
-        self._lazy_net = dev.type == "cuda"      # GPU: the [E,384] state is re-indexed, not copied, when the graph changes
         self._net_map = None                     # host int64 [E]: row of _net_buf per current edge (-1: zeros)
         self._net_map_dev = None
         self._ixm = None
         self._pre_cache = None                   # the next frame's graph (host + device arrays, plan), prepared by keyframe()
-        self._up_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         # Frame pipelining (GPU, opt-in): when the caller guarantees that the tensors it hands to __call__ are
         # complete (not still being produced on the current stream), the keyframe decision of frame t is left
         # pending when __call__ returns, and frame t+1's front end -- which depends on nothing but the new input
@@ -117,13 +116,9 @@ class Ramp_vo:
         self._cur_stream = None
         self._fe_pool = None
         self._corr_levels = None
-        self._fe_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._fe_free = None
         self._ba_event = None
-        # events are re-recorded every frame (creating one costs a hipEventCreate/Destroy pair per use)
-        mk = (lambda: torch.cuda.Event()) if dev.type == "cuda" else (lambda: None)
-        self._ev_done, self._ev_fe_done, self._ev_fe_free, self._ev_ba, self._ev_up = mk(), mk(), mk(), mk(), mk()
-        self._mm_host = torch.empty(2, dtype=torch.float32).pin_memory() if dev.type == "cuda" else None
+        self._init_streams(dev)
         self.net = torch.zeros(1, 0, DIM, dtype=torch.float, device=dev)   # hidden state is fp32 (as under autocast)
         self.ii = torch.zeros(0, dtype=torch.long, device=dev)
         self.jj = torch.zeros(0, dtype=torch.long, device=dev)
@@ -141,6 +136,32 @@ class Ramp_vo:
         self._ba_info = torch.zeros(1, dtype=torch.int32, device=dev)
         self._last_K = self._last_K_raw = None     # last intrinsics written to a row of intrinsics_, and which row
         self._last_K_row = -1
+
+    def close(self):
+        """release the helper thread of the pipelined mode (also called when the tracker is collected)"""
+        pool, self._fe_pool = getattr(self, "_fe_pool", None), None
+        if pool is not None:
+            pool.shutdown(wait=True)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _layout_flags(self, h, w):
+        """(fp16 pyramid in the MFMA correlation kernel's [h][C/8][w][8] slots, lazy hidden-state row map: the [E,384]
+        state is re-indexed, not copied, when the graph changes)"""
+        chunked = self.dtype == torch.half and ops.pyramid_pack_supported(h, w) and (h // 4) > 0 and (w // 4) > 0
+        return chunked, True
+
+    def _init_streams(self, dev):
+        self._up_stream = torch.cuda.Stream(device=dev)
+        self._fe_stream = torch.cuda.Stream(device=dev)
+        # events are re-recorded every frame (creating one costs a hipEventCreate/Destroy pair per use)
+        mk = lambda: torch.cuda.Event()
+        self._ev_done, self._ev_fe_done, self._ev_fe_free, self._ev_ba, self._ev_up = mk(), mk(), mk(), mk(), mk()
+        self._mm_host = torch.empty(2, dtype=torch.float32).pin_memory()
 
     # ------------------------------------------------------------------ weights
     def load_weights(self, network):
@@ -303,17 +324,12 @@ class Ramp_vo:
             # the tracker's own per-frame call: same launch as below without the generic wrapper's checks (the
             # level descriptors of the fixed pyramid buffers are built once)
             return self._corr_launch(coords, ii, jj, order)
-        if self.device.type == "cuda":
-            # ring-buffer slots (kk % (M*mem), jj % mem) are taken inside the kernel; fp16: rows padded 882 -> 896
-            # (16-byte aligned rows for the first Linear layer, update_fused.py)
-            return altcorr.corr_pyramid(self.gmap_.view(-1, 3, 3, 128), self.pyramid, coords[0], ii, jj, 3, (1, 4),
-                                        RAMP_NHWC8 if self._chunked else RAMP_NHWC, order=order,
-                                        row_elems=CORR_ROW if self.dtype == torch.half else 0,
-                                        mod_ii=self.M * self.mem, mod_jj=self.mem)
-        ii1 = ii % (self.M * self.mem)
-        jj1 = jj % self.mem
-        return altcorr.corr_pyramid(self.gmap_.view(-1, 3, 3, 128), self.pyramid, coords[0], ii1, jj1, 3,
-                                    (1, 4), RAMP_NHWC, order=order)
+        # ring-buffer slots (kk % (M*mem), jj % mem) are taken inside the kernel; fp16: rows padded 882 -> 896
+        # (16-byte aligned rows for the first Linear layer, update_fused.py)
+        return altcorr.corr_pyramid(self.gmap_.view(-1, 3, 3, 128), self.pyramid, coords[0], ii, jj, 3, (1, 4),
+                                    RAMP_NHWC8 if self._chunked else RAMP_NHWC, order=order,
+                                    row_elems=CORR_ROW if self.dtype == torch.half else 0,
+                                    mod_ii=self.M * self.mem, mod_jj=self.mem)
 
     def _corr_launch(self, coords, ii, jj, order):
         """ramp_corr_fwd_ordered on the tracker's own buffers (fp16 chunked pyramid, padded rows)"""
@@ -331,7 +347,7 @@ class Ramp_vo:
         return out.view(1, E, CORR_ROW)
 
     def reproject(self, indicies=None, poses=None, patches=None, intrinsics=None):
-        if indicies is None and poses is None and patches is None and intrinsics is None and self.device.type == "cuda":
+        if indicies is None and poses is None and patches is None and intrinsics is None:
             # the tracker's own per-frame call on its own (contiguous fp32) buffers and graph
             E = self.ii.shape[0]
             out = torch.empty((1, E, 2, self.P, self.P), dtype=torch.float32, device=self.device)
@@ -480,59 +496,11 @@ class Ramp_vo:
         ii = kk // self.M
         coords = self.reproject(indicies=(ii, jj, kk))
         corr = self.corr(coords, indicies=(kk, jj)).to(self.dtype)
-        if self.device.type == "cuda":
-            fu = self.network.update.fused(self.dtype)
-            from .net import GraphPlan
-            plan = GraphPlan.build(ii, jj, kk, kk_bound=self.N * self.M, jj_bound=self.N, max_kk=self.M, max_ij=1)
-            _, relu_t = fu.hidden(None, self.imap_.view(-1, self.DIM), kk, self.M * self.mem, corr[0], plan)
-            delta = fu.heads(relu_t)[None, :, :2]
-        else:
-            net = torch.zeros(1, len(ii), self.DIM, dtype=torch.float, device=self.device)
-            ctx = self.imap[:, kk % (self.M * self.mem)]
-            net, (delta, weight, _) = self.network.update(net, ctx, corr, None, ii, jj, kk)
+        fu = self.network.update.fused(self.dtype)
+        plan = GraphPlan.build(ii, jj, kk, kk_bound=self.N * self.M, jj_bound=self.N, max_kk=self.M, max_ij=1)
+        _, relu_t = fu.hidden(None, self.imap_.view(-1, self.DIM), kk, self.M * self.mem, corr[0], plan)
+        delta = fu.heads(relu_t)[None, :, :2]
         return torch.quantile(delta.norm(dim=-1).float(), 0.5)
-
-    def _motionmag_pair(self, i, j):
-        """0.5*(motionmag(i,j) + motionmag(j,i)) (reference :227-243).  GPU: one fused kernel over the
-        pair grouping of the current graph plan + one read-back (the frame's only sync)."""
-        if self.device.type == "cuda":
-            plan = self._graph_plan()
-            mm = ops.motionmag(self.poses, self.patches, self.intrinsics, self.ii, self.jj, self.kk, plan.g_ij,
-                               j * plan.pair_mul + i, i * plan.pair_mul + j, beta=0.5)   # keys are jj*mul+ii
-            return float(mm.mean().item())
-        mags = []
-        for a, b in ((i, j), (j, i)):
-            sel = np.nonzero((self._ii == a) & (self._jj == b))[0]
-            if len(sel) == 0:
-                mags.append(torch.full((), float("nan"), device=self.device))
-                continue
-            s = self._upload(sel)
-            flow = pops.flow_mag(self.poses, self.patches, self.intrinsics, self.ii[s], self.jj[s], self.kk[s],
-                                 beta=0.5)
-            mags.append(flow.mean())
-        return float(((mags[0] + mags[1]) / 2).item())
-
-    def _graph_edit(self, remove_kf):
-        """host-side result of keyframe() for one outcome of the motion test (reference :247-274): the
-        graph after dropping keyframe n-KEYFRAME_INDEX (if remove_kf) and culling factors older than
-        REMOVAL_WINDOW.  Pure function of the host mirror."""
-        ii, jj, kk = self._ii, self._jj, self._kk
-        keep = np.ones(len(ii), bool)
-        n = self.n
-        if remove_kf:
-            k = self.n - self.cfg.KEYFRAME_INDEX
-            keep &= ~((ii == k) | (jj == k))
-            ii, jj, kk = ii.copy(), jj.copy(), kk.copy()
-            kk[ii > k] -= self.M
-            ii[ii > k] -= 1
-            jj[jj > k] -= 1
-            n -= 1
-        keep &= ~((kk // self.M) < n - self.cfg.REMOVAL_WINDOW)
-        changed = remove_kf or not keep.all()
-        idx = np.nonzero(keep)[0] if changed else None
-        if changed:
-            ii, jj, kk = ii[idx], jj[idx], kk[idx]
-        return dict(changed=changed, ii=ii, jj=jj, kk=kk, idx=idx, n=n)
 
     def _apply_removal(self, k):
         """device side of dropping keyframe k: shift the per-frame state down by one row"""
@@ -540,7 +508,7 @@ class Ramp_vo:
         del self._tstamps[k]
         if self._last_K_row > k:
             self._last_K_row -= 1
-        if self.device.type == "cuda" and (self.M * 3) % 4 == 0:
+        if (self.M * 3) % 4 == 0:
             if self._shift_plan is None:
                 self._shift_plan = ops.ShiftPlan([(self.tstamps_, 0), (self.colors_, 0), (self.poses_, 0),
                                                   (self.patches_, 0), (self.intrinsics_, 0), (self.imap_, self.mem),
@@ -562,30 +530,7 @@ class Ramp_vo:
         than REMOVAL_WINDOW (reference :237-274).  Both removals are decided on the host mirror and
         applied to the device state as ONE compaction."""
         self.settle()
-        if self.device.type == "cuda" and self._lazy_net:
-            return self._keyframe_speculative()
-        i = self.n - self.cfg.KEYFRAME_INDEX - 1
-        j = self.n - self.cfg.KEYFRAME_INDEX + 1
-        m = self._motionmag_pair(i, j)
-        remove = m < self.cfg.KEYFRAME_THRESH
-        if remove:
-            k = self.n - self.cfg.KEYFRAME_INDEX
-            t0, t1 = self._tstamps[k - 1], self._tstamps[k]
-            dP = SE3(self.poses_[k]) * SE3(self.poses_[k - 1]).inv()
-            self.delta[t1] = (t0, dP)
-        ed = self._graph_edit(remove)
-        if remove:
-            self._apply_removal(self.n - self.cfg.KEYFRAME_INDEX)
-        if not ed["changed"]:
-            return
-        idx = ed["idx"]
-        self._ii, self._jj, self._kk = ed["ii"], ed["jj"], ed["kk"]
-        self.ii, self.jj, self.kk = self._upload(self._ii), self._upload(self._jj), self._upload(self._kk)
-        if self._lazy_net:
-            self._net_map, self._net_map_dev = self._net_rows()[idx], None
-        elif len(idx) != self.net.shape[1]:
-            self.net = self.net[:, self._upload(idx)]
-        self._plan = None
+        return self._keyframe_speculative()
 
     def _keyframe_speculative(self):
         """GPU: the motion test is the frame's only device->host read, and at that point the GPU still has
@@ -744,35 +689,27 @@ class Ramp_vo:
         with Timer("other", enabled=self.enable_timing):
             plan = self._graph_plan()
             coords = self.reproject()
-            order = plan.g_ij.order if (self.device.type == "cuda" and os.environ.get("RAMP_CORR_ORDER", "1") == "1") else None
+            order = plan.g_ij.order if os.environ.get("RAMP_CORR_ORDER", "1") == "1" else None
             corr = self.corr(coords, order=order).to(self.dtype)
-            if self.device.type == "cuda":
-                # GEMMs + row-fused glue (csrc/update.hip); the context gather, the heads' activations,
-                # `target = centre + delta` and filter_features are folded into those kernels
-                fu = self.network.update.fused(self.dtype)
-                fe_at = os.environ.get("RAMP_FE_AT", "gru")    # where the next front end may start (ba|gru|softagg|nbr)
-                fu.before_gru = self._mark_fe_start if (self.inputs_ready and fe_at != "ba") else None
-                fu.hook_at = fe_at
-                net_map = None
-                if self._net_map is not None:
-                    net_map = self._net_map_dev if self._net_map_dev is not None else self._upload(self._net_map)
-                out32, relu_t = fu.hidden(self._net_buf[0], self.imap_.view(-1, self.DIM), self.kk, self.M * self.mem,
-                                          corr[0], plan, net_map=net_map)
-                self.net = out32[None]
-                tw = fu.heads_target_weight(relu_t, coords[0], self.wd // 4, self.ht // 4)
-                if tw is not None:
-                    target, weight = tw
-                else:
-                    target, weight, _ = fu.target_weight(fu.heads(relu_t), coords[0], self.wd // 4, self.ht // 4)
+            # GEMMs + row-fused glue (csrc/update.hip); the context gather, the heads' activations,
+            # `target = centre + delta` and filter_features are folded into those kernels
+            fu = self.network.update.fused(self.dtype)
+            fe_at = os.environ.get("RAMP_FE_AT", "gru")    # where the next front end may start (ba|gru|softagg|nbr)
+            fu.before_gru = self._mark_fe_start if (self.inputs_ready and fe_at != "ba") else None
+            fu.hook_at = fe_at
+            net_map = None
+            if self._net_map is not None:
+                net_map = self._net_map_dev if self._net_map_dev is not None else self._upload(self._net_map)
+            out32, relu_t = fu.hidden(self._net_buf[0], self.imap_.view(-1, self.DIM), self.kk, self.M * self.mem,
+                                      corr[0], plan, net_map=net_map)
+            self.net = out32[None]
+            tw = fu.heads_target_weight(relu_t, coords[0], self.wd // 4, self.ht // 4)
+            if tw is not None:
+                target, weight = tw
             else:
-                ctx = self.imap[:, self.kk % (self.M * self.mem)]
-                self.net, (delta, weight, _) = self.network.update(self.net, ctx, corr, None, self.ii, self.jj,
-                                                                   self.kk, plan=plan)
-                weight = weight.float()
-                target = coords[..., self.P // 2, self.P // 2] + delta.float()
-                weight = filter_features(confidences=weight, target=target, data_shape=(self.ht // 4, self.wd // 4))
+                target, weight, _ = fu.target_weight(fu.heads(relu_t), coords[0], self.wd // 4, self.ht // 4)
             self.last_weight = weight
-            if self.inputs_ready and self.device.type == "cuda" and fe_at == "ba":
+            if self.inputs_ready and fe_at == "ba":
                 # the next frame's front end may start here, next to BA's small kernels (default: one kernel
                 # earlier, at the gru chain -- measured 1.43 vs 1.46 ms per step; earlier than that it costs the
                 # bandwidth-bound update kernels more than it hides)
@@ -783,8 +720,7 @@ class Ramp_vo:
             t0 = max(t0, 1)
             try:
                 fastba.BA(self.poses, self.patches, self.intrinsics, target, weight, self.lmbda, self.ii, self.jj,
-                          self.kk, t0, self.n, M=self.M, iterations=2, eff_impl=False, info=self._ba_info,
-                          plan=plan if self.device.type == "cuda" else None)
+                          self.kk, t0, self.n, M=self.M, iterations=2, eff_impl=False, info=self._ba_info, plan=plan)
             except Exception as e:  # same recovery as the reference (:302-306)
                 print(f"WARNING: BA failed...{e}")
             if self._ixm is None or self._ixm.shape[0] < self.m:
@@ -798,11 +734,14 @@ class Ramp_vo:
         """track a new frame"""
         input_ = preprocess_input(input_tensor=input_tensor)
         with torch.no_grad():
-            self._cur_stream = torch.cuda.current_stream() if self.device.type == "cuda" else None
+            self._cur_stream = self._current_stream()
             try:
                 return self._track(tstamp, input_, intrinsics)
             finally:
                 self._cur_stream = None
+
+    def _current_stream(self):
+        return torch.cuda.current_stream()
 
     def _track(self, tstamp, input_, intrinsics):
         mask = input_[2]
@@ -840,7 +779,7 @@ class Ramp_vo:
             if job is not None:
                 fmap, gmap, imap, patches, _, clr = job.result()
             cur.wait_event(fe_done)
-        pre = self._prefetch_edges() if (accepts and self.device.type == "cuda") else None
+        pre = self._prefetch_edges() if accepts else None
         # intrinsics at feature resolution; the usual case (same values as the previous frame, CPU fp32 tensor)
         # is recognised without building new arrays
         k_dev = None
@@ -872,7 +811,7 @@ class Ramp_vo:
         self._tstamps.append(self.counter)
         ex = getattr(self.network.patchify, "_extra", None)
         slot = n % self.mem
-        if (self.device.type == "cuda" and ex is not None and ex["fmap"].dtype == self.dtype
+        if (ex is not None and ex["fmap"].dtype == self.dtype
                 and ex["chunked"] == self._chunked and (self.M * 3) % 16 == 0 and patches.is_contiguous()
                 and patches.dtype == torch.float32 and ops.depth_median_supported(3, self.M, self.P)
                 and (not self.is_initialized or n >= 3)
@@ -894,7 +833,7 @@ class Ramp_vo:
         else:
             self._frame_stores_stepwise(n, slot, k_dev, kq, patches, imap, gmap, fmap, clr, ex)
         self._last_K_row = n                         # row n now holds _last_K (written or copied from row n-1)
-        if self.inputs_ready and self.device.type == "cuda":
+        if self.inputs_ready:
             self._fe_free = self._ev_fe_free
             self._fe_free.record()
         self.counter += 1
@@ -1003,46 +942,26 @@ class Ramp_vo:
         self.tstamps_[self.n] = 0
 
     def _frame_stores_stepwise(self, n, slot, k_dev, kq, patches, imap, gmap, fmap, clr, ex):
-        """the same writes as ops.frame_commit, one step at a time (CPU oracle backend, first frames, odd shapes)"""
-        if self.device.type == "cuda":
-            # time stamp, index map, intrinsics row and motion-model pose: one launch
-            copy_k = k_dev is None and n > 0
-            if not copy_k:
-                self.intrinsics_[n] = k_dev if k_dev is not None else self._upload(kq.astype(np.float32))
-                self._last_K, self._last_K_raw = kq, self._K_raw_now
-            motion = 0 if n <= 1 else (1 if self.cfg.MOTION_MODEL == 'DAMPED_LINEAR' else 2)
-            ops.frame_begin(self.poses_, n, motion, self.cfg.MOTION_DAMPING, self.tstamps_, self.counter,
-                            self.index_map_, self.m + self.M, self.intrinsics_, copy_k)
-        else:
-            self.tstamps_[n].fill_(self.counter)
-            self.index_map_[n + 1].fill_(self.m + self.M)
-            if k_dev is None and n > 0:
-                self.intrinsics_[n] = self.intrinsics_[n - 1]     # unchanged intrinsics: device-side row copy
-            else:
-                self.intrinsics_[n] = k_dev if k_dev is not None else self._upload(kq.astype(np.float32))
-                self._last_K, self._last_K_raw = kq, self._K_raw_now
-            if n > 1:
-                if self.cfg.MOTION_MODEL == 'DAMPED_LINEAR':
-                    P1 = SE3(self.poses_[n - 1])
-                    P2 = SE3(self.poses_[n - 2])
-                    xi = self.cfg.MOTION_DAMPING * (P1 * P2.inv()).log()
-                    self.poses_[n] = (SE3.exp(xi) * P1).data
-                else:
-                    self.poses_[n] = self.poses_[n - 1]
-
+        """the same writes as ops.frame_commit, a few launches instead of one (first frames, odd shapes)"""
+        # time stamp, index map, intrinsics row and motion-model pose: one launch
+        copy_k = k_dev is None and n > 0
+        if not copy_k:
+            self.intrinsics_[n] = k_dev if k_dev is not None else self._upload(kq.astype(np.float32))
+            self._last_K, self._last_K_raw = kq, self._K_raw_now
+        motion = 0 if n <= 1 else (1 if self.cfg.MOTION_MODEL == 'DAMPED_LINEAR' else 2)
+        ops.frame_begin(self.poses_, n, motion, self.cfg.MOTION_DAMPING, self.tstamps_, self.counter,
+                        self.index_map_, self.m + self.M, self.intrinsics_, copy_k)
         # reference :369-372: random inverse depths, replaced by the median of the last three keyframes once the
         # tracker is initialised -- the draw is dead then and is not made (nothing else consumes the generator)
         if self.is_initialized:
-            if (self.device.type == "cuda" and patches.is_contiguous() and patches.dtype == torch.float32
-                    and ops.depth_median_supported(3, self.M, self.P)):
+            if patches.is_contiguous() and patches.dtype == torch.float32 and ops.depth_median_supported(3, self.M, self.P):
                 ops.depth_median_fill(self.patches_, n, 3, patches[0])       # radix select + fill, one launch
             else:
                 patches[:, :, 2] = torch.median(self.patches_[n - 3:n, :, 2])
         else:
             patches[:, :, 2] = self._initial_depth(patches)
-
-        if (ex is not None and self.device.type == "cuda" and ex["fmap"].dtype == self.dtype
-                and (self.M * 3) % 4 == 0 and patches.is_contiguous() and ex["chunked"] == self._chunked):
+        if (ex is not None and ex["fmap"].dtype == self.dtype and (self.M * 3) % 4 == 0 and patches.is_contiguous()
+                and ex["chunked"] == self._chunked):
             # one launch: patches, colours and the four feature tensors into their state rows / ring slots
             ops.store_rows([patches, ex["colors"], ex["imap"], ex["gmap"], ex["fmap"], ex["fmap2"]],
                            [(self.patches_, n), (self.colors_, n), (self.imap_, slot), (self.gmap_, slot),
@@ -1060,7 +979,6 @@ class Ramp_vo:
             else:
                 self.fmap1_[slot] = f[0].permute(1, 2, 0).to(self.dtype)
                 self.fmap2_[slot] = F.avg_pool2d(f, 4, 4)[0].permute(1, 2, 0).to(self.dtype)
-
 
     def _initial_depth(self, patches):
         """reference :369 -- torch.rand_like; overridable so parity tests can inject the

@@ -326,13 +326,50 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 // quarter-wave -- 16 neighbouring window pixels, same 8-channel chunk -- read one or two
 // contiguous runs instead of 16 cache lines 256 B apart.  The vector L1 looks up one line per
 // cycle, and with NHWC those lookups (64 per load instruction) were what the kernel waited on.
-template <bool CHUNKED>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CORR_WAVES, 8)))
-    corr_mfma_f16_kernel(const CorrParams prm) {
+// element-type traits of the MFMA correlation kernel below: fp16 -> v_mfma_f32_16x16x32_f16 (4 steps of 32 channels,
+// lane (q, .) supplies 8 channels per step); fp32 -> v_mfma_f32_16x16x4_f32 (exact fp32 products; the channel axis is
+// permuted so that ONE 16-byte load per lane feeds 4 MFMA steps on both operands: lane (q, .) of load g holds
+// channels 16 g + 4 q + t, t = 0..3, and step (g, t) contracts them: 32 MFMAs per group of 16 window pixels).
+// The fp32 variant is opt-in (dtype | RAMP_CORR_MFMA32): 2.1x faster than corr_kernel<float> (445 vs 940 us at E = 40k)
+// but its accumulation order is the MFMA's, not the reference kernel's channel-ordered fmaf chain that
+// corr_kernel<float> reproduces bit for bit -- so the exact-parity path stays the default.
+template <typename T> struct CorrMma;
+template <> struct CorrMma<_Float16> {
+  typedef f16x8_t frag;
+  static constexpr int STEPS = 4, PER = 8, PGB = CORR_PGB, WAVES = CORR_WAVES;
+  static __device__ __forceinline__ frag zero() { return (frag){0, 0, 0, 0, 0, 0, 0, 0}; }
+  static __device__ __forceinline__ f32x4_t mma(const frag &a, const frag &b, f32x4_t acc) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
+  }
+  static __device__ __forceinline__ void st(_Float16 *p, float v) { *p = (_Float16)v; }
+  static __device__ __forceinline__ void st2(_Float16 *p, float a, float b) {
+    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+    *reinterpret_cast<h2v *>(p) = (h2v){(_Float16)a, (_Float16)b};
+  }
+};
+template <> struct CorrMma<float> {
+  typedef f32x4_t frag;
+  static constexpr int STEPS = 8, PER = 4, PGB = 2, WAVES = 3;
+  static __device__ __forceinline__ frag zero() { return (frag){0.f, 0.f, 0.f, 0.f}; }
+  static __device__ __forceinline__ f32x4_t mma(const frag &a, const frag &b, f32x4_t acc) {
+#pragma unroll
+    for (int t4 = 0; t4 < 4; t4++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t4], b[t4], acc, 0, 0, 0);
+    return acc;
+  }
+  static __device__ __forceinline__ void st(float *p, float v) { *p = v; }
+  static __device__ __forceinline__ void st2(float *p, float a, float b) { *reinterpret_cast<float2 *>(p) = make_float2(a, b); }
+};
+
+template <typename T, bool CHUNKED>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CorrMma<T>::WAVES, 8)))
+    corr_mfma_kernel(const CorrParams prm) {
+  typedef CorrMma<T> M;
+  typedef typename M::frag frag_t;
+  constexpr int STEPS = M::STEPS, PER = M::PER;   // MFMA-operand loads per pixel, channels per lane and load
   constexpr int C = 128, PP = 9, R = 3, D = 8, d = 7;
   constexpr int NOUT = d * d * PP;           // 441 values per level
   constexpr int KOUT = d;                    // 7 per lane (lanes 0..62), held until both levels are done
-  constexpr int PGB = CORR_PGB;                   // pixel groups whose loads are in flight together
+  constexpr int PGB = M::PGB;                     // pixel groups whose loads are in flight together
   __shared__ __attribute__((aligned(16))) float Cs[PP * CORR_T];
   __shared__ float outs[NOUT];               // staging for the ragged (non-union) paths only
   __shared__ int s_ox[PP], s_oy[PP], s_live[PP];
@@ -345,13 +382,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CORR_WA
   const long j2 = prm.mod_jj > 0 ? prm.jj[e] % prm.mod_jj : prm.jj[e];
   const int L = prm.nlevels;
 
-  f16x8_t afrag[4];
+  frag_t afrag[STEPS];
   {
-    const _Float16 *src = reinterpret_cast<const _Float16 *>(prm.fmap1) + (size_t)i1 * C * PP;
+    const T *src = reinterpret_cast<const T *>(prm.fmap1) + (size_t)i1 * C * PP;
 #pragma unroll
-    for (int s = 0; s < 4; s++) {
-      if (j < PP) afrag[s] = *reinterpret_cast<const f16x8_t *>(src + j * C + 32 * s + 8 * q);
-      else afrag[s] = (f16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
+    for (int s = 0; s < STEPS; s++) {
+      if (j < PP) afrag[s] = *reinterpret_cast<const frag_t *>(src + j * C + 4 * PER * s + PER * q);
+      else afrag[s] = M::zero();
     }
   }
 
@@ -361,7 +398,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CORR_WA
   for (int lvl = 0; lvl < CORR_MAXLEV; lvl++) {
     if (lvl >= L) break;
     const int H2 = prm.H2[lvl], W2 = prm.W2[lvl];
-    const _Float16 *f2 = reinterpret_cast<const _Float16 *>(prm.fmap2[lvl]) + (size_t)j2 * C * H2 * W2;
+    const T *f2 = reinterpret_cast<const T *>(prm.fmap2[lvl]) + (size_t)j2 * C * H2 * W2;
     if (lane < PP) {
       const float cdv = prm.cdiv[lvl];
       const float x = prm.coords[((size_t)e * 2 + 0) * PP + lane] / cdv;
@@ -420,7 +457,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CORR_WA
       for (int pg0 = 0; pg0 < npg; pg0 += PGB) {
         // all PGB x 4 sixteen-byte loads of the batch are issued before the first MFMA waits on
         // one: the address is always a valid pixel, out-of-window lanes are zeroed afterwards
-        f16x8_t bfr[PGB][4];
+        frag_t bfr[PGB][STEPS];
         bool inb[PGB];
 #pragma unroll
         for (int u = 0; u < PGB; u++) {
@@ -429,20 +466,19 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CORR_WA
           const int px = gx0 + tx, py = gy0 + ty;
           inb[u] = (t < Tn) && px >= 0 && px < W2 && py >= 0 && py < H2;
           const int cy = inb[u] ? py : 0, cx = inb[u] ? px : 0;
-          // MFMA step s, quarter q <-> channels [32 s + 8 q, +8) = chunk 4 s + q
-          const _Float16 *pp = CHUNKED ? f2 + (((size_t)cy * (C / 8) + q) * W2 + cx) * 8
-                                       : f2 + ((size_t)cy * W2 + cx) * C + 8 * q;
-          const size_t sstride = CHUNKED ? (size_t)4 * W2 * 8 : 32;
+          // load s, quarter q <-> channels [4 PER s + PER q, + PER) (fp16: = chunk 4 s + q of the [h][C/8][w][8] layout)
+          const T *pp = CHUNKED ? f2 + (((size_t)cy * (C / 8) + q) * W2 + cx) * 8
+                                : f2 + ((size_t)cy * W2 + cx) * C + PER * q;
+          const size_t sstride = CHUNKED ? (size_t)4 * W2 * 8 : 4 * PER;
 #pragma unroll
-          for (int s = 0; s < 4; s++) bfr[u][s] = *reinterpret_cast<const f16x8_t *>(pp + s * sstride);
+          for (int s = 0; s < STEPS; s++) bfr[u][s] = *reinterpret_cast<const frag_t *>(pp + s * sstride);
         }
 #pragma unroll
         for (int u = 0; u < PGB; u++) {
           const int t = (pg0 + u) * 16 + j;
           f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int s = 0; s < 4; s++)
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag[s], bfr[u][s], acc, 0, 0, 0);
+          for (int s = 0; s < STEPS; s++) acc = M::mma(afrag[s], bfr[u][s], acc);
           // D: rows 4q..4q+3 = patch pixels, column j = union pixel t; an out-of-map pixel
           // contributes zeros (the loads above fetched a valid stand-in pixel for it)
           if (t < Tn) {
@@ -504,215 +540,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CORR_WA
     __syncthreads();
   }
   // out[e][o][lvl]: with two levels a lane's pair is one 4-byte store, consecutive over lanes
-  __half *op = reinterpret_cast<__half *>(prm.out) + (size_t)e * prm.row_elems;
-  for (int q = NOUT * L + lane; q < prm.row_elems; q += 64) op[q] = __float2half(0.0f);   // row padding
+  T *op = reinterpret_cast<T *>(prm.out) + (size_t)e * prm.row_elems;
+  for (int q = NOUT * L + lane; q < prm.row_elems; q += 64) M::st(op + q, 0.0f);   // row padding
   if (lane < 63) {
     if (L == 2) {
 #pragma unroll
       for (int k = 0; k < KOUT; k++)
-        reinterpret_cast<__half2 *>(op)[lane + 63 * k] =
-            __halves2half2(__float2half(res[0][k]), __float2half(res[1][k]));
+        M::st2(op + 2 * (lane + 63 * k), res[0][k], res[1][k]);
     } else {
 #pragma unroll
-      for (int k = 0; k < KOUT; k++) op[lane + 63 * k] = __float2half(res[0][k]);
-    }
-  }
-}
-
-// fp32 twin, opt-in (dtype | RAMP_CORR_MFMA32), plain NHWC maps: 2.1x faster than corr_kernel<float> (445 vs
-// 940 us at E = 40k) but its accumulation order is the MFMA's, not the reference kernel's channel-ordered
-// fmaf chain that corr_kernel<float> reproduces bit for bit -- so the exact-parity path stays the default.
-// The same structure on v_mfma_f32_16x16x4_f32 (exact
-// fp32 products, fp32 accumulate).  K = 4 per MFMA; the channel axis is permuted so that ONE 16-byte
-// load per lane feeds 4 MFMA steps on both operands: lane (q, .) of load g holds channels 16g + 4q + t,
-// t = 0..3, and step (g, t) contracts them.  32 MFMAs per group of 16 window pixels.
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8)))
-    corr_mfma_f32_kernel(const CorrParams prm) {
-  constexpr bool CHUNKED = false;
-  constexpr int C = 128, PP = 9, R = 3, D = 8, d = 7;
-  constexpr int NOUT = d * d * PP;           // 441 values per level
-  constexpr int KOUT = d;                    // 7 per lane (lanes 0..62), held until both levels are done
-  constexpr int PGB = 2;                          // pixel groups whose loads are in flight together
-  __shared__ __attribute__((aligned(16))) float Cs[PP * CORR_T];
-  __shared__ float outs[NOUT];               // staging for the ragged (non-union) paths only
-  __shared__ int s_ox[PP], s_oy[PP], s_live[PP];
-  __shared__ float s_dx[PP], s_dy[PP];
-
-  const int e = corr_edge_of_block(prm);
-  if (e < 0) return;
-  const int lane = threadIdx.x, q = lane >> 4, j = lane & 15;
-  const long i1 = prm.mod_ii > 0 ? prm.ii[e] % prm.mod_ii : prm.ii[e];   // ring-buffer slots (Ramp_vo.py:178-179)
-  const long j2 = prm.mod_jj > 0 ? prm.jj[e] % prm.mod_jj : prm.jj[e];
-  const int L = prm.nlevels;
-
-  f32x4_t afrag[8];
-  {
-    const float *src = reinterpret_cast<const float *>(prm.fmap1) + (size_t)i1 * C * PP;
-#pragma unroll
-    for (int s = 0; s < 8; s++) {
-      if (j < PP) afrag[s] = *reinterpret_cast<const f32x4_t *>(src + j * C + 16 * s + 4 * q);
-      else afrag[s] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    }
-  }
-
-  float res[CORR_MAXLEV][KOUT];
-  const int op_p = lane % PP, op_a = lane / PP;   // output ownership, see the union epilogue
-#pragma unroll
-  for (int lvl = 0; lvl < CORR_MAXLEV; lvl++) {
-    if (lvl >= L) break;
-    const int H2 = prm.H2[lvl], W2 = prm.W2[lvl];
-    const float *f2 = reinterpret_cast<const float *>(prm.fmap2[lvl]) + (size_t)j2 * C * H2 * W2;
-    if (lane < PP) {
-      const float cdv = prm.cdiv[lvl];
-      const float x = prm.coords[((size_t)e * 2 + 0) * PP + lane] / cdv;
-      const float y = prm.coords[((size_t)e * 2 + 1) * PP + lane] / cdv;
-      const float flx = floorf(x), fly = floorf(y);
-      const int ox = ramp_f2i(flx), oy = ramp_f2i(fly);
-      s_dx[lane] = x - flx;
-      s_dy[lane] = y - fly;
-      const bool live = ((long)ox - R < W2) && ((long)ox - R + D > 0) &&
-                        ((long)oy - R < H2) && ((long)oy - R + D > 0);
-      s_live[lane] = live ? 1 : 0;
-      s_ox[lane] = live ? ox - R : 0;
-      s_oy[lane] = live ? oy - R : 0;
-    }
-    __syncthreads();
-    int minx = 1 << 30, miny = 1 << 30, maxx = -(1 << 30), maxy = -(1 << 30), nlive = 0;
-#pragma unroll
-    for (int p = 0; p < PP; p++) {
-      if (s_live[p]) {
-        nlive++;
-        minx = min(minx, s_ox[p]); maxx = max(maxx, s_ox[p]);
-        miny = min(miny, s_oy[p]); maxy = max(maxy, s_oy[p]);
-      }
-    }
-    const long bw = (long)maxx - minx + D, bh = (long)maxy - miny + D;
-    const bool uni = (nlive > 0) && (bw * bh <= CORR_T);
-    const int ngroups = (nlive == 0) ? 0 : (uni ? 1 : PP);
-    if (nlive == 0) {
-      for (int o = lane; o < NOUT; o += 64) {
-        const int p = o % PP;
-        const float dx = s_dx[p], dy = s_dy[p];
-        float s = ((1 - dx) * (1 - dy)) * 0.0f;
-        s = s + (dx * (1 - dy)) * 0.0f;
-        s = s + ((1 - dx) * dy) * 0.0f;
-        s = s + (dx * dy) * 0.0f;
-        outs[o] = s;
-      }
-    }
-    for (int g = 0; g < ngroups; g++) {
-      if (!uni && !s_live[g]) {
-        for (int ab = lane; ab < d * d; ab += 64) {
-          const float dx = s_dx[g], dy = s_dy[g];
-          float s = ((1 - dx) * (1 - dy)) * 0.0f;
-          s = s + (dx * (1 - dy)) * 0.0f;
-          s = s + ((1 - dx) * dy) * 0.0f;
-          s = s + (dx * dy) * 0.0f;
-          outs[ab * PP + g] = s;
-        }
-        continue;
-      }
-      const int gx0 = uni ? minx : s_ox[g], gy0 = uni ? miny : s_oy[g];
-      const int gw = uni ? (int)bw : D, gh = uni ? (int)bh : D;
-      const int Tn = gw * gh;                      // <= CORR_T = 128
-      const int npg = (Tn + 15) / 16;
-      const int inv_gw = (65536 + gw - 1) / gw;    // t / gw == (t * inv_gw) >> 16 for t < 128, gw <= 128
-      for (int pg0 = 0; pg0 < npg; pg0 += PGB) {
-        // all PGB x 4 sixteen-byte loads of the batch are issued before the first MFMA waits on
-        // one: the address is always a valid pixel, out-of-window lanes are zeroed afterwards
-        f32x4_t bfr[PGB][8];
-        bool inb[PGB];
-#pragma unroll
-        for (int u = 0; u < PGB; u++) {
-          const int t = (pg0 + u) * 16 + j;
-          const int ty = (t * inv_gw) >> 16, tx = t - ty * gw;
-          const int px = gx0 + tx, py = gy0 + ty;
-          inb[u] = (t < Tn) && px >= 0 && px < W2 && py >= 0 && py < H2;
-          const int cy = inb[u] ? py : 0, cx = inb[u] ? px : 0;
-          const float *pp = f2 + ((size_t)cy * W2 + cx) * C + 4 * q;
-#pragma unroll
-          for (int s = 0; s < 8; s++) bfr[u][s] = *reinterpret_cast<const f32x4_t *>(pp + 16 * s);
-        }
-#pragma unroll
-        for (int u = 0; u < PGB; u++) {
-          const int t = (pg0 + u) * 16 + j;
-          f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int s = 0; s < 8; s++)
-#pragma unroll
-            for (int t4 = 0; t4 < 4; t4++)
-              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[s][t4], bfr[u][s][t4], acc, 0, 0, 0);
-          // D: rows 4q..4q+3 = patch pixels, column j = union pixel t; an out-of-map pixel
-          // contributes zeros (the loads above fetched a valid stand-in pixel for it)
-          if (t < Tn) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-              const int p = 4 * q + r;
-              if (p < PP) Cs[p * CORR_T + t] = inb[u] ? acc[r] : 0.0f;
-            }
-          }
-        }
-      }
-      __syncthreads();
-      if (uni) {
-        // lane = 9 a + p owns output row a of patch pixel p; its 7 outputs (b = 0..6) are
-        // o = (7 b + a) 9 + p = lane + 63 b and need two 8-wide rows of Cs
-        if (lane < 63) {
-          float r0[D], r1[D];
-          if (s_live[op_p]) {
-            const float *row = &Cs[op_p * CORR_T + (s_oy[op_p] - gy0 + op_a) * gw + (s_ox[op_p] - gx0)];
-#pragma unroll
-            for (int b = 0; b < D; b++) { r0[b] = row[b]; r1[b] = row[gw + b]; }
-          } else {
-#pragma unroll
-            for (int b = 0; b < D; b++) { r0[b] = 0.f; r1[b] = 0.f; }
-          }
-          const float dx = s_dx[op_p], dy = s_dy[op_p];
-#pragma unroll
-          for (int b = 0; b < d; b++) {
-            float s = ((1 - dx) * (1 - dy)) * r0[b];
-            s = s + (dx * (1 - dy)) * r0[b + 1];
-            s = s + ((1 - dx) * dy) * r1[b];
-            s = s + (dx * dy) * r1[b + 1];
-            res[lvl][b] = s;
-          }
-        }
-      } else {
-        for (int ab = lane; ab < d * d; ab += 64) {
-          const int b = ab / d, a = ab - b * d;
-          const int wx = s_ox[g] - gx0 + b, wy = s_oy[g] - gy0 + a;
-          const float *row = &Cs[g * CORR_T + wy * gw + wx];
-          const float c00 = row[0], c01 = row[1], c10 = row[gw], c11 = row[gw + 1];
-          const float dx = s_dx[g], dy = s_dy[g];
-          float s = ((1 - dx) * (1 - dy)) * c00;
-          s = s + (dx * (1 - dy)) * c01;
-          s = s + ((1 - dx) * dy) * c10;
-          s = s + (dx * dy) * c11;
-          outs[ab * PP + g] = s;
-        }
-      }
-      __syncthreads();
-    }
-    if (!uni) {
-      __syncthreads();
-      if (lane < 63) {
-#pragma unroll
-        for (int k = 0; k < KOUT; k++) res[lvl][k] = outs[lane + 63 * k];
-      }
-    }
-    __syncthreads();
-  }
-  // out[e][o][lvl]: with two levels a lane's pair is one 4-byte store, consecutive over lanes
-  float *op = reinterpret_cast<float *>(prm.out) + (size_t)e * prm.row_elems;
-  for (int q = NOUT * L + lane; q < prm.row_elems; q += 64) op[q] = 0.0f;   // row padding
-  if (lane < 63) {
-    if (L == 2) {
-#pragma unroll
-      for (int k = 0; k < KOUT; k++)
-        reinterpret_cast<float2 *>(op)[lane + 63 * k] = make_float2(res[0][k], res[1][k]);
-    } else {
-#pragma unroll
-      for (int k = 0; k < KOUT; k++) op[lane + 63 * k] = res[0][k];
+      for (int k = 0; k < KOUT; k++) M::st(op + lane + 63 * k, res[0][k]);
     }
   }
 }
@@ -835,15 +672,15 @@ int ramp_corr_fwd_ordered(const void *fmap1, const ramp_corr_level *levels, int 
   const bool fast32 = (dtype & RAMP_CORR_MFMA32) != 0;
   dtype &= ~RAMP_CORR_MFMA32;
   if (dtype == RAMP_F32 && layout == RAMP_NHWC && fast32)
-    hipLaunchKernelGGL(corr_mfma_f32_kernel, grid, dim3(64), 0, st, prm);
+    hipLaunchKernelGGL((corr_mfma_kernel<float, false>), grid, dim3(64), 0, st, prm);
   else if (dtype == RAMP_F32 && layout == RAMP_NHWC)
     hipLaunchKernelGGL((corr_kernel<float, RAMP_NHWC>), grid, dim3(64), 0, st, prm);
   else if (dtype == RAMP_F32 && layout == RAMP_NCHW)
     hipLaunchKernelGGL((corr_kernel<float, RAMP_NCHW>), grid, dim3(64), 0, st, prm);
   else if (dtype == RAMP_F16 && layout == RAMP_NHWC)
-    hipLaunchKernelGGL(corr_mfma_f16_kernel<false>, grid, dim3(64), 0, st, prm);
+    hipLaunchKernelGGL((corr_mfma_kernel<_Float16, false>), grid, dim3(64), 0, st, prm);
   else if (dtype == RAMP_F16 && layout == RAMP_NHWC8)
-    hipLaunchKernelGGL(corr_mfma_f16_kernel<true>, grid, dim3(64), 0, st, prm);
+    hipLaunchKernelGGL((corr_mfma_kernel<_Float16, true>), grid, dim3(64), 0, st, prm);
   else if (dtype == RAMP_F16 && layout == RAMP_NCHW)
     hipLaunchKernelGGL((corr_kernel<__half, RAMP_NCHW>), grid, dim3(64), 0, st, prm);
   else

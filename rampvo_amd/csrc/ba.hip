@@ -323,7 +323,7 @@ __global__ void __launch_bounds__(256)
     ba_assemble_kernel(const float *__restrict__ pairs, const int32_t *__restrict__ pair_ij,
                        const int32_t *__restrict__ npairs, const float *__restrict__ S_part,
                        const float *__restrict__ y_part, float *__restrict__ S,
-                       float *__restrict__ yv, int n6, int KS) {
+                       float *__restrict__ yv, int n6, int KS, int32_t *__restrict__ info) {
   __shared__ int s_list[BA_MAXLIST];
   __shared__ int s_wcnt[4];
   __shared__ int s_base;
@@ -346,6 +346,9 @@ __global__ void __launch_bounds__(256)
     __syncthreads();
   }
   const int nl = min(s_base, BA_MAXLIST);
+  // more pair records on one pose than the list holds (> 512 frames connected to one): the result would silently lose
+  // terms -- flagged in *info (bit 1), never truncated quietly
+  if (s_base > BA_MAXLIST && tid == 0 && info) atomicOr(info, 2);
   // The listed pair records are staged through LDS in chunks (coalesced, all loads in flight at
   // once) -- walking them straight from memory costs one dependent global round trip per record.
   __shared__ __attribute__((aligned(16))) float s_pr[BA_CHUNK][BA_PAIR];
@@ -474,7 +477,7 @@ __global__ void __launch_bounds__(1024)
     }
     __syncthreads();
   }
-  if (bad && tid == 0 && info) *info = 1;
+  if (bad && tid == 0 && info) atomicOr(info, 1);
   // z = column n6 of the upper triangle;  L' x = z, column oriented; L[k][i] sits at A[i][k]
   for (int q = tid; q < n6; q += nt) t[q] = A[q * ld + n6];
   __syncthreads();
@@ -529,7 +532,7 @@ __global__ void __launch_bounds__(64)
       a[k] = __builtin_fmaf(-a[j], lkj, a[k]);              // only rows i >= k are ever read
     }
   }
-  if (bad && i == 0 && info) *info = 1;
+  if (bad && i == 0 && info) atomicOr(info, 1);
   // z = row n6;  L' x = z, column oriented
 #pragma unroll
   for (int c = 0; c < 64; c++) Lt[c * 65 + i] = a[c];
@@ -680,7 +683,7 @@ static int ba_iterate(float *poses, float *patches, const float *intrinsics, con
       hipLaunchKernelGGL(ba_schur_kernel, dim3(w.tiles, w.tiles, w.KS), dim3(256), 0, st, w.Erow,
                          w.Qv, w.uv, nk, w.S_part, w.y_part, n6, w.KS);
       hipLaunchKernelGGL(ba_assemble_kernel, dim3(N, ramp_cdiv(6 * n6, 192)), dim3(256), 0, st, w.pairs, w.pair_ij, np,
-                         w.S_part, w.y_part, w.S, w.yv, n6, w.KS);
+                         w.S_part, w.y_part, w.S, w.yv, n6, w.KS, info);
       if (n6 <= 63)
         hipLaunchKernelGGL(ba_chol64_kernel, dim3(1), dim3(64), 0, st, w.S, w.yv, w.dX, info, n6);
       else

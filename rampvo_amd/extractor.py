@@ -10,13 +10,16 @@ are this package's own:
   * the per-pixel LSTM + super-state 1x1 convolutions are evaluated as fused
     pointwise math on [H*W, C] matrices (the reference calls cuDNN's LSTM on
     307,200 length-1 sequences and syncs on ``torch.any`` per modality);
-  * the conv towers go through ``conv.conv2d`` / ``conv.instance_norm_relu``
-    (HIP implicit-GEMM MFMA kernels when built, see csrc/conv.hip).
+  * the conv towers are the HIP implicit-GEMM MFMA kernels of csrc/conv.hip (conv_hip.py).
+
+There is no ATen path in this package: the modules hold the parameters (and load the reference's checkpoints);
+their forward runs the HIP front end or raises.  The plain-PyTorch restatement used as the numerics reference and
+by the CPU baseline lives with the test infrastructure (oracle/host_cpu.py).
 """
 import torch
 import torch.nn as nn
 
-from . import conv as C
+from ._lib import require_cuda
 
 DIM = 32
 
@@ -50,11 +53,8 @@ class ResidualBlock(nn.Module):
             self.downsample = nn.Sequential(nn.Conv2d(in_planes, planes, kernel_size=1, stride=stride), self.norm3)
 
     def forward(self, x):
-        y = C.conv_norm_relu(x, self.conv1, self.norm1, relu=True)
-        y = C.conv_norm_relu(y, self.conv2, self.norm2, relu=True)
-        if self.downsample is not None:
-            x = C.conv_norm_relu(x, self.downsample[0], self.norm3, relu=False)
-        return C.add_relu(x, y)
+        raise RuntimeError("rampvo_amd: the conv towers run as a whole on the HIP kernels (conv_hip.basic_encoder4 / "
+                           "multiscale_encoder4); there is no per-module ATen forward")
 
 
 class BasicEncoder4(nn.Module):
@@ -84,15 +84,8 @@ class BasicEncoder4(nn.Module):
         return nn.Sequential(*layers)
 
     def forward(self, x, out_scale=1.0):
-        """x [b,n,c,h,w] (any strides) -> [b,n,out,h/4,w/4], channels-last storage.
-        ``out_scale`` folds the Patchifier's ``fmap / 4`` into the last conv's epilogue."""
-        b, n, c1, h1, w1 = x.shape
-        x = x.reshape(b * n, c1, h1, w1)
-        x = C.conv_norm_relu(x, self.conv1, self.norm1, relu=True)
-        x = self.layer1(x)
-        x = self.layer2(x)
-        x = C.conv_norm_relu(x, self.conv2, None, relu=False, out_scale=out_scale)
-        return x.view(b, n, *x.shape[1:])
+        """x [b,n,c,h,w] -> [b,n,out,h/4,w/4]: runs inside the encoder's HIP front end only"""
+        raise RuntimeError("rampvo_amd: the conv towers run as a whole on the HIP kernels (conv_hip.basic_encoder4)")
 
 
 class MultiScaleBasicEncoder4(BasicEncoder4):
@@ -110,17 +103,7 @@ class MultiScaleBasicEncoder4(BasicEncoder4):
         self.conv3 = nn.Conv2d(2 * DIM + internal_input_dimensions[2], output_dim, kernel_size=1)
 
     def forward(self, x, x_down2, x_down4, out_scale=1.0):
-        b, n = x.shape[:2]
-        x = x.reshape(b * n, *x.shape[2:])
-        x_down2 = x_down2.reshape(b * n, *x_down2.shape[2:])
-        x_down4 = x_down4.reshape(b * n, *x_down4.shape[2:])
-        x = C.conv_norm_relu(x, self.conv1, self.norm1, relu=True)
-        x = self.layer1(x)
-        x = C.cat_channels(x, x_down2)
-        x = self.layer3(x)
-        x = C.cat_channels(x, x_down4)
-        x = C.conv_norm_relu(x, self.conv3, None, relu=False, out_scale=out_scale)
-        return x.view(b, n, *x.shape[1:])
+        raise RuntimeError("rampvo_amd: the conv towers run as a whole on the HIP kernels (conv_hip.multiscale_encoder4)")
 
 
 def _two_towers(owner, fmap_fn, imap_fn):
@@ -144,32 +127,6 @@ def _two_towers(owner, fmap_fn, imap_fn):
     return f, i
 
 
-def _pixel_lstm(lstm, x2d, state):
-    """one step of nn.LSTM (gate order i,f,g,o) for every pixel row of x2d [HW,Cin].
-    state = (h, c) [HW,hid] or None (zeros)."""
-    gates = torch.addmm(lstm.bias_ih_l0 + lstm.bias_hh_l0, x2d, lstm.weight_ih_l0.t())
-    if state is not None:
-        gates = gates + state[0] @ lstm.weight_hh_l0.t()
-    i, f, g, o = gates.chunk(4, dim=1)
-    i, f, o = torch.sigmoid(i), torch.sigmoid(f), torch.sigmoid(o)
-    g = torch.tanh(g)
-    c = i * g if state is None else f * state[1] + i * g
-    h = o * torch.tanh(c)
-    return h, c
-
-
-def _pixel_mix(conv, s2d, e2d):
-    """1x1 conv on the channel concat [s ; e] as two [HW,C] GEMMs"""
-    w = conv.weight.view(conv.out_channels, -1)
-    k = s2d.shape[1]
-    return torch.addmm(conv.bias, s2d, w[:, :k].t()) + e2d @ w[:, k:].t()
-
-
-def _to_rows(x):
-    """[C,H,W] (any strides) -> [H*W, C] contiguous"""
-    return x.permute(1, 2, 0).reshape(-1, x.shape[0]).contiguous()
-
-
 class MergerLSTMsceneEncoder(nn.Module):
     """SingleScale RAMP encoder; reference :187-269"""
 
@@ -183,7 +140,7 @@ class MergerLSTMsceneEncoder(nn.Module):
         self.superstate_encoder = nn.Conv2d(2 * output_lstm_dim, output_lstm_dim, kernel_size=1)
         self.fmap_encoder = BasicEncoder4(output_dim=output_dim_f, norm_fn=norm_fn_fmap, channel_dim=output_lstm_dim)
         self.imap_encoder = BasicEncoder4(output_dim=output_dim_i, norm_fn=norm_fn_imap, channel_dim=output_lstm_dim)
-        self.states_events, self.states_image, self.super_state = None, None, None
+        self.states_events, self.states_image, self.super_state = None, None, None   # (oracle-side torch forward)
         self._hip_state = None
         self.mixed_precision = False      # fp16 storage / fp16 MFMA conv towers (set by Ramp_vo from cfg)
 
@@ -206,30 +163,10 @@ class MergerLSTMsceneEncoder(nn.Module):
 
     def forward(self, events, images, reinit_hidden=False, out_scale=1.0):
         B, T, Ce, H, W = events.shape
-        assert B == 1 and images.shape[1] == T
-        if T == 1 and C.use_hip(events):
-            return self._forward_hip(events, images, reinit_hidden, out_scale)
-        if reinit_hidden:
-            self.states_events, self.states_image, self.super_state = None, None, None
-        super_states = []
-        for t in range(T):
-            ev, im = events[0, t], images[0, t]
-            e_rows, i_rows = _to_rows(ev.float()), _to_rows(im.float())
-            self.states_events = _pixel_lstm(self.events_convlstm, e_rows, self.states_events)
-            self.states_image = _pixel_lstm(self.image_convlstm, i_rows, self.states_image)
-            s = self.super_state if self.super_state is not None else torch.zeros_like(self.states_events[0])
-            # reference gates each update on torch.any(x != 0) with a host sync; here the
-            # flag stays on the device and selects the result
-            s_ev = _pixel_mix(self.superstate_encoder, s, self.states_events[0])
-            s = torch.where((ev != 0).any(), s_ev, s)
-            s_im = _pixel_mix(self.superstate_encoder, s, self.states_image[0])
-            s = torch.where((im != 0).any(), s_im, s)
-            self.super_state = s
-            super_states.append(s.view(H, W, -1))
-        ss = torch.stack(super_states, 0).permute(0, 3, 1, 2)[None]       # [1,T,15,H,W], NHWC storage
-        fmap = self.fmap_encoder(ss, out_scale=out_scale)
-        imap = self.imap_encoder(ss, out_scale=out_scale)
-        return fmap, imap, None
+        require_cuda(events, images)
+        if B != 1 or T != 1 or images.shape[1] != 1:
+            raise RuntimeError("rampvo_amd: the encoder advances one frame per call (batch 1, T = 1: the tracking path)")
+        return self._forward_hip(events, images, reinit_hidden, out_scale)
 
 
 class LSTMEncoder(nn.Module):
@@ -247,10 +184,7 @@ class LSTMEncoder(nn.Module):
         self.norm_layer = nn.Sequential()
 
     def forward(self, x):
-        """x [1,T,C,H,W] -> list over T of hidden rows [H'*W', hid] and (H', W')"""
-        y = C.conv_norm_relu(x[0].float(), self.conv_1, None, relu=False)     # [T,C,H',W']
-        Hs, Ws = y.shape[-2:]
-        return [_pixel_lstm(self.convlstm, _to_rows(y[t]), None)[0] for t in range(y.shape[0])], (Hs, Ws)
+        raise RuntimeError("rampvo_amd: fused into ms_lstm_superstate_kernel (conv_hip.ms_lstm_superstate_step)")
 
 
 class SuperStateEncoder(nn.Module):
@@ -319,27 +253,7 @@ class MultiScaleMergerDoubleNet(nn.Module):
 
     def forward(self, events, images, mask, reinit_hidden=False, out_scale=1.0):
         mask_list = [bool(m) for m in mask.reshape(-1).tolist()]
-        if events.shape[1] == 1 and len(mask_list) == 1 and C.use_hip(events):
-            return self._forward_hip(events, images, mask_list[0], reinit_hidden, out_scale)
-        outs = []
-        for k in range(len(self.scales)):
-            if reinit_hidden:
-                self.super_states[k] = None
-            ev_rows, (Hs, Ws) = self.ev_encoders[k](events)
-            im_rows, _ = self.im_encoders[k](images)
-            s = self.super_states[k]
-            collected, ind_im = [], 0
-            for t, e in enumerate(ev_rows):
-                if s is None:
-                    s = torch.zeros_like(e)
-                s = _pixel_mix(self.super_state_ev_encoder[k].encoder, s, e)
-                if mask_list[t] if len(mask_list) > 1 else mask_list[0]:
-                    s = _pixel_mix(self.super_state_im_encoders[k].encoder, s, im_rows[ind_im])
-                    ind_im += 1
-                    collected.append(s)
-            self.super_states[k] = s
-            stack = collected if collected else [s]
-            outs.append(torch.stack([r.view(Hs, Ws, -1) for r in stack], 0).permute(0, 3, 1, 2)[None])
-        fmap = self.fmap_encoder(outs[0], outs[1], outs[2], out_scale=out_scale)
-        imap = self.imap_encoder(outs[0], outs[1], outs[2], out_scale=out_scale)
-        return fmap, imap
+        require_cuda(events, images)
+        if events.shape[0] != 1 or events.shape[1] != 1 or len(mask_list) != 1:
+            raise RuntimeError("rampvo_amd: the encoder advances one frame per call (batch 1, T = 1: the tracking path)")
+        return self._forward_hip(events, images, mask_list[0], reinit_hidden, out_scale)

@@ -69,11 +69,6 @@ class GraphPlan:
             p.pair_mul = nb if nb else 12345
             p.g_ij = ops.group_by(jj * p.pair_mul + ii, nb * nb if nb else 0)
         p.ix_raw, p.jx_raw = p.ix, p.jx
-        if not ii.is_cuda:               # the ATen path of Update.forward wants masks + clamped indices
-            p.mask_ix = (p.ix >= 0).reshape(1, -1, 1)
-            p.mask_jx = (p.jx >= 0).reshape(1, -1, 1)
-            p.ix = p.ix.clamp(min=0)
-            p.jx = p.jx.clamp(min=0)
         # group counts: caller-supplied upper bounds avoid a device->host read-back
         p.max_kk = int(max_kk) if max_kk is not None else int(p.g_kk.ngroups.item())
         p.max_ij = int(max_ij) if max_ij is not None else int(p.g_ij.ngroups.item())
@@ -107,23 +102,16 @@ class Update(nn.Module):
         return self._fused_impl[dtype]
 
     def forward(self, net, inp, corr, flow, ii, jj, kk, plan=None):
+        from ._lib import require_cuda
+        require_cuda(net, inp, corr)
         if plan is None:
             plan = GraphPlan.build(ii, jj, kk)
-        if corr.is_cuda:
-            # GPU: GEMMs + row-fused glue kernels; dtype = the caller's feature dtype
-            fu = self.fused(corr.dtype)
-            out32, relu_t = fu.hidden(net[0].float().contiguous(), inp[0].to(corr.dtype).contiguous(), None, 0,
-                                      corr[0].contiguous(), plan)
-            hw = fu.heads(relu_t)
-            return out32[None], (hw[None, :, :2], torch.sigmoid(hw[None, :, 2:]), None)
-        net = net + inp + self.corr(corr)
-        net = self.norm(net)
-        net = net + self.c1(plan.mask_ix.to(net.dtype) * net[:, plan.ix])
-        net = net + self.c2(plan.mask_jx.to(net.dtype) * net[:, plan.jx])
-        net = net + self.agg_kk(net, kk, plan.g_kk, plan.max_kk)
-        net = net + self.agg_ij(net, None, plan.g_ij, plan.max_ij)
-        net = self.gru(net)
-        return net, (self.d(net), self.w(net), None)
+        # GEMMs + row-fused glue kernels / fused MFMA chains (update_fused.py); dtype = the caller's feature dtype
+        fu = self.fused(corr.dtype)
+        out32, relu_t = fu.hidden(net[0].float().contiguous(), inp[0].to(corr.dtype).contiguous(), None, 0,
+                                  corr[0].contiguous(), plan)
+        hw = fu.heads(relu_t)
+        return out32[None], (hw[None, :, :2], torch.sigmoid(hw[None, :, 2:]), None)
 
 
 class Patchifier(nn.Module):

@@ -20,3 +20,17 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _quiesce_gpu_between_tests(request):
+    """GPU tests build and drop trackers (hipGraphs, helper threads, side streams) in quick succession: drain the device
+    and collect the dead objects at a quiescent point, so that no graph is destroyed while another one is captured"""
+    yield
+    if request.node.get_closest_marker("gpu") is not None:
+        import gc
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+            gc.collect()
+            torch.cuda.synchronize()

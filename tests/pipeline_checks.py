@@ -17,6 +17,15 @@ def gold(name):
     return np.load(os.path.join(GOLD, name))
 
 
+def make_tracker(cfg, net, ht, wd, device):
+    """the product tracker on the GPU; the oracle-side tracker (oracle/host_cpu.py) for the CPU host-logic tests"""
+    if torch.device(device).type == "cuda":
+        from rampvo_amd.Ramp_vo import Ramp_vo
+        return Ramp_vo(cfg, net, {"event_bias": True}, ht=ht, wd=wd, device=device)
+    from oracle.backend_cpu import Ramp_vo as cpu_tracker
+    return cpu_tracker(cfg, net, {"event_bias": True}, ht=ht, wd=wd, device=device)
+
+
 def depth_draw(frame, M):
     g = torch.Generator().manual_seed(DEPTH_SEED + frame)
     return torch.rand(1, M, 1, 1, generator=g)
@@ -90,13 +99,12 @@ def run_ramp_vo(device, mixed=False):
     """drive rampvo_amd.Ramp_vo over the RAMPVO stream exactly as oracle/make_golden.py
     drives the reference class; returns the per-frame record + final state"""
     from rampvo_amd.config import make_cfg
-    from rampvo_amd.Ramp_vo import Ramp_vo
     from rampvo_amd.synthetic import SyntheticStream, make_network
     p = RAMPVO
     net = make_network("SingleScale", device=device)
     cfg = make_cfg("default", PATCHES_PER_FRAME=p["M"], MIXED_PRECISION=mixed)
     stream = SyntheticStream(p["H"], p["W"], p["T"], seed=p["seed"])
-    slam = Ramp_vo(cfg, net, {"event_bias": True}, ht=p["H"], wd=p["W"], device=device)
+    slam = make_tracker(cfg, net, p["H"], p["W"], device)
     frame_no = [0]
     slam._initial_depth = lambda patches: depth_draw(frame_no[0], patches.shape[1]).to(patches.device)
     rec = dict(n=[], m=[], E=[], pose=[], depth_med=[], init=[])
@@ -120,14 +128,13 @@ def check_update_step(device, mixed=False):
     """teacher-forced: inject the reference's captured state, run ONE update(), compare with what the
     reference's update() produced from the same state (fixture update_step.npz)"""
     from rampvo_amd.config import make_cfg
-    from rampvo_amd.Ramp_vo import Ramp_vo
     from rampvo_amd.synthetic import make_network
     p = STEP
     g = gold("update_step.npz")
     net = make_network("SingleScale", device=device)
     cfg = make_cfg("default", PATCHES_PER_FRAME=p["M"], MIXED_PRECISION=mixed,
                    OPTIMIZATION_WINDOW=p["OPTIMIZATION_WINDOW"])
-    slam = Ramp_vo(cfg, net, {"event_bias": True}, ht=p["H"], wd=p["W"], device=device)
+    slam = make_tracker(cfg, net, p["H"], p["W"], device)
     k = g["in_poses"].shape[0]
     mem = slam.mem
 
@@ -222,12 +229,11 @@ TRAJ = {
 @torch.no_grad()
 def run_trajectory(tag, device, mixed=False, pipelined=False):
     from rampvo_amd.config import make_cfg
-    from rampvo_amd.Ramp_vo import Ramp_vo
     from rampvo_amd.synthetic import SyntheticStream, make_network
     p = TRAJ[tag]
     net = make_network(p["mode"], device=device, profile="damped")
     cfg = make_cfg(p["preset"], PATCHES_PER_FRAME=p["M"], MIXED_PRECISION=mixed, **p["over"])
-    slam = Ramp_vo(cfg, net, {"event_bias": True}, ht=p["H"], wd=p["W"], device=device)
+    slam = make_tracker(cfg, net, p["H"], p["W"], device)
     slam.inputs_ready = pipelined
     stream = SyntheticStream(p["H"], p["W"], p["T"], seed=p["seed"])
     frame_no = [0]

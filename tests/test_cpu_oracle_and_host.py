@@ -49,6 +49,26 @@ def test_ops_have_no_cpu_fallback():
         ops.group_by(torch.zeros(4, dtype=torch.int64))
 
 
+def test_product_modules_and_tracker_refuse_cpu():
+    """no ATen / CPU path inside the package: the encoder, the update operator and the tracker run their HIP
+    kernels or raise (the torch restatements used by these CPU tests live in oracle/host_cpu.py)"""
+    from rampvo_amd.config import make_cfg
+    from rampvo_amd.Ramp_vo import Ramp_vo
+    from rampvo_amd.synthetic import make_network
+    assert not os.path.exists(os.path.join(ROOT, "rampvo_amd", "conv.py"))
+    net = make_network("SingleScale", device="cpu")
+    with pytest.raises(RuntimeError):
+        net.patchify.encoder(events=torch.zeros(1, 1, 5, 32, 32), images=torch.zeros(1, 1, 3, 32, 32))
+    with pytest.raises(RuntimeError):
+        net.update(torch.zeros(1, 4, 384), torch.zeros(1, 4, 384), torch.zeros(1, 4, 882), None,
+                   torch.zeros(4, dtype=torch.long), torch.zeros(4, dtype=torch.long), torch.zeros(4, dtype=torch.long))
+    with pytest.raises(RuntimeError):
+        make_network("MultiScale", device="cpu").patchify.encoder(
+            events=torch.zeros(1, 1, 5, 32, 32), images=torch.zeros(1, 1, 3, 32, 32), mask=torch.tensor([True]))
+    with pytest.raises(RuntimeError):
+        Ramp_vo(make_cfg("default"), net, {"event_bias": True}, device="cpu")
+
+
 # ----------------------------------------------------------------- oracle pins
 def test_oracle_se3_identities_of_reference_run_tests():
     """ramp/lietorch/run_tests.py:16-52 (exp/log, inverse, adjoint, act == matrix) at fp32"""
@@ -122,11 +142,11 @@ def test_oracle_event_stack_against_reference_golden():
 
 
 def test_host_graph_edit_matches_numpy_logic():
-    """libramp_hip.so's HOST helper ramp_graph_edit_host (one C pass) against Ramp_vo._graph_edit (the numpy
-    restatement of reference Ramp_vo.py:247-274 + :203-208), both outcomes of the motion test"""
+    """libramp_hip.so's HOST helper ramp_graph_edit_host (one C pass) against the oracle-side tracker's _graph_edit (the
+    numpy restatement of reference Ramp_vo.py:247-274 + :203-208), both outcomes of the motion test"""
     import ctypes
+    from oracle.host_cpu import RampVoCPU
     from rampvo_amd import _lib
-    from rampvo_amd.Ramp_vo import Ramp_vo
     rng = np.random.default_rng(3)
     M, n, R, KI = 8, 30, 22, 4
     fake = type("T", (), {})()
@@ -137,7 +157,7 @@ def test_host_graph_edit_matches_numpy_logic():
     fake._jj = rng.integers(0, n, 5000).astype(np.int64)
     rows = rng.permutation(5000).astype(np.int64)
     for remove in (True, False):
-        ref = Ramp_vo._graph_edit(fake, remove)
+        ref = RampVoCPU._graph_edit(fake, remove)
         out = np.empty((4, 5000), np.int64)
         rng_out = np.empty(4, np.int64)
         k = n - KI if remove else -1
@@ -221,18 +241,18 @@ def test_update_step_teacher_forced_cpu():
 def test_vo_state_roundtrip_cpu():
     """state_dict() / load_state_dict(): a restored tracker continues identically"""
     with cpu_oracle_ops():
+        from oracle.backend_cpu import Ramp_vo as cpu_tracker
         from rampvo_amd.config import make_cfg
-        from rampvo_amd.Ramp_vo import Ramp_vo
         from rampvo_amd.synthetic import SyntheticStream, make_network
         cfg = make_cfg("default", PATCHES_PER_FRAME=8, MIXED_PRECISION=False)
         net = make_network("SingleScale", device="cpu")
-        a = Ramp_vo(cfg, net, {"event_bias": True}, ht=64, wd=96, device="cpu")
+        a = cpu_tracker(cfg, net, {"event_bias": True}, ht=64, wd=96)
         stream = SyntheticStream(64, 96, 12, seed=3)
         torch.manual_seed(0)
         for t in range(10):
             im, ev, K, mask = stream.frame(t)
             a(t, input_tensor=(ev, im, mask), intrinsics=K)
-        b = Ramp_vo(cfg, net, {"event_bias": True}, ht=64, wd=96, device="cpu")
+        b = cpu_tracker(cfg, net, {"event_bias": True}, ht=64, wd=96)
         b.load_state_dict(a.state_dict())
         a.update()
         b.update()

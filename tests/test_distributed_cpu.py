@@ -21,9 +21,8 @@ def _free_port():
 
 
 def _track(seed):
-    from oracle.backend_cpu import cpu_oracle_ops
+    from oracle.backend_cpu import Ramp_vo, cpu_oracle_ops
     from rampvo_amd.config import make_cfg
-    from rampvo_amd.Ramp_vo import Ramp_vo
     from rampvo_amd.synthetic import SyntheticStream, make_network
     torch.manual_seed(100 + seed)
     with cpu_oracle_ops(), torch.no_grad():

@@ -727,3 +727,31 @@ def test_depth_median_fill_matches_torch_median():
         ops.depth_median_fill(state, n, 3, new)
         med = torch.median(state[n - 3:n, :, 2])
         assert torch.equal(new[:, 2], med.expand(M, P, P)) and torch.equal(new[:, :2], keep[:, :2])
+
+
+def test_ba_flags_pair_list_overflow_instead_of_truncating():
+    """> 1024 pose-pair records on one pose (a frame connected to 1100 others): ramp_ba_forward must raise bit 1 of
+    *info rather than drop terms silently (csrc/ba.hip::ba_assemble_kernel's LDS list)"""
+    from rampvo_amd import ops
+    NF, M = 1102, 1
+    rng = np.random.default_rng(0)
+    poses = np.zeros((NF, 7), np.float32); poses[:, 6] = 1.0
+    poses[:, :3] = rng.normal(0, 0.01, (NF, 3))
+    patches = np.zeros((NF * M, 3, 3, 3), np.float32)
+    gy, gx = np.meshgrid(np.arange(-1, 2), np.arange(-1, 2), indexing="ij")
+    patches[:, 0] = 40 + gx; patches[:, 1] = 30 + gy; patches[:, 2] = 0.5
+    intr = np.tile(np.array([80, 80, 80, 60], np.float32), (NF, 1))
+    ii = np.arange(1, NF, dtype=np.int64); jj = np.zeros(NF - 1, np.int64); kk = ii.copy()      # every frame -> frame 0 ... and back
+    ii = np.concatenate([ii, np.zeros(NF - 1, np.int64)]); jj = np.concatenate([jj, np.arange(1, NF)]); kk = np.concatenate([kk, np.zeros(NF - 1, np.int64)])
+    E = len(ii)
+    target = np.full((E, 2), 40.0, np.float32); weight = np.full((E, 2), 0.5, np.float32)
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    p, pt = cu(poses), cu(patches)
+    ops.ba(p, pt, cu(intr), cu(target), cu(weight), cu(np.array([1e-4], np.float32)), cu(ii), cu(jj), cu(kk), 0, 4, 1, info)
+    assert int(info.item()) & 2, int(info.item())
+    # the same call on a graph within the limit leaves the bit clear
+    sel = (ii < 300) & (jj < 300)
+    info.zero_()
+    ops.ba(cu(poses), cu(patches), cu(intr), cu(target[sel]), cu(weight[sel]), cu(np.array([1e-4], np.float32)), cu(ii[sel]),
+           cu(jj[sel]), cu(kk[sel]), 0, 4, 1, info)
+    assert int(info.item()) & 2 == 0

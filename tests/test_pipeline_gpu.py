@@ -86,6 +86,7 @@ def _one_update_vs_cpu_oracle(mode, preset, H, W, sd, cfgk, legs=(False,)):
     """ONE update() (reproject -> corr -> update operator -> BA x2 -> point cloud) from the same snapshot: HIP kernels
     (a fresh tracker per precision leg) vs the CPU oracle backend in fp32 (torch-CPU GEMMs + oracle C natives).
     Returns {leg: errors}; errors are max-abs, poses/depths relative to max(1, size of the GN step)."""
+    from oracle.backend_cpu import Ramp_vo as cpu_tracker
     from oracle.backend_cpu import cpu_oracle_ops
     from rampvo_amd.config import make_cfg
     from rampvo_amd.Ramp_vo import Ramp_vo
@@ -96,8 +97,8 @@ def _one_update_vs_cpu_oracle(mode, preset, H, W, sd, cfgk, legs=(False,)):
     for k in ("net", "imap", "gmap", "fmap1", "fmap2"):
         f32[k] = sd[k].float()
     with cpu_oracle_ops():
-        ref = Ramp_vo(make_cfg(preset, **dict(cfgk, MIXED_PRECISION=False)),
-                      make_network(mode, device="cpu", w_bias=STEP_W_BIAS), {"event_bias": True}, ht=H, wd=W, device="cpu")
+        ref = cpu_tracker(make_cfg(preset, **dict(cfgk, MIXED_PRECISION=False)),
+                          make_network(mode, device="cpu", w_bias=STEP_W_BIAS), {"event_bias": True}, ht=H, wd=W)
         ref.load_state_dict(f32)
         ref.update()
         r_poses = ref.poses_[:n].numpy().copy()
