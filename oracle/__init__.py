@@ -194,9 +194,10 @@ def neighbors(ii, jj):
     return ix, jx
 
 
-def ba(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t1, iterations=2):
+def ba(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t1, iterations=2, eff_ppf=0):
     """fastba.BA; ``poses`` and ``patches`` (float32, C-contiguous numpy) are
-    updated in place like the reference.  Returns the Cholesky status."""
+    updated in place like the reference.  Returns the Cholesky status.  eff_ppf > 0: the reference's
+    ``eff_impl=True`` path with PPF = eff_ppf patches per frame (block-sparse E lookup, fastba/block_e.cu)."""
     for a in (poses, patches):
         assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
     P = patches.shape[-1]
@@ -206,6 +207,11 @@ def ba(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t1, it
     lmbda = _f(lmbda).reshape(-1)
     ii, jj, kk = _i(ii), _i(jj), _i(kk)
     E = ii.shape[0]
+    if eff_ppf:
+        lib().orc_ba_eff.restype = ctypes.c_int
+        return lib().orc_ba_eff(_p(poses), _p(patches), _p(intrinsics), _p(target), _p(weight),
+                                _p(lmbda), _p(ii), _p(jj), _p(kk), E, P, int(t0), int(t1),
+                                int(iterations), int(eff_ppf))
     return lib().orc_ba(_p(poses), _p(patches), _p(intrinsics), _p(target), _p(weight),
                         _p(lmbda), _p(ii), _p(jj), _p(kk), E, P, int(t0), int(t1),
                         int(iterations))

@@ -499,10 +499,15 @@ static int i64cmp(const void *a, const void *b) {
   const int64_t x = *(const int64_t *)a, y = *(const int64_t *)b;
   return x < y ? -1 : (x > y);
 }
-ORC_API int orc_ba(float *poses, float *patches, const float *intr, const float *target,
+/* ppf > 0: the reference's eff_impl = true path (ba_cuda.cu:261-275, 353-362, 472-478, 538-550): the coupling
+ * matrix E is not stored as a dense [6N x M] matrix but as E_lookup[(i, j) block][patch within frame i][6]
+ * (EfficentE, fastba/block_e.cu:43-145), and E Q E', E (Q u), E' dX are formed from the lookup by
+ * EEt_kernel / Ev_kernel / Etv_kernel (block_e.cu:147-283).  Same algebra as the dense path, other summation
+ * order (the reference's is atomic, i.e. unordered; here: block order).  ppf = patches per frame.          */
+static int ba_impl(float *poses, float *patches, const float *intr, const float *target,
                    const float *weight, const float *lmbda_p, const int64_t *ii,
                    const int64_t *jj, const int64_t *kk, int E, int P, int t0, int t1,
-                   int iterations) {
+                   int iterations, int ppf) {
   const float lmbda = lmbda_p[0];
   int status = 0;
   /* torch::_unique(kk, sorted, return_inverse)  (ba_cuda.cu:447-449) */
@@ -535,12 +540,46 @@ ORC_API int orc_ba(float *poses, float *patches, const float *intr, const float 
   const int c11 = 1 * P + 1;
   (void)ctr;
 
+  /* ---- EfficentE::EfficentE (block_e.cu:43-145) */
+  int nf = 0, nblk = 0, nidx = 0;
+  int *blk_of = NULL, *ijx = NULL, *ijs = NULL, *blk_i = NULL, *blk_j = NULL, *p2ku = NULL, *idx5 = NULL;
+  float *Elk = NULL;
+  if (ppf > 0) {
+    for (int n = 0; n < E; n++) { if (ii[n] + 1 > nf) nf = (int)ii[n] + 1; if (jj[n] + 1 > nf) nf = (int)jj[n] + 1; }
+    blk_of = (int *)malloc(sizeof(int) * (size_t)nf * nf);          /* frame_to_idx: (i, j) -> block or -1 */
+    for (int q = 0; q < nf * nf; q++) blk_of[q] = -1;
+    for (int n = 0; n < E; n++) { blk_of[ii[n] * nf + jj[n]] = 0; blk_of[ii[n] * nf + ii[n]] = 0; }
+    for (int q = 0; q < nf * nf; q++) if (blk_of[q] == 0) blk_of[q] = nblk++;       /* sorted unique of i * nf + j */
+    blk_i = (int *)malloc(sizeof(int) * (size_t)(nblk + 1)); blk_j = (int *)malloc(sizeof(int) * (size_t)(nblk + 1));
+    for (int q = 0; q < nf * nf; q++) if (blk_of[q] >= 0) { blk_i[blk_of[q]] = q / nf; blk_j[blk_of[q]] = q % nf; }
+    ijx = (int *)malloc(sizeof(int) * (size_t)(E + 1)); ijs = (int *)malloc(sizeof(int) * (size_t)(E + 1));
+    for (int n = 0; n < E; n++) { ijx[n] = blk_of[ii[n] * nf + jj[n]]; ijs[n] = blk_of[ii[n] * nf + ii[n]]; }
+    Elk = (float *)malloc(sizeof(float) * ((size_t)nblk * ppf * 6 + 1));
+    p2ku = (int *)malloc(sizeof(int) * ((size_t)nf * ppf + 1));       /* (frame, patch) -> row of Q or -1 */
+    for (int q = 0; q < nf * ppf; q++) p2ku[q] = -1;
+    for (int m = 0; m < M; m++) if (kx[m] / ppf < nf) p2ku[(kx[m] / ppf) * ppf + kx[m] % ppf] = m;
+    /* index_tensor: for every source frame i all pairs (j1, j2) of frames it is connected to (incl. itself) */
+    for (int i = 0; i < nf; i++) { int c = 0; for (int j = 0; j < nf; j++) c += blk_of[i * nf + j] >= 0; nidx += c * c; }
+    idx5 = (int *)malloc(sizeof(int) * ((size_t)nidx * 5 + 1));
+    int cx_ = 0;
+    for (int i = 0; i < nf; i++)
+      for (int j1 = 0; j1 < nf; j1++) {
+        if (blk_of[i * nf + j1] < 0) continue;
+        for (int j2 = 0; j2 < nf; j2++) {
+          if (blk_of[i * nf + j2] < 0) continue;
+          int *r = idx5 + 5 * (size_t)cx_++;
+          r[0] = i; r[1] = j1; r[2] = j2; r[3] = blk_of[i * nf + j1]; r[4] = blk_of[i * nf + j2];
+        }
+      }
+  }
+
   for (int itr = 0; itr < iterations; itr++) {
     memset(B, 0, sizeof(float) * (size_t)n6 * n6);
     memset(Em, 0, sizeof(float) * (size_t)n6 * M);
     memset(C, 0, sizeof(float) * (size_t)M);
     memset(v, 0, sizeof(float) * (size_t)n6);
     memset(u, 0, sizeof(float) * (size_t)M);
+    if (ppf > 0) memset(Elk, 0, sizeof(float) * (size_t)nblk * ppf * 6);     /* blockE->E_lookup.zero_() */
 
     for (int n = 0; n < E; n++) {
       const int k = ku[n];
@@ -596,8 +635,13 @@ ORC_API int orc_ba(float *poses, float *patches, const float *intr, const float 
             }
           }
         for (int i = 0; i < 6; i++) {
-          if (ix >= 0) Em[(size_t)(6 * ix + i) * M + k] += -w * Jz * Ji[i];
-          if (jx >= 0) Em[(size_t)(6 * jx + i) * M + k] += w * Jz * Jj[i];
+          if (ppf > 0) {   /* ba_cuda.cu:353-356: no test of ix / jx here, the lookup kernels test the block's frame */
+            Elk[((size_t)ijs[n] * ppf + kxn % ppf) * 6 + i] += -w * Jz * Ji[i];
+            Elk[((size_t)ijx[n] * ppf + kxn % ppf) * 6 + i] += w * Jz * Jj[i];
+          } else {
+            if (ix >= 0) Em[(size_t)(6 * ix + i) * M + k] += -w * Jz * Ji[i];
+            if (jx >= 0) Em[(size_t)(6 * jx + i) * M + k] += w * Jz * Jj[i];
+          }
         }
         for (int i = 0; i < 6; i++) {
           if (ix >= 0) v[6 * ix + i] += -w * r * Ji[i];
@@ -612,7 +656,33 @@ ORC_API int orc_ba(float *poses, float *patches, const float *intr, const float 
 
     if (N == 0) { /* ba_cuda.cu:521-531 */
       for (int k = 0; k < M; k++) dZ[k] = Q[k] * u[k];
-    } else {   /* ba_cuda.cu:552-565 */
+    } else {
+      if (ppf > 0) {   /* ba_cuda.cu:538-550 over block_e.cu:147-283 */
+      memcpy(S, B, sizeof(float) * (size_t)n6 * n6);
+      memcpy(y, v, sizeof(float) * (size_t)n6);
+      for (int r = 0; r < nidx; r++) {                       /* EEt_kernel: S -= E Q E' */
+        const int *ix5 = idx5 + 5 * (size_t)r;
+        const int j1 = ix5[1] - t0, j2 = ix5[2] - t0;
+        if (j1 < 0 || j2 < 0 || j1 >= N || j2 >= N) continue;
+        for (int kq = 0; kq < ppf; kq++) {
+          const int qi = p2ku[ix5[0] * ppf + kq];
+          if (qi < 0) continue;                                /* no such patch: its lookup slices are zero */
+          const float *s1 = Elk + ((size_t)ix5[3] * ppf + kq) * 6, *s2 = Elk + ((size_t)ix5[4] * ppf + kq) * 6;
+          for (int xi = 0; xi < 6; xi++)
+            for (int xj = 0; xj < 6; xj++) S[(6 * j1 + xi) * n6 + 6 * j2 + xj] -= s1[xi] * s2[xj] * Q[qi];
+        }
+      }
+      for (int bq = 0; bq < nblk; bq++) {                     /* Ev_kernel with vec = Q * u: y -= E (Q u) */
+        const int jb = blk_j[bq] - t0;
+        if (jb < 0 || jb >= N) continue;
+        for (int kq = 0; kq < ppf; kq++) {
+          const int qi = p2ku[blk_i[bq] * ppf + kq];
+          if (qi < 0) continue;
+          const float *sl = Elk + ((size_t)bq * ppf + kq) * 6;
+          for (int r = 0; r < 6; r++) y[jb * 6 + r] -= sl[r] * (Q[qi] * u[qi]);
+        }
+      }
+      } else {   /* ba_cuda.cu:552-565 */
       for (int a = 0; a < n6; a++) {
         for (int b = 0; b < n6; b++) {
           float s = 0;
@@ -622,6 +692,7 @@ ORC_API int orc_ba(float *poses, float *patches, const float *intr, const float 
         float s = 0;
         for (int k = 0; k < M; k++) s += (Em[(size_t)a * M + k] * Q[k]) * u[k];
         y[a] = v[a] - s;
+      }
       }
       for (int a = 0; a < n6; a++) S[a * n6 + a] += (1e-4f * S[a * n6 + a] + 1.0f);
       /* lower Cholesky in place + solve  (linalg_cholesky_ex / cholesky_solve) */
@@ -647,10 +718,25 @@ ORC_API int orc_ba(float *poses, float *patches, const float *intr, const float 
         for (int k = i + 1; k < n6; k++) t -= S[k * n6 + i] * dX[k];
         dX[i] = t / S[i * n6 + i];
       }
-      for (int k = 0; k < M; k++) {
-        float s = 0;
-        for (int a = 0; a < n6; a++) s += Em[(size_t)a * M + k] * dX[a];
-        dZ[k] = Q[k] * (u[k] - s);
+      if (ppf > 0) {                                          /* Etv_kernel: E' dX per patch */
+        for (int k = 0; k < M; k++) dZ[k] = 0.0f;
+        for (int bq = 0; bq < nblk; bq++) {
+          const int jb = blk_j[bq] - t0;
+          if (jb < 0 || jb >= N) continue;
+          for (int kq = 0; kq < ppf; kq++) {
+            const int qi = p2ku[blk_i[bq] * ppf + kq];
+            if (qi < 0) continue;
+            const float *sl = Elk + ((size_t)bq * ppf + kq) * 6;
+            for (int r = 0; r < 6; r++) dZ[qi] += sl[r] * dX[jb * 6 + r];
+          }
+        }
+        for (int k = 0; k < M; k++) dZ[k] = Q[k] * (u[k] - dZ[k]);
+      } else {
+        for (int k = 0; k < M; k++) {
+          float s = 0;
+          for (int a = 0; a < n6; a++) s += Em[(size_t)a * M + k] * dX[a];
+          dZ[k] = Q[k] * (u[k] - s);
+        }
       }
       for (int i = 0; i < N; i++) { /* pose_retr_kernel */
         float *p = poses + 7 * (t0 + i);
@@ -671,7 +757,24 @@ ORC_API int orc_ba(float *poses, float *patches, const float *intr, const float 
   }
   free(kx); free(ku); free(B); free(Em); free(C); free(v); free(u); free(Q);
   free(S); free(y); free(dX); free(dZ);
+  free(blk_of); free(ijx); free(ijs); free(blk_i); free(blk_j); free(p2ku); free(idx5); free(Elk);
   return status;
+}
+
+/* cuda_ba.forward(..., eff_impl = false) */
+ORC_API int orc_ba(float *poses, float *patches, const float *intr, const float *target,
+                   const float *weight, const float *lmbda_p, const int64_t *ii,
+                   const int64_t *jj, const int64_t *kk, int E, int P, int t0, int t1,
+                   int iterations) {
+  return ba_impl(poses, patches, intr, target, weight, lmbda_p, ii, jj, kk, E, P, t0, t1, iterations, 0);
+}
+
+/* cuda_ba.forward(..., PPF = ppf, eff_impl = true) */
+ORC_API int orc_ba_eff(float *poses, float *patches, const float *intr, const float *target,
+                       const float *weight, const float *lmbda_p, const int64_t *ii,
+                       const int64_t *jj, const int64_t *kk, int E, int P, int t0, int t1,
+                       int iterations, int ppf) {
+  return ba_impl(poses, patches, intr, target, weight, lmbda_p, ii, jj, kk, E, P, t0, t1, iterations, ppf);
 }
 
 /* ------------------------------------------------------------------------- */

@@ -755,3 +755,51 @@ def test_ba_flags_pair_list_overflow_instead_of_truncating():
     ops.ba(cu(poses), cu(patches), cu(intr), cu(target[sel]), cu(weight[sel]), cu(np.array([1e-4], np.float32)), cu(ii[sel]),
            cu(jj[sel]), cu(kk[sel]), 0, 4, 1, info)
     assert int(info.item()) & 2 == 0
+
+
+def test_ba_eff_impl_at_config5_size():
+    """BASELINE configs[4]'s bundle adjustment (32 free keyframes: a 192 x 192 Schur system, 256 patches per frame,
+    lifetime 33, ~10k patch depths, ~0.6M edges) with ``eff_impl=True``: against the oracle's restatement of the
+    reference's block-sparse E lookup (fastba/block_e.cu:43-283, ``orc.ba(eff_ppf=...)``), which itself agrees with the
+    dense restatement; the flag does not change this implementation's result (one storage serves both)."""
+    import time
+    from rampvo_amd import fastba, _lib
+    M, NF, N = 256, 50, 32
+    s = ba_scene(seed=31, n_frames=NF, M=M, lifetime=33, H=180, W=320, noise=0.4, n_total_frames=NF + 2)
+    E = len(s["ii"])
+    assert E > 500000
+    t0, t1 = NF - N, NF
+    w = (s["weight"] * 1e-2).astype(np.float32)      # small confidences keep this random problem well conditioned
+    rp, rpt = s["poses"].copy(), s["patches"].copy()
+    tic = time.perf_counter()
+    st = orc.ba(rp, rpt, s["intr"], s["target"], w, s["lmbda"], s["ii"], s["jj"], s["kk"], t0, t1, 2, eff_ppf=M)
+    t_cpu = time.perf_counter() - tic
+    dp, dpt = s["poses"].copy(), s["patches"].copy()
+    orc.ba(dp, dpt, s["intr"], s["target"], w, s["lmbda"], s["ii"], s["jj"], s["kk"], t0, t1, 2)
+    step = float(np.abs(rp - s["poses"]).max())
+    assert st == 0 and step > 1e-4
+    assert np.abs(rp - dp).max() <= 1e-5 * max(1.0, step) and np.abs(rpt - dpt).max() <= 1e-4        # lookup == dense
+    out = {}
+    for eff in (True, False):
+        poses, patches = cu(s["poses"]), cu(s["patches"])
+        info = torch.zeros(1, dtype=torch.int32, device="cuda")
+        args = (cu(s["intr"]), cu(s["target"]), cu(w), cu(s["lmbda"]), cu(s["ii"]), cu(s["jj"]), cu(s["kk"]), t0, t1)
+        fastba.BA(poses, patches, *args, M=M, iterations=2, eff_impl=eff, info=info)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        p2, pt2 = cu(s["poses"]), cu(s["patches"])
+        a.record()
+        fastba.BA(p2, pt2, *args, M=M, iterations=2, eff_impl=eff, info=info)
+        b.record(); torch.cuda.synchronize()
+        assert int(info.item()) == 0
+        out[eff] = (poses.cpu().numpy(), patches.cpu().numpy(), a.elapsed_time(b))
+    assert np.array_equal(out[True][0], out[False][0]) and np.array_equal(out[True][1], out[False][1])
+    scale = max(1.0, step)
+    assert np.abs(out[True][0] - rp).max() <= 1e-4 * scale, np.abs(out[True][0] - rp).max()
+    d_ref = rpt[:, 2, 1, 1]
+    assert (np.abs(out[True][1][:, 2, 1, 1] - d_ref) / np.maximum(np.abs(d_ref), 1.0)).max() <= 1e-4 * scale
+    Mu = len(np.unique(s["kk"]))
+    ws = _lib.lib().ramp_ba_workspace_bytes(E, NF + 2, (NF + 2) * M, t0, t1)
+    print("configs[4]-size BA: E=%d Mu=%d 6N=%d | per-patch E rows %.1f MB of a %.1f MB workspace | HIP %.2f ms (incl. its own "
+          "group-by) vs oracle lookup path %.1f s | |GN step| %.3g, pose err %.2e"
+          % (E, Mu, 6 * N, Mu * 6 * N * 4 / 1e6, ws / 1e6, out[True][2], t_cpu, step, np.abs(out[True][0] - rp).max()))
