@@ -18,6 +18,7 @@
 // Math restates ramp/fastba/ba_cuda.cu:232-376 (kernel), 433-582 (host loop),
 // 178-229 (retractions).  Everything is fp32 like the reference (mtype=float).
 #include "ramp_device.h"
+#include <stdlib.h>
 #include "ramp_internal.h"
 
 #define BA_REC 32     // floats per edge record
@@ -548,6 +549,141 @@ __global__ void __launch_bounds__(64)
   if (i < n6) dX[i] = bad ? 0.0f : x;                      // see ba_chol_kernel: a failed factorisation drops the pose step
 }
 
+// Blocked variant (block width 6 = one pose).  Per block column every thread factors the 6 x 6 diagonal block in
+// REGISTERS (21 broadcast LDS reads, then no LDS traffic inside the dependency chain: with the block left in LDS the
+// loads cannot move above the stores and every one of them is an exposed round trip), the row threads solve their
+// panel row against it, and the whole workgroup applies the rank-6 update to the trailing matrix on a TG x TG thread
+// grid -- two barriers per pose instead of one per column.  The right-hand side rides along as row n6 (z = L^-1 y
+// falls out of the panel solves); the back substitution is blocked the same way.
+template <int TG>
+__global__ void __launch_bounds__(TG * TG)
+    ba_cholb_kernel(const float *__restrict__ S, const float *__restrict__ yv,
+                    float *__restrict__ dX, int32_t *__restrict__ info, int n6) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int ld = n6 + 1;                       // odd for every 6N: conflict-free column walks
+  float *A = sm;                               // (n6 + 1) x ld: rows 0..n6-1 = S (lower triangle), row n6 = y
+  float *xv = sm + (n6 + 1) * ld;              // n6: solution
+  float *Lk = xv + n6;                         // nb x 28: the factored diagonal blocks (21 lower entries + 6 inverses)
+  __shared__ int s_bad;
+  const int tid = threadIdx.x, nt = TG * TG;
+  const int ty = tid / TG, tx = tid % TG;
+  {
+    int r = tid / n6, c = tid - r * n6;        // one division, then stepping
+    const int dr = nt / n6, dc = nt - dr * n6;
+    for (int q = tid; q < n6 * n6; q += nt) {
+      A[r * ld + c] = S[q];
+      r += dr; c += dc;
+      if (c >= n6) { c -= n6; r++; }
+    }
+  }
+  for (int q = tid; q < n6; q += nt) A[n6 * ld + q] = yv[q];
+  if (tid == 0) s_bad = 0;
+  __syncthreads();
+  const int nb = n6 / 6;
+  for (int kb = 0; kb < nb; kb++) {
+    const int c0 = 6 * kb;
+    const int r0 = c0 + 6, m = n6 - r0;        // m trailing columns, m + 1 rows (rhs)
+    // only the waves that own a panel row factor the block (tid 0 is one of them: row n6 always exists)
+    if ((tid & ~63) <= m) {
+    float l[6][6], li[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+      for (int j = 0; j <= i; j++) l[i][j] = A[(c0 + i) * ld + c0 + j];
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      float d = l[j][j];
+#pragma unroll
+      for (int k = 0; k < j; k++) d = __builtin_fmaf(-l[j][k], l[j][k], d);
+      bad |= !(d > 0.0f);
+      li[j] = __builtin_amdgcn_rsqf(d);          // v_rsq_f32, 1 ulp; d is O(1..1e6) here, no denormal range
+      l[j][j] = d * li[j];
+#pragma unroll
+      for (int i = j + 1; i < 6; i++) {
+        float t = l[i][j];
+#pragma unroll
+        for (int k = 0; k < j; k++) t = __builtin_fmaf(-l[i][k], l[j][k], t);
+        l[i][j] = t * li[j];
+      }
+    }
+    if (tid == 0) {
+      int q = 0;
+#pragma unroll
+      for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j <= i; j++) Lk[kb * 28 + q++] = l[i][j];
+#pragma unroll
+      for (int j = 0; j < 6; j++) Lk[kb * 28 + 21 + j] = li[j];
+      if (bad) s_bad = 1;
+    }
+    // panel: rows below the block (and the rhs row n6): X L_kk' = A_ik  ->  forward substitution along the row
+    for (int i = c0 + 6 + tid; i <= n6; i += nt) {
+      float x[6];
+#pragma unroll
+      for (int j = 0; j < 6; j++) x[j] = A[i * ld + c0 + j];
+#pragma unroll
+      for (int j = 0; j < 6; j++) {
+#pragma unroll
+        for (int k = 0; k < j; k++) x[j] = __builtin_fmaf(-x[k], l[j][k], x[j]);
+        x[j] *= li[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 6; j++) A[i * ld + c0 + j] = x[j];
+    }
+    }
+    __syncthreads();
+    // trailing update: A[i][j] -= sum_k L[i][c0+k] L[j][c0+k],  c0 + 6 <= j <= i <= n6,  j < n6
+    for (int ii = ty; ii <= m; ii += TG) {
+      float ri[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) ri[k] = A[(r0 + ii) * ld + c0 + k];
+      const int jmax = ii < m - 1 ? ii : m - 1;
+      for (int jj = tx; jj <= jmax; jj += TG) {
+        const float *rj = A + (r0 + jj) * ld + c0;
+        float t = A[(r0 + ii) * ld + r0 + jj];
+#pragma unroll
+        for (int k = 0; k < 6; k++) t = __builtin_fmaf(-ri[k], rj[k], t);
+        A[(r0 + ii) * ld + r0 + jj] = t;
+      }
+    }
+    __syncthreads();
+  }
+  const bool bad = s_bad != 0;
+  if (bad && tid == 0 && info) atomicOr(info, 1);
+  // L' x = z (z = row n6), block by block from the bottom
+  for (int kb = nb - 1; kb >= 0; kb--) {
+    const int c0 = 6 * kb;
+    if (tid < 64) {                            // wave 0 (uniform work, lane 0 writes)
+      float lk[27], x[6];
+#pragma unroll
+      for (int q = 0; q < 27; q++) lk[q] = Lk[kb * 28 + q];
+#pragma unroll
+      for (int j = 0; j < 6; j++) x[j] = A[n6 * ld + c0 + j];
+#pragma unroll
+      for (int j = 5; j >= 0; j--) {
+#pragma unroll
+        for (int k = j + 1; k < 6; k++) x[j] = __builtin_fmaf(-lk[k * (k + 1) / 2 + j], x[k], x[j]);
+        x[j] *= lk[21 + j];
+      }
+      if (tid == 0) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) xv[c0 + j] = x[j];
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < c0; i += nt) {       // z_i -= sum_k L[c0+k][i] x[c0+k]
+      float t = A[n6 * ld + i];
+#pragma unroll
+      for (int k = 0; k < 6; k++) t = __builtin_fmaf(-A[(c0 + k) * ld + i], xv[c0 + k], t);
+      A[n6 * ld + i] = t;
+    }
+    __syncthreads();
+  }
+  // a failed factorisation drops the pose step (see ba_chol_kernel)
+  for (int q = tid; q < n6; q += nt) dX[q] = bad ? 0.0f : xv[q];
+}
+
 // ------------------------------------------------------------------ K7
 __global__ void __launch_bounds__(256)
     ba_retract_kernel(float *__restrict__ poses, float *__restrict__ patches,
@@ -651,6 +787,16 @@ static size_t ba_carve(void *ws, int E, int n_poses, int n_patches, int N, int o
   return off;
 }
 
+// RAMP_BA_CHOL: 0 / unset = blocked kernel (default), 1 = blocked (forced), 2 = the per-column kernels (A/B runs)
+static int ba_chol_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("RAMP_BA_CHOL");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+
 // the GN iterations, given the two groupings
 static int ba_iterate(float *poses, float *patches, const float *intrinsics, const float *target,
                       const float *weight, const float *lmbda, const int64_t *ii, const int64_t *jj,
@@ -659,10 +805,12 @@ static int ba_iterate(float *poses, float *patches, const float *intrinsics, con
                       const int32_t *order_p, const int32_t *seg_p, const int32_t *np, int32_t *info,
                       hipStream_t st) {
   const int N = t1 - t0, n6 = 6 * N;
-  const size_t lds = (size_t)((n6 + 1) * (n6 + 1) + 2 * n6) * sizeof(float);
+  const size_t lds = (size_t)((n6 + 1) * (n6 + 1) + 6 * n6) * sizeof(float);
   const int PP = P * P, c11 = 1 * P + 1;
-  if (N > 0 && n6 > 64 && lds > 64 * 1024) {
+  if (N > 0 && lds > 64 * 1024) {
     if (hipFuncSetAttribute((const void *)ba_chol_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess ||
+        hipFuncSetAttribute((const void *)ba_cholb_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
       return RAMP_ELAUNCH;
   }
@@ -684,7 +832,10 @@ static int ba_iterate(float *poses, float *patches, const float *intrinsics, con
                          w.Qv, w.uv, nk, w.S_part, w.y_part, n6, w.KS);
       hipLaunchKernelGGL(ba_assemble_kernel, dim3(N, ramp_cdiv(6 * n6, 192)), dim3(256), 0, st, w.pairs, w.pair_ij, np,
                          w.S_part, w.y_part, w.S, w.yv, n6, w.KS, info);
-      if (n6 <= 63)
+      const int chol = ba_chol_variant();
+      if (chol == 1 || (chol == 0 && n6 % 6 == 0))      // blocked: every 6N
+        hipLaunchKernelGGL(ba_cholb_kernel<32>, dim3(1), dim3(1024), lds, st, w.S, w.yv, w.dX, info, n6);
+      else if (n6 <= 63)
         hipLaunchKernelGGL(ba_chol64_kernel, dim3(1), dim3(64), 0, st, w.S, w.yv, w.dX, info, n6);
       else
         hipLaunchKernelGGL(ba_chol_kernel, dim3(1), dim3(1024), lds, st, w.S, w.yv, w.dX, info, n6);
