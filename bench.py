@@ -279,7 +279,7 @@ class BaTimer:
 class EncoderTimer:
     """HIP events around the encoder front end (one hipGraph replay per frame: fused LSTM + conv towers
     + patch selection + gathers) and the conv FLOPs of one frame, counted from the shapes of the
-    ramp_conv2d_nhwc calls of an eager (un-captured) frame."""
+    conv launches of an eager (un-captured) frame."""
 
     def __init__(self):
         self.pairs, self.enabled = [], False
@@ -287,16 +287,17 @@ class EncoderTimer:
 
     def install(self, net):
         from rampvo_amd import conv_hip
-        timer, conv_inner = self, conv_hip.conv2d
+        timer, towers_inner = self, conv_hip.conv2d_towers
 
-        def counted(x, conv, *a, **k):
-            y = conv_inner(x, conv, *a, **k)
-            o = y.raw if isinstance(y, conv_hip.Pending) else y
-            cout, cin, kh, kw = conv.weight.shape
-            timer._acc += 2 * o.shape[0] * o.shape[1] * cout * cin * kh * kw
-            return y
+        def counted(jobs, half):                      # every conv of the towers goes through conv2d_towers
+            ys = towers_inner(jobs, half)
+            for j, y in zip(jobs, ys):
+                o = y.raw if isinstance(y, conv_hip.Pending) else y
+                cout, cin, kh, kw = j["conv"].weight.shape
+                timer._acc += 2 * o.shape[0] * o.shape[1] * cout * cin * kh * kw
+            return ys
 
-        conv_hip.conv2d = counted
+        conv_hip.conv2d_towers = counted
         pat = net.patchify
         impl_inner, fwd_inner = pat._forward_impl, pat.forward
 

@@ -64,6 +64,16 @@ int ramp_patchify_fwd(const void *net, const float *coords, void *out, int n, in
                       int W, int M, int radius, int bilinear, int dtype, int layout,
                       int out_layout, void *stream);
 
+/* All per-frame gathers at the M patch centres in one launch (ramp/net.py:167-203: gmap = 3x3 patches of fmap, imap =
+ * 1x1 of the context map, the 3x3 (x, y, disparity=1) patches of the coordinate grid, the colours of the full-resolution
+ * image at 4*(coords+0.5); Ramp_vo.py:353-354: uint8 BGR colours).  Bit-identical to the four ramp_patchify_fwd calls.
+ *   fmap [h][w][CF], imap [h][w][CI] (NHWC, dtype RAMP_F32 / RAMP_F16); image [3][H][W] fp32; coords [M][2] fp32
+ *   -> gmap [M][3][3][CF], imap_p [M][CI] (dtype), patches [M][3][3][3] fp32 (channel-major), clr [M][3] fp32,
+ *      colors [M][3] uint8 (BGR)                                                                                  */
+int ramp_frame_gather(const void *fmap, const void *imap, const float *image, const float *coords, void *gmap,
+                      void *imap_p, float *patches, float *clr, unsigned char *colors, int M, int h, int w, int H,
+                      int W, int CF, int CI, int dtype, void *stream);
+
 /* cuda_corr.forward (ramp/altcorr/correlation.cpp:28-35,
  * correlation_kernel.cu:82-136 + host blend/permute 193-233), fused over the
  * levels of the feature pyramid and with the torch.stack(..., -1) of
@@ -343,6 +353,22 @@ int ramp_conv2d_nhwc(const void *x, const void *wpk, const float *bias, const fl
                      int Cin, int Cout, int KH, int KW, int stride, int relu, float out_scale,
                      int dtype, void *stream);
 
+/* One layer of up to TWO independent conv problems of the same shape (the fmap and imap towers read the same input
+ * through the same layer shapes and differ in weights, norm and the last layer's Cout) as ONE launch of the
+ * LDS-tiled fp16 kernel; fields as the arguments of ramp_conv2d_nhwc (stats: reduce with ramp_in_stats_finalize).
+ * RAMP_EUNSUPPORTED for layer shapes the tiled kernel does not cover (use ramp_conv2d_nhwc).                     */
+typedef struct ramp_conv_job {
+  const void *x, *wpk;
+  const float *bias, *pre_scale, *pre_shift;
+  const void *res;
+  void *y;
+  float *stats;
+  int32_t Cout, relu;
+  float out_scale;
+} ramp_conv_job;
+int ramp_conv2d_nhwc_multi(const ramp_conv_job *jobs, int njobs, int H, int W, int Cin, int KH, int stride,
+                           int dtype, void *stream);
+
 /* dtype of ramp_conv2d_nhwc: RAMP_F32 (fp32 in/out, exact fp32 MFMA), RAMP_F16 (half in/out, fp16
  * MFMA, fp32 accumulation / bias / statistics; Cin % 32 == 0) or RAMP_F16|RAMP_IN_F32 (fp32 in,
  * half out: the first layer of the mixed-precision tower, Cin == 16)                            */
@@ -366,8 +392,10 @@ int ramp_affine_relu(const float *x, const float *s, const float *h, float *out,
 /* half-storage variants (x, y, skip, out are half; scale/shift stay fp32) */
 int ramp_affine_relu_f16(const void *x, const float *s, const float *h, void *out, long n, int C,
                          void *stream);
+/* skip_relu: the skip operand is relu(skip*ss + hs) (an InstanceNorm + ReLU that was never materialised) */
 int ramp_norm_add_relu_f16(const void *y, const float *sy, const float *hy, const void *skip,
-                           const float *ss, const float *hs, void *out, long n, int C, void *stream);
+                           const float *ss, const float *hs, void *out, long n, int C, int skip_relu,
+                           void *stream);
 
 /* residual-block tail: out = relu( skip' + relu(y*sy + hy) ), skip' = skip*ss + hs if ss else skip
  * (ramp/extractor.py:49-57 with the norms folded in)                                           */

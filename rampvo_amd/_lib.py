@@ -16,6 +16,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("RAMP_HIP_LIB") or os.path.join(CSRC, "libramp_hip.so")   # env: kernel A/B builds
 
 RAMP_F32, RAMP_F16 = 0, 1
+RAMP_EUNSUPPORTED = -4
 RAMP_IN_F32, RAMP_CONV_DIRECT, RAMP_CORR_MFMA32 = 0x10, 0x20, 0x40
 RAMP_NCHW, RAMP_NHWC, RAMP_NHWC8 = 0, 1, 2
 
@@ -33,6 +34,7 @@ class CorrLevel(ctypes.Structure):
 SIGNATURES = {
     "ramp_version": (ctypes.c_char_p, []),
     "ramp_patchify_fwd": (c_i, [c_p, c_p, c_p] + [c_i] * 10 + [c_p]),
+    "ramp_frame_gather": (c_i, [c_p] * 9 + [c_i] * 8 + [c_p]),
     "ramp_corr_fwd": (c_i, [c_p, ctypes.POINTER(CorrLevel), c_i, c_p, c_p, c_p, c_p] + [c_i] * 8 + [c_p]),
     "ramp_ms_lstm_superstate": (c_i, [c_p, c_p, ctypes.POINTER(c_p), c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "ramp_conv2d_stats_blocks": (c_i, [c_i] * 7),
@@ -81,7 +83,8 @@ SIGNATURES = {
     "ramp_affine_relu": (c_i, [c_p, c_p, c_p, c_p, ctypes.c_long, c_i, c_p]),
     "ramp_norm_add_relu": (c_i, [c_p] * 7 + [ctypes.c_long, c_i, c_p]),
     "ramp_affine_relu_f16": (c_i, [c_p, c_p, c_p, c_p, ctypes.c_long, c_i, c_p]),
-    "ramp_norm_add_relu_f16": (c_i, [c_p] * 7 + [ctypes.c_long, c_i, c_p]),
+    "ramp_norm_add_relu_f16": (c_i, [c_p] * 7 + [ctypes.c_long, c_i, c_i, c_p]),
+    "ramp_conv2d_nhwc_multi": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "ramp_upd_row_fuse": (c_i, [c_p] * 6 + [ctypes.c_long, c_p, c_p, c_p, c_p, c_f, c_i, c_p, c_p, c_i, c_i, c_p]),
     "ramp_upd_gather_mask": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p]),
     "ramp_upd_gated": (c_i, [c_p] * 5 + [c_f, c_p, c_p, c_p, c_i, c_i, c_p]),

@@ -3,6 +3,9 @@ implicit-GEMM MFMA conv towers (csrc/conv.hip).  Activations are NHWC float32 te
 [H, W, C]; InstanceNorm + ReLU are never materialised on their own -- they ride on the
 consumer conv's load path (``pre``) or on the residual-block tail kernel.
 """
+import ctypes
+import os
+
 import torch
 import torch.nn as nn
 
@@ -103,11 +106,32 @@ def pack_lstm_mfma(enc):
 
 # ------------------------------------------------------------------------ primitives
 class Pending:
-    """a raw conv output whose InstanceNorm(+ReLU) has not been applied yet"""
-    __slots__ = ("raw", "scale", "shift")
+    """a raw conv output whose InstanceNorm has not been applied yet; ``relu``: the norm is followed by a ReLU
+    (conv1 / the residual block's convs) or not (the downsample path's norm3)"""
+    __slots__ = ("raw", "scale", "shift", "relu")
 
-    def __init__(self, raw, scale, shift):
-        self.raw, self.scale, self.shift = raw, scale, shift
+    def __init__(self, raw, scale, shift, relu=True):
+        self.raw, self.scale, self.shift, self.relu = raw, scale, shift, relu
+
+
+class ConvJob(ctypes.Structure):
+    """include/ramp_hip.h::ramp_conv_job"""
+    _fields_ = [("x", ctypes.c_void_p), ("wpk", ctypes.c_void_p), ("bias", ctypes.c_void_p),
+                ("pre_scale", ctypes.c_void_p), ("pre_shift", ctypes.c_void_p), ("res", ctypes.c_void_p),
+                ("y", ctypes.c_void_p), ("stats", ctypes.c_void_p),
+                ("Cout", ctypes.c_int32), ("relu", ctypes.c_int32), ("out_scale", ctypes.c_float)]
+
+
+def _conv_mode(x, half, direct=False):
+    if not half:
+        return "f32", RAMP_F32, torch.float32
+    if x.dtype == torch.float32:
+        mode, code = "f16_first", _lib.RAMP_F16 | _lib.RAMP_IN_F32
+    else:
+        mode, code = "f16", _lib.RAMP_F16
+    if direct:
+        code |= _lib.RAMP_CONV_DIRECT        # the one-round-trip-per-tap kernel (A/B test of the LDS-tiled one)
+    return mode, code, torch.float16
 
 
 def conv2d(x, conv, pre=None, res=None, relu=False, want_stats=False, out_scale=1.0, eps=1e-5, half=False,
@@ -116,16 +140,10 @@ def conv2d(x, conv, pre=None, res=None, relu=False, want_stats=False, out_scale=
     half out and half in (fp32 in allowed for the 16-channel first layer).  Returns y [OH,OW,Cout],
     or Pending(y, scale, shift) when want_stats (InstanceNorm statistics of y, always fp32)."""
     if isinstance(x, Pending):
+        assert x.relu
         pre, x = (x.scale, x.shift), x.raw
     H, W, Cin = x.shape
-    if not half:
-        mode, code, odt = "f32", RAMP_F32, torch.float32
-    elif x.dtype == torch.float32:
-        mode, code, odt = "f16_first", _lib.RAMP_F16 | _lib.RAMP_IN_F32, torch.float16
-    else:
-        mode, code, odt = "f16", _lib.RAMP_F16, torch.float16
-    if direct and half:
-        code |= _lib.RAMP_CONV_DIRECT        # the one-round-trip-per-tap kernel (A/B test of the LDS-tiled one)
+    mode, code, odt = _conv_mode(x, half, direct)
     wpk, bias = pack_conv_weight(conv, mode)
     cout, _, kh, kw = conv.weight.shape
     stride = conv.stride[0]
@@ -151,6 +169,71 @@ def conv2d(x, conv, pre=None, res=None, relu=False, want_stats=False, out_scale=
     return Pending(y, scale, shift)
 
 
+def conv2d_towers(jobs, half):
+    """one layer of every tower: ``jobs`` = [dict(x=, conv=, res=None, relu=False, want_stats=False, out_scale=1.0,
+    eps=1e-5)] with the same layer shape.  Two fp16 towers go out as ONE launch of the LDS-tiled kernel
+    (ramp_conv2d_nhwc_multi) followed by the statistics' finalize launch where a tower has a norm; anything else
+    (fp32 towers, shapes the tiled kernel does not cover) is the per-tower conv2d() above.  Returns one tensor /
+    Pending per job.  (Finalising the statistics inside the conv launch -- last workgroup per tile row, then last
+    row -- was measured and dropped: the device-scope release every workgroup needs before its ticket writes the
+    XCD's L2 back, 1.24 ms per front end instead of 0.47.)"""
+    def single():
+        return [conv2d(j["x"], j["conv"], res=j.get("res"), relu=j.get("relu", False),
+                       want_stats=j.get("want_stats", False), out_scale=j.get("out_scale", 1.0),
+                       eps=j.get("eps", 1e-5), half=half) for j in jobs]
+    if not half or len(jobs) > 2 or os.environ.get("RAMP_TOWER_PAIR", "1") != "1":
+        return single()
+    x0 = jobs[0]["x"].raw if isinstance(jobs[0]["x"], Pending) else jobs[0]["x"]
+    H, W, Cin = x0.shape
+    mode, code, odt = _conv_mode(x0, True)
+    c0 = jobs[0]["conv"]
+    kh, stride = c0.weight.shape[2], c0.stride[0]
+    OH = (H + 2 * (kh // 2) - kh) // stride + 1
+    OW = (W + 2 * (kh // 2) - kh) // stride + 1
+    nblk = lib().ramp_conv2d_stats_blocks(H, W, Cin, c0.weight.shape[0], kh, stride, code)
+    tiles_y = (OH + 7) // 8
+    if nblk != tiles_y * ((OW + 15) // 16):
+        return single()                          # not a tiled-kernel layer shape
+    arr = (ConvJob * len(jobs))()
+    outs, finalize = [], []
+    for t, j in enumerate(jobs):
+        x, conv = j["x"], j["conv"]
+        pre = None
+        if isinstance(x, Pending):
+            assert x.relu
+            pre, x = (x.scale, x.shift), x.raw
+        wpk, bias = pack_conv_weight(conv, mode)
+        cout = conv.weight.shape[0]
+        assert tuple(x.shape) == (H, W, Cin) and x.dtype == x0.dtype and x.is_contiguous()
+        assert conv.weight.shape[2] == kh and conv.stride[0] == stride and conv.padding[0] == kh // 2
+        assert Cin == wpk.shape[1] * (32 if mode == "f16" else 16)
+        res = j.get("res")
+        assert res is None or (res.is_contiguous() and res.dtype == odt)
+        y = torch.empty(OH, OW, cout, dtype=odt, device=x.device)
+        a = arr[t]
+        a.x, a.wpk, a.bias = ptr(x), ptr(wpk), ptr(bias)
+        a.pre_scale, a.pre_shift = (ptr(pre[0]), ptr(pre[1])) if pre else (None, None)
+        a.res, a.y = ptr(res), ptr(y)
+        a.Cout, a.relu, a.out_scale = cout, int(j.get("relu", False)), float(j.get("out_scale", 1.0))
+        if j.get("want_stats", False):
+            ws = torch.empty(cout * 2 * nblk + 2 * cout, dtype=torch.float32, device=x.device)
+            scale, shift, stats = ws[:cout], ws[cout:2 * cout], ws[2 * cout:]
+            a.stats = ptr(stats)
+            finalize.append((stats, cout, scale, shift, float(j.get("eps", 1e-5))))
+            outs.append(Pending(y, scale, shift))
+        else:
+            a.stats = None
+            outs.append(y)
+    rc = lib().ramp_conv2d_nhwc_multi(arr, len(jobs), H, W, Cin, kh, stride, code, stream())
+    if rc == _lib.RAMP_EUNSUPPORTED:
+        return single()
+    check(rc, "ramp_conv2d_nhwc_multi")
+    for stats, cout, scale, shift, eps in finalize:
+        check(lib().ramp_in_stats_finalize(ptr(stats), nblk, cout, float(OH * OW), eps, ptr(scale), ptr(shift),
+                                           stream()), "ramp_in_stats_finalize")
+    return outs
+
+
 def materialize(p):
     """relu(norm(raw))"""
     out = torch.empty_like(p.raw)
@@ -161,61 +244,91 @@ def materialize(p):
 
 
 def norm_add_relu(y, skip):
-    """relu(skip' + relu(norm(y)));  skip is a tensor or a Pending (norm, no ReLU)"""
+    """relu(skip' + relu(norm(y)));  skip is a tensor or a Pending (its norm, with or without ReLU, applied here)"""
     out = torch.empty_like(y.raw)
     s_raw, ss, hs = (skip.raw, skip.scale, skip.shift) if isinstance(skip, Pending) else (skip, None, None)
-    fn = lib().ramp_norm_add_relu_f16 if y.raw.dtype == torch.float16 else lib().ramp_norm_add_relu
-    check(fn(ptr(y.raw), ptr(y.scale), ptr(y.shift), ptr(s_raw), ptr(ss), ptr(hs), ptr(out), y.raw.numel(),
-             y.raw.shape[-1], stream()), "ramp_norm_add_relu")
+    if y.raw.dtype == torch.float16:
+        check(lib().ramp_norm_add_relu_f16(ptr(y.raw), ptr(y.scale), ptr(y.shift), ptr(s_raw), ptr(ss), ptr(hs),
+                                           ptr(out), y.raw.numel(), y.raw.shape[-1],
+                                           int(isinstance(skip, Pending) and skip.relu), stream()),
+              "ramp_norm_add_relu_f16")
+        return out
+    if isinstance(skip, Pending) and skip.relu:
+        s_raw, ss, hs = materialize(skip), None, None
+    check(lib().ramp_norm_add_relu(ptr(y.raw), ptr(y.scale), ptr(y.shift), ptr(s_raw), ptr(ss), ptr(hs), ptr(out),
+                                   y.raw.numel(), y.raw.shape[-1], stream()), "ramp_norm_add_relu")
     return out
 
 
 # --------------------------------------------------------------------------- towers
-def _res_block(blk, x, norm, half):
-    """reference ResidualBlock.forward (extractor.py:49-57)"""
-    if norm:
-        y = conv2d(x, blk.conv1, want_stats=True, half=half)
-        y = conv2d(y, blk.conv2, want_stats=True, half=half)
-        skip = x if blk.downsample is None else conv2d(x, blk.downsample[0], want_stats=True, half=half)
-        return norm_add_relu(y, skip)
-    y = conv2d(x, blk.conv1, relu=True, half=half)
-    skip = x if blk.downsample is None else conv2d(x, blk.downsample[0], half=half)
-    return conv2d(y, blk.conv2, res=skip, relu=True, half=half)       # relu(skip + relu(conv2(y)))
+def _res_blocks(blks, xs, norms, half):
+    """reference ResidualBlock.forward (extractor.py:49-57) for the same block of every tower, one launch per
+    conv for all of them.  xs[t]: tensor, or (norm towers, first block) the Pending relu(norm(conv1))."""
+    job = lambda t, x, conv, **k: dict(x=x, conv=conv, want_stats=norms[t], **k)
+    T = range(len(blks))
+    skips = list(xs)
+    if blks[0].downsample is not None:
+        skips = conv2d_towers([job(t, xs[t], blks[t].downsample[0]) for t in T], half)
+        for t in T:
+            if norms[t]:
+                skips[t].relu = False            # norm3 has no ReLU behind it
+    y = conv2d_towers([job(t, xs[t], blks[t].conv1, relu=not norms[t]) for t in T], half)
+    # plain towers: relu(skip + relu(conv2(y))) in the conv's epilogue
+    y = conv2d_towers([job(t, y[t], blks[t].conv2, relu=not norms[t], res=None if norms[t] else skips[t])
+                       for t in T], half)
+    return [norm_add_relu(y[t], skips[t]) if norms[t] else y[t] for t in T]
+
+
+def _tower_norms(encs):
+    norms = [isinstance(e.norm1, nn.InstanceNorm2d) for e in encs]
+    for e, n in zip(encs, norms):
+        assert n or (isinstance(e.norm1, nn.Sequential) and len(e.norm1) == 0)
+    return norms
+
+
+def _first_layer(encs, x, norms, half):
+    xs = conv2d_towers([dict(x=x, conv=e.conv1, want_stats=n, relu=not n, eps=e.norm1.eps if n else 1e-5)
+                        for e, n in zip(encs, norms)], half)
+    if not half:                                  # fp32 tail kernel takes a materialised skip
+        xs = [materialize(v) if isinstance(v, Pending) else v for v in xs]
+    return xs
+
+
+def basic_encoder4_towers(encs, x, out_scale=1.0, half=False):
+    """BasicEncoder4._forward of every tower in ``encs`` on one NHWC image x [H,W,Cin_padded] -> [H/4,W/4,out] each
+    (``half``: fp16 storage + fp16 MFMA after the first layer's fp32 input).  relu(norm1(conv1)) is never
+    materialised: layer1's first conv applies it while loading, the block's tail while adding the skip."""
+    norms = _tower_norms(encs)
+    xs = _first_layer(encs, x, norms, half)
+    for li in ("layer1", "layer2"):
+        for b in range(2):
+            xs = _res_blocks([getattr(e, li)[b] for e in encs], xs, norms, half)
+    return conv2d_towers([dict(x=xs[t], conv=e.conv2, out_scale=out_scale) for t, e in enumerate(encs)], half)
 
 
 def basic_encoder4(enc, x, out_scale=1.0, half=False):
-    """BasicEncoder4._forward on one NHWC image x [H,W,Cin_padded] -> [H/4,W/4,out]
-    (``half``: fp16 storage + fp16 MFMA after the first layer's fp32 input)"""
-    norm = isinstance(enc.norm1, nn.InstanceNorm2d)
-    if norm:
-        x = materialize(conv2d(x, enc.conv1, want_stats=True, eps=enc.norm1.eps, half=half))
-    else:
-        assert isinstance(enc.norm1, nn.Sequential) and len(enc.norm1) == 0
-        x = conv2d(x, enc.conv1, relu=True, half=half)
-    for blk in enc.layer1:
-        x = _res_block(blk, x, norm, half)
-    for blk in enc.layer2:
-        x = _res_block(blk, x, norm, half)
-    return conv2d(x, enc.conv2, out_scale=out_scale, half=half)
+    return basic_encoder4_towers([enc], x, out_scale, half)[0]
+
+
+def multiscale_encoder4_towers(encs, x, x2, x4, out_scale=1.0, half=False):
+    """MultiScaleBasicEncoder4.forward (reference extractor.py:288-311) of every tower on NHWC inputs: x [H,W,16],
+    x2 [H/2,W/2,32] and x4 [H/4,W/4,64] (the three super-states) -> [H/4,W/4,out].  The channel
+    concatenations are the only non-conv steps; layer2/conv2 are unused, as upstream."""
+    norms = _tower_norms(encs)
+    xs = _first_layer(encs, x, norms, half)
+    for b in range(2):
+        xs = _res_blocks([e.layer1[b] for e in encs], xs, norms, half)
+    x2 = x2.to(xs[0].dtype)
+    xs = [torch.cat((v, x2), dim=-1) for v in xs]
+    for b in range(2):
+        xs = _res_blocks([e.layer3[b] for e in encs], xs, norms, half)
+    x4 = x4.to(xs[0].dtype)
+    xs = [torch.cat((v, x4), dim=-1) for v in xs]
+    return conv2d_towers([dict(x=xs[t], conv=e.conv3, out_scale=out_scale) for t, e in enumerate(encs)], half)
 
 
 def multiscale_encoder4(enc, x, x2, x4, out_scale=1.0, half=False):
-    """MultiScaleBasicEncoder4.forward (reference extractor.py:288-311) on NHWC inputs: x [H,W,16],
-    x2 [H/2,W/2,32] and x4 [H/4,W/4,64] (the three super-states) -> [H/4,W/4,out].  The channel
-    concatenations are the only non-conv steps; layer2/conv2 are unused, as upstream."""
-    norm = isinstance(enc.norm1, nn.InstanceNorm2d)
-    if norm:
-        x = materialize(conv2d(x, enc.conv1, want_stats=True, eps=enc.norm1.eps, half=half))
-    else:
-        assert isinstance(enc.norm1, nn.Sequential) and len(enc.norm1) == 0
-        x = conv2d(x, enc.conv1, relu=True, half=half)
-    for blk in enc.layer1:
-        x = _res_block(blk, x, norm, half)
-    x = torch.cat((x, x2.to(x.dtype)), dim=-1)
-    for blk in enc.layer3:
-        x = _res_block(blk, x, norm, half)
-    x = torch.cat((x, x4.to(x.dtype)), dim=-1)
-    return conv2d(x, enc.conv3, out_scale=out_scale, half=half)
+    return multiscale_encoder4_towers([enc], x, x2, x4, out_scale, half)[0]
 
 
 # ------------------------------------------------------------------ LSTM / super-state

@@ -69,6 +69,91 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// Everything the tracker gathers at a frame's patch centres, one launch (reference ramp/net.py:167-203: four patchify
+// calls -- gmap 3x3x128 from fmap, imap 1x1x384, the 3x3 (x, y, disparity) patches from the coordinate grid, the colours from
+// the full-resolution image -- plus the elementwise steps around them, and Ramp_vo.py:353-354's uint8 BGR colours).
+// Same blend expression as patchify_kernel, tap by tap, so the results are bit-identical to the separate launches.
+// The coordinate grid is not read: its value at (i, j) is (j, i, 1).
+struct FrameGather {
+  const void *fmap, *imap;        // NHWC [h][w][CF], [h][w][CI]
+  const float *image;             // [3][H][W]
+  const float *coords;            // [M][2] at feature resolution
+  void *gmap, *imap_p;            // [M][3][3][CF], [M][CI]
+  float *patches, *clr;           // [M][3][3][3] (channel-major), [M][3]
+  unsigned char *colors;          // [M][3] BGR
+  int h, w, H, W, CF, CI;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) frame_gather_kernel(const FrameGather p) {
+  const int m = blockIdx.x;
+  const float x = p.coords[2 * (size_t)m + 0], y = p.coords[2 * (size_t)m + 1];
+  auto blend = [](float xx, float yy, int &fx, int &fy, float &w00, float &w01, float &w10, float &w11) {
+    const float flx = floorf(xx), fly = floorf(yy);
+    fx = ramp_f2i(flx); fy = ramp_f2i(fly);
+    const float dx = xx - flx, dy = yy - fly;
+    w00 = (1 - dy) * (1 - dx); w01 = (1 - dy) * dx; w10 = dy * (1 - dx); w11 = dy * dx;
+  };
+  int fx, fy;
+  float w00, w01, w10, w11;
+  blend(x, y, fx, fy, w00, w01, w10, w11);
+  const T *fm = reinterpret_cast<const T *>(p.fmap), *im = reinterpret_cast<const T *>(p.imap);
+  auto feat = [&](const T *base, int C, int k, long i, long j) -> float {
+    if (i < 0 || i >= p.h || j < 0 || j >= p.w) return 0.0f;
+    return ld_as_float(base + ((size_t)i * p.w + j) * C + k);
+  };
+  // gmap: radius 1, channels-last out
+  for (int o = threadIdx.x; o < 9 * p.CF; o += blockDim.x) {
+    const int k = o % p.CF, c = (o / p.CF) % 3, a = o / (p.CF * 3);
+    const long i = (long)fy + (a - 1), j = (long)fx + (c - 1);
+    float s = w00 * feat(fm, p.CF, k, i, j);
+    s = s + w01 * feat(fm, p.CF, k, i, j + 1);
+    s = s + w10 * feat(fm, p.CF, k, i + 1, j);
+    s = s + w11 * feat(fm, p.CF, k, i + 1, j + 1);
+    st_from_float(reinterpret_cast<T *>(p.gmap) + (size_t)m * 9 * p.CF + o, s);
+  }
+  // imap: radius 0
+  for (int k = threadIdx.x; k < p.CI; k += blockDim.x) {
+    float s = w00 * feat(im, p.CI, k, fy, fx);
+    s = s + w01 * feat(im, p.CI, k, fy, (long)fx + 1);
+    s = s + w10 * feat(im, p.CI, k, (long)fy + 1, fx);
+    s = s + w11 * feat(im, p.CI, k, (long)fy + 1, (long)fx + 1);
+    st_from_float(reinterpret_cast<T *>(p.imap_p) + (size_t)m * p.CI + k, s);
+  }
+  // patches: the (x, y, disparity = 1) grid, radius 1, channel-major out
+  if (threadIdx.x < 27) {
+    const int o = threadIdx.x, c = o % 3, a = (o / 3) % 3, k = o / 9;
+    auto g = [&](long i, long j) -> float {
+      if (i < 0 || i >= p.h || j < 0 || j >= p.w) return 0.0f;
+      return k == 0 ? (float)j : (k == 1 ? (float)i : 1.0f);
+    };
+    const long i = (long)fy + (a - 1), j = (long)fx + (c - 1);
+    float s = w00 * g(i, j);
+    s = s + w01 * g(i, j + 1);
+    s = s + w10 * g(i + 1, j);
+    s = s + w11 * g(i + 1, j + 1);
+    p.patches[(size_t)m * 27 + o] = s;
+  }
+  // colours: the image at 4 (coords + 0.5), radius 0
+  if (threadIdx.x >= 64 && threadIdx.x < 67) {
+    const int k = threadIdx.x - 64;
+    int qx, qy;
+    float v00, v01, v10, v11;
+    blend(4.0f * (x + 0.5f), 4.0f * (y + 0.5f), qx, qy, v00, v01, v10, v11);
+    auto px = [&](long i, long j) -> float {
+      if (i < 0 || i >= p.H || j < 0 || j >= p.W) return 0.0f;
+      return p.image[((size_t)k * p.H + i) * p.W + j];
+    };
+    float s = v00 * px(qy, qx);
+    s = s + v01 * px(qy, (long)qx + 1);
+    s = s + v10 * px((long)qy + 1, qx);
+    s = s + v11 * px((long)qy + 1, (long)qx + 1);
+    p.clr[(size_t)m * 3 + k] = s;
+    // torch's float -> uint8 goes through int64 (c10 static_cast_with_inter_type)
+    p.colors[(size_t)m * 3 + (2 - k)] = (unsigned char)(long long)((s + 0.5f) * 127.5f);
+  }
+}
+
 // -------------------------------------------------------------------- corr
 #define CORR_MAXLEV 2
 #ifndef CORR_PGB
@@ -629,6 +714,26 @@ int ramp_patchify_fwd(const void *net, const float *coords, void *out, int n, in
     hipLaunchKernelGGL(patchify_kernel<__half>, dim3(n * M), dim3(threads), 0,
                        (hipStream_t)stream, (const __half *)net, coords, (__half *)out, C, H, W,
                        M, radius, bilinear, layout, out_layout);
+  else
+    return RAMP_EINVAL;
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+
+int ramp_frame_gather(const void *fmap, const void *imap, const float *image, const float *coords, void *gmap,
+                      void *imap_p, float *patches, float *clr, unsigned char *colors, int M, int h, int w, int H,
+                      int W, int CF, int CI, int dtype, void *stream) {
+  if (M < 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || CF <= 0 || CI <= 0) return RAMP_EINVAL;
+  if (M == 0) return RAMP_OK;
+  if (!fmap || !imap || !image || !coords || !gmap || !imap_p || !patches || !clr || !colors) return RAMP_EINVAL;
+  FrameGather p;
+  p.fmap = fmap; p.imap = imap; p.image = image; p.coords = coords; p.gmap = gmap; p.imap_p = imap_p;
+  p.patches = patches; p.clr = clr; p.colors = colors;
+  p.h = h; p.w = w; p.H = H; p.W = W; p.CF = CF; p.CI = CI;
+  if (dtype == RAMP_F32)
+    hipLaunchKernelGGL(frame_gather_kernel<float>, dim3(M), dim3(256), 0, (hipStream_t)stream, p);
+  else if (dtype == RAMP_F16)
+    hipLaunchKernelGGL(frame_gather_kernel<__half>, dim3(M), dim3(256), 0, (hipStream_t)stream, p);
   else
     return RAMP_EINVAL;
   RAMP_CHECK_LAUNCH();

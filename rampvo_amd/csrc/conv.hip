@@ -71,6 +71,8 @@ struct ConvParams {
   int relu;             // ReLU on the conv output (before the residual add; the add is followed by its own ReLU)
   float out_scale;
 };
+// up to two independent problems of one layer shape in one launch (blockIdx.z): the towers of the encoder
+struct ConvMulti { ConvParams t[2]; };
 
 // fp32: wave tile 32 px x 32 ch, K chunk = 16 input channels per tap.
 // A fragment (v_mfma_f32_16x16x4_f32): lane l supplies A[i=l&15][k=l>>4]; with the channel
@@ -350,7 +352,9 @@ __global__ void __launch_bounds__(256)
 //      the residual is read and the result written as contiguous 16-byte pieces.
 // Same accumulation order as the direct kernel => identical results.
 template <int K, int S, bool IN_F32, int CIN, int NT>
-__global__ void __launch_bounds__(256) conv_tile_f16_kernel(const ConvParams p) {
+__global__ void __launch_bounds__(256) conv_tile_f16_kernel(const ConvMulti pm) {
+  const ConvParams &p = pm.t[blockIdx.z];
+  if ((int)blockIdx.y * NT * 16 >= p.Cout) return;    // the towers may differ in Cout (grid.y = the larger one's)
   constexpr int PAD = K / 2, TH = 8, TW = 16;
   constexpr int SP = K == 1 ? 1 : S;                  // tile-pixel step between output neighbours
   constexpr int STEP = K == 1 ? S : 1;                // image-pixel step between tile pixels
@@ -598,7 +602,7 @@ __global__ void __launch_bounds__(256)
     norm_add_relu_f16_kernel(const _Float16 *__restrict__ y, const float *__restrict__ sy,
                              const float *__restrict__ hy, const _Float16 *__restrict__ skip,
                              const float *__restrict__ ss, const float *__restrict__ hs,
-                             _Float16 *__restrict__ out, long n8, int C) {
+                             _Float16 *__restrict__ out, long n8, int C, int skip_relu) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n8) return;
   const int c = (int)((i * 8) % C);
@@ -610,6 +614,8 @@ __global__ void __launch_bounds__(256)
     float a = fmaxf((float)v[e] * sy[c + e] + hy[c + e], 0.f);
     float b = (float)k[e];
     if (ss) b = b * ss[c + e] + hs[c + e];
+    // skip = relu(norm(.)) that was never materialised: rounded to half as the materialised tensor would be
+    if (skip_relu) b = (float)(_Float16)fmaxf(b, 0.f);
     o[e] = (_Float16)fmaxf(a + b, 0.f);
   }
   reinterpret_cast<f16x8 *>(out)[i] = o;
@@ -896,12 +902,13 @@ int ramp_affine_relu_f16(const void *x, const float *s, const float *h, void *ou
 }
 
 int ramp_norm_add_relu_f16(const void *y, const float *sy, const float *hy, const void *skip,
-                           const float *ss, const float *hs, void *out, long n, int C, void *stream) {
-  if (!y || !sy || !hy || !skip || !out || n <= 0 || C % 8 || n % 8) return RAMP_EINVAL;
+                           const float *ss, const float *hs, void *out, long n, int C, int skip_relu,
+                           void *stream) {
+  if (!y || !sy || !hy || !skip || !out || n <= 0 || C % 8 || n % 8 || (skip_relu && !ss)) return RAMP_EINVAL;
   const long n8 = n / 8;
   hipLaunchKernelGGL(norm_add_relu_f16_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, (const _Float16 *)y, sy, hy, (const _Float16 *)skip, ss, hs,
-                     (_Float16 *)out, n8, C);
+                     (_Float16 *)out, n8, C, skip_relu);
   RAMP_CHECK_LAUNCH();
   return RAMP_OK;
 }
@@ -962,8 +969,10 @@ int ramp_conv2d_nhwc(const void *x, const void *wpk, const float *bias, const fl
     const dim3 tg(ramp_cdiv(p.OH, 8) * ramp_cdiv(p.OW, 16), 1);
 #define TILE_CASE(K, S, INF32, CIN, NT)                                                              \
   if (KH == K && stride == S && in_f32 == INF32 && Cin == CIN && Cout % (NT * 16) == 0) {             \
-    hipLaunchKernelGGL((conv_tile_f16_kernel<K, S, INF32, CIN, NT>), dim3(tg.x, Cout / (NT * 16)),     \
-                       block, 0, st, p);                                                              \
+    ConvMulti pm;                                                                                     \
+    pm.t[0] = p; pm.t[1] = p;                                                                         \
+    hipLaunchKernelGGL((conv_tile_f16_kernel<K, S, INF32, CIN, NT>), dim3(tg.x, Cout / (NT * 16), 1),  \
+                       block, 0, st, pm);                                                             \
     RAMP_CHECK_LAUNCH();                                                                              \
     return RAMP_OK;                                                                                   \
   }
@@ -991,6 +1000,49 @@ int ramp_conv2d_nhwc(const void *x, const void *wpk, const float *bias, const fl
   CONV_CASE(1, 1)
   CONV_CASE(1, 2)
 #undef CONV_CASE
+  return RAMP_EUNSUPPORTED;
+}
+
+int ramp_conv2d_nhwc_multi(const ramp_conv_job *jobs, int njobs, int H, int W, int Cin, int KH, int stride,
+                           int dtype, void *stream) {
+  if (!jobs || njobs < 1 || njobs > 2 || H <= 0 || W <= 0) return RAMP_EINVAL;
+  const bool f16 = (dtype & 0xf) == RAMP_F16, in_f32 = f16 && (dtype & RAMP_IN_F32);
+  if (!f16 || (dtype & RAMP_CONV_DIRECT)) return RAMP_EUNSUPPORTED;
+  const int pad = KH / 2;
+  const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KH) / stride + 1;
+  if (OH <= 0 || OW <= 0) return RAMP_EINVAL;
+  ConvMulti pm;
+  int cmax = 0, cgcd_ok64 = 1;
+  for (int t = 0; t < 2; t++) {
+    const ramp_conv_job &j = jobs[t < njobs ? t : 0];
+    if (!j.x || !j.wpk || !j.y || j.Cout <= 0 || j.Cout % 32) return RAMP_EINVAL;
+    ConvParams &p = pm.t[t];
+    p.x = j.x; p.wpk = j.wpk; p.bias = j.bias; p.pre_scale = j.pre_scale; p.pre_shift = j.pre_shift;
+    p.res = j.res; p.y = j.y; p.stats = j.stats;
+    p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = j.Cout;
+    p.relu = j.relu; p.out_scale = j.out_scale;
+    cmax = j.Cout > cmax ? j.Cout : cmax;
+    if (j.Cout % 64) cgcd_ok64 = 0;
+  }
+  const dim3 block(256);
+  const int tiles = ramp_cdiv(OH, 8) * ramp_cdiv(OW, 16);
+  hipStream_t st = (hipStream_t)stream;
+#define TILE_CASE(K, S, INF32, CIN, NT)                                                              \
+  if (KH == K && stride == S && in_f32 == INF32 && Cin == CIN && (NT == 2 || cgcd_ok64)) {            \
+    hipLaunchKernelGGL((conv_tile_f16_kernel<K, S, INF32, CIN, NT>), dim3(tiles, cmax / (NT * 16), njobs), \
+                       block, 0, st, pm);                                                             \
+    RAMP_CHECK_LAUNCH();                                                                              \
+    return RAMP_OK;                                                                                   \
+  }
+  TILE_CASE(7, 2, true, 16, 2)
+  TILE_CASE(3, 1, false, 32, 2)
+  TILE_CASE(3, 2, false, 32, 2)
+  TILE_CASE(3, 1, false, 64, 2)
+  TILE_CASE(1, 2, false, 32, 4)
+  TILE_CASE(1, 2, false, 64, 4)
+  TILE_CASE(1, 1, false, 64, 4)
+  TILE_CASE(1, 1, false, 128, 4)
+#undef TILE_CASE
   return RAMP_EUNSUPPORTED;
 }
 

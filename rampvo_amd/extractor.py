@@ -106,27 +106,6 @@ class MultiScaleBasicEncoder4(BasicEncoder4):
         raise RuntimeError("rampvo_amd: the conv towers run as a whole on the HIP kernels (conv_hip.multiscale_encoder4)")
 
 
-def _two_towers(owner, fmap_fn, imap_fn):
-    """the two conv towers share only their input: the imap tower runs on a side HIP stream (fork / join
-    around it, also inside the front end's hipGraph capture), so its ~20 small launches fill the CUs the
-    fmap tower's leave idle.  RAMP_TOWER_STREAMS=0 keeps everything on one stream."""
-    import os
-    if os.environ.get("RAMP_TOWER_STREAMS", "1") != "1":
-        return fmap_fn(), imap_fn()
-    cur = torch.cuda.current_stream()
-    side = owner.__dict__.get("_side_stream")
-    if side is None or side.device != cur.device:
-        side = torch.cuda.Stream(device=cur.device)
-        object.__setattr__(owner, "_side_stream", side)
-    side.wait_stream(cur)
-    with torch.cuda.stream(side):
-        i = imap_fn()
-    f = fmap_fn()
-    cur.wait_stream(side)
-    i.record_stream(cur)
-    return f, i
-
-
 class MergerLSTMsceneEncoder(nn.Module):
     """SingleScale RAMP encoder; reference :187-269"""
 
@@ -155,10 +134,11 @@ class MergerLSTMsceneEncoder(nn.Module):
             st.fresh = True
         s16 = conv_hip.lstm_superstate_step(self, events[0, 0].float().contiguous(),
                                             images[0, 0].float().contiguous(), st)
-        f, i = _two_towers(self, lambda: conv_hip.basic_encoder4(self.fmap_encoder, s16, out_scale,
-                                                                  half=self.mixed_precision),      # [h,w,128]
-                           lambda: conv_hip.basic_encoder4(self.imap_encoder, s16, out_scale,
-                                                           half=self.mixed_precision))             # [h,w,384]
+        # both towers layer by layer; fp16: one launch per layer for the two of them ([h,w,128], [h,w,384]).  One stream:
+        # a fork / join inside the front end's hipGraph bought nothing measurable (the paired launches fill the
+        # chip) and multi-stream captures were the one configuration that crashed hipGraphLaunch in long test runs.
+        f, i = conv_hip.basic_encoder4_towers([self.fmap_encoder, self.imap_encoder], s16, out_scale,
+                                              half=self.mixed_precision)
         return f.permute(2, 0, 1)[None, None], i.permute(2, 0, 1)[None, None], None
 
     def forward(self, events, images, reinit_hidden=False, out_scale=1.0):
@@ -245,10 +225,8 @@ class MultiScaleMergerDoubleNet(nn.Module):
         if not present:
             return None, None
         half = self.mixed_precision
-        f, i = _two_towers(self, lambda: conv_hip.multiscale_encoder4(self.fmap_encoder, xs[0], xs[1], xs[2],
-                                                                       out_scale, half=half),
-                           lambda: conv_hip.multiscale_encoder4(self.imap_encoder, xs[0], xs[1], xs[2],
-                                                                out_scale, half=half))
+        f, i = conv_hip.multiscale_encoder4_towers([self.fmap_encoder, self.imap_encoder], xs[0], xs[1], xs[2],
+                                                   out_scale, half=half)
         return f.permute(2, 0, 1)[None, None], i.permute(2, 0, 1)[None, None]
 
     def forward(self, events, images, mask, reinit_hidden=False, out_scale=1.0):

@@ -139,7 +139,7 @@ class Patchifier(nn.Module):
         self._graph_warm = 0
         self._plist = None
         self._extra = None
-        self._sel_stream = None
+        self._index = None
 
     def _apply(self, fn, *a, **k):
         """.to() / .half() / .cuda() replace the parameter tensors: captured graphs point at the old ones"""
@@ -202,17 +202,6 @@ class Patchifier(nn.Module):
     def _forward_impl(self, input_, patches_per_image=80, reinit_hidden=False, disps=None, event_bias=False,
                       gradient_bias=False):
         events, images, mask = input_
-        # patch selection only reads the events: on the GPU it runs on a side stream next to the encoder
-        early = None
-        if (event_bias and events.is_cuda and events.shape[1] == 1
-                and (self.input_mode == "SingleScale" or (mask is not None and bool(mask.all())))):
-            cur = torch.cuda.current_stream()
-            if self._sel_stream is None or self._sel_stream.device != cur.device:
-                self._sel_stream = torch.cuda.Stream(device=cur.device)
-            self._sel_stream.wait_stream(cur)
-            with torch.cuda.stream(self._sel_stream):
-                early = get_coords_from_topk_events(events=events, patches_per_image=patches_per_image,
-                                                    border_suppression_size=0, non_max_supp_rad=11)
         if self.input_mode == "SingleScale":
             fmap, imap, _ = self.encoder(events=events, images=images, reinit_hidden=reinit_hidden,
                                          out_scale=0.25)           # fmap / 4.0, imap / 4.0 folded in
@@ -225,11 +214,7 @@ class Patchifier(nn.Module):
         if mask is not None and not mask.any():
             return None, None, None, None, None, None
         b, n, c, h, w = fmap.shape
-        if early is not None:
-            torch.cuda.current_stream().wait_stream(self._sel_stream)
-            early.record_stream(torch.cuda.current_stream())
-            coords = early
-        elif event_bias:
+        if event_bias:
             coords = get_coords_from_topk_events(events=events, patches_per_image=patches_per_image,
                                                  border_suppression_size=0, non_max_supp_rad=11)
         else:
@@ -242,6 +227,25 @@ class Patchifier(nn.Module):
         # channels-last storage -> NHWC kernels; results are handed out in the reference's shapes
         f_nhwc = fmap[0].permute(0, 2, 3, 1)
         i_nhwc = imap[0].permute(0, 2, 3, 1)
+        if (fmap.is_cuda and n == 1 and disps is None and f_nhwc[0].is_contiguous() and i_nhwc[0].is_contiguous()
+                and images.dtype == torch.float32):
+            # the tracking path: the four gathers and the steps around them as ONE launch
+            g, ip, pt, cl, col = ops.frame_gather(f_nhwc[0], i_nhwc[0], images[0, 0], coords[0])
+            gmap = g[None].permute(0, 1, 4, 2, 3)                             # [1,M,128,3,3] view
+            imap_p = ip.view(b, -1, DIM, 1, 1)
+            patches = pt.view(b, -1, 3, self.P, self.P)
+            clr = cl.view(b, -1, 3)
+            if self._index is None or self._index.shape[0] != patches_per_image or self._index.device != fmap.device:
+                self._index = torch.zeros(patches_per_image, dtype=torch.long, device=fmap.device)
+            chunked = (fmap.dtype == torch.float16 and ops.pyramid_pack_supported(h, w))
+            if chunked:
+                f1, f2 = ops.pyramid_pack(f_nhwc[0])
+            else:
+                import torch.nn.functional as F
+                f1 = f_nhwc[0]
+                f2 = F.avg_pool2d(fmap[0], 4, 4).permute(0, 2, 3, 1).contiguous()[0]
+            self._extra = dict(gmap=g[None], imap=ip, fmap=f1, fmap2=f2, colors=col, chunked=chunked)
+            return fmap, gmap, imap_p, patches, self._index, clr
         gmap = ops.patchify(f_nhwc, coords, 1, True, RAMP_NHWC, RAMP_NHWC)           # [n,M,3,3,128]
         gmap = gmap.permute(0, 1, 4, 2, 3).reshape(b, -1, 128, self.P, self.P)   # a view when n == 1
         imap_p = ops.patchify(i_nhwc, coords, 0, True, RAMP_NHWC, RAMP_NHWC)         # [n,M,1,1,384]

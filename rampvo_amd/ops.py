@@ -35,6 +35,27 @@ def patchify(net, coords, radius, bilinear=True, layout=RAMP_NCHW, out_layout=RA
     return out
 
 
+def frame_gather(f_nhwc, i_nhwc, image, coords):
+    """all gathers of one frame at its patch centres, one launch (csrc/altcorr.hip::frame_gather_kernel):
+    f_nhwc [h,w,CF], i_nhwc [h,w,CI] (same dtype), image [3,H,W] fp32, coords [M,2] ->
+    gmap [M,3,3,CF], imap [M,CI], patches [M,3,3,3] fp32, clr [M,3] fp32, colors [M,3] uint8 BGR"""
+    require_cuda(f_nhwc, i_nhwc, image, coords)
+    assert f_nhwc.is_contiguous() and i_nhwc.is_contiguous() and f_nhwc.dtype == i_nhwc.dtype
+    image, coords = image.contiguous(), coords.contiguous()
+    assert image.dtype == torch.float32 and coords.dtype == torch.float32
+    (h, w, CF), CI, M = f_nhwc.shape, i_nhwc.shape[-1], coords.shape[0]
+    dev = f_nhwc.device
+    gmap = torch.empty(M, 3, 3, CF, dtype=f_nhwc.dtype, device=dev)
+    imap = torch.empty(M, CI, dtype=f_nhwc.dtype, device=dev)
+    patches = torch.empty(M, 3, 3, 3, dtype=torch.float32, device=dev)
+    clr = torch.empty(M, 3, dtype=torch.float32, device=dev)
+    colors = torch.empty(M, 3, dtype=torch.uint8, device=dev)
+    check(lib().ramp_frame_gather(ptr(f_nhwc), ptr(i_nhwc), ptr(image), ptr(coords), ptr(gmap), ptr(imap),
+                                  ptr(patches), ptr(clr), ptr(colors), M, h, w, image.shape[1], image.shape[2], CF,
+                                  CI, dtype_code(f_nhwc), stream()), "ramp_frame_gather")
+    return gmap, imap, patches, clr, colors
+
+
 def corr(fmap1, fmaps2, coords, ii, jj, radius=3, coord_divs=(1.0,), layout=RAMP_NCHW, order=None, row_elems=0,
          fast_f32=None, mod_ii=0, mod_jj=0):
     """fused multi-level patch correlation.  order: optional int32 [E] schedule (a permutation of

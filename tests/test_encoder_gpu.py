@@ -116,6 +116,41 @@ def test_conv_tiled_equals_direct(cin, cout, k, stride, hw, first):
         assert float((pa.shift - pb.shift).abs().max()) <= 1e-5 * max(1.0, float(pa.shift.abs().max()))
 
 
+@pytest.mark.parametrize("cin,couts,k,stride,hw,first", [(16, (32, 32), 7, 2, (96, 128), True),
+                                                          (32, (32, 32), 3, 1, (37, 53), False),
+                                                          (32, (64, 64), 3, 2, (40, 56), False),
+                                                          (64, (64, 64), 3, 1, (120, 160), False),
+                                                          (32, (64, 64), 1, 2, (40, 56), False),
+                                                          (64, (128, 384), 1, 1, (21, 29), False)])
+def test_conv_tower_pair_equals_single_launches(cin, couts, k, stride, hw, first):
+    """two towers' layer as ONE launch (ramp_conv2d_nhwc_multi; ramp/extractor.py:233-259 runs fnet and inet on the
+    same input): outputs and InstanceNorm (scale, shift) bit-identical to the per-tower launches, and stable under
+    repetition"""
+    from rampvo_amd import conv_hip
+    torch.manual_seed(5)
+    convs = [nn.Conv2d(cin, c, k, stride=stride, padding=k // 2).cuda() for c in couts]
+    with torch.no_grad():
+        x = torch.randn(hw[0], hw[1], cin, device="cuda")
+        xin = x if first else x.half()
+        sc, sh = torch.rand(cin, device="cuda") + 0.5, torch.randn(cin, device="cuda") * 0.1
+        oh, ow = (hw[0] + 2 * (k // 2) - k) // stride + 1, (hw[1] + 2 * (k // 2) - k) // stride + 1
+        res = torch.randn(oh, ow, couts[1], device="cuda").half()
+        xa = conv_hip.Pending(xin, sc, sh) if not first else xin
+        # tower 0: norm tower (statistics, no ReLU); tower 1: plain tower (ReLU + residual + scale)
+        jobs = [dict(x=xa, conv=convs[0], want_stats=True, eps=1e-5),
+                dict(x=xin, conv=convs[1], relu=True, res=res, out_scale=0.25)]
+        pair = conv_hip.conv2d_towers(jobs, half=True)
+        ref0 = conv_hip.conv2d(xa, convs[0], want_stats=True, half=True)
+        ref1 = conv_hip.conv2d(xin, convs[1], relu=True, res=res, out_scale=0.25, half=True)
+        assert isinstance(pair[0], conv_hip.Pending) and torch.equal(pair[0].raw, ref0.raw)
+        assert torch.equal(pair[1], ref1)
+        assert torch.equal(pair[0].scale, ref0.scale) and torch.equal(pair[0].shift, ref0.shift)
+        for _ in range(5):
+            again = conv_hip.conv2d_towers(jobs, half=True)
+            assert torch.equal(again[0].scale, pair[0].scale) and torch.equal(again[0].shift, pair[0].shift)
+            assert torch.equal(again[1], pair[1])
+
+
 def test_singlescale_encoder_half_vs_fp32():
     from rampvo_amd.synthetic import SyntheticStream, make_network
     net = make_network("SingleScale")

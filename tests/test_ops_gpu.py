@@ -803,3 +803,30 @@ def test_ba_eff_impl_at_config5_size():
     print("configs[4]-size BA: E=%d Mu=%d 6N=%d | per-patch E rows %.1f MB of a %.1f MB workspace | HIP %.2f ms (incl. its own "
           "group-by) vs oracle lookup path %.1f s | |GN step| %.3g, pose err %.2e"
           % (E, Mu, 6 * N, Mu * 6 * N * 4 / 1e6, ws / 1e6, out[True][2], t_cpu, step, np.abs(out[True][0] - rp).max()))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_frame_gather_equals_the_separate_patchify_launches(dtype):
+    """ramp_frame_gather = the four patchify calls of ramp/net.py:167-203 + the colour conversion of
+    Ramp_vo.py:353-354 in one launch: bit-identical, including centres on the border and fractional centres"""
+    from rampvo_amd import altcorr, ops
+    from rampvo_amd._lib import RAMP_NHWC
+    from rampvo_amd.utils import coords_grid_with_index
+    torch.manual_seed(8)
+    h, w, M = 30, 40, 24
+    f = torch.randn(h, w, 128, device="cuda").to(dtype)
+    i = torch.randn(h, w, 384, device="cuda").to(dtype)
+    img = torch.rand(3, 4 * h, 4 * w, device="cuda") - 0.5
+    coords = torch.stack([torch.randint(0, w, (M,)), torch.randint(0, h, (M,))], -1).float().cuda()
+    coords[0] = torch.tensor([0.0, 0.0]); coords[1] = torch.tensor([w - 1.0, h - 1.0])
+    coords[2] = torch.tensor([3.25, 7.75]); coords[3] = torch.tensor([w - 1.5, 0.5])
+    g, ip, pt, cl, col = ops.frame_gather(f, i, img, coords)
+    cn = coords[None]
+    g_ref = ops.patchify(f[None], cn, 1, True, RAMP_NHWC, RAMP_NHWC)[0]
+    i_ref = ops.patchify(i[None], cn, 0, True, RAMP_NHWC, RAMP_NHWC)[0].view(M, 384)
+    grid, _ = coords_grid_with_index(torch.ones(1, 1, h, w, device="cuda"), device="cuda")
+    p_ref = altcorr.patchify(grid[0].contiguous(), cn, 1)[0]
+    c_ref = altcorr.patchify(img[None], 4 * (cn + 0.5), 0)[0].view(M, 3)
+    col_ref = ((c_ref.flip(-1) + 0.5) * (255.0 / 2)).to(torch.uint8)
+    assert torch.equal(g, g_ref) and torch.equal(ip, i_ref)
+    assert torch.equal(pt, p_ref) and torch.equal(cl, c_ref) and torch.equal(col, col_ref)

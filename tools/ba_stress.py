@@ -160,7 +160,6 @@ with torch.no_grad():
     G_f = cap(lambda: conv_hip.basic_encoder4(enc.fmap_encoder, s16, 0.25, half=True))
     G_i = cap(lambda: conv_hip.basic_encoder4(enc.imap_encoder, s16, 0.25, half=True))
     G_sel = cap(lambda: get_coords_from_topk_events(events=EV, patches_per_image=96, border_suppression_size=0, non_max_supp_rad=11))
-    os.environ["RAMP_TOWER_STREAMS"] = "0"
     G_all1 = cap(lambda: net.patchify._forward_impl((EV, IM, frames[5][3]), 96, False, None, True, False))
 for nm, g in (("imap tower graph", G_i), ("fmap tower graph", G_f), ("imap tower graph", G_i), ("imap tower graph", G_i)):
     print(nm + ":", trial(g)[0], flush=True)
