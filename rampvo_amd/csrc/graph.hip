@@ -188,14 +188,33 @@ __global__ void __launch_bounds__(128)
 __device__ __forceinline__ long gbc_key(const int64_t *a, const int64_t *b, long mul, long sub, int e) {
   return a[e] * mul + (b ? b[e] : 0) - sub;
 }
+// The tracker's pair grouping has ~90 distinct keys for 40k edges: one global atomic per edge is 40k atomics on 90
+// addresses (22 us).  With K <= GBC_LDS_K the workgroup counts in LDS first and issues one global atomic per key it
+// saw (a few dozen per workgroup).
+#define GBC_LDS_K 4096
+template <bool LDS>
 __global__ void __launch_bounds__(256)
     gbc_hist_kernel(const int64_t *__restrict__ a, const int64_t *__restrict__ b, long mul, long sub,
                     int32_t *__restrict__ hist, int E, int K, int32_t *__restrict__ bad) {
+  __shared__ int s_bin[LDS ? GBC_LDS_K : 1];
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= E) return;
-  const long k = gbc_key(a, b, mul, sub, e);
-  if (k < 0 || k >= K) { *bad = 1; return; }
-  atomicAdd(&hist[k], 1);
+  long k = -1;
+  if (e < E) {
+    k = gbc_key(a, b, mul, sub, e);
+    if (k < 0 || k >= K) { *bad = 1; k = -1; }
+  }
+  if (!LDS) {
+    if (k >= 0) atomicAdd(&hist[k], 1);
+    return;
+  }
+  for (int q = threadIdx.x; q < K; q += 256) s_bin[q] = 0;
+  __syncthreads();
+  if (k >= 0) atomicAdd(&s_bin[k], 1);
+  __syncthreads();
+  for (int q = threadIdx.x; q < K; q += 256) {
+    const int c = s_bin[q];
+    if (c) atomicAdd(&hist[q], c);
+  }
 }
 // one workgroup: exclusive scan of the counts (-> cursor/offset) and of (count > 0) (-> group id)
 __global__ void __launch_bounds__(1024)
@@ -233,17 +252,40 @@ __global__ void __launch_bounds__(1024)
   }
   if (tid == 1023) { *ngroups = s_grp[1023]; seg_start[s_grp[1023]] = E; }
 }
+// (the order inside a segment is arbitrary here either way; gbc_segsort_kernel restores it)
+template <bool LDS>
 __global__ void __launch_bounds__(256)
     gbc_scatter_kernel(const int64_t *__restrict__ a, const int64_t *__restrict__ b, long mul, long sub,
                        int32_t *__restrict__ cursor, const int32_t *__restrict__ gidmap,
                        int32_t *__restrict__ tmp_order, int32_t *__restrict__ gid, int E, int K) {
+  __shared__ int s_bin[LDS ? GBC_LDS_K : 1];
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= E) return;
-  const long k = gbc_key(a, b, mul, sub, e);
-  if (k < 0 || k >= K) return;
-  const int pos = atomicAdd(&cursor[k], 1);
-  tmp_order[pos] = e;
-  if (gid) gid[e] = gidmap[k];
+  long k = -1;
+  if (e < E) {
+    k = gbc_key(a, b, mul, sub, e);
+    if (k < 0 || k >= K) k = -1;
+  }
+  if (!LDS) {
+    if (k < 0) return;
+    const int pos = atomicAdd(&cursor[k], 1);
+    tmp_order[pos] = e;
+    if (gid) gid[e] = gidmap[k];
+    return;
+  }
+  for (int q = threadIdx.x; q < K; q += 256) s_bin[q] = 0;
+  __syncthreads();
+  int r = 0;
+  if (k >= 0) r = atomicAdd(&s_bin[k], 1);            // rank inside this workgroup's share of the segment
+  __syncthreads();
+  for (int q = threadIdx.x; q < K; q += 256) {
+    const int c = s_bin[q];
+    if (c) s_bin[q] = atomicAdd(&cursor[q], c);       // the share's base
+  }
+  __syncthreads();
+  if (k >= 0) {
+    tmp_order[s_bin[k] + r] = e;
+    if (gid) gid[e] = gidmap[k];
+  }
 }
 // restore ascending edge order inside every segment (rank by counting; segments are short)
 __global__ void __launch_bounds__(64)
@@ -314,11 +356,19 @@ int ramp_group_by_small(const int64_t *a, const int64_t *b, int64_t mul, int64_t
   (void)hipMemsetAsync(hist, 0, (size_t)(K + 1) * 4, st);
   (void)hipMemsetAsync(bad, 0, 4, st);
   const int nb = ramp_cdiv(E, 256);
-  hipLaunchKernelGGL(gbc_hist_kernel, dim3(nb), dim3(256), 0, st, a, b, (long)mul, (long)sub, hist, E, K, bad);
+  const bool lds = K <= GBC_LDS_K;
+  if (lds)
+    hipLaunchKernelGGL(gbc_hist_kernel<true>, dim3(nb), dim3(256), 0, st, a, b, (long)mul, (long)sub, hist, E, K, bad);
+  else
+    hipLaunchKernelGGL(gbc_hist_kernel<false>, dim3(nb), dim3(256), 0, st, a, b, (long)mul, (long)sub, hist, E, K, bad);
   hipLaunchKernelGGL(gbc_scan_kernel, dim3(1), dim3(1024), 0, st, hist, gidmap, seg_start, ukeys, ngroups, K, E,
                      (long)sub, 0L);
-  hipLaunchKernelGGL(gbc_scatter_kernel, dim3(nb), dim3(256), 0, st, a, b, (long)mul, (long)sub, hist, gidmap,
-                     tmp, gid, E, K);
+  if (lds)
+    hipLaunchKernelGGL(gbc_scatter_kernel<true>, dim3(nb), dim3(256), 0, st, a, b, (long)mul, (long)sub, hist, gidmap,
+                       tmp, gid, E, K);
+  else
+    hipLaunchKernelGGL(gbc_scatter_kernel<false>, dim3(nb), dim3(256), 0, st, a, b, (long)mul, (long)sub, hist, gidmap,
+                       tmp, gid, E, K);
   const int ng = max_groups > 0 ? (max_groups < E ? max_groups : E) : (K < E ? K : E);
   hipLaunchKernelGGL(gbc_segsort_kernel, dim3(ng), dim3(64), 0, st, tmp, seg_start, ngroups, order);
   RAMP_CHECK_LAUNCH();
