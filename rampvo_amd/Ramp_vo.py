@@ -220,11 +220,16 @@ class Ramp_vo:
             m = torch.from_numpy(self._net_map).to(self._net_buf.device)
             rows = self._net_buf[:, m.clamp(min=0)] * (m >= 0).to(self._net_buf.dtype)[None, :, None]
             self._net_buf, self._net_map, self._net_map_dev = rows, None, None
+            self._pre_cache = None     # its row map points into the buffer that was just replaced
         return self._net_buf
 
     @net.setter
     def net(self, value):
         self._net_buf, self._net_map, self._net_map_dev = value, None, None
+        # a graph prepared for the next frame carries a row map into the PREVIOUS buffer.  In the tracking loop none
+        # exists at this point (update() runs before keyframe() prepares one); after an extra update() between two
+        # frames (evaluate.run_pose_pred does twelve) it would be stale: the next frame lays its graph out afresh.
+        self._pre_cache = None
 
     def _net_rows(self):
         return self._net_map if self._net_map is not None else np.arange(self._net_buf.shape[1], dtype=np.int64)

@@ -22,6 +22,12 @@
 #define MKS (MD / 32)          // K steps per 384-wide layer
 #define MNTW 3                 // 16-column tiles per wave
 #define MWAVES 8
+#ifndef MLP_PREFETCH_DEFAULT
+#define MLP_PREFETCH_DEFAULT 0
+#endif
+#ifndef GRU_PF
+#define GRU_PF 2
+#endif
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -35,7 +41,7 @@ __device__ __forceinline__ float sigm(float x) { return __builtin_amdgcn_rcpf(1.
 // acc[mt][nt] += Xs[64 x 384] * W^T for this wave's 48 columns; NB weight matrices share the A reads
 // SWAP: operands exchanged -> the accumulators hold the TRANSPOSED tile (lane (q, j): row j of the 16-row tile,
 // columns 4q..4q+3 of the 16-column tile), i.e. four consecutive output columns per lane for direct row-major stores
-template <int NB, bool SWAP = false>
+template <int NB, bool SWAP = false, int PF = MLP_PREFETCH_DEFAULT>
 __device__ __forceinline__ void mlp_gemm(const _Float16 *Xs, const _Float16 *const (&wp)[NB], int wave, int lane,
                                          f4 (&acc)[NB][4][MNTW]) {
   const int q = lane >> 4, j = lane & 15;
@@ -45,46 +51,14 @@ __device__ __forceinline__ void mlp_gemm(const _Float16 *Xs, const _Float16 *con
     for (int mt = 0; mt < 4; mt++)
 #pragma unroll
       for (int nt = 0; nt < MNTW; nt++) acc[b][mt][nt] = (f4){0.f, 0.f, 0.f, 0.f};
-#ifndef MLP_PREFETCH
-#define MLP_PREFETCH 0
-#endif
 #ifndef MLP_UNROLL
 #define MLP_UNROLL 2
 #endif
-#if MLP_PREFETCH
-  // weight fragments of K step ks+1 are in flight while the matrix cores work on step ks
-  h8 bn[NB][MNTW];
-#pragma unroll
-  for (int b = 0; b < NB; b++)
-#pragma unroll
-    for (int nt = 0; nt < MNTW; nt++)
-      bn[b][nt] = *reinterpret_cast<const h8 *>(wp[b] + (((size_t)(wave * MNTW + nt)) * 64 + lane) * 8);
-#pragma unroll MLP_UNROLL
-  for (int ks = 0; ks < MKS; ks++) {
-    h8 a[4], bw[NB][MNTW];
-#pragma unroll
-    for (int b = 0; b < NB; b++)
-#pragma unroll
-      for (int nt = 0; nt < MNTW; nt++) bw[b][nt] = bn[b][nt];
-    const int kn = ks + 1 < MKS ? ks + 1 : ks;
-#pragma unroll
-    for (int b = 0; b < NB; b++)
-#pragma unroll
-      for (int nt = 0; nt < MNTW; nt++)
-        bn[b][nt] = *reinterpret_cast<const h8 *>(wp[b] + (((size_t)kn * (MD / 16) + wave * MNTW + nt) * 64 + lane) * 8);
-    // the scheduling barrier keeps the loads ABOVE the matrix work (the compiler sinks them to their first use
-    // otherwise, which exposes their full L2 latency on every K step -- the reason this prefetch once looked useless)
-    __builtin_amdgcn_sched_barrier(0);
-#else
-#pragma unroll MLP_UNROLL
-  for (int ks = 0; ks < MKS; ks++) {
-    h8 a[4], bw[NB][MNTW];
-#pragma unroll
-    for (int b = 0; b < NB; b++)
-#pragma unroll
-      for (int nt = 0; nt < MNTW; nt++)
-        bw[b][nt] = *reinterpret_cast<const h8 *>(wp[b] + (((size_t)ks * (MD / 16) + wave * MNTW + nt) * 64 + lane) * 8);
-#endif
+  auto wfrag = [&](int b, int ks, int nt) {
+    return *reinterpret_cast<const h8 *>(wp[b] + (((size_t)ks * (MD / 16) + wave * MNTW + nt) * 64 + lane) * 8);
+  };
+  auto mma = [&](int ks, h8 (&bw)[NB][MNTW]) {
+    h8 a[4];
 #pragma unroll
     for (int mt = 0; mt < 4; mt++) a[mt] = *reinterpret_cast<const h8 *>(Xs + (mt * 16 + j) * MXS + ks * 32 + 8 * q);
 #pragma unroll
@@ -95,6 +69,40 @@ __device__ __forceinline__ void mlp_gemm(const _Float16 *Xs, const _Float16 *con
         for (int nt = 0; nt < MNTW; nt++)
           acc[b][mt][nt] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_f16(bw[b][nt], a[mt], acc[b][mt][nt], 0, 0, 0)
                                 : __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mt], bw[b][nt], acc[b][mt][nt], 0, 0, 0);
+  };
+  if constexpr (PF > 0) {
+    // the weight fragments of K steps ks+1 .. ks+PF are in flight while the matrix cores work on step ks (a ring of
+    // PF+1 fragment sets, fully unrolled so that the ring index is static); the scheduling barrier keeps each load
+    // ABOVE the matrix work of the step it is issued in -- the compiler sinks it to its first use otherwise, which
+    // exposes the full L2 latency on every K step
+    h8 ring[PF + 1][NB][MNTW];
+#pragma unroll
+    for (int d = 0; d < PF; d++)
+#pragma unroll
+      for (int b = 0; b < NB; b++)
+#pragma unroll
+        for (int nt = 0; nt < MNTW; nt++) ring[d][b][nt] = wfrag(b, d, nt);
+#pragma unroll
+    for (int ks = 0; ks < MKS; ks++) {
+      if (ks + PF < MKS) {
+#pragma unroll
+        for (int b = 0; b < NB; b++)
+#pragma unroll
+          for (int nt = 0; nt < MNTW; nt++) ring[(ks + PF) % (PF + 1)][b][nt] = wfrag(b, ks + PF, nt);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mma(ks, ring[ks % (PF + 1)]);
+    }
+  } else {
+#pragma unroll MLP_UNROLL
+    for (int ks = 0; ks < MKS; ks++) {
+      h8 bw[NB][MNTW];
+#pragma unroll
+      for (int b = 0; b < NB; b++)
+#pragma unroll
+        for (int nt = 0; nt < MNTW; nt++) bw[b][nt] = wfrag(b, ks, nt);
+      mma(ks, bw);
+    }
   }
 }
 
@@ -191,122 +199,194 @@ struct GruParams {
   int E;
 };
 
-// gru = LayerNorm (done by the caller's row kernel), GatedResidual, LayerNorm, GatedResidual
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+// Two-pass LayerNorm of the workgroup's 64 x 384 tile held in TRANSPOSED accumulator layout (lane (q, j) of wave w:
+// rows 16 mt + j, columns 48 w + 16 nt + 4 q + {0..3}): per-wave partial sums meet in an LDS table [64 rows][8 waves],
+// every lane then adds the eight partials of its rows in wave order.  Same arithmetic as row_ln (mean, then the
+// variance of the deviations); the order of the additions differs.
+__device__ __forceinline__ void tile_ln(f4 (&v)[4][MNTW], const float *__restrict__ w, const float *__restrict__ b,
+                                        float eps, float *T1, float *T2, int wave, int q, int j, int col0) {
+  float mean[4], rstd[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; mt++) {
+    float s = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < MNTW; nt++) s += (v[mt][nt][0] + v[mt][nt][1]) + (v[mt][nt][2] + v[mt][nt][3]);
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if (q == 0) T1[(mt * 16 + j) * MWAVES + wave] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int mt = 0; mt < 4; mt++) {
+    const f4 a = *reinterpret_cast<const f4 *>(T1 + (mt * 16 + j) * MWAVES), c = *reinterpret_cast<const f4 *>(T1 + (mt * 16 + j) * MWAVES + 4);
+    mean[mt] = ((((((a[0] + a[1]) + a[2]) + a[3]) + c[0]) + c[1]) + c[2] + c[3]) * (1.0f / MD);
+    float s = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < MNTW; nt++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const float d = v[mt][nt][i] - mean[mt];
+        s += d * d;
+      }
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if (q == 0) T2[(mt * 16 + j) * MWAVES + wave] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int mt = 0; mt < 4; mt++) {
+    const f4 a = *reinterpret_cast<const f4 *>(T2 + (mt * 16 + j) * MWAVES), c = *reinterpret_cast<const f4 *>(T2 + (mt * 16 + j) * MWAVES + 4);
+    rstd[mt] = 1.0f / sqrtf(((((((a[0] + a[1]) + a[2]) + a[3]) + c[0]) + c[1]) + c[2] + c[3]) * (1.0f / MD) + eps);
+  }
+#pragma unroll
+  for (int nt = 0; nt < MNTW; nt++) {
+    const f4 wv = *reinterpret_cast<const f4 *>(w + col0 + nt * 16 + 4 * q), bv = *reinterpret_cast<const f4 *>(b + col0 + nt * 16 + 4 * q);
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) v[mt][nt][i] = (v[mt][nt][i] - mean[mt]) * rstd[mt] * wv[i] + bv[i];
+  }
+}
+
+#ifdef GRU_TRACE
+__device__ long long g_gru_trace[32 * 4096];
+#define GT(k) do { if (threadIdx.x == 0) g_gru_trace[blockIdx.x * 32 + (k)] = wall_clock64(); } while (0)
+#else
+#define GT(k)
+#endif
+// gru = LayerNorm, GatedResidual, LayerNorm, GatedResidual (ramp/net.py:49-54, ramp/blocks.py:15-31) for 64 rows.
+//   * Everything row-wise happens in the accumulators' own layout.  The MFMA operands are exchanged (weights as A), so
+//     lane (q, j) holds row j of a 16-row tile and FOUR CONSECUTIVE columns: the fp32 residual stream lives in 48
+//     registers of that layout for the whole kernel, is loaded and stored as 16-byte pieces, and the fp16 copies the
+//     next layer multiplies go to LDS as 8-byte pieces.  (An earlier version parked every product in LDS as fp32 and
+//     gave whole rows to single waves for the LayerNorm: 2 x 2.5 us per stage of a 46 us workgroup.)
+//   * Three K loops of ONE weight matrix each per stage: 48 accumulator registers instead of 96 leave room for a ring
+//     of weight fragments GRU_PF K steps deep (the loads of a step are otherwise exposed with their full L2 latency;
+//     two waves per SIMD cannot cover it).  The gate does not stay in registers across the other two loops: its
+//     sigmoid (a half tensor under the reference's autocast) waits in the third LDS tile, every lane reading back
+//     exactly the elements it wrote.
 __global__ void __launch_bounds__(64 * MWAVES) upd_gru_kernel(const GruParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   _Float16 *Xs = reinterpret_cast<_Float16 *>(smem_raw);            // [64][MXS]
   _Float16 *Hs = Xs + MBM * MXS;                                    // [64][MXS]
+  _Float16 *Gs = Hs + MBM * MXS;                                    // [64][MXS]: sigmoid(gate)
+  float *T1 = reinterpret_cast<float *>(Gs + MBM * MXS), *T2 = T1 + MBM * MWAVES;   // LayerNorm partials
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
   const int row0 = blockIdx.x * MBM;
   const int col0 = wave * (16 * MNTW);
+  const int cq = col0 + 4 * q;                  // this lane's first column in n-tile 0
 
-  // ---- stage the input tile (fp32 -> fp16).  Wave w owns rows 4w..4w+3 of each 32-row half for the
-  // row-major passes and keeps them in fp32 (lane l: channels 2l + 128k + {0,1}): the residual stream is
-  // read from memory once and never parked
-  float xrow[2][MPR / MWAVES][3][2];
+  GT(0);
+  // ---- the residual stream, fp32, in registers (rows past E: clamped loads, no stores)
+  f4 res[4][MNTW];
+  size_t roff[4];
 #pragma unroll
-  for (int half = 0; half < 2; half++)
+  for (int mt = 0; mt < 4; mt++) {
+    const int row = row0 + mt * 16 + j;
+    roff[mt] = (size_t)(row < p.E ? row : p.E - 1) * MD;
 #pragma unroll
-    for (int rr = 0; rr < MPR / MWAVES; rr++) {
-      const int rt = half * MPR + wave * (MPR / MWAVES) + rr;
-      const int row = row0 + rt;
+    for (int nt = 0; nt < MNTW; nt++) res[mt][nt] = *reinterpret_cast<const f4 *>(p.x32 + roff[mt] + cq + nt * 16);
+  }
+  if (p.add_t) {                                // uniform
 #pragma unroll
-      for (int k = 0; k < 3; k++) {
-        const int c = 2 * lane + 128 * k;
-        float2 v = make_float2(0.f, 0.f);
-        if (row < p.E) v = *reinterpret_cast<const float2 *>(p.x32 + (size_t)row * MD + c);
-        xrow[half][rr][k][0] = v.x; xrow[half][rr][k][1] = v.y;
+    for (int mt = 0; mt < 4; mt++) {
+      const _Float16 *a = p.add_t + (size_t)p.add_idx[roff[mt] / MD] * MD;
+#pragma unroll
+      for (int nt = 0; nt < MNTW; nt++) {
+        const h4 v = *reinterpret_cast<const h4 *>(a + cq + nt * 16);
+#pragma unroll
+        for (int i = 0; i < 4; i++) res[mt][nt][i] += (float)v[i];
       }
-      if (p.add_t) {             // wave-uniform
-        if (row < p.E) {
-          const _Float16 *a = p.add_t + (size_t)p.add_idx[row] * MD;
-#pragma unroll
-          for (int k = 0; k < 3; k++) {
-            const h2 b = *reinterpret_cast<const h2 *>(a + 2 * lane + 128 * k);
-            xrow[half][rr][k][0] += (float)b[0]; xrow[half][rr][k][1] += (float)b[1];
-          }
-        }
-        row_ln(xrow[half][rr], p.pre_w, p.pre_b, p.pre_eps, lane);
-      }
-#pragma unroll
-      for (int k = 0; k < 3; k++)
-        *reinterpret_cast<h2 *>(Xs + rt * MXS + 2 * lane + 128 * k) =
-            (h2){(_Float16)xrow[half][rr][k][0], (_Float16)xrow[half][rr][k][1]};
     }
+    tile_ln(res, p.pre_w, p.pre_b, p.pre_eps, T1, T2, wave, q, j, col0);
+  }
+  auto to_lds = [&](_Float16 *tile, const f4 (&v)[4][MNTW]) {
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+      for (int nt = 0; nt < MNTW; nt++)
+        *reinterpret_cast<h4 *>(tile + (mt * 16 + j) * MXS + cq + nt * 16) =
+            (h4){(_Float16)v[mt][nt][0], (_Float16)v[mt][nt][1], (_Float16)v[mt][nt][2], (_Float16)v[mt][nt][3]};
+  };
+  to_lds(Xs, res);
   __syncthreads();
-  float *P = reinterpret_cast<float *>(Hs);              // parking tile, aliases h once h is dead
+  GT(1);
 
 #pragma unroll 1
   for (int stage = 0; stage < 2; stage++) {
     const int wb = 3 * stage;
-    // gate pre-activation and first residual layer share the A operand
-    f4 acc2[2][4][MNTW];
+    f4 acc[1][4][MNTW];
     {
-      const _Float16 *const w2[2] = {p.wp[wb + 0], p.wp[wb + 1]};
-      mlp_gemm<2>(Xs, w2, wave, lane, acc2);
+      const _Float16 *const w1[1] = {p.wp[wb + 0]};
+      mlp_gemm<1, true, GRU_PF>(Xs, w1, wave, lane, acc);
     }
+    GT(2 + 8 * stage);
+#pragma unroll
+    for (int nt = 0; nt < MNTW; nt++) {
+      const f4 bg = *reinterpret_cast<const f4 *>(p.bias[wb + 0] + cq + nt * 16);
+#pragma unroll
+      for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc[0][mt][nt][i] = sigm(h_round(acc[0][mt][nt][i] + bg[i]));
+    }
+    to_lds(Gs, acc[0]);
+    GT(3 + 8 * stage);
+    {
+      const _Float16 *const w1[1] = {p.wp[wb + 1]};
+      mlp_gemm<1, true, GRU_PF>(Xs, w1, wave, lane, acc);
+    }
+    GT(4 + 8 * stage);
     // h = relu(L1 x + b1) -> Hs (fp16)
 #pragma unroll
     for (int nt = 0; nt < MNTW; nt++) {
-      const float b1 = p.bias[wb + 1][col0 + nt * 16 + j];
+      const f4 b1 = *reinterpret_cast<const f4 *>(p.bias[wb + 1] + cq + nt * 16);
 #pragma unroll
       for (int mt = 0; mt < 4; mt++)
 #pragma unroll
-        for (int r = 0; r < 4; r++)
-          Hs[(mt * 16 + 4 * q + r) * MXS + col0 + nt * 16 + j] = (_Float16)fmaxf(acc2[1][mt][nt][r] + b1, 0.f);
+        for (int i = 0; i < 4; i++) acc[0][mt][nt][i] = fmaxf(acc[0][mt][nt][i] + b1[i], 0.f);
     }
+    to_lds(Hs, acc[0]);
     __syncthreads();
-    f4 accr[1][4][MNTW];
+    GT(5 + 8 * stage);
     {
       const _Float16 *const w1[1] = {p.wp[wb + 2]};
-      mlp_gemm<1>(Hs, w1, wave, lane, accr);
+      mlp_gemm<1, true, GRU_PF>(Hs, w1, wave, lane, acc);
     }
-    // sigmoid(gate) * r     (gate and r are half tensors under the reference's autocast)
-    float pr[4][MNTW][4];
+    GT(6 + 8 * stage);
+    // residual += sigmoid(gate) * r     (gate and r are half tensors under the reference's autocast)
 #pragma unroll
     for (int nt = 0; nt < MNTW; nt++) {
-      const float bg = p.bias[wb + 0][col0 + nt * 16 + j], b2 = p.bias[wb + 2][col0 + nt * 16 + j];
+      const f4 b2 = *reinterpret_cast<const f4 *>(p.bias[wb + 2] + cq + nt * 16);
 #pragma unroll
-      for (int mt = 0; mt < 4; mt++)
+      for (int mt = 0; mt < 4; mt++) {
+        const h4 g = *reinterpret_cast<const h4 *>(Gs + (mt * 16 + j) * MXS + cq + nt * 16);
 #pragma unroll
-        for (int r = 0; r < 4; r++)
-          pr[mt][nt][r] = sigm(h_round(acc2[0][mt][nt][r] + bg)) * h_round(accr[0][mt][nt][r] + b2);
+        for (int i = 0; i < 4; i++) res[mt][nt][i] += (float)g[i] * h_round(acc[0][mt][nt][i] + b2[i]);
+      }
     }
-    __syncthreads();                                     // every wave is past its reads of h (and of x)
-    // row pass: residual += product; stage 0: LayerNorm -> next residual (registers) + fp16 x (LDS);
-    // stage 1: the result and its ReLU copy
-#pragma unroll
-    for (int half = 0; half < 2; half++) {
-      park_half(P, pr, half, col0, q, j);
+    GT(7 + 8 * stage);
+    if (stage == 0) {
+      // gru[2]: LayerNorm -> the next residual (registers) and its fp16 copy (every wave is past its reads of x:
+      // they ended before the barrier that published h)
+      tile_ln(res, p.ln_w, p.ln_b, p.eps, T1, T2, wave, q, j, col0);
+      to_lds(Xs, res);
       __syncthreads();
+    } else {
 #pragma unroll
-      for (int rr = 0; rr < MPR / MWAVES; rr++) {      // 4 rows per wave
-        const int rl = wave * (MPR / MWAVES) + rr;        // row within the parking pass
-        const int rt = half * MPR + rl;                   // row within the tile
-        const int row = row0 + rt;
-        float (&v)[3][2] = xrow[half][rr];
+      for (int mt = 0; mt < 4; mt++) {
+        if (row0 + mt * 16 + j >= p.E) continue;
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-          const float2 pv = *reinterpret_cast<const float2 *>(P + rl * MPS + 2 * lane + 128 * k);
-          v[k][0] += pv.x; v[k][1] += pv.y;
-        }
-        if (stage == 0) {
-          row_ln(v, p.ln_w, p.ln_b, p.eps, lane);
-#pragma unroll
-          for (int k = 0; k < 3; k++)
-            *reinterpret_cast<h2 *>(Xs + rt * MXS + 2 * lane + 128 * k) = (h2){(_Float16)v[k][0], (_Float16)v[k][1]};
-        } else if (row < p.E) {
-#pragma unroll
-          for (int k = 0; k < 3; k++) {
-            const int c = 2 * lane + 128 * k;
-            *reinterpret_cast<float2 *>(p.out32 + (size_t)row * MD + c) = make_float2(v[k][0], v[k][1]);
-            *reinterpret_cast<h2 *>(p.relu_t + (size_t)row * MD + c) =
-                (h2){(_Float16)fmaxf(v[k][0], 0.f), (_Float16)fmaxf(v[k][1], 0.f)};
-          }
+        for (int nt = 0; nt < MNTW; nt++) {
+          const f4 v = res[mt][nt];
+          *reinterpret_cast<f4 *>(p.out32 + roff[mt] + cq + nt * 16) = v;
+          *reinterpret_cast<h4 *>(p.relu_t + roff[mt] + cq + nt * 16) =
+              (h4){(_Float16)fmaxf(v[0], 0.f), (_Float16)fmaxf(v[1], 0.f), (_Float16)fmaxf(v[2], 0.f), (_Float16)fmaxf(v[3], 0.f)};
         }
       }
-      __syncthreads();                                   // before the parking tile is overwritten / x is read
     }
+    GT(8 + 8 * stage);
   }
 }
 
@@ -910,6 +990,11 @@ static int big_launch(KernelT kernel, const ParamsT &p, int E, int nmt, int nw, 
 
 extern "C" {
 
+#ifdef GRU_TRACE
+int ramp_debug_gru_trace(long long *host, int n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gru_trace), (size_t)n * 8) == hipSuccess ? 0 : -1;
+}
+#endif
 size_t ramp_upd_mlp_lds_bytes(void) { return (size_t)2 * MBM * MXS * 2; }
 
 int ramp_upd_gru(const float *x32, const void *add_t, const int32_t *add_idx, const float *pre_w, const float *pre_b,
@@ -928,7 +1013,7 @@ int ramp_upd_gru(const float *x32, const void *add_t, const int32_t *add_idx, co
     p.bias[i] = bias_host[i];
   }
   p.ln_w = ln_w; p.ln_b = ln_b; p.eps = eps; p.out32 = out32; p.relu_t = (_Float16 *)relu_t; p.E = E;
-  const size_t lds = ramp_upd_mlp_lds_bytes();
+  const size_t lds = (size_t)3 * MBM * MXS * 2 + 2 * MBM * MWAVES * sizeof(float);   // x, h, sigmoid(gate) tiles + the LayerNorm tables
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void *)upd_gru_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=

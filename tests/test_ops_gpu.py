@@ -573,7 +573,7 @@ def test_fused_gru_chain_matches_gemm_path():
 FUSED_CHAIN_TOL = 3e-3      # x the output scale; measured worst case is recorded by the test's print
 
 
-@pytest.mark.parametrize("E", [1003, 20011, 41003])
+@pytest.mark.parametrize("E", [1003, 5408, 20011, 41003])
 @torch.no_grad()
 def test_fused_update_chains_against_fp32_torch(E):
     """every fused fp16 MFMA chain of the update operator (csrc/update_mlp.hip, update.hip) on its own against a

@@ -442,3 +442,34 @@ def test_front_end_graph_follows_weight_updates_and_state_reloads():
         exp = ref_net.patchify(input_=(ev, im, mask), patches_per_image=16, event_bias=True, reinit_hidden=False)
         for a, b in zip(got[k], exp[:4]):
             assert (a - b.float()).abs().max() <= 2e-3 * max(1.0, float(b.float().abs().max()))
+
+
+@torch.no_grad()
+def test_extra_update_between_frames_does_not_reuse_a_stale_prepared_graph():
+    """keyframe() prepares the next frame's graph together with a row map into the hidden-state buffer of that moment.
+    An update() between two frames (rampvo_amd.evaluate.run_pose_pred / reference evaluate.py:206-208 run twelve)
+    or a read of ``.net`` replaces that buffer: the prepared graph must not be adopted with its old map (it indexed
+    rows past the new buffer).  Same result as a tracker whose prepared graph is dropped by hand."""
+    from rampvo_amd.config import make_cfg
+    from rampvo_amd.Ramp_vo import Ramp_vo
+    from rampvo_amd.synthetic import SyntheticStream, make_network
+    T, K = 18, 14
+    stream = SyntheticStream(240, 320, T, seed=8, device="cuda")
+    data = [stream.frame(t) for t in range(T)]
+    out = []
+    for by_hand in (False, True):
+        cfg = make_cfg("default", PATCHES_PER_FRAME=32, MIXED_PRECISION=True)
+        slam = Ramp_vo(cfg, make_network("SingleScale", profile="damped"), {"event_bias": True}, ht=240, wd=320)
+        for t in range(T):
+            im, ev, Kc, mask = data[t]
+            slam(t, input_tensor=(ev, im, mask), intrinsics=Kc)
+            if t == K:
+                slam.update()
+                assert slam.net.shape[1] == len(slam._ii)          # also materialises the state
+                if by_hand:
+                    slam._pre_cache = None
+        assert bool(torch.isfinite(slam._net_buf).all()) and bool(torch.isfinite(slam.poses_[:slam.n]).all())
+        out.append((slam.poses_[:slam.n].clone(), slam._net_buf.clone(), slam._net_rows().copy()))
+        slam.close()
+    assert torch.equal(out[0][0], out[1][0])
+    assert torch.equal(out[0][1][0][out[0][2]], out[1][1][0][out[1][2]])
