@@ -411,26 +411,26 @@ __global__ void __launch_bounds__(256)
     if (q >= q_hi) break;
     const int x = q / n6, c = q - x * n6;
     const int r = 6 * a + x;
-    // split-K partials in z order; 16 loads in flight at a time
+    // split-K partials in z order, all KS <= 64 loads in flight (branch-free: clamped index, masked add)
     float sp = 0.0f;
-    for (int z0 = 0; z0 < KS; z0 += 16) {
-      float v[16];
+    {
+      float v[64];
 #pragma unroll
-      for (int u = 0; u < 16; u++) v[u] = (z0 + u < KS) ? S_part[((size_t)(z0 + u) * n6 + r) * n6 + c] : 0.0f;
+      for (int u = 0; u < 64; u++) v[u] = S_part[((size_t)(u < KS ? u : KS - 1) * n6 + r) * n6 + c];
 #pragma unroll
-      for (int u = 0; u < 16; u++) if (z0 + u < KS) sp += v[u];
+      for (int u = 0; u < 64; u++) sp += u < KS ? v[u] : 0.0f;
     }
     float s = bsum[t] - sp;
     if (r == c) s += (1e-4f * s + 1.0f);
     S[(size_t)r * n6 + c] = s;
     if (c == 0) {
       float yp = 0.0f;
-      for (int z0 = 0; z0 < KS; z0 += 16) {
-        float v[16];
+      {
+        float v[64];
 #pragma unroll
-        for (int u = 0; u < 16; u++) v[u] = (z0 + u < KS) ? y_part[(size_t)(z0 + u) * n6 + r] : 0.0f;
+        for (int u = 0; u < 64; u++) v[u] = y_part[(size_t)(u < KS ? u : KS - 1) * n6 + r];
 #pragma unroll
-        for (int u = 0; u < 16; u++) if (z0 + u < KS) yp += v[u];
+        for (int u = 0; u < 64; u++) yp += u < KS ? v[u] : 0.0f;
       }
       yv[r] = vsum[t] - yp;
     }

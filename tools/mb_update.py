@@ -15,7 +15,9 @@ rnd = lambda *s: (torch.randn(*s, generator=g) * 0.5).cuda()
 x32, hy = rnd(E, 384), rnd(2200, 384).half()
 gid = torch.randint(0, 2200, (E,), generator=g).int().cuda()
 out32 = torch.empty(E, 384, device="cuda"); relu_t = torch.empty(E, 384, dtype=torch.half, device="cuda")
-idx = torch.randint(-1, E, (E,), generator=g).cuda()
+idx = (torch.arange(E) - 1).cuda() if os.environ.get("MB_ADJ") else torch.randint(-1, E, (E,), generator=g).cuda()
+if os.environ.get("MB_ADJ"):
+    gid = (torch.arange(E) // 19).int().cuda()
 corr = F.pad(rnd(E, 882).half(), (0, 14)).contiguous()
 net_map = torch.randint(-1, E, (E,), generator=g).cuda()
 table = rnd(3072, 384).half(); inp_idx = torch.randint(0, 100000, (E,), generator=g).cuda()
