@@ -20,6 +20,7 @@
 //  3. in_stats_finalize_kernel, norm_add_relu_kernel: InstanceNorm statistics -> (scale, shift),
 //     and the residual-block tail relu(skip' + relu(norm(y))).
 #include "ramp_device.h"
+#include <stdlib.h>
 
 // ------------------------------------------------------------------ any != 0
 __global__ void __launch_bounds__(256)
@@ -339,6 +340,69 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// epilogue of the LDS-tiled kernels: bias, InstanceNorm partial statistics, ReLU -> fp32 tile in LDS (aliases the
+// input / weight tiles: the caller has passed a barrier after its last read of them) -> residual, scale, coalesced
+// 16-byte stores.  acc[mt][nt]: rows 2 wave + mt of the 8 x 16 tile, 16-channel tile nt of the block starting at n0.
+template <int NT>
+__device__ __forceinline__ void conv_tile_epilogue(const ConvParams &p, const f32x4 (&acc)[2][NT], unsigned char *smem,
+                                                   float (&s_stat)[4][NT * 16][2], int oy0, int ox0, int n0) {
+  constexpr int TH = 8, TW = 16;
+  constexpr int OSTR = NT * 16 + 4;                   // fp32 staging row (floats), 16-byte aligned
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, j = lane & 15;
+  float *s_out = reinterpret_cast<float *>(smem);
+#pragma unroll
+  for (int nt = 0; nt < NT; nt++) {
+    const int c = n0 + nt * 16 + j;
+    const float bv = p.bias ? p.bias[c] : 0.0f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++) {
+      const int r = 2 * wave + mt;
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++) {
+        const int xx = 4 * q + rr;
+        float v = acc[mt][nt][rr] + bv;
+        if (oy0 + r < p.OH && ox0 + xx < p.OW) { s1 += v; s2 += v * v; }
+        if (p.relu) v = fmaxf(v, 0.f);
+        s_out[(r * TW + xx) * OSTR + nt * 16 + j] = v;
+      }
+    }
+    if (p.stats) {
+      s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+      if (q == 0) { s_stat[wave][nt * 16 + j][0] = s1; s_stat[wave][nt * 16 + j][1] = s2; }
+    }
+  }
+  __syncthreads();
+  if (p.stats && tid < NT * 32) {
+    const int c = tid >> 1, k = tid & 1;
+    const float v = ((s_stat[0][c][k] + s_stat[1][c][k]) + s_stat[2][c][k]) + s_stat[3][c][k];
+    p.stats[((size_t)(n0 + c) * 2 + k) * gridDim.x + blockIdx.x] = v;   // [C][2][nblk]: contiguous per channel
+  }
+  // 16-byte pieces: pixel-major, 8 channels each
+  constexpr int PPP = NT * 2;                         // pieces per pixel
+  for (int i = tid; i < TH * TW * PPP; i += 256) {
+    const int pix = i / PPP, piece = i - pix * PPP;
+    const int r = pix / TW, xx = pix - r * TW;
+    const int oy = oy0 + r, ox = ox0 + xx;
+    if (oy >= p.OH || ox >= p.OW) continue;
+    const float *sv = s_out + pix * OSTR + piece * 8;
+    const size_t go = ((size_t)oy * p.OW + ox) * p.Cout + n0 + piece * 8;
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) v[c] = sv[c];
+    if (p.res) {
+      const f16x8 rv = *reinterpret_cast<const f16x8 *>(reinterpret_cast<const _Float16 *>(p.res) + go);
+#pragma unroll
+      for (int c = 0; c < 8; c++) v[c] = fmaxf(v[c] + (float)rv[c], 0.f);
+    }
+    f16x8 h;
+#pragma unroll
+    for (int c = 0; c < 8; c++) h[c] = (_Float16)(v[c] * p.out_scale);
+    *reinterpret_cast<f16x8 *>(reinterpret_cast<_Float16 *>(p.y) + go) = h;
+  }
+}
+
 // LDS-tiled fp16 variant: the layers of these towers are tiny (32/64 channels, <= 77k pixels), so
 // the direct kernel above spends its time on one global round trip per tap and on re-applying
 // the InstanceNorm prologue 9 (49) times per input value.  Here a workgroup owns an 8 x 16 output
@@ -487,59 +551,111 @@ __global__ void __launch_bounds__(256) conv_tile_f16_kernel(const ConvMulti pm) 
   }
   __syncthreads();          // every wave is done with the input / weight tiles
 
-  // ---- 3. epilogue: bias, statistics, ReLU -> fp32 tile in LDS
-  float *s_out = reinterpret_cast<float *>(smem);
+  conv_tile_epilogue<NT>(p, acc, smem, s_stat, oy0, ox0, n0);
+}
+
+// First layer of BOTH towers in one workgroup (7x7 stride 2, 16 fp32 input channels -> 32 channels per tower): the two
+// towers read the same super-state, so the halo tile is staged once and feeds four 16-channel output tiles.  Unlike
+// the generic tiled kernel the weight fragments are not parked in LDS (49 taps x 4 tiles = 100 KB) but streamed from
+// L2 through a ring of registers CONV7_PF taps deep -- LDS holds the 37 KB input tile only, four workgroups per CU
+// instead of one, and the 600 tiles of a 640x480 frame are one round (the generic kernel ran 2 x 600 workgroups at one
+// per CU: 41 us).  Same tap order and accumulation as conv_tile_f16_kernel<7, 2, true, 16, 2>: identical results.
+#ifndef CONV7_PF
+#define CONV7_PF 4
+#endif
+__global__ void __launch_bounds__(256) conv7_dual_kernel(const ConvMulti pm) {
+  constexpr int K = 7, S = 2, PAD = 3, TH = 8, TW = 16, NT = 2;
+  constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
+  constexpr int CIN = 16, PSTR = CIN * 2 + 16;        // LDS bytes per tile pixel
+  constexpr int CH8 = CIN / 4;                        // 16-byte (4 x fp32) items per pixel
+  constexpr int NITEM = IH * IW * CH8, NI = (NITEM + 255) / 256;
+  constexpr int IBYTES = IH * IW * PSTR;
+  constexpr int OBYTES = TH * TW * (NT * 16 + 4) * 4;
+  constexpr int SMB = IBYTES > OBYTES ? IBYTES : OBYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMB];
+  __shared__ float s_stat[4][NT * 16][2];
+  const ConvParams &p = pm.t[0];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, j = lane & 15;
+  const int tiles_x = (p.OW + TW - 1) / TW;
+  const int ty0 = blockIdx.x / tiles_x, tx0 = blockIdx.x - ty0 * tiles_x;
+  const int oy0 = ty0 * TH, ox0 = tx0 * TW;
+
+  // ---- 1. the halo tile: all loads first, fp32 -> fp16 into LDS
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 ibuf[NI];
+  bool iok[NI];
+  const int cslot = tid % CH8;
 #pragma unroll
-  for (int nt = 0; nt < NT; nt++) {
-    const int c = n0 + nt * 16 + j;
-    const float bv = p.bias ? p.bias[c] : 0.0f;
-    float s1 = 0.f, s2 = 0.f;
+  for (int n = 0; n < NI; n++) {
+    const int i = tid + n * 256;
+    const int pix = i / CH8, ty = pix / IW, tx = pix - ty * IW;
+    const int gy = oy0 * S + ty - PAD, gx = ox0 * S + tx - PAD;
+    iok[n] = i < NITEM && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+    const int cy = iok[n] ? gy : 0, cx = iok[n] ? gx : 0;
+    ibuf[n] = reinterpret_cast<const u32x4 *>(p.x)[((size_t)cy * p.W + cx) * CH8 + cslot];
+  }
+  // ---- the first taps' weight fragments: lane fragment = 8 bytes at ((tap * 2 + nt) * 64 + lane) * 8 of a tower's pack
+  f16x4 ring[CONV7_PF + 1][2][NT];
+  const unsigned char *w0 = reinterpret_cast<const unsigned char *>(pm.t[0].wpk) + lane * 8;
+  const unsigned char *w1 = reinterpret_cast<const unsigned char *>(pm.t[1].wpk) + lane * 8;
+  auto wfrag = [&](int tap, int t, int nt) {
+    return *reinterpret_cast<const f16x4 *>((t ? w1 : w0) + (size_t)(tap * NT + nt) * 512);
+  };
 #pragma unroll
-    for (int mt = 0; mt < 2; mt++) {
-      const int r = 2 * wave + mt;
+  for (int d = 0; d < CONV7_PF; d++)
 #pragma unroll
-      for (int rr = 0; rr < 4; rr++) {
-        const int xx = 4 * q + rr;
-        float v = acc[mt][nt][rr] + bv;
-        if (oy0 + r < p.OH && ox0 + xx < p.OW) { s1 += v; s2 += v * v; }
-        if (p.relu) v = fmaxf(v, 0.f);
-        s_out[(r * TW + xx) * OSTR + nt * 16 + j] = v;
-      }
-    }
-    if (p.stats) {
-      s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
-      s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
-      if (q == 0) { s_stat[wave][nt * 16 + j][0] = s1; s_stat[wave][nt * 16 + j][1] = s2; }
-    }
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) ring[d][t][nt] = wfrag(d, t, nt);
+#pragma unroll
+  for (int n = 0; n < NI; n++) {
+    const int i = tid + n * 256;
+    const int pix = i / CH8;
+    const f32x4 f = __builtin_bit_cast(f32x4, ibuf[n]);
+    f16x4 h;
+#pragma unroll
+    for (int c = 0; c < 4; c++) h[c] = iok[n] ? (_Float16)f[c] : (_Float16)0.f;
+    if (i < NITEM) *reinterpret_cast<f16x4 *>(smem + pix * PSTR + cslot * 8) = h;
   }
   __syncthreads();
-  if (p.stats && tid < NT * 32) {
-    const int c = tid >> 1, k = tid & 1;
-    const float v = ((s_stat[0][c][k] + s_stat[1][c][k]) + s_stat[2][c][k]) + s_stat[3][c][k];
-    p.stats[((size_t)(n0 + c) * 2 + k) * gridDim.x + blockIdx.x] = v;   // [C][2][nblk]: contiguous per channel
-  }
-  // 16-byte pieces: pixel-major, 8 channels each
-  constexpr int PPP = NT * 2;                         // pieces per pixel
-  for (int i = tid; i < TH * TW * PPP; i += 256) {
-    const int pix = i / PPP, piece = i - pix * PPP;
-    const int r = pix / TW, xx = pix - r * TW;
-    const int oy = oy0 + r, ox = ox0 + xx;
-    if (oy >= p.OH || ox >= p.OW) continue;
-    const float *sv = s_out + pix * OSTR + piece * 8;
-    const size_t go = ((size_t)oy * p.OW + ox) * p.Cout + n0 + piece * 8;
-    float v[8];
+
+  // ---- 2. 49 taps x (2 row tiles x 4 channel tiles) MFMA from LDS / the ring
+  f32x4 acc[2][2][NT];                                // [tower][mt][nt]
 #pragma unroll
-    for (int c = 0; c < 8; c++) v[c] = sv[c];
-    if (p.res) {
-      const f16x8 rv = *reinterpret_cast<const f16x8 *>(reinterpret_cast<const _Float16 *>(p.res) + go);
+  for (int t = 0; t < 2; t++)
 #pragma unroll
-      for (int c = 0; c < 8; c++) v[c] = fmaxf(v[c] + (float)rv[c], 0.f);
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int b = 0; b < NT; b++) acc[t][a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const unsigned char *a_base = smem + ((2 * wave) * S * IW + j * S) * PSTR + q * 8;
+#pragma unroll
+  for (int tap = 0; tap < K * K; tap++) {
+    if (tap + CONV7_PF < K * K) {
+#pragma unroll
+      for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) ring[(tap + CONV7_PF) % (CONV7_PF + 1)][t][nt] = wfrag(tap + CONV7_PF, t, nt);
     }
-    f16x8 h;
+#ifndef CONV7_NOSB
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    const int ky = tap / K, kx = tap - ky * K;
+    f16x4 a[2];
 #pragma unroll
-    for (int c = 0; c < 8; c++) h[c] = (_Float16)(v[c] * p.out_scale);
-    *reinterpret_cast<f16x8 *>(reinterpret_cast<_Float16 *>(p.y) + go) = h;
+    for (int mt = 0; mt < 2; mt++)
+      a[mt] = *reinterpret_cast<const f16x4 *>(a_base + ((mt * S + ky) * IW + kx) * PSTR);
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+          acc[t][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a[mt], ring[tap % (CONV7_PF + 1)][t][nt], acc[t][mt][nt], 0, 0, 0);
   }
+  __syncthreads();          // every wave is done with the input tile
+  conv_tile_epilogue<NT>(pm.t[0], acc[0], smem, s_stat, oy0, ox0, 0);
+  __syncthreads();          // the staging tile and the statistics table are reused
+  conv_tile_epilogue<NT>(pm.t[1], acc[1], smem, s_stat, oy0, ox0, 0);
 }
 
 // InstanceNorm statistics: partial[nblk][C][2] -> scale = rstd, shift = -mean*rstd (biased variance)
@@ -1027,6 +1143,13 @@ int ramp_conv2d_nhwc_multi(const ramp_conv_job *jobs, int njobs, int H, int W, i
   const dim3 block(256);
   const int tiles = ramp_cdiv(OH, 8) * ramp_cdiv(OW, 16);
   hipStream_t st = (hipStream_t)stream;
+  // the first layer of the two towers: one workgroup per tile computes both (shared input, no prologue)
+  if (KH == 7 && stride == 2 && in_f32 && Cin == 16 && njobs == 2 && jobs[0].x == jobs[1].x && jobs[0].Cout == 32 &&
+      jobs[1].Cout == 32 && !jobs[0].pre_scale && !jobs[1].pre_scale && !getenv("RAMP_CONV7_SINGLE")) {
+    hipLaunchKernelGGL(conv7_dual_kernel, dim3(tiles, 1, 1), block, 0, st, pm);
+    RAMP_CHECK_LAUNCH();
+    return RAMP_OK;
+  }
 #define TILE_CASE(K, S, INF32, CIN, NT)                                                              \
   if (KH == K && stride == S && in_f32 == INF32 && Cin == CIN && (NT == 2 || cgcd_ok64)) {            \
     hipLaunchKernelGGL((conv_tile_f16_kernel<K, S, INF32, CIN, NT>), dim3(tiles, cmax / (NT * 16), njobs), \
