@@ -265,8 +265,8 @@ int ramp_segment_softmax_sum(const void *fx, const void *gx, const int32_t *orde
  *   target, weight [E][2]; lmbda [1]; intrinsics [>=1][4] (row 0 is used,
  *   ba_cuda.cu:253-258)
  *   info: optional device int (bit mask, zeroed by the call): bit 0 = the Cholesky factorisation hit a
- *         non-positive pivot (the reference discards cholesky_ex's info and returns NaN poses; here the pose step of
- *         that iteration is dropped); bit 1 = more than 1024 pose-pair records touch one pose (> 512 frames
+ *         non-positive pivot or produced a step that is not finite (the reference discards cholesky_ex's info and
+ *         returns NaN poses; here the pose step of that iteration is dropped); bit 1 = more than 1024 pose-pair records touch one pose (> 512 frames
  *         connected to one frame): the normal equations are incomplete, the result must be discarded
  * Deterministic: all reductions are ordered segment sums, no float atomics.  */
 size_t ramp_ba_workspace_bytes(int E, int n_poses, int n_patches, int t0, int t1);

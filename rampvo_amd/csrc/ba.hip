@@ -680,8 +680,17 @@ __global__ void __launch_bounds__(TG * TG)
     }
     __syncthreads();
   }
-  // a failed factorisation drops the pose step (see ba_chol_kernel)
-  for (int q = tid; q < n6; q += nt) dX[q] = bad ? 0.0f : xv[q];
+  // a failed factorisation -- or a step that is not finite: a vanishing pivot passes the sign test -- drops the pose
+  // step (see ba_chol_kernel); bit 0 of *info either way
+  __shared__ int s_nf;
+  if (tid == 0) s_nf = 0;
+  __syncthreads();
+  for (int q = tid; q < n6; q += nt)
+    if (!(fabsf(xv[q]) <= 3.0e38f)) s_nf = 1;
+  __syncthreads();
+  const bool drop = bad || s_nf != 0;
+  if (!bad && s_nf != 0 && tid == 0 && info) atomicOr(info, 1);
+  for (int q = tid; q < n6; q += nt) dX[q] = drop ? 0.0f : xv[q];
 }
 
 // ------------------------------------------------------------------ K7

@@ -315,6 +315,9 @@ def test_evaluate_harness_run_and_run_pose_pred():
     assert points.shape[1] == 3 and points.shape[0] == colors.shape[0] and points.shape[0] % 32 == 0
     tr = ev.Trajectory.from_terminate(poses, ts)
     assert ev.ate_rmse(tr.positions_xyz, tr.positions_xyz) < 1e-12
+    # (the throughput weight profile on purpose: its random confidences on extrapolated targets of 1e4..1e5 px leave a
+    # window whose normal equations are singular to fp32 in one of the twelve closing updates -- the solve kernel's
+    # non-finite-step guard drops that pose step, bit 0 of the BA info word, and the run stays finite)
     p2, ts2 = ev.run_pose_pred(cfg, make_network("SingleScale"), eval_cfg, data, t_horizon_to_pred=3, t_to_pred=16,
                                deg_approx=4, ht=240, wd=320)
     assert p2.shape == (16 + 4, 7) and np.isfinite(p2).all()        # 16 tracked frames + predictions for t = 16..19
