@@ -506,6 +506,11 @@ struct CorrTailParams {
   int E;
 };
 
+#ifdef GRU_TRACE
+#define CT(k) do { if (threadIdx.x == 0) g_gru_trace[blockIdx.x * 32 + (k)] = wall_clock64(); } while (0)
+#else
+#define CT(k)
+#endif
 template <bool FULL>
 __global__ void __launch_bounds__(64 * MWAVES) __attribute__((amdgpu_waves_per_eu(6, 6)))
     upd_corr_tail_kernel(const CorrTailParams p) {
@@ -515,6 +520,20 @@ __global__ void __launch_bounds__(64 * MWAVES) __attribute__((amdgpu_waves_per_e
   const int row0 = blockIdx.x * MBM;
   const int col0 = wave * (16 * MNTW);
   f4 acc[1][4][MNTW];
+  CT(0);
+  // the rows of the previous state and of the context table this tile will add in its last pass: their indices are
+  // fetched now (the last pass used to start with two dependent round trips per row, eight rows per wave in sequence)
+  __shared__ long s_ra[MBM], s_rb[MBM];
+  if (tid < MBM) {
+    const int row = row0 + tid;
+    long ra = -1, rb = 0;
+    if (row < p.E) {
+      ra = p.net ? (p.net_map ? p.net_map[row] : (long)row) : -1;
+      rb = p.inp_idx ? p.inp_idx[row] : (long)row;
+      if (p.inp_mod > 0) rb %= p.inp_mod;
+    }
+    s_ra[tid] = ra; s_rb[tid] = rb;
+  }
   if (FULL) {
     // Linear1 over K = corr_k in chunks of <= 12 K steps (the tile is 384 wide), then relu(+b1) becomes the tile
 #pragma unroll
@@ -553,10 +572,12 @@ __global__ void __launch_bounds__(64 * MWAVES) __attribute__((amdgpu_waves_per_e
     }
   }
   __syncthreads();
+  CT(1);
   {
     const _Float16 *const w1[1] = {p.w2};
     mlp_gemm<1>(Xs, w1, wave, lane, acc);
   }
+  CT(2);
   float y[4][MNTW][4];
 #pragma unroll
   for (int nt = 0; nt < MNTW; nt++) {
@@ -599,6 +620,7 @@ __global__ void __launch_bounds__(64 * MWAVES) __attribute__((amdgpu_waves_per_e
       for (int k = 0; k < 3; k++) *reinterpret_cast<h2 *>(Xs + rt * MXS + 2 * lane + 128 * k) = hrow[half][rr][k];
     }
   __syncthreads();
+  CT(3);
   {
     const _Float16 *const w1[1] = {p.w3};
     mlp_gemm<1>(Xs, w1, wave, lane, acc);
@@ -611,6 +633,7 @@ __global__ void __launch_bounds__(64 * MWAVES) __attribute__((amdgpu_waves_per_e
 #pragma unroll
       for (int r = 0; r < 4; r++) y[mt][nt][r] = h_round(acc[0][mt][nt][r] + b);
   }
+  CT(4);
   __syncthreads();
   // row pass 2: net_prev + inp + c (in that order), LayerNorm, fp32 store
 #pragma unroll
@@ -625,19 +648,15 @@ __global__ void __launch_bounds__(64 * MWAVES) __attribute__((amdgpu_waves_per_e
       float v[3][2];
 #pragma unroll
       for (int k = 0; k < 3; k++) { v[k][0] = 0.f; v[k][1] = 0.f; }
-      if (p.net) {
-        const long ra = p.net_map ? p.net_map[row] : (long)row;
-        if (ra >= 0) {
+      const long ra = s_ra[half * MPR + rl], rb = s_rb[half * MPR + rl];
+      if (ra >= 0) {
 #pragma unroll
-          for (int k = 0; k < 3; k++) {
-            const float2 a = *reinterpret_cast<const float2 *>(p.net + (size_t)ra * MD + 2 * lane + 128 * k);
-            v[k][0] = a.x; v[k][1] = a.y;
-          }
+        for (int k = 0; k < 3; k++) {
+          const float2 a = *reinterpret_cast<const float2 *>(p.net + (size_t)ra * MD + 2 * lane + 128 * k);
+          v[k][0] = a.x; v[k][1] = a.y;
         }
       }
       {
-        long rb = p.inp_idx ? p.inp_idx[row] : (long)row;
-        if (p.inp_mod > 0) rb %= p.inp_mod;
         const _Float16 *b = p.inp + (size_t)rb * MD;
 #pragma unroll
         for (int k = 0; k < 3; k++) {
@@ -657,6 +676,7 @@ __global__ void __launch_bounds__(64 * MWAVES) __attribute__((amdgpu_waves_per_e
     }
     __syncthreads();
   }
+  CT(5);
 }
 
 // SoftAgg front half (ramp/blocks.py:42-46): fg[e] = [f(x_e) | g(x_e)] for x = x32 (+ add_t[add_idx], the previous
