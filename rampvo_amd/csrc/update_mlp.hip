@@ -868,21 +868,32 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) upd_nbr_big_kernel(const NbrP
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
   const int row0 = blockIdx.x * ROWS;
   const int col0 = wave * (16 * NTW);
-  // gather: wave w stages rows w, w + NW, ... (lane l: channels 2l + 128k): 512-byte contiguous reads
-  for (int r = wave; r < ROWS; r += NW) {
-    float2 v[3];
+  // gather: wave w stages rows w, w + NW, ... (lane l: channels 2l + 128k): 512-byte contiguous reads.  All of the
+  // wave's neighbour indices first, then all of its rows: one dependent round trip per workgroup instead of one per
+  // row (branch-free: a missing neighbour reads row 0 and is masked)
+  constexpr int RPW = ROWS / NW;
+  {
+    long src[RPW];
 #pragma unroll
-    for (int k = 0; k < 3; k++) v[k] = make_float2(0.f, 0.f);
-    if (row0 + r < p.E) {
-      const long src = p.idx[row0 + r];
-      if (src >= 0) {
+    for (int i = 0; i < RPW; i++) {
+      const int row = row0 + wave + i * NW;
+      src[i] = p.idx[row < p.E ? row : p.E - 1];
+      if (row >= p.E) src[i] = -1;
+    }
+    float2 v[RPW][3];
 #pragma unroll
-        for (int k = 0; k < 3; k++) v[k] = *reinterpret_cast<const float2 *>(p.net_in + (size_t)src * MD + 2 * lane + 128 * k);
-      }
+    for (int i = 0; i < RPW; i++) {
+      const float *b = p.net_in + (size_t)(src[i] >= 0 ? src[i] : 0) * MD + 2 * lane;
+#pragma unroll
+      for (int k = 0; k < 3; k++) v[i][k] = *reinterpret_cast<const float2 *>(b + 128 * k);
     }
 #pragma unroll
-    for (int k = 0; k < 3; k++)
-      *reinterpret_cast<h2 *>(Xs + r * MXS + 2 * lane + 128 * k) = (h2){(_Float16)v[k].x, (_Float16)v[k].y};
+    for (int i = 0; i < RPW; i++)
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const float2 a = src[i] >= 0 ? v[i][k] : make_float2(0.f, 0.f);
+        *reinterpret_cast<h2 *>(Xs + (wave + i * NW) * MXS + 2 * lane + 128 * k) = (h2){(_Float16)a.x, (_Float16)a.y};
+      }
   }
   unsigned ro[NMT];
   const unsigned live = big_row_offsets<NMT>(ro, row0, col0, q, j, p.E);
@@ -923,34 +934,49 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) upd_fg_big_kernel(const FgPar
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
   const int row0 = blockIdx.x * ROWS;
   const int col0 = wave * (16 * NTW);
-  for (int r = wave; r < ROWS; r += NW) {
-    const int row = row0 + r;
-    float v[3][2];
+  // stage x = x32 (+ add_t[add_idx]): all of the wave's group indices first, then all of its rows (rows past E read
+  // row E - 1 and are not written back)
+  constexpr int RPW = ROWS / NW;
+  {
+    int ai[RPW];
 #pragma unroll
-    for (int k = 0; k < 3; k++) { v[k][0] = 0.f; v[k][1] = 0.f; }
-    if (row < p.E) {                                     // wave-uniform
+    for (int i = 0; i < RPW; i++) {
+      const int row = row0 + wave + i * NW;
+      ai[i] = p.add_t ? p.add_idx[row < p.E ? row : p.E - 1] : 0;
+    }
+    float2 v[RPW][3];
 #pragma unroll
-      for (int k = 0; k < 3; k++) {
-        const float2 a = *reinterpret_cast<const float2 *>(p.x32 + (size_t)row * MD + 2 * lane + 128 * k);
-        v[k][0] = a.x; v[k][1] = a.y;
+    for (int i = 0; i < RPW; i++) {
+      const int row = row0 + wave + i * NW;
+      const float *b = p.x32 + (size_t)(row < p.E ? row : p.E - 1) * MD + 2 * lane;
+#pragma unroll
+      for (int k = 0; k < 3; k++) v[i][k] = *reinterpret_cast<const float2 *>(b + 128 * k);
+    }
+    if (p.add_t) {                                       // uniform
+      h2 t[RPW][3];
+#pragma unroll
+      for (int i = 0; i < RPW; i++) {
+        const _Float16 *b = p.add_t + (size_t)ai[i] * MD + 2 * lane;
+#pragma unroll
+        for (int k = 0; k < 3; k++) t[i][k] = *reinterpret_cast<const h2 *>(b + 128 * k);
       }
-      if (p.add_t) {
-        const _Float16 *b = p.add_t + (size_t)p.add_idx[row] * MD;
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-          const h2 t = *reinterpret_cast<const h2 *>(b + 2 * lane + 128 * k);
-          v[k][0] += (float)t[0]; v[k][1] += (float)t[1];
-        }
-      }
-      if (p.x32_out) {
+      for (int i = 0; i < RPW; i++)
 #pragma unroll
-        for (int k = 0; k < 3; k++)
-          *reinterpret_cast<float2 *>(p.x32_out + (size_t)row * MD + 2 * lane + 128 * k) = make_float2(v[k][0], v[k][1]);
-      }
+        for (int k = 0; k < 3; k++) { v[i][k].x += (float)t[i][k][0]; v[i][k].y += (float)t[i][k][1]; }
     }
 #pragma unroll
-    for (int k = 0; k < 3; k++)
-      *reinterpret_cast<h2 *>(Xs + r * MXS + 2 * lane + 128 * k) = (h2){(_Float16)v[k][0], (_Float16)v[k][1]};
+    for (int i = 0; i < RPW; i++) {
+      const int r = wave + i * NW, row = row0 + r;
+      const bool live_row = row < p.E;                   // wave-uniform
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        if (live_row && p.x32_out)
+          *reinterpret_cast<float2 *>(p.x32_out + (size_t)row * MD + 2 * lane + 128 * k) = v[i][k];
+        const float2 a = live_row ? v[i][k] : make_float2(0.f, 0.f);
+        *reinterpret_cast<h2 *>(Xs + r * MXS + 2 * lane + 128 * k) = (h2){(_Float16)a.x, (_Float16)a.y};
+      }
+    }
   }
   unsigned ro[NMT];
   const unsigned live = big_row_offsets<NMT>(ro, row0, col0, q, j, p.E);
