@@ -333,7 +333,7 @@ __global__ void __launch_bounds__(64)
 extern "C" {
 
 size_t ramp_group_by_small_workspace_bytes(int E, int K) {
-  return align_up((size_t)(K + 1) * 4, 256) * 2 + align_up((size_t)(E > 0 ? E : 1) * 4, 256) + 256;
+  return align_up((size_t)(K + 2) * 4, 256) * 2 + align_up((size_t)(E > 0 ? E : 1) * 4, 256) + 256;
 }
 
 int ramp_group_by_small(const int64_t *a, const int64_t *b, int64_t mul, int64_t sub, int K, int E,
@@ -349,12 +349,11 @@ int ramp_group_by_small(const int64_t *a, const int64_t *b, int64_t mul, int64_t
   if (!a || !order || !ws) return RAMP_EINVAL;
   if (ws_bytes < ramp_group_by_small_workspace_bytes(E, K)) return RAMP_EWORKSPACE;
   char *base = (char *)ws;
-  int32_t *hist = (int32_t *)base;
-  int32_t *gidmap = (int32_t *)(base + align_up((size_t)(K + 1) * 4, 256));
-  int32_t *tmp = (int32_t *)(base + 2 * align_up((size_t)(K + 1) * 4, 256));
-  int32_t *bad = (int32_t *)(base + 2 * align_up((size_t)(K + 1) * 4, 256) + align_up((size_t)E * 4, 256));
-  (void)hipMemsetAsync(hist, 0, (size_t)(K + 1) * 4, st);
-  (void)hipMemsetAsync(bad, 0, 4, st);
+  int32_t *hist = (int32_t *)base;                 // [K + 1] counts, then the out-of-range flag: one memset for both
+  int32_t *bad = hist + (K + 1);
+  int32_t *gidmap = (int32_t *)(base + align_up((size_t)(K + 2) * 4, 256));
+  int32_t *tmp = (int32_t *)(base + 2 * align_up((size_t)(K + 2) * 4, 256));
+  (void)hipMemsetAsync(hist, 0, (size_t)(K + 2) * 4, st);
   const int nb = ramp_cdiv(E, 256);
   const bool lds = K <= GBC_LDS_K;
   if (lds)
