@@ -133,6 +133,8 @@ int ramp_event_stack(const int32_t *x, const int32_t *y, const int8_t *p, int N,
  * inverse depths of the last F frames' patches -- patches_src = &patches_[n-F], [F][M][3][P][P] -- written
  * into channel 2 of the M new patches patches_dst [M][3][P][P].  F*M*P*P <= 4096.                   */
 int ramp_depth_median_fill(const float *patches_src, int F, int M, int P, float *patches_dst, void *stream);
+/* the same median into device memory (*out), for a caller that computes it ahead of ramp_frame_commit (median_dev) */
+int ramp_depth_median(const float *patches_src, int F, int M, int P, float *out, void *stream);
 
 /* Event-biased patch-centre selection: get_coords_from_topk_events + nms_image
  * (ramp/utils.py:186-226, 157-183; upstream ~20 ATen launches) for one frame.
@@ -211,7 +213,7 @@ int ramp_frame_begin(float *poses, int n, int motion, float damping, int64_t *ts
 int ramp_frame_commit(float *poses, int n, int motion, float damping, int64_t *tstamps, int64_t counter,
                       int64_t *index_map, int64_t index_val, float *intrinsics, int copy_k, float *patches_state,
                       int median_frames, int M, int P, float *patches_new, int n_copy, const void *const *src_host,
-                      void *const *dst_host, const long *bytes_host, void *stream);
+                      void *const *dst_host, const long *bytes_host, const float *median_dev, void *stream);
 
 /* Tracker bookkeeping helpers (host-side pointer arrays, <= 10 buffers per call).
  * ramp_multi_copy: dst[b][0:bytes[b]) = src[b][...] -- the per-frame stores of imap/gmap/fmap1/fmap2/

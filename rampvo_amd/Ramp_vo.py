@@ -118,6 +118,9 @@ class Ramp_vo:
         self._corr_levels = None
         self._fe_free = None
         self._ba_event = None
+        self._median_dev = None        # device scalar: median depth of the three newest frames, computed after BA
+        self._median_n = None          # self.n at that moment (valid for the next frame's commit at n or n - 1)
+        self._median_synced = True     # the current stream has waited for the stream it was computed on
         self._init_streams(dev)
         self.net = torch.zeros(1, 0, DIM, dtype=torch.float, device=dev)   # hidden state is fp32 (as under autocast)
         self.ii = torch.zeros(0, dtype=torch.long, device=dev)
@@ -161,6 +164,7 @@ class Ramp_vo:
         # events are re-recorded every frame (creating one costs a hipEventCreate/Destroy pair per use)
         mk = lambda: torch.cuda.Event()
         self._ev_done, self._ev_fe_done, self._ev_fe_free, self._ev_ba, self._ev_up = mk(), mk(), mk(), mk(), mk()
+        self._ev_med = mk()
         self._mm_host = torch.empty(2, dtype=torch.float32).pin_memory()
 
     # ------------------------------------------------------------------ weights
@@ -294,6 +298,7 @@ class Ramp_vo:
         # nothing prepared for the previous state may survive: the speculative next-frame graph (validated only by
         # its sizes), the keyframe predictor, the intrinsics row cache, the pinned layout buffers' bookkeeping
         self._pre_cache, self._pending, self._net_map_dev = None, None, None
+        self._median_n = None
         self._mm_prev, self._spec_ema = None, 1.0
         self._last_K = self._last_K_raw = None
         self._last_K_row = -1
@@ -591,6 +596,7 @@ class Ramp_vo:
         """current stream waits for everything queued on the upload stream (wait_stream without a new event)"""
         self._ev_up.record(self._up_stream)
         self._cur().wait_event(self._ev_up)
+        self._median_synced = True
 
     def _spec_outcome(self, remove, k):
         """the graph after keyframe() for one outcome of the motion test, laid out together with the next frame's
@@ -728,6 +734,18 @@ class Ramp_vo:
                           self.kk, t0, self.n, M=self.M, iterations=2, eff_impl=False, info=self._ba_info, plan=plan)
             except Exception as e:  # same recovery as the reference (:302-306)
                 print(f"WARNING: BA failed...{e}")
+            if (self.is_initialized and self.n >= 3 and self._up_stream is not None
+                    and ops.depth_median_supported(3, self.M, self.P)):
+                # the next frame's initial depth (reference :369-372: the median of the three newest frames) does not
+                # depend on the keyframe decision (it drops an older frame): computed now, on the side stream, instead of
+                # inside the next frame's commit launch between the read-back and the correlation kernel
+                if self._median_dev is None:
+                    self._median_dev = torch.empty(1, dtype=torch.float32, device=self.device)
+                self._ev_med.record(self._cur())
+                self._up_stream.wait_event(self._ev_med)
+                with torch.cuda.stream(self._up_stream):
+                    ops.depth_median(self.patches_, self.n, 3, self._median_dev)
+                self._median_n, self._median_synced = self.n, False
             if self._ixm is None or self._ixm.shape[0] < self.m:
                 self._ixm = torch.arange(self.N * self.M, device=self.device) // self.M     # patch -> source frame
             ixm = self._ixm[:self.m]
@@ -829,12 +847,18 @@ class Ramp_vo:
             motion = 0 if n <= 1 else (1 if self.cfg.MOTION_MODEL == 'DAMPED_LINEAR' else 2)
             if not self.is_initialized:
                 patches[:, :, 2] = self._initial_depth(patches)       # reference :369; replaced by the median later
+            med = None
+            if self.is_initialized and self._median_n is not None and self._median_n in (n, n + 1):
+                if not self._median_synced:
+                    self._wait_upload_stream()
+                med = self._median_dev
+            self._median_n = None                          # one use: the next update() computes the next one
             ops.frame_commit(self.poses_, n, motion, self.cfg.MOTION_DAMPING, self.tstamps_, self.counter,
                              self.index_map_, self.m + self.M, self.intrinsics_, copy_k, self.patches_,
                              3 if self.is_initialized else 0, patches,
                              [ex["colors"], ex["imap"], ex["gmap"], ex["fmap"], ex["fmap2"]],
                              [(self.colors_, n), (self.imap_, slot), (self.gmap_, slot), (self.fmap1_, slot),
-                              (self.fmap2_, slot)])
+                              (self.fmap2_, slot)], median_dev=med)
         else:
             self._frame_stores_stepwise(n, slot, k_dev, kq, patches, imap, gmap, fmap, clr, ex)
         self._last_K_row = n                         # row n now holds _last_K (written or copied from row n-1)
@@ -927,6 +951,7 @@ class Ramp_vo:
 
     def update_attributes(self, abs_time, next_frame_index, poses):
         """expose the virtual pose to terminate() (reference :510-519)"""
+        self._median_n = None
         assert self._tstamps[self.n - 1] != 0 if self._tstamps else int(self.tstamps_[self.n - 1]) != 0
         self.tstamps_[self.n] = abs_time
         del self._tstamps[self.n:]
@@ -939,6 +964,7 @@ class Ramp_vo:
     def remove_attributes(self):
         """undo update_attributes (reference :521-528; upstream's ``poses_[:,6] = 1.0`` there rewrites the qw of
         EVERY keyframe -- only the removed row is reset here)"""
+        self._median_n = None
         self.n -= 1
         self.counter -= 1
         self.tlist.pop()

@@ -42,6 +42,7 @@ SIGNATURES = {
     "ramp_event_stack_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "ramp_event_stack": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_sz, c_p]),
     "ramp_depth_median_fill": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p]),
+    "ramp_depth_median": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p]),
     "ramp_event_topk_workspace_bytes": (c_sz, [c_i, c_i]),
     "ramp_event_topk": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_sz, c_p]),
     "ramp_pyramid_pack": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
@@ -62,7 +63,7 @@ SIGNATURES = {
     "ramp_motionmag": (c_i, [c_p] * 10 + [c_i64, c_i64, c_f, c_p, c_i, c_p]),
     "ramp_motion_model": (c_i, [c_p, c_i, c_f, c_p]),
     "ramp_frame_commit": (c_i, [c_p, c_i, c_i, c_f, c_p, c_i64, c_p, c_i64, c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_i,
-                                ctypes.POINTER(c_p), ctypes.POINTER(c_p), ctypes.POINTER(ctypes.c_long), c_p]),
+                                ctypes.POINTER(c_p), ctypes.POINTER(c_p), ctypes.POINTER(ctypes.c_long), c_p, c_p]),
     "ramp_frame_begin": (c_i, [c_p, c_i, c_i, c_f, c_p, c_i64, c_p, c_i64, c_p, c_i, c_p]),
     "ramp_group_by_workspace_bytes": (c_sz, [c_i]),
     "ramp_group_by": (c_i, [c_p, c_i, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),

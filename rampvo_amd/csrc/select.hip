@@ -275,6 +275,14 @@ __global__ void __launch_bounds__(MED_THREADS)
   }
 }
 
+// the median alone, into device memory: the tracker computes it right after bundle adjustment, off the critical path
+// (the three newest frames are the same whether or not the keyframe test then drops an older one)
+__global__ void __launch_bounds__(MED_THREADS)
+    depth_median_kernel(const float *__restrict__ src, int F, int M, int PP, float *__restrict__ out) {
+  const float med = depth_median_block(src, F, M, PP);
+  if (threadIdx.x == 0) *out = med;
+}
+
 // Everything a steady-state Ramp_vo.__call__ writes before its reprojection (ramp/Ramp_vo.py:345-381) as ONE launch
 // -- these were three dependent tiny launches on the frame's critical path.  Workgroup (0, 0): time stamp, index
 // map, intrinsics row, motion-model pose (ramp_frame_begin), the depth median (ramp_depth_median_fill) and the new
@@ -285,6 +293,7 @@ struct FrameCommit {
   float *intrinsics; int copy_k;
   const float *median_src; int F, M, PP; float *patches_new; float *patches_row;
   int n_copy; const char *src[FC_MAXBUF]; char *dst[FC_MAXBUF]; long bytes[FC_MAXBUF];
+  const float *median_val;   // optional: the median of median_src, computed ahead (ramp_depth_median)
 };
 __global__ void __launch_bounds__(MED_THREADS) frame_commit_kernel(const FrameCommit a) {
   const int t = threadIdx.x;
@@ -317,7 +326,7 @@ __global__ void __launch_bounds__(MED_THREADS) frame_commit_kernel(const FrameCo
     for (int c = 0; c < 7; c++) a.poses[7 * n + c] = Pn[c];
   }
   const bool fill = a.F > 0;
-  const float med = fill ? depth_median_block(a.median_src, a.F, a.M, a.PP) : 0.f;
+  const float med = !fill ? 0.f : (a.median_val ? *a.median_val : depth_median_block(a.median_src, a.F, a.M, a.PP));
   for (int i = t; i < a.M * 3 * a.PP; i += MED_THREADS) {
     const int ch = (i / a.PP) % 3;
     float v = a.patches_new[i];
@@ -365,10 +374,18 @@ int ramp_event_topk(const float *events, int bins, int H, int W, int k, int nms_
   return RAMP_OK;
 }
 
+int ramp_depth_median(const float *patches_src, int F, int M, int P, float *out, void *stream) {
+  if (!patches_src || !out || F <= 0 || M <= 0 || P <= 0) return RAMP_EINVAL;
+  if ((long)F * M * P * P > MED_THREADS * MED_PER) return RAMP_EUNSUPPORTED;
+  hipLaunchKernelGGL(depth_median_kernel, dim3(1), dim3(MED_THREADS), 0, (hipStream_t)stream, patches_src, F, M, P * P, out);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+
 int ramp_frame_commit(float *poses, int n, int motion, float damping, int64_t *tstamps, int64_t counter,
                       int64_t *index_map, int64_t index_val, float *intrinsics, int copy_k, float *patches_state,
                       int median_frames, int M, int P, float *patches_new, int n_copy, const void *const *src_host,
-                      void *const *dst_host, const long *bytes_host, void *stream) {
+                      void *const *dst_host, const long *bytes_host, const float *median_dev, void *stream) {
   if (!poses || !patches_state || !patches_new || n < 0 || M <= 0 || P <= 0 || n_copy < 0 || n_copy > FC_MAXBUF)
     return RAMP_EINVAL;
   if ((motion == 1 && n < 2) || ((motion == 2 || copy_k) && n < 1) || (copy_k && !intrinsics)) return RAMP_EINVAL;
@@ -380,6 +397,7 @@ int ramp_frame_commit(float *poses, int n, int motion, float damping, int64_t *t
   const size_t row = (size_t)M * 3 * P * P;
   a.median_src = patches_state + (size_t)(n - median_frames) * row; a.F = median_frames; a.M = M; a.PP = P * P;
   a.patches_new = patches_new; a.patches_row = patches_state + (size_t)n * row;
+  a.median_val = median_dev;
   a.n_copy = n_copy;
   long mx = 0;
   for (int i = 0; i < n_copy; i++) {

@@ -300,10 +300,18 @@ def store_rows(srcs, rows):
     check(lib().ramp_multi_copy(src, dst, (ctypes.c_long * n)(*rb), n, stream()), "ramp_multi_copy")
 
 
+def depth_median(patches_state, n, frames, out):
+    """median depth of patches_state[n - frames : n] into the device scalar ``out`` (ramp_depth_median)"""
+    _, M, _, P, _ = patches_state.shape
+    check(lib().ramp_depth_median(ptr(patches_state[n - frames]), int(frames), M, P, ptr(out), stream()),
+          "ramp_depth_median")
+
+
 def frame_commit(poses, n, motion, damping, tstamps, counter, index_map, index_val, intrinsics, copy_k, patches_state,
-                 median_frames, patches_new, srcs, rows):
+                 median_frames, patches_new, srcs, rows, median_dev=None):
     """ramp_frame_commit: frame_begin + depth_median_fill + the state stores of one frame in one launch;
-    srcs[i] -> row rows[i][1] of buffer rows[i][0] (like store_rows), patches_new -> patches_state[n]"""
+    srcs[i] -> row rows[i][1] of buffer rows[i][0] (like store_rows), patches_new -> patches_state[n];
+    median_dev: the median of the last ``median_frames`` frames if the caller computed it ahead (depth_median)"""
     n_copy = len(srcs)
     rb = [b.stride(0) * b.element_size() for b, _ in rows]
     for s_, (b, _), nb in zip(srcs, rows, rb):
@@ -314,7 +322,7 @@ def frame_commit(poses, n, motion, damping, tstamps, counter, index_map, index_v
     check(lib().ramp_frame_commit(ptr(poses), int(n), int(motion), float(damping), ptr(tstamps), int(counter),
                                   ptr(index_map), int(index_val), ptr(intrinsics), int(bool(copy_k)), ptr(patches_state),
                                   int(median_frames), M, P, ptr(patches_new), n_copy, src, dst,
-                                  (ctypes.c_long * n_copy)(*rb), stream()), "ramp_frame_commit")
+                                  (ctypes.c_long * n_copy)(*rb), ptr(median_dev), stream()), "ramp_frame_commit")
 
 
 class ShiftPlan:
