@@ -171,6 +171,29 @@ def test_host_graph_edit_matches_numpy_logic():
         assert np.array_equal(out[2, :m], ref["kk"]) and np.array_equal(out[3, :m], rows[ref["idx"]])
 
 
+@pytest.mark.parametrize("window", ["window", "all_free"])
+def test_oracle_eff_impl_lookup_equals_dense(window):
+    """the oracle's restatement of the reference's ``eff_impl=True`` path (block-sparse E behind a per-frame block
+    table, fastba/block_e.cu:43-283: ``orc.ba(eff_ppf=M)``) against its restatement of the dense path
+    (fastba/ba_cuda.cu:433-582): the same Gauss-Newton step, so the two agree to fp32 rounding -- which is what lets
+    the product serve ``eff_impl`` from one storage"""
+    M = 14
+    s = ba_scene(seed=5, n_frames=9, M=M, lifetime=4, n_total_frames=12)
+    nf = s["n_frames"]
+    t0, t1 = (nf - 5, nf) if window == "window" else (1, nf)
+    out = []
+    for ppf in (0, M):
+        p, pt = s["poses"].copy(), s["patches"].copy()
+        st = orc.ba(p, pt, s["intr"], s["target"], s["weight"], s["lmbda"], s["ii"], s["jj"], s["kk"], t0, t1, 2, eff_ppf=ppf)
+        assert st == 0
+        out.append((p, pt))
+    step = np.abs(out[0][0] - s["poses"]).max()
+    assert step > 1e-4
+    tol = 1e-5 if window == "window" else 2e-4        # all_free: gauge freedom, the ill-conditioned case of the GPU test
+    assert np.abs(out[0][0] - out[1][0]).max() <= tol * max(1.0, step)
+    assert np.abs(out[0][1] - out[1][1]).max() <= 10 * tol * max(1.0, np.abs(out[0][1][:, 2]).max())
+
+
 def test_oracle_ba_properties():
     s = ba_scene(seed=5, n_frames=8, M=10, lifetime=4)
     p, pt = s["poses"].copy(), s["patches"].copy()
