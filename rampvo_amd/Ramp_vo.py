@@ -118,6 +118,8 @@ class Ramp_vo:
         self._corr_levels = None
         self._fe_free = None
         self._ba_event = None
+        self._fc_plan = None           # (front-end outputs, patches, FrameCommitPlan or None)
+        self._up_dirty = False         # something was enqueued on the upload stream since the last join
         self._median_dev = None        # device scalar: median depth of the three newest frames, computed after BA
         self._median_n = None          # self.n at that moment (valid for the next frame's commit at n or n - 1)
         self._median_synced = True     # the current stream has waited for the stream it was computed on
@@ -594,9 +596,12 @@ class Ramp_vo:
 
     def _wait_upload_stream(self):
         """current stream waits for everything queued on the upload stream (wait_stream without a new event)"""
+        if not self._up_dirty:
+            return
         self._ev_up.record(self._up_stream)
         self._cur().wait_event(self._ev_up)
         self._median_synced = True
+        self._up_dirty = False
 
     def _spec_outcome(self, remove, k):
         """the graph after keyframe() for one outcome of the motion test, laid out together with the next frame's
@@ -604,6 +609,7 @@ class Ramp_vo:
         cfg = self.cfg
         base_rows = self._net_map            # None: identity
         E, M = len(self._ii), self.M
+        self._up_dirty = True
         with torch.cuda.stream(self._up_stream):
             n_after = self.n - 1 if remove else self.n
             n1 = n_after + 1
@@ -686,6 +692,7 @@ class Ramp_vo:
         """plan of the graph this frame will have after append_factors, on the upload stream, concurrently with
         the encoder (the plan kernels are small; the front end leaves most CUs idle)"""
         b4, d4, tot = pre["host"], pre["dev"], pre["Ek"] + pre["ne"]
+        self._up_dirty = True
         with torch.cuda.stream(self._up_stream):
             pre["plan"] = self._build_plan(b4[0, :tot], b4[1, :tot], b4[2, :tot], d4[0, :tot], d4[1, :tot],
                                            d4[2, :tot], ranges=pre["ranges"])
@@ -741,6 +748,7 @@ class Ramp_vo:
                 # inside the next frame's commit launch between the read-back and the correlation kernel
                 if self._median_dev is None:
                     self._median_dev = torch.empty(1, dtype=torch.float32, device=self.device)
+                self._up_dirty = True
                 self._ev_med.record(self._cur())
                 self._up_stream.wait_event(self._ev_med)
                 with torch.cuda.stream(self._up_stream):
@@ -834,11 +842,21 @@ class Ramp_vo:
         self._tstamps.append(self.counter)
         ex = getattr(self.network.patchify, "_extra", None)
         slot = n % self.mem
-        if (ex is not None and ex["fmap"].dtype == self.dtype
-                and ex["chunked"] == self._chunked and (self.M * 3) % 16 == 0 and patches.is_contiguous()
-                and patches.dtype == torch.float32 and ops.depth_median_supported(3, self.M, self.P)
-                and (not self.is_initialized or n >= 3)
-                and all(ex[k].data_ptr() % 16 == 0 for k in ("colors", "imap", "gmap", "fmap", "fmap2"))):
+        # (the eligibility of the front end's outputs for the one-launch commit is checked once per output set: the
+        # hipGraph's static buffers are the same objects every frame)
+        fc = self._fc_plan
+        if ex is None or fc is None or fc[0] is not ex or fc[1] is not patches:
+            ok = (ex is not None and ex["fmap"].dtype == self.dtype
+                  and ex["chunked"] == self._chunked and (self.M * 3) % 16 == 0 and patches.is_contiguous()
+                  and patches.dtype == torch.float32 and ops.depth_median_supported(3, self.M, self.P)
+                  and all(ex[k].data_ptr() % 16 == 0 for k in ("colors", "imap", "gmap", "fmap", "fmap2")))
+            plan_fc = None
+            if ok:
+                plan_fc = ops.FrameCommitPlan([ex["colors"], ex["imap"], ex["gmap"], ex["fmap"], ex["fmap2"]],
+                                              [self.colors_, self.imap_, self.gmap_, self.fmap1_, self.fmap2_],
+                                              self.patches_)
+            fc = self._fc_plan = (ex, patches, plan_fc)
+        if fc[2] is not None and (not self.is_initialized or n >= 3):
             # bookkeeping writes, depth initialisation and all state stores of the frame: ONE launch
             copy_k = k_dev is None and n > 0
             if not copy_k:
@@ -853,12 +871,9 @@ class Ramp_vo:
                     self._wait_upload_stream()
                 med = self._median_dev
             self._median_n = None                          # one use: the next update() computes the next one
-            ops.frame_commit(self.poses_, n, motion, self.cfg.MOTION_DAMPING, self.tstamps_, self.counter,
-                             self.index_map_, self.m + self.M, self.intrinsics_, copy_k, self.patches_,
-                             3 if self.is_initialized else 0, patches,
-                             [ex["colors"], ex["imap"], ex["gmap"], ex["fmap"], ex["fmap2"]],
-                             [(self.colors_, n), (self.imap_, slot), (self.gmap_, slot), (self.fmap1_, slot),
-                              (self.fmap2_, slot)], median_dev=med)
+            fc[2].run(self.poses_, n, motion, self.cfg.MOTION_DAMPING, self.tstamps_, self.counter,
+                      self.index_map_, self.m + self.M, self.intrinsics_, copy_k, self.patches_,
+                      3 if self.is_initialized else 0, patches, (n, slot, slot, slot, slot), median_dev=med)
         else:
             self._frame_stores_stepwise(n, slot, k_dev, kq, patches, imap, gmap, fmap, clr, ex)
         self._last_K_row = n                         # row n now holds _last_K (written or copied from row n-1)

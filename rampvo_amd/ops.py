@@ -325,6 +325,35 @@ def frame_commit(poses, n, motion, damping, tstamps, counter, index_map, index_v
                                   (ctypes.c_long * n_copy)(*rb), ptr(median_dev), stream()), "ramp_frame_commit")
 
 
+class FrameCommitPlan:
+    """ramp_frame_commit for a fixed set of sources / destination buffers: the descriptor arrays are built once, a
+    call only fills in the destination rows (this launch sits between the keyframe read-back and the correlation
+    kernel, where the host is the limiter)"""
+
+    def __init__(self, srcs, bufs, patches_state):
+        n = self.n_copy = len(srcs)
+        self.keep = (list(srcs), list(bufs), patches_state)
+        self.rb = [b.stride(0) * b.element_size() for b in bufs]
+        for s_, b, nb in zip(srcs, bufs, self.rb):
+            assert s_.numel() * s_.element_size() == nb and s_.is_contiguous() and b.is_contiguous()
+        self.src = (ctypes.c_void_p * n)(*[s_.data_ptr() for s_ in srcs])
+        self.dst = (ctypes.c_void_p * n)()
+        self.base = [b.data_ptr() for b in bufs]
+        self.rbc = (ctypes.c_long * n)(*self.rb)
+        _, self.M, _, self.P, _ = patches_state.shape
+        self.src_ptrs = tuple(s_.data_ptr() for s_ in srcs)
+
+    def run(self, poses, n, motion, damping, tstamps, counter, index_map, index_val, intrinsics, copy_k, patches_state,
+            median_frames, patches_new, rows, median_dev=None):
+        for i in range(self.n_copy):
+            self.dst[i] = self.base[i] + int(rows[i]) * self.rb[i]
+        check(lib().ramp_frame_commit(ptr(poses), int(n), int(motion), float(damping), ptr(tstamps), int(counter),
+                                      ptr(index_map), int(index_val), ptr(intrinsics), int(bool(copy_k)),
+                                      ptr(patches_state), int(median_frames), self.M, self.P, ptr(patches_new),
+                                      self.n_copy, self.src, self.dst, self.rbc, ptr(median_dev), stream()),
+              "ramp_frame_commit")
+
+
 class ShiftPlan:
     """descriptor arrays of shift_rows for a fixed set of buffers (built once)"""
 
