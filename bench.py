@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--preset", default="default", choices=("default", "precise", "fast"),
                     help="config_vo preset for the BA / lifetime windows (configs[2] uses precise)")
     ap.add_argument("--opt-window", type=int, default=0, help="override OPTIMIZATION_WINDOW (configs[4]: 32)")
+    ap.add_argument("--encoder-fp8", type=int, default=0,
+                    help="1: the conv towers' products on the fp8 MFMA (configs[4]: 'fp16 encoder on fp8 MFMA'); needs --mixed 1")
     ap.add_argument("--mixed", type=int, default=1,
                     help="1 (default.yaml's MIXED_PRECISION: True): fp16 features / conv + GEMM I/O with fp32 "
                          "accumulation, fp32 hidden state, BA and geometry; 0: fp32 everywhere")
@@ -289,8 +291,8 @@ class EncoderTimer:
         from rampvo_amd import conv_hip
         timer, towers_inner = self, conv_hip.conv2d_towers
 
-        def counted(jobs, half):                      # every conv of the towers goes through conv2d_towers
-            ys = towers_inner(jobs, half)
+        def counted(jobs, half, *a, **k):             # every conv of the towers goes through conv2d_towers
+            ys = towers_inner(jobs, half, *a, **k)
             for j, y in zip(jobs, ys):
                 o = y.raw if isinstance(y, conv_hip.Pending) else y
                 cout, cin, kh, kw = j["conv"].weight.shape
@@ -472,6 +474,8 @@ def main():
     cfg_kwargs = dict(PATCHES_PER_FRAME=args.patches, MIXED_PRECISION=bool(args.mixed))
     if args.opt_window:
         cfg_kwargs["OPTIMIZATION_WINDOW"] = args.opt_window
+    if args.encoder_fp8:
+        cfg_kwargs["ENCODER_FP8"] = True
     cfg = make_cfg(args.preset, **cfg_kwargs)
     torch.manual_seed(1234 + rank)
     net = make_network(args.mode, device=dev)

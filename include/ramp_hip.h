@@ -367,6 +367,8 @@ typedef struct ramp_conv_job {
   float *stats;
   int32_t Cout, relu;
   float out_scale;
+  float act_scale, w_scale;   /* RAMP_CONV_FP8 only: x * act_scale and w * w_scale (wpk packed as e4m3 bytes) are the
+                                 MFMA operands, saturating at +-448; the accumulator is divided by their product */
 } ramp_conv_job;
 int ramp_conv2d_nhwc_multi(const ramp_conv_job *jobs, int njobs, int H, int W, int Cin, int KH, int stride,
                            int dtype, void *stream);
@@ -378,6 +380,10 @@ int ramp_conv2d_nhwc_multi(const ramp_conv_job *jobs, int njobs, int H, int W, i
 /* fp16 only: use the direct (one global round trip per tap) kernel instead of the LDS-tiled one;
  * both give identical results (kept for the A/B test)                                          */
 #define RAMP_CONV_DIRECT 0x20
+/* ramp_conv2d_nhwc_multi only, with RAMP_F16 (half in / out): the layer's products run on the fp8 MFMA
+ * (v_mfma_f32_16x16x32_fp8_fp8, OCP e4m3 operands, fp32 accumulate) -- BASELINE configs[4]'s "fp16 encoder on fp8
+ * MFMA"; weights packed as e4m3 fragments (rampvo_amd/conv_hip.py::pack_conv_weight mode "f8")                    */
+#define RAMP_CONV_FP8 0x40
 
 /* number of per-block partials ramp_conv2d_nhwc writes to `stats` for this layer shape / dtype   */
 int ramp_conv2d_stats_blocks(int H, int W, int Cin, int Cout, int KH, int stride, int dtype);

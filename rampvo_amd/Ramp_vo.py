@@ -189,6 +189,7 @@ class Ramp_vo:
         enc = getattr(self.network.patchify, "encoder", None)
         if hasattr(enc, "mixed_precision"):
             enc.mixed_precision = bool(self.cfg.MIXED_PRECISION)
+            enc.fp8_mfma = bool(self.cfg.get("ENCODER_FP8", False))
 
     # -------------------------------------------------------------------- views
     @property

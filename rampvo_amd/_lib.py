@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("RAMP_HIP_LIB") or os.path.join(CSRC, "libramp_hip.so"
 
 RAMP_F32, RAMP_F16 = 0, 1
 RAMP_EUNSUPPORTED = -4
+RAMP_CONV_FP8 = 0x40
 RAMP_IN_F32, RAMP_CONV_DIRECT, RAMP_CORR_MFMA32 = 0x10, 0x20, 0x40
 RAMP_NCHW, RAMP_NHWC, RAMP_NHWC8 = 0, 1, 2
 

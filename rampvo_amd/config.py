@@ -7,7 +7,10 @@ import yaml
 _DEFAULTS = dict(
     BUFFER_SIZE=2048, GRADIENT_BIAS=True, PATCHES_PER_FRAME=80, REMOVAL_WINDOW=20,
     OPTIMIZATION_WINDOW=12, PATCH_LIFETIME=12, KEYFRAME_INDEX=4, KEYFRAME_THRESH=12.5,
-    MOTION_MODEL='DAMPED_LINEAR', MOTION_DAMPING=0.5, MIXED_PRECISION=True)
+    MOTION_MODEL='DAMPED_LINEAR', MOTION_DAMPING=0.5, MIXED_PRECISION=True,
+    # not a reference key (BASELINE configs[4]): with MIXED_PRECISION, the conv towers' products run on the fp8 MFMA
+    # (fp16 storage, e4m3 operands, fp32 accumulate); off by default
+    ENCODER_FP8=False)
 
 # the reference's shipped presets (config_vo/{default,precise,fast}.yaml)
 PRESETS = {

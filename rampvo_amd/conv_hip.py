@@ -33,22 +33,28 @@ def available():
 def pack_conv_weight(conv, mode="f32"):
     """[Cout,Cin,KH,KW] -> MFMA fragment order [tap][Cin/KC][Cout/16][64 lanes][CPL]:
     lane (q = lane>>4, j = lane&15) holds W[16*nt + j][KC*ch + CPL*q + s], s < CPL.
-    mode "f32": KC=16, CPL=4 fp32;  "f16": KC=32, CPL=8 half;  "f16_first": KC=16, CPL=4 half"""
+    mode "f32": KC=16, CPL=4 fp32;  "f16": KC=32, CPL=8 half;  "f16_first": KC=16, CPL=4 half;
+    "f8": the "f16" order with OCP e4m3 bytes of w * w_scale, w_scale = 448 / max|w| (-> third return value)"""
     w = conv.weight
     key = (mode, w._version, w.device, w.data_ptr())
     hit = _cache(conv).get(mode)
     if hit is not None and hit[0] == key:
-        return hit[1], hit[2]
-    kc, cpl = (32, 8) if mode == "f16" else (16, 4)
+        return hit[1:] if mode == "f8" else (hit[1], hit[2])
+    kc, cpl = (32, 8) if mode in ("f16", "f8") else (16, 4)
     cout, cin, kh, kw = w.shape
     cin_p = (cin + kc - 1) // kc * kc
     wp = torch.zeros(cout, cin_p, kh, kw, dtype=torch.float32, device=w.device)
     wp[:, :cin] = w.detach().float()
     t = wp.permute(2, 3, 1, 0).reshape(kh * kw, cin_p // kc, 4, cpl, cout // 16, 16)   # tap, ch, q, s, nt, j
     t = t.permute(0, 1, 4, 2, 5, 3).contiguous()                                        # tap, ch, nt, q, j, s
+    bias = conv.bias.detach().float().contiguous() if conv.bias is not None else None
+    if mode == "f8":
+        w_scale = 448.0 / max(float(w.detach().abs().max()), 1e-30)
+        t = (t * w_scale).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+        _cache(conv)[mode] = (key, t, bias, w_scale)
+        return t, bias, w_scale
     if mode != "f32":
         t = t.half()
-    bias = conv.bias.detach().float().contiguous() if conv.bias is not None else None
     _cache(conv)[mode] = (key, t, bias)
     return t, bias
 
@@ -119,7 +125,14 @@ class ConvJob(ctypes.Structure):
     _fields_ = [("x", ctypes.c_void_p), ("wpk", ctypes.c_void_p), ("bias", ctypes.c_void_p),
                 ("pre_scale", ctypes.c_void_p), ("pre_shift", ctypes.c_void_p), ("res", ctypes.c_void_p),
                 ("y", ctypes.c_void_p), ("stats", ctypes.c_void_p),
-                ("Cout", ctypes.c_int32), ("relu", ctypes.c_int32), ("out_scale", ctypes.c_float)]
+                ("Cout", ctypes.c_int32), ("relu", ctypes.c_int32), ("out_scale", ctypes.c_float),
+                ("act_scale", ctypes.c_float), ("w_scale", ctypes.c_float)]
+
+
+# fp8 variant: activations are multiplied by this before the e4m3 conversion (saturating at 448 / FP8_ACT_SCALE = 56;
+# post-InstanceNorm / ReLU activations and the random-init plain tower stay well inside; e4m3's relative precision,
+# 2^-4, does not depend on the scale)
+FP8_ACT_SCALE = 8.0
 
 
 def _conv_mode(x, half, direct=False):
@@ -169,7 +182,7 @@ def conv2d(x, conv, pre=None, res=None, relu=False, want_stats=False, out_scale=
     return Pending(y, scale, shift)
 
 
-def conv2d_towers(jobs, half):
+def conv2d_towers(jobs, half, fp8=False):
     """one layer of every tower: ``jobs`` = [dict(x=, conv=, res=None, relu=False, want_stats=False, out_scale=1.0,
     eps=1e-5)] with the same layer shape.  Two fp16 towers go out as ONE launch of the LDS-tiled kernel
     (ramp_conv2d_nhwc_multi) followed by the statistics' finalize launch where a tower has a norm; anything else
@@ -186,6 +199,9 @@ def conv2d_towers(jobs, half):
     x0 = jobs[0]["x"].raw if isinstance(jobs[0]["x"], Pending) else jobs[0]["x"]
     H, W, Cin = x0.shape
     mode, code, odt = _conv_mode(x0, True)
+    use8 = bool(fp8) and mode == "f16"            # (the fp32-input first layer stays on the f16 MFMA)
+    if use8:
+        code |= _lib.RAMP_CONV_FP8
     c0 = jobs[0]["conv"]
     kh, stride = c0.weight.shape[2], c0.stride[0]
     OH = (H + 2 * (kh // 2) - kh) // stride + 1
@@ -202,7 +218,11 @@ def conv2d_towers(jobs, half):
         if isinstance(x, Pending):
             assert x.relu
             pre, x = (x.scale, x.shift), x.raw
-        wpk, bias = pack_conv_weight(conv, mode)
+        w_scale = 0.0
+        if use8:
+            wpk, bias, w_scale = pack_conv_weight(conv, "f8")
+        else:
+            wpk, bias = pack_conv_weight(conv, mode)
         cout = conv.weight.shape[0]
         assert tuple(x.shape) == (H, W, Cin) and x.dtype == x0.dtype and x.is_contiguous()
         assert conv.weight.shape[2] == kh and conv.stride[0] == stride and conv.padding[0] == kh // 2
@@ -215,6 +235,7 @@ def conv2d_towers(jobs, half):
         a.pre_scale, a.pre_shift = (ptr(pre[0]), ptr(pre[1])) if pre else (None, None)
         a.res, a.y = ptr(res), ptr(y)
         a.Cout, a.relu, a.out_scale = cout, int(j.get("relu", False)), float(j.get("out_scale", 1.0))
+        a.act_scale, a.w_scale = (FP8_ACT_SCALE, w_scale) if use8 else (0.0, 0.0)
         if j.get("want_stats", False):
             ws = torch.empty(cout * 2 * nblk + 2 * cout, dtype=torch.float32, device=x.device)
             scale, shift, stats = ws[:cout], ws[cout:2 * cout], ws[2 * cout:]
@@ -226,6 +247,8 @@ def conv2d_towers(jobs, half):
             outs.append(y)
     rc = lib().ramp_conv2d_nhwc_multi(arr, len(jobs), H, W, Cin, kh, stride, code, stream())
     if rc == _lib.RAMP_EUNSUPPORTED:
+        if use8:
+            return conv2d_towers(jobs, half, fp8=False)      # a layer shape without an fp8 instantiation: f16 MFMA
         return single()
     check(rc, "ramp_conv2d_nhwc_multi")
     for stats, cout, scale, shift, eps in finalize:
@@ -261,21 +284,21 @@ def norm_add_relu(y, skip):
 
 
 # --------------------------------------------------------------------------- towers
-def _res_blocks(blks, xs, norms, half):
+def _res_blocks(blks, xs, norms, half, fp8=False):
     """reference ResidualBlock.forward (extractor.py:49-57) for the same block of every tower, one launch per
     conv for all of them.  xs[t]: tensor, or (norm towers, first block) the Pending relu(norm(conv1))."""
     job = lambda t, x, conv, **k: dict(x=x, conv=conv, want_stats=norms[t], **k)
     T = range(len(blks))
     skips = list(xs)
     if blks[0].downsample is not None:
-        skips = conv2d_towers([job(t, xs[t], blks[t].downsample[0]) for t in T], half)
+        skips = conv2d_towers([job(t, xs[t], blks[t].downsample[0]) for t in T], half, fp8)
         for t in T:
             if norms[t]:
                 skips[t].relu = False            # norm3 has no ReLU behind it
-    y = conv2d_towers([job(t, xs[t], blks[t].conv1, relu=not norms[t]) for t in T], half)
+    y = conv2d_towers([job(t, xs[t], blks[t].conv1, relu=not norms[t]) for t in T], half, fp8)
     # plain towers: relu(skip + relu(conv2(y))) in the conv's epilogue
     y = conv2d_towers([job(t, y[t], blks[t].conv2, relu=not norms[t], res=None if norms[t] else skips[t])
-                       for t in T], half)
+                       for t in T], half, fp8)
     return [norm_add_relu(y[t], skips[t]) if norms[t] else y[t] for t in T]
 
 
@@ -294,7 +317,7 @@ def _first_layer(encs, x, norms, half):
     return xs
 
 
-def basic_encoder4_towers(encs, x, out_scale=1.0, half=False):
+def basic_encoder4_towers(encs, x, out_scale=1.0, half=False, fp8=False):
     """BasicEncoder4._forward of every tower in ``encs`` on one NHWC image x [H,W,Cin_padded] -> [H/4,W/4,out] each
     (``half``: fp16 storage + fp16 MFMA after the first layer's fp32 input).  relu(norm1(conv1)) is never
     materialised: layer1's first conv applies it while loading, the block's tail while adding the skip."""
@@ -302,29 +325,29 @@ def basic_encoder4_towers(encs, x, out_scale=1.0, half=False):
     xs = _first_layer(encs, x, norms, half)
     for li in ("layer1", "layer2"):
         for b in range(2):
-            xs = _res_blocks([getattr(e, li)[b] for e in encs], xs, norms, half)
-    return conv2d_towers([dict(x=xs[t], conv=e.conv2, out_scale=out_scale) for t, e in enumerate(encs)], half)
+            xs = _res_blocks([getattr(e, li)[b] for e in encs], xs, norms, half, fp8)
+    return conv2d_towers([dict(x=xs[t], conv=e.conv2, out_scale=out_scale) for t, e in enumerate(encs)], half, fp8)
 
 
 def basic_encoder4(enc, x, out_scale=1.0, half=False):
     return basic_encoder4_towers([enc], x, out_scale, half)[0]
 
 
-def multiscale_encoder4_towers(encs, x, x2, x4, out_scale=1.0, half=False):
+def multiscale_encoder4_towers(encs, x, x2, x4, out_scale=1.0, half=False, fp8=False):
     """MultiScaleBasicEncoder4.forward (reference extractor.py:288-311) of every tower on NHWC inputs: x [H,W,16],
     x2 [H/2,W/2,32] and x4 [H/4,W/4,64] (the three super-states) -> [H/4,W/4,out].  The channel
     concatenations are the only non-conv steps; layer2/conv2 are unused, as upstream."""
     norms = _tower_norms(encs)
     xs = _first_layer(encs, x, norms, half)
     for b in range(2):
-        xs = _res_blocks([e.layer1[b] for e in encs], xs, norms, half)
+        xs = _res_blocks([e.layer1[b] for e in encs], xs, norms, half, fp8)
     x2 = x2.to(xs[0].dtype)
     xs = [torch.cat((v, x2), dim=-1) for v in xs]
     for b in range(2):
-        xs = _res_blocks([e.layer3[b] for e in encs], xs, norms, half)
+        xs = _res_blocks([e.layer3[b] for e in encs], xs, norms, half, fp8)
     x4 = x4.to(xs[0].dtype)
     xs = [torch.cat((v, x4), dim=-1) for v in xs]
-    return conv2d_towers([dict(x=xs[t], conv=e.conv3, out_scale=out_scale) for t, e in enumerate(encs)], half)
+    return conv2d_towers([dict(x=xs[t], conv=e.conv3, out_scale=out_scale) for t, e in enumerate(encs)], half, fp8)
 
 
 def multiscale_encoder4(enc, x, x2, x4, out_scale=1.0, half=False):

@@ -71,6 +71,9 @@ struct ConvParams {
   int H, W, Cin, OH, OW, Cout;
   int relu;             // ReLU on the conv output (before the residual add; the add is followed by its own ReLU)
   float out_scale;
+  // fp8 MFMA variant of the LDS-tiled kernel: operands are x * act_scale and w * w_scale rounded to OCP e4m3
+  // (saturating at +-448), the fp32 accumulator is multiplied by descale = 1 / (act_scale * w_scale) before the bias
+  float act_scale, descale;
 };
 // up to two independent problems of one layer shape in one launch (blockIdx.z): the towers of the encoder
 struct ConvMulti { ConvParams t[2]; };
@@ -415,17 +418,18 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvParams &p, const f3
 //   3. bias / statistics / ReLU in registers, then the tile goes through LDS once more (fp32) so
 //      the residual is read and the result written as contiguous 16-byte pieces.
 // Same accumulation order as the direct kernel => identical results.
-template <int K, int S, bool IN_F32, int CIN, int NT>
+template <int K, int S, bool IN_F32, int CIN, int NT, bool FP8 = false>
 __global__ void __launch_bounds__(256) conv_tile_f16_kernel(const ConvMulti pm) {
+  static_assert(!(FP8 && IN_F32), "the fp32-input first layer stays on the f16 MFMA");
   const ConvParams &p = pm.t[blockIdx.z];
   if ((int)blockIdx.y * NT * 16 >= p.Cout) return;    // the towers may differ in Cout (grid.y = the larger one's)
   constexpr int PAD = K / 2, TH = 8, TW = 16;
   constexpr int SP = K == 1 ? 1 : S;                  // tile-pixel step between output neighbours
   constexpr int STEP = K == 1 ? S : 1;                // image-pixel step between tile pixels
   constexpr int IH = (TH - 1) * SP + K, IW = (TW - 1) * SP + K;
-  constexpr int PSTR = CIN * 2 + 16;                  // LDS bytes per tile pixel
+  constexpr int PSTR = FP8 ? CIN + 8 : CIN * 2 + 16;  // LDS bytes per tile pixel (fp8: 1 byte per channel)
   constexpr int KC = IN_F32 ? 16 : 32, NCH = CIN / KC;
-  constexpr int FRAG = IN_F32 ? 8 : 16;               // bytes per lane per B fragment
+  constexpr int FRAG = (IN_F32 || FP8) ? 8 : 16;      // bytes per lane per B fragment
   constexpr int CPI = IN_F32 ? 4 : 8;                 // channels per 16-byte global item
   constexpr int CH8 = CIN / CPI;                      // items per pixel
   constexpr int NITEM = IH * IW * CH8, NI = (NITEM + 255) / 256;
@@ -492,6 +496,20 @@ __global__ void __launch_bounds__(256) conv_tile_f16_kernel(const ConvMulti pm) 
         h[c] = iok[n] ? (_Float16)v : (_Float16)0.f;
       }
       if (i < NITEM) *reinterpret_cast<f16x4 *>(s_in + pix * PSTR + cslot * 8) = h;
+    } else if (FP8) {
+      const f16x8 h = __builtin_bit_cast(f16x8, ibuf[n]);
+      float v[8];
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        const float t = pre ? fmaxf((float)h[c] * sc[c] + sh[c], 0.f) : (float)h[c];
+        v[c] = iok[n] ? fminf(fmaxf(t * p.act_scale, -448.f), 448.f) : 0.f;
+      }
+      int lo = 0, hi = 0;                               // 8 x e4m3, channel c in byte c
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], lo, false);
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], hi, false);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], hi, true);
+      if (i < NITEM) *reinterpret_cast<int2 *>(s_in + pix * PSTR + cslot * 8) = make_int2(lo, hi);
     } else {
       f16x8 h = __builtin_bit_cast(f16x8, ibuf[n]);
 #pragma unroll
@@ -510,7 +528,7 @@ __global__ void __launch_bounds__(256) conv_tile_f16_kernel(const ConvMulti pm) 
   for (int a = 0; a < 2; a++)
 #pragma unroll
     for (int b = 0; b < NT; b++) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const unsigned char *a_base = s_in + ((2 * wave) * SP * IW + j * SP) * PSTR + q * (IN_F32 ? 8 : 16);
+  const unsigned char *a_base = s_in + ((2 * wave) * SP * IW + j * SP) * PSTR + q * ((IN_F32 || FP8) ? 8 : 16);
   const unsigned char *b_base = s_w + lane * FRAG;
 #pragma unroll
   for (int ky = 0; ky < K; ky++) {
@@ -532,6 +550,19 @@ __global__ void __launch_bounds__(256) conv_tile_f16_kernel(const ConvMulti pm) 
 #pragma unroll
             for (int nt = 0; nt < NT; nt++)
               acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+        } else if (FP8) {
+          long a[2], b[NT];
+#pragma unroll
+          for (int mt = 0; mt < 2; mt++)
+            a[mt] = *reinterpret_cast<const long *>(a_base + ((mt * SP + ky) * IW + kx) * PSTR + ch * KC);
+#pragma unroll
+          for (int nt = 0; nt < NT; nt++)
+            b[nt] = *reinterpret_cast<const long *>(b_base + ((tap * NCH + ch) * NT + nt) * 64 * FRAG);
+#pragma unroll
+          for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
         } else {
           f16x8 a[2], b[NT];
 #pragma unroll
@@ -551,6 +582,14 @@ __global__ void __launch_bounds__(256) conv_tile_f16_kernel(const ConvMulti pm) 
   }
   __syncthreads();          // every wave is done with the input / weight tiles
 
+  if (FP8) {
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int b = 0; b < NT; b++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[a][b][r] *= p.descale;
+  }
   conv_tile_epilogue<NT>(p, acc, smem, s_stat, oy0, ox0, n0);
 }
 
@@ -1077,6 +1116,7 @@ int ramp_conv2d_nhwc(const void *x, const void *wpk, const float *bias, const fl
   p.OH = (H + 2 * pad - KH) / stride + 1;
   p.OW = (W + 2 * pad - KW) / stride + 1;
   p.relu = relu; p.out_scale = out_scale;
+  p.act_scale = 1.0f; p.descale = 1.0f;
   const int M = p.OH * p.OW;
   dim3 grid(ramp_cdiv(M, 128), Cout / 32), block(256);
   hipStream_t st = (hipStream_t)stream;
@@ -1124,6 +1164,8 @@ int ramp_conv2d_nhwc_multi(const ramp_conv_job *jobs, int njobs, int H, int W, i
   if (!jobs || njobs < 1 || njobs > 2 || H <= 0 || W <= 0) return RAMP_EINVAL;
   const bool f16 = (dtype & 0xf) == RAMP_F16, in_f32 = f16 && (dtype & RAMP_IN_F32);
   if (!f16 || (dtype & RAMP_CONV_DIRECT)) return RAMP_EUNSUPPORTED;
+  const bool fp8 = (dtype & RAMP_CONV_FP8) != 0;
+  if (fp8 && in_f32) return RAMP_EUNSUPPORTED;
   const int pad = KH / 2;
   const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KH) / stride + 1;
   if (OH <= 0 || OW <= 0) return RAMP_EINVAL;
@@ -1137,6 +1179,11 @@ int ramp_conv2d_nhwc_multi(const ramp_conv_job *jobs, int njobs, int H, int W, i
     p.res = j.res; p.y = j.y; p.stats = j.stats;
     p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = j.Cout;
     p.relu = j.relu; p.out_scale = j.out_scale;
+    p.act_scale = 1.0f; p.descale = 1.0f;
+    if (fp8) {
+      if (!(j.act_scale > 0.0f) || !(j.w_scale > 0.0f)) return RAMP_EINVAL;
+      p.act_scale = j.act_scale; p.descale = 1.0f / (j.act_scale * j.w_scale);
+    }
     cmax = j.Cout > cmax ? j.Cout : cmax;
     if (j.Cout % 64) cgcd_ok64 = 0;
   }
@@ -1150,6 +1197,22 @@ int ramp_conv2d_nhwc_multi(const ramp_conv_job *jobs, int njobs, int H, int W, i
     RAMP_CHECK_LAUNCH();
     return RAMP_OK;
   }
+#define TILE_CASE8(K, S, CIN, NT)                                                                    \
+  if (fp8 && KH == K && stride == S && Cin == CIN && (NT == 2 || cgcd_ok64)) {                        \
+    hipLaunchKernelGGL((conv_tile_f16_kernel<K, S, false, CIN, NT, true>), dim3(tiles, cmax / (NT * 16), njobs), \
+                       block, 0, st, pm);                                                             \
+    RAMP_CHECK_LAUNCH();                                                                              \
+    return RAMP_OK;                                                                                   \
+  }
+  TILE_CASE8(3, 1, 32, 2)
+  TILE_CASE8(3, 2, 32, 2)
+  TILE_CASE8(3, 1, 64, 2)
+  TILE_CASE8(1, 2, 32, 4)
+  TILE_CASE8(1, 2, 64, 4)
+  TILE_CASE8(1, 1, 64, 4)
+  TILE_CASE8(1, 1, 128, 4)
+#undef TILE_CASE8
+  if (fp8) return RAMP_EUNSUPPORTED;
 #define TILE_CASE(K, S, INF32, CIN, NT)                                                              \
   if (KH == K && stride == S && in_f32 == INF32 && Cin == CIN && (NT == 2 || cgcd_ok64)) {            \
     hipLaunchKernelGGL((conv_tile_f16_kernel<K, S, INF32, CIN, NT>), dim3(tiles, cmax / (NT * 16), njobs), \

@@ -122,6 +122,7 @@ class MergerLSTMsceneEncoder(nn.Module):
         self.states_events, self.states_image, self.super_state = None, None, None   # (oracle-side torch forward)
         self._hip_state = None
         self.mixed_precision = False      # fp16 storage / fp16 MFMA conv towers (set by Ramp_vo from cfg)
+        self.fp8_mfma = False             # with mixed_precision: the towers' products on the fp8 MFMA (configs[4])
 
     def _forward_hip(self, events, images, reinit_hidden, out_scale):
         """fused LSTM/super-state kernel + MFMA conv towers (csrc/conv.hip)"""
@@ -138,7 +139,7 @@ class MergerLSTMsceneEncoder(nn.Module):
         # a fork / join inside the front end's hipGraph bought nothing measurable (the paired launches fill the
         # chip) and multi-stream captures were the one configuration that crashed hipGraphLaunch in long test runs.
         f, i = conv_hip.basic_encoder4_towers([self.fmap_encoder, self.imap_encoder], s16, out_scale,
-                                              half=self.mixed_precision)
+                                              half=self.mixed_precision, fp8=self.mixed_precision and self.fp8_mfma)
         return f.permute(2, 0, 1)[None, None], i.permute(2, 0, 1)[None, None], None
 
     def forward(self, events, images, reinit_hidden=False, out_scale=1.0):
@@ -206,6 +207,7 @@ class MultiScaleMergerDoubleNet(nn.Module):
                                                     internal_input_dimensions=self.internal_dimensions)
         self._hip_state = None
         self.mixed_precision = False      # fp16 storage / fp16 MFMA conv towers (set by Ramp_vo from cfg)
+        self.fp8_mfma = False             # with mixed_precision: the towers' products on the fp8 MFMA (configs[4])
 
     def _forward_hip(self, events, images, present, reinit_hidden, out_scale):
         """one time step on the GPU: fused conv_1 + LSTM + super-state kernel per scale, then the MFMA
@@ -226,7 +228,7 @@ class MultiScaleMergerDoubleNet(nn.Module):
             return None, None
         half = self.mixed_precision
         f, i = conv_hip.multiscale_encoder4_towers([self.fmap_encoder, self.imap_encoder], xs[0], xs[1], xs[2],
-                                                   out_scale, half=half)
+                                                   out_scale, half=half, fp8=half and self.fp8_mfma)
         return f.permute(2, 0, 1)[None, None], i.permute(2, 0, 1)[None, None]
 
     def forward(self, events, images, mask, reinit_hidden=False, out_scale=1.0):

@@ -169,7 +169,8 @@ class Patchifier(nn.Module):
             self._graph_warm = 0 if reinit_hidden else self._graph_warm
             return self._forward_impl(input_, patches_per_image, reinit_hidden, disps, event_bias, gradient_bias)
         key = (self.input_mode, tuple(events.shape), tuple(images.shape), patches_per_image, events.dtype,
-               images.dtype, bool(getattr(self.encoder, "mixed_precision", False)), events.device)
+               images.dtype, bool(getattr(self.encoder, "mixed_precision", False)),
+               bool(getattr(self.encoder, "fp8_mfma", False)), events.device)
         # the captured graph bakes in raw pointers to the packed encoder weights and to the encoder's recurrent
         # state buffers: it is only valid for the parameter values and the state object it was captured with
         # (in-place weight updates bump ``_version``; a resolution change reallocates the state)

@@ -227,12 +227,12 @@ TRAJ = {
 
 
 @torch.no_grad()
-def run_trajectory(tag, device, mixed=False, pipelined=False):
+def run_trajectory(tag, device, mixed=False, pipelined=False, **cfg_extra):
     from rampvo_amd.config import make_cfg
     from rampvo_amd.synthetic import SyntheticStream, make_network
     p = TRAJ[tag]
     net = make_network(p["mode"], device=device, profile="damped")
-    cfg = make_cfg(p["preset"], PATCHES_PER_FRAME=p["M"], MIXED_PRECISION=mixed, **p["over"])
+    cfg = make_cfg(p["preset"], PATCHES_PER_FRAME=p["M"], MIXED_PRECISION=mixed, **dict(p["over"], **cfg_extra))
     slam = make_tracker(cfg, net, p["H"], p["W"], device)
     slam.inputs_ready = pipelined
     stream = SyntheticStream(p["H"], p["W"], p["T"], seed=p["seed"])
@@ -250,13 +250,13 @@ def run_trajectory(tag, device, mixed=False, pipelined=False):
     return slam, rec, traj, ts
 
 
-def check_trajectory(tag, device, mixed=False, pipelined=False):
+def check_trajectory(tag, device, mixed=False, pipelined=False, **cfg_extra):
     """N-frame free run (damped weight profile) against the reference's own run of the same stream: structure
     exact, every float within the returned errors.  ``rel`` = max abs trajectory difference / max(1, largest
     reference translation) -- the north-star's 'pose trajectory within 1e-4 rel'."""
     from rampvo_amd.evaluate import ate_rmse
     g = gold(f"ramp_vo_traj_{tag}.npz")
-    slam, rec, traj, ts = run_trajectory(tag, device, mixed, pipelined)
+    slam, rec, traj, ts = run_trajectory(tag, device, mixed, pipelined, **cfg_extra)
     assert rec["n"] == list(g["n"]) and rec["E"] == list(g["E"]), "keyframe decisions / graph sizes"
     for a, b in ((slam._ii, "ii"), (slam._jj, "jj"), (slam._kk, "kk")):
         assert np.array_equal(a, g["final_" + b]), b

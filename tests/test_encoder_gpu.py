@@ -151,6 +151,82 @@ def test_conv_tower_pair_equals_single_launches(cin, couts, k, stride, hw, first
             assert torch.equal(again[1], pair[1])
 
 
+FP8_LAYER_TOL = 2e-3        # x the output scale: what is left after both sides use the SAME e4m3-rounded operands
+FP8_ENCODER_TOL = 0.2       # max abs error of fmap / imap against the f16-MFMA towers, x the map's largest entry (measured: 0.07-0.125)
+
+
+@pytest.mark.parametrize("cin,couts,k,stride,hw", [(32, (32, 32), 3, 1, (37, 53)), (32, (64, 64), 3, 2, (40, 56)),
+                                                   (64, (64, 64), 3, 1, (30, 44)), (32, (64, 64), 1, 2, (40, 56)),
+                                                   (64, (128, 384), 1, 1, (21, 29)), (128, (128, 384), 1, 1, (19, 35))])
+def test_conv_fp8_mfma_layer_against_fp32_on_rounded_operands(cin, couts, k, stride, hw):
+    """BASELINE configs[4]'s "fp16 encoder on fp8 MFMA" (ramp_conv2d_nhwc_multi with RAMP_CONV_FP8): the kernel
+    multiplies e4m3(x * 8) by e4m3(w * 448 / max|w|) and accumulates in fp32.  Products of e4m3 numbers are exact in
+    fp32, so a plain fp32 convolution of the SAME rounded operands is the reference: what separates the two is the
+    accumulation order and the fp16 rounding of the output.  Prologue (InstanceNorm + ReLU on load), bias,
+    statistics, ReLU, residual and scale are the f16 kernel's own (shared epilogue)."""
+    from rampvo_amd import conv_hip
+    torch.manual_seed(7)
+    convs = [nn.Conv2d(cin, c, k, stride=stride, padding=k // 2).cuda() for c in couts]
+    e4 = torch.float8_e4m3fn
+    with torch.no_grad():
+        x = (torch.randn(hw[0], hw[1], cin, device="cuda") * 1.5).half()
+        sc, sh = torch.rand(cin, device="cuda") + 0.5, torch.randn(cin, device="cuda") * 0.1
+        oh, ow = (hw[0] + 2 * (k // 2) - k) // stride + 1, (hw[1] + 2 * (k // 2) - k) // stride + 1
+        res = torch.randn(oh, ow, couts[1], device="cuda").half()
+        jobs = [dict(x=conv_hip.Pending(x, sc, sh), conv=convs[0], want_stats=True),
+                dict(x=x, conv=convs[1], relu=True, res=res, out_scale=0.25)]
+        out = conv_hip.conv2d_towers(jobs, half=True, fp8=True)
+
+        def ref(xin, conv):
+            a = conv_hip.FP8_ACT_SCALE
+            xq = (xin * a).clamp(-448, 448).to(e4).float() / a
+            ws = 448.0 / float(conv.weight.abs().max())
+            wq = (conv.weight.float() * ws).clamp(-448, 448).to(e4).float() / ws
+            return F.conv2d(xq.permute(2, 0, 1)[None], wq, conv.bias.float(), conv.stride, conv.padding)[0].permute(1, 2, 0)
+        r0 = ref(torch.relu(x.float() * sc + sh), convs[0])
+        r1 = torch.relu(torch.relu(ref(x.float(), convs[1])) + res.float()) * 0.25
+        assert float((out[0].raw.float() - r0).abs().max()) <= FP8_LAYER_TOL * float(r0.abs().max())
+        assert float((out[1].float() - r1).abs().max()) <= FP8_LAYER_TOL * max(1.0, float(r1.abs().max()))
+        mean, var = r0.mean((0, 1)), r0.var((0, 1), unbiased=False)
+        assert float((out[0].scale - (var + 1e-5).rsqrt()).abs().max()) <= 2e-3 * float(out[0].scale.abs().max())
+        assert float((out[0].shift + mean * (var + 1e-5).rsqrt()).abs().max()) <= 2e-3 * max(1.0, float(out[0].shift.abs().max()))
+        # and the size of the step from the f16 MFMA, for the record (e4m3 carries 4 significant bits)
+        f16 = conv_hip.conv2d_towers(jobs, half=True)
+        print("fp8 vs f16 MFMA layer: max abs %.3g of %.3g" % (float((out[1].float() - f16[1].float()).abs().max()),
+                                                             float(f16[1].float().abs().max())))
+
+
+@pytest.mark.parametrize("mode", ["SingleScale", "MultiScale"])
+def test_encoder_fp8_mfma_against_f16_mfma(mode):
+    """the whole front end with ENCODER_FP8 against the same front end on the f16 MFMA (three frames, recurrent state
+    carried): fmap / imap within FP8_ENCODER_TOL of their largest entry -- eleven layers of 4-bit-mantissa products,
+    re-normalised by InstanceNorm in the fmap tower; the first layer (fp32 input) stays on the f16 MFMA"""
+    from rampvo_amd.synthetic import SyntheticStream, make_network
+    stream = SyntheticStream(96, 128, 3, seed=6)
+    outs = {}
+    with torch.no_grad():
+        for fp8 in (False, True):
+            net = make_network(mode)
+            enc = net.patchify.encoder
+            enc.mixed_precision, enc.fp8_mfma = True, fp8
+            res = []
+            for t in range(3):
+                im, ev, _, mask = stream.frame(t)
+                if mode == "SingleScale":
+                    f, i, _ = enc(events=ev.cuda(), images=im.cuda(), reinit_hidden=(t == 0), out_scale=0.25)
+                else:
+                    f, i = enc(events=ev.cuda(), images=im.cuda(), mask=torch.ones(1, dtype=torch.bool), reinit_hidden=(t == 0),
+                               out_scale=0.25)
+                res.append((f.float().clone(), i.float().clone()))
+            outs[fp8] = res
+    worst = 0.0
+    for (f0, i0), (f1, i1) in zip(outs[False], outs[True]):
+        ef, ei = float((f0 - f1).abs().max()) / float(f0.abs().max()), float((i0 - i1).abs().max()) / float(i0.abs().max())
+        worst = max(worst, ef, ei)
+        assert ef <= FP8_ENCODER_TOL and ei <= FP8_ENCODER_TOL, (ef, ei)
+    print("%s fp8 vs f16 MFMA encoder: worst relative max-abs error %.3g" % (mode, worst))
+
+
 def test_singlescale_encoder_half_vs_fp32():
     from rampvo_amd.synthetic import SyntheticStream, make_network
     net = make_network("SingleScale")

@@ -228,6 +228,20 @@ def test_trajectory_mixed_precision_against_reference_run(tag):
     assert e["rel"] <= TRAJ_MIXED_REL[tag], e
 
 
+TRAJ_FP8_REL = {"ss": 6e-3, "ms": 1.2e-1}      # measured 2.5e-3 / 5.5e-2 (f16 MFMA: 1.9e-3 / 5.2e-2)
+
+
+@pytest.mark.parametrize("tag", ["ss", "ms"])
+def test_trajectory_fp8_encoder_against_reference_run(tag):
+    """BASELINE configs[4]'s encoder precision (fp16 storage, conv towers on the fp8 MFMA: cfg.ENCODER_FP8) free-running
+    against the reference's fp32 run: still the same keyframe decisions and graphs (the patch selection does not
+    depend on the encoder); the trajectory error is stated (4-bit-mantissa products in eleven layers, fed back through
+    40 / 48 frames)."""
+    e = pc.check_trajectory(tag, "cuda", mixed=True, ENCODER_FP8=True)
+    print(e)
+    assert e["rel"] <= TRAJ_FP8_REL[tag], e
+
+
 @torch.no_grad()
 def test_frame_pipelining_does_not_change_results():
     """Ramp_vo.inputs_ready (front end of frame t+1 launched before the host waits for frame t's keyframe

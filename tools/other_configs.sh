@@ -11,5 +11,6 @@ PY
 run multiscale_default --mode MultiScale
 run multiscale_precise --mode MultiScale --preset precise --prime 160
 run multiscale_720p_m256 --mode MultiScale --height 720 --width 1280 --patches 256 --opt-window 32
+run multiscale_720p_m256_fp8 --mode MultiScale --height 720 --width 1280 --patches 256 --opt-window 32 --encoder-fp8 1
 run singlescale_fp32 --mixed 0
 run singlescale_pipeline0 --pipeline 0
