@@ -195,8 +195,13 @@ class Patchifier(nn.Module):
             graph.replay()               # capture does not execute: run this frame now (inputs already staged)
             return outs
         graph, ev_s, im_s, outs, self._extra, _ = g
-        ev_s.copy_(events)
-        im_s.copy_(images)
+        if (events.is_contiguous() and images.is_contiguous() and events.dtype == ev_s.dtype and images.dtype == im_s.dtype
+                and (events.numel() * events.element_size()) % 16 == 0 and (images.numel() * images.element_size()) % 16 == 0
+                and events.data_ptr() % 16 == 0 and images.data_ptr() % 16 == 0):
+            ops.multi_copy([(events, ev_s), (images, im_s)])          # one launch for the two staging copies
+        else:
+            ev_s.copy_(events)
+            im_s.copy_(images)
         graph.replay()
         return outs
 
