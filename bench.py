@@ -200,6 +200,40 @@ class CorrTimer:
         return out
 
 
+class DeviceProbe:
+    """The device-resident step is one C call (csrc/track.hip::ramp_track_step): its kernels are not launched from
+    Python, so the HIP events of the roofline legs are recorded by the C function itself, on the stream it launches
+    on, through the optional ``ramp_track.probe`` handles -- one pre-created event set per timed step."""
+
+    def __init__(self, steps):
+        self.sets = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(steps)]
+        for evs in self.sets:
+            for ev in evs:
+                ev.record()                    # torch creates the hipEvent on the first record
+        self.used, self.edges, self.enabled = 0, [], False
+
+    def install(self):
+        from rampvo_amd import track_dev
+        inner, probe = track_dev.DeviceTrack.step, self
+
+        def step(dv, counter, flags, **k):
+            on = probe.enabled and probe.used < len(probe.sets) and (flags & track_dev.UPDATE)
+            for i in range(5):
+                dv.t.probe[i] = probe.sets[probe.used][i].cuda_event if on else None
+            if on:
+                probe.edges.append(int(dv.lazy_state()[track_dev.DYN_E]))      # a frame or two old: fine for a mean
+                probe.used += 1
+            return inner(dv, counter, flags, **k)
+
+        track_dev.DeviceTrack.step = step
+
+    def feed(self, ctimer, utimer, btimer, opt_window):
+        for evs, E in zip(self.sets[:self.used], self.edges):
+            ctimer.pairs.append((evs[0], evs[1])); ctimer.edges.append(E)
+            utimer.pairs.append((evs[1], evs[2])); utimer.edges.append(E)
+            btimer.pairs.append((evs[3], evs[4])); btimer.meta.append((E, opt_window, 2))
+
+
 class UpdateTimer:
     """HIP events around the update operator (FusedUpdate.hidden: correlation MLP, neighbour MLPs, SoftAgg x2, gru)"""
 
@@ -430,22 +464,30 @@ def parity_block(state, args, cfg_kwargs, net, dev):
     out = dict(teacher_forced=tf)
     # trajectory level: tests/pipeline_checks.py::check_trajectory against tests/golden/ramp_vo_traj_ss.npz
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    try:
-        import pipeline_checks as pc
-        tr = {}
-        for name, mixed in (("fp32", False), ("fp16", True)):
-            e = pc.check_trajectory("ss", "cuda", mixed=mixed)
-            tr[name] = dict(ate_vs_reference=float("%.3g" % e["ate_rmse"]), rel=float("%.3g" % e["rel"]),
-                            depths_rel=float("%.3g" % e["depths_rel"]))
-            tr.update(frames=e["frames"], path_length=round(e["path_length"], 4))
-        tr["note"] = ("free-running %s 192x256, 16 patches, default.yaml windows, damped weight profile, against the "
-                      "reference's own CPU run of the same stream (tests/golden/ramp_vo_traj_ss.npz): identical keyframe "
-                      "decisions and graph; ate = Sim(3)-aligned RMSE (evaluate.py:295-304), rel = max abs / "
-                      "max(1, largest translation)" % pc.TRAJ["ss"]["mode"])
-        out["trajectory"] = tr
-    except Exception as e:  # parity is reported, it must not take the throughput number down
-        out["trajectory"] = {"error": repr(e)}
+    import pipeline_checks as pc
+    tr = {}
+    for name, mixed in (("fp32", False), ("fp16", True)):
+        e = pc.check_trajectory("ss", "cuda", mixed=mixed)
+        tr[name] = dict(ate_vs_reference=float("%.3g" % e["ate_rmse"]), rel=float("%.3g" % e["rel"]),
+                        depths_rel=float("%.3g" % e["depths_rel"]))
+        tr.update(frames=e["frames"], path_length=round(e["path_length"], 4))
+    tr["note"] = ("free-running %s 192x256, 16 patches, default.yaml windows, damped weight profile, against the "
+                  "reference's own CPU run of the same stream (tests/golden/ramp_vo_traj_ss.npz): identical keyframe "
+                  "decisions and graph; ate = Sim(3)-aligned RMSE (evaluate.py:295-304), rel = max abs / "
+                  "max(1, largest translation)" % pc.TRAJ["ss"]["mode"])
+    out["trajectory"] = tr
     return out
+
+
+def graph_size(slam):
+    """(factors, keyframes) of the tracker without taking a device-resident state back to the host"""
+    dv = getattr(slam, "_dev", None)
+    if dv is not None and dv.active:
+        from rampvo_amd import track_dev
+        torch.cuda.synchronize()
+        d = dv.dyn.cpu().numpy()
+        return int(d[track_dev.DYN_EKEPT]), int(d[track_dev.DYN_NROW])
+    return len(slam._ii), slam.n
 
 
 def main():
@@ -490,11 +532,14 @@ def main():
     frames = [tuple(x.to(dev) if i < 2 else x for i, x in enumerate(stream.frame(t))) for t in range(total)]
 
     ctimer, etimer, btimer, utimer = CorrTimer(), EncoderTimer(), BaTimer(), UpdateTimer()
+    dprobe = None
     if not args.no_kernel_timing:
         ctimer.install()
         etimer.install(net)
         btimer.install()
         utimer.install()
+        dprobe = DeviceProbe(args.steps)
+        dprobe.install()
 
     pos = {"t": 0}
 
@@ -523,35 +568,39 @@ def main():
     warm_s = time.perf_counter() - warm_tic
     for _ in range(args.warmup):
         step()
-    E0, n0 = len(slam._ii), slam.n
+    E0, n0 = graph_size(slam)
 
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     ctimer.enabled = etimer.enabled = btimer.enabled = utimer.enabled = True
+    if dprobe is not None:
+        dprobe.enabled = True
     tic = time.perf_counter()
     marks = [tic]
     for _ in range(args.steps):
         step()
         marks.append(time.perf_counter())         # host-side return times (the GPU may lag by less than a step)
-    slam.settle()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - tic
     ctimer.enabled = etimer.enabled = btimer.enabled = utimer.enabled = False
+    if dprobe is not None:
+        dprobe.enabled = False
+        dprobe.feed(ctimer, utimer, btimer, cfg.OPTIMIZATION_WINDOW)
 
     from rampvo_amd.shard import gather_metrics, max_over_ranks
     dt_all = max_over_ranks(dt, dev)
     per_rank = None
     if world > 1:
         # the path's single collective: per-sequence metrics (kf/s, E, n, pose checksum)
-        g = gather_metrics([args.steps / dt, float(len(slam._ii)), float(slam.n),
-                            float(slam.poses_[:slam.n].double().sum())], dev)
+        E_r, n_r = graph_size(slam)
+        g = gather_metrics([args.steps / dt, float(E_r), float(n_r), float(slam.poses_[:n_r].double().sum())], dev)
         per_rank = [[round(float(v), 4) for v in row] for row in g.tolist()]
-    E1 = len(slam._ii)
+    E1 = graph_size(slam)[0]
 
     # the strictly sequential rate (no frame pipelining): what evaluate.run's loop gets
     np_kfps = None
@@ -561,7 +610,6 @@ def main():
         t_np = time.perf_counter()
         for _ in range(n_np):
             step()
-        slam.settle()
         torch.cuda.synchronize()
         np_kfps = n_np / (time.perf_counter() - t_np)
 
@@ -575,9 +623,15 @@ def main():
             "dtype": "f16 (features, MFMA inputs; f32 accumulate, hidden state, BA, geometry: default.yaml "
                      "MIXED_PRECISION)" if args.mixed else "f32",
             "data": "synthetic (seeded %dx%d event+frame stream, seeded random-init weights)" % (args.width, args.height),
-            "config": {"workload": "%s %dx%d, %d patches/frame, %s.yaml windows, 2 BA iters/keyframe, "
-                                   "steady-state sliding window" % (args.mode, args.width, args.height, args.patches,
-                                                                    args.preset),
+            "config": {"workload": "%s %dx%d, %d patches/frame, %s.yaml windows%s, 2 BA iters/keyframe, "
+                                   "steady-state sliding window%s"
+                                   % (args.mode, args.width, args.height, args.patches, args.preset,
+                                      " with OPTIMIZATION_WINDOW %d" % args.opt_window if args.opt_window else "",
+                                      "".join([", fp8-MFMA encoder" if args.encoder_fp8 else "",
+                                               ", fp32 everywhere" if not args.mixed else "",
+                                               ", frame pipelining off" if not args.pipeline else "",
+                                               ", host-driven steps (RAMP_DEVICE_STEP=0)"
+                                               if os.environ.get("RAMP_DEVICE_STEP", "1") != "1" else ""])),
                        "ba_iters_per_s": round(2 * value, 2), "edges": E0, "edges_end": E1,
                        "keyframes_in_window": n0, "prime_frames": args.prime,
                        "clock_warm": "%d untimed steady-state steps (%.2f s) before the %d warm-up steps"
@@ -602,21 +656,16 @@ def main():
                 out[key] = val
         snapshot = slam.state_dict() if (n_cpu or (solo and args.parity)) else None
         if solo and args.parity:
-            try:
-                out["parity"] = parity_block(snapshot, args, cfg_kwargs, net, dev)
-                tr = out["parity"].get("trajectory", {})
-                if "fp32" in tr:
-                    out["ate_vs_oracle"] = tr["fp32"]["ate_vs_reference"]
-            except Exception as e:
-                out["parity"] = {"error": repr(e)}
+            # a failing checker fails the run (rc != 0): a headline without its parity block is not a result
+            out["parity"] = parity_block(snapshot, args, cfg_kwargs, net, dev)
+            tr = out["parity"].get("trajectory", {})
+            if "fp32" in tr:
+                out["ate_vs_oracle"] = tr["fp32"]["ate_vs_reference"]
         if n_cpu:
             cpu_frames = [stream.frame(total + i) for i in range(n_cpu)]
             cpu_frames = [tuple(x.cpu() for x in f) for f in cpu_frames]
-            try:
-                out["cpu_baseline"] = cpu_baseline(snapshot, args, cfg_kwargs, cpu_frames, args.cpu_steps)
-                out["config"]["speedup_vs_cpu_port"] = round(value / out["cpu_baseline"]["value"], 1)
-            except Exception as e:  # the baseline must never take the GPU number down with it
-                out["cpu_baseline"] = {"error": repr(e)}
+            out["cpu_baseline"] = cpu_baseline(snapshot, args, cfg_kwargs, cpu_frames, args.cpu_steps)
+            out["config"]["speedup_vs_cpu_port"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -505,6 +505,121 @@ int ramp_upd_heads_linear(const void *relu_t, const void *heads_w, const float *
 int ramp_upd_fg(const float *x32, const void *add_t, const int32_t *add_idx, float *x32_out, const void *wf,
                 const float *bf, const void *wg, const float *bg, void *fg, int E, void *stream);
 
+/* nn.Linear(384, 384) on a small fp16 table: y[r] = fp16(x[r] W^T + b) -- SoftAgg's `h` layer on the group table
+ * (ramp/blocks.py:46-47), the one GEMM of the fused update operator that used to be a library call.  w_packed like
+ * ramp_upd_gru's weights, bias fp32 [384]; rows_dev (optional, device int32): only rows < *rows_dev are computed.   */
+int ramp_upd_linear(const void *x, const void *w_packed, const float *bias, void *y, int rows, const int32_t *rows_dev,
+                    void *stream);
+
+/* ---------------------------------------------------------------- device-resident tracking step
+ *
+ * Ramp_vo.__call__ in steady state (ramp/Ramp_vo.py:327-410): the frame's state stores, update() (:276-310:
+ * reproject, corr, the update operator, two BA iterations, point cloud) and keyframe() (:237-274: the motion test, the
+ * removal of a keyframe and of old factors) followed by the NEXT frame's append_factors (:194-201, :312-325) -- as ONE
+ * host call that never reads the device.  The reference decides keyframe() on the host (`.item()`), so every frame
+ * waits for the GPU to drain; here the decision is taken by a kernel and everything that depends on it -- the row a
+ * frame is stored to, the factor count, the optimisation window -- is read by the kernels from a block of int32 words
+ * in device memory (`dyn`), their launch sizes being capacity bounds.  The host mirrors the state lazily (dyn_host).
+ */
+#define RAMP_DYN_WORDS 32
+#define RAMP_DYN_N 0        /* keyframes incl. the newest frame: Ramp_vo.n during update() / keyframe(), BA's t1   */
+#define RAMP_DYN_NROW 1     /* row the NEXT frame is stored to (Ramp_vo.n before its `n += 1`)                    */
+#define RAMP_DYN_E 2        /* factors in the current graph (incl. the ones the newest frame added)               */
+#define RAMP_DYN_KLO 3      /* lower bound of kk (offset of the counting group-by)                                */
+#define RAMP_DYN_FLO 4      /* lowest frame index in ii / jj                                                      */
+#define RAMP_DYN_W 5        /* pair keys are jj * W + ii                                                          */
+#define RAMP_DYN_REMOVED 6  /* outcome of the last keyframe test: 1 = keyframe K was dropped                      */
+#define RAMP_DYN_K 7        /* the keyframe that test looked at (n - KEYFRAME_INDEX)                              */
+#define RAMP_DYN_NPREV 8    /* Ramp_vo.n when the test ran                                                        */
+#define RAMP_DYN_EPREV 9    /* factors before the edit                                                            */
+#define RAMP_DYN_EKEPT 10   /* factors the edit kept (next graph = kept ++ new)                                   */
+#define RAMP_DYN_STATUS 11  /* sticky bits: 1 BA pose step dropped, 2 BA pair list overflow (ramp_ba_forward's
+                               info), 4 factor capacity exceeded, 8 group-by key out of range, 16 delta log full  */
+#define RAMP_DYN_NLOG 12    /* entries written to the delta log                                                   */
+#define RAMP_DYN_FRAME 13   /* `counter` of the last frame stepped (tags the host's lazy copy)                    */
+#define RAMP_TRACK_LOG 12   /* floats per delta-log entry: t1, t0 (as int32 bit patterns), dP[7], pad             */
+
+#define RAMP_TRACK_COMMIT 1    /* store the front end's outputs as frame NROW first                               */
+#define RAMP_TRACK_UPDATE 2    /* Ramp_vo.update()                                                                */
+#define RAMP_TRACK_KEYFRAME 4  /* Ramp_vo.keyframe() + the next frame's append_factors + its plan                 */
+#define RAMP_TRACK_MM_GIVEN 8  /* (tests) keyframe(): take the two flow magnitudes from t->mm instead of computing */
+
+typedef struct ramp_track_weights {      /* update operator, fp16 fused formats of ramp_upd_* */
+  const void *corr_w1, *corr_w2, *corr_w3;
+  const float *corr_b1, *corr_b2, *corr_b3, *corr_ln_w, *corr_ln_b, *norm_w, *norm_b;
+  const void *c1_wa, *c1_wb, *c2_wa, *c2_wb;
+  const float *c1_ba, *c1_bb, *c2_ba, *c2_bb;
+  const void *kk_wf, *kk_wg, *kk_wh, *ij_wf, *ij_wg, *ij_wh;
+  const float *kk_bf, *kk_bg, *kk_bh, *ij_bf, *ij_bg, *ij_bh;
+  const float *ln1_w, *ln1_b, *ln2_w, *ln2_b;
+  const void *gru_w[6];
+  const float *gru_b[6];
+  const void *heads_w;
+  const float *heads_b;
+  float corr_ln_eps, norm_eps, ln1_eps, ln2_eps;
+} ramp_track_weights;
+
+typedef struct ramp_track {
+  /* configuration (cfg: PATCHES_PER_FRAME, PATCH_LIFETIME, REMOVAL_WINDOW, OPTIMIZATION_WINDOW, KEYFRAME_INDEX,
+   * KEYFRAME_THRESH, MOTION_MODEL (1 DAMPED_LINEAR, 2 copy), MOTION_DAMPING) */
+  int M, P, mem, n_rows, patch_lifetime, removal_window, opt_window, keyframe_index, motion_model;
+  int feat_h, feat_w;                 /* level-1 feature plane (level 4 is feat_h/4 x feat_w/4)                  */
+  int E_cap, kk_cap, ij_cap, kkey_cap, pkey_cap, log_cap, m_cap;
+  float motion_damping, pad0;
+  double keyframe_thresh;
+  /* tracker state (ramp/Ramp_vo.py:54-100), layouts as in rampvo_amd/Ramp_vo.py */
+  int32_t *dyn;                       /* [RAMP_DYN_WORDS] */
+  float *poses, *patches, *intrinsics, *points;
+  int64_t *tstamps, *index_map;
+  const int64_t *ixm;                 /* [n_rows * M]: patch -> source frame                                     */
+  void *colors, *imap, *gmap, *fmap1, *fmap2;
+  const float *lmbda;
+  /* the front end's outputs of the frame being committed */
+  const void *fe_colors, *fe_imap, *fe_gmap, *fe_fmap1, *fe_fmap2;
+  float *fe_patches;
+  /* factor graph, double buffered: [4][E_cap] int64 rows (ii, jj, kk, hidden-state row) */
+  int64_t *graph[2];
+  /* graph plan */
+  int32_t *kk_order, *kk_gid, *kk_seg, *kk_ngroups, *ij_order, *ij_gid, *ij_seg, *ij_ngroups;
+  int64_t *kk_ukeys, *ij_ukeys, *ix, *jx;
+  void *plan_ws;
+  size_t plan_ws_bytes;
+  /* update operator */
+  ramp_track_weights w;
+  float *coords;                      /* [E_cap][2][P][P] */
+  void *corr;                         /* [E_cap][896] fp16 */
+  float *net[3];                      /* [E_cap][384] fp32: [0] the hidden state (in: previous, out: new), [1], [2] scratch */
+  void *fg, *ykk, *hkk, *yij, *hij, *relu_t;
+  float *target, *weight;             /* [E_cap][2] */
+  /* bundle adjustment */
+  void *ba_ws;
+  size_t ba_ws_bytes;
+  /* keyframe() */
+  float *mm;                          /* [2] flow magnitudes of the motion test */
+  float *dlog;                        /* [log_cap][RAMP_TRACK_LOG] */
+  int32_t *edit_ws;                   /* [2 * ceil(E_cap / 1024) + 8] */
+  int32_t *dyn_host;                  /* optional pinned host copy of dyn, refreshed asynchronously after each step */
+  /* optional hipEvent_t handles recorded on `stream` by ramp_track_step (measurement only: bench.py's roofline legs):
+   * [0] before / [1] after the correlation kernel, [2] after the update operator's last chain (gru), [3] before /
+   * [4] after bundle adjustment                                                                                  */
+  void *probe[5];
+} ramp_track;
+
+size_t ramp_track_sizeof(void);      /* sizeof(ramp_track): lets a binding check its mirror of the struct */
+size_t ramp_track_plan_workspace_bytes(int E_cap, int kkey_cap, int pkey_cap);
+size_t ramp_track_ba_workspace_bytes(int E_cap, int n_rows, int M, int opt_window, int kk_cap, int ij_cap);
+
+/* plan (groupings + temporal neighbours) of graph[cur] with the sizes in dyn: needed once, when the host hands a graph
+ * over; afterwards every step builds the next one                                                                  */
+int ramp_track_plan(const ramp_track *t, int cur, void *stream);
+
+/* One tracked frame (flags = COMMIT | UPDATE | KEYFRAME), a bare update() (flags = UPDATE), ...; `cur` = which half of
+ * graph[] holds the current graph (KEYFRAME writes the next one to 1 - cur).  k_new: optional device [4] intrinsics at
+ * feature resolution when they differ from the previous frame's.  gate_event: optional hipEvent_t recorded before the
+ * last kernel of the update operator (where the next frame's front end may start on another stream).              */
+int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, const float *k_new, void *gate_event,
+                    void *stream);
+
 #ifdef __cplusplus
 }
 #endif

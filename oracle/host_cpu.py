@@ -205,14 +205,10 @@ class RampVoCPU(Ramp_vo):
         return False, False            # plain NHWC ring slots; the hidden state is compacted eagerly like the reference's
 
     def _init_streams(self, dev):
-        self._up_stream = self._fe_stream = None
-        self._ev_done = self._ev_fe_done = self._ev_fe_free = self._ev_ba = self._ev_up = None
-        self._mm_host = None
+        self._fe_stream = self._ev_fe_done = self._ev_gate = self._ev_in = None
+        self._gate_armed = False
 
     def _current_stream(self):
-        return None
-
-    def _prefetch_edges(self):
         return None
 
     def corr(self, coords, indicies=None, order=None):

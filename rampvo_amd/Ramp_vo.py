@@ -11,20 +11,28 @@ MI355X-first differences that do not change results:
   * feature ring buffers are channels-last (one pixel's 128 channels contiguous);
   * reproject / corr(+pyramid stack) / BA / point cloud are one fused HIP launch
     each (reference: ~13 / ~26 / ~50 / 4 launches);
-  * the factor graph (ii, jj, kk) is mirrored on the host, so edge generation,
-    factor removal and the keyframe shuffle need no device->host size reads; the
-    only sync per frame is the keyframe decision itself;
   * neighbour / group index structures are built once per graph change and
-    shared by the update operator and BA.
+    shared by the update operator and BA;
+  * STEADY STATE IS DEVICE RESIDENT (``track_dev.DeviceTrack``, csrc/track.hip): once the
+    optimisation window is full, a tracked frame is ONE host call that never reads the
+    device -- the keyframe decision (the reference's ``.item()``), the edit of the factor
+    graph, the next frame's new factors and the graph plan are kernels, and every size that
+    depends on a decision is read by the kernels from device memory.  ``settle()`` is the
+    one synchronisation that brings the host mirror (``n``, ``ii/jj/kk``, ``net``, ``delta``)
+    up to date; public attributes call it.  The first frames (initialisation, a window
+    that is still filling), fp32 mode and anything unusual run the host-driven path below,
+    which makes the same calls in the reference's order.
 """
 from collections import OrderedDict
 
 import os
+import warnings
+
 import numpy as np
 import torch
 import torch.nn.functional as F
 
-from . import altcorr, fastba, lietorch, ops
+from . import altcorr, fastba, lietorch, ops, track_dev
 from . import projective_ops as pops
 from . import _lib
 from ._lib import RAMP_NHWC, RAMP_NHWC8
@@ -44,13 +52,14 @@ class Ramp_vo:
         if dev.type != "cuda" and not getattr(self, "_allow_cpu", False):
             raise RuntimeError("rampvo_amd.Ramp_vo runs on the GPU only (HIP kernels, no CPU fallback); got device %s" % dev)
 
+        self._dev = None                # DeviceTrack while the steady state is device resident
         self.lmbda = torch.as_tensor([1e-4], device=dev)
         self.load_weights(network)
         self.is_initialized = False
         self.enable_timing = False
 
-        self.n = 0      # number of keyframes
-        self.m = 0      # number of patches
+        self._n = 0     # number of keyframes
+        self._m = 0     # number of patches
         self.M = self.cfg.PATCHES_PER_FRAME
         self.N = self.cfg.BUFFER_SIZE
         self.ht, self.wd = ht, wd
@@ -59,7 +68,6 @@ class Ramp_vo:
         self.tlist = []
         self.counter = 0
         self._tstamps = []          # host mirror of tstamps_[:n]
-
         self.tstamps_ = torch.zeros(self.N, dtype=torch.long, device=dev)
         self.poses_ = torch.zeros(self.N, 7, dtype=torch.float, device=dev)
         self.patches_ = torch.zeros(self.N, self.M, 3, self.P, self.P, dtype=torch.float, device=dev)
@@ -91,52 +99,31 @@ class Ramp_vo:
         self._net_map = None                     # host int64 [E]: row of _net_buf per current edge (-1: zeros)
         self._net_map_dev = None
         self._ixm = None
-        self._pre_cache = None                   # the next frame's graph (host + device arrays, plan), prepared by keyframe()
-        # Frame pipelining (GPU, opt-in): when the caller guarantees that the tensors it hands to __call__ are
-        # complete (not still being produced on the current stream), the keyframe decision of frame t is left
-        # pending when __call__ returns, and frame t+1's front end -- which depends on nothing but the new input
-        # and the encoder's own recurrent state -- is launched on a side stream BEFORE the host waits for that
-        # decision: it then runs next to frame t's bundle adjustment (a few small blocks on a 256-CU chip).
-        # Results are unchanged; read public state through settle() (update/terminate/state_dict call it).
+        # Frame pipelining (opt-in): the caller guarantees that the tensors it hands to __call__ are complete (not
+        # still being produced on the current stream).  In the device-resident steady state the next frame's front
+        # end is then launched on a side stream, gated by an event recorded before the last kernel of the previous
+        # frame's update operator: it runs next to the gru chain and BA (a few small blocks on a 256-CU chip).
         self.inputs_ready = False
-        self._pending = None
+        self.device_steps = os.environ.get("RAMP_DEVICE_STEP", "1") == "1"     # A/B and test switch
         self._edge_tmpl = None
-        self._spec_ema = 1.0                     # running frequency of "keyframe removed" (see _keyframe_speculative)
-        self._mm_prev, self._mm_inc = None, 3.0  # previous motion-test value / decision, its typical step
-        self._pred_score, self._pred_last = [0.5, 0.5], (True, True)
-        self._pred_stats = [0, 0]                # motion tests, misses (which outcome was prepared ahead)
-        # pinned host buffers for the speculative graph layouts: the host mirror of the graph is a view of one of
-        # them, the outcome(s) being prepared live in the others (fresh numpy buffers cost ~80 us of page faults
-        # per MB, pageable uploads another ~50 us)
-        self._pool = [None, None, None, None]
-        self._pool_busy = set()
-        self._mirror_pool = None
-        self._keep = (None, None)
         self._shift_plan = None
         self._cur_stream = None
-        self._fe_pool = None
         self._corr_levels = None
-        self._fe_free = None
-        self._ba_event = None
-        self._early = None             # launches already made for this frame right after the read-back (_early_launches)
         self._fc_plan = None           # (front-end outputs, patches, FrameCommitPlan or None)
-        self._up_dirty = False         # something was enqueued on the upload stream since the last join
-        self._median_dev = None        # device scalar: median depth of the three newest frames, computed after BA
-        self._median_n = None          # self.n at that moment (valid for the next frame's commit at n or n - 1)
-        self._median_synced = True     # the current stream has waited for the stream it was computed on
+        self._ba_flags = 0             # bits of fastba's info seen so far (1: a pose step was dropped, 2: pair list overflow)
         self._init_streams(dev)
-        self.net = torch.zeros(1, 0, DIM, dtype=torch.float, device=dev)   # hidden state is fp32 (as under autocast)
-        self.ii = torch.zeros(0, dtype=torch.long, device=dev)
-        self.jj = torch.zeros(0, dtype=torch.long, device=dev)
-        self.kk = torch.zeros(0, dtype=torch.long, device=dev)
+        self._net_buf = torch.zeros(1, 0, DIM, dtype=torch.float, device=dev)   # hidden state is fp32 (as under autocast)
+        self._dii = torch.zeros(0, dtype=torch.long, device=dev)
+        self._djj = torch.zeros(0, dtype=torch.long, device=dev)
+        self._dkk = torch.zeros(0, dtype=torch.long, device=dev)
         # host mirror of the factor graph
-        self._ii = np.zeros(0, np.int64)
-        self._jj = np.zeros(0, np.int64)
-        self._kk = np.zeros(0, np.int64)
+        self._hii = np.zeros(0, np.int64)
+        self._hjj = np.zeros(0, np.int64)
+        self._hkk = np.zeros(0, np.int64)
         self._plan = None
 
         self.poses_[:, 6] = 1.0
-        self.delta = {}
+        self._delta = {}
         self.patch_dict_ = None          # pose-prediction mode (reference :34-35)
         self.patches_models = None
         self._ba_info = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -144,16 +131,29 @@ class Ramp_vo:
         self._last_K_row = -1
 
     def close(self):
-        """release the helper thread of the pipelined mode (also called when the tracker is collected)"""
-        pool, self._fe_pool = getattr(self, "_fe_pool", None), None
-        if pool is not None:
-            pool.shutdown(wait=True)
+        """kept for callers of earlier versions (the pipelined mode no longer owns a helper thread)"""
 
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
+    # ------------------------------------------------------- state the device may own
+    # In the device-resident steady state the keyframe count, the factor graph, the hidden state and the delta chain
+    # live on the GPU; reading any of them through its public name first hands the state back (one synchronisation).
+    def _mirror(name):
+        priv = "_" + name if not name.startswith("_") else "_h" + name[1:]
+
+        def get(self):
+            if self._dev is not None and self._dev.active:
+                self.settle()
+            return getattr(self, priv)
+
+        def put(self, v):
+            if self._dev is not None and self._dev.active:
+                self.settle()
+            setattr(self, priv, v)
+        return property(get, put)
+
+    n, m, delta = _mirror("n"), _mirror("m"), _mirror("delta")
+    ii, jj, kk = _mirror("dii"), _mirror("djj"), _mirror("dkk")
+    _ii, _jj, _kk = _mirror("_ii"), _mirror("_jj"), _mirror("_kk")
+    del _mirror
 
     def _layout_flags(self, h, w):
         """(fp16 pyramid in the MFMA correlation kernel's [h][C/8][w][8] slots, lazy hidden-state row map: the [E,384]
@@ -162,13 +162,12 @@ class Ramp_vo:
         return chunked, True
 
     def _init_streams(self, dev):
-        self._up_stream = torch.cuda.Stream(device=dev)
         self._fe_stream = torch.cuda.Stream(device=dev)
         # events are re-recorded every frame (creating one costs a hipEventCreate/Destroy pair per use)
-        mk = lambda: torch.cuda.Event()
-        self._ev_done, self._ev_fe_done, self._ev_fe_free, self._ev_ba, self._ev_up = mk(), mk(), mk(), mk(), mk()
-        self._ev_med = mk()
-        self._mm_host = torch.empty(2, dtype=torch.float32).pin_memory()
+        self._ev_fe_done, self._ev_gate, self._ev_in = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+        for ev in (self._ev_fe_done, self._ev_gate, self._ev_in):
+            ev.record()                      # torch creates the hipEvent lazily; csrc/track.hip records the raw handle
+        self._gate_armed = False
 
     # ------------------------------------------------------------------ weights
     def load_weights(self, network):
@@ -220,33 +219,68 @@ class Ramp_vo:
     # --------------------------------------------------------------- hidden state
     # Reference: ``self.net`` [1,E,384] is compacted on every factor removal (:203-208) and grown with zero
     # rows on every append (:194-201) -- two full copies of a 60 MB tensor per frame.  On the GPU the tensor
-    # of the PREVIOUS update is kept as is and a host-side row map follows the graph edits; the update
-    # operator's first row kernel gathers through the map.  Reading ``self.net`` materialises it.
+    # of the PREVIOUS update is kept as is and a row map follows the graph edits; the update
+    # operator's first row kernel gathers through it.  Reading ``self.net`` materialises it.
     @property
     def net(self):
+        self.settle()
         if self._net_map is not None:
             m = torch.from_numpy(self._net_map).to(self._net_buf.device)
             rows = self._net_buf[:, m.clamp(min=0)] * (m >= 0).to(self._net_buf.dtype)[None, :, None]
             self._net_buf, self._net_map, self._net_map_dev = rows, None, None
-            self._pre_cache = None     # its row map points into the buffer that was just replaced
         return self._net_buf
 
     @net.setter
     def net(self, value):
+        self.settle()
         self._net_buf, self._net_map, self._net_map_dev = value, None, None
-        # a graph prepared for the next frame carries a row map into the PREVIOUS buffer.  In the tracking loop none
-        # exists at this point (update() runs before keyframe() prepares one); after an extra update() between two
-        # frames (evaluate.run_pose_pred does twelve) it would be stale: the next frame lays its graph out afresh.
-        self._pre_cache = None
 
     def _net_rows(self):
         return self._net_map if self._net_map is not None else np.arange(self._net_buf.shape[1], dtype=np.int64)
 
     # ----------------------------------------------------------------- snapshot
     def settle(self):
-        """apply a keyframe decision left pending by the pipelined mode (see ``inputs_ready``)"""
-        if self._pending is not None:
-            self._keyframe_finish()
+        """bring the host mirror up to date: if the steady state is device resident, synchronise and take the
+        keyframe count, the factor graph, the hidden-state row map and the delta chain back (the next tracked frame
+        runs host-driven and hands the state over again)"""
+        dv = self._dev
+        if dv is None or not dv.active:
+            return
+        st = dv.leave()
+        self._n, self._m = st["n"], st["n"] * self.M
+        self._hii, self._hjj, self._hkk = st["ii"], st["jj"], st["kk"]
+        g = torch.from_numpy(np.stack([st["ii"], st["jj"], st["kk"], st["rows"]])).to(self.device)
+        self._dii, self._djj, self._dkk = g[0], g[1], g[2]
+        self._net_buf, self._net_map, self._net_map_dev = st["net"][None], st["rows"], g[3]
+        self._plan = None
+        for t1, t0, dP in st["log"]:
+            self._delta[t1] = (t0, SE3(dP))
+        self._tstamps = [int(v) for v in self.tstamps_[:self._n].tolist()]
+        self._last_K_row = self._n - 1           # every committed frame copied (or wrote) its intrinsics row
+        self._note_ba_flags(st["status"] & 3)
+        if st["status"] & ~3:
+            raise RuntimeError("device-resident tracker: capacity exceeded (status bits %d: 4 = factor list, "
+                               "8 = group-by key range, 16 = delta log)" % st["status"])
+
+    def peek(self):
+        """(keyframes, factors) right now -- synchronises, but leaves a device-resident state where it is (tests and
+        benchmarks read these per frame; ``n`` / ``_ii`` would hand the state back to the host every time)"""
+        dv = self._dev
+        if dv is not None and dv.active:
+            torch.cuda.current_stream().synchronize()
+            d = dv.dyn.cpu().numpy()
+            return dict(n=int(d[track_dev.DYN_NROW]), E=int(d[track_dev.DYN_EKEPT]), resident=True)
+        return dict(n=self._n, E=len(self._hii), resident=False)
+
+    def _note_ba_flags(self, bits):
+        """bit 0: bundle adjustment dropped a pose step (Cholesky failed / not finite), bit 1: pair list overflow --
+        the reference would have propagated NaN / exited; here the tracker goes on and says so once"""
+        new = bits & ~self._ba_flags
+        self._ba_flags |= bits
+        if new & 1:
+            warnings.warn("bundle adjustment dropped a pose step (normal equations not positive definite)")
+        if new & 2:
+            raise RuntimeError("bundle adjustment: more pair records on one pose than ba_assemble's list holds")
 
     def state_dict(self):
         """VO state as CPU tensors in the REFERENCE's layouts (NCHW feature buffers), so a
@@ -299,15 +333,9 @@ class Ramp_vo:
         self._ii, self._jj, self._kk = (sd[x].cpu().numpy().astype(np.int64) for x in ("ii", "jj", "kk"))
         self.delta = {k: (v[0], SE3(v[1].to(dev))) for k, v in sd.get("delta", {}).items()}
         self._plan = None
-        # nothing prepared for the previous state may survive: the speculative next-frame graph (validated only by
-        # its sizes), the keyframe predictor, the intrinsics row cache, the pinned layout buffers' bookkeeping
-        self._pre_cache, self._pending, self._net_map_dev = None, None, None
-        self._median_n = None
-        self._mm_prev, self._spec_ema = None, 1.0
+        self._net_map_dev = None
         self._last_K = self._last_K_raw = None
         self._last_K_row = -1
-        self._pool_busy.clear()
-        self._mirror_pool = None
 
     # --------------------------------------------------------------- trajectory
     def get_pose(self, t):
@@ -375,11 +403,10 @@ class Ramp_vo:
         intrinsics = intrinsics if intrinsics is not None else self.intrinsics
         return pops.reproject(poses, patches, intrinsics, ii, jj, kk)      # [1,E,2,3,3]
 
+
     # -------------------------------------------------------------------- graph
     def _upload(self, a):
-        """host array -> device.  A pageable host->device copy blocks the host until everything queued
-        before it has run, so the tracker issues its uploads only where the stream is known to be
-        (nearly) empty: at the top of a frame (_prefetch_edges) and right after keyframe()'s read-back."""
+        """host array -> device"""
         return torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
 
     def _new_edges(self, n1):
@@ -402,54 +429,21 @@ class Ramp_vo:
         jj = np.concatenate([jf.reshape(-1), jb.reshape(-1)]).astype(np.int64)
         return kk // M, jj, kk
 
-    def _prefetch_edges(self):
-        """the factors this frame will add if it is accepted depend only on (n, M, lifetime): build and
-        upload them BEFORE the encoder is enqueued, while the GPU is idle -- or take the copy the
-        speculative keyframe() of the previous frame already made."""
-        n1 = self.n + 1                       # value of self.n when the edges are generated
-        pre = self._pre_cache
-        self._pre_cache = None
-        if pre is not None and pre["n1"] == n1 and pre["Ek"] == len(self._ii):
-            return pre
-        ii, jj, kk = self._new_edges(n1)
-        dev = self._upload(np.stack([ii, jj, kk]))            # one copy for the three arrays
-        map_dev = None
-        if self._lazy_net:                                    # the state row map as it will be after the append
-            map_dev = self._upload(np.concatenate([self._net_rows(), np.full(len(kk), -1, np.int64)]))
-        return (n1, ii, jj, kk, dev, map_dev)
-
-    def append_factors(self, ii, jj, pre=None):
-        """ii: patch indices, jj: frame indices (host arrays) -- reference :194-201.  ``pre``: the same
-        edges already uploaded by _prefetch_edges"""
-        map_dev = None
-        if isinstance(pre, dict):
-            # the speculative keyframe() laid the whole next graph out (host + device) and built its plan:
-            # kept factors [0, Ek) followed by this frame's new ones -- nothing is concatenated or uploaded
-            b4, d4, tot = pre["host"], pre["dev"], pre["Ek"] + pre["ne"]
-            self._ii, self._jj, self._kk = b4[0, :tot], b4[1, :tot], b4[2, :tot]
-            self.ii, self.jj, self.kk = d4[0, :tot], d4[1, :tot], d4[2, :tot]
-            self._net_map, self._net_map_dev = b4[3, :tot], d4[3, :tot]
-            self._plan = pre.get("plan")
-            if self._plan is not None:                 # built on the upload stream: order it before this stream's use
-                self._wait_upload_stream()
-            return
-        if pre is not None:
-            _, src, jj, ii, dev, map_dev = pre
-            d_ii, d_jj, d_kk = dev[0], dev[1], dev[2]
-        else:
-            ii = np.asarray(ii, np.int64)
-            jj = np.asarray(jj, np.int64)
-            src = ii // self.M                      # == self.ix[ii]: index_[r] = r for every frame row
-            d_ii, d_jj, d_kk = self._upload(src), self._upload(jj), self._upload(ii)
+    def append_factors(self, ii, jj):
+        """ii: patch indices, jj: frame indices (host arrays) -- reference :194-201"""
+        ii = np.asarray(ii, np.int64)
+        jj = np.asarray(jj, np.int64)
+        src = ii // self.M                      # == self.ix[ii]: index_[r] = r for every frame row
+        dev = self._upload(np.stack([src, jj, ii]))                # one copy for the three arrays
         self._jj = np.concatenate([self._jj, jj])
         self._kk = np.concatenate([self._kk, ii])
         self._ii = np.concatenate([self._ii, src])
-        self.jj = torch.cat([self.jj, d_jj])
-        self.kk = torch.cat([self.kk, d_kk])
-        self.ii = torch.cat([self.ii, d_ii])
+        self.ii = torch.cat([self.ii, dev[0]])
+        self.jj = torch.cat([self.jj, dev[1]])
+        self.kk = torch.cat([self.kk, dev[2]])
         if self._lazy_net:
             self._net_map = np.concatenate([self._net_rows(), np.full(len(ii), -1, np.int64)])
-            self._net_map_dev = map_dev if (map_dev is not None and map_dev.shape[0] == len(self._net_map)) else None
+            self._net_map_dev = None
         else:
             net = torch.zeros(1, len(ii), self.DIM, dtype=torch.float, device=self.device)
             self.net = torch.cat([self.net, net], dim=1)
@@ -501,7 +495,6 @@ class Ramp_vo:
         t1 = self.M * max((self.n - 0), 0)
         kk, jj = np.meshgrid(np.arange(t0, t1), np.arange(max(self.n - r, 0), self.n), indexing='ij')
         return kk.reshape(-1), jj.reshape(-1)
-
     # ------------------------------------------------------------------- motion
     def motion_probe(self):
         """median update magnitude of the newest patches against the newest frame (reference :210-225)"""
@@ -528,8 +521,7 @@ class Ramp_vo:
                                                   (self.patches_, 0), (self.intrinsics_, 0), (self.imap_, self.mem),
                                                   (self.gmap_, self.mem), (self.fmap1_, self.mem),
                                                   (self.fmap2_, self.mem)])
-            if not (self._early is not None and self._early.pop("shift_done", False)):
-                self._shift_plan.run(k, n)                                                # one launch
+            self._shift_plan.run(k, n)                                                # one launch
         else:
             for buf in (self.tstamps_, self.colors_, self.poses_, self.patches_, self.intrinsics_):
                 buf[k:n - 1] = buf[k + 1:n].clone()
@@ -539,241 +531,59 @@ class Ramp_vo:
                 buf[dst] = buf[src]
         self.n -= 1
         self.m -= self.M
-
     def keyframe(self):
         """drop keyframe n-KEYFRAME_INDEX if the motion around it is small, then cull factors older
-        than REMOVAL_WINDOW (reference :237-274).  Both removals are decided on the host mirror and
-        applied to the device state as ONE compaction."""
-        self.settle()
-        return self._keyframe_speculative()
-
-    def _keyframe_speculative(self):
-        """GPU: the motion test is the frame's only device->host read, and at that point the GPU still has
-        most of update() queued.  While it drains, the host prepares the outcome -- edited graph, hidden-
-        state row map, the next frame's new edges -- and uploads it on a side stream; after the read-back
-        it only adopts it.  (Doing this work after the read-back left the GPU idle for ~0.4 ms per frame.)"""
+        than REMOVAL_WINDOW (reference :237-274) -- the host-driven form: the motion test is read back (the
+        reference's two ``.item()``), both removals are decided on the host mirror in one pass
+        (``ramp_graph_edit_host``) and applied to the device state as ONE compaction.  The device-resident steady
+        state takes the same decision and makes the same edit with kernels (csrc/track.hip)."""
         cfg = self.cfg
         i, j = self.n - cfg.KEYFRAME_INDEX - 1, self.n - cfg.KEYFRAME_INDEX + 1
         k = self.n - cfg.KEYFRAME_INDEX
         plan = self._graph_plan()
         mm = ops.motionmag(self.poses, self.patches, self.intrinsics, self.ii, self.jj, self.kk, plan.g_ij,
                            j * plan.pair_mul + i, i * plan.pair_mul + j, beta=0.5)   # keys are jj*mul+ii
-        self._mm_host.copy_(mm.reshape(2), non_blocking=True)       # both directions; averaged on the host
-        done = self._ev_done
-        done.record()
-        dP = SE3(self.poses_[k]) * SE3(self.poses_[k - 1]).inv()      # only used if the keyframe goes
-        # steady motion gives the same answer frame after frame: only the more frequent outcome so far is
-        # prepared ahead; the other one is built after the read-back if the guess was wrong
-        g_freq = self._spec_ema >= 0.5
-        g_saw = g_freq
-        if self._mm_prev is not None:
-            # the test value is a sawtooth under steady motion: it grows by a fairly constant step while keyframes
-            # are being removed (the compared frames drift apart) and drops once one is kept
-            pm, prem = self._mm_prev
-            g_saw = True if not prem else (pm + self._mm_inc < cfg.KEYFRAME_THRESH)
-        guess = g_saw if self._pred_score[1] >= self._pred_score[0] else g_freq
-        self._pred_last = (g_freq, g_saw)
-        spec = {guess: self._spec_outcome(guess, k)}
-        self._pending = dict(done=done, spec=spec, k=k, dP=dP)
-        if not (self.inputs_ready and getattr(self.network.patchify, "_graphs", None)):
-            self._keyframe_finish()
-        else:
-            # pipelined: nothing hides host work after the read-back, so the guessed graph's plan is built now too
-            self._build_next_plan(spec[guess])
-
-    def _pool_take(self, nelem):
-        idx = next(i for i in range(len(self._pool)) if i not in self._pool_busy)
-        t = self._pool[idx]
-        if t is None or t.numel() < nelem:
-            # sized once for the largest graph the windows allow (a pinned allocation in steady state is a
-            # multi-millisecond stall): patches alive x factors per patch, 4 rows
-            cfg = self.cfg
-            bound = 4 * self.M * (cfg.REMOVAL_WINDOW + 2) * (2 * cfg.PATCH_LIFETIME)
-            t = self._pool[idx] = torch.empty(max(int(nelem * 1.25) + 1024, bound), dtype=torch.long).pin_memory()
-        self._pool_busy.add(idx)
-        return idx, t
-
-    def _cur(self):
-        """the caller's stream; looked up once per __call__ (torch.cuda.current_stream() costs ~4 us)"""
-        return self._cur_stream if self._cur_stream is not None else torch.cuda.current_stream()
-
-    def _wait_upload_stream(self):
-        """current stream waits for everything queued on the upload stream (wait_stream without a new event)"""
-        if not self._up_dirty:
-            return
-        self._ev_up.record(self._up_stream)
-        self._cur().wait_event(self._ev_up)
-        self._median_synced = True
-        self._up_dirty = False
-
-    def _spec_outcome(self, remove, k):
-        """the graph after keyframe() for one outcome of the motion test, laid out together with the next frame's
-        new factors, on the host and (uploaded on the side stream) on the device"""
-        cfg = self.cfg
-        base_rows = self._net_map            # None: identity
-        E, M = len(self._ii), self.M
-        self._up_dirty = True
-        with torch.cuda.stream(self._up_stream):
-            n_after = self.n - 1 if remove else self.n
-            n1 = n_after + 1
-            e_ii, e_jj, e_kk = self._new_edges(n1)
-            ne = len(e_kk)
-            # ONE host buffer / one upload per outcome: rows (ii, jj, kk, state row) of capacity E + ne;
-            # the factors kept by the edit come first, the next frame's new factors follow -- so the
-            # current graph is the [:Ek] view and the next frame's graph the [:Ek+ne] view of the same
-            # arrays, on the host and on the device
-            cap = E + ne
-            pool, flat = self._pool_take(4 * cap)
-            flat = flat[:4 * cap].view(4, cap)
-            buf = flat.numpy()
-            rng = np.empty(4, np.int64)
-            Ek = _lib.lib().ramp_graph_edit_host(
-                self._ii.ctypes.data, self._jj.ctypes.data, self._kk.ctypes.data,
-                base_rows.ctypes.data if base_rows is not None else None, E, M, k if remove else -1, n_after,
-                cfg.REMOVAL_WINDOW, buf.ctypes.data, cap, rng.ctypes.data)
-            assert Ek >= 0
-            # index ranges of the next frame's graph: kept factors (from the C pass) + the new ones (closed form)
-            r_ = cfg.PATCH_LIFETIME
-            k_lo, k_hi = M * max(n1 - r_, 0), M * n1
-            f_lo, f_hi = max(n1 - r_, 0), n1
-            if Ek > 0:
-                k_lo, k_hi = min(k_lo, int(rng[0])), max(k_hi, int(rng[1]) + 1)
-                f_lo, f_hi = min(f_lo, int(rng[2])), max(f_hi, int(rng[3]) + 1)
-            buf[0, Ek:Ek + ne] = e_ii
-            buf[1, Ek:Ek + ne] = e_jj
-            buf[2, Ek:Ek + ne] = e_kk
-            buf[3, Ek:Ek + ne] = -1
-            dev = torch.empty((4, cap), dtype=torch.long, device=self.device)
-            dev.copy_(flat, non_blocking=True)
-            return dict(n1=n1, n=n_after, Ek=Ek, ne=ne, host=buf, dev=dev, ranges=(k_lo, k_hi, f_lo, f_hi), pool=pool)
-
-    def _early_launches(self, job, intrinsics, accepts):
-        """Pipelined steady state, the moment the motion test has been read back.  The GPU is idle from here to the
-        correlation kernel, and what it needs to get there is four launches -- the row shift of a dropped keyframe,
-        the frame commit, the reprojection, the correlation -- while the host has ~170 us of bookkeeping to walk
-        through in the order the reference does it.  When the prepared outcome is the right one and nothing unusual
-        is going on (intrinsics unchanged, one-launch commit available, plan built), those launches go out FIRST, with
-        exactly the arguments the regular path would compute; the regular path then runs as always and skips them
-        (``self._early``).  Returns the front end's outputs if it took them from ``job``."""
-        pend = self._pending
-        pend["done"].synchronize()
-        cfg, mmh = self.cfg, self._mm_host.numpy()
-        remove = float((mmh[0] + mmh[1]) * np.float32(0.5)) < cfg.KEYFRAME_THRESH
-        pre, k, n0 = pend["spec"].get(remove), pend["k"], self.n
-        n1 = n0 - 1 if remove else n0
-        fc, raw = self._fc_plan, self._last_K_raw
-        if not (os.environ.get("RAMP_EARLY", "1") == "1" and accepts and job is not None and self.is_initialized
-                and pre is not None and pre.get("plan") is not None and pre["n1"] == n1 + 1 and n1 >= 3
-                and fc is not None and fc[2] is not None and self._chunked
-                and (not remove or (self._shift_plan is not None and (self.M * 3) % 4 == 0))
-                and raw is not None and self._last_K_row == n0 - 1 and self._last_K is not None
-                and intrinsics.device.type == "cpu" and intrinsics.dtype == torch.float32
-                and torch.equal(intrinsics, raw)):
-            return None
-        self._wait_upload_stream()
-        early = self._early = {}
-        if remove:
-            self._shift_plan.run(k, n0)
-            early["shift_done"] = True
-        fe_out = job.result()
-        self._cur().wait_event(self._ev_fe_done)
-        patches = fe_out[3]
-        if fc[0] is not getattr(self.network.patchify, "_extra", None) or fc[1] is not patches:
-            return fe_out                              # other output buffers than last frame's: the regular commit
-        slot = n1 % self.mem
-        med = self._median_dev if (self._median_n is not None and self._median_n in (n1, n1 + 1)) else None
-        m1 = self.m - (self.M if remove else 0)
-        fc[2].run(self.poses_, n1, 1 if cfg.MOTION_MODEL == 'DAMPED_LINEAR' else 2, cfg.MOTION_DAMPING, self.tstamps_,
-                  self.counter, self.index_map_, m1 + self.M, self.intrinsics_, True, self.patches_, 3, patches,
-                  (n1, slot, slot, slot, slot), median_dev=med)
-        early["commit_done"] = True
-        tot, d4 = pre["Ek"] + pre["ne"], pre["dev"]
-        ii_, jj_, kk_ = d4[0, :tot], d4[1, :tot], d4[2, :tot]
-        coords = torch.empty((1, tot, 2, self.P, self.P), dtype=torch.float32, device=self.device)
-        _lib.check(_lib.lib().ramp_transform(_lib.ptr(self.poses_), _lib.ptr(self.patches_), _lib.ptr(self.intrinsics_),
-                                             _lib.ptr(ii_), _lib.ptr(jj_), _lib.ptr(kk_), _lib.ptr(coords), tot, self.P,
-                                             0, _lib.stream()), "ramp_transform")
-        early["coords"] = coords
-        early["corr"] = self._corr_launch(coords, kk_, jj_, pre["plan"].g_ij.order)
-        early["E"] = tot
-        return fe_out
-
-    def _keyframe_finish(self, synced=False):
-        """second half of keyframe(): wait for the motion test, pick the prepared outcome"""
-        cfg = self.cfg
-        pend, self._pending = self._pending, None
-        spec, k, dP = pend["spec"], pend["k"], pend["dP"]
-        if not synced:
-            pend["done"].synchronize()
-        mmh = self._mm_host.numpy()
-        remove = float((mmh[0] + mmh[1]) * np.float32(0.5)) < cfg.KEYFRAME_THRESH      # fp32 mean, as torch's
-        pre = spec.get(remove)
-        self._pred_stats[0] += 1
-        if pre is None:
-            self._pred_stats[1] += 1
-            pre = self._spec_outcome(remove, k)
-        self._spec_ema = 0.9 * self._spec_ema + (0.1 if remove else 0.0)
-        m_now = float((mmh[0] + mmh[1]) * np.float32(0.5))
-        if self._mm_prev is not None and self._mm_prev[1] and m_now > self._mm_prev[0]:
-            self._mm_inc = 0.9 * self._mm_inc + 0.1 * (m_now - self._mm_prev[0])
-        self._mm_prev = (m_now, remove) if m_now == m_now else None          # NaN: no edges between the pair
-        for i, g in enumerate(self._pred_last):                              # running hit rate of both predictors
-            self._pred_score[i] = 0.95 * self._pred_score[i] + (0.05 if g == remove else 0.0)
-        for other in spec.values():               # host buffers: the adopted layout becomes the mirror
-            if other is not pre:
-                self._pool_busy.discard(other["pool"])
-        self._pool_busy.discard(self._mirror_pool)
-        self._mirror_pool = pre["pool"]
-        self._wait_upload_stream()
-        # arrays and plan were allocated on the side stream and are consumed on this one: instead of
-        # record_stream() on ~15 tensors they are simply kept alive for two frames -- every consumer of frame t
-        # has finished when frame t+1's motion test has been read back
-        self._keep = (self._keep[1], pre)
+        vals = torch.cat([mm.reshape(2), self._ba_info.to(torch.float32)]).cpu().numpy()   # the read-back
+        self._note_ba_flags(int(vals[2]))
+        remove = (float(vals[0]) + float(vals[1])) / 2 < cfg.KEYFRAME_THRESH      # python floats, as the reference
         if remove:
             t0, t1 = self._tstamps[k - 1], self._tstamps[k]
+            dP = SE3(self.poses_[k]) * SE3(self.poses_[k - 1]).inv()
             self.delta[t1] = (t0, dP)
+        n_after = self.n - 1 if remove else self.n
+        E = len(self._ii)
+        buf = np.empty((4, max(E, 1)), np.int64)
+        rows = self._net_map
+        h_ii, h_jj, h_kk = (np.ascontiguousarray(a) for a in (self._ii, self._jj, self._kk))
+        Ek = _lib.lib().ramp_graph_edit_host(
+            h_ii.ctypes.data, h_jj.ctypes.data, h_kk.ctypes.data,
+            np.ascontiguousarray(rows).ctypes.data if rows is not None else None, E, self.M, k if remove else -1,
+            n_after, cfg.REMOVAL_WINDOW, buf.ctypes.data, buf.shape[1], None)
+        assert Ek >= 0
+        if remove:
             self._apply_removal(k)
-        b4, d4, Ek = pre["host"], pre["dev"], pre["Ek"]
-        self._ii, self._jj, self._kk = b4[0, :Ek], b4[1, :Ek], b4[2, :Ek]
-        self.ii, self.jj, self.kk = d4[0, :Ek], d4[1, :Ek], d4[2, :Ek]
-        self._net_map, self._net_map_dev = b4[3, :Ek], None
+        if Ek == E and not remove:
+            return
+        dev = self._upload(buf[:, :Ek])
+        self._ii, self._jj, self._kk = buf[0, :Ek], buf[1, :Ek], buf[2, :Ek]
+        self.ii, self.jj, self.kk = dev[0], dev[1], dev[2]
+        if self._lazy_net:
+            self._net_map, self._net_map_dev = buf[3, :Ek], dev[3]
+        else:
+            self.net = self.net[:, dev[3]]
         self._plan = None
-        # the next frame's graph is known now; its plan is built by _track() right after the next front end has
-        # been enqueued (side stream), so nothing but the selection sits between the read-back and that launch
-        pre.setdefault("plan", None)
-        self._pre_cache = pre
-
-    def _build_next_plan(self, pre):
-        """plan of the graph this frame will have after append_factors, on the upload stream, concurrently with
-        the encoder (the plan kernels are small; the front end leaves most CUs idle)"""
-        b4, d4, tot = pre["host"], pre["dev"], pre["Ek"] + pre["ne"]
-        self._up_dirty = True
-        with torch.cuda.stream(self._up_stream):
-            pre["plan"] = self._build_plan(b4[0, :tot], b4[1, :tot], b4[2, :tot], d4[0, :tot], d4[1, :tot],
-                                           d4[2, :tot], ranges=pre["ranges"])
-
-    def _mark_fe_start(self):
-        self._ba_event = self._ev_ba
-        self._ba_event.record()
 
     # ------------------------------------------------------------------- update
     def update(self):
-        self.settle()
+        """reference :276-310 (host-driven form; the device-resident step makes the same launches from C)"""
         with Timer("other", enabled=self.enable_timing):
             plan = self._graph_plan()
-            early, self._early = self._early, None
-            if early is not None and "corr" in early and early["E"] == self.ii.shape[0]:
-                coords, corr = early["coords"], early["corr"]          # launched right after the read-back
-            else:
-                coords = self.reproject()
-                order = plan.g_ij.order if os.environ.get("RAMP_CORR_ORDER", "1") == "1" else None
-                corr = self.corr(coords, order=order).to(self.dtype)
-            # GEMMs + row-fused glue (csrc/update.hip); the context gather, the heads' activations,
-            # `target = centre + delta` and filter_features are folded into those kernels
+            coords = self.reproject()
+            order = plan.g_ij.order if os.environ.get("RAMP_CORR_ORDER", "1") == "1" else None
+            corr = self.corr(coords, order=order).to(self.dtype)
+            # GEMMs + row-fused glue (csrc/update.hip) / the fused fp16 chains (csrc/update_mlp.hip); the context
+            # gather, the heads' activations, `target = centre + delta` and filter_features are folded in
             fu = self.network.update.fused(self.dtype)
-            fe_at = os.environ.get("RAMP_FE_AT", "gru")    # where the next front end may start (ba|gru|softagg|nbr)
-            fu.before_gru = self._mark_fe_start if (self.inputs_ready and fe_at != "ba") else None
-            fu.hook_at = fe_at
             net_map = None
             if self._net_map is not None:
                 net_map = self._net_map_dev if self._net_map_dev is not None else self._upload(self._net_map)
@@ -786,12 +596,6 @@ class Ramp_vo:
             else:
                 target, weight, _ = fu.target_weight(fu.heads(relu_t), coords[0], self.wd // 4, self.ht // 4)
             self.last_weight = weight
-            if self.inputs_ready and fe_at == "ba":
-                # the next frame's front end may start here, next to BA's small kernels (default: one kernel
-                # earlier, at the gru chain -- measured 1.43 vs 1.46 ms per step; earlier than that it costs the
-                # bandwidth-bound update kernels more than it hides)
-                self._ba_event = self._ev_ba
-                self._ba_event.record()
         with Timer("BA", enabled=self.enable_timing):
             t0 = self.n - self.cfg.OPTIMIZATION_WINDOW if self.is_initialized else 1
             t0 = max(t0, 1)
@@ -800,19 +604,6 @@ class Ramp_vo:
                           self.kk, t0, self.n, M=self.M, iterations=2, eff_impl=False, info=self._ba_info, plan=plan)
             except Exception as e:  # same recovery as the reference (:302-306)
                 print(f"WARNING: BA failed...{e}")
-            if (self.is_initialized and self.n >= 3 and self._up_stream is not None
-                    and ops.depth_median_supported(3, self.M, self.P)):
-                # the next frame's initial depth (reference :369-372: the median of the three newest frames) does not
-                # depend on the keyframe decision (it drops an older frame): computed now, on the side stream, instead of
-                # inside the next frame's commit launch between the read-back and the correlation kernel
-                if self._median_dev is None:
-                    self._median_dev = torch.empty(1, dtype=torch.float32, device=self.device)
-                self._up_dirty = True
-                self._ev_med.record(self._cur())
-                self._up_stream.wait_event(self._ev_med)
-                with torch.cuda.stream(self._up_stream):
-                    ops.depth_median(self.patches_, self.n, 3, self._median_dev)
-                self._median_n, self._median_synced = self.n, False
             if self._ixm is None or self._ixm.shape[0] < self.m:
                 self._ixm = torch.arange(self.N * self.M, device=self.device) // self.M     # patch -> source frame
             ixm = self._ixm[:self.m]
@@ -826,6 +617,8 @@ class Ramp_vo:
         with torch.no_grad():
             self._cur_stream = self._current_stream()
             try:
+                if self._dev is not None and self._dev.active:
+                    return self._track_device(tstamp, input_, intrinsics)
                 return self._track(tstamp, input_, intrinsics)
             finally:
                 self._cur_stream = None
@@ -833,53 +626,19 @@ class Ramp_vo:
     def _current_stream(self):
         return torch.cuda.current_stream()
 
-    def _track(self, tstamp, input_, intrinsics):
-        mask = input_[2]
-        accepts = mask is None or bool(mask)
-        fe_done = None
-        if self._pending is not None:
-            # pipelined: this frame's front end goes out first, on its own stream, next to what is left of the
-            # previous frame; only then does the host wait for the previous frame's keyframe decision
-            cur, fe = self._cur(), self._fe_stream
-            fe_done = self._ev_fe_done
+    def _cur(self):
+        """the caller's stream; looked up once per __call__ (torch.cuda.current_stream() costs ~4 us)"""
+        return self._cur_stream if self._cur_stream is not None else torch.cuda.current_stream()
 
-            def front_end():
-                if self._fe_free is not None:
-                    fe.wait_event(self._fe_free)          # the previous frame has copied the static outputs away
-                if self._ba_event is not None:
-                    fe.wait_event(self._ba_event)
-                with torch.no_grad(), torch.cuda.stream(fe):
-                    out = self.network.patchify(
-                        input_=input_, patches_per_image=self.cfg.PATCHES_PER_FRAME, event_bias=self.event_bias,
-                        reinit_hidden=False)
-                fe_done.record(fe)
-                return out
-
-            # the graph launch (~0.17 ms of host time inside the runtime, GIL released) runs on a helper thread
-            # while this thread waits for the read-back and applies the keyframe decision
-            if self._fe_pool is None and os.environ.get("RAMP_FE_THREAD", "1") == "1":
-                import concurrent.futures
-                self._fe_pool = concurrent.futures.ThreadPoolExecutor(
-                    max_workers=1, initializer=torch.cuda.set_device,
-                    initargs=(self.device.index if self.device.index is not None else torch.cuda.current_device(),))
-            job = self._fe_pool.submit(front_end) if self._fe_pool is not None else None
-            if job is None:
-                fmap, gmap, imap, patches, _, clr = front_end()
-            self._early = None
-            fe_out = self._early_launches(job, intrinsics, accepts)
-            self._keyframe_finish(synced=True)
-            if job is not None:
-                fmap, gmap, imap, patches, _, clr = fe_out if fe_out is not None else job.result()
-            if fe_out is None:
-                cur.wait_event(fe_done)
-        pre = self._prefetch_edges() if accepts else None
-        # intrinsics at feature resolution; the usual case (same values as the previous frame, CPU fp32 tensor)
-        # is recognised without building new arrays
+    def _intrinsics_row(self, intrinsics, accepts):
+        """intrinsics at feature resolution.  Returns (kq, k_dev): k_dev is a device [4] tensor when row n needs new
+        values, None when it can be copied from row n-1 (the usual case: same values as the previous frame, recognised
+        without building new arrays)"""
         k_dev = None
         raw = self._last_K_raw
         # the row copy (intrinsics_[n] = intrinsics_[n-1]) is only right while row n-1 is the row that holds
         # _last_K: not after a frame that wrote a new K to row n and was then rejected by the motion probe
-        row_ok = self._last_K_row == self.n - 1
+        row_ok = self._last_K_row == self._n - 1
         if (raw is not None and row_ok and intrinsics.device.type == "cpu" and intrinsics.dtype == torch.float32
                 and torch.equal(intrinsics, raw)):
             kq = self._last_K
@@ -888,16 +647,83 @@ class Ramp_vo:
             self._K_raw_now = intrinsics.detach().cpu().float().clone()
             if accepts and not (row_ok and self._last_K is not None and np.array_equal(kq, self._last_K)):
                 k_dev = self._upload(kq.astype(np.float32))
-        if fe_done is None:
-            fmap, gmap, imap, patches, _, clr = self.network.patchify(
-                input_=input_, patches_per_image=self.cfg.PATCHES_PER_FRAME, event_bias=self.event_bias,
-                reinit_hidden=True if tstamp == 0 else False)
-        if isinstance(pre, dict) and pre.get("plan") is None:
-            self._build_next_plan(pre)
+        return kq, k_dev
+
+    # ----------------------------------------------------- device-resident steady state
+    def _track_device(self, tstamp, input_, intrinsics):
+        """one tracked frame without a device->host read: front end (hipGraph), then ONE C call that enqueues the frame
+        stores, update(), keyframe() and the next frame's append_factors (csrc/track.hip::ramp_track_step)"""
+        dv = self._dev
+        mask = input_[2]
+        accepts = mask is None or bool(mask)
+        lazy = dv.lazy_state()                      # whatever copy of the device-side sizes has arrived: never waited for
+        if (accepts and (lazy[track_dev.DYN_N] + 8 >= self.N or lazy[track_dev.DYN_NLOG] + 8 >= dv.log_cap
+                         or lazy[track_dev.DYN_STATUS] & ~3)):
+            self.settle()                           # buffer / log nearly full, or a capacity flag: back to the host
+            return self._track(tstamp, input_, intrinsics)
+        cur = self._cur()
+        if self.inputs_ready and self._gate_armed:
+            # the caller's tensors are complete: the front end runs on its own stream, next to what is left of the
+            # previous frame from the gru chain on (the event is recorded inside ramp_track_step)
+            fe = self._fe_stream
+            fe.wait_event(self._ev_gate)
+            with torch.cuda.stream(fe):
+                out = self.network.patchify(input_=input_, patches_per_image=self.cfg.PATCHES_PER_FRAME,
+                                            event_bias=self.event_bias, reinit_hidden=False)
+            self._ev_fe_done.record(fe)
+            cur.wait_event(self._ev_fe_done)
+        else:
+            out = self.network.patchify(input_=input_, patches_per_image=self.cfg.PATCHES_PER_FRAME,
+                                        event_bias=self.event_bias, reinit_hidden=False)
+        if not accepts:
+            return      # events only: the encoder state has advanced, the VO has not
+        patches = out[3]
+        ex = getattr(self.network.patchify, "_extra", None)
+        if patches is None or not dv.bind_front_end(ex, patches):
+            self.settle()                           # outputs the one-launch commit cannot take: host-driven frame
+            return self._track_tail(tstamp, out, intrinsics)
+        dv.bind_weights(self.network.update.fused(self.dtype))
+        kq, k_dev = self._intrinsics_row(intrinsics, True)
+        if k_dev is not None:
+            dv.k_new.copy_(k_dev)
+            self._last_K, self._last_K_raw = kq, self._K_raw_now
+        self.tlist.append(tstamp)
+        dv.step(self.counter, track_dev.COMMIT | track_dev.UPDATE | track_dev.KEYFRAME,
+                k_new=dv.k_new if k_dev is not None else None,
+                gate_event=self._ev_gate.cuda_event if self.inputs_ready else None)
+        self._gate_armed = self.inputs_ready
+        self.counter += 1
+
+    def _enter_device(self):
+        """hand the state over to the device-resident step if this tracker / configuration supports it and the
+        optimisation window is full (BA's system then has a fixed size)"""
+        if not (self.device_steps and self.is_initialized and self._n >= self.cfg.OPTIMIZATION_WINDOW
+                and not self.enable_timing and self.device.type == "cuda" and track_dev.supported(self)
+                and getattr(self.network.patchify, "_graphs", None)):
+            return
+        if self._dev is None:
+            self._dev = track_dev.DeviceTrack(self)
+        n1 = self._n + 1
+        ok = self._dev.enter(self._hii, self._hjj, self._hkk, self._net_rows(), self._new_edges(n1),
+                             self._net_buf[0], self._n)
+        if ok:
+            self._gate_armed = False
+            # the device owns these now (their public names settle() first)
+            self._plan = None
+
+    # ----------------------------------------------------------- host-driven frame
+    def _track(self, tstamp, input_, intrinsics):
+        out = self.network.patchify(
+            input_=input_, patches_per_image=self.cfg.PATCHES_PER_FRAME, event_bias=self.event_bias,
+            reinit_hidden=True if tstamp == 0 else False)
         mask = input_[2]
         if mask is not None and not mask:
             return      # events only: the encoder state has advanced, the VO has not
+        return self._track_tail(tstamp, out, intrinsics)
 
+    def _track_tail(self, tstamp, out, intrinsics):
+        fmap, gmap, imap, patches, _, clr = out
+        kq, k_dev = self._intrinsics_row(intrinsics, True)
         n = self.n
         self.tlist.append(tstamp)
         del self._tstamps[n:]
@@ -927,24 +753,12 @@ class Ramp_vo:
             motion = 0 if n <= 1 else (1 if self.cfg.MOTION_MODEL == 'DAMPED_LINEAR' else 2)
             if not self.is_initialized:
                 patches[:, :, 2] = self._initial_depth(patches)       # reference :369; replaced by the median later
-            med = None
-            if self.is_initialized and self._median_n is not None and self._median_n in (n, n + 1):
-                if not self._median_synced:
-                    self._wait_upload_stream()
-                med = self._median_dev
-            self._median_n = None                          # one use: the next update() computes the next one
-            if self._early is not None and self._early.pop("commit_done", False):
-                assert copy_k and self.is_initialized                  # launched right after the read-back
-            else:
-                fc[2].run(self.poses_, n, motion, self.cfg.MOTION_DAMPING, self.tstamps_, self.counter,
-                          self.index_map_, self.m + self.M, self.intrinsics_, copy_k, self.patches_,
-                          3 if self.is_initialized else 0, patches, (n, slot, slot, slot, slot), median_dev=med)
+            fc[2].run(self.poses_, n, motion, self.cfg.MOTION_DAMPING, self.tstamps_, self.counter,
+                      self.index_map_, self.m + self.M, self.intrinsics_, copy_k, self.patches_,
+                      3 if self.is_initialized else 0, patches, (n, slot, slot, slot, slot))
         else:
             self._frame_stores_stepwise(n, slot, k_dev, kq, patches, imap, gmap, fmap, clr, ex)
         self._last_K_row = n                         # row n now holds _last_K (written or copied from row n-1)
-        if self.inputs_ready:
-            self._fe_free = self._ev_fe_free
-            self._fe_free.record()
         self.counter += 1
         if n > 0 and not self.is_initialized:
             if self.motion_probe() < 2.0:
@@ -953,12 +767,9 @@ class Ramp_vo:
 
         self.n += 1
         self.m += self.M
-        if pre is not None and (pre["n1"] if isinstance(pre, dict) else pre[0]) == self.n:
-            self.append_factors(None, None, pre=pre)
-        else:
-            kf, jf = self.__edges_forw()
-            kb, jb = self.__edges_back()
-            self.append_factors(np.concatenate([kf, kb]), np.concatenate([jf, jb]))
+        kf, jf = self.__edges_forw()
+        kb, jb = self.__edges_back()
+        self.append_factors(np.concatenate([kf, kb]), np.concatenate([jf, jb]))
 
         if self.n == 8 and not self.is_initialized:
             self.is_initialized = True
@@ -967,6 +778,7 @@ class Ramp_vo:
         elif self.is_initialized:
             self.update()
             self.keyframe()
+            self._enter_device()
 
     # -------------------------------------------------------- pose prediction
     def _virtual_frame(self, last_keyframe_number):
@@ -1031,7 +843,6 @@ class Ramp_vo:
 
     def update_attributes(self, abs_time, next_frame_index, poses):
         """expose the virtual pose to terminate() (reference :510-519)"""
-        self._median_n = None
         assert self._tstamps[self.n - 1] != 0 if self._tstamps else int(self.tstamps_[self.n - 1]) != 0
         self.tstamps_[self.n] = abs_time
         del self._tstamps[self.n:]
@@ -1044,7 +855,6 @@ class Ramp_vo:
     def remove_attributes(self):
         """undo update_attributes (reference :521-528; upstream's ``poses_[:,6] = 1.0`` there rewrites the qw of
         EVERY keyframe -- only the removed row is reset here)"""
-        self._median_n = None
         self.n -= 1
         self.counter -= 1
         self.tlist.pop()

@@ -102,6 +102,13 @@ SIGNATURES = {
                            c_p, c_i, c_p]),
     "ramp_upd_mlp_lds_bytes": (c_sz, []),
     "ramp_upd_nbr": (c_i, [c_p] * 8 + [c_i, c_p]),
+    "ramp_upd_linear": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_p]),
+    # device-resident tracking step (csrc/track.hip); the ramp_track descriptor is mirrored in track_dev.py
+    "ramp_track_sizeof": (c_sz, []),
+    "ramp_track_plan_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
+    "ramp_track_ba_workspace_bytes": (c_sz, [c_i] * 6),
+    "ramp_track_plan": (c_i, [c_p, c_i, c_p]),
+    "ramp_track_step": (c_i, [c_p, c_i, c_i64, c_i, c_p, c_p, c_p]),
 }
 
 _lib = None

@@ -176,6 +176,7 @@ struct CorrParams {
   int row_elems;          // elements per edge row of `out` (>= 441 * nlevels; the tail is zero filled)
   const int32_t *order;   // optional schedule: position -> edge (any permutation of 0..E-1)
   int chunk;              // ceil(E / CORR_XCDS)
+  const int32_t *dyn;     // optional device-side sizes (RAMP_DYN_E): E / chunk above are then the launch bound
 };
 
 // Workgroup ids are dealt round-robin to the 8 XCDs, each with a private L2.  Position p of the
@@ -185,8 +186,14 @@ struct CorrParams {
 constexpr int CORR_XCDS = 8;
 static __device__ __forceinline__ int corr_edge_of_block(const CorrParams &prm) {
   const int b = blockIdx.x;
-  const int pos = (b % CORR_XCDS) * prm.chunk + b / CORR_XCDS;
-  if (pos >= prm.E) return -1;
+  int E = prm.E, chunk = prm.chunk;
+  if (prm.dyn) {                                   // the live edge count lives in device memory
+    E = prm.dyn[RAMP_DYN_E];
+    chunk = (E + CORR_XCDS - 1) / CORR_XCDS;
+    if (b / CORR_XCDS >= chunk) return -1;
+  }
+  const int pos = (b % CORR_XCDS) * chunk + b / CORR_XCDS;
+  if (pos >= E) return -1;
   return prm.order ? prm.order[pos] : pos;
 }
 
@@ -740,10 +747,10 @@ int ramp_frame_gather(const void *fmap, const void *imap, const float *image, co
   return RAMP_OK;
 }
 
-int ramp_corr_fwd_ordered(const void *fmap1, const ramp_corr_level *levels, int nlevels,
-                          const float *coords, const int64_t *ii, const int64_t *jj,
-                          const int32_t *order, void *out, int out_row_elems, long mod_ii, long mod_jj, int E,
-                          int N1, int N2, int C, int P, int radius, int dtype, int layout, void *stream) {
+int ramp_i_corr_fwd(const void *fmap1, const ramp_corr_level *levels, int nlevels,
+                    const float *coords, const int64_t *ii, const int64_t *jj,
+                    const int32_t *order, void *out, int out_row_elems, long mod_ii, long mod_jj, int E,
+                    int N1, int N2, int C, int P, int radius, int dtype, int layout, const int32_t *dyn, void *stream) {
   if (E < 0 || nlevels < 1 || nlevels > CORR_MAXLEV || !levels) return RAMP_EINVAL;
   if (C != 128 || P != 3 || radius != 3) return RAMP_EUNSUPPORTED;
   if (E == 0) return RAMP_OK;
@@ -772,6 +779,7 @@ int ramp_corr_fwd_ordered(const void *fmap1, const ramp_corr_level *levels, int 
   prm.row_elems = out_row_elems > 0 ? out_row_elems : 49 * 9 * nlevels;
   if (prm.row_elems < 49 * 9 * nlevels || (nlevels == 2 && (prm.row_elems & 1))) return RAMP_EINVAL;   // half2 stores
   prm.chunk = (E + CORR_XCDS - 1) / CORR_XCDS;
+  prm.dyn = dyn;
   const dim3 grid(prm.chunk * CORR_XCDS);
   hipStream_t st = (hipStream_t)stream;
   const bool fast32 = (dtype & RAMP_CORR_MFMA32) != 0;
@@ -792,6 +800,14 @@ int ramp_corr_fwd_ordered(const void *fmap1, const ramp_corr_level *levels, int 
     return RAMP_EINVAL;
   RAMP_CHECK_LAUNCH();
   return RAMP_OK;
+}
+
+int ramp_corr_fwd_ordered(const void *fmap1, const ramp_corr_level *levels, int nlevels,
+                          const float *coords, const int64_t *ii, const int64_t *jj,
+                          const int32_t *order, void *out, int out_row_elems, long mod_ii, long mod_jj, int E,
+                          int N1, int N2, int C, int P, int radius, int dtype, int layout, void *stream) {
+  return ramp_i_corr_fwd(fmap1, levels, nlevels, coords, ii, jj, order, out, out_row_elems, mod_ii, mod_jj, E, N1, N2,
+                         C, P, radius, dtype, layout, nullptr, stream);
 }
 
 int ramp_corr_fwd(const void *fmap1, const ramp_corr_level *levels, int nlevels,

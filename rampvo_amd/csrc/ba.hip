@@ -34,8 +34,15 @@ __global__ void __launch_bounds__(256)
                    const float *__restrict__ intr, const float *__restrict__ target,
                    const float *__restrict__ weight, const int64_t *__restrict__ ii,
                    const int64_t *__restrict__ jj, const int64_t *__restrict__ kk,
-                   float *__restrict__ rec, int E, int PP, int c11, int t0, int N) {
+                   float *__restrict__ rec, int E, int PP, int c11, int t0, int N,
+                   const int32_t *__restrict__ dyn, int opt_window) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (dyn) {                                     // device-side sizes: E is the launch bound, the window ends at n
+    E = dyn[RAMP_DYN_E];
+    const int t1 = dyn[RAMP_DYN_N];
+    t0 = max(t1 - opt_window, 1);
+    N = min(N, t1 - t0);
+  }
   if (n >= E) return;
   const float fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];
   int ix = (int)ii[n], jx = (int)jj[n];
@@ -699,7 +706,13 @@ __global__ void __launch_bounds__(256)
                       const float *__restrict__ Erow, const float *__restrict__ Qv,
                       const float *__restrict__ uv, const float *__restrict__ dX,
                       const int64_t *__restrict__ kx, const int32_t *__restrict__ ngroups,
-                      int n6, int PP, int t0, int N, int depth_blocks) {
+                      int n6, int PP, int t0, int N, int depth_blocks, const int32_t *__restrict__ dyn,
+                      int opt_window) {
+  if (dyn) {
+    const int t1 = dyn[RAMP_DYN_N];
+    t0 = max(t1 - opt_window, 1);
+    N = min(N, t1 - t0);
+  }
   if ((int)blockIdx.x >= depth_blocks) {
     // pose retraction (ba_cuda.cu:178-206)
     const int i = (blockIdx.x - depth_blocks) * blockDim.x + threadIdx.x;
@@ -812,7 +825,7 @@ static int ba_iterate(float *poses, float *patches, const float *intrinsics, con
                       const int64_t *kk, int E, int P, int t0, int t1, int iterations, BaWs &w,
                       const int32_t *order_k, const int32_t *seg_k, const int32_t *nk, const int64_t *kx,
                       const int32_t *order_p, const int32_t *seg_p, const int32_t *np, int32_t *info,
-                      hipStream_t st) {
+                      hipStream_t st, const int32_t *dyn = nullptr, int opt_window = 0) {
   const int N = t1 - t0, n6 = 6 * N;
   const size_t lds = (size_t)((n6 + 1) * (n6 + 1) + 6 * n6) * sizeof(float);
   const int PP = P * P, c11 = 1 * P + 1;
@@ -829,7 +842,7 @@ static int ba_iterate(float *poses, float *patches, const float *intrinsics, con
   const int pose_blocks = N > 0 ? ramp_cdiv(N, 256) : 0;
   for (int itr = 0; itr < iterations; itr++) {
     hipLaunchKernelGGL(ba_edge_kernel, dim3(ramp_cdiv(E, 256)), dim3(256), 0, st, poses, patches,
-                       intrinsics, target, weight, ii, jj, kk, w.rec, E, PP, c11, t0, N);
+                       intrinsics, target, weight, ii, jj, kk, w.rec, E, PP, c11, t0, N, dyn, opt_window);
     if (N > 0)
       hipLaunchKernelGGL(ba_patch_pair_kernel, dim3(w.Mu_b + w.Gp_b), dim3(256), 0, st, w.Mu_b, w.rec, order_k,
                          seg_k, nk, lmbda, w.Erow, w.Cv, w.uv, w.Qv, n6, order_p, seg_p, np, w.pairs, w.pair_ij);
@@ -850,7 +863,7 @@ static int ba_iterate(float *poses, float *patches, const float *intrinsics, con
         hipLaunchKernelGGL(ba_chol_kernel, dim3(1), dim3(1024), lds, st, w.S, w.yv, w.dX, info, n6);
     }
     hipLaunchKernelGGL(ba_retract_kernel, dim3(depth_blocks + pose_blocks), dim3(256), 0, st,
-                       poses, patches, w.Erow, w.Qv, w.uv, w.dX, kx, nk, n6, PP, t0, N, depth_blocks);
+                       poses, patches, w.Erow, w.Qv, w.uv, w.dX, kx, nk, n6, PP, t0, N, depth_blocks, dyn, opt_window);
     RAMP_CHECK_LAUNCH();
   }
   return RAMP_OK;
@@ -862,6 +875,30 @@ static int ba_check_args(int E, int P, int n_poses, int n_patches, int t0, int t
   const int n6 = 6 * (t1 - t0);
   if ((size_t)((n6 + 1) * (n6 + 1) + 2 * n6) * sizeof(float) > 160 * 1024) return RAMP_EUNSUPPORTED;  // > 32 free poses
   return RAMP_OK;
+}
+
+// ---- device-side sizes (csrc/track.hip): the window [max(n - opt_window, 1), n) with n = dyn[RAMP_DYN_N] and the
+// factor count dyn[RAMP_DYN_E] are read by the kernels; E_cap bounds the launches, the system has opt_window poses.
+// Status bits accumulate in *info (not cleared here).
+size_t ramp_i_ba_dyn_ws(int E_cap, int n_poses, int n_patches, int opt_window, int max_patches, int max_pairs) {
+  BaWs w;
+  return ba_carve(nullptr, E_cap, n_poses, n_patches, opt_window, 0, max_patches, max_pairs, &w);
+}
+int ramp_i_ba_dyn(float *poses, float *patches, const float *intrinsics, const float *target, const float *weight,
+                  const float *lmbda, const int64_t *ii, const int64_t *jj, const int64_t *kk, int E_cap, int P,
+                  int n_poses, int n_patches, int opt_window, int iterations, const int32_t *order_k,
+                  const int32_t *seg_k, const int32_t *ngroups_k, const int64_t *ukeys_k, int max_patches,
+                  const int32_t *order_p, const int32_t *seg_p, const int32_t *ngroups_p, int max_pairs, void *ws,
+                  size_t ws_bytes, int32_t *info, const int32_t *dyn, hipStream_t st) {
+  if (E_cap <= 0 || opt_window <= 0 || !dyn || !ws) return RAMP_EINVAL;
+  int rc = ba_check_args(E_cap, P, n_poses, n_patches, 1, 1 + opt_window, iterations);
+  if (rc != RAMP_OK) return rc;
+  BaWs w;
+  if (ba_carve(ws, E_cap, n_poses, n_patches, opt_window, 0, max_patches, max_pairs, &w) > ws_bytes)
+    return RAMP_EWORKSPACE;
+  return ba_iterate(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, E_cap, P, 1, 1 + opt_window,
+                    iterations, w, order_k, seg_k, ngroups_k, ukeys_k, order_p, seg_p, ngroups_p, info, st, dyn,
+                    opt_window);
 }
 
 extern "C" {

@@ -330,6 +330,197 @@ __global__ void __launch_bounds__(64)
   }
 }
 
+// ------------------------------------------------- both groupings of the tracker's graph, device-side sizes
+// The same counting group-by for the two keys the update operator and BA share (kk; (jj, ii) lexicographic), in ONE
+// set of launches (blockIdx.y = grouping) and with the edge count / key offsets read from the tracker's device-side
+// size block (RAMP_DYN_*): nothing here waits for the host to learn the outcome of the keyframe test.
+//   grouping 0: key = kk - KLO,                     K = N * M - KLO
+//   grouping 1: key = (jj - FLO) * W + (ii - FLO),  K = W * W          (ukeys = jj * W + ii, like the host path)
+#define PLAN_LDS_K 12288
+struct PlanDyn {
+  const int64_t *ii, *jj, *kk;
+  const int32_t *dyn;
+  int M;
+  int32_t *hist[2], *gidmap[2], *tmp[2];
+  int32_t *order[2], *gid[2], *seg[2], *ngroups[2];
+  int64_t *ukeys[2];
+  int Kcap[2];
+};
+__device__ __forceinline__ long plan_key(const PlanDyn &p, int g, int e, int &K, long &sub) {
+  if (g == 0) {
+    sub = p.dyn[RAMP_DYN_KLO];
+    K = p.dyn[RAMP_DYN_N] * p.M - (int)sub;
+    return p.kk[e] - sub;
+  }
+  const long flo = p.dyn[RAMP_DYN_FLO], W = p.dyn[RAMP_DYN_W];
+  sub = flo * W + flo;
+  K = (int)(W * W);
+  return p.jj[e] * W + p.ii[e] - sub;
+}
+__device__ __forceinline__ void plan_K(const PlanDyn &p, int g, int &K, long &sub) {
+  if (g == 0) {
+    sub = p.dyn[RAMP_DYN_KLO];
+    K = p.dyn[RAMP_DYN_N] * p.M - (int)sub;
+  } else {
+    const long flo = p.dyn[RAMP_DYN_FLO], W = p.dyn[RAMP_DYN_W];
+    sub = flo * W + flo;
+    K = (int)(W * W);
+  }
+  if (K > p.Kcap[g] || K < 0) K = 0;     // flagged by plan_hist_kernel; nothing is written out of bounds
+}
+template <bool LDS>
+__global__ void __launch_bounds__(256) plan_hist_kernel(const PlanDyn p, int32_t *__restrict__ status) {
+  __shared__ int s_bin[LDS ? PLAN_LDS_K : 1];
+  const int g = blockIdx.y, E = p.dyn[RAMP_DYN_E];
+  if ((int)blockIdx.x * 256 >= E) return;
+  int K; long sub;
+  plan_K(p, g, K, sub);
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  long k = -1;
+  if (e < E) {
+    int K2; long s2;
+    k = plan_key(p, g, e, K2, s2);
+    if (k < 0 || k >= K) { atomicOr(status, 8); k = -1; }
+  }
+  int32_t *hist = p.hist[g];
+  if (!LDS) {
+    if (k >= 0) atomicAdd(&hist[k], 1);
+    return;
+  }
+  for (int q = threadIdx.x; q < K; q += 256) s_bin[q] = 0;
+  __syncthreads();
+  if (k >= 0) atomicAdd(&s_bin[k], 1);
+  __syncthreads();
+  for (int q = threadIdx.x; q < K; q += 256) {
+    const int c = s_bin[q];
+    if (c) atomicAdd(&hist[q], c);
+  }
+}
+__global__ void __launch_bounds__(1024) plan_scan_kernel(const PlanDyn p) {
+  __shared__ int s_cnt[1024], s_grp[1024];
+  const int g = blockIdx.x, tid = threadIdx.x, E = p.dyn[RAMP_DYN_E];
+  int K; long sub;
+  plan_K(p, g, K, sub);
+  int32_t *hist = p.hist[g], *gidmap = p.gidmap[g], *seg_start = p.seg[g];
+  int64_t *ukeys = p.ukeys[g];
+  const int per = (K + 1023) / 1024;
+  const int k0 = tid * per, k1 = min(K, k0 + per);
+  int c = 0, n = 0;
+  for (int k = k0; k < k1; k++) { const int h = hist[k]; c += h; n += (h > 0); }
+  s_cnt[tid] = c; s_grp[tid] = n;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    int vc = 0, vg = 0;
+    if (tid >= off) { vc = s_cnt[tid - off]; vg = s_grp[tid - off]; }
+    __syncthreads();
+    s_cnt[tid] += vc; s_grp[tid] += vg;
+    __syncthreads();
+  }
+  int oc = s_cnt[tid] - c, og = s_grp[tid] - n;
+  for (int k = k0; k < k1; k++) {
+    const int h = hist[k];
+    hist[k] = oc;
+    if (h > 0) {
+      gidmap[k] = og;
+      seg_start[og] = oc;
+      if (ukeys) ukeys[og] = (int64_t)k + sub;
+      og++;
+    } else {
+      gidmap[k] = -1;
+    }
+    oc += h;
+  }
+  if (tid == 1023) { *p.ngroups[g] = s_grp[1023]; seg_start[s_grp[1023]] = E; }
+}
+template <bool LDS>
+__global__ void __launch_bounds__(256) plan_scatter_kernel(const PlanDyn p) {
+  __shared__ int s_bin[LDS ? PLAN_LDS_K : 1];
+  const int g = blockIdx.y, E = p.dyn[RAMP_DYN_E];
+  if ((int)blockIdx.x * 256 >= E) return;
+  int K; long sub;
+  plan_K(p, g, K, sub);
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  long k = -1;
+  if (e < E) {
+    int K2; long s2;
+    k = plan_key(p, g, e, K2, s2);
+    if (k < 0 || k >= K) k = -1;
+  }
+  int32_t *cursor = p.hist[g], *tmp_order = p.tmp[g], *gid = p.gid[g];
+  const int32_t *gidmap = p.gidmap[g];
+  if (!LDS) {
+    if (k < 0) return;
+    const int pos = atomicAdd(&cursor[k], 1);
+    tmp_order[pos] = e;
+    gid[e] = gidmap[k];
+    return;
+  }
+  for (int q = threadIdx.x; q < K; q += 256) s_bin[q] = 0;
+  __syncthreads();
+  int r = 0;
+  if (k >= 0) r = atomicAdd(&s_bin[k], 1);
+  __syncthreads();
+  for (int q = threadIdx.x; q < K; q += 256) {
+    const int c = s_bin[q];
+    if (c) s_bin[q] = atomicAdd(&cursor[q], c);
+  }
+  __syncthreads();
+  if (k >= 0) {
+    tmp_order[s_bin[k] + r] = e;
+    gid[e] = gidmap[k];
+  }
+}
+__global__ void __launch_bounds__(64) plan_segsort_kernel(const PlanDyn p) {
+  const int g = blockIdx.y, grp = blockIdx.x;
+  if (grp >= *p.ngroups[g]) return;
+  const int32_t *tmp_order = p.tmp[g], *seg_start = p.seg[g];
+  int32_t *order = p.order[g];
+  const int s0 = seg_start[grp], n = seg_start[grp + 1] - s0;
+  for (int q = threadIdx.x; q < n; q += 64) {
+    const int v = tmp_order[s0 + q];
+    int r = 0;
+    for (int u = 0; u < n; u++) r += (tmp_order[s0 + u] < v);
+    order[s0 + r] = v;
+  }
+}
+
+size_t ramp_i_plan_dyn_ws(int E_cap, int kkey_cap, int pkey_cap) {
+  const size_t e = (size_t)(E_cap > 0 ? E_cap : 1);
+  return align_up((size_t)(kkey_cap + pkey_cap + 4) * 4, 256) * 2 + 2 * align_up(e * 4, 256) + 256;
+}
+
+// the graph plan (two groupings + temporal neighbours) of the factor list g4 = [4][E_cap] int64 (ii, jj, kk, row)
+int ramp_i_plan_dyn(const int64_t *g4, int E_cap, const int32_t *dyn, int32_t *status, int M, int kkey_cap,
+                    int pkey_cap, int kk_cap, int ij_cap, int32_t *kk_order, int32_t *kk_gid, int32_t *kk_seg,
+                    int32_t *kk_ngroups, int64_t *kk_ukeys, int32_t *ij_order, int32_t *ij_gid, int32_t *ij_seg,
+                    int32_t *ij_ngroups, int64_t *ij_ukeys, int64_t *ix, int64_t *jx, void *ws, size_t ws_bytes,
+                    hipStream_t st) {
+  if (!g4 || !dyn || !status || !ws || E_cap <= 0 || kkey_cap <= 0 || pkey_cap <= 0) return RAMP_EINVAL;
+  if (ws_bytes < ramp_i_plan_dyn_ws(E_cap, kkey_cap, pkey_cap)) return RAMP_EWORKSPACE;
+  PlanDyn p;
+  p.ii = g4; p.jj = g4 + E_cap; p.kk = g4 + 2 * (size_t)E_cap; p.dyn = dyn; p.M = M;
+  char *base = (char *)ws;
+  const size_t hb = align_up((size_t)(kkey_cap + pkey_cap + 4) * 4, 256);
+  p.hist[0] = (int32_t *)base; p.hist[1] = p.hist[0] + kkey_cap + 2;
+  p.gidmap[0] = (int32_t *)(base + hb); p.gidmap[1] = p.gidmap[0] + kkey_cap + 2;
+  p.tmp[0] = (int32_t *)(base + 2 * hb); p.tmp[1] = (int32_t *)(base + 2 * hb + align_up((size_t)E_cap * 4, 256));
+  p.order[0] = kk_order; p.gid[0] = kk_gid; p.seg[0] = kk_seg; p.ngroups[0] = kk_ngroups; p.ukeys[0] = kk_ukeys;
+  p.order[1] = ij_order; p.gid[1] = ij_gid; p.seg[1] = ij_seg; p.ngroups[1] = ij_ngroups; p.ukeys[1] = ij_ukeys;
+  p.Kcap[0] = kkey_cap; p.Kcap[1] = pkey_cap;
+  (void)hipMemsetAsync(p.hist[0], 0, (size_t)(kkey_cap + pkey_cap + 4) * 4, st);
+  const int nb = ramp_cdiv(E_cap, 256);
+  const bool lds = kkey_cap <= PLAN_LDS_K && pkey_cap <= PLAN_LDS_K;
+  if (lds) hipLaunchKernelGGL(plan_hist_kernel<true>, dim3(nb, 2), dim3(256), 0, st, p, status);
+  else hipLaunchKernelGGL(plan_hist_kernel<false>, dim3(nb, 2), dim3(256), 0, st, p, status);
+  hipLaunchKernelGGL(plan_scan_kernel, dim3(2), dim3(1024), 0, st, p);
+  if (lds) hipLaunchKernelGGL(plan_scatter_kernel<true>, dim3(nb, 2), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL(plan_scatter_kernel<false>, dim3(nb, 2), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(plan_segsort_kernel, dim3(kk_cap > ij_cap ? kk_cap : ij_cap, 2), dim3(64), 0, st, p);
+  hipLaunchKernelGGL(nb_from_groups_kernel, dim3(kk_cap), dim3(64), 0, st, kk_order, kk_seg, kk_ngroups, p.jj, ix, jx);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+
 extern "C" {
 
 size_t ramp_group_by_small_workspace_bytes(int E, int K) {

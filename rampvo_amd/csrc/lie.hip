@@ -121,8 +121,9 @@ __global__ void __launch_bounds__(LIE_THREADS)
     transform_kernel(const float *__restrict__ poses, const float *__restrict__ patches,
                      const float *__restrict__ intr, const int64_t *__restrict__ ii,
                      const int64_t *__restrict__ jj, const int64_t *__restrict__ kk,
-                     float *__restrict__ out, int E, int tonly) {
+                     float *__restrict__ out, int E, int tonly, const int32_t *__restrict__ dyn) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (dyn) E = dyn[RAMP_DYN_E];                 // device-side size: the argument is the launch bound
   if (e >= E) return;
   const long i = ii[e], j = jj[e], k = kk[e];
   float Ti[7], Tj[7], Tinv[7], G[7];
@@ -186,8 +187,9 @@ template <int P>
 __global__ void __launch_bounds__(LIE_THREADS)
     point_cloud_kernel(const float *__restrict__ poses, const float *__restrict__ patches,
                        const float *__restrict__ intr, const int64_t *__restrict__ ix,
-                       float *__restrict__ out, int m) {
+                       float *__restrict__ out, int m, const int32_t *__restrict__ dyn, int M) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (dyn) m = min(m, dyn[RAMP_DYN_N] * M);     // device-side size: the argument is the launch bound
   if (n >= m) return;
   const long f = ix[n];
   float T[7], Tinv[7], t[3], q[4];
@@ -234,9 +236,16 @@ __global__ void __launch_bounds__(256)
                      const int64_t *__restrict__ jj, const int64_t *__restrict__ kk,
                      const int32_t *__restrict__ order, const int32_t *__restrict__ seg,
                      const int64_t *__restrict__ ukeys, const int32_t *__restrict__ ngroups,
-                     long key0, long key1, float beta, float *__restrict__ out) {
+                     long key0, long key1, float beta, float *__restrict__ out, const int32_t *__restrict__ dyn,
+                     int keyframe_index) {
   __shared__ float s_part[256];
   __shared__ int s_seg[2];
+  if (dyn) {                                    // Ramp_vo.keyframe(): i = n - KEYFRAME_INDEX - 1, j = i + 2; keys are jj * W + ii
+    const long n = dyn[RAMP_DYN_N], W = dyn[RAMP_DYN_W];
+    const long i = n - keyframe_index - 1, j = n - keyframe_index + 1;
+    key0 = j * W + i;
+    key1 = i * W + j;
+  }
   const long key = blockIdx.x == 0 ? key0 : key1;
   if (threadIdx.x == 0) {
     int lo = 0, hi = *ngroups - 1, g = -1;
@@ -374,6 +383,32 @@ __global__ void __launch_bounds__(256) shift_rows_kernel(const ShiftDesc d, int 
   }
 }
 
+// ---- launchers with device-side sizes (csrc/track.hip): E / m are launch bounds, the live counts come from dyn
+int ramp_i_transform_dyn(const float *poses, const float *patches, const float *intrinsics, const int64_t *ii,
+                         const int64_t *jj, const int64_t *kk, float *out, int E_cap, const int32_t *dyn,
+                         hipStream_t st) {
+  hipLaunchKernelGGL(transform_kernel<3>, dim3(ramp_cdiv(E_cap, LIE_THREADS)), dim3(LIE_THREADS), 0, st, poses, patches,
+                     intrinsics, ii, jj, kk, out, E_cap, 0, dyn);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+int ramp_i_point_cloud_dyn(const float *poses, const float *patches, const float *intrinsics, const int64_t *ix,
+                           float *out, int m_cap, const int32_t *dyn, int M, hipStream_t st) {
+  hipLaunchKernelGGL(point_cloud_kernel<3>, dim3(ramp_cdiv(m_cap, LIE_THREADS)), dim3(LIE_THREADS), 0, st, poses,
+                     patches, intrinsics, ix, out, m_cap, dyn, M);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+int ramp_i_motionmag_dyn(const float *poses, const float *patches, const float *intrinsics, const int64_t *ii,
+                         const int64_t *jj, const int64_t *kk, const int32_t *order, const int32_t *seg,
+                         const int64_t *ukeys, const int32_t *ngroups, float beta, float *out2, const int32_t *dyn,
+                         int keyframe_index, hipStream_t st) {
+  hipLaunchKernelGGL(motionmag_kernel<3>, dim3(2), dim3(256), 0, st, poses, patches, intrinsics, ii, jj, kk, order, seg,
+                     ukeys, ngroups, 0L, 0L, beta, out2, dyn, keyframe_index);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+
 extern "C" {
 int ramp_multi_copy(const void *const *src_host, void *const *dst_host, const long *bytes_host, int n,
                     void *stream) {
@@ -421,7 +456,7 @@ int ramp_motionmag(const float *poses, const float *patches, const float *intrin
   if (P != 3) return RAMP_EUNSUPPORTED;
   hipLaunchKernelGGL(motionmag_kernel<3>, dim3(2), dim3(256), 0, (hipStream_t)stream, poses, patches,
                      intrinsics, ii, jj, kk, order, seg, ukeys, ngroups, (long)key_ij, (long)key_ji, beta,
-                     out2);
+                     out2, (const int32_t *)nullptr, 0);
   RAMP_CHECK_LAUNCH();
   return RAMP_OK;
 }
@@ -448,7 +483,7 @@ int ramp_transform(const float *poses, const float *patches, const float *intrin
   if (!poses || !patches || !intrinsics || !ii || !jj || !kk || !out) return RAMP_EINVAL;
   if (P != 3) return RAMP_EUNSUPPORTED;
   hipLaunchKernelGGL(transform_kernel<3>, dim3(ramp_cdiv(E, LIE_THREADS)), dim3(LIE_THREADS), 0,
-                     (hipStream_t)stream, poses, patches, intrinsics, ii, jj, kk, out, E, tonly);
+                     (hipStream_t)stream, poses, patches, intrinsics, ii, jj, kk, out, E, tonly, (const int32_t *)nullptr);
   RAMP_CHECK_LAUNCH();
   return RAMP_OK;
 }
@@ -471,7 +506,7 @@ int ramp_point_cloud(const float *poses, const float *patches, const float *intr
   if (!poses || !patches || !intrinsics || !ix || !out) return RAMP_EINVAL;
   if (P != 3) return RAMP_EUNSUPPORTED;
   hipLaunchKernelGGL(point_cloud_kernel<3>, dim3(ramp_cdiv(m, LIE_THREADS)), dim3(LIE_THREADS), 0,
-                     (hipStream_t)stream, poses, patches, intrinsics, ix, out, m);
+                     (hipStream_t)stream, poses, patches, intrinsics, ix, out, m, (const int32_t *)nullptr, 0);
   RAMP_CHECK_LAUNCH();
   return RAMP_OK;
 }

@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(TOPK_THREADS)
 // i.e. the lower median of the F*M*PP inverse depths of the last F frames, broadcast into the depth plane
 // of the M new patches.  One workgroup: keys in registers, 4 x 8-bit radix passes (k-th smallest), fill.
 #define MED_THREADS 1024
-#define MED_PER 4               // up to 4096 values
+#define MED_PER 8               // up to 8192 values (3 frames x 256 patches x 9 pixels = 6912)
 // lower median of the F*M*PP depth values of src ([F*M][3][PP] rows, channel 2); every thread of the 1024 returns it
 __device__ __forceinline__ float depth_median_block(const float *__restrict__ src, int F, int M, int PP) {
   __shared__ unsigned hist[256];
@@ -294,24 +294,41 @@ struct FrameCommit {
   const float *median_src; int F, M, PP; float *patches_new; float *patches_row;
   int n_copy; const char *src[FC_MAXBUF]; char *dst[FC_MAXBUF]; long bytes[FC_MAXBUF];
   const float *median_val;   // optional: the median of median_src, computed ahead (ramp_depth_median)
+  // device-side row (csrc/track.hip): n = dyn[RAMP_DYN_NROW]; dst[b] is then the BASE of buffer b and the row is
+  // n % mod[b] (ring buffers) or n (mod[b] == 0); median_src / patches_row are the base of the patch buffer; k_new
+  // (optional) replaces the copy of the previous intrinsics row
+  const int32_t *dyn; int mod[FC_MAXBUF]; const float *k_new;
 };
 __global__ void __launch_bounds__(MED_THREADS) frame_commit_kernel(const FrameCommit a) {
   const int t = threadIdx.x;
+  int n = a.n;
+  int64_t index_val = a.index_val;
+  const float *median_src = a.median_src;
+  float *patches_row = a.patches_row;
+  if (a.dyn) {
+    n = a.dyn[RAMP_DYN_NROW];
+    const size_t row = (size_t)a.M * 3 * a.PP;
+    index_val = (int64_t)(n + 1) * a.M;
+    median_src += (size_t)(n - a.F) * row;
+    patches_row += (size_t)n * row;
+  }
   if (blockIdx.y > 0) {
     const int b = blockIdx.y - 1;
     if (b >= a.n_copy) return;
     const long n16 = a.bytes[b] / 16;                       // 16-byte multiples, 16-byte aligned (checked on the host)
     const uint4 *s = reinterpret_cast<const uint4 *>(a.src[b]);
-    uint4 *o = reinterpret_cast<uint4 *>(a.dst[b]);
+    char *d = a.dst[b];
+    if (a.dyn) d += (size_t)(a.mod[b] ? n % a.mod[b] : n) * a.bytes[b];
+    uint4 *o = reinterpret_cast<uint4 *>(d);
     for (long i = (long)blockIdx.x * blockDim.x + t; i < n16; i += (long)gridDim.x * blockDim.x) o[i] = s[i];
     return;
   }
   if (blockIdx.x != 0) return;
-  const int n = a.n;
   if (t == 0) {
     if (a.tstamps) a.tstamps[n] = a.counter;
-    if (a.index_map) a.index_map[n + 1] = a.index_val;
+    if (a.index_map) a.index_map[n + 1] = index_val;
   }
+  if (a.k_new && t < 4) a.intrinsics[4 * n + t] = a.k_new[t];
   if (a.copy_k && t < 4) a.intrinsics[4 * n + t] = a.intrinsics[4 * (n - 1) + t];
   if (a.motion == 2 && t < 7) a.poses[7 * n + t] = a.poses[7 * (n - 1) + t];
   if (a.motion == 1 && t == 0) {
@@ -326,15 +343,47 @@ __global__ void __launch_bounds__(MED_THREADS) frame_commit_kernel(const FrameCo
     for (int c = 0; c < 7; c++) a.poses[7 * n + c] = Pn[c];
   }
   const bool fill = a.F > 0;
-  const float med = !fill ? 0.f : (a.median_val ? *a.median_val : depth_median_block(a.median_src, a.F, a.M, a.PP));
+  const float med = !fill ? 0.f : (a.median_val ? *a.median_val : depth_median_block(median_src, a.F, a.M, a.PP));
   for (int i = t; i < a.M * 3 * a.PP; i += MED_THREADS) {
     const int ch = (i / a.PP) % 3;
     float v = a.patches_new[i];
     if (fill && ch == 2) { v = med; a.patches_new[i] = med; }
-    a.patches_row[i] = v;
+    patches_row[i] = v;
   }
 }
 
+
+// ---- the same launch with the row taken from device memory (csrc/track.hip): bases[b] + row * bytes[b], row =
+// dyn[RAMP_DYN_NROW] % mod[b] (mod[b] > 0: ring buffer) -- the host does not know the row before the previous frame's
+// keyframe test has run
+int ramp_i_frame_commit_dyn(float *poses, int motion, float damping, int64_t *tstamps, int64_t counter,
+                            int64_t *index_map, float *intrinsics, const float *k_new, float *patches_state,
+                            int median_frames, int M, int P, float *patches_new, int n_copy, const void *const *src,
+                            void *const *base, const long *bytes, const int *mod, const int32_t *dyn, hipStream_t st) {
+  if (!poses || !patches_state || !patches_new || !dyn || M <= 0 || P <= 0 || n_copy < 0 || n_copy > FC_MAXBUF)
+    return RAMP_EINVAL;
+  if ((long)median_frames * M * P * P > MED_THREADS * MED_PER) return RAMP_EUNSUPPORTED;
+  FrameCommit a;
+  a.poses = poses; a.n = 0; a.motion = motion; a.damping = damping; a.tstamps = tstamps; a.counter = counter;
+  a.index_map = index_map; a.index_val = 0; a.intrinsics = intrinsics; a.copy_k = k_new ? 0 : 1;
+  a.median_src = patches_state; a.F = median_frames; a.M = M; a.PP = P * P;
+  a.patches_new = patches_new; a.patches_row = patches_state;
+  a.median_val = nullptr; a.dyn = dyn; a.k_new = k_new;
+  a.n_copy = n_copy;
+  long mx = 0;
+  for (int i = 0; i < FC_MAXBUF; i++) a.mod[i] = 0;
+  for (int i = 0; i < n_copy; i++) {
+    if (!src[i] || !base[i] || bytes[i] <= 0 || (bytes[i] & 15) || (((uintptr_t)src[i] | (uintptr_t)base[i]) & 15))
+      return RAMP_EINVAL;
+    a.src[i] = (const char *)src[i]; a.dst[i] = (char *)base[i]; a.bytes[i] = bytes[i]; a.mod[i] = mod[i];
+    if (bytes[i] > mx) mx = bytes[i];
+  }
+  int bx = (int)((mx / 16 + MED_THREADS - 1) / MED_THREADS);
+  bx = bx < 1 ? 1 : (bx > 256 ? 256 : bx);
+  hipLaunchKernelGGL(frame_commit_kernel, dim3(bx, 1 + n_copy), dim3(MED_THREADS), 0, st, a);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
 
 extern "C" {
 
@@ -398,6 +447,8 @@ int ramp_frame_commit(float *poses, int n, int motion, float damping, int64_t *t
   a.median_src = patches_state + (size_t)(n - median_frames) * row; a.F = median_frames; a.M = M; a.PP = P * P;
   a.patches_new = patches_new; a.patches_row = patches_state + (size_t)n * row;
   a.median_val = median_dev;
+  a.dyn = nullptr; a.k_new = nullptr;
+  for (int i = 0; i < FC_MAXBUF; i++) a.mod[i] = 0;
   a.n_copy = n_copy;
   long mx = 0;
   for (int i = 0; i < n_copy; i++) {

@@ -1,0 +1,378 @@
+// The device-resident tracking step: Ramp_vo.__call__ in steady state as one host call (include/ramp_hip.h,
+// "device-resident tracking step").
+//
+// The reference takes the keyframe decision on the host (ramp/Ramp_vo.py:237-246: two `.item()` reads), so every frame
+// waits for the GPU to drain and the GPU then waits for the host to edit the factor graph.  Here
+//   * trk_flag / trk_decide / trk_apply take the decision and edit the graph on the device: keep mask -> per-workgroup
+//     counts -> scan -> stable compaction into the other half of the double-buffered factor list, the next frame's new
+//     factors appended in closed form (Ramp_vo.py:312-325), the keyframe's rows shifted out of the per-frame buffers
+//     by the same launch, the (t0, dP) pair the trajectory interpolation needs (:250-253) appended to a log;
+//   * every size that depends on a decision -- the row a frame is stored to, the factor count, BA's window -- lives in
+//     the int32 block `dyn` and is read by the kernels (their grids are capacity bounds);
+//   * ramp_track_step enqueues the whole frame (frame stores, reprojection, correlation, update operator, two BA
+//     iterations, point cloud, motion test, graph edit, the next graph's plan) without reading anything back.
+#include "ramp_device.h"
+#include "ramp_internal.h"
+
+#define TRK_EB 1024        // factors per workgroup of the edit kernels (256 threads x 4 passes)
+#define TRK_MAXBUF 10
+
+struct TrkEdit {
+  int32_t *dyn;
+  const float *mm;
+  const int64_t *gin;      // [4][E_cap]
+  int64_t *gout;
+  int E_cap, M, r, removal_window, keyframe_index, log_cap;
+  double thresh;
+  int32_t *cnt, *off, *fmin;   // per edit workgroup: kept factors, their exclusive prefix, lowest frame index kept
+  const int64_t *tstamps;
+  const float *poses;
+  float *dlog;
+  int64_t counter;
+  int nb;                  // edit workgroups = ceil(E_cap / TRK_EB)
+  // row shift of a dropped keyframe (ramp/Ramp_vo.py:259-271)
+  char *base[TRK_MAXBUF];
+  long row_bytes[TRK_MAXBUF];
+  int mod[TRK_MAXBUF];
+  int nbuf;
+};
+
+// Ramp_vo.keyframe(): m = motionmag(i, j) + motionmag(j, i);  m / 2 < KEYFRAME_THRESH  (python floats: doubles)
+__device__ __forceinline__ bool trk_remove(const float *mm, double thresh) {
+  const double m = (double)mm[0] + (double)mm[1];
+  return m / 2 < thresh;
+}
+// one factor through keyframe()'s edit (Ramp_vo.py:255-274): dropped if it touches keyframe k, renumbered if it lies
+// behind it, dropped if its source frame left the removal window.  Same arithmetic as ramp_graph_edit_host.
+__device__ __forceinline__ bool trk_edge(bool remove, long k, long kcut, int M, long &i, long &j, long &q) {
+  const bool hit = remove && (i == k || j == k);
+  const long gi = (remove && i > k) ? 1 : 0, gj = (remove && j > k) ? 1 : 0;
+  i -= gi; q -= gi * M; j -= gj;
+  return !hit && q >= kcut;
+}
+struct TrkDecision { bool remove; long k, kcut; int n, n_after; };
+__device__ __forceinline__ TrkDecision trk_decision(const int32_t *dyn, const float *mm, double thresh, int ki,
+                                                    int removal_window, int M, bool after_decide) {
+  TrkDecision d;
+  if (after_decide) {              // trk_decide has already rewritten dyn
+    d.n = dyn[RAMP_DYN_NPREV];
+    d.remove = dyn[RAMP_DYN_REMOVED] != 0;
+  } else {
+    d.n = dyn[RAMP_DYN_N];
+    d.remove = trk_remove(mm, thresh);
+  }
+  d.k = d.n - ki;
+  d.n_after = d.remove ? d.n - 1 : d.n;
+  const long oldest = (long)d.n_after - removal_window;
+  d.kcut = oldest > 0 ? oldest * M : 0;
+  return d;
+}
+
+__global__ void __launch_bounds__(256) trk_flag_kernel(const TrkEdit p) {
+  __shared__ int s_cnt[4], s_min[4];
+  const int E = p.dyn[RAMP_DYN_E];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (b * TRK_EB >= E) return;
+  const TrkDecision d = trk_decision(p.dyn, p.mm, p.thresh, p.keyframe_index, p.removal_window, p.M, false);
+  int cnt = 0, fmin = 0x7fffffff;
+#pragma unroll
+  for (int pass = 0; pass < TRK_EB / 256; pass++) {
+    const int e = b * TRK_EB + pass * 256 + tid;
+    bool keep = false;
+    if (e < E) {
+      long i = p.gin[e], j = p.gin[(size_t)p.E_cap + e], q = p.gin[2 * (size_t)p.E_cap + e];
+      keep = trk_edge(d.remove, d.k, d.kcut, p.M, i, j, q);
+      if (keep) fmin = min(fmin, (int)min(i, j));
+    }
+    cnt += __popcll(__ballot(keep));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) fmin = min(fmin, __shfl_xor(fmin, o, 64));
+  if (lane == 0) { s_cnt[wave] = cnt; s_min[wave] = fmin; }
+  __syncthreads();
+  if (tid == 0) {
+    p.cnt[b] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    p.fmin[b] = min(min(s_min[0], s_min[1]), min(s_min[2], s_min[3]));
+  }
+}
+
+__global__ void __launch_bounds__(256) trk_decide_kernel(const TrkEdit p) {
+  __shared__ int s_sum[256], s_min[256];
+  const int tid = threadIdx.x;
+  const int E = p.dyn[RAMP_DYN_E];
+  const int nbl = (E + TRK_EB - 1) / TRK_EB;
+  const int per = (nbl + 255) / 256;
+  const int b0 = tid * per, b1 = min(nbl, b0 + per);
+  int c = 0, fm = 0x7fffffff;
+  for (int b = b0; b < b1; b++) { c += p.cnt[b]; fm = min(fm, p.fmin[b]); }
+  s_sum[tid] = c; s_min[tid] = fm;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    int v = 0;
+    if (tid >= o) v = s_sum[tid - o];
+    __syncthreads();
+    s_sum[tid] += v;
+    __syncthreads();
+  }
+  int run = s_sum[tid] - c;
+  for (int b = b0; b < b1; b++) { const int h = p.cnt[b]; p.off[b] = run; run += h; }
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) s_min[tid] = min(s_min[tid], s_min[tid + o]);
+    __syncthreads();
+  }
+  if (tid != 0) return;
+  const int Ek = s_sum[255];
+  const TrkDecision d = trk_decision(p.dyn, p.mm, p.thresh, p.keyframe_index, p.removal_window, p.M, false);
+  int status = 0;
+  if (d.remove) {
+    // Ramp_vo.py:249-253: delta[t1] = (t0, poses[k] * poses[k-1]^-1), read back by terminate()
+    const int idx = p.dyn[RAMP_DYN_NLOG];
+    if (idx < p.log_cap) {
+      float Pk[7], Pm[7], Pi[7], dP[7];
+      for (int q = 0; q < 7; q++) { Pk[q] = p.poses[7 * d.k + q]; Pm[q] = p.poses[7 * (d.k - 1) + q]; }
+      lt_inv(Pm, Pi);
+      lt_mul(Pk, Pi, dP);
+      float *o = p.dlog + (size_t)idx * RAMP_TRACK_LOG;
+      o[0] = __int_as_float((int)p.tstamps[d.k]);
+      o[1] = __int_as_float((int)p.tstamps[d.k - 1]);
+      for (int q = 0; q < 7; q++) o[2 + q] = dP[q];
+      p.dyn[RAMP_DYN_NLOG] = idx + 1;
+    } else {
+      status |= 16;
+    }
+  }
+  // the next frame's factors (Ramp_vo.py:312-325 with n = n_after + 1)
+  const int n1 = d.n_after + 1;
+  const int lo = max(n1 - p.r, 0);
+  const int nf = p.M * (max(n1 - 1, 0) - lo), nbk = p.M * (n1 - lo);
+  int ne = nf + nbk;
+  if (Ek + ne > p.E_cap) { status |= 4; ne = max(p.E_cap - Ek, 0); }
+  const int flo = min(s_min[0], lo);
+  p.dyn[RAMP_DYN_NPREV] = d.n;
+  p.dyn[RAMP_DYN_EPREV] = E;
+  p.dyn[RAMP_DYN_EKEPT] = Ek;
+  p.dyn[RAMP_DYN_REMOVED] = d.remove ? 1 : 0;
+  p.dyn[RAMP_DYN_K] = (int)d.k;
+  p.dyn[RAMP_DYN_NROW] = d.n_after;
+  p.dyn[RAMP_DYN_N] = n1;
+  p.dyn[RAMP_DYN_E] = Ek + ne;
+  p.dyn[RAMP_DYN_KLO] = (int)min(d.kcut, (long)p.M * lo);
+  p.dyn[RAMP_DYN_FLO] = flo;
+  p.dyn[RAMP_DYN_W] = n1 - flo;
+  p.dyn[RAMP_DYN_FRAME] = (int)p.counter;
+  if (status) p.dyn[RAMP_DYN_STATUS] |= status;
+}
+
+// grid (nb + new-factor workgroups, 1 + nbuf).  y = 0: x < nb compacts the kept factors of edit workgroup x (stable),
+// the rest appends the next frame's factors; y > 0: row shift of buffer y - 1 if the keyframe was dropped.
+__global__ void __launch_bounds__(256) trk_apply_kernel(const TrkEdit p) {
+  const int tid = threadIdx.x;
+  if (blockIdx.y > 0) {
+    if (!p.dyn[RAMP_DYN_REMOVED]) return;
+    const int b = blockIdx.y - 1, k = p.dyn[RAMP_DYN_K], nrows = p.dyn[RAMP_DYN_NPREV];
+    const long n4 = p.row_bytes[b] / 4;
+    // each thread owns columns c, c + stride, ... and walks the rows itself, ascending: no cross-thread hazard
+    for (long col = (long)blockIdx.x * 256 + tid; col < n4; col += (long)gridDim.x * 256) {
+      for (int r = k; r < nrows - 1; r++) {
+        const int sd = p.mod[b] ? r % p.mod[b] : r, ss = p.mod[b] ? (r + 1) % p.mod[b] : r + 1;
+        reinterpret_cast<uint32_t *>(p.base[b] + (size_t)sd * p.row_bytes[b])[col] =
+            reinterpret_cast<const uint32_t *>(p.base[b] + (size_t)ss * p.row_bytes[b])[col];
+      }
+    }
+    return;
+  }
+  int64_t *oi = p.gout, *oj = p.gout + p.E_cap, *ok = p.gout + 2 * (size_t)p.E_cap, *orow = p.gout + 3 * (size_t)p.E_cap;
+  const int b = blockIdx.x;
+  if (b < p.nb) {
+    __shared__ int s_w[4];
+    const int E = p.dyn[RAMP_DYN_EPREV];
+    if (b * TRK_EB >= E) return;
+    const TrkDecision d = trk_decision(p.dyn, p.mm, p.thresh, p.keyframe_index, p.removal_window, p.M, true);
+    const int lane = tid & 63, wave = tid >> 6;
+    int base = p.off[b];
+    for (int pass = 0; pass < TRK_EB / 256; pass++) {
+      const int e = b * TRK_EB + pass * 256 + tid;
+      bool keep = false;
+      long i = 0, j = 0, q = 0;
+      if (e < E) {
+        i = p.gin[e]; j = p.gin[(size_t)p.E_cap + e]; q = p.gin[2 * (size_t)p.E_cap + e];
+        keep = trk_edge(d.remove, d.k, d.kcut, p.M, i, j, q);
+      }
+      const unsigned long long m = __ballot(keep);
+      __syncthreads();                                   // s_w of the previous pass has been read
+      if (lane == 0) s_w[wave] = __popcll(m);
+      __syncthreads();
+      int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+      for (int w = 0; w < wave; w++) pos += s_w[w];
+      if (keep) { oi[pos] = i; oj[pos] = j; ok[pos] = q; orow[pos] = e; }
+      base += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    }
+    return;
+  }
+  // new factors: forward (every live patch of the last r - 1 frames -> the new frame), then backward (the new frame's
+  // patches -> the last r frames incl. itself), patch-major like the reference's meshgrid(indexing='ij')
+  const int Ek = p.dyn[RAMP_DYN_EKEPT], ne = p.dyn[RAMP_DYN_E] - Ek;
+  const int idx = (b - p.nb) * 256 + tid;
+  if (idx >= ne) return;
+  const int n1 = p.dyn[RAMP_DYN_N];
+  const int lo = max(n1 - p.r, 0);
+  const int nf = p.M * (max(n1 - 1, 0) - lo);
+  long kk, jj;
+  if (idx < nf) {
+    kk = (long)p.M * lo + idx;
+    jj = n1 - 1;
+  } else {
+    const int q = idx - nf, nt = n1 - lo;
+    kk = (long)p.M * (n1 - 1) + q / nt;
+    jj = lo + q % nt;
+  }
+  oi[Ek + idx] = kk / p.M; oj[Ek + idx] = jj; ok[Ek + idx] = kk; orow[Ek + idx] = -1;
+}
+
+__global__ void __launch_bounds__(256) trk_iota_kernel(int64_t *__restrict__ row, const int32_t *__restrict__ dyn) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < dyn[RAMP_DYN_E]) row[e] = e;
+}
+
+static int trk_edit_fill(const ramp_track *t, int cur, int64_t counter, TrkEdit &p) {
+  p.dyn = t->dyn; p.mm = t->mm; p.gin = t->graph[cur]; p.gout = t->graph[1 - cur];
+  p.E_cap = t->E_cap; p.M = t->M; p.r = t->patch_lifetime; p.removal_window = t->removal_window;
+  p.keyframe_index = t->keyframe_index; p.log_cap = t->log_cap; p.thresh = t->keyframe_thresh;
+  p.nb = ramp_cdiv(t->E_cap, TRK_EB);
+  p.cnt = t->edit_ws; p.off = t->edit_ws + p.nb; p.fmin = t->edit_ws + 2 * p.nb;
+  p.tstamps = t->tstamps; p.poses = t->poses; p.dlog = t->dlog; p.counter = counter;
+  const int PP = t->P * t->P;
+  const long fb1 = (long)t->feat_h * t->feat_w * 128 * 2, fb2 = (long)(t->feat_h / 4) * (t->feat_w / 4) * 128 * 2;
+  void *bufs[9] = {t->tstamps, t->colors, t->poses, t->patches, t->intrinsics, t->imap, t->gmap, t->fmap1, t->fmap2};
+  const long rb[9] = {8, (long)t->M * 3, 28, (long)t->M * 3 * PP * 4, 16, (long)t->M * 384 * 2, (long)t->M * PP * 128 * 2, fb1, fb2};
+  const int md[9] = {0, 0, 0, 0, 0, t->mem, t->mem, t->mem, t->mem};
+  p.nbuf = 9;
+  for (int i = 0; i < 9; i++) {
+    if (!bufs[i] || (rb[i] & 3)) return RAMP_EINVAL;
+    p.base[i] = (char *)bufs[i]; p.row_bytes[i] = rb[i]; p.mod[i] = md[i];
+  }
+  return RAMP_OK;
+}
+
+static bool trk_valid(const ramp_track *t) {
+  return t && t->dyn && t->M > 0 && t->P == 3 && t->E_cap > 0 && t->graph[0] && t->graph[1] && t->plan_ws &&
+         t->kk_order && t->ij_order && t->ix && t->jx && t->opt_window > 0 && t->mem > 0 && t->edit_ws;
+}
+
+extern "C" {
+
+size_t ramp_track_sizeof(void) { return sizeof(ramp_track); }
+size_t ramp_track_plan_workspace_bytes(int E_cap, int kkey_cap, int pkey_cap) {
+  return ramp_i_plan_dyn_ws(E_cap, kkey_cap, pkey_cap);
+}
+size_t ramp_track_ba_workspace_bytes(int E_cap, int n_rows, int M, int opt_window, int kk_cap, int ij_cap) {
+  return ramp_i_ba_dyn_ws(E_cap, n_rows, n_rows * M, opt_window, kk_cap, ij_cap);
+}
+
+int ramp_track_plan(const ramp_track *t, int cur, void *stream) {
+  if (!trk_valid(t) || cur < 0 || cur > 1) return RAMP_EINVAL;
+  return ramp_i_plan_dyn(t->graph[cur], t->E_cap, t->dyn, t->dyn + RAMP_DYN_STATUS, t->M, t->kkey_cap, t->pkey_cap,
+                         t->kk_cap, t->ij_cap, t->kk_order, t->kk_gid, t->kk_seg, t->kk_ngroups, t->kk_ukeys, t->ij_order,
+                         t->ij_gid, t->ij_seg, t->ij_ngroups, t->ij_ukeys, t->ix, t->jx, t->plan_ws, t->plan_ws_bytes,
+                         (hipStream_t)stream);
+}
+
+#define TRK_PROBE(i)                                                                             \
+  do {                                                                                           \
+    if (t->probe[i] && hipEventRecord((hipEvent_t)t->probe[i], st) != hipSuccess) return RAMP_ELAUNCH; \
+  } while (0)
+#define TRK_DO(call)          \
+  do {                        \
+    const int rc_ = (call);   \
+    if (rc_ != RAMP_OK) return rc_; \
+  } while (0)
+
+int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, const float *k_new, void *gate_event,
+                    void *stream) {
+  if (!trk_valid(t) || cur < 0 || cur > 1) return RAMP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int Ec = t->E_cap, PP = t->P * t->P;
+  const int64_t *g = t->graph[cur];
+  const int64_t *ii = g, *jj = g + Ec, *kk = g + 2 * (size_t)Ec, *row = g + 3 * (size_t)Ec;
+  const int32_t *dyn = t->dyn;
+  if (flags & RAMP_TRACK_COMMIT) {
+    if (!t->fe_colors || !t->fe_imap || !t->fe_gmap || !t->fe_fmap1 || !t->fe_fmap2 || !t->fe_patches) return RAMP_EINVAL;
+    const void *src[5] = {t->fe_colors, t->fe_imap, t->fe_gmap, t->fe_fmap1, t->fe_fmap2};
+    void *base[5] = {t->colors, t->imap, t->gmap, t->fmap1, t->fmap2};
+    const long bytes[5] = {(long)t->M * 3, (long)t->M * 384 * 2, (long)t->M * PP * 128 * 2,
+                           (long)t->feat_h * t->feat_w * 128 * 2, (long)(t->feat_h / 4) * (t->feat_w / 4) * 128 * 2};
+    const int mod[5] = {0, t->mem, t->mem, t->mem, t->mem};
+    TRK_DO(ramp_i_frame_commit_dyn(t->poses, t->motion_model, t->motion_damping, t->tstamps, counter, t->index_map,
+                                   t->intrinsics, k_new, t->patches, 3, t->M, t->P, t->fe_patches, 5, src, base, bytes,
+                                   mod, dyn, st));
+  }
+  if (flags & RAMP_TRACK_UPDATE) {
+    const ramp_track_weights &w = t->w;
+    if (!t->coords || !t->corr || !t->net[0] || !t->net[1] || !t->net[2] || !t->fg || !t->ykk || !t->hkk || !t->yij ||
+        !t->hij || !t->relu_t || !t->target || !t->weight || !t->ba_ws)
+      return RAMP_EINVAL;
+    // Ramp_vo.update(), ramp/Ramp_vo.py:276-310
+    TRK_DO(ramp_i_transform_dyn(t->poses, t->patches, t->intrinsics, ii, jj, kk, t->coords, Ec, dyn, st));
+    ramp_corr_level lv[2];
+    lv[0].fmap = t->fmap1; lv[0].H2 = t->feat_h; lv[0].W2 = t->feat_w; lv[0].coord_div = 1.0f;
+    lv[1].fmap = t->fmap2; lv[1].H2 = t->feat_h / 4; lv[1].W2 = t->feat_w / 4; lv[1].coord_div = 4.0f;
+    TRK_PROBE(0);
+    TRK_DO(ramp_i_corr_fwd(t->gmap, lv, 2, t->coords, kk, jj, t->ij_order, t->corr, 896, (long)t->M * t->mem, t->mem, Ec,
+                           t->mem * t->M, t->mem, 128, t->P, 3, RAMP_F16, RAMP_NHWC8, dyn, st));
+    TRK_PROBE(1);
+    // the update operator, ramp/net.py:69-90 (the fp16 fused chains of csrc/update_mlp.hip)
+    TRK_DO(ramp_i_upd_corr_mlp(t->corr, 896, w.corr_w1, w.corr_b1, w.corr_w2, w.corr_b2, w.corr_w3, w.corr_b3, w.corr_ln_w,
+                               w.corr_ln_b, w.corr_ln_eps, t->net[0], row, t->imap, kk, (long)t->M * t->mem, w.norm_w,
+                               w.norm_b, w.norm_eps, t->net[1], Ec, dyn, st));
+    TRK_DO(ramp_i_upd_nbr(t->net[1], t->ix, w.c1_wa, w.c1_ba, w.c1_wb, w.c1_bb, t->net[2], nullptr, Ec, dyn, st));
+    TRK_DO(ramp_i_upd_nbr(t->net[2], t->jx, w.c2_wa, w.c2_ba, w.c2_wb, w.c2_bb, t->net[1], nullptr, Ec, dyn, st));
+    TRK_DO(ramp_i_upd_fg(t->net[1], nullptr, nullptr, nullptr, w.kk_wf, w.kk_bf, w.kk_wg, w.kk_bg, t->fg, Ec, dyn, st));
+    TRK_DO(ramp_upd_segment_softmax(t->fg, t->kk_order, t->kk_seg, t->kk_ngroups, t->ykk, t->kk_cap, RAMP_F16, stream));
+    TRK_DO(ramp_upd_linear(t->ykk, w.kk_wh, w.kk_bh, t->hkk, t->kk_cap, t->kk_ngroups, stream));
+    TRK_DO(ramp_i_upd_fg(t->net[1], t->hkk, t->kk_gid, t->net[1], w.ij_wf, w.ij_bf, w.ij_wg, w.ij_bg, t->fg, Ec, dyn, st));
+    TRK_DO(ramp_upd_segment_softmax(t->fg, t->ij_order, t->ij_seg, t->ij_ngroups, t->yij, t->ij_cap, RAMP_F16, stream));
+    TRK_DO(ramp_upd_linear(t->yij, w.ij_wh, w.ij_bh, t->hij, t->ij_cap, t->ij_ngroups, stream));
+    if (gate_event && hipEventRecord((hipEvent_t)gate_event, st) != hipSuccess) return RAMP_ELAUNCH;
+    TRK_DO(ramp_i_upd_gru(t->net[1], t->hij, t->ij_gid, w.ln1_w, w.ln1_b, w.ln1_eps, w.gru_w, w.gru_b, w.ln2_w, w.ln2_b,
+                          w.ln2_eps, t->net[0], t->relu_t, Ec, dyn, st));
+    TRK_PROBE(2);
+    TRK_DO(ramp_i_upd_heads_linear(t->relu_t, w.heads_w, w.heads_b, t->coords, t->target, t->weight, Ec, t->P,
+                                   (float)t->feat_w, (float)t->feat_h, dyn, st));
+    TRK_PROBE(3);
+    TRK_DO(ramp_i_ba_dyn(t->poses, t->patches, t->intrinsics, t->target, t->weight, t->lmbda, ii, jj, kk, Ec, t->P,
+                         t->n_rows, t->n_rows * t->M, t->opt_window, 2, t->kk_order, t->kk_seg, t->kk_ngroups, t->kk_ukeys,
+                         t->kk_cap, t->ij_order, t->ij_seg, t->ij_ngroups, t->ij_cap, t->ba_ws, t->ba_ws_bytes,
+                         t->dyn + RAMP_DYN_STATUS, dyn, st));
+    TRK_PROBE(4);
+    if (t->points && t->ixm)
+      TRK_DO(ramp_i_point_cloud_dyn(t->poses, t->patches, t->intrinsics, t->ixm, t->points, t->m_cap, dyn, t->M, st));
+    if (!(flags & RAMP_TRACK_KEYFRAME)) {
+      // the new hidden state is indexed by the factors themselves from here on
+      hipLaunchKernelGGL(trk_iota_kernel, dim3(ramp_cdiv(Ec, 256)), dim3(256), 0, st, t->graph[cur] + 3 * (size_t)Ec, dyn);
+    }
+  }
+  if (flags & RAMP_TRACK_KEYFRAME) {
+    if (!t->mm || !t->dlog) return RAMP_EINVAL;
+    // Ramp_vo.keyframe(), ramp/Ramp_vo.py:237-274, and the next frame's append_factors (:394-395)
+    if (!(flags & RAMP_TRACK_MM_GIVEN))
+      TRK_DO(ramp_i_motionmag_dyn(t->poses, t->patches, t->intrinsics, ii, jj, kk, t->ij_order, t->ij_seg, t->ij_ukeys,
+                                  t->ij_ngroups, 0.5f, t->mm, dyn, t->keyframe_index, st));
+    TrkEdit p;
+    TRK_DO(trk_edit_fill(t, cur, counter, p));
+    hipLaunchKernelGGL(trk_flag_kernel, dim3(p.nb), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(trk_decide_kernel, dim3(1), dim3(256), 0, st, p);
+    const int new_cap = (2 * t->patch_lifetime - 1) * t->M;          // factors one frame adds
+    int gx = p.nb + ramp_cdiv(new_cap, 256);
+    if (gx < 1024) gx = 1024;                                         // column chunks of the row shift
+    hipLaunchKernelGGL(trk_apply_kernel, dim3(gx, 1 + p.nbuf), dim3(256), 0, st, p);
+    RAMP_CHECK_LAUNCH();
+    TRK_DO(ramp_track_plan(t, 1 - cur, stream));
+  }
+  if (t->dyn_host &&
+      hipMemcpyAsync(t->dyn_host, t->dyn, RAMP_DYN_WORDS * sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess)
+    return RAMP_ELAUNCH;
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+
+}  // extern "C"

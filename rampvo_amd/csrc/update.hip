@@ -225,9 +225,10 @@ __global__ void __launch_bounds__(256)
     upd_heads_linear_f16_kernel(const _Float16 *__restrict__ relu_t, const _Float16 *__restrict__ hwt,
                                 const float *__restrict__ hb, const float *__restrict__ coords,
                                 float *__restrict__ target, float *__restrict__ weight, int E, int PP, int ctr,
-                                float wd, float ht) {
+                                float wd, float ht, const int32_t *__restrict__ dyn) {
   const int lane = threadIdx.x & 63;
   const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (dyn) E = dyn[RAMP_DYN_E];                 // device-side size: the argument is the launch bound
   if (e >= E) return;
   float x[6];
 #pragma unroll
@@ -429,17 +430,22 @@ int ramp_upd_heads(const void *hw, const float *coords, float *target, float *we
   return RAMP_OK;
 }
 
-int ramp_upd_heads_linear(const void *relu_t, const void *heads_w, const float *heads_b, const float *coords,
-                          float *target, float *weight, int E, int P, float wd, float ht, void *stream) {
+int ramp_i_upd_heads_linear(const void *relu_t, const void *heads_w, const float *heads_b, const float *coords,
+                            float *target, float *weight, int E, int P, float wd, float ht, const int32_t *dyn,
+                            void *stream) {
   if (E < 0 || P < 1) return RAMP_EINVAL;
   if (E == 0) return RAMP_OK;
   if (!relu_t || !heads_w || !heads_b || !coords || !target || !weight) return RAMP_EINVAL;
   const int PP = P * P, ctr = (P / 2) * P + P / 2;
   hipLaunchKernelGGL(upd_heads_linear_f16_kernel, dim3(ramp_cdiv(E, 4)), dim3(256), 0, (hipStream_t)stream,
                      (const _Float16 *)relu_t, (const _Float16 *)heads_w, heads_b, coords, target, weight, E, PP, ctr,
-                     wd, ht);
+                     wd, ht, dyn);
   RAMP_CHECK_LAUNCH();
   return RAMP_OK;
+}
+int ramp_upd_heads_linear(const void *relu_t, const void *heads_w, const float *heads_b, const float *coords,
+                          float *target, float *weight, int E, int P, float wd, float ht, void *stream) {
+  return ramp_i_upd_heads_linear(relu_t, heads_w, heads_b, coords, target, weight, E, P, wd, ht, nullptr, stream);
 }
 
 int ramp_upd_segment_softmax(const void *fg, const int32_t *order, const int32_t *seg_start,

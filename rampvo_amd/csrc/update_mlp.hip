@@ -197,6 +197,7 @@ struct GruParams {
   const float *pre_w, *pre_b;  // gru[0] LayerNorm
   float pre_eps;
   int E;
+  const int32_t *dyn;          // optional device-side sizes (RAMP_DYN_*): E is then the launch bound
 };
 
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -275,6 +276,8 @@ __global__ void __launch_bounds__(64 * MWAVES) upd_gru_kernel(const GruParams p)
   float *T1 = reinterpret_cast<float *>(Gs + MBM * MXS), *T2 = T1 + MBM * MWAVES;   // LayerNorm partials
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
   const int row0 = blockIdx.x * MBM;
+  const int pE = p.dyn ? p.dyn[RAMP_DYN_E] : p.E;
+  if (row0 >= pE) return;                      // (workgroup-uniform: only with device-side sizes)
   const int col0 = wave * (16 * MNTW);
   const int cq = col0 + 4 * q;                  // this lane's first column in n-tile 0
 
@@ -285,7 +288,7 @@ __global__ void __launch_bounds__(64 * MWAVES) upd_gru_kernel(const GruParams p)
 #pragma unroll
   for (int mt = 0; mt < 4; mt++) {
     const int row = row0 + mt * 16 + j;
-    roff[mt] = (size_t)(row < p.E ? row : p.E - 1) * MD;
+    roff[mt] = (size_t)(row < pE ? row : pE - 1) * MD;
 #pragma unroll
     for (int nt = 0; nt < MNTW; nt++) res[mt][nt] = *reinterpret_cast<const f4 *>(p.x32 + roff[mt] + cq + nt * 16);
   }
@@ -376,7 +379,7 @@ __global__ void __launch_bounds__(64 * MWAVES) upd_gru_kernel(const GruParams p)
     } else {
 #pragma unroll
       for (int mt = 0; mt < 4; mt++) {
-        if (row0 + mt * 16 + j >= p.E) continue;
+        if (row0 + mt * 16 + j >= pE) continue;
 #pragma unroll
         for (int nt = 0; nt < MNTW; nt++) {
           const f4 v = res[mt][nt];
@@ -402,6 +405,7 @@ struct NbrParams {
   float *net_out;              // [E][384] fp32
   _Float16 *out_t;             // optional [E][384] fp16 copy of net_out
   int E;
+  const int32_t *dyn;          // optional device-side sizes (RAMP_DYN_*): E is then the launch bound
 };
 
 // waves_per_eu 6: 80 VGPRs -> three workgroups per CU (3 x 50 KB LDS): all ~625 workgroups of an update are
@@ -414,11 +418,13 @@ __global__ void __launch_bounds__(64 * MWAVES) __attribute__((amdgpu_waves_per_e
   _Float16 *Hs = Xs;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
   const int row0 = blockIdx.x * MBM;
+  const int pE = p.dyn ? p.dyn[RAMP_DYN_E] : p.E;
+  if (row0 >= pE) return;                      // (workgroup-uniform: only with device-side sizes)
   const int col0 = wave * (16 * MNTW);
   for (int i = tid; i < MBM * (MD / 4); i += 64 * MWAVES) {
     const int r = i / (MD / 4), c4 = i - r * (MD / 4);
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row0 + r < p.E) {
+    if (row0 + r < pE) {
       const long src = p.idx[row0 + r];
       if (src >= 0) v = *reinterpret_cast<const float4 *>(p.net_in + (size_t)src * MD + 4 * c4);
     }
@@ -465,7 +471,7 @@ __global__ void __launch_bounds__(64 * MWAVES) __attribute__((amdgpu_waves_per_e
     for (int rr = 0; rr < MPR / MWAVES; rr++) {
       const int rl = wave * (MPR / MWAVES) + rr;
       const int row = row0 + half * MPR + rl;
-      if (row >= p.E) continue;
+      if (row >= pE) continue;
 #pragma unroll
       for (int k = 0; k < 3; k++) {
         const int c = 2 * lane + 128 * k;
@@ -504,6 +510,7 @@ struct CorrTailParams {
   float norm_eps;
   float *net_out;              // [E][384] fp32
   int E;
+  const int32_t *dyn;          // optional device-side sizes (RAMP_DYN_*): E is then the launch bound
 };
 
 #ifdef GRU_TRACE
@@ -518,6 +525,8 @@ __global__ void __launch_bounds__(64 * MWAVES) __attribute__((amdgpu_waves_per_e
   _Float16 *Xs = reinterpret_cast<_Float16 *>(smem_raw);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
   const int row0 = blockIdx.x * MBM;
+  const int pE = p.dyn ? p.dyn[RAMP_DYN_E] : p.E;
+  if (row0 >= pE) return;                      // (workgroup-uniform: only with device-side sizes)
   const int col0 = wave * (16 * MNTW);
   f4 acc[1][4][MNTW];
   CT(0);
@@ -527,7 +536,7 @@ __global__ void __launch_bounds__(64 * MWAVES) __attribute__((amdgpu_waves_per_e
   if (tid < MBM) {
     const int row = row0 + tid;
     long ra = -1, rb = 0;
-    if (row < p.E) {
+    if (row < pE) {
       ra = p.net ? (p.net_map ? p.net_map[row] : (long)row) : -1;
       rb = p.inp_idx ? p.inp_idx[row] : (long)row;
       if (p.inp_mod > 0) rb %= p.inp_mod;
@@ -547,7 +556,7 @@ __global__ void __launch_bounds__(64 * MWAVES) __attribute__((amdgpu_waves_per_e
       for (int i = tid; i < MBM * v8; i += 64 * MWAVES) {
         const int r = i / v8, c8 = i - r * v8;
         h8 v = (h8){0, 0, 0, 0, 0, 0, 0, 0};
-        if (row0 + r < p.E) v = *reinterpret_cast<const h8 *>(p.corr + (size_t)(row0 + r) * p.corr_k + ks0 * 32 + 8 * c8);
+        if (row0 + r < pE) v = *reinterpret_cast<const h8 *>(p.corr + (size_t)(row0 + r) * p.corr_k + ks0 * 32 + 8 * c8);
         *reinterpret_cast<h8 *>(Xs + r * MXS + 8 * c8) = v;
       }
       __syncthreads();
@@ -567,7 +576,7 @@ __global__ void __launch_bounds__(64 * MWAVES) __attribute__((amdgpu_waves_per_e
     for (int i = tid; i < MBM * (MD / 8); i += 64 * MWAVES) {
       const int r = i / (MD / 8), c8 = i - r * (MD / 8);
       h8 v = (h8){0, 0, 0, 0, 0, 0, 0, 0};
-      if (row0 + r < p.E) v = *reinterpret_cast<const h8 *>(p.c1 + (size_t)(row0 + r) * MD + 8 * c8);
+      if (row0 + r < pE) v = *reinterpret_cast<const h8 *>(p.c1 + (size_t)(row0 + r) * MD + 8 * c8);
       *reinterpret_cast<h8 *>(Xs + r * MXS + 8 * c8) = v;
     }
   }
@@ -644,7 +653,7 @@ __global__ void __launch_bounds__(64 * MWAVES) __attribute__((amdgpu_waves_per_e
     for (int rr = 0; rr < MPR / MWAVES; rr++) {
       const int rl = wave * (MPR / MWAVES) + rr;
       const int row = row0 + half * MPR + rl;
-      if (row >= p.E) continue;                          // wave-uniform
+      if (row >= pE) continue;                          // wave-uniform
       float v[3][2];
 #pragma unroll
       for (int k = 0; k < 3; k++) { v[k][0] = 0.f; v[k][1] = 0.f; }
@@ -692,6 +701,7 @@ struct FgParams {
   const float *bf, *bg;        // biases (fp16-rounded values as fp32)
   _Float16 *fg;                // [E][768] fp16
   int E;
+  const int32_t *dyn;          // optional device-side sizes (RAMP_DYN_*): E is then the launch bound
 };
 
 __global__ void __launch_bounds__(64 * MWAVES) __attribute__((amdgpu_waves_per_eu(6, 6))) upd_fg_kernel(const FgParams p) {
@@ -699,6 +709,8 @@ __global__ void __launch_bounds__(64 * MWAVES) __attribute__((amdgpu_waves_per_e
   _Float16 *Xs = reinterpret_cast<_Float16 *>(smem_raw);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
   const int row0 = blockIdx.x * MBM;
+  const int pE = p.dyn ? p.dyn[RAMP_DYN_E] : p.E;
+  if (row0 >= pE) return;                      // (workgroup-uniform: only with device-side sizes)
   const int col0 = wave * (16 * MNTW);
 #pragma unroll
   for (int rr = 0; rr < MBM / MWAVES; rr++) {            // 8 whole rows per wave
@@ -707,7 +719,7 @@ __global__ void __launch_bounds__(64 * MWAVES) __attribute__((amdgpu_waves_per_e
     float v[3][2];
 #pragma unroll
     for (int k = 0; k < 3; k++) { v[k][0] = 0.f; v[k][1] = 0.f; }
-    if (row < p.E) {                                     // wave-uniform
+    if (row < pE) {                                     // wave-uniform
 #pragma unroll
       for (int k = 0; k < 3; k++) {
         const float2 a = *reinterpret_cast<const float2 *>(p.x32 + (size_t)row * MD + 2 * lane + 128 * k);
@@ -745,7 +757,7 @@ __global__ void __launch_bounds__(64 * MWAVES) __attribute__((amdgpu_waves_per_e
 #pragma unroll
       for (int mt = 0; mt < 4; mt++) {
         const int row = row0 + mt * 16 + j;
-        if (row < p.E)
+        if (row < pE)
           *reinterpret_cast<hh4 *>(p.fg + (size_t)row * (2 * MD) + part * MD + col0 + nt * 16 + 4 * q) =
               (hh4){(_Float16)(acc[0][mt][nt][0] + b.x), (_Float16)(acc[0][mt][nt][1] + b.y),
                     (_Float16)(acc[0][mt][nt][2] + b.z), (_Float16)(acc[0][mt][nt][3] + b.w)};
@@ -867,6 +879,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) upd_nbr_big_kernel(const NbrP
   _Float16 *Xs = reinterpret_cast<_Float16 *>(smem_raw);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
   const int row0 = blockIdx.x * ROWS;
+  const int pE = p.dyn ? p.dyn[RAMP_DYN_E] : p.E;
+  if (row0 >= pE) return;                      // (workgroup-uniform: only with device-side sizes)
   const int col0 = wave * (16 * NTW);
   // gather: wave w stages rows w, w + NW, ... (lane l: channels 2l + 128k): 512-byte contiguous reads.  All of the
   // wave's neighbour indices first, then all of its rows: one dependent round trip per workgroup instead of one per
@@ -877,8 +891,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) upd_nbr_big_kernel(const NbrP
 #pragma unroll
     for (int i = 0; i < RPW; i++) {
       const int row = row0 + wave + i * NW;
-      src[i] = p.idx[row < p.E ? row : p.E - 1];
-      if (row >= p.E) src[i] = -1;
+      src[i] = p.idx[row < pE ? row : pE - 1];
+      if (row >= pE) src[i] = -1;
     }
     float2 v[RPW][3];
 #pragma unroll
@@ -896,7 +910,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) upd_nbr_big_kernel(const NbrP
       }
   }
   unsigned ro[NMT];
-  const unsigned live = big_row_offsets<NMT>(ro, row0, col0, q, j, p.E);
+  const unsigned live = big_row_offsets<NMT>(ro, row0, col0, q, j, pE);
   __syncthreads();
   f4 acc[NMT][NTW];
   big_zero<NMT, NTW>(acc);
@@ -933,6 +947,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) upd_fg_big_kernel(const FgPar
   _Float16 *Xs = reinterpret_cast<_Float16 *>(smem_raw);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
   const int row0 = blockIdx.x * ROWS;
+  const int pE = p.dyn ? p.dyn[RAMP_DYN_E] : p.E;
+  if (row0 >= pE) return;                      // (workgroup-uniform: only with device-side sizes)
   const int col0 = wave * (16 * NTW);
   // stage x = x32 (+ add_t[add_idx]): all of the wave's group indices first, then all of its rows (rows past E read
   // row E - 1 and are not written back)
@@ -942,13 +958,13 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) upd_fg_big_kernel(const FgPar
 #pragma unroll
     for (int i = 0; i < RPW; i++) {
       const int row = row0 + wave + i * NW;
-      ai[i] = p.add_t ? p.add_idx[row < p.E ? row : p.E - 1] : 0;
+      ai[i] = p.add_t ? p.add_idx[row < pE ? row : pE - 1] : 0;
     }
     float2 v[RPW][3];
 #pragma unroll
     for (int i = 0; i < RPW; i++) {
       const int row = row0 + wave + i * NW;
-      const float *b = p.x32 + (size_t)(row < p.E ? row : p.E - 1) * MD + 2 * lane;
+      const float *b = p.x32 + (size_t)(row < pE ? row : pE - 1) * MD + 2 * lane;
 #pragma unroll
       for (int k = 0; k < 3; k++) v[i][k] = *reinterpret_cast<const float2 *>(b + 128 * k);
     }
@@ -968,7 +984,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) upd_fg_big_kernel(const FgPar
 #pragma unroll
     for (int i = 0; i < RPW; i++) {
       const int r = wave + i * NW, row = row0 + r;
-      const bool live_row = row < p.E;                   // wave-uniform
+      const bool live_row = row < pE;                   // wave-uniform
 #pragma unroll
       for (int k = 0; k < 3; k++) {
         if (live_row && p.x32_out)
@@ -979,7 +995,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) upd_fg_big_kernel(const FgPar
     }
   }
   unsigned ro[NMT];
-  const unsigned live = big_row_offsets<NMT>(ro, row0, col0, q, j, p.E);
+  const unsigned live = big_row_offsets<NMT>(ro, row0, col0, q, j, pE);
   __syncthreads();
 #pragma unroll 1
   for (int part = 0; part < 2; part++) {
@@ -1001,6 +1017,51 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) upd_fg_big_kernel(const FgPar
     }
   }
 }
+
+// ------------------------------------------------------------------ plain Linear on a small table
+// y[r] = fp16(x[r] W^T + b), r < rows: SoftAgg's `h` layer on the group table (ramp/blocks.py:46-47; a few hundred to a
+// few thousand rows).  16 rows per workgroup, 4 waves x 96 columns, operands exchanged so that a lane holds four
+// consecutive columns of one row (8-byte stores).  rows_dev: optional device-side row count (the grouping's ngroups).
+__global__ void __launch_bounds__(256) upd_linear_kernel(const _Float16 *__restrict__ x, const _Float16 *__restrict__ wp,
+                                                         const float *__restrict__ bias, _Float16 *__restrict__ y,
+                                                         int rows, const int32_t *__restrict__ rows_dev) {
+  __shared__ __attribute__((aligned(16))) _Float16 Xs[16 * MXS];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
+  const int row0 = blockIdx.x * 16;
+  int R = rows;
+  if (rows_dev) { const int d = *rows_dev; R = d < rows ? d : rows; }
+  if (row0 >= R) return;
+  for (int i = tid; i < 16 * (MD / 8); i += 256) {
+    const int r = i / (MD / 8), c8 = i - r * (MD / 8);
+    h8 v = (h8){0, 0, 0, 0, 0, 0, 0, 0};
+    if (row0 + r < R) v = *reinterpret_cast<const h8 *>(x + (size_t)(row0 + r) * MD + 8 * c8);
+    *reinterpret_cast<h8 *>(Xs + r * MXS + 8 * c8) = v;
+  }
+  __syncthreads();
+  constexpr int NT = 6;
+  f4 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; nt++) acc[nt] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+  for (int ks = 0; ks < MKS; ks++) {
+    const h8 a = *reinterpret_cast<const h8 *>(Xs + j * MXS + ks * 32 + 8 * q);
+    h8 bw[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++)
+      bw[nt] = *reinterpret_cast<const h8 *>(wp + (((size_t)ks * (MD / 16) + wave * NT + nt) * 64 + lane) * 8);
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bw[nt], a, acc[nt], 0, 0, 0);
+  }
+  if (row0 + j >= R) return;
+  _Float16 *o = y + (size_t)(row0 + j) * MD + wave * (16 * NT) + 4 * q;
+#pragma unroll
+  for (int nt = 0; nt < NT; nt++) {
+    const f4 b = *reinterpret_cast<const f4 *>(bias + wave * (16 * NT) + nt * 16 + 4 * q);
+    *reinterpret_cast<h4 *>(o + nt * 16) = (h4){(_Float16)(acc[nt][0] + b[0]), (_Float16)(acc[nt][1] + b[1]),
+                                                (_Float16)(acc[nt][2] + b[2]), (_Float16)(acc[nt][3] + b[3])};
+  }
+}
+
 
 // row tiles per workgroup for E edges (0: the 64-row kernels -- small problems, or RAMP_UPD_BIG=0; 4..8 forces a tile
 // for A/B runs); `best`: the measured optimum of the chain at the bench size
@@ -1043,9 +1104,9 @@ int ramp_debug_gru_trace(long long *host, int n) {
 #endif
 size_t ramp_upd_mlp_lds_bytes(void) { return (size_t)2 * MBM * MXS * 2; }
 
-int ramp_upd_gru(const float *x32, const void *add_t, const int32_t *add_idx, const float *pre_w, const float *pre_b,
+int ramp_i_upd_gru(const float *x32, const void *add_t, const int32_t *add_idx, const float *pre_w, const float *pre_b,
                  float pre_eps, const void *const *wp_host, const float *const *bias_host, const float *ln_w,
-                 const float *ln_b, float eps, float *out32, void *relu_t, int E, void *stream) {
+                 const float *ln_b, float eps, float *out32, void *relu_t, int E, const int32_t *dyn, void *stream) {
   if (E < 0) return RAMP_EINVAL;
   if (E == 0) return RAMP_OK;
   if (!x32 || !wp_host || !bias_host || !ln_w || !ln_b || !out32 || !relu_t) return RAMP_EINVAL;
@@ -1058,7 +1119,7 @@ int ramp_upd_gru(const float *x32, const void *add_t, const int32_t *add_idx, co
     p.wp[i] = (const _Float16 *)wp_host[i];
     p.bias[i] = bias_host[i];
   }
-  p.ln_w = ln_w; p.ln_b = ln_b; p.eps = eps; p.out32 = out32; p.relu_t = (_Float16 *)relu_t; p.E = E;
+  p.ln_w = ln_w; p.ln_b = ln_b; p.eps = eps; p.out32 = out32; p.relu_t = (_Float16 *)relu_t; p.E = E; p.dyn = dyn;
   const size_t lds = (size_t)3 * MBM * MXS * 2 + 2 * MBM * MWAVES * sizeof(float);   // x, h, sigmoid(gate) tiles + the LayerNorm tables
   static bool attr_set = false;
   if (!attr_set) {
@@ -1072,14 +1133,14 @@ int ramp_upd_gru(const float *x32, const void *add_t, const int32_t *add_idx, co
   return RAMP_OK;
 }
 
-int ramp_upd_nbr(const float *net_in, const int64_t *idx, const void *wa, const float *ba, const void *wb,
-                 const float *bb, float *net_out, void *out_t, int E, void *stream) {
+int ramp_i_upd_nbr(const float *net_in, const int64_t *idx, const void *wa, const float *ba, const void *wb,
+                 const float *bb, float *net_out, void *out_t, int E, const int32_t *dyn, void *stream) {
   if (E < 0) return RAMP_EINVAL;
   if (E == 0) return RAMP_OK;
   if (!net_in || !idx || !wa || !ba || !wb || !bb || !net_out || net_in == net_out) return RAMP_EINVAL;
   NbrParams p;
   p.net_in = net_in; p.idx = idx; p.wa = (const _Float16 *)wa; p.wb = (const _Float16 *)wb; p.ba = ba; p.bb = bb;
-  p.net_out = net_out; p.out_t = (_Float16 *)out_t; p.E = E;
+  p.net_out = net_out; p.out_t = (_Float16 *)out_t; p.E = E; p.dyn = dyn;
   if (const int nmt = big_pick_nmt(E, 5)) { BIG_DISPATCH(upd_nbr_big_kernel, 8, p, E, nmt, false, (hipStream_t)stream) }
   const size_t lds = (size_t)MBM * MXS * 2;          // one tile (see the kernel)
   static bool attr_set = false;
@@ -1106,7 +1167,7 @@ int ramp_upd_corr_tail(const void *c1, const void *w2, const float *b2, const vo
   p.c1 = (const _Float16 *)c1; p.w2 = (const _Float16 *)w2; p.w3 = (const _Float16 *)w3; p.b2 = b2; p.b3 = b3;
   p.ln_w = ln_w; p.ln_b = ln_b; p.ln_eps = ln_eps; p.net = net; p.net_map = net_map; p.inp = (const _Float16 *)inp;
   p.inp_idx = inp_idx; p.inp_mod = inp_mod; p.norm_w = norm_w; p.norm_b = norm_b; p.norm_eps = norm_eps;
-  p.net_out = net_out; p.E = E;
+  p.net_out = net_out; p.E = E; p.dyn = nullptr;
   const size_t lds = (size_t)MBM * MXS * 2;
   p.corr = nullptr; p.w1 = nullptr; p.b1 = nullptr; p.corr_k = 0;
   hipLaunchKernelGGL(upd_corr_tail_kernel<false>, dim3(ramp_cdiv(E, MBM)), dim3(64 * MWAVES), lds, (hipStream_t)stream, p);
@@ -1114,10 +1175,10 @@ int ramp_upd_corr_tail(const void *c1, const void *w2, const float *b2, const vo
   return RAMP_OK;
 }
 
-int ramp_upd_corr_mlp(const void *corr, int corr_k, const void *w1, const float *b1, const void *w2, const float *b2,
+int ramp_i_upd_corr_mlp(const void *corr, int corr_k, const void *w1, const float *b1, const void *w2, const float *b2,
                       const void *w3, const float *b3, const float *ln_w, const float *ln_b, float ln_eps,
                       const float *net, const int64_t *net_map, const void *inp, const int64_t *inp_idx, long inp_mod,
-                      const float *norm_w, const float *norm_b, float norm_eps, float *net_out, int E, void *stream) {
+                      const float *norm_w, const float *norm_b, float norm_eps, float *net_out, int E, const int32_t *dyn, void *stream) {
   if (E < 0) return RAMP_EINVAL;
   if (E == 0) return RAMP_OK;
   if (!corr || corr_k <= 0 || (corr_k & 31) || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !ln_w || !ln_b || !inp ||
@@ -1128,24 +1189,60 @@ int ramp_upd_corr_mlp(const void *corr, int corr_k, const void *w1, const float 
   p.w2 = (const _Float16 *)w2; p.w3 = (const _Float16 *)w3; p.b2 = b2; p.b3 = b3;
   p.ln_w = ln_w; p.ln_b = ln_b; p.ln_eps = ln_eps; p.net = net; p.net_map = net_map; p.inp = (const _Float16 *)inp;
   p.inp_idx = inp_idx; p.inp_mod = inp_mod; p.norm_w = norm_w; p.norm_b = norm_b; p.norm_eps = norm_eps;
-  p.net_out = net_out; p.E = E;
+  p.net_out = net_out; p.E = E; p.dyn = dyn;
   const size_t lds = (size_t)MBM * MXS * 2;
   hipLaunchKernelGGL(upd_corr_tail_kernel<true>, dim3(ramp_cdiv(E, MBM)), dim3(64 * MWAVES), lds, (hipStream_t)stream, p);
   RAMP_CHECK_LAUNCH();
   return RAMP_OK;
 }
 
-int ramp_upd_fg(const float *x32, const void *add_t, const int32_t *add_idx, float *x32_out, const void *wf,
-                const float *bf, const void *wg, const float *bg, void *fg, int E, void *stream) {
+int ramp_i_upd_fg(const float *x32, const void *add_t, const int32_t *add_idx, float *x32_out, const void *wf,
+                const float *bf, const void *wg, const float *bg, void *fg, int E, const int32_t *dyn, void *stream) {
   if (E < 0) return RAMP_EINVAL;
   if (E == 0) return RAMP_OK;
   if (!x32 || !wf || !bf || !wg || !bg || !fg || (add_t && !add_idx)) return RAMP_EINVAL;
   FgParams p;
   p.x32 = x32; p.add_t = (const _Float16 *)add_t; p.add_idx = add_idx; p.x32_out = x32_out;
-  p.wf = (const _Float16 *)wf; p.wg = (const _Float16 *)wg; p.bf = bf; p.bg = bg; p.fg = (_Float16 *)fg; p.E = E;
+  p.wf = (const _Float16 *)wf; p.wg = (const _Float16 *)wg; p.bf = bf; p.bg = bg; p.fg = (_Float16 *)fg; p.E = E; p.dyn = dyn;
   if (const int nmt = big_pick_nmt(E, 6)) { BIG_DISPATCH(upd_fg_big_kernel, 8, p, E, nmt, false, (hipStream_t)stream) }
   const size_t lds = (size_t)MBM * MXS * 2;
   hipLaunchKernelGGL(upd_fg_kernel, dim3(ramp_cdiv(E, MBM)), dim3(64 * MWAVES), lds, (hipStream_t)stream, p);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+
+
+// ---- public entry points: host-side sizes (dyn = NULL)
+int ramp_upd_gru(const float *x32, const void *add_t, const int32_t *add_idx, const float *pre_w, const float *pre_b,
+                 float pre_eps, const void *const *wp_host, const float *const *bias_host, const float *ln_w,
+                 const float *ln_b, float eps, float *out32, void *relu_t, int E, void *stream) {
+  return ramp_i_upd_gru(x32, add_t, add_idx, pre_w, pre_b, pre_eps, wp_host, bias_host, ln_w, ln_b, eps, out32, relu_t, E, nullptr, stream);
+}
+
+int ramp_upd_nbr(const float *net_in, const int64_t *idx, const void *wa, const float *ba, const void *wb,
+                 const float *bb, float *net_out, void *out_t, int E, void *stream) {
+  return ramp_i_upd_nbr(net_in, idx, wa, ba, wb, bb, net_out, out_t, E, nullptr, stream);
+}
+
+int ramp_upd_corr_mlp(const void *corr, int corr_k, const void *w1, const float *b1, const void *w2, const float *b2,
+                      const void *w3, const float *b3, const float *ln_w, const float *ln_b, float ln_eps,
+                      const float *net, const int64_t *net_map, const void *inp, const int64_t *inp_idx, long inp_mod,
+                      const float *norm_w, const float *norm_b, float norm_eps, float *net_out, int E, void *stream) {
+  return ramp_i_upd_corr_mlp(corr, corr_k, w1, b1, w2, b2, w3, b3, ln_w, ln_b, ln_eps, net, net_map, inp, inp_idx, inp_mod, norm_w, norm_b, norm_eps, net_out, E, nullptr, stream);
+}
+
+int ramp_upd_fg(const float *x32, const void *add_t, const int32_t *add_idx, float *x32_out, const void *wf,
+                const float *bf, const void *wg, const float *bg, void *fg, int E, void *stream) {
+  return ramp_i_upd_fg(x32, add_t, add_idx, x32_out, wf, bf, wg, bg, fg, E, nullptr, stream);
+}
+
+int ramp_upd_linear(const void *x, const void *w_packed, const float *bias, void *y, int rows, const int32_t *rows_dev,
+                    void *stream) {
+  if (rows < 0) return RAMP_EINVAL;
+  if (rows == 0) return RAMP_OK;
+  if (!x || !w_packed || !bias || !y) return RAMP_EINVAL;
+  hipLaunchKernelGGL(upd_linear_kernel, dim3(ramp_cdiv(rows, 16)), dim3(256), 0, (hipStream_t)stream,
+                     (const _Float16 *)x, (const _Float16 *)w_packed, bias, (_Float16 *)y, rows, rows_dev);
   RAMP_CHECK_LAUNCH();
   return RAMP_OK;
 }

@@ -141,7 +141,7 @@ def depth_median_fill(patches_state, n, F, patches_new):
 
 
 def depth_median_supported(F, M, P):
-    return F * M * P * P <= 4096
+    return F * M * P * P <= 8192
 
 
 def event_topk(events, k, nms_kernel_size=11, want_indices=False):

@@ -1,0 +1,246 @@
+"""Device-resident steady state of the tracker (csrc/track.hip, include/ramp_hip.h ``ramp_track_step``).
+
+``DeviceTrack`` owns the capacity-sized buffers of one ``Ramp_vo`` instance and the ``ramp_track`` descriptor that
+points at them and at the tracker's own state tensors.  Between ``enter()`` and ``leave()`` the factor graph, the
+keyframe count and the hidden state live on the GPU only: ``step()`` enqueues a whole frame (reference
+ramp/Ramp_vo.py:327-410: frame stores, update(), keyframe(), the next frame's append_factors) in one C call and never
+reads the device; ``leave()`` is the one synchronisation that hands the state back to the host mirror.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import c_i, c_p, c_sz
+
+DYN_WORDS = 32
+(DYN_N, DYN_NROW, DYN_E, DYN_KLO, DYN_FLO, DYN_W, DYN_REMOVED, DYN_K, DYN_NPREV, DYN_EPREV, DYN_EKEPT, DYN_STATUS,
+ DYN_NLOG, DYN_FRAME) = range(14)
+LOG_WORDS = 12
+COMMIT, UPDATE, KEYFRAME, MM_GIVEN = 1, 2, 4, 8
+CORR_ROW = 896
+
+
+def _ptr_fields(names):
+    return [(n, c_p) for n in names]
+
+
+class TrackWeights(ctypes.Structure):
+    _fields_ = (_ptr_fields(["corr_w1", "corr_w2", "corr_w3", "corr_b1", "corr_b2", "corr_b3", "corr_ln_w", "corr_ln_b",
+                             "norm_w", "norm_b", "c1_wa", "c1_wb", "c2_wa", "c2_wb", "c1_ba", "c1_bb", "c2_ba", "c2_bb",
+                             "kk_wf", "kk_wg", "kk_wh", "ij_wf", "ij_wg", "ij_wh", "kk_bf", "kk_bg", "kk_bh", "ij_bf",
+                             "ij_bg", "ij_bh", "ln1_w", "ln1_b", "ln2_w", "ln2_b"])
+                + [("gru_w", c_p * 6), ("gru_b", c_p * 6), ("heads_w", c_p), ("heads_b", c_p)]
+                + [(n, ctypes.c_float) for n in ("corr_ln_eps", "norm_eps", "ln1_eps", "ln2_eps")])
+
+
+class Track(ctypes.Structure):
+    _fields_ = ([(n, c_i) for n in ("M", "P", "mem", "n_rows", "patch_lifetime", "removal_window", "opt_window",
+                                    "keyframe_index", "motion_model", "feat_h", "feat_w", "E_cap", "kk_cap", "ij_cap",
+                                    "kkey_cap", "pkey_cap", "log_cap", "m_cap")]
+                + [("motion_damping", ctypes.c_float), ("pad0", ctypes.c_float), ("keyframe_thresh", ctypes.c_double)]
+                + _ptr_fields(["dyn", "poses", "patches", "intrinsics", "points", "tstamps", "index_map", "ixm", "colors",
+                               "imap", "gmap", "fmap1", "fmap2", "lmbda", "fe_colors", "fe_imap", "fe_gmap", "fe_fmap1",
+                               "fe_fmap2", "fe_patches"])
+                + [("graph", c_p * 2)]
+                + _ptr_fields(["kk_order", "kk_gid", "kk_seg", "kk_ngroups", "ij_order", "ij_gid", "ij_seg", "ij_ngroups",
+                               "kk_ukeys", "ij_ukeys", "ix", "jx", "plan_ws"])
+                + [("plan_ws_bytes", c_sz), ("w", TrackWeights)]
+                + _ptr_fields(["coords", "corr"]) + [("net", c_p * 3)]
+                + _ptr_fields(["fg", "ykk", "hkk", "yij", "hij", "relu_t", "target", "weight", "ba_ws"])
+                + [("ba_ws_bytes", c_sz)]
+                + _ptr_fields(["mm", "dlog", "edit_ws", "dyn_host"]) + [("probe", c_p * 5)])
+
+
+def supported(slam):
+    """the fused fp16 path on the tracker's own chunked buffers, with a full optimisation window"""
+    cfg = slam.cfg
+    return (slam.dtype == torch.half and slam._chunked and slam._lazy_net and slam.P == 3 and slam.DIM == 384
+            and (slam.M * 3) % 16 == 0 and 3 * slam.M * 9 <= 8192 and cfg.MOTION_MODEL in ("DAMPED_LINEAR",)
+            and cfg.PATCH_LIFETIME <= cfg.REMOVAL_WINDOW + 1 and cfg.KEYFRAME_INDEX >= 2
+            and 6 * cfg.OPTIMIZATION_WINDOW <= 192)
+
+
+class DeviceTrack:
+    def __init__(self, slam):
+        assert supported(slam)
+        lib = _lib.lib()
+        cfg, dev = slam.cfg, slam.device
+        M, r, R = slam.M, cfg.PATCH_LIFETIME, cfg.REMOVAL_WINDOW
+        self.slam = slam
+        self.E_cap = E_cap = (R + 2) * (2 * r - 1) * M
+        self.kk_cap = kk_cap = (R + 2) * M
+        self.ij_cap = ij_cap = min((R + 2) * (2 * r), (R + r + 1) ** 2)
+        self.kkey_cap = (R + 2) * M
+        self.pkey_cap = (R + r + 1) ** 2
+        self.log_cap = 4096
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
+        e = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
+        i32, i64, f32, f16 = torch.int32, torch.int64, torch.float32, torch.float16
+        self.dyn = z(DYN_WORDS, i32)
+        self.dyn_host = torch.zeros(DYN_WORDS, dtype=i32).pin_memory()
+        self.graph = [z((4, E_cap), i64), z((4, E_cap), i64)]
+        self.kk = dict(order=z(E_cap, i32), gid=z(E_cap, i32), seg=z(kk_cap + 2, i32), ngroups=z(1, i32),
+                       ukeys=z(kk_cap + 2, i64))
+        self.ij = dict(order=z(E_cap, i32), gid=z(E_cap, i32), seg=z(ij_cap + 2, i32), ngroups=z(1, i32),
+                       ukeys=z(ij_cap + 2, i64))
+        self.ix, self.jx = z(E_cap, i64), z(E_cap, i64)
+        self.plan_ws = e(lib.ramp_track_plan_workspace_bytes(E_cap, self.kkey_cap, self.pkey_cap), torch.uint8)
+        self.coords = e((E_cap, 2, 3, 3), f32)
+        self.corr = e((E_cap, CORR_ROW), f16)
+        self.net = [z((E_cap, 384), f32) for _ in range(3)]
+        self.fg = e((E_cap, 768), f16)
+        self.ykk, self.hkk = z((kk_cap, 384), f16), z((kk_cap, 384), f16)
+        self.yij, self.hij = z((ij_cap, 384), f16), z((ij_cap, 384), f16)
+        self.relu_t = e((E_cap, 384), f16)
+        self.target, self.weight = z((E_cap, 2), f32), z((E_cap, 2), f32)
+        self.ba_ws = e(lib.ramp_track_ba_workspace_bytes(E_cap, slam.N, M, cfg.OPTIMIZATION_WINDOW, kk_cap, ij_cap),
+                       torch.uint8)
+        self.mm = z(2, f32)
+        self.dlog = z((self.log_cap, LOG_WORDS), f32)
+        self.edit_ws = z(3 * ((E_cap + 1023) // 1024) + 8, i32)
+        self.ixm = (torch.arange(slam.N * M, device=dev) // M).contiguous()
+        self.k_new = z(4, f32)
+        self.cur = 0
+        self.active = False
+        self._wkey = None
+        self._fe_key = None
+        self._keep = []
+        t = self.t = Track()
+        assert ctypes.sizeof(Track) == lib.ramp_track_sizeof(), "ramp_track mirror out of date"
+        h, w = slam.fmap1_.shape[1], slam.fmap1_.shape[3]
+        for name, val in dict(M=M, P=slam.P, mem=slam.mem, n_rows=slam.N, patch_lifetime=r, removal_window=R,
+                              opt_window=cfg.OPTIMIZATION_WINDOW, keyframe_index=cfg.KEYFRAME_INDEX, motion_model=1,
+                              feat_h=h, feat_w=w, E_cap=E_cap, kk_cap=kk_cap, ij_cap=ij_cap, kkey_cap=self.kkey_cap,
+                              pkey_cap=self.pkey_cap, log_cap=self.log_cap, m_cap=slam.N * M).items():
+            setattr(t, name, int(val))
+        t.motion_damping = float(cfg.MOTION_DAMPING)
+        t.keyframe_thresh = float(cfg.KEYFRAME_THRESH)
+        P = lambda x: x.data_ptr()
+        for name, ten in dict(dyn=self.dyn, poses=slam.poses_, patches=slam.patches_, intrinsics=slam.intrinsics_,
+                              points=slam.points_, tstamps=slam.tstamps_, index_map=slam.index_map_, ixm=self.ixm,
+                              colors=slam.colors_, imap=slam.imap_, gmap=slam.gmap_, fmap1=slam.fmap1_, fmap2=slam.fmap2_,
+                              lmbda=slam.lmbda, kk_order=self.kk["order"], kk_gid=self.kk["gid"], kk_seg=self.kk["seg"],
+                              kk_ngroups=self.kk["ngroups"], kk_ukeys=self.kk["ukeys"], ij_order=self.ij["order"],
+                              ij_gid=self.ij["gid"], ij_seg=self.ij["seg"], ij_ngroups=self.ij["ngroups"],
+                              ij_ukeys=self.ij["ukeys"], ix=self.ix, jx=self.jx, plan_ws=self.plan_ws,
+                              coords=self.coords, corr=self.corr, fg=self.fg, ykk=self.ykk, hkk=self.hkk, yij=self.yij,
+                              hij=self.hij, relu_t=self.relu_t, target=self.target, weight=self.weight,
+                              ba_ws=self.ba_ws, mm=self.mm, dlog=self.dlog, edit_ws=self.edit_ws,
+                              dyn_host=self.dyn_host).items():
+            setattr(t, name, P(ten))
+        t.plan_ws_bytes, t.ba_ws_bytes = self.plan_ws.numel(), self.ba_ws.numel()
+        t.graph[0], t.graph[1] = P(self.graph[0]), P(self.graph[1])
+        for i in range(3):
+            t.net[i] = P(self.net[i])
+
+    # ------------------------------------------------------------------ weights / front-end outputs
+    def bind_weights(self, fu):
+        w = fu.weights()
+        if self._wkey == fu._key:
+            return
+        tw = self.t.w
+        P = lambda x: x.data_ptr()
+        tw.corr_w1, tw.corr_b1 = map(P, w["corr1_pack"])
+        tw.corr_w2, tw.corr_b2, tw.corr_w3, tw.corr_b3 = map(P, w["tail_pack"])
+        tw.corr_ln_w, tw.corr_ln_b, tw.corr_ln_eps = P(w["corr_ln"][0]), P(w["corr_ln"][1]), float(w["corr_ln"][2])
+        tw.norm_w, tw.norm_b, tw.norm_eps = P(w["norm"][0]), P(w["norm"][1]), float(w["norm"][2])
+        tw.c1_wa, tw.c1_ba, tw.c1_wb, tw.c1_bb = map(P, w["c1_pack"])
+        tw.c2_wa, tw.c2_ba, tw.c2_wb, tw.c2_bb = map(P, w["c2_pack"])
+        tw.kk_wf, tw.kk_bf, tw.kk_wg, tw.kk_bg = map(P, w["kk_fg_pack"])
+        tw.ij_wf, tw.ij_bf, tw.ij_wg, tw.ij_bg = map(P, w["ij_fg_pack"])
+        tw.kk_wh, tw.kk_bh = map(P, w["kk_h_pack"])
+        tw.ij_wh, tw.ij_bh = map(P, w["ij_h_pack"])
+        tw.ln1_w, tw.ln1_b, tw.ln1_eps = P(w["ln1"][0]), P(w["ln1"][1]), float(w["ln1"][2])
+        tw.ln2_w, tw.ln2_b, tw.ln2_eps = P(w["ln2"][0]), P(w["ln2"][1]), float(w["ln2"][2])
+        wp, bs = w["gru_pack"][0], w["gru_pack"][1]
+        for i in range(6):
+            tw.gru_w[i], tw.gru_b[i] = P(wp[i]), P(bs[i])
+        tw.heads_w, tw.heads_b = map(P, w["heads_pack"])
+        self._wkey = fu._key
+
+    def bind_front_end(self, ex, patches):
+        """the static output buffers of the front-end graph (the same objects every frame)"""
+        key = (id(ex), patches.data_ptr())
+        if self._fe_key == key:
+            return True
+        ok = (ex is not None and ex["fmap"].dtype == torch.float16 and ex["chunked"] and patches.is_contiguous()
+              and patches.dtype == torch.float32
+              and all(ex[k].data_ptr() % 16 == 0 and ex[k].is_contiguous()
+                      for k in ("colors", "imap", "gmap", "fmap", "fmap2")))
+        if not ok:
+            return False
+        t = self.t
+        t.fe_colors, t.fe_imap, t.fe_gmap = ex["colors"].data_ptr(), ex["imap"].data_ptr(), ex["gmap"].data_ptr()
+        t.fe_fmap1, t.fe_fmap2, t.fe_patches = ex["fmap"].data_ptr(), ex["fmap2"].data_ptr(), patches.data_ptr()
+        self._fe_key = key
+        self._keep = [ex, patches]
+        return True
+
+    # ------------------------------------------------------------------ host <-> device hand-over
+    def enter(self, ii, jj, kk, rows, new_edges, net_buf, n):
+        """host state after keyframe() -> device: kept factors (host arrays, ``rows`` = their hidden-state rows in
+        ``net_buf``) followed by the factors the next frame adds; n = Ramp_vo.n"""
+        slam = self.slam
+        e_ii, e_jj, e_kk = new_edges
+        Ek, ne = len(ii), len(e_kk)
+        E = Ek + ne
+        if E > self.E_cap or net_buf.shape[0] > self.E_cap:
+            return False
+        g = torch.empty((4, self.E_cap), dtype=torch.int64).pin_memory() if not hasattr(self, "_g_host") else self._g_host
+        self._g_host = g
+        gn = g.numpy()
+        for row, a, b, fill in ((0, ii, e_ii, None), (1, jj, e_jj, None), (2, kk, e_kk, None), (3, rows, None, -1)):
+            gn[row, :Ek] = a
+            gn[row, Ek:E] = b if b is not None else fill
+        self.cur = 0
+        self.graph[0][:, :E].copy_(g[:, :E], non_blocking=True)
+        if net_buf.data_ptr() != self.net[0].data_ptr():
+            self.net[0][:net_buf.shape[0]].copy_(net_buf)
+        M = slam.M
+        k_lo = int(gn[2, :E].min())
+        f_lo = int(min(gn[0, :E].min(), gn[1, :E].min()))
+        d = self.dyn_host.numpy()
+        d[:] = 0
+        d[DYN_N], d[DYN_NROW], d[DYN_E] = n + 1, n, E
+        d[DYN_KLO], d[DYN_FLO], d[DYN_W] = (k_lo // M) * M, f_lo, n + 1 - f_lo
+        d[DYN_NPREV], d[DYN_EPREV], d[DYN_EKEPT] = n, net_buf.shape[0], Ek
+        d[DYN_FRAME] = slam.counter - 1
+        if (n + 1) * M - d[DYN_KLO] > self.kkey_cap or d[DYN_W] ** 2 > self.pkey_cap:
+            return False
+        self.dyn.copy_(self.dyn_host, non_blocking=True)
+        _lib.check(_lib.lib().ramp_track_plan(ctypes.byref(self.t), self.cur, _lib.stream()), "ramp_track_plan")
+        self.active = True
+        self._frames = 0
+        return True
+
+    def step(self, counter, flags, k_new=None, gate_event=None):
+        ev = ctypes.c_void_p(gate_event) if gate_event else None
+        _lib.check(_lib.lib().ramp_track_step(ctypes.byref(self.t), self.cur, int(counter), int(flags),
+                                              _lib.ptr(k_new), ev, _lib.stream()), "ramp_track_step")
+        if flags & KEYFRAME:
+            self.cur ^= 1
+        self._frames += 1
+
+    def lazy_state(self):
+        """the host's (possibly one or two frames old) copy of dyn -- never waited for"""
+        return self.dyn_host.numpy()
+
+    def leave(self):
+        """synchronise and return the host-side view of the state: dict(n, ii, jj, kk, rows (host arrays of the kept
+        factors), net (device [EPREV, 384] view), log (list of (t1, t0, dP[7] device tensor)), status)"""
+        torch.cuda.current_stream().synchronize()
+        d = self.dyn.cpu().numpy()
+        Ek, n = int(d[DYN_EKEPT]), int(d[DYN_NROW])
+        g = self.graph[self.cur][:, :Ek].cpu().numpy()
+        nlog = int(d[DYN_NLOG])
+        log = []
+        if nlog:
+            raw = self.dlog[:nlog].clone()
+            ints = raw[:, :2].contiguous().view(torch.int32).cpu().numpy()
+            log = [(int(ints[i, 0]), int(ints[i, 1]), raw[i, 2:9].clone()) for i in range(nlog)]
+        self.active = False
+        return dict(n=n, ii=np.ascontiguousarray(g[0]), jj=np.ascontiguousarray(g[1]), kk=np.ascontiguousarray(g[2]),
+                    rows=np.ascontiguousarray(g[3]), net=self.net[0][:int(d[DYN_EPREV])], log=log,
+                    status=int(d[DYN_STATUS]))

@@ -89,6 +89,8 @@ class FusedUpdate:
             w["c2_pack"] = (pack_linear_f16(m.c2[0].weight), hb(m.c2[0]), pack_linear_f16(m.c2[2].weight), hb(m.c2[2]))
             for name, agg in (("kk_fg_pack", m.agg_kk), ("ij_fg_pack", m.agg_ij)):
                 w[name] = (pack_linear_f16(agg.f.weight), hb(agg.f), pack_linear_f16(agg.g.weight), hb(agg.g))
+            w["kk_h_pack"] = (pack_linear_f16(m.agg_kk.h.weight), hb(m.agg_kk.h))
+            w["ij_h_pack"] = (pack_linear_f16(m.agg_ij.h.weight), hb(m.agg_ij.h))
             w["corr1_pack"] = (pack_linear_f16(F.pad(m.corr[0].weight, (0, CORR_ROW - m.corr[0].weight.shape[1]))),
                                hb(m.corr[0]))
             w["heads_pack"] = (w["heads"][0], w["heads"][1].float().contiguous())
@@ -152,6 +154,14 @@ class FusedUpdate:
                                              ptr(y), int(max_groups), _code[self.dtype], stream()),
               "ramp_upd_segment_softmax")
         return y
+
+    def h_lin(self, y, pack, groups):
+        """SoftAgg's `h` Linear on the group table, rows below the device-side group count only
+        (csrc/update_mlp.hip::upd_linear_kernel; the device-resident step runs the same kernel)"""
+        out = torch.empty_like(y)
+        check(lib().ramp_upd_linear(ptr(y), ptr(pack[0]), ptr(pack[1]), ptr(out), y.shape[0], ptr(groups.ngroups),
+                                    stream()), "ramp_upd_linear")
+        return out
 
     # ------------------------------------------------------------------ forward
     def hidden(self, net, inp_table, inp_idx, inp_mod, corr, plan, net_map=None):
@@ -220,9 +230,10 @@ class FusedUpdate:
         if net_t is None:
             # fused path: the [f | g] GEMM forms its own fp16 input tile from the fp32 state (and applies the
             # previous SoftAgg's expand-and-add on the way): no fp16 state copy, no separate row pass
-            hy = self.lin(self.seg(self.fg(net32, None, None, w["kk_fg_pack"], E), plan.g_kk, plan.max_kk), w["kk_h"])
-            hy = self.lin(self.seg(self.fg(net32, hy, plan.g_kk.gid, w["ij_fg_pack"], E), plan.g_ij, plan.max_ij),
-                          w["ij_h"])
+            hy = self.h_lin(self.seg(self.fg(net32, None, None, w["kk_fg_pack"], E), plan.g_kk, plan.max_kk),
+                            w["kk_h_pack"], plan.g_kk)
+            hy = self.h_lin(self.seg(self.fg(net32, hy, plan.g_kk.gid, w["ij_fg_pack"], E), plan.g_ij, plan.max_ij),
+                            w["ij_h_pack"], plan.g_ij)
         else:
             hy = self.lin(self.seg(self.lin(net_t, w["kk_fg"]), plan.g_kk, plan.max_kk), w["kk_h"])
             _, net_t = self.row_fuse(E, A=net32, B=hy, idxB32=plan.g_kk.gid, out_f32=net32, want_t=True)

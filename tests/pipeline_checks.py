@@ -112,9 +112,10 @@ def run_ramp_vo(device, mixed=False):
         image, events, K, mask = stream.frame(t)
         frame_no[0] = t
         slam(t, input_tensor=(events.to(device), image.to(device), mask), intrinsics=K)
-        rec["n"].append(slam.n); rec["m"].append(slam.m); rec["E"].append(len(slam._ii))
-        rec["pose"].append(slam.poses_[max(slam.n - 1, 0)].cpu().numpy().copy())
-        rec["depth_med"].append(float(slam.patches_[:max(slam.n, 1), :, 2].median()))
+        st = slam.peek()                            # (does not take a device-resident state back to the host)
+        rec["n"].append(st["n"]); rec["m"].append(st["n"] * slam.M); rec["E"].append(st["E"])
+        rec["pose"].append(slam.poses_[max(st["n"] - 1, 0)].cpu().numpy().copy())
+        rec["depth_med"].append(float(slam.patches_[:max(st["n"], 1), :, 2].median()))
         rec["init"].append(slam.is_initialized)
     traj, ts = slam.terminate()
     return slam, rec, traj, ts
@@ -243,9 +244,9 @@ def run_trajectory(tag, device, mixed=False, pipelined=False, **cfg_extra):
         image, events, K, mask = stream.frame(t)
         frame_no[0] = t
         slam(t, input_tensor=(events.to(device), image.to(device), mask), intrinsics=K)
-        slam.settle()
-        rec["n"].append(slam.n); rec["E"].append(len(slam._ii))
-        rec["pose"].append(slam.poses_[max(slam.n - 1, 0)].cpu().numpy().copy())
+        st = slam.peek()                            # (does not take a device-resident state back to the host)
+        rec["n"].append(st["n"]); rec["E"].append(st["E"])
+        rec["pose"].append(slam.poses_[max(st["n"] - 1, 0)].cpu().numpy().copy())
     traj, ts = slam.terminate()
     return slam, rec, traj, ts
 

@@ -830,3 +830,126 @@ def test_frame_gather_equals_the_separate_patchify_launches(dtype):
     col_ref = ((c_ref.flip(-1) + 0.5) * (255.0 / 2)).to(torch.uint8)
     assert torch.equal(g, g_ref) and torch.equal(ip, i_ref)
     assert torch.equal(pt, p_ref) and torch.equal(cl, c_ref) and torch.equal(col, col_ref)
+
+
+# ------------------------------------------------------- device-resident tracking step (csrc/track.hip)
+@torch.no_grad()
+@pytest.mark.parametrize("remove", [False, True])
+def test_device_graph_edit_matches_host_edit(remove):
+    """Ramp_vo.keyframe() + the next frame's append_factors as kernels (trk_flag / trk_decide / trk_apply, then the
+    graph plan with device-side sizes) against the host-side restatements the host-driven path uses: the kept factors
+    and their hidden-state rows (ramp_graph_edit_host), the new factors (Ramp_vo._new_edges, the reference's meshgrid),
+    the rows of the per-frame buffers after the shift, the (t0, dP) log entry, and the plan (GraphPlan.build with
+    host-side sizes).  Integer outputs exact; dP bit-equal to the lietorch ops."""
+    from rampvo_amd import _lib, ops, track_dev as td
+    from rampvo_amd.config import make_cfg
+    from rampvo_amd.lietorch import SE3
+    from rampvo_amd.net import GraphPlan
+    from rampvo_amd.Ramp_vo import Ramp_vo
+    from rampvo_amd.synthetic import make_network
+    cfg = make_cfg("default", PATCHES_PER_FRAME=48, MIXED_PRECISION=True)
+    slam = Ramp_vo(cfg, make_network("SingleScale"), {"event_bias": True}, ht=128, wd=192)
+    dv = td.DeviceTrack(slam)
+    M, r, R, KI = slam.M, cfg.PATCH_LIFETIME, cfg.REMOVAL_WINDOW, cfg.KEYFRAME_INDEX
+    rng = np.random.default_rng(11 + remove)
+    n = 31                                       # keyframes when keyframe() runs
+    # a plausible graph: patches of the frames in the removal window (a few older ones that the edit must cull), each
+    # connected to some frames within its lifetime; in append order of nothing in particular
+    E = 9000
+    kk = rng.integers((n - R - 3) * M, n * M, E).astype(np.int64)
+    ii = kk // M
+    jj = np.clip(ii + rng.integers(-r + 1, r, E), 0, n - 1).astype(np.int64)
+    g = np.zeros((4, dv.E_cap), np.int64)
+    g[0, :E], g[1, :E], g[2, :E], g[3, :E] = ii, jj, kk, np.arange(E)
+    dv.graph[0].copy_(torch.from_numpy(g).cuda())
+    dv.cur = 0
+    flo = int(min(ii.min(), jj.min()))
+    d = np.zeros(td.DYN_WORDS, np.int32)
+    d[td.DYN_N], d[td.DYN_NROW], d[td.DYN_E] = n, n - 1, E
+    d[td.DYN_KLO], d[td.DYN_FLO], d[td.DYN_W] = int(kk.min()) // M * M, flo, n - flo
+    dv.dyn.copy_(torch.from_numpy(d).cuda())
+    # recognisable per-frame state
+    slam.tstamps_[:n] = torch.arange(100, 100 + n, device="cuda")
+    xi = torch.from_numpy((0.2 * rng.normal(size=(n, 6))).astype(np.float32)).cuda()
+    slam.poses_[:n] = ops.se3_unary("ramp_se3_exp", xi, 6, 7)
+    for buf in (slam.patches_, slam.intrinsics_, slam.imap_, slam.gmap_, slam.fmap1_, slam.fmap2_):
+        buf.copy_(torch.randn(buf.shape, device="cuda").to(buf.dtype))
+    slam.colors_.copy_(torch.randint(0, 255, slam.colors_.shape, device="cuda", dtype=torch.uint8))
+    before = {k: getattr(slam, k).clone() for k in ("tstamps_", "colors_", "poses_", "patches_", "intrinsics_", "imap_",
+                                                     "gmap_", "fmap1_", "fmap2_")}
+    thresh = cfg.KEYFRAME_THRESH
+    dv.mm.copy_(torch.tensor([thresh - 1.0, thresh - 3.0] if remove else [thresh + 1.0, thresh - 0.5], device="cuda"))
+    dv.active = True
+    dv._frames = 0
+    dv.step(counter=77, flags=td.KEYFRAME | td.MM_GIVEN)
+    torch.cuda.synchronize()
+    dd = dv.dyn.cpu().numpy()
+    # ---- host restatement
+    k = n - KI
+    n_after = n - 1 if remove else n
+    buf = np.empty((4, E), np.int64)
+    Ek = _lib.lib().ramp_graph_edit_host(ii.ctypes.data, jj.ctypes.data, kk.ctypes.data, None, E, M, k if remove else -1,
+                                         n_after, R, buf.ctypes.data, E, None)
+    e_ii, e_jj, e_kk = slam._new_edges(n_after + 1)
+    ne = len(e_kk)
+    assert (dd[td.DYN_REMOVED], dd[td.DYN_K], dd[td.DYN_NPREV], dd[td.DYN_EPREV]) == (int(remove), k, n, E)
+    assert (dd[td.DYN_EKEPT], dd[td.DYN_E], dd[td.DYN_NROW], dd[td.DYN_N]) == (Ek, Ek + ne, n_after, n_after + 1)
+    assert dd[td.DYN_STATUS] == 0 and dd[td.DYN_FRAME] == 77
+    got = dv.graph[1][:, :Ek + ne].cpu().numpy()
+    assert np.array_equal(got[:, :Ek], buf[:, :Ek])
+    assert np.array_equal(got[0, Ek:], e_ii) and np.array_equal(got[1, Ek:], e_jj) and np.array_equal(got[2, Ek:], e_kk)
+    assert (got[3, Ek:] == -1).all()
+    # ---- per-frame rows
+    for name, ring in (("tstamps_", 0), ("colors_", 0), ("poses_", 0), ("patches_", 0), ("intrinsics_", 0),
+                       ("imap_", slam.mem), ("gmap_", slam.mem), ("fmap1_", slam.mem), ("fmap2_", slam.mem)):
+        exp = before[name].clone()
+        if remove:
+            for row in range(k, n - 1):
+                exp[row % ring if ring else row] = exp[(row + 1) % ring if ring else row + 1]
+        assert torch.equal(getattr(slam, name), exp), name
+    # ---- delta log
+    assert dd[td.DYN_NLOG] == int(remove)
+    if remove:
+        ent = dv.dlog[0].cpu()
+        t1, t0 = ent[:2].view(torch.int32).tolist()
+        assert (t1, t0) == (100 + k, 100 + k - 1)
+        dP = (SE3(before["poses_"][k]) * SE3(before["poses_"][k - 1]).inv()).data
+        assert torch.equal(ent[2:9].cuda(), dP)
+    # ---- plan of the new graph
+    cu_ = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    a_ii, a_jj, a_kk = cu_(got[0]), cu_(got[1]), cu_(got[2])
+    f_lo, f_hi = int(min(got[0].min(), got[1].min())), n_after + 1
+    assert dd[td.DYN_FLO] == f_lo and dd[td.DYN_W] == f_hi - f_lo
+    k_lo = int(dd[td.DYN_KLO])
+    assert k_lo <= got[2].min()
+    ref = GraphPlan.build(a_ii, a_jj, a_kk, max_kk=dv.kk_cap, max_ij=dv.ij_cap, kk_range=(k_lo, f_hi * M),
+                          frame_range=(f_lo, f_hi))
+    Et = Ek + ne
+    for mine, theirs in ((dv.kk, ref.g_kk), (dv.ij, ref.g_ij)):
+        ng = int(theirs.ngroups.item())
+        assert int(mine["ngroups"].item()) == ng
+        assert torch.equal(mine["order"][:Et], theirs.order[:Et]) and torch.equal(mine["gid"][:Et], theirs.gid[:Et])
+        assert torch.equal(mine["seg"][:ng + 1], theirs.seg_start[:ng + 1])
+        assert torch.equal(mine["ukeys"][:ng], theirs.ukeys[:ng])
+    assert torch.equal(dv.ix[:Et], ref.ix) and torch.equal(dv.jx[:Et], ref.jx)
+
+
+@torch.no_grad()
+def test_upd_linear_matches_fp32_torch():
+    """SoftAgg's `h` Linear on the group table (csrc/update_mlp.hip::upd_linear_kernel) against plain fp32 torch on the
+    fp16-rounded operands; rows at and past the device-side row count are left alone"""
+    from rampvo_amd import _lib
+    from rampvo_amd.update_fused import pack_linear_f16
+    torch.manual_seed(3)
+    rows, live = 1000, 933
+    x = torch.randn(rows, 384, device="cuda").half()
+    lin = torch.nn.Linear(384, 384).cuda()
+    y = torch.full((rows, 384), 7.0, device="cuda").half()
+    nd = torch.tensor([live], dtype=torch.int32, device="cuda")
+    _lib.check(_lib.lib().ramp_upd_linear(_lib.ptr(x), _lib.ptr(pack_linear_f16(lin.weight)),
+                                          _lib.ptr(lin.bias.detach().half().float().contiguous()), _lib.ptr(y), rows,
+                                          _lib.ptr(nd), _lib.stream()), "ramp_upd_linear")
+    ref = x.float() @ lin.weight.detach().half().float().t() + lin.bias.detach().half().float()
+    err = (y[:live].float() - ref[:live]).abs().max().item()
+    assert err <= 2e-3 * ref.abs().max().item(), err
+    assert bool((y[live:] == 7.0).all())

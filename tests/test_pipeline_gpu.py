@@ -243,35 +243,41 @@ def test_trajectory_fp8_encoder_against_reference_run(tag):
 
 
 @torch.no_grad()
-def test_frame_pipelining_does_not_change_results():
-    """Ramp_vo.inputs_ready (front end of frame t+1 launched before the host waits for frame t's keyframe
-    decision, on its own stream) is scheduling only: same graph, same poses, same depths -- bit for bit."""
+def test_device_resident_steps_and_frame_pipelining_do_not_change_results():
+    """The device-resident steady state (keyframe decision, graph edit, new factors and graph plan as kernels, sizes read
+    from device memory: csrc/track.hip) against the host-driven path that reads the motion test back and edits the graph
+    on the host like the reference -- and Ramp_vo.inputs_ready (the next front end on its own stream next to the gru chain
+    and BA), which is scheduling only: same graph, same poses, same depths, same trajectory -- bit for bit."""
     from rampvo_amd.config import make_cfg
     from rampvo_amd.Ramp_vo import Ramp_vo
     from rampvo_amd.synthetic import SyntheticStream, make_network
-    T = 30
+    T = 44
     stream = SyntheticStream(240, 320, T, seed=77, device="cuda")
     frames = [stream.frame(t) for t in range(T)]
     torch.cuda.synchronize()
     out = []
-    for ready in (False, True):
+    for device_steps, ready in ((False, False), (True, False), (True, True)):
         torch.manual_seed(5)
         slam = Ramp_vo(make_cfg("default", PATCHES_PER_FRAME=48, MIXED_PRECISION=True),
                        make_network("SingleScale"), {"event_bias": True}, ht=240, wd=320)
+        slam.device_steps = device_steps
         slam.inputs_ready = ready
-        pipelined = 0
+        resident = 0
         for t, (im, ev, K, mask) in enumerate(frames):
             slam(t, input_tensor=(ev, im, mask), intrinsics=K)
-            pipelined += slam._pending is not None
-        assert (pipelined > 5) == ready, pipelined
-        slam.update()                                   # settles the pending decision first
+            resident += slam._dev is not None and slam._dev.active
+        assert (resident > 20) == device_steps, resident
+        slam.update()                                   # hands the state back to the host first
         traj, ts = slam.terminate()
-        out.append((slam.n, slam._ii.copy(), slam._kk.copy(), slam.poses_[:slam.n].cpu().numpy(),
-                    slam.patches_[:slam.n].cpu().numpy(), traj, ts))
-    a, b = out
-    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
-    for x, y in zip(a[3:], b[3:]):
-        assert np.array_equal(x, y)
+        out.append((slam.n, slam._ii.copy(), slam._jj.copy(), slam._kk.copy(), slam.poses_[:slam.n].cpu().numpy(),
+                    slam.patches_[:slam.n].cpu().numpy(), slam.tstamps_[:slam.n].cpu().numpy(),
+                    slam.points_[:slam.m].cpu().numpy(), slam.colors_[:slam.n].cpu().numpy(), traj, ts,
+                    sorted(slam.delta.keys())))
+    for b in out[1:]:
+        a = out[0]
+        assert a[0] == b[0] and a[-1] == b[-1]
+        for x, y in zip(a[1:-1], b[1:-1]):
+            assert np.array_equal(x, y)
 
 
 @torch.no_grad()
@@ -462,31 +468,32 @@ def test_front_end_graph_follows_weight_updates_and_state_reloads():
 
 
 @torch.no_grad()
-def test_extra_update_between_frames_does_not_reuse_a_stale_prepared_graph():
-    """keyframe() prepares the next frame's graph together with a row map into the hidden-state buffer of that moment.
-    An update() between two frames (rampvo_amd.evaluate.run_pose_pred / reference evaluate.py:206-208 run twelve)
-    or a read of ``.net`` replaces that buffer: the prepared graph must not be adopted with its old map (it indexed
-    rows past the new buffer).  Same result as a tracker whose prepared graph is dropped by hand."""
+def test_extra_update_between_frames_hands_the_state_back_and_forth():
+    """An update() between two frames (rampvo_amd.evaluate.run_pose_pred / reference evaluate.py:206-208 run twelve) or a
+    read of ``.net`` while the steady state is device resident: the state is handed back to the host (settle), the
+    update runs host-driven, the next frame hands it over again.  Same result as a tracker that never leaves the host."""
     from rampvo_amd.config import make_cfg
     from rampvo_amd.Ramp_vo import Ramp_vo
     from rampvo_amd.synthetic import SyntheticStream, make_network
-    T, K = 18, 14
+    T, K = 26, 18
     stream = SyntheticStream(240, 320, T, seed=8, device="cuda")
     data = [stream.frame(t) for t in range(T)]
     out = []
-    for by_hand in (False, True):
+    for device_steps in (True, False):
         cfg = make_cfg("default", PATCHES_PER_FRAME=32, MIXED_PRECISION=True)
         slam = Ramp_vo(cfg, make_network("SingleScale", profile="damped"), {"event_bias": True}, ht=240, wd=320)
+        slam.device_steps = device_steps
+        resident = 0
         for t in range(T):
             im, ev, Kc, mask = data[t]
             slam(t, input_tensor=(ev, im, mask), intrinsics=Kc)
+            resident += slam._dev is not None and slam._dev.active
             if t == K:
                 slam.update()
                 assert slam.net.shape[1] == len(slam._ii)          # also materialises the state
-                if by_hand:
-                    slam._pre_cache = None
+        assert (resident > 5) == device_steps
+        slam.settle()
         assert bool(torch.isfinite(slam._net_buf).all()) and bool(torch.isfinite(slam.poses_[:slam.n]).all())
-        out.append((slam.poses_[:slam.n].clone(), slam._net_buf.clone(), slam._net_rows().copy()))
-        slam.close()
-    assert torch.equal(out[0][0], out[1][0])
-    assert torch.equal(out[0][1][0][out[0][2]], out[1][1][0][out[1][2]])
+        out.append((slam.poses_[:slam.n].clone(), slam.net.clone(), slam._ii.copy()))
+    assert torch.equal(out[0][0], out[1][0]) and np.array_equal(out[0][2], out[1][2])
+    assert torch.equal(out[0][1], out[1][1])
