@@ -502,7 +502,21 @@ def main():
     dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    host = {}
     if world > 1:
+        # N trackers on one host: each rank's Python needs about one core (a tracked frame is one C call in steady
+        # state: ~0.2 ms of host time per 1.1 ms step).  Without this every rank brings torch's intra-op pool of
+        # all-cores threads and the ranks migrate over each other's caches: one thread per rank, and a private,
+        # contiguous slice of the cores this job may use (contiguous = same NUMA node / CCD on the usual enumeration)
+        torch.set_num_threads(1)
+        try:
+            cores = sorted(os.sched_getaffinity(0))
+            per = max(len(cores) // world, 1)
+            mine = cores[(local_rank * per) % len(cores):][:per] or cores
+            os.sched_setaffinity(0, mine)
+            host = {"threads": 1, "cores_of_rank0": "%d-%d" % (mine[0], mine[-1]), "cores_per_rank": len(mine)}
+        except (AttributeError, OSError):
+            host = {"threads": 1}
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
@@ -645,6 +659,7 @@ def main():
         }
         if per_rank is not None:
             out["config"]["per_rank_kfps_E_n_chk"] = per_rank
+            out["config"]["host_placement"] = host
         rl = ctimer.summary(2 if args.mixed else 4, slam)
         assert rl is not None or args.no_kernel_timing, "no correlation launch was timed: the roofline hook is stale"
         if rl is not None:

@@ -534,7 +534,8 @@ int ramp_upd_linear(const void *x, const void *w_packed, const float *bias, void
 #define RAMP_DYN_EPREV 9    /* factors before the edit                                                            */
 #define RAMP_DYN_EKEPT 10   /* factors the edit kept (next graph = kept ++ new)                                   */
 #define RAMP_DYN_STATUS 11  /* sticky bits: 1 BA pose step dropped, 2 BA pair list overflow (ramp_ba_forward's
-                               info), 4 factor capacity exceeded, 8 group-by key out of range, 16 delta log full  */
+                               info), 4 factor capacity exceeded, 8 group-by key out of range, 16 delta log full,
+                               32 a step's E_bound was below the live factor count                                */
 #define RAMP_DYN_NLOG 12    /* entries written to the delta log                                                   */
 #define RAMP_DYN_FRAME 13   /* `counter` of the last frame stepped (tags the host's lazy copy)                    */
 #define RAMP_TRACK_LOG 12   /* floats per delta-log entry: t1, t0 (as int32 bit patterns), dP[7], pad             */
@@ -616,9 +617,11 @@ int ramp_track_plan(const ramp_track *t, int cur, void *stream);
 /* One tracked frame (flags = COMMIT | UPDATE | KEYFRAME), a bare update() (flags = UPDATE), ...; `cur` = which half of
  * graph[] holds the current graph (KEYFRAME writes the next one to 1 - cur).  k_new: optional device [4] intrinsics at
  * feature resolution when they differ from the previous frame's.  gate_event: optional hipEvent_t recorded before the
- * last kernel of the update operator (where the next frame's front end may start on another stream).              */
-int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, const float *k_new, void *gate_event,
-                    void *stream);
+ * last kernel of the update operator (where the next frame's front end may start on another stream).  E_bound: the
+ * caller's upper bound of the current factor count (from its lazy copy of dyn; 0 = E_cap) -- sizes the per-factor
+ * launches; a bound below the live count raises status bit 32 instead of truncating silently.                      */
+int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, int E_bound, const float *k_new,
+                    void *gate_event, void *stream);
 
 #ifdef __cplusplus
 }

@@ -260,7 +260,8 @@ class Ramp_vo:
         self._note_ba_flags(st["status"] & 3)
         if st["status"] & ~3:
             raise RuntimeError("device-resident tracker: capacity exceeded (status bits %d: 4 = factor list, "
-                               "8 = group-by key range, 16 = delta log)" % st["status"])
+                               "8 = group-by key range, 16 = delta log, 32 = launch bound below the factor count)"
+                               % st["status"])
 
     def peek(self):
         """(keyframes, factors) right now -- synchronises, but leaves a device-resident state where it is (tests and

@@ -108,7 +108,7 @@ SIGNATURES = {
     "ramp_track_plan_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "ramp_track_ba_workspace_bytes": (c_sz, [c_i] * 6),
     "ramp_track_plan": (c_i, [c_p, c_i, c_p]),
-    "ramp_track_step": (c_i, [c_p, c_i, c_i64, c_i, c_p, c_p, c_p]),
+    "ramp_track_step": (c_i, [c_p, c_i, c_i64, c_i, c_i, c_p, c_p, c_p]),
 }
 
 _lib = None
@@ -178,15 +178,31 @@ def ptr(t):
 
 _ws_cache = {}
 _ws_retired = []
+_ws_owner = [None]
+
+
+class scratch_owner:
+    """``with scratch_owner(obj):`` -- scratch taken inside belongs to ``obj`` as well as to the stream.  hipGraph
+    captures all run on torch's one capture stream, so the stream alone would hand two captured graphs (two
+    Patchifiers, a re-capture) the same scratch buffer although they replay on different streams."""
+
+    def __init__(self, owner):
+        self.owner = owner
+
+    def __enter__(self):
+        self.prev, _ws_owner[0] = _ws_owner[0], id(self.owner)
+
+    def __exit__(self, *exc):
+        _ws_owner[0] = self.prev
 
 
 def workspace(nbytes, device, tag="ws"):
-    """grow-only scratch buffer per (device, stream, tag): two trackers on different streams of one GPU (or one
-    tracker's main and plan-building streams) never share scratch.  Contents are never reused across calls.  A
-    buffer that is outgrown is retired, not freed: launches already queued on its stream (or captured in a
-    hipGraph) may still reference it."""
+    """grow-only scratch buffer per (device, stream, owner, tag): two trackers on different streams of one GPU never
+    share scratch, and neither do two captured graphs (see ``scratch_owner``).  Contents are never reused across
+    calls.  A buffer that is outgrown is retired, not freed: launches already queued on its stream (or captured in
+    a hipGraph) may still reference it."""
     key = (device, torch._C._cuda_getCurrentRawStream(device.index if device.index is not None
-                                                      else torch.cuda.current_device()), tag)
+                                                      else torch.cuda.current_device()), _ws_owner[0], tag)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         if buf is not None:

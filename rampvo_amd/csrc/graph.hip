@@ -490,7 +490,7 @@ size_t ramp_i_plan_dyn_ws(int E_cap, int kkey_cap, int pkey_cap) {
 }
 
 // the graph plan (two groupings + temporal neighbours) of the factor list g4 = [4][E_cap] int64 (ii, jj, kk, row)
-int ramp_i_plan_dyn(const int64_t *g4, int E_cap, const int32_t *dyn, int32_t *status, int M, int kkey_cap,
+int ramp_i_plan_dyn(const int64_t *g4, int E_cap, int E_grid, const int32_t *dyn, int32_t *status, int M, int kkey_cap,
                     int pkey_cap, int kk_cap, int ij_cap, int32_t *kk_order, int32_t *kk_gid, int32_t *kk_seg,
                     int32_t *kk_ngroups, int64_t *kk_ukeys, int32_t *ij_order, int32_t *ij_gid, int32_t *ij_seg,
                     int32_t *ij_ngroups, int64_t *ij_ukeys, int64_t *ix, int64_t *jx, void *ws, size_t ws_bytes,
@@ -508,7 +508,7 @@ int ramp_i_plan_dyn(const int64_t *g4, int E_cap, const int32_t *dyn, int32_t *s
   p.order[1] = ij_order; p.gid[1] = ij_gid; p.seg[1] = ij_seg; p.ngroups[1] = ij_ngroups; p.ukeys[1] = ij_ukeys;
   p.Kcap[0] = kkey_cap; p.Kcap[1] = pkey_cap;
   (void)hipMemsetAsync(p.hist[0], 0, (size_t)(kkey_cap + pkey_cap + 4) * 4, st);
-  const int nb = ramp_cdiv(E_cap, 256);
+  const int nb = ramp_cdiv(E_grid > 0 && E_grid < E_cap ? E_grid : E_cap, 256);
   const bool lds = kkey_cap <= PLAN_LDS_K && pkey_cap <= PLAN_LDS_K;
   if (lds) hipLaunchKernelGGL(plan_hist_kernel<true>, dim3(nb, 2), dim3(256), 0, st, p, status);
   else hipLaunchKernelGGL(plan_hist_kernel<false>, dim3(nb, 2), dim3(256), 0, st, p, status);

@@ -271,7 +271,7 @@ size_t ramp_track_ba_workspace_bytes(int E_cap, int n_rows, int M, int opt_windo
 
 int ramp_track_plan(const ramp_track *t, int cur, void *stream) {
   if (!trk_valid(t) || cur < 0 || cur > 1) return RAMP_EINVAL;
-  return ramp_i_plan_dyn(t->graph[cur], t->E_cap, t->dyn, t->dyn + RAMP_DYN_STATUS, t->M, t->kkey_cap, t->pkey_cap,
+  return ramp_i_plan_dyn(t->graph[cur], t->E_cap, t->E_cap, t->dyn, t->dyn + RAMP_DYN_STATUS, t->M, t->kkey_cap, t->pkey_cap,
                          t->kk_cap, t->ij_cap, t->kk_order, t->kk_gid, t->kk_seg, t->kk_ngroups, t->kk_ukeys, t->ij_order,
                          t->ij_gid, t->ij_seg, t->ij_ngroups, t->ij_ukeys, t->ix, t->jx, t->plan_ws, t->plan_ws_bytes,
                          (hipStream_t)stream);
@@ -287,11 +287,20 @@ int ramp_track_plan(const ramp_track *t, int cur, void *stream) {
     if (rc_ != RAMP_OK) return rc_; \
   } while (0)
 
-int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, const float *k_new, void *gate_event,
-                    void *stream) {
-  if (!trk_valid(t) || cur < 0 || cur > 1) return RAMP_EINVAL;
+// the launch bound was below the live factor count: the frame would have been computed on a truncated graph
+__global__ void trk_bound_check_kernel(int32_t *dyn, int E_bound) {
+  if (dyn[RAMP_DYN_E] > E_bound) atomicOr(dyn + RAMP_DYN_STATUS, 32);
+}
+
+int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, int E_bound, const float *k_new,
+                    void *gate_event, void *stream) {
+  if (!trk_valid(t) || cur < 0 || cur > 1 || E_bound < 0) return RAMP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int Ec = t->E_cap, PP = t->P * t->P;
+  // launch bound of the per-factor kernels: the caller's upper bound of dyn[RAMP_DYN_E] (0: the capacity)
+  const int Eb = (E_bound > 0 && E_bound < Ec) ? E_bound : Ec;
+  const int new_cap = (2 * t->patch_lifetime - 1) * t->M;          // factors one frame adds
+  if (Eb < Ec) hipLaunchKernelGGL(trk_bound_check_kernel, dim3(1), dim3(1), 0, st, t->dyn, Eb);
   const int64_t *g = t->graph[cur];
   const int64_t *ii = g, *jj = g + Ec, *kk = g + 2 * (size_t)Ec, *row = g + 3 * (size_t)Ec;
   const int32_t *dyn = t->dyn;
@@ -312,34 +321,34 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, co
         !t->hij || !t->relu_t || !t->target || !t->weight || !t->ba_ws)
       return RAMP_EINVAL;
     // Ramp_vo.update(), ramp/Ramp_vo.py:276-310
-    TRK_DO(ramp_i_transform_dyn(t->poses, t->patches, t->intrinsics, ii, jj, kk, t->coords, Ec, dyn, st));
+    TRK_DO(ramp_i_transform_dyn(t->poses, t->patches, t->intrinsics, ii, jj, kk, t->coords, Eb, dyn, st));
     ramp_corr_level lv[2];
     lv[0].fmap = t->fmap1; lv[0].H2 = t->feat_h; lv[0].W2 = t->feat_w; lv[0].coord_div = 1.0f;
     lv[1].fmap = t->fmap2; lv[1].H2 = t->feat_h / 4; lv[1].W2 = t->feat_w / 4; lv[1].coord_div = 4.0f;
     TRK_PROBE(0);
-    TRK_DO(ramp_i_corr_fwd(t->gmap, lv, 2, t->coords, kk, jj, t->ij_order, t->corr, 896, (long)t->M * t->mem, t->mem, Ec,
+    TRK_DO(ramp_i_corr_fwd(t->gmap, lv, 2, t->coords, kk, jj, t->ij_order, t->corr, 896, (long)t->M * t->mem, t->mem, Eb,
                            t->mem * t->M, t->mem, 128, t->P, 3, RAMP_F16, RAMP_NHWC8, dyn, st));
     TRK_PROBE(1);
     // the update operator, ramp/net.py:69-90 (the fp16 fused chains of csrc/update_mlp.hip)
     TRK_DO(ramp_i_upd_corr_mlp(t->corr, 896, w.corr_w1, w.corr_b1, w.corr_w2, w.corr_b2, w.corr_w3, w.corr_b3, w.corr_ln_w,
                                w.corr_ln_b, w.corr_ln_eps, t->net[0], row, t->imap, kk, (long)t->M * t->mem, w.norm_w,
-                               w.norm_b, w.norm_eps, t->net[1], Ec, dyn, st));
-    TRK_DO(ramp_i_upd_nbr(t->net[1], t->ix, w.c1_wa, w.c1_ba, w.c1_wb, w.c1_bb, t->net[2], nullptr, Ec, dyn, st));
-    TRK_DO(ramp_i_upd_nbr(t->net[2], t->jx, w.c2_wa, w.c2_ba, w.c2_wb, w.c2_bb, t->net[1], nullptr, Ec, dyn, st));
-    TRK_DO(ramp_i_upd_fg(t->net[1], nullptr, nullptr, nullptr, w.kk_wf, w.kk_bf, w.kk_wg, w.kk_bg, t->fg, Ec, dyn, st));
+                               w.norm_b, w.norm_eps, t->net[1], Eb, dyn, st));
+    TRK_DO(ramp_i_upd_nbr(t->net[1], t->ix, w.c1_wa, w.c1_ba, w.c1_wb, w.c1_bb, t->net[2], nullptr, Eb, dyn, st));
+    TRK_DO(ramp_i_upd_nbr(t->net[2], t->jx, w.c2_wa, w.c2_ba, w.c2_wb, w.c2_bb, t->net[1], nullptr, Eb, dyn, st));
+    TRK_DO(ramp_i_upd_fg(t->net[1], nullptr, nullptr, nullptr, w.kk_wf, w.kk_bf, w.kk_wg, w.kk_bg, t->fg, Eb, dyn, st));
     TRK_DO(ramp_upd_segment_softmax(t->fg, t->kk_order, t->kk_seg, t->kk_ngroups, t->ykk, t->kk_cap, RAMP_F16, stream));
     TRK_DO(ramp_upd_linear(t->ykk, w.kk_wh, w.kk_bh, t->hkk, t->kk_cap, t->kk_ngroups, stream));
-    TRK_DO(ramp_i_upd_fg(t->net[1], t->hkk, t->kk_gid, t->net[1], w.ij_wf, w.ij_bf, w.ij_wg, w.ij_bg, t->fg, Ec, dyn, st));
+    TRK_DO(ramp_i_upd_fg(t->net[1], t->hkk, t->kk_gid, t->net[1], w.ij_wf, w.ij_bf, w.ij_wg, w.ij_bg, t->fg, Eb, dyn, st));
     TRK_DO(ramp_upd_segment_softmax(t->fg, t->ij_order, t->ij_seg, t->ij_ngroups, t->yij, t->ij_cap, RAMP_F16, stream));
     TRK_DO(ramp_upd_linear(t->yij, w.ij_wh, w.ij_bh, t->hij, t->ij_cap, t->ij_ngroups, stream));
     if (gate_event && hipEventRecord((hipEvent_t)gate_event, st) != hipSuccess) return RAMP_ELAUNCH;
     TRK_DO(ramp_i_upd_gru(t->net[1], t->hij, t->ij_gid, w.ln1_w, w.ln1_b, w.ln1_eps, w.gru_w, w.gru_b, w.ln2_w, w.ln2_b,
-                          w.ln2_eps, t->net[0], t->relu_t, Ec, dyn, st));
+                          w.ln2_eps, t->net[0], t->relu_t, Eb, dyn, st));
     TRK_PROBE(2);
-    TRK_DO(ramp_i_upd_heads_linear(t->relu_t, w.heads_w, w.heads_b, t->coords, t->target, t->weight, Ec, t->P,
+    TRK_DO(ramp_i_upd_heads_linear(t->relu_t, w.heads_w, w.heads_b, t->coords, t->target, t->weight, Eb, t->P,
                                    (float)t->feat_w, (float)t->feat_h, dyn, st));
     TRK_PROBE(3);
-    TRK_DO(ramp_i_ba_dyn(t->poses, t->patches, t->intrinsics, t->target, t->weight, t->lmbda, ii, jj, kk, Ec, t->P,
+    TRK_DO(ramp_i_ba_dyn(t->poses, t->patches, t->intrinsics, t->target, t->weight, t->lmbda, ii, jj, kk, Eb, t->P,
                          t->n_rows, t->n_rows * t->M, t->opt_window, 2, t->kk_order, t->kk_seg, t->kk_ngroups, t->kk_ukeys,
                          t->kk_cap, t->ij_order, t->ij_seg, t->ij_ngroups, t->ij_cap, t->ba_ws, t->ba_ws_bytes,
                          t->dyn + RAMP_DYN_STATUS, dyn, st));
@@ -348,7 +357,7 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, co
       TRK_DO(ramp_i_point_cloud_dyn(t->poses, t->patches, t->intrinsics, t->ixm, t->points, t->m_cap, dyn, t->M, st));
     if (!(flags & RAMP_TRACK_KEYFRAME)) {
       // the new hidden state is indexed by the factors themselves from here on
-      hipLaunchKernelGGL(trk_iota_kernel, dim3(ramp_cdiv(Ec, 256)), dim3(256), 0, st, t->graph[cur] + 3 * (size_t)Ec, dyn);
+      hipLaunchKernelGGL(trk_iota_kernel, dim3(ramp_cdiv(Eb, 256)), dim3(256), 0, st, t->graph[cur] + 3 * (size_t)Ec, dyn);
     }
   }
   if (flags & RAMP_TRACK_KEYFRAME) {
@@ -361,12 +370,15 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, co
     TRK_DO(trk_edit_fill(t, cur, counter, p));
     hipLaunchKernelGGL(trk_flag_kernel, dim3(p.nb), dim3(256), 0, st, p);
     hipLaunchKernelGGL(trk_decide_kernel, dim3(1), dim3(256), 0, st, p);
-    const int new_cap = (2 * t->patch_lifetime - 1) * t->M;          // factors one frame adds
     int gx = p.nb + ramp_cdiv(new_cap, 256);
     if (gx < 1024) gx = 1024;                                         // column chunks of the row shift
     hipLaunchKernelGGL(trk_apply_kernel, dim3(gx, 1 + p.nbuf), dim3(256), 0, st, p);
     RAMP_CHECK_LAUNCH();
-    TRK_DO(ramp_track_plan(t, 1 - cur, stream));
+    const int Ep = Eb + new_cap < Ec ? Eb + new_cap : Ec;            // the next graph: at most one frame's factors more
+    TRK_DO(ramp_i_plan_dyn(t->graph[1 - cur], Ec, Ep, t->dyn, t->dyn + RAMP_DYN_STATUS, t->M, t->kkey_cap, t->pkey_cap,
+                           t->kk_cap, t->ij_cap, t->kk_order, t->kk_gid, t->kk_seg, t->kk_ngroups, t->kk_ukeys, t->ij_order,
+                           t->ij_gid, t->ij_seg, t->ij_ngroups, t->ij_ukeys, t->ix, t->jx, t->plan_ws, t->plan_ws_bytes,
+                           st));
   }
   if (t->dyn_host &&
       hipMemcpyAsync(t->dyn_host, t->dyn, RAMP_DYN_WORDS * sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess)

@@ -205,8 +205,13 @@ class Patchifier(nn.Module):
         graph.replay()
         return outs
 
-    def _forward_impl(self, input_, patches_per_image=80, reinit_hidden=False, disps=None, event_bias=False,
-                      gradient_bias=False):
+    def _forward_impl(self, *a, **k):
+        from . import _lib
+        with _lib.scratch_owner(self):          # (captured graphs must not share scratch: _lib.workspace)
+            return self._forward_steps(*a, **k)
+
+    def _forward_steps(self, input_, patches_per_image=80, reinit_hidden=False, disps=None, event_bias=False,
+                       gradient_bias=False):
         events, images, mask = input_
         if self.input_mode == "SingleScale":
             fmap, imap, _ = self.encoder(events=events, images=images, reinit_hidden=reinit_hidden,

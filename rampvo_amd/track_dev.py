@@ -75,6 +75,7 @@ class DeviceTrack:
         self.kkey_cap = (R + 2) * M
         self.pkey_cap = (R + r + 1) ** 2
         self.log_cap = 4096
+        self.new_cap = (2 * r - 1) * M
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
         e = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
         i32, i64, f32, f16 = torch.int32, torch.int64, torch.float32, torch.float16
@@ -215,10 +216,19 @@ class DeviceTrack:
         self._frames = 0
         return True
 
+    def factor_bound(self, counter):
+        """upper bound of the live factor count from the lazy host copy of dyn: a frame adds at most (2r - 1) M
+        factors, the copy is `lag` frames old (one more frame of slack in case it was read mid-update); the step
+        flags a bound that turns out too small (status bit 32)"""
+        d = self.dyn_host.numpy()
+        lag = max(int(counter) - int(d[DYN_FRAME]), 1) + 1
+        return min(int(d[DYN_E]) + lag * self.new_cap, self.E_cap)
+
     def step(self, counter, flags, k_new=None, gate_event=None):
         ev = ctypes.c_void_p(gate_event) if gate_event else None
         _lib.check(_lib.lib().ramp_track_step(ctypes.byref(self.t), self.cur, int(counter), int(flags),
-                                              _lib.ptr(k_new), ev, _lib.stream()), "ramp_track_step")
+                                              self.factor_bound(counter), _lib.ptr(k_new), ev, _lib.stream()),
+                   "ramp_track_step")
         if flags & KEYFRAME:
             self.cur ^= 1
         self._frames += 1
