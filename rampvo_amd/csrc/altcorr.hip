@@ -16,6 +16,7 @@
 //   Dots are a channel-ordered fmaf chain == the reference kernel's
 //   accumulation (correlation_kernel.cu:121-131) in fp32.
 #include "ramp_device.h"
+#include <stdlib.h>
 
 // ---------------------------------------------------------------- patchify
 template <typename T>
@@ -545,7 +546,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CorrMma
       const int gw = uni ? (int)bw : D, gh = uni ? (int)bh : D;
       const int Tn = gw * gh;                      // <= CORR_T = 128
       const int npg = (Tn + 15) / 16;
-      const int inv_gw = (65536 + gw - 1) / gw;    // t / gw == (t * inv_gw) >> 16 for t < 128, gw <= 128
+      const int inv_gw = (65536 + gw - 1) / gw;    // t / gw == (t * inv_gw) >> 16 while t * gw < 65536
       for (int pg0 = 0; pg0 < npg; pg0 += PGB) {
         // all PGB x 4 sixteen-byte loads of the batch are issued before the first MFMA waits on
         // one: the address is always a valid pixel, out-of-window lanes are zeroed afterwards

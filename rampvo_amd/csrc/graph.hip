@@ -470,16 +470,29 @@ __global__ void __launch_bounds__(256) plan_scatter_kernel(const PlanDyn p) {
     gid[e] = gidmap[k];
   }
 }
-__global__ void __launch_bounds__(64) plan_segsort_kernel(const PlanDyn p) {
+// restore ascending factor order inside every segment: rank by counting, the segment staged in LDS (the pair
+// grouping has ~100 segments of ~450 factors: walking them from memory was 34 us)
+#define PLAN_SEG_LDS 4096
+__global__ void __launch_bounds__(256) plan_segsort_kernel(const PlanDyn p) {
+  __shared__ int s_v[PLAN_SEG_LDS];
   const int g = blockIdx.y, grp = blockIdx.x;
   if (grp >= *p.ngroups[g]) return;
   const int32_t *tmp_order = p.tmp[g], *seg_start = p.seg[g];
   int32_t *order = p.order[g];
   const int s0 = seg_start[grp], n = seg_start[grp + 1] - s0;
-  for (int q = threadIdx.x; q < n; q += 64) {
-    const int v = tmp_order[s0 + q];
+  const bool lds = n <= PLAN_SEG_LDS;
+  if (lds) {
+    for (int q = threadIdx.x; q < n; q += 256) s_v[q] = tmp_order[s0 + q];
+    __syncthreads();
+  }
+  for (int q = threadIdx.x; q < n; q += 256) {
+    const int v = lds ? s_v[q] : tmp_order[s0 + q];
     int r = 0;
-    for (int u = 0; u < n; u++) r += (tmp_order[s0 + u] < v);
+    if (lds) {
+      for (int u = 0; u < n; u++) r += (s_v[u] < v);
+    } else {
+      for (int u = 0; u < n; u++) r += (tmp_order[s0 + u] < v);
+    }
     order[s0 + r] = v;
   }
 }
@@ -515,7 +528,7 @@ int ramp_i_plan_dyn(const int64_t *g4, int E_cap, int E_grid, const int32_t *dyn
   hipLaunchKernelGGL(plan_scan_kernel, dim3(2), dim3(1024), 0, st, p);
   if (lds) hipLaunchKernelGGL(plan_scatter_kernel<true>, dim3(nb, 2), dim3(256), 0, st, p);
   else hipLaunchKernelGGL(plan_scatter_kernel<false>, dim3(nb, 2), dim3(256), 0, st, p);
-  hipLaunchKernelGGL(plan_segsort_kernel, dim3(kk_cap > ij_cap ? kk_cap : ij_cap, 2), dim3(64), 0, st, p);
+  hipLaunchKernelGGL(plan_segsort_kernel, dim3(kk_cap > ij_cap ? kk_cap : ij_cap, 2), dim3(256), 0, st, p);
   hipLaunchKernelGGL(nb_from_groups_kernel, dim3(kk_cap), dim3(64), 0, st, kk_order, kk_seg, kk_ngroups, p.jj, ix, jx);
   RAMP_CHECK_LAUNCH();
   return RAMP_OK;

@@ -1020,9 +1020,10 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) upd_fg_big_kernel(const FgPar
 
 // ------------------------------------------------------------------ plain Linear on a small table
 // y[r] = fp16(x[r] W^T + b), r < rows: SoftAgg's `h` layer on the group table (ramp/blocks.py:46-47; a few hundred to a
-// few thousand rows).  16 rows per workgroup, 4 waves x 96 columns, operands exchanged so that a lane holds four
-// consecutive columns of one row (8-byte stores).  rows_dev: optional device-side row count (the grouping's ngroups).
-__global__ void __launch_bounds__(256) upd_linear_kernel(const _Float16 *__restrict__ x, const _Float16 *__restrict__ wp,
+// few thousand rows).  16 rows per workgroup, 8 waves x 48 columns, operands exchanged so that a lane holds four
+// consecutive columns of one row (8-byte stores); the weight fragments of three K steps are in flight ahead of the
+// matrix cores (the kernel is one L2 round trip per K step otherwise).  rows_dev: optional device-side row count (the grouping's ngroups).
+__global__ void __launch_bounds__(512) upd_linear_kernel(const _Float16 *__restrict__ x, const _Float16 *__restrict__ wp,
                                                          const float *__restrict__ bias, _Float16 *__restrict__ y,
                                                          int rows, const int32_t *__restrict__ rows_dev) {
   __shared__ __attribute__((aligned(16))) _Float16 Xs[16 * MXS];
@@ -1031,26 +1032,36 @@ __global__ void __launch_bounds__(256) upd_linear_kernel(const _Float16 *__restr
   int R = rows;
   if (rows_dev) { const int d = *rows_dev; R = d < rows ? d : rows; }
   if (row0 >= R) return;
-  for (int i = tid; i < 16 * (MD / 8); i += 256) {
+  constexpr int NT = MNTW, PF = 3;             // 8 waves x 48 columns; weight fragments of PF K steps in flight
+  auto wfrag = [&](int ks, int nt) {
+    return *reinterpret_cast<const h8 *>(wp + (((size_t)ks * (MD / 16) + wave * NT + nt) * 64 + lane) * 8);
+  };
+  h8 ring[PF + 1][NT];
+#pragma unroll
+  for (int d = 0; d < PF; d++)
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) ring[d][nt] = wfrag(d, nt);
+  for (int i = tid; i < 16 * (MD / 8); i += 512) {
     const int r = i / (MD / 8), c8 = i - r * (MD / 8);
     h8 v = (h8){0, 0, 0, 0, 0, 0, 0, 0};
     if (row0 + r < R) v = *reinterpret_cast<const h8 *>(x + (size_t)(row0 + r) * MD + 8 * c8);
     *reinterpret_cast<h8 *>(Xs + r * MXS + 8 * c8) = v;
   }
   __syncthreads();
-  constexpr int NT = 6;
   f4 acc[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; nt++) acc[nt] = (f4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
+#pragma unroll
   for (int ks = 0; ks < MKS; ks++) {
+    if (ks + PF < MKS) {
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) ring[(ks + PF) % (PF + 1)][nt] = wfrag(ks + PF, nt);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     const h8 a = *reinterpret_cast<const h8 *>(Xs + j * MXS + ks * 32 + 8 * q);
-    h8 bw[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; nt++)
-      bw[nt] = *reinterpret_cast<const h8 *>(wp + (((size_t)ks * (MD / 16) + wave * NT + nt) * 64 + lane) * 8);
-#pragma unroll
-    for (int nt = 0; nt < NT; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bw[nt], a, acc[nt], 0, 0, 0);
+      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[ks % (PF + 1)][nt], a, acc[nt], 0, 0, 0);
   }
   if (row0 + j >= R) return;
   _Float16 *o = y + (size_t)(row0 + j) * MD + wave * (16 * NT) + 4 * q;
@@ -1061,7 +1072,6 @@ __global__ void __launch_bounds__(256) upd_linear_kernel(const _Float16 *__restr
                                                 (_Float16)(acc[nt][2] + b[2]), (_Float16)(acc[nt][3] + b[3])};
   }
 }
-
 
 // row tiles per workgroup for E edges (0: the 64-row kernels -- small problems, or RAMP_UPD_BIG=0; 4..8 forces a tile
 // for A/B runs); `best`: the measured optimum of the chain at the bench size
@@ -1241,7 +1251,7 @@ int ramp_upd_linear(const void *x, const void *w_packed, const float *bias, void
   if (rows < 0) return RAMP_EINVAL;
   if (rows == 0) return RAMP_OK;
   if (!x || !w_packed || !bias || !y) return RAMP_EINVAL;
-  hipLaunchKernelGGL(upd_linear_kernel, dim3(ramp_cdiv(rows, 16)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(upd_linear_kernel, dim3(ramp_cdiv(rows, 16)), dim3(512), 0, (hipStream_t)stream,
                      (const _Float16 *)x, (const _Float16 *)w_packed, bias, (_Float16 *)y, rows, rows_dev);
   RAMP_CHECK_LAUNCH();
   return RAMP_OK;
