@@ -304,10 +304,11 @@ int ramp_group_by_small(const int64_t *a, const int64_t *b, int64_t mul, int64_t
 
 /* cuda_ba.neighbors derived from the per-kk groups (no second sort): every group's edges are
  * ranked by (jj, edge index).  Groups longer than 1024 edges are left untouched (use
- * ramp_neighbors for such graphs).                                                              */
+ * ramp_neighbors for such graphs).  kj_order (optional, int32 [E]): the factors in that (kk, jj) order -- a
+ * factor's temporal neighbours are its neighbours in this list (ramp_upd_nbr2).                  */
 int ramp_neighbors_from_groups(const int32_t *order, const int32_t *seg_start, const int32_t *ngroups,
-                               const int64_t *jj, int64_t *ix, int64_t *jx, int E, int max_groups,
-                               void *stream);
+                               const int64_t *jj, int64_t *ix, int64_t *jx, int32_t *kj_order, int E,
+                               int max_groups, void *stream);
 
 /* ------------------------------------------------------------------ encoder */
 /* flags[0] = any(a != 0), flags[1] = any(b != 0): the "events / image present" tests of
@@ -505,6 +506,15 @@ int ramp_upd_heads_linear(const void *relu_t, const void *heads_w, const float *
 int ramp_upd_fg(const float *x32, const void *add_t, const int32_t *add_idx, float *x32_out, const void *wf,
                 const float *bf, const void *wg, const float *bg, void *fg, int E, void *stream);
 
+/* Both temporal-neighbour MLPs of the update operator in ONE launch (ramp/net.py:77-82: net += c1(mask * net[ix]);
+ * net += c2(mask * net[jx])): a workgroup walks 78 consecutive positions of the (kk, jj)-sorted factor list kj
+ * (ramp_neighbors_from_groups), where a factor's temporal neighbours are the positions before / after it; the state is
+ * read once and written once instead of 4 + 2 times.  Bit-identical to ramp_upd_nbr(c1) followed by ramp_upd_nbr(c2).
+ * Weights / biases as ramp_upd_nbr; net_out must not alias net_in.                                                   */
+int ramp_upd_nbr2(const float *net_in, const int32_t *kj, const int64_t *ix, const int64_t *jx, const void *w1a,
+                  const float *b1a, const void *w1b, const float *b1b, const void *w2a, const float *b2a,
+                  const void *w2b, const float *b2b, float *net_out, int E, void *stream);
+
 /* nn.Linear(384, 384) on a small fp16 table: y[r] = fp16(x[r] W^T + b) -- SoftAgg's `h` layer on the group table
  * (ramp/blocks.py:46-47), the one GEMM of the fused update operator that used to be a library call.  w_packed like
  * ramp_upd_gru's weights, bias fp32 [384]; rows_dev (optional, device int32): only rows < *rows_dev are computed.   */
@@ -583,6 +593,7 @@ typedef struct ramp_track {
   /* graph plan */
   int32_t *kk_order, *kk_gid, *kk_seg, *kk_ngroups, *ij_order, *ij_gid, *ij_seg, *ij_ngroups;
   int64_t *kk_ukeys, *ij_ukeys, *ix, *jx;
+  int32_t *kj;                        /* [E_cap] factors in (kk, jj) order (ramp_upd_nbr2)                        */
   void *plan_ws;
   size_t plan_ws_bytes;
   /* update operator */

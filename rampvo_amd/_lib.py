@@ -77,7 +77,7 @@ SIGNATURES = {
     "ramp_ba_forward_planned": (c_i, [c_p] * 9 + [c_i] * 7 + [c_p] * 4 + [c_i] + [c_p] * 3 + [c_i, c_p, c_sz, c_p, c_p]),
     "ramp_group_by_small_workspace_bytes": (c_sz, [c_i, c_i]),
     "ramp_group_by_small": (c_i, [c_p, c_p, c_i64, c_i64, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_sz, c_p]),
-    "ramp_neighbors_from_groups": (c_i, [c_p] * 6 + [c_i, c_i, c_p]),
+    "ramp_neighbors_from_groups": (c_i, [c_p] * 7 + [c_i, c_i, c_p]),
     "ramp_any_nonzero": (c_i, [c_p, ctypes.c_long, c_p, ctypes.c_long, c_p, c_p]),
     "ramp_lstm_superstate_tiled": (c_i, [c_p] * 9 + [c_i, c_i, c_i, c_p]),
     "ramp_conv2d_nhwc": (c_i, [c_p] * 8 + [c_i] * 8 + [c_f, c_i, c_p]),
@@ -102,6 +102,7 @@ SIGNATURES = {
                            c_p, c_i, c_p]),
     "ramp_upd_mlp_lds_bytes": (c_sz, []),
     "ramp_upd_nbr": (c_i, [c_p] * 8 + [c_i, c_p]),
+    "ramp_upd_nbr2": (c_i, [c_p] * 13 + [c_i, c_p]),
     "ramp_upd_linear": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_p]),
     # device-resident tracking step (csrc/track.hip); the ramp_track descriptor is mirrored in track_dev.py
     "ramp_track_sizeof": (c_sz, []),

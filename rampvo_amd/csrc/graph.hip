@@ -305,7 +305,7 @@ __global__ void __launch_bounds__(64)
 __global__ void __launch_bounds__(64)
     nb_from_groups_kernel(const int32_t *__restrict__ order, const int32_t *__restrict__ seg_start,
                           const int32_t *__restrict__ ngroups, const int64_t *__restrict__ jj,
-                          int64_t *__restrict__ ix, int64_t *__restrict__ jx) {
+                          int64_t *__restrict__ ix, int64_t *__restrict__ jx, int32_t *__restrict__ kj) {
   __shared__ int s_sorted[1024];
   const int g = blockIdx.x;
   if (g >= *ngroups) return;
@@ -327,6 +327,7 @@ __global__ void __launch_bounds__(64)
     const int e = s_sorted[r];
     ix[e] = r > 0 ? s_sorted[r - 1] : -1;
     jx[e] = r + 1 < n ? s_sorted[r + 1] : -1;
+    if (kj) kj[s0 + r] = e;                    // the (kk, jj)-sorted factor list (csrc/update_mlp.hip::upd_nbr2_kernel)
   }
 }
 
@@ -506,8 +507,8 @@ size_t ramp_i_plan_dyn_ws(int E_cap, int kkey_cap, int pkey_cap) {
 int ramp_i_plan_dyn(const int64_t *g4, int E_cap, int E_grid, const int32_t *dyn, int32_t *status, int M, int kkey_cap,
                     int pkey_cap, int kk_cap, int ij_cap, int32_t *kk_order, int32_t *kk_gid, int32_t *kk_seg,
                     int32_t *kk_ngroups, int64_t *kk_ukeys, int32_t *ij_order, int32_t *ij_gid, int32_t *ij_seg,
-                    int32_t *ij_ngroups, int64_t *ij_ukeys, int64_t *ix, int64_t *jx, void *ws, size_t ws_bytes,
-                    hipStream_t st) {
+                    int32_t *ij_ngroups, int64_t *ij_ukeys, int64_t *ix, int64_t *jx, int32_t *kj, void *ws,
+                    size_t ws_bytes, hipStream_t st) {
   if (!g4 || !dyn || !status || !ws || E_cap <= 0 || kkey_cap <= 0 || pkey_cap <= 0) return RAMP_EINVAL;
   if (ws_bytes < ramp_i_plan_dyn_ws(E_cap, kkey_cap, pkey_cap)) return RAMP_EWORKSPACE;
   PlanDyn p;
@@ -529,7 +530,7 @@ int ramp_i_plan_dyn(const int64_t *g4, int E_cap, int E_grid, const int32_t *dyn
   if (lds) hipLaunchKernelGGL(plan_scatter_kernel<true>, dim3(nb, 2), dim3(256), 0, st, p);
   else hipLaunchKernelGGL(plan_scatter_kernel<false>, dim3(nb, 2), dim3(256), 0, st, p);
   hipLaunchKernelGGL(plan_segsort_kernel, dim3(kk_cap > ij_cap ? kk_cap : ij_cap, 2), dim3(256), 0, st, p);
-  hipLaunchKernelGGL(nb_from_groups_kernel, dim3(kk_cap), dim3(64), 0, st, kk_order, kk_seg, kk_ngroups, p.jj, ix, jx);
+  hipLaunchKernelGGL(nb_from_groups_kernel, dim3(kk_cap), dim3(64), 0, st, kk_order, kk_seg, kk_ngroups, p.jj, ix, jx, kj);
   RAMP_CHECK_LAUNCH();
   return RAMP_OK;
 }
@@ -579,13 +580,13 @@ int ramp_group_by_small(const int64_t *a, const int64_t *b, int64_t mul, int64_t
 }
 
 int ramp_neighbors_from_groups(const int32_t *order, const int32_t *seg_start, const int32_t *ngroups,
-                               const int64_t *jj, int64_t *ix, int64_t *jx, int E, int max_groups,
+                               const int64_t *jj, int64_t *ix, int64_t *jx, int32_t *kj_order, int E, int max_groups,
                                void *stream) {
   if (E < 0 || max_groups < 0) return RAMP_EINVAL;
   if (E == 0 || max_groups == 0) return RAMP_OK;
   if (!order || !seg_start || !ngroups || !jj || !ix || !jx) return RAMP_EINVAL;
   hipLaunchKernelGGL(nb_from_groups_kernel, dim3(max_groups), dim3(64), 0, (hipStream_t)stream, order,
-                     seg_start, ngroups, jj, ix, jx);
+                     seg_start, ngroups, jj, ix, jx, kj_order);
   RAMP_CHECK_LAUNCH();
   return RAMP_OK;
 }

@@ -256,7 +256,7 @@ static int trk_edit_fill(const ramp_track *t, int cur, int64_t counter, TrkEdit 
 
 static bool trk_valid(const ramp_track *t) {
   return t && t->dyn && t->M > 0 && t->P == 3 && t->E_cap > 0 && t->graph[0] && t->graph[1] && t->plan_ws &&
-         t->kk_order && t->ij_order && t->ix && t->jx && t->opt_window > 0 && t->mem > 0 && t->edit_ws;
+         t->kk_order && t->ij_order && t->ix && t->jx && t->kj && t->opt_window > 0 && t->mem > 0 && t->edit_ws;
 }
 
 extern "C" {
@@ -273,7 +273,7 @@ int ramp_track_plan(const ramp_track *t, int cur, void *stream) {
   if (!trk_valid(t) || cur < 0 || cur > 1) return RAMP_EINVAL;
   return ramp_i_plan_dyn(t->graph[cur], t->E_cap, t->E_cap, t->dyn, t->dyn + RAMP_DYN_STATUS, t->M, t->kkey_cap, t->pkey_cap,
                          t->kk_cap, t->ij_cap, t->kk_order, t->kk_gid, t->kk_seg, t->kk_ngroups, t->kk_ukeys, t->ij_order,
-                         t->ij_gid, t->ij_seg, t->ij_ngroups, t->ij_ukeys, t->ix, t->jx, t->plan_ws, t->plan_ws_bytes,
+                         t->ij_gid, t->ij_seg, t->ij_ngroups, t->ij_ukeys, t->ix, t->jx, t->kj, t->plan_ws, t->plan_ws_bytes,
                          (hipStream_t)stream);
 }
 
@@ -333,16 +333,18 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
     TRK_DO(ramp_i_upd_corr_mlp(t->corr, 896, w.corr_w1, w.corr_b1, w.corr_w2, w.corr_b2, w.corr_w3, w.corr_b3, w.corr_ln_w,
                                w.corr_ln_b, w.corr_ln_eps, t->net[0], row, t->imap, kk, (long)t->M * t->mem, w.norm_w,
                                w.norm_b, w.norm_eps, t->net[1], Eb, dyn, st));
-    TRK_DO(ramp_i_upd_nbr(t->net[1], t->ix, w.c1_wa, w.c1_ba, w.c1_wb, w.c1_bb, t->net[2], nullptr, Eb, dyn, st));
-    TRK_DO(ramp_i_upd_nbr(t->net[2], t->jx, w.c2_wa, w.c2_ba, w.c2_wb, w.c2_bb, t->net[1], nullptr, Eb, dyn, st));
-    TRK_DO(ramp_i_upd_fg(t->net[1], nullptr, nullptr, nullptr, w.kk_wf, w.kk_bf, w.kk_wg, w.kk_bg, t->fg, Eb, dyn, st));
+    // c1 and c2 in one launch over the (kk, jj)-sorted factor list; the state moves net[1] -> net[2]
+    TRK_DO(ramp_i_upd_nbr2(t->net[1], t->kj, t->ix, t->jx, w.c1_wa, w.c1_ba, w.c1_wb, w.c1_bb, w.c2_wa, w.c2_ba, w.c2_wb,
+                           w.c2_bb, t->net[2], Eb, dyn, st));
+    float *net = t->net[2];
+    TRK_DO(ramp_i_upd_fg(net, nullptr, nullptr, nullptr, w.kk_wf, w.kk_bf, w.kk_wg, w.kk_bg, t->fg, Eb, dyn, st));
     TRK_DO(ramp_upd_segment_softmax(t->fg, t->kk_order, t->kk_seg, t->kk_ngroups, t->ykk, t->kk_cap, RAMP_F16, stream));
     TRK_DO(ramp_upd_linear(t->ykk, w.kk_wh, w.kk_bh, t->hkk, t->kk_cap, t->kk_ngroups, stream));
-    TRK_DO(ramp_i_upd_fg(t->net[1], t->hkk, t->kk_gid, t->net[1], w.ij_wf, w.ij_bf, w.ij_wg, w.ij_bg, t->fg, Eb, dyn, st));
+    TRK_DO(ramp_i_upd_fg(net, t->hkk, t->kk_gid, net, w.ij_wf, w.ij_bf, w.ij_wg, w.ij_bg, t->fg, Eb, dyn, st));
     TRK_DO(ramp_upd_segment_softmax(t->fg, t->ij_order, t->ij_seg, t->ij_ngroups, t->yij, t->ij_cap, RAMP_F16, stream));
     TRK_DO(ramp_upd_linear(t->yij, w.ij_wh, w.ij_bh, t->hij, t->ij_cap, t->ij_ngroups, stream));
     if (gate_event && hipEventRecord((hipEvent_t)gate_event, st) != hipSuccess) return RAMP_ELAUNCH;
-    TRK_DO(ramp_i_upd_gru(t->net[1], t->hij, t->ij_gid, w.ln1_w, w.ln1_b, w.ln1_eps, w.gru_w, w.gru_b, w.ln2_w, w.ln2_b,
+    TRK_DO(ramp_i_upd_gru(net, t->hij, t->ij_gid, w.ln1_w, w.ln1_b, w.ln1_eps, w.gru_w, w.gru_b, w.ln2_w, w.ln2_b,
                           w.ln2_eps, t->net[0], t->relu_t, Eb, dyn, st));
     TRK_PROBE(2);
     TRK_DO(ramp_i_upd_heads_linear(t->relu_t, w.heads_w, w.heads_b, t->coords, t->target, t->weight, Eb, t->P,
@@ -377,7 +379,7 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
     const int Ep = Eb + new_cap < Ec ? Eb + new_cap : Ec;            // the next graph: at most one frame's factors more
     TRK_DO(ramp_i_plan_dyn(t->graph[1 - cur], Ec, Ep, t->dyn, t->dyn + RAMP_DYN_STATUS, t->M, t->kkey_cap, t->pkey_cap,
                            t->kk_cap, t->ij_cap, t->kk_order, t->kk_gid, t->kk_seg, t->kk_ngroups, t->kk_ukeys, t->ij_order,
-                           t->ij_gid, t->ij_seg, t->ij_ngroups, t->ij_ukeys, t->ix, t->jx, t->plan_ws, t->plan_ws_bytes,
+                           t->ij_gid, t->ij_seg, t->ij_ngroups, t->ij_ukeys, t->ix, t->jx, t->kj, t->plan_ws, t->plan_ws_bytes,
                            st));
   }
   if (t->dyn_host &&

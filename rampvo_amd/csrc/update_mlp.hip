@@ -939,6 +939,162 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) upd_nbr_big_kernel(const NbrP
   }
 }
 
+// ------------------------------------------------------------------ c1 AND c2 in one launch
+// net += c1(mask * net[ix]);  net += c2(mask * net[jx])   (ramp/net.py:77-82)
+// The two launches above each read the state twice (own row + neighbour row) and write it once: 6 passes over
+// [E][384] fp32.  Here a workgroup owns 78 CONSECUTIVE POSITIONS of the (kk, jj)-sorted factor list `kj` (the graph
+// plan emits it): the temporal neighbours of position P are positions P - 1 and P + 1 (if in the same patch group), so
+//   c1:  G[t]  = c1(net[kj[p0 - 1 + t]]),  t = 0..78         -> out1 at position p0 + t = net + (has_prev ? G[t] : c1(0))
+//   c2:  G2[v] = c2(out1 at position p0 + 1 + v), v = 0..77  -> out  at position p0 + v = out1 + (has_next ? G2[v] : c2(0))
+// with ONE read of every state row (plus the one-row halo at either end) and one write.  Tile row 79 is a zero row in
+// both chains: it yields c1(0) / c2(0), what the reference's masked gather feeds a factor without a neighbour.  The
+// row shift between the chains happens where out1 goes back to LDS as the c2 input (row u is stored as row u - 1), so
+// every lane adds values of rows it owns; out1 stays in registers (fp32) for the final sum.
+struct Nbr2Params {
+  const float *net_in;         // [E][384] fp32
+  float *net_out;              // [E][384] fp32, a different buffer
+  const int32_t *kj;           // [E] position in (kk, jj) order -> factor
+  const int64_t *ix, *jx;      // [E] temporal neighbours (only their sign is read here)
+  const _Float16 *w1a, *w1b, *w2a, *w2b;
+  const float *b1a, *b1b, *b2a, *b2b;
+  int E;
+  const int32_t *dyn;          // optional device-side sizes (RAMP_DYN_*): E is then the launch bound
+};
+#define NBR2_OUT 78
+__global__ void __launch_bounds__(512, 2) upd_nbr2_kernel(const Nbr2Params p) {
+  constexpr int NMT = 5, NW = 8, NTW = 3, ROWS = 80;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  _Float16 *Xs = reinterpret_cast<_Float16 *>(smem_raw);
+  float *Ks = reinterpret_cast<float *>(Xs + ROWS * MXS);          // [384]: the zero row's result
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
+  const int p0 = blockIdx.x * NBR2_OUT;
+  const int pE = p.dyn ? p.dyn[RAMP_DYN_E] : p.E;
+  if (p0 >= pE) return;                        // (workgroup-uniform)
+  const int col0 = wave * (16 * NTW);
+  // ---- c1 input: tile row t <- state row of position p0 - 1 + t (rows past either end of the list: zeros)
+  constexpr int RPW = ROWS / NW;
+  {
+    int src[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; i++) {
+      const int t = wave + i * NW, P = p0 - 1 + t;
+      src[i] = (t < ROWS - 1 && P >= 0 && P < pE) ? p.kj[P] : -1;
+    }
+    float2 v[RPW][3];
+#pragma unroll
+    for (int i = 0; i < RPW; i++) {
+      const float *b = p.net_in + (size_t)(src[i] >= 0 ? src[i] : 0) * MD + 2 * lane;
+#pragma unroll
+      for (int k = 0; k < 3; k++) v[i][k] = *reinterpret_cast<const float2 *>(b + 128 * k);
+    }
+#pragma unroll
+    for (int i = 0; i < RPW; i++)
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const float2 a = src[i] >= 0 ? v[i][k] : make_float2(0.f, 0.f);
+        *reinterpret_cast<h2 *>(Xs + (wave + i * NW) * MXS + 2 * lane + 128 * k) = (h2){(_Float16)a.x, (_Float16)a.y};
+      }
+  }
+  // ---- the rows this lane owns in accumulator layout: row u = 16 mt + j <-> position p0 + u
+  unsigned ro[NMT];            // byte offset of the factor's state row + this lane's first column
+  unsigned has_prev = 0, has_next = 0, live1 = 0, live2 = 0;
+#pragma unroll
+  for (int mt = 0; mt < NMT; mt++) {
+    const int u = mt * 16 + j, P = p0 + u;
+    const bool in = u < ROWS - 1 && P < pE;
+    const int e = p.kj[in ? P : pE - 1];
+    ro[mt] = (unsigned)(e * MD + col0 + 4 * q) * 4u;
+    if (in) {
+      live1 |= 1u << mt;
+      if (u < NBR2_OUT) live2 |= 1u << mt;
+      if (p.ix[e] >= 0) has_prev |= 1u << mt;
+      if (p.jx[e] >= 0) has_next |= 1u << mt;
+    }
+  }
+  __syncthreads();
+  f4 acc[NMT][NTW];
+  big_zero<NMT, NTW>(acc);
+  big_gemm<NMT, NTW>(Xs, p.w1a, MKS, 0, wave, lane, acc);
+  __syncthreads();                                       // every wave is past its reads of x
+  big_store_tile<NMT, NTW, true>(Xs, acc, p.b1a, col0, q, j);
+  __syncthreads();
+  big_zero<NMT, NTW>(acc);
+  big_gemm<NMT, NTW>(Xs, p.w1b, MKS, 0, wave, lane, acc);
+  // G = round_fp16(acc + bias); the zero row's G (tile row 79: m-tile 4, j = 15) -> Ks
+  float4 bv[NTW];
+#pragma unroll
+  for (int nt = 0; nt < NTW; nt++) bv[nt] = *reinterpret_cast<const float4 *>(p.b1b + col0 + nt * 16 + 4 * q);
+  if (j == 15) {
+#pragma unroll
+    for (int nt = 0; nt < NTW; nt++)
+      *reinterpret_cast<float4 *>(Ks + col0 + nt * 16 + 4 * q) =
+          make_float4(h_round(acc[NMT - 1][nt][0] + bv[nt].x), h_round(acc[NMT - 1][nt][1] + bv[nt].y),
+                      h_round(acc[NMT - 1][nt][2] + bv[nt].z), h_round(acc[NMT - 1][nt][3] + bv[nt].w));
+  }
+  __syncthreads();                                       // Ks written; every wave is past its reads of the hidden tile
+  float4 o1[NMT][NTW];
+  {
+    float4 kz[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; nt++) kz[nt] = *reinterpret_cast<const float4 *>(Ks + col0 + nt * 16 + 4 * q);
+#pragma unroll
+    for (int mt = 0; mt < NMT; mt++) {
+      const bool hp = (has_prev >> mt) & 1, lv = (live1 >> mt) & 1;
+#pragma unroll
+      for (int nt = 0; nt < NTW; nt++) {
+        const float4 x = ldg4(p.net_in, ro[mt], nt);
+        float4 g = make_float4(h_round(acc[mt][nt][0] + bv[nt].x), h_round(acc[mt][nt][1] + bv[nt].y),
+                               h_round(acc[mt][nt][2] + bv[nt].z), h_round(acc[mt][nt][3] + bv[nt].w));
+        if (!hp) g = kz[nt];
+        o1[mt][nt] = lv ? make_float4(x.x + g.x, x.y + g.y, x.z + g.z, x.w + g.w) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      // c2 input: out1 of row u goes to tile row u - 1 (row 0 feeds the previous workgroup's last factor, not ours)
+      const int u = mt * 16 + j;
+      if (u >= 1) {
+#pragma unroll
+        for (int nt = 0; nt < NTW; nt++)
+          *reinterpret_cast<hh4 *>(Xs + (u - 1) * MXS + col0 + nt * 16 + 4 * q) =
+              (hh4){(_Float16)o1[mt][nt].x, (_Float16)o1[mt][nt].y, (_Float16)o1[mt][nt].z, (_Float16)o1[mt][nt].w};
+      }
+    }
+    if (j == 15) {                                         // tile row 79: the zero row of the second chain
+#pragma unroll
+      for (int nt = 0; nt < NTW; nt++)
+        *reinterpret_cast<hh4 *>(Xs + (ROWS - 1) * MXS + col0 + nt * 16 + 4 * q) = (hh4){0, 0, 0, 0};
+    }
+  }
+  __syncthreads();
+  big_zero<NMT, NTW>(acc);
+  big_gemm<NMT, NTW>(Xs, p.w2a, MKS, 0, wave, lane, acc);
+  __syncthreads();
+  big_store_tile<NMT, NTW, true>(Xs, acc, p.b2a, col0, q, j);
+  __syncthreads();
+  big_zero<NMT, NTW>(acc);
+  big_gemm<NMT, NTW>(Xs, p.w2b, MKS, 0, wave, lane, acc);
+#pragma unroll
+  for (int nt = 0; nt < NTW; nt++) bv[nt] = *reinterpret_cast<const float4 *>(p.b2b + col0 + nt * 16 + 4 * q);
+  if (j == 15) {
+#pragma unroll
+    for (int nt = 0; nt < NTW; nt++)
+      *reinterpret_cast<float4 *>(Ks + col0 + nt * 16 + 4 * q) =
+          make_float4(h_round(acc[NMT - 1][nt][0] + bv[nt].x), h_round(acc[NMT - 1][nt][1] + bv[nt].y),
+                      h_round(acc[NMT - 1][nt][2] + bv[nt].z), h_round(acc[NMT - 1][nt][3] + bv[nt].w));
+  }
+  __syncthreads();
+#pragma unroll
+  for (int nt = 0; nt < NTW; nt++) {
+    const float4 kz = *reinterpret_cast<const float4 *>(Ks + col0 + nt * 16 + 4 * q);
+#pragma unroll
+    for (int mt = 0; mt < NMT; mt++) {
+      if (!((live2 >> mt) & 1)) continue;
+      float4 g = make_float4(h_round(acc[mt][nt][0] + bv[nt].x), h_round(acc[mt][nt][1] + bv[nt].y),
+                             h_round(acc[mt][nt][2] + bv[nt].z), h_round(acc[mt][nt][3] + bv[nt].w));
+      if (!((has_next >> mt) & 1)) g = kz;
+      stg4(p.net_out, ro[mt], nt, make_float4(o1[mt][nt].x + g.x, o1[mt][nt].y + g.y, o1[mt][nt].z + g.z, o1[mt][nt].w + g.w));
+    }
+  }
+}
+
 // ------------------------------------------------------------------ SoftAgg [f | g] (big tile)
 template <int NMT, int NW>
 __global__ void __launch_bounds__(64 * NW, NW / 4) upd_fg_big_kernel(const FgParams p) {
@@ -1255,6 +1411,36 @@ int ramp_upd_linear(const void *x, const void *w_packed, const float *bias, void
                      (const _Float16 *)x, (const _Float16 *)w_packed, bias, (_Float16 *)y, rows, rows_dev);
   RAMP_CHECK_LAUNCH();
   return RAMP_OK;
+}
+
+int ramp_i_upd_nbr2(const float *net_in, const int32_t *kj, const int64_t *ix, const int64_t *jx, const void *w1a,
+                    const float *b1a, const void *w1b, const float *b1b, const void *w2a, const float *b2a,
+                    const void *w2b, const float *b2b, float *net_out, int E, const int32_t *dyn, void *stream) {
+  if (E < 0) return RAMP_EINVAL;
+  if (E == 0) return RAMP_OK;
+  if (!net_in || !kj || !ix || !jx || !w1a || !b1a || !w1b || !b1b || !w2a || !b2a || !w2b || !b2b || !net_out ||
+      net_in == net_out)
+    return RAMP_EINVAL;
+  if ((long)E * MD * 4 >= (1l << 32)) return RAMP_EUNSUPPORTED;       // 32-bit row offsets
+  Nbr2Params p;
+  p.net_in = net_in; p.net_out = net_out; p.kj = kj; p.ix = ix; p.jx = jx;
+  p.w1a = (const _Float16 *)w1a; p.w1b = (const _Float16 *)w1b; p.w2a = (const _Float16 *)w2a; p.w2b = (const _Float16 *)w2b;
+  p.b1a = b1a; p.b1b = b1b; p.b2a = b2a; p.b2b = b2b; p.E = E; p.dyn = dyn;
+  const size_t lds = (size_t)80 * MXS * 2 + MD * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void *)upd_nbr2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return RAMP_ELAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(upd_nbr2_kernel, dim3(ramp_cdiv(E, NBR2_OUT)), dim3(512), lds, (hipStream_t)stream, p);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+int ramp_upd_nbr2(const float *net_in, const int32_t *kj, const int64_t *ix, const int64_t *jx, const void *w1a,
+                  const float *b1a, const void *w1b, const float *b1b, const void *w2a, const float *b2a,
+                  const void *w2b, const float *b2b, float *net_out, int E, void *stream) {
+  return ramp_i_upd_nbr2(net_in, kj, ix, jx, w1a, b1a, w1b, b1b, w2a, b2a, w2b, b2b, net_out, E, nullptr, stream);
 }
 
 }  // extern "C"

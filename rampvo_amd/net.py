@@ -30,12 +30,14 @@ class GraphPlan:
     neighbours and the two SoftAgg groupings.  Built on the device in one go
     (``build``); ``Ramp_vo`` rebuilds it only when the factor graph changes."""
     __slots__ = ("ix", "jx", "ix_raw", "jx_raw", "mask_ix", "mask_jx", "g_kk", "g_ij", "max_kk", "max_ij", "E",
-                 "pair_mul")
+                 "pair_mul", "kj")
 
     def tensors(self):
         """every device tensor of the plan (for stream bookkeeping)"""
         out = [t for t in (self.ix, self.jx, self.ix_raw, self.jx_raw, self.mask_ix, self.mask_jx)
                if isinstance(t, torch.Tensor)]
+        if isinstance(self.kj, torch.Tensor):
+            out.append(self.kj)
         for g in (self.g_kk, self.g_ij):
             out += [getattr(g, n) for n in ("order", "gid", "seg_start", "ukeys", "ngroups")
                     if isinstance(getattr(g, n, None), torch.Tensor)]
@@ -48,6 +50,7 @@ class GraphPlan:
         from the counting group-by and the neighbours from the kk groups, no radix sort."""
         p = GraphPlan()
         p.mask_ix = p.mask_jx = None
+        p.kj = None                    # factors in (kk, jj) order, when the counting group-by built the plan
         p.E = ii.shape[0]
         small = (kk_range is not None and frame_range is not None and max_kk is not None and max_ij is not None
                  and ii.is_cuda and hasattr(ops, "group_by_small"))
@@ -60,7 +63,7 @@ class GraphPlan:
             # the correlation kernel wants (ops.corr(order=))
             p.g_ij = ops.group_by_small(jj, ii, W, f_lo * W + f_lo, W * W, max_ij)
             p.pair_mul = W                 # g_ij.ukeys = jj * W + ii
-            p.ix, p.jx = ops.neighbors_from_groups(p.g_kk, jj, max_kk)
+            p.ix, p.jx, p.kj = ops.neighbors_from_groups(p.g_kk, jj, max_kk, want_kj=True)
         else:
             p.ix, p.jx = ops.neighbors(kk, jj, kk_bound, jj_bound)
             p.g_kk = ops.group_by(kk, kk_bound)

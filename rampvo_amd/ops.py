@@ -447,17 +447,18 @@ def group_by_small(a, b, mul, sub, K, max_groups=0):
     return g
 
 
-def neighbors_from_groups(groups, jj, max_groups):
-    """cuda_ba.neighbors(kk, jj) from the per-kk groups (no extra sort)"""
+def neighbors_from_groups(groups, jj, max_groups, want_kj=False):
+    """cuda_ba.neighbors(kk, jj) from the per-kk groups (no extra sort); want_kj: also the factors in (kk, jj) order"""
     require_cuda(jj)
     jj = _idx(jj)
     E = jj.shape[0]
     ix = torch.empty(E, dtype=torch.int64, device=jj.device)
     jx = torch.empty(E, dtype=torch.int64, device=jj.device)
+    kj = torch.empty(E, dtype=torch.int32, device=jj.device) if want_kj else None
     check(lib().ramp_neighbors_from_groups(ptr(groups.order), ptr(groups.seg_start), ptr(groups.ngroups), ptr(jj),
-                                           ptr(ix), ptr(jx), E, int(max_groups), stream()),
+                                           ptr(ix), ptr(jx), ptr(kj), E, int(max_groups), stream()),
           "ramp_neighbors_from_groups")
-    return ix, jx
+    return (ix, jx, kj) if want_kj else (ix, jx)
 
 
 def neighbors(kk, jj, kk_bound=0, jj_bound=0):

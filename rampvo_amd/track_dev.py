@@ -45,7 +45,7 @@ class Track(ctypes.Structure):
                                "fe_fmap2", "fe_patches"])
                 + [("graph", c_p * 2)]
                 + _ptr_fields(["kk_order", "kk_gid", "kk_seg", "kk_ngroups", "ij_order", "ij_gid", "ij_seg", "ij_ngroups",
-                               "kk_ukeys", "ij_ukeys", "ix", "jx", "plan_ws"])
+                               "kk_ukeys", "ij_ukeys", "ix", "jx", "kj", "plan_ws"])
                 + [("plan_ws_bytes", c_sz), ("w", TrackWeights)]
                 + _ptr_fields(["coords", "corr"]) + [("net", c_p * 3)]
                 + _ptr_fields(["fg", "ykk", "hkk", "yij", "hij", "relu_t", "target", "weight", "ba_ws"])
@@ -86,7 +86,7 @@ class DeviceTrack:
                        ukeys=z(kk_cap + 2, i64))
         self.ij = dict(order=z(E_cap, i32), gid=z(E_cap, i32), seg=z(ij_cap + 2, i32), ngroups=z(1, i32),
                        ukeys=z(ij_cap + 2, i64))
-        self.ix, self.jx = z(E_cap, i64), z(E_cap, i64)
+        self.ix, self.jx, self.kj = z(E_cap, i64), z(E_cap, i64), z(E_cap, i32)
         self.plan_ws = e(lib.ramp_track_plan_workspace_bytes(E_cap, self.kkey_cap, self.pkey_cap), torch.uint8)
         self.coords = e((E_cap, 2, 3, 3), f32)
         self.corr = e((E_cap, CORR_ROW), f16)
@@ -125,7 +125,7 @@ class DeviceTrack:
                               lmbda=slam.lmbda, kk_order=self.kk["order"], kk_gid=self.kk["gid"], kk_seg=self.kk["seg"],
                               kk_ngroups=self.kk["ngroups"], kk_ukeys=self.kk["ukeys"], ij_order=self.ij["order"],
                               ij_gid=self.ij["gid"], ij_seg=self.ij["seg"], ij_ngroups=self.ij["ngroups"],
-                              ij_ukeys=self.ij["ukeys"], ix=self.ix, jx=self.jx, plan_ws=self.plan_ws,
+                              ij_ukeys=self.ij["ukeys"], ix=self.ix, jx=self.jx, kj=self.kj, plan_ws=self.plan_ws,
                               coords=self.coords, corr=self.corr, fg=self.fg, ykk=self.ykk, hkk=self.hkk, yij=self.yij,
                               hij=self.hij, relu_t=self.relu_t, target=self.target, weight=self.weight,
                               ba_ws=self.ba_ws, mm=self.mm, dlog=self.dlog, edit_ws=self.edit_ws,

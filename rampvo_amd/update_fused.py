@@ -39,6 +39,7 @@ class FusedUpdate:
         self._act_ok = True
         self.use_mlp = os.environ.get("RAMP_UPD_MLP", "1") == "1"    # fused GEMM-chain kernels (fp16 only)
         self.use_corr_mlp = os.environ.get("RAMP_CORR_MLP", "1") == "1"
+        self.use_nbr2 = os.environ.get("RAMP_NBR2", "1") == "1"      # c1 + c2 as one launch (A/B switch)
         self.before_gru = None                   # optional callable run right before a stage is enqueued
         self.hook_at = "gru"
 
@@ -208,10 +209,16 @@ class FusedUpdate:
             if self.before_gru is not None and self.hook_at == "nbr":
                 self.before_gru()
             wa, ba, wb, bb = w["c1_pack"]
+            wa2, ba2, wb2, bb2 = w["c2_pack"]
+            if getattr(plan, "kj", None) is not None and self.use_nbr2 and E * 384 * 4 < (1 << 32):
+                # c1 and c2 in ONE launch over the (kk, jj)-sorted factor list (bit-identical to the two below)
+                check(lib().ramp_upd_nbr2(ptr(net32), ptr(plan.kj), ptr(plan.ix_raw), ptr(plan.jx_raw), ptr(wa), ptr(ba),
+                                          ptr(wb), ptr(bb), ptr(wa2), ptr(ba2), ptr(wb2), ptr(bb2), ptr(tmp), E,
+                                          stream()), "ramp_upd_nbr2")
+                return self._tail(w, E, tmp, None, plan)
             check(lib().ramp_upd_nbr(ptr(net32), ptr(plan.ix_raw), ptr(wa), ptr(ba), ptr(wb), ptr(bb), ptr(tmp), None,
                                      E, stream()), "ramp_upd_nbr")
-            wa, ba, wb, bb = w["c2_pack"]
-            check(lib().ramp_upd_nbr(ptr(tmp), ptr(plan.jx_raw), ptr(wa), ptr(ba), ptr(wb), ptr(bb), ptr(net32),
+            check(lib().ramp_upd_nbr(ptr(tmp), ptr(plan.jx_raw), ptr(wa2), ptr(ba2), ptr(wb2), ptr(bb2), ptr(net32),
                                      None, E, stream()), "ramp_upd_nbr")
             return self._tail(w, E, net32, None, plan)
         g = self.gather_mask(net32, plan.ix_raw, E)

@@ -953,3 +953,36 @@ def test_upd_linear_matches_fp32_torch():
     err = (y[:live].float() - ref[:live]).abs().max().item()
     assert err <= 2e-3 * ref.abs().max().item(), err
     assert bool((y[live:] == 7.0).all())
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("E", [1003, 20011, 41003])
+def test_upd_nbr2_equals_the_two_neighbour_launches(E):
+    """c1 and c2 in one launch over the (kk, jj)-sorted factor list (csrc/update_mlp.hip::upd_nbr2_kernel) against the
+    two ramp_upd_nbr launches it replaces: every row goes through the same products in the same order -- bit equal.
+    Graph: patches with 1..40 factors each (single-factor patches: no neighbour on either side), factors shuffled."""
+    from rampvo_amd import _lib, ops
+    from rampvo_amd.update_fused import pack_linear_f16
+    rng = np.random.default_rng(E)
+    sizes = []
+    while sum(sizes) < E:
+        sizes.append(int(rng.integers(1, 41)))
+    sizes[-1] -= sum(sizes) - E
+    kk = np.repeat(np.arange(len(sizes)) + 500, sizes)
+    jj = np.concatenate([rng.permutation(60)[:s] if s <= 60 else np.arange(s) for s in sizes])
+    perm = rng.permutation(E)
+    kk, jj = kk[perm].astype(np.int64), jj[perm].astype(np.int64)
+    g = ops.group_by_small(cu(kk), None, 1, 500, len(sizes), len(sizes))
+    ix, jx, kj = ops.neighbors_from_groups(g, cu(jj), len(sizes), want_kj=True)
+    torch.manual_seed(E)
+    net = torch.randn(E, 384, device="cuda")
+    lins = [torch.nn.Linear(384, 384).cuda() for _ in range(4)]
+    wp = [pack_linear_f16(l.weight) for l in lins]
+    bs = [l.bias.detach().half().float().contiguous() for l in lins]
+    L, P = _lib.lib(), _lib.ptr
+    tmp, ref, got = torch.empty_like(net), torch.empty_like(net), torch.empty_like(net)
+    _lib.check(L.ramp_upd_nbr(P(net), P(ix), P(wp[0]), P(bs[0]), P(wp[1]), P(bs[1]), P(tmp), None, E, _lib.stream()), "nbr")
+    _lib.check(L.ramp_upd_nbr(P(tmp), P(jx), P(wp[2]), P(bs[2]), P(wp[3]), P(bs[3]), P(ref), None, E, _lib.stream()), "nbr")
+    _lib.check(L.ramp_upd_nbr2(P(net), P(kj), P(ix), P(jx), P(wp[0]), P(bs[0]), P(wp[1]), P(bs[1]), P(wp[2]), P(bs[2]),
+                               P(wp[3]), P(bs[3]), P(got), E, _lib.stream()), "nbr2")
+    assert torch.equal(got, ref), float((got - ref).abs().max())
