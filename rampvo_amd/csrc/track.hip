@@ -13,6 +13,7 @@
 //     iterations, point cloud, motion test, graph edit, the next graph's plan) without reading anything back.
 #include "ramp_device.h"
 #include "ramp_internal.h"
+#include <stdlib.h>
 
 #define TRK_EB 1024        // factors per workgroup of the edit kernels (256 threads x 4 passes)
 #define TRK_MAXBUF 10
@@ -333,10 +334,19 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
     TRK_DO(ramp_i_upd_corr_mlp(t->corr, 896, w.corr_w1, w.corr_b1, w.corr_w2, w.corr_b2, w.corr_w3, w.corr_b3, w.corr_ln_w,
                                w.corr_ln_b, w.corr_ln_eps, t->net[0], row, t->imap, kk, (long)t->M * t->mem, w.norm_w,
                                w.norm_b, w.norm_eps, t->net[1], Eb, dyn, st));
-    // c1 and c2 in one launch over the (kk, jj)-sorted factor list; the state moves net[1] -> net[2]
-    TRK_DO(ramp_i_upd_nbr2(t->net[1], t->kj, t->ix, t->jx, w.c1_wa, w.c1_ba, w.c1_wb, w.c1_bb, w.c2_wa, w.c2_ba, w.c2_wb,
-                           w.c2_bb, t->net[2], Eb, dyn, st));
+    // RAMP_NBR2=1: c1 and c2 in one launch over the (kk, jj)-sorted factor list (bit-identical; measured 2 % SLOWER on
+    // the whole operator than the two launches although it moves a third of their bytes -- DESIGN.md section 8)
+    static int nbr2 = -1;
+    if (nbr2 < 0) { const char *e = getenv("RAMP_NBR2"); nbr2 = e ? atoi(e) : 0; }
     float *net = t->net[2];
+    if (nbr2) {
+      TRK_DO(ramp_i_upd_nbr2(t->net[1], t->kj, t->ix, t->jx, w.c1_wa, w.c1_ba, w.c1_wb, w.c1_bb, w.c2_wa, w.c2_ba, w.c2_wb,
+                             w.c2_bb, t->net[2], Eb, dyn, st));
+    } else {
+      TRK_DO(ramp_i_upd_nbr(t->net[1], t->ix, w.c1_wa, w.c1_ba, w.c1_wb, w.c1_bb, t->net[2], nullptr, Eb, dyn, st));
+      TRK_DO(ramp_i_upd_nbr(t->net[2], t->jx, w.c2_wa, w.c2_ba, w.c2_wb, w.c2_bb, t->net[1], nullptr, Eb, dyn, st));
+      net = t->net[1];
+    }
     TRK_DO(ramp_i_upd_fg(net, nullptr, nullptr, nullptr, w.kk_wf, w.kk_bf, w.kk_wg, w.kk_bg, t->fg, Eb, dyn, st));
     TRK_DO(ramp_upd_segment_softmax(t->fg, t->kk_order, t->kk_seg, t->kk_ngroups, t->ykk, t->kk_cap, RAMP_F16, stream));
     TRK_DO(ramp_upd_linear(t->ykk, w.kk_wh, w.kk_bh, t->hkk, t->kk_cap, t->kk_ngroups, stream));

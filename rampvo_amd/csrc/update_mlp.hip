@@ -797,36 +797,45 @@ __device__ __forceinline__ void big_zero(f4 (&acc)[NMT][NTW]) {
 // accumulators).  The weight fragments of K step ks + 1 are ISSUED before the matrix work of step ks (the scheduling
 // barrier keeps the compiler from sinking them to their first use, which exposed their full L2 latency every step);
 // the A fragment of row tile mt + 1 is read from LDS while tile mt multiplies.
+#ifndef BIG_PF
+#define BIG_PF 1   // measured: 2 is 2 % slower on the whole operator (128 / 146 VGPRs), 1 is the round-2 kernel
+#endif
 template <int NMT, int NTW>
 __device__ __forceinline__ void big_gemm(const _Float16 *Xs, const _Float16 *wp, int nks, int w_ks0, int wave, int lane,
                                          f4 (&acc)[NMT][NTW]) {
   const int q = lane >> 4, j = lane & 15;
   const _Float16 *wb = wp + (((size_t)w_ks0 * (MD / 16) + wave * NTW) * 64 + lane) * 8;
   const _Float16 *xb = Xs + j * MXS + 8 * q;
-  h8 bn[NTW];
+  // the weight fragments of the next BIG_PF K steps are in flight while the matrix cores work on this one
+  h8 ring[BIG_PF + 1][NTW];
 #pragma unroll
-  for (int nt = 0; nt < NTW; nt++) bn[nt] = *reinterpret_cast<const h8 *>(wb + (size_t)nt * 512);
-#pragma unroll 1
-  for (int ks = 0; ks < nks; ks++) {
-    h8 bw[NTW];
-#pragma unroll
-    for (int nt = 0; nt < NTW; nt++) bw[nt] = bn[nt];
-    const int kn = ks + 1 < nks ? ks + 1 : ks;
+  for (int d = 0; d < BIG_PF; d++)
 #pragma unroll
     for (int nt = 0; nt < NTW; nt++)
-      bn[nt] = *reinterpret_cast<const h8 *>(wb + ((size_t)kn * (MD / 16) + nt) * 512);
-    h8 a = *reinterpret_cast<const h8 *>(xb + ks * 32);
-    __builtin_amdgcn_sched_barrier(0);
+      ring[d][nt] = *reinterpret_cast<const h8 *>(wb + ((size_t)(d < nks ? d : nks - 1) * (MD / 16) + nt) * 512);
+#pragma unroll 1
+  for (int ks0 = 0; ks0 < nks; ks0 += BIG_PF + 1) {
 #pragma unroll
-    for (int mt = 0; mt < NMT; mt++) {
-      h8 an = a;
-      if (mt + 1 < NMT) an = *reinterpret_cast<const h8 *>(xb + (mt + 1) * 16 * MXS + ks * 32);
+    for (int r = 0; r < BIG_PF + 1; r++) {             // static ring index
+      const int ks = ks0 + r;
+      if (ks >= nks) break;
+      const int kn = ks + BIG_PF < nks ? ks + BIG_PF : nks - 1;
 #pragma unroll
       for (int nt = 0; nt < NTW; nt++)
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bw[nt], a, acc[mt][nt], 0, 0, 0);
-      a = an;
+        ring[(r + BIG_PF) % (BIG_PF + 1)][nt] = *reinterpret_cast<const h8 *>(wb + ((size_t)kn * (MD / 16) + nt) * 512);
+      h8 a = *reinterpret_cast<const h8 *>(xb + ks * 32);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mt = 0; mt < NMT; mt++) {
+        h8 an = a;
+        if (mt + 1 < NMT) an = *reinterpret_cast<const h8 *>(xb + (mt + 1) * 16 * MXS + ks * 32);
+#pragma unroll
+        for (int nt = 0; nt < NTW; nt++)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[r][nt], a, acc[mt][nt], 0, 0, 0);
+        a = an;
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -949,7 +958,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) upd_nbr_big_kernel(const NbrP
 // with ONE read of every state row (plus the one-row halo at either end) and one write.  Tile row 79 is a zero row in
 // both chains: it yields c1(0) / c2(0), what the reference's masked gather feeds a factor without a neighbour.  The
 // row shift between the chains happens where out1 goes back to LDS as the c2 input (row u is stored as row u - 1), so
-// every lane adds values of rows it owns; out1 stays in registers (fp32) for the final sum.
+// every lane adds values of rows it owns.
 struct Nbr2Params {
   const float *net_in;         // [E][384] fp32
   float *net_out;              // [E][384] fp32, a different buffer
@@ -961,7 +970,7 @@ struct Nbr2Params {
   const int32_t *dyn;          // optional device-side sizes (RAMP_DYN_*): E is then the launch bound
 };
 #define NBR2_OUT 78
-__global__ void __launch_bounds__(512, 2) upd_nbr2_kernel(const Nbr2Params p) {
+__global__ void __launch_bounds__(512, 4) upd_nbr2_kernel(const Nbr2Params p) {
   constexpr int NMT = 5, NW = 8, NTW = 3, ROWS = 80;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   _Float16 *Xs = reinterpret_cast<_Float16 *>(smem_raw);
@@ -1032,7 +1041,9 @@ __global__ void __launch_bounds__(512, 2) upd_nbr2_kernel(const Nbr2Params p) {
                       h_round(acc[NMT - 1][nt][2] + bv[nt].z), h_round(acc[NMT - 1][nt][3] + bv[nt].w));
   }
   __syncthreads();                                       // Ks written; every wave is past its reads of the hidden tile
-  float4 o1[NMT][NTW];
+  // out1 = net + (has_prev ? G : c1(0)): its fp16 copy is the c2 input; the fp32 value is parked in the OUTPUT row
+  // (this lane re-reads its own 16-byte pieces after the second chain: program order, no fence) -- holding it in 60
+  // registers instead left one workgroup per CU (176 VGPRs) and nothing to overlap a workgroup's gather with
   {
     float4 kz[NTW];
 #pragma unroll
@@ -1040,21 +1051,19 @@ __global__ void __launch_bounds__(512, 2) upd_nbr2_kernel(const Nbr2Params p) {
 #pragma unroll
     for (int mt = 0; mt < NMT; mt++) {
       const bool hp = (has_prev >> mt) & 1, lv = (live1 >> mt) & 1;
+      const int u = mt * 16 + j;
 #pragma unroll
       for (int nt = 0; nt < NTW; nt++) {
         const float4 x = ldg4(p.net_in, ro[mt], nt);
         float4 g = make_float4(h_round(acc[mt][nt][0] + bv[nt].x), h_round(acc[mt][nt][1] + bv[nt].y),
                                h_round(acc[mt][nt][2] + bv[nt].z), h_round(acc[mt][nt][3] + bv[nt].w));
         if (!hp) g = kz[nt];
-        o1[mt][nt] = lv ? make_float4(x.x + g.x, x.y + g.y, x.z + g.z, x.w + g.w) : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-      // c2 input: out1 of row u goes to tile row u - 1 (row 0 feeds the previous workgroup's last factor, not ours)
-      const int u = mt * 16 + j;
-      if (u >= 1) {
-#pragma unroll
-        for (int nt = 0; nt < NTW; nt++)
+        const float4 o = lv ? make_float4(x.x + g.x, x.y + g.y, x.z + g.z, x.w + g.w) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((live2 >> mt) & 1) stg4(p.net_out, ro[mt], nt, o);
+        // c2 input: out1 of row u goes to tile row u - 1 (row 0 feeds the previous workgroup's last factor, not ours)
+        if (u >= 1)
           *reinterpret_cast<hh4 *>(Xs + (u - 1) * MXS + col0 + nt * 16 + 4 * q) =
-              (hh4){(_Float16)o1[mt][nt].x, (_Float16)o1[mt][nt].y, (_Float16)o1[mt][nt].z, (_Float16)o1[mt][nt].w};
+              (hh4){(_Float16)o.x, (_Float16)o.y, (_Float16)o.z, (_Float16)o.w};
       }
     }
     if (j == 15) {                                         // tile row 79: the zero row of the second chain
@@ -1090,7 +1099,8 @@ __global__ void __launch_bounds__(512, 2) upd_nbr2_kernel(const Nbr2Params p) {
       float4 g = make_float4(h_round(acc[mt][nt][0] + bv[nt].x), h_round(acc[mt][nt][1] + bv[nt].y),
                              h_round(acc[mt][nt][2] + bv[nt].z), h_round(acc[mt][nt][3] + bv[nt].w));
       if (!((has_next >> mt) & 1)) g = kz;
-      stg4(p.net_out, ro[mt], nt, make_float4(o1[mt][nt].x + g.x, o1[mt][nt].y + g.y, o1[mt][nt].z + g.z, o1[mt][nt].w + g.w));
+      const float4 o1 = ldg4(p.net_out, ro[mt], nt);
+      stg4(p.net_out, ro[mt], nt, make_float4(o1.x + g.x, o1.y + g.y, o1.z + g.z, o1.w + g.w));
     }
   }
 }
@@ -1370,7 +1380,10 @@ int ramp_i_upd_fg(const float *x32, const void *add_t, const int32_t *add_idx, f
   FgParams p;
   p.x32 = x32; p.add_t = (const _Float16 *)add_t; p.add_idx = add_idx; p.x32_out = x32_out;
   p.wf = (const _Float16 *)wf; p.wg = (const _Float16 *)wg; p.bf = bf; p.bg = bg; p.fg = (_Float16 *)fg; p.E = E; p.dyn = dyn;
-  if (const int nmt = big_pick_nmt(E, 6)) { BIG_DISPATCH(upd_fg_big_kernel, 8, p, E, nmt, false, (hipStream_t)stream) }
+  #ifndef FG_BEST
+#define FG_BEST 6
+#endif
+  if (const int nmt = big_pick_nmt(E, FG_BEST)) { BIG_DISPATCH(upd_fg_big_kernel, 8, p, E, nmt, false, (hipStream_t)stream) }
   const size_t lds = (size_t)MBM * MXS * 2;
   hipLaunchKernelGGL(upd_fg_kernel, dim3(ramp_cdiv(E, MBM)), dim3(64 * MWAVES), lds, (hipStream_t)stream, p);
   RAMP_CHECK_LAUNCH();

@@ -39,7 +39,7 @@ class FusedUpdate:
         self._act_ok = True
         self.use_mlp = os.environ.get("RAMP_UPD_MLP", "1") == "1"    # fused GEMM-chain kernels (fp16 only)
         self.use_corr_mlp = os.environ.get("RAMP_CORR_MLP", "1") == "1"
-        self.use_nbr2 = os.environ.get("RAMP_NBR2", "1") == "1"      # c1 + c2 as one launch (A/B switch)
+        self.use_nbr2 = os.environ.get("RAMP_NBR2", "0") == "1"      # c1 + c2 as one launch (A/B switch; measured slower)
         self.before_gru = None                   # optional callable run right before a stage is enqueued
         self.hook_at = "gru"
 
