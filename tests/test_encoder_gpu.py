@@ -151,6 +151,7 @@ def test_conv_tower_pair_equals_single_launches(cin, couts, k, stride, hw, first
             assert torch.equal(again[1], pair[1])
 
 
+ENC_HIP_VS_ATEN_TOL = 4e-5  # fp32 HIP encoder against the ATen forward of the same modules, x the map's largest entry (measured 4.9e-6 / 9.4e-6)
 FP8_LAYER_TOL = 2e-3        # x the output scale: what is left after both sides use the SAME e4m3-rounded operands
 FP8_ENCODER_TOL = 0.2       # max abs error of fmap / imap against the f16-MFMA towers, x the map's largest entry (measured: 0.07-0.125)
 
@@ -299,10 +300,14 @@ def test_singlescale_encoder_hip_vs_aten():
                     f, i, _ = fwd(events=ev.cuda(), images=im.cuda(), reinit_hidden=(t == 0), out_scale=0.25)
                 res.append((f.float().clone(), i.float().clone()))
             outs[backend] = res
+    worst = 0.0
     for (f0, i0), (f1, i1) in zip(outs["torch"], outs["hip"]):
         assert f0.shape == f1.shape and i0.shape == i1.shape
-        assert float((f0 - f1).abs().max()) <= 2e-3 * float(f0.abs().max())
-        assert float((i0 - i1).abs().max()) <= 2e-3 * float(i0.abs().max())
+        ef = float((f0 - f1).abs().max()) / float(f0.abs().max())
+        ei = float((i0 - i1).abs().max()) / float(i0.abs().max())
+        worst = max(worst, ef, ei)
+        assert ef <= ENC_HIP_VS_ATEN_TOL and ei <= ENC_HIP_VS_ATEN_TOL, (ef, ei)
+    print("HIP fp32 encoder vs ATen, worst max-abs / max:", worst)
 
 
 def _torch_towers():
@@ -354,10 +359,14 @@ def test_multiscale_encoder_hip_vs_aten():
     for a, b in zip(ref_states, states):
         assert a.shape == b.shape and float((a - b).abs().max()) <= 2e-5 * max(1.0, float(a.abs().max()))
     assert len(outs["hip"]) == 3
+    worst = 0.0
     for (f0, i0), (f1, i1) in zip(outs["torch"], outs["hip"]):
         assert f0.shape == f1.shape and i0.shape == i1.shape
-        assert float((f0 - f1).abs().max()) <= 2e-3 * float(f0.abs().max())
-        assert float((i0 - i1).abs().max()) <= 2e-3 * float(i0.abs().max())
+        ef = float((f0 - f1).abs().max()) / float(f0.abs().max())
+        ei = float((i0 - i1).abs().max()) / float(i0.abs().max())
+        worst = max(worst, ef, ei)
+        assert ef <= ENC_HIP_VS_ATEN_TOL and ei <= ENC_HIP_VS_ATEN_TOL, (ef, ei)
+    print("HIP fp32 encoder vs ATen, worst max-abs / max:", worst)
 
 
 @pytest.mark.parametrize("mode", ["SingleScale", "MultiScale"])

@@ -12,11 +12,11 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["SingleScale", "MultiScale"])
 def test_patchify_against_reference_golden(mode):
     # encoder runs through MIOpen/own conv kernels: fp32, different summation order than CPU
-    print(pc.check_patchify(mode, "cuda", tol=2e-3))
+    print(pc.check_patchify(mode, "cuda", tol=6e-5))      # measured 4.8e-6 (SingleScale) / 1.4e-5 (MultiScale)
 
 
 def test_update_operator_against_reference_golden():
-    print(pc.check_update("cuda", tol=1e-3))
+    print(pc.check_update("cuda", tol=3e-6))                # measured 5.7e-7
 
 
 def test_update_step_teacher_forced():
@@ -82,7 +82,7 @@ def _steady_state_snapshot(mode, preset, M, H, W, frames, mixed, seed=4321, **ov
 STEP_W_BIAS = -14.0
 
 
-def _one_update_vs_cpu_oracle(mode, preset, H, W, sd, cfgk, legs=(False,)):
+def _one_update_vs_cpu_oracle(mode, preset, H, W, sd, cfgk, legs=(False,), w_bias=None):
     """ONE update() (reproject -> corr -> update operator -> BA x2 -> point cloud) from the same snapshot: HIP kernels
     (a fresh tracker per precision leg) vs the CPU oracle backend in fp32 (torch-CPU GEMMs + oracle C natives).
     Returns {leg: errors}; errors are max-abs, poses/depths relative to max(1, size of the GN step)."""
@@ -91,6 +91,7 @@ def _one_update_vs_cpu_oracle(mode, preset, H, W, sd, cfgk, legs=(False,)):
     from rampvo_amd.config import make_cfg
     from rampvo_amd.Ramp_vo import Ramp_vo
     from rampvo_amd.synthetic import make_network
+    w_bias = STEP_W_BIAS if w_bias is None else w_bias
     n = int(sd["n"])
     before = sd["poses"][:n].numpy().copy()
     f32 = dict(sd)
@@ -98,7 +99,7 @@ def _one_update_vs_cpu_oracle(mode, preset, H, W, sd, cfgk, legs=(False,)):
         f32[k] = sd[k].float()
     with cpu_oracle_ops():
         ref = cpu_tracker(make_cfg(preset, **dict(cfgk, MIXED_PRECISION=False)),
-                          make_network(mode, device="cpu", w_bias=STEP_W_BIAS), {"event_bias": True}, ht=H, wd=W)
+                          make_network(mode, device="cpu", w_bias=w_bias), {"event_bias": True}, ht=H, wd=W)
         ref.load_state_dict(f32)
         ref.update()
         r_poses = ref.poses_[:n].numpy().copy()
@@ -107,7 +108,7 @@ def _one_update_vs_cpu_oracle(mode, preset, H, W, sd, cfgk, legs=(False,)):
         r_w = ref.last_weight.numpy().copy()
     step = float(np.abs(r_poses - before).max())
     out = {}
-    net = make_network(mode, w_bias=STEP_W_BIAS)
+    net = make_network(mode, w_bias=w_bias)
     for mixed in legs:
         slam = Ramp_vo(make_cfg(preset, **dict(cfgk, MIXED_PRECISION=mixed)), net, {"event_bias": True}, ht=H, wd=W)
         slam.load_state_dict(sd)
@@ -125,7 +126,9 @@ def _one_update_vs_cpu_oracle(mode, preset, H, W, sd, cfgk, legs=(False,)):
             E=len(slam._ii), n=n, jj_max=int(slam._jj.max()), step=step,
             net=float(np.abs(g_net - r_net).max() / np.abs(r_net).max()), weight=float(np.abs(g_w - r_w).max()),
             poses=float(np.abs(g_poses - r_poses).max()),
+            poses_over_step=float(np.abs(g_poses - r_poses).max() / max(step, 1e-12)),
             depths=float(derr[~at_reset].max()), depths_p995=float(np.percentile(derr, 99.5)),
+            depths_p999=float(np.percentile(derr, 99.9)), w_mean=float(r_w.mean()),
             at_reset=int(at_reset.sum()), patches=int(at_reset.size),
             depth_range=(float(r_depth.min()), float(r_depth.max())))
     return out
@@ -136,6 +139,7 @@ def _assert_fp32_leg(e):
     assert e["at_reset"] <= 0.02 * e["patches"], e
     assert e["net"] <= 1e-4 and e["weight"] <= 1e-4, e
     assert e["poses"] <= 1e-4 * scale and e["depths"] <= 1e-4 * scale, e
+    assert e["poses_over_step"] <= 1e-4, e           # also relative to the GN step itself (measured 2.6e-6)
 
 
 # stated bounds of the fp16 (MIXED_PRECISION, the benchmarked) leg against the fp32 oracle: hidden state / confidence
@@ -143,6 +147,14 @@ def _assert_fp32_leg(e):
 # depths: 99.5th percentile of the relative error (measured <= 2e-3 ... the maximum is a patch that one leg resets
 # through d > 20 -> 1 and the other does not: a step function of an fp16-accurate input)
 MIXED_NET, MIXED_WEIGHT, MIXED_POSES, MIXED_DEPTHS = 2e-3, 1e-4, 5e-3, 2e-2
+MIXED_DEPTHS_P999 = 1e-1       # the 99.9th percentile (p99.5 alone lets a handful of broken patches through)
+
+
+def _assert_fp16_leg(m):
+    scale = max(1.0, m["step"])
+    assert m["net"] <= MIXED_NET and m["weight"] <= MIXED_WEIGHT, m
+    assert m["poses"] <= MIXED_POSES * scale and m["depths_p995"] <= MIXED_DEPTHS * scale, m
+    assert m["depths_p999"] <= MIXED_DEPTHS_P999 * scale, m
 
 
 @torch.no_grad()
@@ -155,10 +167,32 @@ def test_full_size_update_step_against_cpu_oracle():
     e = _one_update_vs_cpu_oracle("SingleScale", "default", 480, 640, sd, cfgk, legs=(False, True))
     print(e)
     _assert_fp32_leg(e["fp32"])
-    m = e["fp16"]
-    scale = max(1.0, m["step"])
-    assert m["net"] <= MIXED_NET and m["weight"] <= MIXED_WEIGHT, m
-    assert m["poses"] <= MIXED_POSES * scale and m["depths_p995"] <= MIXED_DEPTHS * scale, m
+    _assert_fp16_leg(e["fp16"])
+
+
+# (w_bias shift, stated bound on |pose error| / GN step and on the depth error relative to max(1, |depth|), fp32 leg).
+# -14: the regime every other full-size test uses.  -6 and 0 (the "wide" profile as tracked, confidences ~0.5): the
+# normal equations of a random-weight tracker get ill conditioned (Q = 1 / (C + 1e-4) up to 1e4 on depths seen over almost
+# no baseline) and fp32 rounding differences between two correct implementations grow with the condition number; the
+# bounds are 4x the values measured on MI355X (printed by the test), not 1e-4.
+# Measured (MI355X, E = 27,360): w_bias -6: |pose error| / GN step 7.0e-6, depths 99.9th percentile 1.2e-3, worst 3.1e-3;
+# w_bias 0: 1.6e-5, 1.9e-3, 2.3e-3 (w_bias -14: 2.6e-6, 4.3e-6, 5.2e-6).  Poses meet the north star's 1e-4 of the step
+# in every regime; the depths that do not are the ill-conditioned ones (fp64 build of the same oracle: same order).
+REGIME_BOUNDS = {-6.0: (1e-4, 5e-3, 1.3e-2), 0.0: (1e-4, 8e-3, 1.0e-2)}      # poses / step, depths p99.9, depths max
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("w_bias", [-6.0, 0.0])
+def test_full_size_update_step_in_the_wide_regime(w_bias):
+    """configs[1] size, ONE update() vs the CPU oracle with the confidence head NOT damped to 1e-6 (ADVICE r2 /
+    VERDICT r2 4d): -6 = moderately conditioned (confidences ~2.5e-3), 0 = the weights exactly as the benchmark tracks
+    with them.  fp32 leg; the error is reported relative to the GN step itself and bounded by REGIME_BOUNDS."""
+    slam, sd, cfgk = _steady_state_snapshot("SingleScale", "default", 96, 480, 640, 34, mixed=True)
+    e = _one_update_vs_cpu_oracle("SingleScale", "default", 480, 640, sd, cfgk, legs=(False,), w_bias=w_bias)["fp32"]
+    print(w_bias, e)
+    assert e["net"] <= 1e-4 and e["weight"] <= 1e-4, e            # everything in front of BA is regime independent
+    bp, bd, bm = REGIME_BOUNDS[w_bias]
+    assert e["poses_over_step"] <= bp and e["depths_p999"] <= bd and e["depths"] <= bm, e
 
 
 @torch.no_grad()
@@ -174,10 +208,7 @@ def test_config3_multiscale_precise_windows_update_step_against_cpu_oracle():
     e = _one_update_vs_cpu_oracle("MultiScale", "precise", 480, 640, sd, cfgk, legs=(False, True))
     print(e)
     _assert_fp32_leg(e["fp32"])
-    m = e["fp16"]
-    scale = max(1.0, m["step"])
-    assert m["net"] <= MIXED_NET and m["weight"] <= MIXED_WEIGHT, m
-    assert m["poses"] <= MIXED_POSES * scale and m["depths_p995"] <= MIXED_DEPTHS * scale, m
+    _assert_fp16_leg(e["fp16"])
 
 
 @torch.no_grad()
@@ -190,10 +221,63 @@ def test_config5_720p_256_patches_32_keyframe_window_update_step_against_cpu_ora
     e = _one_update_vs_cpu_oracle("MultiScale", "precise", 720, 1280, sd, cfgk, legs=(False, True))
     print(e)
     _assert_fp32_leg(e["fp32"])
-    m = e["fp16"]
-    scale = max(1.0, m["step"])
-    assert m["net"] <= MIXED_NET and m["weight"] <= MIXED_WEIGHT, m
-    assert m["poses"] <= MIXED_POSES * scale and m["depths_p995"] <= MIXED_DEPTHS * scale, m
+    _assert_fp16_leg(e["fp16"])
+
+
+@torch.no_grad()
+def test_config5_as_written_fp8_encoder_update_step_against_cpu_oracle():
+    """BASELINE.json configs[4] AS WRITTEN: MultiScale 1280x720, 256 patches, 32-keyframe window, precise.yaml lifetimes,
+    "fp16 encoder on fp8 MFMA" (cfg.ENCODER_FP8): the snapshot is tracked with the fp8-MFMA conv towers at full size,
+    then one update() in the benchmarked precision vs the CPU oracle from the same snapshot (the oracle takes the
+    features the fp8 encoder produced: the update operator, correlation and BA are what is compared here; the fp8
+    encoder's own error is stated in tests/test_encoder_gpu.py)."""
+    over = dict(OPTIMIZATION_WINDOW=32, KEYFRAME_THRESH=0.0, ENCODER_FP8=True)
+    slam, sd, cfgk = _steady_state_snapshot("MultiScale", "precise", 256, 720, 1280, 40, mixed=True, **over)
+    assert slam.network.patchify.encoder.fp8_mfma and slam.n > 33 and len(slam._ii) > 300000, (slam.n, len(slam._ii))
+    cfgk = {k: v for k, v in cfgk.items() if k != "ENCODER_FP8"}          # (the oracle backend has no such switch)
+    e = _one_update_vs_cpu_oracle("MultiScale", "precise", 720, 1280, sd, cfgk, legs=(True,))
+    print(e)
+    _assert_fp16_leg(e["fp16"])
+
+
+@torch.no_grad()
+def test_pose_prediction_helpers_against_reference_golden_on_the_gpu():
+    """SURVEY 8f N4 on the device: the virtual keyframe's pose (motion model through the HIP SE3 kernels), the appended
+    factors, the patch tracks cut out of the factor list and the coords / weights the spline models write -- CUDA
+    tensors in, against the reference helpers' own outputs (tests/golden/pose_pred.npz; the CPU twin of this test runs
+    the same calls over the oracle backend)."""
+    import os
+    from rampvo_amd.pose_prediction import pose_pred_utils as pp
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pose_pred.npz"))
+    n, M, r = int(g["n"]), int(g["M"]), int(g["r"])
+    T = lambda k: torch.from_numpy(g[k]).cuda()          # noqa: E731
+    boot = pp.motion_bootstrap(n=n, poses=T("poses_in")[0], MOTION_MODEL="DAMPED_LINEAR", MOTION_DAMPING=0.5)
+    err = float(np.abs(boot.cpu().numpy() - g["boot"]).max())
+    print("virtual keyframe pose vs reference:", err)
+    assert err <= 1e-6
+    ii, jj, kk, w = pp.add_forward_elements(frame_num=n + 1, patch_extracted_num=M, r=r, ii=T("ii"), jj=T("jj"),
+                                            kk=T("kk"), ix=T("ix"), weights=T("last_weight").clone())
+    assert np.array_equal(ii.cpu().numpy(), g["ii2"]) and np.array_equal(jj.cpu().numpy(), g["jj2"])
+    assert np.array_equal(kk.cpu().numpy(), g["kk2"]) and tuple(w.shape) == tuple(g["w_up_shape"])
+    coords = T("coords_in").clone()
+    tracks = pp.compute_patch_track__(coords=coords, ii=ii, jj=jj, kk=kk, image_to_proj=n)
+    assert np.array_equal(np.array(list(tracks.keys()), np.int64), g["track_keys"])
+    assert np.array_equal(np.array([len(v) for v in tracks.values()]), g["track_lens"])
+    assert np.array_equal(np.concatenate([v.cpu().numpy() for v in tracks.values()], 0), g["track_xy"])
+    # The time stamps stay a CPU tensor here: `tstamps / frequency` is one float32 division per keyframe, and torch's
+    # device kernel divides by a scalar as x * (1 / 30) -- one ulp off the CPU's true division on some stamps, which the
+    # cubic splines' extrapolation amplifies to 4e-2 px (measured).  The fixture was generated on the CPU; upstream runs
+    # that line on its CUDA tensor.  Everything else in the call is a CUDA tensor.
+    models = pp.fit_model_patch_track(next_frame_index=n, patch_dict=tracks, img_to_keyframe_map=T("tstamps").cpu(),
+                                      ii=ii, jj=jj, data_shape=(int(g["ht"]), int(g["wd"])),
+                                      frequency=int(g["frequency"]), deg=int(g["deg"]))
+    c2, w2 = pp.predict_patch_on_model(patch_models=models, step_to_pred_future=int(g["step"]),
+                                       frequency=int(g["frequency"]), next_frame_index=n, coords=coords, weights=w,
+                                       ii=ii, jj=jj, kk=kk)
+    assert np.array_equal(w.cpu().numpy(), g["weights_out"])
+    cerr = float(np.abs(coords.cpu().numpy() - g["coords_out"]).max())
+    print("predicted coords vs reference:", cerr)
+    assert cerr <= 1e-6, cerr                                          # same FITPACK, same arithmetic (measured 0)
 
 
 @pytest.mark.parametrize("tag", ["ss", "ms"])
