@@ -457,10 +457,31 @@ def parity_block(state, args, cfg_kwargs, net, dev):
                 net=float(np.abs(slam.net[0].float().cpu().numpy() - r["net"]).max() / np.abs(r["net"]).max()),
                 weight=float(np.abs(slam.last_weight.cpu().numpy() - r["w"]).max()),
                 poses=float(np.abs(slam.poses_[:n].cpu().numpy() - r["poses"]).max() / scale),
-                depths=float(np.percentile(derr, 99.5) / scale), depths_max=float(derr.max() / scale),
+                poses_over_gn_step=float(np.abs(slam.poses_[:n].cpu().numpy() - r["poses"]).max() / max(step, 1e-12)),
+                depths=float(np.percentile(derr, 99.5) / scale), depths_p999=float(np.percentile(derr, 99.9) / scale),
+                depths_max=float(derr.max() / scale),
                 depths_at_reset_threshold=float(at_reset.sum()))
             tf[name] = {k: float("%.3g" % v) for k, v in leg.items()}
             del slam
+    # the same step with the weights exactly as the benchmark tracks with them (no bias shift: confidences ~0.5, the
+    # ill-conditioned regime), fp32 leg: the stated bounds of tests/test_pipeline_gpu.py::REGIME_BOUNDS apply
+    net0 = make_network(args.mode, device=dev)
+    with cpu_oracle_ops():
+        ref = _cpu_tracker(state, args, cfg_kwargs)
+        ref.update()
+        r0 = dict(poses=ref.poses_[:n].numpy().copy(), depth=ref.patches_[:n, :, 2, 1, 1].numpy().copy())
+    slam = Ramp_vo(make_cfg(args.preset, **dict(cfg_kwargs, MIXED_PRECISION=False)), net0, {"event_bias": True},
+                   ht=args.height, wd=args.width, device=dev)
+    slam.load_state_dict(state)
+    slam.update()
+    g_depth = slam.patches_[:n, :, 2, 1, 1].cpu().numpy()
+    step0 = float(np.abs(r0["poses"] - before).max())
+    at_reset = (np.abs(r0["depth"] - 20.0) < 0.1) | (np.abs(g_depth - 20.0) < 0.1)
+    derr = (np.abs(g_depth - r0["depth"]) / np.maximum(np.abs(r0["depth"]), 1.0))[~at_reset]
+    tf["fp32_wide_regime"] = {k: float("%.3g" % v) for k, v in dict(
+        gn_step=step0, poses_over_gn_step=float(np.abs(slam.poses_[:n].cpu().numpy() - r0["poses"]).max() / max(step0, 1e-12)),
+        depths_p999=float(np.percentile(derr, 99.9)), depths_max=float(derr.max())).items()}
+    del slam
     out = dict(teacher_forced=tf)
     # trajectory level: tests/pipeline_checks.py::check_trajectory against tests/golden/ramp_vo_traj_ss.npz
     sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -453,6 +453,16 @@ template <> struct CorrMma<float> {
   static __device__ __forceinline__ void st2(float *p, float a, float b) { *reinterpret_cast<float2 *>(p) = make_float2(a, b); }
 };
 
+#ifdef CORR_TRACE
+// phase timeline of corr_mfma_kernel (tools/corr_trace.py): shader-clock stamps of every wave, summed per phase
+#define CORR_TRACE_WAVES 65536
+__device__ unsigned long long g_corr_trace[CORR_TRACE_WAVES * 8];    // one row per workgroup (= wave = edge), no atomics
+#define CTS(var) const unsigned long long var = __builtin_readcyclecounter()
+#define CTACC(k, v) do { if (threadIdx.x == 0 && blockIdx.x < CORR_TRACE_WAVES) g_corr_trace[blockIdx.x * 8 + (k)] = (unsigned long long)(v); } while (0)
+#else
+#define CTS(var)
+#define CTACC(k, v)
+#endif
 template <typename T, bool CHUNKED>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CorrMma<T>::WAVES, 8)))
     corr_mfma_kernel(const CorrParams prm) {
@@ -470,6 +480,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CorrMma
 
   const int e = corr_edge_of_block(prm);
   if (e < 0) return;
+  CTS(ct_start);
+#ifdef CORR_TRACE
+  unsigned long long ct_load = 0, ct_mma = 0, ct_blend = 0, ct_setup = 0;
+#endif
   const int lane = threadIdx.x, q = lane >> 4, j = lane & 15;
   const long i1 = prm.mod_ii > 0 ? prm.ii[e] % prm.mod_ii : prm.ii[e];   // ring-buffer slots (Ramp_vo.py:178-179)
   const long j2 = prm.mod_jj > 0 ? prm.jj[e] % prm.mod_jj : prm.jj[e];
@@ -490,6 +504,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CorrMma
 #pragma unroll
   for (int lvl = 0; lvl < CORR_MAXLEV; lvl++) {
     if (lvl >= L) break;
+    CTS(ct_l0);
     const int H2 = prm.H2[lvl], W2 = prm.W2[lvl];
     const T *f2 = reinterpret_cast<const T *>(prm.fmap2[lvl]) + (size_t)j2 * C * H2 * W2;
     if (lane < PP) {
@@ -547,7 +562,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CorrMma
       const int Tn = gw * gh;                      // <= CORR_T = 128
       const int npg = (Tn + 15) / 16;
       const int inv_gw = (65536 + gw - 1) / gw;    // t / gw == (t * inv_gw) >> 16 while t * gw < 65536
+#ifdef CORR_TRACE
+      { CTS(ct_l1); ct_setup += ct_l1 - ct_l0; }
+#endif
       for (int pg0 = 0; pg0 < npg; pg0 += PGB) {
+        CTS(ct_b0);
         // all PGB x 4 sixteen-byte loads of the batch are issued before the first MFMA waits on
         // one: the address is always a valid pixel, out-of-window lanes are zeroed afterwards
         frag_t bfr[PGB][STEPS];
@@ -566,6 +585,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CorrMma
 #pragma unroll
           for (int s = 0; s < STEPS; s++) bfr[u][s] = *reinterpret_cast<const frag_t *>(pp + s * sstride);
         }
+#ifdef CORR_TRACE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        CTS(ct_b1);
+        ct_load += ct_b1 - ct_b0;
+#endif
 #pragma unroll
         for (int u = 0; u < PGB; u++) {
           const int t = (pg0 + u) * 16 + j;
@@ -582,8 +606,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CorrMma
             }
           }
         }
+#ifdef CORR_TRACE
+        { CTS(ct_b2); ct_mma += ct_b2 - ct_b1; }
+#endif
       }
       __syncthreads();
+      CTS(ct_c0);
       if (uni) {
         // lane = 9 a + p owns output row a of patch pixel p; its 7 outputs (b = 0..6) are
         // o = (7 b + a) 9 + p = lane + 63 b and need two 8-wide rows of Cs
@@ -622,6 +650,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CorrMma
         }
       }
       __syncthreads();
+#ifdef CORR_TRACE
+      { CTS(ct_c1); ct_blend += ct_c1 - ct_c0; }
+#endif
     }
     if (!uni) {
       __syncthreads();
@@ -645,6 +676,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CorrMma
       for (int k = 0; k < KOUT; k++) M::st(op + lane + 63 * k, res[0][k]);
     }
   }
+#ifdef CORR_TRACE
+  {
+    CTS(ct_end);
+    CTACC(0, 1); CTACC(1, ct_end - ct_start); CTACC(2, ct_setup); CTACC(3, ct_load); CTACC(4, ct_mma); CTACC(5, ct_blend);
+  }
+#endif
 }
 
 
@@ -694,6 +731,11 @@ __global__ void __launch_bounds__(256) pyramid_pack_kernel(const uint4 *__restri
 
 extern "C" {
 
+#ifdef CORR_TRACE
+int ramp_debug_corr_trace(unsigned long long *host, int n_waves) {     // host [n_waves][8]
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_corr_trace), (size_t)n_waves * 8 * 8) == hipSuccess ? 0 : -1;
+}
+#endif
 int ramp_pyramid_pack(const void *fmap, void *level1, void *level4, int H, int W, int C, int dtype,
                       void *stream) {
   if (!fmap || !level1 || !level4 || H <= 0 || W <= 0) return RAMP_EINVAL;

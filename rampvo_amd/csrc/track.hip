@@ -334,6 +334,12 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
     TRK_DO(ramp_i_upd_corr_mlp(t->corr, 896, w.corr_w1, w.corr_b1, w.corr_w2, w.corr_b2, w.corr_w3, w.corr_b3, w.corr_ln_w,
                                w.corr_ln_b, w.corr_ln_eps, t->net[0], row, t->imap, kk, (long)t->M * t->mem, w.norm_w,
                                w.norm_b, w.norm_eps, t->net[1], Eb, dyn, st));
+    // where the next frame's front end may start (RAMP_GATE_AT: 0 = before the gru chain, the default; 1 = before the
+    // second SoftAgg; 2 = before the first; 3 = before c1 / c2 -- A/B runs)
+    static int gate_at = -1;
+    if (gate_at < 0) { const char *e = getenv("RAMP_GATE_AT"); gate_at = e ? atoi(e) : 0; }
+#define TRK_GATE(pos) do { if (gate_event && gate_at == (pos) && hipEventRecord((hipEvent_t)gate_event, st) != hipSuccess) return RAMP_ELAUNCH; } while (0)
+    TRK_GATE(3);
     // RAMP_NBR2=1: c1 and c2 in one launch over the (kk, jj)-sorted factor list (bit-identical; measured 2 % SLOWER on
     // the whole operator than the two launches although it moves a third of their bytes -- DESIGN.md section 8)
     static int nbr2 = -1;
@@ -347,13 +353,15 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
       TRK_DO(ramp_i_upd_nbr(t->net[2], t->jx, w.c2_wa, w.c2_ba, w.c2_wb, w.c2_bb, t->net[1], nullptr, Eb, dyn, st));
       net = t->net[1];
     }
+    TRK_GATE(2);
     TRK_DO(ramp_i_upd_fg(net, nullptr, nullptr, nullptr, w.kk_wf, w.kk_bf, w.kk_wg, w.kk_bg, t->fg, Eb, dyn, st));
     TRK_DO(ramp_upd_segment_softmax(t->fg, t->kk_order, t->kk_seg, t->kk_ngroups, t->ykk, t->kk_cap, RAMP_F16, stream));
     TRK_DO(ramp_upd_linear(t->ykk, w.kk_wh, w.kk_bh, t->hkk, t->kk_cap, t->kk_ngroups, stream));
+    TRK_GATE(1);
     TRK_DO(ramp_i_upd_fg(net, t->hkk, t->kk_gid, net, w.ij_wf, w.ij_bf, w.ij_wg, w.ij_bg, t->fg, Eb, dyn, st));
     TRK_DO(ramp_upd_segment_softmax(t->fg, t->ij_order, t->ij_seg, t->ij_ngroups, t->yij, t->ij_cap, RAMP_F16, stream));
     TRK_DO(ramp_upd_linear(t->yij, w.ij_wh, w.ij_bh, t->hij, t->ij_cap, t->ij_ngroups, stream));
-    if (gate_event && hipEventRecord((hipEvent_t)gate_event, st) != hipSuccess) return RAMP_ELAUNCH;
+    TRK_GATE(0);
     TRK_DO(ramp_i_upd_gru(net, t->hij, t->ij_gid, w.ln1_w, w.ln1_b, w.ln1_eps, w.gru_w, w.gru_b, w.ln2_w, w.ln2_b,
                           w.ln2_eps, t->net[0], t->relu_t, Eb, dyn, st));
     TRK_PROBE(2);
