@@ -986,3 +986,47 @@ def test_upd_nbr2_equals_the_two_neighbour_launches(E):
     _lib.check(L.ramp_upd_nbr2(P(net), P(kj), P(ix), P(jx), P(wp[0]), P(bs[0]), P(wp[1]), P(bs[1]), P(wp[2]), P(bs[2]),
                                P(wp[3]), P(bs[3]), P(got), E, _lib.stream()), "nbr2")
     assert torch.equal(got, ref), float((got - ref).abs().max())
+
+
+@torch.no_grad()
+def test_geometry_kernels_are_bit_stable_next_to_the_conv_towers():
+    """The hazard behind -fno-slp-vectorize (tools/mb/pk_hazard.hip): per-lane fp32 kernels whose
+    arithmetic the SLP vectoriser had packed (v_pk_*_f32) returned rounding-level-wrong values in 1-20 % of their launches
+    while conv_tile_f16_kernel ran on another stream.  The library is built without packed fp32; this is the
+    driver-visible guard: pops.transform and fastba.BA on static inputs, 200 launches each, bit-equal to their first
+    run while the 1x1 / 3x3 tower layers replay from a hipGraph on a side stream."""
+    from rampvo_amd import conv_hip, fastba, ops
+    from rampvo_amd.synthetic import make_network
+    rng = np.random.default_rng(5)
+    s = ba_scene(seed=11, n_frames=16, M=96, lifetime=8, n_total_frames=20)
+    poses0, patches0 = cu(s["poses"]), cu(s["patches"])
+    intr, target, weight, lmbda = cu(s["intr"]), cu(s["target"]), cu(s["weight"]), cu(s["lmbda"])
+    ii, jj, kk = cu(s["ii"]), cu(s["jj"]), cu(s["kk"])
+    enc = make_network("SingleScale").patchify.encoder.imap_encoder
+    x32 = torch.randn(240, 320, 32, device="cuda").half()
+    x64 = torch.randn(120, 160, 64, device="cuda").half()
+    load = lambda: [conv_hip.conv2d(x64, enc.conv2, half=True), conv_hip.conv2d(x32, enc.layer1[0].conv1, relu=True, half=True)]
+    load(); torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        keep = [load() for _ in range(4)]
+    side = torch.cuda.Stream()
+
+    def transform():
+        return ops.transform(poses0, patches0, intr, ii, jj, kk)
+
+    def ba():
+        p, pt = poses0.clone(), patches0.clone()
+        ops.ba(p, pt, intr, target, weight, lmbda, ii, jj, kk, 3, 16, 2)
+        return torch.cat([p.reshape(-1), pt.reshape(-1)])
+
+    for fn in (transform, ba):
+        ref = fn().clone()
+        torch.cuda.synchronize()
+        bad = 0
+        for _ in range(200):
+            with torch.cuda.stream(side):
+                g.replay()
+            bad += not torch.equal(fn(), ref)
+        torch.cuda.synchronize()
+        assert bad == 0, (fn.__name__, bad)

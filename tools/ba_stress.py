@@ -9,6 +9,7 @@ from rampvo_amd.Ramp_vo import Ramp_vo
 from rampvo_amd.synthetic import SyntheticStream, make_network
 net = make_network("SingleScale")
 slam = Ramp_vo(make_cfg("default", PATCHES_PER_FRAME=96, MIXED_PRECISION=True), net, {"event_bias": True})
+slam.device_steps = False
 T = 60
 stream = SyntheticStream(480, 640, T + 1, seed=100, device="cuda")
 frames = [stream.frame(t) for t in range(T + 1)]

@@ -1,0 +1,212 @@
+// Standalone reproducer (no torch, no libramp_hip) for the hazard behind -fno-slp-vectorize:
+// a per-lane fp32 VALU kernel -- csrc/lie.hip's transform_kernel, compiled here WITH the SLP vectoriser so that its
+// SE3 arithmetic becomes v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 -- runs on stream A over STATIC inputs and its
+// output is compared bit for bit with its own first run, while stream B keeps the chip busy.
+//   mode 0: nothing on stream B                 mode 1: an MFMA kernel chain replayed from a hipGraph
+//   mode 2: the same MFMA kernels, plain launches   mode 3: a VALU-only load kernel from a hipGraph
+//   mode 4 / 5: K = 16 MFMA with AGPR accumulators (conv_tile_f16_kernel's form), hipGraph / plain launches
+// build (hazard expected):   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I include -o /tmp/pk_slp tools/mb/pk_hazard.hip
+// build (control):           ... -fno-slp-vectorize -o /tmp/pk_noslp ...
+#include "../../rampvo_amd/csrc/ramp_device.h"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %d at %s:%d\n", (int)e_, __FILE__, __LINE__); exit(1); } } while (0)
+
+// ---- kernel under test: pops.transform (same source as csrc/lie.hip::transform_kernel<3>)
+__global__ void __launch_bounds__(256)
+    transform_kernel(const float *__restrict__ poses, const float *__restrict__ patches, const float *__restrict__ intr,
+                     const int64_t *__restrict__ ii, const int64_t *__restrict__ jj, const int64_t *__restrict__ kk,
+                     float *__restrict__ out, int E, int tonly, const int32_t *__restrict__ dyn) {
+  constexpr int P = 3;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (dyn) E = dyn[RAMP_DYN_E];
+  if (e >= E) return;
+  const long i = ii[e], j = jj[e], k = kk[e];
+  float Ti[7], Tj[7], Tinv[7], G[7];
+#pragma unroll
+  for (int c = 0; c < 7; c++) { Ti[c] = poses[7 * i + c]; Tj[c] = poses[7 * j + c]; }
+  lt_inv(Ti, Tinv);
+  lt_mul(Tj, Tinv, G);
+  if (tonly) { G[3] = 0; G[4] = 0; G[5] = 0; G[6] = 1; }
+  float t[3], q[4];
+  lt_load(G, t, q);
+  const float fxi = intr[4 * i + 0], fyi = intr[4 * i + 1], cxi = intr[4 * i + 2], cyi = intr[4 * i + 3];
+  const float fxj = intr[4 * j + 0], fyj = intr[4 * j + 1], cxj = intr[4 * j + 2], cyj = intr[4 * j + 3];
+  const float *pt = patches + (size_t)k * 3 * P * P;
+  float *o = out + (size_t)e * 2 * P * P;
+#pragma unroll
+  for (int a = 0; a < P * P; a++) {
+    float X0[4], X1[4];
+    X0[0] = (pt[a] - cxi) / fxi;
+    X0[1] = (pt[P * P + a] - cyi) / fyi;
+    X0[2] = 1.0f;
+    X0[3] = pt[2 * P * P + a];
+    lt_act4_tq(t, q, X0, X1);
+    const float Z = X1[2] < 0.1f ? 0.1f : X1[2];
+    const float d = 1.0f / Z;
+    o[a] = fxj * (d * X1[0]) + cxj;
+    o[P * P + a] = fyj * (d * X1[1]) + cyj;
+  }
+}
+
+// ---- load kernels for stream B
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) mfma_load_kernel(const _Float16 *__restrict__ a, float *__restrict__ sink, int iters) {
+  __shared__ __attribute__((aligned(16))) _Float16 tile[64 * 72];
+  for (int i = threadIdx.x; i < 64 * 72; i += 256) tile[i] = a[(blockIdx.x * 64 * 72 + i) % (1 << 20)];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
+  f4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+      const h8 x = *reinterpret_cast<const h8 *>(tile + (m * 16 + j) * 72 + 8 * q + (it & 1) * 32);
+      const h8 w = *reinterpret_cast<const h8 *>(tile + (((m + it) & 3) * 16 + j) * 72 + 8 * q);
+      acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(x, w, acc[m], 0, 0, 0);
+    }
+  }
+  float s = 0.f;
+  for (int m = 0; m < 4; m++) s += acc[m][0] + acc[m][1] + acc[m][2] + acc[m][3];
+  if (s == 12345.678f) sink[blockIdx.x] = s;
+}
+// mode 4 / 5: the matrix instruction and register layout of csrc/conv.hip::conv_tile_f16_kernel -- v_mfma_f32_16x16x16_f16
+// (the K = 16 form) with many live accumulators (the compiler keeps them in AGPRs), operands from LDS
+typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) mfma16_load_kernel(const _Float16 *__restrict__ a, float *__restrict__ sink, int iters) {
+  __shared__ __attribute__((aligned(16))) _Float16 tile[128 * 40];
+  for (int i = threadIdx.x; i < 128 * 40; i += 256) tile[i] = a[(blockIdx.x * 128 * 40 + i) % (1 << 20)];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
+  f4 acc[2][6];
+#pragma unroll
+  for (int m = 0; m < 2; m++)
+#pragma unroll
+    for (int n = 0; n < 6; n++) acc[m][n] = (f4){0, 0, 0, 0};
+  for (int it = 0; it < iters; it++) {
+    h4v x[2], w[6];
+#pragma unroll
+    for (int m = 0; m < 2; m++) x[m] = *reinterpret_cast<const h4v *>(tile + ((m * 16 + j + it) & 127) * 40 + 4 * q);
+#pragma unroll
+    for (int n = 0; n < 6; n++) w[n] = *reinterpret_cast<const h4v *>(tile + ((n * 16 + j) & 127) * 40 + 16 + 4 * q);
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+      for (int n = 0; n < 6; n++) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16f16(x[m], w[n], acc[m][n], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int m = 0; m < 2; m++) for (int n = 0; n < 6; n++) s += acc[m][n][0] + acc[m][n][1] + acc[m][n][2] + acc[m][n][3];
+  if (s == 12345.678f) sink[blockIdx.x] = s;
+}
+__global__ void __launch_bounds__(256) valu_load_kernel(const float *__restrict__ a, float *__restrict__ sink, int iters) {
+  float x = a[(blockIdx.x * 256 + threadIdx.x) % (1 << 18)], y = x * 0.5f + 1.f;
+  for (int it = 0; it < iters; it++) { x = __builtin_fmaf(x, 0.9999f, y); y = __builtin_fmaf(y, 1.0001f, -x * 1e-3f); }
+  if (x + y == 12345.678f) sink[blockIdx.x] = x;
+}
+
+// mode 6 / 7: the real thing -- libramp_hip.so's conv_tile_f16_kernel<1, 1, false, 64, 4> (the 1x1 64 -> 384 layer that
+// closes the towers), through the C ABI, from a hipGraph / as plain launches.  Link with -L rampvo_amd/csrc -lramp_hip.
+extern "C" int ramp_conv2d_nhwc(const void *x, const void *wpk, const float *bias, const float *pre_scale,
+                                const float *pre_shift, const void *res, void *y, float *stats, int H, int W, int Cin,
+                                int Cout, int KH, int KW, int stride, int relu, float out_scale, int dtype, void *stream);
+
+int main(int argc, char **argv) {
+  const int mode = argc > 1 ? atoi(argv[1]) : 1, rounds = argc > 2 ? atoi(argv[2]) : 400;
+  const int E = 40000, NF = 40, M = 96, NP = NF * M;
+  std::vector<float> poses(NF * 7), patches((size_t)NP * 27), intr(NF * 4);
+  std::vector<int64_t> ii(E), jj(E), kk(E);
+  srand(1234);
+  auto rnd = [] { return (float)rand() / RAND_MAX; };
+  for (int f = 0; f < NF; f++) {
+    float q[4] = {0.05f * (rnd() - 0.5f), 0.05f * (rnd() - 0.5f), 0.05f * (rnd() - 0.5f), 1.f};
+    const float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    poses[7 * f + 0] = 0.02f * f + 0.01f * rnd(); poses[7 * f + 1] = 0.01f * rnd(); poses[7 * f + 2] = 0.005f * f;
+    for (int c = 0; c < 4; c++) poses[7 * f + 3 + c] = q[c] / n;
+    intr[4 * f + 0] = 80.f; intr[4 * f + 1] = 80.f; intr[4 * f + 2] = 80.f; intr[4 * f + 3] = 60.f;
+  }
+  for (int p = 0; p < NP; p++) {
+    const float cx = 4.f + 150.f * rnd(), cy = 4.f + 110.f * rnd(), d = 0.2f + rnd();
+    for (int a = 0; a < 9; a++) {
+      patches[(size_t)p * 27 + a] = cx + (a % 3) - 1;
+      patches[(size_t)p * 27 + 9 + a] = cy + (a / 3) - 1;
+      patches[(size_t)p * 27 + 18 + a] = d;
+    }
+  }
+  for (int e = 0; e < E; e++) { kk[e] = rand() % NP; ii[e] = kk[e] / M; jj[e] = (ii[e] + rand() % 13) % NF; }
+  float *d_poses, *d_patches, *d_intr, *d_out, *d_ref, *d_sink, *d_f32;
+  int64_t *d_ii, *d_jj, *d_kk;
+  _Float16 *d_a;
+  CK(hipMalloc(&d_poses, poses.size() * 4)); CK(hipMalloc(&d_patches, patches.size() * 4)); CK(hipMalloc(&d_intr, intr.size() * 4));
+  CK(hipMalloc(&d_ii, E * 8)); CK(hipMalloc(&d_jj, E * 8)); CK(hipMalloc(&d_kk, E * 8));
+  CK(hipMalloc(&d_out, (size_t)E * 18 * 4)); CK(hipMalloc(&d_ref, (size_t)E * 18 * 4)); CK(hipMalloc(&d_sink, 1 << 20));
+  CK(hipMalloc(&d_a, 2 << 20)); CK(hipMalloc(&d_f32, 1 << 20));
+  CK(hipMemset(d_a, 0x3c, 2 << 20)); CK(hipMemset(d_f32, 0x3c, 1 << 20));
+  CK(hipMemcpy(d_poses, poses.data(), poses.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(d_patches, patches.data(), patches.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(d_intr, intr.data(), intr.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(d_ii, ii.data(), E * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(d_jj, jj.data(), E * 8, hipMemcpyHostToDevice));
+  CK(hipMemcpy(d_kk, kk.data(), E * 8, hipMemcpyHostToDevice));
+  hipStream_t sa, sb;
+  CK(hipStreamCreate(&sa)); CK(hipStreamCreate(&sb));
+  auto launch_a = [&](float *dst) {
+    hipLaunchKernelGGL(transform_kernel, dim3((E + 255) / 256), dim3(256), 0, sa, d_poses, d_patches, d_intr, d_ii, d_jj, d_kk, dst, E, 0, (const int32_t *)nullptr);
+  };
+  _Float16 *d_cx, *d_cw, *d_cy; float *d_cb;
+  CK(hipMalloc(&d_cx, 120 * 160 * 64 * 2)); CK(hipMalloc(&d_cw, 64 * 384 * 2)); CK(hipMalloc(&d_cy, 120 * 160 * 384 * 2));
+  CK(hipMalloc(&d_cb, 384 * 4));
+  CK(hipMemset(d_cx, 0x3c, 120 * 160 * 64 * 2)); CK(hipMemset(d_cw, 0x2c, 64 * 384 * 2)); CK(hipMemset(d_cb, 0, 384 * 4));
+  auto launch_b = [&](hipStream_t s) {
+    if (mode >= 6) {
+      for (int n = 0; n < 8; n++)
+        if (ramp_conv2d_nhwc(d_cx, d_cw, d_cb, nullptr, nullptr, nullptr, d_cy, nullptr, 120, 160, 64, 384, 1, 1, 1, 0, 0.25f,
+                             1 /* RAMP_F16 */, s) != 0) { printf("ramp_conv2d_nhwc failed\n"); exit(1); }
+      return;
+    }
+    for (int n = 0; n < 12; n++) {
+      if (mode == 3) hipLaunchKernelGGL(valu_load_kernel, dim3(1200), dim3(256), 0, s, d_f32, d_sink, 400);
+      else if (mode >= 4) hipLaunchKernelGGL(mfma16_load_kernel, dim3(1200), dim3(256), 0, s, d_a, d_sink, 100);
+      else hipLaunchKernelGGL(mfma_load_kernel, dim3(1200), dim3(256), 0, s, d_a, d_sink, 200);
+    }
+  };
+  hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr;
+  if (mode == 1 || mode == 3 || mode == 4 || mode == 6) {
+    CK(hipStreamBeginCapture(sb, hipStreamCaptureModeGlobal));
+    launch_b(sb);
+    CK(hipStreamEndCapture(sb, &graph));
+    CK(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
+  }
+  launch_a(d_ref);
+  CK(hipStreamSynchronize(sa));
+  std::vector<float> ref((size_t)E * 18), got((size_t)E * 18);
+  CK(hipMemcpy(ref.data(), d_ref, ref.size() * 4, hipMemcpyDeviceToHost));
+  int bad_launches = 0; long bad_words = 0;
+  for (int r = 0; r < rounds; r++) {
+    if (mode == 1 || mode == 3 || mode == 4 || mode == 6) CK(hipGraphLaunch(gexec, sb));
+    else if (mode == 2 || mode == 5 || mode == 7) launch_b(sb);
+    for (int rep = 0; rep < 4; rep++) {          // several launches of A fall inside one load burst
+      launch_a(d_out);
+      CK(hipStreamSynchronize(sa));
+      CK(hipMemcpy(got.data(), d_out, got.size() * 4, hipMemcpyDeviceToHost));
+      long w = 0;
+      for (size_t q = 0; q < got.size(); q++) {
+        if (memcmp(&got[q], &ref[q], 4) != 0) {
+          if (bad_launches < 2 && w < 24)
+            printf("    edge %6zu (block %4zu, lane %2zu of wave %zu) word %2zu: got %-14.8g expected %-14.8g\n", q / 18, q / 18 / 256,
+                   (q / 18) % 64, ((q / 18) % 256) / 64, q % 18, got[q], ref[q]);
+          w++;
+        }
+      }
+      if (w) { bad_launches++; bad_words += w; }
+    }
+    CK(hipStreamSynchronize(sb));
+  }
+  const char *names[] = {"idle", "MFMA kernels from a hipGraph", "MFMA kernels, plain launches", "VALU kernels from a hipGraph",
+                         "16x16x16 MFMA + AGPRs, hipGraph", "16x16x16 MFMA + AGPRs, plain",
+                         "libramp conv 1x1 64->384, hipGraph", "libramp conv 1x1 64->384, plain"};
+  printf("stream B: %-32s  %d of %d launches of the kernel under test differ from its first run (%ld words)\n", names[mode],
+         bad_launches, rounds * 4, bad_words);
+  return 0;
+}
