@@ -697,8 +697,14 @@ class Ramp_vo:
 
     def _enter_device(self):
         """hand the state over to the device-resident step if this tracker / configuration supports it and the
-        optimisation window is full (BA's system then has a fixed size)"""
-        if not (self.device_steps and self.is_initialized and self._n >= self.cfg.OPTIMIZATION_WINDOW
+        optimisation window is full: BA's system then has a fixed size (OPTIMIZATION_WINDOW poses) and the two paths
+        are bit-identical.  A configuration whose optimisation window is longer than its removal window (BASELINE
+        configs[4]: 32 vs 22) may never fill it; there the hand-over happens once the removal window is full and BA runs
+        the OPTIMIZATION_WINDOW-pose system with the unused pose slots identity-damped (dX = 0 for them: the same
+        Gauss-Newton step up to fp32 rounding, csrc/ba.hip::ba_edge_kernel)"""
+        cfg = self.cfg
+        if not (self.device_steps and self.is_initialized
+                and self._n >= min(cfg.OPTIMIZATION_WINDOW, cfg.REMOVAL_WINDOW + 1)
                 and not self.enable_timing and self.device.type == "cuda" and track_dev.supported(self)
                 and getattr(self.network.patchify, "_graphs", None)):
             return

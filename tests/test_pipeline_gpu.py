@@ -365,6 +365,44 @@ def test_device_resident_steps_and_frame_pipelining_do_not_change_results():
 
 
 @torch.no_grad()
+def test_device_resident_steps_with_an_optimisation_window_that_never_fills():
+    """BASELINE configs[4] shape of windows (OPTIMIZATION_WINDOW 32 > REMOVAL_WINDOW 22): the keyframe count can stay below
+    the optimisation window for good, so the state is handed to the device once the removal window is full and BA solves
+    the 32-pose system with the unused pose slots identity-damped.  Not bit-identical to the host-driven path (whose system
+    has n - 1 poses: another split of the same sums) but the same Gauss-Newton step: same keyframe decisions and graph,
+    poses within 1e-5 of the step sizes, over 60 frames."""
+    from rampvo_amd.config import make_cfg
+    from rampvo_amd.Ramp_vo import Ramp_vo
+    from rampvo_amd.synthetic import SyntheticStream, make_network
+    T = 60
+    stream = SyntheticStream(240, 320, T, seed=77, device="cuda")
+    frames = [stream.frame(t) for t in range(T)]
+    out = []
+    for device_steps in (False, True):
+        torch.manual_seed(5)
+        # (KEYFRAME_THRESH 0: every frame stays a keyframe, so n passes REMOVAL_WINDOW + 1 = 23 within the test)
+        slam = Ramp_vo(make_cfg("default", PATCHES_PER_FRAME=48, MIXED_PRECISION=True, OPTIMIZATION_WINDOW=32,
+                                KEYFRAME_THRESH=0.0),
+                       make_network("SingleScale", profile="damped"), {"event_bias": True}, ht=240, wd=320)
+        slam.device_steps = device_steps
+        resident, below = 0, 0
+        for t, (im, ev, K, mask) in enumerate(frames):
+            slam(t, input_tensor=(ev, im, mask), intrinsics=K)
+            st = slam.peek()
+            resident += st["resident"]
+            below += st["resident"] and st["n"] < 32
+        assert (resident > 10) == device_steps, resident
+        assert below > 5 or not device_steps, below              # the padded regime was exercised
+        traj, _ = slam.terminate()
+        out.append((slam.n, slam._ii.copy(), slam._jj.copy(), slam._kk.copy(), slam.poses_[:slam.n].cpu().numpy(), traj))
+    a, b = out
+    assert a[0] == b[0] and all(np.array_equal(x, y) for x, y in zip(a[1:4], b[1:4]))
+    err = float(np.abs(a[4] - b[4]).max())
+    print("padded-window device path vs host path: poses", err, "trajectory", float(np.abs(a[5] - b[5]).max()))
+    assert err <= 1e-5
+
+
+@torch.no_grad()
 def test_pose_prediction_mode():
     """Ramp_vo.predict_future_pose driven like evaluate.py::run_pose_pred (reference :185-229): track, 12 updates
     at the hand-over, then virtual keyframes 0, 1, 2 frames ahead.  The predicted factors carry weights of 1e-9
