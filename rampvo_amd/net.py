@@ -12,6 +12,7 @@ from . import altcorr, fastba, ops
 from ._lib import RAMP_NCHW, RAMP_NHWC
 from .blocks import GatedResidual, SoftAgg
 from .extractor import MergerLSTMsceneEncoder, MultiScaleMergerDoubleNet
+from ._lib import scratch_owner as _lib_scratch_owner
 from .utils import coords_grid_with_index, get_channel_dim, get_coords_from_topk_events, preprocess_input
 
 DIM = 384
@@ -157,12 +158,16 @@ class Patchifier(nn.Module):
         return self._grid
 
     def forward(self, input_, patches_per_image=80, reinit_hidden=False, disps=None, event_bias=False,
-                gradient_bias=False):
+                gradient_bias=False, pre_replay=None):
         """On the GPU the whole front-end (fused LSTM, ~35 conv-tower launches, patch
         selection, 4 patch gathers: ~60 launches of static shape) is captured into ONE hipGraph
         after a warm-up call and replayed per frame; results live in the graph's static output
         buffers until the next call (Ramp_vo copies them into its ring buffers immediately)."""
         events, images, mask = input_
+        # pre_replay (optional callable): run once everything that depends only on the INPUTS has been enqueued -- the
+        # staging copies and the patch selection (a function of the events alone) -- and before the encoder: the
+        # device-resident tracker gates the encoder behind the previous frame's update operator there, while the
+        # staging and the selection (40 us of small launches) run ahead of the gate
         graphable = (self.use_graph and events.is_cuda and event_bias
                      and disps is None and not reinit_hidden and events.shape[1] == 1 and not torch.is_grad_enabled())
         if graphable and self.input_mode != "SingleScale":
@@ -170,6 +175,8 @@ class Patchifier(nn.Module):
             graphable = mask is not None and mask.device.type == "cpu" and mask.numel() == 1 and bool(mask.all())
         if not graphable:
             self._graph_warm = 0 if reinit_hidden else self._graph_warm
+            if pre_replay is not None:
+                pre_replay()
             return self._forward_impl(input_, patches_per_image, reinit_hidden, disps, event_bias, gradient_bias)
         key = (self.input_mode, tuple(events.shape), tuple(images.shape), patches_per_image, events.dtype,
                images.dtype, bool(getattr(self.encoder, "mixed_precision", False)),
@@ -185,19 +192,26 @@ class Patchifier(nn.Module):
             del self._graphs[key]              # stale: captured against other weights / another state buffer
             g, self._graph_warm = None, 0
         if g is None:
+            if pre_replay is not None:
+                pre_replay()
             if self._graph_warm < 1:      # one eager call with carried state first (allocator / pack caches warm)
                 self._graph_warm += 1
                 return self._forward_impl(input_, patches_per_image, False, None, event_bias, gradient_bias)
             ev_s, im_s = events.clone(), images.clone()
+            # the patch centres are a function of the events alone: selected OUTSIDE the graph into a static buffer
+            # (three small launches that need not wait for the encoder's turn, see pre_replay)
+            import os
+            in_graph = os.environ.get("RAMP_SELECT_IN_GRAPH", "0") == "1"      # A/B switch: the round-2 placement
+            coords_s = None if in_graph else self._select(ev_s, mask, patches_per_image, None)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 outs = self._forward_impl((ev_s, im_s, mask), patches_per_image, False, None, event_bias,
-                                          gradient_bias)
+                                          gradient_bias, coords_in=coords_s)
             sig = (sig[0], sig[1], id(getattr(self.encoder, "_hip_state", None)))
-            self._graphs[key] = g = (graph, ev_s, im_s, outs, self._extra, sig)
-            graph.replay()               # capture does not execute: run this frame now (inputs already staged)
+            self._graphs[key] = g = (graph, ev_s, im_s, outs, self._extra, sig, coords_s)
+            self._run_graph(graph)       # capture does not execute: run this frame now (inputs already staged)
             return outs
-        graph, ev_s, im_s, outs, self._extra, _ = g
+        graph, ev_s, im_s, outs, self._extra, _, coords_s = g
         if (events.is_contiguous() and images.is_contiguous() and events.dtype == ev_s.dtype and images.dtype == im_s.dtype
                 and (events.numel() * events.element_size()) % 16 == 0 and (images.numel() * images.element_size()) % 16 == 0
                 and events.data_ptr() % 16 == 0 and images.data_ptr() % 16 == 0):
@@ -205,8 +219,25 @@ class Patchifier(nn.Module):
         else:
             ev_s.copy_(events)
             im_s.copy_(images)
-        graph.replay()
+        if coords_s is not None:
+            self._select(ev_s, mask, patches_per_image, coords_s)
+        if pre_replay is not None:
+            pre_replay()
+        self._run_graph(graph)
         return outs
+
+    def _run_graph(self, graph):
+        graph.replay()
+
+    def _select(self, events, mask, patches_per_image, out):
+        """patch centres [1, M, 2] of the frame(s) present (reference net.py:176-180), into ``out`` when given"""
+        if self.input_mode != "SingleScale" and mask is not None and not bool(mask.all()):
+            events = events[mask]
+        with _lib_scratch_owner(self):
+            c = get_coords_from_topk_events(events=events, patches_per_image=patches_per_image,
+                                            border_suppression_size=0, non_max_supp_rad=11,
+                                            out=out[0] if out is not None else None)
+        return c.float().contiguous() if out is None else out
 
     def _forward_impl(self, *a, **k):
         from . import _lib
@@ -214,7 +245,7 @@ class Patchifier(nn.Module):
             return self._forward_steps(*a, **k)
 
     def _forward_steps(self, input_, patches_per_image=80, reinit_hidden=False, disps=None, event_bias=False,
-                       gradient_bias=False):
+                       gradient_bias=False, coords_in=None):
         events, images, mask = input_
         if self.input_mode == "SingleScale":
             fmap, imap, _ = self.encoder(events=events, images=images, reinit_hidden=reinit_hidden,
@@ -228,7 +259,9 @@ class Patchifier(nn.Module):
         if mask is not None and not mask.any():
             return None, None, None, None, None, None
         b, n, c, h, w = fmap.shape
-        if event_bias:
+        if coords_in is not None:
+            coords = coords_in           # selected ahead of the captured graph (forward())
+        elif event_bias:
             coords = get_coords_from_topk_events(events=events, patches_per_image=patches_per_image,
                                                  border_suppression_size=0, non_max_supp_rad=11)
         else:

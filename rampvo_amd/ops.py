@@ -144,14 +144,15 @@ def depth_median_supported(F, M, P):
     return F * M * P * P <= 8192
 
 
-def event_topk(events, k, nms_kernel_size=11, want_indices=False):
+def event_topk(events, k, nms_kernel_size=11, want_indices=False, out=None):
     """patch centres of one frame: events [bins,H,W] float32 -> coords [k,2] float32 (x + y/h, y) at the
     top-k cells of the NMS'ed mean |event| map (reference utils.py:186-226), one score kernel + one NMS
     kernel + a one-workgroup radix select"""
     require_cuda(events)
     bins, H, W = events.shape
     events = events.contiguous().float()
-    coords = torch.empty((k, 2), dtype=torch.float32, device=events.device)
+    coords = out if out is not None else torch.empty((k, 2), dtype=torch.float32, device=events.device)
+    assert coords.shape == (k, 2) and coords.dtype == torch.float32 and coords.is_contiguous()
     idx = torch.empty(k, dtype=torch.int64, device=events.device) if want_indices else None
     nbytes = lib().ramp_event_topk_workspace_bytes(H, W)
     ws = _lib_workspace(nbytes, events.device, "topk")

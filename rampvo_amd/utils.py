@@ -52,7 +52,7 @@ def nms_image(x, kernel_size=3):
 
 
 def get_coords_from_topk_events(events, patches_per_image, border_suppression_size=0,
-                                non_max_supp_rad=0):
+                                non_max_supp_rad=0, out=None):
     """patch centres at the top-k cells of the NMS'ed mean |event| map at 1/4
     resolution (reference utils.py:186-226).  The map is laid out [w, h] and the
     reference derives x by TRUE division of the flat index by h, so x carries the
@@ -62,7 +62,8 @@ def get_coords_from_topk_events(events, patches_per_image, border_suppression_si
         from . import ops
         if ops.event_topk_supported(e4[0], patches_per_image, non_max_supp_rad):
             # GPU: score + NMS + radix select in three HIP launches (csrc/select.hip)
-            return ops.event_topk(e4[0], patches_per_image, non_max_supp_rad)[None]
+            return ops.event_topk(e4[0], patches_per_image, non_max_supp_rad, out=out)[None]
+    assert out is None
     ev = torch.abs(e4)
     ev = F.avg_pool2d(ev, 4, 4).transpose(3, 2).mean(dim=1)      # [T, w, h]
     if border_suppression_size != 0:
