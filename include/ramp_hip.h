@@ -594,7 +594,7 @@ typedef struct ramp_track {
   int32_t *kk_order, *kk_gid, *kk_seg, *kk_ngroups, *ij_order, *ij_gid, *ij_seg, *ij_ngroups;
   int64_t *kk_ukeys, *ij_ukeys, *ix, *jx;
   int32_t *kj;                        /* [E_cap] factors in (kk, jj) order (ramp_upd_nbr2)                        */
-  void *plan_ws;
+  void *plan_ws;                      /* ZERO before the first plan (each plan leaves its histograms cleared)      */
   size_t plan_ws_bytes;
   /* update operator */
   ramp_track_weights w;

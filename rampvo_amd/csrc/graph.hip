@@ -369,28 +369,39 @@ __device__ __forceinline__ void plan_K(const PlanDyn &p, int g, int &K, long &su
   }
   if (K > p.Kcap[g] || K < 0) K = 0;     // flagged by plan_hist_kernel; nothing is written out of bounds
 }
+// 1024 factors per workgroup (4 per thread): the LDS table (K bins to clear and to flush per workgroup) is amortised
+// over four times the factors of a one-per-thread launch
+#define PLAN_EPB 1024
 template <bool LDS>
 __global__ void __launch_bounds__(256) plan_hist_kernel(const PlanDyn p, int32_t *__restrict__ status) {
   __shared__ int s_bin[LDS ? PLAN_LDS_K : 1];
   const int g = blockIdx.y, E = p.dyn[RAMP_DYN_E];
-  if ((int)blockIdx.x * 256 >= E) return;
+  if ((int)blockIdx.x * PLAN_EPB >= E) return;
   int K; long sub;
   plan_K(p, g, K, sub);
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  long k = -1;
-  if (e < E) {
-    int K2; long s2;
-    k = plan_key(p, g, e, K2, s2);
-    if (k < 0 || k >= K) { atomicOr(status, 8); k = -1; }
+  long k[PLAN_EPB / 256];
+#pragma unroll
+  for (int u = 0; u < PLAN_EPB / 256; u++) {
+    const int e = blockIdx.x * PLAN_EPB + u * 256 + threadIdx.x;
+    k[u] = -1;
+    if (e < E) {
+      int K2; long s2;
+      k[u] = plan_key(p, g, e, K2, s2);
+      if (k[u] < 0 || k[u] >= K) { atomicOr(status, 8); k[u] = -1; }
+    }
   }
   int32_t *hist = p.hist[g];
   if (!LDS) {
-    if (k >= 0) atomicAdd(&hist[k], 1);
+#pragma unroll
+    for (int u = 0; u < PLAN_EPB / 256; u++)
+      if (k[u] >= 0) atomicAdd(&hist[k[u]], 1);
     return;
   }
   for (int q = threadIdx.x; q < K; q += 256) s_bin[q] = 0;
   __syncthreads();
-  if (k >= 0) atomicAdd(&s_bin[k], 1);
+#pragma unroll
+  for (int u = 0; u < PLAN_EPB / 256; u++)
+    if (k[u] >= 0) atomicAdd(&s_bin[k[u]], 1);
   __syncthreads();
   for (int q = threadIdx.x; q < K; q += 256) {
     const int c = s_bin[q];
@@ -437,46 +448,65 @@ template <bool LDS>
 __global__ void __launch_bounds__(256) plan_scatter_kernel(const PlanDyn p) {
   __shared__ int s_bin[LDS ? PLAN_LDS_K : 1];
   const int g = blockIdx.y, E = p.dyn[RAMP_DYN_E];
-  if ((int)blockIdx.x * 256 >= E) return;
+  if ((int)blockIdx.x * PLAN_EPB >= E) return;
   int K; long sub;
   plan_K(p, g, K, sub);
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  long k = -1;
-  if (e < E) {
-    int K2; long s2;
-    k = plan_key(p, g, e, K2, s2);
-    if (k < 0 || k >= K) k = -1;
+  long k[PLAN_EPB / 256];
+#pragma unroll
+  for (int u = 0; u < PLAN_EPB / 256; u++) {
+    const int e = blockIdx.x * PLAN_EPB + u * 256 + threadIdx.x;
+    k[u] = -1;
+    if (e < E) {
+      int K2; long s2;
+      k[u] = plan_key(p, g, e, K2, s2);
+      if (k[u] < 0 || k[u] >= K) k[u] = -1;
+    }
   }
   int32_t *cursor = p.hist[g], *tmp_order = p.tmp[g], *gid = p.gid[g];
   const int32_t *gidmap = p.gidmap[g];
   if (!LDS) {
-    if (k < 0) return;
-    const int pos = atomicAdd(&cursor[k], 1);
-    tmp_order[pos] = e;
-    gid[e] = gidmap[k];
+#pragma unroll
+    for (int u = 0; u < PLAN_EPB / 256; u++) {
+      if (k[u] < 0) continue;
+      const int e = blockIdx.x * PLAN_EPB + u * 256 + threadIdx.x;
+      tmp_order[atomicAdd(&cursor[k[u]], 1)] = e;
+      gid[e] = gidmap[k[u]];
+    }
     return;
   }
   for (int q = threadIdx.x; q < K; q += 256) s_bin[q] = 0;
   __syncthreads();
-  int r = 0;
-  if (k >= 0) r = atomicAdd(&s_bin[k], 1);
+  int r[PLAN_EPB / 256];
+#pragma unroll
+  for (int u = 0; u < PLAN_EPB / 256; u++) r[u] = k[u] >= 0 ? atomicAdd(&s_bin[k[u]], 1) : 0;   // rank in this workgroup's share
   __syncthreads();
   for (int q = threadIdx.x; q < K; q += 256) {
     const int c = s_bin[q];
-    if (c) s_bin[q] = atomicAdd(&cursor[q], c);
+    if (c) s_bin[q] = atomicAdd(&cursor[q], c);       // the share's base
   }
   __syncthreads();
-  if (k >= 0) {
-    tmp_order[s_bin[k] + r] = e;
-    gid[e] = gidmap[k];
+#pragma unroll
+  for (int u = 0; u < PLAN_EPB / 256; u++) {
+    if (k[u] < 0) continue;
+    const int e = blockIdx.x * PLAN_EPB + u * 256 + threadIdx.x;
+    tmp_order[s_bin[k[u]] + r[u]] = e;
+    gid[e] = gidmap[k[u]];
   }
 }
-// restore ascending factor order inside every segment: rank by counting, the segment staged in LDS (the pair
-// grouping has ~100 segments of ~450 factors: walking them from memory was 34 us)
+// Per segment, from LDS: restore ascending factor order (rank by counting), and -- for the kk grouping -- the temporal
+// neighbours of every factor of the patch and the patch's run of the (kk, jj)-sorted factor list (rank by (jj, factor)):
+// what nb_from_groups_kernel computed in a launch of its own.  The first workgroups also clear the histograms for the
+// next plan (nobody reads them after the scatter): no memset launch.
 #define PLAN_SEG_LDS 4096
-__global__ void __launch_bounds__(256) plan_segsort_kernel(const PlanDyn p) {
+__global__ void __launch_bounds__(256) plan_segsort_kernel(const PlanDyn p, int64_t *__restrict__ ix, int64_t *__restrict__ jx,
+                                                           int32_t *__restrict__ kj, int hist_words) {
   __shared__ int s_v[PLAN_SEG_LDS];
+  __shared__ int s_kj[1024];
   const int g = blockIdx.y, grp = blockIdx.x;
+  if (g == 0) {
+    const int z = grp * 256 + threadIdx.x;
+    if (z < hist_words) p.hist[0][z] = 0;               // hist[0] and hist[1] are one allocation
+  }
   if (grp >= *p.ngroups[g]) return;
   const int32_t *tmp_order = p.tmp[g], *seg_start = p.seg[g];
   int32_t *order = p.order[g];
@@ -495,6 +525,25 @@ __global__ void __launch_bounds__(256) plan_segsort_kernel(const PlanDyn p) {
       for (int u = 0; u < n; u++) r += (tmp_order[s0 + u] < v);
     }
     order[s0 + r] = v;
+  }
+  if (g != 0 || !ix || n > 1024) return;                // (longer patch groups: ramp_neighbors' sort-based path)
+  for (int q = threadIdx.x; q < n; q += 256) {
+    const int e = s_v[q];
+    const long j = p.jj[e];
+    int r = 0;
+    for (int u = 0; u < n; u++) {
+      const int f = s_v[u];
+      const long jf = p.jj[f];
+      r += (jf < j) || (jf == j && f < e);
+    }
+    s_kj[r] = e;
+  }
+  __syncthreads();
+  for (int r = threadIdx.x; r < n; r += 256) {
+    const int e = s_kj[r];
+    ix[e] = r > 0 ? s_kj[r - 1] : -1;
+    jx[e] = r + 1 < n ? s_kj[r + 1] : -1;
+    if (kj) kj[s0 + r] = e;
   }
 }
 
@@ -521,16 +570,18 @@ int ramp_i_plan_dyn(const int64_t *g4, int E_cap, int E_grid, const int32_t *dyn
   p.order[0] = kk_order; p.gid[0] = kk_gid; p.seg[0] = kk_seg; p.ngroups[0] = kk_ngroups; p.ukeys[0] = kk_ukeys;
   p.order[1] = ij_order; p.gid[1] = ij_gid; p.seg[1] = ij_seg; p.ngroups[1] = ij_ngroups; p.ukeys[1] = ij_ukeys;
   p.Kcap[0] = kkey_cap; p.Kcap[1] = pkey_cap;
-  (void)hipMemsetAsync(p.hist[0], 0, (size_t)(kkey_cap + pkey_cap + 4) * 4, st);
-  const int nb = ramp_cdiv(E_grid > 0 && E_grid < E_cap ? E_grid : E_cap, 256);
+  // (the histograms are zero on entry: the caller's workspace starts zeroed and every plan clears them at its end)
+  const int nb = ramp_cdiv(E_grid > 0 && E_grid < E_cap ? E_grid : E_cap, PLAN_EPB);
   const bool lds = kkey_cap <= PLAN_LDS_K && pkey_cap <= PLAN_LDS_K;
   if (lds) hipLaunchKernelGGL(plan_hist_kernel<true>, dim3(nb, 2), dim3(256), 0, st, p, status);
   else hipLaunchKernelGGL(plan_hist_kernel<false>, dim3(nb, 2), dim3(256), 0, st, p, status);
   hipLaunchKernelGGL(plan_scan_kernel, dim3(2), dim3(1024), 0, st, p);
   if (lds) hipLaunchKernelGGL(plan_scatter_kernel<true>, dim3(nb, 2), dim3(256), 0, st, p);
   else hipLaunchKernelGGL(plan_scatter_kernel<false>, dim3(nb, 2), dim3(256), 0, st, p);
-  hipLaunchKernelGGL(plan_segsort_kernel, dim3(kk_cap > ij_cap ? kk_cap : ij_cap, 2), dim3(256), 0, st, p);
-  hipLaunchKernelGGL(nb_from_groups_kernel, dim3(kk_cap), dim3(64), 0, st, kk_order, kk_seg, kk_ngroups, p.jj, ix, jx, kj);
+  const int hist_words = kkey_cap + pkey_cap + 4;
+  int gx = kk_cap > ij_cap ? kk_cap : ij_cap;
+  if (gx < ramp_cdiv(hist_words, 256)) gx = ramp_cdiv(hist_words, 256);
+  hipLaunchKernelGGL(plan_segsort_kernel, dim3(gx, 2), dim3(256), 0, st, p, ix, jx, kj, hist_words);
   RAMP_CHECK_LAUNCH();
   return RAMP_OK;
 }

@@ -87,7 +87,8 @@ class DeviceTrack:
         self.ij = dict(order=z(E_cap, i32), gid=z(E_cap, i32), seg=z(ij_cap + 2, i32), ngroups=z(1, i32),
                        ukeys=z(ij_cap + 2, i64))
         self.ix, self.jx, self.kj = z(E_cap, i64), z(E_cap, i64), z(E_cap, i32)
-        self.plan_ws = e(lib.ramp_track_plan_workspace_bytes(E_cap, self.kkey_cap, self.pkey_cap), torch.uint8)
+        # (zeroed: the plan's histograms are cleared by each plan at its end instead of by a memset launch at its start)
+        self.plan_ws = z(lib.ramp_track_plan_workspace_bytes(E_cap, self.kkey_cap, self.pkey_cap), torch.uint8)
         self.coords = e((E_cap, 2, 3, 3), f32)
         self.corr = e((E_cap, CORR_ROW), f16)
         self.net = [z((E_cap, 384), f32) for _ in range(3)]
