@@ -29,32 +29,27 @@
 static inline size_t al(size_t x) { return (x + 255) / 256 * 256; }
 
 // ------------------------------------------------------------------ K1
-__global__ void __launch_bounds__(256)
-    ba_edge_kernel(const float *__restrict__ poses, const float *__restrict__ patches,
-                   const float *__restrict__ intr, const float *__restrict__ target,
-                   const float *__restrict__ weight, const int64_t *__restrict__ ii,
-                   const int64_t *__restrict__ jj, const int64_t *__restrict__ kk,
-                   float *__restrict__ rec, int E, int PP, int c11, int t0, int N,
-                   const int32_t *__restrict__ dyn, int opt_window) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (dyn) {                                     // device-side sizes: E is the launch bound, the window ends at n
-    E = dyn[RAMP_DYN_E];
-    const int t1 = dyn[RAMP_DYN_N];
-    t0 = max(t1 - opt_window, 1);
-    N = min(N, t1 - t0);
-  }
-  if (n >= E) return;
-  const float fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];
-  int ix = (int)ii[n], jx = (int)jj[n];
-  const long kx = kk[n];
+// The per-edge record: residual, validity, Jacobians (32 floats).  ba_edge_kernel writes it to memory (the path without
+// free poses); the patch / pair kernels of a regular iteration recompute it in registers from the edge's 116 bytes of
+// inputs while they stage their segment -- the record never goes through HBM (it was written once and read twice per
+// iteration) and the launch is gone.  Same expressions either way: identical results.
+struct BaEdgeIn {
+  const float *poses, *patches, *intr, *target, *weight;
+  const int64_t *ii, *jj, *kk;
+  int PP, c11, t0, N;
+};
+__device__ __forceinline__ void ba_edge_compute(const BaEdgeIn &in, int n, float (&r)[BA_REC]) {
+  const float fx = in.intr[0], fy = in.intr[1], cx = in.intr[2], cy = in.intr[3];
+  int ix = (int)in.ii[n], jx = (int)in.jj[n];
+  const long kx = in.kk[n];
   float pi[7], pj[7];
 #pragma unroll
-  for (int c = 0; c < 7; c++) { pi[c] = poses[7 * (size_t)ix + c]; pj[c] = poses[7 * (size_t)jx + c]; }
+  for (int c = 0; c < 7; c++) { pi[c] = in.poses[7 * (size_t)ix + c]; pj[c] = in.poses[7 * (size_t)jx + c]; }
   float Xi[4], Xj[4];
-  Xi[0] = (patches[((size_t)kx * 3 + 0) * PP + c11] - cx) / fx;
-  Xi[1] = (patches[((size_t)kx * 3 + 1) * PP + c11] - cy) / fy;
+  Xi[0] = (in.patches[((size_t)kx * 3 + 0) * in.PP + in.c11] - cx) / fx;
+  Xi[1] = (in.patches[((size_t)kx * 3 + 1) * in.PP + in.c11] - cy) / fy;
   Xi[2] = 1.0f;
-  Xi[3] = patches[((size_t)kx * 3 + 2) * PP + c11];
+  Xi[3] = in.patches[((size_t)kx * 3 + 2) * in.PP + in.c11];
   float tij[3], qij[4];
   fb_relSE3(pi, pi + 3, pj, pj + 3, tij, qij);
   fb_actSE3(tij, qij, Xi, Xj);
@@ -63,15 +58,15 @@ __global__ void __launch_bounds__(256)
   const float d2 = d * d;
   const float x1 = fx * (X / Z) + cx;
   const float y1 = fy * (Y / Z) + cy;
-  const float tx_ = target[2 * (size_t)n + 0], ty_ = target[2 * (size_t)n + 1];
+  const float tx_ = in.target[2 * (size_t)n + 0], ty_ = in.target[2 * (size_t)n + 1];
   const float rx = tx_ - x1, ry = ty_ - y1;
   const bool in_bounds = (sqrtf(rx * rx + ry * ry) < 128) && (Z > 0.2f) && (x1 > -64) &&
                          (y1 > -64) && (x1 < 2 * cx + 64) && (y1 < 2 * cy + 64);
   const float mask = in_bounds ? 1.0f : 0.0f;
-  ix -= t0;
-  jx -= t0;
-  if (ix >= N) ix = -1;  // poses >= t1 are not free (out of B in the reference)
-  if (jx >= N) jx = -1;
+  ix -= in.t0;
+  jx -= in.t0;
+  if (ix >= in.N) ix = -1;  // poses >= t1 are not free (out of B in the reference)
+  if (jx >= in.N) jx = -1;
   if (ix < 0) ix = -1;
   if (jx < 0) jx = -1;
   float Jj0[6] = {fx * W * d, 0, fx * -X * W * d2, fx * -X * Y * d2, fx * (1 + X * X * d2),
@@ -83,16 +78,31 @@ __global__ void __launch_bounds__(256)
   fb_adjSE3(tij, qij, Jj1, Ji1);
   const float Jz0 = fx * (tij[0] * d - tij[2] * (X * d2));
   const float Jz1 = fy * (tij[1] * d - tij[2] * (Y * d2));
-  const float w0 = mask * weight[2 * (size_t)n + 0], w1 = mask * weight[2 * (size_t)n + 1];
+#pragma unroll
+  for (int c = 0; c < 6; c++) { r[c] = Ji0[c]; r[6 + c] = Ji1[c]; r[12 + c] = Jj0[c]; r[18 + c] = Jj1[c]; }
+  r[24] = mask * in.weight[2 * (size_t)n + 0];
+  r[25] = mask * in.weight[2 * (size_t)n + 1];
+  r[26] = rx; r[27] = ry; r[28] = Jz0; r[29] = Jz1;
+  r[30] = __int_as_float(ix); r[31] = __int_as_float(jx);
+}
+// window from the device-side sizes (csrc/track.hip): [max(n - opt_window, 1), n)
+__device__ __forceinline__ void ba_dyn_window(const int32_t *dyn, int opt_window, int &t0, int &N) {
+  if (!dyn) return;
+  const int t1 = dyn[RAMP_DYN_N];
+  t0 = max(t1 - opt_window, 1);
+  N = min(N, t1 - t0);
+}
+__global__ void __launch_bounds__(256)
+    ba_edge_kernel(BaEdgeIn in, float *__restrict__ rec, int E, const int32_t *__restrict__ dyn, int opt_window) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (dyn) E = dyn[RAMP_DYN_E];              // device-side sizes: E is the launch bound, the window ends at n
+  ba_dyn_window(dyn, opt_window, in.t0, in.N);
+  if (n >= E) return;
+  float r[BA_REC];
+  ba_edge_compute(in, n, r);
   float4 *r4 = reinterpret_cast<float4 *>(rec + (size_t)n * BA_REC);
-  r4[0] = make_float4(Ji0[0], Ji0[1], Ji0[2], Ji0[3]);
-  r4[1] = make_float4(Ji0[4], Ji0[5], Ji1[0], Ji1[1]);
-  r4[2] = make_float4(Ji1[2], Ji1[3], Ji1[4], Ji1[5]);
-  r4[3] = make_float4(Jj0[0], Jj0[1], Jj0[2], Jj0[3]);
-  r4[4] = make_float4(Jj0[4], Jj0[5], Jj1[0], Jj1[1]);
-  r4[5] = make_float4(Jj1[2], Jj1[3], Jj1[4], Jj1[5]);
-  r4[6] = make_float4(w0, w1, rx, ry);
-  r4[7] = make_float4(Jz0, Jz1, __int_as_float(ix), __int_as_float(jx));
+#pragma unroll
+  for (int c = 0; c < 8; c++) r4[c] = make_float4(r[4 * c], r[4 * c + 1], r[4 * c + 2], r[4 * c + 3]);
 }
 // record field offsets
 #define R_JI0 0
@@ -118,7 +128,7 @@ __device__ __forceinline__ void
                   const int32_t *__restrict__ seg, const int32_t *__restrict__ ngroups,
                   const float *__restrict__ lmbda, float *__restrict__ Erow,
                   float *__restrict__ Cv, float *__restrict__ uv, float *__restrict__ Qv,
-                  int n6) {
+                  int n6, const BaEdgeIn &ein, const bool fused) {
   __shared__ float s_rec[BA_PCHUNK][BA_REC + 1];
   if (g >= *ngroups) return;
   const int tid = threadIdx.x, nthr = blockDim.x;
@@ -128,9 +138,18 @@ __device__ __forceinline__ void
   for (int b0 = s0; b0 < s1; b0 += BA_PCHUNK) {
     const int nb = min(BA_PCHUNK, s1 - b0);
     __syncthreads();
-    for (int e = tid; e < nb * BA_REC; e += nthr) {
-      const int l = e / BA_REC, k = e - l * BA_REC;
-      s_rec[l][k] = rec[(size_t)order[b0 + l] * BA_REC + k];
+    if (fused) {                                // one thread per edge of the chunk recomputes its record
+      if (tid < nb) {
+        float r[BA_REC];
+        ba_edge_compute(ein, order[b0 + tid], r);
+#pragma unroll
+        for (int k = 0; k < BA_REC; k++) s_rec[tid][k] = r[k];
+      }
+    } else {
+      for (int e = tid; e < nb * BA_REC; e += nthr) {
+        const int l = e / BA_REC, k = e - l * BA_REC;
+        s_rec[l][k] = rec[(size_t)order[b0 + l] * BA_REC + k];
+      }
     }
     __syncthreads();
     if (tid < n6) {
@@ -172,7 +191,7 @@ __global__ void __launch_bounds__(256)
                     const float *__restrict__ lmbda, float *__restrict__ Erow,
                     float *__restrict__ Cv, float *__restrict__ uv, float *__restrict__ Qv,
                     int n6) {
-  ba_patch_body(blockIdx.x, rec, order, seg, ngroups, lmbda, Erow, Cv, uv, Qv, n6);
+  ba_patch_body(blockIdx.x, rec, order, seg, ngroups, lmbda, Erow, Cv, uv, Qv, n6, BaEdgeIn(), false);
 }
 
 // ------------------------------------------------------------------ K3
@@ -181,7 +200,7 @@ __global__ void __launch_bounds__(256)
 __device__ __forceinline__ void
     ba_pair_body(int g, const float *__restrict__ rec, const int32_t *__restrict__ order,
                  const int32_t *__restrict__ seg, const int32_t *__restrict__ ngroups,
-                 float *__restrict__ pairs, int32_t *__restrict__ pair_ij) {
+                 float *__restrict__ pairs, int32_t *__restrict__ pair_ij, const BaEdgeIn &ein, const bool fused) {
   __shared__ __attribute__((aligned(16))) float s_rec[48 * BA_REC];   // 48 records per batch
   if (g >= *ngroups) return;
   const int tid = threadIdx.x;
@@ -206,10 +225,20 @@ __device__ __forceinline__ void
   for (int b0 = s0; b0 < s1; b0 += 48) {
     const int nb = min(48, s1 - b0);
     __syncthreads();
-    for (int q = tid < 192 ? tid : nb * (BA_REC / 4); q < nb * (BA_REC / 4); q += 192) {      // coalesced 16-byte loads of whole records
-      const int rr = q / (BA_REC / 4), cc = q - rr * (BA_REC / 4);
-      reinterpret_cast<float4 *>(s_rec)[q] =
-          reinterpret_cast<const float4 *>(rec + (size_t)order[b0 + rr] * BA_REC)[cc];
+    if (fused) {                                // one thread per edge of the batch recomputes its record
+      if (tid < nb) {
+        float r[BA_REC];
+        ba_edge_compute(ein, order[b0 + tid], r);
+#pragma unroll
+        for (int c = 0; c < BA_REC / 4; c++)
+          reinterpret_cast<float4 *>(s_rec)[tid * (BA_REC / 4) + c] = make_float4(r[4 * c], r[4 * c + 1], r[4 * c + 2], r[4 * c + 3]);
+      }
+    } else {
+      for (int q = tid < 192 ? tid : nb * (BA_REC / 4); q < nb * (BA_REC / 4); q += 192) {      // coalesced 16-byte loads of whole records
+        const int rr = q / (BA_REC / 4), cc = q - rr * (BA_REC / 4);
+        reinterpret_cast<float4 *>(s_rec)[q] =
+            reinterpret_cast<const float4 *>(rec + (size_t)order[b0 + rr] * BA_REC)[cc];
+      }
     }
     __syncthreads();
     if (tid < 144) {
@@ -237,7 +266,7 @@ __global__ void __launch_bounds__(192)
     ba_pair_kernel(const float *__restrict__ rec, const int32_t *__restrict__ order,
                    const int32_t *__restrict__ seg, const int32_t *__restrict__ ngroups,
                    float *__restrict__ pairs, int32_t *__restrict__ pair_ij) {
-  ba_pair_body(blockIdx.x, rec, order, seg, ngroups, pairs, pair_ij);
+  ba_pair_body(blockIdx.x, rec, order, seg, ngroups, pairs, pair_ij, BaEdgeIn(), false);
 }
 
 // K2 and K3 read the same per-edge records and do not depend on each other: one launch, the first n_patch
@@ -248,11 +277,13 @@ __global__ void __launch_bounds__(256)
                          const float *__restrict__ lmbda, float *__restrict__ Erow, float *__restrict__ Cv,
                          float *__restrict__ uv, float *__restrict__ Qv, int n6,
                          const int32_t *__restrict__ order_p, const int32_t *__restrict__ seg_p,
-                         const int32_t *__restrict__ np, float *__restrict__ pairs, int32_t *__restrict__ pair_ij) {
+                         const int32_t *__restrict__ np, float *__restrict__ pairs, int32_t *__restrict__ pair_ij,
+                         BaEdgeIn ein, int fused, const int32_t *__restrict__ dyn, int opt_window) {
+  ba_dyn_window(dyn, opt_window, ein.t0, ein.N);
   if ((int)blockIdx.x < n_patch)
-    ba_patch_body(blockIdx.x, rec, order_k, seg_k, nk, lmbda, Erow, Cv, uv, Qv, n6);
+    ba_patch_body(blockIdx.x, rec, order_k, seg_k, nk, lmbda, Erow, Cv, uv, Qv, n6, ein, fused != 0);
   else
-    ba_pair_body(blockIdx.x - n_patch, rec, order_p, seg_p, np, pairs, pair_ij);
+    ba_pair_body(blockIdx.x - n_patch, rec, order_p, seg_p, np, pairs, pair_ij, ein, fused != 0);
 }
 
 // ------------------------------------------------------------------ K4
@@ -840,12 +871,18 @@ static int ba_iterate(float *poses, float *patches, const float *intrinsics, con
   if (pthreads > 256) return RAMP_EUNSUPPORTED;
   const int depth_blocks = ramp_cdiv(w.Mu_b, 4);
   const int pose_blocks = N > 0 ? ramp_cdiv(N, 256) : 0;
+  BaEdgeIn ein;
+  ein.poses = poses; ein.patches = patches; ein.intr = intrinsics; ein.target = target; ein.weight = weight;
+  ein.ii = ii; ein.jj = jj; ein.kk = kk; ein.PP = PP; ein.c11 = c11; ein.t0 = t0; ein.N = N;
+  static int fuse_edge = -1;                        // RAMP_BA_FUSE_EDGE=0: records through memory (A/B runs)
+  if (fuse_edge < 0) { const char *e = getenv("RAMP_BA_FUSE_EDGE"); fuse_edge = e ? atoi(e) : 1; }
   for (int itr = 0; itr < iterations; itr++) {
-    hipLaunchKernelGGL(ba_edge_kernel, dim3(ramp_cdiv(E, 256)), dim3(256), 0, st, poses, patches,
-                       intrinsics, target, weight, ii, jj, kk, w.rec, E, PP, c11, t0, N, dyn, opt_window);
+    if (N <= 0 || !fuse_edge)
+      hipLaunchKernelGGL(ba_edge_kernel, dim3(ramp_cdiv(E, 256)), dim3(256), 0, st, ein, w.rec, E, dyn, opt_window);
     if (N > 0)
       hipLaunchKernelGGL(ba_patch_pair_kernel, dim3(w.Mu_b + w.Gp_b), dim3(256), 0, st, w.Mu_b, w.rec, order_k,
-                         seg_k, nk, lmbda, w.Erow, w.Cv, w.uv, w.Qv, n6, order_p, seg_p, np, w.pairs, w.pair_ij);
+                         seg_k, nk, lmbda, w.Erow, w.Cv, w.uv, w.Qv, n6, order_p, seg_p, np, w.pairs, w.pair_ij, ein,
+                         fuse_edge, dyn, opt_window);
     else
       hipLaunchKernelGGL(ba_patch_kernel, dim3(w.Mu_b), dim3(pthreads), 0, st, w.rec, order_k, seg_k, nk,
                          lmbda, w.Erow, w.Cv, w.uv, w.Qv, n6);
