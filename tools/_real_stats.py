@@ -1,0 +1,32 @@
+import os, sys
+sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tools")
+import numpy as np, torch
+from corr_tile_check import window_stats
+from rampvo_amd.config import make_cfg
+from rampvo_amd.Ramp_vo import Ramp_vo
+from rampvo_amd.synthetic import SyntheticStream, make_network
+torch.manual_seed(1234)
+slam = Ramp_vo(make_cfg("default", PATCHES_PER_FRAME=96, MIXED_PRECISION=True), make_network("SingleScale"), {"event_bias": True})
+T = int(os.environ.get("T", 120))
+torch.manual_seed(1234)
+st = SyntheticStream(480, 640, T + 1, seed=1234, device="cuda")
+with torch.no_grad():
+    for t in range(T):
+        im, ev, K, mask = st.frame(t)
+        slam(t, input_tensor=(ev, im, mask), intrinsics=K)
+torch.cuda.synchronize()
+dv = slam._dev
+E = int(dv.dyn.cpu()[2])
+print("E", E)
+co = dv.coords[:E]
+for name, H, W, cdv in (("fine", 120, 160, 1.0), ("coarse", 30, 40, 4.0)):
+    n, bw, bh = window_stats(co, H, W, cdv)
+    a = bw * bh
+    print(name, "nlive==0: %.4f" % (n == 0).mean(), "| area<=112: %.4f  <=128: %.4f" % ((a[n > 0] <= 112).mean(), (a[n > 0] <= 128).mean()),
+          "| bw<=12&bh<=12: %.4f" % ((bw <= 12) & (bh <= 12))[n > 0].mean(), "| hist bw", np.bincount(bw[n > 0])[8:16], "| partial live: %.4f" % ((n > 0) & (n < 9)).mean())
+    ok = (n > 0) & (a <= 128)
+jj = dv.graph[dv.cur][dv.t.E_cap:dv.t.E_cap + E].cpu().numpy()
+n0, bw0, bh0 = window_stats(co, 120, 160, 1.0); n1, bw1, bh1 = window_stats(co, 30, 40, 4.0)
+elig = (n0 > 0) & (bw0 * bh0 <= 112) & (n1 > 0) & (bw1 * bh1 <= 128) & (bw1 <= 12) & (bh1 <= 12)
+elig8 = (n0 > 0) & (bw0 * bh0 <= 128) & (n1 > 0) & (bw1 * bh1 <= 128) & (bw1 <= 12) & (bh1 <= 12)
+print("eligible (7 groups): %.4f  (8 groups): %.4f" % (elig.mean(), elig8.mean()))
