@@ -111,21 +111,6 @@ int ramp_corr_fwd_ordered(const void *fmap1, const ramp_corr_level *levels_host,
                           const int32_t *order, void *out, int out_row_elems, long mod_ii, long mod_jj, int E,
                           int N1, int N2, int C, int P, int radius, int dtype, int layout, void *stream);
 
-/* ramp_corr_fwd_ordered with the coarse level (levels_host[1]) computed from LDS-resident tiles of the target
- * planes: the factors are binned by (target slot, window origin), a workgroup loads a 21 x 21 pixel tile once and
- * serves every factor whose union window lies in it (csrc/altcorr.hip::corr_tile_kernel) -- the same MFMA steps and
- * blend as the gather kernel, bit-identical values; factors that do not fit a tile keep both levels in the gather
- * kernel.  fp16, RAMP_NHWC8, nlevels == 2, mod_jj > 0 (the number of ring slots the planes hold).
- * ws: ramp_corr_tile_workspace_bytes(E capacity, mod_jj, levels_host[1].H2, levels_host[1].W2) bytes (0: the size has
- * no tile path), ZERO before the first call -- the kernels leave the counters zero again.
- * (ramp/altcorr/correlation_kernel.cu:82-136 at ramp/Ramp_vo.py:175-182's second call, coords / 4)          */
-size_t ramp_corr_tile_workspace_bytes(int E_cap, int slots, int H2, int W2);
-int ramp_corr_fwd_tiled(const void *fmap1, const ramp_corr_level *levels_host, int nlevels,
-                        const float *coords, const int64_t *ii, const int64_t *jj,
-                        const int32_t *order, void *out, int out_row_elems, long mod_ii, long mod_jj, int E,
-                        int N1, int N2, int C, int P, int radius, int dtype, int layout, void *ws, size_t ws_bytes,
-                        void *stream);
-
 /* Ramp_vo.__call__'s pyramid store (ramp/Ramp_vo.py:378-381: fmap1_[slot] =
  * fmap, fmap2_[slot] = avg_pool2d(fmap, 4, 4)) for fp16 channels-last features:
  * fmap [H][W][C] -> level1 [H][C/8][W][8] (same values) and level4
@@ -615,8 +600,6 @@ typedef struct ramp_track {
   ramp_track_weights w;
   float *coords;                      /* [E_cap][2][P][P] */
   void *corr;                         /* [E_cap][896] fp16 */
-  void *corr_ws;                      /* optional: ramp_corr_tile_workspace_bytes(E_cap, mem, feat_h / 4, feat_w / 4), ZERO at */
-  size_t corr_ws_bytes;               /* first use -- the coarse correlation level from LDS tiles (ramp_corr_fwd_tiled)      */
   float *net[3];                      /* [E_cap][384] fp32: [0] the hidden state (in: previous, out: new), [1], [2] scratch */
   void *fg, *ykk, *hkk, *yij, *hij, *relu_t;
   float *target, *weight;             /* [E_cap][2] */

@@ -161,7 +161,11 @@ __global__ void __launch_bounds__(256) frame_gather_kernel(const FrameGather p) 
 #define CORR_PGB 4    // pixel groups (of 16) whose loads are in flight together, MFMA kernel
 #define CORR_WAVES 4  // waves per SIMD the MFMA kernel is register-budgeted for
 #endif
-#define CORR_T 128  // union pixels handled per group (2 per lane)
+#define CORR_T 128  // union pixels handled per group (2 per lane), VALU kernel
+#ifndef CORR_TM
+#define CORR_TM 192 // ... of the MFMA kernel: twelve 16-pixel products.  In the bench's steady state a tenth of the live
+#endif              // factors have a 12 x 11 .. 13 x 13 union window at the fine level (tools/corr_window_stats.py); at 128 they
+                    // took the nine-separate-windows path (36 products instead of 9-11)
 
 struct CorrParams {
   const void *fmap1;
@@ -178,8 +182,6 @@ struct CorrParams {
   const int32_t *order;   // optional schedule: position -> edge (any permutation of 0..E-1)
   int chunk;              // ceil(E / CORR_XCDS)
   const int32_t *dyn;     // optional device-side sizes (RAMP_DYN_E): E / chunk above are then the launch bound
-  const int32_t *list;    // list mode (corr_mfma_list_kernel): the edges to compute, *list_n of them
-  int32_t *list_n;        // (... and three ints behind it: a ticket; the last workgroup out zeroes both)
 };
 
 // Workgroup ids are dealt round-robin to the 8 XCDs, each with a private L2.  Position p of the
@@ -466,7 +468,8 @@ __device__ unsigned long long g_corr_trace[CORR_TRACE_WAVES * 8];    // one row 
 #define CTACC(k, v)
 #endif
 template <typename T, bool CHUNKED>
-__device__ __forceinline__ void corr_mfma_edge(const CorrParams &prm, const int e) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CorrMma<T>::WAVES, 8)))
+    corr_mfma_kernel(const CorrParams prm) {
   typedef CorrMma<T> M;
   typedef typename M::frag frag_t;
   constexpr int STEPS = M::STEPS, PER = M::PER;   // MFMA-operand loads per pixel, channels per lane and load
@@ -474,11 +477,13 @@ __device__ __forceinline__ void corr_mfma_edge(const CorrParams &prm, const int 
   constexpr int NOUT = d * d * PP;           // 441 values per level
   constexpr int KOUT = d;                    // 7 per lane (lanes 0..62), held until both levels are done
   constexpr int PGB = M::PGB;                     // pixel groups whose loads are in flight together
-  __shared__ __attribute__((aligned(16))) float Cs[PP * CORR_T];
+  __shared__ __attribute__((aligned(16))) float Cs[PP * CORR_TM];
   __shared__ float outs[NOUT];               // staging for the ragged (non-union) paths only
   __shared__ int s_ox[PP], s_oy[PP], s_live[PP];
   __shared__ float s_dx[PP], s_dy[PP];
 
+  const int e = corr_edge_of_block(prm);
+  if (e < 0) return;
   CTS(ct_start);
 #ifdef CORR_TRACE
   unsigned long long ct_load = 0, ct_mma = 0, ct_blend = 0, ct_setup = 0;
@@ -531,7 +536,7 @@ __device__ __forceinline__ void corr_mfma_edge(const CorrParams &prm, const int 
       }
     }
     const long bw = (long)maxx - minx + D, bh = (long)maxy - miny + D;
-    const bool uni = (nlive > 0) && (bw * bh <= CORR_T);
+    const bool uni = (nlive > 0) && (bw * bh <= CORR_TM);
     const int ngroups = (nlive == 0) ? 0 : (uni ? 1 : PP);
     if (nlive == 0) {
       for (int o = lane; o < NOUT; o += 64) {
@@ -558,7 +563,7 @@ __device__ __forceinline__ void corr_mfma_edge(const CorrParams &prm, const int 
       }
       const int gx0 = uni ? minx : s_ox[g], gy0 = uni ? miny : s_oy[g];
       const int gw = uni ? (int)bw : D, gh = uni ? (int)bh : D;
-      const int Tn = gw * gh;                      // <= CORR_T = 128
+      const int Tn = gw * gh;                      // <= CORR_TM
       const int npg = (Tn + 15) / 16;
       const int inv_gw = (65536 + gw - 1) / gw;    // t / gw == (t * inv_gw) >> 16 while t * gw < 65536
 #ifdef CORR_TRACE
@@ -601,7 +606,7 @@ __device__ __forceinline__ void corr_mfma_edge(const CorrParams &prm, const int 
 #pragma unroll
             for (int r = 0; r < 4; r++) {
               const int p = 4 * q + r;
-              if (p < PP) Cs[p * CORR_T + t] = inb[u] ? acc[r] : 0.0f;
+              if (p < PP) Cs[p * CORR_TM + t] = inb[u] ? acc[r] : 0.0f;
             }
           }
         }
@@ -617,7 +622,7 @@ __device__ __forceinline__ void corr_mfma_edge(const CorrParams &prm, const int 
         if (lane < 63) {
           float r0[D], r1[D];
           if (s_live[op_p]) {
-            const float *row = &Cs[op_p * CORR_T + (s_oy[op_p] - gy0 + op_a) * gw + (s_ox[op_p] - gx0)];
+            const float *row = &Cs[op_p * CORR_TM + (s_oy[op_p] - gy0 + op_a) * gw + (s_ox[op_p] - gx0)];
 #pragma unroll
             for (int b = 0; b < D; b++) { r0[b] = row[b]; r1[b] = row[gw + b]; }
           } else {
@@ -638,7 +643,7 @@ __device__ __forceinline__ void corr_mfma_edge(const CorrParams &prm, const int 
         for (int ab = lane; ab < d * d; ab += 64) {
           const int b = ab / d, a = ab - b * d;
           const int wx = s_ox[g] - gx0 + b, wy = s_oy[g] - gy0 + a;
-          const float *row = &Cs[g * CORR_T + wy * gw + wx];
+          const float *row = &Cs[g * CORR_TM + wy * gw + wx];
           const float c00 = row[0], c01 = row[1], c10 = row[gw], c11 = row[gw + 1];
           const float dx = s_dx[g], dy = s_dy[g];
           float s = ((1 - dx) * (1 - dy)) * c00;
@@ -683,443 +688,6 @@ __device__ __forceinline__ void corr_mfma_edge(const CorrParams &prm, const int 
 #endif
 }
 
-template <typename T, bool CHUNKED>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CorrMma<T>::WAVES, 8)))
-    corr_mfma_kernel(const CorrParams prm) {
-  const int e = corr_edge_of_block(prm);
-  if (e < 0) return;
-  corr_mfma_edge<T, CHUNKED>(prm, e);
-}
-
-// the factors corr_tile_kernel left out (prm.list, *prm.list_n of them): a fixed grid walks the list
-template <typename T, bool CHUNKED>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CorrMma<T>::WAVES, 8)))
-    corr_mfma_list_kernel(const CorrParams prm) {
-  const int n = *prm.list_n;
-  for (int pos = blockIdx.x; pos < n; pos += gridDim.x) {
-    corr_mfma_edge<T, CHUNKED>(prm, prm.list[pos]);
-    __syncthreads();
-  }
-  __shared__ int s_last;
-  if (threadIdx.x == 0) s_last = (atomicAdd(prm.list_n + 1, 1) == (int)gridDim.x - 1);
-  __syncthreads();
-  if (s_last && threadIdx.x == 0) { prm.list_n[0] = 0; prm.list_n[1] = 0; }
-}
-
-
-// ------------------------------------------------------------- tile-resident level
-// The coarse level of the pyramid is read ~170 times per pixel and step (2112 factors per target frame, each a
-// 10 x 10 window of a 30 x 40 plane), every time through the vector L1 -- the limiter of corr_mfma_kernel
-// (DESIGN.md section 5).  Here the factors of one level are binned by (target slot, window origin): a bin owns the
-// origins of a CT_SX x CT_SY cell, all of its windows fall inside one CT_TW x CT_TH pixel tile, and a workgroup
-// brings that tile into LDS ONCE (coalesced 16-byte pieces, zeros outside the plane) and hands the bin's factors
-// to its waves.  A wave does exactly what corr_mfma_kernel does for the level -- the same union window, the same
-// four v_mfma_f32_16x16x32_f16 steps in the same channel order, the same blend -- with ds_read_b128 as the source of
-// the B operands: bit-identical values.  The FINE level of the same factor is computed by the same wave with the
-// gather kernel's window loads, issued before the coarse level's LDS work and consumed after it: the vector L1's
-// latency runs under the tile work, and both levels leave as the half2 pairs of the reference layout.  Factors that
-// do not fit (a union window wider than CT_MAXB at the coarse level or of more than 128 pixels at either, nothing in
-// a plane, bin list full) go to a fallback list for corr_mfma_list_kernel.
-//   corr_bin_kernel : one thread per factor -> record in its bin (slot by atomic counter; the order inside a bin
-//                     is irrelevant: factors are independent) or the fallback list
-//   corr_tile_kernel: persistent workgroups, work items = (bin, chunk of CT_CHUNK factors), one contiguous run of
-//                     items per XCD; the last workgroup to finish clears the counters for the next call (ticket)
-#define CT_SX 10
-#define CT_SY 10
-#define CT_MAXB 12                       // widest union window a tile holds
-#define CT_TW (CT_SX + CT_MAXB - 1)      // 21
-#define CT_TH (CT_SY + CT_MAXB - 1)      // 21
-#define CT_WAVES 8
-#define CT_NT (64 * CT_WAVES)
-#define CT_CHUNK 32                      // factors per work item
-#define CT_CAP 384                       // records per bin
-#define CT_REC 64                        // words per record
-#define CT_MAXBINS 2560
-#define CT_HDR 16                        // ints in front of the counters: [0] ticket, [1] fallback count, [2] its ticket
-#define CT_UNITS (CT_TH * 16 * CT_TW)    // 16-byte pieces of a tile
-#define CT_FILL ((CT_UNITS + CT_NT - 1) / CT_NT)
-#define CT_FG 8                          // fine-level pixel groups of a factor (128 union pixels)
-#define CT_DEADBINS 128                   // extra bins (no tile) for factors with nothing in the coarse plane
-#if CT_CHUNK * CT_REC * 4 > CT_NT * 16
-#error "one 16-byte piece per thread moves a work item's records"
-#endif
-
-// Record of a binned factor (written by corr_bin_kernel, 256 bytes, so that the tile kernel's loads do not depend
-// on one another): [0] factor, [1] patch slot, [2] target slot; per level (fine at +4, coarse at +32): [0] window
-// origin x | y << 16 (int16 each), [1] gw | gh << 8 | live mask << 16, [2..10] dx, [11..19] dy of the nine patch
-// pixels, [20..22] their window offsets inside the union window, one byte each (x | y << 4)
-#define CT_L0 4
-#define CT_L1 32
-struct CorrTile {
-  const _Float16 *fmap1;       // [N1][9][128]
-  const _Float16 *plane0;      // fine level   [mod_jj slots][H0][16][W0][8]
-  const _Float16 *plane;       // coarse level [mod_jj slots][H2][16][W2][8]
-  const float *coords;
-  const int64_t *ii, *jj;
-  _Float16 *out;
-  int32_t *head;               // [CT_HDR], then count [nbins]
-  int32_t *list;               // [nbins][CT_CAP][CT_REC]
-  int32_t *fallback;           // [E] factors left to corr_mfma_list_kernel
-  const int32_t *dyn;
-  long mod_ii, mod_jj;
-  float cdv0, cdv;
-  int H0, W0, H2, W2, nbx, nby, nbins, nbins_all, E, row_elems;    // bins [nbins, nbins_all): no tile
-};
-
-// window geometry of the nine patch pixels at one level: the arithmetic of corr_mfma_kernel, line for line
-struct CorrGeom {
-  int minx, miny, bw, bh, nlive;
-  unsigned lmask;
-  int ox[9], oy[9];
-  float dx[9], dy[9];
-};
-__device__ __forceinline__ void corr_geom(const float *__restrict__ coords, int e, float cdv, int H2, int W2, CorrGeom &g) {
-  constexpr int PP = 9, R = 3, D = 8;
-  int minx = 1 << 30, miny = 1 << 30, maxx = -(1 << 30), maxy = -(1 << 30);
-  g.nlive = 0; g.lmask = 0;
-#pragma unroll
-  for (int p = 0; p < PP; p++) {
-    const float x = coords[((size_t)e * 2 + 0) * PP + p] / cdv;
-    const float y = coords[((size_t)e * 2 + 1) * PP + p] / cdv;
-    const float flx = floorf(x), fly = floorf(y);
-    const int fx = ramp_f2i(flx), fy = ramp_f2i(fly);
-    g.dx[p] = x - flx;
-    g.dy[p] = y - fly;
-    const bool live = ((long)fx - R < W2) && ((long)fx - R + D > 0) && ((long)fy - R < H2) && ((long)fy - R + D > 0);
-    g.ox[p] = live ? fx - R : 0;
-    g.oy[p] = live ? fy - R : 0;
-    if (live) {
-      g.nlive++;
-      g.lmask |= 1u << p;
-      minx = min(minx, g.ox[p]); maxx = max(maxx, g.ox[p]);
-      miny = min(miny, g.oy[p]); maxy = max(maxy, g.oy[p]);
-    }
-  }
-  g.minx = minx; g.miny = miny;
-  g.bw = g.nlive ? maxx - minx + D : 0;
-  g.bh = g.nlive ? maxy - miny + D : 0;
-}
-__device__ __forceinline__ void corr_geom_pack(const CorrGeom &g, int32_t *w) {    // 23 words
-  w[0] = (g.minx & 0xffff) | (g.miny << 16);
-  w[1] = g.bw | (g.bh << 8) | (int)(g.lmask << 16);
-#pragma unroll
-  for (int p = 0; p < 9; p++) { w[2 + p] = __float_as_int(g.dx[p]); w[11 + p] = __float_as_int(g.dy[p]); }
-  w[20] = w[21] = w[22] = 0;
-#pragma unroll
-  for (int p = 0; p < 9; p++) {
-    const int off = (g.lmask >> p) & 1 ? ((g.ox[p] - g.minx) | ((g.oy[p] - g.miny) << 4)) : 0;
-    w[20 + p / 4] |= off << (8 * (p % 4));
-  }
-}
-
-__global__ void __launch_bounds__(256) corr_bin_kernel(const CorrTile t) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  const int E = t.dyn ? t.dyn[RAMP_DYN_E] : t.E;
-  if (e >= E) return;
-  int32_t w[CT_REC];
-  CorrGeom g;
-  corr_geom(t.coords, e, t.cdv0, t.H0, t.W0, g);
-  // a level with nothing in its plane costs the tile kernel nothing (no window, the blend's zero formula)
-  bool ok = g.nlive == 0 || (long)g.bw * g.bh <= 16 * CT_FG;       // (the union path of corr_mfma_kernel: <= 128)
-  corr_geom_pack(g, w + CT_L0);
-  corr_geom(t.coords, e, t.cdv, t.H2, t.W2, g);
-  ok = ok && (g.nlive == 0 || ((long)g.bw * g.bh <= CORR_T && g.bw <= CT_MAXB && g.bh <= CT_MAXB));
-  corr_geom_pack(g, w + CT_L1);
-  if (ok) {
-    const long j2 = t.jj[e] % t.mod_jj;
-    int bin;
-    if (g.nlive > 0) {
-      const int bx = (g.minx + 7) / CT_SX, by = (g.miny + 7) / CT_SY;          // live: origin >= -7
-      bin = ((int)j2 * t.nby + by) * t.nbx + bx;
-      ok = j2 >= 0 && bx < t.nbx && by < t.nby && bin < t.nbins;
-    } else {
-      bin = t.nbins + e % CT_DEADBINS;
-      ok = j2 >= 0;
-    }
-    if (ok) {
-      const int slot = atomicAdd(t.head + CT_HDR + bin, 1);
-      ok = slot < CT_CAP;
-      if (ok) {
-        w[0] = e; w[1] = (int)(t.mod_ii > 0 ? t.ii[e] % t.mod_ii : t.ii[e]); w[2] = (int)j2; w[3] = 0;
-#pragma unroll
-        for (int c = CT_L0 + 23; c < CT_L1; c++) w[c] = 0;
-#pragma unroll
-        for (int c = CT_L1 + 23; c < CT_REC; c++) w[c] = 0;
-        int4 *dst = reinterpret_cast<int4 *>(t.list + ((size_t)bin * CT_CAP + slot) * CT_REC);
-#pragma unroll
-        for (int c = 0; c < CT_REC / 4; c++) dst[c] = make_int4(w[4 * c], w[4 * c + 1], w[4 * c + 2], w[4 * c + 3]);
-      }
-    }
-  }
-  if (!ok) t.fallback[atomicAdd(t.head + 1, 1)] = e;
-}
-
-// blend of corr_mfma_kernel's union epilogue: lane = 9 a + p owns output row a of patch pixel p (lanes 0..62)
-__device__ __forceinline__ void corr_tile_blend(const float *Cs, const int *lv, int gw, int op_p, int op_a, float (&res)[7]) {
-  constexpr int D = 8, d = 7;
-  const float pdx = __int_as_float(lv[2 + op_p]), pdy = __int_as_float(lv[11 + op_p]);
-  const int off = (lv[20 + op_p / 4] >> (8 * (op_p % 4))) & 0xff;
-  float r0[D], r1[D];
-  if ((lv[1] >> (16 + op_p)) & 1) {
-    const float *row = &Cs[op_p * CORR_T + ((off >> 4) + op_a) * gw + (off & 15)];
-#pragma unroll
-    for (int b = 0; b < D; b++) { r0[b] = row[b]; r1[b] = row[gw + b]; }
-  } else {
-#pragma unroll
-    for (int b = 0; b < D; b++) { r0[b] = 0.f; r1[b] = 0.f; }
-  }
-#pragma unroll
-  for (int b = 0; b < d; b++) {
-    float s = ((1 - pdx) * (1 - pdy)) * r0[b];
-    s = s + (pdx * (1 - pdy)) * r0[b + 1];
-    s = s + ((1 - pdx) * pdy) * r1[b];
-    s = s + (pdx * pdy) * r1[b + 1];
-    res[b] = s;
-  }
-}
-
-__global__ void __launch_bounds__(CT_NT) corr_tile_kernel(const CorrTile t) {
-  constexpr int C = 128, PP = 9;
-  extern __shared__ __attribute__((aligned(16))) unsigned char ct_smem[];
-  uint4 *tile = reinterpret_cast<uint4 *>(ct_smem);                          // [CT_TH * CT_TW pixels][16 chunk slots]
-  float *Cs_all = reinterpret_cast<float *>(ct_smem + (size_t)CT_UNITS * 16);  // [CT_WAVES][9][CORR_T]
-  int *recs = reinterpret_cast<int *>(Cs_all + CT_WAVES * PP * CORR_T);       // [CT_CHUNK][CT_REC]
-  int *pref = recs + CT_CHUNK * CT_REC;                                       // [nbins + 1] work items before bin b
-  int *s_part = reinterpret_cast<int *>(Cs_all);                              // (prologue only)
-  __shared__ int s_last;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
-  const int32_t *count = t.head + CT_HDR;
-
-  // ---- work items: bin b has ceil(min(count, CAP) / CHUNK) of them
-  const int per = (t.nbins_all + CT_NT - 1) / CT_NT;
-  {
-    int sum = 0;
-    for (int k = 0; k < per; k++) {
-      const int b = tid * per + k;
-      if (b < t.nbins_all) sum += (min(count[b], CT_CAP) + CT_CHUNK - 1) / CT_CHUNK;
-    }
-    s_part[tid] = sum;
-  }
-  __syncthreads();
-  if (wave == 0) {                                   // exclusive scan of the partial sums (CT_WAVES per lane)
-    int v[CT_WAVES], run = 0;
-#pragma unroll
-    for (int k = 0; k < CT_WAVES; k++) { v[k] = s_part[lane * CT_WAVES + k]; run += v[k]; }
-    int inc = run;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int u = __shfl_up(inc, o, 64);
-      if (lane >= o) inc += u;
-    }
-    int base = inc - run;
-#pragma unroll
-    for (int k = 0; k < CT_WAVES; k++) { s_part[lane * CT_WAVES + k] = base; base += v[k]; }
-  }
-  __syncthreads();
-  {
-    int base = s_part[tid];
-    for (int k = 0; k < per; k++) {
-      const int b = tid * per + k;
-      if (b < t.nbins_all) {
-        pref[b] = base;
-        base += (min(count[b], CT_CAP) + CT_CHUNK - 1) / CT_CHUNK;
-        if (b == t.nbins_all - 1) pref[t.nbins_all] = base;
-      }
-    }
-  }
-  __syncthreads();
-  const int nitems = pref[t.nbins_all];
-  // workgroup ids are dealt round-robin to the XCDs: each XCD takes one contiguous run of the items (target slot
-  // major), so a frame's planes stay in one L2
-  const int xcd = blockIdx.x % CORR_XCDS, nx = (gridDim.x - xcd + CORR_XCDS - 1) / CORR_XCDS;
-  const int run = (nitems + CORR_XCDS - 1) / CORR_XCDS;
-  const int item_end = min(nitems, (xcd + 1) * run);
-
-  float *Cs = Cs_all + wave * PP * CORR_T;
-  const int op_p = lane % PP, op_a = lane / PP;
-  for (int item = xcd * run + blockIdx.x / CORR_XCDS; item < item_end; item += nx) {
-    int lo = 0, hi = t.nbins_all - 1;                   // last bin with pref[b] <= item
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (pref[mid] <= item) lo = mid; else hi = mid - 1;
-    }
-    const int bin = lo, chunk = item - pref[bin];
-    const int bx = bin % t.nbx, by = (bin / t.nbx) % t.nby, slot2 = bin / (t.nbx * t.nby);
-    const int X0 = bx * CT_SX - 7, Y0 = by * CT_SY - 7;
-    const int n = min(min(count[bin], CT_CAP) - chunk * CT_CHUNK, CT_CHUNK);
-    const bool with_tile = bin < t.nbins_all - CT_DEADBINS;
-#ifdef CT_NO_FILL
-    const int e0 = t.E;
-#endif
-    __syncthreads();                                // the previous item's waves are done with the tile
-    {
-      const _Float16 *f2 = t.plane + (size_t)slot2 * C * t.H2 * t.W2;
-      uint4 v[CT_FILL], vrec = make_uint4(0, 0, 0, 0);
-      if (tid < n * (CT_REC / 4))
-        vrec = reinterpret_cast<const uint4 *>(t.list + ((size_t)bin * CT_CAP + chunk * CT_CHUNK) * CT_REC)[tid];
-#pragma unroll
-      for (int k = 0; k < CT_FILL; k++) {
-        int u = tid + k * CT_NT;
-        asm volatile("" : "+v"(u));                  // (keeps the index arithmetic out of the registers between items)
-        const int py = u / (16 * CT_TW), rem = u - py * (16 * CT_TW), c = rem / CT_TW, px = rem - c * CT_TW;
-        const int gy = Y0 + py, gx = X0 + px;
-        v[k] = make_uint4(0, 0, 0, 0);
-#ifdef CT_NO_FILL
-        if (with_tile && e0 < 0 && u < CT_UNITS && gy >= 0 && gy < t.H2 && gx >= 0 && gx < t.W2)
-#else
-        if (with_tile && u < CT_UNITS && gy >= 0 && gy < t.H2 && gx >= 0 && gx < t.W2)
-#endif
-          v[k] = *reinterpret_cast<const uint4 *>(f2 + (((size_t)gy * (C / 8) + c) * t.W2 + gx) * 8);
-      }
-      if (tid < CT_CHUNK * (CT_REC / 4)) reinterpret_cast<uint4 *>(recs)[tid] = vrec;
-#pragma unroll
-      for (int k = 0; k < CT_FILL; k++) {
-        int u = tid + k * CT_NT;
-        asm volatile("" : "+v"(u));
-        const int py = u / (16 * CT_TW), rem = u - py * (16 * CT_TW), c = rem / CT_TW, px = rem - c * CT_TW;
-        const int pix = py * CT_TW + px;
-        if (with_tile && u < CT_UNITS) tile[pix * 16 + ((c + pix) & 15)] = v[k];
-      }
-    }
-    __syncthreads();
-
-    for (int k = wave; k < n; k += CT_WAVES) {
-      const int *rec = recs + k * CT_REC;
-      const int e = rec[0];
-      // the patch features and every fine-level window load go out together; the coarse level's products wait for
-      // the former only
-      f16x8_t afrag[4];
-      {
-        const _Float16 *src = t.fmap1 + (size_t)rec[1] * C * PP;
-#pragma unroll
-        for (int s = 0; s < 4; s++) {
-          if (j < PP) afrag[s] = *reinterpret_cast<const f16x8_t *>(src + j * C + 32 * s + 8 * q);
-          else afrag[s] = (f16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
-        }
-      }
-      // ---- fine level: every window load of the factor goes out now (the vector L1's latency is spent on the coarse
-      // level's LDS work below); the address is always a valid pixel, out-of-plane lanes are zeroed afterwards
-      const int *l0 = rec + CT_L0;
-      const int fx0 = (int)(short)(l0[0] & 0xffff), fy0 = l0[0] >> 16, fw = l0[1] & 0xff, fh = (l0[1] >> 8) & 0xff;
-      const int fTn = fw * fh, fnpg = (fTn + 15) / 16, finv = (65536 + fw - 1) / (fw > 0 ? fw : 1);   // (fTn == 0: nothing in the plane)
-      f16x8_t bF[CT_FG][4];
-      unsigned inb = 0;
-      {
-        const _Float16 *f0 = t.plane0 + (size_t)rec[2] * C * t.H0 * t.W0;
-#pragma unroll
-        for (int u = 0; u < CT_FG; u++) {
-#ifdef CT_NO_FINE
-          if (u < fnpg && e < 0) {
-#else
-          if (u < fnpg) {                             // (wave uniform)
-#endif
-            const int tt = u * 16 + j;
-            const int ty = (tt * finv) >> 16, tx = tt - ty * fw;
-            const int px = fx0 + tx, py = fy0 + ty;
-            const bool in = (tt < fTn) && px >= 0 && px < t.W0 && py >= 0 && py < t.H0;
-            inb |= (unsigned)in << u;
-            const int cy = in ? py : 0, cx = in ? px : 0;
-            const _Float16 *pp = f0 + (((size_t)cy * (C / 8) + q) * t.W0 + cx) * 8;
-            const size_t sstride = (size_t)4 * t.W0 * 8;
-#pragma unroll
-            for (int s = 0; s < 4; s++) bF[u][s] = *reinterpret_cast<const f16x8_t *>(pp + s * sstride);
-          }
-        }
-      }
-      // ---- coarse level from the tile
-      float res1[7], res0[7];
-      {
-        const int *l1 = rec + CT_L1;
-        const int gx0 = (int)(short)(l1[0] & 0xffff), gy0 = l1[0] >> 16, gw = l1[1] & 0xff, gh = (l1[1] >> 8) & 0xff;
-        const int Tn = gw * gh, npg = (Tn + 15) / 16, inv_gw = (65536 + gw - 1) / (gw > 0 ? gw : 1);
-        const int lx0 = gx0 - X0, ly0 = gy0 - Y0;     // the bin guarantees [lx0, lx0 + gw) x [ly0, ly0 + gh) inside the tile
-        auto load_b = [&](int pg, f16x8_t (&b)[4]) {
-          const int tt = pg * 16 + j;
-          const int ty = (tt * inv_gw) >> 16, tx = tt - ty * gw;
-          const int pix = tt < Tn ? (ly0 + ty) * CT_TW + lx0 + tx : 0;
-#pragma unroll
-          for (int s = 0; s < 4; s++) b[s] = *reinterpret_cast<const f16x8_t *>(&tile[pix * 16 + ((4 * s + q + pix) & 15)]);
-        };
-#ifdef CT_NO_COARSE
-        for (int pg = 0; pg < (e < 0 ? npg : 0); pg++) {
-#else
-        for (int pg = 0; pg < npg; pg++) {
-#endif
-          f16x8_t bc[4];
-          load_b(pg, bc);
-          const int tt = pg * 16 + j;
-          f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag[s], bc[s], acc, 0, 0, 0);
-          if (tt < Tn) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-              const int p = 4 * q + r;
-              if (p < PP) Cs[p * CORR_T + tt] = acc[r];
-            }
-          }
-        }
-        __builtin_amdgcn_wave_barrier();
-#ifdef CT_NO_BLEND
-        if (lane < 63 && e < 0) corr_tile_blend(Cs, l1, gw, op_p, op_a, res1);
-#else
-        if (lane < 63) corr_tile_blend(Cs, l1, gw, op_p, op_a, res1);
-#endif
-        __builtin_amdgcn_wave_barrier();
-      }
-      // ---- fine level: products of the loads issued above
-#pragma unroll
-      for (int u = 0; u < CT_FG; u++) {
-#ifdef CT_NO_FINE
-        if (u < fnpg && e < 0) {
-#else
-        if (u < fnpg) {
-#endif
-          const int tt = u * 16 + j;
-          f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag[s], bF[u][s], acc, 0, 0, 0);
-          if (tt < fTn) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-              const int p = 4 * q + r;
-              if (p < PP) Cs[p * CORR_T + tt] = ((inb >> u) & 1) ? acc[r] : 0.0f;
-            }
-          }
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-#ifdef CT_NO_BLEND
-      if (lane < 63 && e < 0) {
-#else
-      if (lane < 63) {
-#endif
-        corr_tile_blend(Cs, l0, fw, op_p, op_a, res0);
-        typedef _Float16 h2v __attribute__((ext_vector_type(2)));
-        _Float16 *op = t.out + (size_t)e * t.row_elems;
-#pragma unroll
-        for (int b = 0; b < 7; b++)
-          *reinterpret_cast<h2v *>(op + 2 * (lane + 63 * b)) = (h2v){(_Float16)res0[b], (_Float16)res1[b]};
-      }
-      {
-        _Float16 *op = t.out + (size_t)e * t.row_elems;
-        for (int z = 882 + lane; z < t.row_elems; z += 64) op[z] = (_Float16)0.0f;   // row padding
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-  }
-  // ---- the last workgroup out clears the counters (every workgroup is past its last read of them)
-  __syncthreads();
-  if (tid == 0) {
-    __threadfence();
-    s_last = (atomicAdd(t.head, 1) == (int)gridDim.x - 1);
-  }
-  __syncthreads();
-  if (s_last) {
-    for (int b = tid; b < t.nbins_all; b += CT_NT) t.head[CT_HDR + b] = 0;
-    if (tid == 0) t.head[0] = 0;
-  }
-}
 
 // ------------------------------------------------------------- pyramid pack
 // One frame's fp16 NHWC feature map [H][W][128] -> the two correlation levels in the chunked
@@ -1226,26 +794,10 @@ int ramp_frame_gather(const void *fmap, const void *imap, const float *image, co
   return RAMP_OK;
 }
 
-static void corr_tile_geometry(int H2, int W2, long slots, int &nbx, int &nby, long &nbins) {
-  nbx = (W2 + 7 + CT_SX - 1) / CT_SX;      // window origins of live pixels: -7 .. W2 - 1
-  nby = (H2 + 7 + CT_SY - 1) / CT_SY;
-  nbins = slots * nbx * nby;
-}
-static size_t corr_tile_head_bytes(long nbins) { return (((size_t)(CT_HDR + nbins + CT_DEADBINS) * 4 + 255) / 256) * 256; }
-
-size_t ramp_corr_tile_workspace_bytes(int E_cap, int slots, int H2, int W2) {
-  int nbx, nby; long nbins;
-  if (E_cap <= 0 || slots <= 0 || H2 <= 0 || W2 <= 0) return 0;
-  corr_tile_geometry(H2, W2, slots, nbx, nby, nbins);
-  if (nbins + CT_DEADBINS > CT_MAXBINS) return 0;             // no tile path at this size
-  return corr_tile_head_bytes(nbins) + (size_t)(nbins + CT_DEADBINS) * CT_CAP * CT_REC * 4 + (size_t)E_cap * 4;
-}
-
 int ramp_i_corr_fwd(const void *fmap1, const ramp_corr_level *levels, int nlevels,
                     const float *coords, const int64_t *ii, const int64_t *jj,
                     const int32_t *order, void *out, int out_row_elems, long mod_ii, long mod_jj, int E,
-                    int N1, int N2, int C, int P, int radius, int dtype, int layout, const int32_t *dyn,
-                    void *tile_ws, size_t tile_ws_bytes, void *stream) {
+                    int N1, int N2, int C, int P, int radius, int dtype, int layout, const int32_t *dyn, void *stream) {
   if (E < 0 || nlevels < 1 || nlevels > CORR_MAXLEV || !levels) return RAMP_EINVAL;
   if (C != 128 || P != 3 || radius != 3) return RAMP_EUNSUPPORTED;
   if (E == 0) return RAMP_OK;
@@ -1275,48 +827,8 @@ int ramp_i_corr_fwd(const void *fmap1, const ramp_corr_level *levels, int nlevel
   if (prm.row_elems < 49 * 9 * nlevels || (nlevels == 2 && (prm.row_elems & 1))) return RAMP_EINVAL;   // half2 stores
   prm.chunk = (E + CORR_XCDS - 1) / CORR_XCDS;
   prm.dyn = dyn;
-  prm.list = nullptr;
-  prm.list_n = nullptr;
   const dim3 grid(prm.chunk * CORR_XCDS);
   hipStream_t st = (hipStream_t)stream;
-  // both levels of the regular factors in corr_tile_kernel (fp16 chunked pyramid, ring slots known), the rest from a list
-  static int tile_on = -1;                          // RAMP_CORR_TILE=0: everything in corr_mfma_kernel (A/B runs)
-  if (tile_on < 0) { const char *ev = getenv("RAMP_CORR_TILE"); tile_on = ev ? atoi(ev) : 1; }
-  if (tile_ws && tile_on && nlevels == 2 && dtype == RAMP_F16 && layout == RAMP_NHWC8 && mod_jj > 0) {
-    int nbx, nby; long nbins;
-    corr_tile_geometry(levels[1].H2, levels[1].W2, mod_jj, nbx, nby, nbins);
-    const size_t need = nbins + CT_DEADBINS <= CT_MAXBINS ? corr_tile_head_bytes(nbins) + (size_t)(nbins + CT_DEADBINS) * CT_CAP * CT_REC * 4 + (size_t)E * 4 : 0;
-    if (!need || tile_ws_bytes < need) return RAMP_EWORKSPACE;
-    CorrTile t;
-    t.fmap1 = (const _Float16 *)fmap1; t.plane0 = (const _Float16 *)levels[0].fmap; t.plane = (const _Float16 *)levels[1].fmap;
-    t.coords = coords; t.ii = ii; t.jj = jj; t.out = (_Float16 *)out;
-    t.head = (int32_t *)tile_ws;
-    t.list = (int32_t *)((char *)tile_ws + corr_tile_head_bytes(nbins));
-    t.fallback = t.list + (size_t)(nbins + CT_DEADBINS) * CT_CAP * CT_REC;
-    t.dyn = dyn; t.mod_ii = mod_ii; t.mod_jj = mod_jj; t.cdv0 = levels[0].coord_div; t.cdv = levels[1].coord_div;
-    t.H0 = levels[0].H2; t.W0 = levels[0].W2; t.H2 = levels[1].H2; t.W2 = levels[1].W2;
-    t.nbx = nbx; t.nby = nby; t.nbins = (int)nbins; t.nbins_all = (int)nbins + CT_DEADBINS; t.E = E; t.row_elems = prm.row_elems;
-    const size_t lds = (size_t)CT_UNITS * 16 + (size_t)CT_WAVES * 9 * CORR_T * 4 + (size_t)CT_CHUNK * CT_REC * 4 + ((size_t)nbins + CT_DEADBINS + 1) * 4;
-    if (lds > 160 * 1024 - 64) return RAMP_EUNSUPPORTED;
-    static int n_wg = 0;
-    if (!n_wg) {
-      if (hipFuncSetAttribute((const void *)corr_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64) !=
-          hipSuccess)
-        return RAMP_ELAUNCH;
-      int dev = 0, cus = 0;
-      if (hipGetDevice(&dev) != hipSuccess ||
-          hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-        return RAMP_ELAUNCH;
-      n_wg = cus;
-    }
-    hipLaunchKernelGGL(corr_bin_kernel, dim3(ramp_cdiv(E, 256)), dim3(256), 0, st, t);
-    hipLaunchKernelGGL(corr_tile_kernel, dim3(n_wg), dim3(CT_NT), lds, st, t);
-    prm.list = t.fallback;
-    prm.list_n = t.head + 1;
-    hipLaunchKernelGGL((corr_mfma_list_kernel<_Float16, true>), dim3(2048), dim3(64), 0, st, prm);
-    RAMP_CHECK_LAUNCH();
-    return RAMP_OK;
-  }
   const bool fast32 = (dtype & RAMP_CORR_MFMA32) != 0;
   dtype &= ~RAMP_CORR_MFMA32;
   if (dtype == RAMP_F32 && layout == RAMP_NHWC && fast32)
@@ -1342,17 +854,7 @@ int ramp_corr_fwd_ordered(const void *fmap1, const ramp_corr_level *levels, int 
                           const int32_t *order, void *out, int out_row_elems, long mod_ii, long mod_jj, int E,
                           int N1, int N2, int C, int P, int radius, int dtype, int layout, void *stream) {
   return ramp_i_corr_fwd(fmap1, levels, nlevels, coords, ii, jj, order, out, out_row_elems, mod_ii, mod_jj, E, N1, N2,
-                         C, P, radius, dtype, layout, nullptr, nullptr, 0, stream);
-}
-
-int ramp_corr_fwd_tiled(const void *fmap1, const ramp_corr_level *levels, int nlevels,
-                        const float *coords, const int64_t *ii, const int64_t *jj,
-                        const int32_t *order, void *out, int out_row_elems, long mod_ii, long mod_jj, int E,
-                        int N1, int N2, int C, int P, int radius, int dtype, int layout, void *ws, size_t ws_bytes,
-                        void *stream) {
-  if (!ws) return RAMP_EINVAL;
-  return ramp_i_corr_fwd(fmap1, levels, nlevels, coords, ii, jj, order, out, out_row_elems, mod_ii, mod_jj, E, N1, N2,
-                         C, P, radius, dtype, layout, nullptr, ws, ws_bytes, stream);
+                         C, P, radius, dtype, layout, nullptr, stream);
 }
 
 int ramp_corr_fwd(const void *fmap1, const ramp_corr_level *levels, int nlevels,

@@ -328,7 +328,7 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
     lv[1].fmap = t->fmap2; lv[1].H2 = t->feat_h / 4; lv[1].W2 = t->feat_w / 4; lv[1].coord_div = 4.0f;
     TRK_PROBE(0);
     TRK_DO(ramp_i_corr_fwd(t->gmap, lv, 2, t->coords, kk, jj, t->ij_order, t->corr, 896, (long)t->M * t->mem, t->mem, Eb,
-                           t->mem * t->M, t->mem, 128, t->P, 3, RAMP_F16, RAMP_NHWC8, dyn, t->corr_ws, t->corr_ws_bytes, st));
+                           t->mem * t->M, t->mem, 128, t->P, 3, RAMP_F16, RAMP_NHWC8, dyn, st));
     TRK_PROBE(1);
     // the update operator, ramp/net.py:69-90 (the fp16 fused chains of csrc/update_mlp.hip)
     TRK_DO(ramp_i_upd_corr_mlp(t->corr, 896, w.corr_w1, w.corr_b1, w.corr_w2, w.corr_b2, w.corr_w3, w.corr_b3, w.corr_ln_w,

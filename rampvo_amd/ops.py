@@ -57,9 +57,8 @@ def frame_gather(f_nhwc, i_nhwc, image, coords):
 
 
 def corr(fmap1, fmaps2, coords, ii, jj, radius=3, coord_divs=(1.0,), layout=RAMP_NCHW, order=None, row_elems=0,
-         fast_f32=None, mod_ii=0, mod_jj=0, tile_ws=None):
-    """fused multi-level patch correlation.  tile_ws: optional workspace of corr_tile_workspace() -- the coarse level
-    then comes from LDS-resident tiles (ramp_corr_fwd_tiled; same values).  order: optional int32 [E] schedule (a permutation of
+         fast_f32=None, mod_ii=0, mod_jj=0):
+    """fused multi-level patch correlation.  order: optional int32 [E] schedule (a permutation of
     the edges, e.g. target-frame-major) -- affects which XCD computes an edge, never a value.
 
     fmap1  [N1,C,P,P] (NCHW) / [N1,P,P,C] (NHWC) patch features
@@ -105,24 +104,12 @@ def corr(fmap1, fmaps2, coords, ii, jj, radius=3, coord_divs=(1.0,), layout=RAMP
         fast_f32 = os.environ.get("RAMP_CORR_F32_MFMA", "0") == "1"
     if fast_f32 and fmap1.dtype == torch.float32 and layout == RAMP_NHWC:
         code |= _LIB_CORR_MFMA32         # opt-in: MFMA accumulation order instead of the reference's fmaf chain
-    if tile_ws is not None:
-        check(lib().ramp_corr_fwd_tiled(ptr(fmap1), levels, L, ptr(coords), ptr(ii), ptr(jj),
-                                        ptr(order) if order is not None else None, ptr(out), int(row_elems),
-                                        int(mod_ii), int(mod_jj), E, N1, N2, C, P, radius, code, layout, ptr(tile_ws),
-                                        tile_ws.numel(), stream()), "ramp_corr_fwd_tiled")
-        return out
     check(lib().ramp_corr_fwd_ordered(ptr(fmap1), levels, L, ptr(coords), ptr(ii), ptr(jj),
                                       ptr(order) if order is not None else None, ptr(out), int(row_elems), int(mod_ii),
                                       int(mod_jj), E,
                                       N1, N2, C, P, radius, code, layout, stream()),
           "ramp_corr_fwd_ordered")
     return out
-
-
-def corr_tile_workspace(E_cap, slots, H2, W2, device="cuda"):
-    """zeroed workspace of ramp_corr_fwd_tiled (None: no tile path at this size)"""
-    n = lib().ramp_corr_tile_workspace_bytes(int(E_cap), int(slots), int(H2), int(W2))
-    return torch.zeros(n, dtype=torch.uint8, device=device) if n else None
 
 
 def event_stack(x, y, p, height, width, num_bins=5, as_float=True):

@@ -47,7 +47,7 @@ class Track(ctypes.Structure):
                 + _ptr_fields(["kk_order", "kk_gid", "kk_seg", "kk_ngroups", "ij_order", "ij_gid", "ij_seg", "ij_ngroups",
                                "kk_ukeys", "ij_ukeys", "ix", "jx", "kj", "plan_ws"])
                 + [("plan_ws_bytes", c_sz), ("w", TrackWeights)]
-                + _ptr_fields(["coords", "corr", "corr_ws"]) + [("corr_ws_bytes", c_sz), ("net", c_p * 3)]
+                + _ptr_fields(["coords", "corr"]) + [("net", c_p * 3)]
                 + _ptr_fields(["fg", "ykk", "hkk", "yij", "hij", "relu_t", "target", "weight", "ba_ws"])
                 + [("ba_ws_bytes", c_sz)]
                 + _ptr_fields(["mm", "dlog", "edit_ws", "dyn_host"]) + [("probe", c_p * 5)])
@@ -91,9 +91,6 @@ class DeviceTrack:
         self.plan_ws = z(lib.ramp_track_plan_workspace_bytes(E_cap, self.kkey_cap, self.pkey_cap), torch.uint8)
         self.coords = e((E_cap, 2, 3, 3), f32)
         self.corr = e((E_cap, CORR_ROW), f16)
-        # coarse correlation level from LDS-resident tiles (0 bytes: no tile path at this size); zeroed once
-        h4, w4 = slam.fmap2_.shape[1], slam.fmap2_.shape[3]
-        self.corr_ws = z(lib.ramp_corr_tile_workspace_bytes(E_cap, slam.mem, h4, w4), torch.uint8)
         self.net = [z((E_cap, 384), f32) for _ in range(3)]
         self.fg = e((E_cap, 768), f16)
         self.ykk, self.hkk = z((kk_cap, 384), f16), z((kk_cap, 384), f16)
@@ -136,8 +133,6 @@ class DeviceTrack:
                               dyn_host=self.dyn_host).items():
             setattr(t, name, P(ten))
         t.plan_ws_bytes, t.ba_ws_bytes = self.plan_ws.numel(), self.ba_ws.numel()
-        if self.corr_ws.numel():
-            t.corr_ws, t.corr_ws_bytes = P(self.corr_ws), self.corr_ws.numel()
         t.graph[0], t.graph[1] = P(self.graph[0]), P(self.graph[1])
         for i in range(3):
             t.net[i] = P(self.net[i])

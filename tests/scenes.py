@@ -50,7 +50,7 @@ def ba_scene(seed=0, n_frames=8, M=12, lifetime=5, H=120, W=160, noise=1.5, n_to
                 lmbda=np.array([1e-4], np.float32), n_frames=n_frames, M=M)
 
 
-def corr_case(seed=0, E=48, N1=40, N2=6, H=30, W=40, C=128, distort=True):
+def corr_case(seed=0, E=48, N1=40, N2=6, H=30, W=40, C=128, distort=True, wide=False):
     rng = np.random.default_rng(seed)
     fmap1 = rng.normal(0, 1, (1, N1, C, 3, 3)).astype(np.float32)
     fmap2 = rng.normal(0, 1, (1, N2, C, H, W)).astype(np.float32)
@@ -60,6 +60,8 @@ def corr_case(seed=0, E=48, N1=40, N2=6, H=30, W=40, C=128, distort=True):
     scale = rng.uniform(0.6, 1.6, (E, 1, 1)).astype(np.float32)
     if distort:
         scale[::7] *= 6.0          # union of windows > 128 px -> per-pixel fallback path
+    if wide:
+        scale[1::3] = rng.uniform(1.7, 2.4, scale[1::3].shape)     # 12 x 12 .. 13 x 14 unions (one pass up to 192 px)
     x = cx[:, 0] + gx[None] * scale + rng.normal(0, 0.05, (E, 3, 3))
     y = cy[:, 0] + gy[None] * scale + rng.normal(0, 0.05, (E, 3, 3))
     coords = np.stack([x, y], 1).astype(np.float32)[None]          # [1,E,2,3,3]

@@ -147,13 +147,19 @@ def test_corr_reference_signature_and_half():
     assert np.abs(outh.float().cpu().numpy()[ok] - refh[ok]).max() <= 2e-2 * np.abs(refh[ok]).max()
 
 
-def test_corr_half_mfma_path_matches_oracle():
+@pytest.mark.parametrize("wide", [False, True])
+def test_corr_half_mfma_path_matches_oracle(wide):
     """fp16 channels-last features -> v_mfma_f32_16x16x32_f16 kernel (fp32 accumulation; the reference
     accumulates in half, so the oracle on fp16-rounded inputs is the tighter target): only the final
-    rounding of the output to half separates the two"""
+    rounding of the output to half separates the two.  wide: a third of the patches projected 1.7-2.4 px apart --
+    union windows of 130-190 pixels, the upper range of the kernel's single-pass path"""
     from rampvo_amd import ops
     from rampvo_amd._lib import RAMP_NHWC
-    fmap1, fmap2, coords, ii, jj = corr_case(seed=8, E=64)
+    fmap1, fmap2, coords, ii, jj = corr_case(seed=8, E=64, wide=wide)
+    if wide:
+        fx = np.floor(coords[0, :, 0]).reshape(64, 9); fy = np.floor(coords[0, :, 1]).reshape(64, 9)
+        area = (fx.max(1) - fx.min(1) + 8) * (fy.max(1) - fy.min(1) + 8)
+        assert ((area > 128) & (area <= 192)).sum() >= 10
     fmap2b = np.ascontiguousarray(fmap2[:, :, :, ::2, ::2])
     h = lambda a: a.astype(np.float16).astype(np.float32)
     ref0 = orc.corr(h(fmap1), h(fmap2), coords / 1, ii, jj, 3)[0]

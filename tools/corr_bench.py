@@ -1,0 +1,69 @@
+#!/usr/bin/env python
+"""correlation kernel alone at the bench size on a factor mix like the bench's steady state (tools/corr_window_stats.py:
+about half of the factors have nothing in the target plane, a tenth of the live ones a union window of more than 128
+pixels at the fine level): time per call, and bit equality against the library named by CORR_REF_LIB (an older build) if given"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+
+
+def case(E=40000, M=96, slots=36, H=120, W=160, seed=0, window=22, far=0.48):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    rng = np.random.default_rng(seed)
+    f1 = (torch.randn(slots * M, 3, 3, 128, generator=g, device="cuda") * 0.5).half()
+    l1 = (torch.randn(slots, H, 16, W, 8, generator=g, device="cuda") * 0.5).half()
+    l4 = (torch.randn(slots, H // 4, 16, W // 4, 8, generator=g, device="cuda") * 0.5).half()
+    jj = np.sort(rng.integers(100, 100 + window, E)).astype(np.int64)
+    kk = rng.integers(0, 3 * slots * M, E).astype(np.int64)
+    cx = rng.uniform(-4, W + 4, E); cy = rng.uniform(-4, H + 4, E)
+    sc = rng.choice([0.8, 1.0, 1.2, 1.45, 1.9], E, p=[0.05, 0.55, 0.28, 0.10, 0.02])      # pixel spacing of the projected patch
+    d = np.arange(-1, 2, dtype=np.float64)
+    x = cx[:, None, None] + sc[:, None, None] * d[None, None, :] + rng.normal(0, 0.05, (E, 3, 3))
+    y = cy[:, None, None] + sc[:, None, None] * d[None, :, None] + rng.normal(0, 0.05, (E, 3, 3))
+    coords = torch.from_numpy(np.stack([x, y], 1).astype(np.float32)).cuda()
+    coords[torch.from_numpy(rng.random(E) < far).cuda()] += 1000.0     # nothing in the plane
+    return f1, l1, l4, coords, torch.from_numpy(kk).cuda(), torch.from_numpy(jj).cuda(), M, slots
+
+
+def window_stats(coords, H, W, cdv):
+    """union-window sizes of the factors at one level (numpy restatement of the kernel's window geometry)"""
+    c = coords.detach().cpu().numpy().astype(np.float32) / np.float32(cdv)
+    fx = np.floor(c[:, 0].reshape(-1, 9)).astype(np.int64); fy = np.floor(c[:, 1].reshape(-1, 9)).astype(np.int64)
+    live = (fx - 3 < W) & (fx - 3 + 8 > 0) & (fy - 3 < H) & (fy - 3 + 8 > 0)
+    big = 1 << 30
+    minx = np.where(live, fx, big).min(1); maxx = np.where(live, fx, -big).max(1)
+    miny = np.where(live, fy, big).min(1); maxy = np.where(live, fy, -big).max(1)
+    n = live.sum(1)
+    bw = np.where(n > 0, maxx - minx + 8, 0); bh = np.where(n > 0, maxy - miny + 8, 0)
+    return n, bw, bh
+
+
+def timed(fn, n=30):
+    fn(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e3
+
+
+if __name__ == "__main__":
+    from rampvo_amd import ops
+    from rampvo_amd._lib import RAMP_NHWC8
+    f1, l1, l4, coords, kk, jj, M, slots = case()
+    E = coords.shape[0]
+    n0, bw0, bh0 = window_stats(coords, 120, 160, 1.0)
+    print("fine level: nothing in the plane %.3f | union window > 128 px %.3f of the live ones" % ((n0 == 0).mean(), (bw0 * bh0 > 128)[n0 > 0].mean()))
+    order = torch.argsort(jj, stable=True).int()
+    kw = dict(order=order, row_elems=896, mod_ii=slots * M, mod_jj=slots)
+    fn = lambda: ops.corr(f1, [l1, l4], coords, kk, jj, 3, (1.0, 4.0), RAMP_NHWC8, **kw)
+    out = fn()
+    print("corr: %.1f us per call" % timed(fn))
+    ref = os.environ.get("CORR_REF_OUT")
+    if ref and os.path.exists(ref):
+        base = torch.load(ref)
+        print("bit-identical to", ref, ":", torch.equal(torch.nan_to_num(out.float().cpu(), nan=-7.0), torch.nan_to_num(base.float(), nan=-7.0)))
+    elif ref:
+        torch.save(out.cpu(), ref)
+        print("saved", ref)

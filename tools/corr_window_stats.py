@@ -1,7 +1,8 @@
+"""union-window statistics of the correlation kernel's factors in the bench's steady state (T frames of the synthetic stream)"""
 import os, sys
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tools")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np, torch
-from corr_tile_check import window_stats
+from corr_bench import window_stats
 from rampvo_amd.config import make_cfg
 from rampvo_amd.Ramp_vo import Ramp_vo
 from rampvo_amd.synthetic import SyntheticStream, make_network
@@ -25,8 +26,3 @@ for name, H, W, cdv in (("fine", 120, 160, 1.0), ("coarse", 30, 40, 4.0)):
     print(name, "nlive==0: %.4f" % (n == 0).mean(), "| area<=112: %.4f  <=128: %.4f" % ((a[n > 0] <= 112).mean(), (a[n > 0] <= 128).mean()),
           "| bw<=12&bh<=12: %.4f" % ((bw <= 12) & (bh <= 12))[n > 0].mean(), "| hist bw", np.bincount(bw[n > 0])[8:16], "| partial live: %.4f" % ((n > 0) & (n < 9)).mean())
     ok = (n > 0) & (a <= 128)
-jj = dv.graph[dv.cur][dv.t.E_cap:dv.t.E_cap + E].cpu().numpy()
-n0, bw0, bh0 = window_stats(co, 120, 160, 1.0); n1, bw1, bh1 = window_stats(co, 30, 40, 4.0)
-elig = (n0 > 0) & (bw0 * bh0 <= 112) & (n1 > 0) & (bw1 * bh1 <= 128) & (bw1 <= 12) & (bh1 <= 12)
-elig8 = (n0 > 0) & (bw0 * bh0 <= 128) & (n1 > 0) & (bw1 * bh1 <= 128) & (bw1 <= 12) & (bh1 <= 12)
-print("eligible (7 groups): %.4f  (8 groups): %.4f" % (elig.mean(), elig8.mean()))
