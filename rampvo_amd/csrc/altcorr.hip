@@ -479,8 +479,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CorrMma
   constexpr int PGB = M::PGB;                     // pixel groups whose loads are in flight together
   __shared__ __attribute__((aligned(16))) float Cs[PP * CORR_TM];
   __shared__ float outs[NOUT];               // staging for the ragged (non-union) paths only
-  __shared__ int s_ox[PP], s_oy[PP], s_live[PP];
-  __shared__ float s_dx[PP], s_dy[PP];
 
   const int e = corr_edge_of_block(prm);
   if (e < 0) return;
@@ -493,12 +491,41 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CorrMma
   const long j2 = prm.mod_jj > 0 ? prm.jj[e] % prm.mod_jj : prm.jj[e];
   const int L = prm.nlevels;
 
+  // window geometry of the nine patch pixels at every level: lane p < 9 holds pixel p's in registers; what the wave
+  // needs as a whole comes over v_readlane / ds_bpermute (an LDS round trip + barrier per level before: a level with
+  // nothing in the plane -- every second one in the bench's steady state -- cost 2 us of LDS latency for a row of zeros)
+  int g_ox_[CORR_MAXLEV], g_oy_[CORR_MAXLEV];
+  float g_dx_[CORR_MAXLEV], g_dy_[CORR_MAXLEV];
+  unsigned g_lm_[CORR_MAXLEV];
+#pragma unroll
+  for (int lvl = 0; lvl < CORR_MAXLEV; lvl++) {
+    g_ox_[lvl] = 0; g_oy_[lvl] = 0; g_dx_[lvl] = 0.f; g_dy_[lvl] = 0.f;
+    bool live = false;
+    if (lvl < L && lane < PP) {
+      const int H2 = prm.H2[lvl], W2 = prm.W2[lvl];
+      const float cdv = prm.cdiv[lvl];
+      const float x = prm.coords[((size_t)e * 2 + 0) * PP + lane] / cdv;
+      const float y = prm.coords[((size_t)e * 2 + 1) * PP + lane] / cdv;
+      const float flx = floorf(x), fly = floorf(y);
+      const int ox = ramp_f2i(flx), oy = ramp_f2i(fly);
+      g_dx_[lvl] = x - flx;
+      g_dy_[lvl] = y - fly;
+      live = ((long)ox - R < W2) && ((long)ox - R + D > 0) && ((long)oy - R < H2) && ((long)oy - R + D > 0);
+      g_ox_[lvl] = live ? ox - R : 0;
+      g_oy_[lvl] = live ? oy - R : 0;
+    }
+    g_lm_[lvl] = (unsigned)__ballot(live);
+  }
+  // (a factor with nothing in any plane needs no patch features)
+  bool any_live = false;
+#pragma unroll
+  for (int lvl = 0; lvl < CORR_MAXLEV; lvl++) any_live |= g_lm_[lvl] != 0;
   frag_t afrag[STEPS];
   {
     const T *src = reinterpret_cast<const T *>(prm.fmap1) + (size_t)i1 * C * PP;
 #pragma unroll
     for (int s = 0; s < STEPS; s++) {
-      if (j < PP) afrag[s] = *reinterpret_cast<const frag_t *>(src + j * C + 4 * PER * s + PER * q);
+      if (j < PP && any_live) afrag[s] = *reinterpret_cast<const frag_t *>(src + j * C + 4 * PER * s + PER * q);
       else afrag[s] = M::zero();
     }
   }
@@ -511,48 +538,41 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CorrMma
     CTS(ct_l0);
     const int H2 = prm.H2[lvl], W2 = prm.W2[lvl];
     const T *f2 = reinterpret_cast<const T *>(prm.fmap2[lvl]) + (size_t)j2 * C * H2 * W2;
-    if (lane < PP) {
-      const float cdv = prm.cdiv[lvl];
-      const float x = prm.coords[((size_t)e * 2 + 0) * PP + lane] / cdv;
-      const float y = prm.coords[((size_t)e * 2 + 1) * PP + lane] / cdv;
-      const float flx = floorf(x), fly = floorf(y);
-      const int ox = ramp_f2i(flx), oy = ramp_f2i(fly);
-      s_dx[lane] = x - flx;
-      s_dy[lane] = y - fly;
-      const bool live = ((long)ox - R < W2) && ((long)ox - R + D > 0) &&
-                        ((long)oy - R < H2) && ((long)oy - R + D > 0);
-      s_live[lane] = live ? 1 : 0;
-      s_ox[lane] = live ? ox - R : 0;
-      s_oy[lane] = live ? oy - R : 0;
+    const int my_ox = g_ox_[lvl], my_oy = g_oy_[lvl];
+    const float my_dx = g_dx_[lvl], my_dy = g_dy_[lvl];
+    const unsigned lmask = g_lm_[lvl];
+    const float o_dx = __shfl(my_dx, op_p, 64), o_dy = __shfl(my_dy, op_p, 64);   // of the pixel whose outputs the lane owns
+    if (lmask == 0) {
+      // output o = lane + 63 k belongs to pixel o % 9 = lane % 9 for every k
+      float s = ((1 - o_dx) * (1 - o_dy)) * 0.0f;
+      s = s + (o_dx * (1 - o_dy)) * 0.0f;
+      s = s + ((1 - o_dx) * o_dy) * 0.0f;
+      s = s + (o_dx * o_dy) * 0.0f;
+#pragma unroll
+      for (int k = 0; k < KOUT; k++) res[lvl][k] = s;
+      continue;
     }
-    __syncthreads();
-    int minx = 1 << 30, miny = 1 << 30, maxx = -(1 << 30), maxy = -(1 << 30), nlive = 0;
+    const int o_ox = __shfl(my_ox, op_p, 64), o_oy = __shfl(my_oy, op_p, 64);
+    const bool o_live = (lmask >> op_p) & 1;
+    int minx = 1 << 30, miny = 1 << 30, maxx = -(1 << 30), maxy = -(1 << 30);
 #pragma unroll
     for (int p = 0; p < PP; p++) {
-      if (s_live[p]) {
-        nlive++;
-        minx = min(minx, s_ox[p]); maxx = max(maxx, s_ox[p]);
-        miny = min(miny, s_oy[p]); maxy = max(maxy, s_oy[p]);
+      const int px = __builtin_amdgcn_readlane(my_ox, p), py = __builtin_amdgcn_readlane(my_oy, p);
+      if ((lmask >> p) & 1) {
+        minx = min(minx, px); maxx = max(maxx, px);
+        miny = min(miny, py); maxy = max(maxy, py);
       }
     }
     const long bw = (long)maxx - minx + D, bh = (long)maxy - miny + D;
-    const bool uni = (nlive > 0) && (bw * bh <= CORR_TM);
-    const int ngroups = (nlive == 0) ? 0 : (uni ? 1 : PP);
-    if (nlive == 0) {
-      for (int o = lane; o < NOUT; o += 64) {
-        const int p = o % PP;
-        const float dx = s_dx[p], dy = s_dy[p];
-        float s = ((1 - dx) * (1 - dy)) * 0.0f;
-        s = s + (dx * (1 - dy)) * 0.0f;
-        s = s + ((1 - dx) * dy) * 0.0f;
-        s = s + (dx * dy) * 0.0f;
-        outs[o] = s;
-      }
-    }
+    const bool uni = bw * bh <= CORR_TM;
+    const int ngroups = uni ? 1 : PP;
     for (int g = 0; g < ngroups; g++) {
-      if (!uni && !s_live[g]) {
+      const int g_ox = __builtin_amdgcn_readlane(my_ox, g), g_oy = __builtin_amdgcn_readlane(my_oy, g);
+      const float g_dx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_dx), g));
+      const float g_dy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_dy), g));
+      if (!uni && !((lmask >> g) & 1)) {
         for (int ab = lane; ab < d * d; ab += 64) {
-          const float dx = s_dx[g], dy = s_dy[g];
+          const float dx = g_dx, dy = g_dy;
           float s = ((1 - dx) * (1 - dy)) * 0.0f;
           s = s + (dx * (1 - dy)) * 0.0f;
           s = s + ((1 - dx) * dy) * 0.0f;
@@ -561,7 +581,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CorrMma
         }
         continue;
       }
-      const int gx0 = uni ? minx : s_ox[g], gy0 = uni ? miny : s_oy[g];
+      const int gx0 = uni ? minx : g_ox, gy0 = uni ? miny : g_oy;
       const int gw = uni ? (int)bw : D, gh = uni ? (int)bh : D;
       const int Tn = gw * gh;                      // <= CORR_TM
       const int npg = (Tn + 15) / 16;
@@ -621,15 +641,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CorrMma
         // o = (7 b + a) 9 + p = lane + 63 b and need two 8-wide rows of Cs
         if (lane < 63) {
           float r0[D], r1[D];
-          if (s_live[op_p]) {
-            const float *row = &Cs[op_p * CORR_TM + (s_oy[op_p] - gy0 + op_a) * gw + (s_ox[op_p] - gx0)];
+          if (o_live) {
+            const float *row = &Cs[op_p * CORR_TM + (o_oy - gy0 + op_a) * gw + (o_ox - gx0)];
 #pragma unroll
             for (int b = 0; b < D; b++) { r0[b] = row[b]; r1[b] = row[gw + b]; }
           } else {
 #pragma unroll
             for (int b = 0; b < D; b++) { r0[b] = 0.f; r1[b] = 0.f; }
           }
-          const float dx = s_dx[op_p], dy = s_dy[op_p];
+          const float dx = o_dx, dy = o_dy;
 #pragma unroll
           for (int b = 0; b < d; b++) {
             float s = ((1 - dx) * (1 - dy)) * r0[b];
@@ -642,10 +662,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CorrMma
       } else {
         for (int ab = lane; ab < d * d; ab += 64) {
           const int b = ab / d, a = ab - b * d;
-          const int wx = s_ox[g] - gx0 + b, wy = s_oy[g] - gy0 + a;
+          const int wx = g_ox - gx0 + b, wy = g_oy - gy0 + a;
           const float *row = &Cs[g * CORR_TM + wy * gw + wx];
           const float c00 = row[0], c01 = row[1], c10 = row[gw], c11 = row[gw + 1];
-          const float dx = s_dx[g], dy = s_dy[g];
+          const float dx = g_dx, dy = g_dy;
           float s = ((1 - dx) * (1 - dy)) * c00;
           s = s + (dx * (1 - dy)) * c01;
           s = s + ((1 - dx) * dy) * c10;

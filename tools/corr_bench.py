@@ -51,7 +51,7 @@ def timed(fn, n=30):
 if __name__ == "__main__":
     from rampvo_amd import ops
     from rampvo_amd._lib import RAMP_NHWC8
-    f1, l1, l4, coords, kk, jj, M, slots = case()
+    f1, l1, l4, coords, kk, jj, M, slots = case(far=float(os.environ.get("CORR_FAR", 0.48)))
     E = coords.shape[0]
     n0, bw0, bh0 = window_stats(coords, 120, 160, 1.0)
     print("fine level: nothing in the plane %.3f | union window > 128 px %.3f of the live ones" % ((n0 == 0).mean(), (bw0 * bh0 > 128)[n0 > 0].mean()))
