@@ -512,6 +512,26 @@ def graph_size(slam):
     return len(slam._ii), slam.n
 
 
+def live_factor_fractions(slam):
+    """share of the current graph's factors with a correlation window inside the target plane, per level (the
+    kernel's own test, ramp/altcorr/correlation_kernel.cu:104-110's bounds on the 8 x 8 window), from the
+    device-resident step's reprojection"""
+    dv = getattr(slam, "_dev", None)
+    if dv is None or not dv.active:
+        return None
+    from rampvo_amd import track_dev
+    torch.cuda.synchronize()
+    E = int(dv.dyn.cpu().numpy()[track_dev.DYN_E])
+    co = dv.coords[:E].reshape(E, 2, 9)
+    h, w = slam.ht // slam.RES, slam.wd // slam.RES
+    out = []
+    for div, (H, W) in ((1.0, (h, w)), (4.0, (h // 4, w // 4))):
+        fx, fy = torch.floor(co[:, 0] / div), torch.floor(co[:, 1] / div)
+        live = (fx - 3 < W) & (fx - 3 + 8 > 0) & (fy - 3 < H) & (fy - 3 + 8 > 0)
+        out.append(round(float(live.any(1).float().mean()), 3))
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -637,6 +657,7 @@ def main():
         g = gather_metrics([args.steps / dt, float(E_r), float(n_r), float(slam.poses_[:n_r].double().sum())], dev)
         per_rank = [[round(float(v), 4) for v in row] for row in g.tolist()]
     E1 = graph_size(slam)[0]
+    live = live_factor_fractions(slam)
 
     # the strictly sequential rate (no frame pipelining): what evaluate.run's loop gets
     np_kfps = None
@@ -685,6 +706,11 @@ def main():
         rl = ctimer.summary(2 if args.mixed else 4, slam)
         assert rl is not None or args.no_kernel_timing, "no correlation launch was timed: the roofline hook is stale"
         if rl is not None:
+            if live is not None:
+                # factors with at least one patch pixel's window inside the target plane, per pyramid level: the others
+                # (the random-init network lets half of the projections leave the image) cost a row of zeros, and
+                # model_bytes / mfma_tflops count them as if they gathered
+                rl["live_factor_fraction_fine_coarse"] = live
             out["roofline"] = rl
         for key, val in (("roofline_update", utimer.summary(bool(args.mixed))),
                          ("roofline_encoder", etimer.summary(bool(args.mixed))),
