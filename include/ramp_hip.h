@@ -617,6 +617,11 @@ typedef struct ramp_track {
   void *probe[5];
 } ramp_track;
 
+/* cache warm-up for the next step's correlation kernel: reads the planes of the window's frames and the patch features
+ * once (no effect on any value; `sink` [1] is never written in practice).  Meant for the front-end stream, in the slack
+ * behind the front end.                                                                                            */
+int ramp_track_warm(const ramp_track *t, int32_t *sink, void *stream);
+
 size_t ramp_track_sizeof(void);      /* sizeof(ramp_track): lets a binding check its mirror of the struct */
 size_t ramp_track_plan_workspace_bytes(int E_cap, int kkey_cap, int pkey_cap);
 size_t ramp_track_ba_workspace_bytes(int E_cap, int n_rows, int M, int opt_window, int kk_cap, int ij_cap);

@@ -42,6 +42,9 @@ from .net import GraphPlan, VONet
 from .utils import Timer, preprocess_input
 
 
+_WARM = os.environ.get("RAMP_WARM", "1") != "0"     # A/B switch: the cache warm-up behind the front end
+
+
 class Ramp_vo:
     def __init__(self, cfg, network, train_cfg, ht=480, wd=640, device="cuda"):
         self.cfg = cfg
@@ -679,6 +682,11 @@ class Ramp_vo:
                                             pre_replay=(lambda: fe.wait_event(self._ev_gate)) if ahead else None)
             self._ev_fe_done.record(fe)
             cur.wait_event(self._ev_fe_done)
+            if _WARM:
+                # (behind the event: the frame does not wait for it) the window's correlation planes back into the
+                # memory-side cache while the previous frame's bundle adjustment is still running
+                with torch.cuda.stream(fe):
+                    dv.warm()
         else:
             out = self.network.patchify(input_=input_, patches_per_image=self.cfg.PATCHES_PER_FRAME,
                                         event_bias=self.event_bias, reinit_hidden=False)

@@ -110,6 +110,7 @@ SIGNATURES = {
     "ramp_track_ba_workspace_bytes": (c_sz, [c_i] * 6),
     "ramp_track_plan": (c_i, [c_p, c_i, c_p]),
     "ramp_track_step": (c_i, [c_p, c_i, c_i64, c_i, c_i, c_p, c_p, c_p]),
+    "ramp_track_warm": (c_i, [c_p, c_p, c_p]),
 }
 
 _lib = None

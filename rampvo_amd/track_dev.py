@@ -100,6 +100,7 @@ class DeviceTrack:
         self.ba_ws = e(lib.ramp_track_ba_workspace_bytes(E_cap, slam.N, M, cfg.OPTIMIZATION_WINDOW, kk_cap, ij_cap),
                        torch.uint8)
         self.mm = z(2, f32)
+        self.sink = z(1, i32)
         self.dlog = z((self.log_cap, LOG_WORDS), f32)
         self.edit_ws = z(3 * ((E_cap + 1023) // 1024) + 8, i32)
         self.ixm = (torch.arange(slam.N * M, device=dev) // M).contiguous()
@@ -233,6 +234,10 @@ class DeviceTrack:
         if flags & KEYFRAME:
             self.cur ^= 1
         self._frames += 1
+
+    def warm(self):
+        """(on the current stream) read the correlation planes of the window once: csrc/track.hip::trk_warm_kernel"""
+        _lib.check(_lib.lib().ramp_track_warm(ctypes.byref(self.t), _lib.ptr(self.sink), _lib.stream()), "ramp_track_warm")
 
     def lazy_state(self):
         """the host's (possibly one or two frames old) copy of dyn -- never waited for"""

@@ -26,3 +26,31 @@ for name, H, W, cdv in (("fine", 120, 160, 1.0), ("coarse", 30, 40, 4.0)):
     print(name, "nlive==0: %.4f" % (n == 0).mean(), "| area<=112: %.4f  <=128: %.4f" % ((a[n > 0] <= 112).mean(), (a[n > 0] <= 128).mean()),
           "| bw<=12&bh<=12: %.4f" % ((bw <= 12) & (bh <= 12))[n > 0].mean(), "| hist bw", np.bincount(bw[n > 0])[8:16], "| partial live: %.4f" % ((n > 0) & (n < 9)).mean())
     ok = (n > 0) & (a <= 128)
+
+# ---- the correlation kernel alone on exactly these factors (the tracker's own buffers and schedule)
+from rampvo_amd import ops
+from rampvo_amd._lib import RAMP_NHWC8
+from corr_bench import timed
+Ec = dv.t.E_cap
+g = dv.graph[dv.cur]
+jj, kk = g[1, :E].contiguous(), g[2, :E].contiguous()
+order = dv.ij["order"][:E].contiguous()
+fn = lambda o: slam._corr_launch(co.contiguous()[None], kk, jj, o)
+iota = torch.arange(E, dtype=torch.int32, device="cuda")
+print("corr on the tracker's factors: %.1f us per call (plan schedule) | %.1f us (graph order)" % (timed(lambda: fn(order)), timed(lambda: fn(iota))))
+n0, bw0, bh0 = window_stats(co, 120, 160, 1.0)
+sub = torch.nonzero(torch.from_numpy(n0 > 0).cuda()).flatten()
+co_l, kk_l, jj_l = co[sub].contiguous(), kk[sub].contiguous(), jj[sub].contiguous()
+o_l = torch.argsort(jj_l * 100000 + kk_l // slam.M, stable=True).int()
+print("  only the %d factors live at the fine level: %.1f us" % (len(sub), timed(lambda: slam._corr_launch(co_l[None], kk_l, jj_l, o_l))))
+
+# the same launch with the caches in the state a tracked frame leaves them in: ~1.5 GB streamed through L2 / MALL in between
+big = torch.empty(768 * 1024 * 1024 // 4, device="cuda")
+evs = []
+for _ in range(20):
+    big.add_(1.0)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); fn(order); b.record()
+    evs.append((a, b))
+torch.cuda.synchronize()
+print("  ... after 1.5 GB of other traffic: %.1f us per call" % (1e3 * np.median([a.elapsed_time(b) for a, b in evs])))
