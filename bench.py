@@ -235,7 +235,8 @@ class DeviceProbe:
 
 
 class UpdateTimer:
-    """HIP events around the update operator (FusedUpdate.hidden: correlation MLP, neighbour MLPs, SoftAgg x2, gru)"""
+    """HIP events around the update operator (FusedUpdate.hidden: correlation MLP, neighbour MLPs, SoftAgg x2, gru -- the gru
+    launch carries the two heads in its epilogue)"""
 
     def __init__(self):
         self.pairs, self.edges, self.enabled = [], [], False
@@ -244,12 +245,12 @@ class UpdateTimer:
         from rampvo_amd.update_fused import FusedUpdate
         inner, timer = FusedUpdate.hidden, self
 
-        def timed(fu, net, inp_table, inp_idx, inp_mod, corr, plan, net_map=None):
+        def timed(fu, net, inp_table, inp_idx, inp_mod, corr, plan, **kw):
             if not timer.enabled:
-                return inner(fu, net, inp_table, inp_idx, inp_mod, corr, plan, net_map=net_map)
+                return inner(fu, net, inp_table, inp_idx, inp_mod, corr, plan, **kw)
             s, e = _event_pair()
             s.record()
-            out = inner(fu, net, inp_table, inp_idx, inp_mod, corr, plan, net_map=net_map)
+            out = inner(fu, net, inp_table, inp_idx, inp_mod, corr, plan, **kw)
             e.record()
             timer.pairs.append((s, e))
             timer.edges.append(int(corr.shape[0]))

@@ -467,6 +467,15 @@ int ramp_graph_edit_host(const int64_t *ii, const int64_t *jj, const int64_t *kk
 int ramp_upd_gru(const float *x32, const void *add_t, const int32_t *add_idx, const float *pre_w, const float *pre_b,
                  float pre_eps, const void *const *wp_host, const float *const *bias_host, const float *ln_w,
                  const float *ln_b, float eps, float *out32, void *relu_t, int E, void *stream);
+/* ramp_upd_gru with the two heads and target / weight formed from the result tile in the same launch
+ * (ramp/net.py:87-90 `d`, `w`; ramp/Ramp_vo.py:291-297: target = centre + delta, weight = sigmoid, zero outside the
+ * image): heads_w [4][384] fp16 (d.weight rows 0..1, w.weight rows 0..1), heads_b [4], coords [E][2][P][P],
+ * target / weight [E][2] fp32.  The heads' fp16 input relu(out32) is not written.  Same arithmetic as
+ * ramp_upd_heads_linear up to the order of the 384-term sums.                                              */
+int ramp_upd_gru_heads(const float *x32, const void *add_t, const int32_t *add_idx, const float *pre_w, const float *pre_b,
+                       float pre_eps, const void *const *wp_host, const float *const *bias_host, const float *ln_w,
+                       const float *ln_b, float eps, float *out32, const void *heads_w, const float *heads_b,
+                       const float *coords, float *target, float *weight, int E, int P, float wd, float ht, void *stream);
 size_t ramp_upd_mlp_lds_bytes(void);
 
 /* net_out[e] = net_in[e] + Lb(relu(La(idx[e] >= 0 ? net_in[idx[e]] : 0)))  -- the temporal-neighbour MLPs
@@ -601,7 +610,7 @@ typedef struct ramp_track {
   float *coords;                      /* [E_cap][2][P][P] */
   void *corr;                         /* [E_cap][896] fp16 */
   float *net[3];                      /* [E_cap][384] fp32: [0] the hidden state (in: previous, out: new), [1], [2] scratch */
-  void *fg, *ykk, *hkk, *yij, *hij, *relu_t;
+  void *fg, *ykk, *hkk, *yij, *hij, *relu_t;      /* (relu_t: unused since the heads moved into the gru launch) */
   float *target, *weight;             /* [E_cap][2] */
   /* bundle adjustment */
   void *ba_ws;

@@ -592,9 +592,10 @@ class Ramp_vo:
             if self._net_map is not None:
                 net_map = self._net_map_dev if self._net_map_dev is not None else self._upload(self._net_map)
             out32, relu_t = fu.hidden(self._net_buf[0], self.imap_.view(-1, self.DIM), self.kk, self.M * self.mem,
-                                      corr[0], plan, net_map=net_map)
+                                      corr[0], plan, net_map=net_map,
+                                      heads_at=(coords[0].contiguous(), self.wd // 4, self.ht // 4))
             self.net = out32[None]
-            tw = fu.heads_target_weight(relu_t, coords[0], self.wd // 4, self.ht // 4)
+            tw = fu.last_tw if relu_t is None else fu.heads_target_weight(relu_t, coords[0], self.wd // 4, self.ht // 4)
             if tw is not None:
                 target, weight = tw
             else:

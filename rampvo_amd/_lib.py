@@ -100,6 +100,8 @@ SIGNATURES = {
     "ramp_upd_fg": (c_i, [c_p] * 9 + [c_i, c_p]),
     "ramp_upd_gru": (c_i, [c_p, c_p, c_p, c_p, c_p, c_f, ctypes.POINTER(c_p), ctypes.POINTER(c_p), c_p, c_p, c_f, c_p,
                            c_p, c_i, c_p]),
+    "ramp_upd_gru_heads": (c_i, [c_p, c_p, c_p, c_p, c_p, c_f, ctypes.POINTER(c_p), ctypes.POINTER(c_p), c_p, c_p, c_f, c_p,
+                                 c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_p]),
     "ramp_upd_mlp_lds_bytes": (c_sz, []),
     "ramp_upd_nbr": (c_i, [c_p] * 8 + [c_i, c_p]),
     "ramp_upd_nbr2": (c_i, [c_p] * 13 + [c_i, c_p]),

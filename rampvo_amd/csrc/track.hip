@@ -356,7 +356,7 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
   if (flags & RAMP_TRACK_UPDATE) {
     const ramp_track_weights &w = t->w;
     if (!t->coords || !t->corr || !t->net[0] || !t->net[1] || !t->net[2] || !t->fg || !t->ykk || !t->hkk || !t->yij ||
-        !t->hij || !t->relu_t || !t->target || !t->weight || !t->ba_ws)
+        !t->hij || !t->target || !t->weight || !t->ba_ws)
       return RAMP_EINVAL;
     // Ramp_vo.update(), ramp/Ramp_vo.py:276-310
     TRK_DO(ramp_i_transform_dyn(t->poses, t->patches, t->intrinsics, ii, jj, kk, t->coords, Eb, dyn, st));
@@ -399,11 +399,11 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
     TRK_DO(ramp_upd_segment_softmax(t->fg, t->ij_order, t->ij_seg, t->ij_ngroups, t->yij, t->ij_cap, RAMP_F16, stream));
     TRK_DO(ramp_upd_linear(t->yij, w.ij_wh, w.ij_bh, t->hij, t->ij_cap, t->ij_ngroups, stream));
     TRK_GATE(0);
+    // (the heads and target / weight are formed in the gru launch's epilogue: no relu(net) round trip, one launch less)
     TRK_DO(ramp_i_upd_gru(net, t->hij, t->ij_gid, w.ln1_w, w.ln1_b, w.ln1_eps, w.gru_w, w.gru_b, w.ln2_w, w.ln2_b,
-                          w.ln2_eps, t->net[0], t->relu_t, Eb, dyn, st));
+                          w.ln2_eps, t->net[0], nullptr, Eb, dyn, w.heads_w, w.heads_b, t->coords, t->target, t->weight, t->P,
+                          (float)t->feat_w, (float)t->feat_h, st));
     TRK_PROBE(2);
-    TRK_DO(ramp_i_upd_heads_linear(t->relu_t, w.heads_w, w.heads_b, t->coords, t->target, t->weight, Eb, t->P,
-                                   (float)t->feat_w, (float)t->feat_h, dyn, st));
     TRK_PROBE(3);
     TRK_DO(ramp_i_ba_dyn(t->poses, t->patches, t->intrinsics, t->target, t->weight, t->lmbda, ii, jj, kk, Eb, t->P,
                          t->n_rows, t->n_rows * t->M, t->opt_window, 2, t->kk_order, t->kk_seg, t->kk_ngroups, t->kk_ukeys,

@@ -198,6 +198,14 @@ struct GruParams {
   float pre_eps;
   int E;
   const int32_t *dyn;          // optional device-side sizes (RAMP_DYN_*): E is then the launch bound
+  // optional epilogue: the two heads and target / weight (ramp/net.py:87-90, ramp/Ramp_vo.py:291-297) from the
+  // result tile while it is in registers -- relu_t is then not written (may be NULL)
+  const _Float16 *heads_w;     // [4][384] fp16: d.weight rows 0..1, w.weight rows 0..1
+  const float *heads_b;        // [4]
+  const float *coords;         // [E][2][PP]
+  float *target, *weight;      // [E][2]
+  int PP, ctr;
+  float wd, ht;
 };
 
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -384,8 +392,66 @@ __global__ void __launch_bounds__(64 * MWAVES) upd_gru_kernel(const GruParams p)
         for (int nt = 0; nt < MNTW; nt++) {
           const f4 v = res[mt][nt];
           *reinterpret_cast<f4 *>(p.out32 + roff[mt] + cq + nt * 16) = v;
-          *reinterpret_cast<h4 *>(p.relu_t + roff[mt] + cq + nt * 16) =
-              (h4){(_Float16)fmaxf(v[0], 0.f), (_Float16)fmaxf(v[1], 0.f), (_Float16)fmaxf(v[2], 0.f), (_Float16)fmaxf(v[3], 0.f)};
+          if (p.relu_t)
+            *reinterpret_cast<h4 *>(p.relu_t + roff[mt] + cq + nt * 16) =
+                (h4){(_Float16)fmaxf(v[0], 0.f), (_Float16)fmaxf(v[1], 0.f), (_Float16)fmaxf(v[2], 0.f), (_Float16)fmaxf(v[3], 0.f)};
+        }
+      }
+      if (p.heads_w) {                            // (uniform)
+        // d / w heads: 4 dot products of relu(result) (a half tensor) with the head rows, per row of the tile.  A lane
+        // sums its 12 columns, the four quarter-lanes of a row meet over two shuffles, the eight waves over an LDS table
+        // in the x tile (dead since the barrier that published h); fixed order throughout.
+        float part[4][4];
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+          for (int c = 0; c < 4; c++) part[mt][c] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+          for (int nt = 0; nt < MNTW; nt++) {
+            const h4 wv = *reinterpret_cast<const h4 *>(p.heads_w + c * MD + cq + nt * 16);
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+              for (int i = 0; i < 4; i++) part[mt][c] += h_round(fmaxf(res[mt][nt][i], 0.f)) * (float)wv[i];
+          }
+        float *HT = reinterpret_cast<float *>(Xs);              // [64 rows][8 waves][4]
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+          for (int c = 0; c < 4; c++) {
+            float v = part[mt][c];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            part[mt][c] = v;
+          }
+        if (q == 0) {
+#pragma unroll
+          for (int mt = 0; mt < 4; mt++)
+            *reinterpret_cast<f4 *>(HT + ((mt * 16 + j) * MWAVES + wave) * 4) = (f4){part[mt][0], part[mt][1], part[mt][2], part[mt][3]};
+        }
+        __syncthreads();
+        const int e = row0 + tid;
+        if (tid < MBM && e < pE) {
+          float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int w = 0; w < MWAVES; w++) {
+            const f4 v = *reinterpret_cast<const f4 *>(HT + (tid * MWAVES + w) * 4);
+#pragma unroll
+            for (int c = 0; c < 4; c++) o[c] += v[c];
+          }
+#pragma unroll
+          for (int c = 0; c < 4; c++) o[c] = h_round(o[c] + p.heads_b[c]);         // the Linear output is a half tensor
+          const float wx = h_round(1.0f / (1.0f + expf(-o[2])));
+          const float wy = h_round(1.0f / (1.0f + expf(-o[3])));
+          const float tx = p.coords[((size_t)e * 2 + 0) * p.PP + p.ctr] + o[0];
+          const float ty = p.coords[((size_t)e * 2 + 1) * p.PP + p.ctr] + o[1];
+          const bool outside = (tx < 0) || (tx > p.wd) || (ty < 0) || (ty > p.ht);
+          p.target[2 * (size_t)e + 0] = tx;
+          p.target[2 * (size_t)e + 1] = ty;
+          p.weight[2 * (size_t)e + 0] = outside ? 0.0f : wx;
+          p.weight[2 * (size_t)e + 1] = outside ? 0.0f : wy;
         }
       }
     }
@@ -1282,10 +1348,13 @@ size_t ramp_upd_mlp_lds_bytes(void) { return (size_t)2 * MBM * MXS * 2; }
 
 int ramp_i_upd_gru(const float *x32, const void *add_t, const int32_t *add_idx, const float *pre_w, const float *pre_b,
                  float pre_eps, const void *const *wp_host, const float *const *bias_host, const float *ln_w,
-                 const float *ln_b, float eps, float *out32, void *relu_t, int E, const int32_t *dyn, void *stream) {
+                 const float *ln_b, float eps, float *out32, void *relu_t, int E, const int32_t *dyn,
+                 const void *heads_w, const float *heads_b, const float *coords, float *target, float *weight, int P,
+                 float wd, float ht, void *stream) {
   if (E < 0) return RAMP_EINVAL;
   if (E == 0) return RAMP_OK;
-  if (!x32 || !wp_host || !bias_host || !ln_w || !ln_b || !out32 || !relu_t) return RAMP_EINVAL;
+  if (!x32 || !wp_host || !bias_host || !ln_w || !ln_b || !out32 || (!relu_t && !heads_w)) return RAMP_EINVAL;
+  if (heads_w && (!heads_b || !coords || !target || !weight || P < 1)) return RAMP_EINVAL;
   if (add_t && (!add_idx || !pre_w || !pre_b)) return RAMP_EINVAL;
   GruParams p;
   p.x32 = x32;
@@ -1296,6 +1365,8 @@ int ramp_i_upd_gru(const float *x32, const void *add_t, const int32_t *add_idx, 
     p.bias[i] = bias_host[i];
   }
   p.ln_w = ln_w; p.ln_b = ln_b; p.eps = eps; p.out32 = out32; p.relu_t = (_Float16 *)relu_t; p.E = E; p.dyn = dyn;
+  p.heads_w = (const _Float16 *)heads_w; p.heads_b = heads_b; p.coords = coords; p.target = target; p.weight = weight;
+  p.PP = P * P; p.ctr = (P / 2) * P + P / 2; p.wd = wd; p.ht = ht;
   const size_t lds = (size_t)3 * MBM * MXS * 2 + 2 * MBM * MWAVES * sizeof(float);   // x, h, sigmoid(gate) tiles + the LayerNorm tables
   static bool attr_set = false;
   if (!attr_set) {
@@ -1395,7 +1466,17 @@ int ramp_i_upd_fg(const float *x32, const void *add_t, const int32_t *add_idx, f
 int ramp_upd_gru(const float *x32, const void *add_t, const int32_t *add_idx, const float *pre_w, const float *pre_b,
                  float pre_eps, const void *const *wp_host, const float *const *bias_host, const float *ln_w,
                  const float *ln_b, float eps, float *out32, void *relu_t, int E, void *stream) {
-  return ramp_i_upd_gru(x32, add_t, add_idx, pre_w, pre_b, pre_eps, wp_host, bias_host, ln_w, ln_b, eps, out32, relu_t, E, nullptr, stream);
+  return ramp_i_upd_gru(x32, add_t, add_idx, pre_w, pre_b, pre_eps, wp_host, bias_host, ln_w, ln_b, eps, out32, relu_t, E, nullptr,
+                        nullptr, nullptr, nullptr, nullptr, nullptr, 3, 0.f, 0.f, stream);
+}
+
+int ramp_upd_gru_heads(const float *x32, const void *add_t, const int32_t *add_idx, const float *pre_w, const float *pre_b,
+                       float pre_eps, const void *const *wp_host, const float *const *bias_host, const float *ln_w,
+                       const float *ln_b, float eps, float *out32, const void *heads_w, const float *heads_b,
+                       const float *coords, float *target, float *weight, int E, int P, float wd, float ht, void *stream) {
+  if (!heads_w) return RAMP_EINVAL;
+  return ramp_i_upd_gru(x32, add_t, add_idx, pre_w, pre_b, pre_eps, wp_host, bias_host, ln_w, ln_b, eps, out32, nullptr, E, nullptr,
+                        heads_w, heads_b, coords, target, weight, P, wd, ht, stream);
 }
 
 int ramp_upd_nbr(const float *net_in, const int64_t *idx, const void *wa, const float *ba, const void *wb,

@@ -165,10 +165,12 @@ class FusedUpdate:
         return out
 
     # ------------------------------------------------------------------ forward
-    def hidden(self, net, inp_table, inp_idx, inp_mod, corr, plan, net_map=None):
+    def hidden(self, net, inp_table, inp_idx, inp_mod, corr, plan, net_map=None, heads_at=None):
         """net [*,384] fp32 or None (zeros), row net_map[e] of it per edge when net_map is given (-1: zero
         row); inp = inp_table[inp_idx % inp_mod] (or inp_table rows when inp_idx is None); corr [E,882] in
-        self.dtype.  Returns (net_out fp32 [E,384], relu copy T)."""
+        self.dtype.  Returns (net_out fp32 [E,384], relu copy T).  heads_at = (coords [E,2,P,P], wd, ht): the fused gru
+        launch also forms the heads and target / weight (left in self.last_tw; the relu copy is then None)."""
+        self.last_tw, self._heads_at = None, heads_at
         w = self.weights()
         E = corr.shape[0]
         if "tail_pack" in w and self.use_mlp and corr.shape[1] == CORR_ROW and self.use_corr_mlp:
@@ -254,6 +256,19 @@ class FusedUpdate:
             ln1 = w["ln1"]
             if self.before_gru is not None and self.hook_at == "gru":
                 self.before_gru()
+            heads_at = getattr(self, "_heads_at", None)
+            if heads_at is not None and "heads_pack" in w and self.dtype == torch.float16:
+                coords, wd, ht = heads_at
+                hwt, hb = w["heads_pack"]
+                target = torch.empty(1, E, 2, dtype=torch.float32, device=net32.device)
+                weight = torch.empty(1, E, 2, dtype=torch.float32, device=net32.device)
+                check(lib().ramp_upd_gru_heads(ptr(net32), ptr(hy), ptr(plan.g_ij.gid), ptr(ln1[0]), ptr(ln1[1]),
+                                               float(ln1[2]), wptr, bptr, ptr(w["ln2"][0]), ptr(w["ln2"][1]),
+                                               float(w["ln2"][2]), ptr(out32), ptr(hwt), ptr(hb), ptr(coords), ptr(target),
+                                               ptr(weight), E, coords.shape[-1], float(wd), float(ht), stream()),
+                      "ramp_upd_gru_heads")
+                self.last_tw = (target, weight)
+                return out32, None
             check(lib().ramp_upd_gru(ptr(net32), ptr(hy), ptr(plan.g_ij.gid), ptr(ln1[0]), ptr(ln1[1]), float(ln1[2]),
                                      wptr, bptr, ptr(w["ln2"][0]), ptr(w["ln2"][1]), float(w["ln2"][2]),
                                      ptr(out32), ptr(relu_t), E, stream()), "ramp_upd_gru")

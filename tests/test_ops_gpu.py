@@ -623,6 +623,22 @@ def test_fused_update_chains_against_fp32_torch(E):
     exp = ref.gru(x32 + hy.float()[gid.long()])
     cmp("gru", out32, exp)
     cmp("gru_relu", relu_t, torch.relu(exp))
+    # the same launch with the heads in its epilogue (ramp_upd_gru_heads): out32 bit-equal, target / weight against fp32
+    # torch on the launch's own relu copy (the heads' half input)
+    out32_h = torch.empty(E, 384, device="cuda")
+    hcoords = (torch.rand(E, 2, 3, 3, generator=g) * 60).cuda()
+    htarget, hweight = torch.empty(1, E, 2, device="cuda"), torch.empty(1, E, 2, device="cuda")
+    hwt, hb = w["heads_pack"]
+    check(lib().ramp_upd_gru_heads(ptr(x32), ptr(hy), ptr(gid), ptr(ln1[0]), ptr(ln1[1]), float(ln1[2]), wptr, bptr,
+                                   ptr(ln2[0]), ptr(ln2[1]), float(ln2[2]), ptr(out32_h), ptr(hwt), ptr(hb), ptr(hcoords),
+                                   ptr(htarget), ptr(hweight), E, 3, 40.0, 30.0, stream()), "gru_heads")
+    assert torch.equal(out32_h, out32)
+    t_exp = hcoords[:, :, 1, 1] + ref.d[1](relu_t.float())
+    w_exp = torch.sigmoid(ref.w[1](relu_t.float()))
+    inside = (t_exp[:, 0] >= 0) & (t_exp[:, 1] >= 0) & (t_exp[:, 0] <= 40.0) & (t_exp[:, 1] <= 30.0)
+    cmp("gru_heads_target", htarget[0], t_exp, tol=2e-3)
+    far = ((t_exp - torch.tensor([40.0, 30.0], device="cuda")).abs().min(-1).values > 0.2) & (t_exp.abs().min(-1).values > 0.2)
+    assert float(((hweight[0] - w_exp * inside[:, None].float()).abs().max(-1).values * far.float()).max()) <= 2e-3
     # without the prologue: x32 is already gru[0]'s output
     xin = ref.gru[0](x32)
     check(lib().ramp_upd_gru(ptr(xin), None, None, None, None, 0.0, wptr, bptr, ptr(ln2[0]), ptr(ln2[1]),
