@@ -184,11 +184,10 @@ __global__ void __launch_bounds__(LIE_THREADS)
 
 // reference: ramp/projective_ops.py:103-105 + ramp/Ramp_vo.py:308-310
 template <int P>
-__global__ void __launch_bounds__(LIE_THREADS)
-    point_cloud_kernel(const float *__restrict__ poses, const float *__restrict__ patches,
-                       const float *__restrict__ intr, const int64_t *__restrict__ ix,
-                       float *__restrict__ out, int m, const int32_t *__restrict__ dyn, int M) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void point_cloud_block(int bid, const float *__restrict__ poses, const float *__restrict__ patches,
+                                                  const float *__restrict__ intr, const int64_t *__restrict__ ix,
+                                                  float *__restrict__ out, int m, const int32_t *__restrict__ dyn, int M) {
+  const int n = bid * LIE_THREADS + threadIdx.x;
   if (dyn) m = min(m, dyn[RAMP_DYN_N] * M);     // device-side size: the argument is the launch bound
   if (n >= m) return;
   const long f = ix[n];
@@ -208,6 +207,13 @@ __global__ void __launch_bounds__(LIE_THREADS)
   out[3 * (size_t)n + 0] = X1[0] / X1[3];
   out[3 * (size_t)n + 1] = X1[1] / X1[3];
   out[3 * (size_t)n + 2] = X1[2] / X1[3];
+}
+template <int P>
+__global__ void __launch_bounds__(LIE_THREADS)
+    point_cloud_kernel(const float *__restrict__ poses, const float *__restrict__ patches,
+                       const float *__restrict__ intr, const int64_t *__restrict__ ix,
+                       float *__restrict__ out, int m, const int32_t *__restrict__ dyn, int M) {
+  point_cloud_block<P>(blockIdx.x, poses, patches, intr, ix, out, m, dyn, M);
 }
 
 // Ramp_vo.motionmag both ways in one launch (ramp/Ramp_vo.py:227-243, pops.flow_mag :108-118):
@@ -230,14 +236,13 @@ __device__ __forceinline__ void mm_project(const float *t, const float *q, const
 }
 
 template <int P>
-__global__ void __launch_bounds__(256)
-    motionmag_kernel(const float *__restrict__ poses, const float *__restrict__ patches,
-                     const float *__restrict__ intr, const int64_t *__restrict__ ii,
-                     const int64_t *__restrict__ jj, const int64_t *__restrict__ kk,
-                     const int32_t *__restrict__ order, const int32_t *__restrict__ seg,
-                     const int64_t *__restrict__ ukeys, const int32_t *__restrict__ ngroups,
-                     long key0, long key1, float beta, float *__restrict__ out, const int32_t *__restrict__ dyn,
-                     int keyframe_index) {
+__device__ __forceinline__ void motionmag_block(int bid, const float *__restrict__ poses, const float *__restrict__ patches,
+                                                const float *__restrict__ intr, const int64_t *__restrict__ ii,
+                                                const int64_t *__restrict__ jj, const int64_t *__restrict__ kk,
+                                                const int32_t *__restrict__ order, const int32_t *__restrict__ seg,
+                                                const int64_t *__restrict__ ukeys, const int32_t *__restrict__ ngroups,
+                                                long key0, long key1, float beta, float *__restrict__ out,
+                                                const int32_t *__restrict__ dyn, int keyframe_index) {
   __shared__ float s_part[256];
   __shared__ int s_seg[2];
   if (dyn) {                                    // Ramp_vo.keyframe(): i = n - KEYFRAME_INDEX - 1, j = i + 2; keys are jj * W + ii
@@ -246,7 +251,7 @@ __global__ void __launch_bounds__(256)
     key0 = j * W + i;
     key1 = i * W + j;
   }
-  const long key = blockIdx.x == 0 ? key0 : key1;
+  const long key = bid == 0 ? key0 : key1;
   if (threadIdx.x == 0) {
     int lo = 0, hi = *ngroups - 1, g = -1;
     while (lo <= hi) {
@@ -294,7 +299,36 @@ __global__ void __launch_bounds__(256)
     if (threadIdx.x < off) s_part[threadIdx.x] += s_part[threadIdx.x + off];
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[blockIdx.x] = n > 0 ? s_part[0] / (float)(n * P * P) : __int_as_float(0x7fc00000);
+  if (threadIdx.x == 0) out[bid] = n > 0 ? s_part[0] / (float)(n * P * P) : __int_as_float(0x7fc00000);
+}
+template <int P>
+__global__ void __launch_bounds__(256)
+    motionmag_kernel(const float *__restrict__ poses, const float *__restrict__ patches,
+                     const float *__restrict__ intr, const int64_t *__restrict__ ii,
+                     const int64_t *__restrict__ jj, const int64_t *__restrict__ kk,
+                     const int32_t *__restrict__ order, const int32_t *__restrict__ seg,
+                     const int64_t *__restrict__ ukeys, const int32_t *__restrict__ ngroups,
+                     long key0, long key1, float beta, float *__restrict__ out, const int32_t *__restrict__ dyn,
+                     int keyframe_index) {
+  motionmag_block<P>(blockIdx.x, poses, patches, intr, ii, jj, kk, order, seg, ukeys, ngroups, key0, key1, beta, out, dyn,
+                     keyframe_index);
+}
+// the motion test's two flow magnitudes (workgroups 0, 1: the longer ones first) and the point cloud in one launch: both
+// read the poses / patches bundle adjustment just wrote, neither reads the other's output
+template <int P>
+__global__ void __launch_bounds__(256)
+    motionmag_point_cloud_kernel(const float *__restrict__ poses, const float *__restrict__ patches,
+                                 const float *__restrict__ intr, const int64_t *__restrict__ ii,
+                                 const int64_t *__restrict__ jj, const int64_t *__restrict__ kk,
+                                 const int32_t *__restrict__ order, const int32_t *__restrict__ seg,
+                                 const int64_t *__restrict__ ukeys, const int32_t *__restrict__ ngroups, float beta,
+                                 float *__restrict__ out2, const int32_t *__restrict__ dyn, int keyframe_index,
+                                 const int64_t *__restrict__ ix, float *__restrict__ points, int m_cap, int M) {
+  if (blockIdx.x < 2)
+    motionmag_block<P>(blockIdx.x, poses, patches, intr, ii, jj, kk, order, seg, ukeys, ngroups, 0L, 0L, beta, out2, dyn,
+                       keyframe_index);
+  else
+    point_cloud_block<P>(blockIdx.x - 2, poses, patches, intr, ix, points, m_cap, dyn, M);
 }
 
 // DAMPED_LINEAR motion model (ramp/Ramp_vo.py:356-363): poses[n] = Exp(d * Log(P1 * P2^-1)) * P1
@@ -405,6 +439,18 @@ int ramp_i_motionmag_dyn(const float *poses, const float *patches, const float *
                          int keyframe_index, hipStream_t st) {
   hipLaunchKernelGGL(motionmag_kernel<3>, dim3(2), dim3(256), 0, st, poses, patches, intrinsics, ii, jj, kk, order, seg,
                      ukeys, ngroups, 0L, 0L, beta, out2, dyn, keyframe_index);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+
+int ramp_i_motionmag_point_cloud_dyn(const float *poses, const float *patches, const float *intrinsics, const int64_t *ii,
+                                     const int64_t *jj, const int64_t *kk, const int32_t *order, const int32_t *seg,
+                                     const int64_t *ukeys, const int32_t *ngroups, float beta, float *out2,
+                                     const int32_t *dyn, int keyframe_index, const int64_t *ix, float *points, int m_cap,
+                                     int M, hipStream_t st) {
+  hipLaunchKernelGGL(motionmag_point_cloud_kernel<3>, dim3(2 + ramp_cdiv(m_cap, LIE_THREADS)), dim3(256), 0, st, poses,
+                     patches, intrinsics, ii, jj, kk, order, seg, ukeys, ngroups, beta, out2, dyn, keyframe_index, ix, points,
+                     m_cap, M);
   RAMP_CHECK_LAUNCH();
   return RAMP_OK;
 }

@@ -17,6 +17,11 @@ int ramp_i_transform_dyn(const float *poses, const float *patches, const float *
                          hipStream_t st);
 int ramp_i_point_cloud_dyn(const float *poses, const float *patches, const float *intrinsics, const int64_t *ix,
                            float *out, int m_cap, const int32_t *dyn, int M, hipStream_t st);
+int ramp_i_motionmag_point_cloud_dyn(const float *poses, const float *patches, const float *intrinsics, const int64_t *ii,
+                                     const int64_t *jj, const int64_t *kk, const int32_t *order, const int32_t *seg,
+                                     const int64_t *ukeys, const int32_t *ngroups, float beta, float *out2,
+                                     const int32_t *dyn, int keyframe_index, const int64_t *ix, float *points, int m_cap,
+                                     int M, hipStream_t st);
 int ramp_i_motionmag_dyn(const float *poses, const float *patches, const float *intrinsics, const int64_t *ii,
                          const int64_t *jj, const int64_t *kk, const int32_t *order, const int32_t *seg,
                          const int64_t *ukeys, const int32_t *ngroups, float beta, float *out2, const int32_t *dyn,

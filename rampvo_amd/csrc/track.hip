@@ -342,6 +342,7 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
   const int64_t *g = t->graph[cur];
   const int64_t *ii = g, *jj = g + Ec, *kk = g + 2 * (size_t)Ec, *row = g + 3 * (size_t)Ec;
   const int32_t *dyn = t->dyn;
+  bool pc_with_mm = false;
   if (flags & RAMP_TRACK_COMMIT) {
     if (!t->fe_colors || !t->fe_imap || !t->fe_gmap || !t->fe_fmap1 || !t->fe_fmap2 || !t->fe_patches) return RAMP_EINVAL;
     const void *src[5] = {t->fe_colors, t->fe_imap, t->fe_gmap, t->fe_fmap1, t->fe_fmap2};
@@ -410,7 +411,9 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
                          t->kk_cap, t->ij_order, t->ij_seg, t->ij_ngroups, t->ij_cap, t->ba_ws, t->ba_ws_bytes,
                          t->dyn + RAMP_DYN_STATUS, dyn, st));
     TRK_PROBE(4);
-    if (t->points && t->ixm)
+    // (with the motion test following, the point cloud rides in its launch)
+    pc_with_mm = t->points && t->ixm && (flags & RAMP_TRACK_KEYFRAME) && !(flags & RAMP_TRACK_MM_GIVEN) && t->mm;
+    if (t->points && t->ixm && !pc_with_mm)
       TRK_DO(ramp_i_point_cloud_dyn(t->poses, t->patches, t->intrinsics, t->ixm, t->points, t->m_cap, dyn, t->M, st));
     if (!(flags & RAMP_TRACK_KEYFRAME)) {
       // the new hidden state is indexed by the factors themselves from here on
@@ -420,7 +423,11 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
   if (flags & RAMP_TRACK_KEYFRAME) {
     if (!t->mm || !t->dlog) return RAMP_EINVAL;
     // Ramp_vo.keyframe(), ramp/Ramp_vo.py:237-274, and the next frame's append_factors (:394-395)
-    if (!(flags & RAMP_TRACK_MM_GIVEN))
+    if (pc_with_mm)
+      TRK_DO(ramp_i_motionmag_point_cloud_dyn(t->poses, t->patches, t->intrinsics, ii, jj, kk, t->ij_order, t->ij_seg,
+                                              t->ij_ukeys, t->ij_ngroups, 0.5f, t->mm, dyn, t->keyframe_index, t->ixm,
+                                              t->points, t->m_cap, t->M, st));
+    else if (!(flags & RAMP_TRACK_MM_GIVEN))
       TRK_DO(ramp_i_motionmag_dyn(t->poses, t->patches, t->intrinsics, ii, jj, kk, t->ij_order, t->ij_seg, t->ij_ukeys,
                                   t->ij_ngroups, 0.5f, t->mm, dyn, t->keyframe_index, st));
     TrkEdit p;
