@@ -314,6 +314,10 @@ int ramp_neighbors_from_groups(const int32_t *order, const int32_t *seg_start, c
 /* flags[0] = any(a != 0), flags[1] = any(b != 0): the "events / image present" tests of
  * ramp/extractor.py:253-254, kept on the device (the reference syncs the host on each).       */
 int ramp_any_nonzero(const float *a, long na, const float *b, long nb, int32_t *flags, void *stream);
+/* the same test with one result per workgroup and no memset in front: blockflags [2][1024] int32 (row 0: a, row 1: b);
+ * returns the number of workgroups nblk (> 0) whose results are valid, or an error code (< 0).  The consumer
+ * (ramp_lstm_superstate_blocks) ORs blockflags[r][0 .. nblk).                                                       */
+int ramp_any_nonzero_blocks(const float *a, long na, const float *b, long nb, int32_t *blockflags, void *stream);
 
 /* The two per-pixel LSTM cells and the super-state 1x1 convolution of the SingleScale encoder,
  * fused (ramp/extractor.py:239-259: nn.LSTM x2 on [H*W,1,C] sequences + Conv2d(30->15) x2), on the
@@ -328,6 +332,10 @@ int ramp_any_nonzero(const float *a, long na, const float *b, long nb, int32_t *
 int ramp_lstm_superstate_tiled(const float *ev, const float *im, float *h_ev, float *c_ev, float *h_im,
                                float *c_im, float *ss, const float *wfrag, const int32_t *flags, int HW,
                                int has_state, int has_ss, void *stream);
+/* ramp_lstm_superstate_tiled with the presence flags as ramp_any_nonzero_blocks leaves them (nblk > 0) */
+int ramp_lstm_superstate_blocks(const float *ev, const float *im, float *h_ev, float *c_ev, float *h_im,
+                                float *c_im, float *ss, const float *wfrag, const int32_t *blockflags, int nblk, int HW,
+                                int has_state, int has_ss, void *stream);
 
 /* One scale (1, 2 or 4) of the MultiScale encoder's recurrent front end for one time step
  * (ramp/extractor.py:540-566 with LSTMEncoder :376-385 and SuperStateEncoder :432-463): strided

@@ -365,7 +365,7 @@ class LstmState:
         nt = (HW + 15) // 16
         self.h_ev, self.c_ev, self.h_im, self.c_im = z(nt, 16, 16), z(nt, 16, 16), z(nt, 16, 16), z(nt, 16, 16)
         self.ss = z(HW, 16)
-        self.flags = torch.zeros(2, dtype=torch.int32, device=device)
+        self.flags = torch.zeros(2, 1024, dtype=torch.int32, device=device)     # per-workgroup results (ramp_any_nonzero_blocks)
         self.fresh = True
         self.HW = HW
 
@@ -380,12 +380,13 @@ def lstm_superstate_step(enc, ev, im, st):
     as an NHWC16 tensor [H,W,16] (a view of st.ss)"""
     w = pack_lstm_mfma(enc)
     H, W = ev.shape[-2:]
-    check(lib().ramp_any_nonzero(ptr(ev), ev.numel(), ptr(im), im.numel(), ptr(st.flags), stream()),
-          "ramp_any_nonzero")
+    nblk = lib().ramp_any_nonzero_blocks(ptr(ev), ev.numel(), ptr(im), im.numel(), ptr(st.flags), stream())
+    if nblk <= 0:
+        check(nblk or -1, "ramp_any_nonzero_blocks")
     has = 0 if st.fresh else 1
-    check(lib().ramp_lstm_superstate_tiled(ptr(ev), ptr(im), ptr(st.h_ev), ptr(st.c_ev), ptr(st.h_im),
-                                           ptr(st.c_im), ptr(st.ss), ptr(w), ptr(st.flags), H * W, has, has,
-                                           stream()), "ramp_lstm_superstate_tiled")
+    check(lib().ramp_lstm_superstate_blocks(ptr(ev), ptr(im), ptr(st.h_ev), ptr(st.c_ev), ptr(st.h_im),
+                                            ptr(st.c_im), ptr(st.ss), ptr(w), ptr(st.flags), nblk, H * W, has, has,
+                                            stream()), "ramp_lstm_superstate_blocks")
     st.fresh = False
     return st.ss.view(H, W, 16)
 

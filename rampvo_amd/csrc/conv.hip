@@ -23,9 +23,10 @@
 #include <stdlib.h>
 
 // ------------------------------------------------------------------ any != 0
+#define ANY_MAXB 1024          // workgroups of any_nonzero_kernel (per-workgroup results: flags [2][ANY_MAXB])
 __global__ void __launch_bounds__(256)
     any_nonzero_kernel(const float *__restrict__ a, long na, const float *__restrict__ b, long nb,
-                       int *__restrict__ flags) {
+                       int *__restrict__ flags, int per_block) {
   __shared__ int s_any[2];
   if (threadIdx.x < 2) s_any[threadIdx.x] = 0;
   __syncthreads();
@@ -52,7 +53,11 @@ __global__ void __launch_bounds__(256)
   if (__any(fa) && (threadIdx.x & 63) == 0) s_any[0] = 1;
   if (__any(fb) && (threadIdx.x & 63) == 0) s_any[1] = 1;
   __syncthreads();
-  if (threadIdx.x < 2 && s_any[threadIdx.x]) flags[threadIdx.x] = 1;
+  if (per_block) {                               // every workgroup reports: nothing to clear beforehand
+    if (threadIdx.x < 2) flags[threadIdx.x * ANY_MAXB + blockIdx.x] = s_any[threadIdx.x];
+  } else if (threadIdx.x < 2 && s_any[threadIdx.x]) {
+    flags[threadIdx.x] = 1;
+  }
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -844,7 +849,7 @@ __global__ void __launch_bounds__(256)
                                 float *__restrict__ h_im, float *__restrict__ c_im,
                                 float *__restrict__ ss, const float *__restrict__ Wf,
                                 const int *__restrict__ flags, int HW, int has_state, int has_ss,
-                                int tiles_per_wave) {
+                                int tiles_per_wave, int nblk) {
   const int lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
   const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int ntile = (HW + 15) / 16;
@@ -860,7 +865,17 @@ __global__ void __launch_bounds__(256)
   for (int f = 0; f < 16; f++) { b_ev[f] = Wf[(LM_BEV + f) * 64 + lane]; b_im[f] = Wf[(LM_BIM + f) * 64 + lane]; }
 #pragma unroll
   for (int f = 0; f < 4; f++) b_ss[f] = Wf[(LM_BSS + f) * 64 + lane];
-  const int f_ev = flags[0], f_im = flags[1];
+  int f_ev, f_im;
+  if (nblk > 0) {
+    // per-workgroup results of any_nonzero_kernel ([2][ANY_MAXB], the first nblk of each row): every wave ORs them
+    // itself (4 KB from L2) -- the flags then need no memset launch in front of the front end
+    int a = 0, b = 0;
+    for (int i = lane; i < nblk; i += 64) { a |= flags[i]; b |= flags[ANY_MAXB + i]; }
+    f_ev = __any(a != 0) ? 1 : 0;
+    f_im = __any(b != 0) ? 1 : 0;
+  } else {
+    f_ev = flags[0]; f_im = flags[1];
+  }
 
   for (int it = 0; it < tiles_per_wave; it++) {
     const int tile = gw * tiles_per_wave + it;
@@ -1083,21 +1098,39 @@ int ramp_any_nonzero(const float *a, long na, const float *b, long nb, int32_t *
   int blocks = (int)((n / 4 + 255) / 256);
   if (blocks > 1024) blocks = 1024;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(any_nonzero_kernel, dim3(blocks), dim3(256), 0, st, a, na, b, nb, flags);
+  hipLaunchKernelGGL(any_nonzero_kernel, dim3(blocks), dim3(256), 0, st, a, na, b, nb, flags, 0);
   RAMP_CHECK_LAUNCH();
   return RAMP_OK;
+}
+
+int ramp_any_nonzero_blocks(const float *a, long na, const float *b, long nb, int32_t *blockflags, void *stream) {
+  if (!blockflags) return RAMP_EINVAL;
+  const long n = na > nb ? na : nb;
+  if (n <= 0) return RAMP_EINVAL;
+  int blocks = (int)((n / 4 + 255) / 256);
+  if (blocks > ANY_MAXB) blocks = ANY_MAXB;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(any_nonzero_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, na, b, nb, blockflags, 1);
+  if (hipGetLastError() != hipSuccess) return RAMP_ELAUNCH;
+  return blocks;
 }
 
 int ramp_lstm_superstate_tiled(const float *ev, const float *im, float *h_ev, float *c_ev, float *h_im,
                                float *c_im, float *ss, const float *wfrag, const int32_t *flags, int HW,
                                int has_state, int has_ss, void *stream) {
-  if (HW <= 0 || !ev || !im || !h_ev || !c_ev || !h_im || !c_im || !ss || !wfrag || !flags)
+  return ramp_lstm_superstate_blocks(ev, im, h_ev, c_ev, h_im, c_im, ss, wfrag, flags, 0, HW, has_state, has_ss, stream);
+}
+
+int ramp_lstm_superstate_blocks(const float *ev, const float *im, float *h_ev, float *c_ev, float *h_im,
+                                float *c_im, float *ss, const float *wfrag, const int32_t *flags, int nblk, int HW,
+                                int has_state, int has_ss, void *stream) {
+  if (HW <= 0 || !ev || !im || !h_ev || !c_ev || !h_im || !c_im || !ss || !wfrag || !flags || nblk < 0 || nblk > ANY_MAXB)
     return RAMP_EINVAL;
   const int ntile = ramp_cdiv(HW, 16);
   const int tpw = ntile >= 8192 ? 4 : 1;           // tiles per wave: amortise the 104 weight registers
   hipLaunchKernelGGL(lstm_superstate_mfma_kernel, dim3(ramp_cdiv(ntile, 4 * tpw)), dim3(256), 0,
                      (hipStream_t)stream, ev, im, h_ev, c_ev, h_im, c_im, ss, wfrag, flags, HW, has_state,
-                     has_ss, tpw);
+                     has_ss, tpw, nblk);
   RAMP_CHECK_LAUNCH();
   return RAMP_OK;
 }
