@@ -54,3 +54,11 @@ for _ in range(20):
     evs.append((a, b))
 torch.cuda.synchronize()
 print("  ... after 1.5 GB of other traffic: %.1f us per call" % (1e3 * np.median([a.elapsed_time(b) for a, b in evs])))
+
+# how the dead factors sit in the factor list: tiles of 64 / 80 consecutive factors (the update operator's workgroups)
+n1, _, _ = window_stats(co, 30, 40, 4.0)
+dead = (n0 == 0) & (n1 == 0)
+for T in (64, 80):
+    nt = len(dead) // T
+    d = dead[:nt * T].reshape(nt, T)
+    print("tiles of %d consecutive factors: all dead %.3f | none dead %.3f | dead factors %.3f" % (T, d.all(1).mean(), (~d.any(1)).mean(), dead.mean()))
