@@ -378,7 +378,16 @@ typedef struct ramp_conv_job {
   float out_scale;
   float act_scale, w_scale;   /* RAMP_CONV_FP8 only: x * act_scale and w * w_scale (wpk packed as e4m3 bytes) are the
                                  MFMA operands, saturating at +-448; the accumulator is divided by their product */
+  /* accumulator mode of the InstanceNorm statistics (no ramp_in_stats_finalize launch between two layers): the layer
+   * ADDS its per-workgroup partial sums, as exact 2^-20 fixed-point integers, to acc_out [RAMP_IN_ACC_R][Cout][2] uint64
+   * (ZERO before the layer; order independent, so reproducible), and takes its input's normalisation from acc_in
+   * [RAMP_IN_ACC_R][Cin][2] (+ the pixel count and eps of that InstanceNorm) instead of pre_scale / pre_shift: every
+   * consumer workgroup sums the replicas and forms scale = rsqrt(var + eps), shift = -mean * scale itself (Cin <= 128) */
+  void *acc_out;
+  const void *acc_in;
+  float in_count, in_eps;
 } ramp_conv_job;
+#define RAMP_IN_ACC_R 8
 int ramp_conv2d_nhwc_multi(const ramp_conv_job *jobs, int njobs, int H, int W, int Cin, int KH, int stride,
                            int dtype, void *stream);
 
@@ -401,6 +410,13 @@ int ramp_conv2d_stats_blocks(int H, int W, int Cin, int Cout, int KH, int stride
  * shift = -mean*scale, from the per-block partials of ramp_conv2d_nhwc                         */
 int ramp_in_stats_finalize(const float *partial, int nblk, int C, float count, float eps, float *scale,
                            float *shift, void *stream);
+
+/* accumulator-mode counterparts: ramp_norm_add_relu_f16 with y's (and a normalised skip's) statistics taken from their
+ * accumulators, and the (scale, shift) arrays of an accumulator for a consumer without that path                      */
+int ramp_norm_add_relu_f16_acc(const void *y, const void *acc_y, float count_y, float eps_y, const void *skip,
+                               const void *acc_skip, float count_skip, float eps_skip, void *out, long n, int C,
+                               int skip_relu, void *stream);
+int ramp_in_acc_finalize(const void *acc, int C, float count, float eps, float *scale, float *shift, void *stream);
 
 /* out = relu(x*s + h)   (InstanceNorm + ReLU materialised where a skip connection needs it)    */
 int ramp_affine_relu(const float *x, const float *s, const float *h, float *out, long n, int C,

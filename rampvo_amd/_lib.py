@@ -88,6 +88,8 @@ SIGNATURES = {
     "ramp_norm_add_relu": (c_i, [c_p] * 7 + [ctypes.c_long, c_i, c_p]),
     "ramp_affine_relu_f16": (c_i, [c_p, c_p, c_p, c_p, ctypes.c_long, c_i, c_p]),
     "ramp_norm_add_relu_f16": (c_i, [c_p] * 7 + [ctypes.c_long, c_i, c_i, c_p]),
+    "ramp_norm_add_relu_f16_acc": (c_i, [c_p, c_p, c_f, c_f, c_p, c_p, c_f, c_f, c_p, ctypes.c_long, c_i, c_i, c_p]),
+    "ramp_in_acc_finalize": (c_i, [c_p, c_i, c_f, c_f, c_p, c_p, c_p]),
     "ramp_conv2d_nhwc_multi": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "ramp_upd_row_fuse": (c_i, [c_p] * 6 + [ctypes.c_long, c_p, c_p, c_p, c_p, c_f, c_i, c_p, c_p, c_i, c_i, c_p]),
     "ramp_upd_gather_mask": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p]),

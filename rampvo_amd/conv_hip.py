@@ -111,13 +111,59 @@ def pack_lstm_mfma(enc):
 
 
 # ------------------------------------------------------------------------ primitives
+IN_ACC_R = 8             # include/ramp_hip.h::RAMP_IN_ACC_R
+_IN_ACC = os.environ.get("RAMP_IN_ACC", "1") != "0"     # A/B switch: 0 = per-layer ramp_in_stats_finalize launches
+
+
 class Pending:
     """a raw conv output whose InstanceNorm has not been applied yet; ``relu``: the norm is followed by a ReLU
-    (conv1 / the residual block's convs) or not (the downsample path's norm3)"""
-    __slots__ = ("raw", "scale", "shift", "relu")
+    (conv1 / the residual block's convs) or not (the downsample path's norm3).  The statistics are either finalised
+    (scale, shift) arrays or -- accumulator mode -- the replicated fixed-point sums ``acc`` [R][C][2] int64 with the pixel
+    count and eps, which the consuming kernels reduce themselves; asking such a Pending for ``scale`` / ``shift``
+    finalises it in a launch of its own (consumers without the accumulator path)."""
+    __slots__ = ("raw", "_scale", "_shift", "relu", "acc", "count", "eps")
 
-    def __init__(self, raw, scale, shift, relu=True):
-        self.raw, self.scale, self.shift, self.relu = raw, scale, shift, relu
+    def __init__(self, raw, scale, shift, relu=True, acc=None, count=0.0, eps=1e-5):
+        self.raw, self._scale, self._shift, self.relu = raw, scale, shift, relu
+        self.acc, self.count, self.eps = acc, float(count), float(eps)
+
+    def _finalise(self):
+        if self._scale is None:
+            C = self.raw.shape[-1]
+            ws = torch.empty(2, C, dtype=torch.float32, device=self.raw.device)
+            check(lib().ramp_in_acc_finalize(ptr(self.acc), C, self.count, self.eps, ptr(ws[0]), ptr(ws[1]), stream()),
+                  "ramp_in_acc_finalize")
+            self._scale, self._shift = ws[0], ws[1]
+
+    @property
+    def scale(self):
+        self._finalise()
+        return self._scale
+
+    @property
+    def shift(self):
+        self._finalise()
+        return self._shift
+
+
+class _AccArena:
+    """the accumulators of one tower pass: ONE zeroed int64 allocation (one memset for all layers), slots of
+    [R][128][2] handed out in order"""
+    SLOTS = 16
+
+    def __init__(self, device):
+        self.buf = torch.zeros(self.SLOTS, IN_ACC_R * 128 * 2, dtype=torch.int64, device=device)
+        self.used = 0
+
+    def slot(self, C):
+        if self.used >= self.SLOTS or C > 128:
+            return None
+        v = self.buf[self.used][:IN_ACC_R * C * 2]
+        self.used += 1
+        return v
+
+
+_arena = None            # set by the tower passes below while they run
 
 
 class ConvJob(ctypes.Structure):
@@ -126,7 +172,9 @@ class ConvJob(ctypes.Structure):
                 ("pre_scale", ctypes.c_void_p), ("pre_shift", ctypes.c_void_p), ("res", ctypes.c_void_p),
                 ("y", ctypes.c_void_p), ("stats", ctypes.c_void_p),
                 ("Cout", ctypes.c_int32), ("relu", ctypes.c_int32), ("out_scale", ctypes.c_float),
-                ("act_scale", ctypes.c_float), ("w_scale", ctypes.c_float)]
+                ("act_scale", ctypes.c_float), ("w_scale", ctypes.c_float),
+                ("acc_out", ctypes.c_void_p), ("acc_in", ctypes.c_void_p), ("in_count", ctypes.c_float),
+                ("in_eps", ctypes.c_float)]
 
 
 # fp8 variant: activations are multiplied by this before the e4m3 conversion (saturating at 448 / FP8_ACT_SCALE = 56;
@@ -214,10 +262,14 @@ def conv2d_towers(jobs, half, fp8=False):
     outs, finalize = [], []
     for t, j in enumerate(jobs):
         x, conv = j["x"], j["conv"]
-        pre = None
+        pre = acc_in = None
         if isinstance(x, Pending):
             assert x.relu
-            pre, x = (x.scale, x.shift), x.raw
+            if x.acc is not None and x._scale is None and Cin <= 128:
+                acc_in = x
+            else:
+                pre = (x.scale, x.shift)
+            x = x.raw
         w_scale = 0.0
         if use8:
             wpk, bias, w_scale = pack_conv_weight(conv, "f8")
@@ -233,10 +285,16 @@ def conv2d_towers(jobs, half, fp8=False):
         a = arr[t]
         a.x, a.wpk, a.bias = ptr(x), ptr(wpk), ptr(bias)
         a.pre_scale, a.pre_shift = (ptr(pre[0]), ptr(pre[1])) if pre else (None, None)
+        a.acc_in, a.in_count, a.in_eps = (ptr(acc_in.acc), acc_in.count, acc_in.eps) if acc_in else (None, 0.0, 0.0)
+        a.acc_out = None
         a.res, a.y = ptr(res), ptr(y)
         a.Cout, a.relu, a.out_scale = cout, int(j.get("relu", False)), float(j.get("out_scale", 1.0))
         a.act_scale, a.w_scale = (FP8_ACT_SCALE, w_scale) if use8 else (0.0, 0.0)
-        if j.get("want_stats", False):
+        acc = _arena.slot(cout) if (j.get("want_stats", False) and _arena is not None) else None
+        if acc is not None:
+            a.stats, a.acc_out = None, ptr(acc)
+            outs.append(Pending(y, None, None, acc=acc, count=OH * OW, eps=j.get("eps", 1e-5)))
+        elif j.get("want_stats", False):
             ws = torch.empty(cout * 2 * nblk + 2 * cout, dtype=torch.float32, device=x.device)
             scale, shift, stats = ws[:cout], ws[cout:2 * cout], ws[2 * cout:]
             a.stats = ptr(stats)
@@ -269,6 +327,14 @@ def materialize(p):
 def norm_add_relu(y, skip):
     """relu(skip' + relu(norm(y)));  skip is a tensor or a Pending (its norm, with or without ReLU, applied here)"""
     out = torch.empty_like(y.raw)
+    sp = isinstance(skip, Pending)
+    if (y.raw.dtype == torch.float16 and y.acc is not None and y._scale is None and y.raw.shape[-1] <= 128
+            and (not sp or (skip.acc is not None and skip._scale is None))):
+        check(lib().ramp_norm_add_relu_f16_acc(ptr(y.raw), ptr(y.acc), y.count, y.eps, ptr(skip.raw if sp else skip),
+                                               ptr(skip.acc) if sp else None, skip.count if sp else 0.0,
+                                               skip.eps if sp else 0.0, ptr(out), y.raw.numel(), y.raw.shape[-1],
+                                               int(sp and skip.relu), stream()), "ramp_norm_add_relu_f16_acc")
+        return out
     s_raw, ss, hs = (skip.raw, skip.scale, skip.shift) if isinstance(skip, Pending) else (skip, None, None)
     if y.raw.dtype == torch.float16:
         check(lib().ramp_norm_add_relu_f16(ptr(y.raw), ptr(y.scale), ptr(y.shift), ptr(s_raw), ptr(ss), ptr(hs),
@@ -321,12 +387,17 @@ def basic_encoder4_towers(encs, x, out_scale=1.0, half=False, fp8=False):
     """BasicEncoder4._forward of every tower in ``encs`` on one NHWC image x [H,W,Cin_padded] -> [H/4,W/4,out] each
     (``half``: fp16 storage + fp16 MFMA after the first layer's fp32 input).  relu(norm1(conv1)) is never
     materialised: layer1's first conv applies it while loading, the block's tail while adding the skip."""
+    global _arena
     norms = _tower_norms(encs)
-    xs = _first_layer(encs, x, norms, half)
-    for li in ("layer1", "layer2"):
-        for b in range(2):
-            xs = _res_blocks([getattr(e, li)[b] for e in encs], xs, norms, half, fp8)
-    return conv2d_towers([dict(x=xs[t], conv=e.conv2, out_scale=out_scale) for t, e in enumerate(encs)], half, fp8)
+    _arena = _AccArena(x.device) if (half and _IN_ACC and any(norms)) else None
+    try:
+        xs = _first_layer(encs, x, norms, half)
+        for li in ("layer1", "layer2"):
+            for b in range(2):
+                xs = _res_blocks([getattr(e, li)[b] for e in encs], xs, norms, half, fp8)
+        return conv2d_towers([dict(x=xs[t], conv=e.conv2, out_scale=out_scale) for t, e in enumerate(encs)], half, fp8)
+    finally:
+        _arena = None
 
 
 def basic_encoder4(enc, x, out_scale=1.0, half=False):

@@ -73,6 +73,12 @@ struct ConvParams {
   const void *res;      // NHWC [OH][OW][Cout] residual (added before the final ReLU) or null
   void *y;              // NHWC [OH][OW][Cout]
   float *stats;         // [Cout][2][nblk] partial (sum, sumsq) of the raw (bias-added) output or null
+  // accumulator mode (LDS-tiled fp16 kernels): the statistics travel as exact fixed-point integers -- every workgroup
+  // adds its partial sums to one of IN_ACC_R replicas (order independent, so bit reproducible), every CONSUMER
+  // workgroup sums the replicas and forms (scale, shift) itself: no finalize launch between two layers
+  unsigned long long *acc_out;         // [IN_ACC_R][Cout][2] of this layer's output or null
+  const unsigned long long *acc_in;    // [IN_ACC_R][Cin][2] of the input (instead of pre_scale / pre_shift) or null
+  float in_count, in_eps;
   int H, W, Cin, OH, OW, Cout;
   int relu;             // ReLU on the conv output (before the residual add; the add is followed by its own ReLU)
   float out_scale;
@@ -82,6 +88,32 @@ struct ConvParams {
 };
 // up to two independent problems of one layer shape in one launch (blockIdx.z): the towers of the encoder
 struct ConvMulti { ConvParams t[2]; };
+
+#define IN_ACC_R 8
+#define IN_ACC_ONE 1048576.0          // fixed point: 2^20 per unit (a tile's sum of squares stays below 2^43)
+__device__ __forceinline__ unsigned long long in_acc_fix(float v) { return (unsigned long long)(long long)rint((double)v * IN_ACC_ONE); }
+// (scale, shift) of channels [0, C) from the replicated accumulators into LDS tables; all threads of the workgroup call
+// it, a barrier follows inside
+__device__ __forceinline__ void in_acc_finalize(const unsigned long long *__restrict__ acc, int C, float count, float eps,
+                                                float *s_scale, float *s_shift, long long *s_sum /* [2 * C] */) {
+  const int tid = threadIdx.x, nth = blockDim.x;
+  for (int i = tid; i < 2 * C; i += nth) {
+    long long t = 0;
+#pragma unroll
+    for (int r = 0; r < IN_ACC_R; r++) t += (long long)acc[(size_t)r * 2 * C + i];
+    s_sum[i] = t;
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += nth) {
+    const double mean = (double)s_sum[2 * c] / IN_ACC_ONE / (double)count;
+    double var = (double)s_sum[2 * c + 1] / IN_ACC_ONE / (double)count - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    s_scale[c] = (float)rstd;
+    s_shift[c] = (float)(-mean * rstd);
+  }
+  __syncthreads();
+}
 
 // fp32: wave tile 32 px x 32 ch, K chunk = 16 input channels per tap.
 // A fragment (v_mfma_f32_16x16x4_f32): lane l supplies A[i=l&15][k=l>>4]; with the channel
@@ -375,17 +407,20 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvParams &p, const f3
         s_out[(r * TW + xx) * OSTR + nt * 16 + j] = v;
       }
     }
-    if (p.stats) {
+    if (p.stats || p.acc_out) {
       s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
       s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
       if (q == 0) { s_stat[wave][nt * 16 + j][0] = s1; s_stat[wave][nt * 16 + j][1] = s2; }
     }
   }
   __syncthreads();
-  if (p.stats && tid < NT * 32) {
+  if ((p.stats || p.acc_out) && tid < NT * 32) {
     const int c = tid >> 1, k = tid & 1;
     const float v = ((s_stat[0][c][k] + s_stat[1][c][k]) + s_stat[2][c][k]) + s_stat[3][c][k];
-    p.stats[((size_t)(n0 + c) * 2 + k) * gridDim.x + blockIdx.x] = v;   // [C][2][nblk]: contiguous per channel
+    if (p.acc_out)
+      atomicAdd(p.acc_out + ((size_t)(blockIdx.x % IN_ACC_R) * p.Cout + n0 + c) * 2 + k, in_acc_fix(v));
+    else
+      p.stats[((size_t)(n0 + c) * 2 + k) * gridDim.x + blockIdx.x] = v;   // [C][2][nblk]: contiguous per channel
   }
   // 16-byte pieces: pixel-major, 8 channels each
   constexpr int PPP = NT * 2;                         // pieces per pixel
@@ -478,8 +513,15 @@ __global__ void __launch_bounds__(256) conv_tile_f16_kernel(const ConvMulti pm) 
     ibuf[n] = reinterpret_cast<const u32x4 *>(p.x)[((size_t)cy * p.W + cx) * CH8 + cslot];
   }
   float sc[8], sh[8];
-  const bool pre = p.pre_scale != nullptr;
-  if (pre) {
+  const bool pre = p.pre_scale != nullptr || p.acc_in != nullptr;
+  if (p.acc_in) {                                     // (uniform) the input's InstanceNorm from its accumulators
+    float *s_sc = reinterpret_cast<float *>(s_in), *s_sh = s_sc + 128;
+    long long *s_sum = reinterpret_cast<long long *>(s_sh + 128);
+    in_acc_finalize(p.acc_in, p.Cin, p.in_count, p.in_eps, s_sc, s_sh, s_sum);
+#pragma unroll
+    for (int c = 0; c < CPI; c++) { sc[c] = s_sc[cslot * CPI + c]; sh[c] = s_sh[cslot * CPI + c]; }
+    __syncthreads();                                  // the tables sit where the input tile goes
+  } else if (pre) {
 #pragma unroll
     for (int c = 0; c < CPI; c++) { sc[c] = p.pre_scale[cslot * CPI + c]; sh[c] = p.pre_shift[cslot * CPI + c]; }
   }
@@ -786,6 +828,42 @@ __global__ void __launch_bounds__(256)
   }
   reinterpret_cast<f16x8 *>(out)[i] = o;
 }
+// the same with the statistics of y (and of a normalised skip) taken from their accumulators: every workgroup forms the
+// (scale, shift) tables itself (in_acc_finalize)
+__global__ void __launch_bounds__(256)
+    norm_add_relu_f16_acc_kernel(const _Float16 *__restrict__ y, const unsigned long long *__restrict__ acc_y, float count_y,
+                                 float eps_y, const _Float16 *__restrict__ skip,
+                                 const unsigned long long *__restrict__ acc_s, float count_s, float eps_s,
+                                 _Float16 *__restrict__ out, long n8, int C, int skip_relu) {
+  __shared__ float s_tab[4][128];
+  __shared__ long long s_sum[256];
+  in_acc_finalize(acc_y, C, count_y, eps_y, s_tab[0], s_tab[1], s_sum);
+  if (acc_s) in_acc_finalize(acc_s, C, count_s, eps_s, s_tab[2], s_tab[3], s_sum);
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const int c = (int)((i * 8) % C);
+  const f16x8 v = reinterpret_cast<const f16x8 *>(y)[i];
+  const f16x8 k = reinterpret_cast<const f16x8 *>(skip)[i];
+  f16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; e++) {
+    float a = fmaxf((float)v[e] * s_tab[0][c + e] + s_tab[1][c + e], 0.f);
+    float b = (float)k[e];
+    if (acc_s) b = b * s_tab[2][c + e] + s_tab[3][c + e];
+    if (skip_relu) b = (float)(_Float16)fmaxf(b, 0.f);
+    o[e] = (_Float16)fmaxf(a + b, 0.f);
+  }
+  reinterpret_cast<f16x8 *>(out)[i] = o;
+}
+// (scale, shift) arrays from accumulators, for a consumer without the accumulator path
+__global__ void __launch_bounds__(128)
+    in_acc_to_scale_shift_kernel(const unsigned long long *__restrict__ acc, int C, float count, float eps,
+                                 float *__restrict__ scale, float *__restrict__ shift) {
+  __shared__ float s_tab[2][128];
+  __shared__ long long s_sum[256];
+  in_acc_finalize(acc, C, count, eps, s_tab[0], s_tab[1], s_sum);
+  if ((int)threadIdx.x < C) { scale[threadIdx.x] = s_tab[0][threadIdx.x]; shift[threadIdx.x] = s_tab[1][threadIdx.x]; }
+}
 __global__ void __launch_bounds__(256)
     affine_relu_f16_kernel(const _Float16 *__restrict__ x, const float *__restrict__ s,
                            const float *__restrict__ h, _Float16 *__restrict__ out, long n8, int C) {
@@ -1089,6 +1167,28 @@ int ramp_norm_add_relu_f16(const void *y, const float *sy, const float *hy, cons
   return RAMP_OK;
 }
 
+int ramp_norm_add_relu_f16_acc(const void *y, const void *acc_y, float count_y, float eps_y, const void *skip,
+                               const void *acc_skip, float count_skip, float eps_skip, void *out, long n, int C,
+                               int skip_relu, void *stream) {
+  if (!y || !acc_y || !skip || !out || n <= 0 || C % 8 || C > 128 || n % 8 || count_y <= 0.f || (skip_relu && !acc_skip) ||
+      (acc_skip && count_skip <= 0.f))
+    return RAMP_EINVAL;
+  const long n8 = n / 8;
+  hipLaunchKernelGGL(norm_add_relu_f16_acc_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const _Float16 *)y, (const unsigned long long *)acc_y, count_y, eps_y, (const _Float16 *)skip,
+                     (const unsigned long long *)acc_skip, count_skip, eps_skip, (_Float16 *)out, n8, C, skip_relu);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+
+int ramp_in_acc_finalize(const void *acc, int C, float count, float eps, float *scale, float *shift, void *stream) {
+  if (!acc || !scale || !shift || C <= 0 || C > 128 || count <= 0.f) return RAMP_EINVAL;
+  hipLaunchKernelGGL(in_acc_to_scale_shift_kernel, dim3(1), dim3(128), 0, (hipStream_t)stream,
+                     (const unsigned long long *)acc, C, count, eps, scale, shift);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+
 int ramp_any_nonzero(const float *a, long na, const float *b, long nb, int32_t *flags, void *stream) {
   if (!flags) return RAMP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
@@ -1150,6 +1250,7 @@ int ramp_conv2d_nhwc(const void *x, const void *wpk, const float *bias, const fl
   ConvParams p;
   p.x = x; p.wpk = wpk; p.bias = bias; p.pre_scale = pre_scale; p.pre_shift = pre_shift;
   p.res = res; p.y = y; p.stats = stats;
+  p.acc_out = nullptr; p.acc_in = nullptr; p.in_count = 0.f; p.in_eps = 0.f;
   p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
   const int pad = KH / 2;
   p.OH = (H + 2 * pad - KH) / stride + 1;
@@ -1216,6 +1317,9 @@ int ramp_conv2d_nhwc_multi(const ramp_conv_job *jobs, int njobs, int H, int W, i
     ConvParams &p = pm.t[t];
     p.x = j.x; p.wpk = j.wpk; p.bias = j.bias; p.pre_scale = j.pre_scale; p.pre_shift = j.pre_shift;
     p.res = j.res; p.y = j.y; p.stats = j.stats;
+    p.acc_out = (unsigned long long *)j.acc_out; p.acc_in = (const unsigned long long *)j.acc_in;
+    p.in_count = j.in_count; p.in_eps = j.in_eps;
+    if (p.acc_in && (Cin > 128 || p.in_count <= 0.f)) return RAMP_EINVAL;
     p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = j.Cout;
     p.relu = j.relu; p.out_scale = j.out_scale;
     p.act_scale = 1.0f; p.descale = 1.0f;
