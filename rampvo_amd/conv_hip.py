@@ -408,17 +408,22 @@ def multiscale_encoder4_towers(encs, x, x2, x4, out_scale=1.0, half=False, fp8=F
     """MultiScaleBasicEncoder4.forward (reference extractor.py:288-311) of every tower on NHWC inputs: x [H,W,16],
     x2 [H/2,W/2,32] and x4 [H/4,W/4,64] (the three super-states) -> [H/4,W/4,out].  The channel
     concatenations are the only non-conv steps; layer2/conv2 are unused, as upstream."""
+    global _arena
     norms = _tower_norms(encs)
-    xs = _first_layer(encs, x, norms, half)
-    for b in range(2):
-        xs = _res_blocks([e.layer1[b] for e in encs], xs, norms, half, fp8)
-    x2 = x2.to(xs[0].dtype)
-    xs = [torch.cat((v, x2), dim=-1) for v in xs]
-    for b in range(2):
-        xs = _res_blocks([e.layer3[b] for e in encs], xs, norms, half, fp8)
-    x4 = x4.to(xs[0].dtype)
-    xs = [torch.cat((v, x4), dim=-1) for v in xs]
-    return conv2d_towers([dict(x=xs[t], conv=e.conv3, out_scale=out_scale) for t, e in enumerate(encs)], half, fp8)
+    _arena = _AccArena(x.device) if (half and _IN_ACC and any(norms)) else None
+    try:
+        xs = _first_layer(encs, x, norms, half)
+        for b in range(2):
+            xs = _res_blocks([e.layer1[b] for e in encs], xs, norms, half, fp8)
+        x2 = x2.to(xs[0].dtype)
+        xs = [torch.cat((v, x2), dim=-1) for v in xs]
+        for b in range(2):
+            xs = _res_blocks([e.layer3[b] for e in encs], xs, norms, half, fp8)
+        x4 = x4.to(xs[0].dtype)
+        xs = [torch.cat((v, x4), dim=-1) for v in xs]
+        return conv2d_towers([dict(x=xs[t], conv=e.conv3, out_scale=out_scale) for t, e in enumerate(encs)], half, fp8)
+    finally:
+        _arena = None
 
 
 def multiscale_encoder4(enc, x, x2, x4, out_scale=1.0, half=False):

@@ -499,7 +499,7 @@ __global__ void __launch_bounds__(256) plan_scatter_kernel(const PlanDyn p) {
 // next plan (nobody reads them after the scatter): no memset launch.
 #define PLAN_SEG_LDS 4096
 __global__ void __launch_bounds__(256) plan_segsort_kernel(const PlanDyn p, int64_t *__restrict__ ix, int64_t *__restrict__ jx,
-                                                           int32_t *__restrict__ kj, int hist_words) {
+                                                           int32_t *__restrict__ kj, int hist_words, int32_t *__restrict__ mirror) {
   __shared__ int s_v[PLAN_SEG_LDS];
   __shared__ int s_kj[1024];
   const int g = blockIdx.y, grp = blockIdx.x;
@@ -507,6 +507,8 @@ __global__ void __launch_bounds__(256) plan_segsort_kernel(const PlanDyn p, int6
     const int z = grp * 256 + threadIdx.x;
     if (z < hist_words) p.hist[0][z] = 0;               // hist[0] and hist[1] are one allocation
   }
+  // the host's lazy copy of the sizes (mapped pinned memory): nothing changes them after this launch has started
+  if (mirror && g == 1 && grp == 0 && threadIdx.x < RAMP_DYN_WORDS) mirror[threadIdx.x] = p.dyn[threadIdx.x];
   if (grp >= *p.ngroups[g]) return;
   const int32_t *tmp_order = p.tmp[g], *seg_start = p.seg[g];
   int32_t *order = p.order[g];
@@ -557,7 +559,7 @@ int ramp_i_plan_dyn(const int64_t *g4, int E_cap, int E_grid, const int32_t *dyn
                     int pkey_cap, int kk_cap, int ij_cap, int32_t *kk_order, int32_t *kk_gid, int32_t *kk_seg,
                     int32_t *kk_ngroups, int64_t *kk_ukeys, int32_t *ij_order, int32_t *ij_gid, int32_t *ij_seg,
                     int32_t *ij_ngroups, int64_t *ij_ukeys, int64_t *ix, int64_t *jx, int32_t *kj, void *ws,
-                    size_t ws_bytes, hipStream_t st) {
+                    size_t ws_bytes, int32_t *mirror, hipStream_t st) {
   if (!g4 || !dyn || !status || !ws || E_cap <= 0 || kkey_cap <= 0 || pkey_cap <= 0) return RAMP_EINVAL;
   if (ws_bytes < ramp_i_plan_dyn_ws(E_cap, kkey_cap, pkey_cap)) return RAMP_EWORKSPACE;
   PlanDyn p;
@@ -581,7 +583,7 @@ int ramp_i_plan_dyn(const int64_t *g4, int E_cap, int E_grid, const int32_t *dyn
   const int hist_words = kkey_cap + pkey_cap + 4;
   int gx = kk_cap > ij_cap ? kk_cap : ij_cap;
   if (gx < ramp_cdiv(hist_words, 256)) gx = ramp_cdiv(hist_words, 256);
-  hipLaunchKernelGGL(plan_segsort_kernel, dim3(gx, 2), dim3(256), 0, st, p, ix, jx, kj, hist_words);
+  hipLaunchKernelGGL(plan_segsort_kernel, dim3(gx, 2), dim3(256), 0, st, p, ix, jx, kj, hist_words, mirror);
   RAMP_CHECK_LAUNCH();
   return RAMP_OK;
 }

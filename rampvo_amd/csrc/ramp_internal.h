@@ -35,7 +35,7 @@ int ramp_i_plan_dyn(const int64_t *g4, int E_cap, int E_grid, const int32_t *dyn
                     int pkey_cap, int kk_cap, int ij_cap, int32_t *kk_order, int32_t *kk_gid, int32_t *kk_seg,
                     int32_t *kk_ngroups, int64_t *kk_ukeys, int32_t *ij_order, int32_t *ij_gid, int32_t *ij_seg,
                     int32_t *ij_ngroups, int64_t *ij_ukeys, int64_t *ix, int64_t *jx, int32_t *kj, void *ws,
-                    size_t ws_bytes, hipStream_t st);
+                    size_t ws_bytes, int32_t *mirror, hipStream_t st);
 size_t ramp_i_ba_dyn_ws(int E_cap, int n_poses, int n_patches, int opt_window, int max_patches, int max_pairs);
 int ramp_i_ba_dyn(float *poses, float *patches, const float *intrinsics, const float *target, const float *weight,
                   const float *lmbda, const int64_t *ii, const int64_t *jj, const int64_t *kk, int E_cap, int P,

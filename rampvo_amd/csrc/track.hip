@@ -312,7 +312,7 @@ int ramp_track_plan(const ramp_track *t, int cur, void *stream) {
   return ramp_i_plan_dyn(t->graph[cur], t->E_cap, t->E_cap, t->dyn, t->dyn + RAMP_DYN_STATUS, t->M, t->kkey_cap, t->pkey_cap,
                          t->kk_cap, t->ij_cap, t->kk_order, t->kk_gid, t->kk_seg, t->kk_ngroups, t->kk_ukeys, t->ij_order,
                          t->ij_gid, t->ij_seg, t->ij_ngroups, t->ij_ukeys, t->ix, t->jx, t->kj, t->plan_ws, t->plan_ws_bytes,
-                         (hipStream_t)stream);
+                         nullptr, (hipStream_t)stream);
 }
 
 #define TRK_PROBE(i)                                                                             \
@@ -343,6 +343,13 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
   const int64_t *ii = g, *jj = g + Ec, *kk = g + 2 * (size_t)Ec, *row = g + 3 * (size_t)Ec;
   const int32_t *dyn = t->dyn;
   bool pc_with_mm = false;
+  // the host's lazy copy of the sizes: written by the plan's last launch straight into the (mapped, pinned) host buffer
+  int32_t *mirror = nullptr;
+  if (t->dyn_host) {
+    void *dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, t->dyn_host, 0) == hipSuccess) mirror = (int32_t *)dp;
+    else (void)hipGetLastError();
+  }
   if (flags & RAMP_TRACK_COMMIT) {
     if (!t->fe_colors || !t->fe_imap || !t->fe_gmap || !t->fe_fmap1 || !t->fe_fmap2 || !t->fe_patches) return RAMP_EINVAL;
     const void *src[5] = {t->fe_colors, t->fe_imap, t->fe_gmap, t->fe_fmap1, t->fe_fmap2};
@@ -442,9 +449,10 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
     TRK_DO(ramp_i_plan_dyn(t->graph[1 - cur], Ec, Ep, t->dyn, t->dyn + RAMP_DYN_STATUS, t->M, t->kkey_cap, t->pkey_cap,
                            t->kk_cap, t->ij_cap, t->kk_order, t->kk_gid, t->kk_seg, t->kk_ngroups, t->kk_ukeys, t->ij_order,
                            t->ij_gid, t->ij_seg, t->ij_ngroups, t->ij_ukeys, t->ix, t->jx, t->kj, t->plan_ws, t->plan_ws_bytes,
-                           st));
+                           mirror, st));
   }
-  if (t->dyn_host &&
+  // (without a plan in this call, or without a device mapping of the host buffer: an asynchronous copy)
+  if (t->dyn_host && !(mirror && (flags & RAMP_TRACK_KEYFRAME)) &&
       hipMemcpyAsync(t->dyn_host, t->dyn, RAMP_DYN_WORDS * sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess)
     return RAMP_ELAUNCH;
   RAMP_CHECK_LAUNCH();
