@@ -151,6 +151,48 @@ def test_conv_tower_pair_equals_single_launches(cin, couts, k, stride, hw, first
             assert torch.equal(again[1], pair[1])
 
 
+@pytest.mark.parametrize("cin,cout,k,stride,hw", [(32, 32, 3, 1, (120, 160)), (32, 64, 3, 2, (61, 83)), (64, 64, 3, 1, (60, 80)),
+                                                  (64, 128, 1, 1, (30, 40))])
+def test_instance_norm_accumulators_match_the_finalize_launch(cin, cout, k, stride, hw):
+    """accumulator mode of the InstanceNorm statistics (csrc/conv.hip: producers add exact 2^-20 fixed-point partial
+    sums to one of 8 replicas, consumers reduce them): the (scale, shift) the accumulators give (ramp_in_acc_finalize)
+    against ramp_in_stats_finalize on the same layer, the consuming conv and the residual tail against the classic
+    path, and bit stability of everything under repetition (integer sums: no order dependence)"""
+    from rampvo_amd import conv_hip
+    torch.manual_seed(11)
+    conv_a = nn.Conv2d(cin, cout, k, stride=stride, padding=k // 2).cuda()
+    conv_b = nn.Conv2d(cout, cout, 3, padding=1).cuda()
+    dummy = nn.Conv2d(cin, cout, k, stride=stride, padding=k // 2).cuda()      # second tower: the paired launch
+    with torch.no_grad():
+        x = (torch.randn(hw[0], hw[1], cin, device="cuda") * 1.5 + 0.3).half()
+
+        def run(acc):
+            conv_hip._arena = conv_hip._AccArena(x.device) if acc else None
+            try:
+                pa = conv_hip.conv2d_towers([dict(x=x, conv=conv_a, want_stats=True), dict(x=x, conv=dummy)], half=True)[0]
+                assert (pa.acc is not None) == acc
+                pb = conv_hip.conv2d_towers([dict(x=pa, conv=conv_b, want_stats=True), dict(x=pa.raw, conv=conv_b)], half=True)[0]
+                out = conv_hip.norm_add_relu(pb, pa.raw)
+                return pa, pb, out
+            finally:
+                conv_hip._arena = None
+
+        ca, cb, cout_ = run(False)
+        aa, ab, aout = run(True)
+        assert torch.equal(aa.raw, ca.raw)
+        for acc_p, ref_p in ((aa, ca), (ab, cb)):
+            sc, sh = acc_p.scale, acc_p.shift                  # (a finalize launch of its own, from the accumulators)
+            assert float((sc - ref_p.scale).abs().max()) <= 2e-6 * float(ref_p.scale.abs().max())
+            assert float((sh - ref_p.shift).abs().max()) <= 2e-6 * max(1.0, float(ref_p.shift.abs().max()))
+        # the consumers: same values up to the rounding of (scale, shift)
+        assert float((ab.raw.float() - cb.raw.float()).abs().max()) <= 2e-3 * float(cb.raw.float().abs().max())
+        assert float((aout.float() - cout_.float()).abs().max()) <= 4e-3 * float(cout_.float().abs().max())
+        for _ in range(3):
+            ra, rb, rout = run(True)
+            assert torch.equal(ra.acc, aa.acc) and (ab.acc is None or torch.equal(rb.acc, ab.acc))   # (None: a layer shape on the per-tower kernel)
+            assert torch.equal(rb.raw, ab.raw) and torch.equal(rout, aout)
+
+
 ENC_HIP_VS_ATEN_TOL = 4e-5  # fp32 HIP encoder against the ATen forward of the same modules, x the map's largest entry (measured 4.9e-6 / 9.4e-6)
 FP8_LAYER_TOL = 2e-3        # x the output scale: what is left after both sides use the SAME e4m3-rounded operands
 FP8_ENCODER_TOL = 0.2       # max abs error of fmap / imap against the f16-MFMA towers, x the map's largest entry (measured: 0.07-0.125)
