@@ -921,7 +921,20 @@ __global__ void __launch_bounds__(256)
 __device__ __forceinline__ float lm_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
 __device__ __forceinline__ float lm_tanh(float x) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f; }
 
-__global__ void __launch_bounds__(256)
+// LDSW: the 104 weight fragments per lane sit in LDS (26 KB per workgroup) instead of registers: <= 64 VGPRs, so a wave of
+// this kernel fits on a SIMD next to the two 222-VGPR waves of the update operator's gru launch -- behind the gate the two
+// launches otherwise TIME-SHARE the chip -- and eight of them fit when it runs alone
+// The recurrent state is read once and written once per frame (120 MB): streamed with the nontemporal hint, so that it
+// does not push the update operator's weights -- which the gru launch on the other stream streams from L2 -- out of the L2
+#ifdef LM_CACHED
+#define LM_LD(p) (*(p))
+#define LM_ST(v, p) (*(p) = (v))
+#else
+#define LM_LD(p) __builtin_nontemporal_load(p)
+#define LM_ST(v, p) __builtin_nontemporal_store((v), (p))
+#endif
+template <bool LDSW>
+__global__ void __launch_bounds__(256, LDSW ? 8 : 1)
     lstm_superstate_mfma_kernel(const float *__restrict__ ev, const float *__restrict__ im,
                                 float *__restrict__ h_ev, float *__restrict__ c_ev,
                                 float *__restrict__ h_im, float *__restrict__ c_im,
@@ -931,18 +944,26 @@ __global__ void __launch_bounds__(256)
   const int lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
   const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int ntile = (HW + 15) / 16;
-  // weights: one float per lane per fragment, held for every tile of this wave
-  float a_ev[24], a_im[20], a_ss[8], b_ev[16], b_im[16], b_ss[4];
+  // weights: one float per lane per fragment -- in registers for every tile of this wave, or (LDSW) in LDS
+  __shared__ float s_wf[LDSW ? LM_TOTAL * 64 : 1];
+  float a_ev[LDSW ? 1 : 24], a_im[LDSW ? 1 : 20], a_ss[LDSW ? 1 : 8], b_ev[LDSW ? 1 : 16], b_im[LDSW ? 1 : 16], b_ss[LDSW ? 1 : 4];
+  if constexpr (LDSW) {
+    for (int i = threadIdx.x; i < LM_TOTAL * 64 / 4; i += 256)
+      reinterpret_cast<float4 *>(s_wf)[i] = reinterpret_cast<const float4 *>(Wf)[i];
+    __syncthreads();
+  } else {
 #pragma unroll
-  for (int f = 0; f < 24; f++) a_ev[f] = Wf[(LM_EV + f) * 64 + lane];
+    for (int f = 0; f < 24; f++) a_ev[f] = Wf[(LM_EV + f) * 64 + lane];
 #pragma unroll
-  for (int f = 0; f < 20; f++) a_im[f] = Wf[(LM_IM + f) * 64 + lane];
+    for (int f = 0; f < 20; f++) a_im[f] = Wf[(LM_IM + f) * 64 + lane];
 #pragma unroll
-  for (int f = 0; f < 8; f++) a_ss[f] = Wf[(LM_SS + f) * 64 + lane];
+    for (int f = 0; f < 8; f++) a_ss[f] = Wf[(LM_SS + f) * 64 + lane];
 #pragma unroll
-  for (int f = 0; f < 16; f++) { b_ev[f] = Wf[(LM_BEV + f) * 64 + lane]; b_im[f] = Wf[(LM_BIM + f) * 64 + lane]; }
+    for (int f = 0; f < 16; f++) { b_ev[f] = Wf[(LM_BEV + f) * 64 + lane]; b_im[f] = Wf[(LM_BIM + f) * 64 + lane]; }
 #pragma unroll
-  for (int f = 0; f < 4; f++) b_ss[f] = Wf[(LM_BSS + f) * 64 + lane];
+    for (int f = 0; f < 4; f++) b_ss[f] = Wf[(LM_BSS + f) * 64 + lane];
+  }
+  auto WA = [&](int base, int f, const float *reg) -> float { if constexpr (LDSW) return s_wf[(base + f) * 64 + lane]; else return reg[f]; };
   int f_ev, f_im;
   if (nblk > 0) {
     // per-workgroup results of any_nonzero_kernel ([2][ANY_MAXB], the first nblk of each row): every wave ORs them
@@ -970,28 +991,28 @@ __global__ void __launch_bounds__(256)
       // B operand: K-steps 0..3 = h (unit 4s+q), then the input channels
       float bk[6];
 #pragma unroll
-      for (int s4 = 0; s4 < 4; s4++) bk[s4] = has_state ? hs[sbase + 64 * s4] : 0.0f;
+      for (int s4 = 0; s4 < 4; s4++) bk[s4] = has_state ? LM_LD(hs + sbase + 64 * s4) : 0.0f;
 #pragma unroll
       for (int s4 = 4; s4 < 6; s4++) {
         const int ch = 4 * (s4 - 4) + q;
-        bk[s4] = (ch < CIN && pv) ? xin[(size_t)ch * HW + p] : 0.0f;
+        bk[s4] = (ch < CIN && pv) ? LM_LD(xin + (size_t)ch * HW + p) : 0.0f;
       }
       float cold[4];
 #pragma unroll
-      for (int t = 0; t < 4; t++) cold[t] = has_state ? cs[sbase + 64 * t] : 0.0f;
+      for (int t = 0; t < 4; t++) cold[t] = has_state ? LM_LD(cs + sbase + 64 * t) : 0.0f;
 #pragma unroll
       for (int t = 0; t < 4; t++) {
         f32x4 acc;
 #pragma unroll
-        for (int r = 0; r < 4; r++) acc[r] = mod == 0 ? b_ev[t * 4 + r] : b_im[t * 4 + r];
+        for (int r = 0; r < 4; r++) acc[r] = mod == 0 ? WA(LM_BEV, t * 4 + r, b_ev) : WA(LM_BIM, t * 4 + r, b_im);
         if (mod == 0) {
 #pragma unroll
           for (int s4 = 0; s4 < 6; s4++)
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_ev[t * 6 + s4], bk[s4], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(WA(LM_EV, t * 6 + s4, a_ev), bk[s4], acc, 0, 0, 0);
         } else {
 #pragma unroll
           for (int s4 = 0; s4 < 5; s4++)
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_im[t * 5 + s4], bk[s4], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(WA(LM_IM, t * 5 + s4, a_im), bk[s4], acc, 0, 0, 0);
         }
         // acc = (i, f, g, o) pre-activations of unit 4t+q, pixel j (torch gate order i, f, g, o)
         const float ig = lm_sigmoid(acc[0]), fg = lm_sigmoid(acc[1]), gg = lm_tanh(acc[2]), og = lm_sigmoid(acc[3]);
@@ -999,8 +1020,8 @@ __global__ void __launch_bounds__(256)
         const float hv = og * lm_tanh(cn);
         const bool unit_ok = 4 * t + q < 15;
         hn[mod][t] = unit_ok ? hv : 0.0f;
-        cs[sbase + 64 * t] = unit_ok ? cn : 0.0f;
-        hs[sbase + 64 * t] = hn[mod][t];
+        LM_ST(unit_ok ? cn : 0.0f, cs + sbase + 64 * t);
+        LM_ST(hn[mod][t], hs + sbase + 64 * t);
       }
     }
     // super-state: channels 4q..4q+3 of pixel j
@@ -1011,12 +1032,12 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int mod = 0; mod < 2; mod++) {
       if (!(mod == 0 ? f_ev : f_im)) continue;       // uniform
-      f32x4 acc = (f32x4){b_ss[0], b_ss[1], b_ss[2], b_ss[3]};
+      f32x4 acc = (f32x4){WA(LM_BSS, 0, b_ss), WA(LM_BSS, 1, b_ss), WA(LM_BSS, 2, b_ss), WA(LM_BSS, 3, b_ss)};
 #pragma unroll
-      for (int s4 = 0; s4 < 4; s4++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_ss[s4], sreg[s4], acc, 0, 0, 0);
+      for (int s4 = 0; s4 < 4; s4++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(WA(LM_SS, s4, a_ss), sreg[s4], acc, 0, 0, 0);
 #pragma unroll
       for (int t = 0; t < 4; t++)
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_ss[4 + t], hn[mod][t], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(WA(LM_SS, 4 + t, a_ss), hn[mod][t], acc, 0, 0, 0);
       sreg = acc;
     }
     if (pv) *sp = make_float4(sreg[0], sreg[1], sreg[2], q == 3 ? 0.0f : sreg[3]);
@@ -1227,10 +1248,17 @@ int ramp_lstm_superstate_blocks(const float *ev, const float *im, float *h_ev, f
   if (HW <= 0 || !ev || !im || !h_ev || !c_ev || !h_im || !c_im || !ss || !wfrag || !flags || nblk < 0 || nblk > ANY_MAXB)
     return RAMP_EINVAL;
   const int ntile = ramp_cdiv(HW, 16);
-  const int tpw = ntile >= 8192 ? 4 : 1;           // tiles per wave: amortise the 104 weight registers
-  hipLaunchKernelGGL(lstm_superstate_mfma_kernel, dim3(ramp_cdiv(ntile, 4 * tpw)), dim3(256), 0,
-                     (hipStream_t)stream, ev, im, h_ev, c_ev, h_im, c_im, ss, wfrag, flags, HW, has_state,
-                     has_ss, tpw, nblk);
+  const int tpw = ntile >= 8192 ? 4 : 1;           // tiles per wave: amortise the 104 weight fragments
+  static int ldsw = -1;                            // RAMP_LSTM_LDSW=0: weights in registers (A/B runs)
+  if (ldsw < 0) { const char *ev_ = getenv("RAMP_LSTM_LDSW"); ldsw = ev_ ? atoi(ev_) : 1; }
+  if (ldsw)
+    hipLaunchKernelGGL(lstm_superstate_mfma_kernel<true>, dim3(ramp_cdiv(ntile, 4 * tpw)), dim3(256), 0,
+                       (hipStream_t)stream, ev, im, h_ev, c_ev, h_im, c_im, ss, wfrag, flags, HW, has_state,
+                       has_ss, tpw, nblk);
+  else
+    hipLaunchKernelGGL(lstm_superstate_mfma_kernel<false>, dim3(ramp_cdiv(ntile, 4 * tpw)), dim3(256), 0,
+                       (hipStream_t)stream, ev, im, h_ev, c_ev, h_im, c_im, ss, wfrag, flags, HW, has_state,
+                       has_ss, tpw, nblk);
   RAMP_CHECK_LAUNCH();
   return RAMP_OK;
 }

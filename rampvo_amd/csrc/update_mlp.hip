@@ -279,8 +279,10 @@ __device__ long long g_gru_trace[32 * 4096];
 __global__ void __launch_bounds__(64 * MWAVES) upd_gru_kernel(const GruParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   _Float16 *Xs = reinterpret_cast<_Float16 *>(smem_raw);            // [64][MXS]
-  _Float16 *Hs = Xs + MBM * MXS;                                    // [64][MXS]
-  _Float16 *Gs = Hs + MBM * MXS;                                    // [64][MXS]: sigmoid(gate)
+  _Float16 *Hs = Xs;                                                // the hidden tile takes x's place (x is dead after the second
+                                                                    // K loop): 104 KB instead of 154, so that a workgroup of the
+                                                                    // front end's LSTM launch (22 KB) fits on the CU beside this one
+  _Float16 *Gs = Xs + MBM * MXS;                                    // [64][MXS]: sigmoid(gate)
   float *T1 = reinterpret_cast<float *>(Gs + MBM * MXS), *T2 = T1 + MBM * MWAVES;   // LayerNorm partials
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
   const int row0 = blockIdx.x * MBM;
@@ -358,6 +360,7 @@ __global__ void __launch_bounds__(64 * MWAVES) upd_gru_kernel(const GruParams p)
 #pragma unroll
         for (int i = 0; i < 4; i++) acc[0][mt][nt][i] = fmaxf(acc[0][mt][nt][i] + b1[i], 0.f);
     }
+    __syncthreads();                            // every wave is past its reads of x: h takes its place
     to_lds(Hs, acc[0]);
     __syncthreads();
     GT(5 + 8 * stage);
@@ -400,7 +403,7 @@ __global__ void __launch_bounds__(64 * MWAVES) upd_gru_kernel(const GruParams p)
       if (p.heads_w) {                            // (uniform)
         // d / w heads: 4 dot products of relu(result) (a half tensor) with the head rows, per row of the tile.  A lane
         // sums its 12 columns, the four quarter-lanes of a row meet over two shuffles, the eight waves over an LDS table
-        // in the x tile (dead since the barrier that published h); fixed order throughout.
+        // in the x / h tile (behind a barrier: the last K loop read it); fixed order throughout.
         float part[4][4];
 #pragma unroll
         for (int mt = 0; mt < 4; mt++)
@@ -417,6 +420,7 @@ __global__ void __launch_bounds__(64 * MWAVES) upd_gru_kernel(const GruParams p)
               for (int i = 0; i < 4; i++) part[mt][c] += h_round(fmaxf(res[mt][nt][i], 0.f)) * (float)wv[i];
           }
         float *HT = reinterpret_cast<float *>(Xs);              // [64 rows][8 waves][4]
+        __syncthreads();                                        // every wave is past its reads of h (the x / h tile)
 #pragma unroll
         for (int mt = 0; mt < 4; mt++)
 #pragma unroll
@@ -1367,7 +1371,7 @@ int ramp_i_upd_gru(const float *x32, const void *add_t, const int32_t *add_idx, 
   p.ln_w = ln_w; p.ln_b = ln_b; p.eps = eps; p.out32 = out32; p.relu_t = (_Float16 *)relu_t; p.E = E; p.dyn = dyn;
   p.heads_w = (const _Float16 *)heads_w; p.heads_b = heads_b; p.coords = coords; p.target = target; p.weight = weight;
   p.PP = P * P; p.ctr = (P / 2) * P + P / 2; p.wd = wd; p.ht = ht;
-  const size_t lds = (size_t)3 * MBM * MXS * 2 + 2 * MBM * MWAVES * sizeof(float);   // x, h, sigmoid(gate) tiles + the LayerNorm tables
+  const size_t lds = (size_t)2 * MBM * MXS * 2 + 2 * MBM * MWAVES * sizeof(float);   // x / h and sigmoid(gate) tiles + the LayerNorm tables
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void *)upd_gru_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
