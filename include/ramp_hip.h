@@ -654,6 +654,9 @@ typedef struct ramp_track {
  * once (no effect on any value; `sink` [1] is never written in practice).  Meant for the front-end stream, in the slack
  * behind the front end.                                                                                            */
 int ramp_track_warm(const ramp_track *t, int32_t *sink, void *stream);
+/* holds `stream` back for about `microseconds` with one sleeping wave (frame pipelining: the next frame's encoder
+ * should reach the chip a little behind the gru launch)                                         */
+int ramp_stream_delay(int microseconds, void *stream);
 
 size_t ramp_track_sizeof(void);      /* sizeof(ramp_track): lets a binding check its mirror of the struct */
 size_t ramp_track_plan_workspace_bytes(int E_cap, int kkey_cap, int pkey_cap);

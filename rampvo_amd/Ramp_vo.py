@@ -42,6 +42,7 @@ from .net import GraphPlan, VONet
 from .utils import Timer, preprocess_input
 
 
+_FE_DELAY_US = int(os.environ.get("RAMP_FE_DELAY_US", "35"))     # A/B switch: 0 = the encoder graph right behind the selection
 _WARM = os.environ.get("RAMP_WARM", "1") != "0"     # A/B switch: the cache warm-up behind the front end
 
 
@@ -654,6 +655,12 @@ class Ramp_vo:
                 k_dev = self._upload(kq.astype(np.float32))
         return kq, k_dev
 
+    def _fe_delay(self):
+        """(on the front-end stream, behind the selection) hold the encoder graph back a little: its LSTM launch should not
+        arrive while the gru launch is still filling the chip (csrc/track.hip::trk_delay_kernel)"""
+        if _FE_DELAY_US > 0:
+            _lib.check(_lib.lib().ramp_stream_delay(_FE_DELAY_US, _lib.stream()), "ramp_stream_delay")
+
     # ----------------------------------------------------- device-resident steady state
     def _track_device(self, tstamp, input_, intrinsics):
         """one tracked frame without a device->host read: front end (hipGraph), then ONE C call that enqueues the frame
@@ -680,7 +687,7 @@ class Ramp_vo:
             with torch.cuda.stream(fe):
                 out = self.network.patchify(input_=input_, patches_per_image=self.cfg.PATCHES_PER_FRAME,
                                             event_bias=self.event_bias, reinit_hidden=False,
-                                            pre_replay=(lambda: fe.wait_event(self._ev_gate)) if ahead else None)
+                                            pre_replay=(lambda: fe.wait_event(self._ev_gate)) if ahead else self._fe_delay)
             self._ev_fe_done.record(fe)
             cur.wait_event(self._ev_fe_done)
             if _WARM:

@@ -117,6 +117,7 @@ SIGNATURES = {
     "ramp_track_plan": (c_i, [c_p, c_i, c_p]),
     "ramp_track_step": (c_i, [c_p, c_i, c_i64, c_i, c_i, c_p, c_p, c_p]),
     "ramp_track_warm": (c_i, [c_p, c_p, c_p]),
+    "ramp_stream_delay": (c_i, [c_i, c_p]),
 }
 
 _lib = None

@@ -284,7 +284,22 @@ __global__ void __launch_bounds__(256) trk_warm_kernel(const uint4 *__restrict__
   if (acc == 0x9e3779b9u) *sink = (int)acc;        // (keeps the loads)
 }
 
+// One wave that sleeps: holds the front-end stream back for `ticks` of the 100 MHz wall clock.  The next frame's LSTM
+// launch should reach the chip ~70 us behind the gru launch, not ~40: arriving while the gru launch is still filling
+// the CUs it takes them first, and gru finishes 45 us later (tools/corun_gru_lstm.py)
+__global__ void trk_delay_kernel(long ticks) {
+  const long t0 = wall_clock64();
+  while ((long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+
 extern "C" {
+
+int ramp_stream_delay(int microseconds, void *stream) {
+  if (microseconds <= 0) return RAMP_OK;
+  hipLaunchKernelGGL(trk_delay_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long)microseconds * 100);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
 
 int ramp_track_warm(const ramp_track *t, int32_t *sink, void *stream) {
   if (!trk_valid(t) || !sink || !t->fmap1 || !t->fmap2 || !t->gmap) return RAMP_EINVAL;

@@ -75,6 +75,29 @@ for name, fn in variants.items():
         g_end, l_end = both(order)
         print("co-runner %-22s (%s): gru done after %.1f us, co-runner after %.1f us" % (name, order.replace("lstm", "co-runner"), g_end, l_end))
 lstm = _lstm_full
+# the LSTM step arriving d small launches (~5 us each) after gru has started, as in the frame (the selection runs first)
+tiny = torch.zeros(64, device="cuda")
+for d in (0, 2, 4, 8, 12, 16, 24):
+    def delayed(d=d):
+        for _ in range(d):
+            tiny.add_(1.0)
+        _lstm_full()
+    lstm = delayed
+    g_end, l_end = both("gru first")
+    print("LSTM step %2d small launches behind the gru launch: gru done after %.1f us, LSTM after %.1f us" % (d, g_end, l_end))
+lstm = _lstm_full
+# the same with the gru launch on a HIGH-priority stream (the LSTM's stream keeps the default priority)
+hi = torch.cuda.Stream(priority=-1)
+for d in (0, 4, 8):
+    def delayed(d=d):
+        for _ in range(d):
+            tiny.add_(1.0)
+        _lstm_full()
+    lstm = delayed
+    with torch.cuda.stream(hi):
+        g_end, l_end = both("gru first")
+    print("high-priority gru, LSTM step %2d small launches behind: gru done after %.1f us, LSTM after %.1f us" % (d, g_end, l_end))
+lstm = _lstm_full
 for order in ():
     g_end, l_end = both(order)
     print("launched together (%s): gru done after %.1f us, LSTM step done after %.1f us" % (order, g_end, l_end))
