@@ -324,7 +324,8 @@ int ramp_any_nonzero_blocks(const float *a, long na, const float *b, long nb, in
  * matrix cores (v_mfma_f32_16x16x4_f32, exact fp32 products): the three matrix-vector products per
  * pixel are batched over 16-pixel tiles.
  *   ev [5][HW], im [3][HW] planar float32
- *   h_ev,c_ev,h_im,c_im [ceil(HW/16)][16 units][16 px] tile-major recurrent state (in/out, unit 15 = 0)
+ *   h_ev,c_ev,h_im,c_im [ceil(HW/16)][16 px][4 q][4 t] tile-major recurrent state, unit = 4 t + q (in/out, unit 15 = 0):
+ *   a lane's four K-step operands / outputs are one 16-byte access
  *   ss [HW][16] channels-last super-state (in/out, channel 15 = 0)
  *   wfrag: per-lane MFMA fragments of the weights, rampvo_amd/conv_hip.py::pack_lstm_mfma
  *   flags[2]: events / image present (ramp_any_nonzero)

@@ -432,8 +432,9 @@ def multiscale_encoder4(enc, x, x2, x4, out_scale=1.0, half=False):
 
 # ------------------------------------------------------------------ LSTM / super-state
 class LstmState:
-    """recurrent state of the SingleScale front end.  h_*, c_*: tile-major [ceil(HW/16), 16 units,
-    16 px] (the MFMA kernel's layout; unit 15 is padding); ss: channels-last [HW, 16]."""
+    """recurrent state of the SingleScale front end.  h_*, c_*: tile-major [ceil(HW/16)][16 px][4 q][4 t], unit = 4 t + q
+    (the MFMA kernel's layout: a lane's four operands are 16 contiguous bytes; unit 15 is padding; held here as
+    [tiles, 16, 16]); ss: channels-last [HW, 16]."""
     __slots__ = ("h_ev", "c_ev", "h_im", "c_im", "ss", "flags", "fresh", "HW")
 
     def __init__(self, HW, device):
@@ -447,8 +448,8 @@ class LstmState:
 
     def rows(self, name):
         """state `name` as [HW, 15] rows (pixel-major), for inspection / tests"""
-        t = getattr(self, name)
-        return t.permute(0, 2, 1).reshape(-1, 16)[:self.HW, :15]
+        t = getattr(self, name)                     # [tile][16 px][4 q][4 t], unit = 4 t + q
+        return t.view(-1, 16, 4, 4).permute(0, 1, 3, 2).reshape(-1, 16)[:self.HW, :15]
 
 
 def lstm_superstate_step(enc, ev, im, st):

@@ -901,7 +901,7 @@ __global__ void __launch_bounds__(256)
 // The freedom in ordering rows and K columns is used so that nothing is ever shuffled:
 //   * gate rows are permuted so that output tile t, lane (q, j) holds (i, f, g, o) of unit 4t+q
 //     for pixel j in its four accumulator registers -> the cell update is lane-local;
-//   * the recurrent state is stored tile-major, [HW/16][16 units][16 px]: for a fixed t the wave
+//   * the recurrent state is stored tile-major, [HW/16][16 px][4 q][4 t] (unit 4 t + q; rounds 1-2: [HW/16][16 units][16 px]): for a fixed t the wave
 //     reads / writes one contiguous 256-byte run, and the same registers are the B operand of
 //     K-step t of the next gate product and of K-step 4+t of the super-state product;
 //   * the super-state K order is channel 4q+step, i.e. lane (q, j) feeds component `step` of the
@@ -981,25 +981,40 @@ __global__ void __launch_bounds__(256, LDSW ? 8 : 1)
     if (tile >= ntile) break;
     const int p = tile * 16 + j;
     const bool pv = p < HW;
-    const size_t sbase = (size_t)tile * 256 + lane;      // + 64 t : unit 4t+q, pixel j
+    // state layout [tile][pixel j][q][4]: the lane's units 4t+q, t = 0..3, are 16 contiguous bytes -- one load / store per
+    // array and lane (the [tile][unit][pixel] layout of rounds 1-2 moved 4 bytes per lane and instruction)
+    const size_t sbase = (size_t)tile * 256 + j * 16 + q * 4;
     float hn[2][4];                                       // new h of both modalities, per tile t
+    // every load of the tile goes out first (both modalities' h / c / inputs and the super-state): one HBM round trip
+    // per tile instead of three dependent ones
+    f32x4 hv4_[2], cold_[2];
+    float xin_[2][2];
+    float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 *sp = reinterpret_cast<float4 *>(ss + (size_t)p * 16) + q;
 #pragma unroll
     for (int mod = 0; mod < 2; mod++) {
       const float *xin = mod == 0 ? ev : im;
-      float *hs = mod == 0 ? h_ev : h_im, *cs = mod == 0 ? c_ev : c_im;
+      const float *hs = mod == 0 ? h_ev : h_im, *cs = mod == 0 ? c_ev : c_im;
       const int CIN = mod == 0 ? 5 : 3;
-      // B operand: K-steps 0..3 = h (unit 4s+q), then the input channels
-      float bk[6];
-#pragma unroll
-      for (int s4 = 0; s4 < 4; s4++) bk[s4] = has_state ? LM_LD(hs + sbase + 64 * s4) : 0.0f;
+      hv4_[mod] = has_state ? LM_LD(reinterpret_cast<const f32x4 *>(hs + sbase)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      cold_[mod] = has_state ? LM_LD(reinterpret_cast<const f32x4 *>(cs + sbase)) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s4 = 4; s4 < 6; s4++) {
         const int ch = 4 * (s4 - 4) + q;
-        bk[s4] = (ch < CIN && pv) ? LM_LD(xin + (size_t)ch * HW + p) : 0.0f;
+        xin_[mod][s4 - 4] = (ch < CIN && pv) ? LM_LD(xin + (size_t)ch * HW + p) : 0.0f;
       }
-      float cold[4];
+    }
+    if (has_ss && pv) sv = *sp;
 #pragma unroll
-      for (int t = 0; t < 4; t++) cold[t] = has_state ? LM_LD(cs + sbase + 64 * t) : 0.0f;
+    for (int mod = 0; mod < 2; mod++) {
+      float *hs = mod == 0 ? h_ev : h_im, *cs = mod == 0 ? c_ev : c_im;
+      // B operand: K-steps 0..3 = h (unit 4s+q), then the input channels
+      float bk[6];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; s4++) bk[s4] = hv4_[mod][s4];
+      bk[4] = xin_[mod][0]; bk[5] = xin_[mod][1];
+      const f32x4 cold = cold_[mod];
+      f32x4 cnew, hnew;
 #pragma unroll
       for (int t = 0; t < 4; t++) {
         f32x4 acc;
@@ -1020,14 +1035,13 @@ __global__ void __launch_bounds__(256, LDSW ? 8 : 1)
         const float hv = og * lm_tanh(cn);
         const bool unit_ok = 4 * t + q < 15;
         hn[mod][t] = unit_ok ? hv : 0.0f;
-        LM_ST(unit_ok ? cn : 0.0f, cs + sbase + 64 * t);
-        LM_ST(hn[mod][t], hs + sbase + 64 * t);
+        cnew[t] = unit_ok ? cn : 0.0f;
+        hnew[t] = hn[mod][t];
       }
+      LM_ST(cnew, reinterpret_cast<f32x4 *>(cs + sbase));
+      LM_ST(hnew, reinterpret_cast<f32x4 *>(hs + sbase));
     }
-    // super-state: channels 4q..4q+3 of pixel j
-    float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 *sp = reinterpret_cast<float4 *>(ss + (size_t)p * 16) + q;
-    if (has_ss && pv) sv = *sp;
+    // super-state: channels 4q..4q+3 of pixel j (loaded above)
     f32x4 sreg = (f32x4){sv.x, sv.y, sv.z, sv.w};
 #pragma unroll
     for (int mod = 0; mod < 2; mod++) {
