@@ -42,6 +42,24 @@ from .net import GraphPlan, VONet
 from .utils import Timer, preprocess_input
 
 
+_CUS = {}
+
+
+def _gru_tile_rows(E, device):
+    """rows per workgroup ramp_upd_gru picks for E factors (csrc/update_mlp.hip: the tile that needs fewer rounds of one
+    workgroup per CU)"""
+    forced = os.environ.get("RAMP_GRU_MT")
+    if forced in ("4", "5"):
+        return 16 * int(forced)
+    key = str(device)
+    if key not in _CUS:
+        _CUS[key] = torch.cuda.get_device_properties(device).multi_processor_count
+    cus = _CUS[key]
+    r4 = -(-(-(-E // 64)) // cus) * 4
+    r5 = -(-(-(-E // 80)) // cus) * 5
+    return 80 if r5 < r4 else 64
+
+
 _FE_DELAY_US = int(os.environ.get("RAMP_FE_DELAY_US", "35"))     # A/B switch: 0 = the encoder graph right behind the selection
 _WARM = os.environ.get("RAMP_WARM", "1") != "0"     # A/B switch: the cache warm-up behind the front end
 
@@ -679,9 +697,14 @@ class Ramp_vo:
             # previous frame from the gru chain on (the event is recorded inside ramp_track_step)
             # (the staging copies and the patch selection go out ahead of the gate: they depend on the input alone)
             fe = self._fe_stream
-            ahead = os.environ.get("RAMP_SELECT_AHEAD", "0") == "1"       # A/B switch: 1 = the selection ahead of the gate
-            # (measured: 899 vs 918 kf/s -- the heavy front-end kernels then start WITH the gru chain instead of 40 us
-            # behind it, and that contention costs more than the 40 us; the default runs the selection behind the gate)
+            # Where the encoder graph starts relative to the gru launch depends on that launch's tile (csrc/update_mlp.hip
+            # picks 64 or 80 rows per workgroup by the factor count, tools/corun_gru_lstm.py): with 80-row tiles (two full
+            # rounds of one workgroup per CU, 254 VGPRs) the front end's LSTM launch cannot take a CU from it, so the
+            # selection goes out AHEAD of the gate and the graph right behind it; with 64-row tiles an LSTM launch that
+            # arrives within ~40 us costs gru 45 us, so the selection runs behind the gate and the graph is held back
+            # another 35 us (_fe_delay).  RAMP_SELECT_AHEAD=0|1 forces either.
+            env = os.environ.get("RAMP_SELECT_AHEAD")
+            ahead = (env == "1") if env is not None else _gru_tile_rows(dv.factor_bound(self.counter), self.device) == 80
             if not ahead:
                 fe.wait_event(self._ev_gate)
             with torch.cuda.stream(fe):

@@ -41,14 +41,14 @@ __device__ __forceinline__ float sigm(float x) { return __builtin_amdgcn_rcpf(1.
 // acc[mt][nt] += Xs[64 x 384] * W^T for this wave's 48 columns; NB weight matrices share the A reads
 // SWAP: operands exchanged -> the accumulators hold the TRANSPOSED tile (lane (q, j): row j of the 16-row tile,
 // columns 4q..4q+3 of the 16-column tile), i.e. four consecutive output columns per lane for direct row-major stores
-template <int NB, bool SWAP = false, int PF = MLP_PREFETCH_DEFAULT>
+template <int NB, bool SWAP = false, int PF = MLP_PREFETCH_DEFAULT, int MT = 4>
 __device__ __forceinline__ void mlp_gemm(const _Float16 *Xs, const _Float16 *const (&wp)[NB], int wave, int lane,
-                                         f4 (&acc)[NB][4][MNTW]) {
+                                         f4 (&acc)[NB][MT][MNTW]) {
   const int q = lane >> 4, j = lane & 15;
 #pragma unroll
   for (int b = 0; b < NB; b++)
 #pragma unroll
-    for (int mt = 0; mt < 4; mt++)
+    for (int mt = 0; mt < MT; mt++)
 #pragma unroll
       for (int nt = 0; nt < MNTW; nt++) acc[b][mt][nt] = (f4){0.f, 0.f, 0.f, 0.f};
 #ifndef MLP_UNROLL
@@ -58,13 +58,13 @@ __device__ __forceinline__ void mlp_gemm(const _Float16 *Xs, const _Float16 *con
     return *reinterpret_cast<const h8 *>(wp[b] + (((size_t)ks * (MD / 16) + wave * MNTW + nt) * 64 + lane) * 8);
   };
   auto mma = [&](int ks, h8 (&bw)[NB][MNTW]) {
-    h8 a[4];
+    h8 a[MT];
 #pragma unroll
-    for (int mt = 0; mt < 4; mt++) a[mt] = *reinterpret_cast<const h8 *>(Xs + (mt * 16 + j) * MXS + ks * 32 + 8 * q);
+    for (int mt = 0; mt < MT; mt++) a[mt] = *reinterpret_cast<const h8 *>(Xs + (mt * 16 + j) * MXS + ks * 32 + 8 * q);
 #pragma unroll
     for (int b = 0; b < NB; b++)
 #pragma unroll
-      for (int mt = 0; mt < 4; mt++)
+      for (int mt = 0; mt < MT; mt++)
 #pragma unroll
         for (int nt = 0; nt < MNTW; nt++)
           acc[b][mt][nt] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_f16(bw[b][nt], a[mt], acc[b][mt][nt], 0, 0, 0)
@@ -214,11 +214,12 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 // rows 16 mt + j, columns 48 w + 16 nt + 4 q + {0..3}): per-wave partial sums meet in an LDS table [64 rows][8 waves],
 // every lane then adds the eight partials of its rows in wave order.  Same arithmetic as row_ln (mean, then the
 // variance of the deviations); the order of the additions differs.
-__device__ __forceinline__ void tile_ln(f4 (&v)[4][MNTW], const float *__restrict__ w, const float *__restrict__ b,
+template <int MT>
+__device__ __forceinline__ void tile_ln(f4 (&v)[MT][MNTW], const float *__restrict__ w, const float *__restrict__ b,
                                         float eps, float *T1, float *T2, int wave, int q, int j, int col0) {
-  float mean[4], rstd[4];
+  float mean[MT], rstd[MT];
 #pragma unroll
-  for (int mt = 0; mt < 4; mt++) {
+  for (int mt = 0; mt < MT; mt++) {
     float s = 0.f;
 #pragma unroll
     for (int nt = 0; nt < MNTW; nt++) s += (v[mt][nt][0] + v[mt][nt][1]) + (v[mt][nt][2] + v[mt][nt][3]);
@@ -228,7 +229,7 @@ __device__ __forceinline__ void tile_ln(f4 (&v)[4][MNTW], const float *__restric
   }
   __syncthreads();
 #pragma unroll
-  for (int mt = 0; mt < 4; mt++) {
+  for (int mt = 0; mt < MT; mt++) {
     const f4 a = *reinterpret_cast<const f4 *>(T1 + (mt * 16 + j) * MWAVES), c = *reinterpret_cast<const f4 *>(T1 + (mt * 16 + j) * MWAVES + 4);
     mean[mt] = ((((((a[0] + a[1]) + a[2]) + a[3]) + c[0]) + c[1]) + c[2] + c[3]) * (1.0f / MD);
     float s = 0.f;
@@ -245,7 +246,7 @@ __device__ __forceinline__ void tile_ln(f4 (&v)[4][MNTW], const float *__restric
   }
   __syncthreads();
 #pragma unroll
-  for (int mt = 0; mt < 4; mt++) {
+  for (int mt = 0; mt < MT; mt++) {
     const f4 a = *reinterpret_cast<const f4 *>(T2 + (mt * 16 + j) * MWAVES), c = *reinterpret_cast<const f4 *>(T2 + (mt * 16 + j) * MWAVES + 4);
     rstd[mt] = 1.0f / sqrtf(((((((a[0] + a[1]) + a[2]) + a[3]) + c[0]) + c[1]) + c[2] + c[3]) * (1.0f / MD) + eps);
   }
@@ -253,7 +254,7 @@ __device__ __forceinline__ void tile_ln(f4 (&v)[4][MNTW], const float *__restric
   for (int nt = 0; nt < MNTW; nt++) {
     const f4 wv = *reinterpret_cast<const f4 *>(w + col0 + nt * 16 + 4 * q), bv = *reinterpret_cast<const f4 *>(b + col0 + nt * 16 + 4 * q);
 #pragma unroll
-    for (int mt = 0; mt < 4; mt++)
+    for (int mt = 0; mt < MT; mt++)
 #pragma unroll
       for (int i = 0; i < 4; i++) v[mt][nt][i] = (v[mt][nt][i] - mean[mt]) * rstd[mt] * wv[i] + bv[i];
   }
@@ -276,16 +277,19 @@ __device__ long long g_gru_trace[32 * 4096];
 //     two waves per SIMD cannot cover it).  The gate does not stay in registers across the other two loops: its
 //     sigmoid (a half tensor under the reference's autocast) waits in the third LDS tile, every lane reading back
 //     exactly the elements it wrote.
+template <int MT>
 __global__ void __launch_bounds__(64 * MWAVES) upd_gru_kernel(const GruParams p) {
+  constexpr int ROWS = 16 * MT;                 // rows per workgroup: 64, or 80 when that saves a round of workgroups (one per CU:
+                                                // 40k factors are 625 tiles of 64 rows = 2.44 rounds of 256, or 500 of 80 = 1.95)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   _Float16 *Xs = reinterpret_cast<_Float16 *>(smem_raw);            // [64][MXS]
   _Float16 *Hs = Xs;                                                // the hidden tile takes x's place (x is dead after the second
                                                                     // K loop): 104 KB instead of 154, so that a workgroup of the
                                                                     // front end's LSTM launch (22 KB) fits on the CU beside this one
-  _Float16 *Gs = Xs + MBM * MXS;                                    // [64][MXS]: sigmoid(gate)
-  float *T1 = reinterpret_cast<float *>(Gs + MBM * MXS), *T2 = T1 + MBM * MWAVES;   // LayerNorm partials
+  _Float16 *Gs = Xs + ROWS * MXS;                                    // [64][MXS]: sigmoid(gate)
+  float *T1 = reinterpret_cast<float *>(Gs + ROWS * MXS), *T2 = T1 + ROWS * MWAVES;   // LayerNorm partials
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
-  const int row0 = blockIdx.x * MBM;
+  const int row0 = blockIdx.x * ROWS;
   const int pE = p.dyn ? p.dyn[RAMP_DYN_E] : p.E;
   if (row0 >= pE) return;                      // (workgroup-uniform: only with device-side sizes)
   const int col0 = wave * (16 * MNTW);
@@ -293,10 +297,10 @@ __global__ void __launch_bounds__(64 * MWAVES) upd_gru_kernel(const GruParams p)
 
   GT(0);
   // ---- the residual stream, fp32, in registers (rows past E: clamped loads, no stores)
-  f4 res[4][MNTW];
-  size_t roff[4];
+  f4 res[MT][MNTW];
+  size_t roff[MT];
 #pragma unroll
-  for (int mt = 0; mt < 4; mt++) {
+  for (int mt = 0; mt < MT; mt++) {
     const int row = row0 + mt * 16 + j;
     roff[mt] = (size_t)(row < pE ? row : pE - 1) * MD;
 #pragma unroll
@@ -304,7 +308,7 @@ __global__ void __launch_bounds__(64 * MWAVES) upd_gru_kernel(const GruParams p)
   }
   if (p.add_t) {                                // uniform
 #pragma unroll
-    for (int mt = 0; mt < 4; mt++) {
+    for (int mt = 0; mt < MT; mt++) {
       const _Float16 *a = p.add_t + (size_t)p.add_idx[roff[mt] / MD] * MD;
 #pragma unroll
       for (int nt = 0; nt < MNTW; nt++) {
@@ -313,11 +317,11 @@ __global__ void __launch_bounds__(64 * MWAVES) upd_gru_kernel(const GruParams p)
         for (int i = 0; i < 4; i++) res[mt][nt][i] += (float)v[i];
       }
     }
-    tile_ln(res, p.pre_w, p.pre_b, p.pre_eps, T1, T2, wave, q, j, col0);
+    tile_ln<MT>(res, p.pre_w, p.pre_b, p.pre_eps, T1, T2, wave, q, j, col0);
   }
-  auto to_lds = [&](_Float16 *tile, const f4 (&v)[4][MNTW]) {
+  auto to_lds = [&](_Float16 *tile, const f4 (&v)[MT][MNTW]) {
 #pragma unroll
-    for (int mt = 0; mt < 4; mt++)
+    for (int mt = 0; mt < MT; mt++)
 #pragma unroll
       for (int nt = 0; nt < MNTW; nt++)
         *reinterpret_cast<h4 *>(tile + (mt * 16 + j) * MXS + cq + nt * 16) =
@@ -330,17 +334,17 @@ __global__ void __launch_bounds__(64 * MWAVES) upd_gru_kernel(const GruParams p)
 #pragma unroll 1
   for (int stage = 0; stage < 2; stage++) {
     const int wb = 3 * stage;
-    f4 acc[1][4][MNTW];
+    f4 acc[1][MT][MNTW];
     {
       const _Float16 *const w1[1] = {p.wp[wb + 0]};
-      mlp_gemm<1, true, GRU_PF>(Xs, w1, wave, lane, acc);
+      mlp_gemm<1, true, GRU_PF, MT>(Xs, w1, wave, lane, acc);
     }
     GT(2 + 8 * stage);
 #pragma unroll
     for (int nt = 0; nt < MNTW; nt++) {
       const f4 bg = *reinterpret_cast<const f4 *>(p.bias[wb + 0] + cq + nt * 16);
 #pragma unroll
-      for (int mt = 0; mt < 4; mt++)
+      for (int mt = 0; mt < MT; mt++)
 #pragma unroll
         for (int i = 0; i < 4; i++) acc[0][mt][nt][i] = sigm(h_round(acc[0][mt][nt][i] + bg[i]));
     }
@@ -348,7 +352,7 @@ __global__ void __launch_bounds__(64 * MWAVES) upd_gru_kernel(const GruParams p)
     GT(3 + 8 * stage);
     {
       const _Float16 *const w1[1] = {p.wp[wb + 1]};
-      mlp_gemm<1, true, GRU_PF>(Xs, w1, wave, lane, acc);
+      mlp_gemm<1, true, GRU_PF, MT>(Xs, w1, wave, lane, acc);
     }
     GT(4 + 8 * stage);
     // h = relu(L1 x + b1) -> Hs (fp16)
@@ -356,7 +360,7 @@ __global__ void __launch_bounds__(64 * MWAVES) upd_gru_kernel(const GruParams p)
     for (int nt = 0; nt < MNTW; nt++) {
       const f4 b1 = *reinterpret_cast<const f4 *>(p.bias[wb + 1] + cq + nt * 16);
 #pragma unroll
-      for (int mt = 0; mt < 4; mt++)
+      for (int mt = 0; mt < MT; mt++)
 #pragma unroll
         for (int i = 0; i < 4; i++) acc[0][mt][nt][i] = fmaxf(acc[0][mt][nt][i] + b1[i], 0.f);
     }
@@ -366,7 +370,7 @@ __global__ void __launch_bounds__(64 * MWAVES) upd_gru_kernel(const GruParams p)
     GT(5 + 8 * stage);
     {
       const _Float16 *const w1[1] = {p.wp[wb + 2]};
-      mlp_gemm<1, true, GRU_PF>(Hs, w1, wave, lane, acc);
+      mlp_gemm<1, true, GRU_PF, MT>(Hs, w1, wave, lane, acc);
     }
     GT(6 + 8 * stage);
     // residual += sigmoid(gate) * r     (gate and r are half tensors under the reference's autocast)
@@ -374,7 +378,7 @@ __global__ void __launch_bounds__(64 * MWAVES) upd_gru_kernel(const GruParams p)
     for (int nt = 0; nt < MNTW; nt++) {
       const f4 b2 = *reinterpret_cast<const f4 *>(p.bias[wb + 2] + cq + nt * 16);
 #pragma unroll
-      for (int mt = 0; mt < 4; mt++) {
+      for (int mt = 0; mt < MT; mt++) {
         const h4 g = *reinterpret_cast<const h4 *>(Gs + (mt * 16 + j) * MXS + cq + nt * 16);
 #pragma unroll
         for (int i = 0; i < 4; i++) res[mt][nt][i] += (float)g[i] * h_round(acc[0][mt][nt][i] + b2[i]);
@@ -384,12 +388,12 @@ __global__ void __launch_bounds__(64 * MWAVES) upd_gru_kernel(const GruParams p)
     if (stage == 0) {
       // gru[2]: LayerNorm -> the next residual (registers) and its fp16 copy (every wave is past its reads of x:
       // they ended before the barrier that published h)
-      tile_ln(res, p.ln_w, p.ln_b, p.eps, T1, T2, wave, q, j, col0);
+      tile_ln<MT>(res, p.ln_w, p.ln_b, p.eps, T1, T2, wave, q, j, col0);
       to_lds(Xs, res);
       __syncthreads();
     } else {
 #pragma unroll
-      for (int mt = 0; mt < 4; mt++) {
+      for (int mt = 0; mt < MT; mt++) {
         if (row0 + mt * 16 + j >= pE) continue;
 #pragma unroll
         for (int nt = 0; nt < MNTW; nt++) {
@@ -404,9 +408,9 @@ __global__ void __launch_bounds__(64 * MWAVES) upd_gru_kernel(const GruParams p)
         // d / w heads: 4 dot products of relu(result) (a half tensor) with the head rows, per row of the tile.  A lane
         // sums its 12 columns, the four quarter-lanes of a row meet over two shuffles, the eight waves over an LDS table
         // in the x / h tile (behind a barrier: the last K loop read it); fixed order throughout.
-        float part[4][4];
+        float part[MT][4];
 #pragma unroll
-        for (int mt = 0; mt < 4; mt++)
+        for (int mt = 0; mt < MT; mt++)
 #pragma unroll
           for (int c = 0; c < 4; c++) part[mt][c] = 0.f;
 #pragma unroll
@@ -415,14 +419,14 @@ __global__ void __launch_bounds__(64 * MWAVES) upd_gru_kernel(const GruParams p)
           for (int nt = 0; nt < MNTW; nt++) {
             const h4 wv = *reinterpret_cast<const h4 *>(p.heads_w + c * MD + cq + nt * 16);
 #pragma unroll
-            for (int mt = 0; mt < 4; mt++)
+            for (int mt = 0; mt < MT; mt++)
 #pragma unroll
               for (int i = 0; i < 4; i++) part[mt][c] += h_round(fmaxf(res[mt][nt][i], 0.f)) * (float)wv[i];
           }
         float *HT = reinterpret_cast<float *>(Xs);              // [64 rows][8 waves][4]
         __syncthreads();                                        // every wave is past its reads of h (the x / h tile)
 #pragma unroll
-        for (int mt = 0; mt < 4; mt++)
+        for (int mt = 0; mt < MT; mt++)
 #pragma unroll
           for (int c = 0; c < 4; c++) {
             float v = part[mt][c];
@@ -432,12 +436,12 @@ __global__ void __launch_bounds__(64 * MWAVES) upd_gru_kernel(const GruParams p)
           }
         if (q == 0) {
 #pragma unroll
-          for (int mt = 0; mt < 4; mt++)
+          for (int mt = 0; mt < MT; mt++)
             *reinterpret_cast<f4 *>(HT + ((mt * 16 + j) * MWAVES + wave) * 4) = (f4){part[mt][0], part[mt][1], part[mt][2], part[mt][3]};
         }
         __syncthreads();
         const int e = row0 + tid;
-        if (tid < MBM && e < pE) {
+        if (tid < ROWS && e < pE) {
           float o[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int w = 0; w < MWAVES; w++) {
@@ -1371,15 +1375,36 @@ int ramp_i_upd_gru(const float *x32, const void *add_t, const int32_t *add_idx, 
   p.ln_w = ln_w; p.ln_b = ln_b; p.eps = eps; p.out32 = out32; p.relu_t = (_Float16 *)relu_t; p.E = E; p.dyn = dyn;
   p.heads_w = (const _Float16 *)heads_w; p.heads_b = heads_b; p.coords = coords; p.target = target; p.weight = weight;
   p.PP = P * P; p.ctr = (P / 2) * P + P / 2; p.wd = wd; p.ht = ht;
-  const size_t lds = (size_t)2 * MBM * MXS * 2 + 2 * MBM * MWAVES * sizeof(float);   // x / h and sigmoid(gate) tiles + the LayerNorm tables
+  // rows per workgroup: whichever of 64 / 80 needs fewer rounds of one-workgroup-per-CU (ties: fewer row-rounds); with
+  // device-side sizes E is the launch bound, the live count is a little below it
+  static int mt_force = -1, cus = 0;
+  if (mt_force < 0) { const char *ev = getenv("RAMP_GRU_MT"); mt_force = ev ? atoi(ev) : 0; }
+  if (!cus) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+  }
+  int mt = 4;
+  if (mt_force == 4 || mt_force == 5) mt = mt_force;
+  else {
+    const long r4 = (long)ramp_cdiv(ramp_cdiv(E, 64), cus) * 4, r5 = (long)ramp_cdiv(ramp_cdiv(E, 80), cus) * 5;
+    mt = r5 < r4 ? 5 : 4;
+  }
+  const int rows = 16 * mt;
+  const size_t lds = (size_t)2 * rows * MXS * 2 + 2 * rows * MWAVES * sizeof(float);   // x / h and sigmoid(gate) tiles + the LayerNorm tables
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void *)upd_gru_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-        hipSuccess)
+    if (hipFuncSetAttribute((const void *)upd_gru_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)((size_t)2 * 64 * MXS * 2 + 2 * 64 * MWAVES * sizeof(float))) != hipSuccess ||
+        hipFuncSetAttribute((const void *)upd_gru_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)((size_t)2 * 80 * MXS * 2 + 2 * 80 * MWAVES * sizeof(float))) != hipSuccess)
       return RAMP_ELAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL(upd_gru_kernel, dim3(ramp_cdiv(E, MBM)), dim3(64 * MWAVES), lds, (hipStream_t)stream, p);
+  if (mt == 5)
+    hipLaunchKernelGGL(upd_gru_kernel<5>, dim3(ramp_cdiv(E, rows)), dim3(64 * MWAVES), lds, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(upd_gru_kernel<4>, dim3(ramp_cdiv(E, rows)), dim3(64 * MWAVES), lds, (hipStream_t)stream, p);
   RAMP_CHECK_LAUNCH();
   return RAMP_OK;
 }
