@@ -649,6 +649,8 @@ typedef struct ramp_track {
    * [0] before / [1] after the correlation kernel, [2] after the update operator's last chain (gru), [3] before /
    * [4] after bundle adjustment                                                                                  */
   void *probe[5];
+  int32_t E_hint;                     /* optional (> 0): the caller's estimate of the live factor count (E_bound is an upper
+                                       * bound): picks the gru launch's tile (64 / 80 rows per workgroup)                    */
 } ramp_track;
 
 /* cache warm-up for the next step's correlation kernel: reads the planes of the window's frames and the patch features

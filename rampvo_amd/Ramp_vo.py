@@ -704,7 +704,7 @@ class Ramp_vo:
             # arrives within ~40 us costs gru 45 us, so the selection runs behind the gate and the graph is held back
             # another 35 us (_fe_delay).  RAMP_SELECT_AHEAD=0|1 forces either.
             env = os.environ.get("RAMP_SELECT_AHEAD")
-            ahead = (env == "1") if env is not None else _gru_tile_rows(dv.factor_bound(self.counter), self.device) == 80
+            ahead = (env == "1") if env is not None else _gru_tile_rows(dv.factor_estimate(), self.device) == 80
             if not ahead:
                 fe.wait_event(self._ev_gate)
             with torch.cuda.stream(fe):

@@ -425,7 +425,7 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
     // (the heads and target / weight are formed in the gru launch's epilogue: no relu(net) round trip, one launch less)
     TRK_DO(ramp_i_upd_gru(net, t->hij, t->ij_gid, w.ln1_w, w.ln1_b, w.ln1_eps, w.gru_w, w.gru_b, w.ln2_w, w.ln2_b,
                           w.ln2_eps, t->net[0], nullptr, Eb, dyn, w.heads_w, w.heads_b, t->coords, t->target, t->weight, t->P,
-                          (float)t->feat_w, (float)t->feat_h, st));
+                          (float)t->feat_w, (float)t->feat_h, t->E_hint, st));
     TRK_PROBE(2);
     TRK_PROBE(3);
     TRK_DO(ramp_i_ba_dyn(t->poses, t->patches, t->intrinsics, t->target, t->weight, t->lmbda, ii, jj, kk, Eb, t->P,

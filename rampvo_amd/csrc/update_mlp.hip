@@ -1358,7 +1358,7 @@ int ramp_i_upd_gru(const float *x32, const void *add_t, const int32_t *add_idx, 
                  float pre_eps, const void *const *wp_host, const float *const *bias_host, const float *ln_w,
                  const float *ln_b, float eps, float *out32, void *relu_t, int E, const int32_t *dyn,
                  const void *heads_w, const float *heads_b, const float *coords, float *target, float *weight, int P,
-                 float wd, float ht, void *stream) {
+                 float wd, float ht, int E_hint, void *stream) {
   if (E < 0) return RAMP_EINVAL;
   if (E == 0) return RAMP_OK;
   if (!x32 || !wp_host || !bias_host || !ln_w || !ln_b || !out32 || (!relu_t && !heads_w)) return RAMP_EINVAL;
@@ -1387,7 +1387,8 @@ int ramp_i_upd_gru(const float *x32, const void *add_t, const int32_t *add_idx, 
   int mt = 4;
   if (mt_force == 4 || mt_force == 5) mt = mt_force;
   else {
-    const long r4 = (long)ramp_cdiv(ramp_cdiv(E, 64), cus) * 4, r5 = (long)ramp_cdiv(ramp_cdiv(E, 80), cus) * 5;
+    const int El = (E_hint > 0 && E_hint < E) ? E_hint : E;      // (device-side sizes: E is the launch bound, the hint the caller's estimate)
+    const long r4 = (long)ramp_cdiv(ramp_cdiv(El, 64), cus) * 4, r5 = (long)ramp_cdiv(ramp_cdiv(El, 80), cus) * 5;
     mt = r5 < r4 ? 5 : 4;
   }
   const int rows = 16 * mt;
@@ -1496,7 +1497,7 @@ int ramp_upd_gru(const float *x32, const void *add_t, const int32_t *add_idx, co
                  float pre_eps, const void *const *wp_host, const float *const *bias_host, const float *ln_w,
                  const float *ln_b, float eps, float *out32, void *relu_t, int E, void *stream) {
   return ramp_i_upd_gru(x32, add_t, add_idx, pre_w, pre_b, pre_eps, wp_host, bias_host, ln_w, ln_b, eps, out32, relu_t, E, nullptr,
-                        nullptr, nullptr, nullptr, nullptr, nullptr, 3, 0.f, 0.f, stream);
+                        nullptr, nullptr, nullptr, nullptr, nullptr, 3, 0.f, 0.f, 0, stream);
 }
 
 int ramp_upd_gru_heads(const float *x32, const void *add_t, const int32_t *add_idx, const float *pre_w, const float *pre_b,
@@ -1505,7 +1506,7 @@ int ramp_upd_gru_heads(const float *x32, const void *add_t, const int32_t *add_i
                        const float *coords, float *target, float *weight, int E, int P, float wd, float ht, void *stream) {
   if (!heads_w) return RAMP_EINVAL;
   return ramp_i_upd_gru(x32, add_t, add_idx, pre_w, pre_b, pre_eps, wp_host, bias_host, ln_w, ln_b, eps, out32, nullptr, E, nullptr,
-                        heads_w, heads_b, coords, target, weight, P, wd, ht, stream);
+                        heads_w, heads_b, coords, target, weight, P, wd, ht, 0, stream);
 }
 
 int ramp_upd_nbr(const float *net_in, const int64_t *idx, const void *wa, const float *ba, const void *wb,

@@ -6,6 +6,7 @@ keyframe count and the hidden state live on the GPU only: ``step()`` enqueues a 
 ramp/Ramp_vo.py:327-410: frame stores, update(), keyframe(), the next frame's append_factors) in one C call and never
 reads the device; ``leave()`` is the one synchronisation that hands the state back to the host mirror.
 """
+import collections
 import ctypes
 
 import numpy as np
@@ -50,7 +51,7 @@ class Track(ctypes.Structure):
                 + _ptr_fields(["coords", "corr"]) + [("net", c_p * 3)]
                 + _ptr_fields(["fg", "ykk", "hkk", "yij", "hij", "relu_t", "target", "weight", "ba_ws"])
                 + [("ba_ws_bytes", c_sz)]
-                + _ptr_fields(["mm", "dlog", "edit_ws", "dyn_host"]) + [("probe", c_p * 5)])
+                + _ptr_fields(["mm", "dlog", "edit_ws", "dyn_host"]) + [("probe", c_p * 5), ("E_hint", c_i)])
 
 
 def supported(slam):
@@ -107,6 +108,7 @@ class DeviceTrack:
         self.k_new = z(4, f32)
         self.cur = 0
         self.active = False
+        self._e_seen = collections.deque(maxlen=64)
         self._wkey = None
         self._fe_key = None
         self._keep = []
@@ -226,8 +228,17 @@ class DeviceTrack:
         lag = max(int(counter) - int(d[DYN_FRAME]), 1) + 1
         return min(int(d[DYN_E]) + lag * self.new_cap, self.E_cap)
 
+    def factor_estimate(self):
+        """the largest live factor count among the last 64 lazy copies of the sizes (the steady state oscillates by a
+        frame's worth around its level): picks tile sizes, bounds nothing"""
+        e = int(self.dyn_host.numpy()[DYN_E])
+        if not self._e_seen or self._e_seen[-1] != e:
+            self._e_seen.append(e)
+        return int(min(max(self._e_seen), self.E_cap))
+
     def step(self, counter, flags, k_new=None, gate_event=None):
         ev = ctypes.c_void_p(gate_event) if gate_event else None
+        self.t.E_hint = self.factor_estimate()
         _lib.check(_lib.lib().ramp_track_step(ctypes.byref(self.t), self.cur, int(counter), int(flags),
                                               self.factor_bound(counter), _lib.ptr(k_new), ev, _lib.stream()),
                    "ramp_track_step")
