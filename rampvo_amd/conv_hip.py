@@ -4,6 +4,7 @@ implicit-GEMM MFMA conv towers (csrc/conv.hip).  Activations are NHWC float32 te
 consumer conv's load path (``pre``) or on the residual-block tail kernel.
 """
 import ctypes
+import threading
 import os
 
 import torch
@@ -163,7 +164,18 @@ class _AccArena:
         return v
 
 
-_arena = None            # set by the tower passes below while they run
+class _ArenaScope(threading.local):
+    """the accumulator arena of the tower pass running in THIS thread (None outside one): two trackers on two threads do
+    not see each other's"""
+    cur = None
+
+
+_scope = _ArenaScope()
+
+
+def set_arena(a):
+    """(tests) make `a` the arena the next conv2d_towers calls of this thread take their accumulators from"""
+    _scope.cur = a
 
 
 class ConvJob(ctypes.Structure):
@@ -290,7 +302,7 @@ def conv2d_towers(jobs, half, fp8=False):
         a.res, a.y = ptr(res), ptr(y)
         a.Cout, a.relu, a.out_scale = cout, int(j.get("relu", False)), float(j.get("out_scale", 1.0))
         a.act_scale, a.w_scale = (FP8_ACT_SCALE, w_scale) if use8 else (0.0, 0.0)
-        acc = _arena.slot(cout) if (j.get("want_stats", False) and _arena is not None) else None
+        acc = _scope.cur.slot(cout) if (j.get("want_stats", False) and _scope.cur is not None) else None
         if acc is not None:
             a.stats, a.acc_out = None, ptr(acc)
             outs.append(Pending(y, None, None, acc=acc, count=OH * OW, eps=j.get("eps", 1e-5)))
@@ -387,9 +399,8 @@ def basic_encoder4_towers(encs, x, out_scale=1.0, half=False, fp8=False):
     """BasicEncoder4._forward of every tower in ``encs`` on one NHWC image x [H,W,Cin_padded] -> [H/4,W/4,out] each
     (``half``: fp16 storage + fp16 MFMA after the first layer's fp32 input).  relu(norm1(conv1)) is never
     materialised: layer1's first conv applies it while loading, the block's tail while adding the skip."""
-    global _arena
     norms = _tower_norms(encs)
-    _arena = _AccArena(x.device) if (half and _IN_ACC and any(norms)) else None
+    _scope.cur = _AccArena(x.device) if (half and _IN_ACC and any(norms)) else None
     try:
         xs = _first_layer(encs, x, norms, half)
         for li in ("layer1", "layer2"):
@@ -397,7 +408,7 @@ def basic_encoder4_towers(encs, x, out_scale=1.0, half=False, fp8=False):
                 xs = _res_blocks([getattr(e, li)[b] for e in encs], xs, norms, half, fp8)
         return conv2d_towers([dict(x=xs[t], conv=e.conv2, out_scale=out_scale) for t, e in enumerate(encs)], half, fp8)
     finally:
-        _arena = None
+        _scope.cur = None
 
 
 def basic_encoder4(enc, x, out_scale=1.0, half=False):
@@ -408,9 +419,8 @@ def multiscale_encoder4_towers(encs, x, x2, x4, out_scale=1.0, half=False, fp8=F
     """MultiScaleBasicEncoder4.forward (reference extractor.py:288-311) of every tower on NHWC inputs: x [H,W,16],
     x2 [H/2,W/2,32] and x4 [H/4,W/4,64] (the three super-states) -> [H/4,W/4,out].  The channel
     concatenations are the only non-conv steps; layer2/conv2 are unused, as upstream."""
-    global _arena
     norms = _tower_norms(encs)
-    _arena = _AccArena(x.device) if (half and _IN_ACC and any(norms)) else None
+    _scope.cur = _AccArena(x.device) if (half and _IN_ACC and any(norms)) else None
     try:
         xs = _first_layer(encs, x, norms, half)
         for b in range(2):
@@ -423,7 +433,7 @@ def multiscale_encoder4_towers(encs, x, x2, x4, out_scale=1.0, half=False, fp8=F
         xs = [torch.cat((v, x4), dim=-1) for v in xs]
         return conv2d_towers([dict(x=xs[t], conv=e.conv3, out_scale=out_scale) for t, e in enumerate(encs)], half, fp8)
     finally:
-        _arena = None
+        _scope.cur = None
 
 
 def multiscale_encoder4(enc, x, x2, x4, out_scale=1.0, half=False):

@@ -167,7 +167,7 @@ def test_instance_norm_accumulators_match_the_finalize_launch(cin, cout, k, stri
         x = (torch.randn(hw[0], hw[1], cin, device="cuda") * 1.5 + 0.3).half()
 
         def run(acc):
-            conv_hip._arena = conv_hip._AccArena(x.device) if acc else None
+            conv_hip.set_arena(conv_hip._AccArena(x.device) if acc else None)
             try:
                 pa = conv_hip.conv2d_towers([dict(x=x, conv=conv_a, want_stats=True), dict(x=x, conv=dummy)], half=True)[0]
                 assert (pa.acc is not None) == acc
@@ -175,7 +175,7 @@ def test_instance_norm_accumulators_match_the_finalize_launch(cin, cout, k, stri
                 out = conv_hip.norm_add_relu(pb, pa.raw)
                 return pa, pb, out
             finally:
-                conv_hip._arena = None
+                conv_hip.set_arena(None)
 
         ca, cb, cout_ = run(False)
         aa, ab, aout = run(True)
