@@ -582,6 +582,8 @@ int ramp_upd_linear(const void *x, const void *w_packed, const float *bias, void
                                32 a step's E_bound was below the live factor count                                */
 #define RAMP_DYN_NLOG 12    /* entries written to the delta log                                                   */
 #define RAMP_DYN_FRAME 13   /* `counter` of the last frame stepped (tags the host's lazy copy)                    */
+#define RAMP_DYN_MEDOK 14   /* 1: ramp_track.median holds the depth median of the three newest frames (set beside the
+                             * motion test, cleared by an update-only step; 0 when the host hands the state over)     */
 #define RAMP_TRACK_LOG 12   /* floats per delta-log entry: t1, t0 (as int32 bit patterns), dP[7], pad             */
 
 #define RAMP_TRACK_COMMIT 1    /* store the front end's outputs as frame NROW first                               */
@@ -642,6 +644,9 @@ typedef struct ramp_track {
   size_t ba_ws_bytes;
   /* keyframe() */
   float *mm;                          /* [2] flow magnitudes of the motion test */
+  float *median;                      /* optional [1]: depth initialisation of the next frame (ramp/Ramp_vo.py:370-371), computed in
+                                       * the motion test's launch instead of at the head of the next step (KEYFRAME_INDEX >= 4:
+                                       * the three newest frames are the same whether or not the test drops a keyframe)       */
   float *dlog;                        /* [log_cap][RAMP_TRACK_LOG] */
   int32_t *edit_ws;                   /* [2 * ceil(E_cap / 1024) + 8] */
   int32_t *dyn_host;                  /* optional pinned host copy of dyn, refreshed asynchronously after each step */

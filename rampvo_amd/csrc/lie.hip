@@ -4,6 +4,7 @@
 // reference is fusing ~13 launches (inv, mul, 9x broadcast act4, iproj, proj)
 // of pops.transform into one.
 #include "ramp_device.h"
+#include "median.h"
 
 #define LIE_THREADS 256
 
@@ -322,8 +323,18 @@ __global__ void __launch_bounds__(256)
                                  const int64_t *__restrict__ jj, const int64_t *__restrict__ kk,
                                  const int32_t *__restrict__ order, const int32_t *__restrict__ seg,
                                  const int64_t *__restrict__ ukeys, const int32_t *__restrict__ ngroups, float beta,
-                                 float *__restrict__ out2, const int32_t *__restrict__ dyn, int keyframe_index,
-                                 const int64_t *__restrict__ ix, float *__restrict__ points, int m_cap, int M) {
+                                 float *__restrict__ out2, int32_t *__restrict__ dyn, int keyframe_index,
+                                 const int64_t *__restrict__ ix, float *__restrict__ points, int m_cap, int M,
+                                 float *__restrict__ median) {
+  if (median && blockIdx.x == gridDim.x - 1) {
+    // the next frame's depth initialisation: lower median over the three newest frames' patches (they stay the three
+    // newest whether or not the test below drops keyframe n - KEYFRAME_INDEX, KEYFRAME_INDEX >= 4)
+    const int n = dyn[RAMP_DYN_N];
+    if (n < 3) return;
+    const float med = depth_median_block_t<256, 32>(patches + (size_t)(n - 3) * M * 3 * P * P, 3, M, P * P);
+    if (threadIdx.x == 0) { *median = med; dyn[RAMP_DYN_MEDOK] = 1; }
+    return;
+  }
   if (blockIdx.x < 2)
     motionmag_block<P>(blockIdx.x, poses, patches, intr, ii, jj, kk, order, seg, ukeys, ngroups, 0L, 0L, beta, out2, dyn,
                        keyframe_index);
@@ -446,11 +457,12 @@ int ramp_i_motionmag_dyn(const float *poses, const float *patches, const float *
 int ramp_i_motionmag_point_cloud_dyn(const float *poses, const float *patches, const float *intrinsics, const int64_t *ii,
                                      const int64_t *jj, const int64_t *kk, const int32_t *order, const int32_t *seg,
                                      const int64_t *ukeys, const int32_t *ngroups, float beta, float *out2,
-                                     const int32_t *dyn, int keyframe_index, const int64_t *ix, float *points, int m_cap,
-                                     int M, hipStream_t st) {
-  hipLaunchKernelGGL(motionmag_point_cloud_kernel<3>, dim3(2 + ramp_cdiv(m_cap, LIE_THREADS)), dim3(256), 0, st, poses,
-                     patches, intrinsics, ii, jj, kk, order, seg, ukeys, ngroups, beta, out2, dyn, keyframe_index, ix, points,
-                     m_cap, M);
+                                     int32_t *dyn, int keyframe_index, const int64_t *ix, float *points, int m_cap,
+                                     int M, float *median, hipStream_t st) {
+  if (median && 3 * M * 9 > 256 * 32) median = nullptr;
+  hipLaunchKernelGGL(motionmag_point_cloud_kernel<3>, dim3(2 + ramp_cdiv(m_cap, LIE_THREADS) + (median ? 1 : 0)), dim3(256), 0,
+                     st, poses, patches, intrinsics, ii, jj, kk, order, seg, ukeys, ngroups, beta, out2, dyn, keyframe_index,
+                     ix, points, m_cap, M, median);
   RAMP_CHECK_LAUNCH();
   return RAMP_OK;
 }

@@ -20,8 +20,8 @@ int ramp_i_point_cloud_dyn(const float *poses, const float *patches, const float
 int ramp_i_motionmag_point_cloud_dyn(const float *poses, const float *patches, const float *intrinsics, const int64_t *ii,
                                      const int64_t *jj, const int64_t *kk, const int32_t *order, const int32_t *seg,
                                      const int64_t *ukeys, const int32_t *ngroups, float beta, float *out2,
-                                     const int32_t *dyn, int keyframe_index, const int64_t *ix, float *points, int m_cap,
-                                     int M, hipStream_t st);
+                                     int32_t *dyn, int keyframe_index, const int64_t *ix, float *points, int m_cap,
+                                     int M, float *median, hipStream_t st);
 int ramp_i_motionmag_dyn(const float *poses, const float *patches, const float *intrinsics, const int64_t *ii,
                          const int64_t *jj, const int64_t *kk, const int32_t *order, const int32_t *seg,
                          const int64_t *ukeys, const int32_t *ngroups, float beta, float *out2, const int32_t *dyn,
@@ -29,7 +29,8 @@ int ramp_i_motionmag_dyn(const float *poses, const float *patches, const float *
 int ramp_i_frame_commit_dyn(float *poses, int motion, float damping, int64_t *tstamps, int64_t counter,
                             int64_t *index_map, float *intrinsics, const float *k_new, float *patches_state,
                             int median_frames, int M, int P, float *patches_new, int n_copy, const void *const *src,
-                            void *const *base, const long *bytes, const int *mod, const int32_t *dyn, hipStream_t st);
+                            void *const *base, const long *bytes, const int *mod, const int32_t *dyn,
+                            const float *median_ahead, hipStream_t st);
 size_t ramp_i_plan_dyn_ws(int E_cap, int kkey_cap, int pkey_cap);
 int ramp_i_plan_dyn(const int64_t *g4, int E_cap, int E_grid, const int32_t *dyn, int32_t *status, int M, int kkey_cap,
                     int pkey_cap, int kk_cap, int ij_cap, int32_t *kk_order, int32_t *kk_gid, int32_t *kk_seg,

@@ -5,6 +5,7 @@
 // upstream: abs, avg_pool2d, transpose, mean, max_pool2d, eq, mul, topk (radix sort + merges), div,
 // remainder, stack = ~20 launches.  Here: score kernel, NMS kernel, one-workgroup radix select.
 #include "ramp_device.h"
+#include "median.h"
 #include "ramp_internal.h"
 
 // thread per 1/4-resolution cell, X fastest: a thread reads 16 contiguous bytes per row per bin
@@ -206,64 +207,8 @@ __global__ void __launch_bounds__(TOPK_THREADS)
 // of the M new patches.  One workgroup: keys in registers, 4 x 8-bit radix passes (k-th smallest), fill.
 #define MED_THREADS 1024
 #define MED_PER 8               // up to 8192 values (3 frames x 256 patches x 9 pixels = 6912)
-// lower median of the F*M*PP depth values of src ([F*M][3][PP] rows, channel 2); every thread of the 1024 returns it
 __device__ __forceinline__ float depth_median_block(const float *__restrict__ src, int F, int M, int PP) {
-  __shared__ unsigned hist[256];
-  __shared__ unsigned s_prefix, s_remaining;
-  const int tid = threadIdx.x, n = F * M * PP;
-  unsigned key[MED_PER];
-  bool has[MED_PER];
-#pragma unroll
-  for (int u = 0; u < MED_PER; u++) {
-    const int i = tid + u * MED_THREADS;
-    has[u] = i < n;
-    unsigned b = 0;
-    if (has[u]) {
-      const int fm = i / PP, p = i - fm * PP;               // (frame, patch) pair, pixel
-      b = __float_as_uint(src[((size_t)fm * 3 + 2) * PP + p]);
-      b ^= (b >> 31) ? 0xffffffffu : 0x80000000u;          // order-preserving map of float to uint
-    }
-    key[u] = b;
-  }
-  if (tid == 0) { s_prefix = 0; s_remaining = (unsigned)((n - 1) / 2) + 1; }   // rank of the lower median, 1-based
-  unsigned mask = 0;
-  for (int shift = 24; shift >= 0; shift -= 8) {
-    if (tid < 256) hist[tid] = 0;
-    __syncthreads();
-    const unsigned prefix = s_prefix;
-#pragma unroll
-    for (int u = 0; u < MED_PER; u++)
-      if (has[u] && (key[u] & mask) == prefix) atomicAdd(&hist[(key[u] >> shift) & 255u], 1u);
-    __syncthreads();
-    if (tid < 64) {
-      unsigned c[4];
-#pragma unroll
-      for (int b = 0; b < 4; b++) c[b] = hist[4 * tid + b];
-      const unsigned tot = c[0] + c[1] + c[2] + c[3];
-      unsigned pre = tot;                                   // inclusive prefix sum over lanes (ascending bins)
-      for (int o = 1; o < 64; o <<= 1) {
-        const unsigned v = __shfl_up(pre, o, 64);
-        if (tid >= o) pre += v;
-      }
-      const unsigned rem = s_remaining, below = pre - tot;
-      if (below < rem && pre >= rem) {
-        unsigned rr = rem - below;
-        int bin = 4 * tid + 3;
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-          if (c[b] >= rr) { bin = 4 * tid + b; break; }
-          rr -= c[b];
-        }
-        s_remaining = rr;
-        s_prefix = prefix | ((unsigned)bin << shift);
-      }
-    }
-    mask |= 255u << shift;
-    __syncthreads();
-  }
-  unsigned b = s_prefix;
-  b ^= (b >> 31) ? 0x80000000u : 0xffffffffu;             // inverse map
-  return __uint_as_float(b);
+  return depth_median_block_t<MED_THREADS, MED_PER>(src, F, M, PP);
 }
 
 __global__ void __launch_bounds__(MED_THREADS)
@@ -343,7 +288,8 @@ __global__ void __launch_bounds__(MED_THREADS) frame_commit_kernel(const FrameCo
     for (int c = 0; c < 7; c++) a.poses[7 * n + c] = Pn[c];
   }
   const bool fill = a.F > 0;
-  const float med = !fill ? 0.f : (a.median_val ? *a.median_val : depth_median_block(median_src, a.F, a.M, a.PP));
+  const bool ahead = a.median_val && (!a.dyn || a.dyn[RAMP_DYN_MEDOK]);      // (workgroup uniform)
+  const float med = !fill ? 0.f : (ahead ? *a.median_val : depth_median_block(median_src, a.F, a.M, a.PP));
   for (int i = t; i < a.M * 3 * a.PP; i += MED_THREADS) {
     const int ch = (i / a.PP) % 3;
     float v = a.patches_new[i];
@@ -359,7 +305,8 @@ __global__ void __launch_bounds__(MED_THREADS) frame_commit_kernel(const FrameCo
 int ramp_i_frame_commit_dyn(float *poses, int motion, float damping, int64_t *tstamps, int64_t counter,
                             int64_t *index_map, float *intrinsics, const float *k_new, float *patches_state,
                             int median_frames, int M, int P, float *patches_new, int n_copy, const void *const *src,
-                            void *const *base, const long *bytes, const int *mod, const int32_t *dyn, hipStream_t st) {
+                            void *const *base, const long *bytes, const int *mod, const int32_t *dyn,
+                            const float *median_ahead, hipStream_t st) {
   if (!poses || !patches_state || !patches_new || !dyn || M <= 0 || P <= 0 || n_copy < 0 || n_copy > FC_MAXBUF)
     return RAMP_EINVAL;
   if ((long)median_frames * M * P * P > MED_THREADS * MED_PER) return RAMP_EUNSUPPORTED;
@@ -368,7 +315,8 @@ int ramp_i_frame_commit_dyn(float *poses, int motion, float damping, int64_t *ts
   a.index_map = index_map; a.index_val = 0; a.intrinsics = intrinsics; a.copy_k = k_new ? 0 : 1;
   a.median_src = patches_state; a.F = median_frames; a.M = M; a.PP = P * P;
   a.patches_new = patches_new; a.patches_row = patches_state;
-  a.median_val = nullptr; a.dyn = dyn; a.k_new = k_new;
+  a.median_val = median_ahead;      // valid while dyn[RAMP_DYN_MEDOK] (csrc/lie.hip: computed beside the previous motion test)
+  a.dyn = dyn; a.k_new = k_new;
   a.n_copy = n_copy;
   long mx = 0;
   for (int i = 0; i < FC_MAXBUF; i++) a.mod[i] = 0;

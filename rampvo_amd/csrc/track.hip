@@ -230,8 +230,9 @@ __global__ void __launch_bounds__(256) trk_apply_kernel(const TrkEdit p) {
   oi[Ek + idx] = kk / p.M; oj[Ek + idx] = jj; ok[Ek + idx] = kk; orow[Ek + idx] = -1;
 }
 
-__global__ void __launch_bounds__(256) trk_iota_kernel(int64_t *__restrict__ row, const int32_t *__restrict__ dyn) {
+__global__ void __launch_bounds__(256) trk_iota_kernel(int64_t *__restrict__ row, int32_t *__restrict__ dyn) {
   const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e == 0) dyn[RAMP_DYN_MEDOK] = 0;           // bundle adjustment moved the depths and no motion test follows
   if (e < dyn[RAMP_DYN_E]) row[e] = e;
 }
 
@@ -374,7 +375,7 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
     const int mod[5] = {0, t->mem, t->mem, t->mem, t->mem};
     TRK_DO(ramp_i_frame_commit_dyn(t->poses, t->motion_model, t->motion_damping, t->tstamps, counter, t->index_map,
                                    t->intrinsics, k_new, t->patches, 3, t->M, t->P, t->fe_patches, 5, src, base, bytes,
-                                   mod, dyn, st));
+                                   mod, dyn, (t->median && t->keyframe_index >= 4) ? t->median : nullptr, st));
   }
   if (flags & RAMP_TRACK_UPDATE) {
     const ramp_track_weights &w = t->w;
@@ -439,7 +440,7 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
       TRK_DO(ramp_i_point_cloud_dyn(t->poses, t->patches, t->intrinsics, t->ixm, t->points, t->m_cap, dyn, t->M, st));
     if (!(flags & RAMP_TRACK_KEYFRAME)) {
       // the new hidden state is indexed by the factors themselves from here on
-      hipLaunchKernelGGL(trk_iota_kernel, dim3(ramp_cdiv(Eb, 256)), dim3(256), 0, st, t->graph[cur] + 3 * (size_t)Ec, dyn);
+      hipLaunchKernelGGL(trk_iota_kernel, dim3(ramp_cdiv(Eb, 256)), dim3(256), 0, st, t->graph[cur] + 3 * (size_t)Ec, t->dyn);
     }
   }
   if (flags & RAMP_TRACK_KEYFRAME) {
@@ -447,8 +448,9 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
     // Ramp_vo.keyframe(), ramp/Ramp_vo.py:237-274, and the next frame's append_factors (:394-395)
     if (pc_with_mm)
       TRK_DO(ramp_i_motionmag_point_cloud_dyn(t->poses, t->patches, t->intrinsics, ii, jj, kk, t->ij_order, t->ij_seg,
-                                              t->ij_ukeys, t->ij_ngroups, 0.5f, t->mm, dyn, t->keyframe_index, t->ixm,
-                                              t->points, t->m_cap, t->M, st));
+                                              t->ij_ukeys, t->ij_ngroups, 0.5f, t->mm, t->dyn, t->keyframe_index, t->ixm,
+                                              t->points, t->m_cap, t->M, (t->median && t->keyframe_index >= 4) ? t->median : nullptr,
+                                              st));
     else if (!(flags & RAMP_TRACK_MM_GIVEN))
       TRK_DO(ramp_i_motionmag_dyn(t->poses, t->patches, t->intrinsics, ii, jj, kk, t->ij_order, t->ij_seg, t->ij_ukeys,
                                   t->ij_ngroups, 0.5f, t->mm, dyn, t->keyframe_index, st));

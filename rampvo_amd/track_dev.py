@@ -8,6 +8,7 @@ reads the device; ``leave()`` is the one synchronisation that hands the state ba
 """
 import collections
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -51,7 +52,7 @@ class Track(ctypes.Structure):
                 + _ptr_fields(["coords", "corr"]) + [("net", c_p * 3)]
                 + _ptr_fields(["fg", "ykk", "hkk", "yij", "hij", "relu_t", "target", "weight", "ba_ws"])
                 + [("ba_ws_bytes", c_sz)]
-                + _ptr_fields(["mm", "dlog", "edit_ws", "dyn_host"]) + [("probe", c_p * 5), ("E_hint", c_i)])
+                + _ptr_fields(["mm", "median", "dlog", "edit_ws", "dyn_host"]) + [("probe", c_p * 5), ("E_hint", c_i)])
 
 
 def supported(slam):
@@ -101,6 +102,7 @@ class DeviceTrack:
         self.ba_ws = e(lib.ramp_track_ba_workspace_bytes(E_cap, slam.N, M, cfg.OPTIMIZATION_WINDOW, kk_cap, ij_cap),
                        torch.uint8)
         self.mm = z(2, f32)
+        self.median = z(1, f32)
         self.sink = z(1, i32)
         self.dlog = z((self.log_cap, LOG_WORDS), f32)
         self.edit_ws = z(3 * ((E_cap + 1023) // 1024) + 8, i32)
@@ -136,6 +138,8 @@ class DeviceTrack:
                               dyn_host=self.dyn_host).items():
             setattr(t, name, P(ten))
         t.plan_ws_bytes, t.ba_ws_bytes = self.plan_ws.numel(), self.ba_ws.numel()
+        if os.environ.get("RAMP_MEDIAN_AHEAD", "1") != "0":       # (A/B: 0 = the median at the head of the next step)
+            t.median = P(self.median)
         t.graph[0], t.graph[1] = P(self.graph[0]), P(self.graph[1])
         for i in range(3):
             t.net[i] = P(self.net[i])
