@@ -243,6 +243,7 @@ struct FrameCommit {
   // n % mod[b] (ring buffers) or n (mod[b] == 0); median_src / patches_row are the base of the patch buffer; k_new
   // (optional) replaces the copy of the previous intrinsics row
   const int32_t *dyn; int mod[FC_MAXBUF]; const float *k_new;
+  int32_t *status; int E_bound;      // optional: status bit 32 if dyn[RAMP_DYN_E] exceeds the step's launch bound
 };
 __global__ void __launch_bounds__(MED_THREADS) frame_commit_kernel(const FrameCommit a) {
   const int t = threadIdx.x;
@@ -270,6 +271,9 @@ __global__ void __launch_bounds__(MED_THREADS) frame_commit_kernel(const FrameCo
   }
   if (blockIdx.x != 0) return;
   if (t == 0) {
+    // (the launch bound of this step's per-factor kernels was below the live factor count: the frame would be computed on
+    // a truncated graph -- flagged, csrc/track.hip)
+    if (a.status && a.dyn && a.dyn[RAMP_DYN_E] > a.E_bound) atomicOr(a.status, 32);
     if (a.tstamps) a.tstamps[n] = a.counter;
     if (a.index_map) a.index_map[n + 1] = index_val;
   }
@@ -306,7 +310,7 @@ int ramp_i_frame_commit_dyn(float *poses, int motion, float damping, int64_t *ts
                             int64_t *index_map, float *intrinsics, const float *k_new, float *patches_state,
                             int median_frames, int M, int P, float *patches_new, int n_copy, const void *const *src,
                             void *const *base, const long *bytes, const int *mod, const int32_t *dyn,
-                            const float *median_ahead, hipStream_t st) {
+                            const float *median_ahead, int32_t *status, int E_bound, hipStream_t st) {
   if (!poses || !patches_state || !patches_new || !dyn || M <= 0 || P <= 0 || n_copy < 0 || n_copy > FC_MAXBUF)
     return RAMP_EINVAL;
   if ((long)median_frames * M * P * P > MED_THREADS * MED_PER) return RAMP_EUNSUPPORTED;
@@ -317,6 +321,7 @@ int ramp_i_frame_commit_dyn(float *poses, int motion, float damping, int64_t *ts
   a.patches_new = patches_new; a.patches_row = patches_state;
   a.median_val = median_ahead;      // valid while dyn[RAMP_DYN_MEDOK] (csrc/lie.hip: computed beside the previous motion test)
   a.dyn = dyn; a.k_new = k_new;
+  a.status = E_bound > 0 ? status : nullptr; a.E_bound = E_bound;
   a.n_copy = n_copy;
   long mx = 0;
   for (int i = 0; i < FC_MAXBUF; i++) a.mod[i] = 0;
@@ -395,7 +400,7 @@ int ramp_frame_commit(float *poses, int n, int motion, float damping, int64_t *t
   a.median_src = patches_state + (size_t)(n - median_frames) * row; a.F = median_frames; a.M = M; a.PP = P * P;
   a.patches_new = patches_new; a.patches_row = patches_state + (size_t)n * row;
   a.median_val = median_dev;
-  a.dyn = nullptr; a.k_new = nullptr;
+  a.dyn = nullptr; a.k_new = nullptr; a.status = nullptr; a.E_bound = 0;
   for (int i = 0; i < FC_MAXBUF; i++) a.mod[i] = 0;
   a.n_copy = n_copy;
   long mx = 0;

@@ -354,7 +354,11 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
   // launch bound of the per-factor kernels: the caller's upper bound of dyn[RAMP_DYN_E] (0: the capacity)
   const int Eb = (E_bound > 0 && E_bound < Ec) ? E_bound : Ec;
   const int new_cap = (2 * t->patch_lifetime - 1) * t->M;          // factors one frame adds
-  if (Eb < Ec) hipLaunchKernelGGL(trk_bound_check_kernel, dim3(1), dim3(1), 0, st, t->dyn, Eb);
+  // (the bound check rides in the frame commit's launch when there is one)
+  static int fold = -1;                                  // RAMP_BOUND_FOLD=0: a launch of its own (A/B runs)
+  if (fold < 0) { const char *e = getenv("RAMP_BOUND_FOLD"); fold = e ? atoi(e) : 1; }
+  const bool folded = fold && (flags & RAMP_TRACK_COMMIT);
+  if (Eb < Ec && !folded) hipLaunchKernelGGL(trk_bound_check_kernel, dim3(1), dim3(1), 0, st, t->dyn, Eb);
   const int64_t *g = t->graph[cur];
   const int64_t *ii = g, *jj = g + Ec, *kk = g + 2 * (size_t)Ec, *row = g + 3 * (size_t)Ec;
   const int32_t *dyn = t->dyn;
@@ -375,7 +379,7 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
     const int mod[5] = {0, t->mem, t->mem, t->mem, t->mem};
     TRK_DO(ramp_i_frame_commit_dyn(t->poses, t->motion_model, t->motion_damping, t->tstamps, counter, t->index_map,
                                    t->intrinsics, k_new, t->patches, 3, t->M, t->P, t->fe_patches, 5, src, base, bytes,
-                                   mod, dyn, (t->median && t->keyframe_index >= 4) ? t->median : nullptr, st));
+                                   mod, dyn, (t->median && t->keyframe_index >= 4) ? t->median : nullptr, t->dyn + RAMP_DYN_STATUS, (Eb < Ec && folded) ? Eb : 0, st));
   }
   if (flags & RAMP_TRACK_UPDATE) {
     const ramp_track_weights &w = t->w;
