@@ -316,6 +316,73 @@ __global__ void __launch_bounds__(SEG_T * SEG_R)
       (seg_h4){(_Float16)(a[0] / z[0]), (_Float16)(a[1] / z[1]), (_Float16)(a[2] / z[2]), (_Float16)(a[3] / z[3])};
 }
 
+// The same arithmetic (row lane w walks rows w, w + R, ... in order; partials merged in lane order: bit-identical
+// results) with more bytes in flight: a thread owns 8 channels (two 16-byte loads per row instead of two 8-byte ones),
+// a row lane is 48 threads, and the indices and rows of SEG_D steps are requested before the first one is used.  The
+// 8-byte kernel keeps 16 B per thread behind a dependent index load in flight -- 24 KB per CU at its two workgroups per
+// CU, i.e. ~2.8 TB/s at ~2 us of latency, which is what it measured (61 MB in 22 us).
+#define SEG_T8 48
+#define SEG_D 4
+typedef _Float16 seg_h8 __attribute__((ext_vector_type(8)));
+__global__ void __launch_bounds__(SEG_T8 * SEG_R)
+    upd_segment_softmax_f16x8_kernel(const _Float16 *__restrict__ fg, const int32_t *__restrict__ order,
+                                     const int32_t *__restrict__ seg_start, const int32_t *__restrict__ ngroups,
+                                     _Float16 *__restrict__ y) {
+  __shared__ float part[SEG_R][24][SEG_T8];
+  const int g = blockIdx.x;
+  const int t = threadIdx.x % SEG_T8, w = threadIdx.x / SEG_T8;
+  const int c = 8 * t;
+  if (g >= *ngroups) {          // unused tail of the table: defined (zero) rows
+    if (w == 0) *reinterpret_cast<seg_h8 *>(y + (size_t)g * UD + c) = (seg_h8){0, 0, 0, 0, 0, 0, 0, 0};
+    return;
+  }
+  const int s0 = seg_start[g], s1 = seg_start[g + 1];
+  float m[8], z[8], a[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) { m[k] = -INFINITY; z[k] = 0.f; a[k] = 0.f; }
+  for (int p0 = s0 + w; p0 < s1; p0 += SEG_R * SEG_D) {
+    int idx[SEG_D];
+#pragma unroll
+    for (int d = 0; d < SEG_D; d++) { const int p = p0 + d * SEG_R; idx[d] = order[p < s1 ? p : p0]; }
+    seg_h8 fv[SEG_D], gv[SEG_D];
+#pragma unroll
+    for (int d = 0; d < SEG_D; d++) {
+      const size_t r0 = (size_t)idx[d] * (2 * UD);
+      fv[d] = *reinterpret_cast<const seg_h8 *>(fg + r0 + c);
+      gv[d] = *reinterpret_cast<const seg_h8 *>(fg + r0 + UD + c);
+    }
+#pragma unroll
+    for (int d = 0; d < SEG_D; d++) {
+      if (p0 + d * SEG_R >= s1) break;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const float gk = (float)gv[d][k], n = fmaxf(m[k], gk);
+        const float sc = __expf(m[k] - n), e = __expf(gk - n);
+        z[k] = z[k] * sc + e; a[k] = a[k] * sc + (float)fv[d][k] * e;
+        m[k] = n;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; k++) { part[w][k][t] = m[k]; part[w][8 + k][t] = z[k]; part[w][16 + k][t] = a[k]; }
+  __syncthreads();
+  if (w != 0) return;
+  for (int q = 1; q < SEG_R; q++) {
+    if (part[q][8][t] == 0.f) continue;       // this row lane saw no row (all channels share the rows)
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const float mk = part[q][k][t], n = fmaxf(m[k], mk);
+      const float sc = __expf(m[k] - n), tc = __expf(mk - n);
+      z[k] = z[k] * sc + part[q][8 + k][t] * tc; a[k] = a[k] * sc + part[q][16 + k][t] * tc;
+      m[k] = n;
+    }
+  }
+  seg_h8 o;
+#pragma unroll
+  for (int k = 0; k < 8; k++) o[k] = (_Float16)(a[k] / z[k]);
+  *reinterpret_cast<seg_h8 *>(y + (size_t)g * UD + c) = o;
+}
+
 // Sequential variant (fp32 path): the summation order the fp32 parity fixtures were recorded with.
 // y[g][c] = sum softmax(g) * f over the stacked [f | g] rows (row stride 768).
 // One workgroup (192 lanes x 2 channels) per group, single pass with a running max (online
@@ -457,9 +524,18 @@ int ramp_upd_segment_softmax(const void *fg, const int32_t *order, const int32_t
   if (dtype == RAMP_F32)
     hipLaunchKernelGGL(upd_segment_softmax_seq_kernel<float>, grid, dim3(192), 0, (hipStream_t)stream,
                        (const float *)fg, order, seg_start, ngroups, (float *)y);
-  else if (dtype == RAMP_F16)
-    hipLaunchKernelGGL(upd_segment_softmax_f16_kernel, grid, dim3(SEG_T * SEG_R), 0, (hipStream_t)stream,
-                       (const _Float16 *)fg, order, seg_start, ngroups, (_Float16 *)y);
+  else if (dtype == RAMP_F16) {
+    static int v8 = -1;                                  // RAMP_SEG_X8=0: the 8-byte kernel (A/B runs)
+    if (v8 < 0) { const char *e = getenv("RAMP_SEG_X8"); v8 = e ? atoi(e) : 1; }
+    // many short groups (the patch grouping: ~2100 x ~19 rows) gain from the 16-byte kernel (27.3 -> 23.7 us); the pair
+    // grouping's 420 x 96 rows are bound by the work per thread and want the 768-thread kernel (18.1 vs 21.9 us)
+    if (v8 && max_groups >= 1024)
+      hipLaunchKernelGGL(upd_segment_softmax_f16x8_kernel, grid, dim3(SEG_T8 * SEG_R), 0, (hipStream_t)stream,
+                         (const _Float16 *)fg, order, seg_start, ngroups, (_Float16 *)y);
+    else
+      hipLaunchKernelGGL(upd_segment_softmax_f16_kernel, grid, dim3(SEG_T * SEG_R), 0, (hipStream_t)stream,
+                         (const _Float16 *)fg, order, seg_start, ngroups, (_Float16 *)y);
+  }
   else return RAMP_EINVAL;
   RAMP_CHECK_LAUNCH();
   return RAMP_OK;

@@ -194,6 +194,8 @@ struct GruParams {
   // optional prologue: x = LayerNorm_pre(x32 + add_t[add_idx]) -- the last SoftAgg's expand-and-add and gru[0]
   const _Float16 *add_t;       // [groups][384] fp16 or NULL
   const int32_t *add_idx;      // [E]
+  const _Float16 *add0_t;      // optional: a FIRST expand-and-add (x32 + add0_t[add0_idx]) + add_t[add_idx] -- the second-last
+  const int32_t *add0_idx;     // SoftAgg's, when the launch that consumed it did not write the sum back
   const float *pre_w, *pre_b;  // gru[0] LayerNorm
   float pre_eps;
   int E;
@@ -305,6 +307,18 @@ __global__ void __launch_bounds__(64 * MWAVES) upd_gru_kernel(const GruParams p)
     roff[mt] = (size_t)(row < pE ? row : pE - 1) * MD;
 #pragma unroll
     for (int nt = 0; nt < MNTW; nt++) res[mt][nt] = *reinterpret_cast<const f4 *>(p.x32 + roff[mt] + cq + nt * 16);
+  }
+  if (p.add0_t) {                               // uniform
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+      const _Float16 *a = p.add0_t + (size_t)p.add0_idx[roff[mt] / MD] * MD;
+#pragma unroll
+      for (int nt = 0; nt < MNTW; nt++) {
+        const h4 v = *reinterpret_cast<const h4 *>(a + cq + nt * 16);
+#pragma unroll
+        for (int i = 0; i < 4; i++) res[mt][nt][i] += (float)v[i];
+      }
+    }
   }
   if (p.add_t) {                                // uniform
 #pragma unroll
@@ -1354,7 +1368,8 @@ int ramp_debug_gru_trace(long long *host, int n) {
 #endif
 size_t ramp_upd_mlp_lds_bytes(void) { return (size_t)2 * MBM * MXS * 2; }
 
-int ramp_i_upd_gru(const float *x32, const void *add_t, const int32_t *add_idx, const float *pre_w, const float *pre_b,
+int ramp_i_upd_gru(const float *x32, const void *add0_t, const int32_t *add0_idx, const void *add_t, const int32_t *add_idx,
+                 const float *pre_w, const float *pre_b,
                  float pre_eps, const void *const *wp_host, const float *const *bias_host, const float *ln_w,
                  const float *ln_b, float eps, float *out32, void *relu_t, int E, const int32_t *dyn,
                  const void *heads_w, const float *heads_b, const float *coords, float *target, float *weight, int P,
@@ -1364,8 +1379,10 @@ int ramp_i_upd_gru(const float *x32, const void *add_t, const int32_t *add_idx, 
   if (!x32 || !wp_host || !bias_host || !ln_w || !ln_b || !out32 || (!relu_t && !heads_w)) return RAMP_EINVAL;
   if (heads_w && (!heads_b || !coords || !target || !weight || P < 1)) return RAMP_EINVAL;
   if (add_t && (!add_idx || !pre_w || !pre_b)) return RAMP_EINVAL;
+  if (add0_t && (!add0_idx || !add_t)) return RAMP_EINVAL;
   GruParams p;
   p.x32 = x32;
+  p.add0_t = (const _Float16 *)add0_t; p.add0_idx = add0_idx;
   p.add_t = (const _Float16 *)add_t; p.add_idx = add_idx; p.pre_w = pre_w; p.pre_b = pre_b; p.pre_eps = pre_eps;
   for (int i = 0; i < 6; i++) {
     if (!wp_host[i] || !bias_host[i]) return RAMP_EINVAL;
@@ -1496,7 +1513,7 @@ int ramp_i_upd_fg(const float *x32, const void *add_t, const int32_t *add_idx, f
 int ramp_upd_gru(const float *x32, const void *add_t, const int32_t *add_idx, const float *pre_w, const float *pre_b,
                  float pre_eps, const void *const *wp_host, const float *const *bias_host, const float *ln_w,
                  const float *ln_b, float eps, float *out32, void *relu_t, int E, void *stream) {
-  return ramp_i_upd_gru(x32, add_t, add_idx, pre_w, pre_b, pre_eps, wp_host, bias_host, ln_w, ln_b, eps, out32, relu_t, E, nullptr,
+  return ramp_i_upd_gru(x32, nullptr, nullptr, add_t, add_idx, pre_w, pre_b, pre_eps, wp_host, bias_host, ln_w, ln_b, eps, out32, relu_t, E, nullptr,
                         nullptr, nullptr, nullptr, nullptr, nullptr, 3, 0.f, 0.f, 0, stream);
 }
 
@@ -1505,7 +1522,7 @@ int ramp_upd_gru_heads(const float *x32, const void *add_t, const int32_t *add_i
                        const float *ln_b, float eps, float *out32, const void *heads_w, const float *heads_b,
                        const float *coords, float *target, float *weight, int E, int P, float wd, float ht, void *stream) {
   if (!heads_w) return RAMP_EINVAL;
-  return ramp_i_upd_gru(x32, add_t, add_idx, pre_w, pre_b, pre_eps, wp_host, bias_host, ln_w, ln_b, eps, out32, nullptr, E, nullptr,
+  return ramp_i_upd_gru(x32, nullptr, nullptr, add_t, add_idx, pre_w, pre_b, pre_eps, wp_host, bias_host, ln_w, ln_b, eps, out32, nullptr, E, nullptr,
                         heads_w, heads_b, coords, target, weight, P, wd, ht, 0, stream);
 }
 
