@@ -78,6 +78,12 @@ def parse():
                          "tracker may launch frame t+1's front end while frame t's bundle adjustment drains "
                          "(Ramp_vo.inputs_ready); 0: strictly one frame at a time")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--probe-every", type=int, default=4,
+                    help="the correlation launch is bracketed by HIP events on every N-th timed step (an event record "
+                         "is a ~6 us bubble on the stream it is recorded on)")
+    ap.add_argument("--inst-steps", type=int, default=100,
+                    help="instrumented steps behind the timed region: events around the update operator, bundle adjustment "
+                         "and the front end (roofline_update / roofline_ba / roofline_encoder)")
     ap.add_argument("--clock-warm-s", type=float, default=0.6,
                     help="untimed steady-state steps for at least this long right before the warm-up steps, so that a "
                          "short timed region (the driver's --steps 20 is ~30 ms) runs at settled clocks")
@@ -211,27 +217,33 @@ class DeviceProbe:
             for ev in evs:
                 ev.record()                    # torch creates the hipEvent on the first record
         self.used, self.edges, self.enabled = 0, [], False
+        self.mode, self.modes = "all", []              # "corr": only the correlation launch is bracketed (the timed region)
+        self.corr_inst_ms = []
 
     def install(self):
         from rampvo_amd import track_dev
         inner, probe = track_dev.DeviceTrack.step, self
 
         def step(dv, counter, flags, **k):
-            on = probe.enabled and probe.used < len(probe.sets) and (flags & track_dev.UPDATE)
+            on = probe.enabled and probe.mode and probe.used < len(probe.sets) and (flags & track_dev.UPDATE)
             for i in range(5):
-                dv.t.probe[i] = probe.sets[probe.used][i].cuda_event if on else None
+                dv.t.probe[i] = probe.sets[probe.used][i].cuda_event if on and (probe.mode == "all" or i < 2) else None
             if on:
                 probe.edges.append(int(dv.lazy_state()[track_dev.DYN_E]))      # a frame or two old: fine for a mean
+                probe.modes.append(probe.mode)
                 probe.used += 1
             return inner(dv, counter, flags, **k)
 
         track_dev.DeviceTrack.step = step
 
     def feed(self, ctimer, utimer, btimer, opt_window):
-        for evs, E in zip(self.sets[:self.used], self.edges):
-            ctimer.pairs.append((evs[0], evs[1])); ctimer.edges.append(E)
-            utimer.pairs.append((evs[1], evs[2])); utimer.edges.append(E)
-            btimer.pairs.append((evs[3], evs[4])); btimer.meta.append((E, opt_window, 2))
+        for evs, E, mode in zip(self.sets[:self.used], self.edges, self.modes):
+            if mode == "corr":                 # the timed region's samples: what roofline.achieved is computed from
+                ctimer.pairs.append((evs[0], evs[1])); ctimer.edges.append(E)
+            else:                              # the instrumented pass behind it
+                self.corr_inst_ms.append(evs[0].elapsed_time(evs[1]))
+                utimer.pairs.append((evs[1], evs[2])); utimer.edges.append(E)
+                btimer.pairs.append((evs[3], evs[4])); btimer.meta.append((E, opt_window, 2))
 
 
 class UpdateTimer:
@@ -583,7 +595,8 @@ def main():
     solo = rank == 0 and world == 1
     n_warm = args.clock_warm_max if args.clock_warm_s > 0 else 0
     n_np = args.np_steps if args.pipeline else 0
-    total = args.prime + n_warm + args.warmup + args.steps + n_np
+    n_inst = 0 if args.no_kernel_timing else args.inst_steps
+    total = args.prime + n_warm + args.warmup + args.steps + n_inst + n_np
     n_cpu = args.cpu_steps + 1 if (solo and args.cpu_steps > 0) else 0
     stream = SyntheticStream(args.height, args.width, total + n_cpu + 1, seed=1234 + rank, device=dev)
     frames = [tuple(x.to(dev) if i < 2 else x for i, x in enumerate(stream.frame(t))) for t in range(total)]
@@ -595,7 +608,7 @@ def main():
         etimer.install(net)
         btimer.install()
         utimer.install()
-        dprobe = DeviceProbe(args.steps)
+        dprobe = DeviceProbe(args.steps + n_inst)
         dprobe.install()
 
     pos = {"t": 0}
@@ -631,12 +644,20 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ctimer.enabled = etimer.enabled = btimer.enabled = utimer.enabled = True
+    # Inside the timed region only the dominant kernel is bracketed, and only on every --probe-every-th step: an event
+    # record costs a ~6 us bubble on its stream (five per step were 1.4 % of the rate).  The update operator, bundle
+    # adjustment and the front end are timed in the instrumented pass BEHIND the timed region (same stream of frames).
+    device_step = dprobe is not None and os.environ.get("RAMP_DEVICE_STEP", "1") == "1"
+    ctimer.enabled = not device_step             # (host-driven path: the Python-level hooks, every step, as before)
+    etimer.enabled = btimer.enabled = utimer.enabled = ctimer.enabled and dprobe is not None
     if dprobe is not None:
         dprobe.enabled = True
     tic = time.perf_counter()
     marks = [tic]
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if dprobe is not None:
+            # (not the first step behind the synchronisation: the drained pipeline ran no cache warm-up for it)
+            dprobe.mode = "corr" if i % max(1, args.probe_every) == max(1, args.probe_every) // 2 else None
         step()
         marks.append(time.perf_counter())         # host-side return times (the GPU may lag by less than a step)
     torch.cuda.synchronize()
@@ -645,6 +666,12 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - tic
     ctimer.enabled = etimer.enabled = btimer.enabled = utimer.enabled = False
+    if dprobe is not None and device_step:
+        dprobe.mode, etimer.enabled = "all", True
+        for _ in range(n_inst):
+            step()
+        torch.cuda.synchronize()
+        etimer.enabled = False
     if dprobe is not None:
         dprobe.enabled = False
         dprobe.feed(ctimer, utimer, btimer, cfg.OPTIMIZATION_WINDOW)
@@ -712,11 +739,18 @@ def main():
                 # (the random-init network lets half of the projections leave the image) cost a row of zeros, and
                 # model_bytes / mfma_tflops count them as if they gathered
                 rl["live_factor_fraction_fine_coarse"] = live
+            if dprobe is not None and device_step:
+                rl["sampling"] = ("HIP events around the launch on every %d-th step of the timed region (%d launches); "
+                                  "mean over the %d-step instrumented pass behind it: %.1f us"
+                                  % (max(1, args.probe_every), rl["launches"], n_inst,
+                                     1e3 * float(np.mean(dprobe.corr_inst_ms)) if dprobe.corr_inst_ms else float("nan")))
             out["roofline"] = rl
         for key, val in (("roofline_update", utimer.summary(bool(args.mixed))),
                          ("roofline_encoder", etimer.summary(bool(args.mixed))),
                          ("roofline_ba", btimer.summary(args.patches, cfg.REMOVAL_WINDOW))):
             if val is not None:
+                if device_step:
+                    val["measured_in"] = "the %d-step instrumented pass behind the timed region" % n_inst
                 out[key] = val
         snapshot = slam.state_dict() if (n_cpu or (solo and args.parity)) else None
         if solo and args.parity:
