@@ -19,6 +19,41 @@ __global__ void spin_kernel(long ticks, uint64_t *stamp, uint32_t *flag, uint32_
   if (threadIdx.x == 0 && blockIdx.x == 0) stamp[1] = wall_clock64();
 }
 
+// (c) what ONE resident wave on a second stream costs a chain of large launches on the first: a pure sleeper, and one
+//     that polls a word between sleeps
+__global__ void copy_kernel(const uint4 *__restrict__ a, uint4 *__restrict__ b, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) b[i] = a[i];
+}
+__global__ void resident_kernel(long ticks, const uint32_t *flag) {
+  const uint64_t t0 = wall_clock64();
+  uint32_t v = 0;
+  while ((long)(wall_clock64() - t0) < ticks) {
+    if (flag) v += __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __builtin_amdgcn_s_sleep(8);
+  }
+  if (v == 0xFFFFFFFFu) __builtin_trap();
+}
+static int resident_cost(hipStream_t A, hipStream_t B, uint32_t *flag) {
+  const long n = (64l << 20) / 16;
+  uint4 *a, *b; CK(hipMalloc(&a, n * 16)); CK(hipMalloc(&b, n * 16)); CK(hipMemset(a, 1, n * 16));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int mode = 0; mode < 3; mode++) {
+    float best = 1e9f;
+    for (int it = 0; it < 6; it++) {
+      CK(hipDeviceSynchronize());
+      if (mode) hipLaunchKernelGGL(resident_kernel, dim3(1), dim3(64), 0, B, 200000l, mode == 2 ? flag : (const uint32_t *)nullptr);   // 2 ms
+      CK(hipEventRecord(e0, A));
+      for (int k = 0; k < 40; k++) hipLaunchKernelGGL(copy_kernel, dim3(2048), dim3(256), 0, A, a, b, n);
+      CK(hipEventRecord(e1, A));
+      CK(hipDeviceSynchronize());
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      if (it >= 2 && ms < best) best = ms;
+    }
+    printf("40 x 64 MB copies on stream A, %-38s %.1f us per launch\n", mode == 0 ? "alone:" : mode == 1 ? "one sleeping wave resident on B:" : "one polling wave resident on B:", best * 1e3 / 40);
+  }
+  return 0;
+}
+
 int main() {
   int can = 0;
   CK(hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, 0));
@@ -50,5 +85,5 @@ int main() {
     if (mode) printf("   stream B's kernel starts %.1f us after A's second kernel (median; p90 %.1f)", lagB[lagB.size() / 2], lagB[lagB.size() * 9 / 10]);
     printf("\n");
   }
-  return 0;
+  return resident_cost(A, B, flag);
 }
