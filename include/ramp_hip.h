@@ -656,6 +656,11 @@ typedef struct ramp_track {
   void *probe[5];
   int32_t E_hint;                     /* optional (> 0): the caller's estimate of the live factor count (E_bound is an upper
                                        * bound): picks the gru launch's tile (64 / 80 rows per workgroup)                    */
+  uint32_t gate_seq;                  /* with gate_flag: the value the update operator's last launch (gru) stores into it  */
+  uint32_t *gate_flag;                /* optional signal word (ramp_signal_alloc): "the next frame's front end may start"  *
+                                       * without a packet on this stream -- the other stream waits with                    *
+                                       * ramp_stream_wait_flag (a hipEventRecord costs ~5 us between two kernels of the   *
+                                       * recording stream, tools/mb/stream_signal.hip); takes the place of gate_event     */
 } ramp_track;
 
 /* cache warm-up for the next step's correlation kernel: reads the planes of the window's frames and the patch features
@@ -665,6 +670,16 @@ int ramp_track_warm(const ramp_track *t, int32_t *sink, void *stream);
 /* holds `stream` back for about `microseconds` with one sleeping wave (frame pipelining: the next frame's encoder
  * should reach the chip a little behind the gru launch)                                         */
 int ramp_stream_delay(int microseconds, void *stream);
+
+/* Cross-stream "go" through a 32-bit word instead of an event: the producer is a KERNEL that stores a sequence number
+ * (no packet between its stream's launches); the consumer stream waits with ONE sleeping wave that looks at the word
+ * every ~3 us and ends when it is >= value, or after timeout_us (a producer that never comes must not hang the stream);
+ * it then sleeps then_delay_us more.  (A hipStreamWaitValue32 in its place slows the other streams' launches down for
+ * as long as it is pending, and so does a wave that polls without pauses: DESIGN.md section 8.0.)  The word lives in
+ * signal memory (hipExtMallocWithFlags(hipMallocSignalMemory)), zero-initialised.                                    */
+int ramp_signal_alloc(uint32_t **flag);
+int ramp_signal_free(uint32_t *flag);
+int ramp_stream_wait_flag(void *stream, const uint32_t *flag, uint32_t value, int timeout_us, int then_delay_us);
 
 size_t ramp_track_sizeof(void);      /* sizeof(ramp_track): lets a binding check its mirror of the struct */
 size_t ramp_track_plan_workspace_bytes(int E_cap, int kkey_cap, int pkey_cap);

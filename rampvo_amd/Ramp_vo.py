@@ -61,6 +61,7 @@ def _gru_tile_rows(E, device):
 
 
 _FE_DELAY_US = int(os.environ.get("RAMP_FE_DELAY_US", "35"))     # A/B switch: 0 = the encoder graph right behind the selection
+_GATE_FLAG_DELAY_US = int(os.environ.get("RAMP_GATE_FLAG_DELAY_US", "0"))
 _WARM = os.environ.get("RAMP_WARM", "1") != "0"     # A/B switch: the cache warm-up behind the front end
 
 
@@ -190,6 +191,9 @@ class Ramp_vo:
         for ev in (self._ev_fe_done, self._ev_gate, self._ev_in):
             ev.record()                      # torch creates the hipEvent lazily; csrc/track.hip records the raw handle
         self._gate_armed = False
+        # the gate as a signal word the gru launch stores a sequence number into (no event packet between the update
+        # operator's launches: tools/mb/stream_signal.hip); RAMP_GATE_FLAG=0: the event (A/B runs)
+        self._gate_sig, self._gate_seq, self._gate_by_flag = None, 0, False
 
     # ------------------------------------------------------------------ weights
     def load_weights(self, network):
@@ -673,6 +677,22 @@ class Ramp_vo:
                 k_dev = self._upload(kq.astype(np.float32))
         return kq, k_dev
 
+    def _gate_signal(self):
+        """the signal word of the gate, or None (RAMP_GATE_FLAG=0, a gate position other than the default, no signal
+        memory, or 2^31 frames behind us: the event then)"""
+        if self._gate_sig is None:
+            use = os.environ.get("RAMP_GATE_FLAG", "1") != "0" and os.environ.get("RAMP_GATE_AT", "0") == "0"
+            self._gate_sig = track_dev.Signal() if use else False
+        sig = self._gate_sig
+        return sig if (sig and sig.ptr is not None and self._gate_seq < 0x7FFFFFF0) else None
+
+    def _gate_wait(self, fe):
+        """(front-end stream) wait for the previous frame's gate: the signal word if that step stored one, else the event"""
+        if self._gate_by_flag:
+            self._gate_sig.wait(fe, self._gate_seq, then_delay_us=_GATE_FLAG_DELAY_US)
+        else:
+            fe.wait_event(self._ev_gate)
+
     def _fe_delay(self):
         """(on the front-end stream, behind the selection) hold the encoder graph back a little: its LSTM launch should not
         arrive while the gru launch is still filling the chip (csrc/track.hip::trk_delay_kernel)"""
@@ -706,11 +726,11 @@ class Ramp_vo:
             env = os.environ.get("RAMP_SELECT_AHEAD")
             ahead = (env == "1") if env is not None else _gru_tile_rows(dv.factor_estimate(), self.device) == 80
             if not ahead:
-                fe.wait_event(self._ev_gate)
+                self._gate_wait(fe)
             with torch.cuda.stream(fe):
                 out = self.network.patchify(input_=input_, patches_per_image=self.cfg.PATCHES_PER_FRAME,
                                             event_bias=self.event_bias, reinit_hidden=False,
-                                            pre_replay=(lambda: fe.wait_event(self._ev_gate)) if ahead else self._fe_delay)
+                                            pre_replay=(lambda: self._gate_wait(fe)) if ahead else self._fe_delay)
             self._ev_fe_done.record(fe)
             cur.wait_event(self._ev_fe_done)
             if _WARM:
@@ -734,10 +754,14 @@ class Ramp_vo:
             dv.k_new.copy_(k_dev)
             self._last_K, self._last_K_raw = kq, self._K_raw_now
         self.tlist.append(tstamp)
+        sig = self._gate_signal() if self.inputs_ready else None
+        if sig is not None:
+            self._gate_seq += 1
         dv.step(self.counter, track_dev.COMMIT | track_dev.UPDATE | track_dev.KEYFRAME,
                 k_new=dv.k_new if k_dev is not None else None,
-                gate_event=self._ev_gate.cuda_event if self.inputs_ready else None)
-        self._gate_armed = self.inputs_ready
+                gate_event=self._ev_gate.cuda_event if (self.inputs_ready and sig is None) else None,
+                gate_flag=sig.ptr if sig is not None else None, gate_seq=self._gate_seq)
+        self._gate_armed, self._gate_by_flag = self.inputs_ready, sig is not None
         self.counter += 1
 
     def _enter_device(self):

@@ -118,6 +118,9 @@ SIGNATURES = {
     "ramp_track_step": (c_i, [c_p, c_i, c_i64, c_i, c_i, c_p, c_p, c_p]),
     "ramp_track_warm": (c_i, [c_p, c_p, c_p]),
     "ramp_stream_delay": (c_i, [c_i, c_p]),
+    "ramp_signal_alloc": (c_i, [c_p]),
+    "ramp_signal_free": (c_i, [c_p]),
+    "ramp_stream_wait_flag": (c_i, [c_p, c_p, ctypes.c_uint32, c_i, c_i]),
 }
 
 _lib = None

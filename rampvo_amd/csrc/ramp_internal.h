@@ -54,7 +54,7 @@ int ramp_i_upd_gru(const float *x32, const void *add0_t, const int32_t *add0_idx
                    float pre_eps, const void *const *wp_host, const float *const *bias_host, const float *ln_w,
                    const float *ln_b, float eps, float *out32, void *relu_t, int E, const int32_t *dyn,
                    const void *heads_w, const float *heads_b, const float *coords, float *target, float *weight, int P,
-                   float wd, float ht, int E_hint, void *stream);
+                   float wd, float ht, int E_hint, uint32_t *gate_flag, uint32_t gate_seq, void *stream);
 int ramp_i_upd_nbr(const float *net_in, const int64_t *idx, const void *wa, const float *ba, const void *wb,
                    const float *bb, float *net_out, void *out_t, int E, const int32_t *dyn, void *stream);
 int ramp_i_upd_nbr2(const float *net_in, const int32_t *kj, const int64_t *ix, const int64_t *jx, const void *w1a,

@@ -293,7 +293,37 @@ __global__ void trk_delay_kernel(long ticks) {
   while ((long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
 }
 
+// One sleeping wave that ends when *flag >= value (or after `ticks` of the 100 MHz clock), then sleeps `after` more.  It
+// looks at the word only every ~3 us: a wave that polls a system-scope word without pauses slows the other streams'
+// kernels down (tools/mb/stream_signal.hip: 64 MB copies 20.8 -> 22.3 us; the update operator 505 -> 608 us).
+__global__ void trk_wait_flag_kernel(const uint32_t *flag, uint32_t value, long ticks, long after, int nap) {
+  const long t0 = wall_clock64();
+  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < value && (long)wall_clock64() - t0 < ticks)
+    for (int i = 0; i < nap; i++) __builtin_amdgcn_s_sleep(64);
+  const long t1 = wall_clock64();
+  while ((long)wall_clock64() - t1 < after) __builtin_amdgcn_s_sleep(64);
+}
+
 extern "C" {
+
+int ramp_stream_wait_flag(void *stream, const uint32_t *flag, uint32_t value, int timeout_us, int then_delay_us) {
+  if (!flag || timeout_us <= 0 || then_delay_us < 0) return RAMP_EINVAL;
+  static int nap = 0;                                  // RAMP_FLAG_NAP: s_sleep(64) units (~1.7 us each) between two looks
+  if (!nap) { const char *e = getenv("RAMP_FLAG_NAP"); nap = e ? atoi(e) : 2; if (nap < 1) nap = 1; }
+  hipLaunchKernelGGL(trk_wait_flag_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, flag, value, (long)timeout_us * 100,
+                     (long)then_delay_us * 100, nap);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+int ramp_signal_alloc(uint32_t **flag) {
+  if (!flag) return RAMP_EINVAL;
+  void *p = nullptr;
+  if (hipExtMallocWithFlags(&p, 8, hipMallocSignalMemory) != hipSuccess) return RAMP_EUNSUPPORTED;
+  if (hipMemset(p, 0, 8) != hipSuccess) { (void)hipFree(p); return RAMP_ELAUNCH; }
+  *flag = (uint32_t *)p;
+  return RAMP_OK;
+}
+int ramp_signal_free(uint32_t *flag) { return (!flag || hipFree(flag) == hipSuccess) ? RAMP_OK : RAMP_ELAUNCH; }
 
 int ramp_stream_delay(int microseconds, void *stream) {
   if (microseconds <= 0) return RAMP_OK;
@@ -403,7 +433,7 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
     // second SoftAgg; 2 = before the first; 3 = before c1 / c2 -- A/B runs)
     static int gate_at = -1;
     if (gate_at < 0) { const char *e = getenv("RAMP_GATE_AT"); gate_at = e ? atoi(e) : 0; }
-#define TRK_GATE(pos) do { if (gate_event && gate_at == (pos) && hipEventRecord((hipEvent_t)gate_event, st) != hipSuccess) return RAMP_ELAUNCH; } while (0)
+#define TRK_GATE(pos) do { if (gate_event && !(t->gate_flag && gate_at == 0) && gate_at == (pos) && hipEventRecord((hipEvent_t)gate_event, st) != hipSuccess) return RAMP_ELAUNCH; } while (0)
     TRK_GATE(3);
     // RAMP_NBR2=1: c1 and c2 in one launch over the (kk, jj)-sorted factor list (bit-identical; measured 2 % SLOWER on
     // the whole operator than the two launches although it moves a third of their bytes -- DESIGN.md section 8)
@@ -435,7 +465,7 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
     // (the heads and target / weight are formed in the gru launch's epilogue: no relu(net) round trip, one launch less)
     TRK_DO(ramp_i_upd_gru(net, add2 ? t->hkk : nullptr, add2 ? t->kk_gid : nullptr, t->hij, t->ij_gid, w.ln1_w, w.ln1_b, w.ln1_eps, w.gru_w, w.gru_b, w.ln2_w, w.ln2_b,
                           w.ln2_eps, t->net[0], nullptr, Eb, dyn, w.heads_w, w.heads_b, t->coords, t->target, t->weight, t->P,
-                          (float)t->feat_w, (float)t->feat_h, t->E_hint, st));
+                          (float)t->feat_w, (float)t->feat_h, t->E_hint, gate_at == 0 ? t->gate_flag : nullptr, t->gate_seq, st));
     TRK_PROBE(2);
     TRK_PROBE(3);
     TRK_DO(ramp_i_ba_dyn(t->poses, t->patches, t->intrinsics, t->target, t->weight, t->lmbda, ii, jj, kk, Eb, t->P,

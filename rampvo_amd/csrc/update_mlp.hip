@@ -194,6 +194,8 @@ struct GruParams {
   // optional prologue: x = LayerNorm_pre(x32 + add_t[add_idx]) -- the last SoftAgg's expand-and-add and gru[0]
   const _Float16 *add_t;       // [groups][384] fp16 or NULL
   const int32_t *add_idx;      // [E]
+  uint32_t *gate_flag;         // optional: workgroup 0 stores gate_seq here when it starts (ramp_track.gate_flag)
+  uint32_t gate_seq;
   const _Float16 *add0_t;      // optional: a FIRST expand-and-add (x32 + add0_t[add0_idx]) + add_t[add_idx] -- the second-last
   const int32_t *add0_idx;     // SoftAgg's, when the launch that consumed it did not write the sum back
   const float *pre_w, *pre_b;  // gru[0] LayerNorm
@@ -292,6 +294,10 @@ __global__ void __launch_bounds__(64 * MWAVES) upd_gru_kernel(const GruParams p)
   float *T1 = reinterpret_cast<float *>(Gs + ROWS * MXS), *T2 = T1 + ROWS * MWAVES;   // LayerNorm partials
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
   const int row0 = blockIdx.x * ROWS;
+  // "the next frame's front end may start": a plain store the other stream's sleeping wave looks for (timing only, no
+  // data rides on it)
+  if (p.gate_flag && blockIdx.x == 0 && tid == 0)
+    __hip_atomic_store(p.gate_flag, p.gate_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   const int pE = p.dyn ? p.dyn[RAMP_DYN_E] : p.E;
   if (row0 >= pE) return;                      // (workgroup-uniform: only with device-side sizes)
   const int col0 = wave * (16 * MNTW);
@@ -1373,7 +1379,7 @@ int ramp_i_upd_gru(const float *x32, const void *add0_t, const int32_t *add0_idx
                  float pre_eps, const void *const *wp_host, const float *const *bias_host, const float *ln_w,
                  const float *ln_b, float eps, float *out32, void *relu_t, int E, const int32_t *dyn,
                  const void *heads_w, const float *heads_b, const float *coords, float *target, float *weight, int P,
-                 float wd, float ht, int E_hint, void *stream) {
+                 float wd, float ht, int E_hint, uint32_t *gate_flag, uint32_t gate_seq, void *stream) {
   if (E < 0) return RAMP_EINVAL;
   if (E == 0) return RAMP_OK;
   if (!x32 || !wp_host || !bias_host || !ln_w || !ln_b || !out32 || (!relu_t && !heads_w)) return RAMP_EINVAL;
@@ -1382,7 +1388,7 @@ int ramp_i_upd_gru(const float *x32, const void *add0_t, const int32_t *add0_idx
   if (add0_t && (!add0_idx || !add_t)) return RAMP_EINVAL;
   GruParams p;
   p.x32 = x32;
-  p.add0_t = (const _Float16 *)add0_t; p.add0_idx = add0_idx;
+  p.add0_t = (const _Float16 *)add0_t; p.add0_idx = add0_idx; p.gate_flag = gate_flag; p.gate_seq = gate_seq;
   p.add_t = (const _Float16 *)add_t; p.add_idx = add_idx; p.pre_w = pre_w; p.pre_b = pre_b; p.pre_eps = pre_eps;
   for (int i = 0; i < 6; i++) {
     if (!wp_host[i] || !bias_host[i]) return RAMP_EINVAL;
@@ -1514,7 +1520,7 @@ int ramp_upd_gru(const float *x32, const void *add_t, const int32_t *add_idx, co
                  float pre_eps, const void *const *wp_host, const float *const *bias_host, const float *ln_w,
                  const float *ln_b, float eps, float *out32, void *relu_t, int E, void *stream) {
   return ramp_i_upd_gru(x32, nullptr, nullptr, add_t, add_idx, pre_w, pre_b, pre_eps, wp_host, bias_host, ln_w, ln_b, eps, out32, relu_t, E, nullptr,
-                        nullptr, nullptr, nullptr, nullptr, nullptr, 3, 0.f, 0.f, 0, stream);
+                        nullptr, nullptr, nullptr, nullptr, nullptr, 3, 0.f, 0.f, 0, nullptr, 0u, stream);
 }
 
 int ramp_upd_gru_heads(const float *x32, const void *add_t, const int32_t *add_idx, const float *pre_w, const float *pre_b,
@@ -1523,7 +1529,7 @@ int ramp_upd_gru_heads(const float *x32, const void *add_t, const int32_t *add_i
                        const float *coords, float *target, float *weight, int E, int P, float wd, float ht, void *stream) {
   if (!heads_w) return RAMP_EINVAL;
   return ramp_i_upd_gru(x32, nullptr, nullptr, add_t, add_idx, pre_w, pre_b, pre_eps, wp_host, bias_host, ln_w, ln_b, eps, out32, nullptr, E, nullptr,
-                        heads_w, heads_b, coords, target, weight, P, wd, ht, 0, stream);
+                        heads_w, heads_b, coords, target, weight, P, wd, ht, 0, nullptr, 0u, stream);
 }
 
 int ramp_upd_nbr(const float *net_in, const int64_t *idx, const void *wa, const float *ba, const void *wb,

@@ -52,7 +52,30 @@ class Track(ctypes.Structure):
                 + _ptr_fields(["coords", "corr"]) + [("net", c_p * 3)]
                 + _ptr_fields(["fg", "ykk", "hkk", "yij", "hij", "relu_t", "target", "weight", "ba_ws"])
                 + [("ba_ws_bytes", c_sz)]
-                + _ptr_fields(["mm", "median", "dlog", "edit_ws", "dyn_host"]) + [("probe", c_p * 5), ("E_hint", c_i)])
+                + _ptr_fields(["mm", "median", "dlog", "edit_ws", "dyn_host"]) + [("probe", c_p * 5), ("E_hint", c_i),
+                   ("gate_seq", ctypes.c_uint32), ("gate_flag", c_p)])
+
+
+class Signal:
+    """a 32-bit word in signal memory (csrc/track.hip::ramp_signal_alloc): a kernel stores a sequence number, another
+    stream waits for it with one sleeping wave -- a cross-stream "go" without a packet on the producer's stream.  ptr is
+    None where the allocation is not supported (the caller keeps its event then)."""
+
+    def __init__(self):
+        p = ctypes.c_void_p()
+        rc = _lib.lib().ramp_signal_alloc(ctypes.byref(p))
+        self.ptr = p if rc == 0 and p.value else None
+
+    def wait(self, stream, value, timeout_us=50000, then_delay_us=0):
+        _lib.check(_lib.lib().ramp_stream_wait_flag(ctypes.c_void_p(stream.cuda_stream), self.ptr, int(value) & 0xFFFFFFFF,
+                                                    int(timeout_us), int(then_delay_us)), "ramp_stream_wait_flag")
+
+    def __del__(self):
+        try:
+            if self.ptr is not None:
+                _lib.lib().ramp_signal_free(self.ptr)
+        except Exception:
+            pass
 
 
 def supported(slam):
@@ -240,9 +263,12 @@ class DeviceTrack:
             self._e_seen.append(e)
         return int(min(max(self._e_seen), self.E_cap))
 
-    def step(self, counter, flags, k_new=None, gate_event=None):
+    def step(self, counter, flags, k_new=None, gate_event=None, gate_flag=None, gate_seq=0):
+        """gate_flag / gate_seq: a signal word (Signal) the update operator's last launch stores gate_seq into -- the
+        cheaper form of gate_event (no packet on this stream); the waiting stream uses Signal.wait"""
         ev = ctypes.c_void_p(gate_event) if gate_event else None
         self.t.E_hint = self.factor_estimate()
+        self.t.gate_flag, self.t.gate_seq = (gate_flag, int(gate_seq) & 0xFFFFFFFF) if gate_flag else (None, 0)
         _lib.check(_lib.lib().ramp_track_step(ctypes.byref(self.t), self.cur, int(counter), int(flags),
                                               self.factor_bound(counter), _lib.ptr(k_new), ev, _lib.stream()),
                    "ramp_track_step")
