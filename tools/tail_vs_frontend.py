@@ -18,7 +18,8 @@ torch.cuda.synchronize()
 mk = lambda: torch.cuda.Event(enable_timing=True)
 rec = []
 inner = track_dev.DeviceTrack.step
-def step(dv, counter, flags, k_new=None, gate_event=None):
+os.environ["RAMP_GATE_FLAG"] = "0"       # the gate must be an event here: it is the time origin of both chains
+def step(dv, counter, flags, k_new=None, gate_event=None, **kw):
     g, e = mk(), mk()
     g.record(); e.record()            # create the handles
     dv.t.probe[2] = None
