@@ -56,6 +56,10 @@ class Track(ctypes.Structure):
                    ("gate_seq", ctypes.c_uint32), ("gate_flag", c_p)])
 
 
+_E_EST_LAST = int(os.environ.get("RAMP_E_EST_LAST", "1"))        # 0: the largest of the last 64 copies (round 3's first rule)
+_E_EST_MARGIN = int(os.environ.get("RAMP_E_EST_MARGIN", "0"))
+
+
 class Signal:
     """a 32-bit word in signal memory (csrc/track.hip::ramp_signal_alloc): a kernel stores a sequence number, another
     stream waits for it with one sleeping wave -- a cross-stream "go" without a packet on the producer's stream.  ptr is
@@ -256,11 +260,17 @@ class DeviceTrack:
         return min(int(d[DYN_E]) + lag * self.new_cap, self.E_cap)
 
     def factor_estimate(self):
-        """the largest live factor count among the last 64 lazy copies of the sizes (the steady state oscillates by a
-        frame's worth around its level): picks tile sizes, bounds nothing"""
+        """the live factor count of the newest lazy copy of the sizes (a frame or two old; tools/e_trace.py: the count
+        drifts by a few hundred per frame over 39k .. 46k at the bench size, so a maximum over 64 frames sits above the
+        80-row gru tile's limit of 40960 most of the time although half of the frames are below it): picks tile sizes,
+        bounds nothing.  Sequential rate 834 -> 853 kf/s, pipelined unchanged (RAMP_E_EST_LAST=0: the maximum)."""
         e = int(self.dyn_host.numpy()[DYN_E])
         if not self._e_seen or self._e_seen[-1] != e:
             self._e_seen.append(e)
+        k = _E_EST_LAST
+        if k > 0:                                     # the last k copies + a frame's growth (tools/e_trace.py: the count moves
+            recent = list(self._e_seen)[-k:]          # by a few hundred per frame, over a range of 39k .. 46k)
+            return int(min(max(recent) + _E_EST_MARGIN, self.E_cap))
         return int(min(max(self._e_seen), self.E_cap))
 
     def step(self, counter, flags, k_new=None, gate_event=None, gate_flag=None, gate_seq=0):
