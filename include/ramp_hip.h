@@ -318,6 +318,10 @@ int ramp_any_nonzero(const float *a, long na, const float *b, long nb, int32_t *
  * returns the number of workgroups nblk (> 0) whose results are valid, or an error code (< 0).  The consumer
  * (ramp_lstm_superstate_blocks) ORs blockflags[r][0 .. nblk).                                                       */
 int ramp_any_nonzero_blocks(const float *a, long na, const float *b, long nb, int32_t *blockflags, void *stream);
+/* the same launch also zeroes `clear` [clear_bytes] (16-byte aligned, a multiple of 16): the InstanceNorm accumulators of
+ * the frame's tower pass (ramp_conv job acc_out / acc_in) without a memset launch in front of the front end          */
+int ramp_any_nonzero_blocks_clear(const float *a, long na, const float *b, long nb, int32_t *blockflags, void *clear,
+                                  long clear_bytes, void *stream);
 
 /* The two per-pixel LSTM cells and the super-state 1x1 convolution of the SingleScale encoder,
  * fused (ramp/extractor.py:239-259: nn.LSTM x2 on [H*W,1,C] sequences + Conv2d(30->15) x2), on the

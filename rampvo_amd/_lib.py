@@ -82,6 +82,7 @@ SIGNATURES = {
     "ramp_lstm_superstate_tiled": (c_i, [c_p] * 9 + [c_i, c_i, c_i, c_p]),
     "ramp_lstm_superstate_blocks": (c_i, [c_p] * 9 + [c_i, c_i, c_i, c_i, c_p]),
     "ramp_any_nonzero_blocks": (c_i, [c_p, ctypes.c_long, c_p, ctypes.c_long, c_p, c_p]),
+    "ramp_any_nonzero_blocks_clear": (c_i, [c_p, ctypes.c_long, c_p, ctypes.c_long, c_p, c_p, ctypes.c_long, c_p]),
     "ramp_conv2d_nhwc": (c_i, [c_p] * 8 + [c_i] * 8 + [c_f, c_i, c_p]),
     "ramp_in_stats_finalize": (c_i, [c_p, c_i, c_i, c_f, c_f, c_p, c_p, c_p]),
     "ramp_affine_relu": (c_i, [c_p, c_p, c_p, c_p, ctypes.c_long, c_i, c_p]),

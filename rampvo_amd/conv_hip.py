@@ -152,8 +152,10 @@ class _AccArena:
     [R][128][2] handed out in order"""
     SLOTS = 16
 
-    def __init__(self, device):
-        self.buf = torch.zeros(self.SLOTS, IN_ACC_R * 128 * 2, dtype=torch.int64, device=device)
+    def __init__(self, device, zeroed=True):
+        # zeroed=False: the caller zeroes buf itself before the pass (lstm_superstate_step: inside the front end's first launch)
+        make = torch.zeros if zeroed else torch.empty
+        self.buf = make(self.SLOTS, IN_ACC_R * 128 * 2, dtype=torch.int64, device=device)
         self.used = 0
 
     def slot(self, C):
@@ -168,6 +170,7 @@ class _ArenaScope(threading.local):
     """the accumulator arena of the tower pass running in THIS thread (None outside one): two trackers on two threads do
     not see each other's"""
     cur = None
+    prepared = None        # an arena the caller has already zeroed for the next basic_encoder4_towers pass of this thread
 
 
 _scope = _ArenaScope()
@@ -400,7 +403,8 @@ def basic_encoder4_towers(encs, x, out_scale=1.0, half=False, fp8=False):
     (``half``: fp16 storage + fp16 MFMA after the first layer's fp32 input).  relu(norm1(conv1)) is never
     materialised: layer1's first conv applies it while loading, the block's tail while adding the skip."""
     norms = _tower_norms(encs)
-    _scope.cur = _AccArena(x.device) if (half and _IN_ACC and any(norms)) else None
+    _scope.cur = (_scope.prepared or _AccArena(x.device)) if (half and _IN_ACC and any(norms)) else None
+    _scope.prepared = None
     try:
         xs = _first_layer(encs, x, norms, half)
         for li in ("layer1", "layer2"):
@@ -445,7 +449,7 @@ class LstmState:
     """recurrent state of the SingleScale front end.  h_*, c_*: tile-major [ceil(HW/16)][16 px][4 q][4 t], unit = 4 t + q
     (the MFMA kernel's layout: a lane's four operands are 16 contiguous bytes; unit 15 is padding; held here as
     [tiles, 16, 16]); ss: channels-last [HW, 16]."""
-    __slots__ = ("h_ev", "c_ev", "h_im", "c_im", "ss", "flags", "fresh", "HW")
+    __slots__ = ("h_ev", "c_ev", "h_im", "c_im", "ss", "flags", "fresh", "HW", "arena")
 
     def __init__(self, HW, device):
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=device)
@@ -455,6 +459,7 @@ class LstmState:
         self.flags = torch.zeros(2, 1024, dtype=torch.int32, device=device)     # per-workgroup results (ramp_any_nonzero_blocks)
         self.fresh = True
         self.HW = HW
+        self.arena = None      # the tower pass's InstanceNorm accumulators (zeroed by the presence test's launch)
 
     def rows(self, name):
         """state `name` as [HW, 15] rows (pixel-major), for inspection / tests"""
@@ -462,14 +467,25 @@ class LstmState:
         return t.view(-1, 16, 4, 4).permute(0, 1, 3, 2).reshape(-1, 16)[:self.HW, :15]
 
 
-def lstm_superstate_step(enc, ev, im, st):
+def lstm_superstate_step(enc, ev, im, st, arena_for_towers=False):
     """ev [5,H,W], im [3,H,W] contiguous fp32; updates st in place, returns the super-state
     as an NHWC16 tensor [H,W,16] (a view of st.ss)"""
     w = pack_lstm_mfma(enc)
     H, W = ev.shape[-2:]
-    nblk = lib().ramp_any_nonzero_blocks(ptr(ev), ev.numel(), ptr(im), im.numel(), ptr(st.flags), stream())
+    # the presence test is the front end's first launch: it also zeroes the InstanceNorm accumulators of the tower pass
+    # that follows (a persistent arena of this state; its memset launch was 4.8 us + a boundary of every front end)
+    arena = None
+    if arena_for_towers and _IN_ACC:
+        if st.arena is None:
+            st.arena = _AccArena(ev.device, zeroed=False)
+        arena = st.arena
+        arena.used = 0
+    nblk = lib().ramp_any_nonzero_blocks_clear(ptr(ev), ev.numel(), ptr(im), im.numel(), ptr(st.flags),
+                                               ptr(arena.buf) if arena else None, arena.buf.numel() * 8 if arena else 0,
+                                               stream())
     if nblk <= 0:
-        check(nblk or -1, "ramp_any_nonzero_blocks")
+        check(nblk or -1, "ramp_any_nonzero_blocks_clear")
+    _scope.prepared = arena
     has = 0 if st.fresh else 1
     check(lib().ramp_lstm_superstate_blocks(ptr(ev), ptr(im), ptr(st.h_ev), ptr(st.c_ev), ptr(st.h_im),
                                             ptr(st.c_im), ptr(st.ss), ptr(w), ptr(st.flags), nblk, H * W, has, has,

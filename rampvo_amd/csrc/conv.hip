@@ -26,12 +26,14 @@
 #define ANY_MAXB 1024          // workgroups of any_nonzero_kernel (per-workgroup results: flags [2][ANY_MAXB])
 __global__ void __launch_bounds__(256)
     any_nonzero_kernel(const float *__restrict__ a, long na, const float *__restrict__ b, long nb,
-                       int *__restrict__ flags, int per_block) {
+                       int *__restrict__ flags, int per_block, uint4 *__restrict__ clear, long clear_n) {
   __shared__ int s_any[2];
   if (threadIdx.x < 2) s_any[threadIdx.x] = 0;
   __syncthreads();
   const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   const long stride = (long)gridDim.x * blockDim.x * 4;
+  // (the front end's first launch also zeroes the InstanceNorm accumulators of the frame: no memset launch)
+  for (long k = i / 4; k < clear_n; k += stride / 4) clear[k] = make_uint4(0u, 0u, 0u, 0u);
   bool fa = false, fb = false;
   for (long k = i; k < na; k += stride) {
     if (k + 3 < na) {
@@ -1233,19 +1235,25 @@ int ramp_any_nonzero(const float *a, long na, const float *b, long nb, int32_t *
   int blocks = (int)((n / 4 + 255) / 256);
   if (blocks > 1024) blocks = 1024;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(any_nonzero_kernel, dim3(blocks), dim3(256), 0, st, a, na, b, nb, flags, 0);
+  hipLaunchKernelGGL(any_nonzero_kernel, dim3(blocks), dim3(256), 0, st, a, na, b, nb, flags, 0, (uint4 *)nullptr, 0l);
   RAMP_CHECK_LAUNCH();
   return RAMP_OK;
 }
 
 int ramp_any_nonzero_blocks(const float *a, long na, const float *b, long nb, int32_t *blockflags, void *stream) {
-  if (!blockflags) return RAMP_EINVAL;
+  return ramp_any_nonzero_blocks_clear(a, na, b, nb, blockflags, nullptr, 0, stream);
+}
+
+int ramp_any_nonzero_blocks_clear(const float *a, long na, const float *b, long nb, int32_t *blockflags, void *clear,
+                                  long clear_bytes, void *stream) {
+  if (!blockflags || clear_bytes < 0 || (clear_bytes & 15) || (clear_bytes && (!clear || ((size_t)clear & 15)))) return RAMP_EINVAL;
   const long n = na > nb ? na : nb;
   if (n <= 0) return RAMP_EINVAL;
   int blocks = (int)((n / 4 + 255) / 256);
   if (blocks > ANY_MAXB) blocks = ANY_MAXB;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(any_nonzero_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, na, b, nb, blockflags, 1);
+  hipLaunchKernelGGL(any_nonzero_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, na, b, nb, blockflags, 1,
+                     (uint4 *)clear, clear_bytes / 16);
   if (hipGetLastError() != hipSuccess) return RAMP_ELAUNCH;
   return blocks;
 }

@@ -134,7 +134,7 @@ class MergerLSTMsceneEncoder(nn.Module):
         if reinit_hidden:
             st.fresh = True
         s16 = conv_hip.lstm_superstate_step(self, events[0, 0].float().contiguous(),
-                                            images[0, 0].float().contiguous(), st)
+                                            images[0, 0].float().contiguous(), st, arena_for_towers=self.mixed_precision)
         # both towers layer by layer; fp16: one launch per layer for the two of them ([h,w,128], [h,w,384]).  One stream:
         # a fork / join inside the front end's hipGraph bought nothing measurable (the paired launches fill the
         # chip) and multi-stream captures were the one configuration that crashed hipGraphLaunch in long test runs.
