@@ -227,7 +227,7 @@ class DeviceProbe:
         def step(dv, counter, flags, **k):
             on = probe.enabled and probe.mode and probe.used < len(probe.sets) and (flags & track_dev.UPDATE)
             for i in range(5):
-                dv.t.probe[i] = probe.sets[probe.used][i].cuda_event if on and (probe.mode == "all" or i < 2) else None
+                dv.t.probe[i] = probe.sets[probe.used][i].cuda_event if on and (probe.mode != "corr" or i < 2) else None
             if on:
                 probe.edges.append(int(dv.lazy_state()[track_dev.DYN_E]))      # a frame or two old: fine for a mean
                 probe.modes.append(probe.mode)
@@ -240,6 +240,9 @@ class DeviceProbe:
         for evs, E, mode in zip(self.sets[:self.used], self.edges, self.modes):
             if mode == "corr":                 # the timed region's samples: what roofline.achieved is computed from
                 ctimer.pairs.append((evs[0], evs[1])); ctimer.edges.append(E)
+            elif mode == "alone":              # the sequential pass: nothing else on the GPU
+                utimer.alone_ms.append(evs[1].elapsed_time(evs[2]))
+                btimer.alone_ms.append(evs[3].elapsed_time(evs[4]))
             else:                              # the instrumented pass behind it
                 self.corr_inst_ms.append(evs[0].elapsed_time(evs[1]))
                 utimer.pairs.append((evs[1], evs[2])); utimer.edges.append(E)
@@ -251,7 +254,7 @@ class UpdateTimer:
     launch carries the two heads in its epilogue)"""
 
     def __init__(self):
-        self.pairs, self.edges, self.enabled = [], [], False
+        self.pairs, self.edges, self.enabled, self.alone_ms = [], [], False, []
 
     def install(self):
         from rampvo_amd.update_fused import FusedUpdate
@@ -279,18 +282,24 @@ class UpdateTimer:
         E, mean_ms = float(edges[big].mean()), float(ms[big].mean())
         peak = MFMA_F16_PEAK_TFLOPS if mixed else MFMA_F32_PEAK_TFLOPS
         ach = E * UPDATE_FLOP_PER_EDGE / (mean_ms * 1e-3) / 1e12
-        return dict(kernel="update operator: upd_corr_mlp + upd_nbr x2 + (upd_fg + segment softmax + h GEMM) x2 + upd_gru",
-                    bound="mfma", achieved=round(ach, 1), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
-                    mean_call_us=round(mean_ms * 1e3, 1), edges=int(E), flop_per_edge=UPDATE_FLOP_PER_EDGE,
-                    note="18 Linear layers of 384 (one of K = 882) per edge, SURVEY 8(d)'s 5.40 MFLOP/edge; the "
-                         "time is the whole operator incl. its row-wise LayerNorm / gate / softmax passes")
+        out = dict(kernel="update operator: upd_corr_mlp + upd_nbr x2 + (upd_fg + segment softmax + h GEMM) x2 + upd_gru",
+                   bound="mfma", achieved=round(ach, 1), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
+                   mean_call_us=round(mean_ms * 1e3, 1), edges=int(E), flop_per_edge=UPDATE_FLOP_PER_EDGE,
+                   note="18 Linear layers of 384 (one of K = 882) per edge, SURVEY 8(d)'s 5.40 MFLOP/edge; the "
+                        "time is the whole operator incl. its row-wise LayerNorm / gate / softmax passes (pipelined: "
+                        "its gru launch shares the chip with the next frame's front end)")
+        if self.alone_ms:
+            a = float(np.mean(self.alone_ms))
+            out["mean_call_us_alone"] = round(a * 1e3, 1)
+            out["frac_alone"] = round(E * UPDATE_FLOP_PER_EDGE / (a * 1e-3) / 1e12 / peak, 4)
+        return out
 
 
 class BaTimer:
     """HIP events around fastba.BA (two Gauss-Newton iterations)"""
 
     def __init__(self):
-        self.pairs, self.meta, self.enabled = [], [], False
+        self.pairs, self.meta, self.enabled, self.alone_ms = [], [], False, []
 
     def install(self):
         from rampvo_amd import fastba
@@ -318,11 +327,14 @@ class BaTimer:
         # 116 B per edge per iteration in, + per-iteration outputs (6N)^2 + 6N*Mu + 2*Mu + 6N floats
         nbytes = it * (116.0 * E + 4.0 * ((6 * N) ** 2 + 6 * N * mu + 2 * mu + 6 * N))
         ach = nbytes / (ms * 1e-3) / 1e9
-        return dict(kernel="fastba.BA (2 Gauss-Newton iterations)",
-                    bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 5),
-                    traffic=None, mean_call_us=round(ms * 1e3, 1), bytes_per_call=int(nbytes), edges=int(E),
-                    free_poses=int(N), note="a short dependent chain on ~10 MB: latency, not bandwidth, bounds it "
-                                            "(time includes the overlap with the next frame's front end when pipelining)")
+        out = dict(kernel="fastba.BA (2 Gauss-Newton iterations)",
+                   bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 5),
+                   traffic=None, mean_call_us=round(ms * 1e3, 1), bytes_per_call=int(nbytes), edges=int(E),
+                   free_poses=int(N), note="a short dependent chain on ~10 MB: latency, not bandwidth, bounds it "
+                                           "(time includes the overlap with the next frame's front end when pipelining)")
+        if self.alone_ms:
+            out["mean_call_us_alone"] = round(float(np.mean(self.alone_ms)) * 1e3, 1)
+        return out
 
 
 class EncoderTimer:
@@ -616,7 +628,7 @@ def main():
         etimer.install(net)
         btimer.install()
         utimer.install()
-        dprobe = DeviceProbe(args.steps + n_inst)
+        dprobe = DeviceProbe(args.steps + n_inst + n_alone)
         dprobe.install()
 
     pos = {"t": 0}
@@ -682,7 +694,6 @@ def main():
         etimer.enabled = False
     if dprobe is not None:
         dprobe.enabled = False
-        dprobe.feed(ctimer, utimer, btimer, cfg.OPTIMIZATION_WINDOW)
 
     from rampvo_amd.shard import gather_metrics, max_over_ranks
     dt_all = max_over_ranks(dt, dev)
@@ -707,11 +718,15 @@ def main():
         np_kfps = n_np / (time.perf_counter() - t_np)
         if dprobe is not None and device_step:     # (behind the timed sequential pass) the front end's replay alone
             keep, etimer.pairs, etimer.enabled = etimer.pairs, [], True
+            dprobe.enabled, dprobe.mode = True, "alone"
             for _ in range(n_alone):
                 step()
             torch.cuda.synchronize()
+            dprobe.enabled = False
             etimer.alone, etimer.pairs, etimer.enabled = etimer.pairs, keep, False
 
+    if dprobe is not None:
+        dprobe.feed(ctimer, utimer, btimer, cfg.OPTIMIZATION_WINDOW)
     if rank == 0:
         value = world * args.steps / dt_all
         out = {
