@@ -685,6 +685,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - tic
+    gate_kind = "signal word stored by the gru launch" if getattr(slam, "_gate_by_flag", False) else "event"
     ctimer.enabled = etimer.enabled = btimer.enabled = utimer.enabled = False
     if dprobe is not None and device_step:
         dprobe.mode, etimer.enabled = "all", True
@@ -751,6 +752,7 @@ def main():
                        "clock_warm": "%d untimed steady-state steps (%.2f s) before the %d warm-up steps"
                                      % (warm_steps, warm_s, args.warmup),
                        "frame_pipelining": bool(args.pipeline),
+                       "pipeline_gate": gate_kind if args.pipeline else None,
                        "non_pipelined_kfps": round(np_kfps, 1) if np_kfps else None,
                        "host_step_ms_p50_p90_max": [round(1e3 * float(v), 3) for v in
                                                     (np.percentile(np.diff(marks), 50), np.percentile(np.diff(marks), 90),
