@@ -85,5 +85,23 @@ int main() {
     if (mode) printf("   stream B's kernel starts %.1f us after A's second kernel (median; p90 %.1f)", lagB[lagB.size() / 2], lagB[lagB.size() * 9 / 10]);
     printf("\n");
   }
+  // (d) a wait on an event that completed long ago, between two kernels of stream A
+  {
+    hipEvent_t done; CK(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    std::vector<double> gap;
+    for (int it = 0; it < 40; it++) {
+      hipLaunchKernelGGL(spin_kernel, dim3(64), dim3(64), 0, B, 100l, st + 4, (uint32_t *)nullptr, 0u);
+      CK(hipEventRecord(done, B));
+      CK(hipDeviceSynchronize());
+      hipLaunchKernelGGL(spin_kernel, dim3(256), dim3(256), 0, A, T, st, (uint32_t *)nullptr, 0u);
+      CK(hipStreamWaitEvent(A, done, 0));
+      hipLaunchKernelGGL(spin_kernel, dim3(256), dim3(256), 0, A, T, st + 2, (uint32_t *)nullptr, 0u);
+      CK(hipDeviceSynchronize());
+      CK(hipMemcpy(h, st, sizeof(h), hipMemcpyDeviceToHost));
+      if (it >= 8) gap.push_back((double)(h[2] - h[1]) / 100.0);
+    }
+    std::sort(gap.begin(), gap.end());
+    printf("hipStreamWaitEvent on a COMPLETED event between two kernels of stream A: gap median %.1f us\n", gap[gap.size() / 2]);
+  }
   return resident_cost(A, B, flag);
 }
