@@ -1052,3 +1052,35 @@ def test_geometry_kernels_are_bit_stable_next_to_the_conv_towers():
             bad += not torch.equal(fn(), ref)
         torch.cuda.synchronize()
         assert bad == 0, (fn.__name__, bad)
+
+
+def test_signal_word_releases_or_times_out_the_waiting_stream():
+    """the frame pipeline's gate (include/ramp_hip.h: ramp_signal_alloc / ramp_stream_wait_flag): a stream behind a
+    wait for a word that is already >= the value goes on at once; a wait for a value nobody stores ends by its
+    time-out instead of hanging the stream"""
+    import ctypes
+    import time
+    from rampvo_amd import _lib, track_dev
+    sig = track_dev.Signal()
+    assert sig.ptr is not None                                  # MI355X supports signal memory
+    side = torch.cuda.Stream()
+    x = torch.zeros(1, device="cuda")
+    sig.wait(side, 0)                                           # (untimed: loads the kernel, creates the stream's queue)
+    with torch.cuda.stream(side):
+        x += 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sig.wait(side, 0)                                           # the word is 0: satisfied
+    with torch.cuda.stream(side):
+        x += 1
+    side.synchronize()
+    quick = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    sig.wait(side, 7, timeout_us=20000)                         # nobody stores 7: 20 ms, then on
+    with torch.cuda.stream(side):
+        x += 1
+    side.synchronize()
+    slow = time.perf_counter() - t0
+    assert float(x.item()) == 2.0
+    assert quick < 0.015 and 0.018 <= slow < 0.2, (quick, slow)
+    assert _lib.lib().ramp_stream_wait_flag(None, None, 1, 10, 0) != 0        # no word: refused
