@@ -1,5 +1,8 @@
+#!/usr/bin/env python
+"""the live factor count of every steady-state frame (SingleScale 640x480, 96 patches, default.yaml windows): what
+DeviceTrack.factor_estimate() and the gru launch's tile choice see"""
 import os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from rampvo_amd.config import make_cfg
 from rampvo_amd.Ramp_vo import Ramp_vo
