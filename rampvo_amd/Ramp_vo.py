@@ -682,7 +682,8 @@ class Ramp_vo:
         memory, or 2^31 frames behind us: the event then)"""
         if self._gate_sig is None:
             use = os.environ.get("RAMP_GATE_FLAG", "1") != "0" and os.environ.get("RAMP_GATE_AT", "0") == "0"
-            self._gate_sig = track_dev.Signal() if use else False
+            with torch.cuda.device(self.device):          # (the word must live on the tracker's GPU, not the caller's current one)
+                self._gate_sig = track_dev.Signal() if use else False
         sig = self._gate_sig
         return sig if (sig and sig.ptr is not None and self._gate_seq < 0x7FFFFFF0) else None
 
