@@ -667,7 +667,8 @@ def main():
     # Inside the timed region only the dominant kernel is bracketed, and only on every --probe-every-th step: an event
     # record costs a ~6 us bubble on its stream (five per step were 1.4 % of the rate).  The update operator, bundle
     # adjustment and the front end are timed in the instrumented pass BEHIND the timed region (same stream of frames).
-    device_step = dprobe is not None and os.environ.get("RAMP_DEVICE_STEP", "1") == "1"
+    dv = getattr(slam, "_dev", None)              # (the fp32 path and unsupported configurations stay host driven)
+    device_step = dprobe is not None and dv is not None and bool(getattr(dv, "active", False))
     ctimer.enabled = not device_step             # (host-driven path: the Python-level hooks, every step, as before)
     etimer.enabled = btimer.enabled = utimer.enabled = ctimer.enabled and dprobe is not None
     if dprobe is not None:
