@@ -466,6 +466,22 @@ def test_evaluate_harness_run_and_run_pose_pred():
     assert list(ts2[-4:]) == [16, 17, 18, 19]
 
 
+def test_bench_runs_the_host_driven_fp32_path():
+    """bench.py --mixed 0 (the fp32 tracker is host driven: its roofline legs come from the Python-level hooks, not from the
+    device step's probes)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--height", "240", "--width", "320", "--patches", "48",
+                          "--prime", "40", "--warmup", "3", "--steps", "8", "--cpu-steps", "0", "--parity", "0", "--mixed", "0",
+                          "--np-steps", "4", "--inst-steps", "8"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["dtype"] == "f32" and d["roofline"]["launches"] == 8 and d["roofline_update"]["mean_call_us"] > 0
+
+
 def test_bench_json_contract():
     """bench.py prints ONE JSON line with the driver's keys, the roofline of the correlation kernel measured in this
     run (HIP events on the launch stream) and the CPU baseline -- on a small workload so that it runs in seconds"""
