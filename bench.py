@@ -91,10 +91,30 @@ def parse():
     ap.add_argument("--parity", type=int, default=1,
                     help="1: after the timed region, one teacher-forced update() from the run's snapshot on HIP fp16 / "
                          "HIP fp32 / the CPU oracle, and the free-running trajectory check (rank 0, N = 1)")
+    ap.add_argument("--config", type=int, default=0, choices=(0, 1, 2, 3, 4),
+                    help="BASELINE.json configs[i] as written (sets mode / preset / size / patches / windows; explicit flags "
+                         "still override): 1 = SingleScale 640x480 M=96 default.yaml (the default workload), 2 and 3 = "
+                         "MultiScale M=96 precise.yaml windows (3: one such sequence per rank), 4 = MultiScale 1280x720 M=256, "
+                         "32-keyframe optimisation window, precise lifetimes, fp8-MFMA encoder, every frame kept a keyframe")
+    ap.add_argument("--keyframe-thresh", type=float, default=None,
+                    help="override KEYFRAME_THRESH (0: every frame stays a keyframe, so the sliding window fills to its "
+                         "bound whatever the random-init weights' motion test says: configs[2..4] as written)")
+    ap.add_argument("--live-steps", type=int, default=40,
+                    help="steps of the live-factor leg behind everything else (roofline_live): every reprojection is moved "
+                         "into the target plane before the correlation launch, so that every factor gathers (0 = skip)")
     ap.add_argument("--np-steps", type=int, default=40,
                     help="extra steps with frame pipelining OFF after the timed region, reported as "
                          "config.non_pipelined_kfps (what evaluate.run's strictly sequential loop gets); 0 = skip")
-    return ap.parse_args()
+    args = ap.parse_args()
+    given = {a.split("=")[0] for a in sys.argv[1:] if a.startswith("--")}
+    preset_of = {2: dict(mode="MultiScale", preset="precise", prime=160),
+                 3: dict(mode="MultiScale", preset="precise", prime=160),
+                 4: dict(mode="MultiScale", preset="precise", height=720, width=1280, patches=256, opt_window=32,
+                         encoder_fp8=1, keyframe_thresh=0.0, prime=90, clock_warm_max=60, inst_steps=40, np_steps=20)}
+    for k, v in preset_of.get(args.config, {}).items():
+        if "--" + k.replace("_", "-") not in given:
+            setattr(args, k, v)
+    return args
 
 
 def _event_pair():
@@ -219,6 +239,7 @@ class DeviceProbe:
         self.used, self.edges, self.enabled = 0, [], False
         self.mode, self.modes = "all", []              # "corr": only the correlation launch is bracketed (the timed region)
         self.corr_inst_ms = []
+        self.live_pairs, self.live_edges = [], []
 
     def install(self):
         from rampvo_amd import track_dev
@@ -227,7 +248,7 @@ class DeviceProbe:
         def step(dv, counter, flags, **k):
             on = probe.enabled and probe.mode and probe.used < len(probe.sets) and (flags & track_dev.UPDATE)
             for i in range(5):
-                dv.t.probe[i] = probe.sets[probe.used][i].cuda_event if on and (probe.mode != "corr" or i < 2) else None
+                dv.t.probe[i] = probe.sets[probe.used][i].cuda_event if on and (probe.mode not in ("corr", "live") or i < 2) else None
             if on:
                 probe.edges.append(int(dv.lazy_state()[track_dev.DYN_E]))      # a frame or two old: fine for a mean
                 probe.modes.append(probe.mode)
@@ -240,6 +261,8 @@ class DeviceProbe:
         for evs, E, mode in zip(self.sets[:self.used], self.edges, self.modes):
             if mode == "corr":                 # the timed region's samples: what roofline.achieved is computed from
                 ctimer.pairs.append((evs[0], evs[1])); ctimer.edges.append(E)
+            elif mode == "live":               # the live-factor leg (every reprojection inside the plane)
+                self.live_pairs.append((evs[0], evs[1])); self.live_edges.append(E)
             elif mode == "alone":              # the sequential pass: nothing else on the GPU
                 utimer.alone_ms.append(evs[1].elapsed_time(evs[2]))
                 btimer.alone_ms.append(evs[3].elapsed_time(evs[4]))
@@ -533,6 +556,23 @@ def parity_block(state, args, cfg_kwargs, net, dev):
     return out
 
 
+def _which_config(args, world):
+    """names the BASELINE.json config the flags amount to (every rank of an N > 1 run tracks the same workload on its
+    own sequence; configs[3] = --config 3)"""
+    ms, big = args.mode == "MultiScale", (args.height, args.width, args.patches) == (720, 1280, 256)
+    if not ms and args.preset == "default" and (args.height, args.width, args.patches) == (480, 640, 96) and not args.opt_window:
+        name = "BASELINE configs[1]"
+        if world > 1:
+            name += " on every rank (configs[3], MultiScale / precise windows per rank: --config 3)"
+    elif ms and args.preset == "precise" and (args.height, args.width, args.patches) == (480, 640, 96) and not args.opt_window:
+        name = "BASELINE configs[3] (configs[2]'s workload, one sequence per rank)" if world > 1 else "BASELINE configs[2]"
+    elif ms and big and args.opt_window == 32 and args.preset == "precise":
+        name = "BASELINE configs[4]" + (" as written" if (args.encoder_fp8 and args.keyframe_thresh == 0.0) else " (variant)")
+    else:
+        return ""
+    return name + ": "
+
+
 def graph_size(slam):
     """(factors, keyframes) of the tracker without taking a device-resident state back to the host"""
     dv = getattr(slam, "_dev", None)
@@ -602,6 +642,8 @@ def main():
     from rampvo_amd.synthetic import SyntheticStream, make_network
 
     cfg_kwargs = dict(PATCHES_PER_FRAME=args.patches, MIXED_PRECISION=bool(args.mixed))
+    if args.keyframe_thresh is not None:
+        cfg_kwargs["KEYFRAME_THRESH"] = float(args.keyframe_thresh)
     if args.opt_window:
         cfg_kwargs["OPTIMIZATION_WINDOW"] = args.opt_window
     if args.encoder_fp8:
@@ -616,7 +658,8 @@ def main():
     n_np = args.np_steps if args.pipeline else 0
     n_inst = 0 if args.no_kernel_timing else args.inst_steps
     n_alone = 20 if (n_inst and n_np) else 0
-    total = args.prime + n_warm + args.warmup + args.steps + n_inst + n_np + n_alone
+    n_live = args.live_steps if (n_inst and solo) else 0
+    total = args.prime + n_warm + args.warmup + args.steps + n_inst + n_np + n_alone + (n_live + 4 if n_live else 0)
     n_cpu = args.cpu_steps + 1 if (solo and args.cpu_steps > 0) else 0
     stream = SyntheticStream(args.height, args.width, total + n_cpu + 1, seed=1234 + rank, device=dev)
     frames = [tuple(x.to(dev) if i < 2 else x for i, x in enumerate(stream.frame(t))) for t in range(total)]
@@ -628,7 +671,7 @@ def main():
         etimer.install(net)
         btimer.install()
         utimer.install()
-        dprobe = DeviceProbe(args.steps + n_inst + n_alone)
+        dprobe = DeviceProbe(args.steps + n_inst + n_alone + n_live)
         dprobe.install()
 
     pos = {"t": 0}
@@ -727,6 +770,25 @@ def main():
             dprobe.enabled = False
             etimer.alone, etimer.pairs, etimer.enabled = etimer.pairs, keep, False
 
+    # the state the parity block and the CPU baseline start from: taken BEFORE the live-factor leg changes what the
+    # tracker correlates (state_dict() hands a device-resident state back to the host; the next frame re-enters)
+    snapshot = slam.state_dict() if (rank == 0 and ((solo and args.cpu_steps > 0) or (solo and args.parity))) else None
+    live_leg = None
+    if n_live and dprobe is not None and device_step:
+        from rampvo_amd import track_dev
+        slam.inputs_ready = bool(args.pipeline)
+        for _ in range(4):                         # back into the device-resident state
+            step()
+        dvl = getattr(slam, "_dev", None)
+        if dvl is not None and dvl.active:
+            slam._extra_step_flags = track_dev.WRAP_COORDS
+            dprobe.enabled, dprobe.mode = True, "live"
+            for _ in range(n_live):
+                step()
+            torch.cuda.synchronize()
+            dprobe.enabled = False
+            live_leg = live_factor_fractions(slam)
+            slam._extra_step_flags = 0
     if dprobe is not None:
         dprobe.feed(ctimer, utimer, btimer, cfg.OPTIMIZATION_WINDOW)
     if rank == 0:
@@ -739,11 +801,12 @@ def main():
             "dtype": "f16 (features, MFMA inputs; f32 accumulate, hidden state, BA, geometry: default.yaml "
                      "MIXED_PRECISION)" if args.mixed else "f32",
             "data": "synthetic (seeded %dx%d event+frame stream, seeded random-init weights)" % (args.width, args.height),
-            "config": {"workload": "%s %dx%d, %d patches/frame, %s.yaml windows%s, 2 BA iters/keyframe, "
+            "config": {"workload": "%s%s %dx%d, %d patches/frame, %s.yaml windows%s, 2 BA iters/keyframe, "
                                    "steady-state sliding window%s"
-                                   % (args.mode, args.width, args.height, args.patches, args.preset,
+                                   % (_which_config(args, world), args.mode, args.width, args.height, args.patches, args.preset,
                                       " with OPTIMIZATION_WINDOW %d" % args.opt_window if args.opt_window else "",
-                                      "".join([", fp8-MFMA encoder" if args.encoder_fp8 else "",
+                                      "".join([", KEYFRAME_THRESH %g" % args.keyframe_thresh if args.keyframe_thresh is not None else "",
+                                               ", fp8-MFMA encoder" if args.encoder_fp8 else "",
                                                ", fp32 everywhere" if not args.mixed else "",
                                                ", frame pipelining off" if not args.pipeline else "",
                                                ", host-driven steps (RAMP_DEVICE_STEP=0)"
@@ -777,6 +840,19 @@ def main():
                                   % (max(1, args.probe_every), rl["launches"], n_inst,
                                      1e3 * float(np.mean(dprobe.corr_inst_ms)) if dprobe.corr_inst_ms else float("nan")))
             out["roofline"] = rl
+            if live_leg is not None and dprobe.live_pairs:
+                lt = CorrTimer()
+                lt.pairs, lt.edges = dprobe.live_pairs[2:], dprobe.live_edges[2:]     # (the first two: the pipeline refilling)
+                ll = lt.summary(2 if args.mixed else 4, slam)
+                out["roofline_live"] = {
+                    "what": "the same kernel inside the pipelined frame with EVERY factor's windows inside the target plane: each "
+                            "reprojection is moved into the plane by whole plane widths / heights right before the correlation "
+                            "launch (RAMP_TRACK_WRAP_COORDS, %d steps behind everything else; the factor list, target frames "
+                            "and patches are the tracker's own)" % n_live,
+                    "live_factor_fraction_fine_coarse": live_leg,
+                    **{k: ll[k] for k in ("bound", "achieved", "peak", "unit", "frac", "launches", "mean_launch_us",
+                                          "bytes_per_launch", "edges_per_launch", "target_frames", "patches", "model_bytes",
+                                          "model_gbps", "mfma_tflops", "mfma_frac")}}
         for key, val in (("roofline_update", utimer.summary(bool(args.mixed))),
                          ("roofline_encoder", etimer.summary(bool(args.mixed))),
                          ("roofline_ba", btimer.summary(args.patches, cfg.REMOVAL_WINDOW))):
@@ -787,7 +863,6 @@ def main():
                         val["measured_in"] = ("%d sequential steps behind the sequential pass (alone); next to the tail: the "
                                               "%d-step instrumented pass" % (len(etimer.alone), n_inst))
                 out[key] = val
-        snapshot = slam.state_dict() if (n_cpu or (solo and args.parity)) else None
         if solo and args.parity:
             # a failing checker fails the run (rc != 0): a headline without its parity block is not a result
             out["parity"] = parity_block(snapshot, args, cfg_kwargs, net, dev)

@@ -583,17 +583,21 @@ int ramp_upd_linear(const void *x, const void *w_packed, const float *bias, void
 #define RAMP_DYN_EKEPT 10   /* factors the edit kept (next graph = kept ++ new)                                   */
 #define RAMP_DYN_STATUS 11  /* sticky bits: 1 BA pose step dropped, 2 BA pair list overflow (ramp_ba_forward's
                                info), 4 factor capacity exceeded, 8 group-by key out of range, 16 delta log full,
-                               32 a step's E_bound was below the live factor count                                */
+                               32 a step's E_bound was below the live factor count, 64 frame buffers full (n_rows),
+                               128 a gate wait (ramp_stream_wait_flag) timed out: the front end ran unordered       */
 #define RAMP_DYN_NLOG 12    /* entries written to the delta log                                                   */
 #define RAMP_DYN_FRAME 13   /* `counter` of the last frame stepped (tags the host's lazy copy)                    */
 #define RAMP_DYN_MEDOK 14   /* 1: ramp_track.median holds the depth median of the three newest frames (set beside the
                              * motion test, cleared by an update-only step; 0 when the host hands the state over)     */
+#define RAMP_DYN_FRAME2 31  /* = RAMP_DYN_FRAME, in the other half of the block: the two differ in a torn host copy         */
 #define RAMP_TRACK_LOG 12   /* floats per delta-log entry: t1, t0 (as int32 bit patterns), dP[7], pad             */
 
 #define RAMP_TRACK_COMMIT 1    /* store the front end's outputs as frame NROW first                               */
 #define RAMP_TRACK_UPDATE 2    /* Ramp_vo.update()                                                                */
 #define RAMP_TRACK_KEYFRAME 4  /* Ramp_vo.keyframe() + the next frame's append_factors + its plan                 */
 #define RAMP_TRACK_MM_GIVEN 8  /* (tests) keyframe(): take the two flow magnitudes from t->mm instead of computing */
+#define RAMP_TRACK_WRAP_COORDS 16 /* (measurement) move every reprojection into the target plane by whole plane sizes
+                                     before the correlation launch: bench.py's roofline leg with every factor live    */
 
 typedef struct ramp_track_weights {      /* update operator, fp16 fused formats of ramp_upd_* */
   const void *corr_w1, *corr_w2, *corr_w3;
@@ -654,6 +658,8 @@ typedef struct ramp_track {
   float *dlog;                        /* [log_cap][RAMP_TRACK_LOG] */
   int32_t *edit_ws;                   /* [2 * ceil(E_cap / 1024) + 8] */
   int32_t *dyn_host;                  /* optional pinned host copy of dyn, refreshed asynchronously after each step */
+  int32_t *dyn_host_dev;              /* optional: device address of dyn_host (ramp_host_device_pointer, resolved once):
+                                       * the plan's last launch then writes the copy itself                          */
   /* optional hipEvent_t handles recorded on `stream` by ramp_track_step (measurement only: bench.py's roofline legs):
    * [0] before / [1] after the correlation kernel, [2] after the update operator's last chain (gru), [3] before /
    * [4] after bundle adjustment                                                                                  */
@@ -677,13 +683,17 @@ int ramp_stream_delay(int microseconds, void *stream);
 
 /* Cross-stream "go" through a 32-bit word instead of an event: the producer is a KERNEL that stores a sequence number
  * (no packet between its stream's launches); the consumer stream waits with ONE sleeping wave that looks at the word
- * every ~3 us and ends when it is >= value, or after timeout_us (a producer that never comes must not hang the stream);
+ * every ~3 us and ends when it is >= value, or after timeout_us (a producer that never comes must not hang the stream;
+ * a time-out is an ERROR for whoever relied on the order: it is recorded in *status);
  * it then sleeps then_delay_us more.  (A hipStreamWaitValue32 in its place slows the other streams' launches down for
  * as long as it is pending, and so does a wave that polls without pauses: DESIGN.md section 8.0.)  The word lives in
  * signal memory (hipExtMallocWithFlags(hipMallocSignalMemory)), zero-initialised.                                    */
 int ramp_signal_alloc(uint32_t **flag);
 int ramp_signal_free(uint32_t *flag);
-int ramp_stream_wait_flag(void *stream, const uint32_t *flag, uint32_t value, int timeout_us, int then_delay_us);
+int ramp_stream_wait_flag(void *stream, const uint32_t *flag, uint32_t value, int timeout_us, int then_delay_us,
+                          int32_t *status /* optional: bit 128 is ORed in when the wait times out */);
+/* device address of a pinned (mapped) host allocation */
+int ramp_host_device_pointer(void *host, void **dev);
 
 size_t ramp_track_sizeof(void);      /* sizeof(ramp_track): lets a binding check its mirror of the struct */
 size_t ramp_track_plan_workspace_bytes(int E_cap, int kkey_cap, int pkey_cap);

@@ -122,13 +122,14 @@ _NAMES = ("patchify", "corr", "se3_unary", "se3_binary", "transform", "reproject
 
 
 @contextlib.contextmanager
-def cpu_oracle_ops():
+def cpu_oracle_ops(fp16_policy=False):
     """temporarily serve rampvo_amd.ops from the CPU oracle and the network modules' forwards from their plain-PyTorch
-    restatements (oracle/host_cpu.py) -- tests / cpu_baseline only"""
+    restatements (oracle/host_cpu.py) -- tests / cpu_baseline only.  fp16_policy: the update operator with the shipped
+    MIXED_PRECISION path's rounding points (fp16 Linear operands / outputs, fp32 accumulation and row arithmetic)"""
     import rampvo_amd.ops as ops
     from oracle import host_cpu
     saved = {n: getattr(ops, n) for n in _NAMES}
-    patches = host_cpu.module_patches()
+    patches = host_cpu.module_patches(fp16_policy)
     saved_mod = [(c, a, c.__dict__[a]) for c, a, _ in patches]
     try:
         for n in _NAMES:

@@ -179,8 +179,60 @@ def update_forward(self, net, inp, corr, flow, ii, jj, kk, plan=None):       # r
     return net, (self.d(net), self.w(net), None)
 
 
-def module_patches():
+# ------------------------------------------------------------------ update operator, fp16 policy
+# The SAME expressions with the roundings the shipped MIXED_PRECISION path applies (csrc/update_mlp.hip,
+# csrc/update.hip; the reference's autocast makes the same tensors half, ramp/net.py:69-90 under
+# torch.amp.autocast): Linear operands (input, weight, bias) and outputs are fp16 values, products accumulate in
+# fp32; LayerNorm, the residual stream, the segment softmax and every sum stay fp32; sigmoid(gate) is a half tensor.
+# With this leg a full-size step separates KERNEL error (HIP fp16 vs this) from PRECISION-POLICY error (this vs the
+# fp32 oracle): tests/test_pipeline_gpu.py::_one_update_vs_cpu_oracle(policy=True).
+def _h(x):
+    return x.half().float()
+
+
+def _lin16(lin, x):
+    return _h(F.linear(_h(x), _h(lin.weight), _h(lin.bias)))
+
+
+def _gated16(gr, x):
+    gate = _h(torch.sigmoid(_lin16(gr.gate[0], x)))
+    r = _lin16(gr.res[2], torch.relu(_lin16(gr.res[0], x)))
+    return x + gate * r
+
+
+def _softagg16(agg, x, groups, max_groups):
+    f, g = _lin16(agg.f, x[0]), _lin16(agg.g, x[0])
+    y = _h(ops.segment_softmax_sum(f, g, groups, max_groups))
+    hy = _lin16(agg.h, y)
+    return hy[groups.gid[:x.shape[1]].long()].unsqueeze(0)
+
+
+def update_forward_fp16_policy(self, net, inp, corr, flow, ii, jj, kk, plan=None):
+    if plan is None:
+        plan = GraphPlan.build(ii, jj, kk)
+    mask_ix = (plan.ix_raw >= 0).reshape(1, -1, 1)
+    mask_jx = (plan.jx_raw >= 0).reshape(1, -1, 1)
+    ix, jx = plan.ix_raw.clamp(min=0), plan.jx_raw.clamp(min=0)
+    c = self.corr
+    t = torch.relu(_lin16(c[0], _h(corr)))                          # the volume is stored as fp16 (csrc/altcorr.hip)
+    t = torch.relu(c[3](_lin16(c[2], t)))
+    net = self.norm(net.float() + _h(inp) + _lin16(c[5], t))
+    net = net + _lin16(self.c1[2], torch.relu(_lin16(self.c1[0], mask_ix.to(net.dtype) * net[:, ix])))
+    net = net + _lin16(self.c2[2], torch.relu(_lin16(self.c2[0], mask_jx.to(net.dtype) * net[:, jx])))
+    net = net + _softagg16(self.agg_kk, net, plan.g_kk, plan.max_kk)
+    net = net + _softagg16(self.agg_ij, net, plan.g_ij, plan.max_ij)
+    net = self.gru[0](net)
+    net = _gated16(self.gru[1], net)
+    net = self.gru[2](net)
+    net = _gated16(self.gru[3], net)
+    r = torch.relu(net)
+    return net, (_lin16(self.d[1], r), _h(torch.sigmoid(_lin16(self.w[1], r))), None)
+
+
+def module_patches(fp16_policy=False):
     """(class, attribute, function) triples bound by cpu_oracle_ops()"""
+    if fp16_policy:
+        return [t if t[2] is not update_forward else (t[0], t[1], update_forward_fp16_policy) for t in module_patches()]
     from rampvo_amd import extractor as ex
     from rampvo_amd import net as netmod
     return [(ex.ResidualBlock, "forward", residual_block_forward),

@@ -133,6 +133,7 @@ class Ramp_vo:
         self._cur_stream = None
         self._corr_levels = None
         self._fc_plan = None           # (front-end outputs, patches, FrameCommitPlan or None)
+        self._extra_step_flags = 0     # (measurement: track_dev.WRAP_COORDS, bench.py's live-factor leg)
         self._ba_flags = 0             # bits of fastba's info seen so far (1: a pose step was dropped, 2: pair list overflow)
         self._init_streams(dev)
         self._net_buf = torch.zeros(1, 0, DIM, dtype=torch.float, device=dev)   # hidden state is fp32 (as under autocast)
@@ -283,10 +284,13 @@ class Ramp_vo:
             self._delta[t1] = (t0, SE3(dP))
         self._tstamps = [int(v) for v in self.tstamps_[:self._n].tolist()]
         self._last_K_row = self._n - 1           # every committed frame copied (or wrote) its intrinsics row
+        if self._dev._frames:                    # the last update()'s confidence weights (reference :296; the host-driven
+            self.last_weight = st["weight"][None]    # update() sets it; the pose-prediction mode reads it)
         self._note_ba_flags(st["status"] & 3)
         if st["status"] & ~3:
-            raise RuntimeError("device-resident tracker: capacity exceeded (status bits %d: 4 = factor list, "
-                               "8 = group-by key range, 16 = delta log, 32 = launch bound below the factor count)"
+            raise RuntimeError("device-resident tracker: status bits %d (4 = factor list full, 8 = group-by key / group "
+                               "capacity, 16 = delta log full, 32 = launch bound below the factor count, 64 = frame "
+                               "buffers full (BUFFER_SIZE), 128 = a gate wait timed out: a front end ran unordered)"
                                % st["status"])
 
     def peek(self):
@@ -690,7 +694,8 @@ class Ramp_vo:
     def _gate_wait(self, fe):
         """(front-end stream) wait for the previous frame's gate: the signal word if that step stored one, else the event"""
         if self._gate_by_flag:
-            self._gate_sig.wait(fe, self._gate_seq, then_delay_us=_GATE_FLAG_DELAY_US)
+            self._gate_sig.wait(fe, self._gate_seq, then_delay_us=_GATE_FLAG_DELAY_US,
+                                status=self._dev.status_ptr if self._dev is not None else None)
         else:
             fe.wait_event(self._ev_gate)
 
@@ -707,6 +712,7 @@ class Ramp_vo:
         dv = self._dev
         mask = input_[2]
         accepts = mask is None or bool(mask)
+        dv.throttle(self.counter)                   # at most MAX_AHEAD frames ahead of the newest lazy copy (the margins below)
         lazy = dv.lazy_state()                      # whatever copy of the device-side sizes has arrived: never waited for
         if (accepts and (lazy[track_dev.DYN_N] + 8 >= self.N or lazy[track_dev.DYN_NLOG] + 8 >= dv.log_cap
                          or lazy[track_dev.DYN_STATUS] & ~3)):
@@ -758,7 +764,7 @@ class Ramp_vo:
         sig = self._gate_signal() if self.inputs_ready else None
         if sig is not None:
             self._gate_seq += 1
-        dv.step(self.counter, track_dev.COMMIT | track_dev.UPDATE | track_dev.KEYFRAME,
+        dv.step(self.counter, track_dev.COMMIT | track_dev.UPDATE | track_dev.KEYFRAME | self._extra_step_flags,
                 k_new=dv.k_new if k_dev is not None else None,
                 gate_event=self._ev_gate.cuda_event if (self.inputs_ready and sig is None) else None,
                 gate_flag=sig.ptr if sig is not None else None, gate_seq=self._gate_seq)

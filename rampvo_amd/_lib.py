@@ -121,7 +121,8 @@ SIGNATURES = {
     "ramp_stream_delay": (c_i, [c_i, c_p]),
     "ramp_signal_alloc": (c_i, [c_p]),
     "ramp_signal_free": (c_i, [c_p]),
-    "ramp_stream_wait_flag": (c_i, [c_p, c_p, ctypes.c_uint32, c_i, c_i]),
+    "ramp_stream_wait_flag": (c_i, [c_p, c_p, ctypes.c_uint32, c_i, c_i, c_p]),
+    "ramp_host_device_pointer": (c_i, [c_p, c_p]),
 }
 
 _lib = None

@@ -430,6 +430,9 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 // The fp32 variant is opt-in (dtype | RAMP_CORR_MFMA32): 2.1x faster than corr_kernel<float> (445 vs 940 us at E = 40k)
 // but its accumulation order is the MFMA's, not the reference kernel's channel-ordered fmaf chain that
 // corr_kernel<float> reproduces bit for bit -- so the exact-parity path stays the default.
+#ifndef CORR_NT
+#define CORR_NT 0     // (measured with csrc/update_mlp.hip's UPD_NT: the hint makes the step slower)
+#endif
 template <typename T> struct CorrMma;
 template <> struct CorrMma<_Float16> {
   typedef f16x8_t frag;
@@ -441,7 +444,12 @@ template <> struct CorrMma<_Float16> {
   static __device__ __forceinline__ void st(_Float16 *p, float v) { *p = (_Float16)v; }
   static __device__ __forceinline__ void st2(_Float16 *p, float a, float b) {
     typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+    // the [E, 896] volume is written once and read once (by the correlation MLP): streamed (CORR_NT=0: plain stores)
+#if CORR_NT
+    __builtin_nontemporal_store((h2v){(_Float16)a, (_Float16)b}, reinterpret_cast<h2v *>(p));
+#else
     *reinterpret_cast<h2v *>(p) = (h2v){(_Float16)a, (_Float16)b};
+#endif
   }
 };
 template <> struct CorrMma<float> {

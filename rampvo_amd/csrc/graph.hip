@@ -346,6 +346,8 @@ struct PlanDyn {
   int32_t *order[2], *gid[2], *seg[2], *ngroups[2];
   int64_t *ukeys[2];
   int Kcap[2];
+  int Gcap[2];           // capacity of seg / ukeys (groups): more groups than that are flagged (status bit 8), never written
+  int32_t *status;
 };
 __device__ __forceinline__ long plan_key(const PlanDyn &p, int g, int e, int &K, long &sub) {
   if (g == 0) {
@@ -433,16 +435,21 @@ __global__ void __launch_bounds__(1024) plan_scan_kernel(const PlanDyn p) {
     const int h = hist[k];
     hist[k] = oc;
     if (h > 0) {
-      gidmap[k] = og;
-      seg_start[og] = oc;
-      if (ukeys) ukeys[og] = (int64_t)k + sub;
+      if (og < p.Gcap[g]) {
+        gidmap[k] = og;
+        seg_start[og] = oc;
+        if (ukeys) ukeys[og] = (int64_t)k + sub;
+      } else {
+        gidmap[k] = -1;
+        atomicOr(p.status, 8);
+      }
       og++;
     } else {
       gidmap[k] = -1;
     }
     oc += h;
   }
-  if (tid == 1023) { *p.ngroups[g] = s_grp[1023]; seg_start[s_grp[1023]] = E; }
+  if (tid == 1023) { const int ng = min(s_grp[1023], p.Gcap[g]); *p.ngroups[g] = ng; seg_start[ng] = E; }
 }
 template <bool LDS>
 __global__ void __launch_bounds__(256) plan_scatter_kernel(const PlanDyn p) {
@@ -508,7 +515,9 @@ __global__ void __launch_bounds__(256) plan_segsort_kernel(const PlanDyn p, int6
     if (z < hist_words) p.hist[0][z] = 0;               // hist[0] and hist[1] are one allocation
   }
   // the host's lazy copy of the sizes (mapped pinned memory): nothing changes them after this launch has started
-  if (mirror && g == 1 && grp == 0 && threadIdx.x < RAMP_DYN_WORDS) mirror[threadIdx.x] = p.dyn[threadIdx.x];
+  // (word RAMP_DYN_FRAME2 repeats RAMP_DYN_FRAME in the other 64-byte half: the host re-reads a copy whose tags differ)
+  if (mirror && g == 1 && grp == 0 && threadIdx.x < RAMP_DYN_WORDS)
+    mirror[threadIdx.x] = p.dyn[threadIdx.x == RAMP_DYN_FRAME2 ? RAMP_DYN_FRAME : threadIdx.x];
   if (grp >= *p.ngroups[g]) return;
   const int32_t *tmp_order = p.tmp[g], *seg_start = p.seg[g];
   int32_t *order = p.order[g];
@@ -528,7 +537,11 @@ __global__ void __launch_bounds__(256) plan_segsort_kernel(const PlanDyn p, int6
     }
     order[s0 + r] = v;
   }
-  if (g != 0 || !ix || n > 1024) return;                // (longer patch groups: ramp_neighbors' sort-based path)
+  if (g != 0 || !ix) return;
+  if (n > 1024) {                                        // a patch with more than 1024 factors: no neighbours from here --
+    if (threadIdx.x == 0) atomicOr(p.status, 8);         // flagged (the host-driven path has ramp_neighbors' sort for such graphs)
+    return;
+  }
   for (int q = threadIdx.x; q < n; q += 256) {
     const int e = s_v[q];
     const long j = p.jj[e];
@@ -572,6 +585,7 @@ int ramp_i_plan_dyn(const int64_t *g4, int E_cap, int E_grid, const int32_t *dyn
   p.order[0] = kk_order; p.gid[0] = kk_gid; p.seg[0] = kk_seg; p.ngroups[0] = kk_ngroups; p.ukeys[0] = kk_ukeys;
   p.order[1] = ij_order; p.gid[1] = ij_gid; p.seg[1] = ij_seg; p.ngroups[1] = ij_ngroups; p.ukeys[1] = ij_ukeys;
   p.Kcap[0] = kkey_cap; p.Kcap[1] = pkey_cap;
+  p.Gcap[0] = kk_cap; p.Gcap[1] = ij_cap; p.status = status;
   // (the histograms are zero on entry: the caller's workspace starts zeroed and every plan clears them at its end)
   const int nb = ramp_cdiv(E_grid > 0 && E_grid < E_cap ? E_grid : E_cap, PLAN_EPB);
   const bool lds = kkey_cap <= PLAN_LDS_K && pkey_cap <= PLAN_LDS_K;

@@ -30,7 +30,7 @@ int ramp_i_frame_commit_dyn(float *poses, int motion, float damping, int64_t *ts
                             int64_t *index_map, float *intrinsics, const float *k_new, float *patches_state,
                             int median_frames, int M, int P, float *patches_new, int n_copy, const void *const *src,
                             void *const *base, const long *bytes, const int *mod, const int32_t *dyn,
-                            const float *median_ahead, int32_t *status, int E_bound, hipStream_t st);
+                            const float *median_ahead, int32_t *status, int E_bound, int n_rows, hipStream_t st);
 size_t ramp_i_plan_dyn_ws(int E_cap, int kkey_cap, int pkey_cap);
 int ramp_i_plan_dyn(const int64_t *g4, int E_cap, int E_grid, const int32_t *dyn, int32_t *status, int M, int kkey_cap,
                     int pkey_cap, int kk_cap, int ij_cap, int32_t *kk_order, int32_t *kk_gid, int32_t *kk_seg,

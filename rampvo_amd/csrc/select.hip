@@ -244,6 +244,7 @@ struct FrameCommit {
   // (optional) replaces the copy of the previous intrinsics row
   const int32_t *dyn; int mod[FC_MAXBUF]; const float *k_new;
   int32_t *status; int E_bound;      // optional: status bit 32 if dyn[RAMP_DYN_E] exceeds the step's launch bound
+  int32_t *status_rows; int n_rows;  // with dyn: the frame buffers hold n_rows rows -- a row past them is flagged (bit 64), nothing is stored
 };
 __global__ void __launch_bounds__(MED_THREADS) frame_commit_kernel(const FrameCommit a) {
   const int t = threadIdx.x;
@@ -253,6 +254,10 @@ __global__ void __launch_bounds__(MED_THREADS) frame_commit_kernel(const FrameCo
   float *patches_row = a.patches_row;
   if (a.dyn) {
     n = a.dyn[RAMP_DYN_NROW];
+    if (a.n_rows > 0 && (n < 0 || n > a.n_rows - 2)) {      // (index_map is written at n + 1)
+      if (a.status_rows && blockIdx.x == 0 && blockIdx.y == 0 && t == 0) atomicOr(a.status_rows, 64);
+      return;
+    }
     const size_t row = (size_t)a.M * 3 * a.PP;
     index_val = (int64_t)(n + 1) * a.M;
     median_src += (size_t)(n - a.F) * row;
@@ -310,7 +315,7 @@ int ramp_i_frame_commit_dyn(float *poses, int motion, float damping, int64_t *ts
                             int64_t *index_map, float *intrinsics, const float *k_new, float *patches_state,
                             int median_frames, int M, int P, float *patches_new, int n_copy, const void *const *src,
                             void *const *base, const long *bytes, const int *mod, const int32_t *dyn,
-                            const float *median_ahead, int32_t *status, int E_bound, hipStream_t st) {
+                            const float *median_ahead, int32_t *status, int E_bound, int n_rows, hipStream_t st) {
   if (!poses || !patches_state || !patches_new || !dyn || M <= 0 || P <= 0 || n_copy < 0 || n_copy > FC_MAXBUF)
     return RAMP_EINVAL;
   if ((long)median_frames * M * P * P > MED_THREADS * MED_PER) return RAMP_EUNSUPPORTED;
@@ -322,6 +327,7 @@ int ramp_i_frame_commit_dyn(float *poses, int motion, float damping, int64_t *ts
   a.median_val = median_ahead;      // valid while dyn[RAMP_DYN_MEDOK] (csrc/lie.hip: computed beside the previous motion test)
   a.dyn = dyn; a.k_new = k_new;
   a.status = E_bound > 0 ? status : nullptr; a.E_bound = E_bound;
+  a.status_rows = status; a.n_rows = n_rows;
   a.n_copy = n_copy;
   long mx = 0;
   for (int i = 0; i < FC_MAXBUF; i++) a.mod[i] = 0;
@@ -400,7 +406,7 @@ int ramp_frame_commit(float *poses, int n, int motion, float damping, int64_t *t
   a.median_src = patches_state + (size_t)(n - median_frames) * row; a.F = median_frames; a.M = M; a.PP = P * P;
   a.patches_new = patches_new; a.patches_row = patches_state + (size_t)n * row;
   a.median_val = median_dev;
-  a.dyn = nullptr; a.k_new = nullptr; a.status = nullptr; a.E_bound = 0;
+  a.dyn = nullptr; a.k_new = nullptr; a.status = nullptr; a.E_bound = 0; a.status_rows = nullptr; a.n_rows = 0;
   for (int i = 0; i < FC_MAXBUF; i++) a.mod[i] = 0;
   a.n_copy = n_copy;
   long mx = 0;

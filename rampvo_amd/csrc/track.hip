@@ -23,7 +23,7 @@ struct TrkEdit {
   const float *mm;
   const int64_t *gin;      // [4][E_cap]
   int64_t *gout;
-  int E_cap, M, r, removal_window, keyframe_index, log_cap;
+  int E_cap, M, r, removal_window, keyframe_index, log_cap, n_rows;
   double thresh;
   int32_t *cnt, *off, *fmin;   // per edit workgroup: kept factors, their exclusive prefix, lowest frame index kept
   const int64_t *tstamps;
@@ -143,7 +143,12 @@ __global__ void __launch_bounds__(256) trk_decide_kernel(const TrkEdit p) {
     }
   }
   // the next frame's factors (Ramp_vo.py:312-325 with n = n_after + 1)
-  const int n1 = d.n_after + 1;
+  // the frame buffers hold n_rows frames (row n1 - 1 = n_after is the next frame's; index_map is written at n_after + 1):
+  // a full buffer is flagged and the counts stay in bounds -- the reference raises IndexError there; the host reads
+  // the flag within a few frames (track_dev.py bounds its run-ahead) and raises
+  int n_after = d.n_after;
+  if (n_after > p.n_rows - 2) { status |= 64; n_after = p.n_rows - 2; }
+  const int n1 = n_after + 1;
   const int lo = max(n1 - p.r, 0);
   const int nf = p.M * (max(n1 - 1, 0) - lo), nbk = p.M * (n1 - lo);
   int ne = nf + nbk;
@@ -154,14 +159,15 @@ __global__ void __launch_bounds__(256) trk_decide_kernel(const TrkEdit p) {
   p.dyn[RAMP_DYN_EKEPT] = Ek;
   p.dyn[RAMP_DYN_REMOVED] = d.remove ? 1 : 0;
   p.dyn[RAMP_DYN_K] = (int)d.k;
-  p.dyn[RAMP_DYN_NROW] = d.n_after;
+  p.dyn[RAMP_DYN_NROW] = n_after;
   p.dyn[RAMP_DYN_N] = n1;
   p.dyn[RAMP_DYN_E] = Ek + ne;
   p.dyn[RAMP_DYN_KLO] = (int)min(d.kcut, (long)p.M * lo);
   p.dyn[RAMP_DYN_FLO] = flo;
   p.dyn[RAMP_DYN_W] = n1 - flo;
   p.dyn[RAMP_DYN_FRAME] = (int)p.counter;
-  if (status) p.dyn[RAMP_DYN_STATUS] |= status;
+  p.dyn[RAMP_DYN_FRAME2] = (int)p.counter;       // second tag, in the other half of the block: a torn host copy shows
+  if (status) atomicOr(p.dyn + RAMP_DYN_STATUS, status);   // (the front-end stream's gate wait may OR its time-out bit in)
 }
 
 // grid (nb + new-factor workgroups, 1 + nbuf).  y = 0: x < nb compacts the kept factors of edit workgroup x (stable),
@@ -236,10 +242,28 @@ __global__ void __launch_bounds__(256) trk_iota_kernel(int64_t *__restrict__ row
   if (e < dyn[RAMP_DYN_E]) row[e] = e;
 }
 
+// (measurement only, RAMP_TRACK_WRAP_COORDS) every factor's reprojection moved into the target plane by whole plane
+// widths / heights (the patch keeps its shape): with random-init weights a third to a half of the projections leave
+// the image and cost the correlation kernel a row of zeros and no gathers; bench.py's "live" roofline leg times the
+// kernel with every factor gathering
+__global__ void __launch_bounds__(256) trk_wrap_coords_kernel(float *__restrict__ coords, const int32_t *__restrict__ dyn,
+                                                              int PP, float w, float h) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= dyn[RAMP_DYN_E]) return;
+  float *c = coords + (size_t)e * 2 * PP;
+  const float cx = c[PP / 2], cy = c[PP + PP / 2];
+  const bool ok = fabsf(cx) < 1e8f && fabsf(cy) < 1e8f;       // (false for NaN / inf as well)
+  const float sx = ok ? floorf(cx / w) * w : 0.f, sy = ok ? floorf(cy / h) * h : 0.f;
+  for (int p = 0; p < PP; p++) {
+    c[p] = ok ? c[p] - sx : 0.5f * w;
+    c[PP + p] = ok ? c[PP + p] - sy : 0.5f * h;
+  }
+}
+
 static int trk_edit_fill(const ramp_track *t, int cur, int64_t counter, TrkEdit &p) {
   p.dyn = t->dyn; p.mm = t->mm; p.gin = t->graph[cur]; p.gout = t->graph[1 - cur];
   p.E_cap = t->E_cap; p.M = t->M; p.r = t->patch_lifetime; p.removal_window = t->removal_window;
-  p.keyframe_index = t->keyframe_index; p.log_cap = t->log_cap; p.thresh = t->keyframe_thresh;
+  p.keyframe_index = t->keyframe_index; p.log_cap = t->log_cap; p.thresh = t->keyframe_thresh; p.n_rows = t->n_rows;
   p.nb = ramp_cdiv(t->E_cap, TRK_EB);
   p.cnt = t->edit_ws; p.off = t->edit_ws + p.nb; p.fmin = t->edit_ws + 2 * p.nb;
   p.tstamps = t->tstamps; p.poses = t->poses; p.dlog = t->dlog; p.counter = counter;
@@ -296,22 +320,26 @@ __global__ void trk_delay_kernel(long ticks) {
 // One sleeping wave that ends when *flag >= value (or after `ticks` of the 100 MHz clock), then sleeps `after` more.  It
 // looks at the word only every ~3 us: a wave that polls a system-scope word without pauses slows the other streams'
 // kernels down (tools/mb/stream_signal.hip: 64 MB copies 20.8 -> 22.3 us; the update operator 505 -> 608 us).
-__global__ void trk_wait_flag_kernel(const uint32_t *flag, uint32_t value, long ticks, long after, int nap) {
+__global__ void trk_wait_flag_kernel(const uint32_t *flag, uint32_t value, long ticks, long after, int nap, int32_t *status) {
   const long t0 = wall_clock64();
-  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < value && (long)wall_clock64() - t0 < ticks)
+  bool seen;
+  while (!(seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= value) && (long)wall_clock64() - t0 < ticks)
     for (int i = 0; i < nap; i++) __builtin_amdgcn_s_sleep(64);
+  // gave up: what follows on this stream is no longer ordered behind the producer -- sticky status bit 128, the tracker
+  // raises when it reads it (the wave still ends, so the stream cannot hang on a producer that never comes)
+  if (!seen && status && threadIdx.x == 0) atomicOr(status, 128);
   const long t1 = wall_clock64();
   while ((long)wall_clock64() - t1 < after) __builtin_amdgcn_s_sleep(64);
 }
 
 extern "C" {
 
-int ramp_stream_wait_flag(void *stream, const uint32_t *flag, uint32_t value, int timeout_us, int then_delay_us) {
+int ramp_stream_wait_flag(void *stream, const uint32_t *flag, uint32_t value, int timeout_us, int then_delay_us, int32_t *status) {
   if (!flag || timeout_us <= 0 || then_delay_us < 0) return RAMP_EINVAL;
   static int nap = 0;                                  // RAMP_FLAG_NAP: s_sleep(64) units (~1.7 us each) between two looks
   if (!nap) { const char *e = getenv("RAMP_FLAG_NAP"); nap = e ? atoi(e) : 2; if (nap < 1) nap = 1; }
   hipLaunchKernelGGL(trk_wait_flag_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, flag, value, (long)timeout_us * 100,
-                     (long)then_delay_us * 100, nap);
+                     (long)then_delay_us * 100, nap, status);
   RAMP_CHECK_LAUNCH();
   return RAMP_OK;
 }
@@ -346,6 +374,13 @@ int ramp_track_warm(const ramp_track *t, int32_t *sink, void *stream) {
 }
 
 size_t ramp_track_sizeof(void) { return sizeof(ramp_track); }
+int ramp_host_device_pointer(void *host, void **dev) {
+  if (!host || !dev) return RAMP_EINVAL;
+  void *dp = nullptr;
+  if (hipHostGetDevicePointer(&dp, host, 0) != hipSuccess) { (void)hipGetLastError(); *dev = nullptr; return RAMP_EUNSUPPORTED; }
+  *dev = dp;
+  return RAMP_OK;
+}
 size_t ramp_track_plan_workspace_bytes(int E_cap, int kkey_cap, int pkey_cap) {
   return ramp_i_plan_dyn_ws(E_cap, kkey_cap, pkey_cap);
 }
@@ -395,11 +430,7 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
   bool pc_with_mm = false;
   // the host's lazy copy of the sizes: written by the plan's last launch straight into the (mapped, pinned) host buffer
   int32_t *mirror = nullptr;
-  if (t->dyn_host) {
-    void *dp = nullptr;
-    if (hipHostGetDevicePointer(&dp, t->dyn_host, 0) == hipSuccess) mirror = (int32_t *)dp;
-    else (void)hipGetLastError();
-  }
+  if (t->dyn_host) mirror = t->dyn_host_dev;      // resolved once by the caller (ramp_host_device_pointer)
   if (flags & RAMP_TRACK_COMMIT) {
     if (!t->fe_colors || !t->fe_imap || !t->fe_gmap || !t->fe_fmap1 || !t->fe_fmap2 || !t->fe_patches) return RAMP_EINVAL;
     const void *src[5] = {t->fe_colors, t->fe_imap, t->fe_gmap, t->fe_fmap1, t->fe_fmap2};
@@ -409,7 +440,7 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
     const int mod[5] = {0, t->mem, t->mem, t->mem, t->mem};
     TRK_DO(ramp_i_frame_commit_dyn(t->poses, t->motion_model, t->motion_damping, t->tstamps, counter, t->index_map,
                                    t->intrinsics, k_new, t->patches, 3, t->M, t->P, t->fe_patches, 5, src, base, bytes,
-                                   mod, dyn, (t->median && t->keyframe_index >= 4) ? t->median : nullptr, t->dyn + RAMP_DYN_STATUS, (Eb < Ec && folded) ? Eb : 0, st));
+                                   mod, dyn, (t->median && t->keyframe_index >= 4) ? t->median : nullptr, t->dyn + RAMP_DYN_STATUS, (Eb < Ec && folded) ? Eb : 0, t->n_rows, st));
   }
   if (flags & RAMP_TRACK_UPDATE) {
     const ramp_track_weights &w = t->w;
@@ -418,6 +449,9 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
       return RAMP_EINVAL;
     // Ramp_vo.update(), ramp/Ramp_vo.py:276-310
     TRK_DO(ramp_i_transform_dyn(t->poses, t->patches, t->intrinsics, ii, jj, kk, t->coords, Eb, dyn, st));
+    if (flags & RAMP_TRACK_WRAP_COORDS)
+      hipLaunchKernelGGL(trk_wrap_coords_kernel, dim3(ramp_cdiv(Eb, 256)), dim3(256), 0, st, t->coords, dyn, PP,
+                         (float)t->feat_w, (float)t->feat_h);
     ramp_corr_level lv[2];
     lv[0].fmap = t->fmap1; lv[0].H2 = t->feat_h; lv[0].W2 = t->feat_w; lv[0].coord_div = 1.0f;
     lv[1].fmap = t->fmap2; lv[1].H2 = t->feat_h / 4; lv[1].W2 = t->feat_w / 4; lv[1].coord_div = 4.0f;

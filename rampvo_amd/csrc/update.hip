@@ -268,6 +268,14 @@ __global__ void __launch_bounds__(256)
 // exp: the hardware exponential (v_exp_f32, ~1 ulp) -- with libm's expf this kernel was VALU bound (6 x ~15
 // instructions per row and lane pair); it only runs on the fp16 path, whose inputs carry 11 bits.
 #define SEG_R 8
+#ifndef SEG_NT
+#define SEG_NT 0     // 1: the [f | g] rows (read once) with the nontemporal hint -- part of the A/B of csrc/update_mlp.hip's UPD_NT
+#endif
+#if SEG_NT
+#define SEG_LD(p) __builtin_nontemporal_load(p)
+#else
+#define SEG_LD(p) (*(p))
+#endif
 #define SEG_T 96                // threads per row lane: 4 channels (one 8-byte load) each
 typedef _Float16 seg_h4 __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(SEG_T * SEG_R)
@@ -288,8 +296,8 @@ __global__ void __launch_bounds__(SEG_T * SEG_R)
   for (int k = 0; k < 4; k++) { m[k] = -INFINITY; z[k] = 0.f; a[k] = 0.f; }
   for (int p = s0 + w; p < s1; p += SEG_R) {
     const size_t r0 = (size_t)order[p] * (2 * UD);
-    const seg_h4 fv = *reinterpret_cast<const seg_h4 *>(fg + r0 + c);
-    const seg_h4 gv = *reinterpret_cast<const seg_h4 *>(fg + r0 + UD + c);
+    const seg_h4 fv = SEG_LD(reinterpret_cast<const seg_h4 *>(fg + r0 + c));
+    const seg_h4 gv = SEG_LD(reinterpret_cast<const seg_h4 *>(fg + r0 + UD + c));
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const float gk = (float)gv[k], n = fmaxf(m[k], gk);
@@ -348,8 +356,8 @@ __global__ void __launch_bounds__(SEG_T8 * SEG_R)
 #pragma unroll
     for (int d = 0; d < SEG_D; d++) {
       const size_t r0 = (size_t)idx[d] * (2 * UD);
-      fv[d] = *reinterpret_cast<const seg_h8 *>(fg + r0 + c);
-      gv[d] = *reinterpret_cast<const seg_h8 *>(fg + r0 + UD + c);
+      fv[d] = SEG_LD(reinterpret_cast<const seg_h8 *>(fg + r0 + c));
+      gv[d] = SEG_LD(reinterpret_cast<const seg_h8 *>(fg + r0 + UD + c));
     }
 #pragma unroll
     for (int d = 0; d < SEG_D; d++) {

@@ -32,6 +32,46 @@
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// Nontemporal hints on the operator's state traffic (the [E,384] fp32 residual stream in and out of every chain, the
+// [E,896] correlation rows, the [E,768] [f|g] rows: ~1.3 GB per update) -- VERDICT r3 item 1a -- measured on MI355X
+// (tools/ab_build.sh, alternating builds on one box): with the hint on EVERY such access the step is 12 % SLOWER
+// (899 vs 1020 kf/s; sequential 730 vs 824): a chain's 61 MB output is the next chain's input and is served from the
+// memory-side cache -- the hint takes that away.  UPD_NT = 1 is that build; UPD_NT_DEAD = 1 hints only the loads of rows
+// nobody reads again (the correlation rows, the previous hidden state), see DESIGN.md section 8.
+#ifndef UPD_NT
+#define UPD_NT 0
+#endif
+#ifndef UPD_NT_DEAD
+#define UPD_NT_DEAD 0
+#endif
+template <typename T>
+__device__ __forceinline__ T ld_dead(const T *p) {
+#if UPD_NT || UPD_NT_DEAD
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+template <typename T>
+__device__ __forceinline__ T ld_st(const T *p) {
+#if UPD_NT
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+template <typename T>
+__device__ __forceinline__ void st_st(T *p, T v) {
+#if UPD_NT
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+__device__ __forceinline__ float2 ld_st2(const float *p) { const f2 v = ld_st(reinterpret_cast<const f2 *>(p)); return make_float2(v[0], v[1]); }
+__device__ __forceinline__ void st_st2(float *p, float2 v) { st_st(reinterpret_cast<f2 *>(p), (f2){v.x, v.y}); }
 
 __device__ __forceinline__ float h_round(float v) { return (float)(_Float16)v; }
 // the gate's input was rounded to fp16 one line earlier: the fast exp / reciprocal (~1 ulp) are exact
@@ -312,7 +352,7 @@ __global__ void __launch_bounds__(64 * MWAVES) upd_gru_kernel(const GruParams p)
     const int row = row0 + mt * 16 + j;
     roff[mt] = (size_t)(row < pE ? row : pE - 1) * MD;
 #pragma unroll
-    for (int nt = 0; nt < MNTW; nt++) res[mt][nt] = *reinterpret_cast<const f4 *>(p.x32 + roff[mt] + cq + nt * 16);
+    for (int nt = 0; nt < MNTW; nt++) res[mt][nt] = ld_st(reinterpret_cast<const f4 *>(p.x32 + roff[mt] + cq + nt * 16));
   }
   if (p.add0_t) {                               // uniform
 #pragma unroll
@@ -418,7 +458,7 @@ __global__ void __launch_bounds__(64 * MWAVES) upd_gru_kernel(const GruParams p)
 #pragma unroll
         for (int nt = 0; nt < MNTW; nt++) {
           const f4 v = res[mt][nt];
-          *reinterpret_cast<f4 *>(p.out32 + roff[mt] + cq + nt * 16) = v;
+          st_st(reinterpret_cast<f4 *>(p.out32 + roff[mt] + cq + nt * 16), v);
           if (p.relu_t)
             *reinterpret_cast<h4 *>(p.relu_t + roff[mt] + cq + nt * 16) =
                 (h4){(_Float16)fmaxf(v[0], 0.f), (_Float16)fmaxf(v[1], 0.f), (_Float16)fmaxf(v[2], 0.f), (_Float16)fmaxf(v[3], 0.f)};
@@ -650,7 +690,7 @@ __global__ void __launch_bounds__(64 * MWAVES) __attribute__((amdgpu_waves_per_e
       for (int i = tid; i < MBM * v8; i += 64 * MWAVES) {
         const int r = i / v8, c8 = i - r * v8;
         h8 v = (h8){0, 0, 0, 0, 0, 0, 0, 0};
-        if (row0 + r < pE) v = *reinterpret_cast<const h8 *>(p.corr + (size_t)(row0 + r) * p.corr_k + ks0 * 32 + 8 * c8);
+        if (row0 + r < pE) v = ld_dead(reinterpret_cast<const h8 *>(p.corr + (size_t)(row0 + r) * p.corr_k + ks0 * 32 + 8 * c8));
         *reinterpret_cast<h8 *>(Xs + r * MXS + 8 * c8) = v;
       }
       __syncthreads();
@@ -755,7 +795,8 @@ __global__ void __launch_bounds__(64 * MWAVES) __attribute__((amdgpu_waves_per_e
       if (ra >= 0) {
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-          const float2 a = *reinterpret_cast<const float2 *>(p.net + (size_t)ra * MD + 2 * lane + 128 * k);
+          const f2 a_ = ld_dead(reinterpret_cast<const f2 *>(p.net + (size_t)ra * MD + 2 * lane + 128 * k));
+          const float2 a = make_float2(a_[0], a_[1]);
           v[k][0] = a.x; v[k][1] = a.y;
         }
       }
@@ -775,7 +816,7 @@ __global__ void __launch_bounds__(64 * MWAVES) __attribute__((amdgpu_waves_per_e
       row_ln(v, p.norm_w, p.norm_b, p.norm_eps, lane);
 #pragma unroll
       for (int k = 0; k < 3; k++)
-        *reinterpret_cast<float2 *>(p.net_out + (size_t)row * MD + 2 * lane + 128 * k) = make_float2(v[k][0], v[k][1]);
+        st_st2(p.net_out + (size_t)row * MD + 2 * lane + 128 * k, make_float2(v[k][0], v[k][1]));
     }
     __syncthreads();
   }
@@ -951,10 +992,11 @@ __device__ __forceinline__ void big_store_tile(_Float16 *Xs, const f4 (&acc)[NMT
 }
 
 __device__ __forceinline__ float4 ldg4(const float *base, unsigned off, int nt) {
-  return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + off + nt * 64);
+  const f4 v = ld_st(reinterpret_cast<const f4 *>(reinterpret_cast<const char *>(base) + off + nt * 64));
+  return make_float4(v[0], v[1], v[2], v[3]);
 }
 __device__ __forceinline__ void stg4(float *base, unsigned off, int nt, float4 v) {
-  *reinterpret_cast<float4 *>(reinterpret_cast<char *>(base) + off + nt * 64) = v;
+  st_st(reinterpret_cast<f4 *>(reinterpret_cast<char *>(base) + off + nt * 64), (f4){v.x, v.y, v.z, v.w});
 }
 __device__ __forceinline__ void stg4h(_Float16 *base, unsigned off_f32, int nt, float4 v) {   // fp16 row of the same shape
   *reinterpret_cast<hh4 *>(reinterpret_cast<char *>(base) + (off_f32 >> 1) + nt * 32) =
@@ -1002,7 +1044,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) upd_nbr_big_kernel(const NbrP
     for (int i = 0; i < RPW; i++) {
       const float *b = p.net_in + (size_t)(src[i] >= 0 ? src[i] : 0) * MD + 2 * lane;
 #pragma unroll
-      for (int k = 0; k < 3; k++) v[i][k] = *reinterpret_cast<const float2 *>(b + 128 * k);
+      for (int k = 0; k < 3; k++) v[i][k] = ld_st2(b + 128 * k);
     }
 #pragma unroll
     for (int i = 0; i < RPW; i++)
@@ -1088,7 +1130,7 @@ __global__ void __launch_bounds__(512, 4) upd_nbr2_kernel(const Nbr2Params p) {
     for (int i = 0; i < RPW; i++) {
       const float *b = p.net_in + (size_t)(src[i] >= 0 ? src[i] : 0) * MD + 2 * lane;
 #pragma unroll
-      for (int k = 0; k < 3; k++) v[i][k] = *reinterpret_cast<const float2 *>(b + 128 * k);
+      for (int k = 0; k < 3; k++) v[i][k] = ld_st2(b + 128 * k);
     }
 #pragma unroll
     for (int i = 0; i < RPW; i++)
@@ -1226,7 +1268,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) upd_fg_big_kernel(const FgPar
       const int row = row0 + wave + i * NW;
       const float *b = p.x32 + (size_t)(row < pE ? row : pE - 1) * MD + 2 * lane;
 #pragma unroll
-      for (int k = 0; k < 3; k++) v[i][k] = *reinterpret_cast<const float2 *>(b + 128 * k);
+      for (int k = 0; k < 3; k++) v[i][k] = ld_st2(b + 128 * k);
     }
     if (p.add_t) {                                       // uniform
       h2 t[RPW][3];
@@ -1248,7 +1290,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) upd_fg_big_kernel(const FgPar
 #pragma unroll
       for (int k = 0; k < 3; k++) {
         if (live_row && p.x32_out)
-          *reinterpret_cast<float2 *>(p.x32_out + (size_t)row * MD + 2 * lane + 128 * k) = v[i][k];
+          st_st2(p.x32_out + (size_t)row * MD + 2 * lane + 128 * k, v[i][k]);
         const float2 a = live_row ? v[i][k] : make_float2(0.f, 0.f);
         *reinterpret_cast<h2 *>(Xs + r * MXS + 2 * lane + 128 * k) = (h2){(_Float16)a.x, (_Float16)a.y};
       }
@@ -1271,9 +1313,9 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) upd_fg_big_kernel(const FgPar
 #pragma unroll
       for (int mt = 0; mt < NMT; mt++)
         if ((live >> mt) & 1)
-          *reinterpret_cast<hh4 *>(reinterpret_cast<char *>(dst) + (ro[mt] - cfix) + nt * 32) =
-              (hh4){(_Float16)(acc[mt][nt][0] + b.x), (_Float16)(acc[mt][nt][1] + b.y),
-                    (_Float16)(acc[mt][nt][2] + b.z), (_Float16)(acc[mt][nt][3] + b.w)};
+          st_st(reinterpret_cast<hh4 *>(reinterpret_cast<char *>(dst) + (ro[mt] - cfix) + nt * 32),
+                (hh4){(_Float16)(acc[mt][nt][0] + b.x), (_Float16)(acc[mt][nt][1] + b.y),
+                      (_Float16)(acc[mt][nt][2] + b.z), (_Float16)(acc[mt][nt][3] + b.w)});
     }
   }
 }

@@ -19,8 +19,10 @@ from ._lib import c_i, c_p, c_sz
 DYN_WORDS = 32
 (DYN_N, DYN_NROW, DYN_E, DYN_KLO, DYN_FLO, DYN_W, DYN_REMOVED, DYN_K, DYN_NPREV, DYN_EPREV, DYN_EKEPT, DYN_STATUS,
  DYN_NLOG, DYN_FRAME) = range(14)
+DYN_FRAME2 = 31          # repeats DYN_FRAME in the other 64-byte half of the block (a torn lazy copy shows)
 LOG_WORDS = 12
-COMMIT, UPDATE, KEYFRAME, MM_GIVEN = 1, 2, 4, 8
+MAX_AHEAD = 6            # frames the host may enqueue ahead of the newest lazy copy of the sizes (Ramp_vo._track_device)
+COMMIT, UPDATE, KEYFRAME, MM_GIVEN, WRAP_COORDS = 1, 2, 4, 8, 16
 CORR_ROW = 896
 
 
@@ -52,7 +54,7 @@ class Track(ctypes.Structure):
                 + _ptr_fields(["coords", "corr"]) + [("net", c_p * 3)]
                 + _ptr_fields(["fg", "ykk", "hkk", "yij", "hij", "relu_t", "target", "weight", "ba_ws"])
                 + [("ba_ws_bytes", c_sz)]
-                + _ptr_fields(["mm", "median", "dlog", "edit_ws", "dyn_host"]) + [("probe", c_p * 5), ("E_hint", c_i),
+                + _ptr_fields(["mm", "median", "dlog", "edit_ws", "dyn_host", "dyn_host_dev"]) + [("probe", c_p * 5), ("E_hint", c_i),
                    ("gate_seq", ctypes.c_uint32), ("gate_flag", c_p)])
 
 
@@ -70,9 +72,12 @@ class Signal:
         rc = _lib.lib().ramp_signal_alloc(ctypes.byref(p))
         self.ptr = p if rc == 0 and p.value else None
 
-    def wait(self, stream, value, timeout_us=50000, then_delay_us=0):
+    def wait(self, stream, value, timeout_us=50000, then_delay_us=0, status=None):
+        """status: optional device int32 word; bit 128 is ORed in if the wait gives up (the consumer then ran without the
+        order it asked for -- the tracker raises when it reads the bit)"""
         _lib.check(_lib.lib().ramp_stream_wait_flag(ctypes.c_void_p(stream.cuda_stream), self.ptr, int(value) & 0xFFFFFFFF,
-                                                    int(timeout_us), int(then_delay_us)), "ramp_stream_wait_flag")
+                                                    int(timeout_us), int(then_delay_us),
+                                                    ctypes.c_void_p(status) if status else None), "ramp_stream_wait_flag")
 
     def __del__(self):
         try:
@@ -165,6 +170,10 @@ class DeviceTrack:
                               dyn_host=self.dyn_host).items():
             setattr(t, name, P(ten))
         t.plan_ws_bytes, t.ba_ws_bytes = self.plan_ws.numel(), self.ba_ws.numel()
+        dp = ctypes.c_void_p()                    # device address of the pinned copy: resolved once, not per frame
+        if lib.ramp_host_device_pointer(ctypes.c_void_p(self.dyn_host.data_ptr()), ctypes.byref(dp)) == 0 and dp.value:
+            t.dyn_host_dev = dp.value
+        self.status_ptr = self.dyn.data_ptr() + 4 * DYN_STATUS
         if os.environ.get("RAMP_MEDIAN_AHEAD", "1") != "0":       # (A/B: 0 = the median at the head of the next step)
             t.median = P(self.median)
         t.graph[0], t.graph[1] = P(self.graph[0]), P(self.graph[1])
@@ -242,7 +251,7 @@ class DeviceTrack:
         d[DYN_N], d[DYN_NROW], d[DYN_E] = n + 1, n, E
         d[DYN_KLO], d[DYN_FLO], d[DYN_W] = (k_lo // M) * M, f_lo, n + 1 - f_lo
         d[DYN_NPREV], d[DYN_EPREV], d[DYN_EKEPT] = n, net_buf.shape[0], Ek
-        d[DYN_FRAME] = slam.counter - 1
+        d[DYN_FRAME] = d[DYN_FRAME2] = slam.counter - 1
         if (n + 1) * M - d[DYN_KLO] > self.kkey_cap or d[DYN_W] ** 2 > self.pkey_cap:
             return False
         self.dyn.copy_(self.dyn_host, non_blocking=True)
@@ -255,7 +264,7 @@ class DeviceTrack:
         """upper bound of the live factor count from the lazy host copy of dyn: a frame adds at most (2r - 1) M
         factors, the copy is `lag` frames old (one more frame of slack in case it was read mid-update); the step
         flags a bound that turns out too small (status bit 32)"""
-        d = self.dyn_host.numpy()
+        d = self.lazy_state()
         lag = max(int(counter) - int(d[DYN_FRAME]), 1) + 1
         return min(int(d[DYN_E]) + lag * self.new_cap, self.E_cap)
 
@@ -264,7 +273,7 @@ class DeviceTrack:
         drifts by a few hundred per frame over 39k .. 46k at the bench size, so a maximum over 64 frames sits above the
         80-row gru tile's limit of 40960 most of the time although half of the frames are below it): picks tile sizes,
         bounds nothing.  Sequential rate 834 -> 853 kf/s, pipelined unchanged (RAMP_E_EST_LAST=0: the maximum)."""
-        e = int(self.dyn_host.numpy()[DYN_E])
+        e = int(self.lazy_state()[DYN_E])
         if not self._e_seen or self._e_seen[-1] != e:
             self._e_seen.append(e)
         k = _E_EST_LAST
@@ -291,8 +300,29 @@ class DeviceTrack:
         _lib.check(_lib.lib().ramp_track_warm(ctypes.byref(self.t), _lib.ptr(self.sink), _lib.stream()), "ramp_track_warm")
 
     def lazy_state(self):
-        """the host's (possibly one or two frames old) copy of dyn -- never waited for"""
-        return self.dyn_host.numpy()
+        """the host's (possibly a few frames old) copy of dyn -- never waited for.  The device writes the block while
+        the host may be reading it: the frame tag sits in both 64-byte halves, a copy whose tags differ is re-read."""
+        d = self.dyn_host.numpy()
+        for _ in range(64):
+            c = d.copy()
+            if c[DYN_FRAME] == c[DYN_FRAME2]:
+                return c
+        return c
+
+    def throttle(self, counter):
+        """bound the host's run-ahead: wait (sleeping) until the lazy copy is at most MAX_AHEAD frames old, so that the
+        capacity margins the host checks against it (frame buffers, delta log: + 8) hold -- a caller that feeds
+        preloaded inputs enqueues frames ~5x faster than the GPU tracks them.  The GPU stays MAX_AHEAD frames deep in
+        work, so this never idles it."""
+        import time
+        d = self.dyn_host.numpy()
+        t0 = None
+        while int(counter) - int(d[DYN_FRAME]) > MAX_AHEAD:
+            if t0 is None:
+                t0 = time.perf_counter()
+            elif time.perf_counter() - t0 > 5.0:
+                raise RuntimeError("device-resident tracker: the GPU has not finished a frame for 5 s")
+            time.sleep(2e-5)
 
     def leave(self):
         """synchronise and return the host-side view of the state: dict(n, ii, jj, kk, rows (host arrays of the kept
@@ -310,4 +340,4 @@ class DeviceTrack:
         self.active = False
         return dict(n=n, ii=np.ascontiguousarray(g[0]), jj=np.ascontiguousarray(g[1]), kk=np.ascontiguousarray(g[2]),
                     rows=np.ascontiguousarray(g[3]), net=self.net[0][:int(d[DYN_EPREV])], log=log,
-                    status=int(d[DYN_STATUS]))
+                    status=int(d[DYN_STATUS]), weight=self.weight[:int(d[DYN_EPREV])].clone())
