@@ -239,7 +239,7 @@ class DeviceProbe:
         self.used, self.edges, self.enabled = 0, [], False
         self.mode, self.modes = "all", []              # "corr": only the correlation launch is bracketed (the timed region)
         self.corr_inst_ms = []
-        self.live_pairs, self.live_edges = [], []
+        self.live_pairs, self.live_edges = {"live": [], "compact": []}, {"live": [], "compact": []}
 
     def install(self):
         from rampvo_amd import track_dev
@@ -248,7 +248,7 @@ class DeviceProbe:
         def step(dv, counter, flags, **k):
             on = probe.enabled and probe.mode and probe.used < len(probe.sets) and (flags & track_dev.UPDATE)
             for i in range(5):
-                dv.t.probe[i] = probe.sets[probe.used][i].cuda_event if on and (probe.mode not in ("corr", "live") or i < 2) else None
+                dv.t.probe[i] = probe.sets[probe.used][i].cuda_event if on and (probe.mode not in ("corr", "live", "compact") or i < 2) else None
             if on:
                 probe.edges.append(int(dv.lazy_state()[track_dev.DYN_E]))      # a frame or two old: fine for a mean
                 probe.modes.append(probe.mode)
@@ -261,8 +261,8 @@ class DeviceProbe:
         for evs, E, mode in zip(self.sets[:self.used], self.edges, self.modes):
             if mode == "corr":                 # the timed region's samples: what roofline.achieved is computed from
                 ctimer.pairs.append((evs[0], evs[1])); ctimer.edges.append(E)
-            elif mode == "live":               # the live-factor leg (every reprojection inside the plane)
-                self.live_pairs.append((evs[0], evs[1])); self.live_edges.append(E)
+            elif mode in ("live", "compact"):  # the live-factor legs (every reprojection inside the plane)
+                self.live_pairs[mode].append((evs[0], evs[1])); self.live_edges[mode].append(E)
             elif mode == "alone":              # the sequential pass: nothing else on the GPU
                 utimer.alone_ms.append(evs[1].elapsed_time(evs[2]))
                 btimer.alone_ms.append(evs[3].elapsed_time(evs[4]))
@@ -491,13 +491,23 @@ def parity_block(state, args, cfg_kwargs, net, dev):
         ref.update()
         r = dict(poses=ref.poses_[:n].numpy().copy(), depth=ref.patches_[:n, :, 2, 1, 1].numpy().copy(),
                  net=ref.net[0].float().numpy().copy(), w=ref.last_weight.numpy().copy())
+    # the same step on the oracle WITH the shipped precision policy's roundings (oracle/host_cpu.py): the fp16 leg's
+    # distance to it is kernel error, its distance to the fp32 oracle the policy itself
+    with cpu_oracle_ops(fp16_policy=True):
+        refp = _cpu_tracker(state, args, cfg_kwargs, w_bias=PARITY_W_BIAS)
+        refp.update()
+        rp = dict(poses=refp.poses_[:n].numpy().copy(), depth=refp.patches_[:n, :, 2, 1, 1].numpy().copy(),
+                  net=refp.net[0].float().numpy().copy(), w=refp.last_weight.numpy().copy())
+        del refp
     step = float(np.abs(r["poses"] - before).max())
     scale = max(1.0, step)
     tf = dict(edges=int(state["ii"].shape[0]), keyframes=n, gn_step=round(step, 6), w_head_bias_shift=PARITY_W_BIAS,
               note="max abs error of one update() vs the CPU oracle (fp32) from the same snapshot; net relative to its "
                    "largest entry, poses / depths relative to max(1, |GN step|) (depths also to max(1, |depth|)); depths = "
                    "99.5th percentile over the ~1e4 patches (what tests/test_pipeline_gpu.py bounds), depths_max = the "
-                   "worst patch (a low-confidence patch on an ill-conditioned depth can sit near 1 in the fp16 leg)")
+                   "worst patch (a low-confidence patch on an ill-conditioned depth can sit near 1 in the fp16 leg); "
+                   "fp16_vs_fp16_policy_oracle = the fp16 leg against the CPU oracle with the same rounding points "
+                   "(fp16 Linear operands / outputs, fp32 accumulate): kernel error without the precision policy's")
     if True:
         for name, mixed in (("fp16", True), ("fp32", False)):
             slam = Ramp_vo(make_cfg(args.preset, **dict(cfg_kwargs, MIXED_PRECISION=mixed)), net, {"event_bias": True},
@@ -518,6 +528,15 @@ def parity_block(state, args, cfg_kwargs, net, dev):
                 depths_max=float(derr.max() / scale),
                 depths_at_reset_threshold=float(at_reset.sum()))
             tf[name] = {k: float("%.3g" % v) for k, v in leg.items()}
+            if mixed:
+                at_p = (np.abs(rp["depth"] - 20.0) < 0.1) | (np.abs(g_depth - 20.0) < 0.1)
+                dp = (np.abs(g_depth - rp["depth"]) / np.maximum(np.abs(rp["depth"]), 1.0))[~at_p]
+                tf["fp16_vs_fp16_policy_oracle"] = {k: float("%.3g" % v) for k, v in dict(
+                    net=float(np.abs(slam.net[0].float().cpu().numpy() - rp["net"]).max() / np.abs(rp["net"]).max()),
+                    weight=float(np.abs(slam.last_weight.cpu().numpy() - rp["w"]).max()),
+                    poses_over_gn_step=float(np.abs(slam.poses_[:n].cpu().numpy() - rp["poses"]).max() / max(step, 1e-12)),
+                    depths=float(np.percentile(dp, 99.5) / scale), depths_p999=float(np.percentile(dp, 99.9) / scale),
+                    depths_max=float(dp.max() / scale)).items()}
             del slam
     # the same step with the weights exactly as the benchmark tracks with them (no bias shift: confidences ~0.5, the
     # ill-conditioned regime), fp32 leg: the stated bounds of tests/test_pipeline_gpu.py::REGIME_BOUNDS apply
@@ -584,10 +603,12 @@ def graph_size(slam):
     return len(slam._ii), slam.n
 
 
-def live_factor_fractions(slam):
+def live_factor_fractions(slam, windows=False):
     """share of the current graph's factors with a correlation window inside the target plane, per level (the
     kernel's own test, ramp/altcorr/correlation_kernel.cu:104-110's bounds on the 8 x 8 window), from the
-    device-resident step's reprojection"""
+    device-resident step's reprojection.  windows: a dict that also carries the median / 90th percentile area (pixels) of
+    the union of a factor's nine 8 x 8 windows per level (one 10 x 10 window = 100; the kernel gathers the union in one
+    pass up to 192 pixels and window by window beyond that)"""
     dv = getattr(slam, "_dev", None)
     if dv is None or not dv.active:
         return None
@@ -596,11 +617,19 @@ def live_factor_fractions(slam):
     E = int(dv.dyn.cpu().numpy()[track_dev.DYN_E])
     co = dv.coords[:E].reshape(E, 2, 9)
     h, w = slam.ht // slam.RES, slam.wd // slam.RES
-    out = []
+    out, areas = [], []
     for div, (H, W) in ((1.0, (h, w)), (4.0, (h // 4, w // 4))):
         fx, fy = torch.floor(co[:, 0] / div), torch.floor(co[:, 1] / div)
         live = (fx - 3 < W) & (fx - 3 + 8 > 0) & (fy - 3 < H) & (fy - 3 + 8 > 0)
         out.append(round(float(live.any(1).float().mean()), 3))
+        if windows:
+            big = 1e9
+            bw = torch.where(live, fx, -big).max(1).values - torch.where(live, fx, big).min(1).values + 8
+            bh = torch.where(live, fy, -big).max(1).values - torch.where(live, fy, big).min(1).values + 8
+            a = (bw * bh)[live.any(1)].double().clamp(max=1e9)
+            areas.append([int(a.median()), int(a.quantile(0.9))] if a.numel() else None)
+    if windows:
+        return {"live_factor_fraction_fine_coarse": out, "union_window_px_median_p90_fine_coarse": areas}
     return out
 
 
@@ -659,7 +688,7 @@ def main():
     n_inst = 0 if args.no_kernel_timing else args.inst_steps
     n_alone = 20 if (n_inst and n_np) else 0
     n_live = args.live_steps if (n_inst and solo) else 0
-    total = args.prime + n_warm + args.warmup + args.steps + n_inst + n_np + n_alone + (n_live + 4 if n_live else 0)
+    total = args.prime + n_warm + args.warmup + args.steps + n_inst + n_np + n_alone + (2 * n_live + 4 if n_live else 0)
     n_cpu = args.cpu_steps + 1 if (solo and args.cpu_steps > 0) else 0
     stream = SyntheticStream(args.height, args.width, total + n_cpu + 1, seed=1234 + rank, device=dev)
     frames = [tuple(x.to(dev) if i < 2 else x for i, x in enumerate(stream.frame(t))) for t in range(total)]
@@ -671,7 +700,7 @@ def main():
         etimer.install(net)
         btimer.install()
         utimer.install()
-        dprobe = DeviceProbe(args.steps + n_inst + n_alone + n_live)
+        dprobe = DeviceProbe(args.steps + n_inst + n_alone + 2 * n_live)
         dprobe.install()
 
     pos = {"t": 0}
@@ -781,13 +810,15 @@ def main():
             step()
         dvl = getattr(slam, "_dev", None)
         if dvl is not None and dvl.active:
-            slam._extra_step_flags = track_dev.WRAP_COORDS
-            dprobe.enabled, dprobe.mode = True, "live"
-            for _ in range(n_live):
-                step()
-            torch.cuda.synchronize()
-            dprobe.enabled = False
-            live_leg = live_factor_fractions(slam)
+            live_leg = {}
+            for mode, flag in (("compact", track_dev.COMPACT_COORDS), ("live", track_dev.WRAP_COORDS)):
+                slam._extra_step_flags = flag
+                dprobe.enabled, dprobe.mode = True, mode
+                for _ in range(n_live):
+                    step()
+                torch.cuda.synchronize()
+                dprobe.enabled = False
+                live_leg[mode] = live_factor_fractions(slam, windows=True)
             slam._extra_step_flags = 0
     if dprobe is not None:
         dprobe.feed(ctimer, utimer, btimer, cfg.OPTIMIZATION_WINDOW)
@@ -840,19 +871,24 @@ def main():
                                   % (max(1, args.probe_every), rl["launches"], n_inst,
                                      1e3 * float(np.mean(dprobe.corr_inst_ms)) if dprobe.corr_inst_ms else float("nan")))
             out["roofline"] = rl
-            if live_leg is not None and dprobe.live_pairs:
-                lt = CorrTimer()
-                lt.pairs, lt.edges = dprobe.live_pairs[2:], dprobe.live_edges[2:]     # (the first two: the pipeline refilling)
-                ll = lt.summary(2 if args.mixed else 4, slam)
-                out["roofline_live"] = {
-                    "what": "the same kernel inside the pipelined frame with EVERY factor's windows inside the target plane: each "
+            what = {"live": "the same kernel inside the pipelined frame with EVERY factor's windows inside the target plane: each "
                             "reprojection is moved into the plane by whole plane widths / heights right before the correlation "
-                            "launch (RAMP_TRACK_WRAP_COORDS, %d steps behind everything else; the factor list, target frames "
-                            "and patches are the tracker's own)" % n_live,
-                    "live_factor_fraction_fine_coarse": live_leg,
-                    **{k: ll[k] for k in ("bound", "achieved", "peak", "unit", "frac", "launches", "mean_launch_us",
-                                          "bytes_per_launch", "edges_per_launch", "target_frames", "patches", "model_bytes",
-                                          "model_gbps", "mfma_tflops", "mfma_frac")}}
+                            "launch (RAMP_TRACK_WRAP_COORDS, %d steps behind everything else; factor list, target frames, patches "
+                            "and the patches' projected shapes are the random-weight tracker's own: see union_window_px)" % n_live,
+                    "compact": "the same, and every patch reprojected with unit pixel spacing around its centre "
+                               "(RAMP_TRACK_COMPACT_COORDS): the factors of a converged tracker -- one ~10 x 10 union window "
+                               "per level, where the random-weight tracker's patches spread over tens of pixels and take the "
+                               "kernel's nine-separate-windows path"}
+            for mode, key in (("compact", "roofline_live_compact"), ("live", "roofline_live")):
+                if live_leg is None or not dprobe.live_pairs[mode]:
+                    continue
+                lt = CorrTimer()
+                lt.pairs, lt.edges = dprobe.live_pairs[mode][2:], dprobe.live_edges[mode][2:]   # (the first two: the pipeline refilling)
+                ll = lt.summary(2 if args.mixed else 4, slam)
+                out[key] = {"what": what[mode], **live_leg[mode],
+                            **{k: ll[k] for k in ("bound", "achieved", "peak", "unit", "frac", "launches", "mean_launch_us",
+                                                  "bytes_per_launch", "edges_per_launch", "target_frames", "patches",
+                                                  "model_bytes", "model_gbps", "mfma_tflops", "mfma_frac")}}
         for key, val in (("roofline_update", utimer.summary(bool(args.mixed))),
                          ("roofline_encoder", etimer.summary(bool(args.mixed))),
                          ("roofline_ba", btimer.summary(args.patches, cfg.REMOVAL_WINDOW))):

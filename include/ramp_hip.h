@@ -598,6 +598,8 @@ int ramp_upd_linear(const void *x, const void *w_packed, const float *bias, void
 #define RAMP_TRACK_MM_GIVEN 8  /* (tests) keyframe(): take the two flow magnitudes from t->mm instead of computing */
 #define RAMP_TRACK_WRAP_COORDS 16 /* (measurement) move every reprojection into the target plane by whole plane sizes
                                      before the correlation launch: bench.py's roofline leg with every factor live    */
+#define RAMP_TRACK_COMPACT_COORDS 32 /* (measurement) the same, and every patch with unit pixel spacing around its centre (a
+                                     converged tracker's factors: one 10 x 10 union window per level)                  */
 
 typedef struct ramp_track_weights {      /* update operator, fp16 fused formats of ramp_upd_* */
   const void *corr_w1, *corr_w2, *corr_w3;

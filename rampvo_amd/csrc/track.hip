@@ -246,17 +246,27 @@ __global__ void __launch_bounds__(256) trk_iota_kernel(int64_t *__restrict__ row
 // widths / heights (the patch keeps its shape): with random-init weights a third to a half of the projections leave
 // the image and cost the correlation kernel a row of zeros and no gathers; bench.py's "live" roofline leg times the
 // kernel with every factor gathering
+// RAMP_TRACK_COMPACT_COORDS: in addition the patch is given unit pixel spacing around its (wrapped) centre -- the factors
+// of a converged tracker (a patch reprojects to about its own 3 x 3 footprint: one 10 x 10 union window per level); the
+// random-weight tracker's own patches spread over tens of pixels and take the kernel's nine-separate-windows path.
 __global__ void __launch_bounds__(256) trk_wrap_coords_kernel(float *__restrict__ coords, const int32_t *__restrict__ dyn,
-                                                              int PP, float w, float h) {
+                                                              int P, float w, float h, int compact) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= dyn[RAMP_DYN_E]) return;
+  const int PP = P * P;
   float *c = coords + (size_t)e * 2 * PP;
   const float cx = c[PP / 2], cy = c[PP + PP / 2];
   const bool ok = fabsf(cx) < 1e8f && fabsf(cy) < 1e8f;       // (false for NaN / inf as well)
   const float sx = ok ? floorf(cx / w) * w : 0.f, sy = ok ? floorf(cy / h) * h : 0.f;
+  const float mx = ok ? cx - sx : 0.5f * w, my = ok ? cy - sy : 0.5f * h;
   for (int p = 0; p < PP; p++) {
-    c[p] = ok ? c[p] - sx : 0.5f * w;
-    c[PP + p] = ok ? c[PP + p] - sy : 0.5f * h;
+    if (compact) {
+      c[p] = mx + (float)(p % P - P / 2);
+      c[PP + p] = my + (float)(p / P - P / 2);
+    } else {
+      c[p] = ok ? c[p] - sx : mx;
+      c[PP + p] = ok ? c[PP + p] - sy : my;
+    }
   }
 }
 
@@ -449,9 +459,9 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
       return RAMP_EINVAL;
     // Ramp_vo.update(), ramp/Ramp_vo.py:276-310
     TRK_DO(ramp_i_transform_dyn(t->poses, t->patches, t->intrinsics, ii, jj, kk, t->coords, Eb, dyn, st));
-    if (flags & RAMP_TRACK_WRAP_COORDS)
-      hipLaunchKernelGGL(trk_wrap_coords_kernel, dim3(ramp_cdiv(Eb, 256)), dim3(256), 0, st, t->coords, dyn, PP,
-                         (float)t->feat_w, (float)t->feat_h);
+    if (flags & (RAMP_TRACK_WRAP_COORDS | RAMP_TRACK_COMPACT_COORDS))
+      hipLaunchKernelGGL(trk_wrap_coords_kernel, dim3(ramp_cdiv(Eb, 256)), dim3(256), 0, st, t->coords, dyn, t->P,
+                         (float)t->feat_w, (float)t->feat_h, (flags & RAMP_TRACK_COMPACT_COORDS) ? 1 : 0);
     ramp_corr_level lv[2];
     lv[0].fmap = t->fmap1; lv[0].H2 = t->feat_h; lv[0].W2 = t->feat_w; lv[0].coord_div = 1.0f;
     lv[1].fmap = t->fmap2; lv[1].H2 = t->feat_h / 4; lv[1].W2 = t->feat_w / 4; lv[1].coord_div = 4.0f;

@@ -22,7 +22,7 @@ DYN_WORDS = 32
 DYN_FRAME2 = 31          # repeats DYN_FRAME in the other 64-byte half of the block (a torn lazy copy shows)
 LOG_WORDS = 12
 MAX_AHEAD = 6            # frames the host may enqueue ahead of the newest lazy copy of the sizes (Ramp_vo._track_device)
-COMMIT, UPDATE, KEYFRAME, MM_GIVEN, WRAP_COORDS = 1, 2, 4, 8, 16
+COMMIT, UPDATE, KEYFRAME, MM_GIVEN, WRAP_COORDS, COMPACT_COORDS = 1, 2, 4, 8, 16, 32
 CORR_ROW = 896
 
 

@@ -179,8 +179,10 @@ MIXED_DEPTHS_P999 = 1e-1       # the 99.9th percentile (p99.5 alone l
 
 
 # the HIP fp16 leg against the CPU oracle WITH the same precision policy (kernel error only): <= 4x the values measured on
-# MI355X at configs[1] (printed by the test)
-POLICY_NET, POLICY_WEIGHT, POLICY_POSES, POLICY_DEPTHS_P999, POLICY_DEPTHS_MAX = 2e-3, 1e-4, 5e-3, 1e-1, 1.0
+# MI355X at configs[1] (printed by the test: net 2.8e-4 -- single fp16 roundings that fall the other way under a different
+# fp32 summation order --, weight 6e-8, poses 1.3e-4 of the GN step, depths p99.9 2.3e-3, worst patch 6.9e-3; the same
+# leg against the fp32 oracle: 3.6e-3 of the step, 1.3e-2, 3.7e-2 -- i.e. the fp16 path's error is its precision policy)
+POLICY_NET, POLICY_WEIGHT, POLICY_POSES, POLICY_DEPTHS_P999, POLICY_DEPTHS_MAX = 1.2e-3, 1e-6, 5e-4, 1e-2, 3e-2
 
 
 def _assert_policy_leg(m):
