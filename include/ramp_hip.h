@@ -559,6 +559,22 @@ int ramp_upd_nbr2(const float *net_in, const int32_t *kj, const int64_t *ix, con
 int ramp_upd_linear(const void *x, const void *w_packed, const float *bias, void *y, int rows, const int32_t *rows_dev,
                     void *stream);
 
+/* SoftAgg (ramp/blocks.py:33-50: y = scatter_sum(f(x) * scatter_softmax(g(x))), h(y)) of the fp16 path WITHOUT the
+ * [E, 768] rows of [f | g] going through memory: ramp_upd_softagg walks the grouping's sorted factor list (`order`,
+ * groups = contiguous runs; `gid`: factor -> group), 80 positions per workgroup, forms g and f on the same tile and leaves
+ * one fragment (running maximum, sum, weighted sum)[384] per run of a group inside a 20-position block in
+ * frag[group + position / 20] (ramp_upd_softagg_frag_rows(E, max_groups) rows of 3 x 384 floats); ramp_upd_softagg_finish
+ * merges a group's fragments in slot order (seg_start = the grouping's segment starts), y = a / z, and applies h:
+ * hy [max_groups][384] fp16 (rows >= *ngroups are zero).  x = x32 (+ add_t[add_idx]); weights as ramp_upd_fg /
+ * ramp_upd_linear.  Replaces ramp_upd_fg + ramp_upd_segment_softmax + ramp_upd_linear (same values up to the order of
+ * the fp32 additions).                                                                                             */
+size_t ramp_upd_softagg_frag_rows(int E, int max_groups);
+int ramp_upd_softagg(const float *x32, const void *add_t, const int32_t *add_idx, const int32_t *order,
+                     const int32_t *gid, const void *wf, const float *bf, const void *wg, const float *bg, float *frag,
+                     int E, void *stream);
+int ramp_upd_softagg_finish(const float *frag, const int32_t *seg_start, const int32_t *ngroups, const void *wh,
+                            const float *bh, void *hy, int max_groups, void *stream);
+
 /* ---------------------------------------------------------------- device-resident tracking step
  *
  * Ramp_vo.__call__ in steady state (ramp/Ramp_vo.py:327-410): the frame's state stores, update() (:276-310:
@@ -648,6 +664,8 @@ typedef struct ramp_track {
   void *corr;                         /* [E_cap][896] fp16 */
   float *net[3];                      /* [E_cap][384] fp32: [0] the hidden state (in: previous, out: new), [1], [2] scratch */
   void *fg, *ykk, *hkk, *yij, *hij, *relu_t;      /* (relu_t: unused since the heads moved into the gru launch) */
+  float *sagg_frag;                   /* optional [ramp_upd_softagg_frag_rows(E_cap, max(kk_cap, ij_cap))][3][384]: with it the
+                                       * two SoftAggs run as ramp_upd_softagg + _finish (fg / ykk / yij are then unused)  */
   float *target, *weight;             /* [E_cap][2] */
   /* bundle adjustment */
   void *ba_ws;

@@ -436,12 +436,59 @@ def gen_pose_pred(ns):
           "changed edges", int((coords_in != coords.numpy()).any(axis=(0, 2, 3, 4)).sum()))
 
 
+@torch.no_grad()
+def gen_pose_pred_e2e(ns):
+    """Ramp_vo.predict_future_pose ITSELF (ramp/Ramp_vo.py:446-507), driven like evaluate.py:205-224: track, twelve
+    updates at the hand-over, then virtual keyframes 0, 1, 2 frames ahead -- upstream's method as it is, including what it
+    does to BA's target (the whole [1,E,2,3,3] grid tensor, read by cuda_ba as its first E rows of a [-1,2] view,
+    fastba/ba_cuda.cu:462) and the x / y order of the predicted grids (pose_pred_utils.py:342).  ``damped`` weights: the
+    random-weight tracker stays finite through the twelve closing updates.  The product's bug-compatible mode
+    (rampvo_amd.Ramp_vo.predict_future_pose, the default) is compared with this under -m gpu."""
+    p = RAMPVO
+    net = ref_network(ns, "SingleScale", profile="damped")
+    cfg = ns.CfgNode(make_cfg("default", PATCHES_PER_FRAME=p["M"], MIXED_PRECISION=False))
+    stream = SyntheticStream(p["H"], p["W"], p["T"], seed=p["seed"])
+    frame_no = [0]
+    orig_rand_like = torch.rand_like
+
+    def fake_rand_like(x, *a, **k):
+        return depth_draw(frame_no[0], x.shape[1]).to(x.dtype).expand_as(x).clone()
+
+    rec = dict(pred_pose=[], n=[], counter=[])
+    with rh.CudaToCpu():
+        slam = ns.Ramp_vo.Ramp_vo(cfg=cfg, network=net, train_cfg={"event_bias": True}, ht=p["H"], wd=p["W"])
+        torch.rand_like = fake_rand_like
+        try:
+            for t in range(p["T"]):
+                image, events, K, mask = stream.frame(t)
+                frame_no[0] = t
+                slam(t, input_tensor=(events, image, mask), intrinsics=K)
+        finally:
+            torch.rand_like = orig_rand_like
+        last = slam.n
+        for _ in range(12):
+            slam.update()
+        before = slam.poses_[:last].numpy().copy()
+        for step in range(3):
+            slam.predict_future_pose(last_keyframe_number=last, sec_to_pred_future=step, abs_time=p["T"] + step, deg=3)
+            rec["pred_pose"].append(slam.poses_[slam.n - 1].numpy().copy())
+            rec["n"].append(slam.n); rec["counter"].append(slam.counter)
+        assert np.array_equal(slam.poses_[:last].numpy(), before)
+        traj, ts = slam.terminate()
+    assert np.isfinite(traj).all()
+    np.savez_compressed(os.path.join(OUT, "pose_pred_e2e.npz"), last=last, poses_before=before, traj=traj, tstamps=ts,
+                        **{k: np.asarray(v) for k, v in rec.items()})
+    print("pose_pred_e2e ok: last", last, "n", rec["n"], "pose", rec["pred_pose"][-1])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = rh.load()
     only = sys.argv[1] if len(sys.argv) > 1 else None
     if only == "pose_pred":
         return gen_pose_pred(ns)
+    if only == "pose_pred_e2e":
+        return gen_pose_pred_e2e(ns)
     if only == "traj":
         gen_ramp_vo_traj(ns, "ss")
         return gen_ramp_vo_traj(ns, "ms")
@@ -449,6 +496,7 @@ def main():
         return gen_corr(ns)
     gen_event_stack(ns)
     gen_pose_pred(ns)
+    gen_pose_pred_e2e(ns)
     gen_patchify(ns, "SingleScale")
     gen_patchify(ns, "MultiScale")
     gen_update(ns)

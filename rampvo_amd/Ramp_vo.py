@@ -888,17 +888,18 @@ class Ramp_vo:
         """reference :416-444: builds the virtual frame and its reprojections and stops there (returns None)"""
         self._virtual_frame(last_keyframe_number)
 
-    def predict_future_pose(self, sec_to_pred_future, abs_time, last_keyframe_number, deg=3, frequency=30):
+    def predict_future_pose(self, sec_to_pred_future, abs_time, last_keyframe_number, deg=3, frequency=30, corrected=False):
         """Extrapolate a virtual keyframe ``sec_to_pred_future`` frames past the last real one (reference
         :447-507, driven by evaluate.py::run_pose_pred): motion-model pose, one extra factor per live patch,
         per-patch spline models of the past reprojections (fitted once, on the first call), two BA iterations
         on the predicted targets, then the pose is appended so that terminate() interpolates through it.
 
-        Deviation, on purpose: upstream passes the whole predicted ``coords`` tensor [1,E,2,3,3] as BA's
-        ``target``; cuda_ba views it as [-1,2] and reads its first E rows (fastba/ba_cuda.cu:462), i.e. pairs of
-        neighbouring x values of the first E/9 factors, and the predicted grids are written with x and y
-        exchanged (pose_pred_utils.py:342).  Here BA gets what Ramp_vo.update() gives it -- the patch centres
-        [1,E,2], channel 0 = x -- for the same factors and weights."""
+        Default: WHAT UPSTREAM COMPUTES (pinned by tests/golden/pose_pred_e2e.npz, upstream's own method run over the
+        oracle): the predicted 3x3 grids are written with x and y exchanged (pose_pred_utils.py:342) and the whole
+        ``coords`` tensor [1,E,2,3,3] is handed to BA as ``target``, which cuda_ba views as [-1,2] and reads the first
+        E rows of (fastba/ba_cuda.cu:462) -- pairs of neighbouring grid values of the first E/9 factors.
+        ``corrected=True``: BA gets what Ramp_vo.update() gives it -- the patch centres [1,E,2], channel 0 = x --
+        for the same factors and weights."""
         from .pose_prediction.pose_pred_utils import (compute_patch_track__, fit_model_patch_track,
                                                       predict_patch_on_model)
         (next_frame_number, next_frame_index, poses, patches, intrinsics, (ii, jj, kk), weights_up,
@@ -913,8 +914,12 @@ class Ramp_vo:
         coords, updated_weight = predict_patch_on_model(
             patch_models=self.patches_models, step_to_pred_future=sec_to_pred_future, frequency=frequency,
             next_frame_index=next_frame_index, coords=coords, weights=weights_up, ii=ii, jj=jj, kk=kk,
-            reference_layout=False)
-        target = coords[..., self.P // 2, self.P // 2].contiguous()
+            reference_layout=not corrected)
+        E = ii.shape[0]
+        if corrected:
+            target = coords[..., self.P // 2, self.P // 2].contiguous()
+        else:
+            target = coords.contiguous().view(-1, 2)[:E].view(1, E, 2).contiguous()     # cuda_ba's reading of the tensor
         t0 = max(next_frame_number - self.cfg.OPTIMIZATION_WINDOW if self.is_initialized else 1, 1)
         t1 = next_frame_number
         try:
@@ -935,14 +940,18 @@ class Ramp_vo:
         self.counter += 1
         self.n += 1
 
-    def remove_attributes(self):
-        """undo update_attributes (reference :521-528; upstream's ``poses_[:,6] = 1.0`` there rewrites the qw of
-        EVERY keyframe -- only the removed row is reset here)"""
+    def remove_attributes(self, corrected=False):
+        """undo update_attributes (reference :521-528).  Default: as upstream, whose ``poses_[:,6] = 1.0`` rewrites the qw
+        of EVERY row of the pose buffer (the real keyframes' too); corrected=True resets only the removed row."""
         self.n -= 1
         self.counter -= 1
         self.tlist.pop()
         del self._tstamps[self.n:]
-        self.poses_[self.n] = torch.tensor([0, 0, 0, 0, 0, 0, 1], dtype=torch.float, device=self.device)
+        self.poses_[self.n] = torch.zeros(7, dtype=torch.float, device=self.device)
+        if corrected:
+            self.poses_[self.n, 6] = 1.0
+        else:
+            self.poses_[:, 6] = 1.0
         self.tstamps_[self.n] = 0
 
     def _frame_stores_stepwise(self, n, slot, k_dev, kq, patches, imap, gmap, fmap, clr, ex):

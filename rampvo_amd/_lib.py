@@ -111,6 +111,9 @@ SIGNATURES = {
     "ramp_upd_nbr": (c_i, [c_p] * 8 + [c_i, c_p]),
     "ramp_upd_nbr2": (c_i, [c_p] * 13 + [c_i, c_p]),
     "ramp_upd_linear": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_p]),
+    "ramp_upd_softagg_frag_rows": (c_sz, [c_i, c_i]),
+    "ramp_upd_softagg": (c_i, [c_p] * 10 + [c_i, c_p]),
+    "ramp_upd_softagg_finish": (c_i, [c_p] * 6 + [c_i, c_p]),
     # device-resident tracking step (csrc/track.hip); the ramp_track descriptor is mirrored in track_dev.py
     "ramp_track_sizeof": (c_sz, []),
     "ramp_track_plan_workspace_bytes": (c_sz, [c_i, c_i, c_i]),

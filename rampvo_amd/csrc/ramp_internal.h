@@ -65,6 +65,9 @@ int ramp_i_upd_corr_mlp(const void *corr, int corr_k, const void *w1, const floa
                         const float *net, const int64_t *net_map, const void *inp, const int64_t *inp_idx, long inp_mod,
                         const float *norm_w, const float *norm_b, float norm_eps, float *net_out, int E,
                         const int32_t *dyn, void *stream);
+int ramp_i_upd_softagg(const float *x32, const void *add_t, const int32_t *add_idx, const int32_t *order, const int32_t *gid,
+                       const void *wf, const float *bf, const void *wg, const float *bg, float *frag, int E,
+                       const int32_t *dyn, void *stream);
 int ramp_i_upd_fg(const float *x32, const void *add_t, const int32_t *add_idx, float *x32_out, const void *wf,
                   const float *bf, const void *wg, const float *bg, void *fg, int E, const int32_t *dyn, void *stream);
 int ramp_i_upd_heads_linear(const void *relu_t, const void *heads_w, const float *heads_b, const float *coords,

@@ -493,6 +493,24 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
       net = t->net[1];
     }
     TRK_GATE(2);
+    // SoftAgg x 2 (ramp/net.py:84-85).  With a fragment table: gather-by-group tiles, g and f on the same tile, online
+    // softmax in registers, h on the merged fragments -- 2 launches each, no [E, 768] rows (csrc/update_mlp.hip);
+    // RAMP_SOFTAGG=0 or no table: [f | g] rows + segment softmax + h, 3 launches each.
+    static int sagg = -1;
+    if (sagg < 0) { const char *e = getenv("RAMP_SOFTAGG"); sagg = e ? atoi(e) : 1; }
+    static int add2 = -1;
+    if (add2 < 0) { const char *e = getenv("RAMP_GRU_ADD2"); add2 = e ? atoi(e) : 1; }
+    const bool use_sagg = sagg && t->sagg_frag;
+    if (use_sagg) add2 = 1;                       // (that path never writes net + hkk[.] back: the gru launch forms the sum)
+    if (use_sagg) {
+      TRK_DO(ramp_i_upd_softagg(net, nullptr, nullptr, t->kk_order, t->kk_gid, w.kk_wf, w.kk_bf, w.kk_wg, w.kk_bg, t->sagg_frag,
+                                Eb, dyn, st));
+      TRK_DO(ramp_upd_softagg_finish(t->sagg_frag, t->kk_seg, t->kk_ngroups, w.kk_wh, w.kk_bh, t->hkk, t->kk_cap, stream));
+      TRK_GATE(1);
+      TRK_DO(ramp_i_upd_softagg(net, t->hkk, t->kk_gid, t->ij_order, t->ij_gid, w.ij_wf, w.ij_bf, w.ij_wg, w.ij_bg, t->sagg_frag,
+                                Eb, dyn, st));
+      TRK_DO(ramp_upd_softagg_finish(t->sagg_frag, t->ij_seg, t->ij_ngroups, w.ij_wh, w.ij_bh, t->hij, t->ij_cap, stream));
+    } else {
     TRK_DO(ramp_i_upd_fg(net, nullptr, nullptr, nullptr, w.kk_wf, w.kk_bf, w.kk_wg, w.kk_bg, t->fg, Eb, dyn, st));
     TRK_DO(ramp_upd_segment_softmax(t->fg, t->kk_order, t->kk_seg, t->kk_ngroups, t->ykk, t->kk_cap, RAMP_F16, stream));
     TRK_DO(ramp_upd_linear(t->ykk, w.kk_wh, w.kk_bh, t->hkk, t->kk_cap, t->kk_ngroups, stream));
@@ -500,11 +518,10 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
     // the pair SoftAgg's [f|g] launch reads net + hkk[patch group] and, by default, does NOT write the sum back: the gru
     // launch forms (net + hkk[.]) + hij[.] itself, in the same order (61 MB less to write in the serial part of the step;
     // the extra table rows come from L2).  RAMP_GRU_ADD2=0: the sum is written back (A/B runs).
-    static int add2 = -1;
-    if (add2 < 0) { const char *e = getenv("RAMP_GRU_ADD2"); add2 = e ? atoi(e) : 1; }
     TRK_DO(ramp_i_upd_fg(net, t->hkk, t->kk_gid, add2 ? nullptr : net, w.ij_wf, w.ij_bf, w.ij_wg, w.ij_bg, t->fg, Eb, dyn, st));
     TRK_DO(ramp_upd_segment_softmax(t->fg, t->ij_order, t->ij_seg, t->ij_ngroups, t->yij, t->ij_cap, RAMP_F16, stream));
     TRK_DO(ramp_upd_linear(t->yij, w.ij_wh, w.ij_bh, t->hij, t->ij_cap, t->ij_ngroups, stream));
+    }
     TRK_GATE(0);
     // (the heads and target / weight are formed in the gru launch's epilogue: no relu(net) round trip, one launch less)
     TRK_DO(ramp_i_upd_gru(net, add2 ? t->hkk : nullptr, add2 ? t->kk_gid : nullptr, t->hij, t->ij_gid, w.ln1_w, w.ln1_b, w.ln1_eps, w.gru_w, w.gru_b, w.ln2_w, w.ln2_b,

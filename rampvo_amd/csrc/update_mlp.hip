@@ -935,7 +935,7 @@ __device__ __forceinline__ void big_zero(f4 (&acc)[NMT][NTW]) {
 #ifndef BIG_PF
 #define BIG_PF 1   // measured: 2 is 2 % slower on the whole operator (128 / 146 VGPRs), 1 is the round-2 kernel
 #endif
-template <int NMT, int NTW>
+template <int NMT, int NTW, bool SWAP = true>
 __device__ __forceinline__ void big_gemm(const _Float16 *Xs, const _Float16 *wp, int nks, int w_ks0, int wave, int lane,
                                          f4 (&acc)[NMT][NTW]) {
   const int q = lane >> 4, j = lane & 15;
@@ -966,7 +966,8 @@ __device__ __forceinline__ void big_gemm(const _Float16 *Xs, const _Float16 *wp,
         if (mt + 1 < NMT) an = *reinterpret_cast<const h8 *>(xb + (mt + 1) * 16 * MXS + ks * 32);
 #pragma unroll
         for (int nt = 0; nt < NTW; nt++)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[r][nt], a, acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[r][nt], a, acc[mt][nt], 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_16x16x32_f16(a, ring[r][nt], acc[mt][nt], 0, 0, 0);
         a = an;
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -1320,6 +1321,288 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) upd_fg_big_kernel(const FgPar
   }
 }
 
+
+// ------------------------------------------------------------------ SoftAgg without the [f | g] rows
+// y[group][c] = sum_e softmax_e(g(x_e)[c]) f(x_e)[c] over the factors e of a group, hy = h(y)  (ramp/blocks.py:42-47).
+// upd_fg (+ upd_segment_softmax) write the [E, 768] fp16 rows of [f | g] and read them back through the grouping's
+// order: 4 x 61 MB per SoftAgg, two launches.  Here a workgroup owns 80 CONSECUTIVE POSITIONS of the grouping's sorted
+// factor list (`order`: groups are contiguous runs of it), gathers their state rows (1536 contiguous bytes each), and
+// runs the g and the f product one after the other on the same tile:
+//   * plain (not exchanged) MFMA operands: lane (q, j) holds column j of an n-tile and rows 4q..4q+3 of each of the five
+//     16-row m-tiles -- and the tile rows are PERMUTED so that those 20 rows are 20 consecutive sorted positions
+//     (lane block q <-> positions 20 q .. 20 q + 19 of the tile): a group is a contiguous run of a lane's registers;
+//   * g (a half tensor under the reference's autocast) waits as 30 packed registers while the f product runs;
+//   * one forward sweep per column over the lane's 20 rows: online softmax (running maximum, rescaled sum and weighted
+//     sum -- the arithmetic of upd_segment_softmax), restarted where the group changes.  Each run leaves one FRAGMENT
+//     (m, z, a)[384] in slot  group + 4 tile + q  of a table: (group, block) pairs are distinct and the sum grows along
+//     the list, so slots are unique, and a group's fragments are the consecutive slots
+//     group + first block .. group + last block;
+//   * upd_softagg_finish merges a group's fragments in slot order (fixed order: deterministic), y = a / z -> fp16, and
+//     applies h on 16 groups per workgroup (the matrix part of upd_linear_kernel).
+// Per SoftAgg: 61 MB of state in, ~20 MB of fragments out and in; the two 61 MB [f | g] passes are gone.
+#define SAGG_NMT 5
+#define SAGG_ROWS (16 * SAGG_NMT)   // 80 positions per workgroup
+#define SAGG_BLK (4 * SAGG_NMT)     // 20 positions per lane block
+struct SoftAggParams {
+  const float *x32;            // [E][384] fp32
+  const _Float16 *add_t;       // optional [groups'][384] fp16: x = x32 + add_t[add_idx] (the previous SoftAgg's expand-and-add)
+  const int32_t *add_idx;      // [E]
+  const int32_t *order;        // [E] sorted position -> factor
+  const int32_t *gid;          // [E] factor -> group
+  const _Float16 *wf, *wg;     // packed weights of f and g
+  const float *bf, *bg;        // biases (fp16-rounded values as fp32)
+  float *frag;                 // [slots][3][384] fp32: (m, z, a) per run
+  int E;
+  const int32_t *dyn;          // optional device-side sizes (RAMP_DYN_*): E is then the launch bound
+};
+
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) upd_softagg_kernel(const SoftAggParams p) {
+  constexpr int NMT = SAGG_NMT, NTW = 3, NW = 8, ROWS = SAGG_ROWS, BLK = SAGG_BLK;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  _Float16 *Xs = reinterpret_cast<_Float16 *>(smem_raw);
+  int *s_gid = reinterpret_cast<int *>(Xs + ROWS * MXS);            // [ROWS] group of sorted position p0 + t (-1 past E)
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
+  const int p0 = blockIdx.x * ROWS;
+  const int pE = p.dyn ? p.dyn[RAMP_DYN_E] : p.E;
+  if (p0 >= pE) return;                        // (workgroup-uniform)
+  const int col0 = wave * (16 * NTW);
+  // tile row rho = 16 mt + 4 qq + r holds sorted position p0 + BLK qq + 4 mt + r
+  constexpr int RPW = ROWS / NW;
+  {
+    int fe[RPW], ai[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; i++) {
+      const int rho = wave + i * NW;
+      const int pos = p0 + BLK * ((rho & 15) >> 2) + 4 * (rho >> 4) + (rho & 3);
+      fe[i] = pos < pE ? p.order[pos] : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < RPW; i++) ai[i] = (p.add_t && fe[i] >= 0) ? p.add_idx[fe[i]] : 0;
+    float2 v[RPW][3];
+#pragma unroll
+    for (int i = 0; i < RPW; i++) {
+      const float *b = p.x32 + (size_t)(fe[i] >= 0 ? fe[i] : 0) * MD + 2 * lane;
+#pragma unroll
+      for (int k = 0; k < 3; k++) v[i][k] = *reinterpret_cast<const float2 *>(b + 128 * k);
+    }
+    if (p.add_t) {                                       // uniform
+      h2 t[RPW][3];
+#pragma unroll
+      for (int i = 0; i < RPW; i++) {
+        const _Float16 *b = p.add_t + (size_t)ai[i] * MD + 2 * lane;
+#pragma unroll
+        for (int k = 0; k < 3; k++) t[i][k] = *reinterpret_cast<const h2 *>(b + 128 * k);
+      }
+#pragma unroll
+      for (int i = 0; i < RPW; i++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) { v[i][k].x += (float)t[i][k][0]; v[i][k].y += (float)t[i][k][1]; }
+    }
+#pragma unroll
+    for (int i = 0; i < RPW; i++) {
+      const int rho = wave + i * NW;
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const float2 a = fe[i] >= 0 ? v[i][k] : make_float2(0.f, 0.f);
+        *reinterpret_cast<h2 *>(Xs + rho * MXS + 2 * lane + 128 * k) = (h2){(_Float16)a.x, (_Float16)a.y};
+      }
+    }
+  }
+  if (tid < ROWS) s_gid[tid] = (p0 + tid < pE) ? p.gid[p.order[p0 + tid]] : -1;
+  __syncthreads();
+  // ---- g = x Wg' + bg (half), parked as packed pairs
+  f4 acc[NMT][NTW];
+  big_zero<NMT, NTW>(acc);
+  big_gemm<NMT, NTW, false>(Xs, p.wg, MKS, 0, wave, lane, acc);
+  h2 gp[NMT][NTW][2];
+#pragma unroll
+  for (int nt = 0; nt < NTW; nt++) {
+    const float b = p.bg[col0 + nt * 16 + j];
+#pragma unroll
+    for (int mt = 0; mt < NMT; mt++) {
+      gp[mt][nt][0] = (h2){(_Float16)(acc[mt][nt][0] + b), (_Float16)(acc[mt][nt][1] + b)};
+      gp[mt][nt][1] = (h2){(_Float16)(acc[mt][nt][2] + b), (_Float16)(acc[mt][nt][3] + b)};
+    }
+  }
+  // ---- f = x Wf' + bf on the same tile
+  big_zero<NMT, NTW>(acc);
+#ifndef SAGG_SKIP_F                                  // (diagnostic builds: tools/mb_softagg.py)
+  big_gemm<NMT, NTW, false>(Xs, p.wf, MKS, 0, wave, lane, acc);
+#endif
+#ifdef SAGG_SKIP_SWEEP
+  {
+    float t = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < NMT; mt++)
+#pragma unroll
+      for (int nt = 0; nt < NTW; nt++) t += acc[mt][nt][0] + acc[mt][nt][1] + acc[mt][nt][2] + acc[mt][nt][3] + (float)gp[mt][nt][0][0] + (float)gp[mt][nt][0][1] + (float)gp[mt][nt][1][0] + (float)gp[mt][nt][1][1];
+    if (t == 123.f) p.frag[tid] = t;
+    return;
+  }
+#endif
+  // ---- where this lane block's runs start, and which of its positions exist
+  unsigned startm = 0, validm = 0;
+  {
+    int prev = -2;
+#pragma unroll
+    for (int i = 0; i < BLK; i++) {
+      const int g = s_gid[BLK * q + i];
+      if (g >= 0) validm |= 1u << i;
+      if (g != prev) startm |= 1u << i;
+      prev = g;
+    }
+  }
+  const size_t slot_base = (size_t)4 * blockIdx.x + q;
+#pragma unroll
+  for (int nt = 0; nt < NTW; nt++) {
+    const int col = col0 + nt * 16 + j;
+    const float bfv = p.bf[col];
+    // online softmax per run: running maximum, rescaled sum and weighted sum (the arithmetic of upd_segment_softmax).
+    // (A block-wide shift with one exponential per row + an exact fallback for runs it underflows on was measured: 56 vs 51 us
+    // per launch -- twice the code, 72 instead of 40 spilled registers.)
+    float m = -INFINITY, z = 0.f, a = 0.f;
+    int run_g = -1;
+#pragma unroll
+    for (int mt = 0; mt < NMT; mt++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int i = 4 * mt + r;
+        if (!((validm >> i) & 1)) continue;
+        if ((startm >> i) & 1) {
+          if (run_g >= 0) {
+            float *o = p.frag + ((size_t)run_g + slot_base) * (3 * MD) + col;
+            o[0] = m; o[MD] = z; o[2 * MD] = a;
+          }
+          m = -INFINITY; z = 0.f; a = 0.f;
+          run_g = s_gid[BLK * q + i];
+        }
+        // (in units of log2: one multiplication per row instead of one per exponential; the fragments' maxima stay in
+        // those units, upd_softagg_finish merges them with exp2 as well)
+        const float gk = (float)gp[mt][nt][r >> 1][r & 1] * 1.4426950408889634f;
+        const float fk = h_round(acc[mt][nt][r] + bfv);
+        const float n = fmaxf(m, gk);
+        const float sc = __builtin_amdgcn_exp2f(m - n), e = __builtin_amdgcn_exp2f(gk - n);
+        z = z * sc + e; a = a * sc + fk * e;
+        m = n;
+      }
+    if (run_g >= 0) {
+      float *o = p.frag + ((size_t)run_g + slot_base) * (3 * MD) + col;
+      o[0] = m; o[MD] = z; o[2 * MD] = a;
+    }
+  }
+}
+
+// hy[g] = fp16(h(y[g])), y[g][c] = a / z of group g's merged fragments (slots g + seg[g] / BLK .. g + (seg[g+1] - 1) / BLK).
+// 16 groups per workgroup; 768 threads: thread (c, half) owns column c of 8 groups.  A round loads fragments k .. k + 2 of
+// every one of its groups that has them (up to 72 loads in flight per thread, consecutive threads = consecutive floats),
+// then merges them in slot order -- a loop over a group's fragments per element was a chain of dependent loads on a
+// launch of 27 .. 132 workgroups.  Waves 0..7 then apply h (the matrix part of upd_linear_kernel).
+#define SAGG_FIN_T 768
+#define SAGG_FIN_K 3
+__global__ void __launch_bounds__(SAGG_FIN_T) upd_softagg_finish_kernel(const float *__restrict__ frag, const int32_t *__restrict__ seg,
+                                                                        const int32_t *__restrict__ ngroups,
+                                                                        const _Float16 *__restrict__ wp, const float *__restrict__ bias,
+                                                                        _Float16 *__restrict__ y, int rows) {
+  __shared__ __attribute__((aligned(16))) _Float16 Xs[16 * MXS];
+  __shared__ int s_first[16], s_nfr[16], s_maxn;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
+  const int row0 = blockIdx.x * 16;
+  const int R = min(*ngroups, rows);
+  if (row0 >= R) {                              // unused tail of the table: defined (zero) rows
+    for (int i = tid; i < 16 * (MD / 8); i += SAGG_FIN_T) {
+      const int r = i / (MD / 8), c8 = i - r * (MD / 8);
+      if (row0 + r < rows) *reinterpret_cast<h8 *>(y + (size_t)(row0 + r) * MD + 8 * c8) = (h8){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    return;
+  }
+  constexpr int NT = MNTW, PF = 3;
+  const bool mm = wave < MWAVES;                // the waves that multiply
+  auto wfrag = [&](int ks, int nt) {
+    return *reinterpret_cast<const h8 *>(wp + (((size_t)ks * (MD / 16) + (mm ? wave : 0) * NT + nt) * 64 + lane) * 8);
+  };
+  h8 ring[PF + 1][NT];
+  if (mm) {
+#pragma unroll
+    for (int d = 0; d < PF; d++)
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) ring[d][nt] = wfrag(d, nt);
+  }
+  if (tid < 16) {
+    const int g = row0 + tid;
+    int first = 0, n = 0;
+    if (g < R) {
+      const int s0 = seg[g], s1 = seg[g + 1];
+      first = g + s0 / SAGG_BLK;
+      n = s1 > s0 ? (s1 - 1) / SAGG_BLK - s0 / SAGG_BLK + 1 : 0;
+    }
+    s_first[tid] = first; s_nfr[tid] = n;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int mx = 0;
+    for (int r = 0; r < 16; r++) mx = max(mx, s_nfr[r]);
+    s_maxn = mx;
+  }
+  __syncthreads();
+  {
+    const int c = tid % MD, r0 = 8 * (tid / MD);
+    float m[8], z[8], a[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) { m[r] = -INFINITY; z[r] = 0.f; a[r] = 0.f; }
+    const int maxn = s_maxn;
+    for (int k0 = 0; k0 < maxn; k0 += SAGG_FIN_K) {
+      float mf[SAGG_FIN_K][8], zf[SAGG_FIN_K][8], af[SAGG_FIN_K][8];
+#pragma unroll
+      for (int u = 0; u < SAGG_FIN_K; u++)
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+          const bool on = k0 + u < s_nfr[r0 + r];
+          const float *f = frag + ((size_t)(on ? s_first[r0 + r] + k0 + u : s_first[r0])) * (3 * MD) + c;
+          mf[u][r] = f[0]; zf[u][r] = f[MD]; af[u][r] = f[2 * MD];
+        }
+#pragma unroll
+      for (int u = 0; u < SAGG_FIN_K; u++)
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+          if (k0 + u >= s_nfr[r0 + r]) continue;
+          const float n = fmaxf(m[r], mf[u][r]);
+          const float sc = __builtin_amdgcn_exp2f(m[r] - n), tc = __builtin_amdgcn_exp2f(mf[u][r] - n);   // (maxima in units of log2)
+          z[r] = z[r] * sc + zf[u][r] * tc; a[r] = a[r] * sc + af[u][r] * tc;
+          m[r] = n;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++) Xs[(r0 + r) * MXS + c] = (_Float16)(s_nfr[r0 + r] > 0 ? a[r] / z[r] : 0.f);
+  }
+  __syncthreads();
+  if (!mm) return;
+  f4 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; nt++) acc[nt] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < MKS; ks++) {
+    if (ks + PF < MKS) {
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) ring[(ks + PF) % (PF + 1)][nt] = wfrag(ks + PF, nt);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const h8 a = *reinterpret_cast<const h8 *>(Xs + j * MXS + ks * 32 + 8 * q);
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++)
+      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[ks % (PF + 1)][nt], a, acc[nt], 0, 0, 0);
+  }
+  if (row0 + j >= rows) return;
+  _Float16 *o = y + (size_t)(row0 + j) * MD + wave * (16 * NT) + 4 * q;
+  const bool live = row0 + j < R;
+#pragma unroll
+  for (int nt = 0; nt < NT; nt++) {
+    const f4 b = *reinterpret_cast<const f4 *>(bias + wave * (16 * NT) + nt * 16 + 4 * q);
+    *reinterpret_cast<h4 *>(o + nt * 16) = live ? (h4){(_Float16)(acc[nt][0] + b[0]), (_Float16)(acc[nt][1] + b[1]),
+                                                       (_Float16)(acc[nt][2] + b[2]), (_Float16)(acc[nt][3] + b[3])}
+                                                : (h4){0, 0, 0, 0};
+  }
+}
+
 // ------------------------------------------------------------------ plain Linear on a small table
 // y[r] = fp16(x[r] W^T + b), r < rows: SoftAgg's `h` layer on the group table (ramp/blocks.py:46-47; a few hundred to a
 // few thousand rows).  16 rows per workgroup, 8 waves x 48 columns, operands exchanged so that a lane holds four
@@ -1598,6 +1881,46 @@ int ramp_upd_linear(const void *x, const void *w_packed, const float *bias, void
   if (!x || !w_packed || !bias || !y) return RAMP_EINVAL;
   hipLaunchKernelGGL(upd_linear_kernel, dim3(ramp_cdiv(rows, 16)), dim3(512), 0, (hipStream_t)stream,
                      (const _Float16 *)x, (const _Float16 *)w_packed, bias, (_Float16 *)y, rows, rows_dev);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+
+
+size_t ramp_upd_softagg_frag_rows(int E, int max_groups) {
+  return (size_t)(max_groups > 0 ? max_groups : 0) + (size_t)((E > 0 ? E : 0) + SAGG_BLK - 1) / SAGG_BLK + 1;
+}
+
+int ramp_i_upd_softagg(const float *x32, const void *add_t, const int32_t *add_idx, const int32_t *order, const int32_t *gid,
+                       const void *wf, const float *bf, const void *wg, const float *bg, float *frag, int E,
+                       const int32_t *dyn, void *stream) {
+  if (E < 0) return RAMP_EINVAL;
+  if (E == 0) return RAMP_OK;
+  if (!x32 || !order || !gid || !wf || !bf || !wg || !bg || !frag || (add_t && !add_idx)) return RAMP_EINVAL;
+  SoftAggParams p;
+  p.x32 = x32; p.add_t = (const _Float16 *)add_t; p.add_idx = add_idx; p.order = order; p.gid = gid;
+  p.wf = (const _Float16 *)wf; p.wg = (const _Float16 *)wg; p.bf = bf; p.bg = bg; p.frag = frag; p.E = E; p.dyn = dyn;
+  const size_t lds = (size_t)SAGG_ROWS * MXS * 2 + SAGG_ROWS * sizeof(int);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void *)upd_softagg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return RAMP_ELAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(upd_softagg_kernel, dim3(ramp_cdiv(E, SAGG_ROWS)), dim3(512), lds, (hipStream_t)stream, p);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+int ramp_upd_softagg(const float *x32, const void *add_t, const int32_t *add_idx, const int32_t *order, const int32_t *gid,
+                     const void *wf, const float *bf, const void *wg, const float *bg, float *frag, int E, void *stream) {
+  return ramp_i_upd_softagg(x32, add_t, add_idx, order, gid, wf, bf, wg, bg, frag, E, nullptr, stream);
+}
+int ramp_upd_softagg_finish(const float *frag, const int32_t *seg_start, const int32_t *ngroups, const void *wh,
+                            const float *bh, void *hy, int max_groups, void *stream) {
+  if (max_groups < 0) return RAMP_EINVAL;
+  if (max_groups == 0) return RAMP_OK;
+  if (!frag || !seg_start || !ngroups || !wh || !bh || !hy) return RAMP_EINVAL;
+  hipLaunchKernelGGL(upd_softagg_finish_kernel, dim3(ramp_cdiv(max_groups, 16)), dim3(SAGG_FIN_T), 0, (hipStream_t)stream, frag,
+                     seg_start, ngroups, (const _Float16 *)wh, bh, (_Float16 *)hy, max_groups);
   RAMP_CHECK_LAUNCH();
   return RAMP_OK;
 }

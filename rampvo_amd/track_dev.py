@@ -52,7 +52,7 @@ class Track(ctypes.Structure):
                                "kk_ukeys", "ij_ukeys", "ix", "jx", "kj", "plan_ws"])
                 + [("plan_ws_bytes", c_sz), ("w", TrackWeights)]
                 + _ptr_fields(["coords", "corr"]) + [("net", c_p * 3)]
-                + _ptr_fields(["fg", "ykk", "hkk", "yij", "hij", "relu_t", "target", "weight", "ba_ws"])
+                + _ptr_fields(["fg", "ykk", "hkk", "yij", "hij", "relu_t", "sagg_frag", "target", "weight", "ba_ws"])
                 + [("ba_ws_bytes", c_sz)]
                 + _ptr_fields(["mm", "median", "dlog", "edit_ws", "dyn_host", "dyn_host_dev"]) + [("probe", c_p * 5), ("E_hint", c_i),
                    ("gate_seq", ctypes.c_uint32), ("gate_flag", c_p)])
@@ -130,6 +130,8 @@ class DeviceTrack:
         self.ykk, self.hkk = z((kk_cap, 384), f16), z((kk_cap, 384), f16)
         self.yij, self.hij = z((ij_cap, 384), f16), z((ij_cap, 384), f16)
         self.relu_t = e((E_cap, 384), f16)
+        # fragment table of the fused SoftAgg (csrc/update_mlp.hip::upd_softagg_kernel): (m, z, a)[384] per run
+        self.sagg_frag = e((lib.ramp_upd_softagg_frag_rows(E_cap, max(kk_cap, ij_cap)), 3, 384), f32)
         self.target, self.weight = z((E_cap, 2), f32), z((E_cap, 2), f32)
         self.ba_ws = e(lib.ramp_track_ba_workspace_bytes(E_cap, slam.N, M, cfg.OPTIMIZATION_WINDOW, kk_cap, ij_cap),
                        torch.uint8)
@@ -165,7 +167,7 @@ class DeviceTrack:
                               ij_gid=self.ij["gid"], ij_seg=self.ij["seg"], ij_ngroups=self.ij["ngroups"],
                               ij_ukeys=self.ij["ukeys"], ix=self.ix, jx=self.jx, kj=self.kj, plan_ws=self.plan_ws,
                               coords=self.coords, corr=self.corr, fg=self.fg, ykk=self.ykk, hkk=self.hkk, yij=self.yij,
-                              hij=self.hij, relu_t=self.relu_t, target=self.target, weight=self.weight,
+                              hij=self.hij, relu_t=self.relu_t, sagg_frag=self.sagg_frag, target=self.target, weight=self.weight,
                               ba_ws=self.ba_ws, mm=self.mm, dlog=self.dlog, edit_ws=self.edit_ws,
                               dyn_host=self.dyn_host).items():
             setattr(t, name, P(ten))

@@ -40,6 +40,7 @@ class FusedUpdate:
         self.use_mlp = os.environ.get("RAMP_UPD_MLP", "1") == "1"    # fused GEMM-chain kernels (fp16 only)
         self.use_corr_mlp = os.environ.get("RAMP_CORR_MLP", "1") == "1"
         self.use_nbr2 = os.environ.get("RAMP_NBR2", "0") == "1"      # c1 + c2 as one launch (A/B switch; measured slower)
+        self.use_softagg = os.environ.get("RAMP_SOFTAGG", "1") == "1"   # SoftAgg without the [f | g] rows (csrc/update_mlp.hip)
         self.before_gru = None                   # optional callable run right before a stage is enqueued
         self.hook_at = "gru"
 
@@ -156,6 +157,20 @@ class FusedUpdate:
               "ramp_upd_segment_softmax")
         return y
 
+    def softagg(self, net32, add_t, add_idx, fg_pack, h_pack, groups, max_groups, E):
+        """h(segment softmax-sum of f(x), g(x)) for x = net32 (+ add_t[add_idx]) without the [E, 768] rows:
+        csrc/update_mlp.hip::upd_softagg_kernel + upd_softagg_finish_kernel (the device-resident step runs the same two)"""
+        G = max(int(max_groups), 1)
+        rows = lib().ramp_upd_softagg_frag_rows(E, G)
+        frag = torch.empty(rows, 3, 384, dtype=torch.float32, device=net32.device)
+        wf, bf, wg, bg = fg_pack
+        check(lib().ramp_upd_softagg(ptr(net32), ptr(add_t), ptr(add_idx), ptr(groups.order), ptr(groups.gid), ptr(wf), ptr(bf),
+                                     ptr(wg), ptr(bg), ptr(frag), E, stream()), "ramp_upd_softagg")
+        hy = torch.empty(G, 384, dtype=self.dtype, device=net32.device)
+        check(lib().ramp_upd_softagg_finish(ptr(frag), ptr(groups.seg_start), ptr(groups.ngroups), ptr(h_pack[0]),
+                                            ptr(h_pack[1]), ptr(hy), G, stream()), "ramp_upd_softagg_finish")
+        return hy
+
     def h_lin(self, y, pack, groups):
         """SoftAgg's `h` Linear on the group table, rows below the device-side group count only
         (csrc/update_mlp.hip::upd_linear_kernel; the device-resident step runs the same kernel)"""
@@ -236,7 +251,13 @@ class FusedUpdate:
         # SoftAgg over patches, then over (i, j) pairs (net.py:84-85)
         if self.before_gru is not None and self.hook_at == "softagg":
             self.before_gru()
-        if net_t is None:
+        if net_t is None and self.use_softagg and E > 0:
+            hy0 = self.softagg(net32, None, None, w["kk_fg_pack"], w["kk_h_pack"], plan.g_kk, plan.max_kk, E)
+            # (the device-resident step adds hy0[.] inside the next two launches instead of writing the sum back: the
+            # same fp32 additions in the same order)
+            self.row_fuse(E, A=net32, B=hy0, idxB32=plan.g_kk.gid, out_f32=net32)
+            hy = self.softagg(net32, None, None, w["ij_fg_pack"], w["ij_h_pack"], plan.g_ij, plan.max_ij, E)
+        elif net_t is None:
             # fused path: the [f | g] GEMM forms its own fp16 input tile from the fp32 state (and applies the
             # previous SoftAgg's expand-and-add on the way): no fp16 state copy, no separate row pass
             hy = self.h_lin(self.seg(self.fg(net32, None, None, w["kk_fg_pack"], E), plan.g_kk, plan.max_kk),

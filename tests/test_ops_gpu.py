@@ -579,6 +579,65 @@ def test_fused_gru_chain_matches_gemm_path():
 FUSED_CHAIN_TOL = 3e-3      # x the output scale; measured worst case is recorded by the test's print
 
 
+@pytest.mark.parametrize("E,mode", [(1003, "small"), (20011, "small"), (41003, "small"), (41003, "pairs"), (5000, "ones")])
+@torch.no_grad()
+def test_softagg_fused_against_fp32_torch(E, mode):
+    """SoftAgg without the [f | g] rows (csrc/update_mlp.hip::upd_softagg_kernel + upd_softagg_finish_kernel) against a
+    plain fp32 PyTorch evaluation of ramp/blocks.py:42-47 on the fp16-rounded operands (f, g, y and h(y) are half tensors
+    under the reference's autocast), and against the three-launch path it replaces.  Groupings: `small` = patch-like groups
+    of 1..40 factors scattered over the list (runs cross lane blocks and tiles), `pairs` = 96 factors per group (a group =
+    one and a fifth tiles), `ones` = every factor its own group."""
+    import torch.nn.functional as F
+    from rampvo_amd import ops
+    from rampvo_amd._lib import check, lib, ptr, stream
+    from rampvo_amd.synthetic import make_network
+    net = make_network("SingleScale")
+    fu = net.update.fused(torch.float16)
+    w = fu.weights()
+    agg = make_network("SingleScale").update.float().agg_kk
+    for lin in (agg.f, agg.g, agg.h):
+        lin.weight.copy_(lin.weight.half().float()); lin.bias.copy_(lin.bias.half().float())
+    g = torch.Generator().manual_seed(E)
+    if mode == "small":
+        sizes = torch.randint(1, 41, (E,), generator=g)
+        keys = torch.repeat_interleave(torch.arange(E), sizes)[:E]
+    elif mode == "pairs":
+        keys = torch.arange(E) // 96
+    else:
+        keys = torch.arange(E)
+    keys = keys[torch.randperm(E, generator=g)].cuda()
+    x32 = (torch.randn(E, 384, generator=g) * 0.7).cuda()
+    if mode == "small":
+        # a few groups whose g lies ~100 below their neighbours' in every column: the block-wide shift of the fast sweep
+        # underflows there and the exact sweep takes over (rows scaled so that g = W x + b moves by O(100))
+        x32[keys < 3] *= 60.0
+    G0 = 57
+    hy0 = (torch.randn(G0, 384, generator=g) * 0.5).half().cuda()
+    gid0 = torch.randint(0, G0, (E,), generator=g).int().cuda()
+    grp = ops.group_by(keys)
+    G = int(grp.ngroups.item())
+    for add in (False, True):
+        xe = x32 + hy0.float()[gid0.long()] if add else x32
+        xh = xe.half().float()
+        fh, gh = agg.f(xh).half().float(), agg.g(xh).half().float()
+        inv = grp.gid[:E].long()
+        m = torch.full((G, 384), -float("inf"), device="cuda").scatter_reduce(0, inv[:, None].expand(-1, 384), gh, "amax")
+        e = torch.exp(gh - m[inv])
+        z = torch.zeros(G, 384, device="cuda").index_add_(0, inv, e)
+        y = (torch.zeros(G, 384, device="cuda").index_add_(0, inv, fh * e) / z).half().float()
+        exp = agg.h(y).half().float()
+        got = fu.softagg(x32, hy0 if add else None, gid0 if add else None, w["kk_fg_pack"], w["kk_h_pack"], grp, G + 5, E)
+        assert got.shape == (G + 5, 384) and float(got[G:].abs().max()) == 0.0
+        scale = float(exp.abs().max())
+        err = float((got[:G].float() - exp).abs().max()) / scale
+        old = fu.h_lin(fu.seg(fu.fg(x32.clone(), hy0 if add else None, gid0 if add else None, w["kk_fg_pack"], E), grp, G + 5),
+                       w["kk_h_pack"], grp)
+        err_old = float((old[:G].float() - exp).abs().max()) / scale
+        print(E, mode, add, "softagg vs fp32 torch %.2e (three-launch path: %.2e)" % (err, err_old))
+        assert err <= FUSED_CHAIN_TOL, (E, mode, add, err)
+
+
+
 @pytest.mark.parametrize("E", [1003, 5408, 20011, 41003])
 @torch.no_grad()
 def test_fused_update_chains_against_fp32_torch(E):

@@ -180,9 +180,9 @@ MIXED_DEPTHS_P999 = 1e-1       # the 99.9th percentile (p99.5 alone l
 
 # the HIP fp16 leg against the CPU oracle WITH the same precision policy (kernel error only): <= 4x the values measured on
 # MI355X at configs[1] (printed by the test: net 2.8e-4 -- single fp16 roundings that fall the other way under a different
-# fp32 summation order --, weight 6e-8, poses 1.3e-4 of the GN step, depths p99.9 2.3e-3, worst patch 6.9e-3; the same
+# fp32 summation order --, weight 6e-8, poses 1.3e-4 .. 8e-4 of the GN step over builds (which roundings flip), depths p99.9 2.3e-3, worst patch 6.9e-3; the same
 # leg against the fp32 oracle: 3.6e-3 of the step, 1.3e-2, 3.7e-2 -- i.e. the fp16 path's error is its precision policy)
-POLICY_NET, POLICY_WEIGHT, POLICY_POSES, POLICY_DEPTHS_P999, POLICY_DEPTHS_MAX = 1.2e-3, 1e-6, 5e-4, 1e-2, 3e-2
+POLICY_NET, POLICY_WEIGHT, POLICY_POSES, POLICY_DEPTHS_P999, POLICY_DEPTHS_MAX = 1.2e-3, 1e-6, 2e-3, 1e-2, 3e-2
 
 
 def _assert_policy_leg(m):
@@ -445,6 +445,51 @@ def test_device_resident_steps_with_an_optimisation_window_that_never_fills():
 
 
 @torch.no_grad()
+def test_predict_future_pose_against_upstreams_own_method():
+    """SURVEY 8f N4 end to end: tests/golden/pose_pred_e2e.npz is upstream's Ramp_vo.predict_future_pose run as it is
+    (oracle/make_golden.py::gen_pose_pred_e2e, evaluate.py:205-224's call sequence: track, 12 updates, virtual keyframes
+    0 / 1 / 2 frames ahead) -- including BA's target being the first E rows of the [1,E,2,3,3] grid tensor viewed as
+    [-1,2] (fastba/ba_cuda.cu:462) and the exchanged x / y of the predicted grids (pose_pred_utils.py:342).  The default
+    mode here reproduces it; ``corrected=True`` is the fixed behaviour (printed: how far the two are apart)."""
+    import os
+    from rampvo_amd.config import make_cfg
+    from rampvo_amd.Ramp_vo import Ramp_vo
+    from rampvo_amd.synthetic import SyntheticStream, make_network
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pose_pred_e2e.npz"))
+    H, W, T, M, seed = 128, 160, 20, 8, 1234                       # oracle/make_golden.py::RAMPVO
+    out = {}
+    for corrected in (False, True):
+        slam = Ramp_vo(make_cfg("default", PATCHES_PER_FRAME=M, MIXED_PRECISION=False),
+                       make_network("SingleScale", profile="damped"), {"event_bias": True}, ht=H, wd=W)
+        frame_no = [0]
+        slam._initial_depth = lambda patches: pc.depth_draw(frame_no[0], patches.shape[1]).to(patches.device)
+        stream = SyntheticStream(H, W, T, seed=seed)
+        for t in range(T):
+            im, ev, K, mask = stream.frame(t)
+            frame_no[0] = t
+            slam(t, input_tensor=(ev.cuda(), im.cuda(), mask), intrinsics=K)
+        last = slam.n
+        assert last == int(g["last"])
+        for _ in range(12):
+            slam.update()
+        assert float(np.abs(slam.poses_[:last].cpu().numpy() - g["poses_before"]).max()) <= 1e-4
+        pred = []
+        for step in range(3):
+            slam.predict_future_pose(last_keyframe_number=last, sec_to_pred_future=step, abs_time=T + step, deg=3,
+                                     corrected=corrected)
+            pred.append(slam.poses_[slam.n - 1].cpu().numpy().copy())
+            assert slam.n == int(g["n"][step]) and slam.counter == int(g["counter"][step])
+        traj, ts = slam.terminate()
+        out[corrected] = (np.stack(pred), traj)
+    e_pose = float(np.abs(out[False][0] - g["pred_pose"]).max())
+    e_traj = float(np.abs(out[False][1] - g["traj"]).max())
+    apart = float(np.abs(out[True][0] - g["pred_pose"]).max())
+    print("predict_future_pose vs upstream's own: predicted poses %.2e, trajectory %.2e (corrected mode is %.2e away)"
+          % (e_pose, e_traj, apart))
+    assert e_pose <= 1e-4 and e_traj <= 1e-4
+
+
+@torch.no_grad()
 def test_pose_prediction_mode():
     """Ramp_vo.predict_future_pose driven like evaluate.py::run_pose_pred (reference :185-229): track, 12 updates
     at the hand-over, then virtual keyframes 0, 1, 2 frames ahead.  The predicted factors carry weights of 1e-9
@@ -469,7 +514,7 @@ def test_pose_prediction_mode():
     for step in range(3):
         boot = motion_bootstrap(n=slam.n, poses=slam.poses_, MOTION_MODEL=slam.cfg.MOTION_MODEL,
                                 MOTION_DAMPING=slam.cfg.MOTION_DAMPING).clone()
-        slam.predict_future_pose(sec_to_pred_future=step, abs_time=T + step, last_keyframe_number=last, deg=3)
+        slam.predict_future_pose(sec_to_pred_future=step, abs_time=T + step, last_keyframe_number=last, deg=3, corrected=True)
         assert slam.n == last + step + 1 and slam.counter == counter + step + 1
         got = slam.poses_[slam.n - 1]
         assert torch.isfinite(got).all()
@@ -479,7 +524,7 @@ def test_pose_prediction_mode():
     traj, ts = slam.terminate()
     assert traj.shape == (counter + 3, 7) and np.isfinite(traj).all() and ts[-1] == T + 2
     for _ in range(3):
-        slam.remove_attributes()
+        slam.remove_attributes(corrected=True)
     assert slam.n == last and slam.counter == counter and float(slam.poses_[last, 6]) == 1.0
 
 
