@@ -486,7 +486,7 @@ def test_predict_future_pose_against_upstreams_own_method():
     apart = float(np.abs(out[True][0] - g["pred_pose"]).max())
     print("predict_future_pose vs upstream's own: predicted poses %.2e, trajectory %.2e (corrected mode is %.2e away)"
           % (e_pose, e_traj, apart))
-    assert e_pose <= 1e-4 and e_traj <= 1e-4
+    assert e_pose <= 2e-6 and e_traj <= 2e-6          # (measured 3e-9; the corrected mode sits 5e-5 away on this fixture)
 
 
 @torch.no_grad()
