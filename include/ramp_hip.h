@@ -355,6 +355,13 @@ int ramp_ms_lstm_superstate(const float *ev, const float *im, const float *const
                             float *state, int H, int W, int scale, int has_state, int use_im,
                             void *stream);
 
+/* The same step with every matrix-vector product batched over 16 pixels on v_mfma_f32_16x16x4_f32 (exact fp32 products; the
+ * summation order differs from the VALU kernel's): wfrag = per-lane A fragments [nfrag][64], wsmall = conv_1 weights /
+ * biases and the gate / mix biases (both packed by rampvo_amd/conv_hip.py::pack_ms_scale_mfma; layouts in csrc/conv.hip).
+ * state16: optional [Hs*Ws][D] fp16 copy of the new super-state (the conv towers' second / third input).           */
+int ramp_ms_lstm_superstate_mfma(const float *ev, const float *im, const float *wfrag, const float *wsmall, float *state,
+                                 void *state16, int H, int W, int scale, int has_state, int use_im, void *stream);
+
 /* nn.Conv2d (+ fused neighbours) of the encoder towers as an implicit GEMM on MFMA
  * (ramp/extractor.py:8-57, 60-130; reference: cuDNN).  NHWC activations, padding = K/2.
  *   x [H][W][Cin] (Cin % 16 == 0), y [OH][OW][Cout] (Cout % 32 == 0)

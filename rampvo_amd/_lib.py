@@ -38,6 +38,7 @@ SIGNATURES = {
     "ramp_frame_gather": (c_i, [c_p] * 9 + [c_i] * 8 + [c_p]),
     "ramp_corr_fwd": (c_i, [c_p, ctypes.POINTER(CorrLevel), c_i, c_p, c_p, c_p, c_p] + [c_i] * 8 + [c_p]),
     "ramp_ms_lstm_superstate": (c_i, [c_p, c_p, ctypes.POINTER(c_p), c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "ramp_ms_lstm_superstate_mfma": (c_i, [c_p] * 6 + [c_i] * 5 + [c_p]),
     "ramp_conv2d_stats_blocks": (c_i, [c_i] * 7),
     "ramp_graph_edit_host": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
     "ramp_event_stack_workspace_bytes": (c_sz, [c_i, c_i, c_i]),

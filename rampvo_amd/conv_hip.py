@@ -497,12 +497,13 @@ def lstm_superstate_step(enc, ev, im, st, arena_for_towers=False):
 # ----------------------------------------------------------- MultiScale front end
 class MsState:
     """super-state of one scale: [Hs*Ws, D] channels-last rows"""
-    __slots__ = ("s", "fresh", "Hs", "Ws", "D")
+    __slots__ = ("s", "s16", "fresh", "Hs", "Ws", "D")
 
     def __init__(self, H, W, scale, device):
         k, pad = (scale + 1, 1) if scale > 1 else (1, 0)
         self.Hs, self.Ws, self.D = (H + 2 * pad - k) // scale + 1, (W + 2 * pad - k) // scale + 1, 16 * scale
         self.s = torch.zeros(self.Hs * self.Ws, self.D, dtype=torch.float32, device=device)
+        self.s16 = None              # fp16 copy of the state for the fp16 towers (written by the MFMA kernel)
         self.fresh = True
 
 
@@ -530,11 +531,73 @@ def pack_ms_scale(enc, k):
     return arrs, ptrs
 
 
-def ms_lstm_superstate_step(enc, k, ev, im, st, use_im):
+def pack_ms_scale_mfma(enc, k):
+    """(wfrag [nfrag, 64], wsmall) of ramp_ms_lstm_superstate_mfma for scale index k: the A operand of every
+    v_mfma_f32_16x16x4_f32 as one float per lane (lane l: row i = l & 15, K column kq = l >> 4), in the order the kernel
+    walks them (csrc/conv.hip::ms_lstm_superstate_mfma_kernel: gates ev [t][i,g,o][2 K steps], gates im [t][i,g,o], mix ev
+    [n][K step], mix im), and the small arrays (conv_1 weights / biases, gate biases [i,g,o][D] x 2, mix biases x 2)."""
+    ev, im = enc.ev_encoders[k], enc.im_encoders[k]
+    me, mi = enc.super_state_ev_encoder[k].encoder, enc.super_state_im_encoders[k].encoder
+    params = [ev.conv_1.weight, ev.conv_1.bias, im.conv_1.weight, im.conv_1.bias,
+              ev.convlstm.weight_ih_l0, ev.convlstm.bias_ih_l0, ev.convlstm.bias_hh_l0,
+              im.convlstm.weight_ih_l0, im.convlstm.bias_ih_l0, im.convlstm.bias_hh_l0,
+              me.weight, me.bias, mi.weight, mi.bias]
+    key = tuple((q.data_ptr(), q._version) for q in params)
+    hit = _cache(enc).get(("ms_mfma", k))
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    dev = me.weight.device
+    f = lambda t: t.detach().float().cpu()
+    D = me.out_channels
+    NG = D // 16
+    lane = torch.arange(64)
+    i, kq = lane & 15, lane >> 4
+    gates = (0, 2, 3)                                        # i, g, o rows of torch's (i, f, g, o) order
+    frags = []
+    for lstm, C, steps in ((ev.convlstm, 5, 2), (im.convlstm, 3, 1)):
+        Wih = f(lstm.weight_ih_l0)                           # [4D, C]
+        Wp = torch.zeros(4 * D, 4 * steps)
+        Wp[:, :C] = Wih
+        for t in range(NG):
+            for g in gates:
+                for ks in range(steps):
+                    frags.append(Wp[g * D + 16 * t + i, 4 * ks + kq])
+    for mix in (me, mi):
+        Wm = f(mix.weight).view(D, 2 * D)
+        for n in range(NG):
+            for half in range(2):
+                for t in range(NG):
+                    for r in range(4):
+                        frags.append(Wm[16 * n + i, half * D + 16 * t + 4 * kq + r])
+    wfrag = torch.stack(frags, 0).contiguous().to(dev)
+    gb = lambda lstm: (f(lstm.bias_ih_l0) + f(lstm.bias_hh_l0)).view(4, D)[list(gates)].reshape(-1)
+    wsmall = torch.cat([f(ev.conv_1.weight).reshape(-1), f(ev.conv_1.bias), f(im.conv_1.weight).reshape(-1),
+                        f(im.conv_1.bias), gb(ev.convlstm), gb(im.convlstm), f(me.bias), f(mi.bias)]).contiguous().to(dev)
+    assert wfrag.shape[0] == NG * 9 + 16 * NG * NG
+    _cache(enc)[("ms_mfma", k)] = (key, (wfrag, wsmall))
+    return wfrag, wsmall
+
+
+_MS_MFMA = os.environ.get("RAMP_MS_MFMA", "1") == "1"       # A/B switch: 0 = the fp32 VALU kernel
+
+
+def ms_lstm_superstate_step(enc, k, ev, im, st, use_im, want_half=False):
     """ev [5,H,W], im [3,H,W] contiguous fp32; advances scale k's super-state in place and returns
-    it as an NHWC tensor [Hs, Ws, D] (a view of st.s)"""
-    _, ptrs = pack_ms_scale(enc, k)
+    it as an NHWC tensor [Hs, Ws, D] (a view of st.s; with want_half the kernel's fp16 copy of it)"""
     H, W = ev.shape[-2:]
+    if _MS_MFMA:
+        wfrag, wsmall = pack_ms_scale_mfma(enc, k)
+        s16 = None
+        if want_half:
+            if st.s16 is None:
+                st.s16 = torch.empty(st.Hs * st.Ws, st.D, dtype=torch.float16, device=st.s.device)
+            s16 = st.s16
+        check(lib().ramp_ms_lstm_superstate_mfma(ptr(ev), ptr(im), ptr(wfrag), ptr(wsmall), ptr(st.s), ptr(s16), H, W,
+                                                 enc.scales[k], 0 if st.fresh else 1, int(bool(use_im)), stream()),
+              "ramp_ms_lstm_superstate_mfma")
+        st.fresh = False
+        return (s16 if want_half else st.s).view(st.Hs, st.Ws, st.D)
+    _, ptrs = pack_ms_scale(enc, k)
     check(lib().ramp_ms_lstm_superstate(ptr(ev), ptr(im), ptrs, ptr(st.s), H, W, enc.scales[k],
                                         0 if st.fresh else 1, int(bool(use_im)), stream()),
           "ramp_ms_lstm_superstate")

@@ -1170,6 +1170,175 @@ __global__ void __launch_bounds__(256) ms_lstm_superstate_kernel(const MsLstmPar
   }
 }
 
+
+// ------------------------------------------------- MultiScale LSTM / super-state on MFMA
+// The same step (conv_1 -> zero-state LSTM -> two super-state mixes, per scale) with every matrix-vector product batched
+// over 16 pixels on v_mfma_f32_16x16x4_f32 (exact fp32 products), the recipe of lstm_superstate_mfma_kernel generalised to
+// D = 16, 32, 64 hidden units:
+//   * a wave owns 16-pixel tiles of the scale's grid; lane (q, j) computes conv_1's output channel q of pixel j (events
+//     and image; the events' fifth channel comes from the q = 3 lanes over one shuffle) -- which is the B operand of the
+//     gate products' K steps as it stands;
+//   * gates: one 16-row tile per (16 units, gate) -- i, g, o; the forget gate never acts on a zero state -- so lane (q, j)
+//     holds (i, g, o) of units 16 t + 4 q + r, r = 0..3, in matching accumulator registers: the cell is lane-local and
+//     h[t][r] is, unchanged, the B operand of K step (t, r) of the mix (its K order is channel 16 t + 4 q + r);
+//   * the super-state is read as 16-byte pieces (channels 16 t + 4 q .. + 3 of pixel j) -- the same layout again -- and
+//     the first mix's accumulators feed the second mix as they are; stores are 16-byte pieces, plus an fp16 copy of the
+//     new state for the conv towers (scales 2, 4: what torch.cat((x, x_down2.half())) used to produce);
+//   * the A fragments (one float per lane and MFMA) sit in LDS, packed per lane by conv_hip.pack_ms_scale_mfma.
+// fp32 VALU version above: 53 / 61 / 50 us per scale at 640x480 (transcendental-bound at scale 1, LDS-bound mixes at 4).
+struct MsMfmaParams {
+  const float *ev, *im;                 // [5][H][W], [3][H][W]
+  const float *wfrag;                   // per-lane A fragments [nfrag][64] (see MS_* below)
+  const float *wsmall;                  // conv_1 ev W [5][5][K][K], b [5], conv_1 im W [3][3][K][K], b [3], gate biases ev
+                                        // [3][D] (i, g, o), im [3][D], mix biases ev [D], im [D]
+  float *state;                         // [Hs*Ws][D] fp32 super-state, in/out
+  _Float16 *state16;                    // optional [Hs*Ws][D] fp16 copy of the new state
+  int H, W, Hs, Ws, has_state, use_im, tiles_per_wave;
+};
+template <int D, int S>
+__global__ void __launch_bounds__(256) ms_lstm_superstate_mfma_kernel(const MsMfmaParams p) {
+  constexpr int NG = D / 16;                           // 16-unit groups
+  constexpr int K = S > 1 ? S + 1 : 1, PAD = S > 1 ? 1 : 0, KK = K * K;
+  constexpr int F_GE = 0, F_GI = F_GE + NG * 3 * 2, F_ME = F_GI + NG * 3, F_MI = F_ME + 8 * NG * NG, F_N = F_MI + 8 * NG * NG;
+  constexpr int O_WCE = 0, O_BCE = O_WCE + 25 * KK, O_WCI = O_BCE + 5, O_BCI = O_WCI + 9 * KK, O_BGE = O_BCI + 3,
+                O_BGI = O_BGE + 3 * D, O_BME = O_BGI + 3 * D, O_BMI = O_BME + D, O_N = O_BMI + D;
+  extern __shared__ __attribute__((aligned(16))) float ms_smem[];
+  float *s_wf = ms_smem, *s_sm = ms_smem + F_N * 64;
+  for (int i = threadIdx.x; i < F_N * 16; i += 256)
+    reinterpret_cast<float4 *>(s_wf)[i] = reinterpret_cast<const float4 *>(p.wfrag)[i];
+  for (int i = threadIdx.x; i < O_N; i += 256) s_sm[i] = p.wsmall[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
+  const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int HWs = p.Hs * p.Ws, ntile = (HWs + 15) / 16;
+  for (int it = 0; it < p.tiles_per_wave; it++) {
+    const int tile = gw * p.tiles_per_wave + it;
+    if (tile >= ntile) break;                          // (wave-uniform)
+    const int pix = tile * 16 + j;
+    const bool pv = pix < HWs;
+    const int pc = pv ? pix : HWs - 1;
+    const int oy = pc / p.Ws, ox = pc - oy * p.Ws;
+    // the old super-state (all loads of the tile go out first)
+    f32x4 sreg[NG];
+    const float *sp = p.state + (size_t)pc * D + 4 * q;
+#pragma unroll
+    for (int t = 0; t < NG; t++)
+      sreg[t] = p.has_state ? *reinterpret_cast<const f32x4 *>(sp + 16 * t) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    // conv_1: lane (q, j) -> events channel q, image channel q (q < 3) or events channel 4 (q == 3)
+    const int c2 = q < 3 ? q : 4;                      // second output: image channel q, or events channel 4
+    float y0 = s_sm[O_BCE + q], y1 = q < 3 ? s_sm[O_BCI + q] : s_sm[O_BCE + 4];
+    {
+      const float *w0 = s_sm + O_WCE + q * 5 * KK;
+      const float *w1 = q < 3 ? s_sm + O_WCI + q * 3 * KK : s_sm + O_WCE + 4 * 5 * KK;
+#pragma unroll
+      for (int ky = 0; ky < K; ky++) {
+        const int iy = oy * S - PAD + ky;
+        if (iy < 0 || iy >= p.H) continue;
+#pragma unroll
+        for (int kx = 0; kx < K; kx++) {
+          const int ix = ox * S - PAD + kx;
+          if (ix < 0 || ix >= p.W) continue;
+          const size_t o = (size_t)iy * p.W + ix;
+          float xe[5], xi[3];
+#pragma unroll
+          for (int ci = 0; ci < 5; ci++) xe[ci] = p.ev[(size_t)ci * p.H * p.W + o];
+#pragma unroll
+          for (int ci = 0; ci < 3; ci++) xi[ci] = p.im[(size_t)ci * p.H * p.W + o];
+#pragma unroll
+          for (int ci = 0; ci < 5; ci++) y0 = __builtin_fmaf(w0[(ci * K + ky) * K + kx], xe[ci], y0);
+          if (q < 3) {
+#pragma unroll
+            for (int ci = 0; ci < 3; ci++) y1 = __builtin_fmaf(w1[(ci * K + ky) * K + kx], xi[ci], y1);
+          } else {
+#pragma unroll
+            for (int ci = 0; ci < 5; ci++) y1 = __builtin_fmaf(w1[(ci * K + ky) * K + kx], xe[ci], y1);
+          }
+        }
+      }
+    }
+    (void)c2;
+    const float e4 = __shfl(y1, 48 + j, 64);           // events channel 4 of pixel j (computed by lane (3, j))
+    const float be0 = y0, be1 = q == 0 ? e4 : 0.f, bi0 = q < 3 ? y1 : 0.f;
+    // LSTM step from the zero state: h = sigmoid(o) tanh(sigmoid(i) tanh(g)), both modalities
+    float hn[2][NG][4];
+#pragma unroll
+    for (int mod = 0; mod < 2; mod++) {
+#pragma unroll
+      for (int t = 0; t < NG; t++) {
+        f32x4 g3[3];
+#pragma unroll
+        for (int gi = 0; gi < 3; gi++) {
+          g3[gi] = *reinterpret_cast<const f32x4 *>(s_sm + (mod == 0 ? O_BGE : O_BGI) + gi * D + 16 * t + 4 * q);
+          if (mod == 0) {
+            g3[gi] = __builtin_amdgcn_mfma_f32_16x16x4f32(s_wf[(F_GE + (t * 3 + gi) * 2 + 0) * 64 + lane], be0, g3[gi], 0, 0, 0);
+            g3[gi] = __builtin_amdgcn_mfma_f32_16x16x4f32(s_wf[(F_GE + (t * 3 + gi) * 2 + 1) * 64 + lane], be1, g3[gi], 0, 0, 0);
+          } else {
+            g3[gi] = __builtin_amdgcn_mfma_f32_16x16x4f32(s_wf[(F_GI + t * 3 + gi) * 64 + lane], bi0, g3[gi], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) hn[mod][t][r] = lm_sigmoid(g3[2][r]) * lm_tanh(lm_sigmoid(g3[0][r]) * lm_tanh(g3[1][r]));
+      }
+    }
+    // s <- mix_ev([s ; h_ev]);  if the frame is present: s <- mix_im([s ; h_im])
+#pragma unroll
+    for (int mod = 0; mod < 2; mod++) {
+      if (mod == 1 && !p.use_im) break;                // (uniform)
+      f32x4 acc[NG];
+#pragma unroll
+      for (int n = 0; n < NG; n++) acc[n] = *reinterpret_cast<const f32x4 *>(s_sm + (mod == 0 ? O_BME : O_BMI) + 16 * n + 4 * q);
+      const float *wf = s_wf + (size_t)(mod == 0 ? F_ME : F_MI) * 64 + lane;
+#pragma unroll
+      for (int half = 0; half < 2; half++)
+#pragma unroll
+        for (int t = 0; t < NG; t++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const float b = half == 0 ? sreg[t][r] : hn[mod][t][r];
+            const int ks = (half * NG + t) * 4 + r;
+#pragma unroll
+            for (int n = 0; n < NG; n++)
+              acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[(size_t)(n * 8 * NG + ks) * 64], b, acc[n], 0, 0, 0);
+          }
+#pragma unroll
+      for (int n = 0; n < NG; n++) sreg[n] = acc[n];
+    }
+    if (pv) {
+      float *so = p.state + (size_t)pix * D + 4 * q;
+#pragma unroll
+      for (int t = 0; t < NG; t++) *reinterpret_cast<f32x4 *>(so + 16 * t) = sreg[t];
+      if (p.state16) {
+        _Float16 *ho = p.state16 + (size_t)pix * D + 4 * q;
+#pragma unroll
+        for (int t = 0; t < NG; t++)
+          *reinterpret_cast<f16x4 *>(ho + 16 * t) = (f16x4){(_Float16)sreg[t][0], (_Float16)sreg[t][1], (_Float16)sreg[t][2], (_Float16)sreg[t][3]};
+      }
+    }
+  }
+}
+template <int D, int S>
+static int ms_mfma_launch(const MsMfmaParams &p0, hipStream_t st) {
+  constexpr int NG = D / 16, K = S > 1 ? S + 1 : 1, KK = K * K;
+  constexpr int F_N = NG * 3 * 2 + NG * 3 + 16 * NG * NG;
+  constexpr int O_N = 25 * KK + 5 + 9 * KK + 3 + 6 * D + 2 * D;
+  const size_t lds = (size_t)(F_N * 64 + O_N) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void *)ms_lstm_superstate_mfma_kernel<D, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return RAMP_ELAUNCH;
+    attr_set = true;
+  }
+  MsMfmaParams p = p0;
+  const int ntile = ramp_cdiv(p.Hs * p.Ws, 16);
+  // enough waves to fill the chip a few times over; a wave amortises the workgroup's weight staging over its tiles
+  int tpw = ramp_cdiv(ntile, 4 * 1024);
+  if (tpw < 1) tpw = 1;
+  p.tiles_per_wave = tpw;
+  hipLaunchKernelGGL((ms_lstm_superstate_mfma_kernel<D, S>), dim3(ramp_cdiv(ntile, 4 * tpw)), dim3(256), lds, st, p);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+
 extern "C" {
 
 int ramp_affine_relu(const float *x, const float *s, const float *h, float *out, long n, int C,
@@ -1458,6 +1627,24 @@ int ramp_norm_add_relu(const float *y, const float *sy, const float *hy, const f
                      (hipStream_t)stream, y, sy, hy, skip, ss, hs, out, n4, C);
   RAMP_CHECK_LAUNCH();
   return RAMP_OK;
+}
+
+int ramp_ms_lstm_superstate_mfma(const float *ev, const float *im, const float *wfrag, const float *wsmall, float *state,
+                                 void *state16, int H, int W, int scale, int has_state, int use_im, void *stream) {
+  if (!ev || !im || !wfrag || !wsmall || !state || H <= 0 || W <= 0) return RAMP_EINVAL;
+  if (scale != 1 && scale != 2 && scale != 4) return RAMP_EUNSUPPORTED;
+  MsMfmaParams p;
+  p.ev = ev; p.im = im; p.wfrag = wfrag; p.wsmall = wsmall; p.state = state; p.state16 = (_Float16 *)state16;
+  p.H = H; p.W = W;
+  const int k = scale > 1 ? scale + 1 : 1, pad = scale > 1 ? 1 : 0;
+  p.Hs = (H + 2 * pad - k) / scale + 1;
+  p.Ws = (W + 2 * pad - k) / scale + 1;
+  if (p.Hs <= 0 || p.Ws <= 0) return RAMP_EINVAL;
+  p.has_state = has_state; p.use_im = use_im; p.tiles_per_wave = 1;
+  hipStream_t st = (hipStream_t)stream;
+  if (scale == 1) return ms_mfma_launch<16, 1>(p, st);
+  if (scale == 2) return ms_mfma_launch<32, 2>(p, st);
+  return ms_mfma_launch<64, 4>(p, st);
 }
 
 int ramp_ms_lstm_superstate(const float *ev, const float *im, const float *const *weights_host,

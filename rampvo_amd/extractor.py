@@ -223,7 +223,9 @@ class MultiScaleMergerDoubleNet(nn.Module):
         for k in range(len(self.scales)):
             if reinit_hidden:
                 st[k].fresh = True
-            xs.append(conv_hip.ms_lstm_superstate_step(self, k, ev, im, st[k], present))
+            # (fp16 towers: scales 2 and 4 enter them as half tensors -- the kernel writes that copy itself)
+            xs.append(conv_hip.ms_lstm_superstate_step(self, k, ev, im, st[k], present,
+                                                       want_half=self.mixed_precision and k > 0))
         if not present:
             return None, None
         half = self.mixed_precision
