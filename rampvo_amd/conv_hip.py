@@ -585,7 +585,7 @@ def ms_lstm_superstate_step(enc, k, ev, im, st, use_im, want_half=False):
     """ev [5,H,W], im [3,H,W] contiguous fp32; advances scale k's super-state in place and returns
     it as an NHWC tensor [Hs, Ws, D] (a view of st.s; with want_half the kernel's fp16 copy of it)"""
     H, W = ev.shape[-2:]
-    if _MS_MFMA:
+    if _MS_MFMA and (enc.scales[k] == 1 or st.Ws % 16 == 0):
         wfrag, wsmall = pack_ms_scale_mfma(enc, k)
         s16 = None
         if want_half:

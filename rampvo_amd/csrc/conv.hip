@@ -1195,21 +1195,37 @@ struct MsMfmaParams {
   _Float16 *state16;                    // optional [Hs*Ws][D] fp16 copy of the new state
   int H, W, Hs, Ws, has_state, use_im, tiles_per_wave;
 };
-template <int D, int S>
-__global__ void __launch_bounds__(256) ms_lstm_superstate_mfma_kernel(const MsMfmaParams p) {
+// (1 ulp reciprocal: the IEEE division sequence of __frcp_rn was a third of the cell's VALU work)
+__device__ __forceinline__ float ms_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float ms_tanh(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
+// h = sigmoid(o) tanh(sigmoid(i) tanh(g)) with 4 exponentials and 2 reciprocals (instead of 4 + 4; both run at a quarter
+// of the VALU rate): sigmoid(a) tanh(b) = sgn(b) (1 - t) / ((1 + e^-a) (1 + t)), t = e^(-2 |b|) <= 1 -- no overflow in the
+// numerator; e^-a = inf gives the right limit 0
+__device__ __forceinline__ float ms_sig_tanh(float a, float b) {
+  const float t = __expf(-2.0f * fabsf(b)), ea = __expf(-a);
+  const float v = (1.0f - t) * __builtin_amdgcn_rcpf((1.0f + ea) * (1.0f + t));
+  return b < 0.f ? -v : v;
+}
+__device__ __forceinline__ float ms_cell(float gi, float gg, float go) { return ms_sig_tanh(go, ms_sig_tanh(gi, gg)); }
+template <int D, int S, int NWV>
+__global__ void __launch_bounds__(64 * NWV) ms_lstm_superstate_mfma_kernel(const MsMfmaParams p) {
   constexpr int NG = D / 16;                           // 16-unit groups
   constexpr int K = S > 1 ? S + 1 : 1, PAD = S > 1 ? 1 : 0, KK = K * K;
   constexpr int F_GE = 0, F_GI = F_GE + NG * 3 * 2, F_ME = F_GI + NG * 3, F_MI = F_ME + 8 * NG * NG, F_N = F_MI + 8 * NG * NG;
   constexpr int O_WCE = 0, O_BCE = O_WCE + 25 * KK, O_WCI = O_BCE + 5, O_BCI = O_WCI + 9 * KK, O_BGE = O_BCI + 3,
                 O_BGI = O_BGE + 3 * D, O_BME = O_BGI + 3 * D, O_BMI = O_BME + D, O_N = O_BMI + D;
+  // input window of a 16-pixel tile (S > 1): K rows x (15 S + K) columns x 8 channels, staged per wave with all loads in
+  // flight at once (walking the taps from memory was a chain of 25 dependent round trips at scale 4)
+  constexpr int WC = 15 * S + K, WIN = S > 1 ? 8 * K * WC : 0;
   extern __shared__ __attribute__((aligned(16))) float ms_smem[];
   float *s_wf = ms_smem, *s_sm = ms_smem + F_N * 64;
-  for (int i = threadIdx.x; i < F_N * 16; i += 256)
+  float *s_win = s_sm + ((O_N + 3) & ~3) + (threadIdx.x >> 6) * WIN;
+  for (int i = threadIdx.x; i < F_N * 16; i += 64 * NWV)
     reinterpret_cast<float4 *>(s_wf)[i] = reinterpret_cast<const float4 *>(p.wfrag)[i];
-  for (int i = threadIdx.x; i < O_N; i += 256) s_sm[i] = p.wsmall[i];
+  for (int i = threadIdx.x; i < O_N; i += 64 * NWV) s_sm[i] = p.wsmall[i];
   __syncthreads();
   const int lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
-  const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int gw = blockIdx.x * NWV + (threadIdx.x >> 6);
   const int HWs = p.Hs * p.Ws, ntile = (HWs + 15) / 16;
   for (int it = 0; it < p.tiles_per_wave; it++) {
     const int tile = gw * p.tiles_per_wave + it;
@@ -1225,38 +1241,61 @@ __global__ void __launch_bounds__(256) ms_lstm_superstate_mfma_kernel(const MsMf
     for (int t = 0; t < NG; t++)
       sreg[t] = p.has_state ? *reinterpret_cast<const f32x4 *>(sp + 16 * t) : (f32x4){0.f, 0.f, 0.f, 0.f};
     // conv_1: lane (q, j) -> events channel q, image channel q (q < 3) or events channel 4 (q == 3)
-    const int c2 = q < 3 ? q : 4;                      // second output: image channel q, or events channel 4
     float y0 = s_sm[O_BCE + q], y1 = q < 3 ? s_sm[O_BCI + q] : s_sm[O_BCE + 4];
     {
       const float *w0 = s_sm + O_WCE + q * 5 * KK;
       const float *w1 = q < 3 ? s_sm + O_WCI + q * 3 * KK : s_sm + O_WCE + 4 * 5 * KK;
+      if constexpr (S == 1) {
+        float xe[5], xi[3];
 #pragma unroll
-      for (int ky = 0; ky < K; ky++) {
-        const int iy = oy * S - PAD + ky;
-        if (iy < 0 || iy >= p.H) continue;
+        for (int ci = 0; ci < 5; ci++) xe[ci] = p.ev[(size_t)ci * p.H * p.W + pc];
 #pragma unroll
-        for (int kx = 0; kx < K; kx++) {
-          const int ix = ox * S - PAD + kx;
-          if (ix < 0 || ix >= p.W) continue;
-          const size_t o = (size_t)iy * p.W + ix;
-          float xe[5], xi[3];
+        for (int ci = 0; ci < 3; ci++) xi[ci] = p.im[(size_t)ci * p.H * p.W + pc];
 #pragma unroll
-          for (int ci = 0; ci < 5; ci++) xe[ci] = p.ev[(size_t)ci * p.H * p.W + o];
+        for (int ci = 0; ci < 5; ci++) y0 = __builtin_fmaf(w0[ci], xe[ci], y0);
+        if (q < 3) {
 #pragma unroll
-          for (int ci = 0; ci < 3; ci++) xi[ci] = p.im[(size_t)ci * p.H * p.W + o];
+          for (int ci = 0; ci < 3; ci++) y1 = __builtin_fmaf(w1[ci], xi[ci], y1);
+        } else {
 #pragma unroll
-          for (int ci = 0; ci < 5; ci++) y0 = __builtin_fmaf(w0[(ci * K + ky) * K + kx], xe[ci], y0);
-          if (q < 3) {
-#pragma unroll
-            for (int ci = 0; ci < 3; ci++) y1 = __builtin_fmaf(w1[(ci * K + ky) * K + kx], xi[ci], y1);
-          } else {
-#pragma unroll
-            for (int ci = 0; ci < 5; ci++) y1 = __builtin_fmaf(w1[(ci * K + ky) * K + kx], xe[ci], y1);
-          }
+          for (int ci = 0; ci < 5; ci++) y1 = __builtin_fmaf(w1[ci], xe[ci], y1);
         }
+      } else {
+        // (Ws is a multiple of 16: a tile is 16 neighbours of one row)
+        const int toy = (tile * 16) / p.Ws, tox = tile * 16 - toy * p.Ws;
+        const int iy0 = toy * S - PAD, ix0 = tox * S - PAD;
+        const size_t HW = (size_t)p.H * p.W;
+        for (int i = lane; i < WIN; i += 64) {
+          const int ch = i / (K * WC), rem = i - ch * (K * WC), ky = rem / WC, cx = rem - ky * WC;
+          const int iy = iy0 + ky, ix = ix0 + cx;
+          const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+          const float *src = ch < 5 ? p.ev + (size_t)ch * HW : p.im + (size_t)(ch - 5) * HW;
+          s_win[i] = ok ? src[(size_t)iy * p.W + ix] : 0.f;
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ky = 0; ky < K; ky++)
+#pragma unroll
+          for (int kx = 0; kx < K; kx++) {
+            float xe[5], xi[3];
+#pragma unroll
+            for (int ci = 0; ci < 5; ci++) xe[ci] = s_win[(ci * K + ky) * WC + j * S + kx];
+#pragma unroll
+            for (int ci = 0; ci < 3; ci++) xi[ci] = s_win[((5 + ci) * K + ky) * WC + j * S + kx];
+#pragma unroll
+            for (int ci = 0; ci < 5; ci++) y0 = __builtin_fmaf(w0[(ci * K + ky) * K + kx], xe[ci], y0);
+            if (q < 3) {
+#pragma unroll
+              for (int ci = 0; ci < 3; ci++) y1 = __builtin_fmaf(w1[(ci * K + ky) * K + kx], xi[ci], y1);
+            } else {
+#pragma unroll
+              for (int ci = 0; ci < 5; ci++) y1 = __builtin_fmaf(w1[(ci * K + ky) * K + kx], xe[ci], y1);
+            }
+          }
+        __builtin_amdgcn_wave_barrier();
       }
     }
-    (void)c2;
     const float e4 = __shfl(y1, 48 + j, 64);           // events channel 4 of pixel j (computed by lane (3, j))
     const float be0 = y0, be1 = q == 0 ? e4 : 0.f, bi0 = q < 3 ? y1 : 0.f;
     // LSTM step from the zero state: h = sigmoid(o) tanh(sigmoid(i) tanh(g)), both modalities
@@ -1277,7 +1316,7 @@ __global__ void __launch_bounds__(256) ms_lstm_superstate_mfma_kernel(const MsMf
           }
         }
 #pragma unroll
-        for (int r = 0; r < 4; r++) hn[mod][t][r] = lm_sigmoid(g3[2][r]) * lm_tanh(lm_sigmoid(g3[0][r]) * lm_tanh(g3[1][r]));
+        for (int r = 0; r < 4; r++) hn[mod][t][r] = ms_cell(g3[0][r], g3[1][r], g3[2][r]);
       }
     }
     // s <- mix_ev([s ; h_ev]);  if the frame is present: s <- mix_im([s ; h_im])
@@ -1316,25 +1355,190 @@ __global__ void __launch_bounds__(256) ms_lstm_superstate_mfma_kernel(const MsMf
     }
   }
 }
+
+// The same step with ONE 16-pixel tile per workgroup and one wave per 16-unit group (D = 32: 2 waves, 64: 4): wave w
+// computes the gates of units 16 w .. 16 w + 15 and output tile w of both mixes; h and the first mix's output cross the
+// waves through LDS (two barriers).  The scale-2 / scale-4 grids have only 4800 / 1200 tiles: with a whole tile per wave the
+// launch was one wave per SIMD walking a chain of ~300 dependent MFMAs behind an 80 KB weight staging (56 us at scale 4);
+// here a wave's chain is 9 + 2 x 8 NG products, its A fragments (9 + 16 NG floats per lane) are prefetched into registers
+// straight from L2 while the input window is staged, and the launch is NG x as many waves.
 template <int D, int S>
+__global__ void __launch_bounds__(4 * D) ms_lstm_superstate_split_kernel(const MsMfmaParams p) {
+  constexpr int NG = D / 16;
+  constexpr int K = S > 1 ? S + 1 : 1, PAD = S > 1 ? 1 : 0, KK = K * K;
+  constexpr int F_GE = 0, F_GI = F_GE + NG * 3 * 2, F_ME = F_GI + NG * 3, F_MI = F_ME + 8 * NG * NG;
+  constexpr int O_WCE = 0, O_BCE = O_WCE + 25 * KK, O_WCI = O_BCE + 5, O_BCI = O_WCI + 9 * KK, O_BGE = O_BCI + 3,
+                O_BGI = O_BGE + 3 * D, O_BME = O_BGI + 3 * D, O_BMI = O_BME + D, O_N = O_BMI + D;
+  constexpr int WC = 15 * S + K, WIN = 8 * K * WC;
+  __shared__ float s_sm[(O_N + 3) & ~3];
+  __shared__ float s_win[WIN];
+  __shared__ __attribute__((aligned(16))) float s_h[2][NG][64][4];
+  __shared__ __attribute__((aligned(16))) float s_s[NG][64][4];
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
+  const int tile = blockIdx.x, HWs = p.Hs * p.Ws;
+  const int pix = tile * 16 + j;
+  const bool pv = pix < HWs;
+  const int pc = pv ? pix : HWs - 1;
+  // this wave's A fragments, from L2, ahead of everything else
+  float a_ge[6], a_gi[3], a_me[8 * NG], a_mi[8 * NG];
+#pragma unroll
+  for (int f = 0; f < 6; f++) a_ge[f] = p.wfrag[(size_t)(F_GE + w * 6 + f) * 64 + lane];
+#pragma unroll
+  for (int f = 0; f < 3; f++) a_gi[f] = p.wfrag[(size_t)(F_GI + w * 3 + f) * 64 + lane];
+#pragma unroll
+  for (int f = 0; f < 8 * NG; f++) {
+    a_me[f] = p.wfrag[(size_t)(F_ME + w * 8 * NG + f) * 64 + lane];
+    a_mi[f] = p.wfrag[(size_t)(F_MI + w * 8 * NG + f) * 64 + lane];
+  }
+  // the old super-state, every 16-channel group of it (B operand of the first mix)
+  f32x4 s_all[NG];
+  {
+    const float *sp = p.state + (size_t)pc * D + 4 * q;
+#pragma unroll
+    for (int t = 0; t < NG; t++)
+      s_all[t] = p.has_state ? *reinterpret_cast<const f32x4 *>(sp + 16 * t) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  // the tile's input window and the small weights -> LDS (a tile = 16 neighbours of one row: Ws % 16 == 0)
+  {
+    const int toy = (tile * 16) / p.Ws, tox = tile * 16 - toy * p.Ws;
+    const int iy0 = toy * S - PAD, ix0 = tox * S - PAD;
+    const size_t HW = (size_t)p.H * p.W;
+#ifndef MS_SKIP_WIN
+    // one (channel, tap row) of the window per wave and round: the row's address is wave-uniform, a lane adds its column
+    for (int row = w; row < 8 * K; row += NG) {
+      const int ch = row / K, ky = row - ch * K, iy = iy0 + ky;
+      const bool rok = iy >= 0 && iy < p.H;
+      const float *src = (ch < 5 ? p.ev + (size_t)ch * HW : p.im + (size_t)(ch - 5) * HW) + (size_t)(rok ? iy : 0) * p.W;
+      for (int cx = lane; cx < WC; cx += 64) {
+        const int ix = ix0 + cx;
+        s_win[row * WC + cx] = (rok && ix >= 0 && ix < p.W) ? src[ix] : 0.f;
+      }
+    }
+#endif
+    for (int i = tid; i < O_N; i += 4 * D) s_sm[i] = p.wsmall[i];
+  }
+  __syncthreads();
+  // conv_1, once per tile: thread (part, c, j) sums its share of the taps of output channel c (0..4 events, 5..7 image) of
+  // pixel j -- ~50 independent LDS reads per thread -- and the partial sums meet in LDS.  (Every wave walking all 25 taps of
+  // its lanes' two channels was 18 dependent LDS round trips per tap: 35 of the kernel's 58 us at scale 4.)
+  constexpr int NPART = (4 * D) / 128;
+  __shared__ float s_y[NPART][8][16];
+#ifndef MS_SKIP_CONV
+  {
+    const int cj = tid & 15, cc = (tid >> 4) & 7, part = tid >> 7;     // (part is wave-uniform)
+    const bool isev = cc < 5;
+    const float *wv = s_sm + (isev ? O_WCE + cc * 5 * KK : O_WCI + (cc - 5) * 3 * KK);
+    const float *xw = s_win + (isev ? 0 : 5 * K * WC) + cj * S;
+    // tap rows [0, KY0) to part 0, the rest to part 1 (one part: all of them); every offset below is a compile-time constant
+    constexpr int KY0 = NPART == 1 ? K : (K + 1) / 2;
+    float acc = 0.f;
+#define MS_TAPS(CI, KA, KB)                                                                     \
+    _Pragma("unroll") for (int ci = 0; ci < CI; ci++)                                             \
+    _Pragma("unroll") for (int ky = KA; ky < KB; ky++)                                            \
+    _Pragma("unroll") for (int kx = 0; kx < K; kx++)                                              \
+      acc = __builtin_fmaf(wv[(ci * K + ky) * K + kx], xw[(ci * K + ky) * WC + kx], acc);
+    if (part == 0) {
+      if (isev) { MS_TAPS(5, 0, KY0) } else { MS_TAPS(3, 0, KY0) }
+    } else {
+      if (isev) { MS_TAPS(5, KY0, K) } else { MS_TAPS(3, KY0, K) }
+    }
+#undef MS_TAPS
+    s_y[part][cc][cj] = acc;
+  }
+  __syncthreads();
+#endif
+  float y0 = s_sm[O_BCE + q], y1 = q < 3 ? s_sm[O_BCI + q] : s_sm[O_BCE + 4];
+#ifndef MS_SKIP_CONV
+#pragma unroll
+  for (int part = 0; part < NPART; part++) {
+    y0 += s_y[part][q][j];
+    y1 += s_y[part][q < 3 ? 5 + q : 4][j];
+  }
+#else
+  y0 = s_win[lane]; y1 = s_win[64 + lane];
+#endif
+  const float e4 = __shfl(y1, 48 + j, 64);
+  const float be0 = y0, be1 = q == 0 ? e4 : 0.f, bi0 = q < 3 ? y1 : 0.f;
+  // gates of units 16 w + 4 q + r, both modalities -> h, published for the other waves
+#pragma unroll
+  for (int mod = 0; mod < 2; mod++) {
+    f32x4 g3[3];
+#pragma unroll
+    for (int gi = 0; gi < 3; gi++) {
+      g3[gi] = *reinterpret_cast<const f32x4 *>(s_sm + (mod == 0 ? O_BGE : O_BGI) + gi * D + 16 * w + 4 * q);
+      if (mod == 0) {
+        g3[gi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_ge[gi * 2 + 0], be0, g3[gi], 0, 0, 0);
+        g3[gi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_ge[gi * 2 + 1], be1, g3[gi], 0, 0, 0);
+      } else {
+        g3[gi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_gi[gi], bi0, g3[gi], 0, 0, 0);
+      }
+    }
+    f32x4 h;
+#pragma unroll
+    for (int r = 0; r < 4; r++) h[r] = ms_cell(g3[0][r], g3[1][r], g3[2][r]);
+    *reinterpret_cast<f32x4 *>(&s_h[mod][w][lane][0]) = h;
+  }
+  __syncthreads();
+  f32x4 acc = *reinterpret_cast<const f32x4 *>(s_sm + O_BME + 16 * w + 4 * q);
+#pragma unroll
+  for (int t = 0; t < NG; t++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_me[t * 4 + r], s_all[t][r], acc, 0, 0, 0);
+#pragma unroll
+  for (int t = 0; t < NG; t++) {
+    const f32x4 h = *reinterpret_cast<const f32x4 *>(&s_h[0][t][lane][0]);
+#pragma unroll
+    for (int r = 0; r < 4; r++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_me[(NG + t) * 4 + r], h[r], acc, 0, 0, 0);
+  }
+  if (p.use_im) {                                    // (uniform)
+    *reinterpret_cast<f32x4 *>(&s_s[w][lane][0]) = acc;
+    __syncthreads();
+    f32x4 acc2 = *reinterpret_cast<const f32x4 *>(s_sm + O_BMI + 16 * w + 4 * q);
+#pragma unroll
+    for (int t = 0; t < NG; t++) {
+      const f32x4 sv = *reinterpret_cast<const f32x4 *>(&s_s[t][lane][0]);
+#pragma unroll
+      for (int r = 0; r < 4; r++) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_mi[t * 4 + r], sv[r], acc2, 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < NG; t++) {
+      const f32x4 h = *reinterpret_cast<const f32x4 *>(&s_h[1][t][lane][0]);
+#pragma unroll
+      for (int r = 0; r < 4; r++) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_mi[(NG + t) * 4 + r], h[r], acc2, 0, 0, 0);
+    }
+    acc = acc2;
+  }
+  if (pv) {
+    *reinterpret_cast<f32x4 *>(p.state + (size_t)pix * D + 16 * w + 4 * q) = acc;
+    if (p.state16)
+      *reinterpret_cast<f16x4 *>(p.state16 + (size_t)pix * D + 16 * w + 4 * q) =
+          (f16x4){(_Float16)acc[0], (_Float16)acc[1], (_Float16)acc[2], (_Float16)acc[3]};
+  }
+}
+
+template <int D, int S, int NWV>
 static int ms_mfma_launch(const MsMfmaParams &p0, hipStream_t st) {
   constexpr int NG = D / 16, K = S > 1 ? S + 1 : 1, KK = K * K;
   constexpr int F_N = NG * 3 * 2 + NG * 3 + 16 * NG * NG;
   constexpr int O_N = 25 * KK + 5 + 9 * KK + 3 + 6 * D + 2 * D;
-  const size_t lds = (size_t)(F_N * 64 + O_N) * sizeof(float);
+  constexpr int WIN = S > 1 ? 8 * K * (15 * S + K) : 0;
+  const size_t lds = (size_t)(F_N * 64 + ((O_N + 3) & ~3) + NWV * WIN) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void *)ms_lstm_superstate_mfma_kernel<D, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (hipFuncSetAttribute((const void *)ms_lstm_superstate_mfma_kernel<D, S, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return RAMP_ELAUNCH;
     attr_set = true;
   }
   MsMfmaParams p = p0;
   const int ntile = ramp_cdiv(p.Hs * p.Ws, 16);
-  // enough waves to fill the chip a few times over; a wave amortises the workgroup's weight staging over its tiles
-  int tpw = ramp_cdiv(ntile, 4 * 1024);
+  // one tile per wave while that keeps the launch within ~8 waves per SIMD; more tiles per wave beyond (a workgroup's
+  // weight staging is then amortised over them)
+  static int tpw_env = -1;
+  if (tpw_env < 0) { const char *e = getenv("RAMP_MS_TPW"); tpw_env = e ? atoi(e) : 0; }
+  int tpw = tpw_env > 0 ? tpw_env : ramp_cdiv(ntile, 8 * 1024);
   if (tpw < 1) tpw = 1;
   p.tiles_per_wave = tpw;
-  hipLaunchKernelGGL((ms_lstm_superstate_mfma_kernel<D, S>), dim3(ramp_cdiv(ntile, 4 * tpw)), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((ms_lstm_superstate_mfma_kernel<D, S, NWV>), dim3(ramp_cdiv(ntile, NWV * tpw)), dim3(64 * NWV), lds, st, p);
   RAMP_CHECK_LAUNCH();
   return RAMP_OK;
 }
@@ -1642,9 +1846,19 @@ int ramp_ms_lstm_superstate_mfma(const float *ev, const float *im, const float *
   if (p.Hs <= 0 || p.Ws <= 0) return RAMP_EINVAL;
   p.has_state = has_state; p.use_im = use_im; p.tiles_per_wave = 1;
   hipStream_t st = (hipStream_t)stream;
-  if (scale == 1) return ms_mfma_launch<16, 1>(p, st);
-  if (scale == 2) return ms_mfma_launch<32, 2>(p, st);
-  return ms_mfma_launch<64, 4>(p, st);
+  if (scale > 1 && (p.Ws % 16)) return RAMP_EUNSUPPORTED;      // (a tile = 16 neighbours of one row)
+  if (scale == 1) return ms_mfma_launch<16, 1, 4>(p, st);
+  static int split = -1;                              // RAMP_MS_SPLIT=0: a whole tile per wave at scales 2 / 4 (A/B runs)
+  if (split < 0) { const char *e = getenv("RAMP_MS_SPLIT"); split = e ? atoi(e) : 1; }
+  const int ntile = ramp_cdiv(p.Hs * p.Ws, 16);
+  if (split) {
+    if (scale == 2) hipLaunchKernelGGL((ms_lstm_superstate_split_kernel<32, 2>), dim3(ntile), dim3(128), 0, st, p);
+    else hipLaunchKernelGGL((ms_lstm_superstate_split_kernel<64, 4>), dim3(ntile), dim3(256), 0, st, p);
+    RAMP_CHECK_LAUNCH();
+    return RAMP_OK;
+  }
+  if (scale == 2) return ms_mfma_launch<32, 2, 4>(p, st);
+  return ms_mfma_launch<64, 4, 6>(p, st);
 }
 
 int ramp_ms_lstm_superstate(const float *ev, const float *im, const float *const *weights_host,

@@ -144,7 +144,7 @@ def _one_update_vs_cpu_oracle(mode, preset, H, W, sd, cfgk, legs=(False,), w_bia
             at_reset=int(at_reset.sum()), patches=int(at_reset.size),
             depth_range=(float(r_depth.min()), float(r_depth.max())))
         if mixed and pol is not None:
-            at_p = (np.abs(pol["depth"] - 20.0) < 0.1) | (np.abs(g_depth - 20.0) < 0.1)
+            at_p = (np.abs(pol["depth"] - 20.0) < 0.5) | (np.abs(g_depth - 20.0) < 0.5) | ((pol["depth"] == 1.0) != (g_depth == 1.0))
             dp = np.abs(g_depth - pol["depth"]) / np.maximum(np.abs(pol["depth"]), 1.0)
             dpol = np.abs(pol["depth"] - r_depth) / np.maximum(np.abs(r_depth), 1.0)
             out["fp16_vs_policy"] = dict(
@@ -152,7 +152,7 @@ def _one_update_vs_cpu_oracle(mode, preset, H, W, sd, cfgk, legs=(False,), w_bia
                 weight=float(np.abs(g_w - pol["w"]).max()),
                 poses_over_step=float(np.abs(g_poses - pol["poses"]).max() / max(step, 1e-12)),
                 depths_p995=float(np.percentile(dp, 99.5)), depths_p999=float(np.percentile(dp, 99.9)),
-                depths_max=float(dp[~at_p].max()), at_reset=int(at_p.sum()))
+                depths_max=float(dp[~at_p].max()), at_reset=int(at_p.sum()), at_reset_frac=float(at_p.mean()))
             out["policy_vs_fp32"] = dict(
                 net=float(np.abs(pol["net"] - r_net).max() / np.abs(r_net).max()),
                 weight=float(np.abs(pol["w"] - r_w).max()),
@@ -182,20 +182,32 @@ MIXED_DEPTHS_P999 = 1e-1       # the 99.9th percentile (p99.5 alone l
 # MI355X at configs[1] (printed by the test: net 2.8e-4 -- single fp16 roundings that fall the other way under a different
 # fp32 summation order --, weight 6e-8, poses 1.3e-4 .. 8e-4 of the GN step over builds (which roundings flip), depths p99.9 2.3e-3, worst patch 6.9e-3; the same
 # leg against the fp32 oracle: 3.6e-3 of the step, 1.3e-2, 3.7e-2 -- i.e. the fp16 path's error is its precision policy)
-POLICY_NET, POLICY_WEIGHT, POLICY_POSES, POLICY_DEPTHS_P999, POLICY_DEPTHS_MAX = 1.2e-3, 1e-6, 2e-3, 1e-2, 3e-2
+POLICY_NET, POLICY_WEIGHT, POLICY_POSES, POLICY_DEPTHS_P999, POLICY_DEPTHS_MAX = 1.2e-3, 4e-6, 2e-3, 2e-2, 4e-2
+# (configs[2] / [4] sizes: net 3.0e-4 / 3.1e-4, weight 1.1e-6 -- one fp16 step of a 1e-6 confidence --, poses 4.0e-4 / 3.3e-4 of
+# the step, depths p99.9 1.0e-2 / 3.8e-3, worst patch 8.7e-3 / 5.5e-3 once the patches within 0.5 of the d > 20 -> 1 reset
+# are set aside: a depth of 20.2 in one leg and 19.9 in the other is 1 vs 19.9 after the reset)
 
 
 def _assert_policy_leg(m):
+    assert m["at_reset_frac"] <= 0.06, m           # (the random-weight depths pile up below the d > 20 -> 1 reset: ~4 % within 0.5 of it at configs[2])
     assert m["net"] <= POLICY_NET and m["weight"] <= POLICY_WEIGHT, m
     assert m["poses_over_step"] <= POLICY_POSES and m["depths_p999"] <= POLICY_DEPTHS_P999, m
     assert m["depths_max"] <= POLICY_DEPTHS_MAX, m
 
 
-def _assert_fp16_leg(m):
+def _assert_fp16_leg(m, policy=None):
+    """policy: the same leg against the fp16-policy oracle (kernel error only).  With it the depth TAIL of the comparison
+    with the fp32 oracle is not asserted: at the precise.yaml / 720p windows a random-weight snapshot has a few dozen
+    patches whose depth Gauss-Newton solves with Q = 1 / (C + 1e-4) ~ 1e4, where the precision policy's 3e-4 of the hidden
+    state decides which side of the d > 20 -> 1 reset a depth lands on (p99.9 0.03 .. 0.9 over snapshots) -- the policy
+    oracle lands on the same side as the kernels, and THAT comparison is bounded."""
     scale = max(1.0, m["step"])
     assert m["net"] <= MIXED_NET and m["weight"] <= MIXED_WEIGHT, m
     assert m["poses"] <= MIXED_POSES * scale and m["depths_p995"] <= MIXED_DEPTHS * scale, m
-    assert m["depths_p999"] <= MIXED_DEPTHS_P999 * scale, m
+    if policy is None:
+        assert m["depths_p999"] <= MIXED_DEPTHS_P999 * scale, m
+    else:
+        _assert_policy_leg(policy)
 
 
 @torch.no_grad()
@@ -247,10 +259,10 @@ def test_config3_multiscale_precise_windows_update_step_against_cpu_oracle():
     # weights' motion happens to be (the MultiScale tracker's own decisions settle at ~9 keyframes)
     slam, sd, cfgk = _steady_state_snapshot("MultiScale", "precise", 96, 480, 640, 52, mixed=True, KEYFRAME_THRESH=0.0)
     assert slam.n > 34 and int(slam._jj.max()) >= 33 and len(slam._ii) > 100000, (slam.n, len(slam._ii))
-    e = _one_update_vs_cpu_oracle("MultiScale", "precise", 480, 640, sd, cfgk, legs=(False, True))
+    e = _one_update_vs_cpu_oracle("MultiScale", "precise", 480, 640, sd, cfgk, legs=(False, True), policy=True)
     print(e)
     _assert_fp32_leg(e["fp32"])
-    _assert_fp16_leg(e["fp16"])
+    _assert_fp16_leg(e["fp16"], policy=e["fp16_vs_policy"])
 
 
 @torch.no_grad()
@@ -260,10 +272,10 @@ def test_config5_720p_256_patches_32_keyframe_window_update_step_against_cpu_ora
     over = dict(OPTIMIZATION_WINDOW=32, KEYFRAME_THRESH=0.0)       # see configs[2]'s test
     slam, sd, cfgk = _steady_state_snapshot("MultiScale", "precise", 256, 720, 1280, 40, mixed=True, **over)
     assert slam.n > 33 and len(slam._ii) > 300000, (slam.n, len(slam._ii))
-    e = _one_update_vs_cpu_oracle("MultiScale", "precise", 720, 1280, sd, cfgk, legs=(False, True))
+    e = _one_update_vs_cpu_oracle("MultiScale", "precise", 720, 1280, sd, cfgk, legs=(False, True), policy=True)
     print(e)
     _assert_fp32_leg(e["fp32"])
-    _assert_fp16_leg(e["fp16"])
+    _assert_fp16_leg(e["fp16"], policy=e["fp16_vs_policy"])
 
 
 @torch.no_grad()
@@ -277,9 +289,9 @@ def test_config5_as_written_fp8_encoder_update_step_against_cpu_oracle():
     slam, sd, cfgk = _steady_state_snapshot("MultiScale", "precise", 256, 720, 1280, 40, mixed=True, **over)
     assert slam.network.patchify.encoder.fp8_mfma and slam.n > 33 and len(slam._ii) > 300000, (slam.n, len(slam._ii))
     cfgk = {k: v for k, v in cfgk.items() if k != "ENCODER_FP8"}          # (the oracle backend has no such switch)
-    e = _one_update_vs_cpu_oracle("MultiScale", "precise", 720, 1280, sd, cfgk, legs=(True,))
+    e = _one_update_vs_cpu_oracle("MultiScale", "precise", 720, 1280, sd, cfgk, legs=(True,), policy=True)
     print(e)
-    _assert_fp16_leg(e["fp16"])
+    _assert_fp16_leg(e["fp16"], policy=e["fp16_vs_policy"])
 
 
 @torch.no_grad()
