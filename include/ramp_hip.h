@@ -398,6 +398,11 @@ typedef struct ramp_conv_job {
   void *acc_out;
   const void *acc_in;
   float in_count, in_eps;
+  /* two-source input (half in): channels [c0, Cin) come from x2 [H][W][Cin - c0], x is [H][W][c0] -- the MultiScale
+   * towers' torch.cat((x, x_down2), dim=1) (ramp/extractor.py:300, 306) without the copy; c0 and Cin - c0 multiples of
+   * 8, no input normalisation.  x2 = NULL: one source                                                              */
+  const void *x2;
+  int32_t c0;
 } ramp_conv_job;
 #define RAMP_IN_ACC_R 8
 int ramp_conv2d_nhwc_multi(const ramp_conv_job *jobs, int njobs, int H, int W, int Cin, int KH, int stride,

@@ -189,7 +189,20 @@ class ConvJob(ctypes.Structure):
                 ("Cout", ctypes.c_int32), ("relu", ctypes.c_int32), ("out_scale", ctypes.c_float),
                 ("act_scale", ctypes.c_float), ("w_scale", ctypes.c_float),
                 ("acc_out", ctypes.c_void_p), ("acc_in", ctypes.c_void_p), ("in_count", ctypes.c_float),
-                ("in_eps", ctypes.c_float)]
+                ("in_eps", ctypes.c_float), ("x2", ctypes.c_void_p), ("c0", ctypes.c_int32)]
+
+
+class Pair:
+    """a channel concatenation that is never materialised: (a [H,W,C0], b [H,W,C1]) read as [H,W,C0+C1] by the LDS-tiled
+    conv kernel (ramp_conv_job.x2)"""
+    __slots__ = ("a", "b")
+
+    def __init__(self, a, b):
+        assert a.shape[:2] == b.shape[:2] and a.dtype == b.dtype and a.is_contiguous() and b.is_contiguous()
+        self.a, self.b = a, b
+
+    def cat(self):
+        return torch.cat((self.a, self.b), dim=-1)
 
 
 # fp8 variant: activations are multiplied by this before the e4m3 conversion (saturating at 448 / FP8_ACT_SCALE = 56;
@@ -254,13 +267,21 @@ def conv2d_towers(jobs, half, fp8=False):
     row -- was measured and dropped: the device-scope release every workgroup needs before its ticket writes the
     XCD's L2 back, 1.24 ms per front end instead of 0.47.)"""
     def single():
-        return [conv2d(j["x"], j["conv"], res=j.get("res"), relu=j.get("relu", False),
-                       want_stats=j.get("want_stats", False), out_scale=j.get("out_scale", 1.0),
-                       eps=j.get("eps", 1e-5), half=half) for j in jobs]
+        return [conv2d(j["x"].cat() if isinstance(j["x"], Pair) else j["x"], j["conv"], res=j.get("res"),
+                       relu=j.get("relu", False), want_stats=j.get("want_stats", False),
+                       out_scale=j.get("out_scale", 1.0), eps=j.get("eps", 1e-5), half=half) for j in jobs]
     if not half or len(jobs) > 2 or os.environ.get("RAMP_TOWER_PAIR", "1") != "1":
         return single()
     x0 = jobs[0]["x"].raw if isinstance(jobs[0]["x"], Pending) else jobs[0]["x"]
-    H, W, Cin = x0.shape
+    paired = isinstance(x0, Pair)
+    if paired:
+        if not all(isinstance(j["x"], Pair) and j["x"].a.shape == x0.a.shape and j["x"].b.shape == x0.b.shape for j in jobs):
+            return single()
+        H, W = x0.a.shape[:2]
+        Cin = x0.a.shape[2] + x0.b.shape[2]
+        x0 = x0.a
+    else:
+        H, W, Cin = x0.shape
     mode, code, odt = _conv_mode(x0, True)
     use8 = bool(fp8) and mode == "f16"            # (the fp32-input first layer stays on the f16 MFMA)
     if use8:
@@ -278,6 +299,9 @@ def conv2d_towers(jobs, half, fp8=False):
     for t, j in enumerate(jobs):
         x, conv = j["x"], j["conv"]
         pre = acc_in = None
+        x2 = None
+        if paired:
+            x, x2 = x.a, x.b
         if isinstance(x, Pending):
             assert x.relu
             if x.acc is not None and x._scale is None and Cin <= 128:
@@ -291,7 +315,7 @@ def conv2d_towers(jobs, half, fp8=False):
         else:
             wpk, bias = pack_conv_weight(conv, mode)
         cout = conv.weight.shape[0]
-        assert tuple(x.shape) == (H, W, Cin) and x.dtype == x0.dtype and x.is_contiguous()
+        assert tuple(x.shape) == (H, W, Cin - (x2.shape[2] if x2 is not None else 0)) and x.dtype == x0.dtype and x.is_contiguous()
         assert conv.weight.shape[2] == kh and conv.stride[0] == stride and conv.padding[0] == kh // 2
         assert Cin == wpk.shape[1] * (32 if mode == "f16" else 16)
         res = j.get("res")
@@ -299,6 +323,7 @@ def conv2d_towers(jobs, half, fp8=False):
         y = torch.empty(OH, OW, cout, dtype=odt, device=x.device)
         a = arr[t]
         a.x, a.wpk, a.bias = ptr(x), ptr(wpk), ptr(bias)
+        a.x2, a.c0 = (ptr(x2), x.shape[2]) if x2 is not None else (None, 0)
         a.pre_scale, a.pre_shift = (ptr(pre[0]), ptr(pre[1])) if pre else (None, None)
         a.acc_in, a.in_count, a.in_eps = (ptr(acc_in.acc), acc_in.count, acc_in.eps) if acc_in else (None, 0.0, 0.0)
         a.acc_out = None
@@ -419,6 +444,9 @@ def basic_encoder4(enc, x, out_scale=1.0, half=False):
     return basic_encoder4_towers([enc], x, out_scale, half)[0]
 
 
+_MS_PAIR = os.environ.get("RAMP_MS_PAIR", "1") == "1"       # A/B switch: 0 = torch.cat copies
+
+
 def multiscale_encoder4_towers(encs, x, x2, x4, out_scale=1.0, half=False, fp8=False):
     """MultiScaleBasicEncoder4.forward (reference extractor.py:288-311) of every tower on NHWC inputs: x [H,W,16],
     x2 [H/2,W/2,32] and x4 [H/4,W/4,64] (the three super-states) -> [H/4,W/4,out].  The channel
@@ -429,12 +457,14 @@ def multiscale_encoder4_towers(encs, x, x2, x4, out_scale=1.0, half=False, fp8=F
         xs = _first_layer(encs, x, norms, half)
         for b in range(2):
             xs = _res_blocks([e.layer1[b] for e in encs], xs, norms, half, fp8)
+        # the channel concatenations: two-source inputs of the next layer (fp16 towers; ramp_conv_job.x2), else copies
+        two = half and _MS_PAIR
         x2 = x2.to(xs[0].dtype)
-        xs = [torch.cat((v, x2), dim=-1) for v in xs]
+        xs = [Pair(v, x2) if two else torch.cat((v, x2), dim=-1) for v in xs]
         for b in range(2):
             xs = _res_blocks([e.layer3[b] for e in encs], xs, norms, half, fp8)
         x4 = x4.to(xs[0].dtype)
-        xs = [torch.cat((v, x4), dim=-1) for v in xs]
+        xs = [Pair(v, x4) if two else torch.cat((v, x4), dim=-1) for v in xs]
         return conv2d_towers([dict(x=xs[t], conv=e.conv3, out_scale=out_scale) for t, e in enumerate(encs)], half, fp8)
     finally:
         _scope.cur = None

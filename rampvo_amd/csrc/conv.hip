@@ -87,6 +87,10 @@ struct ConvParams {
   // fp8 MFMA variant of the LDS-tiled kernel: operands are x * act_scale and w * w_scale rounded to OCP e4m3
   // (saturating at +-448), the fp32 accumulator is multiplied by descale = 1 / (act_scale * w_scale) before the bias
   float act_scale, descale;
+  // LDS-tiled fp16 kernel only: channels [C0, Cin) of the input come from a SECOND tensor x2 [H][W][Cin - C0] (x is then
+  // [H][W][C0]) -- the MultiScale towers' torch.cat((x, x_down2), channel) without the copy (ramp/extractor.py:300, 306)
+  const void *x2;
+  int C0;
 };
 // up to two independent problems of one layer shape in one launch (blockIdx.z): the towers of the encoder
 struct ConvMulti { ConvParams t[2]; };
@@ -448,6 +452,22 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvParams &p, const f3
   }
 }
 
+// dynamic LDS bytes of conv_tile_f16_kernel<K, S, IN_F32, CIN, NT, FP8> (the kernel asserts the same number)
+constexpr int conv_tile_lds_bytes(int K, int S, bool IN_F32, int CIN, int NT, bool FP8) {
+  const int TH = 8, TW = 16, SP = K == 1 ? 1 : S;
+  const int IH = (TH - 1) * SP + K, IW = (TW - 1) * SP + K;
+  const int PSTR = FP8 ? CIN + 8 : CIN * 2 + 16;
+  const int KC = IN_F32 ? 16 : 32, NCH = CIN / KC, FRAG = (IN_F32 || FP8) ? 8 : 16;
+  const int WBYTES = K * K * NCH * NT * 64 * FRAG, IBYTES = IH * IW * PSTR;
+  const int OBYTES = TH * TW * (NT * 16 + 4) * 4;
+  return (WBYTES + IBYTES) > OBYTES ? (WBYTES + IBYTES) : OBYTES;
+}
+template <typename KernelT>
+static int conv_tile_attr(KernelT kernel, int lds) {
+  if (lds <= 64 * 1024) return RAMP_OK;
+  return hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess ? RAMP_OK : RAMP_ELAUNCH;
+}
+
 // LDS-tiled fp16 variant: the layers of these towers are tiny (32/64 channels, <= 77k pixels), so
 // the direct kernel above spends its time on one global round trip per tap and on re-applying
 // the InstanceNorm prologue 9 (49) times per input value.  Here a workgroup owns an 8 x 16 output
@@ -481,7 +501,9 @@ __global__ void __launch_bounds__(256) conv_tile_f16_kernel(const ConvMulti pm) 
   constexpr int OBYTES = TH * TW * OSTR * 4;
   constexpr int SMB = (WBYTES + IBYTES) > OBYTES ? (WBYTES + IBYTES) : OBYTES;
   static_assert(256 % CH8 == 0, "a thread keeps one channel slot");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[SMB];
+  static_assert(SMB == conv_tile_lds_bytes(K, S, IN_F32, CIN, NT, FP8), "launch-side size out of date");
+  // (dynamic: the stride-2 64-channel layer of the MultiScale towers needs 118 KB -- above the static limit)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ float s_stat[4][NT * 16][2];
   unsigned char *s_w = smem, *s_in = smem + WBYTES;
 
@@ -512,7 +534,14 @@ __global__ void __launch_bounds__(256) conv_tile_f16_kernel(const ConvMulti pm) 
     const int gy = oy0 * S + ty * STEP - PAD, gx = ox0 * S + tx * STEP - PAD;
     iok[n] = i < NITEM && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
     const int cy = iok[n] ? gy : 0, cx = iok[n] ? gx : 0;      // always a valid address; masked below
-    ibuf[n] = reinterpret_cast<const u32x4 *>(p.x)[((size_t)cy * p.W + cx) * CH8 + cslot];
+    if (!IN_F32 && p.x2) {                                    // (uniform) two sources: the channel slot picks one
+      const int s0 = p.C0 / CPI;
+      const bool second = cslot >= s0;
+      const u32x4 *src = reinterpret_cast<const u32x4 *>(second ? p.x2 : p.x);
+      ibuf[n] = src[((size_t)cy * p.W + cx) * (second ? CH8 - s0 : s0) + (second ? cslot - s0 : cslot)];
+    } else {
+      ibuf[n] = reinterpret_cast<const u32x4 *>(p.x)[((size_t)cy * p.W + cx) * CH8 + cslot];
+    }
   }
   float sc[8], sh[8];
   const bool pre = p.pre_scale != nullptr || p.acc_in != nullptr;
@@ -1672,7 +1701,7 @@ int ramp_conv2d_nhwc(const void *x, const void *wpk, const float *bias, const fl
   if (in_f32 && Cin != 16) return RAMP_EUNSUPPORTED;
   ConvParams p;
   p.x = x; p.wpk = wpk; p.bias = bias; p.pre_scale = pre_scale; p.pre_shift = pre_shift;
-  p.res = res; p.y = y; p.stats = stats;
+  p.res = res; p.y = y; p.stats = stats; p.x2 = nullptr; p.C0 = 0;
   p.acc_out = nullptr; p.acc_in = nullptr; p.in_count = 0.f; p.in_eps = 0.f;
   p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
   const int pad = KH / 2;
@@ -1690,14 +1719,17 @@ int ramp_conv2d_nhwc(const void *x, const void *wpk, const float *bias, const fl
   if (KH == K && stride == S && in_f32 == INF32 && Cin == CIN && Cout % (NT * 16) == 0) {             \
     ConvMulti pm;                                                                                     \
     pm.t[0] = p; pm.t[1] = p;                                                                         \
+    constexpr int lds_ = conv_tile_lds_bytes(K, S, INF32, CIN, NT, false);                            \
+    if (conv_tile_attr(conv_tile_f16_kernel<K, S, INF32, CIN, NT>, lds_) != RAMP_OK) return RAMP_ELAUNCH; \
     hipLaunchKernelGGL((conv_tile_f16_kernel<K, S, INF32, CIN, NT>), dim3(tg.x, Cout / (NT * 16), 1),  \
-                       block, 0, st, pm);                                                             \
+                       block, lds_, st, pm);                                                          \
     RAMP_CHECK_LAUNCH();                                                                              \
     return RAMP_OK;                                                                                   \
   }
     TILE_CASE(7, 2, true, 16, 2)
     TILE_CASE(3, 1, false, 32, 2)
     TILE_CASE(3, 2, false, 32, 2)
+    TILE_CASE(3, 2, false, 64, 2)
     TILE_CASE(3, 1, false, 64, 2)
     TILE_CASE(1, 2, false, 32, 4)
     TILE_CASE(1, 2, false, 64, 4)
@@ -1740,6 +1772,8 @@ int ramp_conv2d_nhwc_multi(const ramp_conv_job *jobs, int njobs, int H, int W, i
     ConvParams &p = pm.t[t];
     p.x = j.x; p.wpk = j.wpk; p.bias = j.bias; p.pre_scale = j.pre_scale; p.pre_shift = j.pre_shift;
     p.res = j.res; p.y = j.y; p.stats = j.stats;
+    p.x2 = j.x2; p.C0 = j.c0;
+    if (p.x2 && (in_f32 || p.C0 <= 0 || p.C0 >= Cin || (p.C0 & 7) || ((Cin - p.C0) & 7) || p.pre_scale || j.acc_in)) return RAMP_EINVAL;
     p.acc_out = (unsigned long long *)j.acc_out; p.acc_in = (const unsigned long long *)j.acc_in;
     p.in_count = j.in_count; p.in_eps = j.in_eps;
     if (p.acc_in && (Cin > 128 || p.in_count <= 0.f)) return RAMP_EINVAL;
@@ -1765,13 +1799,16 @@ int ramp_conv2d_nhwc_multi(const ramp_conv_job *jobs, int njobs, int H, int W, i
   }
 #define TILE_CASE8(K, S, CIN, NT)                                                                    \
   if (fp8 && KH == K && stride == S && Cin == CIN && (NT == 2 || cgcd_ok64)) {                        \
+    constexpr int lds_ = conv_tile_lds_bytes(K, S, false, CIN, NT, true);                             \
+    if (conv_tile_attr(conv_tile_f16_kernel<K, S, false, CIN, NT, true>, lds_) != RAMP_OK) return RAMP_ELAUNCH; \
     hipLaunchKernelGGL((conv_tile_f16_kernel<K, S, false, CIN, NT, true>), dim3(tiles, cmax / (NT * 16), njobs), \
-                       block, 0, st, pm);                                                             \
+                       block, lds_, st, pm);                                                          \
     RAMP_CHECK_LAUNCH();                                                                              \
     return RAMP_OK;                                                                                   \
   }
   TILE_CASE8(3, 1, 32, 2)
   TILE_CASE8(3, 2, 32, 2)
+  TILE_CASE8(3, 2, 64, 2)
   TILE_CASE8(3, 1, 64, 2)
   TILE_CASE8(1, 2, 32, 4)
   TILE_CASE8(1, 2, 64, 4)
@@ -1781,14 +1818,17 @@ int ramp_conv2d_nhwc_multi(const ramp_conv_job *jobs, int njobs, int H, int W, i
   if (fp8) return RAMP_EUNSUPPORTED;
 #define TILE_CASE(K, S, INF32, CIN, NT)                                                              \
   if (KH == K && stride == S && in_f32 == INF32 && Cin == CIN && (NT == 2 || cgcd_ok64)) {            \
+    constexpr int lds_ = conv_tile_lds_bytes(K, S, INF32, CIN, NT, false);                            \
+    if (conv_tile_attr(conv_tile_f16_kernel<K, S, INF32, CIN, NT>, lds_) != RAMP_OK) return RAMP_ELAUNCH; \
     hipLaunchKernelGGL((conv_tile_f16_kernel<K, S, INF32, CIN, NT>), dim3(tiles, cmax / (NT * 16), njobs), \
-                       block, 0, st, pm);                                                             \
+                       block, lds_, st, pm);                                                          \
     RAMP_CHECK_LAUNCH();                                                                              \
     return RAMP_OK;                                                                                   \
   }
   TILE_CASE(7, 2, true, 16, 2)
   TILE_CASE(3, 1, false, 32, 2)
   TILE_CASE(3, 2, false, 32, 2)
+  TILE_CASE(3, 2, false, 64, 2)
   TILE_CASE(3, 1, false, 64, 2)
   TILE_CASE(1, 2, false, 32, 4)
   TILE_CASE(1, 2, false, 64, 4)
@@ -1807,7 +1847,7 @@ int ramp_conv2d_stats_blocks(int H, int W, int Cin, int Cout, int KH, int stride
   if (f16 && !(dtype & RAMP_CONV_DIRECT)) {
     tiled = (KH == 7 && stride == 2 && in_f32 && Cin == 16 && Cout % 32 == 0) ||
             (!in_f32 && KH == 3 && stride == 1 && (Cin == 32 || Cin == 64) && Cout % 32 == 0) ||
-            (!in_f32 && KH == 3 && stride == 2 && Cin == 32 && Cout % 32 == 0) ||
+            (!in_f32 && KH == 3 && stride == 2 && (Cin == 32 || Cin == 64) && Cout % 32 == 0) ||
             (!in_f32 && KH == 1 && stride == 2 && (Cin == 32 || Cin == 64) && Cout % 64 == 0) ||
             (!in_f32 && KH == 1 && stride == 1 && (Cin == 64 || Cin == 128) && Cout % 64 == 0);
   }

@@ -411,6 +411,32 @@ def test_multiscale_encoder_hip_vs_aten():
     print("HIP fp32 encoder vs ATen, worst max-abs / max:", worst)
 
 
+@torch.no_grad()
+def test_multiscale_towers_two_source_input_equals_the_concatenation():
+    """fp16 MultiScale towers: the channel concatenations of reference extractor.py:300, 306 as two-source inputs of the
+    LDS-tiled conv kernel (ramp_conv_job.x2) against torch.cat copies fed to the same kernel: bit-equal maps"""
+    from rampvo_amd import conv_hip
+    from rampvo_amd.synthetic import SyntheticStream, make_network
+    stream = SyntheticStream(96, 128, 3, seed=6)
+    outs = {}
+    old = conv_hip._MS_PAIR
+    try:
+        for pair in (True, False):
+            conv_hip._MS_PAIR = pair
+            enc = make_network("MultiScale").patchify.encoder
+            enc.mixed_precision = True
+            res = []
+            for t in range(3):
+                im, ev, _, _ = stream.frame(t)
+                f, i = enc(events=ev.cuda(), images=im.cuda(), mask=torch.tensor([True]), reinit_hidden=(t == 0), out_scale=0.25)
+                res.append((f.clone(), i.clone()))
+            outs[pair] = res
+    finally:
+        conv_hip._MS_PAIR = old
+    for (f0, i0), (f1, i1) in zip(outs[True], outs[False]):
+        assert f0.dtype == torch.float16 and torch.equal(f0, f1) and torch.equal(i0, i1)
+
+
 @pytest.mark.parametrize("mode", ["SingleScale", "MultiScale"])
 def test_front_end_graph_replay_equals_eager(mode):
     """the hipGraph-captured front end (encoder + patch selection + gathers) replays to exactly what
