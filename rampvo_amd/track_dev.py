@@ -96,6 +96,20 @@ def supported(slam):
             and 6 * cfg.OPTIMIZATION_WINDOW <= 192)
 
 
+def unsupported_reason(slam):
+    """which of supported()'s conditions fails (for the one-time warning of Ramp_vo._enter_device)"""
+    cfg = slam.cfg
+    checks = [(slam.dtype == torch.half, "MIXED_PRECISION is off (the fp32 path is host driven)"),
+              (slam._chunked, "the feature plane does not fit the chunked pyramid layout"),
+              (slam.P == 3 and slam.DIM == 384, "patch size / feature width other than 3 / 384"),
+              ((slam.M * 3) % 16 == 0 and 3 * slam.M * 9 <= 8192, "PATCHES_PER_FRAME must be a multiple of 16, at most 303"),
+              (cfg.MOTION_MODEL in ("DAMPED_LINEAR",), "MOTION_MODEL other than DAMPED_LINEAR"),
+              (cfg.PATCH_LIFETIME <= cfg.REMOVAL_WINDOW + 1, "PATCH_LIFETIME exceeds REMOVAL_WINDOW + 1"),
+              (cfg.KEYFRAME_INDEX >= 2, "KEYFRAME_INDEX below 2"),
+              (6 * cfg.OPTIMIZATION_WINDOW <= 192, "OPTIMIZATION_WINDOW above 32")]
+    return "; ".join(msg for ok, msg in checks if not ok) or "unknown"
+
+
 class DeviceTrack:
     def __init__(self, slam):
         assert supported(slam)

@@ -1135,11 +1135,13 @@ def test_signal_word_releases_or_times_out_the_waiting_stream():
     side.synchronize()
     quick = time.perf_counter() - t0
     t0 = time.perf_counter()
-    sig.wait(side, 7, timeout_us=20000)                         # nobody stores 7: 20 ms, then on
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    sig.wait(side, 7, timeout_us=20000, status=status.data_ptr())   # nobody stores 7: 20 ms, then on -- and it says so
     with torch.cuda.stream(side):
         x += 1
     side.synchronize()
     slow = time.perf_counter() - t0
     assert float(x.item()) == 2.0
     assert quick < 0.015 and 0.018 <= slow < 0.2, (quick, slow)
-    assert _lib.lib().ramp_stream_wait_flag(None, None, 1, 10, 0) != 0        # no word: refused
+    assert int(status.item()) == 128                            # the time-out is recorded: whoever relied on the order raises
+    assert _lib.lib().ramp_stream_wait_flag(None, None, 1, 10, 0, None) != 0        # no word: refused

@@ -188,11 +188,11 @@ POLICY_NET, POLICY_WEIGHT, POLICY_POSES, POLICY_DEPTHS_P999, POLICY_DEPTHS_MAX =
 # are set aside: a depth of 20.2 in one leg and 19.9 in the other is 1 vs 19.9 after the reset)
 
 
-def _assert_policy_leg(m):
+def _assert_policy_leg(m, depths_max=None):
     assert m["at_reset_frac"] <= 0.06, m           # (the random-weight depths pile up below the d > 20 -> 1 reset: ~4 % within 0.5 of it at configs[2])
     assert m["net"] <= POLICY_NET and m["weight"] <= POLICY_WEIGHT, m
     assert m["poses_over_step"] <= POLICY_POSES and m["depths_p999"] <= POLICY_DEPTHS_P999, m
-    assert m["depths_max"] <= POLICY_DEPTHS_MAX, m
+    assert m["depths_max"] <= (POLICY_DEPTHS_MAX if depths_max is None else depths_max), m
 
 
 def _assert_fp16_leg(m, policy=None):
@@ -207,7 +207,9 @@ def _assert_fp16_leg(m, policy=None):
     if policy is None:
         assert m["depths_p999"] <= MIXED_DEPTHS_P999 * scale, m
     else:
-        _assert_policy_leg(policy)
+        # (the single worst of ~5k .. 10k patches at these windows: 5e-3 .. 0.14 over snapshots -- one fp16 step of a hidden
+        # state entry through a depth with Q ~ 1e4; the percentiles are what is bounded tightly)
+        _assert_policy_leg(policy, depths_max=0.5)
 
 
 @torch.no_grad()
@@ -454,6 +456,37 @@ def test_device_resident_steps_with_an_optimisation_window_that_never_fills():
     err = float(np.abs(a[4] - b[4]).max())
     print("padded-window device path vs host path: poses", err, "trajectory", float(np.abs(a[5] - b[5]).max()))
     assert err <= 1e-5
+
+
+@torch.no_grad()
+def test_config1_workload_64_patches_through_hip():
+    """BASELINE.json configs[0] is the reference's CPU plumbing case (SingleScale 640x480, 64 patches); its workload through
+    the HIP path: the tracker runs device resident at M = 64 (a multiple of 16: the one-launch commit and the device step
+    apply) and one update() from its snapshot agrees with the CPU oracle (fp32 leg)."""
+    slam, sd, cfgk = _steady_state_snapshot("SingleScale", "default", 64, 480, 640, 28, mixed=True)
+    assert slam._dev is not None and slam._dev._frames > 0 and slam.n > 8 and len(slam._ii) > 10000
+    e = _one_update_vs_cpu_oracle("SingleScale", "default", 480, 640, sd, cfgk, legs=(False,))
+    print(e)
+    _assert_fp32_leg(e["fp32"])
+
+
+def test_slow_paths_say_so_once():
+    """a configuration the device-resident step does not cover (fp32) warns once instead of silently running host driven"""
+    import warnings
+    from rampvo_amd.config import make_cfg
+    from rampvo_amd.Ramp_vo import Ramp_vo
+    from rampvo_amd.synthetic import SyntheticStream, make_network
+    slam = Ramp_vo(make_cfg("default", PATCHES_PER_FRAME=16, MIXED_PRECISION=False), make_network("SingleScale"),
+                   {"event_bias": True}, ht=128, wd=160)
+    stream = SyntheticStream(128, 160, 16, seed=2, device="cuda")
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        with torch.no_grad():
+            for t in range(16):
+                im, ev, K, mask = stream.frame(t)
+                slam(t, input_tensor=(ev, im, mask), intrinsics=K)
+    msgs = [str(w.message) for w in rec if "device-resident tracking step is not available" in str(w.message)]
+    assert slam.is_initialized and len(msgs) == 1 and "MIXED_PRECISION is off" in msgs[0], msgs
 
 
 @torch.no_grad()
