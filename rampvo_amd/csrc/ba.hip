@@ -475,6 +475,108 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// ------------------------------------------------------------------ K5, one workgroup per 6 x 6 block
+// S[6a.., 6b..] = B block - sum of the split-K partials (+ damping on the diagonal), y likewise (by the diagonal workgroup).
+// An off-diagonal block (a, b) takes the <= 2 pair records (i, j) = (a, b) / (b, a); the diagonal block (a, a) every record
+// with i == a or j == a (~2 x the window): 7 lanes per entry sum every 7th listed record in ascending order and the seven
+// partial sums are added in lane order -- fixed order, no atomics, 20-odd independent loads per thread instead of a chain
+// of chunks staged through LDS behind barriers (ba_assemble_kernel: one workgroup per POSE, 19 us of a 139 us call).
+#define BA_AP 7
+__global__ void __launch_bounds__(256)
+    ba_assemble2_kernel(const float *__restrict__ pairs, const int32_t *__restrict__ pair_ij,
+                        const int32_t *__restrict__ npairs, const float *__restrict__ S_part,
+                        const float *__restrict__ y_part, float *__restrict__ S, float *__restrict__ yv, int n6, int KS,
+                        int32_t *__restrict__ info) {
+  __shared__ int s_list[BA_MAXLIST], s_i[BA_MAXLIST], s_j[BA_MAXLIST];
+  __shared__ int s_wcnt[4];
+  __shared__ int s_base;
+  __shared__ float s_part[BA_AP][48];
+  const int a = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int np = *npairs;
+  const bool diag = a == b;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int g0 = 0; g0 < np; g0 += 256) {
+    const int g = g0 + tid;
+    int pi = -2, pj = -2;
+    if (g < np) { pi = pair_ij[2 * g]; pj = pair_ij[2 * g + 1]; }
+    const bool hit = diag ? (pi == a || pj == a) : ((pi == a && pj == b) || (pi == b && pj == a));
+    const unsigned long long m = __ballot(hit);
+    if (lane == 0) s_wcnt[wave] = __popcll(m);
+    __syncthreads();
+    int off = s_base;
+    for (int w = 0; w < wave; w++) off += s_wcnt[w];
+    off += __popcll(m & ((1ull << lane) - 1ull));
+    if (hit && off < BA_MAXLIST) { s_list[off] = g; s_i[off] = pi; s_j[off] = pj; }
+    __syncthreads();
+    if (tid == 0) s_base += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+    __syncthreads();
+  }
+  const int nl = min(s_base, BA_MAXLIST);
+  if (s_base > BA_MAXLIST && tid == 0 && info) atomicOr(info, 2);       // (never a silent truncation)
+  // threads [0, 36 AP): entry e = tid / AP (x = e / 6, y = e % 6), partial lane pl = tid % AP; [36 AP, 42 AP): gradient x
+  const int e = tid / BA_AP, pl = tid - e * BA_AP;
+  float acc = 0.f;
+  if (e < 36) {
+    const int x = e / 6, y = e - x * 6;
+    for (int l = pl; l < nl; l += BA_AP) {
+      const int i = s_i[l], j = s_j[l];
+      const float *pr = pairs + (size_t)s_list[l] * BA_PAIR + x * 6 + y;
+      // (the four conditions and their order are ba_assemble_kernel's)
+      const float v0 = (i == a && i == b) ? pr[0] : 0.f, v1 = (j == a && j == b) ? pr[36] : 0.f;
+      const float v2 = (i == a && j == b) ? pr[72] : 0.f, v3 = (j == a && i == b) ? pr[108] : 0.f;
+      if (i == a && i == b) acc += v0;
+      if (j == a && j == b) acc += v1;
+      if (i == a && j == b) acc += v2;
+      if (j == a && i == b) acc += v3;
+    }
+    s_part[pl][e] = acc;
+  }
+  if (diag && tid < 6 * BA_AP) {                     // the gradient's six entries, the same way (threads 0 .. 41 again)
+    const int x = tid / BA_AP, p2 = tid - x * BA_AP;
+    float g = 0.f;
+    for (int l = p2; l < nl; l += BA_AP) {
+      const float *pr = pairs + (size_t)s_list[l] * BA_PAIR;
+      if (s_i[l] == a) g += pr[144 + x];
+      if (s_j[l] == a) g += pr[150 + x];
+    }
+    s_part[p2][36 + x] = g;
+  }
+  __syncthreads();
+  if (tid < 36) {
+    const int x = tid / 6, y = tid - x * 6;
+    float bs = 0.f;
+#pragma unroll
+    for (int q = 0; q < BA_AP; q++) bs += s_part[q][tid];
+    const int r = 6 * a + x, c = 6 * b + y;
+    float sp = 0.0f;
+    {
+      float v[64];
+#pragma unroll
+      for (int u = 0; u < 64; u++) v[u] = S_part[((size_t)(u < KS ? u : KS - 1) * n6 + r) * n6 + c];
+#pragma unroll
+      for (int u = 0; u < 64; u++) sp += u < KS ? v[u] : 0.0f;
+    }
+    float sv = bs - sp;
+    if (r == c) sv += (1e-4f * sv + 1.0f);
+    S[(size_t)r * n6 + c] = sv;
+  } else if (tid < 42 && diag) {
+    const int x = tid - 36, r = 6 * a + x;
+    float vs = 0.f;
+#pragma unroll
+    for (int q = 0; q < BA_AP; q++) vs += s_part[q][tid];
+    float yp = 0.0f;
+    {
+      float v[64];
+#pragma unroll
+      for (int u = 0; u < 64; u++) v[u] = y_part[(size_t)(u < KS ? u : KS - 1) * n6 + r];
+#pragma unroll
+      for (int u = 0; u < 64; u++) yp += u < KS ? v[u] : 0.0f;
+    }
+    yv[r] = vs - yp;
+  }
+}
+
 // ------------------------------------------------------------------ K6
 // Single workgroup, matrix in LDS, right-looking Cholesky with ONE barrier per column:
 //   * the pivot d = A[j][j] is read by every thread (no broadcast step); the trailing update uses the
@@ -889,8 +991,14 @@ static int ba_iterate(float *poses, float *patches, const float *intrinsics, con
     if (N > 0) {
       hipLaunchKernelGGL(ba_schur_kernel, dim3(w.tiles, w.tiles, w.KS), dim3(256), 0, st, w.Erow,
                          w.Qv, w.uv, nk, w.S_part, w.y_part, n6, w.KS);
-      hipLaunchKernelGGL(ba_assemble_kernel, dim3(N, ramp_cdiv(6 * n6, 192)), dim3(256), 0, st, w.pairs, w.pair_ij, np,
-                         w.S_part, w.y_part, w.S, w.yv, n6, w.KS, info);
+      static int asm2 = -1;                          // RAMP_BA_ASM2=0: one workgroup per pose (A/B runs)
+      if (asm2 < 0) { const char *e = getenv("RAMP_BA_ASM2"); asm2 = e ? atoi(e) : 1; }
+      if (asm2)
+        hipLaunchKernelGGL(ba_assemble2_kernel, dim3(N, N), dim3(256), 0, st, w.pairs, w.pair_ij, np, w.S_part, w.y_part,
+                           w.S, w.yv, n6, w.KS, info);
+      else
+        hipLaunchKernelGGL(ba_assemble_kernel, dim3(N, ramp_cdiv(6 * n6, 192)), dim3(256), 0, st, w.pairs, w.pair_ij, np,
+                           w.S_part, w.y_part, w.S, w.yv, n6, w.KS, info);
       const int chol = ba_chol_variant();
       if (chol == 1 || (chol == 0 && n6 % 6 == 0))      // blocked: every 6N
         hipLaunchKernelGGL(ba_cholb_kernel<32>, dim3(1), dim3(1024), lds, st, w.S, w.yv, w.dX, info, n6);

@@ -9,8 +9,9 @@ for e in "${envs[@]}"; do
 import json, sys
 d = json.load(open("/tmp/ab_line.json")); c = d["config"]
 u, b, en, r = (d.get(k) or {} for k in ("roofline_update", "roofline_ba", "roofline_encoder", "roofline"))
-print("%-36s %7.1f kf/s np %6s | corr %5.1f upd %5.1f (alone %s) ba %5.1f (alone %s) fe %s (tail %s)" % (
+print("%-36s %7.1f kf/s np %6s | corr %5.1f upd %5.1f (alone %s) ba %5.1f (alone %s) fe %s (tail %s) | E %s..%s live %s" % (
     sys.argv[1], d["value"], c.get("non_pipelined_kfps"), r.get("mean_launch_us", 0), u.get("mean_call_us", 0), u.get("mean_call_us_alone"),
-    b.get("mean_call_us", 0), b.get("mean_call_us_alone"), en.get("mean_front_end_us"), en.get("mean_front_end_us_next_to_the_tail")))
+    b.get("mean_call_us", 0), b.get("mean_call_us_alone"), en.get("mean_front_end_us"), en.get("mean_front_end_us_next_to_the_tail"),
+    c.get("edges"), c.get("edges_end"), r.get("live_factor_fraction_fine_coarse")))
 PY
 done
