@@ -240,19 +240,29 @@ class DeviceProbe:
         self.mode, self.modes = "all", []              # "corr": only the correlation launch is bracketed (the timed region)
         self.corr_inst_ms = []
         self.live_pairs, self.live_edges = {"live": [], "compact": []}, {"live": [], "compact": []}
+        self.fp32, self.cur = False, None
 
     def install(self):
         from rampvo_amd import track_dev
         inner, probe = track_dev.DeviceTrack.step, self
 
         def step(dv, counter, flags, **k):
-            on = probe.enabled and probe.mode and probe.used < len(probe.sets) and (flags & track_dev.UPDATE)
+            # (an fp32 step is two calls -- PRE: reprojection + correlation, POST: BA + keyframe(); they share one event set)
+            starts = flags & (track_dev.UPDATE | track_dev.UPDATE_PRE)
+            if starts:
+                on = bool(probe.enabled and probe.mode and probe.used < len(probe.sets))
+                probe.cur = probe.used if on else None
+                if on:
+                    probe.edges.append(int(dv.lazy_state()[track_dev.DYN_E]))      # a frame or two old: fine for a mean
+                    probe.modes.append(probe.mode)
+                    probe.fp32 = bool(getattr(dv, "fp32", False))
+                    probe.used += 1
+            elif not (flags & track_dev.UPDATE_POST):
+                probe.cur = None
+            idx = getattr(probe, "cur", None)
             for i in range(5):
-                dv.t.probe[i] = probe.sets[probe.used][i].cuda_event if on and (probe.mode not in ("corr", "live", "compact") or i < 2) else None
-            if on:
-                probe.edges.append(int(dv.lazy_state()[track_dev.DYN_E]))      # a frame or two old: fine for a mean
-                probe.modes.append(probe.mode)
-                probe.used += 1
+                dv.t.probe[i] = (probe.sets[idx][i].cuda_event
+                                 if idx is not None and (probe.mode not in ("corr", "live", "compact") or i < 2) else None)
             return inner(dv, counter, flags, **k)
 
         track_dev.DeviceTrack.step = step
@@ -264,11 +274,13 @@ class DeviceProbe:
             elif mode in ("live", "compact"):  # the live-factor legs (every reprojection inside the plane)
                 self.live_pairs[mode].append((evs[0], evs[1])); self.live_edges[mode].append(E)
             elif mode == "alone":              # the sequential pass: nothing else on the GPU
-                utimer.alone_ms.append(evs[1].elapsed_time(evs[2]))
+                if not self.fp32:              # (fp32 steps: the operator is launched from Python, timed by UpdateTimer's hook)
+                    utimer.alone_ms.append(evs[1].elapsed_time(evs[2]))
                 btimer.alone_ms.append(evs[3].elapsed_time(evs[4]))
             else:                              # the instrumented pass behind it
                 self.corr_inst_ms.append(evs[0].elapsed_time(evs[1]))
-                utimer.pairs.append((evs[1], evs[2])); utimer.edges.append(E)
+                if not self.fp32:
+                    utimer.pairs.append((evs[1], evs[2])); utimer.edges.append(E)
                 btimer.pairs.append((evs[3], evs[4])); btimer.meta.append((E, opt_window, 2))
 
 
@@ -760,12 +772,13 @@ def main():
     dt = time.perf_counter() - tic
     gate_kind = "signal word stored by the gru launch" if getattr(slam, "_gate_by_flag", False) else "event"
     ctimer.enabled = etimer.enabled = btimer.enabled = utimer.enabled = False
+    fp32_dev = device_step and bool(getattr(dv, "fp32", False))
     if dprobe is not None and device_step:
-        dprobe.mode, etimer.enabled = "all", True
+        dprobe.mode, etimer.enabled, utimer.enabled = "all", True, fp32_dev
         for _ in range(n_inst):
             step()
         torch.cuda.synchronize()
-        etimer.enabled = False
+        etimer.enabled = utimer.enabled = False
     if dprobe is not None:
         dprobe.enabled = False
 
@@ -839,6 +852,8 @@ def main():
                                       "".join([", KEYFRAME_THRESH %g" % args.keyframe_thresh if args.keyframe_thresh is not None else "",
                                                ", fp8-MFMA encoder" if args.encoder_fp8 else "",
                                                ", fp32 everywhere" if not args.mixed else "",
+                                               ", device-resident steps with the operator's GEMMs launched by the host"
+                                               if (not args.mixed and device_step) else "",
                                                ", frame pipelining off" if not args.pipeline else "",
                                                ", host-driven steps (RAMP_DEVICE_STEP=0)"
                                                if os.environ.get("RAMP_DEVICE_STEP", "1") != "1" else ""])),

@@ -626,6 +626,12 @@ int ramp_upd_softagg_finish(const float *frag, const int32_t *seg_start, const i
 #define RAMP_TRACK_MM_GIVEN 8  /* (tests) keyframe(): take the two flow magnitudes from t->mm instead of computing */
 #define RAMP_TRACK_WRAP_COORDS 16 /* (measurement) move every reprojection into the target plane by whole plane sizes
                                      before the correlation launch: bench.py's roofline leg with every factor live    */
+#define RAMP_TRACK_UPDATE_PRE 64   /* the part of update() in front of the update operator: reprojection + correlation        */
+#define RAMP_TRACK_UPDATE_POST 128 /* the part behind it: two BA iterations + point cloud, from t->target / t->weight.  With
+                                      PRE and POST as two calls the caller runs the operator in between on t->coords / t->corr
+                                      and leaves the new hidden state in t->net[0], target / weight in their buffers -- the
+                                      fp32 path (MIXED_PRECISION off), whose Linear layers are library GEMMs; it still never
+                                      reads the device (launch sizes = E_bound)                                          */
 #define RAMP_TRACK_COMPACT_COORDS 32 /* (measurement) the same, and every patch with unit pixel spacing around its centre (a
                                      converged tracker's factors: one 10 x 10 union window per level)                  */
 
@@ -699,6 +705,10 @@ typedef struct ramp_track {
   int32_t E_hint;                     /* optional (> 0): the caller's estimate of the live factor count (E_bound is an upper
                                        * bound): picks the gru launch's tile (64 / 80 rows per workgroup)                    */
   uint32_t gate_seq;                  /* with gate_flag: the value the update operator's last launch (gru) stores into it  */
+  int32_t feat_fp32;                  /* 0: fp16 features (imap / gmap / fmap rows of 2-byte elements, chunked [h][C/8][w][8] pyramid
+                                       * planes, corr [E_cap][896] fp16); 1: fp32 features, plain NHWC planes, corr [E_cap][882]
+                                       * fp32 (correlation by corr_kernel<float>, the reference kernel's summation order) --
+                                       * only with RAMP_TRACK_UPDATE_PRE / _POST                                          */
   uint32_t *gate_flag;                /* optional signal word (ramp_signal_alloc): "the next frame's front end may start"  *
                                        * without a packet on this stream -- the other stream waits with                    *
                                        * ramp_stream_wait_flag (a hipEventRecord costs ~5 us between two kernels of the   *

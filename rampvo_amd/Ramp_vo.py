@@ -745,7 +745,7 @@ class Ramp_vo:
                                             pre_replay=(lambda: self._gate_wait(fe)) if ahead else self._fe_delay)
             self._ev_fe_done.record(fe)
             cur.wait_event(self._ev_fe_done)
-            if _WARM:
+            if _WARM and not dv.fp32:
                 # (behind the event: the frame does not wait for it) the window's correlation planes back into the
                 # memory-side cache while the previous frame's bundle adjustment is still running
                 with torch.cuda.stream(fe):
@@ -760,12 +760,30 @@ class Ramp_vo:
         if patches is None or not dv.bind_front_end(ex, patches):
             self.settle()                           # outputs the one-launch commit cannot take: host-driven frame
             return self._track_tail(tstamp, out, intrinsics)
-        dv.bind_weights(self.network.update.fused(self.dtype))
+        if not dv.fp32:
+            dv.bind_weights(self.network.update.fused(self.dtype))
         kq, k_dev = self._intrinsics_row(intrinsics, True)
         if k_dev is not None:
             dv.k_new.copy_(k_dev)
             self._last_K, self._last_K_raw = kq, self._K_raw_now
         self.tlist.append(tstamp)
+        if dv.fp32:
+            # MIXED_PRECISION off: the update operator's Linear layers are library GEMMs, issued from here between the two
+            # halves of the step -- on the launch bound's rows, sizes never read back (csrc/track.hip RAMP_TRACK_UPDATE_PRE /
+            # _POST); everything else as in the fp16 step
+            Eb = dv.factor_bound(self.counter)
+            dv.step(self.counter, track_dev.COMMIT | track_dev.UPDATE_PRE, k_new=dv.k_new if k_dev is not None else None,
+                    E_bound=Eb)
+            # the GEMMs take their row count from the host: wait (polling pinned memory, no device call) for the sizes the
+            # previous frame's plan wrote -- the GPU is busy with the correlation launch enqueued above meanwhile
+            E = int(dv.wait_frame(self.counter - 1)[track_dev.DYN_E])
+            self._device_operator_fp32(dv, E)
+            if self.inputs_ready:
+                self._ev_gate.record(cur)                        # the next frame's front end may start (next to BA)
+            dv.step(self.counter, track_dev.UPDATE_POST | track_dev.KEYFRAME, E_bound=E)
+            self._gate_armed, self._gate_by_flag = self.inputs_ready, False
+            self.counter += 1
+            return
         sig = self._gate_signal() if self.inputs_ready else None
         if sig is not None:
             self._gate_seq += 1
@@ -775,6 +793,23 @@ class Ramp_vo:
                 gate_flag=sig.ptr if sig is not None else None, gate_seq=self._gate_seq)
         self._gate_armed, self._gate_by_flag = self.inputs_ready, sig is not None
         self.counter += 1
+
+    def _device_operator_fp32(self, dv, Eb):
+        """the update operator of a device-resident fp32 step (reference :280-297) on the first Eb rows of the device-side
+        factor list: GEMMs through torch (hipBLASLt) + the row kernels of csrc/update.hip, exactly the host-driven path's
+        calls; rows between the live factor count and Eb are defined dummies (zero state row, no neighbour, group 0)"""
+        fu = self.network.update.fused(torch.float32)
+        g = dv.graph[dv.cur]
+        coords = dv.coords[:Eb]
+        prev, work, out = dv.net[0], dv.net[1], dv.net[2]
+        out32, relu_t = fu.hidden(prev, self.imap_.view(-1, self.DIM), g[2, :Eb], self.M * self.mem, dv.corr[:Eb],
+                                  dv.plan_view(Eb), net_map=g[3, :Eb], net32_buf=work, out32_buf=out)
+        target, weight, _ = fu.target_weight(fu.heads(relu_t), coords, self.wd // 4, self.ht // 4)
+        dv.target[:Eb].copy_(target[0])
+        dv.weight[:Eb].copy_(weight[0])
+        # the new hidden state is dv.net[0] from here on (the edit kernel's row map indexes it)
+        dv.net[0], dv.net[2] = dv.net[2], dv.net[0]
+        dv.t.net[0], dv.t.net[2] = dv.net[0].data_ptr(), dv.net[2].data_ptr()
 
     def _enter_device(self):
         """hand the state over to the device-resident step if this tracker / configuration supports it and the

@@ -346,6 +346,7 @@ struct PlanDyn {
   int32_t *order[2], *gid[2], *seg[2], *ngroups[2];
   int64_t *ukeys[2];
   int Kcap[2];
+  int E_fill;            // gid / ix / jx get defined entries up to here (the next step's launch bound)
   int Gcap[2];           // capacity of seg / ukeys (groups): more groups than that are flagged (status bit 8), never written
   int32_t *status;
 };
@@ -514,6 +515,12 @@ __global__ void __launch_bounds__(256) plan_segsort_kernel(const PlanDyn p, int6
     const int z = grp * 256 + threadIdx.x;
     if (z < hist_words) p.hist[0][z] = 0;               // hist[0] and hist[1] are one allocation
   }
+  // rows between the live factor count and the launch bound: defined entries (no neighbour, group 0) -- a caller that runs
+  // its own update operator on E_bound rows gathers through them
+  for (int e = p.dyn[RAMP_DYN_E] + grp * 256 + threadIdx.x; e < p.E_fill; e += gridDim.x * 256) {
+    p.gid[g][e] = 0;
+    if (g == 0 && ix) { ix[e] = -1; jx[e] = -1; }
+  }
   // the host's lazy copy of the sizes (mapped pinned memory): nothing changes them after this launch has started
   // (word RAMP_DYN_FRAME2 repeats RAMP_DYN_FRAME in the other 64-byte half: the host re-reads a copy whose tags differ)
   if (mirror && g == 1 && grp == 0 && threadIdx.x < RAMP_DYN_WORDS)
@@ -586,6 +593,7 @@ int ramp_i_plan_dyn(const int64_t *g4, int E_cap, int E_grid, const int32_t *dyn
   p.order[1] = ij_order; p.gid[1] = ij_gid; p.seg[1] = ij_seg; p.ngroups[1] = ij_ngroups; p.ukeys[1] = ij_ukeys;
   p.Kcap[0] = kkey_cap; p.Kcap[1] = pkey_cap;
   p.Gcap[0] = kk_cap; p.Gcap[1] = ij_cap; p.status = status;
+  p.E_fill = E_grid > 0 && E_grid < E_cap ? E_grid : E_cap;
   // (the histograms are zero on entry: the caller's workspace starts zeroed and every plan clears them at its end)
   const int nb = ramp_cdiv(E_grid > 0 && E_grid < E_cap ? E_grid : E_cap, PLAN_EPB);
   const bool lds = kkey_cap <= PLAN_LDS_K && pkey_cap <= PLAN_LDS_K;

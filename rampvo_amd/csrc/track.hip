@@ -23,7 +23,7 @@ struct TrkEdit {
   const float *mm;
   const int64_t *gin;      // [4][E_cap]
   int64_t *gout;
-  int E_cap, M, r, removal_window, keyframe_index, log_cap, n_rows;
+  int E_cap, M, r, removal_window, keyframe_index, log_cap, n_rows, pad;
   double thresh;
   int32_t *cnt, *off, *fmin;   // per edit workgroup: kept factors, their exclusive prefix, lowest frame index kept
   const int64_t *tstamps;
@@ -220,7 +220,12 @@ __global__ void __launch_bounds__(256) trk_apply_kernel(const TrkEdit p) {
   // patches -> the last r frames incl. itself), patch-major like the reference's meshgrid(indexing='ij')
   const int Ek = p.dyn[RAMP_DYN_EKEPT], ne = p.dyn[RAMP_DYN_E] - Ek;
   const int idx = (b - p.nb) * 256 + tid;
-  if (idx >= ne) return;
+  if (idx >= ne) {
+    // rows between the live count and the next step's launch bound: defined (harmless) entries -- a caller that runs its
+    // own operator on E_bound rows (the fp32 path) gathers through them
+    if (idx < ne + p.pad && Ek + idx < p.E_cap) { oi[Ek + idx] = 0; oj[Ek + idx] = 0; ok[Ek + idx] = 0; orow[Ek + idx] = -1; }
+    return;
+  }
   const int n1 = p.dyn[RAMP_DYN_N];
   const int lo = max(n1 - p.r, 0);
   const int nf = p.M * (max(n1 - 1, 0) - lo);
@@ -274,13 +279,15 @@ static int trk_edit_fill(const ramp_track *t, int cur, int64_t counter, TrkEdit 
   p.dyn = t->dyn; p.mm = t->mm; p.gin = t->graph[cur]; p.gout = t->graph[1 - cur];
   p.E_cap = t->E_cap; p.M = t->M; p.r = t->patch_lifetime; p.removal_window = t->removal_window;
   p.keyframe_index = t->keyframe_index; p.log_cap = t->log_cap; p.thresh = t->keyframe_thresh; p.n_rows = t->n_rows;
+  p.pad = 4 * (2 * t->patch_lifetime - 1) * t->M;
   p.nb = ramp_cdiv(t->E_cap, TRK_EB);
   p.cnt = t->edit_ws; p.off = t->edit_ws + p.nb; p.fmin = t->edit_ws + 2 * p.nb;
   p.tstamps = t->tstamps; p.poses = t->poses; p.dlog = t->dlog; p.counter = counter;
   const int PP = t->P * t->P;
-  const long fb1 = (long)t->feat_h * t->feat_w * 128 * 2, fb2 = (long)(t->feat_h / 4) * (t->feat_w / 4) * 128 * 2;
+  const long es = t->feat_fp32 ? 4 : 2;                // bytes per feature element
+  const long fb1 = (long)t->feat_h * t->feat_w * 128 * es, fb2 = (long)(t->feat_h / 4) * (t->feat_w / 4) * 128 * es;
   void *bufs[9] = {t->tstamps, t->colors, t->poses, t->patches, t->intrinsics, t->imap, t->gmap, t->fmap1, t->fmap2};
-  const long rb[9] = {8, (long)t->M * 3, 28, (long)t->M * 3 * PP * 4, 16, (long)t->M * 384 * 2, (long)t->M * PP * 128 * 2, fb1, fb2};
+  const long rb[9] = {8, (long)t->M * 3, 28, (long)t->M * 3 * PP * 4, 16, (long)t->M * 384 * es, (long)t->M * PP * 128 * es, fb1, fb2};
   const int md[9] = {0, 0, 0, 0, 0, t->mem, t->mem, t->mem, t->mem};
   p.nbuf = 9;
   for (int i = 0; i < 9; i++) {
@@ -445,12 +452,43 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
     if (!t->fe_colors || !t->fe_imap || !t->fe_gmap || !t->fe_fmap1 || !t->fe_fmap2 || !t->fe_patches) return RAMP_EINVAL;
     const void *src[5] = {t->fe_colors, t->fe_imap, t->fe_gmap, t->fe_fmap1, t->fe_fmap2};
     void *base[5] = {t->colors, t->imap, t->gmap, t->fmap1, t->fmap2};
-    const long bytes[5] = {(long)t->M * 3, (long)t->M * 384 * 2, (long)t->M * PP * 128 * 2,
-                           (long)t->feat_h * t->feat_w * 128 * 2, (long)(t->feat_h / 4) * (t->feat_w / 4) * 128 * 2};
+    const long es = t->feat_fp32 ? 4 : 2;
+    const long bytes[5] = {(long)t->M * 3, (long)t->M * 384 * es, (long)t->M * PP * 128 * es,
+                           (long)t->feat_h * t->feat_w * 128 * es, (long)(t->feat_h / 4) * (t->feat_w / 4) * 128 * es};
     const int mod[5] = {0, t->mem, t->mem, t->mem, t->mem};
     TRK_DO(ramp_i_frame_commit_dyn(t->poses, t->motion_model, t->motion_damping, t->tstamps, counter, t->index_map,
                                    t->intrinsics, k_new, t->patches, 3, t->M, t->P, t->fe_patches, 5, src, base, bytes,
                                    mod, dyn, (t->median && t->keyframe_index >= 4) ? t->median : nullptr, t->dyn + RAMP_DYN_STATUS, (Eb < Ec && folded) ? Eb : 0, t->n_rows, st));
+  }
+  if ((flags & RAMP_TRACK_UPDATE) && t->feat_fp32) return RAMP_EUNSUPPORTED;   // (fp32: PRE, the caller's operator, POST)
+  if (flags & RAMP_TRACK_UPDATE_PRE) {
+    if (!t->coords || !t->corr) return RAMP_EINVAL;
+    TRK_DO(ramp_i_transform_dyn(t->poses, t->patches, t->intrinsics, ii, jj, kk, t->coords, Eb, dyn, st));
+    ramp_corr_level lv[2];
+    lv[0].fmap = t->fmap1; lv[0].H2 = t->feat_h; lv[0].W2 = t->feat_w; lv[0].coord_div = 1.0f;
+    lv[1].fmap = t->fmap2; lv[1].H2 = t->feat_h / 4; lv[1].W2 = t->feat_w / 4; lv[1].coord_div = 4.0f;
+    TRK_PROBE(0);
+    if (t->feat_fp32)
+      TRK_DO(ramp_i_corr_fwd(t->gmap, lv, 2, t->coords, kk, jj, t->ij_order, t->corr, 882, (long)t->M * t->mem, t->mem, Eb,
+                             t->mem * t->M, t->mem, 128, t->P, 3, RAMP_F32, RAMP_NHWC, dyn, st));
+    else
+      TRK_DO(ramp_i_corr_fwd(t->gmap, lv, 2, t->coords, kk, jj, t->ij_order, t->corr, 896, (long)t->M * t->mem, t->mem, Eb,
+                             t->mem * t->M, t->mem, 128, t->P, 3, RAMP_F16, RAMP_NHWC8, dyn, st));
+    TRK_PROBE(1);
+  }
+  if (flags & RAMP_TRACK_UPDATE_POST) {
+    if (!t->target || !t->weight || !t->ba_ws) return RAMP_EINVAL;
+    TRK_PROBE(3);
+    TRK_DO(ramp_i_ba_dyn(t->poses, t->patches, t->intrinsics, t->target, t->weight, t->lmbda, ii, jj, kk, Eb, t->P,
+                         t->n_rows, t->n_rows * t->M, t->opt_window, 2, t->kk_order, t->kk_seg, t->kk_ngroups, t->kk_ukeys,
+                         t->kk_cap, t->ij_order, t->ij_seg, t->ij_ngroups, t->ij_cap, t->ba_ws, t->ba_ws_bytes,
+                         t->dyn + RAMP_DYN_STATUS, dyn, st));
+    TRK_PROBE(4);
+    pc_with_mm = t->points && t->ixm && (flags & RAMP_TRACK_KEYFRAME) && !(flags & RAMP_TRACK_MM_GIVEN) && t->mm;
+    if (t->points && t->ixm && !pc_with_mm)
+      TRK_DO(ramp_i_point_cloud_dyn(t->poses, t->patches, t->intrinsics, t->ixm, t->points, t->m_cap, dyn, t->M, st));
+    if (!(flags & RAMP_TRACK_KEYFRAME))
+      hipLaunchKernelGGL(trk_iota_kernel, dim3(ramp_cdiv(Eb, 256)), dim3(256), 0, st, t->graph[cur] + 3 * (size_t)Ec, t->dyn);
   }
   if (flags & RAMP_TRACK_UPDATE) {
     const ramp_track_weights &w = t->w;
@@ -558,7 +596,7 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
     TRK_DO(trk_edit_fill(t, cur, counter, p));
     hipLaunchKernelGGL(trk_flag_kernel, dim3(p.nb), dim3(256), 0, st, p);
     hipLaunchKernelGGL(trk_decide_kernel, dim3(1), dim3(256), 0, st, p);
-    int gx = p.nb + ramp_cdiv(new_cap, 256);
+    int gx = p.nb + ramp_cdiv(new_cap + p.pad, 256);
     if (gx < 1024) gx = 1024;                                         // column chunks of the row shift
     hipLaunchKernelGGL(trk_apply_kernel, dim3(gx, 1 + p.nbuf), dim3(256), 0, st, p);
     RAMP_CHECK_LAUNCH();

@@ -22,7 +22,7 @@ DYN_WORDS = 32
 DYN_FRAME2 = 31          # repeats DYN_FRAME in the other 64-byte half of the block (a torn lazy copy shows)
 LOG_WORDS = 12
 MAX_AHEAD = 6            # frames the host may enqueue ahead of the newest lazy copy of the sizes (Ramp_vo._track_device)
-COMMIT, UPDATE, KEYFRAME, MM_GIVEN, WRAP_COORDS, COMPACT_COORDS = 1, 2, 4, 8, 16, 32
+COMMIT, UPDATE, KEYFRAME, MM_GIVEN, WRAP_COORDS, COMPACT_COORDS, UPDATE_PRE, UPDATE_POST = 1, 2, 4, 8, 16, 32, 64, 128
 CORR_ROW = 896
 
 
@@ -55,7 +55,7 @@ class Track(ctypes.Structure):
                 + _ptr_fields(["fg", "ykk", "hkk", "yij", "hij", "relu_t", "sagg_frag", "target", "weight", "ba_ws"])
                 + [("ba_ws_bytes", c_sz)]
                 + _ptr_fields(["mm", "median", "dlog", "edit_ws", "dyn_host", "dyn_host_dev"]) + [("probe", c_p * 5), ("E_hint", c_i),
-                   ("gate_seq", ctypes.c_uint32), ("gate_flag", c_p)])
+                   ("gate_seq", ctypes.c_uint32), ("feat_fp32", c_i), ("gate_flag", c_p)])
 
 
 _E_EST_LAST = int(os.environ.get("RAMP_E_EST_LAST", "1"))        # 0: the largest of the last 64 copies (round 3's first rule)
@@ -88,9 +88,13 @@ class Signal:
 
 
 def supported(slam):
-    """the fused fp16 path on the tracker's own chunked buffers, with a full optimisation window"""
+    """the fused fp16 path on the tracker's own chunked buffers -- or the fp32 path (plain NHWC fp32 buffers; its update
+    operator's library GEMMs are issued by the host between the two halves of the step, still without reading the device) --
+    with a full optimisation window"""
     cfg = slam.cfg
-    return (slam.dtype == torch.half and slam._chunked and slam._lazy_net and slam.P == 3 and slam.DIM == 384
+    layout_ok = (slam.dtype == torch.half and slam._chunked) or (slam.dtype == torch.float and not slam._chunked
+                                                                 and os.environ.get("RAMP_DEVICE_STEP_FP32", "1") == "1")
+    return (layout_ok and slam._lazy_net and slam.P == 3 and slam.DIM == 384
             and (slam.M * 3) % 16 == 0 and 3 * slam.M * 9 <= 8192 and cfg.MOTION_MODEL in ("DAMPED_LINEAR",)
             and cfg.PATCH_LIFETIME <= cfg.REMOVAL_WINDOW + 1 and cfg.KEYFRAME_INDEX >= 2
             and 6 * cfg.OPTIMIZATION_WINDOW <= 192)
@@ -99,8 +103,9 @@ def supported(slam):
 def unsupported_reason(slam):
     """which of supported()'s conditions fails (for the one-time warning of Ramp_vo._enter_device)"""
     cfg = slam.cfg
-    checks = [(slam.dtype == torch.half, "MIXED_PRECISION is off (the fp32 path is host driven)"),
-              (slam._chunked, "the feature plane does not fit the chunked pyramid layout"),
+    checks = [(slam.dtype == torch.half or os.environ.get("RAMP_DEVICE_STEP_FP32", "1") == "1",
+               "MIXED_PRECISION is off and RAMP_DEVICE_STEP_FP32=0 (the fp32 path is host driven)"),
+              (slam._chunked or slam.dtype == torch.float, "the feature plane does not fit the chunked pyramid layout"),
               (slam.P == 3 and slam.DIM == 384, "patch size / feature width other than 3 / 384"),
               ((slam.M * 3) % 16 == 0 and 3 * slam.M * 9 <= 8192, "PATCHES_PER_FRAME must be a multiple of 16, at most 303"),
               (cfg.MOTION_MODEL in ("DAMPED_LINEAR",), "MOTION_MODEL other than DAMPED_LINEAR"),
@@ -137,15 +142,16 @@ class DeviceTrack:
         self.ix, self.jx, self.kj = z(E_cap, i64), z(E_cap, i64), z(E_cap, i32)
         # (zeroed: the plan's histograms are cleared by each plan at its end instead of by a memset launch at its start)
         self.plan_ws = z(lib.ramp_track_plan_workspace_bytes(E_cap, self.kkey_cap, self.pkey_cap), torch.uint8)
+        self.fp32 = slam.dtype == torch.float
         self.coords = e((E_cap, 2, 3, 3), f32)
-        self.corr = e((E_cap, CORR_ROW), f16)
+        self.corr = e((E_cap, 882), f32) if self.fp32 else e((E_cap, CORR_ROW), f16)
         self.net = [z((E_cap, 384), f32) for _ in range(3)]
-        self.fg = e((E_cap, 768), f16)
+        self.fg = e((16 if self.fp32 else E_cap, 768), f16)
         self.ykk, self.hkk = z((kk_cap, 384), f16), z((kk_cap, 384), f16)
         self.yij, self.hij = z((ij_cap, 384), f16), z((ij_cap, 384), f16)
-        self.relu_t = e((E_cap, 384), f16)
+        self.relu_t = e((16 if self.fp32 else E_cap, 384), f16)
         # fragment table of the fused SoftAgg (csrc/update_mlp.hip::upd_softagg_kernel): (m, z, a)[384] per run
-        self.sagg_frag = e((lib.ramp_upd_softagg_frag_rows(E_cap, max(kk_cap, ij_cap)), 3, 384), f32)
+        self.sagg_frag = e((16 if self.fp32 else lib.ramp_upd_softagg_frag_rows(E_cap, max(kk_cap, ij_cap)), 3, 384), f32)
         self.target, self.weight = z((E_cap, 2), f32), z((E_cap, 2), f32)
         self.ba_ws = e(lib.ramp_track_ba_workspace_bytes(E_cap, slam.N, M, cfg.OPTIMIZATION_WINDOW, kk_cap, ij_cap),
                        torch.uint8)
@@ -164,7 +170,8 @@ class DeviceTrack:
         self._keep = []
         t = self.t = Track()
         assert ctypes.sizeof(Track) == lib.ramp_track_sizeof(), "ramp_track mirror out of date"
-        h, w = slam.fmap1_.shape[1], slam.fmap1_.shape[3]
+        # ring slots: [mem, h, 16, w, 8] (fp16, chunked) or [mem, h, w, 128] (fp32)
+        h, w = slam.fmap1_.shape[1], (slam.fmap1_.shape[3] if slam._chunked else slam.fmap1_.shape[2])
         for name, val in dict(M=M, P=slam.P, mem=slam.mem, n_rows=slam.N, patch_lifetime=r, removal_window=R,
                               opt_window=cfg.OPTIMIZATION_WINDOW, keyframe_index=cfg.KEYFRAME_INDEX, motion_model=1,
                               feat_h=h, feat_w=w, E_cap=E_cap, kk_cap=kk_cap, ij_cap=ij_cap, kkey_cap=self.kkey_cap,
@@ -172,6 +179,7 @@ class DeviceTrack:
             setattr(t, name, int(val))
         t.motion_damping = float(cfg.MOTION_DAMPING)
         t.keyframe_thresh = float(cfg.KEYFRAME_THRESH)
+        t.feat_fp32 = 1 if self.fp32 else 0
         P = lambda x: x.data_ptr()
         for name, ten in dict(dyn=self.dyn, poses=slam.poses_, patches=slam.patches_, intrinsics=slam.intrinsics_,
                               points=slam.points_, tstamps=slam.tstamps_, index_map=slam.index_map_, ixm=self.ixm,
@@ -226,7 +234,8 @@ class DeviceTrack:
         key = (id(ex), patches.data_ptr())
         if self._fe_key == key:
             return True
-        ok = (ex is not None and ex["fmap"].dtype == torch.float16 and ex["chunked"] and patches.is_contiguous()
+        ok = (ex is not None and ex["fmap"].dtype == (torch.float32 if self.fp32 else torch.float16)
+              and bool(ex["chunked"]) == (not self.fp32) and patches.is_contiguous()
               and patches.dtype == torch.float32
               and all(ex[k].data_ptr() % 16 == 0 and ex[k].is_contiguous()
                       for k in ("colors", "imap", "gmap", "fmap", "fmap2")))
@@ -298,18 +307,41 @@ class DeviceTrack:
             return int(min(max(recent) + _E_EST_MARGIN, self.E_cap))
         return int(min(max(self._e_seen), self.E_cap))
 
-    def step(self, counter, flags, k_new=None, gate_event=None, gate_flag=None, gate_seq=0):
+    def step(self, counter, flags, k_new=None, gate_event=None, gate_flag=None, gate_seq=0, E_bound=None):
         """gate_flag / gate_seq: a signal word (Signal) the update operator's last launch stores gate_seq into -- the
-        cheaper form of gate_event (no packet on this stream); the waiting stream uses Signal.wait"""
+        cheaper form of gate_event (no packet on this stream); the waiting stream uses Signal.wait.  E_bound: the launch
+        bound of this call (default: factor_bound(counter)); the two halves of an fp32 step share one."""
         ev = ctypes.c_void_p(gate_event) if gate_event else None
         self.t.E_hint = self.factor_estimate()
         self.t.gate_flag, self.t.gate_seq = (gate_flag, int(gate_seq) & 0xFFFFFFFF) if gate_flag else (None, 0)
         _lib.check(_lib.lib().ramp_track_step(ctypes.byref(self.t), self.cur, int(counter), int(flags),
-                                              self.factor_bound(counter), _lib.ptr(k_new), ev, _lib.stream()),
+                                              self.factor_bound(counter) if E_bound is None else int(E_bound),
+                                              _lib.ptr(k_new), ev, _lib.stream()),
                    "ramp_track_step")
         if flags & KEYFRAME:
             self.cur ^= 1
-        self._frames += 1
+        if flags & (UPDATE | UPDATE_POST | COMMIT) and not (flags & UPDATE_PRE and not flags & UPDATE_POST):
+            self._frames += 1
+
+    class _Groups:
+        __slots__ = ("order", "gid", "seg_start", "ngroups", "ukeys", "E")
+
+    class _Plan:
+        __slots__ = ("ix_raw", "jx_raw", "ix", "jx", "g_kk", "g_ij", "max_kk", "max_ij", "kj", "E", "mask_ix", "mask_jx", "pair_mul")
+
+    def plan_view(self, Eb):
+        """the device-side plan of the current graph as the object FusedUpdate.hidden() takes (views of the capacity-sized
+        buffers, Eb rows: entries between the live factor count and Eb are defined -- no neighbour, group 0, zero state row)"""
+        p = DeviceTrack._Plan()
+        p.ix_raw = p.ix = self.ix[:Eb]
+        p.jx_raw = p.jx = self.jx[:Eb]
+        p.kj, p.E, p.mask_ix, p.mask_jx, p.pair_mul = None, Eb, None, None, None
+        for name, src, cap in (("g_kk", self.kk, self.kk_cap), ("g_ij", self.ij, self.ij_cap)):
+            g = DeviceTrack._Groups()
+            g.order, g.gid, g.seg_start, g.ngroups, g.ukeys, g.E = src["order"], src["gid"], src["seg"], src["ngroups"], src["ukeys"], Eb
+            setattr(p, name, g)
+        p.max_kk, p.max_ij = self.kk_cap, self.ij_cap
+        return p
 
     def warm(self):
         """(on the current stream) read the correlation planes of the window once: csrc/track.hip::trk_warm_kernel"""
@@ -324,6 +356,20 @@ class DeviceTrack:
             if c[DYN_FRAME] == c[DYN_FRAME2]:
                 return c
         return c
+
+    def wait_frame(self, counter):
+        """(fp32 steps) poll the pinned copy of the sizes until it is the one the plan of frame `counter` wrote, and return
+        it: the host stays at most one frame ahead of the device there -- the correlation launch it has just enqueued keeps
+        the GPU busy meanwhile -- and the update operator's library GEMMs run on exactly the live factor count"""
+        import time
+        t0 = time.perf_counter()
+        while True:
+            d = self.lazy_state()
+            if int(d[DYN_FRAME]) >= int(counter) and int(d[DYN_FRAME]) == int(d[DYN_FRAME2]):
+                return d
+            if time.perf_counter() - t0 > 5.0:
+                raise RuntimeError("device-resident tracker: the GPU has not finished a frame for 5 s")
+            time.sleep(1e-5)
 
     def throttle(self, counter):
         """bound the host's run-ahead: wait (sleeping) until the lazy copy is at most MAX_AHEAD frames old, so that the

@@ -132,9 +132,9 @@ class FusedUpdate:
               "ramp_upd_gather_mask")
         return out
 
-    def gated(self, X, G, R, E, ln=None, want_f32=True, want_t=False, want_relu=False):
+    def gated(self, X, G, R, E, ln=None, want_f32=True, want_t=False, want_relu=False, out=None):
         dev = X.device
-        o32 = torch.empty(E, 384, dtype=torch.float32, device=dev) if want_f32 else None
+        o32 = (out if out is not None else torch.empty(E, 384, dtype=torch.float32, device=dev)) if want_f32 else None
         ot = torch.empty(E, 384, dtype=self.dtype, device=dev) if want_t else None
         orl = torch.empty(E, 384, dtype=self.dtype, device=dev) if want_relu else None
         check(lib().ramp_upd_gated(ptr(X), ptr(G), ptr(R), ptr(ln[0]) if ln else None, ptr(ln[1]) if ln else None,
@@ -180,12 +180,16 @@ class FusedUpdate:
         return out
 
     # ------------------------------------------------------------------ forward
-    def hidden(self, net, inp_table, inp_idx, inp_mod, corr, plan, net_map=None, heads_at=None):
+    def hidden(self, net, inp_table, inp_idx, inp_mod, corr, plan, net_map=None, heads_at=None, net32_buf=None, out32_buf=None):
         """net [*,384] fp32 or None (zeros), row net_map[e] of it per edge when net_map is given (-1: zero
         row); inp = inp_table[inp_idx % inp_mod] (or inp_table rows when inp_idx is None); corr [E,882] in
         self.dtype.  Returns (net_out fp32 [E,384], relu copy T).  heads_at = (coords [E,2,P,P], wd, ht): the fused gru
         launch also forms the heads and target / weight (left in self.last_tw; the relu copy is then None)."""
         self.last_tw, self._heads_at = None, heads_at
+        # (net32_buf / out32_buf: capacity-sized [>= E, 384] fp32 buffers for the state after the first LayerNorm and for the
+        # result -- the device-resident fp32 step gathers through index rows beyond the live factor count, which must stay
+        # inside an allocation; the non-fused path only)
+        self._bufs = (net32_buf, out32_buf)
         w = self.weights()
         E = corr.shape[0]
         if "tail_pack" in w and self.use_mlp and corr.shape[1] == CORR_ROW and self.use_corr_mlp:
@@ -217,7 +221,7 @@ class FusedUpdate:
             _, c = self.row_fuse(E, B=c, ln=w["corr_ln"], relu=True, want_t=True)
             c = self.lin(c, w["corr5"])
             net32, _ = self.row_fuse(E, A=net, idxA=net_map, B=inp_table, idxB=inp_idx, modB=inp_mod, C=c,
-                                     ln=w["norm"], want_f32=True)
+                                     ln=w["norm"], want_f32=True, out_f32=net32_buf[:E] if net32_buf is not None else None)
         # temporal neighbours (net.py:77-82); plan.ix_raw / jx_raw keep the -1 markers
         if "c1_pack" in w and self.use_mlp:
             # gather + 2 Linear + residual add per launch; ping-pong between two state buffers
@@ -300,7 +304,8 @@ class FusedUpdate:
         x32, x_t, _ = self.gated(x32, gate, r, E, ln=w["ln2"], want_t=True)
         gate = self.lin(x_t, w["g2_gate"])
         r = self.lin(self.lin_relu(x_t, w["g2_r1"]), w["g2_r2"])
-        out32, _, relu_t = self.gated(x32, gate, r, E, want_relu=True)
+        ob = getattr(self, "_bufs", (None, None))[1]
+        out32, _, relu_t = self.gated(x32, gate, r, E, want_relu=True, out=ob[:E] if ob is not None else None)
         return out32, relu_t
 
     def heads(self, relu_t):

@@ -471,12 +471,13 @@ def test_config1_workload_64_patches_through_hip():
 
 
 def test_slow_paths_say_so_once():
-    """a configuration the device-resident step does not cover (fp32) warns once instead of silently running host driven"""
+    """a configuration the device-resident step does not cover (a motion model other than DAMPED_LINEAR) warns once instead
+    of silently running host driven"""
     import warnings
     from rampvo_amd.config import make_cfg
     from rampvo_amd.Ramp_vo import Ramp_vo
     from rampvo_amd.synthetic import SyntheticStream, make_network
-    slam = Ramp_vo(make_cfg("default", PATCHES_PER_FRAME=16, MIXED_PRECISION=False), make_network("SingleScale"),
+    slam = Ramp_vo(make_cfg("default", PATCHES_PER_FRAME=16, MOTION_MODEL="COPY"), make_network("SingleScale"),
                    {"event_bias": True}, ht=128, wd=160)
     stream = SyntheticStream(128, 160, 16, seed=2, device="cuda")
     with warnings.catch_warnings(record=True) as rec:
@@ -486,7 +487,7 @@ def test_slow_paths_say_so_once():
                 im, ev, K, mask = stream.frame(t)
                 slam(t, input_tensor=(ev, im, mask), intrinsics=K)
     msgs = [str(w.message) for w in rec if "device-resident tracking step is not available" in str(w.message)]
-    assert slam.is_initialized and len(msgs) == 1 and "MIXED_PRECISION is off" in msgs[0], msgs
+    assert slam.is_initialized and len(msgs) == 1 and "MOTION_MODEL" in msgs[0], msgs
 
 
 @torch.no_grad()
@@ -598,9 +599,10 @@ def test_evaluate_harness_run_and_run_pose_pred():
     assert list(ts2[-4:]) == [16, 17, 18, 19]
 
 
-def test_bench_runs_the_host_driven_fp32_path():
-    """bench.py --mixed 0 (the fp32 tracker is host driven: its roofline legs come from the Python-level hooks, not from the
-    device step's probes)"""
+def test_bench_runs_the_fp32_path():
+    """bench.py --mixed 0: the fp32 tracker's steps are device resident too (two C calls around the operator's library GEMMs,
+    which the host launches; nothing is read back) -- correlation / BA legs from the step's probes, the operator's from the
+    Python-level hook"""
     import json
     import os
     import subprocess
@@ -611,7 +613,8 @@ def test_bench_runs_the_host_driven_fp32_path():
                           "--np-steps", "4", "--inst-steps", "8"], capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-    assert d["dtype"] == "f32" and d["roofline"]["launches"] == 8 and d["roofline_update"]["mean_call_us"] > 0
+    assert d["dtype"] == "f32" and d["roofline"]["launches"] >= 1 and d["roofline_update"]["mean_call_us"] > 0
+    assert "device-resident steps" in d["config"]["workload"] and d["roofline_ba"]["mean_call_us"] > 0
 
 
 def test_bench_json_contract():
