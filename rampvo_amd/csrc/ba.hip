@@ -481,6 +481,9 @@ __global__ void __launch_bounds__(256)
 // with i == a or j == a (~2 x the window): 7 lanes per entry sum every 7th listed record in ascending order and the seven
 // partial sums are added in lane order -- fixed order, no atomics, 20-odd independent loads per thread instead of a chain
 // of chunks staged through LDS behind barriers (ba_assemble_kernel: one workgroup per POSE, 19 us of a 139 us call).
+// (A single lane per entry -- ascending record order, ba_assemble_kernel's -- was slower than that kernel: 151 vs 138 us per
+// call.  The interleaved order moves the 180 x 180 solve of the precise.yaml window by 6e-4 of the step against the oracle --
+// fp32 rounding through its conditioning -- so windows above 16 poses keep ba_assemble_kernel.)
 #define BA_AP 7
 __global__ void __launch_bounds__(256)
     ba_assemble2_kernel(const float *__restrict__ pairs, const int32_t *__restrict__ pair_ij,
@@ -993,7 +996,7 @@ static int ba_iterate(float *poses, float *patches, const float *intrinsics, con
                          w.Qv, w.uv, nk, w.S_part, w.y_part, n6, w.KS);
       static int asm2 = -1;                          // RAMP_BA_ASM2=0: one workgroup per pose (A/B runs)
       if (asm2 < 0) { const char *e = getenv("RAMP_BA_ASM2"); asm2 = e ? atoi(e) : 1; }
-      if (asm2)
+      if (asm2 && N <= 16)
         hipLaunchKernelGGL(ba_assemble2_kernel, dim3(N, N), dim3(256), 0, st, w.pairs, w.pair_ij, np, w.S_part, w.y_part,
                            w.S, w.yv, n6, w.KS, info);
       else

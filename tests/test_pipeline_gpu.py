@@ -188,10 +188,10 @@ POLICY_NET, POLICY_WEIGHT, POLICY_POSES, POLICY_DEPTHS_P999, POLICY_DEPTHS_MAX =
 # are set aside: a depth of 20.2 in one leg and 19.9 in the other is 1 vs 19.9 after the reset)
 
 
-def _assert_policy_leg(m, depths_max=None):
+def _assert_policy_leg(m, depths_max=None, poses=None):
     assert m["at_reset_frac"] <= 0.06, m           # (the random-weight depths pile up below the d > 20 -> 1 reset: ~4 % within 0.5 of it at configs[2])
     assert m["net"] <= POLICY_NET and m["weight"] <= POLICY_WEIGHT, m
-    assert m["poses_over_step"] <= POLICY_POSES and m["depths_p999"] <= POLICY_DEPTHS_P999, m
+    assert m["poses_over_step"] <= (POLICY_POSES if poses is None else poses) and m["depths_p999"] <= POLICY_DEPTHS_P999, m
     assert m["depths_max"] <= (POLICY_DEPTHS_MAX if depths_max is None else depths_max), m
 
 
@@ -209,7 +209,9 @@ def _assert_fp16_leg(m, policy=None):
     else:
         # (the single worst of ~5k .. 10k patches at these windows: 5e-3 .. 0.14 over snapshots -- one fp16 step of a hidden
         # state entry through a depth with Q ~ 1e4; the percentiles are what is bounded tightly)
-        _assert_policy_leg(policy, depths_max=0.5)
+        # poses: 3e-4 .. 2.6e-3 of the step over snapshots at these windows (single fp16 roundings of the hidden state that fall
+        # the other way under a different fp32 summation order, through a 180 / 192-wide solve of a random-weight problem)
+        _assert_policy_leg(policy, depths_max=0.5, poses=1e-2)
 
 
 @torch.no_grad()
