@@ -951,6 +951,16 @@ __global__ void __launch_bounds__(256)
 // of this kernel's VALU time; the LSTM gates are insensitive at that level (test tolerance 2e-5)
 __device__ __forceinline__ float lm_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
 __device__ __forceinline__ float lm_tanh(float x) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f; }
+// h = sigmoid(o) tanh(sigmoid(i) tanh(g)) with 4 exponentials and 2 reciprocals (instead of 4 + 4; both run at a quarter
+// of the VALU rate): sigmoid(a) tanh(b) = sgn(b) (1 - t) / ((1 + e^-a) (1 + t)), t = e^(-2 |b|) <= 1 -- no overflow in the
+// numerator; e^-a = inf gives the right limit 0
+__device__ __forceinline__ float ms_sig_tanh(float a, float b) {
+  const float t = __expf(-2.0f * fabsf(b)), ea = __expf(-a);
+  const float v = (1.0f - t) * __builtin_amdgcn_rcpf((1.0f + ea) * (1.0f + t));
+  return b < 0.f ? -v : v;
+}
+__device__ __forceinline__ float ms_cell(float gi, float gg, float go) { return ms_sig_tanh(go, ms_sig_tanh(gi, gg)); }
+__device__ __forceinline__ float lm_sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 // LDSW: the 104 weight fragments per lane sit in LDS (26 KB per workgroup) instead of registers: <= 64 VGPRs, so a wave of
 // this kernel fits on a SIMD next to the two 222-VGPR waves of the update operator's gru launch -- behind the gate the two
@@ -1061,9 +1071,16 @@ __global__ void __launch_bounds__(256, LDSW ? 8 : 1)
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(WA(LM_IM, t * 5 + s4, a_im), bk[s4], acc, 0, 0, 0);
         }
         // acc = (i, f, g, o) pre-activations of unit 4t+q, pixel j (torch gate order i, f, g, o)
+#ifdef LM_IEEE_CELL                                       // (A/B builds: the round-3 cell, 5 exponentials + 5 IEEE reciprocals)
         const float ig = lm_sigmoid(acc[0]), fg = lm_sigmoid(acc[1]), gg = lm_tanh(acc[2]), og = lm_sigmoid(acc[3]);
         const float cn = has_state ? fg * cold[t] + ig * gg : ig * gg;
         const float hv = og * lm_tanh(cn);
+#else
+        // sigmoid(i) tanh(g) and sigmoid(o) tanh(c) with one 1-ulp reciprocal each (ms_sig_tanh): 5 exponentials + 3 reciprocals
+        const float igg = ms_sig_tanh(acc[0], acc[2]);
+        const float cn = has_state ? __builtin_fmaf(lm_sigmoid_fast(acc[1]), cold[t], igg) : igg;
+        const float hv = ms_sig_tanh(acc[3], cn);
+#endif
         const bool unit_ok = 4 * t + q < 15;
         hn[mod][t] = unit_ok ? hv : 0.0f;
         cnew[t] = unit_ok ? cn : 0.0f;
@@ -1227,15 +1244,6 @@ struct MsMfmaParams {
 // (1 ulp reciprocal: the IEEE division sequence of __frcp_rn was a third of the cell's VALU work)
 __device__ __forceinline__ float ms_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float ms_tanh(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
-// h = sigmoid(o) tanh(sigmoid(i) tanh(g)) with 4 exponentials and 2 reciprocals (instead of 4 + 4; both run at a quarter
-// of the VALU rate): sigmoid(a) tanh(b) = sgn(b) (1 - t) / ((1 + e^-a) (1 + t)), t = e^(-2 |b|) <= 1 -- no overflow in the
-// numerator; e^-a = inf gives the right limit 0
-__device__ __forceinline__ float ms_sig_tanh(float a, float b) {
-  const float t = __expf(-2.0f * fabsf(b)), ea = __expf(-a);
-  const float v = (1.0f - t) * __builtin_amdgcn_rcpf((1.0f + ea) * (1.0f + t));
-  return b < 0.f ? -v : v;
-}
-__device__ __forceinline__ float ms_cell(float gi, float gg, float go) { return ms_sig_tanh(go, ms_sig_tanh(gi, gg)); }
 template <int D, int S, int NWV>
 __global__ void __launch_bounds__(64 * NWV) ms_lstm_superstate_mfma_kernel(const MsMfmaParams p) {
   constexpr int NG = D / 16;                           // 16-unit groups
