@@ -182,6 +182,12 @@ struct CorrParams {
   const int32_t *order;   // optional schedule: position -> edge (any permutation of 0..E-1)
   int chunk;              // ceil(E / CORR_XCDS)
   const int32_t *dyn;     // optional device-side sizes (RAMP_DYN_E): E / chunk above are then the launch bound
+  // optional fused reprojection (MFMA kernel, P = 3): the wave computes its edge's coordinates itself -- pops.transform,
+  // csrc/lie.hip::transform_kernel's arithmetic -- from poses / patches / intrinsics and the source frame of the edge, and
+  // writes them to `coords` (the heads and BA's targets read the patch centre): one launch and one 72-byte round trip
+  // per edge less in the serial part of the tracked frame
+  const float *tf_poses, *tf_patches, *tf_intr;
+  const int64_t *tf_src;  // [E] source frame of each edge (ii of the tracker's graph)
 };
 
 // Workgroup ids are dealt round-robin to the 8 XCDs, each with a private L2.  Position p of the
@@ -505,6 +511,36 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CorrMma
   int g_ox_[CORR_MAXLEV], g_oy_[CORR_MAXLEV];
   float g_dx_[CORR_MAXLEV], g_dy_[CORR_MAXLEV];
   unsigned g_lm_[CORR_MAXLEV];
+  // pixel `lane`'s reprojection: loaded, or (fused pops.transform) computed here and written out
+  float cx0 = 0.f, cy0 = 0.f;
+  if (lane < PP) {
+    float *cw = const_cast<float *>(prm.coords) + (size_t)e * 2 * PP;
+    if (prm.tf_poses) {
+      const long si = prm.tf_src[e], sj = prm.jj[e], sk = prm.ii[e];      // (ii of this launch = the patch index kk)
+      float Ti[7], Tj[7], Tinv[7], G[7], t[3], qr[4];
+#pragma unroll
+      for (int c = 0; c < 7; c++) { Ti[c] = prm.tf_poses[7 * si + c]; Tj[c] = prm.tf_poses[7 * sj + c]; }
+      lt_inv(Ti, Tinv);
+      lt_mul(Tj, Tinv, G);
+      lt_load(G, t, qr);
+      const float fxi = prm.tf_intr[4 * si + 0], fyi = prm.tf_intr[4 * si + 1], cxi = prm.tf_intr[4 * si + 2], cyi = prm.tf_intr[4 * si + 3];
+      const float fxj = prm.tf_intr[4 * sj + 0], fyj = prm.tf_intr[4 * sj + 1], cxj = prm.tf_intr[4 * sj + 2], cyj = prm.tf_intr[4 * sj + 3];
+      const float *pt = prm.tf_patches + (size_t)sk * 3 * PP;
+      float X0[4], X1[4];
+      X0[0] = (pt[lane] - cxi) / fxi;
+      X0[1] = (pt[PP + lane] - cyi) / fyi;
+      X0[2] = 1.0f;
+      X0[3] = pt[2 * PP + lane];
+      lt_act4_tq(t, qr, X0, X1);
+      const float Z = X1[2] < 0.1f ? 0.1f : X1[2];
+      const float dz = 1.0f / Z;
+      cx0 = fxj * (dz * X1[0]) + cxj;
+      cy0 = fyj * (dz * X1[1]) + cyj;
+      cw[lane] = cx0; cw[PP + lane] = cy0;
+    } else {
+      cx0 = cw[lane]; cy0 = cw[PP + lane];
+    }
+  }
 #pragma unroll
   for (int lvl = 0; lvl < CORR_MAXLEV; lvl++) {
     g_ox_[lvl] = 0; g_oy_[lvl] = 0; g_dx_[lvl] = 0.f; g_dy_[lvl] = 0.f;
@@ -512,8 +548,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CorrMma
     if (lvl < L && lane < PP) {
       const int H2 = prm.H2[lvl], W2 = prm.W2[lvl];
       const float cdv = prm.cdiv[lvl];
-      const float x = prm.coords[((size_t)e * 2 + 0) * PP + lane] / cdv;
-      const float y = prm.coords[((size_t)e * 2 + 1) * PP + lane] / cdv;
+      const float x = cx0 / cdv;
+      const float y = cy0 / cdv;
       const float flx = floorf(x), fly = floorf(y);
       const int ox = ramp_f2i(flx), oy = ramp_f2i(fly);
       g_dx_[lvl] = x - flx;
@@ -825,8 +861,10 @@ int ramp_frame_gather(const void *fmap, const void *imap, const float *image, co
 int ramp_i_corr_fwd(const void *fmap1, const ramp_corr_level *levels, int nlevels,
                     const float *coords, const int64_t *ii, const int64_t *jj,
                     const int32_t *order, void *out, int out_row_elems, long mod_ii, long mod_jj, int E,
-                    int N1, int N2, int C, int P, int radius, int dtype, int layout, const int32_t *dyn, void *stream) {
+                    int N1, int N2, int C, int P, int radius, int dtype, int layout, const int32_t *dyn, void *stream,
+                    const float *tf_poses, const float *tf_patches, const float *tf_intr, const int64_t *tf_src) {
   if (E < 0 || nlevels < 1 || nlevels > CORR_MAXLEV || !levels) return RAMP_EINVAL;
+  if (tf_poses && (!tf_patches || !tf_intr || !tf_src || (dtype & ~RAMP_CORR_MFMA32) != RAMP_F16 || layout == RAMP_NCHW)) return RAMP_EINVAL;
   if (C != 128 || P != 3 || radius != 3) return RAMP_EUNSUPPORTED;
   if (E == 0) return RAMP_OK;
   if (!fmap1 || !coords || !ii || !jj || !out) return RAMP_EINVAL;
@@ -855,6 +893,7 @@ int ramp_i_corr_fwd(const void *fmap1, const ramp_corr_level *levels, int nlevel
   if (prm.row_elems < 49 * 9 * nlevels || (nlevels == 2 && (prm.row_elems & 1))) return RAMP_EINVAL;   // half2 stores
   prm.chunk = (E + CORR_XCDS - 1) / CORR_XCDS;
   prm.dyn = dyn;
+  prm.tf_poses = tf_poses; prm.tf_patches = tf_patches; prm.tf_intr = tf_intr; prm.tf_src = tf_src;
   const dim3 grid(prm.chunk * CORR_XCDS);
   hipStream_t st = (hipStream_t)stream;
   const bool fast32 = (dtype & RAMP_CORR_MFMA32) != 0;
@@ -882,7 +921,7 @@ int ramp_corr_fwd_ordered(const void *fmap1, const ramp_corr_level *levels, int 
                           const int32_t *order, void *out, int out_row_elems, long mod_ii, long mod_jj, int E,
                           int N1, int N2, int C, int P, int radius, int dtype, int layout, void *stream) {
   return ramp_i_corr_fwd(fmap1, levels, nlevels, coords, ii, jj, order, out, out_row_elems, mod_ii, mod_jj, E, N1, N2,
-                         C, P, radius, dtype, layout, nullptr, stream);
+                         C, P, radius, dtype, layout, nullptr, stream, nullptr, nullptr, nullptr, nullptr);
 }
 
 int ramp_corr_fwd(const void *fmap1, const ramp_corr_level *levels, int nlevels,

@@ -48,7 +48,8 @@ extern "C" {
 int ramp_i_corr_fwd(const void *fmap1, const ramp_corr_level *levels, int nlevels, const float *coords,
                     const int64_t *ii, const int64_t *jj, const int32_t *order, void *out, int out_row_elems,
                     long mod_ii, long mod_jj, int E, int N1, int N2, int C, int P, int radius, int dtype, int layout,
-                    const int32_t *dyn, void *stream);
+                    const int32_t *dyn, void *stream, const float *tf_poses = nullptr, const float *tf_patches = nullptr,
+                    const float *tf_intr = nullptr, const int64_t *tf_src = nullptr);
 int ramp_i_upd_gru(const float *x32, const void *add0_t, const int32_t *add0_idx, const void *add_t, const int32_t *add_idx,
                  const float *pre_w, const float *pre_b,
                    float pre_eps, const void *const *wp_host, const float *const *bias_host, const float *ln_w,

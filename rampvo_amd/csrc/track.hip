@@ -496,7 +496,12 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
         !t->hij || !t->target || !t->weight || !t->ba_ws)
       return RAMP_EINVAL;
     // Ramp_vo.update(), ramp/Ramp_vo.py:276-310
-    TRK_DO(ramp_i_transform_dyn(t->poses, t->patches, t->intrinsics, ii, jj, kk, t->coords, Eb, dyn, st));
+    // RAMP_CORR_TF=1: pops.transform rides in the correlation kernel's geometry prologue (one launch less; bit-identical).
+    // Measured a wash -- the nine-lane Lie algebra adds to every wave what the 7.8 us launch took (corr 158 -> 166 us) --
+    // so the separate launch stays the default
+    static const bool corr_tf = getenv("RAMP_CORR_TF") && atoi(getenv("RAMP_CORR_TF")) != 0;
+    const bool fuse_tf = corr_tf && !(flags & (RAMP_TRACK_WRAP_COORDS | RAMP_TRACK_COMPACT_COORDS));
+    if (!fuse_tf) TRK_DO(ramp_i_transform_dyn(t->poses, t->patches, t->intrinsics, ii, jj, kk, t->coords, Eb, dyn, st));
     if (flags & (RAMP_TRACK_WRAP_COORDS | RAMP_TRACK_COMPACT_COORDS))
       hipLaunchKernelGGL(trk_wrap_coords_kernel, dim3(ramp_cdiv(Eb, 256)), dim3(256), 0, st, t->coords, dyn, t->P,
                          (float)t->feat_w, (float)t->feat_h, (flags & RAMP_TRACK_COMPACT_COORDS) ? 1 : 0);
@@ -505,7 +510,8 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
     lv[1].fmap = t->fmap2; lv[1].H2 = t->feat_h / 4; lv[1].W2 = t->feat_w / 4; lv[1].coord_div = 4.0f;
     TRK_PROBE(0);
     TRK_DO(ramp_i_corr_fwd(t->gmap, lv, 2, t->coords, kk, jj, t->ij_order, t->corr, 896, (long)t->M * t->mem, t->mem, Eb,
-                           t->mem * t->M, t->mem, 128, t->P, 3, RAMP_F16, RAMP_NHWC8, dyn, st));
+                           t->mem * t->M, t->mem, 128, t->P, 3, RAMP_F16, RAMP_NHWC8, dyn, st,
+                           fuse_tf ? t->poses : nullptr, t->patches, t->intrinsics, ii));
     TRK_PROBE(1);
     // the update operator, ramp/net.py:69-90 (the fp16 fused chains of csrc/update_mlp.hip)
     TRK_DO(ramp_i_upd_corr_mlp(t->corr, 896, w.corr_w1, w.corr_b1, w.corr_w2, w.corr_b2, w.corr_w3, w.corr_b3, w.corr_ln_w,
