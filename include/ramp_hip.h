@@ -734,6 +734,8 @@ int ramp_signal_alloc(uint32_t **flag);
 int ramp_signal_free(uint32_t *flag);
 int ramp_stream_wait_flag(void *stream, const uint32_t *flag, uint32_t value, int timeout_us, int then_delay_us,
                           int32_t *status /* optional: bit 128 is ORed in when the wait times out */);
+/* the producer side as a launch of its own (one thread storing `value`), for producers that are not this library's kernels */
+int ramp_stream_signal(void *stream, uint32_t *flag, uint32_t value);
 /* device address of a pinned (mapped) host allocation */
 int ramp_host_device_pointer(void *host, void **dev);
 

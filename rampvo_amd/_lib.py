@@ -125,6 +125,7 @@ SIGNATURES = {
     "ramp_stream_delay": (c_i, [c_i, c_p]),
     "ramp_signal_alloc": (c_i, [c_p]),
     "ramp_signal_free": (c_i, [c_p]),
+    "ramp_stream_signal": (c_i, [c_p, c_p, ctypes.c_uint32]),
     "ramp_stream_wait_flag": (c_i, [c_p, c_p, ctypes.c_uint32, c_i, c_i, c_p]),
     "ramp_host_device_pointer": (c_i, [c_p, c_p]),
 }

@@ -370,6 +370,16 @@ int ramp_signal_alloc(uint32_t **flag) {
 }
 int ramp_signal_free(uint32_t *flag) { return (!flag || hipFree(flag) == hipSuccess) ? RAMP_OK : RAMP_ELAUNCH; }
 
+__global__ void trk_signal_kernel(uint32_t *flag, uint32_t value) {
+  __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+int ramp_stream_signal(void *stream, uint32_t *flag, uint32_t value) {
+  if (!flag) return RAMP_EINVAL;
+  hipLaunchKernelGGL(trk_signal_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, flag, value);
+  RAMP_CHECK_LAUNCH();
+  return RAMP_OK;
+}
+
 int ramp_stream_delay(int microseconds, void *stream) {
   if (microseconds <= 0) return RAMP_OK;
   hipLaunchKernelGGL(trk_delay_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long)microseconds * 100);

@@ -37,6 +37,18 @@ __global__ void __launch_bounds__(64) gather_kernel(const uint4 *__restrict__ bu
       } else if (PAT == 2) {
         const int t = g * 16 + j, ty = t / 10, tx = t - ty * 10;
         off = (((size_t)(y0 + ty) * CH + 4 * s + q) * W + x0 + tx) * 16;
+      } else if (PAT == 5) {
+        // [H][4 K-steps][W][32 halfs]: a window row of a K step is 640 contiguous bytes
+        const int t = g * 16 + j, ty = t / 10, tx = t - ty * 10;
+        off = ((((size_t)(y0 + ty) * 4 + s) * W + x0 + tx) * 4 + q) * 16;
+      } else if (PAT == 6) {
+        // [4 K-steps][H][W][32 halfs]: the same, K-step planes apart
+        const int t = g * 16 + j, ty = t / 10, tx = t - ty * 10;
+        off = ((((size_t)s * H + y0 + ty) * W + x0 + tx) * 4 + q) * 16;
+      } else if (PAT == 7) {
+        // [H][2][W][64 halfs] with two K steps per 128-byte pixel slot: lane (q, j) takes 16 bytes at 32 * q + 16 * (s & 1)
+        const int t = g * 16 + j, ty = t / 10, tx = t - ty * 10;
+        off = ((((size_t)(y0 + ty) * 2 + (s >> 1)) * W + x0 + tx) * 8 + 2 * q + (s & 1)) * 16;
       } else {
         const int t = g * 16 + j, ty = t / 10, tx = t - ty * 10;
         off = ((size_t)(y0 + ty) * W + x0 + tx) * 256 + (size_t)(4 * s + q) * 16;   // NHWC: 256 B per pixel
@@ -130,6 +142,9 @@ int main() {
   run<1>(buf, out, "P1 4 x 256 B (aligned 16-wide rows)");
   run<2>(buf, out, "P2 chunked, 10-wide window (the kernel)");
   run<3>(buf, out, "P3 NHWC, 10-wide window");
+  run<5>(buf, out, "P5 [H][4][W][32], 10-wide window");
+  run<6>(buf, out, "P6 [4][H][W][32], 10-wide window");
+  run<7>(buf, out, "P7 [H][2][W][64] (half a line per lane pair)");
   run<0>(buf, out, "P0 again");
   run_lds(buf, out, 5);
   run_lds(buf, out, 4);
