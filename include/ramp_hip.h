@@ -45,7 +45,7 @@ extern "C" {
 
 #define RAMP_NCHW 0
 #define RAMP_NHWC 1
-#define RAMP_NHWC8 2  /* [H][C/8][W][8]: correlation target maps only (ramp_pyramid_pack) */
+#define RAMP_NHWC32 2  /* [H][C/32][W][32]: correlation target maps only (ramp_pyramid_pack); one plane per MFMA K step */
 
 /* library / build identification: returns a static string */
 const char *ramp_version(void);
@@ -113,9 +113,9 @@ int ramp_corr_fwd_ordered(const void *fmap1, const ramp_corr_level *levels_host,
 
 /* Ramp_vo.__call__'s pyramid store (ramp/Ramp_vo.py:378-381: fmap1_[slot] =
  * fmap, fmap2_[slot] = avg_pool2d(fmap, 4, 4)) for fp16 channels-last features:
- * fmap [H][W][C] -> level1 [H][C/8][W][8] (same values) and level4
- * [H/4][C/8][W/4][8] (4x4 mean, fp32 sum, one rounding).  These are the
- * RAMP_NHWC8 target maps of ramp_corr_fwd (fp16 only; fmap1 stays RAMP_NHWC).
+ * fmap [H][W][C] -> level1 [H][C/32][W][32] (same values) and level4
+ * [H/4][C/32][W/4][32] (4x4 mean, fp32 sum, one rounding).  These are the
+ * RAMP_NHWC32 target maps of ramp_corr_fwd (fp16 only; fmap1 stays RAMP_NHWC).
  * C == 128, W % 16 == 0, H % 4 == 0, else RAMP_EUNSUPPORTED.                 */
 int ramp_pyramid_pack(const void *fmap, void *level1, void *level4, int H, int W, int C, int dtype,
                       void *stream);
@@ -705,7 +705,7 @@ typedef struct ramp_track {
   int32_t E_hint;                     /* optional (> 0): the caller's estimate of the live factor count (E_bound is an upper
                                        * bound): picks the gru launch's tile (64 / 80 rows per workgroup)                    */
   uint32_t gate_seq;                  /* with gate_flag: the value the update operator's last launch (gru) stores into it  */
-  int32_t feat_fp32;                  /* 0: fp16 features (imap / gmap / fmap rows of 2-byte elements, chunked [h][C/8][w][8] pyramid
+  int32_t feat_fp32;                  /* 0: fp16 features (imap / gmap / fmap rows of 2-byte elements, chunked [h][C/32][w][32] pyramid
                                        * planes, corr [E_cap][896] fp16); 1: fp32 features, plain NHWC planes, corr [E_cap][882]
                                        * fp32 (correlation by corr_kernel<float>, the reference kernel's summation order) --
                                        * only with RAMP_TRACK_UPDATE_PRE / _POST                                          */

@@ -35,7 +35,7 @@ import torch.nn.functional as F
 from . import altcorr, fastba, lietorch, ops, track_dev
 from . import projective_ops as pops
 from . import _lib
-from ._lib import RAMP_NHWC, RAMP_NHWC8
+from ._lib import KPLANE, RAMP_NHWC, RAMP_NHWC32
 from .update_fused import CORR_ROW
 from .lietorch import SE3
 from .net import GraphPlan, VONet
@@ -108,12 +108,12 @@ class Ramp_vo:
         # channels-last ring buffers (reference: [mem,M,DIM], [mem,M,128,P,P], [1,mem,128,h,w])
         self.imap_ = torch.zeros(self.mem, self.M, DIM, **kwargs)
         self.gmap_ = torch.zeros(self.mem, self.M, self.P, self.P, 128, **kwargs)
-        # fp16 pyramid on the GPU: [h][C/8][w][8] slots (csrc/altcorr.hip, the MFMA kernel's target
+        # fp16 pyramid on the GPU: [h][C/32][w][32] slots (csrc/altcorr.hip, the MFMA kernel's target
         # layout); otherwise plain channels-last
         self._chunked, self._lazy_net = self._layout_flags(h, w)
         if self._chunked:
-            self.fmap1_ = torch.zeros(self.mem, h, 16, w, 8, **kwargs)
-            self.fmap2_ = torch.zeros(self.mem, h // 4, 16, w // 4, 8, **kwargs)
+            self.fmap1_ = torch.zeros(self.mem, h, 128 // KPLANE, w, KPLANE, **kwargs)
+            self.fmap2_ = torch.zeros(self.mem, h // 4, 128 // KPLANE, w // 4, KPLANE, **kwargs)
         else:
             self.fmap1_ = torch.zeros(self.mem, h, w, 128, **kwargs)
             self.fmap2_ = torch.zeros(self.mem, h // 4, w // 4, 128, **kwargs)
@@ -181,7 +181,7 @@ class Ramp_vo:
     del _mirror
 
     def _layout_flags(self, h, w):
-        """(fp16 pyramid in the MFMA correlation kernel's [h][C/8][w][8] slots, lazy hidden-state row map: the [E,384]
+        """(fp16 pyramid in the MFMA correlation kernel's [h][C/32][w][32] slots, lazy hidden-state row map: the [E,384]
         state is re-indexed, not copied, when the graph changes)"""
         chunked = self.dtype == torch.half and ops.pyramid_pack_supported(h, w) and (h // 4) > 0 and (w // 4) > 0
         if self.dtype == torch.half and not chunked:
@@ -336,7 +336,7 @@ class Ramp_vo:
             delta={k: (v[0], c(v[1].data)) for k, v in self.delta.items()})
 
     def _fmap_nchw(self, buf):
-        if self._chunked:                                              # [mem, h, 16, w, 8] -> [mem, 128, h, w]
+        if self._chunked:                                              # [mem, h, 4, w, 32] -> [mem, 128, h, w]
             return buf.permute(0, 2, 4, 1, 3).reshape(buf.shape[0], 128, buf.shape[1], buf.shape[3])
         return buf.permute(0, 3, 1, 2)
 
@@ -360,7 +360,7 @@ class Ramp_vo:
         for buf, key in ((self.fmap1_, "fmap1"), (self.fmap2_, "fmap2")):
             src = sd[key].to(dev)                                      # [mem, 128, h, w]
             if self._chunked:
-                src = src.reshape(src.shape[0], 16, 8, src.shape[2], src.shape[3]).permute(0, 3, 1, 4, 2)
+                src = src.reshape(src.shape[0], 128 // KPLANE, KPLANE, src.shape[2], src.shape[3]).permute(0, 3, 1, 4, 2)
             else:
                 src = src.permute(0, 2, 3, 1)
             buf.copy_(src)
@@ -405,7 +405,7 @@ class Ramp_vo:
         # ring-buffer slots (kk % (M*mem), jj % mem) are taken inside the kernel; fp16: rows padded 882 -> 896
         # (16-byte aligned rows for the first Linear layer, update_fused.py)
         return altcorr.corr_pyramid(self.gmap_.view(-1, 3, 3, 128), self.pyramid, coords[0], ii, jj, 3, (1, 4),
-                                    RAMP_NHWC8 if self._chunked else RAMP_NHWC, order=order,
+                                    RAMP_NHWC32 if self._chunked else RAMP_NHWC, order=order,
                                     row_elems=CORR_ROW if self.dtype == torch.half else 0,
                                     mod_ii=self.M * self.mem, mod_jj=self.mem)
 
@@ -421,7 +421,7 @@ class Ramp_vo:
         _lib.check(_lib.lib().ramp_corr_fwd_ordered(
             _lib.ptr(self.gmap_), self._corr_levels, 2, _lib.ptr(coords), _lib.ptr(ii), _lib.ptr(jj),
             _lib.ptr(order), _lib.ptr(out), CORR_ROW, self.M * self.mem, self.mem, E, self.mem * self.M,
-            self.mem, 128, 3, 3, _lib.RAMP_F16, RAMP_NHWC8, _lib.stream()), "ramp_corr_fwd_ordered")
+            self.mem, 128, 3, 3, _lib.RAMP_F16, RAMP_NHWC32, _lib.stream()), "ramp_corr_fwd_ordered")
         return out.view(1, E, CORR_ROW)
 
     def reproject(self, indicies=None, poses=None, patches=None, intrinsics=None):

@@ -19,7 +19,8 @@ RAMP_F32, RAMP_F16 = 0, 1
 RAMP_EUNSUPPORTED = -4
 RAMP_CONV_FP8 = 0x40
 RAMP_IN_F32, RAMP_CONV_DIRECT, RAMP_CORR_MFMA32 = 0x10, 0x20, 0x40
-RAMP_NCHW, RAMP_NHWC, RAMP_NHWC8 = 0, 1, 2
+RAMP_NCHW, RAMP_NHWC, RAMP_NHWC32 = 0, 1, 2
+KPLANE = 32            # channels per plane of the packed correlation target maps: [h][128 / KPLANE][w][KPLANE]
 
 _ERR = {-1: "RAMP_EINVAL (bad argument)", -2: "RAMP_ELAUNCH (HIP launch/runtime error)",
         -3: "RAMP_EWORKSPACE (workspace too small)", -4: "RAMP_EUNSUPPORTED (size/shape not supported)"}

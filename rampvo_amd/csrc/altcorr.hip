@@ -157,6 +157,9 @@ __global__ void __launch_bounds__(256) frame_gather_kernel(const FrameGather p) 
 
 // -------------------------------------------------------------------- corr
 #define CORR_MAXLEV 2
+#ifndef CORR_KPLANE
+#define CORR_KPLANE 32  // channels per plane of the packed target maps: [h][128 / KPLANE][w][KPLANE] (8: round 2/3's layout)
+#endif
 #ifndef CORR_PGB
 #define CORR_PGB 4    // pixel groups (of 16) whose loads are in flight together, MFMA kernel
 #define CORR_WAVES 4  // waves per SIMD the MFMA kernel is register-budgeted for
@@ -425,9 +428,10 @@ typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 //
-// Target maps come either as plain NHWC or (CHUNKED) as [H][C/8][W][8]: there the 16 lanes of a
-// quarter-wave -- 16 neighbouring window pixels, same 8-channel chunk -- read one or two
-// contiguous runs instead of 16 cache lines 256 B apart.  The vector L1 looks up one line per
+// Target maps come either as plain NHWC or (CHUNKED) as [H][C/32][W][32] -- one plane per MFMA K step: the 64 lanes of a
+// load (16 neighbouring window pixels x the four 8-channel quarters of the step) read one or two contiguous runs of up
+// to 640 bytes instead of 16 pieces 256 B apart.  (Rounds 2-3: [H][C/8][W][8], four 160-byte runs per quarter-wave;
+// CORR_KPLANE=8 builds it.)  The vector L1 looks up one line per
 // cycle, and with NHWC those lookups (64 per load instruction) were what the kernel waited on.
 // element-type traits of the MFMA correlation kernel below: fp16 -> v_mfma_f32_16x16x32_f16 (4 steps of 32 channels,
 // lane (q, .) supplies 8 channels per step); fp32 -> v_mfma_f32_16x16x4_f32 (exact fp32 products; the channel axis is
@@ -647,9 +651,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CorrMma
           inb[u] = (t < Tn) && px >= 0 && px < W2 && py >= 0 && py < H2;
           const int cy = inb[u] ? py : 0, cx = inb[u] ? px : 0;
           // load s, quarter q <-> channels [4 PER s + PER q, + PER) (fp16: = chunk 4 s + q of the [h][C/8][w][8] layout)
+#if CORR_KPLANE == 32
+          // [h][4][w][32]: K step s of a window row is one run of 64 bytes per pixel (18.8 vs 15.7 TB/s from the vector
+          // L1 for the 10-wide windows, tools/mb/gather_patterns.hip P5 / P2)
+          const T *pp = CHUNKED ? f2 + (((size_t)cy * 4) * W2 + cx) * 32 + 8 * q
+                                : f2 + ((size_t)cy * W2 + cx) * C + PER * q;
+          const size_t sstride = CHUNKED ? (size_t)W2 * 32 : 4 * PER;
+#else
           const T *pp = CHUNKED ? f2 + (((size_t)cy * (C / 8) + q) * W2 + cx) * 8
                                 : f2 + ((size_t)cy * W2 + cx) * C + PER * q;
           const size_t sstride = CHUNKED ? (size_t)4 * W2 * 8 : 4 * PER;
+#endif
 #pragma unroll
           for (int s = 0; s < STEPS; s++) bfr[u][s] = *reinterpret_cast<const frag_t *>(pp + s * sstride);
         }
@@ -755,17 +767,19 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CorrMma
 
 // ------------------------------------------------------------- pyramid pack
 // One frame's fp16 NHWC feature map [H][W][128] -> the two correlation levels in the chunked
-// layout: level 1 = the map itself as [H][16][W][8]; level 4 = its 4x4 average (fp32 sum / 16,
-// rounded once; Ramp_vo.py:378-381's avg_pool2d) as [H/4][16][W/4][8].  A workgroup owns a 4-row x
+// layout: level 1 = the map itself as [H][4][W][32]; level 4 = its 4x4 average (fp32 sum / 16,
+// rounded once; Ramp_vo.py:378-381's avg_pool2d) as [H/4][4][W/4][32].  A workgroup owns a 4-row x
 // 16-pixel tile; thread (xl, c8) moves 16 bytes per row through an LDS transpose so that both the
-// reads (pixel-major) and the writes (chunk-major) are contiguous.
+// reads (pixel-major) and the writes (plane-major, 1 KB runs) are contiguous.
 __global__ void __launch_bounds__(256) pyramid_pack_kernel(const uint4 *__restrict__ in, uint4 *__restrict__ out1,
                                                            uint4 *__restrict__ out4, int H, int W) {
   __shared__ uint4 tile[16][17];
   const int t = threadIdx.x;
   const int x0 = blockIdx.x * 16, y0 = blockIdx.y * 4;
   const int xl = t >> 4, c8 = t & 15;      // read role
+#if CORR_KPLANE != 32
   const int wc = t >> 4, wx = t & 15;      // write role: chunk wc, pixel wx
+#endif
   float sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (int r = 0; r < 4; r++) {
     const int y = y0 + r;
@@ -780,7 +794,14 @@ __global__ void __launch_bounds__(256) pyramid_pack_kernel(const uint4 *__restri
     __syncthreads();
     tile[c8][xl] = v;
     __syncthreads();
+#if CORR_KPLANE == 32
+    {
+      const int ws = t >> 6, px = (t >> 2) & 15, wq = t & 3;     // write role: K step, pixel, quarter -- 1 KB runs
+      out1[(((size_t)y * 4 + ws) * W + x0 + px) * 4 + wq] = tile[4 * ws + wq][px];
+    }
+#else
     out1[((size_t)y * 16 + wc) * W + x0 + wx] = tile[wc][wx];
+#endif
   }
   // 4 neighbouring pixels = lanes t, t^16, t^32, t^48 of one wave
 #pragma unroll
@@ -793,7 +814,11 @@ __global__ void __launch_bounds__(256) pyramid_pack_kernel(const uint4 *__restri
     __half2 *h = reinterpret_cast<__half2 *>(&o);
 #pragma unroll
     for (int k = 0; k < 4; k++) h[k] = __floats2half2_rn(sum[2 * k] * 0.0625f, sum[2 * k + 1] * 0.0625f);
+#if CORR_KPLANE == 32
+    out4[(((size_t)blockIdx.y * 4 + (c8 >> 2)) * (W / 4) + (x0 + xl) / 4) * 4 + (c8 & 3)] = o;
+#else
     out4[((size_t)blockIdx.y * 16 + c8) * (W / 4) + (x0 + xl) / 4] = o;
+#endif
   }
 }
 
@@ -906,7 +931,7 @@ int ramp_i_corr_fwd(const void *fmap1, const ramp_corr_level *levels, int nlevel
     hipLaunchKernelGGL((corr_kernel<float, RAMP_NCHW>), grid, dim3(64), 0, st, prm);
   else if (dtype == RAMP_F16 && layout == RAMP_NHWC)
     hipLaunchKernelGGL((corr_mfma_kernel<_Float16, false>), grid, dim3(64), 0, st, prm);
-  else if (dtype == RAMP_F16 && layout == RAMP_NHWC8)
+  else if (dtype == RAMP_F16 && layout == RAMP_NHWC32)
     hipLaunchKernelGGL((corr_mfma_kernel<_Float16, true>), grid, dim3(64), 0, st, prm);
   else if (dtype == RAMP_F16 && layout == RAMP_NCHW)
     hipLaunchKernelGGL((corr_kernel<__half, RAMP_NCHW>), grid, dim3(64), 0, st, prm);

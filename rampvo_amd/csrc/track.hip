@@ -483,7 +483,7 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
                              t->mem * t->M, t->mem, 128, t->P, 3, RAMP_F32, RAMP_NHWC, dyn, st));
     else
       TRK_DO(ramp_i_corr_fwd(t->gmap, lv, 2, t->coords, kk, jj, t->ij_order, t->corr, 896, (long)t->M * t->mem, t->mem, Eb,
-                             t->mem * t->M, t->mem, 128, t->P, 3, RAMP_F16, RAMP_NHWC8, dyn, st));
+                             t->mem * t->M, t->mem, 128, t->P, 3, RAMP_F16, RAMP_NHWC32, dyn, st));
     TRK_PROBE(1);
   }
   if (flags & RAMP_TRACK_UPDATE_POST) {
@@ -520,7 +520,7 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
     lv[1].fmap = t->fmap2; lv[1].H2 = t->feat_h / 4; lv[1].W2 = t->feat_w / 4; lv[1].coord_div = 4.0f;
     TRK_PROBE(0);
     TRK_DO(ramp_i_corr_fwd(t->gmap, lv, 2, t->coords, kk, jj, t->ij_order, t->corr, 896, (long)t->M * t->mem, t->mem, Eb,
-                           t->mem * t->M, t->mem, 128, t->P, 3, RAMP_F16, RAMP_NHWC8, dyn, st,
+                           t->mem * t->M, t->mem, 128, t->P, 3, RAMP_F16, RAMP_NHWC32, dyn, st,
                            fuse_tf ? t->poses : nullptr, t->patches, t->intrinsics, ii));
     TRK_PROBE(1);
     // the update operator, ramp/net.py:69-90 (the fp16 fused chains of csrc/update_mlp.hip)

@@ -312,7 +312,7 @@ class Patchifier(nn.Module):
             chunked = (fmap.dtype == torch.float16 and ops.pyramid_pack_supported(h, w)
                        and f_nhwc[0].is_contiguous())
             if chunked:
-                # both correlation levels in the MFMA kernel's [h][C/8][w][8] target layout
+                # both correlation levels in the MFMA kernel's [h][C/32][w][32] target layout
                 f1, f2 = ops.pyramid_pack(f_nhwc[0])
             else:
                 import torch.nn.functional as F

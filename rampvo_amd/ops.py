@@ -12,7 +12,7 @@ import torch
 from . import _lib
 from ._lib import RAMP_CORR_MFMA32 as _LIB_CORR_MFMA32
 from ._lib import workspace as _lib_workspace
-from ._lib import RAMP_NHWC8, RAMP_NCHW, RAMP_NHWC, CorrLevel, check, dtype_code, lib, ptr, require_cuda, stream
+from ._lib import KPLANE, RAMP_NHWC32, RAMP_NCHW, RAMP_NHWC, CorrLevel, check, dtype_code, lib, ptr, require_cuda, stream
 
 
 # ------------------------------------------------------------------- altcorr
@@ -77,8 +77,8 @@ def corr(fmap1, fmaps2, coords, ii, jj, radius=3, coord_divs=(1.0,), layout=RAMP
         N1, C, P, _ = fmap1.shape
     else:
         N1, P, _, C = fmap1.shape
-    if layout == RAMP_NHWC8:     # fp16 target maps [N2][H][C/8][W][8] (pyramid_pack); fmap1 stays NHWC
-        assert fmap1.dtype == torch.float16 and all(f.dim() == 5 and f.shape[2] * 8 == C and f.shape[4] == 8
+    if layout == RAMP_NHWC32:     # fp16 target maps [N2][H][C/32][W][32] (pyramid_pack); fmap1 stays NHWC
+        assert fmap1.dtype == torch.float16 and all(f.dim() == 5 and f.shape[2] * KPLANE == C and f.shape[4] == KPLANE
                                                     for f in fmaps2)
     E = coords.shape[0]
     L = len(fmaps2)
@@ -87,7 +87,7 @@ def corr(fmap1, fmaps2, coords, ii, jj, radius=3, coord_divs=(1.0,), layout=RAMP
     for l, f in enumerate(fmaps2):
         assert f.dtype == fmap1.dtype and f.shape[0] == N2
         H2, W2 = ((f.shape[2], f.shape[3]) if layout == RAMP_NCHW else
-                  (f.shape[1], f.shape[3]) if layout == RAMP_NHWC8 else (f.shape[1], f.shape[2]))
+                  (f.shape[1], f.shape[3]) if layout == RAMP_NHWC32 else (f.shape[1], f.shape[2]))
         levels[l] = CorrLevel(f.data_ptr(), H2, W2, float(coord_divs[l]))
     d = 2 * radius + 1
     dense = d * d * P * P * L
@@ -168,15 +168,15 @@ def event_topk_supported(events, k, nms_kernel_size):
 
 
 def pyramid_pack(fmap, out1=None, out4=None):
-    """fp16 NHWC map [H,W,128] -> (level1 [H,16,W,8], level4 [H/4,16,W/4,8]) in the correlation
-    kernel's chunked target layout (RAMP_NHWC8); level4 is the 4x4 mean (Ramp_vo.py:378-381)"""
+    """fp16 NHWC map [H,W,128] -> (level1 [H,4,W,32], level4 [H/4,4,W/4,32]) in the correlation
+    kernel's packed target layout (RAMP_NHWC32: one plane per MFMA K step); level4 is the 4x4 mean (Ramp_vo.py:378-381)"""
     require_cuda(fmap)
     H, W, C = fmap.shape
     assert fmap.dtype == torch.float16 and fmap.is_contiguous()
     if out1 is None:
-        out1 = torch.empty((H, C // 8, W, 8), dtype=fmap.dtype, device=fmap.device)
+        out1 = torch.empty((H, C // KPLANE, W, KPLANE), dtype=fmap.dtype, device=fmap.device)
     if out4 is None:
-        out4 = torch.empty((H // 4, C // 8, W // 4, 8), dtype=fmap.dtype, device=fmap.device)
+        out4 = torch.empty((H // 4, C // KPLANE, W // 4, KPLANE), dtype=fmap.dtype, device=fmap.device)
     check(lib().ramp_pyramid_pack(ptr(fmap), ptr(out1), ptr(out4), H, W, C, dtype_code(fmap), stream()),
           "ramp_pyramid_pack")
     return out1, out4

@@ -170,7 +170,7 @@ class DeviceTrack:
         self._keep = []
         t = self.t = Track()
         assert ctypes.sizeof(Track) == lib.ramp_track_sizeof(), "ramp_track mirror out of date"
-        # ring slots: [mem, h, 16, w, 8] (fp16, chunked) or [mem, h, w, 128] (fp32)
+        # ring slots: [mem, h, 4, w, 32] (fp16, chunked) or [mem, h, w, 128] (fp32)
         h, w = slam.fmap1_.shape[1], (slam.fmap1_.shape[3] if slam._chunked else slam.fmap1_.shape[2])
         for name, val in dict(M=M, P=slam.P, mem=slam.mem, n_rows=slam.N, patch_lifetime=r, removal_window=R,
                               opt_window=cfg.OPTIMIZATION_WINDOW, keyframe_index=cfg.KEYFRAME_INDEX, motion_model=1,

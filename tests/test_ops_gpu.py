@@ -204,12 +204,12 @@ def test_pyramid_pack_and_chunked_corr():
     the MFMA correlation over the chunked maps is bit-identical to the NHWC one"""
     import torch.nn.functional as F
     from rampvo_amd import ops
-    from rampvo_amd._lib import RAMP_NHWC, RAMP_NHWC8
+    from rampvo_amd._lib import KPLANE, RAMP_NHWC, RAMP_NHWC32
     g = torch.Generator().manual_seed(5)
     N2, H, W, C = 3, 24, 32, 128
     maps = (torch.randn(N2, H, W, C, generator=g) * 0.5).half().cuda()
-    l1 = torch.empty(N2, H, C // 8, W, 8, dtype=torch.half, device="cuda")
-    l4 = torch.empty(N2, H // 4, C // 8, W // 4, 8, dtype=torch.half, device="cuda")
+    l1 = torch.empty(N2, H, C // KPLANE, W, KPLANE, dtype=torch.half, device="cuda")
+    l4 = torch.empty(N2, H // 4, C // KPLANE, W // 4, KPLANE, dtype=torch.half, device="cuda")
     for n in range(N2):
         ops.pyramid_pack(maps[n], l1[n], l4[n])
     unchunk = lambda t: t.permute(0, 1, 3, 2, 4).reshape(t.shape[0], t.shape[1], t.shape[3], C)
@@ -227,7 +227,7 @@ def test_pyramid_pack_and_chunked_corr():
     jj = torch.from_numpy(rng.integers(0, N2, E)).cuda()
     pooled_h = unchunk(l4).contiguous()
     a = ops.corr(fmap1, [maps, pooled_h], cu(coords), ii, jj, 3, (1.0, 4.0), RAMP_NHWC)
-    b = ops.corr(fmap1, [l1, l4], cu(coords), ii, jj, 3, (1.0, 4.0), RAMP_NHWC8)
+    b = ops.corr(fmap1, [l1, l4], cu(coords), ii, jj, 3, (1.0, 4.0), RAMP_NHWC32)
     assert torch.equal(torch.nan_to_num(a.float(), nan=-7.0), torch.nan_to_num(b.float(), nan=-7.0))
     assert a.float().abs().max() > 0
 

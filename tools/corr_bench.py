@@ -11,8 +11,8 @@ def case(E=40000, M=96, slots=36, H=120, W=160, seed=0, window=22, far=0.48):
     g = torch.Generator(device="cuda").manual_seed(seed)
     rng = np.random.default_rng(seed)
     f1 = (torch.randn(slots * M, 3, 3, 128, generator=g, device="cuda") * 0.5).half()
-    l1 = (torch.randn(slots, H, 16, W, 8, generator=g, device="cuda") * 0.5).half()
-    l4 = (torch.randn(slots, H // 4, 16, W // 4, 8, generator=g, device="cuda") * 0.5).half()
+    l1 = (torch.randn(slots, H, 4, W, 32, generator=g, device="cuda") * 0.5).half()
+    l4 = (torch.randn(slots, H // 4, 4, W // 4, 32, generator=g, device="cuda") * 0.5).half()
     jj = np.sort(rng.integers(100, 100 + window, E)).astype(np.int64)
     kk = rng.integers(0, 3 * slots * M, E).astype(np.int64)
     cx = rng.uniform(-4, W + 4, E); cy = rng.uniform(-4, H + 4, E)
@@ -50,14 +50,14 @@ def timed(fn, n=30):
 
 if __name__ == "__main__":
     from rampvo_amd import ops
-    from rampvo_amd._lib import RAMP_NHWC8
+    from rampvo_amd._lib import RAMP_NHWC32
     f1, l1, l4, coords, kk, jj, M, slots = case(far=float(os.environ.get("CORR_FAR", 0.48)))
     E = coords.shape[0]
     n0, bw0, bh0 = window_stats(coords, 120, 160, 1.0)
     print("fine level: nothing in the plane %.3f | union window > 128 px %.3f of the live ones" % ((n0 == 0).mean(), (bw0 * bh0 > 128)[n0 > 0].mean()))
     order = torch.argsort(jj, stable=True).int()
     kw = dict(order=order, row_elems=896, mod_ii=slots * M, mod_jj=slots)
-    fn = lambda: ops.corr(f1, [l1, l4], coords, kk, jj, 3, (1.0, 4.0), RAMP_NHWC8, **kw)
+    fn = lambda: ops.corr(f1, [l1, l4], coords, kk, jj, 3, (1.0, 4.0), RAMP_NHWC32, **kw)
     out = fn()
     print("corr: %.1f us per call" % timed(fn))
     ref = os.environ.get("CORR_REF_OUT")

@@ -29,7 +29,7 @@ for name, H, W, cdv in (("fine", 120, 160, 1.0), ("coarse", 30, 40, 4.0)):
 
 # ---- the correlation kernel alone on exactly these factors (the tracker's own buffers and schedule)
 from rampvo_amd import ops
-from rampvo_amd._lib import RAMP_NHWC8
+from rampvo_amd._lib import RAMP_NHWC32
 from corr_bench import timed
 Ec = dv.t.E_cap
 g = dv.graph[dv.cur]

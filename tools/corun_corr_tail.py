@@ -9,7 +9,7 @@ import numpy as np, torch
 from rampvo_amd import _lib
 from rampvo_amd._lib import check, lib, ptr
 from rampvo_amd.config import make_cfg
-from rampvo_amd.Ramp_vo import Ramp_vo, RAMP_NHWC8
+from rampvo_amd.Ramp_vo import Ramp_vo, RAMP_NHWC32
 CORR_ROW = 896
 from rampvo_amd.synthetic import SyntheticStream, make_network
 torch.manual_seed(1234)
@@ -46,7 +46,7 @@ def corr_rows(r0, n):
     check(lib().ramp_corr_fwd_ordered(
         ptr(slam.gmap_), lv, 2, co.data_ptr() + r0 * 72, kk.data_ptr() + r0 * 8, jj.data_ptr() + r0 * 8, None,
         corr.data_ptr() + r0 * CORR_ROW * 2, CORR_ROW, slam.M * slam.mem, slam.mem, n, slam.mem * slam.M, slam.mem, 128, 3, 3,
-        _lib.RAMP_F16, RAMP_NHWC8, _lib.stream()), "corr")
+        _lib.RAMP_F16, RAMP_NHWC32, _lib.stream()), "corr")
 
 
 def mlp_rows(r0, n):
