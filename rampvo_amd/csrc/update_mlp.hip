@@ -687,6 +687,9 @@ __global__ void __launch_bounds__(64 * MWAVES) __attribute__((amdgpu_waves_per_e
     for (int ks0 = 0; ks0 < nks_total; ks0 += MKS) {
       const int nks = min(MKS, nks_total - ks0);
       const int v8 = nks * 4;                                  // 16-byte vectors per row of this chunk
+#ifdef CTAIL_SKIP_STAGE                                        // (diagnostic: what the staging of Linear1's operand costs)
+      if (ks0 == 0)
+#endif
       for (int i = tid; i < MBM * v8; i += 64 * MWAVES) {
         const int r = i / v8, c8 = i - r * v8;
         h8 v = (h8){0, 0, 0, 0, 0, 0, 0, 0};
@@ -694,7 +697,9 @@ __global__ void __launch_bounds__(64 * MWAVES) __attribute__((amdgpu_waves_per_e
         *reinterpret_cast<h8 *>(Xs + r * MXS + 8 * c8) = v;
       }
       __syncthreads();
+#ifndef CTAIL_SKIP_L1                                          // (diagnostic: Linear1's products)
       mlp_gemm_chunk(Xs, p.w1, wave, lane, nks, ks0, acc);
+#endif
       __syncthreads();                                         // before the tile is overwritten
     }
 #pragma unroll
