@@ -424,7 +424,11 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvParams &p, const f3
     const int c = tid >> 1, k = tid & 1;
     const float v = ((s_stat[0][c][k] + s_stat[1][c][k]) + s_stat[2][c][k]) + s_stat[3][c][k];
     if (p.acc_out)
+#ifdef HZ_SKIP_ATOM                                   // (diagnostic: what the statistics' atomics cost)
+      { if (v == 123.456f) p.acc_out[0] = 1; }
+#else
       atomicAdd(p.acc_out + ((size_t)(blockIdx.x % IN_ACC_R) * p.Cout + n0 + c) * 2 + k, in_acc_fix(v));
+#endif
     else
       p.stats[((size_t)(n0 + c) * 2 + k) * gridDim.x + blockIdx.x] = v;   // [C][2][nblk]: contiguous per channel
   }
@@ -448,6 +452,9 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvParams &p, const f3
     f16x8 h;
 #pragma unroll
     for (int c = 0; c < 8; c++) h[c] = (_Float16)(v[c] * p.out_scale);
+#ifdef HZ_SKIP_STORE                                  // (diagnostic: what the output stores cost)
+    if (v[0] == 123.456f)
+#endif
     *reinterpret_cast<f16x8 *>(reinterpret_cast<_Float16 *>(p.y) + go) = h;
   }
 }
@@ -1836,6 +1843,10 @@ int ramp_conv2d_nhwc_multi(const ramp_conv_job *jobs, int njobs, int H, int W, i
   TILE_CASE(7, 2, true, 16, 2)
   TILE_CASE(3, 1, false, 32, 2)
   TILE_CASE(3, 2, false, 32, 2)
+  // (stride 2 at 64 channels, the MultiScale towers' layer3: the 80 KB halo tile leaves one workgroup per CU either way;
+  // with all 64 output channels in it the tile is staged once instead of twice -- RAMP_CONV_S2_NT4=0 for the A/B)
+  static const bool s2nt4 = !getenv("RAMP_CONV_S2_NT4") || atoi(getenv("RAMP_CONV_S2_NT4")) != 0;
+  if (s2nt4) { TILE_CASE(3, 2, false, 64, 4) }
   TILE_CASE(3, 2, false, 64, 2)
   TILE_CASE(3, 1, false, 64, 2)
   TILE_CASE(1, 2, false, 32, 4)
