@@ -403,6 +403,16 @@ typedef struct ramp_conv_job {
    * 8, no input normalisation.  x2 = NULL: one source                                                              */
   const void *x2;
   int32_t c0;
+  /* fused residual-block tail (half in, accumulator mode; ramp/extractor.py:49-57): with `skip` [H][W][Cin] the input
+   * pixel is relu(relu(x * scale + shift) + skip') -- x normalised through acc_in, skip' = skip, or skip normalised through
+   * acc_skip (+ skip_count, skip_eps), or the fp16-rounded relu of that (skip_relu) -- rounded to fp16 once: what
+   * ramp_norm_add_relu_f16_acc writes, without the launch.  `mat` [H][W][Cin] (stride-1 layers): the pixels are also
+   * written out, each by the workgroup that owns it, for the block that takes them as its skip.  NULL: a plain input  */
+  const void *skip;
+  const void *acc_skip;
+  float skip_count, skip_eps;
+  int32_t skip_relu;
+  void *mat;
 } ramp_conv_job;
 #define RAMP_IN_ACC_R 8
 int ramp_conv2d_nhwc_multi(const ramp_conv_job *jobs, int njobs, int H, int W, int Cin, int KH, int stride,

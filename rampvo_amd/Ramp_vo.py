@@ -62,6 +62,7 @@ def _gru_tile_rows(E, device):
 
 _FE_DELAY_US = int(os.environ.get("RAMP_FE_DELAY_US", "35"))     # A/B switch: 0 = the encoder graph right behind the selection
 _GATE_FLAG_DELAY_US = int(os.environ.get("RAMP_GATE_FLAG_DELAY_US", "0"))
+_FE_WAIT_PROBE = os.environ.get("RAMP_FE_WAIT_PROBE", "0") == "1"   # tools/fe_wait.py
 _WARM = os.environ.get("RAMP_WARM", "1") != "0"     # A/B switch: the cache warm-up behind the front end
 
 
@@ -744,7 +745,14 @@ class Ramp_vo:
                                             event_bias=self.event_bias, reinit_hidden=False,
                                             pre_replay=(lambda: self._gate_wait(fe)) if ahead else self._fe_delay)
             self._ev_fe_done.record(fe)
-            cur.wait_event(self._ev_fe_done)
+            if _FE_WAIT_PROBE:                      # (diagnostic: how long the main queue waits for the front end)
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(cur)
+                cur.wait_event(self._ev_fe_done)
+                b.record(cur)
+                self.fe_wait_pairs.append((a, b))
+            else:
+                cur.wait_event(self._ev_fe_done)
             if _WARM and not dv.fp32:
                 # (behind the event: the frame does not wait for it) the window's correlation planes back into the
                 # memory-side cache while the previous frame's bundle adjustment is still running

@@ -189,7 +189,34 @@ class ConvJob(ctypes.Structure):
                 ("Cout", ctypes.c_int32), ("relu", ctypes.c_int32), ("out_scale", ctypes.c_float),
                 ("act_scale", ctypes.c_float), ("w_scale", ctypes.c_float),
                 ("acc_out", ctypes.c_void_p), ("acc_in", ctypes.c_void_p), ("in_count", ctypes.c_float),
-                ("in_eps", ctypes.c_float), ("x2", ctypes.c_void_p), ("c0", ctypes.c_int32)]
+                ("in_eps", ctypes.c_float), ("x2", ctypes.c_void_p), ("c0", ctypes.c_int32),
+                ("skip", ctypes.c_void_p), ("acc_skip", ctypes.c_void_p), ("skip_count", ctypes.c_float),
+                ("skip_eps", ctypes.c_float), ("skip_relu", ctypes.c_int32), ("mat", ctypes.c_void_p)]
+
+
+_TAIL_FUSE = os.environ.get("RAMP_CONV_TAIL_FUSE", "1") != "0"   # A/B switch: 0 = a norm_add_relu launch per residual block
+
+
+class Tail:
+    """a residual block's output relu(skip' + relu(norm(y))) that has not been computed yet (fp16 towers in accumulator
+    mode): the LDS-tiled conv kernel forms it while it loads its input tile (ramp_conv_job.skip), and a stride-1 consumer
+    writes it out on the way (``mat``) for the next block's skip.  ``tensor()`` computes it with the launch of its own
+    (consumers without that path)."""
+    __slots__ = ("y", "skip", "out", "written")
+
+    def __init__(self, y, skip):
+        self.y, self.skip, self.out, self.written = y, skip, None, False
+
+    def tensor(self):
+        if not self.written:
+            self.out = norm_add_relu(self.y, self.skip, fuse=False)
+            self.written = True
+        return self.out
+
+    def fusable(self):
+        sp = isinstance(self.skip, Pending)
+        return (self.y.raw.dtype == torch.float16 and self.y.acc is not None and self.y._scale is None and self.y.relu
+                and self.y.raw.shape[-1] <= 128 and (not sp or (self.skip.acc is not None and self.skip._scale is None)))
 
 
 class Pair:
@@ -228,6 +255,8 @@ def conv2d(x, conv, pre=None, res=None, relu=False, want_stats=False, out_scale=
     """x [H,W,Cin] NHWC (or a Pending: normalise+ReLU on load).  fp32 in/out, or with ``half``:
     half out and half in (fp32 in allowed for the 16-channel first layer).  Returns y [OH,OW,Cout],
     or Pending(y, scale, shift) when want_stats (InstanceNorm statistics of y, always fp32)."""
+    if isinstance(x, Tail):
+        x = x.tensor()
     if isinstance(x, Pending):
         assert x.relu
         pre, x = (x.scale, x.shift), x.raw
@@ -267,12 +296,16 @@ def conv2d_towers(jobs, half, fp8=False):
     row -- was measured and dropped: the device-scope release every workgroup needs before its ticket writes the
     XCD's L2 back, 1.24 ms per front end instead of 0.47.)"""
     def single():
+        for j in jobs:
+            if isinstance(j.get("res"), Tail):
+                j["res"] = j["res"].tensor()
         return [conv2d(j["x"].cat() if isinstance(j["x"], Pair) else j["x"], j["conv"], res=j.get("res"),
                        relu=j.get("relu", False), want_stats=j.get("want_stats", False),
                        out_scale=j.get("out_scale", 1.0), eps=j.get("eps", 1e-5), half=half) for j in jobs]
     if not half or len(jobs) > 2 or os.environ.get("RAMP_TOWER_PAIR", "1") != "1":
         return single()
-    x0 = jobs[0]["x"].raw if isinstance(jobs[0]["x"], Pending) else jobs[0]["x"]
+    x0 = jobs[0]["x"]
+    x0 = x0.y.raw if isinstance(x0, Tail) else x0.raw if isinstance(x0, Pending) else x0
     paired = isinstance(x0, Pair)
     if paired:
         if not all(isinstance(j["x"], Pair) and j["x"].a.shape == x0.a.shape and j["x"].b.shape == x0.b.shape for j in jobs):
@@ -295,13 +328,19 @@ def conv2d_towers(jobs, half, fp8=False):
     if nblk != tiles_y * ((OW + 15) // 16):
         return single()                          # not a tiled-kernel layer shape
     arr = (ConvJob * len(jobs))()
-    outs, finalize = [], []
+    outs, finalize, written = [], [], []
     for t, j in enumerate(jobs):
         x, conv = j["x"], j["conv"]
         pre = acc_in = None
         x2 = None
+        tail = None
         if paired:
             x, x2 = x.a, x.b
+        if isinstance(x, Tail):
+            if x.written or not x.fusable() or use8 or _scope.cur is None:   # (fp8 / per-block statistics: no fused instance)
+                x = x.tensor()
+            else:
+                tail, x = x, x.y
         if isinstance(x, Pending):
             assert x.relu
             if x.acc is not None and x._scale is None and Cin <= 128:
@@ -319,6 +358,8 @@ def conv2d_towers(jobs, half, fp8=False):
         assert conv.weight.shape[2] == kh and conv.stride[0] == stride and conv.padding[0] == kh // 2
         assert Cin == wpk.shape[1] * (32 if mode == "f16" else 16)
         res = j.get("res")
+        if isinstance(res, Tail):
+            res = res.tensor()
         assert res is None or (res.is_contiguous() and res.dtype == odt)
         y = torch.empty(OH, OW, cout, dtype=odt, device=x.device)
         a = arr[t]
@@ -326,6 +367,23 @@ def conv2d_towers(jobs, half, fp8=False):
         a.x2, a.c0 = (ptr(x2), x.shape[2]) if x2 is not None else (None, 0)
         a.pre_scale, a.pre_shift = (ptr(pre[0]), ptr(pre[1])) if pre else (None, None)
         a.acc_in, a.in_count, a.in_eps = (ptr(acc_in.acc), acc_in.count, acc_in.eps) if acc_in else (None, 0.0, 0.0)
+        a.skip = a.acc_skip = a.mat = None
+        a.skip_count = a.skip_eps = 0.0
+        a.skip_relu = 0
+        if tail is not None:
+            assert acc_in is not None
+            sk = tail.skip
+            if isinstance(sk, Tail):
+                sk = sk.tensor()
+            if isinstance(sk, Pending):
+                a.skip, a.acc_skip, a.skip_count, a.skip_eps, a.skip_relu = ptr(sk.raw), ptr(sk.acc), sk.count, sk.eps, int(sk.relu)
+            else:
+                assert sk.is_contiguous() and sk.dtype == x.dtype and sk.shape == x.shape
+                a.skip = ptr(sk)
+            if stride == 1 and j.get("keep", True):
+                tail.out = torch.empty_like(x)
+                a.mat = ptr(tail.out)
+                written.append(tail)
         a.acc_out = None
         a.res, a.y = ptr(res), ptr(y)
         a.Cout, a.relu, a.out_scale = cout, int(j.get("relu", False)), float(j.get("out_scale", 1.0))
@@ -345,10 +403,14 @@ def conv2d_towers(jobs, half, fp8=False):
             outs.append(y)
     rc = lib().ramp_conv2d_nhwc_multi(arr, len(jobs), H, W, Cin, kh, stride, code, stream())
     if rc == _lib.RAMP_EUNSUPPORTED:
+        for tl in written:
+            tl.out = None
         if use8:
             return conv2d_towers(jobs, half, fp8=False)      # a layer shape without an fp8 instantiation: f16 MFMA
         return single()
     check(rc, "ramp_conv2d_nhwc_multi")
+    for tl in written:
+        tl.written = True
     for stats, cout, scale, shift, eps in finalize:
         check(lib().ramp_in_stats_finalize(ptr(stats), nblk, cout, float(OH * OW), eps, ptr(scale), ptr(shift),
                                            stream()), "ramp_in_stats_finalize")
@@ -364,8 +426,15 @@ def materialize(p):
     return out
 
 
-def norm_add_relu(y, skip):
-    """relu(skip' + relu(norm(y)));  skip is a tensor or a Pending (its norm, with or without ReLU, applied here)"""
+def norm_add_relu(y, skip, fuse=True):
+    """relu(skip' + relu(norm(y)));  skip is a tensor or a Pending (its norm, with or without ReLU, applied here).  Returns
+    the tensor, or (fp16 towers in accumulator mode) a Tail the next layer's conv kernel evaluates while loading"""
+    if isinstance(skip, Tail):
+        skip = skip.tensor()
+    if fuse and _TAIL_FUSE:
+        t = Tail(y, skip)
+        if t.fusable():
+            return t
     out = torch.empty_like(y.raw)
     sp = isinstance(skip, Pending)
     if (y.raw.dtype == torch.float16 and y.acc is not None and y._scale is None and y.raw.shape[-1] <= 128
@@ -435,7 +504,7 @@ def basic_encoder4_towers(encs, x, out_scale=1.0, half=False, fp8=False):
         for li in ("layer1", "layer2"):
             for b in range(2):
                 xs = _res_blocks([getattr(e, li)[b] for e in encs], xs, norms, half, fp8)
-        return conv2d_towers([dict(x=xs[t], conv=e.conv2, out_scale=out_scale) for t, e in enumerate(encs)], half, fp8)
+        return conv2d_towers([dict(x=xs[t], conv=e.conv2, out_scale=out_scale, keep=False) for t, e in enumerate(encs)], half, fp8)
     finally:
         _scope.cur = None
 
@@ -459,10 +528,12 @@ def multiscale_encoder4_towers(encs, x, x2, x4, out_scale=1.0, half=False, fp8=F
             xs = _res_blocks([e.layer1[b] for e in encs], xs, norms, half, fp8)
         # the channel concatenations: two-source inputs of the next layer (fp16 towers; ramp_conv_job.x2), else copies
         two = half and _MS_PAIR
+        xs = [v.tensor() if isinstance(v, Tail) else v for v in xs]           # (a two-source input takes tensors)
         x2 = x2.to(xs[0].dtype)
         xs = [Pair(v, x2) if two else torch.cat((v, x2), dim=-1) for v in xs]
         for b in range(2):
             xs = _res_blocks([e.layer3[b] for e in encs], xs, norms, half, fp8)
+        xs = [v.tensor() if isinstance(v, Tail) else v for v in xs]
         x4 = x4.to(xs[0].dtype)
         xs = [Pair(v, x4) if two else torch.cat((v, x4), dim=-1) for v in xs]
         return conv2d_towers([dict(x=xs[t], conv=e.conv3, out_scale=out_scale) for t, e in enumerate(encs)], half, fp8)

@@ -91,6 +91,16 @@ struct ConvParams {
   // [H][W][C0]) -- the MultiScale towers' torch.cat((x, x_down2), channel) without the copy (ramp/extractor.py:300, 306)
   const void *x2;
   int C0;
+  // LDS-tiled fp16 kernel only: the residual block's tail applied while the NEXT layer loads its input -- the input pixel is
+  // relu(relu(x * scale + shift) + skip') with skip' = skip, skip * scale_s + shift_s (acc_skip) or the fp16-rounded
+  // relu of that (skip_relu): norm_add_relu_f16_acc_kernel's expression, rounded to fp16 once as that kernel's output is.
+  // `mat`: the workgroups of a stride-1 layer also write the pixels they own [H][W][Cin], for the block that needs them as
+  // its skip (ramp/extractor.py:49-57; one launch per residual block less)
+  const void *skip;
+  const unsigned long long *acc_skip;
+  float skip_count, skip_eps;
+  int skip_relu;
+  void *mat;
 };
 // up to two independent problems of one layer shape in one launch (blockIdx.z): the towers of the encoder
 struct ConvMulti { ConvParams t[2]; };
@@ -389,10 +399,10 @@ __global__ void __launch_bounds__(256)
 // epilogue of the LDS-tiled kernels: bias, InstanceNorm partial statistics, ReLU -> fp32 tile in LDS (aliases the
 // input / weight tiles: the caller has passed a barrier after its last read of them) -> residual, scale, coalesced
 // 16-byte stores.  acc[mt][nt]: rows 2 wave + mt of the 8 x 16 tile, 16-channel tile nt of the block starting at n0.
-template <int NT>
-__device__ __forceinline__ void conv_tile_epilogue(const ConvParams &p, const f32x4 (&acc)[2][NT], unsigned char *smem,
+template <int NT, int TH = 8>
+__device__ __forceinline__ void conv_tile_epilogue(const ConvParams &p, const f32x4 (&acc)[TH / 4][NT], unsigned char *smem,
                                                    float (&s_stat)[4][NT * 16][2], int oy0, int ox0, int n0) {
-  constexpr int TH = 8, TW = 16;
+  constexpr int TW = 16, MTW = TH / 4;                // (m-tiles per wave: rows MTW wave + mt of the TH x 16 tile)
   constexpr int OSTR = NT * 16 + 4;                   // fp32 staging row (floats), 16-byte aligned
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, j = lane & 15;
   float *s_out = reinterpret_cast<float *>(smem);
@@ -402,8 +412,8 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvParams &p, const f3
     const float bv = p.bias ? p.bias[c] : 0.0f;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int mt = 0; mt < 2; mt++) {
-      const int r = 2 * wave + mt;
+    for (int mt = 0; mt < MTW; mt++) {
+      const int r = MTW * wave + mt;
 #pragma unroll
       for (int rr = 0; rr < 4; rr++) {
         const int xx = 4 * q + rr;
@@ -460,8 +470,8 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvParams &p, const f3
 }
 
 // dynamic LDS bytes of conv_tile_f16_kernel<K, S, IN_F32, CIN, NT, FP8> (the kernel asserts the same number)
-constexpr int conv_tile_lds_bytes(int K, int S, bool IN_F32, int CIN, int NT, bool FP8) {
-  const int TH = 8, TW = 16, SP = K == 1 ? 1 : S;
+constexpr int conv_tile_lds_bytes(int K, int S, bool IN_F32, int CIN, int NT, bool FP8, int TH = 8) {
+  const int TW = 16, SP = K == 1 ? 1 : S;
   const int IH = (TH - 1) * SP + K, IW = (TW - 1) * SP + K;
   const int PSTR = FP8 ? CIN + 8 : CIN * 2 + 16;
   const int KC = IN_F32 ? 16 : 32, NCH = CIN / KC, FRAG = (IN_F32 || FP8) ? 8 : 16;
@@ -487,12 +497,14 @@ static int conv_tile_attr(KernelT kernel, int lds) {
 //   3. bias / statistics / ReLU in registers, then the tile goes through LDS once more (fp32) so
 //      the residual is read and the result written as contiguous 16-byte pieces.
 // Same accumulation order as the direct kernel => identical results.
-template <int K, int S, bool IN_F32, int CIN, int NT, bool FP8 = false>
+template <int K, int S, bool IN_F32, int CIN, int NT, bool FP8 = false, int TH = 8, bool TAIL = false>
 __global__ void __launch_bounds__(256) conv_tile_f16_kernel(const ConvMulti pm) {
+  static_assert(!TAIL || (!IN_F32 && !FP8 && K != 7), "the fused block tail: f16 instances behind the first layer");
   static_assert(!(FP8 && IN_F32), "the fp32-input first layer stays on the f16 MFMA");
   const ConvParams &p = pm.t[blockIdx.z];
   if ((int)blockIdx.y * NT * 16 >= p.Cout) return;    // the towers may differ in Cout (grid.y = the larger one's)
-  constexpr int PAD = K / 2, TH = 8, TW = 16;
+  constexpr int PAD = K / 2, TW = 16, MTW = TH / 4;   // (TH = 16: half the weight staging and 1.27 instead of 1.41 halo reads per
+                                                      // output pixel; for the layers whose tile count still fills the chip)
   constexpr int SP = K == 1 ? 1 : S;                  // tile-pixel step between output neighbours
   constexpr int STEP = K == 1 ? S : 1;                // image-pixel step between tile pixels
   constexpr int IH = (TH - 1) * SP + K, IW = (TW - 1) * SP + K;
@@ -508,7 +520,7 @@ __global__ void __launch_bounds__(256) conv_tile_f16_kernel(const ConvMulti pm) 
   constexpr int OBYTES = TH * TW * OSTR * 4;
   constexpr int SMB = (WBYTES + IBYTES) > OBYTES ? (WBYTES + IBYTES) : OBYTES;
   static_assert(256 % CH8 == 0, "a thread keeps one channel slot");
-  static_assert(SMB == conv_tile_lds_bytes(K, S, IN_F32, CIN, NT, FP8), "launch-side size out of date");
+  static_assert(SMB == conv_tile_lds_bytes(K, S, IN_F32, CIN, NT, FP8, TH), "launch-side size out of date");
   // (dynamic: the stride-2 64-channel layer of the MultiScale towers needs 118 KB -- above the static limit)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ float s_stat[4][NT * 16][2];
@@ -550,7 +562,22 @@ __global__ void __launch_bounds__(256) conv_tile_f16_kernel(const ConvMulti pm) 
       ibuf[n] = reinterpret_cast<const u32x4 *>(p.x)[((size_t)cy * p.W + cx) * CH8 + cslot];
     }
   }
-  float sc[8], sh[8];
+  // (uniform) fused block tail: the skip operand of every tile pixel, in flight with the rest
+  // (TAIL instances: a launch in which one of the towers takes a fused block tail; the other instances keep their registers)
+  constexpr int NS = TAIL ? NI : 1;
+  const bool tail = TAIL && p.skip != nullptr;
+  u32x4 kbuf[NS];
+  if (tail) {
+#pragma unroll
+    for (int n = 0; n < NS; n++) {
+      const int i = tid + n * 256;
+      const int pix = i / CH8, ty = pix / IW, tx = pix - ty * IW;
+      const int gy = oy0 * S + ty * STEP - PAD, gx = ox0 * S + tx * STEP - PAD;
+      const bool ok = i < NITEM && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+      kbuf[n] = reinterpret_cast<const u32x4 *>(p.skip)[((size_t)(ok ? gy : 0) * p.W + (ok ? gx : 0)) * CH8 + cslot];
+    }
+  }
+  float sc[8], sh[8], sc2[8], sh2[8];
   const bool pre = p.pre_scale != nullptr || p.acc_in != nullptr;
   if (p.acc_in) {                                     // (uniform) the input's InstanceNorm from its accumulators
     float *s_sc = reinterpret_cast<float *>(s_in), *s_sh = s_sc + 128;
@@ -558,6 +585,12 @@ __global__ void __launch_bounds__(256) conv_tile_f16_kernel(const ConvMulti pm) 
     in_acc_finalize(p.acc_in, p.Cin, p.in_count, p.in_eps, s_sc, s_sh, s_sum);
 #pragma unroll
     for (int c = 0; c < CPI; c++) { sc[c] = s_sc[cslot * CPI + c]; sh[c] = s_sh[cslot * CPI + c]; }
+    if (tail && p.acc_skip) {                         // (uniform) the skip's own InstanceNorm (conv1's, the downsample path's)
+      __syncthreads();
+      in_acc_finalize(p.acc_skip, p.Cin, p.skip_count, p.skip_eps, s_sc, s_sh, s_sum);
+#pragma unroll
+      for (int c = 0; c < CPI; c++) { sc2[c] = s_sc[cslot * CPI + c]; sh2[c] = s_sh[cslot * CPI + c]; }
+    }
     __syncthreads();                                  // the tables sit where the input tile goes
   } else if (pre) {
 #pragma unroll
@@ -599,8 +632,19 @@ __global__ void __launch_bounds__(256) conv_tile_f16_kernel(const ConvMulti pm) 
       f16x8 h = __builtin_bit_cast(f16x8, ibuf[n]);
 #pragma unroll
       for (int c = 0; c < 8; c++) {
-        const float v = pre ? fmaxf((float)h[c] * sc[c] + sh[c], 0.f) : (float)h[c];
+        float v = pre ? fmaxf((float)h[c] * sc[c] + sh[c], 0.f) : (float)h[c];
+        if (tail) {
+          float b = (float)__builtin_bit_cast(f16x8, kbuf[n < NS ? n : 0])[c];
+          if (p.acc_skip) b = b * sc2[c] + sh2[c];
+          if (p.skip_relu) b = (float)(_Float16)fmaxf(b, 0.f);
+          v = fmaxf(v + b, 0.f);
+        }
         h[c] = iok[n] ? (_Float16)v : (_Float16)0.f;
+      }
+      if (TAIL && tail && p.mat && S == 1) {
+        const int ty = pix / IW, tx = pix - ty * IW;
+        if (i < NITEM && iok[n] && blockIdx.y == 0 && ty >= PAD && ty < PAD + TH && tx >= PAD && tx < PAD + TW)
+          reinterpret_cast<f16x8 *>(p.mat)[((size_t)(oy0 + ty - PAD) * p.W + ox0 + tx - PAD) * CH8 + cslot] = h;
       }
       if (i < NITEM) *reinterpret_cast<f16x8 *>(s_in + pix * PSTR + cslot * 16) = h;
     }
@@ -608,12 +652,12 @@ __global__ void __launch_bounds__(256) conv_tile_f16_kernel(const ConvMulti pm) 
   __syncthreads();
 
   // ---- 2. MFMA from LDS   (HZ_*: diagnostic builds for tools/mb/pk_hazard.hip only)
-  f32x4 acc[2][NT];
+  f32x4 acc[MTW][NT];
 #pragma unroll
-  for (int a = 0; a < 2; a++)
+  for (int a = 0; a < MTW; a++)
 #pragma unroll
     for (int b = 0; b < NT; b++) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const unsigned char *a_base = s_in + ((2 * wave) * SP * IW + j * SP) * PSTR + q * ((IN_F32 || FP8) ? 8 : 16);
+  const unsigned char *a_base = s_in + ((MTW * wave) * SP * IW + j * SP) * PSTR + q * ((IN_F32 || FP8) ? 8 : 16);
   const unsigned char *b_base = s_w + lane * FRAG;
 #ifndef HZ_SKIP_MMA
 #pragma unroll
@@ -624,41 +668,41 @@ __global__ void __launch_bounds__(256) conv_tile_f16_kernel(const ConvMulti pm) 
       for (int ch = 0; ch < NCH; ch++) {
         const int tap = ky * K + kx;
         if (IN_F32) {
-          f16x4 a[2], b[NT];
+          f16x4 a[MTW], b[NT];
 #pragma unroll
-          for (int mt = 0; mt < 2; mt++)
+          for (int mt = 0; mt < MTW; mt++)
             a[mt] = *reinterpret_cast<const f16x4 *>(a_base + ((mt * SP + ky) * IW + kx) * PSTR + ch * KC * 2);
 #pragma unroll
           for (int nt = 0; nt < NT; nt++)
             b[nt] = *reinterpret_cast<const f16x4 *>(b_base + ((tap * NCH + ch) * NT + nt) * 64 * FRAG);
 #pragma unroll
-          for (int mt = 0; mt < 2; mt++)
+          for (int mt = 0; mt < MTW; mt++)
 #pragma unroll
             for (int nt = 0; nt < NT; nt++)
               acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
         } else if (FP8) {
-          long a[2], b[NT];
+          long a[MTW], b[NT];
 #pragma unroll
-          for (int mt = 0; mt < 2; mt++)
+          for (int mt = 0; mt < MTW; mt++)
             a[mt] = *reinterpret_cast<const long *>(a_base + ((mt * SP + ky) * IW + kx) * PSTR + ch * KC);
 #pragma unroll
           for (int nt = 0; nt < NT; nt++)
             b[nt] = *reinterpret_cast<const long *>(b_base + ((tap * NCH + ch) * NT + nt) * 64 * FRAG);
 #pragma unroll
-          for (int mt = 0; mt < 2; mt++)
+          for (int mt = 0; mt < MTW; mt++)
 #pragma unroll
             for (int nt = 0; nt < NT; nt++)
               acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
         } else {
-          f16x8 a[2], b[NT];
+          f16x8 a[MTW], b[NT];
 #pragma unroll
-          for (int mt = 0; mt < 2; mt++)
+          for (int mt = 0; mt < MTW; mt++)
             a[mt] = *reinterpret_cast<const f16x8 *>(a_base + ((mt * SP + ky) * IW + kx) * PSTR + ch * KC * 2);
 #pragma unroll
           for (int nt = 0; nt < NT; nt++)
             b[nt] = *reinterpret_cast<const f16x8 *>(b_base + ((tap * NCH + ch) * NT + nt) * 64 * FRAG);
 #pragma unroll
-          for (int mt = 0; mt < 2; mt++)
+          for (int mt = 0; mt < MTW; mt++)
 #pragma unroll
             for (int nt = 0; nt < NT; nt++)
               acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
@@ -671,16 +715,16 @@ __global__ void __launch_bounds__(256) conv_tile_f16_kernel(const ConvMulti pm) 
 
   if (FP8) {
 #pragma unroll
-    for (int a = 0; a < 2; a++)
+    for (int a = 0; a < MTW; a++)
 #pragma unroll
       for (int b = 0; b < NT; b++)
 #pragma unroll
         for (int r = 0; r < 4; r++) acc[a][b][r] *= p.descale;
   }
 #ifdef HZ_SKIP_EPI
-  if (acc[0][0][0] + acc[1][NT - 1][3] == 123.456f) reinterpret_cast<_Float16 *>(p.y)[tid] = (_Float16)acc[0][0][1];
+  if (acc[0][0][0] + acc[MTW - 1][NT - 1][3] == 123.456f) reinterpret_cast<_Float16 *>(p.y)[tid] = (_Float16)acc[0][0][1];
 #else
-  conv_tile_epilogue<NT>(p, acc, smem, s_stat, oy0, ox0, n0);
+  conv_tile_epilogue<NT, TH>(p, acc, smem, s_stat, oy0, ox0, n0);
 #endif
 }
 
@@ -1717,6 +1761,7 @@ int ramp_conv2d_nhwc(const void *x, const void *wpk, const float *bias, const fl
   ConvParams p;
   p.x = x; p.wpk = wpk; p.bias = bias; p.pre_scale = pre_scale; p.pre_shift = pre_shift;
   p.res = res; p.y = y; p.stats = stats; p.x2 = nullptr; p.C0 = 0;
+  p.skip = nullptr; p.acc_skip = nullptr; p.skip_count = 0.f; p.skip_eps = 0.f; p.skip_relu = 0; p.mat = nullptr;
   p.acc_out = nullptr; p.acc_in = nullptr; p.in_count = 0.f; p.in_eps = 0.f;
   p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
   const int pad = KH / 2;
@@ -1788,6 +1833,13 @@ int ramp_conv2d_nhwc_multi(const ramp_conv_job *jobs, int njobs, int H, int W, i
     p.x = j.x; p.wpk = j.wpk; p.bias = j.bias; p.pre_scale = j.pre_scale; p.pre_shift = j.pre_shift;
     p.res = j.res; p.y = j.y; p.stats = j.stats;
     p.x2 = j.x2; p.C0 = j.c0;
+    p.skip = j.skip; p.acc_skip = (const unsigned long long *)j.acc_skip; p.skip_count = j.skip_count; p.skip_eps = j.skip_eps;
+    p.skip_relu = j.skip_relu; p.mat = j.mat;
+    if (p.skip && (in_f32 || !j.acc_in || p.x2 || Cin > 128 || (p.acc_skip && !(p.skip_count > 0.f)) || (p.skip_relu && !p.acc_skip) ||
+                   (p.mat && (stride != 1 || (KH != 1 && KH != 3)))))
+      return RAMP_EINVAL;
+    if (!p.skip && (p.mat || p.acc_skip)) return RAMP_EINVAL;
+    if (p.skip && (fp8 || j.stats)) return RAMP_EUNSUPPORTED;      // (f16 MFMA instances in accumulator mode only)
     if (p.x2 && (in_f32 || p.C0 <= 0 || p.C0 >= Cin || (p.C0 & 7) || ((Cin - p.C0) & 7) || p.pre_scale || j.acc_in)) return RAMP_EINVAL;
     p.acc_out = (unsigned long long *)j.acc_out; p.acc_in = (const unsigned long long *)j.acc_in;
     p.in_count = j.in_count; p.in_eps = j.in_eps;
@@ -1841,6 +1893,41 @@ int ramp_conv2d_nhwc_multi(const ramp_conv_job *jobs, int njobs, int H, int W, i
     return RAMP_OK;                                                                                   \
   }
   TILE_CASE(7, 2, true, 16, 2)
+  // 16 x 16 output tiles for the 32-channel 3x3 layers at half resolution (600 workgroups of two towers, three per CU: still
+  // one round): weight fragments staged once per 256 pixels and a 1.27x instead of 1.41x halo.  Per-block statistics
+  // (`stats`, the path without accumulators) keep the 8 x 16 grid their buffers are sized for.  RAMP_CONV_TH16=0: A/B
+  static const bool th16 = !getenv("RAMP_CONV_TH16") || atoi(getenv("RAMP_CONV_TH16")) != 0;
+  bool block_stats = false, any_skip = false;
+  for (int t = 0; t < njobs; t++) { block_stats |= jobs[t].stats != nullptr; any_skip |= jobs[t].skip != nullptr; }
+  if (any_skip) {                                     // a tower takes a fused residual-block tail: the TAIL instances
+#define TAIL_CASE(K, S, CIN, NT, TH_)                                                               \
+    if (KH == K && stride == S && !in_f32 && Cin == CIN && (NT == 2 || cgcd_ok64)) {                  \
+      constexpr int lds_ = conv_tile_lds_bytes(K, S, false, CIN, NT, false, TH_);                     \
+      if (conv_tile_attr(conv_tile_f16_kernel<K, S, false, CIN, NT, false, TH_, true>, lds_) != RAMP_OK) return RAMP_ELAUNCH; \
+      hipLaunchKernelGGL((conv_tile_f16_kernel<K, S, false, CIN, NT, false, TH_, true>),              \
+                         dim3(ramp_cdiv(OH, TH_) * ramp_cdiv(OW, 16), cmax / (NT * 16), njobs), block, lds_, st, pm); \
+      RAMP_CHECK_LAUNCH();                                                                          \
+      return RAMP_OK;                                                                               \
+    }
+    if (fp8 || block_stats) return RAMP_EUNSUPPORTED;
+    if (th16 && (long)ramp_cdiv(OH, 16) * ramp_cdiv(OW, 16) * njobs * (cmax / 32) >= 512) { TAIL_CASE(3, 1, 32, 2, 16) }
+    TAIL_CASE(3, 1, 32, 2, 8)
+    TAIL_CASE(3, 2, 32, 2, 8)
+    TAIL_CASE(1, 2, 32, 4, 8)
+    TAIL_CASE(3, 1, 64, 2, 8)
+    TAIL_CASE(1, 1, 64, 4, 8)
+#undef TAIL_CASE
+    return RAMP_EUNSUPPORTED;
+  }
+  if (th16 && !block_stats && KH == 3 && stride == 1 && !in_f32 && Cin == 32 &&
+      (long)ramp_cdiv(OH, 16) * ramp_cdiv(OW, 16) * njobs * (cmax / 32) >= 512) {
+    constexpr int lds_ = conv_tile_lds_bytes(3, 1, false, 32, 2, false, 16);
+    if (conv_tile_attr(conv_tile_f16_kernel<3, 1, false, 32, 2, false, 16>, lds_) != RAMP_OK) return RAMP_ELAUNCH;
+    hipLaunchKernelGGL((conv_tile_f16_kernel<3, 1, false, 32, 2, false, 16>),
+                       dim3(ramp_cdiv(OH, 16) * ramp_cdiv(OW, 16), cmax / 32, njobs), block, lds_, st, pm);
+    RAMP_CHECK_LAUNCH();
+    return RAMP_OK;
+  }
   TILE_CASE(3, 1, false, 32, 2)
   TILE_CASE(3, 2, false, 32, 2)
   // (stride 2 at 64 channels, the MultiScale towers' layer3: the 80 KB halo tile leaves one workgroup per CU either way;

@@ -172,7 +172,7 @@ def test_instance_norm_accumulators_match_the_finalize_launch(cin, cout, k, stri
                 pa = conv_hip.conv2d_towers([dict(x=x, conv=conv_a, want_stats=True), dict(x=x, conv=dummy)], half=True)[0]
                 assert (pa.acc is not None) == acc
                 pb = conv_hip.conv2d_towers([dict(x=pa, conv=conv_b, want_stats=True), dict(x=pa.raw, conv=conv_b)], half=True)[0]
-                out = conv_hip.norm_add_relu(pb, pa.raw)
+                out = conv_hip.norm_add_relu(pb, pa.raw, fuse=False)
                 return pa, pb, out
             finally:
                 conv_hip.set_arena(None)
@@ -435,6 +435,38 @@ def test_multiscale_towers_two_source_input_equals_the_concatenation():
         conv_hip._MS_PAIR = old
     for (f0, i0), (f1, i1) in zip(outs[True], outs[False]):
         assert f0.dtype == torch.float16 and torch.equal(f0, f1) and torch.equal(i0, i1)
+
+
+@pytest.mark.parametrize("mode,fp8,hw", [("SingleScale", False, (96, 128)), ("MultiScale", False, (96, 128)),
+                                         ("SingleScale", True, (96, 128)), ("SingleScale", False, (104, 136))])
+def test_residual_block_tail_in_the_next_layers_load_equals_the_launch_of_its_own(mode, fp8, hw):
+    """fp16 towers (accumulator-mode InstanceNorm): relu(skip + relu(norm2(conv2))) of reference extractor.py:49-57 formed by
+    the NEXT layer's conv kernel while it stages its input tile (ramp_conv_job.skip / .mat: the stride-1 consumer also
+    writes it out for the following block's skip) against ramp_norm_add_relu_f16_acc launches: bit-equal maps, over
+    several frames, on the f16 and the fp8 MFMA, and at a map size with ragged tiles"""
+    from rampvo_amd import conv_hip
+    from rampvo_amd.synthetic import SyntheticStream, make_network
+    stream = SyntheticStream(hw[0], hw[1], 3, seed=6)
+    outs = {}
+    old = conv_hip._TAIL_FUSE
+    try:
+        for fuse in (True, False):
+            conv_hip._TAIL_FUSE = fuse
+            enc = make_network(mode).patchify.encoder
+            enc.mixed_precision = True
+            enc.fp8_mfma = fp8
+            res = []
+            for t in range(3):
+                im, ev, _, _ = stream.frame(t)
+                kw = dict(mask=torch.tensor([True])) if mode == "MultiScale" else {}
+                f, i = enc(events=ev.cuda(), images=im.cuda(), reinit_hidden=(t == 0), out_scale=0.25, **kw)[:2]
+                res.append((f.clone(), i.clone()))
+            outs[fuse] = res
+    finally:
+        conv_hip._TAIL_FUSE = old
+    for (f0, i0), (f1, i1) in zip(outs[True], outs[False]):
+        assert f0.dtype == torch.float16 and torch.equal(f0, f1) and torch.equal(i0, i1)
+        assert float(f0.float().abs().max()) > 0
 
 
 @pytest.mark.parametrize("mode", ["SingleScale", "MultiScale"])
