@@ -688,10 +688,10 @@ class Ramp_vo:
         return kq, k_dev
 
     def _gate_signal(self):
-        """the signal word of the gate, or None (RAMP_GATE_FLAG=0, a gate position other than the default, no signal
-        memory, or 2^31 frames behind us: the event then)"""
+        """the signal word of the gate, or None (RAMP_GATE_FLAG=0, no signal memory, or 2^31 frames behind us: the event
+        then).  Where in the step the word is stored is csrc/track.hip's RAMP_GATE_AT (default: by the first SoftAgg launch)"""
         if self._gate_sig is None:
-            use = os.environ.get("RAMP_GATE_FLAG", "1") != "0" and os.environ.get("RAMP_GATE_AT", "0") == "0"
+            use = os.environ.get("RAMP_GATE_FLAG", "1") != "0"
             with torch.cuda.device(self.device):          # (the word must live on the tracker's GPU, not the caller's current one)
                 self._gate_sig = track_dev.Signal() if use else False
         sig = self._gate_sig

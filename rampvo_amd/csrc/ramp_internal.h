@@ -68,7 +68,7 @@ int ramp_i_upd_corr_mlp(const void *corr, int corr_k, const void *w1, const floa
                         const int32_t *dyn, void *stream);
 int ramp_i_upd_softagg(const float *x32, const void *add_t, const int32_t *add_idx, const int32_t *order, const int32_t *gid,
                        const void *wf, const float *bf, const void *wg, const float *bg, float *frag, int E,
-                       const int32_t *dyn, void *stream);
+                       const int32_t *dyn, void *stream, uint32_t *gate_flag = nullptr, uint32_t gate_seq = 0);
 int ramp_i_upd_fg(const float *x32, const void *add_t, const int32_t *add_idx, float *x32_out, const void *wf,
                   const float *bf, const void *wg, const float *bg, void *fg, int E, const int32_t *dyn, void *stream);
 int ramp_i_upd_heads_linear(const void *relu_t, const void *heads_w, const float *heads_b, const float *coords,

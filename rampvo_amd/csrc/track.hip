@@ -527,11 +527,24 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
     TRK_DO(ramp_i_upd_corr_mlp(t->corr, 896, w.corr_w1, w.corr_b1, w.corr_w2, w.corr_b2, w.corr_w3, w.corr_b3, w.corr_ln_w,
                                w.corr_ln_b, w.corr_ln_eps, t->net[0], row, t->imap, kk, (long)t->M * t->mem, w.norm_w,
                                w.norm_b, w.norm_eps, t->net[1], Eb, dyn, st));
-    // where the next frame's front end may start (RAMP_GATE_AT: 0 = before the gru chain, the default; 1 = before the
-    // second SoftAgg; 2 = before the first; 3 = before c1 / c2 -- A/B runs)
+    // where the next frame's front end may start (RAMP_GATE_AT: 2 = before the first SoftAgg, the default -- with the fused
+    // SoftAgg launches next to it the front end costs the operator ~25 us and gives bundle adjustment 12 back, +1.2 % SingleScale,
+    // +2.1 % MultiScale against 0; 0 = before the gru chain (rounds 2-3); 1 = before the second SoftAgg; 3 = before c1 / c2).
+    // The "go" is a word stored by the first workgroup of the launch behind that point (t->gate_flag: gru, SoftAgg), a
+    // one-thread launch where that kernel cannot (the three-launch SoftAgg, c1), or the caller's event.
     static int gate_at = -1;
-    if (gate_at < 0) { const char *e = getenv("RAMP_GATE_AT"); gate_at = e ? atoi(e) : 0; }
-#define TRK_GATE(pos) do { if (gate_event && !(t->gate_flag && gate_at == 0) && gate_at == (pos) && hipEventRecord((hipEvent_t)gate_event, st) != hipSuccess) return RAMP_ELAUNCH; } while (0)
+    if (gate_at < 0) { const char *e = getenv("RAMP_GATE_AT"); gate_at = e ? atoi(e) : 2; if (gate_at < 0 || gate_at > 3) gate_at = 2; }
+    static int sagg = -1;
+    if (sagg < 0) { const char *e = getenv("RAMP_SOFTAGG"); sagg = e ? atoi(e) : 1; }
+    const bool use_sagg = sagg && t->sagg_frag;
+    const bool flag_in_kernel = t->gate_flag && (gate_at == 0 || ((gate_at == 1 || gate_at == 2) && use_sagg));
+#define TRK_GATE(pos)                                                                                     \
+  do {                                                                                                    \
+    if (gate_at == (pos) && !flag_in_kernel) {                                                            \
+      if (t->gate_flag) hipLaunchKernelGGL(trk_signal_kernel, dim3(1), dim3(1), 0, st, t->gate_flag, t->gate_seq); \
+      else if (gate_event && hipEventRecord((hipEvent_t)gate_event, st) != hipSuccess) return RAMP_ELAUNCH; \
+    }                                                                                                     \
+  } while (0)
     TRK_GATE(3);
     // RAMP_NBR2=1: c1 and c2 in one launch over the (kk, jj)-sorted factor list (bit-identical; measured 2 % SLOWER on
     // the whole operator than the two launches although it moves a third of their bytes -- DESIGN.md section 8)
@@ -550,19 +563,16 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
     // SoftAgg x 2 (ramp/net.py:84-85).  With a fragment table: gather-by-group tiles, g and f on the same tile, online
     // softmax in registers, h on the merged fragments -- 2 launches each, no [E, 768] rows (csrc/update_mlp.hip);
     // RAMP_SOFTAGG=0 or no table: [f | g] rows + segment softmax + h, 3 launches each.
-    static int sagg = -1;
-    if (sagg < 0) { const char *e = getenv("RAMP_SOFTAGG"); sagg = e ? atoi(e) : 1; }
     static int add2 = -1;
     if (add2 < 0) { const char *e = getenv("RAMP_GRU_ADD2"); add2 = e ? atoi(e) : 1; }
-    const bool use_sagg = sagg && t->sagg_frag;
     if (use_sagg) add2 = 1;                       // (that path never writes net + hkk[.] back: the gru launch forms the sum)
     if (use_sagg) {
       TRK_DO(ramp_i_upd_softagg(net, nullptr, nullptr, t->kk_order, t->kk_gid, w.kk_wf, w.kk_bf, w.kk_wg, w.kk_bg, t->sagg_frag,
-                                Eb, dyn, st));
+                                Eb, dyn, st, gate_at == 2 ? t->gate_flag : nullptr, t->gate_seq));
       TRK_DO(ramp_upd_softagg_finish(t->sagg_frag, t->kk_seg, t->kk_ngroups, w.kk_wh, w.kk_bh, t->hkk, t->kk_cap, stream));
       TRK_GATE(1);
       TRK_DO(ramp_i_upd_softagg(net, t->hkk, t->kk_gid, t->ij_order, t->ij_gid, w.ij_wf, w.ij_bf, w.ij_wg, w.ij_bg, t->sagg_frag,
-                                Eb, dyn, st));
+                                Eb, dyn, st, gate_at == 1 ? t->gate_flag : nullptr, t->gate_seq));
       TRK_DO(ramp_upd_softagg_finish(t->sagg_frag, t->ij_seg, t->ij_ngroups, w.ij_wh, w.ij_bh, t->hij, t->ij_cap, stream));
     } else {
     TRK_DO(ramp_i_upd_fg(net, nullptr, nullptr, nullptr, w.kk_wf, w.kk_bf, w.kk_wg, w.kk_bg, t->fg, Eb, dyn, st));

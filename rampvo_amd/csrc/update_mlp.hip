@@ -1359,6 +1359,8 @@ struct SoftAggParams {
   float *frag;                 // [slots][3][384] fp32: (m, z, a) per run
   int E;
   const int32_t *dyn;          // optional device-side sizes (RAMP_DYN_*): E is then the launch bound
+  uint32_t *gate_flag;         // optional: workgroup 0 stores gate_seq here when it starts (ramp_track.gate_flag)
+  uint32_t gate_seq;
 };
 
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) upd_softagg_kernel(const SoftAggParams p) {
@@ -1368,6 +1370,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
   int *s_gid = reinterpret_cast<int *>(Xs + ROWS * MXS);            // [ROWS] group of sorted position p0 + t (-1 past E)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
   const int p0 = blockIdx.x * ROWS;
+  if (p.gate_flag && blockIdx.x == 0 && tid == 0)
+    __hip_atomic_store(p.gate_flag, p.gate_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   const int pE = p.dyn ? p.dyn[RAMP_DYN_E] : p.E;
   if (p0 >= pE) return;                        // (workgroup-uniform)
   const int col0 = wave * (16 * NTW);
@@ -1897,11 +1901,12 @@ size_t ramp_upd_softagg_frag_rows(int E, int max_groups) {
 
 int ramp_i_upd_softagg(const float *x32, const void *add_t, const int32_t *add_idx, const int32_t *order, const int32_t *gid,
                        const void *wf, const float *bf, const void *wg, const float *bg, float *frag, int E,
-                       const int32_t *dyn, void *stream) {
+                       const int32_t *dyn, void *stream, uint32_t *gate_flag, uint32_t gate_seq) {
   if (E < 0) return RAMP_EINVAL;
   if (E == 0) return RAMP_OK;
   if (!x32 || !order || !gid || !wf || !bf || !wg || !bg || !frag || (add_t && !add_idx)) return RAMP_EINVAL;
   SoftAggParams p;
+  p.gate_flag = gate_flag; p.gate_seq = gate_seq;
   p.x32 = x32; p.add_t = (const _Float16 *)add_t; p.add_idx = add_idx; p.order = order; p.gid = gid;
   p.wf = (const _Float16 *)wf; p.wg = (const _Float16 *)wg; p.bf = bf; p.bg = bg; p.frag = frag; p.E = E; p.dyn = dyn;
   const size_t lds = (size_t)SAGG_ROWS * MXS * 2 + SAGG_ROWS * sizeof(int);
@@ -1917,7 +1922,7 @@ int ramp_i_upd_softagg(const float *x32, const void *add_t, const int32_t *add_i
 }
 int ramp_upd_softagg(const float *x32, const void *add_t, const int32_t *add_idx, const int32_t *order, const int32_t *gid,
                      const void *wf, const float *bf, const void *wg, const float *bg, float *frag, int E, void *stream) {
-  return ramp_i_upd_softagg(x32, add_t, add_idx, order, gid, wf, bf, wg, bg, frag, E, nullptr, stream);
+  return ramp_i_upd_softagg(x32, add_t, add_idx, order, gid, wf, bf, wg, bg, frag, E, nullptr, stream, nullptr, 0);
 }
 int ramp_upd_softagg_finish(const float *frag, const int32_t *seg_start, const int32_t *ngroups, const void *wh,
                             const float *bh, void *hy, int max_groups, void *stream) {
