@@ -304,6 +304,60 @@ __device__ __forceinline__ void tile_ln(f4 (&v)[MT][MNTW], const float *__restri
   }
 }
 
+// The same reduction for kernels on a 128-register budget (two workgroups per CU): branch-free -- the four quarter-lanes of
+// a row store the same partial sum -- so that the scheduling barriers bound what is in flight per row tile (the
+// straight-line version above has every table read of the five row tiles live at once: 66 spilled registers).
+// Identical arithmetic and order.
+template <int MT>
+__device__ __forceinline__ void tile_ln_lean(f4 (&v)[MT][MNTW], const float *__restrict__ w, const float *__restrict__ b,
+                                             float eps, float *T1, float *T2, int wave, int q, int j, int col0) {
+  float mean[MT], rstd[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; mt++) {
+    float s = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < MNTW; nt++) s += (v[mt][nt][0] + v[mt][nt][1]) + (v[mt][nt][2] + v[mt][nt][3]);
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    T1[(mt * 16 + j) * MWAVES + wave] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int mt = 0; mt < MT; mt++) {
+    __builtin_amdgcn_sched_barrier(0);
+    const f4 a = *reinterpret_cast<const f4 *>(T1 + (mt * 16 + j) * MWAVES), c = *reinterpret_cast<const f4 *>(T1 + (mt * 16 + j) * MWAVES + 4);
+    mean[mt] = ((((((a[0] + a[1]) + a[2]) + a[3]) + c[0]) + c[1]) + c[2] + c[3]) * (1.0f / MD);
+    float s = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < MNTW; nt++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const float d = v[mt][nt][i] - mean[mt];
+        s += d * d;
+      }
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    T2[(mt * 16 + j) * MWAVES + wave] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int mt = 0; mt < MT; mt++) {
+    __builtin_amdgcn_sched_barrier(0);
+    const f4 a = *reinterpret_cast<const f4 *>(T2 + (mt * 16 + j) * MWAVES), c = *reinterpret_cast<const f4 *>(T2 + (mt * 16 + j) * MWAVES + 4);
+    rstd[mt] = 1.0f / sqrtf(((((((a[0] + a[1]) + a[2]) + a[3]) + c[0]) + c[1]) + c[2] + c[3]) * (1.0f / MD) + eps);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int nt = 0; nt < MNTW; nt++) {
+    const f4 wv = *reinterpret_cast<const f4 *>(w + col0 + nt * 16 + 4 * q), bv = *reinterpret_cast<const f4 *>(b + col0 + nt * 16 + 4 * q);
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) v[mt][nt][i] = (v[mt][nt][i] - mean[mt]) * rstd[mt] * wv[i] + bv[i];
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 #ifdef GRU_TRACE
 __device__ long long g_gru_trace[32 * 4096];
 #define GT(k) do { if (threadIdx.x == 0) g_gru_trace[blockIdx.x * 32 + (k)] = wall_clock64(); } while (0)
@@ -1090,6 +1144,123 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) upd_nbr_big_kernel(const NbrP
   }
 }
 
+// ------------------------------------------------------------------ correlation MLP (big tile)
+// The whole correlation MLP (CorrTailParams, FULL) on the wide-tile recipe of c1 / c2: 16 NMT rows per workgroup (80: 500
+// workgroups for 40k factors, two per CU -- one round), transposed accumulators, weight fragments one K step ahead, and
+// NO fp32 parking passes: a lane holds four consecutive columns of its rows, the two LayerNorms reduce through an LDS
+// table of per-wave partial sums (tile_ln), the previous state / context rows are added and the result stored as
+// 16-byte pieces straight from the accumulators.  Same values as upd_corr_tail_kernel up to the order of the LayerNorm
+// sums (tile_ln vs row_ln).
+template <int NMT, int NW>
+__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4))) upd_corr_mlp_big_kernel(const CorrTailParams p) {
+  static_assert(NW == MWAVES, "tile_ln's table is [rows][MWAVES]");
+  constexpr int NTW = 24 / NW, ROWS = 16 * NMT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  _Float16 *Xs = reinterpret_cast<_Float16 *>(smem_raw);
+  float *T1 = reinterpret_cast<float *>(Xs + ROWS * MXS), *T2 = T1 + ROWS * NW;
+  __shared__ long s_ra[ROWS], s_rb[ROWS];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
+  const int row0 = blockIdx.x * ROWS;
+  const int pE = p.dyn ? p.dyn[RAMP_DYN_E] : p.E;
+  if (row0 >= pE) return;                      // (workgroup-uniform: only with device-side sizes)
+  const int col0 = wave * (16 * NTW);
+  if (tid < ROWS) {                            // the rows the last pass adds: indices fetched now
+    const int row = row0 + tid;
+    long ra = -1, rb = 0;
+    if (row < pE) {
+      ra = p.net ? (p.net_map ? p.net_map[row] : (long)row) : -1;
+      rb = p.inp_idx ? p.inp_idx[row] : (long)row;
+      if (p.inp_mod > 0) rb %= p.inp_mod;
+    }
+    s_ra[tid] = ra; s_rb[tid] = rb;
+  }
+  f4 acc[NMT][NTW];
+  big_zero<NMT, NTW>(acc);
+  // Linear1 over K = corr_k in chunks of <= 12 K steps (the tile is 384 wide)
+  const int nks_total = p.corr_k / 32;
+  for (int ks0 = 0; ks0 < nks_total; ks0 += MKS) {
+    const int nks = min(MKS, nks_total - ks0);
+    const int v8 = nks * 4;                                  // 16-byte vectors per row of this chunk
+    for (int i = tid; i < ROWS * v8; i += 64 * NW) {
+      const int r = i / v8, c8 = i - r * v8;
+      h8 v = (h8){0, 0, 0, 0, 0, 0, 0, 0};
+      if (row0 + r < pE) v = ld_dead(reinterpret_cast<const h8 *>(p.corr + (size_t)(row0 + r) * p.corr_k + ks0 * 32 + 8 * c8));
+      *reinterpret_cast<h8 *>(Xs + r * MXS + 8 * c8) = v;
+    }
+    __syncthreads();
+    big_gemm<NMT, NTW>(Xs, p.w1, nks, ks0, wave, lane, acc);
+    __syncthreads();                                         // before the tile is overwritten
+  }
+  big_store_tile<NMT, NTW, true>(Xs, acc, p.b1, col0, q, j);
+  __syncthreads();
+  big_zero<NMT, NTW>(acc);
+  big_gemm<NMT, NTW>(Xs, p.w2, MKS, 0, wave, lane, acc);
+  {
+#pragma unroll
+    for (int nt = 0; nt < NTW; nt++) {
+      const float4 b = *reinterpret_cast<const float4 *>(p.b2 + col0 + nt * 16 + 4 * q);
+#pragma unroll
+      for (int mt = 0; mt < NMT; mt++) {
+        acc[mt][nt][0] = h_round(acc[mt][nt][0] + b.x); acc[mt][nt][1] = h_round(acc[mt][nt][1] + b.y);
+        acc[mt][nt][2] = h_round(acc[mt][nt][2] + b.z); acc[mt][nt][3] = h_round(acc[mt][nt][3] + b.w);
+      }
+    }
+  }
+  tile_ln_lean<NMT>(acc, p.ln_w, p.ln_b, p.ln_eps, T1, T2, wave, q, j, col0);    // (its barriers: every wave is past its reads of the tile)
+#pragma unroll
+  for (int nt = 0; nt < NTW; nt++)
+#pragma unroll
+    for (int mt = 0; mt < NMT; mt++)
+      *reinterpret_cast<hh4 *>(Xs + (mt * 16 + j) * MXS + col0 + nt * 16 + 4 * q) =
+          (hh4){(_Float16)fmaxf(acc[mt][nt][0], 0.f), (_Float16)fmaxf(acc[mt][nt][1], 0.f), (_Float16)fmaxf(acc[mt][nt][2], 0.f),
+                (_Float16)fmaxf(acc[mt][nt][3], 0.f)};
+  __syncthreads();
+  big_zero<NMT, NTW>(acc);
+  big_gemm<NMT, NTW>(Xs, p.w3, MKS, 0, wave, lane, acc);
+  // net_prev + inp + c (in that order), LayerNorm, fp32 store
+  {
+    float4 bv[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; nt++) bv[nt] = *reinterpret_cast<const float4 *>(p.b3 + col0 + nt * 16 + 4 * q);
+    const char *net_base = reinterpret_cast<const char *>(p.net ? p.net : p.net_out);      // (s_ra is -1 everywhere without a state)
+#pragma unroll
+    for (int mt = 0; mt < NMT; mt++) {
+      __builtin_amdgcn_sched_barrier(0);                       // (the loads stay behind the last product: registers)
+      // (32-bit byte offsets from the uniform bases, the n-tile step as an immediate: one address register per row tile and
+      // table -- with 64-bit addresses per piece the pass peaked at 186 registers)
+      const long ra = s_ra[mt * 16 + j];
+      const unsigned oa = (unsigned)((ra >= 0 ? ra : 0) * MD + col0 + 4 * q) * 4u;
+      const unsigned ob = (unsigned)(s_rb[mt * 16 + j] * MD + col0 + 4 * q) * 2u;
+      float4 a[NTW];
+      hh4 t[NTW];
+#pragma unroll
+      for (int nt = 0; nt < NTW; nt++) {
+        const f4 a_ = ld_dead(reinterpret_cast<const f4 *>(net_base + oa + nt * 64));      // (branch-free: row 0 stands in, masked)
+        a[nt] = ra >= 0 ? make_float4(a_[0], a_[1], a_[2], a_[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        t[nt] = *reinterpret_cast<const hh4 *>(reinterpret_cast<const char *>(p.inp) + ob + nt * 32);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NTW; nt++) {
+        acc[mt][nt][0] = (a[nt].x + (float)t[nt][0]) + h_round(acc[mt][nt][0] + bv[nt].x);
+        acc[mt][nt][1] = (a[nt].y + (float)t[nt][1]) + h_round(acc[mt][nt][1] + bv[nt].y);
+        acc[mt][nt][2] = (a[nt].z + (float)t[nt][2]) + h_round(acc[mt][nt][2] + bv[nt].z);
+        acc[mt][nt][3] = (a[nt].w + (float)t[nt][3]) + h_round(acc[mt][nt][3] + bv[nt].w);
+      }
+      __builtin_amdgcn_sched_barrier(0);                       // (one row tile's 36 bytes per lane in flight at a time: registers)
+    }
+  }
+  __syncthreads();                                           // (tile_ln's tables are free again)
+  tile_ln_lean<NMT>(acc, p.norm_w, p.norm_b, p.norm_eps, T1, T2, wave, q, j, col0);
+#pragma unroll
+  for (int mt = 0; mt < NMT; mt++) {
+    const int row = row0 + mt * 16 + j;
+    if (row >= pE) continue;
+#pragma unroll
+    for (int nt = 0; nt < NTW; nt++)
+      st_st(reinterpret_cast<f4 *>(p.net_out + (size_t)row * MD + col0 + nt * 16 + 4 * q), acc[mt][nt]);
+  }
+}
+
 // ------------------------------------------------------------------ c1 AND c2 in one launch
 // net += c1(mask * net[ix]);  net += c2(mask * net[jx])   (ramp/net.py:77-82)
 // The two launches above each read the state twice (own row + neighbour row) and write it once: 6 passes over
@@ -1824,6 +1995,14 @@ int ramp_i_upd_corr_mlp(const void *corr, int corr_k, const void *w1, const floa
   p.ln_w = ln_w; p.ln_b = ln_b; p.ln_eps = ln_eps; p.net = net; p.net_map = net_map; p.inp = (const _Float16 *)inp;
   p.inp_idx = inp_idx; p.inp_mod = inp_mod; p.norm_w = norm_w; p.norm_b = norm_b; p.norm_eps = norm_eps;
   p.net_out = net_out; p.E = E; p.dyn = dyn;
+  // RAMP_CORR_MLP_BIG=1: the wide-tile kernel without parking passes.  Measured (tools/mb_update.py):
+  // 86.2 vs 87.8 us at 40000 factors (500 tiles, one round of two per CU), 78.2 vs 86.1 at 38400, 112.8 vs 87.5 at 41200
+  // (515 tiles: a second round) -- a CU moves ~1.9 rows per us whichever kernel it runs, the launch is bound by its 220 MB
+  // and the weight stream, not by the row passes; and its LayerNorm sums in another order (tile_ln), so a host-driven and
+  // a device-resident step that choose by their row bound would differ in the last bit.  Off by default.
+  static const bool big = getenv("RAMP_CORR_MLP_BIG") && atoi(getenv("RAMP_CORR_MLP_BIG")) != 0;
+  if (big)
+    if (const int nmt = big_pick_nmt(E, 5)) { BIG_DISPATCH(upd_corr_mlp_big_kernel, 8, p, E, nmt, true, (hipStream_t)stream) }
   const size_t lds = (size_t)MBM * MXS * 2;
   hipLaunchKernelGGL(upd_corr_tail_kernel<true>, dim3(ramp_cdiv(E, MBM)), dim3(64 * MWAVES), lds, (hipStream_t)stream, p);
   RAMP_CHECK_LAUNCH();

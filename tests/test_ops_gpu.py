@@ -1,6 +1,7 @@
 """GPU parity tests: every HIP operator (called through the C ABI) against the CPU
 oracle on the same seeded inputs.  Tolerances are stated per test; integer /
 index outputs must match exactly."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -636,6 +637,17 @@ def test_softagg_fused_against_fp32_torch(E, mode):
         print(E, mode, add, "softagg vs fp32 torch %.2e (three-launch path: %.2e)" % (err, err_old))
         assert err <= FUSED_CHAIN_TOL, (E, mode, add, err)
 
+
+
+def test_wide_tile_corr_mlp_variant_against_fp32_torch():
+    """RAMP_CORR_MLP_BIG=1 (csrc/update_mlp.hip::upd_corr_mlp_big_kernel: 80-row tiles, LayerNorm from the accumulators, no
+    parking passes -- the opt-in variant of the correlation MLP): the chain test below at a ragged big-tile size, in a
+    process of its own (the switch is read once per process)"""
+    import subprocess, sys
+    env = dict(os.environ, RAMP_CORR_MLP_BIG="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", __file__ + "::test_fused_update_chains_against_fp32_torch[20011]"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 @pytest.mark.parametrize("E", [1003, 5408, 20011, 41003])
