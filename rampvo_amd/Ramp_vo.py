@@ -25,6 +25,7 @@ MI355X-first differences that do not change results:
 """
 from collections import OrderedDict
 
+import ctypes
 import os
 import warnings
 
@@ -194,6 +195,7 @@ class Ramp_vo:
     def _init_streams(self, dev):
         self._fe_stream = torch.cuda.Stream(device=dev)
         # events are re-recorded every frame (creating one costs a hipEventCreate/Destroy pair per use)
+        self._fe_done_sig, self._fe_done_seq = None, 0
         self._ev_fe_done, self._ev_gate, self._ev_in = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
         for ev in (self._ev_fe_done, self._ev_gate, self._ev_in):
             ev.record()                      # torch creates the hipEvent lazily; csrc/track.hip records the raw handle
@@ -697,6 +699,23 @@ class Ramp_vo:
         sig = self._gate_sig
         return sig if (sig and sig.ptr is not None and self._gate_seq < 0x7FFFFFF0) else None
 
+    def _fe_done_to(self, fe, cur, dv):
+        """the front end's "done" for the main stream: a word in signal memory stored by a one-thread launch behind the
+        encoder graph and looked at by one sleeping wave in front of the frame commit (RAMP_FE_DONE_FLAG=0, or no signal
+        memory: an event record + stream wait, ~10 us of packets on the serial chain even when the front end is long done)"""
+        if self._fe_done_sig is None:
+            use = os.environ.get("RAMP_FE_DONE_FLAG", "1") != "0"
+            with torch.cuda.device(self.device):
+                self._fe_done_sig = track_dev.Signal() if use else False
+        sig = self._fe_done_sig
+        if sig and sig.ptr is not None and self._fe_done_seq < 0x7FFFFFF0:
+            self._fe_done_seq += 1
+            _lib.check(_lib.lib().ramp_stream_signal(ctypes.c_void_p(fe.cuda_stream), sig.ptr, self._fe_done_seq), "ramp_stream_signal")
+            sig.wait(cur, self._fe_done_seq, status=dv.status_ptr)
+        else:
+            self._ev_fe_done.record(fe)
+            cur.wait_event(self._ev_fe_done)
+
     def _gate_wait(self, fe):
         """(front-end stream) wait for the previous frame's gate: the signal word if that step stored one, else the event"""
         if self._gate_by_flag:
@@ -744,15 +763,14 @@ class Ramp_vo:
                 out = self.network.patchify(input_=input_, patches_per_image=self.cfg.PATCHES_PER_FRAME,
                                             event_bias=self.event_bias, reinit_hidden=False,
                                             pre_replay=(lambda: self._gate_wait(fe)) if ahead else self._fe_delay)
-            self._ev_fe_done.record(fe)
             if _FE_WAIT_PROBE:                      # (diagnostic: how long the main queue waits for the front end)
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record(cur)
-                cur.wait_event(self._ev_fe_done)
+                self._fe_done_to(fe, cur, dv)
                 b.record(cur)
                 self.fe_wait_pairs.append((a, b))
             else:
-                cur.wait_event(self._ev_fe_done)
+                self._fe_done_to(fe, cur, dv)
             if _WARM and not dv.fp32:
                 # (behind the event: the frame does not wait for it) the window's correlation planes back into the
                 # memory-side cache while the previous frame's bundle adjustment is still running
