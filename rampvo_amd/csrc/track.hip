@@ -172,16 +172,51 @@ __global__ void __launch_bounds__(256) trk_decide_kernel(const TrkEdit p) {
 
 // grid (nb + new-factor workgroups, 1 + nbuf).  y = 0: x < nb compacts the kept factors of edit workgroup x (stable),
 // the rest appends the next frame's factors; y > 0: row shift of buffer y - 1 if the keyframe was dropped.
+// rows k + 1 .. k + R of a frame buffer moved down by one (ring rows taken modulo `mod`): a thread reads its 16-byte column
+// of all R rows, then writes them
+template <int R>
+__device__ __forceinline__ void trk_shift_rows(char *base, long row_bytes, int mod, int k, long n16, int tid) {
+  const uint4 *src[R];
+  uint4 *dst[R];
+#pragma unroll
+  for (int u = 0; u < R; u++) {
+    const int ss = mod ? (k + u + 1) % mod : k + u + 1, sd = mod ? (k + u) % mod : k + u;
+    src[u] = reinterpret_cast<const uint4 *>(base + (size_t)ss * row_bytes);
+    dst[u] = reinterpret_cast<uint4 *>(base + (size_t)sd * row_bytes);
+  }
+  for (long col = (long)blockIdx.x * 256 + tid; col < n16; col += (long)gridDim.x * 256) {
+    uint4 v[R];
+#pragma unroll
+    for (int u = 0; u < R; u++) v[u] = src[u][col];
+#pragma unroll
+    for (int u = 0; u < R; u++) dst[u][col] = v[u];
+  }
+}
+
 __global__ void __launch_bounds__(256) trk_apply_kernel(const TrkEdit p) {
   const int tid = threadIdx.x;
   if (blockIdx.y > 0) {
     if (!p.dyn[RAMP_DYN_REMOVED]) return;
     const int b = blockIdx.y - 1, k = p.dyn[RAMP_DYN_K], nrows = p.dyn[RAMP_DYN_NPREV];
     const long n4 = p.row_bytes[b] / 4;
-    // each thread owns columns c, c + stride, ... and walks the rows itself, ascending: no cross-thread hazard
+    // each thread owns columns c, c + stride, ... and moves the rows itself: no cross-thread hazard.  Up to four rows
+    // (KEYFRAME_INDEX - 1 = 3 in every shipped config) are all READ before the first is written -- one round trip
+    // instead of a chain of load -> store pairs per column; 16-byte pieces where the row allows
+    const int nmove = nrows - 1 - k;
+    const int mod = p.mod[b];
+    if (nmove >= 1 && nmove <= 4 && !(p.row_bytes[b] & 15)) {
+      const long n16 = p.row_bytes[b] / 16;
+      switch (nmove) {                                         // (compile-time row count: the rows stay in registers)
+        case 1: trk_shift_rows<1>(p.base[b], p.row_bytes[b], mod, k, n16, tid); break;
+        case 2: trk_shift_rows<2>(p.base[b], p.row_bytes[b], mod, k, n16, tid); break;
+        case 3: trk_shift_rows<3>(p.base[b], p.row_bytes[b], mod, k, n16, tid); break;
+        default: trk_shift_rows<4>(p.base[b], p.row_bytes[b], mod, k, n16, tid); break;
+      }
+      return;
+    }
     for (long col = (long)blockIdx.x * 256 + tid; col < n4; col += (long)gridDim.x * 256) {
       for (int r = k; r < nrows - 1; r++) {
-        const int sd = p.mod[b] ? r % p.mod[b] : r, ss = p.mod[b] ? (r + 1) % p.mod[b] : r + 1;
+        const int sd = mod ? r % mod : r, ss = mod ? (r + 1) % mod : r + 1;
         reinterpret_cast<uint32_t *>(p.base[b] + (size_t)sd * p.row_bytes[b])[col] =
             reinterpret_cast<const uint32_t *>(p.base[b] + (size_t)ss * p.row_bytes[b])[col];
       }
