@@ -723,6 +723,12 @@ typedef struct ramp_track {
                                        * without a packet on this stream -- the other stream waits with                    *
                                        * ramp_stream_wait_flag (a hipEventRecord costs ~5 us between two kernels of the   *
                                        * recording stream, tools/mb/stream_signal.hip); takes the place of gate_event     */
+  int32_t *fmap1_slot;                /* optional [mem] int32, a permutation of 0 .. mem - 1 (identity at hand-over): ring row r of
+                                       * the level-0 correlation planes lives in physical slot fmap1_slot[r] of `fmap1`.  A
+                                       * dropped keyframe then rotates table entries instead of moving three 4.9 MB planes
+                                       * (ramp/Ramp_vo.py:259-271 shifts them); every reader of `fmap1` rows (correlation, frame
+                                       * commit, warm-up) goes through the table; the caller undoes the permutation when it takes
+                                       * the buffers back.  NULL: rows are slots                                           */
 } ramp_track;
 
 /* cache warm-up for the next step's correlation kernel: reads the planes of the window's frames and the patch features

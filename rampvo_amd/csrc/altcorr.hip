@@ -191,6 +191,7 @@ struct CorrParams {
   // per edge less in the serial part of the tracked frame
   const float *tf_poses, *tf_patches, *tf_intr;
   const int64_t *tf_src;  // [E] source frame of each edge (ii of the tracker's graph)
+  const int32_t *slot0;   // optional [mod_jj]: physical slot of ring row r of the LEVEL-0 target maps (ramp_track.fmap1_slot)
 };
 
 // Workgroup ids are dealt round-robin to the 8 XCDs, each with a private L2.  Position p of the
@@ -265,7 +266,7 @@ __global__ void __launch_bounds__(64)
 
   for (int lvl = 0; lvl < L; lvl++) {
     const int H2 = prm.H2[lvl], W2 = prm.W2[lvl];
-    const T *f2 = reinterpret_cast<const T *>(prm.fmap2[lvl]) + (size_t)j2 * C * H2 * W2;
+    const T *f2 = reinterpret_cast<const T *>(prm.fmap2[lvl]) + (size_t)((lvl == 0 && prm.slot0) ? (long)prm.slot0[j2] : j2) * C * H2 * W2;
     if (lane < PP) {
       const float cdv = prm.cdiv[lvl];
       const float x = prm.coords[((size_t)e * 2 + 0) * PP + lane] / cdv;
@@ -585,7 +586,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CorrMma
     if (lvl >= L) break;
     CTS(ct_l0);
     const int H2 = prm.H2[lvl], W2 = prm.W2[lvl];
-    const T *f2 = reinterpret_cast<const T *>(prm.fmap2[lvl]) + (size_t)j2 * C * H2 * W2;
+    const T *f2 = reinterpret_cast<const T *>(prm.fmap2[lvl]) + (size_t)((lvl == 0 && prm.slot0) ? (long)prm.slot0[j2] : j2) * C * H2 * W2;
     const int my_ox = g_ox_[lvl], my_oy = g_oy_[lvl];
     const float my_dx = g_dx_[lvl], my_dy = g_dy_[lvl];
     const unsigned lmask = g_lm_[lvl];
@@ -887,8 +888,10 @@ int ramp_i_corr_fwd(const void *fmap1, const ramp_corr_level *levels, int nlevel
                     const float *coords, const int64_t *ii, const int64_t *jj,
                     const int32_t *order, void *out, int out_row_elems, long mod_ii, long mod_jj, int E,
                     int N1, int N2, int C, int P, int radius, int dtype, int layout, const int32_t *dyn, void *stream,
-                    const float *tf_poses, const float *tf_patches, const float *tf_intr, const int64_t *tf_src) {
+                    const float *tf_poses, const float *tf_patches, const float *tf_intr, const int64_t *tf_src,
+                    const int32_t *slot0) {
   if (E < 0 || nlevels < 1 || nlevels > CORR_MAXLEV || !levels) return RAMP_EINVAL;
+  if (slot0 && mod_jj <= 0) return RAMP_EINVAL;
   if (tf_poses && (!tf_patches || !tf_intr || !tf_src || (dtype & ~RAMP_CORR_MFMA32) != RAMP_F16 || layout == RAMP_NCHW)) return RAMP_EINVAL;
   if (C != 128 || P != 3 || radius != 3) return RAMP_EUNSUPPORTED;
   if (E == 0) return RAMP_OK;
@@ -919,6 +922,7 @@ int ramp_i_corr_fwd(const void *fmap1, const ramp_corr_level *levels, int nlevel
   prm.chunk = (E + CORR_XCDS - 1) / CORR_XCDS;
   prm.dyn = dyn;
   prm.tf_poses = tf_poses; prm.tf_patches = tf_patches; prm.tf_intr = tf_intr; prm.tf_src = tf_src;
+  prm.slot0 = slot0;
   const dim3 grid(prm.chunk * CORR_XCDS);
   hipStream_t st = (hipStream_t)stream;
   const bool fast32 = (dtype & RAMP_CORR_MFMA32) != 0;
@@ -946,7 +950,7 @@ int ramp_corr_fwd_ordered(const void *fmap1, const ramp_corr_level *levels, int 
                           const int32_t *order, void *out, int out_row_elems, long mod_ii, long mod_jj, int E,
                           int N1, int N2, int C, int P, int radius, int dtype, int layout, void *stream) {
   return ramp_i_corr_fwd(fmap1, levels, nlevels, coords, ii, jj, order, out, out_row_elems, mod_ii, mod_jj, E, N1, N2,
-                         C, P, radius, dtype, layout, nullptr, stream, nullptr, nullptr, nullptr, nullptr);
+                         C, P, radius, dtype, layout, nullptr, stream, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 
 int ramp_corr_fwd(const void *fmap1, const ramp_corr_level *levels, int nlevels,

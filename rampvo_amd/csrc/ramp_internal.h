@@ -30,7 +30,8 @@ int ramp_i_frame_commit_dyn(float *poses, int motion, float damping, int64_t *ts
                             int64_t *index_map, float *intrinsics, const float *k_new, float *patches_state,
                             int median_frames, int M, int P, float *patches_new, int n_copy, const void *const *src,
                             void *const *base, const long *bytes, const int *mod, const int32_t *dyn,
-                            const float *median_ahead, int32_t *status, int E_bound, int n_rows, hipStream_t st);
+                            const float *median_ahead, int32_t *status, int E_bound, int n_rows, hipStream_t st,
+                            const int32_t *slot_tab = nullptr, int slot_buf = 0);
 size_t ramp_i_plan_dyn_ws(int E_cap, int kkey_cap, int pkey_cap);
 int ramp_i_plan_dyn(const int64_t *g4, int E_cap, int E_grid, const int32_t *dyn, int32_t *status, int M, int kkey_cap,
                     int pkey_cap, int kk_cap, int ij_cap, int32_t *kk_order, int32_t *kk_gid, int32_t *kk_seg,
@@ -49,7 +50,7 @@ int ramp_i_corr_fwd(const void *fmap1, const ramp_corr_level *levels, int nlevel
                     const int64_t *ii, const int64_t *jj, const int32_t *order, void *out, int out_row_elems,
                     long mod_ii, long mod_jj, int E, int N1, int N2, int C, int P, int radius, int dtype, int layout,
                     const int32_t *dyn, void *stream, const float *tf_poses = nullptr, const float *tf_patches = nullptr,
-                    const float *tf_intr = nullptr, const int64_t *tf_src = nullptr);
+                    const float *tf_intr = nullptr, const int64_t *tf_src = nullptr, const int32_t *slot0 = nullptr);
 int ramp_i_upd_gru(const float *x32, const void *add0_t, const int32_t *add0_idx, const void *add_t, const int32_t *add_idx,
                  const float *pre_w, const float *pre_b,
                    float pre_eps, const void *const *wp_host, const float *const *bias_host, const float *ln_w,

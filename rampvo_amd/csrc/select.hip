@@ -245,6 +245,7 @@ struct FrameCommit {
   const int32_t *dyn; int mod[FC_MAXBUF]; const float *k_new;
   int32_t *status; int E_bound;      // optional: status bit 32 if dyn[RAMP_DYN_E] exceeds the step's launch bound
   int32_t *status_rows; int n_rows;  // with dyn: the frame buffers hold n_rows rows -- a row past them is flagged (bit 64), nothing is stored
+  const int32_t *slot_tab; int slot_buf;   // optional: ring row r of buffer slot_buf lives in physical slot slot_tab[r] (ramp_track.fmap1_slot)
 };
 __global__ void __launch_bounds__(MED_THREADS) frame_commit_kernel(const FrameCommit a) {
   const int t = threadIdx.x;
@@ -269,7 +270,11 @@ __global__ void __launch_bounds__(MED_THREADS) frame_commit_kernel(const FrameCo
     const long n16 = a.bytes[b] / 16;                       // 16-byte multiples, 16-byte aligned (checked on the host)
     const uint4 *s = reinterpret_cast<const uint4 *>(a.src[b]);
     char *d = a.dst[b];
-    if (a.dyn) d += (size_t)(a.mod[b] ? n % a.mod[b] : n) * a.bytes[b];
+    if (a.dyn) {
+      int row = a.mod[b] ? n % a.mod[b] : n;
+      if (a.slot_tab && b == a.slot_buf) row = a.slot_tab[row];
+      d += (size_t)row * a.bytes[b];
+    }
     uint4 *o = reinterpret_cast<uint4 *>(d);
     for (long i = (long)blockIdx.x * blockDim.x + t; i < n16; i += (long)gridDim.x * blockDim.x) o[i] = s[i];
     return;
@@ -315,7 +320,8 @@ int ramp_i_frame_commit_dyn(float *poses, int motion, float damping, int64_t *ts
                             int64_t *index_map, float *intrinsics, const float *k_new, float *patches_state,
                             int median_frames, int M, int P, float *patches_new, int n_copy, const void *const *src,
                             void *const *base, const long *bytes, const int *mod, const int32_t *dyn,
-                            const float *median_ahead, int32_t *status, int E_bound, int n_rows, hipStream_t st) {
+                            const float *median_ahead, int32_t *status, int E_bound, int n_rows, hipStream_t st,
+                            const int32_t *slot_tab, int slot_buf) {
   if (!poses || !patches_state || !patches_new || !dyn || M <= 0 || P <= 0 || n_copy < 0 || n_copy > FC_MAXBUF)
     return RAMP_EINVAL;
   if ((long)median_frames * M * P * P > MED_THREADS * MED_PER) return RAMP_EUNSUPPORTED;
@@ -328,6 +334,8 @@ int ramp_i_frame_commit_dyn(float *poses, int motion, float damping, int64_t *ts
   a.dyn = dyn; a.k_new = k_new;
   a.status = E_bound > 0 ? status : nullptr; a.E_bound = E_bound;
   a.status_rows = status; a.n_rows = n_rows;
+  a.slot_tab = slot_tab; a.slot_buf = slot_buf;
+  if (slot_tab && (slot_buf < 0 || slot_buf >= n_copy || mod[slot_buf] <= 0)) return RAMP_EINVAL;
   a.n_copy = n_copy;
   long mx = 0;
   for (int i = 0; i < FC_MAXBUF; i++) a.mod[i] = 0;
@@ -407,6 +415,7 @@ int ramp_frame_commit(float *poses, int n, int motion, float damping, int64_t *t
   a.patches_new = patches_new; a.patches_row = patches_state + (size_t)n * row;
   a.median_val = median_dev;
   a.dyn = nullptr; a.k_new = nullptr; a.status = nullptr; a.E_bound = 0; a.status_rows = nullptr; a.n_rows = 0;
+  a.slot_tab = nullptr; a.slot_buf = 0;
   for (int i = 0; i < FC_MAXBUF; i++) a.mod[i] = 0;
   a.n_copy = n_copy;
   long mx = 0;

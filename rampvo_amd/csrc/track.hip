@@ -36,6 +36,8 @@ struct TrkEdit {
   long row_bytes[TRK_MAXBUF];
   int mod[TRK_MAXBUF];
   int nbuf;
+  int32_t *slot_tab;       // optional (ramp_track.fmap1_slot): the rows of buffer slot_buf are not moved, the table is rotated
+  int slot_buf, slot_mod;
 };
 
 // Ramp_vo.keyframe(): m = motionmag(i, j) + motionmag(j, i);  m / 2 < KEYFRAME_THRESH  (python floats: doubles)
@@ -198,6 +200,16 @@ __global__ void __launch_bounds__(256) trk_apply_kernel(const TrkEdit p) {
   if (blockIdx.y > 0) {
     if (!p.dyn[RAMP_DYN_REMOVED]) return;
     const int b = blockIdx.y - 1, k = p.dyn[RAMP_DYN_K], nrows = p.dyn[RAMP_DYN_NPREV];
+    if (p.slot_tab && b == p.slot_buf) {
+      // rows k + 1 .. nrows - 1 become rows k .. nrows - 2: their SLOTS move down the table, the dropped row's slot goes
+      // behind them (the next new frame's).  One thread; readers come in later launches.
+      if (blockIdx.x == 0 && tid == 0) {
+        const int freed = p.slot_tab[k % p.slot_mod];
+        for (int r = k; r < nrows - 1; r++) p.slot_tab[r % p.slot_mod] = p.slot_tab[(r + 1) % p.slot_mod];
+        p.slot_tab[(nrows - 1) % p.slot_mod] = freed;
+      }
+      return;
+    }
     const long n4 = p.row_bytes[b] / 4;
     // each thread owns columns c, c + stride, ... and moves the rows itself: no cross-thread hazard.  Up to four rows
     // (KEYFRAME_INDEX - 1 = 3 in every shipped config) are all READ before the first is written -- one round trip
@@ -329,6 +341,7 @@ static int trk_edit_fill(const ramp_track *t, int cur, int64_t counter, TrkEdit 
     if (!bufs[i] || (rb[i] & 3)) return RAMP_EINVAL;
     p.base[i] = (char *)bufs[i]; p.row_bytes[i] = rb[i]; p.mod[i] = md[i];
   }
+  p.slot_tab = t->fmap1_slot; p.slot_buf = 7; p.slot_mod = t->mem;      // (bufs[7] = fmap1)
   return RAMP_OK;
 }
 
@@ -344,7 +357,8 @@ static bool trk_valid(const ramp_track *t) {
 // behind the front end, next to the previous step's bundle adjustment.
 __global__ void __launch_bounds__(256) trk_warm_kernel(const uint4 *__restrict__ fmap1, const uint4 *__restrict__ fmap2,
                                                        const uint4 *__restrict__ gmap, long n1, long n2, long ng, int mem,
-                                                       int frames, const int32_t *__restrict__ dyn, int32_t *sink) {
+                                                       int frames, const int32_t *__restrict__ dyn, int32_t *sink,
+                                                       const int32_t *__restrict__ slot1) {
   const int fi = blockIdx.y;                       // 0 .. frames - 1: frame n - 1 - fi; frames: the patch features
   const long stride = (long)gridDim.x * 256, t0 = (long)blockIdx.x * 256 + threadIdx.x;
   unsigned acc = 0;
@@ -354,7 +368,7 @@ __global__ void __launch_bounds__(256) trk_warm_kernel(const uint4 *__restrict__
     const int f = dyn[RAMP_DYN_N] - fi;            // (the keyframe test may be moving n by one right now: one frame of margin)
     if (f < 0) return;
     const int slot = f % mem;
-    const uint4 *p1 = fmap1 + (size_t)slot * n1, *p2 = fmap2 + (size_t)slot * n2;
+    const uint4 *p1 = fmap1 + (size_t)(slot1 ? slot1[slot] : slot) * n1, *p2 = fmap2 + (size_t)slot * n2;
     for (long i = t0; i < n1; i += stride) { const uint4 v = p1[i]; acc ^= v.x ^ v.y ^ v.z ^ v.w; }
     for (long i = t0; i < n2; i += stride) { const uint4 v = p2[i]; acc ^= v.x ^ v.y ^ v.z ^ v.w; }
   }
@@ -430,7 +444,7 @@ int ramp_track_warm(const ramp_track *t, int32_t *sink, void *stream) {
   static int gx = 0;
   if (!gx) { const char *e = getenv("RAMP_WARM_GX"); gx = e ? atoi(e) : 8; }   // 8 x 26 workgroups: ~100 us of gentle streaming (64: the planes arrive sooner, the tail kernels slow down as much)
   hipLaunchKernelGGL(trk_warm_kernel, dim3(gx, frames + 1), dim3(256), 0, (hipStream_t)stream, (const uint4 *)t->fmap1,
-                     (const uint4 *)t->fmap2, (const uint4 *)t->gmap, n1, n2, ng, t->mem, frames, t->dyn, sink);
+                     (const uint4 *)t->fmap2, (const uint4 *)t->gmap, n1, n2, ng, t->mem, frames, t->dyn, sink, t->fmap1_slot);
   RAMP_CHECK_LAUNCH();
   return RAMP_OK;
 }
@@ -503,7 +517,8 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
     const int mod[5] = {0, t->mem, t->mem, t->mem, t->mem};
     TRK_DO(ramp_i_frame_commit_dyn(t->poses, t->motion_model, t->motion_damping, t->tstamps, counter, t->index_map,
                                    t->intrinsics, k_new, t->patches, 3, t->M, t->P, t->fe_patches, 5, src, base, bytes,
-                                   mod, dyn, (t->median && t->keyframe_index >= 4) ? t->median : nullptr, t->dyn + RAMP_DYN_STATUS, (Eb < Ec && folded) ? Eb : 0, t->n_rows, st));
+                                   mod, dyn, (t->median && t->keyframe_index >= 4) ? t->median : nullptr, t->dyn + RAMP_DYN_STATUS, (Eb < Ec && folded) ? Eb : 0, t->n_rows, st,
+                                   t->fmap1_slot, 3));
   }
   if ((flags & RAMP_TRACK_UPDATE) && t->feat_fp32) return RAMP_EUNSUPPORTED;   // (fp32: PRE, the caller's operator, POST)
   if (flags & RAMP_TRACK_UPDATE_PRE) {
@@ -515,10 +530,12 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
     TRK_PROBE(0);
     if (t->feat_fp32)
       TRK_DO(ramp_i_corr_fwd(t->gmap, lv, 2, t->coords, kk, jj, t->ij_order, t->corr, 882, (long)t->M * t->mem, t->mem, Eb,
-                             t->mem * t->M, t->mem, 128, t->P, 3, RAMP_F32, RAMP_NHWC, dyn, st));
+                             t->mem * t->M, t->mem, 128, t->P, 3, RAMP_F32, RAMP_NHWC, dyn, st, nullptr, nullptr, nullptr, nullptr,
+                             t->fmap1_slot));
     else
       TRK_DO(ramp_i_corr_fwd(t->gmap, lv, 2, t->coords, kk, jj, t->ij_order, t->corr, 896, (long)t->M * t->mem, t->mem, Eb,
-                             t->mem * t->M, t->mem, 128, t->P, 3, RAMP_F16, RAMP_NHWC32, dyn, st));
+                             t->mem * t->M, t->mem, 128, t->P, 3, RAMP_F16, RAMP_NHWC32, dyn, st, nullptr, nullptr, nullptr, nullptr,
+                             t->fmap1_slot));
     TRK_PROBE(1);
   }
   if (flags & RAMP_TRACK_UPDATE_POST) {
@@ -556,7 +573,7 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
     TRK_PROBE(0);
     TRK_DO(ramp_i_corr_fwd(t->gmap, lv, 2, t->coords, kk, jj, t->ij_order, t->corr, 896, (long)t->M * t->mem, t->mem, Eb,
                            t->mem * t->M, t->mem, 128, t->P, 3, RAMP_F16, RAMP_NHWC32, dyn, st,
-                           fuse_tf ? t->poses : nullptr, t->patches, t->intrinsics, ii));
+                           fuse_tf ? t->poses : nullptr, t->patches, t->intrinsics, ii, t->fmap1_slot));
     TRK_PROBE(1);
     // the update operator, ramp/net.py:69-90 (the fp16 fused chains of csrc/update_mlp.hip)
     TRK_DO(ramp_i_upd_corr_mlp(t->corr, 896, w.corr_w1, w.corr_b1, w.corr_w2, w.corr_b2, w.corr_w3, w.corr_b3, w.corr_ln_w,

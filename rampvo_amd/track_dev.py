@@ -55,7 +55,7 @@ class Track(ctypes.Structure):
                 + _ptr_fields(["fg", "ykk", "hkk", "yij", "hij", "relu_t", "sagg_frag", "target", "weight", "ba_ws"])
                 + [("ba_ws_bytes", c_sz)]
                 + _ptr_fields(["mm", "median", "dlog", "edit_ws", "dyn_host", "dyn_host_dev"]) + [("probe", c_p * 5), ("E_hint", c_i),
-                   ("gate_seq", ctypes.c_uint32), ("feat_fp32", c_i), ("gate_flag", c_p)])
+                   ("gate_seq", ctypes.c_uint32), ("feat_fp32", c_i), ("gate_flag", c_p), ("fmap1_slot", c_p)])
 
 
 _E_EST_LAST = int(os.environ.get("RAMP_E_EST_LAST", "1"))        # 0: the largest of the last 64 copies (round 3's first rule)
@@ -194,6 +194,12 @@ class DeviceTrack:
                               dyn_host=self.dyn_host).items():
             setattr(t, name, P(ten))
         t.plan_ws_bytes, t.ba_ws_bytes = self.plan_ws.numel(), self.ba_ws.numel()
+        # level-0 correlation planes by slot table (csrc/track.hip: a dropped keyframe rotates table entries instead of moving
+        # three planes; leave() undoes the permutation).  RAMP_SLOT_TABLE=0: rows are slots, physical shifts
+        self.fmap1_slot = None
+        if os.environ.get("RAMP_SLOT_TABLE", "1") != "0":
+            self.fmap1_slot = torch.arange(slam.mem, dtype=torch.int32, device=dev)
+            t.fmap1_slot = self.fmap1_slot.data_ptr()
         dp = ctypes.c_void_p()                    # device address of the pinned copy: resolved once, not per frame
         if lib.ramp_host_device_pointer(ctypes.c_void_p(self.dyn_host.data_ptr()), ctypes.byref(dp)) == 0 and dp.value:
             t.dyn_host_dev = dp.value
@@ -280,6 +286,8 @@ class DeviceTrack:
         if (n + 1) * M - d[DYN_KLO] > self.kkey_cap or d[DYN_W] ** 2 > self.pkey_cap:
             return False
         self.dyn.copy_(self.dyn_host, non_blocking=True)
+        if self.fmap1_slot is not None:
+            self.fmap1_slot.copy_(torch.arange(slam.mem, dtype=torch.int32, device=self.fmap1_slot.device))   # (rows are slots on the host side)
         _lib.check(_lib.lib().ramp_track_plan(ctypes.byref(self.t), self.cur, _lib.stream()), "ramp_track_plan")
         self.active = True
         self._frames = 0
@@ -390,6 +398,12 @@ class DeviceTrack:
         """synchronise and return the host-side view of the state: dict(n, ii, jj, kk, rows (host arrays of the kept
         factors), net (device [EPREV, 384] view), log (list of (t1, t0, dP[7] device tensor)), status)"""
         torch.cuda.current_stream().synchronize()
+        if self.fmap1_slot is not None:
+            # the host-driven path addresses ring row r as slot r: undo the table's permutation of the level-0 planes
+            perm = self.fmap1_slot.long()
+            if not bool((perm == torch.arange(perm.numel(), device=perm.device)).all()):
+                self.slam.fmap1_.copy_(self.slam.fmap1_[perm])
+                self.fmap1_slot.copy_(torch.arange(perm.numel(), dtype=torch.int32, device=perm.device))
         d = self.dyn.cpu().numpy()
         Ek, n = int(d[DYN_EKEPT]), int(d[DYN_NROW])
         g = self.graph[self.cur][:, :Ek].cpu().numpy()
