@@ -999,7 +999,18 @@ def test_device_graph_edit_matches_host_edit(remove):
         if remove:
             for row in range(k, n - 1):
                 exp[row % ring if ring else row] = exp[(row + 1) % ring if ring else row + 1]
-        assert torch.equal(getattr(slam, name), exp), name
+        rows_now = getattr(slam, name)
+        if name == "fmap1_" and dv.fmap1_slot is not None:
+            # level-0 planes by slot table (ramp_track.fmap1_slot): ring row r lives in slot tab[r]; a dropped keyframe
+            # rotates entries k .. n - 1 (the freed slot goes to row n - 1, the next new frame's: its content is unspecified)
+            tab = dv.fmap1_slot.long()
+            assert sorted(tab.tolist()) == list(range(ring))
+            rows_now = rows_now[tab]
+            if remove:
+                keep = torch.ones(ring, dtype=torch.bool, device=rows_now.device)
+                keep[(n - 1) % ring] = False
+                rows_now, exp = rows_now[keep], exp[keep]
+        assert torch.equal(rows_now, exp), name
     # ---- delta log
     assert dd[td.DYN_NLOG] == int(remove)
     if remove:
