@@ -657,6 +657,11 @@ def main():
     dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    # launched by torch.distributed.run (RANK / WORLD_SIZE in the environment): the process group is created even for a
+    # world of one, so that the RCCL initialisation, the barriers and the two collectives of the N > 1 path run on a
+    # one-GPU box too (tests/test_pipeline_gpu.py::test_bench_under_torchrun_initialises_rccl); a plain
+    # `python bench.py` (the driver's N = 1 run) creates none
+    use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     host = {}
     if world > 1:
         # N trackers on one host: each rank's Python needs about one core (a tracked frame is one C call in steady
@@ -672,6 +677,7 @@ def main():
             host = {"threads": 1, "cores_of_rank0": "%d-%d" % (mine[0], mine[-1]), "cores_per_rank": len(mine)}
         except (AttributeError, OSError):
             host = {"threads": 1}
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
@@ -745,7 +751,7 @@ def main():
     E0, n0 = graph_size(slam)
 
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     # Inside the timed region only the dominant kernel is bracketed, and only on every --probe-every-th step: an event
@@ -766,7 +772,7 @@ def main():
         step()
         marks.append(time.perf_counter())         # host-side return times (the GPU may lag by less than a step)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - tic
@@ -785,7 +791,7 @@ def main():
     from rampvo_amd.shard import gather_metrics, max_over_ranks
     dt_all = max_over_ranks(dt, dev)
     per_rank = None
-    if world > 1:
+    if use_dist:
         # the path's single collective: per-sequence metrics (kf/s, E, n, pose checksum)
         E_r, n_r = graph_size(slam)
         g = gather_metrics([args.steps / dt, float(E_r), float(n_r), float(slam.poses_[:n_r].double().sum())], dev)
@@ -871,6 +877,7 @@ def main():
         }
         if per_rank is not None:
             out["config"]["per_rank_kfps_E_n_chk"] = per_rank
+            out["config"]["process_group"] = {"backend": dist.get_backend(), "world": dist.get_world_size()}
             out["config"]["host_placement"] = host
         rl = ctimer.summary(2 if args.mixed else 4, slam)
         assert rl is not None or args.no_kernel_timing, "no correlation launch was timed: the roofline hook is stale"
@@ -926,7 +933,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(snapshot, args, cfg_kwargs, cpu_frames, args.cpu_steps)
             out["config"]["speedup_vs_cpu_port"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -658,6 +658,38 @@ def test_bench_json_contract():
     assert tr["fp32"]["rel"] <= 1e-4 and tr["fp32"]["ate_vs_reference"] <= 1e-4 and d["ate_vs_oracle"] <= 1e-4, tr
 
 
+def test_bench_under_torchrun_initialises_rccl():
+    """the driver's N > 1 launch line on a one-GPU box: `python -m torch.distributed.run --nproc-per-node 1 bench.py
+    --gpus 1 ...` with the default backend -- `init_process_group("nccl", device_id=...)` (RCCL), the two barriers
+    around the timed region, the MAX all-reduce of the elapsed time and the all-gather of the per-rank metrics all run,
+    with a world of one (configs[3]'s 8-rank run needs a node this pool does not hand out)"""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RAMP_DIST_BACKEND", None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                          "--gpus", "1", "--height", "240", "--width", "320", "--patches", "48", "--prime", "40",
+                          "--steps", "5", "--warmup", "2", "--cpu-steps", "0", "--parity", "0", "--np-steps", "4",
+                          "--inst-steps", "8", "--live-steps", "0"],
+                         capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["config"]["process_group"] == {"backend": "nccl", "world": 1}
+    row, = d["config"]["per_rank_kfps_E_n_chk"]          # the all-gather's result: this rank's own metrics
+    assert row[0] > 0 and row[1] > 0 and row[2] > 0 and np.isfinite(row[3])
+
+
 @torch.no_grad()
 def test_intrinsics_rows_follow_the_input():
     """intrinsics_[n] = K / RES of the frame stored at row n (reference Ramp_vo.py:351), also when K changes between
