@@ -551,12 +551,28 @@ def parity_block(state, args, cfg_kwargs, net, dev):
                     depths_max=float(dp.max() / scale)).items()}
             del slam
     # the same step with the weights exactly as the benchmark tracks with them (no bias shift: confidences ~0.5, the
-    # ill-conditioned regime), fp32 leg: the stated bounds of tests/test_pipeline_gpu.py::REGIME_BOUNDS apply
+    # ill-conditioned regime), fp32 leg, next to the problem's own fp32 rounding envelope: the oracle step's
+    # bundle-adjustment inputs solved by the fp64 build of the same oracle source (as tests/test_pipeline_gpu.py::
+    # test_full_size_update_step_in_the_wide_regime asserts it: HIP-vs-oracle <= 4 x oracle-fp32-vs-fp64)
     net0 = make_network(args.mode, device=dev)
+    ba_in = []
     with cpu_oracle_ops():
+        import rampvo_amd.ops as _ops
+        _ba = _ops.ba
+
+        def spy(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t1, iterations=2, info=None, **kw):
+            P = patches.shape[-1]
+            ba_in.append((poses.view(-1, 7).numpy().copy(), patches.view(-1, 3, P, P).numpy().copy(), intrinsics.numpy().copy(),
+                          target.numpy().copy(), weight.numpy().copy(), lmbda.numpy().copy(), ii.numpy().copy(),
+                          jj.numpy().copy(), kk.numpy().copy(), int(t0), int(t1), int(iterations)))
+            return _ba(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t1, iterations, info, **kw)
+        _ops.ba = spy
         ref = _cpu_tracker(state, args, cfg_kwargs)
         ref.update()
         r0 = dict(poses=ref.poses_[:n].numpy().copy(), depth=ref.patches_[:n, :, 2, 1, 1].numpy().copy())
+    import oracle as _orc
+    p64, pt64 = _orc.ba_f64(*ba_in[-1])
+    d64 = pt64.reshape(-1, r0["depth"].shape[1], 3, 3, 3)[:n, :, 2, 1, 1]
     slam = Ramp_vo(make_cfg(args.preset, **dict(cfg_kwargs, MIXED_PRECISION=False)), net0, {"event_bias": True},
                    ht=args.height, wd=args.width, device=dev)
     slam.load_state_dict(state)
@@ -565,9 +581,13 @@ def parity_block(state, args, cfg_kwargs, net, dev):
     step0 = float(np.abs(r0["poses"] - before).max())
     at_reset = (np.abs(r0["depth"] - 20.0) < 0.1) | (np.abs(g_depth - 20.0) < 0.1)
     derr = (np.abs(g_depth - r0["depth"]) / np.maximum(np.abs(r0["depth"]), 1.0))[~at_reset]
+    at64 = (np.abs(r0["depth"] - 20.0) < 0.1) | (np.abs(d64 - 20.0) < 0.1)
+    e64 = (np.abs(r0["depth"] - d64) / np.maximum(np.abs(d64), 1.0))[~at64]
     tf["fp32_wide_regime"] = {k: float("%.3g" % v) for k, v in dict(
         gn_step=step0, poses_over_gn_step=float(np.abs(slam.poses_[:n].cpu().numpy() - r0["poses"]).max() / max(step0, 1e-12)),
-        depths_p999=float(np.percentile(derr, 99.9)), depths_max=float(derr.max())).items()}
+        depths_p999=float(np.percentile(derr, 99.9)), depths_max=float(derr.max()),
+        oracle_fp32_vs_fp64_poses_over_gn_step=float(np.abs(r0["poses"] - p64[:n]).max() / max(step0, 1e-12)),
+        oracle_fp32_vs_fp64_depths_p999=float(np.percentile(e64, 99.9)), oracle_fp32_vs_fp64_depths_max=float(e64.max())).items()}
     del slam
     out = dict(teacher_forced=tf)
     # trajectory level: tests/pipeline_checks.py::check_trajectory against tests/golden/ramp_vo_traj_ss.npz

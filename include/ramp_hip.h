@@ -119,6 +119,10 @@ int ramp_corr_fwd_ordered(const void *fmap1, const ramp_corr_level *levels_host,
  * C == 128, W % 16 == 0, H % 4 == 0, else RAMP_EUNSUPPORTED.                 */
 int ramp_pyramid_pack(const void *fmap, void *level1, void *level4, int H, int W, int C, int dtype,
                       void *stream);
+/* channels per plane of the RAMP_NHWC32 layout THIS build packs and reads ([H][C/k][W][k]; 32 unless the library was
+ * built with -DCORR_KPLANE=8, round 2/3's layout): the caller sizes and converts its ring buffers with it -- a binding
+ * that assumes another width must refuse to run (rampvo_amd/_lib.py asserts it when the library loads).             */
+int ramp_corr_kplane(void);
 
 /* Event list -> int8 bin stack, the encoder's event input (reference utils/transformers.py:128-161,
  * EventToStack_Numpy; upstream a host-side np.add.at).  Event i goes to bin

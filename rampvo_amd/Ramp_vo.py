@@ -64,6 +64,22 @@ def _gru_tile_rows(E, device):
 _FE_DELAY_US = int(os.environ.get("RAMP_FE_DELAY_US", "35"))     # A/B switch: 0 = the encoder graph right behind the selection
 _GATE_FLAG_DELAY_US = int(os.environ.get("RAMP_GATE_FLAG_DELAY_US", "0"))
 _FE_WAIT_PROBE = os.environ.get("RAMP_FE_WAIT_PROBE", "0") == "1"   # tools/fe_wait.py
+# The front end's "done" is a data dependency (the frame commit reads fe_fmap1 / imap / gmap / patches): the wave that waits
+# for its signal word must not give up while the producer can still arrive.  The time-out is a hang guard only -- 20 s, far
+# beyond any profiler slow-down -- and a wait that does give up still raises sticky status bit 128, on which settle() /
+# lazy_state() raise.  Runtimes that serialise kernels never get here (_kernels_are_serialised: events instead).  The gate
+# wait (_gate_wait) keeps its 50 ms: it orders nothing but timing (a front end that starts early is slower, not wrong).
+_FE_DONE_TIMEOUT_US = int(os.environ.get("RAMP_FE_DONE_TIMEOUT_US", "20000000"))
+
+
+def _kernels_are_serialised():
+    """a cross-stream wait by a spinning wave needs the two streams to run CONCURRENTLY.  Under counter collection
+    (rocprofv3 --pmc: ROCPROF_COUNTER_COLLECTION), AMD_SERIALIZE_KERNEL or HIP_LAUNCH_BLOCKING the runtime runs one
+    kernel at a time -- the waiting wave would keep its producer off the GPU until it times out -- so the signal words
+    are not used there: events order the streams"""
+    def on(k):
+        return os.environ.get(k, "0") not in ("", "0")
+    return on("ROCPROF_COUNTER_COLLECTION") or on("AMD_SERIALIZE_KERNEL") or on("HIP_LAUNCH_BLOCKING") or on("RAMP_NO_FLAG_WAITS")
 _WARM = os.environ.get("RAMP_WARM", "1") != "0"     # A/B switch: the cache warm-up behind the front end
 
 
@@ -693,7 +709,7 @@ class Ramp_vo:
         """the signal word of the gate, or None (RAMP_GATE_FLAG=0, no signal memory, or 2^31 frames behind us: the event
         then).  Where in the step the word is stored is csrc/track.hip's RAMP_GATE_AT (default: by the first SoftAgg launch)"""
         if self._gate_sig is None:
-            use = os.environ.get("RAMP_GATE_FLAG", "1") != "0"
+            use = os.environ.get("RAMP_GATE_FLAG", "1") != "0" and not _kernels_are_serialised()
             with torch.cuda.device(self.device):          # (the word must live on the tracker's GPU, not the caller's current one)
                 self._gate_sig = track_dev.Signal() if use else False
         sig = self._gate_sig
@@ -702,16 +718,18 @@ class Ramp_vo:
     def _fe_done_to(self, fe, cur, dv):
         """the front end's "done" for the main stream: a word in signal memory stored by a one-thread launch behind the
         encoder graph and looked at by one sleeping wave in front of the frame commit (RAMP_FE_DONE_FLAG=0, or no signal
-        memory: an event record + stream wait, ~10 us of packets on the serial chain even when the front end is long done)"""
+        memory, or a runtime that serialises kernels (_kernels_are_serialised): an event record + stream wait, ~10 us of
+        packets on the serial chain even when the front end is long done).  The commit READS what the front end wrote, so
+        this wait's time-out is a hang guard (RAMP_FE_DONE_TIMEOUT_US, 20 s), not a scheduling choice"""
         if self._fe_done_sig is None:
-            use = os.environ.get("RAMP_FE_DONE_FLAG", "1") != "0"
+            use = os.environ.get("RAMP_FE_DONE_FLAG", "1") != "0" and not _kernels_are_serialised()
             with torch.cuda.device(self.device):
                 self._fe_done_sig = track_dev.Signal() if use else False
         sig = self._fe_done_sig
         if sig and sig.ptr is not None and self._fe_done_seq < 0x7FFFFFF0:
             self._fe_done_seq += 1
             _lib.check(_lib.lib().ramp_stream_signal(ctypes.c_void_p(fe.cuda_stream), sig.ptr, self._fe_done_seq), "ramp_stream_signal")
-            sig.wait(cur, self._fe_done_seq, status=dv.status_ptr)
+            sig.wait(cur, self._fe_done_seq, timeout_us=_FE_DONE_TIMEOUT_US, status=dv.status_ptr)
         else:
             self._ev_fe_done.record(fe)
             cur.wait_event(self._ev_fe_done)

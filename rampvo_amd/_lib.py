@@ -35,6 +35,7 @@ class CorrLevel(ctypes.Structure):
 # name -> (restype, argtypes); also the list the CPU test checks for export
 SIGNATURES = {
     "ramp_version": (ctypes.c_char_p, []),
+    "ramp_corr_kplane": (c_i, []),
     "ramp_patchify_fwd": (c_i, [c_p, c_p, c_p] + [c_i] * 10 + [c_p]),
     "ramp_frame_gather": (c_i, [c_p] * 9 + [c_i] * 8 + [c_p]),
     "ramp_corr_fwd": (c_i, [c_p, ctypes.POINTER(CorrLevel), c_i, c_p, c_p, c_p, c_p] + [c_i] * 8 + [c_p]),
@@ -163,6 +164,9 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)  # AttributeError if a declared symbol is not exported
             fn.restype, fn.argtypes = res, args
+        if l.ramp_corr_kplane() != KPLANE:      # (an A/B build with -DCORR_KPLANE=8: this binding would pack the planes wrong)
+            raise RuntimeError("rampvo_amd: %s packs %d-channel correlation planes, this binding is written for %d "
+                               "(rebuild without -DCORR_KPLANE, or set rampvo_amd._lib.KPLANE)" % (LIB_PATH, l.ramp_corr_kplane(), KPLANE))
         _lib = l
     return _lib
 

@@ -830,6 +830,8 @@ int ramp_debug_corr_trace(unsigned long long *host, int n_waves) {     // host [
   return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_corr_trace), (size_t)n_waves * 8 * 8) == hipSuccess ? 0 : -1;
 }
 #endif
+int ramp_corr_kplane(void) { return CORR_KPLANE; }
+
 int ramp_pyramid_pack(const void *fmap, void *level1, void *level4, int H, int W, int C, int dtype,
                       void *stream) {
   if (!fmap || !level1 || !level4 || H <= 0 || W <= 0) return RAMP_EINVAL;

@@ -56,9 +56,10 @@ def run(cfg_VO, network, eval_cfg, data_list, ht=480, wd=640, device="cuda"):
 
 @torch.no_grad()
 def run_pose_pred(cfg_VO, network, eval_cfg, data_list, t_horizon_to_pred, t_to_pred, deg_approx=4, ht=480, wd=640,
-                  device="cuda"):
+                  device="cuda", corrected=False):
     """reference evaluate.py:185-229: track up to frame t_to_pred, then extrapolate virtual keyframes for
-    t_horizon_to_pred frames; returns terminate()'s (poses, tstamps)"""
+    t_horizon_to_pred frames; returns terminate()'s (poses, tstamps).  corrected=False reproduces upstream's pose
+    prediction bugs included (Ramp_vo.predict_future_pose's docstring); corrected=True opts out of them"""
     train_cfg = eval_cfg["data_loader"]["train"]["args"]
     slam = Ramp_vo(cfg=cfg_VO, network=network, train_cfg=train_cfg, ht=ht, wd=wd, device=device)
     last_keyframe_number = 0
@@ -71,7 +72,7 @@ def run_pose_pred(cfg_VO, network, eval_cfg, data_list, t_horizon_to_pred, t_to_
                 slam.update()
         if t >= t_to_pred and t_to_pred > 0:
             slam.predict_future_pose(last_keyframe_number=last_keyframe_number, sec_to_pred_future=t - t_to_pred,
-                                     abs_time=t, deg=deg_approx)
+                                     abs_time=t, deg=deg_approx, corrected=corrected)
         if t == t_to_pred + t_horizon_to_pred:
             break
     for _ in range(12):

@@ -82,10 +82,13 @@ def _steady_state_snapshot(mode, preset, M, H, W, frames, mixed, seed=4321, **ov
 STEP_W_BIAS = -14.0
 
 
-def _one_update_vs_cpu_oracle(mode, preset, H, W, sd, cfgk, legs=(False,), w_bias=None, policy=False):
+def _one_update_vs_cpu_oracle(mode, preset, H, W, sd, cfgk, legs=(False,), w_bias=None, policy=False, envelope=False):
     """ONE update() (reproject -> corr -> update operator -> BA x2 -> point cloud) from the same snapshot: HIP kernels
     (a fresh tracker per precision leg) vs the CPU oracle backend in fp32 (torch-CPU GEMMs + oracle C natives).
-    Returns {leg: errors}; errors are max-abs, poses/depths relative to max(1, size of the GN step)."""
+    Returns {leg: errors}; errors are max-abs, poses/depths relative to max(1, size of the GN step).
+    envelope: also solve the oracle step's OWN bundle-adjustment problem (the inputs its fastba.BA call received) with the
+    fp64 build of the same oracle source (orc.ba_f64) -> out["fp32_rounding_envelope"]: how far the fp32 restatement of
+    the reference is from the exact solution of its own normal equations, in the same error measures."""
     from oracle.backend_cpu import Ramp_vo as cpu_tracker
     from oracle.backend_cpu import cpu_oracle_ops
     from rampvo_amd.config import make_cfg
@@ -97,7 +100,20 @@ def _one_update_vs_cpu_oracle(mode, preset, H, W, sd, cfgk, legs=(False,), w_bia
     f32 = dict(sd)
     for k in ("net", "imap", "gmap", "fmap1", "fmap2"):
         f32[k] = sd[k].float()
+    ba_in = []
     with cpu_oracle_ops():
+        if envelope:
+            import rampvo_amd.ops as _ops
+            _ba = _ops.ba
+
+            def spy(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t1, iterations=2, info=None, **kw):
+                P = patches.shape[-1]
+                ba_in.append(dict(poses=poses.view(-1, 7).numpy().copy(), patches=patches.view(-1, 3, P, P).numpy().copy(),
+                                  intr=intrinsics.numpy().copy(), target=target.numpy().copy(), weight=weight.numpy().copy(),
+                                  lmbda=lmbda.numpy().copy(), ii=ii.numpy().copy(), jj=jj.numpy().copy(),
+                                  kk=kk.numpy().copy(), t0=int(t0), t1=int(t1), iterations=int(iterations)))
+                return _ba(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t1, iterations, info, **kw)
+            _ops.ba = spy
         ref = cpu_tracker(make_cfg(preset, **dict(cfgk, MIXED_PRECISION=False)),
                           make_network(mode, device="cpu", w_bias=w_bias), {"event_bias": True}, ht=H, wd=W)
         ref.load_state_dict(f32)
@@ -120,6 +136,18 @@ def _one_update_vs_cpu_oracle(mode, preset, H, W, sd, cfgk, legs=(False,), w_bia
                        net=rp.net[0].float().numpy().copy(), w=rp.last_weight.numpy().copy())
     step = float(np.abs(r_poses - before).max())
     out = {}
+    if envelope:
+        import oracle as orc
+        b, = ba_in                                   # update() solves one problem (two GN iterations inside)
+        p64, pt64 = orc.ba_f64(b["poses"], b["patches"], b["intr"], b["target"], b["weight"], b["lmbda"], b["ii"],
+                               b["jj"], b["kk"], b["t0"], b["t1"], b["iterations"])
+        d64 = pt64.reshape(-1, sd["patches"].shape[1], 3, 3, 3)[:n, :, 2, 1, 1]
+        at64 = (np.abs(r_depth - 20.0) < 0.1) | (np.abs(d64 - 20.0) < 0.1)
+        e64 = np.abs(r_depth - d64) / np.maximum(np.abs(d64), 1.0)
+        out["fp32_rounding_envelope"] = dict(
+            poses_over_step=float(np.abs(r_poses - p64[:n]).max() / max(step, 1e-12)),
+            depths=float(e64[~at64].max()), depths_p995=float(np.percentile(e64, 99.5)),
+            depths_p999=float(np.percentile(e64, 99.9)), at_reset=int(at64.sum()))
     net = make_network(mode, w_bias=w_bias)
     for mixed in legs:
         slam = Ramp_vo(make_cfg(preset, **dict(cfgk, MIXED_PRECISION=mixed)), net, {"event_bias": True}, ht=H, wd=W)
@@ -228,29 +256,35 @@ def test_full_size_update_step_against_cpu_oracle():
     _assert_policy_leg(e["fp16_vs_policy"])
 
 
-# (w_bias shift, stated bound on |pose error| / GN step and on the depth error relative to max(1, |depth|), fp32 leg).
-# -14: the regime every other full-size test uses.  -6 and 0 (the "wide" profile as tracked, confidences ~0.5): the
-# normal equations of a random-weight tracker get ill conditioned (Q = 1 / (C + 1e-4) up to 1e4 on depths seen over almost
-# no baseline) and fp32 rounding differences between two correct implementations grow with the condition number; the
-# bounds are 4x the values measured on MI355X (printed by the test), not 1e-4.
-# Measured (MI355X, E = 27,360): w_bias -6: |pose error| / GN step 7.0e-6, depths 99.9th percentile 1.2e-3, worst 3.1e-3;
-# w_bias 0: 1.6e-5, 1.9e-3, 2.3e-3 (w_bias -14: 2.6e-6, 4.3e-6, 5.2e-6).  Poses meet the north star's 1e-4 of the step
-# in every regime; the depths that do not are the ill-conditioned ones (fp64 build of the same oracle: same order).
-REGIME_BOUNDS = {-6.0: (1e-4, 5e-3, 1.3e-2), 0.0: (1e-4, 8e-3, 1.0e-2)}      # poses / step, depths p99.9, depths max
+# The wide regime.  -14 (STEP_W_BIAS) is the regime every other full-size test uses.  -6 and 0 (the "wide" profile as
+# tracked, confidences ~0.5) leave the normal equations of a random-weight tracker ill conditioned (Q = 1 / (C + 1e-4) up
+# to 1e4 on depths seen over almost no baseline), and fp32 rounding differences between two correct implementations grow
+# with the condition number.  The claim is therefore stated against the problem's own rounding envelope, not against a
+# hand-set number: the oracle step's bundle-adjustment inputs are solved once more with the fp64 build of the same oracle
+# source (orc.ba_f64) -- |oracle fp32 - fp64| is how far the reference's own fp32 arithmetic is from the exact answer --
+# and the HIP fp32 leg must be within ENVELOPE_FACTOR x that of the fp32 oracle in every depth measure.  Poses meet the
+# north star's 1e-4 of the GN step in every regime, asserted as such.
+# Measured on MI355X (round 4, E = 27,360): w_bias -6: |pose error| / GN step 7.0e-6, depths p99.9 1.2e-3, worst 3.1e-3;
+# w_bias 0: 1.6e-5, 1.9e-3, 2.3e-3 (w_bias -14: 2.6e-6, 4.3e-6, 5.2e-6); the envelope is printed by the test.
+ENVELOPE_FACTOR = 4.0
 
 
 @torch.no_grad()
 @pytest.mark.parametrize("w_bias", [-6.0, 0.0])
 def test_full_size_update_step_in_the_wide_regime(w_bias):
     """configs[1] size, ONE update() vs the CPU oracle with the confidence head NOT damped to 1e-6 (ADVICE r2 /
-    VERDICT r2 4d): -6 = moderately conditioned (confidences ~2.5e-3), 0 = the weights exactly as the benchmark tracks
-    with them.  fp32 leg; the error is reported relative to the GN step itself and bounded by REGIME_BOUNDS."""
+    VERDICT r2 4d): -6 = moderately conditioned (confidences ~2.5e-3), 0 = the weights exactly as the
+    benchmark tracks with them.  fp32 leg: poses <= 1e-4 of the GN step; depths <= ENVELOPE_FACTOR x the fp32-vs-fp64
+    envelope of the oracle on the same problem (99.5th / 99.9th percentile and the worst patch)."""
     slam, sd, cfgk = _steady_state_snapshot("SingleScale", "default", 96, 480, 640, 34, mixed=True)
-    e = _one_update_vs_cpu_oracle("SingleScale", "default", 480, 640, sd, cfgk, legs=(False,), w_bias=w_bias)["fp32"]
-    print(w_bias, e)
+    r = _one_update_vs_cpu_oracle("SingleScale", "default", 480, 640, sd, cfgk, legs=(False,), w_bias=w_bias, envelope=True)
+    e, env = r["fp32"], r["fp32_rounding_envelope"]
+    print(w_bias, e, env)
     assert e["net"] <= 1e-4 and e["weight"] <= 1e-4, e            # everything in front of BA is regime independent
-    bp, bd, bm = REGIME_BOUNDS[w_bias]
-    assert e["poses_over_step"] <= bp and e["depths_p999"] <= bd and e["depths"] <= bm, e
+    assert e["poses_over_step"] <= 1e-4, (e, env)
+    assert e["at_reset"] <= 0.02 * e["patches"], e
+    for k in ("depths_p995", "depths_p999", "depths"):
+        assert e[k] <= max(1e-4, ENVELOPE_FACTOR * env[k]), (k, e, env)
 
 
 @torch.no_grad()
