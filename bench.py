@@ -165,11 +165,14 @@ class CorrTimer:
         Ramp_vo._corr_launch = timed_direct
 
     @staticmethod
-    def pmc_traffic_per_edge(elem_bytes):
+    def pmc_traffic_per_edge(elem_bytes, segment="timed"):
         """fabric-side bytes per edge of the fp16 kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2
         per the guide's gfx950 correction + WRITE_SIZE, separate --pmc passes; the newest
         profiles/pmc/r*_corr_traffic.json, which names its command).  Counters cannot be read inside this process,
-        so the per-edge figure of the PMC run of the same workload is scaled by this run's edges per launch."""
+        so the per-edge figure of the PMC run of the same workload is scaled by this run's edges per launch.  Since
+        round 5 the passes run the bench's own command line to its steady state (profiles/pmc/r05_corr_traffic.json,
+        tools/r05_pmc_corr.sh): ``segment`` picks the launches of the timed region or of the all-live legs, and the
+        source's own edges per launch ride along (the scaling is then a few per cent, not 23k -> 42k factors)."""
         if elem_bytes != 2:
             return None, None
         import glob
@@ -177,12 +180,16 @@ class CorrTimer:
         for f in reversed(files):
             try:
                 with open(f) as fh:
-                    return float(json.load(fh)["bytes_per_edge"]), os.path.relpath(f, ROOT)
+                    d = json.load(fh)
+                d = d.get(segment, d if segment == "timed" else None)
+                if d is None:
+                    return None, None, None
+                return float(d["bytes_per_edge"]), os.path.relpath(f, ROOT), int(d.get("edges_per_launch", 0))
             except Exception:
                 continue
-        return None, None
+        return None, None, None
 
-    def summary(self, elem_bytes, slam):
+    def summary(self, elem_bytes, slam, segment="timed"):
         if not self.pairs:
             return None
         ms = np.array([s.elapsed_time(e) for s, e in self.pairs])
@@ -205,7 +212,7 @@ class CorrTimer:
         per_edge_level = 128 * 9 * elem_bytes + 128 * 100 * elem_bytes + 72 + 16 + 441 * elem_bytes
         model = E * 2 * per_edge_level
         achieved = compulsory / sec / 1e9
-        per_edge, src = self.pmc_traffic_per_edge(elem_bytes)
+        per_edge, src, src_edges = self.pmc_traffic_per_edge(elem_bytes, segment)
         traffic = int(per_edge * E) if per_edge else None
         flops = E * 2 * CORR_FLOP_PER_EDGE_LEVEL
         peak_tf = MFMA_F16_PEAK_TFLOPS if elem_bytes == 2 else MFMA_F32_PEAK_TFLOPS
@@ -223,6 +230,7 @@ class CorrTimer:
             out["traffic_gbps"] = round(traffic / sec / 1e9, 1)
             out["traffic_frac_of_peak"] = round(traffic / sec / 1e9 / HBM_PEAK_GBS, 4)
             out["traffic_source"] = src
+            out["traffic_source_edges_per_launch"] = src_edges     # the PMC pass's own launch size (scaled to this run's)
         return out
 
 
@@ -853,11 +861,19 @@ def main():
             for mode, flag in (("compact", track_dev.COMPACT_COORDS), ("live", track_dev.WRAP_COORDS)):
                 slam._extra_step_flags = flag
                 dprobe.enabled, dprobe.mode = True, mode
-                for _ in range(n_live):
+                for _ in range(2):                 # (the pipeline refilling behind the flag change: untimed)
                     step()
                 torch.cuda.synchronize()
+                t_leg = time.perf_counter()
+                for _ in range(n_live - 2):
+                    step()
+                torch.cuda.synchronize()
+                t_leg = time.perf_counter() - t_leg
                 dprobe.enabled = False
                 live_leg[mode] = live_factor_fractions(slam, windows=True)
+                # the whole step, end to end, with this leg's factors (the correlation launch is bracketed by events on
+                # every step here, ~1 % of the rate): what a converged tracker would run at, not just its kernel
+                live_leg[mode]["kfps"] = round((n_live - 2) / t_leg, 1)
             slam._extra_step_flags = 0
     if dprobe is not None:
         dprobe.feed(ctimer, utimer, btimer, cfg.OPTIMIZATION_WINDOW)
@@ -926,11 +942,16 @@ def main():
                     continue
                 lt = CorrTimer()
                 lt.pairs, lt.edges = dprobe.live_pairs[mode][2:], dprobe.live_edges[mode][2:]   # (the first two: the pipeline refilling)
-                ll = lt.summary(2 if args.mixed else 4, slam)
+                ll = lt.summary(2 if args.mixed else 4, slam, segment={"compact": "live_compact", "live": "live_wrapped"}[mode])
+                if mode == "compact":
+                    out["config"]["converged_kfps"] = live_leg[mode]["kfps"]
+                    rl["frac_live_compact"] = ll["frac"]
                 out[key] = {"what": what[mode], **live_leg[mode],
                             **{k: ll[k] for k in ("bound", "achieved", "peak", "unit", "frac", "launches", "mean_launch_us",
                                                   "bytes_per_launch", "edges_per_launch", "target_frames", "patches",
-                                                  "model_bytes", "model_gbps", "mfma_tflops", "mfma_frac")}}
+                                                  "model_bytes", "model_gbps", "mfma_tflops", "mfma_frac", "traffic",
+                                                  "traffic_gbps", "traffic_frac_of_peak", "traffic_source_edges_per_launch")
+                               if k in ll}}
         for key, val in (("roofline_update", utimer.summary(bool(args.mixed))),
                          ("roofline_encoder", etimer.summary(bool(args.mixed))),
                          ("roofline_ba", btimer.summary(args.patches, cfg.REMOVAL_WINDOW))):
