@@ -111,6 +111,20 @@ int ramp_corr_fwd_ordered(const void *fmap1, const ramp_corr_level *levels_host,
                           const int32_t *order, void *out, int out_row_elems, long mod_ii, long mod_jj, int E,
                           int N1, int N2, int C, int P, int radius, int dtype, int layout, void *stream);
 
+/* Correlation AND the first Linear (+ ReLU) of the update operator's correlation MLP in one launch -- SURVEY N2:
+ * "corr-MLP first layer fused with corr output (avoid materialising [E,882])"; replaces cuda_corr.forward over both
+ * pyramid levels (ramp/altcorr/correlation.cpp:28-35, ramp/Ramp_vo.py:175-182) followed by Update.corr[0] + ReLU
+ * (ramp/net.py:60-61).  fp16 features, P = 3, radius 3, two levels (coord_div 1 and 4), C = 128;
+ * layout RAMP_NHWC or RAMP_NHWC32 (target maps; fmap1 [N1][3][3][128]).
+ *   w1_packed  Linear(882 -> 384).weight zero-padded to corr_k = 896 columns, as fp16 MFMA fragments
+ *              [corr_k / 32][24][64 lanes][8]: lane (q, j) of fragment (ks, nt) holds W[16 nt + j][32 ks + 8 q ..]
+ *   b1 [384] fp32;  c1 [E][384] fp16 = relu(W1 corr_row + b1) -- the input of ramp_upd_corr_tail, bit-identical to
+ *   what ramp_upd_corr_mlp forms from ramp_corr_fwd_ordered's rows.  The [E, 896] rows are never written.          */
+int ramp_corr_l1_fwd_ordered(const void *fmap1, const ramp_corr_level *levels_host, const float *coords,
+                             const int64_t *ii, const int64_t *jj, const int32_t *order, const void *w1_packed,
+                             const float *b1, int corr_k, void *c1, long mod_ii, long mod_jj, int E, int layout,
+                             void *stream);
+
 /* Ramp_vo.__call__'s pyramid store (ramp/Ramp_vo.py:378-381: fmap1_[slot] =
  * fmap, fmap2_[slot] = avg_pool2d(fmap, 4, 4)) for fp16 channels-last features:
  * fmap [H][W][C] -> level1 [H][C/32][W][32] (same values) and level4

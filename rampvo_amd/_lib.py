@@ -52,6 +52,8 @@ SIGNATURES = {
     "ramp_pyramid_pack": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "ramp_corr_fwd_ordered": (c_i, [c_p, ctypes.POINTER(CorrLevel), c_i, c_p, c_p, c_p, c_p, c_p, c_i, ctypes.c_long,
                                     ctypes.c_long] + [c_i] * 8 + [c_p]),
+    "ramp_corr_l1_fwd_ordered": (c_i, [c_p, ctypes.POINTER(CorrLevel), c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, ctypes.c_long,
+                                       ctypes.c_long, c_i, c_i, c_p]),
     "ramp_se3_exp": (c_i, [c_p, c_p, c_i, c_p]),
     "ramp_se3_log": (c_i, [c_p, c_p, c_i, c_p]),
     "ramp_se3_inv": (c_i, [c_p, c_p, c_i, c_p]),

@@ -51,6 +51,15 @@ int ramp_i_corr_fwd(const void *fmap1, const ramp_corr_level *levels, int nlevel
                     long mod_ii, long mod_jj, int E, int N1, int N2, int C, int P, int radius, int dtype, int layout,
                     const int32_t *dyn, void *stream, const float *tf_poses = nullptr, const float *tf_patches = nullptr,
                     const float *tf_intr = nullptr, const int64_t *tf_src = nullptr, const int32_t *slot0 = nullptr);
+int ramp_i_corr_l1_fwd(const void *fmap1, const ramp_corr_level *levels, const float *coords, const int64_t *ii,
+                       const int64_t *jj, const int32_t *order, const void *w1_packed, const float *b1, int corr_k,
+                       void *c1, long mod_ii, long mod_jj, int E, int layout, const int32_t *dyn, void *stream,
+                       const float *tf_poses = nullptr, const float *tf_patches = nullptr, const float *tf_intr = nullptr,
+                       const int64_t *tf_src = nullptr, const int32_t *slot0 = nullptr);
+int ramp_i_upd_corr_tail(const void *c1, const void *w2, const float *b2, const void *w3, const float *b3,
+                         const float *ln_w, const float *ln_b, float ln_eps, const float *net, const int64_t *net_map,
+                         const void *inp, const int64_t *inp_idx, long inp_mod, const float *norm_w, const float *norm_b,
+                         float norm_eps, float *net_out, int E, const int32_t *dyn, void *stream);
 int ramp_i_upd_gru(const float *x32, const void *add0_t, const int32_t *add0_idx, const void *add_t, const int32_t *add_idx,
                  const float *pre_w, const float *pre_b,
                    float pre_eps, const void *const *wp_host, const float *const *bias_host, const float *ln_w,

@@ -571,6 +571,19 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
     lv[0].fmap = t->fmap1; lv[0].H2 = t->feat_h; lv[0].W2 = t->feat_w; lv[0].coord_div = 1.0f;
     lv[1].fmap = t->fmap2; lv[1].H2 = t->feat_h / 4; lv[1].W2 = t->feat_w / 4; lv[1].coord_div = 4.0f;
     TRK_PROBE(0);
+    // RAMP_CORR_L1=1 (first clause): the correlation launch multiplies its rows by the correlation MLP's first
+    // Linear itself (csrc/altcorr.hip::corr_l1_kernel) and hands c1 [E][384] on -- in t->corr's storage, the [E][896]
+    // rows are never written -- to the tail-only correlation MLP.  Bit-identical; measured slower, off.
+    static const bool corr_l1 = getenv("RAMP_CORR_L1") && atoi(getenv("RAMP_CORR_L1")) != 0;
+    if (corr_l1) {
+      TRK_DO(ramp_i_corr_l1_fwd(t->gmap, lv, t->coords, kk, jj, t->ij_order, w.corr_w1, w.corr_b1, 896, t->corr,
+                                (long)t->M * t->mem, t->mem, Eb, RAMP_NHWC32, dyn, st, fuse_tf ? t->poses : nullptr,
+                                t->patches, t->intrinsics, ii, t->fmap1_slot));
+      TRK_PROBE(1);
+      TRK_DO(ramp_i_upd_corr_tail(t->corr, w.corr_w2, w.corr_b2, w.corr_w3, w.corr_b3, w.corr_ln_w, w.corr_ln_b,
+                                  w.corr_ln_eps, t->net[0], row, t->imap, kk, (long)t->M * t->mem, w.norm_w, w.norm_b,
+                                  w.norm_eps, t->net[1], Eb, dyn, st));
+    } else {
     TRK_DO(ramp_i_corr_fwd(t->gmap, lv, 2, t->coords, kk, jj, t->ij_order, t->corr, 896, (long)t->M * t->mem, t->mem, Eb,
                            t->mem * t->M, t->mem, 128, t->P, 3, RAMP_F16, RAMP_NHWC32, dyn, st,
                            fuse_tf ? t->poses : nullptr, t->patches, t->intrinsics, ii, t->fmap1_slot));
@@ -579,6 +592,7 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
     TRK_DO(ramp_i_upd_corr_mlp(t->corr, 896, w.corr_w1, w.corr_b1, w.corr_w2, w.corr_b2, w.corr_w3, w.corr_b3, w.corr_ln_w,
                                w.corr_ln_b, w.corr_ln_eps, t->net[0], row, t->imap, kk, (long)t->M * t->mem, w.norm_w,
                                w.norm_b, w.norm_eps, t->net[1], Eb, dyn, st));
+    }
     // where the next frame's front end may start (RAMP_GATE_AT: 2 = before the first SoftAgg, the default -- with the fused
     // SoftAgg launches next to it the front end costs the operator ~25 us and gives bundle adjustment 12 back, +1.2 % SingleScale,
     // +2.1 % MultiScale against 0; 0 = before the gru chain (rounds 2-3); 1 = before the second SoftAgg; 3 = before c1 / c2).

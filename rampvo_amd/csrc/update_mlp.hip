@@ -1960,10 +1960,10 @@ int ramp_i_upd_nbr(const float *net_in, const int64_t *idx, const void *wa, cons
   return RAMP_OK;
 }
 
-int ramp_upd_corr_tail(const void *c1, const void *w2, const float *b2, const void *w3, const float *b3,
-                       const float *ln_w, const float *ln_b, float ln_eps, const float *net, const int64_t *net_map,
-                       const void *inp, const int64_t *inp_idx, long inp_mod, const float *norm_w,
-                       const float *norm_b, float norm_eps, float *net_out, int E, void *stream) {
+int ramp_i_upd_corr_tail(const void *c1, const void *w2, const float *b2, const void *w3, const float *b3,
+                         const float *ln_w, const float *ln_b, float ln_eps, const float *net, const int64_t *net_map,
+                         const void *inp, const int64_t *inp_idx, long inp_mod, const float *norm_w,
+                         const float *norm_b, float norm_eps, float *net_out, int E, const int32_t *dyn, void *stream) {
   if (E < 0) return RAMP_EINVAL;
   if (E == 0) return RAMP_OK;
   if (!c1 || !w2 || !b2 || !w3 || !b3 || !ln_w || !ln_b || !inp || !norm_w || !norm_b || !net_out || net == net_out)
@@ -1972,7 +1972,7 @@ int ramp_upd_corr_tail(const void *c1, const void *w2, const float *b2, const vo
   p.c1 = (const _Float16 *)c1; p.w2 = (const _Float16 *)w2; p.w3 = (const _Float16 *)w3; p.b2 = b2; p.b3 = b3;
   p.ln_w = ln_w; p.ln_b = ln_b; p.ln_eps = ln_eps; p.net = net; p.net_map = net_map; p.inp = (const _Float16 *)inp;
   p.inp_idx = inp_idx; p.inp_mod = inp_mod; p.norm_w = norm_w; p.norm_b = norm_b; p.norm_eps = norm_eps;
-  p.net_out = net_out; p.E = E; p.dyn = nullptr;
+  p.net_out = net_out; p.E = E; p.dyn = dyn;
   const size_t lds = (size_t)MBM * MXS * 2;
   p.corr = nullptr; p.w1 = nullptr; p.b1 = nullptr; p.corr_k = 0;
   hipLaunchKernelGGL(upd_corr_tail_kernel<false>, dim3(ramp_cdiv(E, MBM)), dim3(64 * MWAVES), lds, (hipStream_t)stream, p);
@@ -2048,6 +2048,14 @@ int ramp_upd_gru_heads(const float *x32, const void *add_t, const int32_t *add_i
 int ramp_upd_nbr(const float *net_in, const int64_t *idx, const void *wa, const float *ba, const void *wb,
                  const float *bb, float *net_out, void *out_t, int E, void *stream) {
   return ramp_i_upd_nbr(net_in, idx, wa, ba, wb, bb, net_out, out_t, E, nullptr, stream);
+}
+
+int ramp_upd_corr_tail(const void *c1, const void *w2, const float *b2, const void *w3, const float *b3,
+                       const float *ln_w, const float *ln_b, float ln_eps, const float *net, const int64_t *net_map,
+                       const void *inp, const int64_t *inp_idx, long inp_mod, const float *norm_w,
+                       const float *norm_b, float norm_eps, float *net_out, int E, void *stream) {
+  return ramp_i_upd_corr_tail(c1, w2, b2, w3, b3, ln_w, ln_b, ln_eps, net, net_map, inp, inp_idx, inp_mod, norm_w, norm_b,
+                              norm_eps, net_out, E, nullptr, stream);
 }
 
 int ramp_upd_corr_mlp(const void *corr, int corr_k, const void *w1, const float *b1, const void *w2, const float *b2,

@@ -192,7 +192,12 @@ class FusedUpdate:
         self._bufs = (net32_buf, out32_buf)
         w = self.weights()
         E = corr.shape[0]
-        if "tail_pack" in w and self.use_mlp and corr.shape[1] == CORR_ROW and self.use_corr_mlp:
+        if corr.shape[1] == 384:
+            # c1 = relu(Linear1(corr)) already: the fused correlation + Linear1 launch (ramp_corr_l1_fwd_ordered)
+            if not ("tail_pack" in w and self.use_mlp):
+                raise RuntimeError("the fused correlation + Linear1 launch needs the fused correlation-MLP tail (RAMP_UPD_MLP=1)")
+            c = corr
+        elif "tail_pack" in w and self.use_mlp and corr.shape[1] == CORR_ROW and self.use_corr_mlp:
             # the whole correlation MLP (3 Linear, LayerNorm, ReLUs) + net + inp + c + LayerNorm: one launch
             w1, b1 = w["corr1_pack"]
             w2, b2, w3, b3 = w["tail_pack"]

@@ -233,6 +233,69 @@ def test_pyramid_pack_and_chunked_corr():
     assert a.float().abs().max() > 0
 
 
+@torch.no_grad()
+@pytest.mark.parametrize("E", [1, 61, 1000])
+def test_corr_l1_fused_launch_equals_corr_then_the_correlation_mlp(E):
+    """SURVEY N2, first clause (ramp_corr_l1_fwd_ordered): correlation + Update.corr[0] + ReLU in one launch.  (a) c1
+    against a plain fp32 PyTorch Linear + ReLU on the unfused kernel's rows (reference: ramp/net.py:60-61 on
+    Ramp_vo.corr's output, ramp/Ramp_vo.py:175-182); (b) through the tail of the correlation MLP the result is
+    bit-identical to the unfused pair's (same rows, same MFMA operand and K order) -- plain and packed target maps, a
+    target-frame-major schedule, wrapped ring-buffer indices, factors off the image, a ragged last group of 16"""
+    import torch.nn.functional as F
+    from rampvo_amd import ops
+    from rampvo_amd._lib import KPLANE, RAMP_NHWC, RAMP_NHWC32, check, lib, ptr, stream
+    from rampvo_amd.synthetic import make_network
+    g = torch.Generator().manual_seed(5 + E)
+    N2, H, W, C, M = 3, 24, 32, 128, 12
+    maps = (torch.randn(N2, H, W, C, generator=g) * 0.5).half().cuda()
+    l1 = torch.empty(N2, H, C // KPLANE, W, KPLANE, dtype=torch.half, device="cuda")
+    l4 = torch.empty(N2, H // 4, C // KPLANE, W // 4, KPLANE, dtype=torch.half, device="cuda")
+    for n in range(N2):
+        ops.pyramid_pack(maps[n], l1[n], l4[n])
+    unchunk = lambda t: t.permute(0, 1, 3, 2, 4).reshape(t.shape[0], t.shape[1], t.shape[3], C)
+    pooled = unchunk(l4).contiguous()
+    rng = np.random.default_rng(4 + E)
+    fmap1 = (torch.randn(M, 3, 3, C, generator=g) * 0.5).half().cuda()
+    coords = np.stack([rng.uniform(-6, W + 6, (E, 3, 3)), rng.uniform(-6, H + 6, (E, 3, 3))], 1).astype(np.float32)
+    k = E // 3
+    coords[:k] = coords[:k, :, :1, :1] + np.arange(3, dtype=np.float32)[None, None, None, :]   # compact windows
+    coords[k:k + max(E // 5, 0)] += 500.0                                                        # off both planes
+    ii = torch.from_numpy(rng.integers(0, 3 * M, E)).cuda()                                     # (taken modulo M / N2)
+    jj = torch.from_numpy(rng.integers(0, 3 * N2, E)).cuda()
+    order = torch.argsort(jj % N2, stable=True).int()
+    fu = make_network("SingleScale").update.fused(torch.float16)
+    w = fu.weights()
+    w1, b1 = w["corr1_pack"]
+    w2, b2, w3, b3 = w["tail_pack"]
+    ln, nm = w["corr_ln"], w["norm"]
+    net = (torch.randn(E, 384, generator=g) * 0.5).cuda()
+    table = (torch.randn(64, 384, generator=g) * 0.5).half().cuda()
+    idx = torch.from_numpy(rng.integers(0, 1000, E)).cuda()
+
+    def tail_from_rows(rows):
+        out = torch.empty(E, 384, device="cuda")
+        check(lib().ramp_upd_corr_mlp(ptr(rows), 896, ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3), ptr(ln[0]),
+                                      ptr(ln[1]), float(ln[2]), ptr(net), None, ptr(table), ptr(idx), 64, ptr(nm[0]),
+                                      ptr(nm[1]), float(nm[2]), ptr(out), E, stream()), "ramp_upd_corr_mlp")
+        return out
+
+    def tail_from_c1(c1):
+        out = torch.empty(E, 384, device="cuda")
+        check(lib().ramp_upd_corr_tail(ptr(c1), ptr(w2), ptr(b2), ptr(w3), ptr(b3), ptr(ln[0]), ptr(ln[1]), float(ln[2]),
+                                       ptr(net), None, ptr(table), ptr(idx), 64, ptr(nm[0]), ptr(nm[1]), float(nm[2]),
+                                       ptr(out), E, stream()), "ramp_upd_corr_tail")
+        return out
+
+    W1 = make_network("SingleScale").update.corr[0]
+    for layout, levels, sched in ((RAMP_NHWC, [maps, pooled], None), (RAMP_NHWC32, [l1, l4], order), (RAMP_NHWC32, [l1, l4], None)):
+        rows = ops.corr(fmap1, levels, cu(coords), ii, jj, 3, (1.0, 4.0), layout, order=sched, row_elems=896, mod_ii=M, mod_jj=N2)
+        c1 = ops.corr_l1(fmap1, levels, cu(coords), ii, jj, w1, b1, layout, order=sched, mod_ii=M, mod_jj=N2)
+        assert c1.shape == (E, 384) and torch.isfinite(c1).all()
+        exp = torch.relu(F.linear(rows[:, :882].float(), W1.weight.half().float().cuda(), W1.bias.half().float().cuda()))
+        assert float((c1.float() - exp).abs().max()) <= 2e-3 * max(1.0, float(exp.abs().max())), (layout, E)
+        assert torch.equal(tail_from_c1(c1), tail_from_rows(rows)), (layout, E)
+
+
 def test_corr_matches_reference_call_site_golden():
     """G3 (tests/golden/corr.npz): what the reference's altcorr.corr python call site returned for both pyramid
     levels, stacked as Ramp_vo.corr stacks them (ramp/Ramp_vo.py:175-182)"""

@@ -635,6 +635,45 @@ def test_evaluate_harness_run_and_run_pose_pred():
     assert list(ts2[-4:]) == [16, 17, 18, 19]
 
 
+def test_fused_correlation_linear1_launch_does_not_change_the_tracker():
+    """RAMP_CORR_L1=1 (first clause: the correlation launch applies the correlation MLP's first Linear itself and
+    the [E, 896] rows are never written -- csrc/altcorr.hip::corr_l1_kernel) in the host-driven AND the device-resident
+    step: a 44-frame fp16 run (host-driven first, device resident once the window is full) ends in the same poses, patches,
+    hidden state, graph and trajectory, bit for bit, as the default two-launch path.  The switch is read once per process: two subprocesses."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
+            "from rampvo_amd.config import make_cfg; from rampvo_amd.Ramp_vo import Ramp_vo\n"
+            "from rampvo_amd.synthetic import SyntheticStream, make_network\n"
+            "T = 44; stream = SyntheticStream(240, 320, T, seed=77, device='cuda'); torch.manual_seed(5)\n"
+            "slam = Ramp_vo(make_cfg('default', PATCHES_PER_FRAME=48, MIXED_PRECISION=True), make_network('SingleScale'),"
+            " {'event_bias': True}, ht=240, wd=320)\n"
+            "resident, E = 0, []\n"
+            "with torch.no_grad():\n"
+            "    for t in range(T):\n"
+            "        im, ev, K, mask = stream.frame(t); slam(t, input_tensor=(ev, im, mask), intrinsics=K)\n"
+            "        resident += int(slam._dev is not None and slam._dev.active); E.append(slam.peek()['E'])\n"
+            "    slam.update(); traj, ts = slam.terminate()\n"
+            "n = slam.n\n"
+            "np.savez(sys.argv[1], traj=traj, ts=ts, poses=slam.poses_[:n].cpu().numpy(), patches=slam.patches_[:n].cpu().numpy(),"
+            " net=slam.net.float().cpu().numpy(), ii=slam._ii, jj=slam._jj, kk=slam._kk, E=np.array(E), dev=np.array([resident]))\n") % (root,)
+    outs = []
+    with tempfile.TemporaryDirectory() as td:
+        for flag in ("0", "1"):
+            path = os.path.join(td, "run%s.npz" % flag)
+            r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, RAMP_CORR_L1=flag), capture_output=True,
+                               text=True, timeout=900, cwd=root)
+            assert r.returncode == 0, r.stderr[-3000:]
+            outs.append({k: v for k, v in np.load(path).items()})
+    a, b = outs
+    assert int(a["dev"][0]) > 20 and int(b["dev"][0]) > 20, "the run never reached the device-resident step"
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+
+
 def test_bench_runs_the_fp32_path():
     """bench.py --mixed 0: the fp32 tracker's steps are device resident too (two C calls around the operator's library GEMMs,
     which the host launches; nothing is read back) -- correlation / BA legs from the step's probes, the operator's from the
