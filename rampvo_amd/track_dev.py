@@ -362,8 +362,11 @@ class DeviceTrack:
         for _ in range(64):
             c = d.copy()
             if c[DYN_FRAME] == c[DYN_FRAME2]:
+                self._lazy_ok = c
                 return c
-        return c
+        # (64 torn reads in a row: the last CONSISTENT copy rather than a torn one -- its sizes are older, the launch bounds
+        # derived from them carry a per-frame margin and status bit 32 flags a bound that was too small)
+        return self._lazy_ok if getattr(self, "_lazy_ok", None) is not None else c
 
     def wait_frame(self, counter):
         """(fp32 steps) poll the pinned copy of the sizes until it is the one the plan of frame `counter` wrote, and return
@@ -400,10 +403,22 @@ class DeviceTrack:
         torch.cuda.current_stream().synchronize()
         if self.fmap1_slot is not None:
             # the host-driven path addresses ring row r as slot r: undo the table's permutation of the level-0 planes
-            perm = self.fmap1_slot.long()
-            if not bool((perm == torch.arange(perm.numel(), device=perm.device)).all()):
-                self.slam.fmap1_.copy_(self.slam.fmap1_[perm])
-                self.fmap1_slot.copy_(torch.arange(perm.numel(), dtype=torch.int32, device=perm.device))
+            # (cycle by cycle through ONE scratch plane: a gather of the whole ring would materialise a second copy of
+            # it -- mem x 4.9 MB at 640 x 480 -- on every hand-back behind a dropped keyframe)
+            perm = [int(v) for v in self.fmap1_slot.cpu().tolist()]          # row r lives in slot perm[r]
+            if perm != list(range(len(perm))):
+                buf, done = self.slam.fmap1_, [False] * len(perm)
+                for r0 in range(len(perm)):
+                    if done[r0] or perm[r0] == r0:
+                        done[r0] = True
+                        continue
+                    tmp, r = buf[r0].clone(), r0
+                    while perm[r] != r0:
+                        buf[r].copy_(buf[perm[r]])
+                        done[r], r = True, perm[r]
+                    buf[r].copy_(tmp)
+                    done[r] = True
+                self.fmap1_slot.copy_(torch.arange(len(perm), dtype=torch.int32, device=self.fmap1_slot.device))
         d = self.dyn.cpu().numpy()
         Ek, n = int(d[DYN_EKEPT]), int(d[DYN_NROW])
         g = self.graph[self.cur][:, :Ek].cpu().numpy()
