@@ -174,7 +174,7 @@ class CorrTimer:
         tools/r05_pmc_corr.sh): ``segment`` picks the launches of the timed region or of the all-live legs, and the
         source's own edges per launch ride along (the scaling is then a few per cent, not 23k -> 42k factors)."""
         if elem_bytes != 2:
-            return None, None
+            return None, None, None
         import glob
         files = sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc", "r*_corr_traffic.json")))
         for f in reversed(files):
@@ -734,7 +734,8 @@ def main():
     n_inst = 0 if args.no_kernel_timing else args.inst_steps
     n_alone = 20 if (n_inst and n_np) else 0
     n_live = args.live_steps if (n_inst and solo) else 0
-    total = args.prime + n_warm + args.warmup + args.steps + n_inst + n_np + n_alone + (2 * n_live + 4 if n_live else 0)
+    n_os = n_np                                   # the own-stream leg (inputs produced on the caller's stream: evaluate.run's loop)
+    total = args.prime + n_warm + args.warmup + args.steps + n_inst + n_os + n_np + n_alone + (2 * n_live + 4 if n_live else 0)
     n_cpu = args.cpu_steps + 1 if (solo and args.cpu_steps > 0) else 0
     stream = SyntheticStream(args.height, args.width, total + n_cpu + 1, seed=1234 + rank, device=dev)
     frames = [tuple(x.to(dev) if i < 2 else x for i, x in enumerate(stream.frame(t))) for t in range(total)]
@@ -827,7 +828,27 @@ def main():
     E1 = graph_size(slam)[0]
     live = live_factor_fractions(slam)
 
-    # the strictly sequential rate (no frame pipelining): what evaluate.run's loop gets
+    # inputs_ready = "stream": what a caller gets that produces every frame's tensors on ITS stream right before the call
+    # -- the reference's evaluate.py resizes each frame there; rampvo_amd.evaluate.run tracks in this mode -- : the tracker
+    # waits for the caller's stream by an event and runs on its own, so the frames still pipeline
+    os_kfps = None
+    if n_os > 0:
+        slam.inputs_ready = "stream"
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        t_os = time.perf_counter()
+        for _ in range(n_os - 2):
+            im, ev, K, mask = frames[pos["t"]]
+            ev2, im2 = ev.clone(), im.clone()      # (the caller's per-frame preprocessing, on the current stream)
+            slam(pos["t"], input_tensor=(ev2, im2, mask), intrinsics=K)
+            del ev2, im2                           # (and its tensors die right behind the call)
+            pos["t"] += 1
+        slam.peek()
+        torch.cuda.synchronize()
+        os_kfps = (n_os - 2) / (time.perf_counter() - t_os)
+        slam.inputs_ready = bool(args.pipeline)
+    # the strictly sequential rate (no frame pipelining): what a caller on ONE stream with inputs_ready False gets
     np_kfps = None
     if n_np > 0:
         slam.inputs_ready = False
@@ -906,6 +927,7 @@ def main():
                        "frame_pipelining": bool(args.pipeline),
                        "pipeline_gate": gate_kind if args.pipeline else None,
                        "non_pipelined_kfps": round(np_kfps, 1) if np_kfps else None,
+                       "own_stream_kfps": round(os_kfps, 1) if os_kfps else None,
                        "host_step_ms_p50_p90_max": [round(1e3 * float(v), 3) for v in
                                                     (np.percentile(np.diff(marks), 50), np.percentile(np.diff(marks), 90),
                                                      np.max(np.diff(marks)))],

@@ -145,6 +145,14 @@ class Ramp_vo:
         # still being produced on the current stream).  In the device-resident steady state the next frame's front
         # end is then launched on a side stream, gated by an event recorded before the last kernel of the previous
         # frame's update operator: it runs next to the gru chain and BA (a few small blocks on a 256-CU chip).
+        # inputs_ready = "stream" (round 5): the same pipelining for callers whose tensors ARE still being produced on the
+        # current stream when they call (the reference's evaluate.py resizes each frame right before slam(...)): the tracker
+        # records an event on the caller's stream, its front end waits for THAT, and everything else of the tracker runs on
+        # the tracker's own stream (_main_stream) -- so the caller's stream carries the caller's work only and the next
+        # frame's inputs are not queued behind this frame's bundle adjustment.  The caller's stream in turn waits until the
+        # front end has taken its copy of the inputs (they may be overwritten or freed right after the call, as on one
+        # stream).  Same contract for reading state as with True: through settle() / update() / terminate() / peek() /
+        # state_dict() / the n, m, ii ... properties, which join the tracker's stream first.  rampvo_amd.evaluate.run sets it.
         self.inputs_ready = False
         self.device_steps = os.environ.get("RAMP_DEVICE_STEP", "1") == "1"     # A/B and test switch
         self._edge_tmpl = None
@@ -211,6 +219,9 @@ class Ramp_vo:
 
     def _init_streams(self, dev):
         self._fe_stream = torch.cuda.Stream(device=dev)
+        self._main_stream = torch.cuda.Stream(device=dev)     # inputs_ready = "stream": the tracker's own main stream
+        self._main_used = False
+        self._ev_taken = torch.cuda.Event()
         # events are re-recorded every frame (creating one costs a hipEventCreate/Destroy pair per use)
         self._fe_done_sig, self._fe_done_seq = None, 0
         self._ev_fe_done, self._ev_gate, self._ev_in = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
@@ -295,6 +306,7 @@ class Ramp_vo:
         """bring the host mirror up to date: if the steady state is device resident, synchronise and take the
         keyframe count, the factor graph, the hidden-state row map and the delta chain back (the next tracked frame
         runs host-driven and hands the state over again)"""
+        self._join_main()
         dv = self._dev
         if dv is None or not dv.active:
             return
@@ -321,6 +333,7 @@ class Ramp_vo:
     def peek(self):
         """(keyframes, factors) right now -- synchronises, but leaves a device-resident state where it is (tests and
         benchmarks read these per frame; ``n`` / ``_ii`` would hand the state back to the host every time)"""
+        self._join_main()
         dv = self._dev
         if dv is not None and dv.active:
             torch.cuda.current_stream().synchronize()
@@ -642,6 +655,8 @@ class Ramp_vo:
     # ------------------------------------------------------------------- update
     def update(self):
         """reference :276-310 (host-driven form; the device-resident step makes the same launches from C)"""
+        if self._cur_stream is None:                 # (a public call, not the tracked frame's own update)
+            self._join_main()
         with Timer("other", enabled=self.enable_timing):
             plan = self._graph_plan()
             coords = self.reproject()
@@ -682,6 +697,9 @@ class Ramp_vo:
         """track a new frame"""
         input_ = preprocess_input(input_tensor=input_tensor)
         with torch.no_grad():
+            if self.inputs_ready == "stream" and self.device.type == "cuda":
+                return self._call_on_own_stream(tstamp, input_, intrinsics)
+            self._join_main()
             self._cur_stream = self._current_stream()
             try:
                 if self._dev is not None and self._dev.active:
@@ -689,6 +707,41 @@ class Ramp_vo:
                 return self._track(tstamp, input_, intrinsics)
             finally:
                 self._cur_stream = None
+
+    def _call_on_own_stream(self, tstamp, input_, intrinsics):
+        """inputs_ready = "stream": see __init__.  The caller's stream gets one event record and one event wait per frame."""
+        user, main, fe = torch.cuda.current_stream(self.device), self._main_stream, self._fe_stream
+        self._ev_in.record(user)                        # the inputs (and whatever else the caller enqueued) up to here
+        for t in input_[:2]:
+            if torch.is_tensor(t) and t.is_cuda:        # allocated on the caller's stream, read on the tracker's
+                t.record_stream(main)
+                t.record_stream(fe)
+        main.wait_event(self._ev_in)
+        self._in_event_pending, self._taken_recorded = True, False
+        self._cur_stream = main
+        try:
+            with torch.cuda.stream(main):
+                if self._dev is not None and self._dev.active:
+                    out = self._track_device(tstamp, input_, intrinsics)
+                else:
+                    out = self._track(tstamp, input_, intrinsics)
+        finally:
+            self._cur_stream = None
+            self._in_event_pending = False
+            self._main_used = True                      # (a settle() inside the call may have joined: there is new work now)
+        # the caller may overwrite / free its tensors once the front end has run on them (a frame whose front end ran on the
+        # tracker's main stream -- host-driven frames -- : once that frame is through)
+        if not self._taken_recorded:
+            self._ev_taken.record(main)
+        user.wait_event(self._ev_taken)
+        return out
+
+    def _join_main(self):
+        """(public entry points that run on the caller's stream) everything the tracker enqueued on its own stream first"""
+        if self._main_used:
+            self._main_stream.synchronize()
+            self._fe_stream.synchronize()
+            self._main_used = False
 
     def _current_stream(self):
         return torch.cuda.current_stream()
@@ -786,12 +839,17 @@ class Ramp_vo:
             # another 35 us (_fe_delay).  RAMP_SELECT_AHEAD=0|1 forces either.
             env = os.environ.get("RAMP_SELECT_AHEAD")
             ahead = (env == "1") if env is not None else _gru_tile_rows(dv.factor_estimate(), self.device) == 80
+            if getattr(self, "_in_event_pending", False):
+                fe.wait_event(self._ev_in)              # inputs_ready = "stream": the caller's stream up to the call
             if not ahead:
                 self._gate_wait(fe)
             with torch.cuda.stream(fe):
                 out = self.network.patchify(input_=input_, patches_per_image=self.cfg.PATCHES_PER_FRAME,
                                             event_bias=self.event_bias, reinit_hidden=False,
                                             pre_replay=(lambda: self._gate_wait(fe)) if ahead else self._fe_delay)
+            if getattr(self, "_in_event_pending", False):
+                self._ev_taken.record(fe)
+                self._taken_recorded = True
             if _FE_WAIT_PROBE:                      # (diagnostic: how long the main queue waits for the front end)
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record(cur)

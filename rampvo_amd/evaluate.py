@@ -40,10 +40,15 @@ class Trajectory:
 
 
 @torch.no_grad()
-def run(cfg_VO, network, eval_cfg, data_list, ht=480, wd=640, device="cuda"):
-    """reference evaluate.py:232-260 (without the dataset-specific resize): returns poses, tstamps, points, colors"""
+def run(cfg_VO, network, eval_cfg, data_list, ht=480, wd=640, device="cuda", inputs_ready="stream"):
+    """reference evaluate.py:232-260 (without the dataset-specific resize): returns poses, tstamps, points, colors.
+    The loop hands the tracker tensors that were produced on the current stream right before the call, as the
+    reference's loop does; ``inputs_ready = "stream"`` lets the frames pipeline anyway (Ramp_vo.__init__: the tracker
+    orders its front end behind the caller's stream with an event and runs on its own stream; results are identical).
+    ``inputs_ready=False``: everything on the caller's stream, frame after frame."""
     train_cfg = eval_cfg["data_loader"]["train"]["args"]
     slam = Ramp_vo(cfg=cfg_VO, network=network, train_cfg=train_cfg, ht=ht, wd=wd, device=device)
+    slam.inputs_ready = inputs_ready
     for t, (image, events, intrinsics, mask) in enumerate(data_list):
         slam(t, input_tensor=(events, image, mask), intrinsics=intrinsics)
     for _ in range(12):

@@ -448,7 +448,8 @@ def test_device_resident_steps_and_frame_pipelining_do_not_change_results():
     """The device-resident steady state (keyframe decision, graph edit, new factors and graph plan as kernels, sizes read
     from device memory: csrc/track.hip) against the host-driven path that reads the motion test back and edits the graph
     on the host like the reference -- and Ramp_vo.inputs_ready (the next front end on its own stream next to the gru chain
-    and BA), which is scheduling only: same graph, same poses, same depths, same trajectory -- bit for bit."""
+    and BA), which is scheduling only: same graph, same poses, same depths, same trajectory -- bit for bit.  Round 5:
+    inputs_ready = "stream" (inputs produced on the caller's stream, the tracker on its own) in both step modes too."""
     from rampvo_amd.config import make_cfg
     from rampvo_amd.Ramp_vo import Ramp_vo
     from rampvo_amd.synthetic import SyntheticStream, make_network
@@ -457,7 +458,7 @@ def test_device_resident_steps_and_frame_pipelining_do_not_change_results():
     frames = [stream.frame(t) for t in range(T)]
     torch.cuda.synchronize()
     out = []
-    for device_steps, ready in ((False, False), (True, False), (True, True)):
+    for device_steps, ready in ((False, False), (True, False), (True, True), (True, "stream"), (False, "stream")):
         torch.manual_seed(5)
         slam = Ramp_vo(make_cfg("default", PATCHES_PER_FRAME=48, MIXED_PRECISION=True),
                        make_network("SingleScale"), {"event_bias": True}, ht=240, wd=320)
@@ -465,7 +466,16 @@ def test_device_resident_steps_and_frame_pipelining_do_not_change_results():
         slam.inputs_ready = ready
         resident = 0
         for t, (im, ev, K, mask) in enumerate(frames):
-            slam(t, input_tensor=(ev, im, mask), intrinsics=K)
+            if ready == "stream":
+                # inputs_ready = "stream": the frame's tensors are produced on the caller's stream right before the call
+                # (the reference's evaluate.py loop) and overwritten right behind it -- the tracker orders itself behind
+                # the first and the caller's stream behind the front end's copy, on its own streams in between
+                ev2, im2 = ev * 1.0, im * 1.0
+                slam(t, input_tensor=(ev2, im2, mask), intrinsics=K)
+                ev2.fill_(float("nan")); im2.fill_(float("nan"))
+                del ev2, im2
+            else:
+                slam(t, input_tensor=(ev, im, mask), intrinsics=K)
             resident += slam._dev is not None and slam._dev.active
         assert (resident > 20) == device_steps, resident
         slam.update()                                   # hands the state back to the host first
