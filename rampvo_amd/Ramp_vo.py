@@ -738,7 +738,7 @@ class Ramp_vo:
 
     def _join_main(self):
         """(public entry points that run on the caller's stream) everything the tracker enqueued on its own stream first"""
-        if self._main_used:
+        if getattr(self, "_main_used", False):
             self._main_stream.synchronize()
             self._fe_stream.synchronize()
             self._main_used = False
