@@ -153,7 +153,9 @@ class Ramp_vo:
         # front end has taken its copy of the inputs (they may be overwritten or freed right after the call, as on one
         # stream).  Same contract for reading state as with True: through settle() / update() / terminate() / peek() /
         # state_dict() / the n, m, ii ... properties, which join the tracker's stream first.  rampvo_amd.evaluate.run sets it.
-        self.inputs_ready = False
+        # RAMP_INPUTS_READY=stream|1 sets the default without touching the caller's code (the reference's evaluate.py with
+        # its imports redirected: it reads points_ / colors_ / m only behind its closing update() calls, which join).
+        self.inputs_ready = {"stream": "stream", "1": True}.get(os.environ.get("RAMP_INPUTS_READY", ""), False)
         self.device_steps = os.environ.get("RAMP_DEVICE_STEP", "1") == "1"     # A/B and test switch
         self._edge_tmpl = None
         self._shift_plan = None
