@@ -222,7 +222,7 @@ class Ramp_vo:
     def _init_streams(self, dev):
         self._fe_stream = torch.cuda.Stream(device=dev)
         self._main_stream = torch.cuda.Stream(device=dev)     # inputs_ready = "stream": the tracker's own main stream
-        self._main_used = False
+        self._main_used, self._user_dirty = False, True
         self._ev_taken = torch.cuda.Event()
         # events are re-recorded every frame (creating one costs a hipEventCreate/Destroy pair per use)
         self._fe_done_sig, self._fe_done_seq = None, 0
@@ -718,7 +718,14 @@ class Ramp_vo:
             if torch.is_tensor(t) and t.is_cuda:        # allocated on the caller's stream, read on the tracker's
                 t.record_stream(main)
                 t.record_stream(fe)
-        main.wait_event(self._ev_in)
+        # the main stream itself waits for the caller's stream only when it has to: after a public call ran tracker work
+        # there (update(), settle() ...: _join_main marks it), or when this frame's front end runs on the main stream (no
+        # gate armed: host-driven frames, the first device-resident one) -- in the steady state the front-end stream's wait
+        # is the only one, and the main stream keeps no event packet between two frames
+        gated = self._dev is not None and self._dev.active and self._gate_armed
+        if self._user_dirty or not gated:
+            main.wait_event(self._ev_in)
+            self._user_dirty = False
         self._in_event_pending, self._taken_recorded = True, False
         self._cur_stream = main
         try:
@@ -740,6 +747,7 @@ class Ramp_vo:
 
     def _join_main(self):
         """(public entry points that run on the caller's stream) everything the tracker enqueued on its own stream first"""
+        self._user_dirty = True                       # (whatever follows runs tracker work on the caller's stream)
         if getattr(self, "_main_used", False):
             self._main_stream.synchronize()
             self._fe_stream.synchronize()
@@ -964,6 +972,8 @@ class Ramp_vo:
 
     # ----------------------------------------------------------- host-driven frame
     def _track(self, tstamp, input_, intrinsics):
+        if getattr(self, "_in_event_pending", False):
+            self._cur().wait_event(self._ev_in)     # inputs_ready = "stream": this frame's front end runs on the main stream
         out = self.network.patchify(
             input_=input_, patches_per_image=self.cfg.PATCHES_PER_FRAME, event_bias=self.event_bias,
             reinit_hidden=True if tstamp == 0 else False)

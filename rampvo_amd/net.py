@@ -212,19 +212,28 @@ class Patchifier(nn.Module):
             in_graph = os.environ.get("RAMP_SELECT_IN_GRAPH", "0") == "1"      # A/B switch: the round-2 placement
             coords_s = None if in_graph else self._select(ev_s, mask, patches_per_image, None)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                join = None
-                if fork:
-                    cap = torch.cuda.current_stream()
-                    if self._fork_stream is None or self._fork_stream.device != events.device:
-                        self._fork_stream = torch.cuda.Stream(device=events.device)
-                    side = self._fork_stream
-                    side.wait_stream(cap)                      # fork: the selection becomes a branch of the graph
-                    with torch.cuda.stream(side):
-                        self._select(ev_s, mask, patches_per_image, coords_s)
-                    join = lambda: torch.cuda.current_stream().wait_stream(side)
-                outs = self._forward_impl((ev_s, im_s, mask), patches_per_image, False, None, event_bias,
-                                          gradient_bias, coords_in=coords_s, before_gather=join)
+            # (no cyclic collection while the capture runs: freeing another tracker's hipGraph -- an object the collector
+            # may find at any allocation -- inside a capture aborts the process)
+            import gc
+            gc_was_on = gc.isenabled()
+            gc.disable()
+            try:
+                with torch.cuda.graph(graph):
+                    join = None
+                    if fork:
+                        cap = torch.cuda.current_stream()
+                        if self._fork_stream is None or self._fork_stream.device != events.device:
+                            self._fork_stream = torch.cuda.Stream(device=events.device)
+                        side = self._fork_stream
+                        side.wait_stream(cap)                      # fork: the selection becomes a branch of the graph
+                        with torch.cuda.stream(side):
+                            self._select(ev_s, mask, patches_per_image, coords_s)
+                        join = lambda: torch.cuda.current_stream().wait_stream(side)
+                    outs = self._forward_impl((ev_s, im_s, mask), patches_per_image, False, None, event_bias,
+                                              gradient_bias, coords_in=coords_s, before_gather=join)
+            finally:
+                if gc_was_on:
+                    gc.enable()
             sig = (sig[0], sig[1], id(getattr(self.encoder, "_hip_state", None)))
             self._graphs[key] = g = (graph, ev_s, im_s, outs, self._extra, sig, coords_s)
             self._run_graph(graph)       # capture does not execute: run this frame now (inputs already staged)
