@@ -123,15 +123,27 @@ __global__ void __launch_bounds__(256)
 // with all loads in flight at once (walking them from memory is one dependent round trip per edge);
 // the sums run over the staged records in segment order.
 #define BA_PCHUNK 32
+#ifndef BA_PBATCH
+#define BA_PBATCH 48    // (128 / 224 measured on MI355X: 126 / 139 us per BA call against 124 -- the pair role is not the long one)
+#endif
 __device__ __forceinline__ void
     ba_patch_body(int g, const float *__restrict__ rec, const int32_t *__restrict__ order,
                   const int32_t *__restrict__ seg, const int32_t *__restrict__ ngroups,
                   const float *__restrict__ lmbda, float *__restrict__ Erow,
                   float *__restrict__ Cv, float *__restrict__ uv, float *__restrict__ Qv,
-                  int n6, const BaEdgeIn &ein, const bool fused) {
-  __shared__ float s_rec[BA_PCHUNK][BA_REC + 1];
+                  int n6, const BaEdgeIn &ein, const bool fused, float *__restrict__ s_buf) {
+  float (*s_rec)[BA_REC + 1] = reinterpret_cast<float (*)[BA_REC + 1]>(s_buf);      // [BA_PCHUNK][BA_REC + 1]
   if (g >= *ngroups) return;
-  const int tid = threadIdx.x, nthr = blockDim.x;
+  // The merged launch's workgroups are sized for the pair role (156 sums); a patch needs n6 + 2 threads.  Waves without a
+  // column leave at once (the barrier counts live waves only): a CU holds 32 waves, and 2,100 patch workgroups of four
+  // live waves each were a second round of workgroups behind 2,048 places -- with one live wave they are all resident.
+#ifndef BA_PATCH_KEEP_WAVES
+  const int nthr = min((int)blockDim.x, ((n6 + 2 + 63) / 64) * 64);
+  if ((int)threadIdx.x >= nthr) return;
+#else
+  const int nthr = blockDim.x;
+#endif
+  const int tid = threadIdx.x;
   const int s0 = seg[g], s1 = seg[g + 1];
   const int a = tid / 6, c = tid - a * 6;
   float acc = 0.0f;
@@ -191,7 +203,8 @@ __global__ void __launch_bounds__(256)
                     const float *__restrict__ lmbda, float *__restrict__ Erow,
                     float *__restrict__ Cv, float *__restrict__ uv, float *__restrict__ Qv,
                     int n6) {
-  ba_patch_body(blockIdx.x, rec, order, seg, ngroups, lmbda, Erow, Cv, uv, Qv, n6, BaEdgeIn(), false);
+  __shared__ __attribute__((aligned(16))) float s_buf[BA_PCHUNK * (BA_REC + 1)];
+  ba_patch_body(blockIdx.x, rec, order, seg, ngroups, lmbda, Erow, Cv, uv, Qv, n6, BaEdgeIn(), false, s_buf);
 }
 
 // ------------------------------------------------------------------ K3
@@ -200,8 +213,9 @@ __global__ void __launch_bounds__(256)
 __device__ __forceinline__ void
     ba_pair_body(int g, const float *__restrict__ rec, const int32_t *__restrict__ order,
                  const int32_t *__restrict__ seg, const int32_t *__restrict__ ngroups,
-                 float *__restrict__ pairs, int32_t *__restrict__ pair_ij, const BaEdgeIn &ein, const bool fused) {
-  __shared__ __attribute__((aligned(16))) float s_rec[48 * BA_REC];   // 48 records per batch
+                 float *__restrict__ pairs, int32_t *__restrict__ pair_ij, const BaEdgeIn &ein, const bool fused,
+                 float *__restrict__ s_rec) {
+  // BA_PBATCH records per batch (any batch size sums the records in the same order: identical values)
   if (g >= *ngroups) return;
   const int tid = threadIdx.x;
   const int s0 = seg[g], s1 = seg[g + 1];
@@ -222,8 +236,8 @@ __device__ __forceinline__ void
     sgn = isj ? 1.0f : -1.0f;
   }
   float acc = 0.0f;
-  for (int b0 = s0; b0 < s1; b0 += 48) {
-    const int nb = min(48, s1 - b0);
+  for (int b0 = s0; b0 < s1; b0 += BA_PBATCH) {
+    const int nb = min(BA_PBATCH, s1 - b0);
     __syncthreads();
     if (fused) {                                // one thread per edge of the batch recomputes its record
       if (tid < nb) {
@@ -266,7 +280,8 @@ __global__ void __launch_bounds__(192)
     ba_pair_kernel(const float *__restrict__ rec, const int32_t *__restrict__ order,
                    const int32_t *__restrict__ seg, const int32_t *__restrict__ ngroups,
                    float *__restrict__ pairs, int32_t *__restrict__ pair_ij) {
-  ba_pair_body(blockIdx.x, rec, order, seg, ngroups, pairs, pair_ij, BaEdgeIn(), false);
+  __shared__ __attribute__((aligned(16))) float s_buf[BA_PBATCH * BA_REC];
+  ba_pair_body(blockIdx.x, rec, order, seg, ngroups, pairs, pair_ij, BaEdgeIn(), false, s_buf);
 }
 
 // K2 and K3 read the same per-edge records and do not depend on each other: one launch, the first n_patch
@@ -280,10 +295,12 @@ __global__ void __launch_bounds__(256)
                          const int32_t *__restrict__ np, float *__restrict__ pairs, int32_t *__restrict__ pair_ij,
                          BaEdgeIn ein, int fused, const int32_t *__restrict__ dyn, int opt_window) {
   ba_dyn_window(dyn, opt_window, ein.t0, ein.N);
+  __shared__ __attribute__((aligned(16))) float s_buf[BA_PBATCH * BA_REC];     // one array for both roles (16 KB)
+  static_assert(BA_PBATCH * BA_REC >= BA_PCHUNK * (BA_REC + 1) && BA_PBATCH <= 256, "role buffers / one thread per record");
   if ((int)blockIdx.x < n_patch)
-    ba_patch_body(blockIdx.x, rec, order_k, seg_k, nk, lmbda, Erow, Cv, uv, Qv, n6, ein, fused != 0);
+    ba_patch_body(blockIdx.x, rec, order_k, seg_k, nk, lmbda, Erow, Cv, uv, Qv, n6, ein, fused != 0, s_buf);
   else
-    ba_pair_body(blockIdx.x - n_patch, rec, order_p, seg_p, np, pairs, pair_ij, ein, fused != 0);
+    ba_pair_body(blockIdx.x - n_patch, rec, order_p, seg_p, np, pairs, pair_ij, ein, fused != 0, s_buf);
 }
 
 // ------------------------------------------------------------------ K4
