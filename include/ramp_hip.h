@@ -678,6 +678,12 @@ typedef struct ramp_track_weights {      /* update operator, fp16 fused formats 
   float corr_ln_eps, norm_eps, ln1_eps, ln2_eps;
 } ramp_track_weights;
 
+typedef struct ramp_plan_set {      /* the graph plan's arrays (a candidate set of ramp_track's speculative keyframe edit) */
+  int32_t *kk_order, *kk_gid, *kk_seg, *kk_ngroups, *ij_order, *ij_gid, *ij_seg, *ij_ngroups;
+  int64_t *kk_ukeys, *ij_ukeys, *ix, *jx;
+  int32_t *kj;
+} ramp_plan_set;
+
 typedef struct ramp_track {
   /* configuration (cfg: PATCHES_PER_FRAME, PATCH_LIFETIME, REMOVAL_WINDOW, OPTIMIZATION_WINDOW, KEYFRAME_INDEX,
    * KEYFRAME_THRESH, MOTION_MODEL (1 DAMPED_LINEAR, 2 copy), MOTION_DAMPING) */
@@ -747,6 +753,23 @@ typedef struct ramp_track {
                                        * (ramp/Ramp_vo.py:259-271 shifts them); every reader of `fmap1` rows (correlation, frame
                                        * commit, warm-up) goes through the table; the caller undoes the permutation when it takes
                                        * the buffers back.  NULL: rows are slots                                           */
+  /* Speculative keyframe edit (round 5; optional, spec_stream NULL = the serial tail).  Ramp_vo.keyframe()'s graph edit and
+   * the next graph's plan (ramp/Ramp_vo.py:247-274, 312-325) depend on the motion test's DECISION only: ramp_track_step
+   * computes both outcomes (keyframe n - KEYFRAME_INDEX kept / dropped) on `spec_stream`, beside correlation and the update operator, into
+   * the candidate buffers below, and the tail behind the motion test is ONE launch that takes the decision and copies the
+   * chosen candidate into graph[1 - cur], the plan arrays and dyn (csrc/track.hip::trk_select_kernel) instead of seven
+   * dependent ones.  Same kernels on the same inputs: bit-identical state.                                              */
+  void *spec_stream;                  /* hipStream_t of the speculative launches                                          */
+  uint32_t *spec_go, *spec_done;      /* signal words (ramp_signal_alloc): "the live graph / sizes are final" (stored by this
+                                       * step's first launch on the caller's stream, the commit) and "both candidates are
+                                       * ready"; NULL: the two events below order the streams (profilers that serialise kernels) */
+  void *spec_ev_go, *spec_ev_done;    /* hipEvent_t handles, used when the signal words are NULL                              */
+  uint32_t spec_seq, spec_pad;        /* this step's sequence number: any value that grows from step to step                  */
+  int64_t *spec_graph[2];             /* [4][E_cap] each: [0] keep, [1] remove                                              */
+  int32_t *spec_dyn;                  /* [2][RAMP_DYN_WORDS]                                                                */
+  ramp_plan_set spec_plan[2];
+  void *spec_plan_ws;                 /* as plan_ws (ZERO before the first use)                                            */
+  int32_t *spec_edit_ws;              /* as edit_ws                                                                        */
 } ramp_track;
 
 /* cache warm-up for the next step's correlation kernel: reads the planes of the window's frames and the patch features

@@ -350,6 +350,12 @@ struct PlanDyn {
   int Gcap[2];           // capacity of seg / ukeys (groups): more groups than that are flagged (status bit 8), never written
   int32_t *status;
 };
+// up to two plans in one set of launches (blockIdx.z): the candidates of the tracker's speculative keyframe edit
+struct PlanPair {
+  PlanDyn s[2];
+  int64_t *ix[2], *jx[2];
+  int32_t *kj[2];
+};
 __device__ __forceinline__ long plan_key(const PlanDyn &p, int g, int e, int &K, long &sub) {
   if (g == 0) {
     sub = p.dyn[RAMP_DYN_KLO];
@@ -376,8 +382,10 @@ __device__ __forceinline__ void plan_K(const PlanDyn &p, int g, int &K, long &su
 // over four times the factors of a one-per-thread launch
 #define PLAN_EPB 1024
 template <bool LDS>
-__global__ void __launch_bounds__(256) plan_hist_kernel(const PlanDyn p, int32_t *__restrict__ status) {
+__global__ void __launch_bounds__(256) plan_hist_kernel(const PlanPair pp) {
   __shared__ int s_bin[LDS ? PLAN_LDS_K : 1];
+  const PlanDyn &p = pp.s[blockIdx.z];
+  int32_t *status = p.status;
   const int g = blockIdx.y, E = p.dyn[RAMP_DYN_E];
   if ((int)blockIdx.x * PLAN_EPB >= E) return;
   int K; long sub;
@@ -411,8 +419,9 @@ __global__ void __launch_bounds__(256) plan_hist_kernel(const PlanDyn p, int32_t
     if (c) atomicAdd(&hist[q], c);
   }
 }
-__global__ void __launch_bounds__(1024) plan_scan_kernel(const PlanDyn p) {
+__global__ void __launch_bounds__(1024) plan_scan_kernel(const PlanPair pp) {
   __shared__ int s_cnt[1024], s_grp[1024];
+  const PlanDyn &p = pp.s[blockIdx.z];
   const int g = blockIdx.x, tid = threadIdx.x, E = p.dyn[RAMP_DYN_E];
   int K; long sub;
   plan_K(p, g, K, sub);
@@ -453,8 +462,9 @@ __global__ void __launch_bounds__(1024) plan_scan_kernel(const PlanDyn p) {
   if (tid == 1023) { const int ng = min(s_grp[1023], p.Gcap[g]); *p.ngroups[g] = ng; seg_start[ng] = E; }
 }
 template <bool LDS>
-__global__ void __launch_bounds__(256) plan_scatter_kernel(const PlanDyn p) {
+__global__ void __launch_bounds__(256) plan_scatter_kernel(const PlanPair pp) {
   __shared__ int s_bin[LDS ? PLAN_LDS_K : 1];
+  const PlanDyn &p = pp.s[blockIdx.z];
   const int g = blockIdx.y, E = p.dyn[RAMP_DYN_E];
   if ((int)blockIdx.x * PLAN_EPB >= E) return;
   int K; long sub;
@@ -506,10 +516,12 @@ __global__ void __launch_bounds__(256) plan_scatter_kernel(const PlanDyn p) {
 // what nb_from_groups_kernel computed in a launch of its own.  The first workgroups also clear the histograms for the
 // next plan (nobody reads them after the scatter): no memset launch.
 #define PLAN_SEG_LDS 4096
-__global__ void __launch_bounds__(256) plan_segsort_kernel(const PlanDyn p, int64_t *__restrict__ ix, int64_t *__restrict__ jx,
-                                                           int32_t *__restrict__ kj, int hist_words, int32_t *__restrict__ mirror) {
+__global__ void __launch_bounds__(256) plan_segsort_kernel(const PlanPair pp, int hist_words, int32_t *__restrict__ mirror) {
   __shared__ int s_v[PLAN_SEG_LDS];
   __shared__ int s_kj[1024];
+  const PlanDyn &p = pp.s[blockIdx.z];
+  int64_t *__restrict__ ix = pp.ix[blockIdx.z], *__restrict__ jx = pp.jx[blockIdx.z];
+  int32_t *__restrict__ kj = pp.kj[blockIdx.z];
   const int g = blockIdx.y, grp = blockIdx.x;
   if (g == 0) {
     const int z = grp * 256 + threadIdx.x;
@@ -575,14 +587,13 @@ size_t ramp_i_plan_dyn_ws(int E_cap, int kkey_cap, int pkey_cap) {
 }
 
 // the graph plan (two groupings + temporal neighbours) of the factor list g4 = [4][E_cap] int64 (ii, jj, kk, row)
-int ramp_i_plan_dyn(const int64_t *g4, int E_cap, int E_grid, const int32_t *dyn, int32_t *status, int M, int kkey_cap,
-                    int pkey_cap, int kk_cap, int ij_cap, int32_t *kk_order, int32_t *kk_gid, int32_t *kk_seg,
-                    int32_t *kk_ngroups, int64_t *kk_ukeys, int32_t *ij_order, int32_t *ij_gid, int32_t *ij_seg,
-                    int32_t *ij_ngroups, int64_t *ij_ukeys, int64_t *ix, int64_t *jx, int32_t *kj, void *ws,
-                    size_t ws_bytes, int32_t *mirror, hipStream_t st) {
+static int plan_fill(PlanPair &pp, int z, const int64_t *g4, int E_cap, int E_grid, const int32_t *dyn, int32_t *status, int M,
+                     int kkey_cap, int pkey_cap, int kk_cap, int ij_cap, int32_t *kk_order, int32_t *kk_gid, int32_t *kk_seg,
+                     int32_t *kk_ngroups, int64_t *kk_ukeys, int32_t *ij_order, int32_t *ij_gid, int32_t *ij_seg,
+                     int32_t *ij_ngroups, int64_t *ij_ukeys, int64_t *ix, int64_t *jx, int32_t *kj, void *ws, size_t ws_bytes) {
   if (!g4 || !dyn || !status || !ws || E_cap <= 0 || kkey_cap <= 0 || pkey_cap <= 0) return RAMP_EINVAL;
   if (ws_bytes < ramp_i_plan_dyn_ws(E_cap, kkey_cap, pkey_cap)) return RAMP_EWORKSPACE;
-  PlanDyn p;
+  PlanDyn &p = pp.s[z];
   p.ii = g4; p.jj = g4 + E_cap; p.kk = g4 + 2 * (size_t)E_cap; p.dyn = dyn; p.M = M;
   char *base = (char *)ws;
   const size_t hb = align_up((size_t)(kkey_cap + pkey_cap + 4) * 4, 256);
@@ -594,20 +605,56 @@ int ramp_i_plan_dyn(const int64_t *g4, int E_cap, int E_grid, const int32_t *dyn
   p.Kcap[0] = kkey_cap; p.Kcap[1] = pkey_cap;
   p.Gcap[0] = kk_cap; p.Gcap[1] = ij_cap; p.status = status;
   p.E_fill = E_grid > 0 && E_grid < E_cap ? E_grid : E_cap;
-  // (the histograms are zero on entry: the caller's workspace starts zeroed and every plan clears them at its end)
+  pp.ix[z] = ix; pp.jx[z] = jx; pp.kj[z] = kj;
+  return RAMP_OK;
+}
+// (the histograms are zero on entry: the caller's workspace starts zeroed and every plan clears them at its end)
+static int plan_launch(const PlanPair &pp, int nz, int E_cap, int E_grid, int kkey_cap, int pkey_cap, int kk_cap, int ij_cap,
+                       int32_t *mirror, hipStream_t st) {
   const int nb = ramp_cdiv(E_grid > 0 && E_grid < E_cap ? E_grid : E_cap, PLAN_EPB);
-  const bool lds = kkey_cap <= PLAN_LDS_K && pkey_cap <= PLAN_LDS_K;
-  if (lds) hipLaunchKernelGGL(plan_hist_kernel<true>, dim3(nb, 2), dim3(256), 0, st, p, status);
-  else hipLaunchKernelGGL(plan_hist_kernel<false>, dim3(nb, 2), dim3(256), 0, st, p, status);
-  hipLaunchKernelGGL(plan_scan_kernel, dim3(2), dim3(1024), 0, st, p);
-  if (lds) hipLaunchKernelGGL(plan_scatter_kernel<true>, dim3(nb, 2), dim3(256), 0, st, p);
-  else hipLaunchKernelGGL(plan_scatter_kernel<false>, dim3(nb, 2), dim3(256), 0, st, p);
+  // (RAMP_SPEC_PLAN_LDS=0: the pair's histogram and scatter straight to memory -- measured slower, the correlation launch
+  // beside it 125 -> 140 us)
+  static int pair_lds = -1;
+  if (pair_lds < 0) { const char *e = getenv("RAMP_SPEC_PLAN_LDS"); pair_lds = e ? atoi(e) : 1; }
+  const bool lds = kkey_cap <= PLAN_LDS_K && pkey_cap <= PLAN_LDS_K && (nz == 1 || pair_lds);
+  if (lds) hipLaunchKernelGGL(plan_hist_kernel<true>, dim3(nb, 2, nz), dim3(256), 0, st, pp);
+  else hipLaunchKernelGGL(plan_hist_kernel<false>, dim3(nb, 2, nz), dim3(256), 0, st, pp);
+  hipLaunchKernelGGL(plan_scan_kernel, dim3(2, 1, nz), dim3(1024), 0, st, pp);
+  if (lds) hipLaunchKernelGGL(plan_scatter_kernel<true>, dim3(nb, 2, nz), dim3(256), 0, st, pp);
+  else hipLaunchKernelGGL(plan_scatter_kernel<false>, dim3(nb, 2, nz), dim3(256), 0, st, pp);
   const int hist_words = kkey_cap + pkey_cap + 4;
   int gx = kk_cap > ij_cap ? kk_cap : ij_cap;
   if (gx < ramp_cdiv(hist_words, 256)) gx = ramp_cdiv(hist_words, 256);
-  hipLaunchKernelGGL(plan_segsort_kernel, dim3(gx, 2), dim3(256), 0, st, p, ix, jx, kj, hist_words, mirror);
+  hipLaunchKernelGGL(plan_segsort_kernel, dim3(gx, 2, nz), dim3(256), 0, st, pp, hist_words, mirror);
   RAMP_CHECK_LAUNCH();
   return RAMP_OK;
+}
+int ramp_i_plan_dyn(const int64_t *g4, int E_cap, int E_grid, const int32_t *dyn, int32_t *status, int M, int kkey_cap,
+                    int pkey_cap, int kk_cap, int ij_cap, int32_t *kk_order, int32_t *kk_gid, int32_t *kk_seg,
+                    int32_t *kk_ngroups, int64_t *kk_ukeys, int32_t *ij_order, int32_t *ij_gid, int32_t *ij_seg,
+                    int32_t *ij_ngroups, int64_t *ij_ukeys, int64_t *ix, int64_t *jx, int32_t *kj, void *ws,
+                    size_t ws_bytes, int32_t *mirror, hipStream_t st) {
+  PlanPair pp;
+  const int rc = plan_fill(pp, 0, g4, E_cap, E_grid, dyn, status, M, kkey_cap, pkey_cap, kk_cap, ij_cap, kk_order, kk_gid, kk_seg,
+                           kk_ngroups, kk_ukeys, ij_order, ij_gid, ij_seg, ij_ngroups, ij_ukeys, ix, jx, kj, ws, ws_bytes);
+  if (rc != RAMP_OK) return rc;
+  pp.s[1] = pp.s[0]; pp.ix[1] = ix; pp.jx[1] = jx; pp.kj[1] = kj;
+  return plan_launch(pp, 1, E_cap, E_grid, kkey_cap, pkey_cap, kk_cap, ij_cap, mirror, st);
+}
+// two plans (the candidates of the speculative keyframe edit) in one set of launches: graphs g4[z], sizes dyn[z] (status word
+// inside: + RAMP_DYN_STATUS), outputs set[z], workspaces ws[z] of ramp_i_plan_dyn_ws bytes each
+int ramp_i_plan_dyn_pair(const int64_t *const g4[2], int E_cap, int E_grid, int32_t *const dyn[2], int M, int kkey_cap,
+                         int pkey_cap, int kk_cap, int ij_cap, const ramp_plan_set set[2], void *const ws[2], size_t ws_bytes,
+                         hipStream_t st) {
+  PlanPair pp;
+  for (int z = 0; z < 2; z++) {
+    const ramp_plan_set &q = set[z];
+    const int rc = plan_fill(pp, z, g4[z], E_cap, E_grid, dyn[z], dyn[z] ? dyn[z] + RAMP_DYN_STATUS : nullptr, M, kkey_cap,
+                             pkey_cap, kk_cap, ij_cap, q.kk_order, q.kk_gid, q.kk_seg, q.kk_ngroups, q.kk_ukeys, q.ij_order,
+                             q.ij_gid, q.ij_seg, q.ij_ngroups, q.ij_ukeys, q.ix, q.jx, q.kj, ws[z], ws_bytes);
+    if (rc != RAMP_OK) return rc;
+  }
+  return plan_launch(pp, 2, E_cap, E_grid, kkey_cap, pkey_cap, kk_cap, ij_cap, nullptr, st);
 }
 
 extern "C" {

@@ -31,13 +31,17 @@ int ramp_i_frame_commit_dyn(float *poses, int motion, float damping, int64_t *ts
                             int median_frames, int M, int P, float *patches_new, int n_copy, const void *const *src,
                             void *const *base, const long *bytes, const int *mod, const int32_t *dyn,
                             const float *median_ahead, int32_t *status, int E_bound, int n_rows, hipStream_t st,
-                            const int32_t *slot_tab = nullptr, int slot_buf = 0);
+                            const int32_t *slot_tab = nullptr, int slot_buf = 0, uint32_t *signal = nullptr,
+                            uint32_t signal_val = 0);
 size_t ramp_i_plan_dyn_ws(int E_cap, int kkey_cap, int pkey_cap);
 int ramp_i_plan_dyn(const int64_t *g4, int E_cap, int E_grid, const int32_t *dyn, int32_t *status, int M, int kkey_cap,
                     int pkey_cap, int kk_cap, int ij_cap, int32_t *kk_order, int32_t *kk_gid, int32_t *kk_seg,
                     int32_t *kk_ngroups, int64_t *kk_ukeys, int32_t *ij_order, int32_t *ij_gid, int32_t *ij_seg,
                     int32_t *ij_ngroups, int64_t *ij_ukeys, int64_t *ix, int64_t *jx, int32_t *kj, void *ws,
                     size_t ws_bytes, int32_t *mirror, hipStream_t st);
+int ramp_i_plan_dyn_pair(const int64_t *const g4[2], int E_cap, int E_grid, int32_t *const dyn[2], int M, int kkey_cap,
+                         int pkey_cap, int kk_cap, int ij_cap, const ramp_plan_set set[2], void *const ws[2], size_t ws_bytes,
+                         hipStream_t st);
 size_t ramp_i_ba_dyn_ws(int E_cap, int n_poses, int n_patches, int opt_window, int max_patches, int max_pairs);
 int ramp_i_ba_dyn(float *poses, float *patches, const float *intrinsics, const float *target, const float *weight,
                   const float *lmbda, const int64_t *ii, const int64_t *jj, const int64_t *kk, int E_cap, int P,

@@ -246,6 +246,7 @@ struct FrameCommit {
   int32_t *status; int E_bound;      // optional: status bit 32 if dyn[RAMP_DYN_E] exceeds the step's launch bound
   int32_t *status_rows; int n_rows;  // with dyn: the frame buffers hold n_rows rows -- a row past them is flagged (bit 64), nothing is stored
   const int32_t *slot_tab; int slot_buf;   // optional: ring row r of buffer slot_buf lives in physical slot slot_tab[r] (ramp_track.fmap1_slot)
+  uint32_t *signal; uint32_t signal_val;   // optional signal word: "everything in front of this launch on its stream is done"
 };
 __global__ void __launch_bounds__(MED_THREADS) frame_commit_kernel(const FrameCommit a) {
   const int t = threadIdx.x;
@@ -253,6 +254,8 @@ __global__ void __launch_bounds__(MED_THREADS) frame_commit_kernel(const FrameCo
   int64_t index_val = a.index_val;
   const float *median_src = a.median_src;
   float *patches_row = a.patches_row;
+  if (a.signal && blockIdx.x == 0 && blockIdx.y == 0 && t == 0)
+    __hip_atomic_store(a.signal, a.signal_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   if (a.dyn) {
     n = a.dyn[RAMP_DYN_NROW];
     if (a.n_rows > 0 && (n < 0 || n > a.n_rows - 2)) {      // (index_map is written at n + 1)
@@ -321,7 +324,7 @@ int ramp_i_frame_commit_dyn(float *poses, int motion, float damping, int64_t *ts
                             int median_frames, int M, int P, float *patches_new, int n_copy, const void *const *src,
                             void *const *base, const long *bytes, const int *mod, const int32_t *dyn,
                             const float *median_ahead, int32_t *status, int E_bound, int n_rows, hipStream_t st,
-                            const int32_t *slot_tab, int slot_buf) {
+                            const int32_t *slot_tab, int slot_buf, uint32_t *signal, uint32_t signal_val) {
   if (!poses || !patches_state || !patches_new || !dyn || M <= 0 || P <= 0 || n_copy < 0 || n_copy > FC_MAXBUF)
     return RAMP_EINVAL;
   if ((long)median_frames * M * P * P > MED_THREADS * MED_PER) return RAMP_EUNSUPPORTED;
@@ -335,6 +338,7 @@ int ramp_i_frame_commit_dyn(float *poses, int motion, float damping, int64_t *ts
   a.status = E_bound > 0 ? status : nullptr; a.E_bound = E_bound;
   a.status_rows = status; a.n_rows = n_rows;
   a.slot_tab = slot_tab; a.slot_buf = slot_buf;
+  a.signal = signal; a.signal_val = signal_val;
   if (slot_tab && (slot_buf < 0 || slot_buf >= n_copy || mod[slot_buf] <= 0)) return RAMP_EINVAL;
   a.n_copy = n_copy;
   long mx = 0;
@@ -415,7 +419,7 @@ int ramp_frame_commit(float *poses, int n, int motion, float damping, int64_t *t
   a.patches_new = patches_new; a.patches_row = patches_state + (size_t)n * row;
   a.median_val = median_dev;
   a.dyn = nullptr; a.k_new = nullptr; a.status = nullptr; a.E_bound = 0; a.status_rows = nullptr; a.n_rows = 0;
-  a.slot_tab = nullptr; a.slot_buf = 0;
+  a.slot_tab = nullptr; a.slot_buf = 0; a.signal = nullptr; a.signal_val = 0;
   for (int i = 0; i < FC_MAXBUF; i++) a.mod[i] = 0;
   a.n_copy = n_copy;
   long mx = 0;

@@ -38,7 +38,33 @@ struct TrkEdit {
   int nbuf;
   int32_t *slot_tab;       // optional (ramp_track.fmap1_slot): the rows of buffer slot_buf are not moved, the table is rotated
   int slot_buf, slot_mod;
+  // speculative edit (trk_select_kernel): spec != 0 -- blockIdx.z is the OUTCOME the launch assumes (0 keep, 1 remove); the
+  // sizes are read from dyn (the live block) and written to that candidate's block, the graph goes to the candidate's
+  // buffer; no delta-log entry, no row shift
+  int spec;
+  int32_t *cdyn[2];
+  int64_t *cgout[2];
+  int32_t *cws[2];         // cnt / off / fmin of each candidate
 };
+// what a launch reads and writes: the live buffers and the motion test's decision, or candidate blockIdx.z's
+struct TrkCand {
+  const int32_t *dyn_in;   // sizes before the edit
+  int32_t *dyn;            // sizes after
+  int64_t *gout;
+  int32_t *cnt, *off, *fmin;
+  int force;               // -1: the motion test decides
+};
+__device__ __forceinline__ TrkCand trk_cand(const TrkEdit &p) {
+  TrkCand c;
+  c.dyn_in = p.dyn;
+  if (!p.spec) {
+    c.dyn = p.dyn; c.gout = p.gout; c.cnt = p.cnt; c.off = p.off; c.fmin = p.fmin; c.force = -1;
+  } else {
+    const int o = blockIdx.z;
+    c.dyn = p.cdyn[o]; c.gout = p.cgout[o]; c.cnt = p.cws[o]; c.off = p.cws[o] + p.nb; c.fmin = p.cws[o] + 2 * p.nb; c.force = o;
+  }
+  return c;
+}
 
 // Ramp_vo.keyframe(): m = motionmag(i, j) + motionmag(j, i);  m / 2 < KEYFRAME_THRESH  (python floats: doubles)
 __device__ __forceinline__ bool trk_remove(const float *mm, double thresh) {
@@ -55,14 +81,14 @@ __device__ __forceinline__ bool trk_edge(bool remove, long k, long kcut, int M, 
 }
 struct TrkDecision { bool remove; long k, kcut; int n, n_after; };
 __device__ __forceinline__ TrkDecision trk_decision(const int32_t *dyn, const float *mm, double thresh, int ki,
-                                                    int removal_window, int M, bool after_decide) {
+                                                    int removal_window, int M, bool after_decide, int force = -1) {
   TrkDecision d;
   if (after_decide) {              // trk_decide has already rewritten dyn
     d.n = dyn[RAMP_DYN_NPREV];
     d.remove = dyn[RAMP_DYN_REMOVED] != 0;
   } else {
     d.n = dyn[RAMP_DYN_N];
-    d.remove = trk_remove(mm, thresh);
+    d.remove = force >= 0 ? force != 0 : trk_remove(mm, thresh);
   }
   d.k = d.n - ki;
   d.n_after = d.remove ? d.n - 1 : d.n;
@@ -73,10 +99,11 @@ __device__ __forceinline__ TrkDecision trk_decision(const int32_t *dyn, const fl
 
 __global__ void __launch_bounds__(256) trk_flag_kernel(const TrkEdit p) {
   __shared__ int s_cnt[4], s_min[4];
-  const int E = p.dyn[RAMP_DYN_E];
+  const TrkCand c = trk_cand(p);
+  const int E = c.dyn_in[RAMP_DYN_E];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (b * TRK_EB >= E) return;
-  const TrkDecision d = trk_decision(p.dyn, p.mm, p.thresh, p.keyframe_index, p.removal_window, p.M, false);
+  const TrkDecision d = trk_decision(c.dyn_in, p.mm, p.thresh, p.keyframe_index, p.removal_window, p.M, false, c.force);
   int cnt = 0, fmin = 0x7fffffff;
 #pragma unroll
   for (int pass = 0; pass < TRK_EB / 256; pass++) {
@@ -94,21 +121,22 @@ __global__ void __launch_bounds__(256) trk_flag_kernel(const TrkEdit p) {
   if (lane == 0) { s_cnt[wave] = cnt; s_min[wave] = fmin; }
   __syncthreads();
   if (tid == 0) {
-    p.cnt[b] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-    p.fmin[b] = min(min(s_min[0], s_min[1]), min(s_min[2], s_min[3]));
+    c.cnt[b] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    c.fmin[b] = min(min(s_min[0], s_min[1]), min(s_min[2], s_min[3]));
   }
 }
 
 __global__ void __launch_bounds__(256) trk_decide_kernel(const TrkEdit p) {
   __shared__ int s_sum[256], s_min[256];
   const int tid = threadIdx.x;
-  const int E = p.dyn[RAMP_DYN_E];
+  const TrkCand c = trk_cand(p);
+  const int E = c.dyn_in[RAMP_DYN_E];
   const int nbl = (E + TRK_EB - 1) / TRK_EB;
   const int per = (nbl + 255) / 256;
   const int b0 = tid * per, b1 = min(nbl, b0 + per);
-  int c = 0, fm = 0x7fffffff;
-  for (int b = b0; b < b1; b++) { c += p.cnt[b]; fm = min(fm, p.fmin[b]); }
-  s_sum[tid] = c; s_min[tid] = fm;
+  int kept = 0, fm = 0x7fffffff;
+  for (int b = b0; b < b1; b++) { kept += c.cnt[b]; fm = min(fm, c.fmin[b]); }
+  s_sum[tid] = kept; s_min[tid] = fm;
   __syncthreads();
   for (int o = 1; o < 256; o <<= 1) {
     int v = 0;
@@ -117,17 +145,17 @@ __global__ void __launch_bounds__(256) trk_decide_kernel(const TrkEdit p) {
     s_sum[tid] += v;
     __syncthreads();
   }
-  int run = s_sum[tid] - c;
-  for (int b = b0; b < b1; b++) { const int h = p.cnt[b]; p.off[b] = run; run += h; }
+  int run = s_sum[tid] - kept;
+  for (int b = b0; b < b1; b++) { const int h = c.cnt[b]; c.off[b] = run; run += h; }
   for (int o = 128; o > 0; o >>= 1) {
     if (tid < o) s_min[tid] = min(s_min[tid], s_min[tid + o]);
     __syncthreads();
   }
   if (tid != 0) return;
   const int Ek = s_sum[255];
-  const TrkDecision d = trk_decision(p.dyn, p.mm, p.thresh, p.keyframe_index, p.removal_window, p.M, false);
+  const TrkDecision d = trk_decision(c.dyn_in, p.mm, p.thresh, p.keyframe_index, p.removal_window, p.M, false, c.force);
   int status = 0;
-  if (d.remove) {
+  if (d.remove && c.force < 0) {
     // Ramp_vo.py:249-253: delta[t1] = (t0, poses[k] * poses[k-1]^-1), read back by terminate()
     const int idx = p.dyn[RAMP_DYN_NLOG];
     if (idx < p.log_cap) {
@@ -156,20 +184,21 @@ __global__ void __launch_bounds__(256) trk_decide_kernel(const TrkEdit p) {
   int ne = nf + nbk;
   if (Ek + ne > p.E_cap) { status |= 4; ne = max(p.E_cap - Ek, 0); }
   const int flo = min(s_min[0], lo);
-  p.dyn[RAMP_DYN_NPREV] = d.n;
-  p.dyn[RAMP_DYN_EPREV] = E;
-  p.dyn[RAMP_DYN_EKEPT] = Ek;
-  p.dyn[RAMP_DYN_REMOVED] = d.remove ? 1 : 0;
-  p.dyn[RAMP_DYN_K] = (int)d.k;
-  p.dyn[RAMP_DYN_NROW] = n_after;
-  p.dyn[RAMP_DYN_N] = n1;
-  p.dyn[RAMP_DYN_E] = Ek + ne;
-  p.dyn[RAMP_DYN_KLO] = (int)min(d.kcut, (long)p.M * lo);
-  p.dyn[RAMP_DYN_FLO] = flo;
-  p.dyn[RAMP_DYN_W] = n1 - flo;
-  p.dyn[RAMP_DYN_FRAME] = (int)p.counter;
-  p.dyn[RAMP_DYN_FRAME2] = (int)p.counter;       // second tag, in the other half of the block: a torn host copy shows
-  if (status) atomicOr(p.dyn + RAMP_DYN_STATUS, status);   // (the front-end stream's gate wait may OR its time-out bit in)
+  c.dyn[RAMP_DYN_NPREV] = d.n;
+  c.dyn[RAMP_DYN_EPREV] = E;
+  c.dyn[RAMP_DYN_EKEPT] = Ek;
+  c.dyn[RAMP_DYN_REMOVED] = d.remove ? 1 : 0;
+  c.dyn[RAMP_DYN_K] = (int)d.k;
+  c.dyn[RAMP_DYN_NROW] = n_after;
+  c.dyn[RAMP_DYN_N] = n1;
+  c.dyn[RAMP_DYN_E] = Ek + ne;
+  c.dyn[RAMP_DYN_KLO] = (int)min(d.kcut, (long)p.M * lo);
+  c.dyn[RAMP_DYN_FLO] = flo;
+  c.dyn[RAMP_DYN_W] = n1 - flo;
+  c.dyn[RAMP_DYN_FRAME] = (int)p.counter;
+  c.dyn[RAMP_DYN_FRAME2] = (int)p.counter;       // second tag, in the other half of the block: a torn host copy shows
+  if (c.force >= 0) c.dyn[RAMP_DYN_STATUS] = status;       // a candidate collects its own capacity flags (the plan ORs in)
+  else if (status) atomicOr(c.dyn + RAMP_DYN_STATUS, status);   // (the front-end stream's gate wait may OR its time-out bit in)
 }
 
 // grid (nb + new-factor workgroups, 1 + nbuf).  y = 0: x < nb compacts the kept factors of edit workgroup x (stable),
@@ -195,55 +224,60 @@ __device__ __forceinline__ void trk_shift_rows(char *base, long row_bytes, int m
   }
 }
 
+// the row shift of frame buffer b behind a dropped keyframe k (rows k + 1 .. nrows - 1 move down by one)
+__device__ __forceinline__ void trk_shift_buffer(const TrkEdit &p, int b, int k, int nrows, int tid) {
+  if (p.slot_tab && b == p.slot_buf) {
+    // rows k + 1 .. nrows - 1 become rows k .. nrows - 2: their SLOTS move down the table, the dropped row's slot goes
+    // behind them (the next new frame's).  One thread; readers come in later launches.
+    if (blockIdx.x == 0 && tid == 0) {
+      const int freed = p.slot_tab[k % p.slot_mod];
+      for (int r = k; r < nrows - 1; r++) p.slot_tab[r % p.slot_mod] = p.slot_tab[(r + 1) % p.slot_mod];
+      p.slot_tab[(nrows - 1) % p.slot_mod] = freed;
+    }
+    return;
+  }
+  const long n4 = p.row_bytes[b] / 4;
+  // each thread owns columns c, c + stride, ... and moves the rows itself: no cross-thread hazard.  Up to four rows
+  // (KEYFRAME_INDEX - 1 = 3 in every shipped config) are all READ before the first is written -- one round trip
+  // instead of a chain of load -> store pairs per column; 16-byte pieces where the row allows
+  const int nmove = nrows - 1 - k;
+  const int mod = p.mod[b];
+  if (nmove >= 1 && nmove <= 4 && !(p.row_bytes[b] & 15)) {
+    const long n16 = p.row_bytes[b] / 16;
+    switch (nmove) {                                         // (compile-time row count: the rows stay in registers)
+      case 1: trk_shift_rows<1>(p.base[b], p.row_bytes[b], mod, k, n16, tid); break;
+      case 2: trk_shift_rows<2>(p.base[b], p.row_bytes[b], mod, k, n16, tid); break;
+      case 3: trk_shift_rows<3>(p.base[b], p.row_bytes[b], mod, k, n16, tid); break;
+      default: trk_shift_rows<4>(p.base[b], p.row_bytes[b], mod, k, n16, tid); break;
+    }
+    return;
+  }
+  for (long col = (long)blockIdx.x * 256 + tid; col < n4; col += (long)gridDim.x * 256) {
+    for (int r = k; r < nrows - 1; r++) {
+      const int sd = mod ? r % mod : r, ss = mod ? (r + 1) % mod : r + 1;
+      reinterpret_cast<uint32_t *>(p.base[b] + (size_t)sd * p.row_bytes[b])[col] =
+          reinterpret_cast<const uint32_t *>(p.base[b] + (size_t)ss * p.row_bytes[b])[col];
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) trk_apply_kernel(const TrkEdit p) {
   const int tid = threadIdx.x;
   if (blockIdx.y > 0) {
     if (!p.dyn[RAMP_DYN_REMOVED]) return;
-    const int b = blockIdx.y - 1, k = p.dyn[RAMP_DYN_K], nrows = p.dyn[RAMP_DYN_NPREV];
-    if (p.slot_tab && b == p.slot_buf) {
-      // rows k + 1 .. nrows - 1 become rows k .. nrows - 2: their SLOTS move down the table, the dropped row's slot goes
-      // behind them (the next new frame's).  One thread; readers come in later launches.
-      if (blockIdx.x == 0 && tid == 0) {
-        const int freed = p.slot_tab[k % p.slot_mod];
-        for (int r = k; r < nrows - 1; r++) p.slot_tab[r % p.slot_mod] = p.slot_tab[(r + 1) % p.slot_mod];
-        p.slot_tab[(nrows - 1) % p.slot_mod] = freed;
-      }
-      return;
-    }
-    const long n4 = p.row_bytes[b] / 4;
-    // each thread owns columns c, c + stride, ... and moves the rows itself: no cross-thread hazard.  Up to four rows
-    // (KEYFRAME_INDEX - 1 = 3 in every shipped config) are all READ before the first is written -- one round trip
-    // instead of a chain of load -> store pairs per column; 16-byte pieces where the row allows
-    const int nmove = nrows - 1 - k;
-    const int mod = p.mod[b];
-    if (nmove >= 1 && nmove <= 4 && !(p.row_bytes[b] & 15)) {
-      const long n16 = p.row_bytes[b] / 16;
-      switch (nmove) {                                         // (compile-time row count: the rows stay in registers)
-        case 1: trk_shift_rows<1>(p.base[b], p.row_bytes[b], mod, k, n16, tid); break;
-        case 2: trk_shift_rows<2>(p.base[b], p.row_bytes[b], mod, k, n16, tid); break;
-        case 3: trk_shift_rows<3>(p.base[b], p.row_bytes[b], mod, k, n16, tid); break;
-        default: trk_shift_rows<4>(p.base[b], p.row_bytes[b], mod, k, n16, tid); break;
-      }
-      return;
-    }
-    for (long col = (long)blockIdx.x * 256 + tid; col < n4; col += (long)gridDim.x * 256) {
-      for (int r = k; r < nrows - 1; r++) {
-        const int sd = mod ? r % mod : r, ss = mod ? (r + 1) % mod : r + 1;
-        reinterpret_cast<uint32_t *>(p.base[b] + (size_t)sd * p.row_bytes[b])[col] =
-            reinterpret_cast<const uint32_t *>(p.base[b] + (size_t)ss * p.row_bytes[b])[col];
-      }
-    }
+    trk_shift_buffer(p, blockIdx.y - 1, p.dyn[RAMP_DYN_K], p.dyn[RAMP_DYN_NPREV], tid);
     return;
   }
-  int64_t *oi = p.gout, *oj = p.gout + p.E_cap, *ok = p.gout + 2 * (size_t)p.E_cap, *orow = p.gout + 3 * (size_t)p.E_cap;
+  const TrkCand c = trk_cand(p);
+  int64_t *oi = c.gout, *oj = c.gout + p.E_cap, *ok = c.gout + 2 * (size_t)p.E_cap, *orow = c.gout + 3 * (size_t)p.E_cap;
   const int b = blockIdx.x;
   if (b < p.nb) {
     __shared__ int s_w[4];
-    const int E = p.dyn[RAMP_DYN_EPREV];
+    const int E = c.dyn[RAMP_DYN_EPREV];
     if (b * TRK_EB >= E) return;
-    const TrkDecision d = trk_decision(p.dyn, p.mm, p.thresh, p.keyframe_index, p.removal_window, p.M, true);
+    const TrkDecision d = trk_decision(c.dyn, p.mm, p.thresh, p.keyframe_index, p.removal_window, p.M, true);
     const int lane = tid & 63, wave = tid >> 6;
-    int base = p.off[b];
+    int base = c.off[b];
     for (int pass = 0; pass < TRK_EB / 256; pass++) {
       const int e = b * TRK_EB + pass * 256 + tid;
       bool keep = false;
@@ -265,7 +299,7 @@ __global__ void __launch_bounds__(256) trk_apply_kernel(const TrkEdit p) {
   }
   // new factors: forward (every live patch of the last r - 1 frames -> the new frame), then backward (the new frame's
   // patches -> the last r frames incl. itself), patch-major like the reference's meshgrid(indexing='ij')
-  const int Ek = p.dyn[RAMP_DYN_EKEPT], ne = p.dyn[RAMP_DYN_E] - Ek;
+  const int Ek = c.dyn[RAMP_DYN_EKEPT], ne = c.dyn[RAMP_DYN_E] - Ek;
   const int idx = (b - p.nb) * 256 + tid;
   if (idx >= ne) {
     // rows between the live count and the next step's launch bound: defined (harmless) entries -- a caller that runs its
@@ -273,7 +307,7 @@ __global__ void __launch_bounds__(256) trk_apply_kernel(const TrkEdit p) {
     if (idx < ne + p.pad && Ek + idx < p.E_cap) { oi[Ek + idx] = 0; oj[Ek + idx] = 0; ok[Ek + idx] = 0; orow[Ek + idx] = -1; }
     return;
   }
-  const int n1 = p.dyn[RAMP_DYN_N];
+  const int n1 = c.dyn[RAMP_DYN_N];
   const int lo = max(n1 - p.r, 0);
   const int nf = p.M * (max(n1 - 1, 0) - lo);
   long kk, jj;
@@ -286,6 +320,87 @@ __global__ void __launch_bounds__(256) trk_apply_kernel(const TrkEdit p) {
     jj = lo + q % nt;
   }
   oi[Ek + idx] = kk / p.M; oj[Ek + idx] = jj; ok[Ek + idx] = kk; orow[Ek + idx] = -1;
+}
+
+// ---------------------------------------------------------------------------------------- speculative keyframe edit
+// The graph edit and the next graph's plan depend on the motion test's DECISION only, not on anything bundle adjustment
+// computes: both possible next graphs (keyframe n - KEYFRAME_INDEX kept / dropped) are structural functions of the current
+// one.  ramp_track_step therefore runs flag -> decide -> apply -> plan for BOTH outcomes on a second stream, beside the
+// update operator, into candidate buffers (trk_*_kernel with TrkEdit.force = 0 / 1 on a candidate's copy of the sizes),
+// and the serial tail behind the motion test shrinks from seven dependent launches (~54 us) to this one: take the
+// decision, copy the chosen candidate's graph, plan and sizes into the live buffers and shift the frame buffers if the
+// keyframe went (the delta-log entry, which needs the poses bundle adjustment just wrote, rides in the wait in front).  Same kernels, same inputs:
+// the live buffers end up bit-identical to the seven-launch path's.
+#define TRK_NCOPY 17
+struct TrkSelect {
+  TrkEdit e;                          // decision parameters, delta log, frame buffers of the row shift
+  int32_t *dyn;                       // live sizes
+  const int32_t *cand;                // [2][RAMP_DYN_WORDS]: [0] keep, [1] remove
+  int32_t *mirror;                    // optional: the host's lazy copy of the sizes (mapped pinned memory)
+  const char *src[2][TRK_NCOPY];
+  char *dst[TRK_NCOPY];
+  long bytes[TRK_NCOPY];              // multiples of 4
+};
+// the launch in front of trk_select_kernel: waits for "both candidates are ready" (flag; nullptr: an event ordered the
+// streams) and appends the delta-log entry of a dropped keyframe -- it reads rows k - 1, k of the poses and time stamps,
+// which the select launch's row shift overwrites (Ramp_vo.py:249-253: delta[t1] = (t0, poses[k] * poses[k-1]^-1))
+__global__ void trk_spec_log_kernel(const TrkEdit p, const uint32_t *flag, uint32_t value, long ticks) {
+  if (flag) {
+    const long t0 = wall_clock64();
+    bool seen;
+    while (!(seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= value) && (long)wall_clock64() - t0 < ticks)
+      __builtin_amdgcn_s_sleep(64);
+    if (!seen && threadIdx.x == 0) atomicOr(p.dyn + RAMP_DYN_STATUS, 128);
+  }
+  if (threadIdx.x != 0 || !trk_remove(p.mm, p.thresh)) return;
+  const int k = p.dyn[RAMP_DYN_N] - p.keyframe_index, idx = p.dyn[RAMP_DYN_NLOG];
+  if (idx < p.log_cap) {
+    float Pk[7], Pm[7], Pi[7], dP[7];
+    for (int q = 0; q < 7; q++) { Pk[q] = p.poses[7 * k + q]; Pm[q] = p.poses[7 * (k - 1) + q]; }
+    lt_inv(Pm, Pi);
+    lt_mul(Pk, Pi, dP);
+    float *lo = p.dlog + (size_t)idx * RAMP_TRACK_LOG;
+    lo[0] = __int_as_float((int)p.tstamps[k]);
+    lo[1] = __int_as_float((int)p.tstamps[k - 1]);
+    for (int q = 0; q < 7; q++) lo[2 + q] = dP[q];
+    p.dyn[RAMP_DYN_NLOG] = idx + 1;
+  } else {
+    atomicOr(p.dyn + RAMP_DYN_STATUS, 16);
+  }
+}
+
+__global__ void __launch_bounds__(256) trk_select_kernel(const TrkSelect s) {
+  const int tid = threadIdx.x;
+  const int o = trk_remove(s.e.mm, s.e.thresh) ? 1 : 0;
+  const int32_t *cd = s.cand + o * RAMP_DYN_WORDS;
+  if (blockIdx.y > 0) {
+    if (o) trk_shift_buffer(s.e, blockIdx.y - 1, cd[RAMP_DYN_K], cd[RAMP_DYN_NPREV], tid);
+    return;
+  }
+  for (int b = 0; b < TRK_NCOPY; b++) {
+    const long n = s.bytes[b];
+    const char *src = s.src[o][b];
+    char *dst = s.dst[b];
+    if (!(n & 15)) {
+      for (long i = (long)blockIdx.x * 256 + tid; i < n / 16; i += (long)gridDim.x * 256)
+        reinterpret_cast<uint4 *>(dst)[i] = reinterpret_cast<const uint4 *>(src)[i];
+    } else {
+      for (long i = (long)blockIdx.x * 256 + tid; i < n / 4; i += (long)gridDim.x * 256)
+        reinterpret_cast<uint32_t *>(dst)[i] = reinterpret_cast<const uint32_t *>(src)[i];
+    }
+  }
+  if (blockIdx.x != 0 || tid != 0) return;
+  // the sizes trk_decide_kernel rewrote in the chosen candidate's copy; the live block keeps what the step itself set
+  // meanwhile (status bits of bundle adjustment / the gate wait, MEDOK, the log length)
+  const int status = cd[RAMP_DYN_STATUS];
+  const int own[13] = {RAMP_DYN_NPREV, RAMP_DYN_EPREV, RAMP_DYN_EKEPT, RAMP_DYN_REMOVED, RAMP_DYN_K, RAMP_DYN_NROW, RAMP_DYN_N,
+                       RAMP_DYN_E, RAMP_DYN_KLO, RAMP_DYN_FLO, RAMP_DYN_W, RAMP_DYN_FRAME, RAMP_DYN_FRAME2};
+  for (int q = 0; q < 13; q++) s.dyn[own[q]] = cd[own[q]];
+  if (status) atomicOr(s.dyn + RAMP_DYN_STATUS, status);
+  if (s.mirror) {
+    __threadfence_system();
+    for (int w = 0; w < RAMP_DYN_WORDS; w++) s.mirror[w] = s.dyn[w == RAMP_DYN_FRAME2 ? RAMP_DYN_FRAME : w];
+  }
 }
 
 __global__ void __launch_bounds__(256) trk_iota_kernel(int64_t *__restrict__ row, int32_t *__restrict__ dyn) {
@@ -342,6 +457,8 @@ static int trk_edit_fill(const ramp_track *t, int cur, int64_t counter, TrkEdit 
     p.base[i] = (char *)bufs[i]; p.row_bytes[i] = rb[i]; p.mod[i] = md[i];
   }
   p.slot_tab = t->fmap1_slot; p.slot_buf = 7; p.slot_mod = t->mem;      // (bufs[7] = fmap1)
+  p.spec = 0;
+  for (int o = 0; o < 2; o++) { p.cdyn[o] = nullptr; p.cgout[o] = nullptr; p.cws[o] = nullptr; }
   return RAMP_OK;
 }
 
@@ -507,6 +624,19 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
   // the host's lazy copy of the sizes: written by the plan's last launch straight into the (mapped, pinned) host buffer
   int32_t *mirror = nullptr;
   if (t->dyn_host) mirror = t->dyn_host_dev;      // resolved once by the caller (ramp_host_device_pointer)
+  // speculative keyframe edit (see trk_select_kernel): both candidates of the next graph + plan on the second stream,
+  // from the live graph and sizes the previous step's select launch (or the hand-over) left final
+  static int spec_on = -1;                               // RAMP_SPEC_EDIT=1 (default 0: measured a wash)
+  static int spec_nap = 2;                               // x s_sleep 64 (~2 us) between two looks at the signal word
+  if (spec_on < 0) {
+    const char *e = getenv("RAMP_SPEC_EDIT"); spec_on = e ? atoi(e) : 0;
+    if ((e = getenv("RAMP_SPEC_NAP")) && atoi(e) > 0) spec_nap = atoi(e);
+  }
+  const int full = RAMP_TRACK_COMMIT | RAMP_TRACK_UPDATE | RAMP_TRACK_KEYFRAME;
+  const bool spec = spec_on && t->spec_stream && (flags & full) == full && !(flags & RAMP_TRACK_MM_GIVEN) && !t->feat_fp32 &&
+                    t->mm && t->dlog && t->spec_graph[0] && t->spec_graph[1] && t->spec_dyn && t->spec_plan_ws && t->spec_edit_ws &&
+                    ((t->spec_go && t->spec_done) || (t->spec_ev_go && t->spec_ev_done));
+  const int Ep_next = Eb + new_cap < Ec ? Eb + new_cap : Ec;       // the next graph: at most one frame's factors more
   if (flags & RAMP_TRACK_COMMIT) {
     if (!t->fe_colors || !t->fe_imap || !t->fe_gmap || !t->fe_fmap1 || !t->fe_fmap2 || !t->fe_patches) return RAMP_EINVAL;
     const void *src[5] = {t->fe_colors, t->fe_imap, t->fe_gmap, t->fe_fmap1, t->fe_fmap2};
@@ -518,7 +648,38 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
     TRK_DO(ramp_i_frame_commit_dyn(t->poses, t->motion_model, t->motion_damping, t->tstamps, counter, t->index_map,
                                    t->intrinsics, k_new, t->patches, 3, t->M, t->P, t->fe_patches, 5, src, base, bytes,
                                    mod, dyn, (t->median && t->keyframe_index >= 4) ? t->median : nullptr, t->dyn + RAMP_DYN_STATUS, (Eb < Ec && folded) ? Eb : 0, t->n_rows, st,
-                                   t->fmap1_slot, 3));
+                                   t->fmap1_slot, 3, spec ? t->spec_go : nullptr, t->spec_seq));
+  }
+  if (spec) {
+    hipStream_t ax = (hipStream_t)t->spec_stream;
+    // behind this step's commit launch (which stores spec_go): the live graph and sizes are the previous step's final ones
+    if (t->spec_go)       // (a data dependency: the time-out is a hang guard, not a scheduling choice -- 20 s)
+      hipLaunchKernelGGL(trk_wait_flag_kernel, dim3(1), dim3(64), 0, ax, t->spec_go, t->spec_seq, 2000000000L, 0L, spec_nap,
+                         t->dyn + RAMP_DYN_STATUS);
+    else if (hipEventRecord((hipEvent_t)t->spec_ev_go, st) != hipSuccess ||
+             hipStreamWaitEvent(ax, (hipEvent_t)t->spec_ev_go, 0) != hipSuccess) return RAMP_ELAUNCH;
+    // both outcomes in the same launches (blockIdx.z): the sizes are read from the live block, each candidate writes its own
+    TrkEdit p;
+    TRK_DO(trk_edit_fill(t, cur, counter, p));
+    p.spec = 1;
+    const size_t pws = t->plan_ws_bytes;
+    int32_t *cdyn[2];
+    const int64_t *cg[2];
+    void *cws[2];
+    for (int o = 0; o < 2; o++) {
+      p.cdyn[o] = cdyn[o] = t->spec_dyn + o * RAMP_DYN_WORDS;
+      p.cgout[o] = t->spec_graph[o]; cg[o] = t->spec_graph[o];
+      p.cws[o] = t->spec_edit_ws + o * (3 * p.nb + 8);
+      cws[o] = (char *)t->spec_plan_ws + o * pws;
+    }
+    hipLaunchKernelGGL(trk_flag_kernel, dim3(p.nb, 1, 2), dim3(256), 0, ax, p);
+    hipLaunchKernelGGL(trk_decide_kernel, dim3(1, 1, 2), dim3(256), 0, ax, p);
+    hipLaunchKernelGGL(trk_apply_kernel, dim3(p.nb + ramp_cdiv(new_cap + p.pad, 256), 1, 2), dim3(256), 0, ax, p);
+    TRK_DO(ramp_i_plan_dyn_pair(cg, Ec, Ep_next, cdyn, t->M, t->kkey_cap, t->pkey_cap, t->kk_cap, t->ij_cap, t->spec_plan, cws,
+                                pws, ax));
+    if (t->spec_done) hipLaunchKernelGGL(trk_signal_kernel, dim3(1), dim3(1), 0, ax, t->spec_done, t->spec_seq);
+    else if (hipEventRecord((hipEvent_t)t->spec_ev_done, ax) != hipSuccess) return RAMP_ELAUNCH;
+    RAMP_CHECK_LAUNCH();
   }
   if ((flags & RAMP_TRACK_UPDATE) && t->feat_fp32) return RAMP_EUNSUPPORTED;   // (fp32: PRE, the caller's operator, POST)
   if (flags & RAMP_TRACK_UPDATE_PRE) {
@@ -686,17 +847,44 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
                                   t->ij_ngroups, 0.5f, t->mm, dyn, t->keyframe_index, st));
     TrkEdit p;
     TRK_DO(trk_edit_fill(t, cur, counter, p));
+    if (spec) {
+      // both candidates are (long) ready: take the decision and copy the chosen one into the live buffers
+      if (!t->spec_done && hipStreamWaitEvent(st, (hipEvent_t)t->spec_ev_done, 0) != hipSuccess) return RAMP_ELAUNCH;
+      hipLaunchKernelGGL(trk_spec_log_kernel, dim3(1), dim3(64), 0, st, p, t->spec_done, t->spec_seq, 2000000000L);
+      TrkSelect sel;
+      sel.e = p; sel.dyn = t->dyn; sel.cand = t->spec_dyn; sel.mirror = mirror;
+      int64_t *gl = t->graph[1 - cur];
+      int nbuf = 0;
+      auto add = [&](const void *a0, const void *a1, void *d, long bytes) {
+        sel.src[0][nbuf] = (const char *)a0; sel.src[1][nbuf] = (const char *)a1; sel.dst[nbuf] = (char *)d;
+        sel.bytes[nbuf] = (bytes + 3) / 4 * 4; nbuf++;
+      };
+      const long ep16 = ((long)Ep_next + 3) / 4 * 4 < Ec ? ((long)Ep_next + 3) / 4 * 4 : Ec;   // whole 16-byte pieces of int32 rows
+      for (int r = 0; r < 4; r++)
+        add(t->spec_graph[0] + r * (size_t)Ec, t->spec_graph[1] + r * (size_t)Ec, gl + r * (size_t)Ec, ep16 * 8);
+      const ramp_plan_set &q0 = t->spec_plan[0], &q1 = t->spec_plan[1];
+      add(q0.kk_order, q1.kk_order, t->kk_order, ep16 * 4); add(q0.kk_gid, q1.kk_gid, t->kk_gid, ep16 * 4);
+      add(q0.ij_order, q1.ij_order, t->ij_order, ep16 * 4); add(q0.ij_gid, q1.ij_gid, t->ij_gid, ep16 * 4);
+      add(q0.ix, q1.ix, t->ix, ep16 * 8); add(q0.jx, q1.jx, t->jx, ep16 * 8); add(q0.kj, q1.kj, t->kj, ep16 * 4);
+      add(q0.kk_seg, q1.kk_seg, t->kk_seg, (long)(t->kk_cap + 2) * 4); add(q0.ij_seg, q1.ij_seg, t->ij_seg, (long)(t->ij_cap + 2) * 4);
+      add(q0.kk_ukeys, q1.kk_ukeys, t->kk_ukeys, (long)(t->kk_cap + 2) * 8); add(q0.ij_ukeys, q1.ij_ukeys, t->ij_ukeys, (long)(t->ij_cap + 2) * 8);
+      add(q0.kk_ngroups, q1.kk_ngroups, t->kk_ngroups, 4); add(q0.ij_ngroups, q1.ij_ngroups, t->ij_ngroups, 4);
+      static_assert(TRK_NCOPY == 17, "the copy list above");
+      hipLaunchKernelGGL(trk_select_kernel, dim3(1024, 1 + p.nbuf), dim3(256), 0, st, sel);
+      RAMP_CHECK_LAUNCH();
+    } else {
     hipLaunchKernelGGL(trk_flag_kernel, dim3(p.nb), dim3(256), 0, st, p);
     hipLaunchKernelGGL(trk_decide_kernel, dim3(1), dim3(256), 0, st, p);
     int gx = p.nb + ramp_cdiv(new_cap + p.pad, 256);
     if (gx < 1024) gx = 1024;                                         // column chunks of the row shift
     hipLaunchKernelGGL(trk_apply_kernel, dim3(gx, 1 + p.nbuf), dim3(256), 0, st, p);
     RAMP_CHECK_LAUNCH();
-    const int Ep = Eb + new_cap < Ec ? Eb + new_cap : Ec;            // the next graph: at most one frame's factors more
+    const int Ep = Ep_next;
     TRK_DO(ramp_i_plan_dyn(t->graph[1 - cur], Ec, Ep, t->dyn, t->dyn + RAMP_DYN_STATUS, t->M, t->kkey_cap, t->pkey_cap,
                            t->kk_cap, t->ij_cap, t->kk_order, t->kk_gid, t->kk_seg, t->kk_ngroups, t->kk_ukeys, t->ij_order,
                            t->ij_gid, t->ij_seg, t->ij_ngroups, t->ij_ukeys, t->ix, t->jx, t->kj, t->plan_ws, t->plan_ws_bytes,
                            mirror, st));
+    }
   }
   // (without a plan in this call, or without a device mapping of the host buffer: an asynchronous copy)
   if (t->dyn_host && !(mirror && (flags & RAMP_TRACK_KEYFRAME)) &&

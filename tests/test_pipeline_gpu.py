@@ -677,11 +677,10 @@ def test_evaluate_harness_run_and_run_pose_pred():
     assert list(ts2[-4:]) == [16, 17, 18, 19]
 
 
-def test_fused_correlation_linear1_launch_does_not_change_the_tracker():
-    """RAMP_CORR_L1=1 (SURVEY N2, first clause: the correlation launch applies the correlation MLP's first Linear itself and
-    the [E, 896] rows are never written -- csrc/altcorr.hip::corr_l1_kernel) in the host-driven AND the device-resident
-    step: a 44-frame fp16 run (host-driven first, device resident once the window is full) ends in the same poses, patches,
-    hidden state, graph and trajectory, bit for bit, as the default two-launch path.  The switch is read once per process: two subprocesses."""
+def _tracker_runs_under(envs, ready="False"):
+    """the same 44-frame fp16 run (host-driven first, device resident once the window is full) in one subprocess per
+    environment (the build / launch switches are read once per process): poses, patches, hidden state, graph, per-frame
+    factor counts and trajectory of each"""
     import os
     import subprocess
     import sys
@@ -693,6 +692,7 @@ def test_fused_correlation_linear1_launch_does_not_change_the_tracker():
             "T = 44; stream = SyntheticStream(240, 320, T, seed=77, device='cuda'); torch.manual_seed(5)\n"
             "slam = Ramp_vo(make_cfg('default', PATCHES_PER_FRAME=48, MIXED_PRECISION=True), make_network('SingleScale'),"
             " {'event_bias': True}, ht=240, wd=320)\n"
+            "slam.inputs_ready = %s\n"
             "resident, E = 0, []\n"
             "with torch.no_grad():\n"
             "    for t in range(T):\n"
@@ -701,19 +701,42 @@ def test_fused_correlation_linear1_launch_does_not_change_the_tracker():
             "    slam.update(); traj, ts = slam.terminate()\n"
             "n = slam.n\n"
             "np.savez(sys.argv[1], traj=traj, ts=ts, poses=slam.poses_[:n].cpu().numpy(), patches=slam.patches_[:n].cpu().numpy(),"
-            " net=slam.net.float().cpu().numpy(), ii=slam._ii, jj=slam._jj, kk=slam._kk, E=np.array(E), dev=np.array([resident]))\n") % (root,)
+            " net=slam.net.float().cpu().numpy(), ii=slam._ii, jj=slam._jj, kk=slam._kk, E=np.array(E), dev=np.array([resident]))\n") % (root, ready)
     outs = []
     with tempfile.TemporaryDirectory() as td:
-        for flag in ("0", "1"):
-            path = os.path.join(td, "run%s.npz" % flag)
-            r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, RAMP_CORR_L1=flag), capture_output=True,
+        for i, env in enumerate(envs):
+            path = os.path.join(td, "run%d.npz" % i)
+            r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **env), capture_output=True,
                                text=True, timeout=900, cwd=root)
             assert r.returncode == 0, r.stderr[-3000:]
             outs.append({k: v for k, v in np.load(path).items()})
-    a, b = outs
-    assert int(a["dev"][0]) > 20 and int(b["dev"][0]) > 20, "the run never reached the device-resident step"
+    for o in outs:
+        assert int(o["dev"][0]) > 20, "the run never reached the device-resident step"
+    return outs
+
+
+def test_fused_correlation_linear1_launch_does_not_change_the_tracker():
+    """RAMP_CORR_L1=1 (SURVEY N2, first clause: the correlation launch applies the correlation MLP's first Linear itself and
+    the [E, 896] rows are never written -- csrc/altcorr.hip::corr_l1_kernel) in the host-driven AND the device-resident
+    step ends in the same poses, patches, hidden state, graph and trajectory, bit for bit, as the default two-launch path."""
+    a, b = _tracker_runs_under(({"RAMP_CORR_L1": "0"}, {"RAMP_CORR_L1": "1"}))
     for k in a:
         assert np.array_equal(a[k], b[k]), k
+
+
+def test_speculative_keyframe_edit_does_not_change_the_tracker():
+    """RAMP_SPEC_EDIT (default on; csrc/track.hip::trk_select_kernel): both outcomes of keyframe()'s graph edit
+    (ramp/Ramp_vo.py:247-274) and the next graph's plan are computed beside the update operator, the tail behind the motion
+    test copies the chosen one.  Against the serial tail (RAMP_SPEC_EDIT=0: flag / decide / apply / plan behind the motion
+    test): the same state bit for bit -- on the front-end stream (default), on a stream of its own, with events instead of
+    signal words (RAMP_NO_FLAG_WAITS), and with frame pipelining on (the front-end stream carries both then)."""
+    envs = ({"RAMP_SPEC_EDIT": "0"}, {"RAMP_SPEC_EDIT": "1"}, {"RAMP_SPEC_EDIT": "1", "RAMP_SPEC_STREAM": "own"},
+            {"RAMP_SPEC_EDIT": "1", "RAMP_NO_FLAG_WAITS": "1"})
+    runs = _tracker_runs_under(envs) + _tracker_runs_under(envs[:2], ready="True")
+    assert len(set(runs[0]["E"][-20:].tolist())) > 1 and 0 < len(runs[0]["ts"])
+    for b in runs[1:]:
+        for k in runs[0]:
+            assert np.array_equal(runs[0][k], b[k]), k
 
 
 def test_bench_runs_the_fp32_path():
