@@ -728,7 +728,7 @@ typedef struct ramp_track {
                                        * the motion test's launch instead of at the head of the next step (KEYFRAME_INDEX >= 4:
                                        * the three newest frames are the same whether or not the test drops a keyframe)       */
   float *dlog;                        /* [log_cap][RAMP_TRACK_LOG] */
-  int32_t *edit_ws;                   /* [2 * ceil(E_cap / 1024) + 8] */
+  int32_t *edit_ws;                   /* [3 * ceil(E_cap / 256) + 8]  */
   int32_t *dyn_host;                  /* optional pinned host copy of dyn, refreshed asynchronously after each step */
   int32_t *dyn_host_dev;              /* optional: device address of dyn_host (ramp_host_device_pointer, resolved once):
                                        * the plan's last launch then writes the copy itself                          */

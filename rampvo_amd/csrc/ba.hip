@@ -369,6 +369,72 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// K4 for systems of one tile (6N <= 64) whose split-K chunk fits the LDS: the chunk's E rows, Q and u are staged ONCE (every
+// load of the workgroup in flight together -- ba_schur_kernel walks the chunk in batches of 8 rows, one dependent memory round
+// trip per batch), then the products run from LDS.  Same fma chain per entry in the same k order: identical partials.
+#define BA_S1_ROWS 160
+__global__ void __launch_bounds__(256)
+    ba_schur1_kernel(const float *__restrict__ Erow, const float *__restrict__ Qv, const float *__restrict__ uv,
+                     const int32_t *__restrict__ ngroups, float *__restrict__ S_part, float *__restrict__ y_part, int n6, int KS) {
+  __shared__ float Es[BA_S1_ROWS][BA_TS];
+  __shared__ float Qs[BA_S1_ROWS], us[BA_S1_ROWS];
+  const int nk = *ngroups;
+  const int z = blockIdx.z;
+  const int per = (nk + KS - 1) / KS;
+  const int k0 = z * per, k1 = min(nk, k0 + per);
+  const int tid = threadIdx.x, ty = tid / 16, tx = tid % 16;
+  const int rows = max(k1 - k0, 0);
+  for (int q0 = 0; q0 < rows * BA_TS; q0 += 12 * 256) {      // 12 loads per thread in flight (48 rows: one round trip)
+    float ev[12];
+#pragma unroll
+    for (int u = 0; u < 12; u++) {
+      const int q = q0 + u * 256 + tid;
+      const int kq = q / BA_TS, col = q - kq * BA_TS;
+      ev[u] = (q < rows * BA_TS && col < n6) ? Erow[(size_t)(k0 + kq) * n6 + col] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < 12; u++) {
+      const int q = q0 + u * 256 + tid;
+      if (q < rows * BA_TS) Es[q / BA_TS][q % BA_TS] = ev[u];
+    }
+  }
+  for (int q = tid; q < rows; q += 256) { Qs[q] = Qv[k0 + q]; us[q] = uv[k0 + q]; }
+  __syncthreads();
+  float acc[4][4];
+  float yacc[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int b = 0; b < 4; b++) acc[a][b] = 0.0f;
+  // (ba_schur_kernel pads its last batch of 8 with zero rows: fma(0, 0, acc) leaves acc as it is, nothing to reproduce)
+  for (int kq = 0; kq < rows; kq++) {
+    float a[4], b[4];
+    const float qk = Qs[kq];
+#pragma unroll
+    for (int q = 0; q < 4; q++) { a[q] = Es[kq][ty * 4 + q] * qk; b[q] = Es[kq][tx * 4 + q]; }
+#pragma unroll
+    for (int x = 0; x < 4; x++)
+#pragma unroll
+      for (int y = 0; y < 4; y++) acc[x][y] = __builtin_fmaf(a[x], b[y], acc[x][y]);
+    if (tx == 0) {
+      const float u = us[kq];
+#pragma unroll
+      for (int x = 0; x < 4; x++) yacc[x] = __builtin_fmaf(a[x], u, yacc[x]);
+    }
+  }
+#pragma unroll
+  for (int x = 0; x < 4; x++) {
+    const int r = ty * 4 + x;
+    if (r >= n6) continue;
+#pragma unroll
+    for (int y = 0; y < 4; y++) {
+      const int c = tx * 4 + y;
+      if (c < n6) S_part[((size_t)z * n6 + r) * n6 + c] = acc[x][y];
+    }
+    if (tx == 0) y_part[(size_t)z * n6 + r] = yacc[x];
+  }
+}
+
 // ------------------------------------------------------------------ K5
 // One workgroup per free pose a (block row of S).  The pair records that touch pose a are first
 // compacted IN ORDER into LDS (ballot prefix), then every thread sums its entries of the 6 x 6N
@@ -502,6 +568,12 @@ __global__ void __launch_bounds__(256)
 // call.  The interleaved order moves the 180 x 180 solve of the precise.yaml window by 6e-4 of the step against the oracle --
 // fp32 rounding through its conditioning -- so windows above 16 poses keep ba_assemble_kernel.)
 #define BA_AP 7
+#ifdef BA_AC_TIMING
+__device__ long ba_ac_t[8];
+#define BA_AC_T(i) do { __syncthreads(); if (threadIdx.x == 0) ba_ac_t[i] = wall_clock64(); } while (0)
+#else
+#define BA_AC_T(i)
+#endif
 __global__ void __launch_bounds__(256)
     ba_assemble2_kernel(const float *__restrict__ pairs, const int32_t *__restrict__ pair_ij,
                         const int32_t *__restrict__ npairs, const float *__restrict__ S_part,
@@ -514,6 +586,18 @@ __global__ void __launch_bounds__(256)
   const int a = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int np = *npairs;
   const bool diag = a == b;
+  // the split-K partials of this thread's entry do not depend on the pair lists: their loads go out first and are in flight
+  // while the list is built (one dependent memory round trip less on a launch that is nothing but round trips)
+  float spv[64];
+  if (tid < 36) {
+    const int r = 6 * a + tid / 6, c = 6 * b + tid % 6;
+#pragma unroll
+    for (int u = 0; u < 64; u++) spv[u] = S_part[((size_t)(u < KS ? u : KS - 1) * n6 + r) * n6 + c];
+  } else if (tid < 42 && diag) {
+    const int r = 6 * a + tid - 36;
+#pragma unroll
+    for (int u = 0; u < 64; u++) spv[u] = y_part[(size_t)(u < KS ? u : KS - 1) * n6 + r];
+  }
   if (tid == 0) s_base = 0;
   __syncthreads();
   for (int g0 = 0; g0 < np; g0 += 256) {
@@ -570,13 +654,8 @@ __global__ void __launch_bounds__(256)
     for (int q = 0; q < BA_AP; q++) bs += s_part[q][tid];
     const int r = 6 * a + x, c = 6 * b + y;
     float sp = 0.0f;
-    {
-      float v[64];
 #pragma unroll
-      for (int u = 0; u < 64; u++) v[u] = S_part[((size_t)(u < KS ? u : KS - 1) * n6 + r) * n6 + c];
-#pragma unroll
-      for (int u = 0; u < 64; u++) sp += u < KS ? v[u] : 0.0f;
-    }
+    for (int u = 0; u < 64; u++) sp += u < KS ? spv[u] : 0.0f;
     float sv = bs - sp;
     if (r == c) sv += (1e-4f * sv + 1.0f);
     S[(size_t)r * n6 + c] = sv;
@@ -586,13 +665,8 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int q = 0; q < BA_AP; q++) vs += s_part[q][tid];
     float yp = 0.0f;
-    {
-      float v[64];
 #pragma unroll
-      for (int u = 0; u < 64; u++) v[u] = y_part[(size_t)(u < KS ? u : KS - 1) * n6 + r];
-#pragma unroll
-      for (int u = 0; u < 64; u++) yp += u < KS ? v[u] : 0.0f;
-    }
+    for (int u = 0; u < 64; u++) yp += u < KS ? spv[u] : 0.0f;
     yv[r] = vs - yp;
   }
 }
@@ -715,28 +789,15 @@ __global__ void __launch_bounds__(64)
 // panel row against it, and the whole workgroup applies the rank-6 update to the trailing matrix on a TG x TG thread
 // grid -- two barriers per pose instead of one per column.  The right-hand side rides along as row n6 (z = L^-1 y
 // falls out of the panel solves); the back substitution is blocked the same way.
+// the factorisation and the solve on a matrix that is already in LDS (A: (n6 + 1) x ld, lower triangle + the rhs as row n6;
+// every thread of the workgroup calls it)
 template <int TG>
-__global__ void __launch_bounds__(TG * TG)
-    ba_cholb_kernel(const float *__restrict__ S, const float *__restrict__ yv,
-                    float *__restrict__ dX, int32_t *__restrict__ info, int n6) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int ld = n6 + 1;                       // odd for every 6N: conflict-free column walks
-  float *A = sm;                               // (n6 + 1) x ld: rows 0..n6-1 = S (lower triangle), row n6 = y
-  float *xv = sm + (n6 + 1) * ld;              // n6: solution
-  float *Lk = xv + n6;                         // nb x 28: the factored diagonal blocks (21 lower entries + 6 inverses)
+__device__ __forceinline__ void ba_cholb_body(float *__restrict__ A, float *__restrict__ xv, float *__restrict__ Lk,
+                                              float *__restrict__ dX, int32_t *__restrict__ info, int n6) {
+  const int ld = n6 + 1;
   __shared__ int s_bad;
   const int tid = threadIdx.x, nt = TG * TG;
   const int ty = tid / TG, tx = tid % TG;
-  {
-    int r = tid / n6, c = tid - r * n6;        // one division, then stepping
-    const int dr = nt / n6, dc = nt - dr * n6;
-    for (int q = tid; q < n6 * n6; q += nt) {
-      A[r * ld + c] = S[q];
-      r += dr; c += dc;
-      if (c >= n6) { c -= n6; r++; }
-    }
-  }
-  for (int q = tid; q < n6; q += nt) A[n6 * ld + q] = yv[q];
   if (tid == 0) s_bad = 0;
   __syncthreads();
   const int nb = n6 / 6;
@@ -812,6 +873,36 @@ __global__ void __launch_bounds__(TG * TG)
   const bool bad = s_bad != 0;
   if (bad && tid == 0 && info) atomicOr(info, 1);
   // L' x = z (z = row n6), block by block from the bottom
+  if (n6 <= 64) {
+    // one wave, no barriers: lane i keeps z_i; a block's six unknowns are solved by every lane (uniform work on broadcast
+    // values), then lane i < c0 takes them out of its z_i -- the blocked loop below operation for operation
+    if (tid < 64) {
+      float z = tid < n6 ? A[n6 * ld + tid] : 0.0f;
+      for (int kb = nb - 1; kb >= 0; kb--) {
+        const int c0 = 6 * kb;
+        float lk[27], x[6];
+#pragma unroll
+        for (int q = 0; q < 27; q++) lk[q] = Lk[kb * 28 + q];
+#pragma unroll
+        for (int j = 0; j < 6; j++) x[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(z), c0 + j));
+#pragma unroll
+        for (int j = 5; j >= 0; j--) {
+#pragma unroll
+          for (int k = j + 1; k < 6; k++) x[j] = __builtin_fmaf(-lk[k * (k + 1) / 2 + j], x[k], x[j]);
+          x[j] *= lk[21 + j];
+        }
+        if (tid == 0) {
+#pragma unroll
+          for (int j = 0; j < 6; j++) xv[c0 + j] = x[j];
+        }
+        if (tid < c0) {
+#pragma unroll
+          for (int k = 0; k < 6; k++) z = __builtin_fmaf(-A[(c0 + k) * ld + tid], x[k], z);
+        }
+      }
+    }
+    __syncthreads();
+  } else
   for (int kb = nb - 1; kb >= 0; kb--) {
     const int c0 = 6 * kb;
     if (tid < 64) {                            // wave 0 (uniform work, lane 0 writes)
@@ -852,6 +943,208 @@ __global__ void __launch_bounds__(TG * TG)
   if (!bad && s_nf != 0 && tid == 0 && info) atomicOr(info, 1);
   for (int q = tid; q < n6; q += nt) dX[q] = drop ? 0.0f : xv[q];
 }
+template <int TG>
+__global__ void __launch_bounds__(TG * TG)
+    ba_cholb_kernel(const float *__restrict__ S, const float *__restrict__ yv,
+                    float *__restrict__ dX, int32_t *__restrict__ info, int n6) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int ld = n6 + 1;                       // odd for every 6N: conflict-free column walks
+  float *A = sm;                               // (n6 + 1) x ld: rows 0..n6-1 = S (lower triangle), row n6 = y
+  float *xv = sm + (n6 + 1) * ld;              // n6: solution
+  float *Lk = xv + n6;                         // nb x 28: the factored diagonal blocks (21 lower entries + 6 inverses)
+  const int tid = threadIdx.x, nt = TG * TG;
+  {
+    int r = tid / n6, c = tid - r * n6;        // one division, then stepping
+    const int dr = nt / n6, dc = nt - dr * n6;
+    for (int q = tid; q < n6 * n6; q += nt) {
+      A[r * ld + c] = S[q];
+      r += dr; c += dc;
+      if (c >= n6) { c -= n6; r++; }
+    }
+  }
+  for (int q = tid; q < n6; q += nt) A[n6 * ld + q] = yv[q];
+  ba_cholb_body<TG>(A, xv, Lk, dX, info, n6);
+}
+
+// ------------------------------------------------------------------ K5 + K6 in one launch (windows of <= 16 poses)
+// The assembly was a launch of N x N small workgroups whose only consumer is the single workgroup of the factorisation: here
+// that workgroup forms S's lower triangle and the right-hand side straight into its LDS matrix -- the same sums in the same
+// order as ba_assemble2_kernel (pair records of a block in ascending record order, dealt to BA_AP partial sums that are added
+// in lane order; split-K partials in z order; the damping), so S, y and dX are bit-identical to the two-launch path -- and
+// factors it.  One wave per pose lists the pair records that touch it (ballot prefix, ascending); a table gives the record of
+// every ordered pair for the off-diagonal blocks.
+// (cap = list entries per pose: BA_MAXLIST where the LDS holds it -- windows of <= 10 poses --, half of it above: a pose with
+// more pair records is flagged in *info, bit 1, like the two-launch path's overflow)
+template <int TG>
+__global__ void __launch_bounds__(TG * TG)
+    ba_asmchol_kernel(const float *__restrict__ pairs, const int32_t *__restrict__ pair_ij, const int32_t *__restrict__ npairs,
+                      const float *__restrict__ S_part, const float *__restrict__ y_part, float *__restrict__ dX,
+                      int32_t *__restrict__ info, int n6, int KS, int BA_AC_LIST) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int ld = n6 + 1, N = n6 / 6;
+  float *A = sm;
+  float *xv = sm + (n6 + 1) * ld;
+  float *Lk = xv + n6;
+  int *s_list = reinterpret_cast<int *>(Lk + N * 28);       // [N][BA_AC_LIST] record numbers
+  int *s_li = s_list + N * BA_AC_LIST;                       // their i
+  int *s_lj = s_li + N * BA_AC_LIST;                         // their j
+  int *s_nl = s_lj + N * BA_AC_LIST;                         // [N]
+  int *s_pid = s_nl + N;                                     // [N][N]: record of the ordered pair (i, j), -1 if none
+  const int tid = threadIdx.x, nt = TG * TG, lane = tid & 63, wave = tid >> 6;
+  const int np = *npairs;
+  BA_AC_T(0);
+  for (int q = tid; q < N * N; q += nt) s_pid[q] = -1;
+  __syncthreads();
+  if (wave < N) {                               // (TG = 32: 16 waves, N <= 16)
+    const int a = wave;
+    int base = 0;
+    constexpr int LR = 8;                       // rounds loaded together
+    for (int g00 = 0; g00 < np; g00 += 64 * LR) {
+    int2 pv[LR];
+#pragma unroll
+    for (int u = 0; u < LR; u++) {
+      const int g = g00 + 64 * u + lane;
+      pv[u] = g < np ? reinterpret_cast<const int2 *>(pair_ij)[g] : make_int2(-2, -2);
+    }
+#pragma unroll
+    for (int u = 0; u < LR; u++) {
+      const int g0 = g00 + 64 * u;
+      if (g0 >= np) break;
+      const int g = g0 + lane;
+      const int pi = pv[u].x, pj = pv[u].y;
+      const bool hit = pi == a || pj == a;
+      const unsigned long long m = __ballot(hit);
+      const int off = base + __popcll(m & ((1ull << lane) - 1ull));
+      if (hit && off < BA_AC_LIST) { s_list[a * BA_AC_LIST + off] = g; s_li[a * BA_AC_LIST + off] = pi; s_lj[a * BA_AC_LIST + off] = pj; }
+      if (pi == a && pj >= 0 && pj < N) s_pid[a * N + pj] = g;       // (one record per ordered pair: the records are the pair groups)
+      base += __popcll(m);
+    }
+    }
+    if (lane == 0) {
+      s_nl[a] = min(base, BA_AC_LIST);
+      if (base > BA_AC_LIST && info) atomicOr(info, 2);              // (never a silent truncation)
+    }
+  }
+  __syncthreads();
+  BA_AC_T(1);
+  // phase A: the partial sums over the pair records of the diagonal blocks' lower entries (21 per pose) and of the gradient
+  // (6 per pose), one (entry, partial lane) item per thread like ba_assemble2_kernel: lane pl sums records pl, pl + AP, ...
+  // of the pose's list in ascending order; a round's loads are all in flight before its first add
+  float *s_part = reinterpret_cast<float *>(s_pid + N * N);       // [N * 27][BA_AP]
+  for (int it = tid; it < N * 27 * BA_AP; it += nt) {
+    const int e = it / BA_AP, pl = it - e * BA_AP, a = e / 27, k = e - 27 * a;
+    int x = 0, y = 0;
+    if (k < 21) {
+      x = k < 1 ? 0 : (k < 3 ? 1 : (k < 6 ? 2 : (k < 10 ? 3 : (k < 15 ? 4 : 5))));
+      y = k - x * (x + 1) / 2;
+    } else {
+      x = k - 21;
+    }
+    const int nl = s_nl[a];
+    const int *li = s_li + a * BA_AC_LIST, *lj = s_lj + a * BA_AC_LIST, *lg = s_list + a * BA_AC_LIST;
+    float acc = 0.f;
+    constexpr int RND = 8;
+    for (int l0 = pl; l0 < nl; l0 += BA_AP * RND) {
+      // a record touches pose a as i or as j: ONE load (its i-block or its j-block); only the self pair (a, a) adds all four
+      // blocks (a workgroup's vector memory instructions, not its bytes, are what this single-CU launch pays for)
+      float v0[RND], v1[RND], v2[RND], v3[RND];
+#pragma unroll
+      for (int u = 0; u < RND; u++) {
+        const int l = l0 + BA_AP * u;
+        const bool on = l < nl;
+        const int i = on ? li[l] : -2, j = on ? lj[l] : -2;
+        const bool self = i == a && j == a;
+        const float *pr = pairs + (size_t)(on ? lg[l] : lg[0]) * BA_PAIR + (k < 21 ? x * 6 + y : 144 + x);
+        const int step = k < 21 ? 36 : 6;
+        const float first = pr[i == a ? 0 : step];
+        v0[u] = i == a ? first : 0.f;
+        v1[u] = j == a ? (self ? pr[step] : first) : 0.f;
+        v2[u] = (self && k < 21) ? pr[72] : 0.f; v3[u] = (self && k < 21) ? pr[108] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < RND; u++) {
+        const int l = l0 + BA_AP * u;
+        if (l >= nl) break;
+        const int i = li[l], j = lj[l];
+        if (i == a) acc += v0[u];
+        if (j == a) acc += v1[u];
+        if (k < 21) {
+          if (i == a && j == a) acc += v2[u];
+          if (j == a && i == a) acc += v3[u];
+        }
+      }
+    }
+    s_part[it] = acc;
+  }
+  __syncthreads();
+  BA_AC_T(2);
+  // phase B: lower triangle in pieces of four columns (r, 4 c4 .. 4 c4 + 3), then the right-hand side; the split-K partials
+  // in z order, 16 bytes per load, 16 loads in flight
+  const int n4 = n6 / 4;                                     // (6N is a multiple of 4 for even N; odd N: scalar tail column pieces)
+  const int row4 = (n6 + 3) / 4;
+  for (int q = tid; q < n6 * row4 + n6; q += nt) {
+    const bool rhs = q >= n6 * row4;
+    const int r = rhs ? q - n6 * row4 : q / row4, c4 = rhs ? 0 : q - r * row4;
+    if (!rhs && 4 * c4 > r) continue;
+    const int a = r / 6, x = r - 6 * a;
+    float sp[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool vec = !rhs && c4 < n4 && (n6 & 3) == 0;
+    const int ncol = rhs ? 1 : min(4, n6 - 4 * c4);
+    for (int z0 = 0; z0 < KS; z0 += 16) {
+      float4 v[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) {
+        const int z = min(z0 + u, KS - 1);
+        if (rhs) {
+          v[u] = make_float4(y_part[(size_t)z * n6 + r], 0.f, 0.f, 0.f);
+        } else if (vec) {
+          v[u] = *reinterpret_cast<const float4 *>(S_part + ((size_t)z * n6 + r) * n6 + 4 * c4);
+        } else {
+          const float *sr = S_part + ((size_t)z * n6 + r) * n6 + 4 * c4;
+          v[u] = make_float4(sr[0], ncol > 1 ? sr[1] : 0.f, ncol > 2 ? sr[2] : 0.f, ncol > 3 ? sr[3] : 0.f);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 16; u++) {
+        if (z0 + u >= KS) break;
+        sp[0] += v[u].x; sp[1] += v[u].y; sp[2] += v[u].z; sp[3] += v[u].w;
+      }
+    }
+    for (int e = 0; e < ncol; e++) {
+      const int c = 4 * c4 + e;
+      if (!rhs && c > r) break;
+      const int b = c / 6, y = c - 6 * b;
+      float bs = 0.f;
+      if (rhs || a == b) {
+        const float *pp = s_part + ((size_t)a * 27 + (rhs ? 21 + x : x * (x + 1) / 2 + y)) * BA_AP;
+#pragma unroll
+        for (int k = 0; k < BA_AP; k++) bs += pp[k];
+      } else {
+        // (a, b), a > b: the records of the ordered pairs (a, b) and (b, a), in ascending record order, on partial lanes 0 / 1
+        const int g1 = s_pid[a * N + b], g2 = s_pid[b * N + a];
+        const int lo = g1 < 0 ? g2 : (g2 < 0 ? g1 : min(g1, g2)), hi = (g1 >= 0 && g2 >= 0) ? max(g1, g2) : -1;
+        float p0 = 0.f, p1 = 0.f;
+        if (lo >= 0) p0 += pairs[(size_t)lo * BA_PAIR + (lo == g1 ? 72 : 108) + x * 6 + y];
+        if (hi >= 0) p1 += pairs[(size_t)hi * BA_PAIR + (hi == g1 ? 72 : 108) + x * 6 + y];
+        bs += p0; bs += p1;
+      }
+      const float spe = e == 0 ? sp[0] : (e == 1 ? sp[1] : (e == 2 ? sp[2] : sp[3]));
+      if (rhs) {
+        A[n6 * ld + r] = bs - spe;
+      } else {
+        float sv = bs - spe;
+        if (r == c) sv += (1e-4f * sv + 1.0f);
+        A[r * ld + c] = sv;
+      }
+    }
+  }
+  BA_AC_T(3);
+  ba_cholb_body<TG>(A, xv, Lk, dX, info, n6);
+  BA_AC_T(4);
+}
+#ifdef BA_AC_TIMING
+extern "C" int ramp_debug_ba_times(long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(ba_ac_t), 8 * sizeof(long)) == hipSuccess ? 0 : 1; }
+#endif
 
 // ------------------------------------------------------------------ K7
 __global__ void __launch_bounds__(256)
@@ -932,6 +1225,11 @@ static size_t ba_carve(void *ws, int E, int n_poses, int n_patches, int N, int o
   if (w->tiles < 1) w->tiles = 1;
   int ks = 256 / (w->tiles * w->tiles);
   w->KS = ks < 4 ? 4 : (ks > 64 ? 64 : ks);   // split-K partials, summed in fixed order by K5
+  {
+    static int ks_env = -1;                    // RAMP_BA_KS: override (A/B runs; 4 .. 64)
+    if (ks_env < 0) { const char *e = getenv("RAMP_BA_KS"); ks_env = e ? atoi(e) : 0; }
+    if (ks_env >= 4 && ks_env <= 64) w->KS = ks_env;
+  }
   w->gb = nullptr; w->gb_bytes = 0;
   w->pkeys = w->kx = w->pukeys = nullptr;
   w->order_k = w->seg_k = w->order_p = w->seg_p = nullptr;
@@ -1009,10 +1307,30 @@ static int ba_iterate(float *poses, float *patches, const float *intrinsics, con
       hipLaunchKernelGGL(ba_patch_kernel, dim3(w.Mu_b), dim3(pthreads), 0, st, w.rec, order_k, seg_k, nk,
                          lmbda, w.Erow, w.Cv, w.uv, w.Qv, n6);
     if (N > 0) {
+      static int schur1 = -1;                        // RAMP_BA_SCHUR1=0: the batched kernel at every size (A/B runs)
+      if (schur1 < 0) { const char *e = getenv("RAMP_BA_SCHUR1"); schur1 = e ? atoi(e) : 1; }
+      if (schur1 && w.tiles == 1 && ramp_cdiv(w.Mu_b, w.KS) <= BA_S1_ROWS)
+        hipLaunchKernelGGL(ba_schur1_kernel, dim3(1, 1, w.KS), dim3(256), 0, st, w.Erow, w.Qv, w.uv, nk, w.S_part, w.y_part,
+                           n6, w.KS);
+      else
       hipLaunchKernelGGL(ba_schur_kernel, dim3(w.tiles, w.tiles, w.KS), dim3(256), 0, st, w.Erow,
                          w.Qv, w.uv, nk, w.S_part, w.y_part, n6, w.KS);
-      static int asm2 = -1;                          // RAMP_BA_ASM2=0: one workgroup per pose (A/B runs)
+      static int asm2 = -1, fuse_ac = -1;            // RAMP_BA_ASM2=0: one workgroup per pose (A/B runs)
       if (asm2 < 0) { const char *e = getenv("RAMP_BA_ASM2"); asm2 = e ? atoi(e) : 1; }
+      if (fuse_ac < 0) { const char *e = getenv("RAMP_BA_ASMCHOL"); fuse_ac = e ? atoi(e) : 0; }     // 1: the assembly inside the factorisation's workgroup (measured slower)
+      const int chol0 = ba_chol_variant();
+      if (fuse_ac && asm2 && N <= 16 && chol0 == 0 && n6 % 6 == 0) {
+        const int cap = N <= 10 ? BA_MAXLIST : BA_MAXLIST / 2;
+        const size_t lds2 = lds + (size_t)(N * 28 + 3 * N * cap + N + N * N + N * 27 * BA_AP) * sizeof(float);
+        static size_t lds2_set = 0;
+        if (lds2 > 64 * 1024 && lds2 > lds2_set) {
+          if (hipFuncSetAttribute((const void *)ba_asmchol_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)
+            return RAMP_ELAUNCH;
+          lds2_set = lds2;
+        }
+        hipLaunchKernelGGL(ba_asmchol_kernel<32>, dim3(1), dim3(1024), lds2, st, w.pairs, w.pair_ij, np, w.S_part, w.y_part,
+                           w.dX, info, n6, w.KS, cap);
+      } else {
       if (asm2 && N <= 16)
         hipLaunchKernelGGL(ba_assemble2_kernel, dim3(N, N), dim3(256), 0, st, w.pairs, w.pair_ij, np, w.S_part, w.y_part,
                            w.S, w.yv, n6, w.KS, info);
@@ -1026,6 +1344,7 @@ static int ba_iterate(float *poses, float *patches, const float *intrinsics, con
         hipLaunchKernelGGL(ba_chol64_kernel, dim3(1), dim3(64), 0, st, w.S, w.yv, w.dX, info, n6);
       else
         hipLaunchKernelGGL(ba_chol_kernel, dim3(1), dim3(1024), lds, st, w.S, w.yv, w.dX, info, n6);
+      }
     }
     hipLaunchKernelGGL(ba_retract_kernel, dim3(depth_blocks + pose_blocks), dim3(256), 0, st,
                        poses, patches, w.Erow, w.Qv, w.uv, w.dX, kx, nk, n6, PP, t0, N, depth_blocks, dyn, opt_window);

@@ -380,7 +380,9 @@ __device__ __forceinline__ void plan_K(const PlanDyn &p, int g, int &K, long &su
 }
 // 1024 factors per workgroup (4 per thread): the LDS table (K bins to clear and to flush per workgroup) is amortised
 // over four times the factors of a one-per-thread launch
+#ifndef PLAN_EPB
 #define PLAN_EPB 1024
+#endif
 template <bool LDS>
 __global__ void __launch_bounds__(256) plan_hist_kernel(const PlanPair pp) {
   __shared__ int s_bin[LDS ? PLAN_LDS_K : 1];

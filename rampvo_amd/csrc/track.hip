@@ -15,7 +15,9 @@
 #include "ramp_internal.h"
 #include <stdlib.h>
 
+#ifndef TRK_EB
 #define TRK_EB 1024        // factors per workgroup of the edit kernels (256 threads x 4 passes)
+#endif
 #define TRK_MAXBUF 10
 
 struct TrkEdit {

@@ -171,7 +171,7 @@ class DeviceTrack:
         self.median = z(1, f32)
         self.sink = z(1, i32)
         self.dlog = z((self.log_cap, LOG_WORDS), f32)
-        self.edit_ws = z(3 * ((E_cap + 1023) // 1024) + 8, i32)
+        self.edit_ws = z(3 * ((E_cap + 255) // 256) + 8, i32)          # (sized for edit workgroups of 256 factors; the build uses 1024)
         self.ixm = (torch.arange(slam.N * M, device=dev) // M).contiguous()
         self.k_new = z(4, f32)
         self.cur = 0

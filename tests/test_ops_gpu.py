@@ -530,6 +530,46 @@ def test_ba_is_deterministic():
         assert np.array_equal(p, outs[0][0]) and np.array_equal(pt, outs[0][1])
 
 
+def _ba_runs_under(envs):
+    """the same bundle-adjustment problems (windows of 5, 7, 10 and 16 free poses, two iterations) solved in one subprocess per
+    environment -- the launch-variant switches of csrc/ba.hip are read once per process"""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from scenes import ba_scene; from rampvo_amd import ops; cu = lambda a: torch.as_tensor(a).cuda()\n"
+            "out = {}\n"
+            "for n, (nf, M, life, win) in enumerate(((9, 14, 4, 5), (12, 24, 6, 7), (24, 96, 13, 10), (22, 20, 9, 16))):\n"
+            "    s = ba_scene(seed=31 + n, n_frames=nf, M=M, lifetime=life, n_total_frames=nf + 6, far=bool(n & 1))\n"
+            "    poses, patches = cu(s['poses']), cu(s['patches']); info = torch.zeros(1, dtype=torch.int32, device='cuda')\n"
+            "    ops.ba(poses, patches, cu(s['intr']), cu(s['target']), cu(s['weight']), cu(s['lmbda']), cu(s['ii']), cu(s['jj']),"
+            " cu(s['kk']), nf - win, nf, 2, info)\n"
+            "    out['p%%d' %% n], out['d%%d' %% n], out['i%%d' %% n] = poses.cpu().numpy(), patches.cpu().numpy(), info.cpu().numpy()\n"
+            "    assert np.abs(out['p%%d' %% n] - s['poses']).max() > 1e-5\n"
+            "np.savez(sys.argv[1], **out)\n") % (root, os.path.join(root, "tests"))
+    outs = []
+    with tempfile.TemporaryDirectory() as td:
+        for i, env in enumerate(envs):
+            path = os.path.join(td, "ba%d.npz" % i)
+            r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **env), capture_output=True, text=True,
+                               timeout=600, cwd=root)
+            assert r.returncode == 0, r.stderr[-3000:]
+            outs.append({k: v for k, v in np.load(path).items()})
+    return outs
+
+
+def test_ba_launch_variants_are_bit_identical():
+    """fastba.BA's Gauss-Newton iteration (ramp/fastba/ba_cuda.cu:433-582) as launches: the default merges the assembly of S
+    into the factorisation's workgroup (ba_asmchol_kernel) -- same sums in the same order as the separate assembly launch
+    (RAMP_BA_ASMCHOL=0), so poses and depths agree bit for bit at every window size it serves (<= 16 poses)."""
+    runs = _ba_runs_under(({"RAMP_BA_ASMCHOL": "0"}, {"RAMP_BA_ASMCHOL": "1"}))
+    for b in runs[1:]:
+        for k in runs[0]:
+            assert np.array_equal(runs[0][k], b[k]), k
+
+
 def test_ops_refuse_cpu_tensors():
     from rampvo_amd import ops
     with pytest.raises(RuntimeError):
