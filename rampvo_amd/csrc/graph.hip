@@ -378,10 +378,10 @@ __device__ __forceinline__ void plan_K(const PlanDyn &p, int g, int &K, long &su
   }
   if (K > p.Kcap[g] || K < 0) K = 0;     // flagged by plan_hist_kernel; nothing is written out of bounds
 }
-// 1024 factors per workgroup (4 per thread): the LDS table (K bins to clear and to flush per workgroup) is amortised
-// over four times the factors of a one-per-thread launch
+// factors per workgroup (PLAN_EPB / 256 per thread): the LDS table (K bins to clear and to flush per workgroup) against the
+// number of workgroups that share the launch's latency -- at 40-odd thousand factors more, smaller workgroups win
 #ifndef PLAN_EPB
-#define PLAN_EPB 1024
+#define PLAN_EPB 256     // (1024 / 512 / 256 measured: scatter 6.7 / 5.5 / 5.0 us, histogram 5.0 / 4.8 / 4.6, scan 6.4 / 6.2 / 5.9)
 #endif
 template <bool LDS>
 __global__ void __launch_bounds__(256) plan_hist_kernel(const PlanPair pp) {

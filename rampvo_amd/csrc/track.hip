@@ -872,13 +872,16 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
       add(q0.kk_ukeys, q1.kk_ukeys, t->kk_ukeys, (long)(t->kk_cap + 2) * 8); add(q0.ij_ukeys, q1.ij_ukeys, t->ij_ukeys, (long)(t->ij_cap + 2) * 8);
       add(q0.kk_ngroups, q1.kk_ngroups, t->kk_ngroups, 4); add(q0.ij_ngroups, q1.ij_ngroups, t->ij_ngroups, 4);
       static_assert(TRK_NCOPY == 17, "the copy list above");
-      hipLaunchKernelGGL(trk_select_kernel, dim3(1024, 1 + p.nbuf), dim3(256), 0, st, sel);
+      hipLaunchKernelGGL(trk_select_kernel, dim3(t->fmap1_slot ? 256 : 1024, 1 + p.nbuf), dim3(256), 0, st, sel);
       RAMP_CHECK_LAUNCH();
     } else {
     hipLaunchKernelGGL(trk_flag_kernel, dim3(p.nb), dim3(256), 0, st, p);
     hipLaunchKernelGGL(trk_decide_kernel, dim3(1), dim3(256), 0, st, p);
     int gx = p.nb + ramp_cdiv(new_cap + p.pad, 256);
-    if (gx < 1024) gx = 1024;                                         // column chunks of the row shift
+    // column chunks of the row shift: with the level-0 planes behind the slot table the largest moved row is a few hundred KB
+    // (256 workgroups x 4 KB), without it 4.9 MB -- the launch deals out gx x (1 + nbuf) workgroups whether a keyframe went or not
+    const int gmin = t->fmap1_slot ? 256 : 1024;
+    if (gx < gmin) gx = gmin;
     hipLaunchKernelGGL(trk_apply_kernel, dim3(gx, 1 + p.nbuf), dim3(256), 0, st, p);
     RAMP_CHECK_LAUNCH();
     const int Ep = Ep_next;
