@@ -13,6 +13,7 @@
 //     iterations, point cloud, motion test, graph edit, the next graph's plan) without reading anything back.
 #include "ramp_device.h"
 #include "ramp_internal.h"
+#include <string.h>
 #include <stdlib.h>
 
 #ifndef TRK_EB
@@ -655,7 +656,14 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
   if (spec) {
     hipStream_t ax = (hipStream_t)t->spec_stream;
     // behind this step's commit launch (which stores spec_go): the live graph and sizes are the previous step's final ones
-    if (t->spec_go)       // (a data dependency: the time-out is a hang guard, not a scheduling choice -- 20 s)
+    // (RAMP_SPEC_AT=gate: the chain starts at this step's gate -- the first SoftAgg launch -- instead of its commit, i.e. on
+    // the front-end stream right ahead of the next frame's front end; measured)
+    static int spec_at_gate = -1;
+    if (spec_at_gate < 0) { const char *e = getenv("RAMP_SPEC_AT"); spec_at_gate = e && !strcmp(e, "gate"); }
+    if (t->spec_go && spec_at_gate && t->gate_flag)
+      hipLaunchKernelGGL(trk_wait_flag_kernel, dim3(1), dim3(64), 0, ax, t->gate_flag, t->gate_seq, 2000000000L, 0L, spec_nap,
+                         t->dyn + RAMP_DYN_STATUS);
+    else if (t->spec_go)       // (a data dependency: the time-out is a hang guard, not a scheduling choice -- 20 s)
       hipLaunchKernelGGL(trk_wait_flag_kernel, dim3(1), dim3(64), 0, ax, t->spec_go, t->spec_seq, 2000000000L, 0L, spec_nap,
                          t->dyn + RAMP_DYN_STATUS);
     else if (hipEventRecord((hipEvent_t)t->spec_ev_go, st) != hipSuccess ||

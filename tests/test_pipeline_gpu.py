@@ -734,9 +734,10 @@ def test_speculative_keyframe_edit_does_not_change_the_tracker():
             {"RAMP_SPEC_EDIT": "1", "RAMP_NO_FLAG_WAITS": "1"})
     runs = _tracker_runs_under(envs) + _tracker_runs_under(envs[:2], ready="True")
     assert len(set(runs[0]["E"][-20:].tolist())) > 1 and 0 < len(runs[0]["ts"])
-    for b in runs[1:]:
+    names = [str(e) for e in envs] + ["pipelined " + str(e) for e in envs[:2]]
+    for name, b in zip(names[1:], runs[1:]):
         for k in runs[0]:
-            assert np.array_equal(runs[0][k], b[k]), k
+            assert np.array_equal(runs[0][k], b[k]), (name, k)
 
 
 def test_bench_runs_the_fp32_path():
