@@ -792,6 +792,11 @@ def main():
     etimer.enabled = btimer.enabled = utimer.enabled = ctimer.enabled and dprobe is not None
     if dprobe is not None:
         dprobe.enabled = True
+    # (the live factor count of every timed frame from the host's lazy copy of the device-side sizes -- pinned memory, a few
+    # frames old, never waited for: a frame's time is proportional to it and it drifts by +-8 % along the stream, which is
+    # most of the spread between two short timed regions)
+    e_lazy = dv.dyn_host.numpy() if device_step else None
+    e_seen = []
     tic = time.perf_counter()
     marks = [tic]
     for i in range(args.steps):
@@ -800,6 +805,8 @@ def main():
             dprobe.mode = "corr" if i % max(1, args.probe_every) == max(1, args.probe_every) // 2 else None
         step()
         marks.append(time.perf_counter())         # host-side return times (the GPU may lag by less than a step)
+        if e_lazy is not None:
+            e_seen.append(int(e_lazy[2]))
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -921,6 +928,9 @@ def main():
                                                ", host-driven steps (RAMP_DEVICE_STEP=0)"
                                                if os.environ.get("RAMP_DEVICE_STEP", "1") != "1" else ""])),
                        "ba_iters_per_s": round(2 * value, 2), "edges": E0, "edges_end": E1,
+                       "factors_per_timed_frame": ({"mean": round(float(np.mean(e_seen)), 1), "min": int(min(e_seen)),
+                                                    "max": int(max(e_seen))} if e_seen else None),
+                       "factor_updates_per_s": round(value * float(np.mean(e_seen)), 0) if e_seen else None,
                        "keyframes_in_window": n0, "prime_frames": args.prime,
                        "clock_warm": "%d untimed steady-state steps (%.2f s) before the %d warm-up steps"
                                      % (warm_steps, warm_s, args.warmup),

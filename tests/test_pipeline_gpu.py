@@ -780,6 +780,8 @@ def test_bench_json_contract():
     assert d["n_gpus"] == 1 and d["steps"] == 12 and d["warmup"] == 3 and d["higher_is_better"] is True
     assert d["unit"] == "keyframes/s" and d["value"] > 0 and d["vs_baseline"] is None and "workload" in d["config"]
     assert "clock_warm" in d["config"] and d["config"]["non_pipelined_kfps"] > 0 and d["config"]["own_stream_kfps"] > 0
+    f = d["config"]["factors_per_timed_frame"]
+    assert f["min"] <= f["mean"] <= f["max"] and abs(d["config"]["factor_updates_per_s"] - d["value"] * f["mean"]) <= 1e-3 * d["value"] * f["mean"]
     assert d["config"]["converged_kfps"] > 0 and 0 < d["roofline"]["frac_live_compact"] <= 1.0
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["launches"] == 3 and r["achieved"] > 0      # every 4th timed step is bracketed
