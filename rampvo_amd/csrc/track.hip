@@ -758,11 +758,14 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
     // (diagnostic, RAMP_CORR_TWICE=1: the launch is issued twice -- same inputs, same output; the second one's time is the
     // kernel with planes, coordinates and output rows just touched: what the first pays for a cold chip, tools/README.md)
     static const bool corr_twice = getenv("RAMP_CORR_TWICE") && atoi(getenv("RAMP_CORR_TWICE")) != 0;
+    // (RAMP_CORR_ORDER=0: the launch walks the factors in graph order instead of the plan's (jj, ii)-major schedule; A/B runs)
+    static const bool corr_sched = !(getenv("RAMP_CORR_ORDER") && atoi(getenv("RAMP_CORR_ORDER")) == 0);
+    const int32_t *corr_order = corr_sched ? t->ij_order : nullptr;
     if (corr_twice)
-      TRK_DO(ramp_i_corr_fwd(t->gmap, lv, 2, t->coords, kk, jj, t->ij_order, t->corr, 896, (long)t->M * t->mem, t->mem, Eb,
+      TRK_DO(ramp_i_corr_fwd(t->gmap, lv, 2, t->coords, kk, jj, corr_order, t->corr, 896, (long)t->M * t->mem, t->mem, Eb,
                              t->mem * t->M, t->mem, 128, t->P, 3, RAMP_F16, RAMP_NHWC32, dyn, st,
                              fuse_tf ? t->poses : nullptr, t->patches, t->intrinsics, ii, t->fmap1_slot));
-    TRK_DO(ramp_i_corr_fwd(t->gmap, lv, 2, t->coords, kk, jj, t->ij_order, t->corr, 896, (long)t->M * t->mem, t->mem, Eb,
+    TRK_DO(ramp_i_corr_fwd(t->gmap, lv, 2, t->coords, kk, jj, corr_order, t->corr, 896, (long)t->M * t->mem, t->mem, Eb,
                            t->mem * t->M, t->mem, 128, t->P, 3, RAMP_F16, RAMP_NHWC32, dyn, st,
                            fuse_tf ? t->poses : nullptr, t->patches, t->intrinsics, ii, t->fmap1_slot));
     TRK_PROBE(1);
