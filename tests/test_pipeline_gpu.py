@@ -689,14 +689,17 @@ def _tracker_runs_under(envs, ready="False"):
     code = ("import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
             "from rampvo_amd.config import make_cfg; from rampvo_amd.Ramp_vo import Ramp_vo\n"
             "from rampvo_amd.synthetic import SyntheticStream, make_network\n"
-            "T = 44; stream = SyntheticStream(240, 320, T, seed=77, device='cuda'); torch.manual_seed(5)\n"
+            "T = 44; stream = SyntheticStream(240, 320, T, seed=77, device='cuda')\n"
+            # (generated and COMPLETE before the first call: inputs_ready = True is the caller's promise of finished tensors --
+            # the front end reads them on its own stream without waiting for the caller's)
+            "frames = [stream.frame(t) for t in range(T)]; torch.cuda.synchronize(); torch.manual_seed(5)\n"
             "slam = Ramp_vo(make_cfg('default', PATCHES_PER_FRAME=48, MIXED_PRECISION=True), make_network('SingleScale'),"
             " {'event_bias': True}, ht=240, wd=320)\n"
             "slam.inputs_ready = %s\n"
             "resident, E = 0, []\n"
             "with torch.no_grad():\n"
             "    for t in range(T):\n"
-            "        im, ev, K, mask = stream.frame(t); slam(t, input_tensor=(ev, im, mask), intrinsics=K)\n"
+            "        im, ev, K, mask = frames[t]; slam(t, input_tensor=(ev, im, mask), intrinsics=K)\n"
             "        resident += int(slam._dev is not None and slam._dev.active); E.append(slam.peek()['E'])\n"
             "    slam.update(); traj, ts = slam.terminate()\n"
             "n = slam.n\n"
