@@ -615,6 +615,42 @@ int ramp_upd_softagg(const float *x32, const void *add_t, const int32_t *add_idx
 int ramp_upd_softagg_finish(const float *frag, const int32_t *seg_start, const int32_t *ngroups, const void *wh,
                             const float *bh, void *hy, int max_groups, void *stream);
 
+/* ---------------------------------------------------------------- the update operator at fp32 accuracy (MIXED_PRECISION off)
+ *
+ * The same chains for fp32 features (ramp/net.py:69-90 without autocast): every Linear layer is formed on the f16 matrix
+ * cores from split operands (x = xh + xl, three f16 products into one fp32 accumulator: csrc/update_x3.hip), nothing
+ * between layers is rounded to fp16; biases, LayerNorm, gate, residual stream, the SoftAgg tables and the heads are fp32.
+ * Agreement with an fp32 GEMM chain: ~1e-6 of the output scale (22-bit operands, fp32 accumulation).  All tables and
+ * rows are float; weights `*w*` are "x3 packs" of an nn.Linear weight W [384][K] (K a multiple of 32):
+ *     [K/32][24][2][64 lanes][8] fp16 -- plane 0 = fp16(W 2^s), plane 1 = fp16(W 2^s - plane 0), s the power of two that
+ *     puts max |W| into [2^12, 2^13); lane (q, j) of fragment (ks, nt) holds W[16 nt + j][32 ks + 8 q .. + 8];
+ *     followed by one float, 2^-s   (rampvo_amd/update_fused.py::pack_linear_x3).
+ * Linear inputs must stay below 65504 in magnitude (as on the MIXED_PRECISION path).  Arguments otherwise as the
+ * ramp_upd_* function of the same name.                                                                              */
+int ramp_x3_corr_mlp(const float *corr, int corr_k, const void *w1, const float *b1, const void *w2, const float *b2,
+                     const void *w3, const float *b3, const float *ln_w, const float *ln_b, float ln_eps, const float *net,
+                     const int64_t *net_map, const float *inp, const int64_t *inp_idx, long inp_mod, const float *norm_w,
+                     const float *norm_b, float norm_eps, float *net_out, int E, void *stream);
+int ramp_x3_nbr(const float *net_in, const int64_t *idx, const void *wa, const float *ba, const void *wb, const float *bb,
+                float *net_out, int E, void *stream);
+/* fg [E][768] fp32 = [f(x) | g(x)], x = x32 (+ add_t[add_idx], fp32 table; written to x32_out when given)              */
+int ramp_x3_fg(const float *x32, const float *add_t, const int32_t *add_idx, float *x32_out, const void *wf, const float *bf,
+               const void *wg, const float *bg, float *fg, int E, void *stream);
+/* y [max_groups][384] fp32: the softmax-weighted segment sums of ramp_x3_fg's rows (ramp/blocks.py:46-48; 8 row lanes per
+ * group, merged in lane order); rows >= *ngroups are zero                                                            */
+int ramp_x3_segment_softmax(const float *fg, const int32_t *order, const int32_t *seg_start, const int32_t *ngroups, float *y,
+                            int max_groups, void *stream);
+/* y[r] = x[r] W^T + b on a table of rows (SoftAgg's `h`); rows_dev (optional, device int32): only rows < *rows_dev      */
+int ramp_x3_linear(const float *x, const void *w_packed, const float *bias, float *y, int rows, const int32_t *rows_dev,
+                   void *stream);
+/* gru (LayerNorm, GatedResidual, LayerNorm, GatedResidual) with x = LayerNorm_pre((x32 (+ add0_t[add0_idx])) + add_t[add_idx])
+ * when add_t is given; relu32 (optional) = relu(out32); heads_w [4][384] / heads_b [4] fp32 (optional): the d / w heads and
+ * target / weight as ramp_upd_gru_heads, in fp32                                                                      */
+int ramp_x3_gru(const float *x32, const float *add0_t, const int32_t *add0_idx, const float *add_t, const int32_t *add_idx,
+                const float *pre_w, const float *pre_b, float pre_eps, const void *const *wp_host, const float *const *bias_host,
+                const float *ln_w, const float *ln_b, float eps, float *out32, float *relu32, int E, const float *heads_w,
+                const float *heads_b, const float *coords, float *target, float *weight, int P, float wd, float ht, void *stream);
+
 /* ---------------------------------------------------------------- device-resident tracking step
  *
  * Ramp_vo.__call__ in steady state (ramp/Ramp_vo.py:327-410): the frame's state stores, update() (:276-310:

@@ -437,12 +437,14 @@ class Ramp_vo:
             # the tracker's own per-frame call: same launch as below without the generic wrapper's checks (the
             # level descriptors of the fixed pyramid buffers are built once)
             return self._corr_launch(coords, ii, jj, order)
-        # ring-buffer slots (kk % (M*mem), jj % mem) are taken inside the kernel; fp16: rows padded 882 -> 896
-        # (16-byte aligned rows for the first Linear layer, update_fused.py)
+        # ring-buffer slots (kk % (M*mem), jj % mem) are taken inside the kernel; rows padded 882 -> 896
+        # (16-byte aligned rows for the first Linear layer, update_fused.py).  fp32 features: the tracker's own volume comes
+        # from corr_mfma_kernel<float> (the fp32 matrix cores' summation order, <= 1e-5 of the reference kernel's fmaf chain --
+        # 2.1x faster; altcorr.corr, the reference entry point, keeps the chain's order; RAMP_CORR_F32_MFMA=0: here too)
         return altcorr.corr_pyramid(self.gmap_.view(-1, 3, 3, 128), self.pyramid, coords[0], ii, jj, 3, (1, 4),
-                                    RAMP_NHWC32 if self._chunked else RAMP_NHWC, order=order,
-                                    row_elems=CORR_ROW if self.dtype == torch.half else 0,
-                                    mod_ii=self.M * self.mem, mod_jj=self.mem)
+                                    RAMP_NHWC32 if self._chunked else RAMP_NHWC, order=order, row_elems=CORR_ROW,
+                                    mod_ii=self.M * self.mem, mod_jj=self.mem,
+                                    fast_f32=os.environ.get("RAMP_CORR_F32_MFMA", "1") != "0")
 
     def _corr_launch(self, coords, ii, jj, order):
         """ramp_corr_fwd_ordered on the tracker's own buffers (fp16 chunked pyramid, padded rows)"""
@@ -883,15 +885,15 @@ class Ramp_vo:
         if patches is None or not dv.bind_front_end(ex, patches):
             self.settle()                           # outputs the one-launch commit cannot take: host-driven frame
             return self._track_tail(tstamp, out, intrinsics)
-        if not dv.fp32:
+        if not dv.fp32 or dv.x3:
             dv.bind_weights(self.network.update.fused(self.dtype))
         kq, k_dev = self._intrinsics_row(intrinsics, True)
         if k_dev is not None:
             dv.k_new.copy_(k_dev)
             self._last_K, self._last_K_raw = kq, self._K_raw_now
         self.tlist.append(tstamp)
-        if dv.fp32:
-            # MIXED_PRECISION off: the update operator's Linear layers are library GEMMs, issued from here between the two
+        if dv.fp32 and not dv.x3:
+            # MIXED_PRECISION off with RAMP_X3=0: the update operator's Linear layers are library GEMMs, issued from here between the two
             # halves of the step -- on the launch bound's rows, sizes never read back (csrc/track.hip RAMP_TRACK_UPDATE_PRE /
             # _POST); everything else as in the fp16 step
             Eb = dv.factor_bound(self.counter)

@@ -119,6 +119,15 @@ SIGNATURES = {
     "ramp_upd_softagg_frag_rows": (c_sz, [c_i, c_i]),
     "ramp_upd_softagg": (c_i, [c_p] * 10 + [c_i, c_p]),
     "ramp_upd_softagg_finish": (c_i, [c_p] * 6 + [c_i, c_p]),
+    # the update operator at fp32 accuracy on the f16 matrix cores (csrc/update_x3.hip)
+    "ramp_x3_corr_mlp": (c_i, [c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, ctypes.c_long,
+                               c_p, c_p, c_f, c_p, c_i, c_p]),
+    "ramp_x3_nbr": (c_i, [c_p] * 7 + [c_i, c_p]),
+    "ramp_x3_fg": (c_i, [c_p] * 9 + [c_i, c_p]),
+    "ramp_x3_segment_softmax": (c_i, [c_p] * 5 + [c_i, c_p]),
+    "ramp_x3_linear": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_p]),
+    "ramp_x3_gru": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, ctypes.POINTER(c_p), ctypes.POINTER(c_p), c_p, c_p, c_f,
+                          c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_f, c_p]),
     # device-resident tracking step (csrc/track.hip); the ramp_track descriptor is mirrored in track_dev.py
     "ramp_track_sizeof": (c_sz, []),
     "ramp_track_plan_workspace_bytes": (c_sz, [c_i, c_i, c_i]),

@@ -29,9 +29,9 @@ def corr(fmap1, fmap2, coords, ii, jj, radius=1, dropout=1):
 
 
 def corr_pyramid(gmap, pyramid, coords, ii, jj, radius=3, levels=(1, 4), layout=RAMP_NCHW, order=None,
-                 row_elems=0, mod_ii=0, mod_jj=0):
+                 row_elems=0, mod_ii=0, mod_jj=0, fast_f32=None):
     """fused form of Ramp_vo.corr (ramp/Ramp_vo.py:175-182): all levels in one
     launch, result already stacked as [1, E, (2r+1)^2 * P^2 * nlevels]."""
     out = ops.corr(gmap, list(pyramid), coords, ii, jj, radius, tuple(float(l) for l in levels),
-                   layout, order=order, row_elems=row_elems, mod_ii=mod_ii, mod_jj=mod_jj)
+                   layout, order=order, row_elems=row_elems, mod_ii=mod_ii, mod_jj=mod_jj, fast_f32=fast_f32)
     return out.view(1, out.shape[0], -1)

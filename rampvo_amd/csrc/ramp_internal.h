@@ -88,4 +88,17 @@ int ramp_i_upd_fg(const float *x32, const void *add_t, const int32_t *add_idx, f
 int ramp_i_upd_heads_linear(const void *relu_t, const void *heads_w, const float *heads_b, const float *coords,
                             float *target, float *weight, int E, int P, float wd, float ht, const int32_t *dyn,
                             void *stream);
+int ramp_i_x3_nbr(const float *net_in, const int64_t *idx, const void *wa, const float *ba, const void *wb, const float *bb,
+                  float *net_out, int E, const int32_t *dyn, void *stream);
+int ramp_i_x3_corr_mlp(const float *corr, int corr_k, const void *w1, const float *b1, const void *w2, const float *b2,
+                       const void *w3, const float *b3, const float *ln_w, const float *ln_b, float ln_eps, const float *net,
+                       const int64_t *net_map, const float *inp, const int64_t *inp_idx, long inp_mod, const float *norm_w,
+                       const float *norm_b, float norm_eps, float *net_out, int E, const int32_t *dyn, void *stream);
+int ramp_i_x3_fg(const float *x32, const float *add_t, const int32_t *add_idx, float *x32_out, const void *wf, const float *bf,
+                 const void *wg, const float *bg, float *fg, int E, const int32_t *dyn, void *stream);
+int ramp_i_x3_gru(const float *x32, const float *add0_t, const int32_t *add0_idx, const float *add_t, const int32_t *add_idx,
+                  const float *pre_w, const float *pre_b, float pre_eps, const void *const *wp_host,
+                  const float *const *bias_host, const float *ln_w, const float *ln_b, float eps, float *out32, float *relu32,
+                  int E, const int32_t *dyn, const float *heads_w, const float *heads_b, const float *coords, float *target,
+                  float *weight, int P, float wd, float ht, uint32_t *gate_flag, uint32_t gate_seq, void *stream);
 }

@@ -691,7 +691,12 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
     else if (hipEventRecord((hipEvent_t)t->spec_ev_done, ax) != hipSuccess) return RAMP_ELAUNCH;
     RAMP_CHECK_LAUNCH();
   }
-  if ((flags & RAMP_TRACK_UPDATE) && t->feat_fp32) return RAMP_EUNSUPPORTED;   // (fp32: PRE, the caller's operator, POST)
+  // fp32 features: the correlation launch is corr_mfma_kernel<float> (RAMP_CORR_F32_MFMA=0: corr_kernel<float>, the reference
+  // kernel's summation order) with rows padded to 896 floats, the operator csrc/update_x3.hip's chains; PRE / POST around a
+  // caller-run operator remain (RAMP_X3=0: library GEMMs)
+  static int corr32_fast = -1;
+  if (corr32_fast < 0) { const char *e = getenv("RAMP_CORR_F32_MFMA"); corr32_fast = e ? atoi(e) : 1; }
+  const int f32_code = RAMP_F32 | (corr32_fast ? RAMP_CORR_MFMA32 : 0);
   if (flags & RAMP_TRACK_UPDATE_PRE) {
     if (!t->coords || !t->corr) return RAMP_EINVAL;
     TRK_DO(ramp_i_transform_dyn(t->poses, t->patches, t->intrinsics, ii, jj, kk, t->coords, Eb, dyn, st));
@@ -700,8 +705,8 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
     lv[1].fmap = t->fmap2; lv[1].H2 = t->feat_h / 4; lv[1].W2 = t->feat_w / 4; lv[1].coord_div = 4.0f;
     TRK_PROBE(0);
     if (t->feat_fp32)
-      TRK_DO(ramp_i_corr_fwd(t->gmap, lv, 2, t->coords, kk, jj, t->ij_order, t->corr, 882, (long)t->M * t->mem, t->mem, Eb,
-                             t->mem * t->M, t->mem, 128, t->P, 3, RAMP_F32, RAMP_NHWC, dyn, st, nullptr, nullptr, nullptr, nullptr,
+      TRK_DO(ramp_i_corr_fwd(t->gmap, lv, 2, t->coords, kk, jj, t->ij_order, t->corr, 896, (long)t->M * t->mem, t->mem, Eb,
+                             t->mem * t->M, t->mem, 128, t->P, 3, f32_code, RAMP_NHWC, dyn, st, nullptr, nullptr, nullptr, nullptr,
                              t->fmap1_slot));
     else
       TRK_DO(ramp_i_corr_fwd(t->gmap, lv, 2, t->coords, kk, jj, t->ij_order, t->corr, 896, (long)t->M * t->mem, t->mem, Eb,
@@ -742,6 +747,46 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
     lv[0].fmap = t->fmap1; lv[0].H2 = t->feat_h; lv[0].W2 = t->feat_w; lv[0].coord_div = 1.0f;
     lv[1].fmap = t->fmap2; lv[1].H2 = t->feat_h / 4; lv[1].W2 = t->feat_w / 4; lv[1].coord_div = 4.0f;
     TRK_PROBE(0);
+    static int gate_at = -1;
+    if (gate_at < 0) { const char *e = getenv("RAMP_GATE_AT"); gate_at = e ? atoi(e) : 2; if (gate_at < 0 || gate_at > 3) gate_at = 2; }
+    if (t->feat_fp32) {
+      // ---- fp32 features (MIXED_PRECISION off): the same step with csrc/update_x3.hip's chains (Linear layers on the f16
+      // matrix cores from split fp32 operands), fp32 tables, [f | g] rows + segment softmax + h for the two SoftAggs
+      TRK_DO(ramp_i_corr_fwd(t->gmap, lv, 2, t->coords, kk, jj, t->ij_order, t->corr, 896, (long)t->M * t->mem, t->mem, Eb,
+                             t->mem * t->M, t->mem, 128, t->P, 3, f32_code, RAMP_NHWC, dyn, st, nullptr, nullptr, nullptr,
+                             nullptr, t->fmap1_slot));
+      TRK_PROBE(1);
+#define TRK_GATE32(pos)                                                                                   \
+  do {                                                                                                    \
+    if (gate_at == (pos) && !(t->gate_flag && (pos) == 0)) {                                              \
+      if (t->gate_flag) hipLaunchKernelGGL(trk_signal_kernel, dim3(1), dim3(1), 0, st, t->gate_flag, t->gate_seq); \
+      else if (gate_event && hipEventRecord((hipEvent_t)gate_event, st) != hipSuccess) return RAMP_ELAUNCH; \
+    }                                                                                                     \
+  } while (0)
+      const float *corr32 = (const float *)t->corr;
+      float *fg32 = (float *)t->fg, *ykk = (float *)t->ykk, *hkk = (float *)t->hkk, *yij = (float *)t->yij, *hij = (float *)t->hij;
+      TRK_DO(ramp_i_x3_corr_mlp(corr32, 896, w.corr_w1, w.corr_b1, w.corr_w2, w.corr_b2, w.corr_w3, w.corr_b3, w.corr_ln_w,
+                                w.corr_ln_b, w.corr_ln_eps, t->net[0], row, (const float *)t->imap, kk, (long)t->M * t->mem,
+                                w.norm_w, w.norm_b, w.norm_eps, t->net[1], Eb, dyn, st));
+      TRK_GATE32(3);
+      TRK_DO(ramp_i_x3_nbr(t->net[1], t->ix, w.c1_wa, w.c1_ba, w.c1_wb, w.c1_bb, t->net[2], Eb, dyn, st));
+      TRK_DO(ramp_i_x3_nbr(t->net[2], t->jx, w.c2_wa, w.c2_ba, w.c2_wb, w.c2_bb, t->net[1], Eb, dyn, st));
+      float *net32 = t->net[1];
+      TRK_GATE32(2);
+      TRK_DO(ramp_i_x3_fg(net32, nullptr, nullptr, nullptr, w.kk_wf, w.kk_bf, w.kk_wg, w.kk_bg, fg32, Eb, dyn, st));
+      TRK_DO(ramp_x3_segment_softmax(fg32, t->kk_order, t->kk_seg, t->kk_ngroups, ykk, t->kk_cap, stream));
+      TRK_DO(ramp_x3_linear(ykk, w.kk_wh, w.kk_bh, hkk, t->kk_cap, t->kk_ngroups, stream));
+      TRK_GATE32(1);
+      TRK_DO(ramp_i_x3_fg(net32, hkk, t->kk_gid, nullptr, w.ij_wf, w.ij_bf, w.ij_wg, w.ij_bg, fg32, Eb, dyn, st));
+      TRK_DO(ramp_x3_segment_softmax(fg32, t->ij_order, t->ij_seg, t->ij_ngroups, yij, t->ij_cap, stream));
+      TRK_DO(ramp_x3_linear(yij, w.ij_wh, w.ij_bh, hij, t->ij_cap, t->ij_ngroups, stream));
+      TRK_GATE32(0);
+      TRK_DO(ramp_i_x3_gru(net32, hkk, t->kk_gid, hij, t->ij_gid, w.ln1_w, w.ln1_b, w.ln1_eps, w.gru_w, w.gru_b, w.ln2_w, w.ln2_b,
+                           w.ln2_eps, t->net[0], nullptr, Eb, dyn, (const float *)w.heads_w, w.heads_b, t->coords, t->target,
+                           t->weight, t->P, (float)t->feat_w, (float)t->feat_h, gate_at == 0 ? t->gate_flag : nullptr,
+                           t->gate_seq, st));
+#undef TRK_GATE32
+    } else {
     // RAMP_CORR_L1=1 (first clause): the correlation launch multiplies its rows by the correlation MLP's first
     // Linear itself (csrc/altcorr.hip::corr_l1_kernel) and hands c1 [E][384] on -- in t->corr's storage, the [E][896]
     // rows are never written -- to the tail-only correlation MLP.  Bit-identical; measured slower, off.
@@ -779,8 +824,6 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
     // +2.1 % MultiScale against 0; 0 = before the gru chain (rounds 2-3); 1 = before the second SoftAgg; 3 = before c1 / c2).
     // The "go" is a word stored by the first workgroup of the launch behind that point (t->gate_flag: gru, SoftAgg), a
     // one-thread launch where that kernel cannot (the three-launch SoftAgg, c1), or the caller's event.
-    static int gate_at = -1;
-    if (gate_at < 0) { const char *e = getenv("RAMP_GATE_AT"); gate_at = e ? atoi(e) : 2; if (gate_at < 0 || gate_at > 3) gate_at = 2; }
     static int sagg = -1;
     if (sagg < 0) { const char *e = getenv("RAMP_SOFTAGG"); sagg = e ? atoi(e) : 1; }
     const bool use_sagg = sagg && t->sagg_frag;
@@ -838,6 +881,7 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
     TRK_DO(ramp_i_upd_gru(net, add2 ? t->hkk : nullptr, add2 ? t->kk_gid : nullptr, t->hij, t->ij_gid, w.ln1_w, w.ln1_b, w.ln1_eps, w.gru_w, w.gru_b, w.ln2_w, w.ln2_b,
                           w.ln2_eps, t->net[0], nullptr, Eb, dyn, w.heads_w, w.heads_b, t->coords, t->target, t->weight, t->P,
                           (float)t->feat_w, (float)t->feat_h, t->E_hint, gate_at == 0 ? t->gate_flag : nullptr, t->gate_seq, st));
+    }   // (fp16 features)
     TRK_PROBE(2);
     TRK_PROBE(3);
     TRK_DO(ramp_i_ba_dyn(t->poses, t->patches, t->intrinsics, t->target, t->weight, t->lmbda, ii, jj, kk, Eb, t->P,

@@ -155,12 +155,16 @@ class DeviceTrack:
         # (zeroed: the plan's histograms are cleared by each plan at its end instead of by a memset launch at its start)
         self.plan_ws = z(lib.ramp_track_plan_workspace_bytes(E_cap, self.kkey_cap, self.pkey_cap), torch.uint8)
         self.fp32 = slam.dtype == torch.float
+        # fp32 features: the operator's chains are csrc/update_x3.hip's (one C call per frame, as on the fp16 path) unless
+        # RAMP_X3=0 (library GEMMs issued by the host between the two halves of the step)
+        self.x3 = self.fp32 and slam.network.update.fused(torch.float32).use_x3
         self.coords = e((E_cap, 2, 3, 3), f32)
-        self.corr = e((E_cap, 882), f32) if self.fp32 else e((E_cap, CORR_ROW), f16)
+        self.corr = e((E_cap, CORR_ROW), f32 if self.fp32 else f16)
         self.net = [z((E_cap, 384), f32) for _ in range(3)]
-        self.fg = e((16 if self.fp32 else E_cap, 768), f16)
-        self.ykk, self.hkk = z((kk_cap, 384), f16), z((kk_cap, 384), f16)
-        self.yij, self.hij = z((ij_cap, 384), f16), z((ij_cap, 384), f16)
+        tt = f32 if self.fp32 else f16                 # SoftAgg rows / tables
+        self.fg = e((16 if (self.fp32 and not self.x3) else E_cap, 768), tt)
+        self.ykk, self.hkk = z((kk_cap, 384), tt), z((kk_cap, 384), tt)
+        self.yij, self.hij = z((ij_cap, 384), tt), z((ij_cap, 384), tt)
         self.relu_t = e((16 if self.fp32 else E_cap, 384), f16)
         # fragment table of the fused SoftAgg (csrc/update_mlp.hip::upd_softagg_kernel): (m, z, a)[384] per run
         self.sagg_frag = e((16 if self.fp32 else lib.ramp_upd_softagg_frag_rows(E_cap, max(kk_cap, ij_cap)), 3, 384), f32)

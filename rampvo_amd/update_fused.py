@@ -29,6 +29,26 @@ def pack_linear_f16(weight):
     return w.view(N // 16, 16, K // 32, 4, 8).permute(2, 0, 3, 1, 4).contiguous()
 
 
+def pack_linear_x3(weight):
+    """nn.Linear weight [N = 384, K] (K a multiple of 32) -> the split-fp16 pack of csrc/update_x3.hip: a flat fp16 tensor
+    [K/32][N/16][2][64 lanes][8] -- plane 0 = fp16(W 2^s), plane 1 = fp16(W 2^s - plane 0), fragment order as
+    pack_linear_f16 -- followed by the float 2^-s (as two fp16 slots) and padding to 16 bytes; s is the power of two that
+    puts max |W| into [2^12, 2^13): the high part, the high part times 2^-11 and the low part are then fp16 NORMAL numbers"""
+    import math
+    w = weight.detach().float()
+    N, K = w.shape
+    assert N == 384 and K % 32 == 0
+    amax = float(w.abs().max())
+    s = 13 - math.frexp(amax)[1] if amax > 0 and math.isfinite(amax) else 0      # amax = m 2^e, m in [0.5, 1)
+    ws = w * (2.0 ** s)                                    # exact
+    hi = ws.half()
+    lo = (ws - hi.float()).half()
+    frag = lambda t: t.view(N // 16, 16, K // 32, 4, 8).permute(2, 0, 3, 1, 4)          # [K/32][N/16][4][16][8]
+    planes = torch.stack([frag(hi), frag(lo)], dim=2).contiguous().view(-1)                 # [K/32][N/16][2][64][8]
+    inv = torch.tensor([2.0 ** -s], dtype=torch.float32, device=w.device).view(torch.float16)
+    return torch.cat([planes, inv, torch.zeros(6, dtype=torch.float16, device=w.device)]).contiguous()
+
+
 class FusedUpdate:
     def __init__(self, update, dtype):
         self.m = update
@@ -41,6 +61,9 @@ class FusedUpdate:
         self.use_corr_mlp = os.environ.get("RAMP_CORR_MLP", "1") == "1"
         self.use_nbr2 = os.environ.get("RAMP_NBR2", "0") == "1"      # c1 + c2 as one launch (A/B switch; measured slower)
         self.use_softagg = os.environ.get("RAMP_SOFTAGG", "1") == "1"   # SoftAgg without the [f | g] rows (csrc/update_mlp.hip)
+        # fp32: the Linear layers on the f16 matrix cores from split operands (csrc/update_x3.hip), fused chains as on the
+        # fp16 path; RAMP_X3=0: library GEMMs + the row kernels of csrc/update.hip (A/B runs)
+        self.use_x3 = dtype == torch.float32 and os.environ.get("RAMP_X3", "1") == "1"
         self.before_gru = None                   # optional callable run right before a stage is enqueued
         self.hook_at = "gru"
 
@@ -98,6 +121,23 @@ class FusedUpdate:
             w["heads_pack"] = (w["heads"][0], w["heads"][1].float().contiguous())
             w["tail_pack"] = (pack_linear_f16(m.corr[2].weight), hb(m.corr[2]), pack_linear_f16(m.corr[5].weight),
                               hb(m.corr[5]))
+        if self.use_x3:
+            import ctypes
+            f32 = lambda t: t.detach().float().contiguous()
+            px = lambda l, pad=0: (pack_linear_x3(F.pad(l.weight, (0, pad)) if pad else l.weight), f32(l.bias))
+            gru = [m.gru[1].gate[0], m.gru[1].res[0], m.gru[1].res[2], m.gru[3].gate[0], m.gru[3].res[0], m.gru[3].res[2]]
+            wp = [pack_linear_x3(l.weight) for l in gru]
+            bs = [f32(l.bias) for l in gru]
+            w["gru_pack"] = (wp, bs, (ctypes.c_void_p * 6)(*[t.data_ptr() for t in wp]),
+                             (ctypes.c_void_p * 6)(*[t.data_ptr() for t in bs]))
+            w["c1_pack"] = px(m.c1[0]) + px(m.c1[2])
+            w["c2_pack"] = px(m.c2[0]) + px(m.c2[2])
+            w["kk_fg_pack"] = px(m.agg_kk.f) + px(m.agg_kk.g)
+            w["ij_fg_pack"] = px(m.agg_ij.f) + px(m.agg_ij.g)
+            w["kk_h_pack"], w["ij_h_pack"] = px(m.agg_kk.h), px(m.agg_ij.h)
+            w["corr1_pack"] = px(m.corr[0], CORR_ROW - m.corr[0].weight.shape[1])
+            w["tail_pack"] = px(m.corr[2]) + px(m.corr[5])
+            w["heads_pack"] = (f32(torch.cat([m.d[1].weight, m.w[1].weight], 0)), f32(torch.cat([m.d[1].bias, m.w[1].bias], 0)))
         self._w, self._key = w, key
         return w
 
@@ -192,6 +232,8 @@ class FusedUpdate:
         self._bufs = (net32_buf, out32_buf)
         w = self.weights()
         E = corr.shape[0]
+        if self.use_x3:
+            return self._hidden_x3(w, net, inp_table, inp_idx, inp_mod, corr, plan, net_map, heads_at)
         if corr.shape[1] == 384:
             # c1 = relu(Linear1(corr)) already: the fused correlation + Linear1 launch (ramp_corr_l1_fwd_ordered)
             if not ("tail_pack" in w and self.use_mlp):
@@ -254,6 +296,80 @@ class FusedUpdate:
         y = self.lin(self.lin_relu(g, w["c2a"]), w["c2b"])
         _, net_t = self.row_fuse(E, A=net32, B=y, out_f32=net32, want_t=True)
         return self._tail(w, E, net32, net_t, plan)
+
+    def _hidden_x3(self, w, net, inp_table, inp_idx, inp_mod, corr, plan, net_map, heads_at):
+        """the fp32 operator as six fused launches + the two SoftAgg tables (csrc/update_x3.hip); the device-resident step
+        (csrc/track.hip) makes the same launches"""
+        E, dev = corr.shape[0], corr.device
+        f32 = torch.float32
+        if E == 0:
+            z = torch.zeros(0, 384, dtype=f32, device=dev)
+            self.last_tw = (torch.zeros(1, 0, 2, dtype=f32, device=dev), torch.zeros(1, 0, 2, dtype=f32, device=dev))
+            return z, None
+        if corr.shape[1] != CORR_ROW:          # (a caller with dense [E, 882] rows: zero tail for the 16-byte row loads)
+            corr = F.pad(corr, (0, CORR_ROW - corr.shape[1]))
+        corr = corr.contiguous()
+        inp_table = inp_table.float() if inp_table.dtype != f32 else inp_table
+        w1, b1 = w["corr1_pack"]
+        w2, b2, w3, b3 = w["tail_pack"]
+        ln, nm = w["corr_ln"], w["norm"]
+        a = torch.empty(E, 384, dtype=f32, device=dev)
+        b = torch.empty(E, 384, dtype=f32, device=dev)
+        check(lib().ramp_x3_corr_mlp(ptr(corr), CORR_ROW, ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3), ptr(ln[0]),
+                                     ptr(ln[1]), float(ln[2]), ptr(net), ptr(net_map), ptr(inp_table), ptr(inp_idx),
+                                     int(inp_mod or 0), ptr(nm[0]), ptr(nm[1]), float(nm[2]), ptr(a), E, stream()),
+              "ramp_x3_corr_mlp")
+        if self.before_gru is not None and self.hook_at == "nbr":
+            self.before_gru()
+        wa, ba, wb, bb = w["c1_pack"]
+        check(lib().ramp_x3_nbr(ptr(a), ptr(plan.ix_raw), ptr(wa), ptr(ba), ptr(wb), ptr(bb), ptr(b), E, stream()), "ramp_x3_nbr")
+        wa, ba, wb, bb = w["c2_pack"]
+        check(lib().ramp_x3_nbr(ptr(b), ptr(plan.jx_raw), ptr(wa), ptr(ba), ptr(wb), ptr(bb), ptr(a), E, stream()), "ramp_x3_nbr")
+        if self.before_gru is not None and self.hook_at == "softagg":
+            self.before_gru()
+        fg = torch.empty(E, 768, dtype=f32, device=dev)
+
+        def softagg(add_t, add_idx, fg_pack, h_pack, groups, max_groups):
+            G = max(int(max_groups), 1)
+            wf, bf, wg, bg = fg_pack
+            check(lib().ramp_x3_fg(ptr(a), ptr(add_t), ptr(add_idx), None, ptr(wf), ptr(bf), ptr(wg), ptr(bg), ptr(fg), E,
+                                   stream()), "ramp_x3_fg")
+            y = torch.empty(G, 384, dtype=f32, device=dev)
+            check(lib().ramp_x3_segment_softmax(ptr(fg), ptr(groups.order), ptr(groups.seg_start), ptr(groups.ngroups), ptr(y),
+                                                G, stream()), "ramp_x3_segment_softmax")
+            hy = torch.zeros(G, 384, dtype=f32, device=dev)
+            check(lib().ramp_x3_linear(ptr(y), ptr(h_pack[0]), ptr(h_pack[1]), ptr(hy), G, ptr(groups.ngroups), stream()),
+                  "ramp_x3_linear")
+            return hy
+        # (the pair SoftAgg reads net + hkk[patch group] without writing the sum back; the gru launch forms
+        # (net + hkk[.]) + hij[.] itself: the same fp32 additions in the same order)
+        hkk = softagg(None, None, w["kk_fg_pack"], w["kk_h_pack"], plan.g_kk, plan.max_kk)
+        hij = softagg(hkk, plan.g_kk.gid, w["ij_fg_pack"], w["ij_h_pack"], plan.g_ij, plan.max_ij)
+        if self.before_gru is not None and self.hook_at == "gru":
+            self.before_gru()
+        _, _, wptr, bptr = w["gru_pack"]
+        ln1, ln2 = w["ln1"], w["ln2"]
+        out32 = b
+        target = weight = relu32 = None
+        hw = hb = coords = None
+        wd = ht = 0.0
+        P = 3
+        if heads_at is not None:
+            coords, wd, ht = heads_at
+            P = coords.shape[-1]
+            hw, hb = w["heads_pack"]
+            target = torch.empty(1, E, 2, dtype=f32, device=dev)
+            weight = torch.empty(1, E, 2, dtype=f32, device=dev)
+        else:
+            relu32 = torch.empty(E, 384, dtype=f32, device=dev)
+        check(lib().ramp_x3_gru(ptr(a), ptr(hkk), ptr(plan.g_kk.gid), ptr(hij), ptr(plan.g_ij.gid), ptr(ln1[0]), ptr(ln1[1]),
+                                float(ln1[2]), wptr, bptr, ptr(ln2[0]), ptr(ln2[1]), float(ln2[2]), ptr(out32), ptr(relu32), E,
+                                ptr(hw), ptr(hb), ptr(coords), ptr(target), ptr(weight), int(P), float(wd), float(ht), stream()),
+              "ramp_x3_gru")
+        if heads_at is not None:
+            self.last_tw = (target, weight)
+            return out32, None
+        return out32, relu32
 
     def _tail(self, w, E, net32, net_t, plan):
         """SoftAgg x2 and the gru block, from the state after c1 / c2"""
