@@ -88,6 +88,9 @@ def parse():
                     help="untimed steady-state steps for at least this long right before the warm-up steps, so that a "
                          "short timed region (the driver's --steps 20 is ~30 ms) runs at settled clocks")
     ap.add_argument("--clock-warm-max", type=int, default=480, help="cap of the clock-warm phase in frames")
+    ap.add_argument("--fp32-leg", type=int, default=60,
+                    help="(with --mixed 1, rank 0, N = 1) timed steps of the same workload with MIXED_PRECISION off, run as "
+                         "`bench.py --mixed 0` in a process of its own behind everything else -> config.fp32_kfps (0 = skip)")
     ap.add_argument("--parity", type=int, default=1,
                     help="1: after the timed region, one teacher-forced update() from the run's snapshot on HIP fp16 / "
                          "HIP fp32 / the CPU oracle, and the free-running trajectory check (rank 0, N = 1)")
@@ -204,7 +207,7 @@ class CorrTimer:
         h, w = slam.ht // slam.RES, slam.wd // slam.RES
         frames = int(len(np.unique(slam._jj % slam.mem)))
         patches = int(len(np.unique(slam._kk % (slam.M * slam.mem))))
-        out_row = (896 if elem_bytes == 2 else 882) * elem_bytes
+        out_row = 896 * elem_bytes
         compulsory = (frames * 128 * (h * w + (h // 4) * (w // 4)) * elem_bytes + patches * 128 * 9 * elem_bytes
                       + E * (72 + 16 + 4) + E * out_row)
         # SURVEY 8(d)'s per-edge model (every edge reads its 10x10 window privately; two levels per launch): counts
@@ -216,7 +219,8 @@ class CorrTimer:
         traffic = int(per_edge * E) if per_edge else None
         flops = E * 2 * CORR_FLOP_PER_EDGE_LEVEL
         peak_tf = MFMA_F16_PEAK_TFLOPS if elem_bytes == 2 else MFMA_F32_PEAK_TFLOPS
-        out = dict(kernel="corr_mfma_kernel<half>" if elem_bytes == 2 else "corr_kernel<float>", bound="hbm",
+        f32_kernel = "corr_mfma_kernel<float>" if os.environ.get("RAMP_CORR_F32_MFMA", "1") != "0" else "corr_kernel<float>"
+        out = dict(kernel="corr_mfma_kernel<half>" if elem_bytes == 2 else f32_kernel, bound="hbm",
                    achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, launches=int(big.sum()),
                    mean_launch_us=round(mean_ms * 1e3, 1), bytes_per_launch=int(compulsory),
@@ -248,7 +252,7 @@ class DeviceProbe:
         self.mode, self.modes = "all", []              # "corr": only the correlation launch is bracketed (the timed region)
         self.corr_inst_ms = []
         self.live_pairs, self.live_edges = {"live": [], "compact": []}, {"live": [], "compact": []}
-        self.fp32, self.cur = False, None
+        self.fp32, self.cur = False, None       # fp32: the operator is launched from Python (fp32 features with RAMP_X3=0)
 
     def install(self):
         from rampvo_amd import track_dev
@@ -263,7 +267,7 @@ class DeviceProbe:
                 if on:
                     probe.edges.append(int(dv.lazy_state()[track_dev.DYN_E]))      # a frame or two old: fine for a mean
                     probe.modes.append(probe.mode)
-                    probe.fp32 = bool(getattr(dv, "fp32", False))
+                    probe.fp32 = bool(getattr(dv, "fp32", False)) and not bool(getattr(dv, "x3", False))   # (RAMP_X3=0)
                     probe.used += 1
             elif not (flags & track_dev.UPDATE_POST):
                 probe.cur = None
@@ -323,9 +327,13 @@ class UpdateTimer:
         edges = np.array(self.edges, dtype=np.float64)
         big = edges > 0.5 * edges.max()
         E, mean_ms = float(edges[big].mean()), float(ms[big].mean())
-        peak = MFMA_F16_PEAK_TFLOPS if mixed else MFMA_F32_PEAK_TFLOPS
+        x3 = (not mixed) and os.environ.get("RAMP_X3", "1") == "1"
+        # fp32 features: every product is three f16 MFMA products (split operands, csrc/update_x3.hip): the bound of the
+        # ALGORITHMIC flops is a third of the f16 peak (RAMP_X3=0: library GEMMs on the f32 MFMA)
+        peak = MFMA_F16_PEAK_TFLOPS if mixed else (round(MFMA_F16_PEAK_TFLOPS / 3.0, 1) if x3 else MFMA_F32_PEAK_TFLOPS)
         ach = E * UPDATE_FLOP_PER_EDGE / (mean_ms * 1e-3) / 1e12
-        out = dict(kernel="update operator: upd_corr_mlp + upd_nbr x2 + (upd_fg + segment softmax + h GEMM) x2 + upd_gru",
+        out = dict(kernel=("update operator (fp32 accuracy, f16x3): x3_corr_mlp + x3_nbr x2 + (x3_fg + x3_segment_softmax + x3_linear) x2 + x3_gru"
+                           if x3 else "update operator: upd_corr_mlp + upd_nbr x2 + (upd_fg + segment softmax + h GEMM) x2 + upd_gru"),
                    bound="mfma", achieved=round(ach, 1), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
                    mean_call_us=round(mean_ms * 1e3, 1), edges=int(E), flop_per_edge=UPDATE_FLOP_PER_EDGE,
                    note="18 Linear layers of 384 (one of K = 882) per edge, SURVEY 8(d)'s 5.40 MFLOP/edge; the "
@@ -615,6 +623,46 @@ def parity_block(state, args, cfg_kwargs, net, dev):
     return out
 
 
+def fp32_leg(args, traj_fp32):
+    """The same workload with MIXED_PRECISION off -- fp32 features, correlation volume, hidden state; the update operator's
+    Linear layers at fp32 accuracy (csrc/update_x3.hip) -- the precision whose poses / depths agree with the reference to
+    north_star's 1e-4 (the fp16 headline is default.yaml's autocast policy, a few 1e-3): a short timed run of this script in a
+    process of its own, behind everything else of rank 0 (N = 1).  Returns the keys merged into `config`."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--mixed", "0", "--steps", str(args.fp32_leg), "--warmup", "10",
+           "--cpu-steps", "0", "--parity", "0", "--fp32-leg", "0", "--np-steps", "0", "--live-steps", "0", "--inst-steps", "40",
+           "--height", str(args.height), "--width", str(args.width), "--patches", str(args.patches), "--mode", args.mode,
+           "--preset", args.preset, "--prime", str(args.prime), "--pipeline", str(args.pipeline)]
+    if args.opt_window:
+        cmd += ["--opt-window", str(args.opt_window)]
+    if args.keyframe_thresh is not None:
+        cmd += ["--keyframe-thresh", str(args.keyframe_thresh)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK",
+                                                            "ROLE_RANK", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    tic = time.perf_counter()
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        raise RuntimeError("bench.py: the fp32 leg failed (rc %d): %s" % (r.returncode, r.stderr[-1500:]))
+    d = json.loads(lines[-1])
+    out = {"fp32_kfps": d["value"], "fp32_ms_per_step": d["ms_per_step"],
+           "fp32_leg": {"what": "the same workload and stream with MIXED_PRECISION off (`bench.py --mixed 0`): %d timed steps in a "
+                                "process of its own behind this one's measurements (%.0f s incl. start-up and priming)"
+                                % (d["steps"], time.perf_counter() - tic),
+                        "edges": d["config"].get("edges"), "frame_pipelining": d["config"].get("frame_pipelining"),
+                        "roofline": {k: d.get("roofline", {}).get(k) for k in ("kernel", "mean_launch_us", "achieved", "frac",
+                                                                               "edges_per_launch")},
+                        "roofline_update": {k: (d.get("roofline_update") or {}).get(k)
+                                            for k in ("kernel", "mean_call_us", "achieved", "peak", "frac", "edges")},
+                        "roofline_encoder_mean_front_end_us": (d.get("roofline_encoder") or {}).get("mean_front_end_us"),
+                        "roofline_ba_mean_call_us": (d.get("roofline_ba") or {}).get("mean_call_us")}}
+    if traj_fp32:
+        # (this process's parity block: the fp32 tracker -- the same kernels -- free running against the reference's own run)
+        out["fp32_traj_rel_vs_reference"] = traj_fp32.get("rel")
+        out["fp32_ate_vs_reference"] = traj_fp32.get("ate_vs_reference")
+    return out
+
+
 def _which_config(args, world):
     """names the BASELINE.json config the flags amount to (every rank of an N > 1 run tracks the same workload on its
     own sequence; configs[3] = --config 3)"""
@@ -814,7 +862,7 @@ def main():
     dt = time.perf_counter() - tic
     gate_kind = "signal word stored by the gru launch" if getattr(slam, "_gate_by_flag", False) else "event"
     ctimer.enabled = etimer.enabled = btimer.enabled = utimer.enabled = False
-    fp32_dev = device_step and bool(getattr(dv, "fp32", False))
+    fp32_dev = device_step and bool(getattr(dv, "fp32", False)) and not bool(getattr(dv, "x3", False))
     if dprobe is not None and device_step:
         dprobe.mode, etimer.enabled, utimer.enabled = "all", True, fp32_dev
         for _ in range(n_inst):
@@ -923,7 +971,11 @@ def main():
                                                ", fp8-MFMA encoder" if args.encoder_fp8 else "",
                                                ", fp32 everywhere" if not args.mixed else "",
                                                ", device-resident steps with the operator's GEMMs launched by the host"
-                                               if (not args.mixed and device_step) else "",
+                                               if fp32_dev else "",
+                                               ", device-resident steps (the operator's Linear layers: split-fp16 operands on the "
+                                               "f16 matrix cores, fp32 accumulate -- csrc/update_x3.hip; correlation: "
+                                               "corr_mfma_kernel<float>)"
+                                               if (not args.mixed and device_step and not fp32_dev) else "",
                                                ", frame pipelining off" if not args.pipeline else "",
                                                ", host-driven steps (RAMP_DEVICE_STEP=0)"
                                                if os.environ.get("RAMP_DEVICE_STEP", "1") != "1" else ""])),
@@ -1000,6 +1052,8 @@ def main():
             tr = out["parity"].get("trajectory", {})
             if "fp32" in tr:
                 out["ate_vs_oracle"] = tr["fp32"]["ate_vs_reference"]
+        if solo and args.mixed and args.fp32_leg > 0 and _which_config(args, world):
+            out["config"].update(fp32_leg(args, out.get("parity", {}).get("trajectory", {}).get("fp32")))
         if n_cpu:
             cpu_frames = [stream.frame(total + i) for i in range(n_cpu)]
             cpu_frames = [tuple(x.cpu() for x in f) for f in cpu_frames]

@@ -744,9 +744,8 @@ def test_speculative_keyframe_edit_does_not_change_the_tracker():
 
 
 def test_bench_runs_the_fp32_path():
-    """bench.py --mixed 0: the fp32 tracker's steps are device resident too (two C calls around the operator's library GEMMs,
-    which the host launches; nothing is read back) -- correlation / BA legs from the step's probes, the operator's from the
-    Python-level hook"""
+    """bench.py --mixed 0: the fp32 tracker's steps are device resident too (one C call per frame, the operator's chains are
+    csrc/update_x3.hip's) -- correlation / operator / BA legs from the step's probes"""
     import json
     import os
     import subprocess
