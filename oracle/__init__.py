@@ -61,6 +61,53 @@ def ba_f64(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t1
     return p, pt
 
 
+def _un64(name, x, din, dout):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    shp = x.shape[:-1]
+    x2 = np.ascontiguousarray(x.reshape(-1, din))
+    out = np.empty((x2.shape[0], dout), np.float64)
+    getattr(lib64(), name)(_p(x2), _p(out), x2.shape[0])
+    return out.reshape(shp + (dout,))
+
+
+def _bin64(name, x, y, dx, dy, dout):
+    x, y = np.asarray(x, np.float64), np.asarray(y, np.float64)
+    bs = np.broadcast_shapes(x.shape[:-1], y.shape[:-1])
+    x2 = np.ascontiguousarray(np.broadcast_to(x, bs + (dx,)).reshape(-1, dx))
+    y2 = np.ascontiguousarray(np.broadcast_to(y, bs + (dy,)).reshape(-1, dy))
+    out = np.empty((x2.shape[0], dout), np.float64)
+    getattr(lib64(), name)(_p(x2), _p(y2), _p(out), x2.shape[0])
+    return out.reshape(bs + (dout,))
+
+
+# the SE3 forward ops of the fp64 build (oracle/refharness.py serves float64 tensors of the reference's python with them:
+# ramp/ba.py + ramp/projective_ops.py in float64 are the independent pin of the bundle-adjustment restatement)
+def se3_exp_f64(a): return _un64("orc_se3_exp", a, 6, 7)
+def se3_log_f64(X): return _un64("orc_se3_log", X, 7, 6)
+def se3_inv_f64(X): return _un64("orc_se3_inv", X, 7, 7)
+def se3_mul_f64(X, Y): return _bin64("orc_se3_mul", X, Y, 7, 7, 7)
+def se3_act4_f64(X, p): return _bin64("orc_se3_act4", X, p, 7, 4, 4)
+def se3_adj_f64(X, a): return _bin64("orc_se3_adj", X, a, 7, 6, 6)
+def se3_adjT_f64(X, a): return _bin64("orc_se3_adjT", X, a, 7, 6, 6)
+
+
+def ba_edge_terms(poses, patches, intrinsics, ii, jj, kk, f64=False):
+    """per-factor terms of the bundle-adjustment kernel (ba_cuda.cu:232-376 as restated in ramp_oracle.c::ba_edge_terms):
+    returns dict(Ji [E,2,6] -- the kernel's sign: d/d(pose i) = -Ji --, Jj [E,2,6], Jz [E,2], xy [E,2] projected centres)"""
+    T = np.float64 if f64 else np.float32
+    L = lib64() if f64 else lib()
+    c = lambda a: np.ascontiguousarray(a, dtype=T)
+    P = patches.shape[-1]
+    poses, patches, intrinsics = c(poses).reshape(-1, 7), c(patches).reshape(-1, 3, P, P), c(intrinsics).reshape(-1, 4)
+    ii, jj, kk = _i(ii), _i(jj), _i(kk)
+    E = ii.shape[0]
+    Ji, Jj, Jz = np.empty((E, 2, 6), T), np.empty((E, 2, 6), T), np.empty((E, 2), T)
+    xy, mask = np.empty((E, 2), T), np.empty(E, T)
+    L.orc_ba_edge_terms(_p(poses), _p(patches), _p(intrinsics), _p(ii), _p(jj), _p(kk), E, P, _p(Ji), _p(Jj), _p(Jz), _p(xy),
+                        _p(mask))
+    return dict(Ji=Ji, Jj=Jj, Jz=Jz, xy=xy)
+
+
 def lib():
     global _lib
     if _lib is None:

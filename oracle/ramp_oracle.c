@@ -37,6 +37,19 @@
 #ifdef ORC_F64
 #define float double
 #define __builtin_fmaf __builtin_fma
+/* (the math library's double forms too: the fp64 pin of the bundle-adjustment algebra against ramp/ba.py run in float64 --
+ * tests/golden/ba_f64_pin.npz -- compares to 1e-8) */
+#define sqrtf sqrt
+#define sinf sin
+#define cosf cos
+#define atanf atan
+#define atan2f atan2
+#define acosf acos
+#define fabsf fabs
+#define fmaxf fmax
+#define fminf fmin
+#define floorf floor
+#define expf exp
 #endif
 
 /* float -> int with the saturating semantics of the GPU conversion the
@@ -499,6 +512,69 @@ static int i64cmp(const void *a, const void *b) {
   const int64_t x = *(const int64_t *)a, y = *(const int64_t *)b;
   return x < y ? -1 : (x > y);
 }
+/* One factor's terms of reprojection_residuals_and_hessian (ba_cuda.cu:232-376): relative pose, projection of the patch
+ * centre, residual, validity mask and the three Jacobians.  Ji carries the kernel's sign convention (Ji = adjSE3(Jj); the
+ * derivative with respect to pose i is -Ji: ba_cuda.cu:337-347 folds the sign into the accumulation).  Shared by the
+ * Gauss-Newton loop below and by orc_ba_edge_terms (the fp64 pin against ramp/ba.py + ramp/projective_ops.py). */
+typedef struct { float Ji[2][6], Jj[2][6], Jz[2], r[2], x1, y1, mask; } ba_edge_t;
+static void ba_edge_terms(const float *poses, const float *patches, const float *intr, int ix, int jx, int64_t kxn, int P,
+                          const float *target2, ba_edge_t *o) {
+  const float fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];
+  const int PP = P * P, c11 = 1 * P + 1;        /* the kernel reads patches[kx][c][1][1] (ba_cuda.cu:282-285) */
+  const float *pi = poses + 7 * ix, *pj = poses + 7 * jx;
+  float Xi[4], Xj[4];
+  Xi[0] = (patches[((size_t)kxn * 3 + 0) * PP + c11] - cx) / fx;
+  Xi[1] = (patches[((size_t)kxn * 3 + 1) * PP + c11] - cy) / fy;
+  Xi[2] = 1.0f;
+  Xi[3] = patches[((size_t)kxn * 3 + 2) * PP + c11];
+  float tij[3], qij[4];
+  relSE3(pi, pi + 3, pj, pj + 3, tij, qij);
+  actSE3(tij, qij, Xi, Xj);
+  const float X = Xj[0], Y = Xj[1], Z = Xj[2], W = Xj[3];
+  const float d = (Z >= 0.2f) ? 1.0f / Z : 0.0f;
+  const float d2 = d * d;
+  const float x1 = fx * (X / Z) + cx;
+  const float y1 = fy * (Y / Z) + cy;
+  const float rx = target2[0] - x1;
+  const float ry = target2[1] - y1;
+  const int in_bounds = (sqrtf(rx * rx + ry * ry) < 128) && (Z > 0.2f) && (x1 > -64) &&
+                        (y1 > -64) && (x1 < 2 * cx + 64) && (y1 < 2 * cy + 64);
+  o->mask = in_bounds ? 1.0f : 0.0f;
+  o->x1 = x1; o->y1 = y1;
+  for (int row = 0; row < 2; row++) {
+    float *Jj = o->Jj[row];
+    if (row == 0) {
+      o->r[0] = target2[0] - x1;
+      o->Jz[0] = fx * (tij[0] * d - tij[2] * (X * d2));
+      Jj[0] = fx * W * d; Jj[1] = 0; Jj[2] = fx * -X * W * d2;
+      Jj[3] = fx * -X * Y * d2; Jj[4] = fx * (1 + X * X * d2); Jj[5] = fx * -Y * d;
+    } else {
+      o->r[1] = target2[1] - y1;
+      o->Jz[1] = fy * (tij[1] * d - tij[2] * (Y * d2));
+      Jj[0] = 0; Jj[1] = fy * W * d; Jj[2] = fy * -Y * W * d2;
+      Jj[3] = fy * (-1 - Y * Y * d2); Jj[4] = fy * (X * Y * d2); Jj[5] = fy * X * d;
+    }
+    adjSE3(tij, qij, Jj, o->Ji[row]);
+  }
+}
+
+/* (tests) the per-factor terms above for E factors: Ji, Jj [E][2][6], Jz [E][2], xy [E][2] (projected centre), mask [E] */
+ORC_API void orc_ba_edge_terms(const float *poses, const float *patches, const float *intr, const int64_t *ii,
+                               const int64_t *jj, const int64_t *kk, int E, int P, float *Ji, float *Jj, float *Jz,
+                               float *xy, float *mask) {
+  const float zero2[2] = {0, 0};
+  for (int n = 0; n < E; n++) {
+    ba_edge_t et;
+    ba_edge_terms(poses, patches, intr, (int)ii[n], (int)jj[n], kk[n], P, zero2, &et);
+    for (int r = 0; r < 2; r++) {
+      for (int c = 0; c < 6; c++) { Ji[(n * 2 + r) * 6 + c] = et.Ji[r][c]; Jj[(n * 2 + r) * 6 + c] = et.Jj[r][c]; }
+      Jz[n * 2 + r] = et.Jz[r];
+    }
+    xy[2 * n] = et.x1; xy[2 * n + 1] = et.y1;
+    mask[n] = (et.x1 == et.x1) ? 1.0f : 0.0f;     /* (the residual gate needs a target; not part of these terms) */
+  }
+}
+
 /* ppf > 0: the reference's eff_impl = true path (ba_cuda.cu:261-275, 353-362, 472-478, 538-550): the coupling
  * matrix E is not stored as a dense [6N x M] matrix but as E_lookup[(i, j) block][patch within frame i][6]
  * (EfficentE, fastba/block_e.cu:43-145), and E Q E', E (Q u), E' dX are formed from the lookup by
@@ -534,11 +610,7 @@ static int ba_impl(float *poses, float *patches, const float *intr, const float 
   float *y = (float *)malloc(sizeof(float) * (size_t)(n6 + 1));
   float *dX = (float *)malloc(sizeof(float) * (size_t)(n6 + 1));
   float *dZ = (float *)malloc(sizeof(float) * (size_t)(M + 1));
-  const float fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];
-  const int PP = P * P, ctr = (P / 2) * P + (P / 2);
-  /* NOTE the kernel reads patches[kx][c][1][1] (ba_cuda.cu:282-285) */
-  const int c11 = 1 * P + 1;
-  (void)ctr;
+  const int PP = P * P;
 
   /* ---- EfficentE::EfficentE (block_e.cu:43-145) */
   int nf = 0, nblk = 0, nidx = 0;
@@ -585,46 +657,16 @@ static int ba_impl(float *poses, float *patches, const float *intr, const float 
       const int k = ku[n];
       int ix = (int)ii[n], jx = (int)jj[n];
       const int64_t kxn = kk[n];
-      const float *pi = poses + 7 * ix, *pj = poses + 7 * jx;
-      float Xi[4], Xj[4];
-      Xi[0] = (patches[((size_t)kxn * 3 + 0) * PP + c11] - cx) / fx;
-      Xi[1] = (patches[((size_t)kxn * 3 + 1) * PP + c11] - cy) / fy;
-      Xi[2] = 1.0f;
-      Xi[3] = patches[((size_t)kxn * 3 + 2) * PP + c11];
-      float tij[3], qij[4];
-      relSE3(pi, pi + 3, pj, pj + 3, tij, qij);
-      actSE3(tij, qij, Xi, Xj);
-      const float X = Xj[0], Y = Xj[1], Z = Xj[2], W = Xj[3];
-      const float d = (Z >= 0.2f) ? 1.0f / Z : 0.0f;
-      const float d2 = d * d;
-      const float x1 = fx * (X / Z) + cx;
-      const float y1 = fy * (Y / Z) + cy;
-      const float rx = target[2 * n + 0] - x1;
-      const float ry = target[2 * n + 1] - y1;
-      const int in_bounds = (sqrtf(rx * rx + ry * ry) < 128) && (Z > 0.2f) && (x1 > -64) &&
-                            (y1 > -64) && (x1 < 2 * cx + 64) && (y1 < 2 * cy + 64);
-      const float mask = in_bounds ? 1.0f : 0.0f;
+      ba_edge_t et;
+      ba_edge_terms(poses, patches, intr, ix, jx, kxn, P, target + 2 * n, &et);
       ix = ix - t0; jx = jx - t0;
       /* poses >= t1 are outside B in the reference (would be an out-of-bounds
        * write there); treated as fixed here and in the HIP path. */
       if (ix >= N) ix = -1;
       if (jx >= N) jx = -1;
       for (int row = 0; row < 2; row++) {
-        float Jj[6], Ji[6], Jz, r, w;
-        if (row == 0) {
-          r = target[2 * n + 0] - x1;
-          w = mask * weight[2 * n + 0];
-          Jz = fx * (tij[0] * d - tij[2] * (X * d2));
-          Jj[0] = fx * W * d; Jj[1] = 0; Jj[2] = fx * -X * W * d2;
-          Jj[3] = fx * -X * Y * d2; Jj[4] = fx * (1 + X * X * d2); Jj[5] = fx * -Y * d;
-        } else {
-          r = target[2 * n + 1] - y1;
-          w = mask * weight[2 * n + 1];
-          Jz = fy * (tij[1] * d - tij[2] * (Y * d2));
-          Jj[0] = 0; Jj[1] = fy * W * d; Jj[2] = fy * -Y * W * d2;
-          Jj[3] = fy * (-1 - Y * Y * d2); Jj[4] = fy * (X * Y * d2); Jj[5] = fy * X * d;
-        }
-        adjSE3(tij, qij, Jj, Ji);
+        const float *Jj = et.Jj[row], *Ji = et.Ji[row];
+        const float Jz = et.Jz[row], r = et.r[row], w = et.mask * weight[2 * n + row];
         for (int i = 0; i < 6; i++)
           for (int j = 0; j < 6; j++) {
             if (ix >= 0) B[(6 * ix + i) * n6 + 6 * ix + j] += w * Ji[i] * Ji[j];

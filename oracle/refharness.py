@@ -111,18 +111,27 @@ def _make_lietorch_backends():
     def _chk(g):
         assert g == 3, "oracle restates SE3 (group_id 3) only"
 
-    def expm(g, a): _chk(g); return _t(orc.se3_exp(_np(a)))
-    def logm(g, X): _chk(g); return _t(orc.se3_log(_np(X)))
-    def inv(g, X): _chk(g); return _t(orc.se3_inv(_np(X)))
-    def mul(g, X, Y): _chk(g); return _t(orc.se3_mul(_np(X), _np(Y)))
-    def adj(g, X, a): _chk(g); return _t(orc.se3_adj(_np(X), _np(a)))
-    def adjT(g, X, a): _chk(g); return _t(orc.se3_adjT(_np(X), _np(a)))
-    def act4(g, X, p): _chk(g); return _t(orc.se3_act4(_np(X), _np(p)))
+    # float64 tensors (the fp64 pin of the bundle-adjustment algebra, oracle/make_golden.py::gen_ba_f64_pin) are served by
+    # the fp64 build of the same oracle source, everything else by the fp32 restatement
+    def _d(*ts):
+        return all(t.dtype == torch.float64 for t in ts)
+
+    def _n(t):
+        return t.detach().cpu().contiguous().numpy() if t.dtype == torch.float64 else _np(t)
+
+    def expm(g, a): _chk(g); return _t((orc.se3_exp_f64 if _d(a) else orc.se3_exp)(_n(a)))
+    def logm(g, X): _chk(g); return _t((orc.se3_log_f64 if _d(X) else orc.se3_log)(_n(X)))
+    def inv(g, X): _chk(g); return _t((orc.se3_inv_f64 if _d(X) else orc.se3_inv)(_n(X)))
+    def mul(g, X, Y): _chk(g); return _t((orc.se3_mul_f64 if _d(X, Y) else orc.se3_mul)(_n(X), _n(Y)))
+    def adj(g, X, a): _chk(g); return _t((orc.se3_adj_f64 if _d(X, a) else orc.se3_adj)(_n(X), _n(a)))
+    def adjT(g, X, a): _chk(g); return _t((orc.se3_adjT_f64 if _d(X, a) else orc.se3_adjT)(_n(X), _n(a)))
+    def act4(g, X, p): _chk(g); return _t((orc.se3_act4_f64 if _d(X, p) else orc.se3_act4)(_n(X), _n(p)))
 
     def act(g, X, p):
         _chk(g)
-        p4 = np.concatenate([_np(p), np.ones(p.shape[:-1] + (1,), np.float32)], -1)
-        return _t(orc.se3_act4(_np(X), p4)[..., :3])
+        f64 = _d(X, p)
+        p4 = np.concatenate([_n(p), np.ones(p.shape[:-1] + (1,), np.float64 if f64 else np.float32)], -1)
+        return _t((orc.se3_act4_f64 if f64 else orc.se3_act4)(_n(X), p4)[..., :3])
 
     for f in (expm, logm, inv, mul, adj, adjT, act, act4):
         setattr(m, f.__name__, f)

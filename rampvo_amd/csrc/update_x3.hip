@@ -56,20 +56,92 @@ __device__ __forceinline__ float x3_inv_scale(const _Float16 *wp, int nks) {
 }
 
 // acc[mt][nt] (+)= X[16 MT x 32 nks] W[:, 32 wks0 ..)^T for this wave's 48 columns, transposed accumulators (lane (q, j):
-// row j of row tile mt, columns 4q .. 4q+3 of column tile nt)
-template <int MT, bool ZERO>
+// row j of row tile mt, columns 4q .. 4q+3 of column tile nt).  One K step = 6 fragment loads (two planes x three column
+// tiles), 2 MT LDS reads, 9 MT matrix instructions.
+#ifndef X3_GRU_PF
+#define X3_GRU_PF 0            // (the gru launch holds the residual stream and the gate in registers: no room for a ring)
+#endif
+#ifndef X3_PF
+#define X3_PF 2                // K steps of weight fragments in flight ahead of the matrix work (0: loaded where used)
+#endif
+template <int MT>
+__device__ __forceinline__ void x3_mma_step(const _Float16 *Xh, const _Float16 *Xl, int ks, int q, int j, const h8 (&wh)[XNTW],
+                                            const h8 (&wl)[XNTW], f4 (&acc)[MT][XNTW]) {
+  const _Float16 c11 = (_Float16)0.00048828125f;           // 2^-11
+  const h8 s11 = (h8){c11, c11, c11, c11, c11, c11, c11, c11};
+  h8 ah[MT], al[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; mt++) {
+    const int off = (mt * 16 + j) * XS + ks * 32 + 8 * q;
+    ah[mt] = *reinterpret_cast<const h8 *>(Xh + off);
+    al[mt] = *reinterpret_cast<const h8 *>(Xl + off);
+  }
+#if defined(X3_DIAG_NOMMA)                                    // (diagnostic build: operand traffic without the matrix work)
+#pragma unroll
+  for (int nt = 0; nt < XNTW; nt++)
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) acc[mt][nt][i] += (float)wh[nt][i] + (float)wl[nt][i + 4] + (float)ah[mt][i] + (float)al[mt][i + 4];
+#else
+#pragma unroll
+  for (int nt = 0; nt < XNTW; nt++) {
+    const h8 ws = wh[nt] * s11;
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], ah[mt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ws, al[mt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[nt], ah[mt], acc[mt][nt], 0, 0, 0);
+  }
+#endif
+}
+
+// NKS K steps, fully unrolled, the weight fragments of steps ks+1 .. ks+PF in flight while the matrix cores work on step ks (a
+// ring of PF+1 fragment sets with static indices; the scheduling barrier keeps each load ABOVE the matrix work of the step it is
+// issued in -- the compiler sinks it to its first use otherwise, which exposes the L2 latency on every K step: two waves per
+// SIMD cannot cover it)
+template <int MT, int NKS, int PF>
+__device__ __forceinline__ void x3_gemm_static(const _Float16 *Xh, const _Float16 *Xl, const _Float16 *wp, int wks0, int wave,
+                                               int lane, f4 (&acc)[MT][XNTW]) {
+  const int q = lane >> 4, j = lane & 15;
+  const _Float16 *wb0 = wp + ((size_t)wks0 * (XD / 16) + wave * XNTW) * XFRAG + lane * 8;
+  h8 rh[PF + 1][XNTW], rl[PF + 1][XNTW];
+  auto wload = [&](int ks, h8 (&wh)[XNTW], h8 (&wl)[XNTW]) {
+#if defined(X3_DIAG_NOW)                                      // (diagnostic build: every K step reads the first step's fragments)
+    const _Float16 *wb = wb0 + (size_t)(ks & 0) * (XD / 16) * XFRAG;
+#else
+    const _Float16 *wb = wb0 + (size_t)ks * (XD / 16) * XFRAG;
+#endif
+#pragma unroll
+    for (int nt = 0; nt < XNTW; nt++) {
+      wh[nt] = *reinterpret_cast<const h8 *>(wb + nt * XFRAG);
+      wl[nt] = *reinterpret_cast<const h8 *>(wb + nt * XFRAG + 512);
+    }
+  };
+#pragma unroll
+  for (int d = 0; d < PF && d < NKS; d++) wload(d, rh[d], rl[d]);
+#pragma unroll
+  for (int ks = 0; ks < NKS; ks++) {
+    if (ks + PF < NKS) wload(ks + PF, rh[(ks + PF) % (PF + 1)], rl[(ks + PF) % (PF + 1)]);
+    if (PF > 0) __builtin_amdgcn_sched_barrier(0);
+    x3_mma_step<MT>(Xh, Xl, ks, q, j, rh[ks % (PF + 1)], rl[ks % (PF + 1)], acc);
+  }
+}
+
+template <int MT, bool ZERO, int PF = X3_PF>
 __device__ __forceinline__ void x3_gemm(const _Float16 *Xh, const _Float16 *Xl, const _Float16 *wp, int nks, int wks0,
                                         int wave, int lane, f4 (&acc)[MT][XNTW]) {
-  const int q = lane >> 4, j = lane & 15;
   if (ZERO) {
 #pragma unroll
     for (int mt = 0; mt < MT; mt++)
 #pragma unroll
       for (int nt = 0; nt < XNTW; nt++) acc[mt][nt] = (f4){0.f, 0.f, 0.f, 0.f};
   }
-  const _Float16 c11 = (_Float16)0.00048828125f;
-  const h8 s11 = (h8){c11, c11, c11, c11, c11, c11, c11, c11};
-#pragma unroll 2
+  if (PF > 0 && nks == XKS) return x3_gemm_static<MT, XKS, PF>(Xh, Xl, wp, wks0, wave, lane, acc);
+  if (PF > 0 && nks == 4) return x3_gemm_static<MT, 4, PF>(Xh, Xl, wp, wks0, wave, lane, acc);
+  const int q = lane >> 4, j = lane & 15;
+#pragma unroll 1
   for (int ks = 0; ks < nks; ks++) {
     const _Float16 *wb = wp + ((size_t)(wks0 + ks) * (XD / 16) + wave * XNTW) * XFRAG + lane * 8;
     h8 wh[XNTW], wl[XNTW];
@@ -78,23 +150,7 @@ __device__ __forceinline__ void x3_gemm(const _Float16 *Xh, const _Float16 *Xl, 
       wh[nt] = *reinterpret_cast<const h8 *>(wb + nt * XFRAG);
       wl[nt] = *reinterpret_cast<const h8 *>(wb + nt * XFRAG + 512);
     }
-    h8 ah[MT], al[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; mt++) {
-      const int off = (mt * 16 + j) * XS + ks * 32 + 8 * q;
-      ah[mt] = *reinterpret_cast<const h8 *>(Xh + off);
-      al[mt] = *reinterpret_cast<const h8 *>(Xl + off);
-    }
-#pragma unroll
-    for (int nt = 0; nt < XNTW; nt++) {
-      const h8 ws = wh[nt] * s11;
-#pragma unroll
-      for (int mt = 0; mt < MT; mt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], ah[mt], acc[mt][nt], 0, 0, 0);
-#pragma unroll
-      for (int mt = 0; mt < MT; mt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ws, al[mt], acc[mt][nt], 0, 0, 0);
-#pragma unroll
-      for (int mt = 0; mt < MT; mt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[nt], ah[mt], acc[mt][nt], 0, 0, 0);
-    }
+    x3_mma_step<MT>(Xh, Xl, ks, q, j, wh, wl, acc);
   }
 }
 
@@ -111,6 +167,32 @@ __device__ __forceinline__ void x3_to_lds(_Float16 *Xh, _Float16 *Xl, const f4 (
       *reinterpret_cast<h4 *>(Xh + off) = hi;
       *reinterpret_cast<h4 *>(Xl + off) = lo;
     }
+}
+
+
+// Stage ROWS x (4 NV4) floats into the two LDS planes: ALL global loads of a thread are issued before the first conversion (a loop
+// that loads, converts and stores element by element waits for one memory round trip per iteration: twelve in a row per tile)
+template <int ROWS, int NV4, typename LoadT>
+__device__ __forceinline__ void x3_stage(_Float16 *Xh, _Float16 *Xl, int tid, LoadT load) {
+  constexpr int N = (ROWS * NV4 + 64 * XWAVES - 1) / (64 * XWAVES);
+  f4 v[N];
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    const int i = tid + k * (64 * XWAVES);
+    const int r = i / NV4, c4 = i - r * NV4;
+    v[k] = (ROWS * NV4) % (64 * XWAVES) == 0 || i < ROWS * NV4 ? load(r, c4) : (f4){0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    const int i = tid + k * (64 * XWAVES);
+    const int r = i / NV4, c4 = i - r * NV4;
+    if ((ROWS * NV4) % (64 * XWAVES) == 0 || i < ROWS * NV4) {
+      h4 hi, lo;
+      x3_split4(v[k], hi, lo);
+      *reinterpret_cast<h4 *>(Xh + r * XS + 4 * c4) = hi;
+      *reinterpret_cast<h4 *>(Xl + r * XS + 4 * c4) = lo;
+    }
+  }
 }
 
 // v = acc * inv_scale + bias (optionally ReLU)
@@ -177,6 +259,20 @@ __device__ __forceinline__ void x3_tile_ln(f4 (&v)[MT][XNTW], const float *__res
   }
 }
 
+// Workgroups that start together run their phases together: every CU gathers rows (HBM saturated, matrix cores idle), then every
+// CU multiplies (HBM idle).  With several workgroups per CU the second one of each CU (dispatch order: 256 workgroups fill the
+// first slot of every CU) starts X3_STAGGER x ~4k cycles late, so that one's row traffic runs beside the other's matrix work.
+#ifndef X3_STAGGER
+#define X3_STAGGER 0
+#endif
+__device__ __forceinline__ void x3_stagger() {
+#if X3_STAGGER > 0
+  if ((blockIdx.x >> 8) & 1) {
+#pragma unroll 1
+    for (int i = 0; i < X3_STAGGER; i++) __builtin_amdgcn_s_sleep(64);
+  }
+#endif
+}
 #define X3_COMMON(MT_)                                                                                      \
   constexpr int ROWS = 16 * (MT_);                                                                          \
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];                                  \
@@ -186,8 +282,14 @@ __device__ __forceinline__ void x3_tile_ln(f4 (&v)[MT][XNTW], const float *__res
   const int pE = p.dyn ? p.dyn[RAMP_DYN_E] : p.E;                                                           \
   if (row0 >= pE) return;                                                                                   \
   const int cq = wave * (16 * XNTW) + 4 * q;                                                                \
+  x3_stagger();                                                                                             \
   (void)tid; (void)j; (void)cq
 
+#ifdef X3_OCC
+#define X3_ATTR __attribute__((amdgpu_waves_per_eu(X3_OCC, X3_OCC)))
+#else
+#define X3_ATTR
+#endif
 static size_t x3_lds_bytes(int mt, bool ln) { return (size_t)2 * 16 * mt * XS * 2 + (ln ? (size_t)2 * 16 * mt * XWAVES * 4 : 0); }
 
 // ------------------------------------------------------------------ c1 / c2 (ramp/net.py:77-82)
@@ -202,20 +304,16 @@ struct X3NbrParams {
 };
 
 template <int MT>
-__global__ void __launch_bounds__(64 * XWAVES) x3_nbr_kernel(const X3NbrParams p) {
+__global__ void __launch_bounds__(64 * XWAVES) X3_ATTR x3_nbr_kernel(const X3NbrParams p) {
   X3_COMMON(MT);
-  for (int i = tid; i < ROWS * (XD / 4); i += 64 * XWAVES) {
-    const int r = i / (XD / 4), c4 = i - r * (XD / 4);
+  x3_stage<ROWS, XD / 4>(Xh, Xl, tid, [&](int r, int c4) {
     f4 v = (f4){0.f, 0.f, 0.f, 0.f};
     if (row0 + r < pE) {
       const long src = p.idx[row0 + r];
       if (src >= 0) v = *reinterpret_cast<const f4 *>(p.net_in + (size_t)src * XD + 4 * c4);
     }
-    h4 hi, lo;
-    x3_split4(v, hi, lo);
-    *reinterpret_cast<h4 *>(Xh + r * XS + 4 * c4) = hi;
-    *reinterpret_cast<h4 *>(Xl + r * XS + 4 * c4) = lo;
-  }
+    return v;
+  });
   __syncthreads();
   f4 acc[MT][XNTW];
   x3_gemm<MT, true>(Xh, Xl, p.wa, XKS, 0, wave, lane, acc);
@@ -259,7 +357,7 @@ struct X3CorrMlpParams {
 };
 
 template <int MT>
-__global__ void __launch_bounds__(64 * XWAVES) x3_corr_mlp_kernel(const X3CorrMlpParams p) {
+__global__ void __launch_bounds__(64 * XWAVES) X3_ATTR x3_corr_mlp_kernel(const X3CorrMlpParams p) {
   X3_COMMON(MT);
   float *T1 = reinterpret_cast<float *>(Xl + ROWS * XS), *T2 = T1 + ROWS * XWAVES;
   f4 acc[MT][XNTW];
@@ -270,18 +368,25 @@ __global__ void __launch_bounds__(64 * XWAVES) x3_corr_mlp_kernel(const X3CorrMl
   const int nks_total = p.corr_k / 32;
   for (int ks0 = 0; ks0 < nks_total; ks0 += XKS) {
     const int nks = min(XKS, nks_total - ks0);
-    const int v4 = nks * 8;                                // 16-byte vectors per row of this chunk
-    for (int i = tid; i < ROWS * v4; i += 64 * XWAVES) {
-      const int r = i / v4, c4 = i - r * v4;
+    auto ld = [&](int r, int c4) {
       f4 v = (f4){0.f, 0.f, 0.f, 0.f};
       if (row0 + r < pE) v = *reinterpret_cast<const f4 *>(p.corr + (size_t)(row0 + r) * p.corr_k + ks0 * 32 + 4 * c4);
-      h4 hi, lo;
-      x3_split4(v, hi, lo);
-      *reinterpret_cast<h4 *>(Xh + r * XS + 4 * c4) = hi;
-      *reinterpret_cast<h4 *>(Xl + r * XS + 4 * c4) = lo;
+      return v;
+    };
+    if (nks == XKS) x3_stage<ROWS, XKS * 8>(Xh, Xl, tid, ld);
+    else if (nks == 4) x3_stage<ROWS, 32>(Xh, Xl, tid, ld);
+    else {
+      const int v4 = nks * 8;                                // 16-byte vectors per row of this chunk
+      for (int i = tid; i < ROWS * v4; i += 64 * XWAVES) {
+        const int r = i / v4, c4 = i - r * v4;
+        h4 hi, lo;
+        x3_split4(ld(r, c4), hi, lo);
+        *reinterpret_cast<h4 *>(Xh + r * XS + 4 * c4) = hi;
+        *reinterpret_cast<h4 *>(Xl + r * XS + 4 * c4) = lo;
+      }
     }
     __syncthreads();
-    x3_gemm<MT, false>(Xh, Xl, p.w1, nks, ks0, wave, lane, acc);
+    x3_gemm<MT, false, 0>(Xh, Xl, p.w1, nks, ks0, wave, lane, acc);      // (the staged chunk's registers are live: no ring)
     __syncthreads();                                       // before the tile is overwritten
   }
   x3_bias<MT, true>(acc, x3_inv_scale(p.w1, nks_total), p.b1, cq);
@@ -340,10 +445,9 @@ struct X3FgParams {
 };
 
 template <int MT>
-__global__ void __launch_bounds__(64 * XWAVES) x3_fg_kernel(const X3FgParams p) {
+__global__ void __launch_bounds__(64 * XWAVES) X3_ATTR x3_fg_kernel(const X3FgParams p) {
   X3_COMMON(MT);
-  for (int i = tid; i < ROWS * (XD / 4); i += 64 * XWAVES) {
-    const int r = i / (XD / 4), c4 = i - r * (XD / 4);
+  x3_stage<ROWS, XD / 4>(Xh, Xl, tid, [&](int r, int c4) {
     f4 v = (f4){0.f, 0.f, 0.f, 0.f};
     const int row = row0 + r;
     if (row < pE) {
@@ -351,11 +455,8 @@ __global__ void __launch_bounds__(64 * XWAVES) x3_fg_kernel(const X3FgParams p) 
       if (p.add_t) v = x3_add(v, *reinterpret_cast<const f4 *>(p.add_t + (size_t)p.add_idx[row] * XD + 4 * c4));
       if (p.x32_out) *reinterpret_cast<f4 *>(p.x32_out + (size_t)row * XD + 4 * c4) = v;
     }
-    h4 hi, lo;
-    x3_split4(v, hi, lo);
-    *reinterpret_cast<h4 *>(Xh + r * XS + 4 * c4) = hi;
-    *reinterpret_cast<h4 *>(Xl + r * XS + 4 * c4) = lo;
-  }
+    return v;
+  });
   __syncthreads();
 #pragma unroll 1
   for (int part = 0; part < 2; part++) {
@@ -540,7 +641,7 @@ __global__ void __launch_bounds__(64 * XWAVES) x3_gru_kernel(const X3GruParams p
   for (int stage = 0; stage < 2; stage++) {
     const int wb = 3 * stage;
     f4 gate[MT][XNTW], acc[MT][XNTW];
-    x3_gemm<MT, true>(Xh, Xl, p.wp[wb + 0], XKS, 0, wave, lane, gate);
+    x3_gemm<MT, true, X3_GRU_PF>(Xh, Xl, p.wp[wb + 0], XKS, 0, wave, lane, gate);
     {
       const float inv = x3_inv_scale(p.wp[wb + 0], XKS);
 #pragma unroll
@@ -552,12 +653,12 @@ __global__ void __launch_bounds__(64 * XWAVES) x3_gru_kernel(const X3GruParams p
           for (int i = 0; i < 4; i++) gate[mt][nt][i] = x3_sigmoid(gate[mt][nt][i] * inv + b[i]);
       }
     }
-    x3_gemm<MT, true>(Xh, Xl, p.wp[wb + 1], XKS, 0, wave, lane, acc);
+    x3_gemm<MT, true, X3_GRU_PF>(Xh, Xl, p.wp[wb + 1], XKS, 0, wave, lane, acc);
     x3_bias<MT, true>(acc, x3_inv_scale(p.wp[wb + 1], XKS), p.bias[wb + 1], cq);
     __syncthreads();                            // every wave is past its reads of x: h takes its place
     x3_to_lds<MT>(Xh, Xl, acc, cq, j);
     __syncthreads();
-    x3_gemm<MT, true>(Xh, Xl, p.wp[wb + 2], XKS, 0, wave, lane, acc);
+    x3_gemm<MT, true, X3_GRU_PF>(Xh, Xl, p.wp[wb + 2], XKS, 0, wave, lane, acc);
     x3_bias<MT, false>(acc, x3_inv_scale(p.wp[wb + 2], XKS), p.bias[wb + 2], cq);
 #pragma unroll
     for (int mt = 0; mt < MT; mt++)

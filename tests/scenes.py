@@ -50,6 +50,37 @@ def ba_scene(seed=0, n_frames=8, M=12, lifetime=5, H=120, W=160, noise=1.5, n_to
                 lmbda=np.array([1e-4], np.float32), n_frames=n_frames, M=M)
 
 
+def ba_pin_scene(seed, n_frames, M=8, lifetime=4, H=120, W=160, noise=0.4):
+    """float64 problem for the fp64 pin of the bundle-adjustment algebra (tests/golden/ba_f64_pin.npz): ba_scene's graph and
+    geometry without anything that makes the two implementations under comparison -- ramp/ba.py::BA and the cuda_ba
+    restatement -- take different branches: no outliers (residual gates 250 vs 128 px), every depth in
+    (0.2, 1.2) and every point in front of every camera (Z > 0.2), projections inside the bounds, one intrinsics row"""
+    import oracle as orc
+    rng = np.random.default_rng(seed)
+    xi = np.cumsum(rng.normal(0, [0.03, 0.02, 0.01, 0.004, 0.004, 0.004], (n_frames, 6)), 0)
+    poses = orc.se3_exp_f64(xi)
+    intr = np.tile(np.array([W * 0.5, W * 0.5, W * 0.5, H * 0.5], np.float64), (n_frames, 1))
+    patches = np.zeros((n_frames * M, 3, 3, 3), np.float64)
+    gx, gy = np.meshgrid(np.arange(-1, 2), np.arange(-1, 2))
+    for k in range(n_frames * M):
+        patches[k, 0] = rng.uniform(20, W - 20) + gx
+        patches[k, 1] = rng.uniform(20, H - 20) + gy
+        patches[k, 2] = rng.uniform(0.2, 1.2)
+    ii, jj, kk = [], [], []
+    for f in range(n_frames):
+        for m in range(M):
+            for j in range(max(0, f - lifetime), min(n_frames, f + lifetime + 1)):
+                ii.append(f); jj.append(j); kk.append(f * M + m)
+    ii, jj, kk = (np.asarray(a, np.int64) for a in (ii, jj, kk))
+    perm = rng.permutation(len(ii))
+    ii, jj, kk = ii[perm], jj[perm], kk[perm]
+    xy = orc.ba_edge_terms(poses, patches, intr, ii, jj, kk, f64=True)["xy"]
+    target = xy + rng.normal(0, noise, xy.shape)
+    weight = rng.uniform(0.05, 1.0, xy.shape)
+    return dict(poses=poses, patches=patches, intr=intr, ii=ii, jj=jj, kk=kk, target=target, weight=weight,
+                lmbda=np.array([1e-4]), n_frames=n_frames, M=M)
+
+
 def corr_case(seed=0, E=48, N1=40, N2=6, H=30, W=40, C=128, distort=True, wide=False):
     rng = np.random.default_rng(seed)
     fmap1 = rng.normal(0, 1, (1, N1, C, 3, 3)).astype(np.float32)
