@@ -751,11 +751,14 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
     if (gate_at < 0) { const char *e = getenv("RAMP_GATE_AT"); gate_at = e ? atoi(e) : 2; if (gate_at < 0 || gate_at > 3) gate_at = 2; }
     if (t->feat_fp32) {
       // ---- fp32 features (MIXED_PRECISION off): the same step with csrc/update_x3.hip's chains (Linear layers on the f16
-      // matrix cores from split fp32 operands), fp32 tables, [f | g] rows + segment softmax + h for the two SoftAggs
-      TRK_DO(ramp_i_corr_fwd(t->gmap, lv, 2, t->coords, kk, jj, t->ij_order, t->corr, 896, (long)t->M * t->mem, t->mem, Eb,
-                             t->mem * t->M, t->mem, 128, t->P, 3, f32_code, RAMP_NHWC, dyn, st, nullptr, nullptr, nullptr,
-                             nullptr, t->fmap1_slot));
-      TRK_PROBE(1);
+      // matrix cores from split fp32 operands), fp32 tables, [f | g] rows + segment softmax + h for the two SoftAggs.
+      // The fp32 front end is ~1.1 ms against ~0.9 ms of step behind the second neighbour chain, so it starts at the top of the
+      // step (RAMP_GATE_AT_F32: 5 = before the correlation launch, the default; 4 = before the correlation MLP, 3 = before
+      // c1 / c2, 0 .. 2 as RAMP_GATE_AT).  Measured (bench.py --mixed 0, two runs each): 2 -> 434 kf/s, 3 -> 455, 4 -> 471,
+      // 5 -> 492
+      static int gate32 = -1;
+      if (gate32 < 0) { const char *e = getenv("RAMP_GATE_AT_F32"); gate32 = e ? atoi(e) : 5; if (gate32 < 0 || gate32 > 5) gate32 = 5; }
+      const int gate_at = gate32;
 #define TRK_GATE32(pos)                                                                                   \
   do {                                                                                                    \
     if (gate_at == (pos) && !(t->gate_flag && (pos) == 0)) {                                              \
@@ -763,6 +766,12 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
       else if (gate_event && hipEventRecord((hipEvent_t)gate_event, st) != hipSuccess) return RAMP_ELAUNCH; \
     }                                                                                                     \
   } while (0)
+      TRK_GATE32(5);
+      TRK_DO(ramp_i_corr_fwd(t->gmap, lv, 2, t->coords, kk, jj, t->ij_order, t->corr, 896, (long)t->M * t->mem, t->mem, Eb,
+                             t->mem * t->M, t->mem, 128, t->P, 3, f32_code, RAMP_NHWC, dyn, st, nullptr, nullptr, nullptr,
+                             nullptr, t->fmap1_slot));
+      TRK_PROBE(1);
+      TRK_GATE32(4);
       const float *corr32 = (const float *)t->corr;
       float *fg32 = (float *)t->fg, *ykk = (float *)t->ykk, *hkk = (float *)t->hkk, *yij = (float *)t->yij, *hij = (float *)t->hij;
       TRK_DO(ramp_i_x3_corr_mlp(corr32, 896, w.corr_w1, w.corr_b1, w.corr_w2, w.corr_b2, w.corr_w3, w.corr_b3, w.corr_ln_w,
