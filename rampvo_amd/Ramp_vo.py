@@ -998,7 +998,7 @@ class Ramp_vo:
         fc = self._fc_plan
         if ex is None or fc is None or fc[0] is not ex or fc[1] is not patches:
             ok = (ex is not None and ex["fmap"].dtype == self.dtype
-                  and ex["chunked"] == self._chunked and (self.M * 3) % 16 == 0 and patches.is_contiguous()
+                  and ex["chunked"] == self._chunked and patches.is_contiguous()
                   and patches.dtype == torch.float32 and ops.depth_median_supported(3, self.M, self.P)
                   and all(ex[k].data_ptr() % 16 == 0 for k in ("colors", "imap", "gmap", "fmap", "fmap2")))
             plan_fc = None

@@ -270,16 +270,27 @@ __global__ void __launch_bounds__(MED_THREADS) frame_commit_kernel(const FrameCo
   if (blockIdx.y > 0) {
     const int b = blockIdx.y - 1;
     if (b >= a.n_copy) return;
-    const long n16 = a.bytes[b] / 16;                       // 16-byte multiples, 16-byte aligned (checked on the host)
-    const uint4 *s = reinterpret_cast<const uint4 *>(a.src[b]);
     char *d = a.dst[b];
     if (a.dyn) {
       int row = a.mod[b] ? n % a.mod[b] : n;
       if (a.slot_tab && b == a.slot_buf) row = a.slot_tab[row];
       d += (size_t)row * a.bytes[b];
     }
-    uint4 *o = reinterpret_cast<uint4 *>(d);
-    for (long i = (long)blockIdx.x * blockDim.x + t; i < n16; i += (long)gridDim.x * blockDim.x) o[i] = s[i];
+    const long g0 = (long)blockIdx.x * blockDim.x + t, gs = (long)gridDim.x * blockDim.x;
+    // 16-byte pieces where the row is made of them (source and buffer base are 16-byte aligned: checked on the host); a row
+    // that is not -- the colours of a frame, 3 M bytes, for a PATCHES_PER_FRAME that is no multiple of 16 (precise.yaml: 300)
+    // -- goes in 4-byte pieces or byte by byte
+    if (!(a.bytes[b] & 15)) {
+      const uint4 *s = reinterpret_cast<const uint4 *>(a.src[b]);
+      uint4 *o = reinterpret_cast<uint4 *>(d);
+      for (long i = g0; i < a.bytes[b] / 16; i += gs) o[i] = s[i];
+    } else if (!(a.bytes[b] & 3)) {
+      const uint32_t *s = reinterpret_cast<const uint32_t *>(a.src[b]);
+      uint32_t *o = reinterpret_cast<uint32_t *>(d);
+      for (long i = g0; i < a.bytes[b] / 4; i += gs) o[i] = s[i];
+    } else {
+      for (long i = g0; i < a.bytes[b]; i += gs) d[i] = a.src[b][i];
+    }
     return;
   }
   if (blockIdx.x != 0) return;
@@ -344,8 +355,7 @@ int ramp_i_frame_commit_dyn(float *poses, int motion, float damping, int64_t *ts
   long mx = 0;
   for (int i = 0; i < FC_MAXBUF; i++) a.mod[i] = 0;
   for (int i = 0; i < n_copy; i++) {
-    if (!src[i] || !base[i] || bytes[i] <= 0 || (bytes[i] & 15) || (((uintptr_t)src[i] | (uintptr_t)base[i]) & 15))
-      return RAMP_EINVAL;
+    if (!src[i] || !base[i] || bytes[i] <= 0 || (((uintptr_t)src[i] | (uintptr_t)base[i]) & 15)) return RAMP_EINVAL;
     a.src[i] = (const char *)src[i]; a.dst[i] = (char *)base[i]; a.bytes[i] = bytes[i]; a.mod[i] = mod[i];
     if (bytes[i] > mx) mx = bytes[i];
   }
@@ -424,8 +434,9 @@ int ramp_frame_commit(float *poses, int n, int motion, float damping, int64_t *t
   a.n_copy = n_copy;
   long mx = 0;
   for (int i = 0; i < n_copy; i++) {
-    if (!src_host[i] || !dst_host[i] || bytes_host[i] <= 0 || (bytes_host[i] & 15) ||
-        (((uintptr_t)src_host[i] | (uintptr_t)dst_host[i]) & 15))
+    // (a destination row that is no multiple of 16 bytes need not be 16-byte aligned: the kernel then copies 4- or 1-byte pieces)
+    if (!src_host[i] || !dst_host[i] || bytes_host[i] <= 0 || ((uintptr_t)src_host[i] & 15) ||
+        ((uintptr_t)dst_host[i] & ((bytes_host[i] & 15) ? ((bytes_host[i] & 3) ? 0 : 3) : 15)))
       return RAMP_EINVAL;
     a.src[i] = (const char *)src_host[i]; a.dst[i] = (char *)dst_host[i]; a.bytes[i] = bytes_host[i];
     if (bytes_host[i] > mx) mx = bytes_host[i];

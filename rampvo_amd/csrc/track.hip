@@ -255,6 +255,14 @@ __device__ __forceinline__ void trk_shift_buffer(const TrkEdit &p, int b, int k,
     }
     return;
   }
+  if (p.row_bytes[b] & 3) {                                  // (an odd PATCHES_PER_FRAME's colour rows: byte by byte)
+    for (long col = (long)blockIdx.x * 256 + tid; col < p.row_bytes[b]; col += (long)gridDim.x * 256)
+      for (int r = k; r < nrows - 1; r++) {
+        const int sd = mod ? r % mod : r, ss = mod ? (r + 1) % mod : r + 1;
+        p.base[b][(size_t)sd * p.row_bytes[b] + col] = p.base[b][(size_t)ss * p.row_bytes[b] + col];
+      }
+    return;
+  }
   for (long col = (long)blockIdx.x * 256 + tid; col < n4; col += (long)gridDim.x * 256) {
     for (int r = k; r < nrows - 1; r++) {
       const int sd = mod ? r % mod : r, ss = mod ? (r + 1) % mod : r + 1;
@@ -456,7 +464,7 @@ static int trk_edit_fill(const ramp_track *t, int cur, int64_t counter, TrkEdit 
   const int md[9] = {0, 0, 0, 0, 0, t->mem, t->mem, t->mem, t->mem};
   p.nbuf = 9;
   for (int i = 0; i < 9; i++) {
-    if (!bufs[i] || (rb[i] & 3)) return RAMP_EINVAL;
+    if (!bufs[i]) return RAMP_EINVAL;
     p.base[i] = (char *)bufs[i]; p.row_bytes[i] = rb[i]; p.mod[i] = md[i];
   }
   p.slot_tab = t->fmap1_slot; p.slot_buf = 7; p.slot_mod = t->mem;      // (bufs[7] = fmap1)

@@ -107,7 +107,7 @@ def supported(slam):
     layout_ok = (slam.dtype == torch.half and slam._chunked) or (slam.dtype == torch.float and not slam._chunked
                                                                  and os.environ.get("RAMP_DEVICE_STEP_FP32", "1") == "1")
     return (layout_ok and slam._lazy_net and slam.P == 3 and slam.DIM == 384
-            and (slam.M * 3) % 16 == 0 and 3 * slam.M * 9 <= 8192 and cfg.MOTION_MODEL in ("DAMPED_LINEAR",)
+            and 3 * slam.M * 9 <= 8192 and cfg.MOTION_MODEL in ("DAMPED_LINEAR",)
             and cfg.PATCH_LIFETIME <= cfg.REMOVAL_WINDOW + 1 and cfg.KEYFRAME_INDEX >= 2
             and 6 * cfg.OPTIMIZATION_WINDOW <= 192)
 
@@ -119,7 +119,7 @@ def unsupported_reason(slam):
                "MIXED_PRECISION is off and RAMP_DEVICE_STEP_FP32=0 (the fp32 path is host driven)"),
               (slam._chunked or slam.dtype == torch.float, "the feature plane does not fit the chunked pyramid layout"),
               (slam.P == 3 and slam.DIM == 384, "patch size / feature width other than 3 / 384"),
-              ((slam.M * 3) % 16 == 0 and 3 * slam.M * 9 <= 8192, "PATCHES_PER_FRAME must be a multiple of 16, at most 303"),
+              (3 * slam.M * 9 <= 8192, "PATCHES_PER_FRAME above 303 (the depth median of three frames is one workgroup's)"),
               (cfg.MOTION_MODEL in ("DAMPED_LINEAR",), "MOTION_MODEL other than DAMPED_LINEAR"),
               (cfg.PATCH_LIFETIME <= cfg.REMOVAL_WINDOW + 1, "PATCH_LIFETIME exceeds REMOVAL_WINDOW + 1"),
               (cfg.KEYFRAME_INDEX >= 2, "KEYFRAME_INDEX below 2"),
