@@ -779,6 +779,9 @@ typedef struct ramp_track {
                                        * planes, corr [E_cap][896] fp16); 1: fp32 features, plain NHWC planes, corr [E_cap][882]
                                        * fp32 (correlation by corr_kernel<float>, the reference kernel's summation order) --
                                        * only with RAMP_TRACK_UPDATE_PRE / _POST                                          */
+  int32_t feat_plain;                 /* (fp16 features) 1: the pyramid planes are plain NHWC [h][w][128] fp16 rows instead of the
+                                       * chunked [h][C/32][w][32] layout -- feature planes whose width is no multiple of 16 or
+                                       * whose height is no multiple of 4 (ramp_pyramid_pack's shapes): corr_mfma_kernel<half, false>  */
   uint32_t *gate_flag;                /* optional signal word (ramp_signal_alloc): "the next frame's front end may start"  *
                                        * without a packet on this stream -- the other stream waits with                    *
                                        * ramp_stream_wait_flag (a hipEventRecord costs ~5 us between two kernels of the   *

@@ -216,7 +216,7 @@ class Ramp_vo:
         if self.dtype == torch.half and not chunked:
             # a performance cliff, not an error: say so once
             warnings.warn("rampvo_amd: feature plane %dx%d does not fit the chunked pyramid layout (width %% 16, height %% 4 at "
-                          "1/4 resolution): plain NHWC slots, the slower correlation path and host-driven steps" % (w, h))
+                          "1/4 resolution): plain NHWC slots and the slower correlation kernel" % (w, h))
         return chunked, True
 
     def _init_streams(self, dev):

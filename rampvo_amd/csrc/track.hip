@@ -718,7 +718,7 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
                              t->fmap1_slot));
     else
       TRK_DO(ramp_i_corr_fwd(t->gmap, lv, 2, t->coords, kk, jj, t->ij_order, t->corr, 896, (long)t->M * t->mem, t->mem, Eb,
-                             t->mem * t->M, t->mem, 128, t->P, 3, RAMP_F16, RAMP_NHWC32, dyn, st, nullptr, nullptr, nullptr, nullptr,
+                             t->mem * t->M, t->mem, 128, t->P, 3, RAMP_F16, t->feat_plain ? RAMP_NHWC : RAMP_NHWC32, dyn, st, nullptr, nullptr, nullptr, nullptr,
                              t->fmap1_slot));
     TRK_PROBE(1);
   }
@@ -810,7 +810,7 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
     static const bool corr_l1 = getenv("RAMP_CORR_L1") && atoi(getenv("RAMP_CORR_L1")) != 0;
     if (corr_l1) {
       TRK_DO(ramp_i_corr_l1_fwd(t->gmap, lv, t->coords, kk, jj, t->ij_order, w.corr_w1, w.corr_b1, 896, t->corr,
-                                (long)t->M * t->mem, t->mem, Eb, RAMP_NHWC32, dyn, st, fuse_tf ? t->poses : nullptr,
+                                (long)t->M * t->mem, t->mem, Eb, t->feat_plain ? RAMP_NHWC : RAMP_NHWC32, dyn, st, fuse_tf ? t->poses : nullptr,
                                 t->patches, t->intrinsics, ii, t->fmap1_slot));
       TRK_PROBE(1);
       TRK_DO(ramp_i_upd_corr_tail(t->corr, w.corr_w2, w.corr_b2, w.corr_w3, w.corr_b3, w.corr_ln_w, w.corr_ln_b,
@@ -825,10 +825,10 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
     const int32_t *corr_order = corr_sched ? t->ij_order : nullptr;
     if (corr_twice)
       TRK_DO(ramp_i_corr_fwd(t->gmap, lv, 2, t->coords, kk, jj, corr_order, t->corr, 896, (long)t->M * t->mem, t->mem, Eb,
-                             t->mem * t->M, t->mem, 128, t->P, 3, RAMP_F16, RAMP_NHWC32, dyn, st,
+                             t->mem * t->M, t->mem, 128, t->P, 3, RAMP_F16, t->feat_plain ? RAMP_NHWC : RAMP_NHWC32, dyn, st,
                              fuse_tf ? t->poses : nullptr, t->patches, t->intrinsics, ii, t->fmap1_slot));
     TRK_DO(ramp_i_corr_fwd(t->gmap, lv, 2, t->coords, kk, jj, corr_order, t->corr, 896, (long)t->M * t->mem, t->mem, Eb,
-                           t->mem * t->M, t->mem, 128, t->P, 3, RAMP_F16, RAMP_NHWC32, dyn, st,
+                           t->mem * t->M, t->mem, 128, t->P, 3, RAMP_F16, t->feat_plain ? RAMP_NHWC : RAMP_NHWC32, dyn, st,
                            fuse_tf ? t->poses : nullptr, t->patches, t->intrinsics, ii, t->fmap1_slot));
     TRK_PROBE(1);
     // the update operator, ramp/net.py:69-90 (the fp16 fused chains of csrc/update_mlp.hip)

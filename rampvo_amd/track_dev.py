@@ -63,7 +63,7 @@ class Track(ctypes.Structure):
                 + _ptr_fields(["fg", "ykk", "hkk", "yij", "hij", "relu_t", "sagg_frag", "target", "weight", "ba_ws"])
                 + [("ba_ws_bytes", c_sz)]
                 + _ptr_fields(["mm", "median", "dlog", "edit_ws", "dyn_host", "dyn_host_dev"]) + [("probe", c_p * 5), ("E_hint", c_i),
-                   ("gate_seq", ctypes.c_uint32), ("feat_fp32", c_i), ("gate_flag", c_p), ("fmap1_slot", c_p)]
+                   ("gate_seq", ctypes.c_uint32), ("feat_fp32", c_i), ("feat_plain", c_i), ("gate_flag", c_p), ("fmap1_slot", c_p)]
                 # speculative keyframe edit (include/ramp_hip.h: ramp_track.spec_*)
                 + _ptr_fields(["spec_stream", "spec_go", "spec_done", "spec_ev_go", "spec_ev_done"])
                 + [("spec_seq", ctypes.c_uint32), ("spec_pad", ctypes.c_uint32), ("spec_graph", c_p * 2), ("spec_dyn", c_p),
@@ -104,8 +104,9 @@ def supported(slam):
     operator's library GEMMs are issued by the host between the two halves of the step, still without reading the device) --
     with a full optimisation window"""
     cfg = slam.cfg
-    layout_ok = (slam.dtype == torch.half and slam._chunked) or (slam.dtype == torch.float and not slam._chunked
-                                                                 and os.environ.get("RAMP_DEVICE_STEP_FP32", "1") == "1")
+    # (fp16 features: the chunked pyramid layout, or plain NHWC planes where the feature plane's shape does not fit it)
+    layout_ok = slam.dtype == torch.half or (slam.dtype == torch.float and not slam._chunked
+                                             and os.environ.get("RAMP_DEVICE_STEP_FP32", "1") == "1")
     return (layout_ok and slam._lazy_net and slam.P == 3 and slam.DIM == 384
             and 3 * slam.M * 9 <= 8192 and cfg.MOTION_MODEL in ("DAMPED_LINEAR",)
             and cfg.PATCH_LIFETIME <= cfg.REMOVAL_WINDOW + 1 and cfg.KEYFRAME_INDEX >= 2
@@ -117,7 +118,6 @@ def unsupported_reason(slam):
     cfg = slam.cfg
     checks = [(slam.dtype == torch.half or os.environ.get("RAMP_DEVICE_STEP_FP32", "1") == "1",
                "MIXED_PRECISION is off and RAMP_DEVICE_STEP_FP32=0 (the fp32 path is host driven)"),
-              (slam._chunked or slam.dtype == torch.float, "the feature plane does not fit the chunked pyramid layout"),
               (slam.P == 3 and slam.DIM == 384, "patch size / feature width other than 3 / 384"),
               (3 * slam.M * 9 <= 8192, "PATCHES_PER_FRAME above 303 (the depth median of three frames is one workgroup's)"),
               (cfg.MOTION_MODEL in ("DAMPED_LINEAR",), "MOTION_MODEL other than DAMPED_LINEAR"),
@@ -196,6 +196,7 @@ class DeviceTrack:
         t.motion_damping = float(cfg.MOTION_DAMPING)
         t.keyframe_thresh = float(cfg.KEYFRAME_THRESH)
         t.feat_fp32 = 1 if self.fp32 else 0
+        t.feat_plain = 1 if (not self.fp32 and not slam._chunked) else 0
         P = lambda x: x.data_ptr()
         for name, ten in dict(dyn=self.dyn, poses=slam.poses_, patches=slam.patches_, intrinsics=slam.intrinsics_,
                               points=slam.points_, tstamps=slam.tstamps_, index_map=slam.index_map_, ixm=self.ixm,
@@ -305,7 +306,7 @@ class DeviceTrack:
         if self._fe_key == key:
             return True
         ok = (ex is not None and ex["fmap"].dtype == (torch.float32 if self.fp32 else torch.float16)
-              and bool(ex["chunked"]) == (not self.fp32) and patches.is_contiguous()
+              and bool(ex["chunked"]) == bool(self.slam._chunked) and patches.is_contiguous()
               and patches.dtype == torch.float32
               and all(ex[k].data_ptr() % 16 == 0 and ex[k].is_contiguous()
                       for k in ("colors", "imap", "gmap", "fmap", "fmap2")))

@@ -498,26 +498,33 @@ def test_device_resident_steps_and_frame_pipelining_do_not_change_results():
             assert np.array_equal(x, y)
 
 
-@pytest.mark.parametrize("M,mixed", [(50, True), (37, True), (50, False)])
+@pytest.mark.parametrize("M,mixed,hw", [(50, True, (240, 320)), (37, True, (240, 320)), (50, False, (240, 320)),
+                                        (48, True, (180, 240)), (48, False, (180, 240))])
 @torch.no_grad()
-def test_device_resident_steps_for_any_patch_count(M, mixed):
+def test_device_resident_steps_for_any_patch_count_and_plane_shape(M, mixed, hw):
     """PATCHES_PER_FRAME that is no multiple of 16 (the reference's precise.yaml ships 300), of 4 (50: the colour rows are
     150 bytes) or of 2 (37): the device-resident step takes them (the frame commit and the row shift copy a row in 16-, 4- or
-    1-byte pieces as its length allows) and stays bit-identical to the host-driven path, in the fp16 and the fp32 mode"""
+    1-byte pieces as its length allows) and stays bit-identical to the host-driven path, in the fp16 and the fp32 mode.
+    180 x 240 (a DAVIS240 frame): the 45 x 60 feature plane does not fit the chunked fp16 pyramid layout (width % 16,
+    height % 4) -- plain NHWC planes and corr_mfma_kernel<half, false>, still device resident (round 5: host driven)"""
     import gc
     import warnings
     from rampvo_amd.config import make_cfg
     from rampvo_amd.Ramp_vo import Ramp_vo
     from rampvo_amd.synthetic import SyntheticStream, make_network
     T = 36
-    stream = SyntheticStream(240, 320, T, seed=78, device="cuda")
+    H, W = hw
+    stream = SyntheticStream(H, W, T, seed=78, device="cuda")
     frames = [stream.frame(t) for t in range(T)]
     torch.cuda.synchronize()
     out = []
     for device_steps in (False, True):
         torch.manual_seed(5)
-        slam = Ramp_vo(make_cfg("default", PATCHES_PER_FRAME=M, MIXED_PRECISION=mixed), make_network("SingleScale"),
-                       {"event_bias": True}, ht=240, wd=320)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")                 # (180 x 240, fp16: the one-time note about the plane layout)
+            slam = Ramp_vo(make_cfg("default", PATCHES_PER_FRAME=M, MIXED_PRECISION=mixed), make_network("SingleScale"),
+                           {"event_bias": True}, ht=H, wd=W)
+        assert slam._chunked == (mixed and hw == (240, 320))
         slam.device_steps = device_steps
         resident = 0
         with warnings.catch_warnings():
