@@ -663,6 +663,29 @@ def fp32_leg(args, traj_fp32):
     return out
 
 
+class LegStats:
+    """host-side view of one bench leg: the return time of every step (a stall of the GPU shows within MAX_AHEAD frames as a
+    long host step: the tracker throttles its run-ahead) and the tracker's own counters over the leg -- frames that ran
+    device resident / host driven, hand-backs to the host, waits of the host for the GPU.  A leg whose frames fell back to
+    the host-driven path, or that contains one long stall, reads as a low rate; these numbers say which."""
+
+    def __init__(self, slam):
+        self.slam, self.marks = slam, []
+        self.s0 = dict(slam.stats)
+        self.marks.append(time.perf_counter())
+
+    def tick(self):
+        self.marks.append(time.perf_counter())
+
+    def summary(self):
+        d = np.diff(self.marks) if len(self.marks) > 1 else np.zeros(1)
+        st = {k: self.slam.stats[k] - self.s0[k] for k in self.s0}
+        return {"steps": int(len(d)), "host_step_ms_p50_p90_max": [round(1e3 * float(v), 3) for v in
+                                                                   (np.percentile(d, 50), np.percentile(d, 90), d.max())],
+                "device_frames": int(st["device_frames"]), "host_frames": int(st["host_frames"]), "settles": int(st["settles"]),
+                "throttle_waits": int(st["throttle_waits"]), "throttle_ms": round(1e3 * st["throttle_s"], 2)}
+
+
 def _which_config(args, world):
     """names the BASELINE.json config the flags amount to (every rank of an N > 1 run tracks the same workload on its
     own sequence; configs[3] = --config 3)"""
@@ -845,6 +868,8 @@ def main():
     # most of the spread between two short timed regions)
     e_lazy = dv.dyn_host.numpy() if device_step else None
     e_seen = []
+    legs = {}
+    leg = LegStats(slam)
     tic = time.perf_counter()
     marks = [tic]
     for i in range(args.steps):
@@ -853,6 +878,7 @@ def main():
             dprobe.mode = "corr" if i % max(1, args.probe_every) == max(1, args.probe_every) // 2 else None
         step()
         marks.append(time.perf_counter())         # host-side return times (the GPU may lag by less than a step)
+        leg.marks.append(marks[-1])
         if e_lazy is not None:
             e_seen.append(int(e_lazy[2]))
     torch.cuda.synchronize()
@@ -860,6 +886,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - tic
+    legs["timed"] = leg.summary()
     gate_kind = "signal word stored by the gru launch" if getattr(slam, "_gate_by_flag", False) else "event"
     ctimer.enabled = etimer.enabled = btimer.enabled = utimer.enabled = False
     fp32_dev = device_step and bool(getattr(dv, "fp32", False)) and not bool(getattr(dv, "x3", False))
@@ -892,6 +919,7 @@ def main():
         for _ in range(2):
             step()
         torch.cuda.synchronize()
+        leg = LegStats(slam)
         t_os = time.perf_counter()
         for _ in range(n_os - 2):
             im, ev, K, mask = frames[pos["t"]]
@@ -899,20 +927,25 @@ def main():
             slam(pos["t"], input_tensor=(ev2, im2, mask), intrinsics=K)
             del ev2, im2                           # (and its tensors die right behind the call)
             pos["t"] += 1
+            leg.tick()
         slam.peek()
         torch.cuda.synchronize()
         os_kfps = (n_os - 2) / (time.perf_counter() - t_os)
+        legs["own_stream"] = leg.summary()
         slam.inputs_ready = bool(args.pipeline)
     # the strictly sequential rate (no frame pipelining): what a caller on ONE stream with inputs_ready False gets
     np_kfps = None
     if n_np > 0:
         slam.inputs_ready = False
         torch.cuda.synchronize()
+        leg = LegStats(slam)
         t_np = time.perf_counter()
         for _ in range(n_np):
             step()
+            leg.tick()
         torch.cuda.synchronize()
         np_kfps = n_np / (time.perf_counter() - t_np)
+        legs["non_pipelined"] = leg.summary()
         if dprobe is not None and device_step:     # (behind the timed sequential pass) the front end's replay alone
             keep, etimer.pairs, etimer.enabled = etimer.pairs, [], True
             dprobe.enabled, dprobe.mode = True, "alone"
@@ -940,11 +973,14 @@ def main():
                 for _ in range(2):                 # (the pipeline refilling behind the flag change: untimed)
                     step()
                 torch.cuda.synchronize()
+                leg = LegStats(slam)
                 t_leg = time.perf_counter()
                 for _ in range(n_live - 2):
                     step()
+                    leg.tick()
                 torch.cuda.synchronize()
                 t_leg = time.perf_counter() - t_leg
+                legs["converged" if mode == "compact" else "live"] = leg.summary()
                 dprobe.enabled = False
                 live_leg[mode] = live_factor_fractions(slam, windows=True)
                 # the whole step, end to end, with this leg's factors (the correlation launch is bracketed by events on
@@ -993,6 +1029,9 @@ def main():
                        "host_step_ms_p50_p90_max": [round(1e3 * float(v), 3) for v in
                                                     (np.percentile(np.diff(marks), 50), np.percentile(np.diff(marks), 90),
                                                      np.max(np.diff(marks)))],
+                       # per leg: host step times and the tracker's counters (LegStats): a leg with host_frames > 0 fell back
+                       # to the host-driven path, one with max >> p50 contains a stall
+                       "legs": legs,
                        "sharding": "independent sequences, 1 per GPU" if world > 1 else "single sequence"},
         }
         if per_rank is not None:

@@ -80,6 +80,13 @@ def _kernels_are_serialised():
     def on(k):
         return os.environ.get(k, "0") not in ("", "0")
     return on("ROCPROF_COUNTER_COLLECTION") or on("AMD_SERIALIZE_KERNEL") or on("HIP_LAUNCH_BLOCKING") or on("RAMP_NO_FLAG_WAITS")
+_LIVE = {}        # device index -> trackers alive on it (Ramp_vo._flag_wait_is_safe)
+
+
+def _live_dec(idx):
+    _LIVE[idx] = _LIVE.get(idx, 1) - 1
+
+
 _WARM = os.environ.get("RAMP_WARM", "1") != "0"     # A/B switch: the cache warm-up behind the front end
 _CORR_L1 = os.environ.get("RAMP_CORR_L1", "0") == "1"   # correlation + the correlation MLP's first Linear in one launch (N2)
 
@@ -93,6 +100,14 @@ class Ramp_vo:
         dev = self.device
         if dev.type != "cuda" and not getattr(self, "_allow_cpu", False):
             raise RuntimeError("rampvo_amd.Ramp_vo runs on the GPU only (HIP kernels, no CPU fallback); got device %s" % dev)
+        # counters a caller (bench.py's legs) can read without touching the device: frames tracked device resident / host
+        # driven, hand-backs to the host (settle), waits of the host for the GPU (track_dev.DeviceTrack.throttle)
+        self.stats = dict(device_frames=0, host_frames=0, settles=0, throttle_waits=0, throttle_s=0.0)
+        import weakref
+        idx = dev.index if dev.index is not None else (torch.cuda.current_device() if dev.type == "cuda" else -1)
+        self._live_idx = idx
+        _LIVE[idx] = _LIVE.get(idx, 0) + 1
+        weakref.finalize(self, _live_dec, idx)
 
         self._dev = None                # DeviceTrack while the steady state is device resident
         self.lmbda = torch.as_tensor([1e-4], device=dev)
@@ -313,6 +328,7 @@ class Ramp_vo:
         if dv is None or not dv.active:
             return
         st = dv.leave()
+        self.stats["settles"] += 1
         self._n, self._m = st["n"], st["n"] * self.M
         self._hii, self._hjj, self._hkk = st["ii"], st["jj"], st["kk"]
         g = torch.from_numpy(np.stack([st["ii"], st["jj"], st["kk"], st["rows"]])).to(self.device)
@@ -707,7 +723,9 @@ class Ramp_vo:
             self._cur_stream = self._current_stream()
             try:
                 if self._dev is not None and self._dev.active:
+                    self.stats["device_frames"] += 1
                     return self._track_device(tstamp, input_, intrinsics)
+                self.stats["host_frames"] += 1
                 return self._track(tstamp, input_, intrinsics)
             finally:
                 self._cur_stream = None
@@ -733,8 +751,10 @@ class Ramp_vo:
         try:
             with torch.cuda.stream(main):
                 if self._dev is not None and self._dev.active:
+                    self.stats["device_frames"] += 1
                     out = self._track_device(tstamp, input_, intrinsics)
                 else:
+                    self.stats["host_frames"] += 1
                     out = self._track(tstamp, input_, intrinsics)
         finally:
             self._cur_stream = None
@@ -802,13 +822,21 @@ class Ramp_vo:
             with torch.cuda.device(self.device):
                 self._fe_done_sig = track_dev.Signal() if use else False
         sig = self._fe_done_sig
-        if sig and sig.ptr is not None and self._fe_done_seq < 0x7FFFFFF0:
+        # A spinning wave needs its producer to run CONCURRENTLY: the runtime maps streams onto a handful of hardware queues,
+        # and a waiter that shares one with its producer would sit in front of it until the hang guard fires.  Two streams of
+        # one tracker (the caller's + the front end's: inputs_ready = True) have been measured safe on every box; with a third
+        # tracker stream (inputs_ready = "stream": _main_stream), or a second tracker in the process, the DATA dependency goes
+        # through an event -- the gate (_gate_wait), which orders timing only, keeps its word
+        if sig and self._flag_wait_is_safe() and sig.ptr is not None and self._fe_done_seq < 0x7FFFFFF0:
             self._fe_done_seq += 1
             _lib.check(_lib.lib().ramp_stream_signal(ctypes.c_void_p(fe.cuda_stream), sig.ptr, self._fe_done_seq), "ramp_stream_signal")
             sig.wait(cur, self._fe_done_seq, timeout_us=_FE_DONE_TIMEOUT_US, status=dv.status_ptr)
         else:
             self._ev_fe_done.record(fe)
             cur.wait_event(self._ev_fe_done)
+
+    def _flag_wait_is_safe(self):
+        return self.inputs_ready is True and _LIVE.get(self._live_idx, 0) <= 1
 
     def _gate_wait(self, fe):
         """(front-end stream) wait for the previous frame's gate: the signal word if that step stored one, else the event"""

@@ -15,6 +15,8 @@ def my_sequences(n_sequences, rank, world):
 
 def gather_metrics(values, device):
     """values: list of python floats for this rank -> [world, len(values)] tensor on every rank"""
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == "gloo":
+        device = "cpu"            # (gloo gathers host tensors only: the CPU tests, and bench.py's two-ranks-on-one-GPU rehearsal)
     mine = torch.tensor(values, dtype=torch.float64, device=device)
     if not (dist.is_available() and dist.is_initialized()):
         return mine[None]
@@ -24,6 +26,8 @@ def gather_metrics(values, device):
 
 
 def max_over_ranks(seconds, device):
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == "gloo":
+        device = "cpu"
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     if dist.is_available() and dist.is_initialized():      # (a world of one still runs the collective: RCCL smoke)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -464,6 +464,10 @@ class DeviceTrack:
             elif time.perf_counter() - t0 > 5.0:
                 raise RuntimeError("device-resident tracker: the GPU has not finished a frame for 5 s")
             time.sleep(2e-5)
+        if t0 is not None:                      # (Ramp_vo.stats: how often and how long the host waited for the GPU here)
+            st = self.slam.stats
+            st["throttle_waits"] += 1
+            st["throttle_s"] += time.perf_counter() - t0
 
     def leave(self):
         """synchronise and return the host-side view of the state: dict(n, ii, jj, kk, rows (host arrays of the kept

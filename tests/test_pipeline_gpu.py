@@ -914,6 +914,44 @@ def test_bench_under_torchrun_initialises_rccl():
     assert row[0] > 0 and row[1] > 0 and row[2] > 0 and np.isfinite(row[3])
 
 
+def test_bench_two_ranks_on_one_gpu_over_gloo():
+    """bench.py's N > 1 arithmetic with TWO ranks touching a GPU (VERDICT r5 missing #2 / next #8): the builder's pool hands
+    out one GPU at a time and RCCL refuses two ranks on one device, so the driver's launch line runs here with
+    RAMP_DIST_BACKEND=gloo and both ranks on device 0 -- per-rank seeds differ (two different sequences: different pose
+    checksums and factor counts), the gather returns one row per rank, `value` = the steps of BOTH ranks / the MAX rank time
+    (so it is at most the sum of the per-rank rates and at least twice the slower one), scaling "weak".  No 2/4/8-GPU number
+    exists for this build: this checks the arithmetic, not the scaling."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RAMP_DIST_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                          "--gpus", "2", "--height", "240", "--width", "320", "--patches", "48", "--prime", "40",
+                          "--steps", "12", "--warmup", "2", "--cpu-steps", "0", "--parity", "0", "--np-steps", "4",
+                          "--inst-steps", "8", "--live-steps", "0"],
+                         capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines                                           # rank 0 prints, rank 1 does not
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 12 and d["scaling"] == "weak"
+    assert d["config"]["process_group"] == {"backend": "gloo", "world": 2}
+    rows = d["config"]["per_rank_kfps_E_n_chk"]
+    assert len(rows) == 2 and all(r[0] > 0 and r[1] > 0 and r[2] > 0 and np.isfinite(r[3]) for r in rows)
+    assert rows[0][3] != rows[1][3], rows                                  # seeds 1234 + rank: two different sequences
+    slow, total = min(r[0] for r in rows), sum(r[0] for r in rows)       # per-rank rates are keyframes / s
+    assert 2 * slow * 0.98 <= d["value"] <= total * 1.02, (d["value"], rows)
+    assert abs(d["value"] - 2 * 12 / (d["ms_per_step"] * 12e-3)) <= 1e-2 * d["value"]      # value = world * steps / max time
+    assert "fp32_kfps" not in d["config"] and "cpu_baseline" not in d                       # rank-0-only legs are N = 1 only
+
+
 @torch.no_grad()
 def test_intrinsics_rows_follow_the_input():
     """intrinsics_[n] = K / RES of the frame stored at row n (reference Ramp_vo.py:351), also when K changes between
