@@ -111,20 +111,6 @@ int ramp_corr_fwd_ordered(const void *fmap1, const ramp_corr_level *levels_host,
                           const int32_t *order, void *out, int out_row_elems, long mod_ii, long mod_jj, int E,
                           int N1, int N2, int C, int P, int radius, int dtype, int layout, void *stream);
 
-/* Correlation AND the first Linear (+ ReLU) of the update operator's correlation MLP in one launch -- SURVEY N2:
- * "corr-MLP first layer fused with corr output (avoid materialising [E,882])"; replaces cuda_corr.forward over both
- * pyramid levels (ramp/altcorr/correlation.cpp:28-35, ramp/Ramp_vo.py:175-182) followed by Update.corr[0] + ReLU
- * (ramp/net.py:60-61).  fp16 features, P = 3, radius 3, two levels (coord_div 1 and 4), C = 128;
- * layout RAMP_NHWC or RAMP_NHWC32 (target maps; fmap1 [N1][3][3][128]).
- *   w1_packed  Linear(882 -> 384).weight zero-padded to corr_k = 896 columns, as fp16 MFMA fragments
- *              [corr_k / 32][24][64 lanes][8]: lane (q, j) of fragment (ks, nt) holds W[16 nt + j][32 ks + 8 q ..]
- *   b1 [384] fp32;  c1 [E][384] fp16 = relu(W1 corr_row + b1) -- the input of ramp_upd_corr_tail, bit-identical to
- *   what ramp_upd_corr_mlp forms from ramp_corr_fwd_ordered's rows.  The [E, 896] rows are never written.          */
-int ramp_corr_l1_fwd_ordered(const void *fmap1, const ramp_corr_level *levels_host, const float *coords,
-                             const int64_t *ii, const int64_t *jj, const int32_t *order, const void *w1_packed,
-                             const float *b1, int corr_k, void *c1, long mod_ii, long mod_jj, int E, int layout,
-                             void *stream);
-
 /* Ramp_vo.__call__'s pyramid store (ramp/Ramp_vo.py:378-381: fmap1_[slot] =
  * fmap, fmap2_[slot] = avg_pool2d(fmap, 4, 4)) for fp16 channels-last features:
  * fmap [H][W][C] -> level1 [H][C/32][W][32] (same values) and level4
@@ -323,7 +309,7 @@ int ramp_group_by_small(const int64_t *a, const int64_t *b, int64_t mul, int64_t
 /* cuda_ba.neighbors derived from the per-kk groups (no second sort): every group's edges are
  * ranked by (jj, edge index).  Groups longer than 1024 edges are left untouched (use
  * ramp_neighbors for such graphs).  kj_order (optional, int32 [E]): the factors in that (kk, jj) order -- a
- * factor's temporal neighbours are its neighbours in this list (ramp_upd_nbr2).                  */
+ * factor's temporal neighbours are its neighbours in this list.                                    */
 int ramp_neighbors_from_groups(const int32_t *order, const int32_t *seg_start, const int32_t *ngroups,
                                const int64_t *jj, int64_t *ix, int64_t *jx, int32_t *kj_order, int E,
                                int max_groups, void *stream);
@@ -554,19 +540,12 @@ size_t ramp_upd_mlp_lds_bytes(void);
 int ramp_upd_nbr(const float *net_in, const int64_t *idx, const void *wa, const float *ba, const void *wb,
                  const float *bb, float *net_out, void *out_t, int E, void *stream);
 
-/* Tail of the correlation MLP and Update.norm in one launch (ramp/net.py:57-62, 71-74):
- *   net_out[e] = LayerNorm_norm(net[net_map[e]] + inp[inp_idx[e] % inp_mod] + L3(relu(LayerNorm_ln(L2(c1[e])))))
- * c1 [E][384] fp16 = relu(L1(corr)) (the K = 896 library GEMM); w2 / w3 packed like ramp_upd_gru's weights,
- * b2 / b3 fp32 [384]; net NULL = zeros, net_map NULL = identity, -1 = zero row; inp_idx NULL = identity,
- * inp_mod <= 0 = no modulo.  net_out fp32 [E][384], must not alias net.                              */
-int ramp_upd_corr_tail(const void *c1, const void *w2, const float *b2, const void *w3, const float *b3,
-                       const float *ln_w, const float *ln_b, float ln_eps, const float *net, const int64_t *net_map,
-                       const void *inp, const int64_t *inp_idx, long inp_mod, const float *norm_w,
-                       const float *norm_b, float norm_eps, float *net_out, int E, void *stream);
-
-/* The whole correlation MLP and Update.norm in one launch: as ramp_upd_corr_tail, with c1 = relu(L1(corr)) formed by
- * the kernel itself from corr [E][corr_k] fp16 (corr_k a multiple of 32: 896 = 882 + zero padding; w1 packed
- * [corr_k/32][24][64][8] from the zero-padded weight, b1 fp32 [384]).                                   */
+/* The whole correlation MLP and Update.norm in one launch (ramp/net.py:57-62, 71-74):
+ *   c = Linear3(relu(LayerNorm(Linear2(relu(Linear1(corr))))));  net_out = LayerNorm_norm((net[net_map] + inp[inp_idx % inp_mod]) + c)
+ * corr [E][corr_k] fp16 (corr_k a multiple of 32: 896 = 882 + zero padding); w1 packed [corr_k/32][24][64][8] from the
+ * zero-padded weight, w2 / w3 packed like ramp_upd_gru's weights, biases fp32 [384] (fp16-rounded values); net [*][384] fp32 or
+ * NULL (zeros), net_map [E] (-1: zero row) or NULL (identity); inp [*][384] fp16, inp_idx NULL = identity.  Linear outputs
+ * are rounded to fp16 where the reference's autocast makes them half tensors.                                             */
 int ramp_upd_corr_mlp(const void *corr, int corr_k, const void *w1, const float *b1, const void *w2, const float *b2,
                       const void *w3, const float *b3, const float *ln_w, const float *ln_b, float ln_eps,
                       const float *net, const int64_t *net_map, const void *inp, const int64_t *inp_idx, long inp_mod,
@@ -583,15 +562,6 @@ int ramp_upd_heads_linear(const void *relu_t, const void *heads_w, const float *
  * weights, bf / bg fp32 [384].                                                                        */
 int ramp_upd_fg(const float *x32, const void *add_t, const int32_t *add_idx, float *x32_out, const void *wf,
                 const float *bf, const void *wg, const float *bg, void *fg, int E, void *stream);
-
-/* Both temporal-neighbour MLPs of the update operator in ONE launch (ramp/net.py:77-82: net += c1(mask * net[ix]);
- * net += c2(mask * net[jx])): a workgroup walks 78 consecutive positions of the (kk, jj)-sorted factor list kj
- * (ramp_neighbors_from_groups), where a factor's temporal neighbours are the positions before / after it; the state is
- * read once and written once instead of 4 + 2 times.  Bit-identical to ramp_upd_nbr(c1) followed by ramp_upd_nbr(c2).
- * Weights / biases as ramp_upd_nbr; net_out must not alias net_in.                                                   */
-int ramp_upd_nbr2(const float *net_in, const int32_t *kj, const int64_t *ix, const int64_t *jx, const void *w1a,
-                  const float *b1a, const void *w1b, const float *b1b, const void *w2a, const float *b2a,
-                  const void *w2b, const float *b2b, float *net_out, int E, void *stream);
 
 /* nn.Linear(384, 384) on a small fp16 table: y[r] = fp16(x[r] W^T + b) -- SoftAgg's `h` layer on the group table
  * (ramp/blocks.py:46-47), the one GEMM of the fused update operator that used to be a library call.  w_packed like
@@ -714,12 +684,6 @@ typedef struct ramp_track_weights {      /* update operator, fp16 fused formats 
   float corr_ln_eps, norm_eps, ln1_eps, ln2_eps;
 } ramp_track_weights;
 
-typedef struct ramp_plan_set {      /* the graph plan's arrays (a candidate set of ramp_track's speculative keyframe edit) */
-  int32_t *kk_order, *kk_gid, *kk_seg, *kk_ngroups, *ij_order, *ij_gid, *ij_seg, *ij_ngroups;
-  int64_t *kk_ukeys, *ij_ukeys, *ix, *jx;
-  int32_t *kj;
-} ramp_plan_set;
-
 typedef struct ramp_track {
   /* configuration (cfg: PATCHES_PER_FRAME, PATCH_LIFETIME, REMOVAL_WINDOW, OPTIMIZATION_WINDOW, KEYFRAME_INDEX,
    * KEYFRAME_THRESH, MOTION_MODEL (1 DAMPED_LINEAR, 2 copy), MOTION_DAMPING) */
@@ -743,7 +707,7 @@ typedef struct ramp_track {
   /* graph plan */
   int32_t *kk_order, *kk_gid, *kk_seg, *kk_ngroups, *ij_order, *ij_gid, *ij_seg, *ij_ngroups;
   int64_t *kk_ukeys, *ij_ukeys, *ix, *jx;
-  int32_t *kj;                        /* [E_cap] factors in (kk, jj) order (ramp_upd_nbr2)                        */
+  int32_t *kj;                        /* [E_cap] factors in (kk, jj) order (a by-product of the neighbour search)  */
   void *plan_ws;                      /* ZERO before the first plan (each plan leaves its histograms cleared)      */
   size_t plan_ws_bytes;
   /* update operator */
@@ -792,23 +756,6 @@ typedef struct ramp_track {
                                        * (ramp/Ramp_vo.py:259-271 shifts them); every reader of `fmap1` rows (correlation, frame
                                        * commit, warm-up) goes through the table; the caller undoes the permutation when it takes
                                        * the buffers back.  NULL: rows are slots                                           */
-  /* Speculative keyframe edit (round 5; optional, spec_stream NULL = the serial tail).  Ramp_vo.keyframe()'s graph edit and
-   * the next graph's plan (ramp/Ramp_vo.py:247-274, 312-325) depend on the motion test's DECISION only: ramp_track_step
-   * computes both outcomes (keyframe n - KEYFRAME_INDEX kept / dropped) on `spec_stream`, beside correlation and the update operator, into
-   * the candidate buffers below, and the tail behind the motion test is ONE launch that takes the decision and copies the
-   * chosen candidate into graph[1 - cur], the plan arrays and dyn (csrc/track.hip::trk_select_kernel) instead of seven
-   * dependent ones.  Same kernels on the same inputs: bit-identical state.                                              */
-  void *spec_stream;                  /* hipStream_t of the speculative launches                                          */
-  uint32_t *spec_go, *spec_done;      /* signal words (ramp_signal_alloc): "the live graph / sizes are final" (stored by this
-                                       * step's first launch on the caller's stream, the commit) and "both candidates are
-                                       * ready"; NULL: the two events below order the streams (profilers that serialise kernels) */
-  void *spec_ev_go, *spec_ev_done;    /* hipEvent_t handles, used when the signal words are NULL                              */
-  uint32_t spec_seq, spec_pad;        /* this step's sequence number: any value that grows from step to step                  */
-  int64_t *spec_graph[2];             /* [4][E_cap] each: [0] keep, [1] remove                                              */
-  int32_t *spec_dyn;                  /* [2][RAMP_DYN_WORDS]                                                                */
-  ramp_plan_set spec_plan[2];
-  void *spec_plan_ws;                 /* as plan_ws (ZERO before the first use)                                            */
-  int32_t *spec_edit_ws;              /* as edit_ws                                                                        */
 } ramp_track;
 
 /* cache warm-up for the next step's correlation kernel: reads the planes of the window's frames and the patch features

@@ -88,7 +88,6 @@ def _live_dec(idx):
 
 
 _WARM = os.environ.get("RAMP_WARM", "1") != "0"     # A/B switch: the cache warm-up behind the front end
-_CORR_L1 = os.environ.get("RAMP_CORR_L1", "0") == "1"   # correlation + the correlation MLP's first Linear in one launch (N2)
 
 
 class Ramp_vo:
@@ -470,16 +469,6 @@ class Ramp_vo:
             lv[1] = _lib.CorrLevel(self.fmap2_.data_ptr(), self.fmap2_.shape[1], self.fmap2_.shape[3], 4.0)
             self._corr_levels = lv
         E = coords.shape[1]
-        if _CORR_L1:
-            # SURVEY N2, first clause (RAMP_CORR_L1=1; the device-resident step reads the same switch): the correlation
-            # launch applies the correlation MLP's first Linear + ReLU itself -- c1 [E, 384] instead of the [E, 896] rows
-            w1, b1 = self.network.update.fused(self.dtype).weights()["corr1_pack"]
-            c1 = torch.empty((E, 384), dtype=torch.half, device=self.device)
-            _lib.check(_lib.lib().ramp_corr_l1_fwd_ordered(
-                _lib.ptr(self.gmap_), self._corr_levels, _lib.ptr(coords), _lib.ptr(ii), _lib.ptr(jj), _lib.ptr(order),
-                _lib.ptr(w1), _lib.ptr(b1), CORR_ROW, _lib.ptr(c1), self.M * self.mem, self.mem, E, RAMP_NHWC32,
-                _lib.stream()), "ramp_corr_l1_fwd_ordered")
-            return c1.view(1, E, 384)
         out = torch.empty((E, CORR_ROW), dtype=torch.half, device=self.device)
         _lib.check(_lib.lib().ramp_corr_fwd_ordered(
             _lib.ptr(self.gmap_), self._corr_levels, 2, _lib.ptr(coords), _lib.ptr(ii), _lib.ptr(jj),
@@ -680,7 +669,7 @@ class Ramp_vo:
         with Timer("other", enabled=self.enable_timing):
             plan = self._graph_plan()
             coords = self.reproject()
-            order = plan.g_ij.order if os.environ.get("RAMP_CORR_ORDER", "1") == "1" else None
+            order = plan.g_ij.order
             corr = self.corr(coords, order=order).to(self.dtype)
             # GEMMs + row-fused glue (csrc/update.hip) / the fused fp16 chains (csrc/update_mlp.hip); the context
             # gather, the heads' activations, `target = centre + delta` and filter_features are folded in

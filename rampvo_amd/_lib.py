@@ -52,8 +52,6 @@ SIGNATURES = {
     "ramp_pyramid_pack": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "ramp_corr_fwd_ordered": (c_i, [c_p, ctypes.POINTER(CorrLevel), c_i, c_p, c_p, c_p, c_p, c_p, c_i, ctypes.c_long,
                                     ctypes.c_long] + [c_i] * 8 + [c_p]),
-    "ramp_corr_l1_fwd_ordered": (c_i, [c_p, ctypes.POINTER(CorrLevel), c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, ctypes.c_long,
-                                       ctypes.c_long, c_i, c_i, c_p]),
     "ramp_se3_exp": (c_i, [c_p, c_p, c_i, c_p]),
     "ramp_se3_log": (c_i, [c_p, c_p, c_i, c_p]),
     "ramp_se3_inv": (c_i, [c_p, c_p, c_i, c_p]),
@@ -102,8 +100,6 @@ SIGNATURES = {
     "ramp_upd_gated": (c_i, [c_p] * 5 + [c_f, c_p, c_p, c_p, c_i, c_i, c_p]),
     "ramp_upd_heads": (c_i, [c_p] * 5 + [c_i, c_i, c_f, c_f, c_i, c_p]),
     "ramp_upd_segment_softmax": (c_i, [c_p] * 5 + [c_i, c_i, c_p]),
-    "ramp_upd_corr_tail": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, ctypes.c_long, c_p, c_p,
-                                 c_f, c_p, c_i, c_p]),
     "ramp_upd_corr_mlp": (c_i, [c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, ctypes.c_long,
                                 c_p, c_p, c_f, c_p, c_i, c_p]),
     "ramp_upd_heads_linear": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_p]),
@@ -114,7 +110,6 @@ SIGNATURES = {
                                  c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_p]),
     "ramp_upd_mlp_lds_bytes": (c_sz, []),
     "ramp_upd_nbr": (c_i, [c_p] * 8 + [c_i, c_p]),
-    "ramp_upd_nbr2": (c_i, [c_p] * 13 + [c_i, c_p]),
     "ramp_upd_linear": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_p]),
     "ramp_upd_softagg_frag_rows": (c_sz, [c_i, c_i]),
     "ramp_upd_softagg": (c_i, [c_p] * 10 + [c_i, c_p]),

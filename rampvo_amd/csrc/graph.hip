@@ -350,7 +350,8 @@ struct PlanDyn {
   int Gcap[2];           // capacity of seg / ukeys (groups): more groups than that are flagged (status bit 8), never written
   int32_t *status;
 };
-// up to two plans in one set of launches (blockIdx.z): the candidates of the tracker's speculative keyframe edit
+// (up to two plans in one set of launches, blockIdx.z: the shipped step launches one; the pair served round 5's speculative
+// keyframe edit, tools/shelved/)
 struct PlanPair {
   PlanDyn s[2];
   int64_t *ix[2], *jx[2];
@@ -614,11 +615,7 @@ static int plan_fill(PlanPair &pp, int z, const int64_t *g4, int E_cap, int E_gr
 static int plan_launch(const PlanPair &pp, int nz, int E_cap, int E_grid, int kkey_cap, int pkey_cap, int kk_cap, int ij_cap,
                        int32_t *mirror, hipStream_t st) {
   const int nb = ramp_cdiv(E_grid > 0 && E_grid < E_cap ? E_grid : E_cap, PLAN_EPB);
-  // (RAMP_SPEC_PLAN_LDS=0: the pair's histogram and scatter straight to memory -- measured slower, the correlation launch
-  // beside it 125 -> 140 us)
-  static int pair_lds = -1;
-  if (pair_lds < 0) { const char *e = getenv("RAMP_SPEC_PLAN_LDS"); pair_lds = e ? atoi(e) : 1; }
-  const bool lds = kkey_cap <= PLAN_LDS_K && pkey_cap <= PLAN_LDS_K && (nz == 1 || pair_lds);
+  const bool lds = kkey_cap <= PLAN_LDS_K && pkey_cap <= PLAN_LDS_K;
   if (lds) hipLaunchKernelGGL(plan_hist_kernel<true>, dim3(nb, 2, nz), dim3(256), 0, st, pp);
   else hipLaunchKernelGGL(plan_hist_kernel<false>, dim3(nb, 2, nz), dim3(256), 0, st, pp);
   hipLaunchKernelGGL(plan_scan_kernel, dim3(2, 1, nz), dim3(1024), 0, st, pp);
@@ -643,22 +640,6 @@ int ramp_i_plan_dyn(const int64_t *g4, int E_cap, int E_grid, const int32_t *dyn
   pp.s[1] = pp.s[0]; pp.ix[1] = ix; pp.jx[1] = jx; pp.kj[1] = kj;
   return plan_launch(pp, 1, E_cap, E_grid, kkey_cap, pkey_cap, kk_cap, ij_cap, mirror, st);
 }
-// two plans (the candidates of the speculative keyframe edit) in one set of launches: graphs g4[z], sizes dyn[z] (status word
-// inside: + RAMP_DYN_STATUS), outputs set[z], workspaces ws[z] of ramp_i_plan_dyn_ws bytes each
-int ramp_i_plan_dyn_pair(const int64_t *const g4[2], int E_cap, int E_grid, int32_t *const dyn[2], int M, int kkey_cap,
-                         int pkey_cap, int kk_cap, int ij_cap, const ramp_plan_set set[2], void *const ws[2], size_t ws_bytes,
-                         hipStream_t st) {
-  PlanPair pp;
-  for (int z = 0; z < 2; z++) {
-    const ramp_plan_set &q = set[z];
-    const int rc = plan_fill(pp, z, g4[z], E_cap, E_grid, dyn[z], dyn[z] ? dyn[z] + RAMP_DYN_STATUS : nullptr, M, kkey_cap,
-                             pkey_cap, kk_cap, ij_cap, q.kk_order, q.kk_gid, q.kk_seg, q.kk_ngroups, q.kk_ukeys, q.ij_order,
-                             q.ij_gid, q.ij_seg, q.ij_ngroups, q.ij_ukeys, q.ix, q.jx, q.kj, ws[z], ws_bytes);
-    if (rc != RAMP_OK) return rc;
-  }
-  return plan_launch(pp, 2, E_cap, E_grid, kkey_cap, pkey_cap, kk_cap, ij_cap, nullptr, st);
-}
-
 extern "C" {
 
 size_t ramp_group_by_small_workspace_bytes(int E, int K) {

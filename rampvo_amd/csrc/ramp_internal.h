@@ -39,9 +39,6 @@ int ramp_i_plan_dyn(const int64_t *g4, int E_cap, int E_grid, const int32_t *dyn
                     int32_t *kk_ngroups, int64_t *kk_ukeys, int32_t *ij_order, int32_t *ij_gid, int32_t *ij_seg,
                     int32_t *ij_ngroups, int64_t *ij_ukeys, int64_t *ix, int64_t *jx, int32_t *kj, void *ws,
                     size_t ws_bytes, int32_t *mirror, hipStream_t st);
-int ramp_i_plan_dyn_pair(const int64_t *const g4[2], int E_cap, int E_grid, int32_t *const dyn[2], int M, int kkey_cap,
-                         int pkey_cap, int kk_cap, int ij_cap, const ramp_plan_set set[2], void *const ws[2], size_t ws_bytes,
-                         hipStream_t st);
 size_t ramp_i_ba_dyn_ws(int E_cap, int n_poses, int n_patches, int opt_window, int max_patches, int max_pairs);
 int ramp_i_ba_dyn(float *poses, float *patches, const float *intrinsics, const float *target, const float *weight,
                   const float *lmbda, const int64_t *ii, const int64_t *jj, const int64_t *kk, int E_cap, int P,
@@ -55,15 +52,6 @@ int ramp_i_corr_fwd(const void *fmap1, const ramp_corr_level *levels, int nlevel
                     long mod_ii, long mod_jj, int E, int N1, int N2, int C, int P, int radius, int dtype, int layout,
                     const int32_t *dyn, void *stream, const float *tf_poses = nullptr, const float *tf_patches = nullptr,
                     const float *tf_intr = nullptr, const int64_t *tf_src = nullptr, const int32_t *slot0 = nullptr);
-int ramp_i_corr_l1_fwd(const void *fmap1, const ramp_corr_level *levels, const float *coords, const int64_t *ii,
-                       const int64_t *jj, const int32_t *order, const void *w1_packed, const float *b1, int corr_k,
-                       void *c1, long mod_ii, long mod_jj, int E, int layout, const int32_t *dyn, void *stream,
-                       const float *tf_poses = nullptr, const float *tf_patches = nullptr, const float *tf_intr = nullptr,
-                       const int64_t *tf_src = nullptr, const int32_t *slot0 = nullptr);
-int ramp_i_upd_corr_tail(const void *c1, const void *w2, const float *b2, const void *w3, const float *b3,
-                         const float *ln_w, const float *ln_b, float ln_eps, const float *net, const int64_t *net_map,
-                         const void *inp, const int64_t *inp_idx, long inp_mod, const float *norm_w, const float *norm_b,
-                         float norm_eps, float *net_out, int E, const int32_t *dyn, void *stream);
 int ramp_i_upd_gru(const float *x32, const void *add0_t, const int32_t *add0_idx, const void *add_t, const int32_t *add_idx,
                  const float *pre_w, const float *pre_b,
                    float pre_eps, const void *const *wp_host, const float *const *bias_host, const float *ln_w,
@@ -72,9 +60,6 @@ int ramp_i_upd_gru(const float *x32, const void *add0_t, const int32_t *add0_idx
                    float wd, float ht, int E_hint, uint32_t *gate_flag, uint32_t gate_seq, void *stream);
 int ramp_i_upd_nbr(const float *net_in, const int64_t *idx, const void *wa, const float *ba, const void *wb,
                    const float *bb, float *net_out, void *out_t, int E, const int32_t *dyn, void *stream);
-int ramp_i_upd_nbr2(const float *net_in, const int32_t *kj, const int64_t *ix, const int64_t *jx, const void *w1a,
-                    const float *b1a, const void *w1b, const float *b1b, const void *w2a, const float *b2a,
-                    const void *w2b, const float *b2b, float *net_out, int E, const int32_t *dyn, void *stream);
 int ramp_i_upd_corr_mlp(const void *corr, int corr_k, const void *w1, const float *b1, const void *w2, const float *b2,
                         const void *w3, const float *b3, const float *ln_w, const float *ln_b, float ln_eps,
                         const float *net, const int64_t *net_map, const void *inp, const int64_t *inp_idx, long inp_mod,

@@ -41,31 +41,17 @@ struct TrkEdit {
   int nbuf;
   int32_t *slot_tab;       // optional (ramp_track.fmap1_slot): the rows of buffer slot_buf are not moved, the table is rotated
   int slot_buf, slot_mod;
-  // speculative edit (trk_select_kernel): spec != 0 -- blockIdx.z is the OUTCOME the launch assumes (0 keep, 1 remove); the
-  // sizes are read from dyn (the live block) and written to that candidate's block, the graph goes to the candidate's
-  // buffer; no delta-log entry, no row shift
-  int spec;
-  int32_t *cdyn[2];
-  int64_t *cgout[2];
-  int32_t *cws[2];         // cnt / off / fmin of each candidate
 };
-// what a launch reads and writes: the live buffers and the motion test's decision, or candidate blockIdx.z's
+// what a launch reads and writes (one indirection kept from the speculative-edit experiment of round 5, tools/shelved/)
 struct TrkCand {
   const int32_t *dyn_in;   // sizes before the edit
   int32_t *dyn;            // sizes after
   int64_t *gout;
   int32_t *cnt, *off, *fmin;
-  int force;               // -1: the motion test decides
 };
 __device__ __forceinline__ TrkCand trk_cand(const TrkEdit &p) {
   TrkCand c;
-  c.dyn_in = p.dyn;
-  if (!p.spec) {
-    c.dyn = p.dyn; c.gout = p.gout; c.cnt = p.cnt; c.off = p.off; c.fmin = p.fmin; c.force = -1;
-  } else {
-    const int o = blockIdx.z;
-    c.dyn = p.cdyn[o]; c.gout = p.cgout[o]; c.cnt = p.cws[o]; c.off = p.cws[o] + p.nb; c.fmin = p.cws[o] + 2 * p.nb; c.force = o;
-  }
+  c.dyn_in = p.dyn; c.dyn = p.dyn; c.gout = p.gout; c.cnt = p.cnt; c.off = p.off; c.fmin = p.fmin;
   return c;
 }
 
@@ -84,14 +70,14 @@ __device__ __forceinline__ bool trk_edge(bool remove, long k, long kcut, int M, 
 }
 struct TrkDecision { bool remove; long k, kcut; int n, n_after; };
 __device__ __forceinline__ TrkDecision trk_decision(const int32_t *dyn, const float *mm, double thresh, int ki,
-                                                    int removal_window, int M, bool after_decide, int force = -1) {
+                                                    int removal_window, int M, bool after_decide) {
   TrkDecision d;
   if (after_decide) {              // trk_decide has already rewritten dyn
     d.n = dyn[RAMP_DYN_NPREV];
     d.remove = dyn[RAMP_DYN_REMOVED] != 0;
   } else {
     d.n = dyn[RAMP_DYN_N];
-    d.remove = force >= 0 ? force != 0 : trk_remove(mm, thresh);
+    d.remove = trk_remove(mm, thresh);
   }
   d.k = d.n - ki;
   d.n_after = d.remove ? d.n - 1 : d.n;
@@ -106,7 +92,7 @@ __global__ void __launch_bounds__(256) trk_flag_kernel(const TrkEdit p) {
   const int E = c.dyn_in[RAMP_DYN_E];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (b * TRK_EB >= E) return;
-  const TrkDecision d = trk_decision(c.dyn_in, p.mm, p.thresh, p.keyframe_index, p.removal_window, p.M, false, c.force);
+  const TrkDecision d = trk_decision(c.dyn_in, p.mm, p.thresh, p.keyframe_index, p.removal_window, p.M, false);
   int cnt = 0, fmin = 0x7fffffff;
 #pragma unroll
   for (int pass = 0; pass < TRK_EB / 256; pass++) {
@@ -156,9 +142,9 @@ __global__ void __launch_bounds__(256) trk_decide_kernel(const TrkEdit p) {
   }
   if (tid != 0) return;
   const int Ek = s_sum[255];
-  const TrkDecision d = trk_decision(c.dyn_in, p.mm, p.thresh, p.keyframe_index, p.removal_window, p.M, false, c.force);
+  const TrkDecision d = trk_decision(c.dyn_in, p.mm, p.thresh, p.keyframe_index, p.removal_window, p.M, false);
   int status = 0;
-  if (d.remove && c.force < 0) {
+  if (d.remove) {
     // Ramp_vo.py:249-253: delta[t1] = (t0, poses[k] * poses[k-1]^-1), read back by terminate()
     const int idx = p.dyn[RAMP_DYN_NLOG];
     if (idx < p.log_cap) {
@@ -200,8 +186,7 @@ __global__ void __launch_bounds__(256) trk_decide_kernel(const TrkEdit p) {
   c.dyn[RAMP_DYN_W] = n1 - flo;
   c.dyn[RAMP_DYN_FRAME] = (int)p.counter;
   c.dyn[RAMP_DYN_FRAME2] = (int)p.counter;       // second tag, in the other half of the block: a torn host copy shows
-  if (c.force >= 0) c.dyn[RAMP_DYN_STATUS] = status;       // a candidate collects its own capacity flags (the plan ORs in)
-  else if (status) atomicOr(c.dyn + RAMP_DYN_STATUS, status);   // (the front-end stream's gate wait may OR its time-out bit in)
+  if (status) atomicOr(c.dyn + RAMP_DYN_STATUS, status);   // (the front-end stream's gate wait may OR its time-out bit in)
 }
 
 // grid (nb + new-factor workgroups, 1 + nbuf).  y = 0: x < nb compacts the kept factors of edit workgroup x (stable),
@@ -333,87 +318,6 @@ __global__ void __launch_bounds__(256) trk_apply_kernel(const TrkEdit p) {
   oi[Ek + idx] = kk / p.M; oj[Ek + idx] = jj; ok[Ek + idx] = kk; orow[Ek + idx] = -1;
 }
 
-// ---------------------------------------------------------------------------------------- speculative keyframe edit
-// The graph edit and the next graph's plan depend on the motion test's DECISION only, not on anything bundle adjustment
-// computes: both possible next graphs (keyframe n - KEYFRAME_INDEX kept / dropped) are structural functions of the current
-// one.  ramp_track_step therefore runs flag -> decide -> apply -> plan for BOTH outcomes on a second stream, beside the
-// update operator, into candidate buffers (trk_*_kernel with TrkEdit.force = 0 / 1 on a candidate's copy of the sizes),
-// and the serial tail behind the motion test shrinks from seven dependent launches (~54 us) to this one: take the
-// decision, copy the chosen candidate's graph, plan and sizes into the live buffers and shift the frame buffers if the
-// keyframe went (the delta-log entry, which needs the poses bundle adjustment just wrote, rides in the wait in front).  Same kernels, same inputs:
-// the live buffers end up bit-identical to the seven-launch path's.
-#define TRK_NCOPY 17
-struct TrkSelect {
-  TrkEdit e;                          // decision parameters, delta log, frame buffers of the row shift
-  int32_t *dyn;                       // live sizes
-  const int32_t *cand;                // [2][RAMP_DYN_WORDS]: [0] keep, [1] remove
-  int32_t *mirror;                    // optional: the host's lazy copy of the sizes (mapped pinned memory)
-  const char *src[2][TRK_NCOPY];
-  char *dst[TRK_NCOPY];
-  long bytes[TRK_NCOPY];              // multiples of 4
-};
-// the launch in front of trk_select_kernel: waits for "both candidates are ready" (flag; nullptr: an event ordered the
-// streams) and appends the delta-log entry of a dropped keyframe -- it reads rows k - 1, k of the poses and time stamps,
-// which the select launch's row shift overwrites (Ramp_vo.py:249-253: delta[t1] = (t0, poses[k] * poses[k-1]^-1))
-__global__ void trk_spec_log_kernel(const TrkEdit p, const uint32_t *flag, uint32_t value, long ticks) {
-  if (flag) {
-    const long t0 = wall_clock64();
-    bool seen;
-    while (!(seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= value) && (long)wall_clock64() - t0 < ticks)
-      __builtin_amdgcn_s_sleep(64);
-    if (!seen && threadIdx.x == 0) atomicOr(p.dyn + RAMP_DYN_STATUS, 128);
-  }
-  if (threadIdx.x != 0 || !trk_remove(p.mm, p.thresh)) return;
-  const int k = p.dyn[RAMP_DYN_N] - p.keyframe_index, idx = p.dyn[RAMP_DYN_NLOG];
-  if (idx < p.log_cap) {
-    float Pk[7], Pm[7], Pi[7], dP[7];
-    for (int q = 0; q < 7; q++) { Pk[q] = p.poses[7 * k + q]; Pm[q] = p.poses[7 * (k - 1) + q]; }
-    lt_inv(Pm, Pi);
-    lt_mul(Pk, Pi, dP);
-    float *lo = p.dlog + (size_t)idx * RAMP_TRACK_LOG;
-    lo[0] = __int_as_float((int)p.tstamps[k]);
-    lo[1] = __int_as_float((int)p.tstamps[k - 1]);
-    for (int q = 0; q < 7; q++) lo[2 + q] = dP[q];
-    p.dyn[RAMP_DYN_NLOG] = idx + 1;
-  } else {
-    atomicOr(p.dyn + RAMP_DYN_STATUS, 16);
-  }
-}
-
-__global__ void __launch_bounds__(256) trk_select_kernel(const TrkSelect s) {
-  const int tid = threadIdx.x;
-  const int o = trk_remove(s.e.mm, s.e.thresh) ? 1 : 0;
-  const int32_t *cd = s.cand + o * RAMP_DYN_WORDS;
-  if (blockIdx.y > 0) {
-    if (o) trk_shift_buffer(s.e, blockIdx.y - 1, cd[RAMP_DYN_K], cd[RAMP_DYN_NPREV], tid);
-    return;
-  }
-  for (int b = 0; b < TRK_NCOPY; b++) {
-    const long n = s.bytes[b];
-    const char *src = s.src[o][b];
-    char *dst = s.dst[b];
-    if (!(n & 15)) {
-      for (long i = (long)blockIdx.x * 256 + tid; i < n / 16; i += (long)gridDim.x * 256)
-        reinterpret_cast<uint4 *>(dst)[i] = reinterpret_cast<const uint4 *>(src)[i];
-    } else {
-      for (long i = (long)blockIdx.x * 256 + tid; i < n / 4; i += (long)gridDim.x * 256)
-        reinterpret_cast<uint32_t *>(dst)[i] = reinterpret_cast<const uint32_t *>(src)[i];
-    }
-  }
-  if (blockIdx.x != 0 || tid != 0) return;
-  // the sizes trk_decide_kernel rewrote in the chosen candidate's copy; the live block keeps what the step itself set
-  // meanwhile (status bits of bundle adjustment / the gate wait, MEDOK, the log length)
-  const int status = cd[RAMP_DYN_STATUS];
-  const int own[13] = {RAMP_DYN_NPREV, RAMP_DYN_EPREV, RAMP_DYN_EKEPT, RAMP_DYN_REMOVED, RAMP_DYN_K, RAMP_DYN_NROW, RAMP_DYN_N,
-                       RAMP_DYN_E, RAMP_DYN_KLO, RAMP_DYN_FLO, RAMP_DYN_W, RAMP_DYN_FRAME, RAMP_DYN_FRAME2};
-  for (int q = 0; q < 13; q++) s.dyn[own[q]] = cd[own[q]];
-  if (status) atomicOr(s.dyn + RAMP_DYN_STATUS, status);
-  if (s.mirror) {
-    __threadfence_system();
-    for (int w = 0; w < RAMP_DYN_WORDS; w++) s.mirror[w] = s.dyn[w == RAMP_DYN_FRAME2 ? RAMP_DYN_FRAME : w];
-  }
-}
-
 __global__ void __launch_bounds__(256) trk_iota_kernel(int64_t *__restrict__ row, int32_t *__restrict__ dyn) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e == 0) dyn[RAMP_DYN_MEDOK] = 0;           // bundle adjustment moved the depths and no motion test follows
@@ -468,8 +372,6 @@ static int trk_edit_fill(const ramp_track *t, int cur, int64_t counter, TrkEdit 
     p.base[i] = (char *)bufs[i]; p.row_bytes[i] = rb[i]; p.mod[i] = md[i];
   }
   p.slot_tab = t->fmap1_slot; p.slot_buf = 7; p.slot_mod = t->mem;      // (bufs[7] = fmap1)
-  p.spec = 0;
-  for (int o = 0; o < 2; o++) { p.cdyn[o] = nullptr; p.cgout[o] = nullptr; p.cws[o] = nullptr; }
   return RAMP_OK;
 }
 
@@ -635,18 +537,6 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
   // the host's lazy copy of the sizes: written by the plan's last launch straight into the (mapped, pinned) host buffer
   int32_t *mirror = nullptr;
   if (t->dyn_host) mirror = t->dyn_host_dev;      // resolved once by the caller (ramp_host_device_pointer)
-  // speculative keyframe edit (see trk_select_kernel): both candidates of the next graph + plan on the second stream,
-  // from the live graph and sizes the previous step's select launch (or the hand-over) left final
-  static int spec_on = -1;                               // RAMP_SPEC_EDIT=1 (default 0: measured a wash)
-  static int spec_nap = 2;                               // x s_sleep 64 (~2 us) between two looks at the signal word
-  if (spec_on < 0) {
-    const char *e = getenv("RAMP_SPEC_EDIT"); spec_on = e ? atoi(e) : 0;
-    if ((e = getenv("RAMP_SPEC_NAP")) && atoi(e) > 0) spec_nap = atoi(e);
-  }
-  const int full = RAMP_TRACK_COMMIT | RAMP_TRACK_UPDATE | RAMP_TRACK_KEYFRAME;
-  const bool spec = spec_on && t->spec_stream && (flags & full) == full && !(flags & RAMP_TRACK_MM_GIVEN) && !t->feat_fp32 &&
-                    t->mm && t->dlog && t->spec_graph[0] && t->spec_graph[1] && t->spec_dyn && t->spec_plan_ws && t->spec_edit_ws &&
-                    ((t->spec_go && t->spec_done) || (t->spec_ev_go && t->spec_ev_done));
   const int Ep_next = Eb + new_cap < Ec ? Eb + new_cap : Ec;       // the next graph: at most one frame's factors more
   if (flags & RAMP_TRACK_COMMIT) {
     if (!t->fe_colors || !t->fe_imap || !t->fe_gmap || !t->fe_fmap1 || !t->fe_fmap2 || !t->fe_patches) return RAMP_EINVAL;
@@ -659,45 +549,7 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
     TRK_DO(ramp_i_frame_commit_dyn(t->poses, t->motion_model, t->motion_damping, t->tstamps, counter, t->index_map,
                                    t->intrinsics, k_new, t->patches, 3, t->M, t->P, t->fe_patches, 5, src, base, bytes,
                                    mod, dyn, (t->median && t->keyframe_index >= 4) ? t->median : nullptr, t->dyn + RAMP_DYN_STATUS, (Eb < Ec && folded) ? Eb : 0, t->n_rows, st,
-                                   t->fmap1_slot, 3, spec ? t->spec_go : nullptr, t->spec_seq));
-  }
-  if (spec) {
-    hipStream_t ax = (hipStream_t)t->spec_stream;
-    // behind this step's commit launch (which stores spec_go): the live graph and sizes are the previous step's final ones
-    // (RAMP_SPEC_AT=gate: the chain starts at this step's gate -- the first SoftAgg launch -- instead of its commit, i.e. on
-    // the front-end stream right ahead of the next frame's front end; measured)
-    static int spec_at_gate = -1;
-    if (spec_at_gate < 0) { const char *e = getenv("RAMP_SPEC_AT"); spec_at_gate = e && !strcmp(e, "gate"); }
-    if (t->spec_go && spec_at_gate && t->gate_flag)
-      hipLaunchKernelGGL(trk_wait_flag_kernel, dim3(1), dim3(64), 0, ax, t->gate_flag, t->gate_seq, 2000000000L, 0L, spec_nap,
-                         t->dyn + RAMP_DYN_STATUS);
-    else if (t->spec_go)       // (a data dependency: the time-out is a hang guard, not a scheduling choice -- 20 s)
-      hipLaunchKernelGGL(trk_wait_flag_kernel, dim3(1), dim3(64), 0, ax, t->spec_go, t->spec_seq, 2000000000L, 0L, spec_nap,
-                         t->dyn + RAMP_DYN_STATUS);
-    else if (hipEventRecord((hipEvent_t)t->spec_ev_go, st) != hipSuccess ||
-             hipStreamWaitEvent(ax, (hipEvent_t)t->spec_ev_go, 0) != hipSuccess) return RAMP_ELAUNCH;
-    // both outcomes in the same launches (blockIdx.z): the sizes are read from the live block, each candidate writes its own
-    TrkEdit p;
-    TRK_DO(trk_edit_fill(t, cur, counter, p));
-    p.spec = 1;
-    const size_t pws = t->plan_ws_bytes;
-    int32_t *cdyn[2];
-    const int64_t *cg[2];
-    void *cws[2];
-    for (int o = 0; o < 2; o++) {
-      p.cdyn[o] = cdyn[o] = t->spec_dyn + o * RAMP_DYN_WORDS;
-      p.cgout[o] = t->spec_graph[o]; cg[o] = t->spec_graph[o];
-      p.cws[o] = t->spec_edit_ws + o * (3 * p.nb + 8);
-      cws[o] = (char *)t->spec_plan_ws + o * pws;
-    }
-    hipLaunchKernelGGL(trk_flag_kernel, dim3(p.nb, 1, 2), dim3(256), 0, ax, p);
-    hipLaunchKernelGGL(trk_decide_kernel, dim3(1, 1, 2), dim3(256), 0, ax, p);
-    hipLaunchKernelGGL(trk_apply_kernel, dim3(p.nb + ramp_cdiv(new_cap + p.pad, 256), 1, 2), dim3(256), 0, ax, p);
-    TRK_DO(ramp_i_plan_dyn_pair(cg, Ec, Ep_next, cdyn, t->M, t->kkey_cap, t->pkey_cap, t->kk_cap, t->ij_cap, t->spec_plan, cws,
-                                pws, ax));
-    if (t->spec_done) hipLaunchKernelGGL(trk_signal_kernel, dim3(1), dim3(1), 0, ax, t->spec_done, t->spec_seq);
-    else if (hipEventRecord((hipEvent_t)t->spec_ev_done, ax) != hipSuccess) return RAMP_ELAUNCH;
-    RAMP_CHECK_LAUNCH();
+                                   t->fmap1_slot, 3, nullptr, 0));
   }
   // fp32 features: the correlation launch is corr_mfma_kernel<float> (RAMP_CORR_F32_MFMA=0: corr_kernel<float>, the reference
   // kernel's summation order) with rows padded to 896 floats, the operator csrc/update_x3.hip's chains; PRE / POST around a
@@ -742,12 +594,9 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
         !t->hij || !t->target || !t->weight || !t->ba_ws)
       return RAMP_EINVAL;
     // Ramp_vo.update(), ramp/Ramp_vo.py:276-310
-    // RAMP_CORR_TF=1: pops.transform rides in the correlation kernel's geometry prologue (one launch less; bit-identical).
-    // Measured a wash -- the nine-lane Lie algebra adds to every wave what the 7.8 us launch took (corr 158 -> 166 us) --
-    // so the separate launch stays the default
-    static const bool corr_tf = getenv("RAMP_CORR_TF") && atoi(getenv("RAMP_CORR_TF")) != 0;
-    const bool fuse_tf = corr_tf && !(flags & (RAMP_TRACK_WRAP_COORDS | RAMP_TRACK_COMPACT_COORDS));
-    if (!fuse_tf) TRK_DO(ramp_i_transform_dyn(t->poses, t->patches, t->intrinsics, ii, jj, kk, t->coords, Eb, dyn, st));
+    // (pops.transform as a launch of its own: riding in the correlation kernel's geometry prologue it was a wash -- the
+    // nine-lane Lie algebra adds to every wave what the 7.8 us launch took, corr 158 -> 166 us)
+    TRK_DO(ramp_i_transform_dyn(t->poses, t->patches, t->intrinsics, ii, jj, kk, t->coords, Eb, dyn, st));
     if (flags & (RAMP_TRACK_WRAP_COORDS | RAMP_TRACK_COMPACT_COORDS))
       hipLaunchKernelGGL(trk_wrap_coords_kernel, dim3(ramp_cdiv(Eb, 256)), dim3(256), 0, st, t->coords, dyn, t->P,
                          (float)t->feat_w, (float)t->feat_h, (flags & RAMP_TRACK_COMPACT_COORDS) ? 1 : 0);
@@ -804,46 +653,21 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
                            t->gate_seq, st));
 #undef TRK_GATE32
     } else {
-    // RAMP_CORR_L1=1 (first clause): the correlation launch multiplies its rows by the correlation MLP's first
-    // Linear itself (csrc/altcorr.hip::corr_l1_kernel) and hands c1 [E][384] on -- in t->corr's storage, the [E][896]
-    // rows are never written -- to the tail-only correlation MLP.  Bit-identical; measured slower, off.
-    static const bool corr_l1 = getenv("RAMP_CORR_L1") && atoi(getenv("RAMP_CORR_L1")) != 0;
-    if (corr_l1) {
-      TRK_DO(ramp_i_corr_l1_fwd(t->gmap, lv, t->coords, kk, jj, t->ij_order, w.corr_w1, w.corr_b1, 896, t->corr,
-                                (long)t->M * t->mem, t->mem, Eb, t->feat_plain ? RAMP_NHWC : RAMP_NHWC32, dyn, st, fuse_tf ? t->poses : nullptr,
-                                t->patches, t->intrinsics, ii, t->fmap1_slot));
-      TRK_PROBE(1);
-      TRK_DO(ramp_i_upd_corr_tail(t->corr, w.corr_w2, w.corr_b2, w.corr_w3, w.corr_b3, w.corr_ln_w, w.corr_ln_b,
-                                  w.corr_ln_eps, t->net[0], row, t->imap, kk, (long)t->M * t->mem, w.norm_w, w.norm_b,
-                                  w.norm_eps, t->net[1], Eb, dyn, st));
-    } else {
-    // (diagnostic, RAMP_CORR_TWICE=1: the launch is issued twice -- same inputs, same output; the second one's time is the
-    // kernel with planes, coordinates and output rows just touched: what the first pays for a cold chip, tools/README.md)
-    static const bool corr_twice = getenv("RAMP_CORR_TWICE") && atoi(getenv("RAMP_CORR_TWICE")) != 0;
-    // (RAMP_CORR_ORDER=0: the launch walks the factors in graph order instead of the plan's (jj, ii)-major schedule; A/B runs)
-    static const bool corr_sched = !(getenv("RAMP_CORR_ORDER") && atoi(getenv("RAMP_CORR_ORDER")) == 0);
-    const int32_t *corr_order = corr_sched ? t->ij_order : nullptr;
-    if (corr_twice)
-      TRK_DO(ramp_i_corr_fwd(t->gmap, lv, 2, t->coords, kk, jj, corr_order, t->corr, 896, (long)t->M * t->mem, t->mem, Eb,
-                             t->mem * t->M, t->mem, 128, t->P, 3, RAMP_F16, t->feat_plain ? RAMP_NHWC : RAMP_NHWC32, dyn, st,
-                             fuse_tf ? t->poses : nullptr, t->patches, t->intrinsics, ii, t->fmap1_slot));
-    TRK_DO(ramp_i_corr_fwd(t->gmap, lv, 2, t->coords, kk, jj, corr_order, t->corr, 896, (long)t->M * t->mem, t->mem, Eb,
+    // (the plan's (jj, ii)-major schedule: worth 1.3 % of the frame against graph order, round 5's A/B)
+    TRK_DO(ramp_i_corr_fwd(t->gmap, lv, 2, t->coords, kk, jj, t->ij_order, t->corr, 896, (long)t->M * t->mem, t->mem, Eb,
                            t->mem * t->M, t->mem, 128, t->P, 3, RAMP_F16, t->feat_plain ? RAMP_NHWC : RAMP_NHWC32, dyn, st,
-                           fuse_tf ? t->poses : nullptr, t->patches, t->intrinsics, ii, t->fmap1_slot));
+                           nullptr, nullptr, nullptr, nullptr, t->fmap1_slot));
     TRK_PROBE(1);
     // the update operator, ramp/net.py:69-90 (the fp16 fused chains of csrc/update_mlp.hip)
     TRK_DO(ramp_i_upd_corr_mlp(t->corr, 896, w.corr_w1, w.corr_b1, w.corr_w2, w.corr_b2, w.corr_w3, w.corr_b3, w.corr_ln_w,
                                w.corr_ln_b, w.corr_ln_eps, t->net[0], row, t->imap, kk, (long)t->M * t->mem, w.norm_w,
                                w.norm_b, w.norm_eps, t->net[1], Eb, dyn, st));
-    }
     // where the next frame's front end may start (RAMP_GATE_AT: 2 = before the first SoftAgg, the default -- with the fused
     // SoftAgg launches next to it the front end costs the operator ~25 us and gives bundle adjustment 12 back, +1.2 % SingleScale,
     // +2.1 % MultiScale against 0; 0 = before the gru chain (rounds 2-3); 1 = before the second SoftAgg; 3 = before c1 / c2).
     // The "go" is a word stored by the first workgroup of the launch behind that point (t->gate_flag: gru, SoftAgg), a
     // one-thread launch where that kernel cannot (the three-launch SoftAgg, c1), or the caller's event.
-    static int sagg = -1;
-    if (sagg < 0) { const char *e = getenv("RAMP_SOFTAGG"); sagg = e ? atoi(e) : 1; }
-    const bool use_sagg = sagg && t->sagg_frag;
+    const bool use_sagg = t->sagg_frag != nullptr;
     const bool flag_in_kernel = t->gate_flag && (gate_at == 0 || ((gate_at == 1 || gate_at == 2) && use_sagg));
 #define TRK_GATE(pos)                                                                                     \
   do {                                                                                                    \
@@ -853,26 +677,14 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
     }                                                                                                     \
   } while (0)
     TRK_GATE(3);
-    // RAMP_NBR2=1: c1 and c2 in one launch over the (kk, jj)-sorted factor list (bit-identical; measured 2 % SLOWER on
-    // the whole operator than the two launches although it moves a third of their bytes -- DESIGN.md section 8)
-    static int nbr2 = -1;
-    if (nbr2 < 0) { const char *e = getenv("RAMP_NBR2"); nbr2 = e ? atoi(e) : 0; }
-    float *net = t->net[2];
-    if (nbr2) {
-      TRK_DO(ramp_i_upd_nbr2(t->net[1], t->kj, t->ix, t->jx, w.c1_wa, w.c1_ba, w.c1_wb, w.c1_bb, w.c2_wa, w.c2_ba, w.c2_wb,
-                             w.c2_bb, t->net[2], Eb, dyn, st));
-    } else {
-      TRK_DO(ramp_i_upd_nbr(t->net[1], t->ix, w.c1_wa, w.c1_ba, w.c1_wb, w.c1_bb, t->net[2], nullptr, Eb, dyn, st));
-      TRK_DO(ramp_i_upd_nbr(t->net[2], t->jx, w.c2_wa, w.c2_ba, w.c2_wb, w.c2_bb, t->net[1], nullptr, Eb, dyn, st));
-      net = t->net[1];
-    }
+    TRK_DO(ramp_i_upd_nbr(t->net[1], t->ix, w.c1_wa, w.c1_ba, w.c1_wb, w.c1_bb, t->net[2], nullptr, Eb, dyn, st));
+    TRK_DO(ramp_i_upd_nbr(t->net[2], t->jx, w.c2_wa, w.c2_ba, w.c2_wb, w.c2_bb, t->net[1], nullptr, Eb, dyn, st));
+    float *net = t->net[1];
     TRK_GATE(2);
     // SoftAgg x 2 (ramp/net.py:84-85).  With a fragment table: gather-by-group tiles, g and f on the same tile, online
     // softmax in registers, h on the merged fragments -- 2 launches each, no [E, 768] rows (csrc/update_mlp.hip);
-    // RAMP_SOFTAGG=0 or no table: [f | g] rows + segment softmax + h, 3 launches each.
-    static int add2 = -1;
-    if (add2 < 0) { const char *e = getenv("RAMP_GRU_ADD2"); add2 = e ? atoi(e) : 1; }
-    if (use_sagg) add2 = 1;                       // (that path never writes net + hkk[.] back: the gru launch forms the sum)
+    // no table: [f | g] rows + segment softmax + h, 3 launches each.
+    const int add2 = 1;                           // (net + hkk[.] is never written back: the gru launch forms the sum itself)
     if (use_sagg) {
       TRK_DO(ramp_i_upd_softagg(net, nullptr, nullptr, t->kk_order, t->kk_gid, w.kk_wf, w.kk_bf, w.kk_wg, w.kk_bg, t->sagg_frag,
                                 Eb, dyn, st, gate_at == 2 ? t->gate_flag : nullptr, t->gate_seq));
@@ -888,7 +700,7 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
     TRK_GATE(1);
     // the pair SoftAgg's [f|g] launch reads net + hkk[patch group] and, by default, does NOT write the sum back: the gru
     // launch forms (net + hkk[.]) + hij[.] itself, in the same order (61 MB less to write in the serial part of the step;
-    // the extra table rows come from L2).  RAMP_GRU_ADD2=0: the sum is written back (A/B runs).
+    // the extra table rows come from L2).
     TRK_DO(ramp_i_upd_fg(net, t->hkk, t->kk_gid, add2 ? nullptr : net, w.ij_wf, w.ij_bf, w.ij_wg, w.ij_bg, t->fg, Eb, dyn, st));
     TRK_DO(ramp_upd_segment_softmax(t->fg, t->ij_order, t->ij_seg, t->ij_ngroups, t->yij, t->ij_cap, RAMP_F16, stream));
     TRK_DO(ramp_upd_linear(t->yij, w.ij_wh, w.ij_bh, t->hij, t->ij_cap, t->ij_ngroups, stream));
@@ -928,32 +740,6 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
                                   t->ij_ngroups, 0.5f, t->mm, dyn, t->keyframe_index, st));
     TrkEdit p;
     TRK_DO(trk_edit_fill(t, cur, counter, p));
-    if (spec) {
-      // both candidates are (long) ready: take the decision and copy the chosen one into the live buffers
-      if (!t->spec_done && hipStreamWaitEvent(st, (hipEvent_t)t->spec_ev_done, 0) != hipSuccess) return RAMP_ELAUNCH;
-      hipLaunchKernelGGL(trk_spec_log_kernel, dim3(1), dim3(64), 0, st, p, t->spec_done, t->spec_seq, 2000000000L);
-      TrkSelect sel;
-      sel.e = p; sel.dyn = t->dyn; sel.cand = t->spec_dyn; sel.mirror = mirror;
-      int64_t *gl = t->graph[1 - cur];
-      int nbuf = 0;
-      auto add = [&](const void *a0, const void *a1, void *d, long bytes) {
-        sel.src[0][nbuf] = (const char *)a0; sel.src[1][nbuf] = (const char *)a1; sel.dst[nbuf] = (char *)d;
-        sel.bytes[nbuf] = (bytes + 3) / 4 * 4; nbuf++;
-      };
-      const long ep16 = ((long)Ep_next + 3) / 4 * 4 < Ec ? ((long)Ep_next + 3) / 4 * 4 : Ec;   // whole 16-byte pieces of int32 rows
-      for (int r = 0; r < 4; r++)
-        add(t->spec_graph[0] + r * (size_t)Ec, t->spec_graph[1] + r * (size_t)Ec, gl + r * (size_t)Ec, ep16 * 8);
-      const ramp_plan_set &q0 = t->spec_plan[0], &q1 = t->spec_plan[1];
-      add(q0.kk_order, q1.kk_order, t->kk_order, ep16 * 4); add(q0.kk_gid, q1.kk_gid, t->kk_gid, ep16 * 4);
-      add(q0.ij_order, q1.ij_order, t->ij_order, ep16 * 4); add(q0.ij_gid, q1.ij_gid, t->ij_gid, ep16 * 4);
-      add(q0.ix, q1.ix, t->ix, ep16 * 8); add(q0.jx, q1.jx, t->jx, ep16 * 8); add(q0.kj, q1.kj, t->kj, ep16 * 4);
-      add(q0.kk_seg, q1.kk_seg, t->kk_seg, (long)(t->kk_cap + 2) * 4); add(q0.ij_seg, q1.ij_seg, t->ij_seg, (long)(t->ij_cap + 2) * 4);
-      add(q0.kk_ukeys, q1.kk_ukeys, t->kk_ukeys, (long)(t->kk_cap + 2) * 8); add(q0.ij_ukeys, q1.ij_ukeys, t->ij_ukeys, (long)(t->ij_cap + 2) * 8);
-      add(q0.kk_ngroups, q1.kk_ngroups, t->kk_ngroups, 4); add(q0.ij_ngroups, q1.ij_ngroups, t->ij_ngroups, 4);
-      static_assert(TRK_NCOPY == 17, "the copy list above");
-      hipLaunchKernelGGL(trk_select_kernel, dim3(t->fmap1_slot ? 256 : 1024, 1 + p.nbuf), dim3(256), 0, st, sel);
-      RAMP_CHECK_LAUNCH();
-    } else {
     hipLaunchKernelGGL(trk_flag_kernel, dim3(p.nb), dim3(256), 0, st, p);
     hipLaunchKernelGGL(trk_decide_kernel, dim3(1), dim3(256), 0, st, p);
     int gx = p.nb + ramp_cdiv(new_cap + p.pad, 256);
@@ -968,7 +754,6 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
                            t->kk_cap, t->ij_cap, t->kk_order, t->kk_gid, t->kk_seg, t->kk_ngroups, t->kk_ukeys, t->ij_order,
                            t->ij_gid, t->ij_seg, t->ij_ngroups, t->ij_ukeys, t->ix, t->jx, t->kj, t->plan_ws, t->plan_ws_bytes,
                            mirror, st));
-    }
   }
   // (without a plan in this call, or without a device mapping of the host buffer: an asynchronous copy)
   if (t->dyn_host && !(mirror && (flags & RAMP_TRACK_KEYFRAME)) &&

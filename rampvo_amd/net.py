@@ -144,7 +144,6 @@ class Patchifier(nn.Module):
         self._plist = None
         self._extra = None
         self._index = None
-        self._fork_stream = None          # the selection's branch of the sequential front-end graph (forward())
 
     def _apply(self, fn, *a, **k):
         """.to() / .half() / .cuda() replace the parameter tensors: captured graphs point at the old ones"""
@@ -179,17 +178,11 @@ class Patchifier(nn.Module):
             if pre_replay is not None:
                 pre_replay()
             return self._forward_impl(input_, patches_per_image, reinit_hidden, disps, event_bias, gradient_bias)
-        import os
-        # RAMP_SELECT_FORK=1 (sequential callers, no pre_replay): the patch selection -- three small launches that read the
-        # events alone -- captured on a FORKED stream of the graph and joined in front of the gathers, so that it runs beside
-        # the recurrent encoder step instead of ahead of it.  Measured on MI355X (round 5, alternating runs on one box):
-        # front end alone 259 -> 277 us, sequential rate 937 -> 932 kf/s -- the two cross-stream edges of the graph and the
-        # selection's traffic next to the bandwidth-bound LSTM launch cost more than the 32 us they hide.  Off.
-        fork = pre_replay is None and os.environ.get("RAMP_SELECT_FORK", "0") == "1" \
-            and os.environ.get("RAMP_SELECT_IN_GRAPH", "0") != "1"
+        # (the patch selection as a forked branch of the graph -- beside the recurrent encoder step instead of ahead of it -- was
+        # measured in round 5: front end alone 259 -> 277 us, sequential rate 937 -> 932 kf/s; not kept)
         key = (self.input_mode, tuple(events.shape), tuple(images.shape), patches_per_image, events.dtype,
                images.dtype, bool(getattr(self.encoder, "mixed_precision", False)),
-               bool(getattr(self.encoder, "fp8_mfma", False)), events.device, fork)
+               bool(getattr(self.encoder, "fp8_mfma", False)), events.device)
         # the captured graph bakes in raw pointers to the packed encoder weights and to the encoder's recurrent
         # state buffers: it is only valid for the parameter values and the state object it was captured with
         # (in-place weight updates bump ``_version``; a resolution change reallocates the state)
@@ -209,8 +202,7 @@ class Patchifier(nn.Module):
             ev_s, im_s = events.clone(), images.clone()
             # the patch centres are a function of the events alone: selected OUTSIDE the graph into a static buffer
             # (three small launches that need not wait for the encoder's turn, see pre_replay)
-            in_graph = os.environ.get("RAMP_SELECT_IN_GRAPH", "0") == "1"      # A/B switch: the round-2 placement
-            coords_s = None if in_graph else self._select(ev_s, mask, patches_per_image, None)
+            coords_s = self._select(ev_s, mask, patches_per_image, None)
             graph = torch.cuda.CUDAGraph()
             # (no cyclic collection while the capture runs: freeing another tracker's hipGraph -- an object the collector
             # may find at any allocation -- inside a capture aborts the process)
@@ -219,18 +211,8 @@ class Patchifier(nn.Module):
             gc.disable()
             try:
                 with torch.cuda.graph(graph):
-                    join = None
-                    if fork:
-                        cap = torch.cuda.current_stream()
-                        if self._fork_stream is None or self._fork_stream.device != events.device:
-                            self._fork_stream = torch.cuda.Stream(device=events.device)
-                        side = self._fork_stream
-                        side.wait_stream(cap)                      # fork: the selection becomes a branch of the graph
-                        with torch.cuda.stream(side):
-                            self._select(ev_s, mask, patches_per_image, coords_s)
-                        join = lambda: torch.cuda.current_stream().wait_stream(side)
                     outs = self._forward_impl((ev_s, im_s, mask), patches_per_image, False, None, event_bias,
-                                              gradient_bias, coords_in=coords_s, before_gather=join)
+                                              gradient_bias, coords_in=coords_s)
             finally:
                 if gc_was_on:
                     gc.enable()
@@ -246,7 +228,7 @@ class Patchifier(nn.Module):
         else:
             ev_s.copy_(events)
             im_s.copy_(images)
-        if coords_s is not None and not fork:
+        if coords_s is not None:
             self._select(ev_s, mask, patches_per_image, coords_s)
         if pre_replay is not None:
             pre_replay()
@@ -272,7 +254,7 @@ class Patchifier(nn.Module):
             return self._forward_steps(*a, **k)
 
     def _forward_steps(self, input_, patches_per_image=80, reinit_hidden=False, disps=None, event_bias=False,
-                       gradient_bias=False, coords_in=None, before_gather=None):
+                       gradient_bias=False, coords_in=None):
         events, images, mask = input_
         if self.input_mode == "SingleScale":
             fmap, imap, _ = self.encoder(events=events, images=images, reinit_hidden=reinit_hidden,
@@ -298,8 +280,6 @@ class Patchifier(nn.Module):
             y = torch.randint(1, h - 1, size=[n, patches_per_image], device=fmap.device)
             coords = torch.stack([x, y], dim=-1).float()
         coords = coords.float().contiguous()
-        if before_gather is not None:
-            before_gather()              # (graph capture: join the forked selection branch before its coordinates are read)
         # channels-last storage -> NHWC kernels; results are handed out in the reference's shapes
         f_nhwc = fmap[0].permute(0, 2, 3, 1)
         i_nhwc = imap[0].permute(0, 2, 3, 1)

@@ -112,33 +112,6 @@ def corr(fmap1, fmaps2, coords, ii, jj, radius=3, coord_divs=(1.0,), layout=RAMP
     return out
 
 
-def corr_l1(fmap1, fmaps2, coords, ii, jj, w1_packed, b1, layout=RAMP_NHWC, order=None, mod_ii=0, mod_jj=0, corr_k=896):
-    """correlation over the two pyramid levels AND the first Linear + ReLU of the update operator's correlation MLP in
-    one launch (ramp_corr_l1_fwd_ordered): -> c1 [E, 384] fp16, bit-identical to what ramp_upd_corr_mlp
-    forms from corr()'s padded rows.  fmap1 [N1,3,3,128] fp16 NHWC; fmaps2 = [level 1, level 4] target maps, NHWC or
-    the packed RAMP_NHWC32 layout; w1_packed = update_fused.pack_linear_f16 of the weight zero-padded to corr_k"""
-    require_cuda(fmap1, coords, ii, jj, w1_packed, b1, *fmaps2)
-    assert fmap1.dtype == torch.float16 and len(fmaps2) == 2 and layout in (RAMP_NHWC, RAMP_NHWC32)
-    fmap1 = fmap1.contiguous()
-    fmaps2 = [f.contiguous() for f in fmaps2]
-    coords = coords.contiguous().float()
-    ii, jj = ii.contiguous(), jj.contiguous()
-    assert ii.dtype == torch.int64 and jj.dtype == torch.int64 and fmap1.shape[1:] == (3, 3, 128)
-    E = coords.shape[0]
-    levels = (CorrLevel * 2)()
-    for l, (f, dv) in enumerate(zip(fmaps2, (1.0, 4.0))):
-        assert f.dtype == torch.float16
-        H2, W2 = (f.shape[1], f.shape[3]) if layout == RAMP_NHWC32 else (f.shape[1], f.shape[2])
-        levels[l] = CorrLevel(f.data_ptr(), H2, W2, dv)
-    if order is not None:
-        assert order.dtype == torch.int32 and order.is_contiguous() and order.shape[0] == E
-    c1 = torch.empty((E, 384), dtype=torch.float16, device=fmap1.device)
-    check(lib().ramp_corr_l1_fwd_ordered(ptr(fmap1), levels, ptr(coords), ptr(ii), ptr(jj),
-                                         ptr(order) if order is not None else None, ptr(w1_packed), ptr(b1), int(corr_k),
-                                         ptr(c1), int(mod_ii), int(mod_jj), E, layout, stream()), "ramp_corr_l1_fwd_ordered")
-    return c1
-
-
 def event_stack(x, y, p, height, width, num_bins=5, as_float=True):
     """EventToStack_Numpy on the device (reference utils/transformers.py:128-161): integer pixel
     coordinates x, y [N] and polarities p [N] (int8, +-1; 0 is read as -1 like data/events.py:29) ->

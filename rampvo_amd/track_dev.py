@@ -39,14 +39,6 @@ class TrackWeights(ctypes.Structure):
                 + [(n, ctypes.c_float) for n in ("corr_ln_eps", "norm_eps", "ln1_eps", "ln2_eps")])
 
 
-_PLAN_SET = ["kk_order", "kk_gid", "kk_seg", "kk_ngroups", "ij_order", "ij_gid", "ij_seg", "ij_ngroups", "kk_ukeys", "ij_ukeys",
-             "ix", "jx", "kj"]
-
-
-class PlanSet(ctypes.Structure):
-    _fields_ = _ptr_fields(_PLAN_SET)
-
-
 class Track(ctypes.Structure):
     _fields_ = ([(n, c_i) for n in ("M", "P", "mem", "n_rows", "patch_lifetime", "removal_window", "opt_window",
                                     "keyframe_index", "motion_model", "feat_h", "feat_w", "E_cap", "kk_cap", "ij_cap",
@@ -63,11 +55,7 @@ class Track(ctypes.Structure):
                 + _ptr_fields(["fg", "ykk", "hkk", "yij", "hij", "relu_t", "sagg_frag", "target", "weight", "ba_ws"])
                 + [("ba_ws_bytes", c_sz)]
                 + _ptr_fields(["mm", "median", "dlog", "edit_ws", "dyn_host", "dyn_host_dev"]) + [("probe", c_p * 5), ("E_hint", c_i),
-                   ("gate_seq", ctypes.c_uint32), ("feat_fp32", c_i), ("feat_plain", c_i), ("gate_flag", c_p), ("fmap1_slot", c_p)]
-                # speculative keyframe edit (include/ramp_hip.h: ramp_track.spec_*)
-                + _ptr_fields(["spec_stream", "spec_go", "spec_done", "spec_ev_go", "spec_ev_done"])
-                + [("spec_seq", ctypes.c_uint32), ("spec_pad", ctypes.c_uint32), ("spec_graph", c_p * 2), ("spec_dyn", c_p),
-                   ("spec_plan", PlanSet * 2), ("spec_plan_ws", c_p), ("spec_edit_ws", c_p)])
+                   ("gate_seq", ctypes.c_uint32), ("feat_fp32", c_i), ("feat_plain", c_i), ("gate_flag", c_p), ("fmap1_slot", c_p)])
 
 
 _E_EST_LAST = int(os.environ.get("RAMP_E_EST_LAST", "1"))        # 0: the largest of the last 64 copies (round 3's first rule)
@@ -226,54 +214,6 @@ class DeviceTrack:
         t.graph[0], t.graph[1] = P(self.graph[0]), P(self.graph[1])
         for i in range(3):
             t.net[i] = P(self.net[i])
-        self._init_speculative_edit(z)
-
-    def _init_speculative_edit(self, z):
-        """candidate buffers, the second stream and the two signal words of the speculative keyframe edit
-        (csrc/track.hip::trk_select_kernel): both possible next graphs and their plans are computed beside the update
-        operator, the tail behind the motion test copies the chosen one.  RAMP_SPEC_EDIT=1 switches it on: bit-identical,
-        24 instead of 29 launches on the main queue, and no faster (next to the correlation launch
-        the side chain's launches wait ~115 us for a CU, next to the correlation MLP they cost it its residency)."""
-        from .Ramp_vo import _kernels_are_serialised
-        self.spec_seq = 0
-        self.spec_stream = None
-        if self.fp32 or os.environ.get("RAMP_SPEC_EDIT", "0") != "1":
-            return
-        t, P = self.t, (lambda x: x.data_ptr())
-        i32, i64 = torch.int32, torch.int64
-        E_cap, kk_cap, ij_cap = self.E_cap, self.kk_cap, self.ij_cap
-        self.spec_graph = [z((4, E_cap), i64), z((4, E_cap), i64)]
-        self.spec_dyn = z(2 * DYN_WORDS, i32)
-        self.spec_plan = [dict(kk_order=z(E_cap, i32), kk_gid=z(E_cap, i32), kk_seg=z(kk_cap + 2, i32), kk_ngroups=z(1, i32),
-                               ij_order=z(E_cap, i32), ij_gid=z(E_cap, i32), ij_seg=z(ij_cap + 2, i32), ij_ngroups=z(1, i32),
-                               kk_ukeys=z(kk_cap + 2, i64), ij_ukeys=z(ij_cap + 2, i64), ix=z(E_cap, i64), jx=z(E_cap, i64),
-                               kj=z(E_cap, i32)) for _ in range(2)]
-        self.spec_plan_ws = z(2 * self.plan_ws.numel(), torch.uint8)      # (one workspace per candidate: they share launches)
-        self.spec_edit_ws = z(2 * self.edit_ws.numel(), i32)
-        # the tracker's front-end stream: idle between the end of a frame's front end and the gate of the next one (the
-        # step's commit .. second neighbour chain), where these ~100 us of small launches fit; a stream of its own costs
-        # a hardware queue (the runtime shares four) and measured slower (DESIGN.md section 8.000)
-        which = os.environ.get("RAMP_SPEC_STREAM", "fe")
-        own = which in ("own", "own_lo") or getattr(self.slam, "_fe_stream", None) is None
-        self.spec_stream = (torch.cuda.Stream(device=self.slam.device, priority=0 if which == "own_lo" else -1) if own
-                            else self.slam._fe_stream)
-        self.spec_sig = self.spec_ev = None
-        if not _kernels_are_serialised():
-            sig = (Signal(), Signal())
-            if sig[0].ptr is not None and sig[1].ptr is not None:
-                self.spec_sig = sig
-                t.spec_go, t.spec_done = sig[0].ptr, sig[1].ptr
-        if self.spec_sig is None:
-            self.spec_ev = (torch.cuda.Event(), torch.cuda.Event())
-            for ev in self.spec_ev:                      # (created lazily: the handle exists after the first record)
-                ev.record(self.spec_stream)
-            t.spec_ev_go, t.spec_ev_done = self.spec_ev[0].cuda_event, self.spec_ev[1].cuda_event
-        t.spec_stream = self.spec_stream.cuda_stream
-        t.spec_graph[0], t.spec_graph[1] = P(self.spec_graph[0]), P(self.spec_graph[1])
-        t.spec_dyn, t.spec_plan_ws, t.spec_edit_ws = P(self.spec_dyn), P(self.spec_plan_ws), P(self.spec_edit_ws)
-        for o in range(2):
-            for name in _PLAN_SET:
-                setattr(t.spec_plan[o], name, P(self.spec_plan[o][name]))
 
     # ------------------------------------------------------------------ weights / front-end outputs
     def bind_weights(self, fu):
@@ -336,6 +276,7 @@ class DeviceTrack:
             gn[row, :Ek] = a
             gn[row, Ek:E] = b if b is not None else fill
         self.cur = 0
+        self._lazy_ok = None                    # (a consistent copy of the sizes from a previous residency is not this one's)
         self.graph[0][:, :E].copy_(g[:, :E], non_blocking=True)
         if net_buf.data_ptr() != self.net[0].data_ptr():
             self.net[0][:net_buf.shape[0]].copy_(net_buf)
@@ -387,9 +328,6 @@ class DeviceTrack:
         ev = ctypes.c_void_p(gate_event) if gate_event else None
         self.t.E_hint = self.factor_estimate()
         self.t.gate_flag, self.t.gate_seq = (gate_flag, int(gate_seq) & 0xFFFFFFFF) if gate_flag else (None, 0)
-        if flags & KEYFRAME:
-            self.spec_seq = (self.spec_seq + 1) & 0xFFFFFFFF
-            self.t.spec_seq = self.spec_seq
         _lib.check(_lib.lib().ramp_track_step(ctypes.byref(self.t), self.cur, int(counter), int(flags),
                                               self.factor_bound(counter) if E_bound is None else int(E_bound),
                                               _lib.ptr(k_new), ev, _lib.stream()),

@@ -57,10 +57,9 @@ class FusedUpdate:
         self._key = None
         self._params = list(update.parameters())     # module structure is fixed; values are tracked by key
         self._act_ok = True
-        self.use_mlp = os.environ.get("RAMP_UPD_MLP", "1") == "1"    # fused GEMM-chain kernels (fp16 only)
-        self.use_corr_mlp = os.environ.get("RAMP_CORR_MLP", "1") == "1"
-        self.use_nbr2 = os.environ.get("RAMP_NBR2", "0") == "1"      # c1 + c2 as one launch (A/B switch; measured slower)
-        self.use_softagg = os.environ.get("RAMP_SOFTAGG", "1") == "1"   # SoftAgg without the [f | g] rows (csrc/update_mlp.hip)
+        self.use_mlp = True          # fp16: the fused GEMM-chain kernels of csrc/update_mlp.hip (instance switches, for tests:
+        self.use_corr_mlp = True     # False falls back to library GEMMs + the row kernels of csrc/update.hip stage by stage)
+        self.use_softagg = True      # SoftAgg without the [f | g] rows
         # fp32: the Linear layers on the f16 matrix cores from split operands (csrc/update_x3.hip), fused chains as on the
         # fp16 path; RAMP_X3=0: library GEMMs + the row kernels of csrc/update.hip (A/B runs)
         self.use_x3 = dtype == torch.float32 and os.environ.get("RAMP_X3", "1") == "1"
@@ -234,12 +233,7 @@ class FusedUpdate:
         E = corr.shape[0]
         if self.use_x3:
             return self._hidden_x3(w, net, inp_table, inp_idx, inp_mod, corr, plan, net_map, heads_at)
-        if corr.shape[1] == 384:
-            # c1 = relu(Linear1(corr)) already: the fused correlation + Linear1 launch (ramp_corr_l1_fwd_ordered)
-            if not ("tail_pack" in w and self.use_mlp):
-                raise RuntimeError("the fused correlation + Linear1 launch needs the fused correlation-MLP tail (RAMP_UPD_MLP=1)")
-            c = corr
-        elif "tail_pack" in w and self.use_mlp and corr.shape[1] == CORR_ROW and self.use_corr_mlp:
+        if "tail_pack" in w and self.use_mlp and corr.shape[1] == CORR_ROW and self.use_corr_mlp:
             # the whole correlation MLP (3 Linear, LayerNorm, ReLUs) + net + inp + c + LayerNorm: one launch
             w1, b1 = w["corr1_pack"]
             w2, b2, w3, b3 = w["tail_pack"]
@@ -254,15 +248,6 @@ class FusedUpdate:
             c = self.lin_relu(corr, w["corr0_pad"] if corr.shape[1] == CORR_ROW else w["corr0"])
         if c is None:
             pass
-        elif "tail_pack" in w and self.use_mlp:
-            # Linear, LayerNorm + ReLU, Linear, net + inp + c, LayerNorm: one launch (csrc/update_mlp.hip)
-            w2, b2, w3, b3 = w["tail_pack"]
-            ln, nm = w["corr_ln"], w["norm"]
-            net32 = torch.empty(E, 384, dtype=torch.float32, device=c.device)
-            check(lib().ramp_upd_corr_tail(ptr(c), ptr(w2), ptr(b2), ptr(w3), ptr(b3), ptr(ln[0]), ptr(ln[1]),
-                                           float(ln[2]), ptr(net), ptr(net_map), ptr(inp_table), ptr(inp_idx),
-                                           int(inp_mod or 0), ptr(nm[0]), ptr(nm[1]), float(nm[2]), ptr(net32), E,
-                                           stream()), "ramp_upd_corr_tail")
         else:
             c = self.lin(c, w["corr2"])
             _, c = self.row_fuse(E, B=c, ln=w["corr_ln"], relu=True, want_t=True)
@@ -278,12 +263,6 @@ class FusedUpdate:
                 self.before_gru()
             wa, ba, wb, bb = w["c1_pack"]
             wa2, ba2, wb2, bb2 = w["c2_pack"]
-            if getattr(plan, "kj", None) is not None and self.use_nbr2 and E * 384 * 4 < (1 << 32):
-                # c1 and c2 in ONE launch over the (kk, jj)-sorted factor list (bit-identical to the two below)
-                check(lib().ramp_upd_nbr2(ptr(net32), ptr(plan.kj), ptr(plan.ix_raw), ptr(plan.jx_raw), ptr(wa), ptr(ba),
-                                          ptr(wb), ptr(bb), ptr(wa2), ptr(ba2), ptr(wb2), ptr(bb2), ptr(tmp), E,
-                                          stream()), "ramp_upd_nbr2")
-                return self._tail(w, E, tmp, None, plan)
             check(lib().ramp_upd_nbr(ptr(net32), ptr(plan.ix_raw), ptr(wa), ptr(ba), ptr(wb), ptr(bb), ptr(tmp), None,
                                      E, stream()), "ramp_upd_nbr")
             check(lib().ramp_upd_nbr(ptr(tmp), ptr(plan.jx_raw), ptr(wa2), ptr(ba2), ptr(wb2), ptr(bb2), ptr(net32),

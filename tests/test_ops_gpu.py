@@ -233,69 +233,6 @@ def test_pyramid_pack_and_chunked_corr():
     assert a.float().abs().max() > 0
 
 
-@torch.no_grad()
-@pytest.mark.parametrize("E", [1, 61, 1000])
-def test_corr_l1_fused_launch_equals_corr_then_the_correlation_mlp(E):
-    """SURVEY N2, first clause (ramp_corr_l1_fwd_ordered): correlation + Update.corr[0] + ReLU in one launch.  (a) c1
-    against a plain fp32 PyTorch Linear + ReLU on the unfused kernel's rows (reference: ramp/net.py:60-61 on
-    Ramp_vo.corr's output, ramp/Ramp_vo.py:175-182); (b) through the tail of the correlation MLP the result is
-    bit-identical to the unfused pair's (same rows, same MFMA operand and K order) -- plain and packed target maps, a
-    target-frame-major schedule, wrapped ring-buffer indices, factors off the image, a ragged last group of 16"""
-    import torch.nn.functional as F
-    from rampvo_amd import ops
-    from rampvo_amd._lib import KPLANE, RAMP_NHWC, RAMP_NHWC32, check, lib, ptr, stream
-    from rampvo_amd.synthetic import make_network
-    g = torch.Generator().manual_seed(5 + E)
-    N2, H, W, C, M = 3, 24, 32, 128, 12
-    maps = (torch.randn(N2, H, W, C, generator=g) * 0.5).half().cuda()
-    l1 = torch.empty(N2, H, C // KPLANE, W, KPLANE, dtype=torch.half, device="cuda")
-    l4 = torch.empty(N2, H // 4, C // KPLANE, W // 4, KPLANE, dtype=torch.half, device="cuda")
-    for n in range(N2):
-        ops.pyramid_pack(maps[n], l1[n], l4[n])
-    unchunk = lambda t: t.permute(0, 1, 3, 2, 4).reshape(t.shape[0], t.shape[1], t.shape[3], C)
-    pooled = unchunk(l4).contiguous()
-    rng = np.random.default_rng(4 + E)
-    fmap1 = (torch.randn(M, 3, 3, C, generator=g) * 0.5).half().cuda()
-    coords = np.stack([rng.uniform(-6, W + 6, (E, 3, 3)), rng.uniform(-6, H + 6, (E, 3, 3))], 1).astype(np.float32)
-    k = E // 3
-    coords[:k] = coords[:k, :, :1, :1] + np.arange(3, dtype=np.float32)[None, None, None, :]   # compact windows
-    coords[k:k + max(E // 5, 0)] += 500.0                                                        # off both planes
-    ii = torch.from_numpy(rng.integers(0, 3 * M, E)).cuda()                                     # (taken modulo M / N2)
-    jj = torch.from_numpy(rng.integers(0, 3 * N2, E)).cuda()
-    order = torch.argsort(jj % N2, stable=True).int()
-    fu = make_network("SingleScale").update.fused(torch.float16)
-    w = fu.weights()
-    w1, b1 = w["corr1_pack"]
-    w2, b2, w3, b3 = w["tail_pack"]
-    ln, nm = w["corr_ln"], w["norm"]
-    net = (torch.randn(E, 384, generator=g) * 0.5).cuda()
-    table = (torch.randn(64, 384, generator=g) * 0.5).half().cuda()
-    idx = torch.from_numpy(rng.integers(0, 1000, E)).cuda()
-
-    def tail_from_rows(rows):
-        out = torch.empty(E, 384, device="cuda")
-        check(lib().ramp_upd_corr_mlp(ptr(rows), 896, ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3), ptr(ln[0]),
-                                      ptr(ln[1]), float(ln[2]), ptr(net), None, ptr(table), ptr(idx), 64, ptr(nm[0]),
-                                      ptr(nm[1]), float(nm[2]), ptr(out), E, stream()), "ramp_upd_corr_mlp")
-        return out
-
-    def tail_from_c1(c1):
-        out = torch.empty(E, 384, device="cuda")
-        check(lib().ramp_upd_corr_tail(ptr(c1), ptr(w2), ptr(b2), ptr(w3), ptr(b3), ptr(ln[0]), ptr(ln[1]), float(ln[2]),
-                                       ptr(net), None, ptr(table), ptr(idx), 64, ptr(nm[0]), ptr(nm[1]), float(nm[2]),
-                                       ptr(out), E, stream()), "ramp_upd_corr_tail")
-        return out
-
-    W1 = make_network("SingleScale").update.corr[0]
-    for layout, levels, sched in ((RAMP_NHWC, [maps, pooled], None), (RAMP_NHWC32, [l1, l4], order), (RAMP_NHWC32, [l1, l4], None)):
-        rows = ops.corr(fmap1, levels, cu(coords), ii, jj, 3, (1.0, 4.0), layout, order=sched, row_elems=896, mod_ii=M, mod_jj=N2)
-        c1 = ops.corr_l1(fmap1, levels, cu(coords), ii, jj, w1, b1, layout, order=sched, mod_ii=M, mod_jj=N2)
-        assert c1.shape == (E, 384) and torch.isfinite(c1).all()
-        exp = torch.relu(F.linear(rows[:, :882].float(), W1.weight.half().float().cuda(), W1.bias.half().float().cuda()))
-        assert float((c1.float() - exp).abs().max()) <= 2e-3 * max(1.0, float(exp.abs().max())), (layout, E)
-        assert torch.equal(tail_from_c1(c1), tail_from_rows(rows)), (layout, E)
-
-
 def test_corr_matches_reference_call_site_golden():
     """G3 (tests/golden/corr.npz): what the reference's altcorr.corr python call site returned for both pyramid
     levels, stacked as Ramp_vo.corr stacks them (ramp/Ramp_vo.py:175-182)"""
@@ -530,46 +467,6 @@ def test_ba_is_deterministic():
         assert np.array_equal(p, outs[0][0]) and np.array_equal(pt, outs[0][1])
 
 
-def _ba_runs_under(envs):
-    """the same bundle-adjustment problems (windows of 5, 7, 10 and 16 free poses, two iterations) solved in one subprocess per
-    environment -- the launch-variant switches of csrc/ba.hip are read once per process"""
-    import os
-    import subprocess
-    import sys
-    import tempfile
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
-            "from scenes import ba_scene; from rampvo_amd import ops; cu = lambda a: torch.as_tensor(a).cuda()\n"
-            "out = {}\n"
-            "for n, (nf, M, life, win) in enumerate(((9, 14, 4, 5), (12, 24, 6, 7), (24, 96, 13, 10), (22, 20, 9, 16))):\n"
-            "    s = ba_scene(seed=31 + n, n_frames=nf, M=M, lifetime=life, n_total_frames=nf + 6, far=bool(n & 1))\n"
-            "    poses, patches = cu(s['poses']), cu(s['patches']); info = torch.zeros(1, dtype=torch.int32, device='cuda')\n"
-            "    ops.ba(poses, patches, cu(s['intr']), cu(s['target']), cu(s['weight']), cu(s['lmbda']), cu(s['ii']), cu(s['jj']),"
-            " cu(s['kk']), nf - win, nf, 2, info)\n"
-            "    out['p%%d' %% n], out['d%%d' %% n], out['i%%d' %% n] = poses.cpu().numpy(), patches.cpu().numpy(), info.cpu().numpy()\n"
-            "    assert np.abs(out['p%%d' %% n] - s['poses']).max() > 1e-5\n"
-            "np.savez(sys.argv[1], **out)\n") % (root, os.path.join(root, "tests"))
-    outs = []
-    with tempfile.TemporaryDirectory() as td:
-        for i, env in enumerate(envs):
-            path = os.path.join(td, "ba%d.npz" % i)
-            r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **env), capture_output=True, text=True,
-                               timeout=600, cwd=root)
-            assert r.returncode == 0, r.stderr[-3000:]
-            outs.append({k: v for k, v in np.load(path).items()})
-    return outs
-
-
-def test_ba_launch_variants_are_bit_identical():
-    """fastba.BA's Gauss-Newton iteration (ramp/fastba/ba_cuda.cu:433-582) as launches: the default merges the assembly of S
-    into the factorisation's workgroup (ba_asmchol_kernel) -- same sums in the same order as the separate assembly launch
-    (RAMP_BA_ASMCHOL=0), so poses and depths agree bit for bit at every window size it serves (<= 16 poses)."""
-    runs = _ba_runs_under(({"RAMP_BA_ASMCHOL": "0"}, {"RAMP_BA_ASMCHOL": "1"}))
-    for b in runs[1:]:
-        for k in runs[0]:
-            assert np.array_equal(runs[0][k], b[k]), k
-
-
 def test_ops_refuse_cpu_tensors():
     from rampvo_amd import ops
     with pytest.raises(RuntimeError):
@@ -741,18 +638,6 @@ def test_softagg_fused_against_fp32_torch(E, mode):
         assert err <= FUSED_CHAIN_TOL, (E, mode, add, err)
 
 
-
-def test_wide_tile_corr_mlp_variant_against_fp32_torch():
-    """RAMP_CORR_MLP_BIG=1 (csrc/update_mlp.hip::upd_corr_mlp_big_kernel: 80-row tiles, LayerNorm from the accumulators, no
-    parking passes -- the opt-in variant of the correlation MLP): the chain test below at a ragged big-tile size, in a
-    process of its own (the switch is read once per process)"""
-    import subprocess, sys
-    env = dict(os.environ, RAMP_CORR_MLP_BIG="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", __file__ + "::test_fused_update_chains_against_fp32_torch[20011]"],
-                       env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-
-
 @pytest.mark.parametrize("E", [1003, 5408, 20011, 41003])
 @torch.no_grad()
 def test_fused_update_chains_against_fp32_torch(E):
@@ -834,7 +719,7 @@ def test_fused_update_chains_against_fp32_torch(E):
         cmp("nbr_" + name, o, exp)
         cmp("nbr_t_" + name, ot, exp)
 
-    # --- upd_corr_mlp: LN_norm(net[map] + inp[idx % mod] + corr-MLP(corr)); upd_corr_tail: the same from c1 = relu(L1 corr)
+    # --- upd_corr_mlp: LN_norm(net[map] + inp[idx % mod] + corr-MLP(corr))
     corr = F.pad(rnd(E, 882, sc=2.0).half(), (0, 14)).contiguous()
     state = rnd(700, 384)
     net_map = torch.randint(-1, 700, (E,), generator=g).cuda()
@@ -851,12 +736,6 @@ def test_fused_update_chains_against_fp32_torch(E):
     st = state[net_map.clamp(min=0)] * (net_map >= 0).float()[:, None]
     exp = ref.norm(st + table.float()[inp_idx % 300] + ref.corr(corr[:, :882].float()))
     cmp("corr_mlp", o, exp)
-    c1 = torch.relu(ref.corr[0](corr[:, :882].float())).half()
-    check(lib().ramp_upd_corr_tail(ptr(c1), ptr(w2), ptr(b2), ptr(w3), ptr(b3), ptr(ln[0]), ptr(ln[1]), float(ln[2]),
-                                   ptr(state), ptr(net_map), ptr(table), ptr(inp_idx), 300, ptr(nm[0]), ptr(nm[1]),
-                                   float(nm[2]), ptr(o), E, stream()), "corr_tail")
-    exp_t = ref.norm(st + table.float()[inp_idx % 300] + ref.corr[5](torch.relu(ref.corr[3](ref.corr[2](c1.float())))))
-    cmp("corr_tail", o, exp_t)
     # zero state / identity context (the motion probe's form)
     check(lib().ramp_upd_corr_mlp(ptr(corr), 896, ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3), ptr(ln[0]),
                                   ptr(ln[1]), float(ln[2]), None, None, ptr(rnd(E, 384).half()), None, 0,
@@ -1160,39 +1039,6 @@ def test_upd_linear_matches_fp32_torch():
     err = (y[:live].float() - ref[:live]).abs().max().item()
     assert err <= 2e-3 * ref.abs().max().item(), err
     assert bool((y[live:] == 7.0).all())
-
-
-@torch.no_grad()
-@pytest.mark.parametrize("E", [1003, 20011, 41003])
-def test_upd_nbr2_equals_the_two_neighbour_launches(E):
-    """c1 and c2 in one launch over the (kk, jj)-sorted factor list (csrc/update_mlp.hip::upd_nbr2_kernel) against the
-    two ramp_upd_nbr launches it replaces: every row goes through the same products in the same order -- bit equal.
-    Graph: patches with 1..40 factors each (single-factor patches: no neighbour on either side), factors shuffled."""
-    from rampvo_amd import _lib, ops
-    from rampvo_amd.update_fused import pack_linear_f16
-    rng = np.random.default_rng(E)
-    sizes = []
-    while sum(sizes) < E:
-        sizes.append(int(rng.integers(1, 41)))
-    sizes[-1] -= sum(sizes) - E
-    kk = np.repeat(np.arange(len(sizes)) + 500, sizes)
-    jj = np.concatenate([rng.permutation(60)[:s] if s <= 60 else np.arange(s) for s in sizes])
-    perm = rng.permutation(E)
-    kk, jj = kk[perm].astype(np.int64), jj[perm].astype(np.int64)
-    g = ops.group_by_small(cu(kk), None, 1, 500, len(sizes), len(sizes))
-    ix, jx, kj = ops.neighbors_from_groups(g, cu(jj), len(sizes), want_kj=True)
-    torch.manual_seed(E)
-    net = torch.randn(E, 384, device="cuda")
-    lins = [torch.nn.Linear(384, 384).cuda() for _ in range(4)]
-    wp = [pack_linear_f16(l.weight) for l in lins]
-    bs = [l.bias.detach().half().float().contiguous() for l in lins]
-    L, P = _lib.lib(), _lib.ptr
-    tmp, ref, got = torch.empty_like(net), torch.empty_like(net), torch.empty_like(net)
-    _lib.check(L.ramp_upd_nbr(P(net), P(ix), P(wp[0]), P(bs[0]), P(wp[1]), P(bs[1]), P(tmp), None, E, _lib.stream()), "nbr")
-    _lib.check(L.ramp_upd_nbr(P(tmp), P(jx), P(wp[2]), P(bs[2]), P(wp[3]), P(bs[3]), P(ref), None, E, _lib.stream()), "nbr")
-    _lib.check(L.ramp_upd_nbr2(P(net), P(kj), P(ix), P(jx), P(wp[0]), P(bs[0]), P(wp[1]), P(bs[1]), P(wp[2]), P(bs[2]),
-                               P(wp[3]), P(bs[3]), P(got), E, _lib.stream()), "nbr2")
-    assert torch.equal(got, ref), float((got - ref).abs().max())
 
 
 @torch.no_grad()
