@@ -49,9 +49,6 @@ _CUS = {}
 def _gru_tile_rows(E, device):
     """rows per workgroup ramp_upd_gru picks for E factors (csrc/update_mlp.hip: the tile that needs fewer rounds of one
     workgroup per CU)"""
-    forced = os.environ.get("RAMP_GRU_MT")
-    if forced in ("4", "5"):
-        return 16 * int(forced)
     key = str(device)
     if key not in _CUS:
         _CUS[key] = torch.cuda.get_device_properties(device).multi_processor_count
@@ -62,14 +59,14 @@ def _gru_tile_rows(E, device):
 
 
 _FE_DELAY_US = int(os.environ.get("RAMP_FE_DELAY_US", "35"))     # A/B switch: 0 = the encoder graph right behind the selection
-_GATE_FLAG_DELAY_US = int(os.environ.get("RAMP_GATE_FLAG_DELAY_US", "0"))
-_FE_WAIT_PROBE = os.environ.get("RAMP_FE_WAIT_PROBE", "0") == "1"   # tools/fe_wait.py
+_GATE_FLAG_DELAY_US = 0
+_FE_WAIT_PROBE = False      # (diagnostic, set by tools/fe_wait.py before the tracker is built: events around the main queue's wait for the front end)
 # The front end's "done" is a data dependency (the frame commit reads fe_fmap1 / imap / gmap / patches): the wave that waits
 # for its signal word must not give up while the producer can still arrive.  The time-out is a hang guard only -- 20 s, far
 # beyond any profiler slow-down -- and a wait that does give up still raises sticky status bit 128, on which settle() /
 # lazy_state() raise.  Runtimes that serialise kernels never get here (_kernels_are_serialised: events instead).  The gate
 # wait (_gate_wait) keeps its 50 ms: it orders nothing but timing (a front end that starts early is slower, not wrong).
-_FE_DONE_TIMEOUT_US = int(os.environ.get("RAMP_FE_DONE_TIMEOUT_US", "20000000"))
+_FE_DONE_TIMEOUT_US = 20000000
 
 
 def _kernels_are_serialised():
@@ -805,7 +802,7 @@ class Ramp_vo:
         encoder graph and looked at by one sleeping wave in front of the frame commit (RAMP_FE_DONE_FLAG=0, or no signal
         memory, or a runtime that serialises kernels (_kernels_are_serialised): an event record + stream wait, ~10 us of
         packets on the serial chain even when the front end is long done).  The commit READS what the front end wrote, so
-        this wait's time-out is a hang guard (RAMP_FE_DONE_TIMEOUT_US, 20 s), not a scheduling choice"""
+        this wait's time-out is a hang guard (20 s), not a scheduling choice"""
         if self._fe_done_sig is None:
             use = os.environ.get("RAMP_FE_DONE_FLAG", "1") != "0" and not _kernels_are_serialised()
             with torch.cuda.device(self.device):
@@ -865,9 +862,8 @@ class Ramp_vo:
             # rounds of one workgroup per CU, 254 VGPRs) the front end's LSTM launch cannot take a CU from it, so the
             # selection goes out AHEAD of the gate and the graph right behind it; with 64-row tiles an LSTM launch that
             # arrives within ~40 us costs gru 45 us, so the selection runs behind the gate and the graph is held back
-            # another 35 us (_fe_delay).  RAMP_SELECT_AHEAD=0|1 forces either.
-            env = os.environ.get("RAMP_SELECT_AHEAD")
-            ahead = (env == "1") if env is not None else _gru_tile_rows(dv.factor_estimate(), self.device) == 80
+            # another 35 us (_fe_delay).
+            ahead = _gru_tile_rows(dv.factor_estimate(), self.device) == 80
             if getattr(self, "_in_event_pending", False):
                 fe.wait_event(self._ev_in)              # inputs_ready = "stream": the caller's stream up to the call
             if not ahead:

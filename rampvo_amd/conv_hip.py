@@ -113,7 +113,7 @@ def pack_lstm_mfma(enc):
 
 # ------------------------------------------------------------------------ primitives
 IN_ACC_R = 8             # include/ramp_hip.h::RAMP_IN_ACC_R
-_IN_ACC = os.environ.get("RAMP_IN_ACC", "1") != "0"     # A/B switch: 0 = per-layer ramp_in_stats_finalize launches
+_IN_ACC = True           # (False: per-layer ramp_in_stats_finalize launches -- round 3's A/B)
 
 
 class Pending:
@@ -194,7 +194,7 @@ class ConvJob(ctypes.Structure):
                 ("skip_eps", ctypes.c_float), ("skip_relu", ctypes.c_int32), ("mat", ctypes.c_void_p)]
 
 
-_TAIL_FUSE = os.environ.get("RAMP_CONV_TAIL_FUSE", "1") != "0"   # A/B switch: 0 = a norm_add_relu launch per residual block
+_TAIL_FUSE = True        # (False: a norm_add_relu launch per residual block -- round 4's A/B)
 
 
 class Tail:
@@ -302,7 +302,7 @@ def conv2d_towers(jobs, half, fp8=False):
         return [conv2d(j["x"].cat() if isinstance(j["x"], Pair) else j["x"], j["conv"], res=j.get("res"),
                        relu=j.get("relu", False), want_stats=j.get("want_stats", False),
                        out_scale=j.get("out_scale", 1.0), eps=j.get("eps", 1e-5), half=half) for j in jobs]
-    if not half or len(jobs) > 2 or os.environ.get("RAMP_TOWER_PAIR", "1") != "1":
+    if not half or len(jobs) > 2:
         return single()
     x0 = jobs[0]["x"]
     x0 = x0.y.raw if isinstance(x0, Tail) else x0.raw if isinstance(x0, Pending) else x0
@@ -513,7 +513,7 @@ def basic_encoder4(enc, x, out_scale=1.0, half=False):
     return basic_encoder4_towers([enc], x, out_scale, half)[0]
 
 
-_MS_PAIR = os.environ.get("RAMP_MS_PAIR", "1") == "1"       # A/B switch: 0 = torch.cat copies
+_MS_PAIR = True          # (False: torch.cat copies -- round 4's A/B)
 
 
 def multiscale_encoder4_towers(encs, x, x2, x4, out_scale=1.0, half=False, fp8=False):
@@ -679,7 +679,7 @@ def pack_ms_scale_mfma(enc, k):
     return wfrag, wsmall
 
 
-_MS_MFMA = os.environ.get("RAMP_MS_MFMA", "1") == "1"       # A/B switch: 0 = the fp32 VALU kernel
+_MS_MFMA = True          # (False: the fp32 VALU kernel -- round 4's A/B)
 
 
 def ms_lstm_superstate_step(enc, k, ev, im, st, use_im, want_half=False):

@@ -1621,9 +1621,7 @@ static int ms_mfma_launch(const MsMfmaParams &p0, hipStream_t st) {
   const int ntile = ramp_cdiv(p.Hs * p.Ws, 16);
   // one tile per wave while that keeps the launch within ~8 waves per SIMD; more tiles per wave beyond (a workgroup's
   // weight staging is then amortised over them)
-  static int tpw_env = -1;
-  if (tpw_env < 0) { const char *e = getenv("RAMP_MS_TPW"); tpw_env = e ? atoi(e) : 0; }
-  int tpw = tpw_env > 0 ? tpw_env : ramp_cdiv(ntile, 8 * 1024);
+  int tpw = ramp_cdiv(ntile, 8 * 1024);
   if (tpw < 1) tpw = 1;
   p.tiles_per_wave = tpw;
   hipLaunchKernelGGL((ms_lstm_superstate_mfma_kernel<D, S, NWV>), dim3(ramp_cdiv(ntile, NWV * tpw)), dim3(64 * NWV), lds, st, p);
@@ -1732,9 +1730,10 @@ int ramp_lstm_superstate_blocks(const float *ev, const float *im, float *h_ev, f
     return RAMP_EINVAL;
   const int ntile = ramp_cdiv(HW, 16);
   const int tpw = ntile >= 8192 ? 4 : 1;           // tiles per wave: amortise the 104 weight fragments
-  static int ldsw = -1;                            // RAMP_LSTM_LDSW=0: weights in registers (A/B runs)
-  if (ldsw < 0) { const char *ev_ = getenv("RAMP_LSTM_LDSW"); ldsw = ev_ ? atoi(ev_) : 1; }
-  if (ldsw)
+#ifndef LSTM_LDSW
+#define LSTM_LDSW 1                                // (build-time A/B, tools/ab_build.sh: 0 = weight fragments in registers)
+#endif
+  if (LSTM_LDSW)
     hipLaunchKernelGGL(lstm_superstate_mfma_kernel<true>, dim3(ramp_cdiv(ntile, 4 * tpw)), dim3(256), 0,
                        (hipStream_t)stream, ev, im, h_ev, c_ev, h_im, c_im, ss, wfrag, flags, HW, has_state,
                        has_ss, tpw, nblk);
@@ -1859,7 +1858,7 @@ int ramp_conv2d_nhwc_multi(const ramp_conv_job *jobs, int njobs, int H, int W, i
   hipStream_t st = (hipStream_t)stream;
   // the first layer of the two towers: one workgroup per tile computes both (shared input, no prologue)
   if (KH == 7 && stride == 2 && in_f32 && Cin == 16 && njobs == 2 && jobs[0].x == jobs[1].x && jobs[0].Cout == 32 &&
-      jobs[1].Cout == 32 && !jobs[0].pre_scale && !jobs[1].pre_scale && !getenv("RAMP_CONV7_SINGLE")) {
+      jobs[1].Cout == 32 && !jobs[0].pre_scale && !jobs[1].pre_scale) {
     hipLaunchKernelGGL(conv7_dual_kernel, dim3(tiles, 1, 1), block, 0, st, pm);
     RAMP_CHECK_LAUNCH();
     return RAMP_OK;
@@ -1895,8 +1894,8 @@ int ramp_conv2d_nhwc_multi(const ramp_conv_job *jobs, int njobs, int H, int W, i
   TILE_CASE(7, 2, true, 16, 2)
   // 16 x 16 output tiles for the 32-channel 3x3 layers at half resolution (600 workgroups of two towers, three per CU: still
   // one round): weight fragments staged once per 256 pixels and a 1.27x instead of 1.41x halo.  Per-block statistics
-  // (`stats`, the path without accumulators) keep the 8 x 16 grid their buffers are sized for.  RAMP_CONV_TH16=0: A/B
-  static const bool th16 = !getenv("RAMP_CONV_TH16") || atoi(getenv("RAMP_CONV_TH16")) != 0;
+  // (`stats`, the path without accumulators) keep the 8 x 16 grid their buffers are sized for.  (8 x 16 tiles: the A/B of round 4)
+  constexpr bool th16 = true;
   bool block_stats = false, any_skip = false;
   for (int t = 0; t < njobs; t++) { block_stats |= jobs[t].stats != nullptr; any_skip |= jobs[t].skip != nullptr; }
   if (any_skip) {                                     // a tower takes a fused residual-block tail: the TAIL instances
@@ -1931,8 +1930,8 @@ int ramp_conv2d_nhwc_multi(const ramp_conv_job *jobs, int njobs, int H, int W, i
   TILE_CASE(3, 1, false, 32, 2)
   TILE_CASE(3, 2, false, 32, 2)
   // (stride 2 at 64 channels, the MultiScale towers' layer3: the 80 KB halo tile leaves one workgroup per CU either way;
-  // with all 64 output channels in it the tile is staged once instead of twice -- RAMP_CONV_S2_NT4=0 for the A/B)
-  static const bool s2nt4 = !getenv("RAMP_CONV_S2_NT4") || atoi(getenv("RAMP_CONV_S2_NT4")) != 0;
+  // with all 64 output channels in it the tile is staged once instead of twice -- round 4's A/B)
+  constexpr bool s2nt4 = true;
   if (s2nt4) { TILE_CASE(3, 2, false, 64, 4) }
   TILE_CASE(3, 2, false, 64, 2)
   TILE_CASE(3, 1, false, 64, 2)
@@ -1994,8 +1993,7 @@ int ramp_ms_lstm_superstate_mfma(const float *ev, const float *im, const float *
   hipStream_t st = (hipStream_t)stream;
   if (scale > 1 && (p.Ws % 16)) return RAMP_EUNSUPPORTED;      // (a tile = 16 neighbours of one row)
   if (scale == 1) return ms_mfma_launch<16, 1, 4>(p, st);
-  static int split = -1;                              // RAMP_MS_SPLIT=0: a whole tile per wave at scales 2 / 4 (A/B runs)
-  if (split < 0) { const char *e = getenv("RAMP_MS_SPLIT"); split = e ? atoi(e) : 1; }
+  constexpr int split = 1;                            // (0: a whole tile per wave at scales 2 / 4 -- measured slower)
   const int ntile = ramp_cdiv(p.Hs * p.Ws, 16);
   if (split) {
     if (scale == 2) hipLaunchKernelGGL((ms_lstm_superstate_split_kernel<32, 2>), dim3(ntile), dim3(128), 0, st, p);

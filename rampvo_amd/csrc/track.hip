@@ -432,8 +432,7 @@ extern "C" {
 
 int ramp_stream_wait_flag(void *stream, const uint32_t *flag, uint32_t value, int timeout_us, int then_delay_us, int32_t *status) {
   if (!flag || timeout_us <= 0 || then_delay_us < 0) return RAMP_EINVAL;
-  static int nap = 0;                                  // RAMP_FLAG_NAP: s_sleep(64) units (~1.7 us each) between two looks
-  if (!nap) { const char *e = getenv("RAMP_FLAG_NAP"); nap = e ? atoi(e) : 2; if (nap < 1) nap = 1; }
+  const int nap = 2;                                   // s_sleep(64) units (~1.7 us each) between two looks at the word
   hipLaunchKernelGGL(trk_wait_flag_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, flag, value, (long)timeout_us * 100,
                      (long)then_delay_us * 100, nap, status);
   RAMP_CHECK_LAUNCH();
@@ -471,8 +470,7 @@ int ramp_track_warm(const ramp_track *t, int32_t *sink, void *stream) {
   const long n1 = (long)t->feat_h * t->feat_w * 128 * 2 / 16, n2 = (long)(t->feat_h / 4) * (t->feat_w / 4) * 128 * 2 / 16;
   const long ng = (long)t->mem * t->M * t->P * t->P * 128 * 2 / 16;
   const int frames = t->removal_window + 3 < t->mem ? t->removal_window + 3 : t->mem;
-  static int gx = 0;
-  if (!gx) { const char *e = getenv("RAMP_WARM_GX"); gx = e ? atoi(e) : 8; }   // 8 x 26 workgroups: ~100 us of gentle streaming (64: the planes arrive sooner, the tail kernels slow down as much)
+  const int gx = 8;   // 8 x 26 workgroups: ~100 us of gentle streaming (64: the planes arrive sooner, the tail kernels slow down as much)
   hipLaunchKernelGGL(trk_warm_kernel, dim3(gx, frames + 1), dim3(256), 0, (hipStream_t)stream, (const uint4 *)t->fmap1,
                      (const uint4 *)t->fmap2, (const uint4 *)t->gmap, n1, n2, ng, t->mem, frames, t->dyn, sink, t->fmap1_slot);
   RAMP_CHECK_LAUNCH();
@@ -526,8 +524,7 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
   const int Eb = (E_bound > 0 && E_bound < Ec) ? E_bound : Ec;
   const int new_cap = (2 * t->patch_lifetime - 1) * t->M;          // factors one frame adds
   // (the bound check rides in the frame commit's launch when there is one)
-  static int fold = -1;                                  // RAMP_BOUND_FOLD=0: a launch of its own (A/B runs)
-  if (fold < 0) { const char *e = getenv("RAMP_BOUND_FOLD"); fold = e ? atoi(e) : 1; }
+  const int fold = 1;
   const bool folded = fold && (flags & RAMP_TRACK_COMMIT);
   if (Eb < Ec && !folded) hipLaunchKernelGGL(trk_bound_check_kernel, dim3(1), dim3(1), 0, st, t->dyn, Eb);
   const int64_t *g = t->graph[cur];

@@ -533,8 +533,7 @@ int ramp_upd_segment_softmax(const void *fg, const int32_t *order, const int32_t
     hipLaunchKernelGGL(upd_segment_softmax_seq_kernel<float>, grid, dim3(192), 0, (hipStream_t)stream,
                        (const float *)fg, order, seg_start, ngroups, (float *)y);
   else if (dtype == RAMP_F16) {
-    static int v8 = -1;                                  // RAMP_SEG_X8=0: the 8-byte kernel (A/B runs)
-    if (v8 < 0) { const char *e = getenv("RAMP_SEG_X8"); v8 = e ? atoi(e) : 1; }
+    const int v8 = 1;
     // many short groups (the patch grouping: ~2100 x ~19 rows) gain from the 16-byte kernel (27.3 -> 23.7 us); the pair
     // grouping's 420 x 96 rows are bound by the work per thread and want the 768-thread kernel (18.1 vs 21.9 us)
     if (v8 && max_groups >= 1024)

@@ -1631,8 +1631,8 @@ int ramp_i_upd_gru(const float *x32, const void *add0_t, const int32_t *add0_idx
   p.PP = P * P; p.ctr = (P / 2) * P + P / 2; p.wd = wd; p.ht = ht;
   // rows per workgroup: whichever of 64 / 80 needs fewer rounds of one-workgroup-per-CU (ties: fewer row-rounds); with
   // device-side sizes E is the launch bound, the live count is a little below it
-  static int mt_force = -1, cus = 0;
-  if (mt_force < 0) { const char *ev = getenv("RAMP_GRU_MT"); mt_force = ev ? atoi(ev) : 0; }
+  static int cus = 0;
+  const int mt_force = 0;
   if (!cus) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)

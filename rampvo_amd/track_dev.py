@@ -58,8 +58,8 @@ class Track(ctypes.Structure):
                    ("gate_seq", ctypes.c_uint32), ("feat_fp32", c_i), ("feat_plain", c_i), ("gate_flag", c_p), ("fmap1_slot", c_p)])
 
 
-_E_EST_LAST = int(os.environ.get("RAMP_E_EST_LAST", "1"))        # 0: the largest of the last 64 copies (round 3's first rule)
-_E_EST_MARGIN = int(os.environ.get("RAMP_E_EST_MARGIN", "0"))
+_E_EST_LAST = 1          # (0: the largest of the last 64 copies, round 3's first rule)
+_E_EST_MARGIN = 0
 
 
 class Signal:
@@ -88,13 +88,13 @@ class Signal:
 
 
 def supported(slam):
-    """the fused fp16 path on the tracker's own chunked buffers -- or the fp32 path (plain NHWC fp32 buffers; its update
-    operator's library GEMMs are issued by the host between the two halves of the step, still without reading the device) --
-    with a full optimisation window"""
+    """the configurations the device-resident step takes: fp16 or fp32 features (update operator: csrc/update_mlp.hip /
+    csrc/update_x3.hip's fused chains), P = 3, DIM = 384, any PATCHES_PER_FRAME up to 303, DAMPED_LINEAR motion model, an
+    optimisation window of at most 32 poses"""
     cfg = slam.cfg
-    # (fp16 features: the chunked pyramid layout, or plain NHWC planes where the feature plane's shape does not fit it)
-    layout_ok = slam.dtype == torch.half or (slam.dtype == torch.float and not slam._chunked
-                                             and os.environ.get("RAMP_DEVICE_STEP_FP32", "1") == "1")
+    # (fp16 features: the chunked pyramid layout, or plain NHWC planes where the feature plane's shape does not fit it; fp32
+    # features: plain NHWC planes)
+    layout_ok = slam.dtype == torch.half or (slam.dtype == torch.float and not slam._chunked)
     return (layout_ok and slam._lazy_net and slam.P == 3 and slam.DIM == 384
             and 3 * slam.M * 9 <= 8192 and cfg.MOTION_MODEL in ("DAMPED_LINEAR",)
             and cfg.PATCH_LIFETIME <= cfg.REMOVAL_WINDOW + 1 and cfg.KEYFRAME_INDEX >= 2
@@ -104,9 +104,7 @@ def supported(slam):
 def unsupported_reason(slam):
     """which of supported()'s conditions fails (for the one-time warning of Ramp_vo._enter_device)"""
     cfg = slam.cfg
-    checks = [(slam.dtype == torch.half or os.environ.get("RAMP_DEVICE_STEP_FP32", "1") == "1",
-               "MIXED_PRECISION is off and RAMP_DEVICE_STEP_FP32=0 (the fp32 path is host driven)"),
-              (slam.P == 3 and slam.DIM == 384, "patch size / feature width other than 3 / 384"),
+    checks = [(slam.P == 3 and slam.DIM == 384, "patch size / feature width other than 3 / 384"),
               (3 * slam.M * 9 <= 8192, "PATCHES_PER_FRAME above 303 (the depth median of three frames is one workgroup's)"),
               (cfg.MOTION_MODEL in ("DAMPED_LINEAR",), "MOTION_MODEL other than DAMPED_LINEAR"),
               (cfg.PATCH_LIFETIME <= cfg.REMOVAL_WINDOW + 1, "PATCH_LIFETIME exceeds REMOVAL_WINDOW + 1"),
@@ -209,8 +207,7 @@ class DeviceTrack:
         if lib.ramp_host_device_pointer(ctypes.c_void_p(self.dyn_host.data_ptr()), ctypes.byref(dp)) == 0 and dp.value:
             t.dyn_host_dev = dp.value
         self.status_ptr = self.dyn.data_ptr() + 4 * DYN_STATUS
-        if os.environ.get("RAMP_MEDIAN_AHEAD", "1") != "0":       # (A/B: 0 = the median at the head of the next step)
-            t.median = P(self.median)
+        t.median = P(self.median)                 # (the depth median of the next frame: computed beside the motion test)
         t.graph[0], t.graph[1] = P(self.graph[0]), P(self.graph[1])
         for i in range(3):
             t.net[i] = P(self.net[i])
@@ -311,7 +308,7 @@ class DeviceTrack:
         """the live factor count of the newest lazy copy of the sizes (a frame or two old; tools/e_trace.py: the count
         drifts by a few hundred per frame over 39k .. 46k at the bench size, so a maximum over 64 frames sits above the
         80-row gru tile's limit of 40960 most of the time although half of the frames are below it): picks tile sizes,
-        bounds nothing.  Sequential rate 834 -> 853 kf/s, pipelined unchanged (RAMP_E_EST_LAST=0: the maximum)."""
+        bounds nothing.  Sequential rate 834 -> 853 kf/s, pipelined unchanged."""
         e = int(self.lazy_state()[DYN_E])
         if not self._e_seen or self._e_seen[-1] != e:
             self._e_seen.append(e)
