@@ -62,7 +62,7 @@ __device__ __forceinline__ float x3_inv_scale(const _Float16 *wp, int nks) {
 #define X3_GRU_PF 0            // (the gru launch holds the residual stream and the gate in registers: no room for a ring)
 #endif
 #ifndef X3_PF
-#define X3_PF 2                // K steps of weight fragments in flight ahead of the matrix work (0: loaded where used)
+#define X3_PF 1                // K steps of weight fragments in flight ahead of the matrix work (0: loaded where used)
 #endif
 template <int MT>
 __device__ __forceinline__ void x3_mma_step(const _Float16 *Xh, const _Float16 *Xl, int ks, int q, int j, const h8 (&wh)[XNTW],
@@ -285,7 +285,19 @@ __device__ __forceinline__ void x3_stagger() {
   x3_stagger();                                                                                             \
   (void)tid; (void)j; (void)cq
 
-#ifdef X3_OCC
+// Tiles (measured in the fp32 frame, profiles/r06_f_x3_tiles_ab.txt: 64-row tiles / one workgroup per CU 496 kf/s; 32-row tiles at
+// four waves per SIMD for the three lighter chains + 48 rows for gru 519): the chains are bound by their row traffic at one
+// workgroup per CU, two smaller ones overlap it with the other's matrix work.  Row-local arithmetic: the tile size changes no value.
+#ifndef X3_MT
+#define X3_MT 2
+#endif
+#ifndef X3_OCC
+#define X3_OCC 4
+#endif
+#ifndef X3_GRU_MT
+#define X3_GRU_MT 3
+#endif
+#if X3_OCC > 0
 #define X3_ATTR __attribute__((amdgpu_waves_per_eu(X3_OCC, X3_OCC)))
 #else
 #define X3_ATTR
@@ -743,12 +755,6 @@ __global__ void __launch_bounds__(64 * XWAVES) x3_gru_kernel(const X3GruParams p
 }
 
 // ------------------------------------------------------------------ launchers
-#ifndef X3_MT
-#define X3_MT 4
-#endif
-#ifndef X3_GRU_MT
-#define X3_GRU_MT 4
-#endif
 
 template <typename KernelT, typename ParamsT>
 static int x3_launch(KernelT kernel, const ParamsT &p, int rows, int mt, bool ln, hipStream_t st) {
