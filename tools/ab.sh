@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/ab.sh "ENV=.. ENV=.." ["ENV=.."...]: bench.py (no parity / cpu legs) once per environment setting, one line each
 for e in "$@"; do
-  env $e python bench.py --cpu-steps 0 --parity 0 2>&1 | grep '^{' > /tmp/ab_line.json
+  env $e python bench.py --cpu-steps 0 --parity 0 --fp32-leg 0 2>&1 | grep '^{' > /tmp/ab_line.json
   python - "$e" <<'PY'
 import json, sys
 d = json.load(open("/tmp/ab_line.json")); c = d["config"]

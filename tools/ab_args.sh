@@ -4,7 +4,7 @@ envs=()
 while [ "$1" != "--" ] && [ $# -gt 0 ]; do envs+=("$1"); shift; done
 shift
 for e in "${envs[@]}"; do
-  env $e python bench.py --cpu-steps 0 --parity 0 --live-steps 0 "$@" 2>/dev/null | grep '^{' > /tmp/ab_line.json
+  env $e python bench.py --cpu-steps 0 --parity 0 --fp32-leg 0 --live-steps 0 "$@" 2>/dev/null | grep '^{' > /tmp/ab_line.json
   python - "$e" <<'PY'
 import json, sys
 d = json.load(open("/tmp/ab_line.json")); c = d["config"]

@@ -15,7 +15,7 @@ tail -5 gpurun_out/$TAG/pytest.log
 timeout 600 python bench.py > gpurun_out/$TAG/bench.json 2> gpurun_out/$TAG/bench.err
 echo "bench rc=$?"; tail -c 3000 gpurun_out/$TAG/bench.json
 timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/$TAG/bench_driver_args.json 2>> gpurun_out/$TAG/bench.err
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --cpu-steps 0 --parity 0 --np-steps 0 > /tmp/prof_$TAG.log 2>&1)
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --cpu-steps 0 --parity 0 --fp32-leg 0 --np-steps 0 > /tmp/prof_$TAG.log 2>&1)
 f=$(find /tmp/prof_$TAG -name '*kernel_stats.csv' | head -1)
 [ -n "$f" ] && python tools/summarize_rocprof.py $f gpurun_out/$TAG/kernel_stats.md "$TAG: bench.py --steps 100 --warmup 10 (default config)"
 grep -h "^{" /tmp/prof_$TAG.log > gpurun_out/$TAG/bench_under_rocprof.json

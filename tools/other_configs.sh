@@ -2,7 +2,7 @@
 # bench.py on the other BASELINE configs (parity / cpu legs off): one JSON line each into gpurun_out/$1/
 TAG=${1:-r02_cfg}
 mkdir -p gpurun_out/$TAG
-run() { name=$1; shift; timeout 900 python bench.py --cpu-steps 0 --parity 0 "$@" 2>/dev/null | grep '^{' > gpurun_out/$TAG/bench_$name.json; python - gpurun_out/$TAG/bench_$name.json $name <<'PY'
+run() { name=$1; shift; timeout 900 python bench.py --cpu-steps 0 --parity 0 --fp32-leg 0 "$@" 2>/dev/null | grep '^{' > gpurun_out/$TAG/bench_$name.json; python - gpurun_out/$TAG/bench_$name.json $name <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1])); c = d["config"]
 print("%-28s %7.1f kf/s %7.3f ms/step  E=%s  non-pipelined %s" % (sys.argv[2], d["value"], d["ms_per_step"], c.get("edges"), c.get("non_pipelined_kfps")))

@@ -5,7 +5,7 @@ TAG=${1:-r04_z}
 O=gpurun_out/$TAG
 mkdir -p $O
 export TMPDIR=/tmp
-line() { name=$1; shift; timeout 1200 python bench.py --cpu-steps 0 --parity 0 "$@" 2>$O/${name}.err | grep '^{' > $O/bench_${name}.json; python - $O/bench_${name}.json $name <<'PY'
+line() { name=$1; shift; timeout 1200 python bench.py --cpu-steps 0 --parity 0 --fp32-leg 0 "$@" 2>$O/${name}.err | grep '^{' > $O/bench_${name}.json; python - $O/bench_${name}.json $name <<'PY'
 import json, sys
 try:
     d = json.load(open(sys.argv[1])); c = d["config"]
@@ -14,7 +14,7 @@ except Exception as e:
     print(sys.argv[2], "FAILED", e)
 PY
 }
-prof() { name=$1; shift; d=/tmp/prof_$name; (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $d -o p -- python $GRAFT_REPO_ROOT/bench.py --cpu-steps 0 --parity 0 --live-steps 0 --np-steps 0 --inst-steps 0 --steps 60 "$@" > /tmp/prof_$name.out 2>&1); f=$(find $d -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && python tools/summarize_rocprof.py $f $O/kernel_stats_${name}.md "bench.py --steps 60 $* (rocprofv3 --kernel-trace --stats)"; }
+prof() { name=$1; shift; d=/tmp/prof_$name; (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $d -o p -- python $GRAFT_REPO_ROOT/bench.py --cpu-steps 0 --parity 0 --fp32-leg 0 --live-steps 0 --np-steps 0 --inst-steps 0 --steps 60 "$@" > /tmp/prof_$name.out 2>&1); f=$(find $d -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && python tools/summarize_rocprof.py $f $O/kernel_stats_${name}.md "bench.py --steps 60 $* (rocprofv3 --kernel-trace --stats)"; }
 line multiscale_default --mode MultiScale
 line config2_multiscale_precise --config 2
 line config2_full_window --config 2 --keyframe-thresh 0 --prime 90 --clock-warm-max 60 --inst-steps 40 --np-steps 20

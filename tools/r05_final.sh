@@ -9,8 +9,8 @@ python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "sm
 timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?"
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_args.json 2> $O/bench_driver_args.err; echo "bench(driver args) rc=$?"
 d=/tmp/prof_default
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $d -o p -- python $GRAFT_REPO_ROOT/bench.py --cpu-steps 0 --parity 0 > /tmp/prof_default.out 2>&1)
-f=$(find $d -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && python tools/summarize_rocprof.py $f $O/bench_default_kernel_stats.md "bench.py --cpu-steps 0 --parity 0 (rocprofv3 --kernel-trace --stats)"
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $d -o p -- python $GRAFT_REPO_ROOT/bench.py --cpu-steps 0 --parity 0 --fp32-leg 0 > /tmp/prof_default.out 2>&1)
+f=$(find $d -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && python tools/summarize_rocprof.py $f $O/bench_default_kernel_stats.md "bench.py --cpu-steps 0 --parity 0 --fp32-leg 0 (rocprofv3 --kernel-trace --stats)"
 grep '^{' /tmp/prof_default.out > $O/bench_under_rocprof.json
 python - $O <<'PY'
 import json, sys, os

@@ -4,7 +4,7 @@
 export TMPDIR=/tmp
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 K=${STEPS:-20}; W=${WARMUP:-5}; L=${LIVE:-40}; I=8
-ARGS="--steps $K --warmup $W --cpu-steps 0 --parity 0 --np-steps 0 --inst-steps $I --live-steps $L --clock-warm-s 0"
+ARGS="--steps $K --warmup $W --cpu-steps 0 --parity 0 --fp32-leg 0 --np-steps 0 --inst-steps $I --live-steps $L --clock-warm-s 0"
 mkdir -p gpurun_out/r05pmc
 for c in FETCH_SIZE WRITE_SIZE; do
   d=/tmp/pmc_$c; rm -rf $d
