@@ -88,6 +88,9 @@ def parse():
                     help="untimed steady-state steps for at least this long right before the warm-up steps, so that a "
                          "short timed region (the driver's --steps 20 is ~30 ms) runs at settled clocks")
     ap.add_argument("--clock-warm-max", type=int, default=480, help="cap of the clock-warm phase in frames")
+    ap.add_argument("--handback-frames", type=int, default=24,
+                    help="frames between the state_dict() hand-back and the converged / live legs (reported as "
+                         "legs.after_handback)")
     ap.add_argument("--fp32-leg", type=int, default=60,
                     help="(with --mixed 1, rank 0, N = 1) timed steps of the same workload with MIXED_PRECISION off, run as "
                          "`bench.py --mixed 0` in a process of its own behind everything else -> config.fp32_kfps (0 = skip)")
@@ -475,7 +478,10 @@ def cpu_baseline(state, args, cfg_kwargs, frames, steps):
     """time `steps` tracker steps on the host cores from the same steady-state snapshot, through
     the CPU oracle backend (torch CPU for the encoder / update GEMMs, oracle C for the natives)"""
     from oracle.backend_cpu import cpu_oracle_ops
-    cores = min(os.cpu_count() or 1, int(os.environ.get("RAMP_CPU_THREADS", "64")))
+    # the CPUs this process may really use (affinity and the container's bandwidth quota, not the machine's count: a team
+    # larger than the quota is frozen by the kernel for most of every period and measures that)
+    from rampvo_amd import hostenv
+    cores = min(hostenv.cpu_quota(), int(os.environ.get("RAMP_CPU_THREADS", "64")))
     torch.set_num_threads(cores)      # also the OpenMP team of the oracle's edge-parallel loops
     with cpu_oracle_ops():
         slam = _cpu_tracker(state, args, cfg_kwargs)
@@ -490,8 +496,8 @@ def cpu_baseline(state, args, cfg_kwargs, frames, steps):
         dt = time.perf_counter() - tic
     return dict(value=round(steps / dt, 4), unit="keyframes/s", cores=cores, kind="port",
                 sample="%d steady-state steps (E~%d edges) from the GPU run's state snapshot; torch-CPU fp32 "
-                       "encoder/update GEMMs + OpenMP oracle C natives on %d threads (host has %d logical cores)"
-                       % (steps, len(slam._ii), cores, os.cpu_count() or 1),
+                       "encoder/update GEMMs + OpenMP oracle C natives on %d threads (host has %d logical cores, this "
+                       "process may use %d)" % (steps, len(slam._ii), cores, os.cpu_count() or 1, hostenv.cpu_quota()),
                 s_per_step=round(dt / steps, 3))
 
 
@@ -513,7 +519,9 @@ def parity_block(state, args, cfg_kwargs, net, dev):
     net = make_network(args.mode, device=dev, w_bias=PARITY_W_BIAS)
     n = int(state["n"])
     before = state["poses"][:n].numpy().copy()
-    torch.set_num_threads(min(os.cpu_count() or 1, int(os.environ.get("RAMP_CPU_THREADS", "64"))))
+    from rampvo_amd import hostenv
+    host_pool = torch.get_num_threads()
+    torch.set_num_threads(min(hostenv.cpu_quota(), int(os.environ.get("RAMP_CPU_THREADS", "64"))))
     with cpu_oracle_ops():
         ref = _cpu_tracker(state, args, cfg_kwargs, w_bias=PARITY_W_BIAS)
         ref.update()
@@ -527,6 +535,7 @@ def parity_block(state, args, cfg_kwargs, net, dev):
         rp = dict(poses=refp.poses_[:n].numpy().copy(), depth=refp.patches_[:n, :, 2, 1, 1].numpy().copy(),
                   net=refp.net[0].float().numpy().copy(), w=refp.last_weight.numpy().copy())
         del refp
+    torch.set_num_threads(host_pool)       # (the HIP legs below: the tracker's own pool again)
     step = float(np.abs(r["poses"] - before).max())
     scale = max(1.0, step)
     tf = dict(edges=int(state["ii"].shape[0]), keyframes=n, gn_step=round(step, 6), w_head_bias_shift=PARITY_W_BIAS,
@@ -806,7 +815,7 @@ def main():
     n_alone = 20 if (n_inst and n_np) else 0
     n_live = args.live_steps if (n_inst and solo) else 0
     n_os = n_np                                   # the own-stream leg (inputs produced on the caller's stream: evaluate.run's loop)
-    total = args.prime + n_warm + args.warmup + args.steps + n_inst + n_os + n_np + n_alone + (2 * n_live + 4 if n_live else 0)
+    total = args.prime + n_warm + args.warmup + args.steps + n_inst + n_os + n_np + n_alone + (2 * n_live + args.handback_frames if n_live else 0)
     n_cpu = args.cpu_steps + 1 if (solo and args.cpu_steps > 0) else 0
     stream = SyntheticStream(args.height, args.width, total + n_cpu + 1, seed=1234 + rank, device=dev)
     frames = [tuple(x.to(dev) if i < 2 else x for i, x in enumerate(stream.frame(t))) for t in range(total)]
@@ -962,8 +971,16 @@ def main():
     if n_live and dprobe is not None and device_step:
         from rampvo_amd import track_dev
         slam.inputs_ready = bool(args.pipeline)
-        for _ in range(4):                         # back into the device-resident state
+        # back into the device-resident state.  These frames are a leg of their own (config.legs.after_handback): a host
+        # pool larger than the container's CPU quota used to get the process frozen for 15 .. 85 ms a few frames behind a
+        # hand-back (rampvo_amd/hostenv.py is the cure) and the converged leg, which started
+        # 6 frames behind the snapshot, measured that -- if anything of the kind comes back it shows here as `max`
+        hb = LegStats(slam)
+        for _ in range(args.handback_frames):
             step()
+            hb.tick()
+        torch.cuda.synchronize()
+        legs["after_handback"] = hb.summary()
         dvl = getattr(slam, "_dev", None)
         if dvl is not None and dvl.active:
             live_leg = {}
@@ -1038,6 +1055,10 @@ def main():
             out["config"]["per_rank_kfps_E_n_chk"] = per_rank
             out["config"]["process_group"] = {"backend": dist.get_backend(), "world": dist.get_world_size()}
             out["config"]["host_placement"] = host
+        from rampvo_amd import hostenv
+        # the host side: torch's intra-op pool as the tracker left it and the CPUs this process may use (rampvo_amd/hostenv.py)
+        out["config"]["host_threads"] = {"pool": torch.get_num_threads(), "cpu_quota": hostenv.cpu_quota(),
+                                         "logical_cpus": os.cpu_count()}
         rl = ctimer.summary(2 if args.mixed else 4, slam)
         assert rl is not None or args.no_kernel_timing, "no correlation launch was timed: the roofline hook is stale"
         if rl is not None:

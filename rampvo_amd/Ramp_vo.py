@@ -33,7 +33,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from . import altcorr, fastba, lietorch, ops, track_dev
+from . import altcorr, fastba, hostenv, lietorch, ops, track_dev
 from . import projective_ops as pops
 from . import _lib
 from ._lib import KPLANE, RAMP_NHWC, RAMP_NHWC32
@@ -99,6 +99,7 @@ class Ramp_vo:
         # counters a caller (bench.py's legs) can read without touching the device: frames tracked device resident / host
         # driven, hand-backs to the host (settle), waits of the host for the GPU (track_dev.DeviceTrack.throttle)
         self.stats = dict(device_frames=0, host_frames=0, settles=0, throttle_waits=0, throttle_s=0.0)
+        hostenv.fit_host_threads()          # (once per process) a host thread pool larger than the container's CPU quota: see there
         import weakref
         idx = dev.index if dev.index is not None else (torch.cuda.current_device() if dev.type == "cuda" else -1)
         self._live_idx = idx
@@ -327,7 +328,12 @@ class Ramp_vo:
         self.stats["settles"] += 1
         self._n, self._m = st["n"], st["n"] * self.M
         self._hii, self._hjj, self._hkk = st["ii"], st["jj"], st["kk"]
-        g = torch.from_numpy(np.stack([st["ii"], st["jj"], st["kk"], st["rows"]])).to(self.device)
+        # (host -> device through the tracker's pinned staging buffer: plain DMA, no pin / unpin of a pageable array)
+        pg, Ek = dv.pinned_graph(), len(st["ii"])
+        for r_, a_ in enumerate((st["ii"], st["jj"], st["kk"], st["rows"])):
+            pg[r_, :Ek].numpy()[:] = a_
+        g = torch.empty((4, Ek), dtype=torch.int64, device=self.device)
+        g.copy_(pg[:, :Ek])
         self._dii, self._djj, self._dkk = g[0], g[1], g[2]
         self._net_buf, self._net_map, self._net_map_dev = st["net"][None], st["rows"], g[3]
         self._plan = None

@@ -266,8 +266,7 @@ class DeviceTrack:
         E = Ek + ne
         if E > self.E_cap or net_buf.shape[0] > self.E_cap:
             return False
-        g = torch.empty((4, self.E_cap), dtype=torch.int64).pin_memory() if not hasattr(self, "_g_host") else self._g_host
-        self._g_host = g
+        g = self.pinned_graph()
         gn = g.numpy()
         for row, a, b, fill in ((0, ii, e_ii, None), (1, jj, e_jj, None), (2, kk, e_kk, None), (3, rows, None, -1)):
             gn[row, :Ek] = a
@@ -295,6 +294,14 @@ class DeviceTrack:
         self.active = True
         self._frames = 0
         return True
+
+    def pinned_graph(self):
+        """the [4][E_cap] int64 staging buffer of the hand-overs, in pinned host memory: the factor list crosses the bus through
+        it in both directions, so the ~1.2 MB copies of a hand-back are plain DMA with no pin / unpin of user pages by the
+        runtime"""
+        if getattr(self, "_g_host", None) is None:
+            self._g_host = torch.empty((4, self.E_cap), dtype=torch.int64).pin_memory()
+        return self._g_host
 
     def factor_bound(self, counter):
         """upper bound of the live factor count from the lazy host copy of dyn: a frame adds at most (2r - 1) M
@@ -428,7 +435,9 @@ class DeviceTrack:
                 self.fmap1_slot.copy_(torch.arange(len(perm), dtype=torch.int32, device=self.fmap1_slot.device))
         d = self.dyn.cpu().numpy()
         Ek, n = int(d[DYN_EKEPT]), int(d[DYN_NROW])
-        g = self.graph[self.cur][:, :Ek].cpu().numpy()
+        pg = self.pinned_graph()
+        pg[:, :Ek].copy_(self.graph[self.cur][:, :Ek])           # (device -> pinned staging; pinned_graph's note)
+        g = pg[:, :Ek].numpy().copy()
         nlog = int(d[DYN_NLOG])
         log = []
         if nlog:

@@ -10,6 +10,13 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the host thread pool inside the container's CPU quota (the oracle legs' OpenMP teams included): a pool sized by the
+    # machine gets the whole session frozen by the kernel's bandwidth control again and again (rampvo_amd/hostenv.py)
+    import warnings
+    from rampvo_amd import hostenv
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        hostenv.fit_host_threads()
 
 
 def pytest_collection_modifyitems(config, items):

@@ -853,6 +853,10 @@ def test_bench_json_contract():
     f = d["config"]["factors_per_timed_frame"]
     assert f["min"] <= f["mean"] <= f["max"] and abs(d["config"]["factor_updates_per_s"] - d["value"] * f["mean"]) <= 1e-3 * d["value"] * f["mean"]
     assert d["config"]["converged_kfps"] > 0 and 0 < d["roofline"]["frac_live_compact"] <= 1.0
+    legs = d["config"]["legs"]                     # every leg with host step percentiles + the tracker's counters
+    for name in ("timed", "after_handback", "converged", "live"):
+        assert len(legs[name]["host_step_ms_p50_p90_max"]) == 3 and legs[name]["steps"] > 0, name
+    assert legs["after_handback"]["steps"] == 24 and legs["converged"]["host_frames"] == 0 and legs["converged"]["settles"] == 0
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["launches"] == 3 and r["achieved"] > 0      # every 4th timed step is bracketed
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r
@@ -1055,3 +1059,67 @@ def test_extra_update_between_frames_hands_the_state_back_and_forth():
         out.append((slam.poses_[:slam.n].clone(), slam.net.clone(), slam._ii.copy()))
     assert torch.equal(out[0][0], out[1][0]) and np.array_equal(out[0][2], out[1][2])
     assert torch.equal(out[0][1], out[1][1])
+
+
+def _nr_throttled():
+    """how often the kernel's CPU bandwidth control has frozen this container so far (cgroup v2 cpu.stat), or None"""
+    try:
+        for line in open("/sys/fs/cgroup/cpu.stat"):
+            if line.startswith("nr_throttled"):
+                return int(line.split()[1])
+    except OSError:
+        pass
+    return None
+
+
+def test_hand_backs_do_not_freeze_the_process():
+    """The fence around VERDICT r5 item 4 (the "426 kf/s stall"): a leg that started a few frames
+    behind a hand-back to the host (settle / state_dict) contained, one time in four, ONE host step of 15 .. 85 ms.  Cause:
+    torch's intra-op pool is sized by the machine (128 threads), the container has a 16-CPU bandwidth quota; the hand-back's
+    CPU-side tensor ops wake the pool, 128 threads spinning after a parallel region spend the quota in ~12 ms and the kernel
+    freezes every thread of the container for the rest of the 100 ms period -- the launching thread in mid-launch, the GPU
+    runs dry.  rampvo_amd.hostenv.fit_host_threads (called by the tracker) sizes the pool to the quota.  Here at the bench
+    size: 200 steady frames with no host step > 5 ms (one allowed), then 12 legs of 30 frames each 6 frames behind a
+    hand-back: at most one with a step > 5 ms (before the fix 3 .. 4 of 12), and the container's throttle count does not
+    move.  Every timed frame is device resident, none settles."""
+    import time
+    from rampvo_amd import hostenv
+    from rampvo_amd.config import make_cfg
+    from rampvo_amd.Ramp_vo import Ramp_vo
+    from rampvo_amd.synthetic import SyntheticStream, make_network
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(1234)
+    slam = Ramp_vo(make_cfg("default", PATCHES_PER_FRAME=96, MIXED_PRECISION=True), make_network("SingleScale", device=dev),
+                   {"event_bias": True}, ht=480, wd=640, device=dev)
+    assert torch.get_num_threads() <= hostenv.cpu_quota()
+    slam.inputs_ready = True
+    warm, steady, legs, behind, leg = 60, 200, 12, 6, 30
+    total = warm + steady + legs * (behind + leg)
+    stream = SyntheticStream(480, 640, total + 1, seed=1234, device=dev)
+    frames = [tuple(x.to(dev) if i < 2 else x for i, x in enumerate(stream.frame(t))) for t in range(total)]
+    pos = [0]
+
+    def run(n, timed):
+        s0, marks = dict(slam.stats), [time.perf_counter()]
+        for _ in range(n):
+            im, ev, Kc, mask = frames[pos[0]]
+            slam(pos[0], input_tensor=(ev, im, mask), intrinsics=Kc)
+            pos[0] += 1
+            marks.append(time.perf_counter())
+        torch.cuda.synchronize()
+        if timed:
+            st = {k: slam.stats[k] - s0[k] for k in s0}
+            assert st["device_frames"] == n and st["host_frames"] == 0 and st["settles"] == 0, st
+        return np.diff(marks) * 1e3
+
+    run(warm, False)
+    d = run(steady, True)
+    assert np.percentile(d, 50) < 2.0 and int((d > 5.0).sum()) <= 1, (np.percentile(d, 50), np.sort(d)[-3:])
+    thr0, slow = _nr_throttled(), []
+    for _ in range(legs):
+        slam.settle()
+        run(behind, False)
+        slow.append(float(run(leg, True).max()))
+    assert sum(v > 5.0 for v in slow) <= 1, slow
+    thr1 = _nr_throttled()
+    assert thr0 is None or thr1 - thr0 <= 1, (thr0, thr1)
