@@ -1115,6 +1115,7 @@ def test_hand_backs_do_not_freeze_the_process():
     run(warm, False)
     d = run(steady, True)
     assert np.percentile(d, 50) < 2.0 and int((d > 5.0).sum()) <= 1, (np.percentile(d, 50), np.sort(d)[-3:])
+    assert np.percentile(d, 90) <= 1.5 * np.percentile(d, 50), (np.percentile(d, 50), np.percentile(d, 90))   # VERDICT r5's criterion
     thr0, slow = _nr_throttled(), []
     for _ in range(legs):
         slam.settle()
