@@ -45,7 +45,8 @@ extern "C" {
 
 #define RAMP_NCHW 0
 #define RAMP_NHWC 1
-#define RAMP_NHWC32 2  /* [H][C/32][W][32]: correlation target maps only (ramp_pyramid_pack); one plane per MFMA K step */
+#define RAMP_NHWC32 2  /* [H][C/32][W][32] (fp16) / [H][C/16][W][16] (fp32: with RAMP_CORR_MFMA32 only): correlation target maps
+                          (ramp_pyramid_pack); 64 bytes per pixel and plane = one 16-byte load of every lane quarter */
 
 /* library / build identification: returns a static string */
 const char *ramp_version(void);
@@ -115,7 +116,9 @@ int ramp_corr_fwd_ordered(const void *fmap1, const ramp_corr_level *levels_host,
  * fmap, fmap2_[slot] = avg_pool2d(fmap, 4, 4)) for fp16 channels-last features:
  * fmap [H][W][C] -> level1 [H][C/32][W][32] (same values) and level4
  * [H/4][C/32][W/4][32] (4x4 mean, fp32 sum, one rounding).  These are the
- * RAMP_NHWC32 target maps of ramp_corr_fwd (fp16 only; fmap1 stays RAMP_NHWC).
+ * RAMP_NHWC32 target maps of ramp_corr_fwd (fmap1 stays RAMP_NHWC).  fp32 features
+ * (dtype RAMP_F32): planes of 16 channels, [H][8][W][16] and [H/4][8][W/4][16]; the
+ * mean is the window summed in (ky, kx) order times 1/16 = torch's avg_pool2d.
  * C == 128, W % 16 == 0, H % 4 == 0, else RAMP_EUNSUPPORTED.                 */
 int ramp_pyramid_pack(const void *fmap, void *level1, void *level4, int H, int W, int C, int dtype,
                       void *stream);
@@ -434,6 +437,12 @@ int ramp_conv2d_nhwc_multi(const ramp_conv_job *jobs, int njobs, int H, int W, i
  * MFMA"; weights packed as e4m3 fragments (rampvo_amd/conv_hip.py::pack_conv_weight mode "f8")                    */
 #define RAMP_CONV_FP8 0x40
 
+/* ramp_conv2d_nhwc only, as RAMP_F32 | RAMP_CONV_X3: fp32 in / out at fp32 accuracy on the f16 matrix cores (every operand split
+ * into two fp16 numbers, three MFMA products into one fp32 accumulator: csrc/conv.hip::conv_x3_kernel); weights packed by
+ * rampvo_amd/conv_hip.py::pack_conv_weight mode "x3"; layer shapes: 3x3 stride 1 (32|64 -> 32|64), 3x3 stride 2 (32 -> 64),
+ * 7x7 stride 2 (16 -> 32), else RAMP_EUNSUPPORTED (ramp_conv2d_stats_blocks says so first)                                   */
+#define RAMP_CONV_X3 0x80
+
 /* number of per-block partials ramp_conv2d_nhwc writes to `stats` for this layer shape / dtype   */
 int ramp_conv2d_stats_blocks(int H, int W, int Cin, int Cout, int KH, int stride, int dtype);
 
@@ -740,10 +749,11 @@ typedef struct ramp_track {
                                        * bound): picks the gru launch's tile (64 / 80 rows per workgroup)                    */
   uint32_t gate_seq;                  /* with gate_flag: the value the update operator's last launch (gru) stores into it  */
   int32_t feat_fp32;                  /* 0: fp16 features (imap / gmap / fmap rows of 2-byte elements, chunked [h][C/32][w][32] pyramid
-                                       * planes, corr [E_cap][896] fp16); 1: fp32 features, plain NHWC planes, corr [E_cap][882]
-                                       * fp32 (correlation by corr_kernel<float>, the reference kernel's summation order) --
-                                       * only with RAMP_TRACK_UPDATE_PRE / _POST                                          */
-  int32_t feat_plain;                 /* (fp16 features) 1: the pyramid planes are plain NHWC [h][w][128] fp16 rows instead of the
+                                       * planes, corr [E_cap][896] fp16); 1: fp32 features, planes chunked as [h][C/16][w][16]
+                                       * (feat_plain = 0) or plain NHWC, corr [E_cap][896] fp32 by corr_mfma_kernel<float>
+                                       * (RAMP_CORR_F32_MFMA=0: corr_kernel<float>, the reference kernel's summation order, plain
+                                       * planes only), operator csrc/update_x3.hip                                          */
+  int32_t feat_plain;                 /* 1: the pyramid planes are plain NHWC [h][w][128] rows instead of the
                                        * chunked [h][C/32][w][32] layout -- feature planes whose width is no multiple of 16 or
                                        * whose height is no multiple of 4 (ramp_pyramid_pack's shapes): corr_mfma_kernel<half, false>  */
   uint32_t *gate_flag;                /* optional signal word (ramp_signal_alloc): "the next frame's front end may start"  *

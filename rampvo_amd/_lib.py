@@ -19,8 +19,16 @@ RAMP_F32, RAMP_F16 = 0, 1
 RAMP_EUNSUPPORTED = -4
 RAMP_CONV_FP8 = 0x40
 RAMP_IN_F32, RAMP_CONV_DIRECT, RAMP_CORR_MFMA32 = 0x10, 0x20, 0x40
+RAMP_CONV_X3 = 0x80
 RAMP_NCHW, RAMP_NHWC, RAMP_NHWC32 = 0, 1, 2
 KPLANE = 32            # channels per plane of the packed correlation target maps: [h][128 / KPLANE][w][KPLANE]
+
+
+def kplane(dtype):
+    """channels per plane of the packed correlation target maps for a feature dtype: 64 bytes per pixel and plane
+    ([h][4][w][32] fp16, [h][8][w][16] fp32)"""
+    import torch
+    return KPLANE if dtype == torch.float16 else KPLANE // 2
 
 _ERR = {-1: "RAMP_EINVAL (bad argument)", -2: "RAMP_ELAUNCH (HIP launch/runtime error)",
         -3: "RAMP_EWORKSPACE (workspace too small)", -4: "RAMP_EUNSUPPORTED (size/shape not supported)"}

@@ -41,8 +41,8 @@ def pack_conv_weight(conv, mode="f32"):
     hit = _cache(conv).get(mode)
     if hit is not None and hit[0] == key:
         return hit[1:] if mode == "f8" else (hit[1], hit[2])
-    kc, cpl = (32, 8) if mode in ("f16", "f8") else (16, 4)
     cout, cin, kh, kw = w.shape
+    kc, cpl = (32, 8) if (mode in ("f16", "f8") or (mode == "x3" and cin >= 32)) else (16, 4)
     cin_p = (cin + kc - 1) // kc * kc
     wp = torch.zeros(cout, cin_p, kh, kw, dtype=torch.float32, device=w.device)
     wp[:, :cin] = w.detach().float()
@@ -54,6 +54,23 @@ def pack_conv_weight(conv, mode="f32"):
         t = (t * w_scale).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
         _cache(conv)[mode] = (key, t, bias, w_scale)
         return t, bias, w_scale
+    if mode == "x3":
+        # exact-class products on the f16 matrix cores (csrc/conv.hip::conv_x3_kernel): fragments of the THREE fp16 parts of
+        # W 2^s -- w0 = fp16(W 2^s), w1 = fp16((W 2^s - w0) 2^11), w2 = fp16((W 2^s - w0 - w1 2^-11) 2^22), s the power of two
+        # that puts max |W| 2^s into [2^12, 2^13) -- followed by the exact inverse 2^-s as one float
+        import math
+        amax = float(w.detach().abs().max())
+        e = (12 - math.floor(math.log2(amax))) if amax > 0 else 0
+        ws = t.double() * (2.0 ** e)
+        w0 = ws.half()
+        r1 = ws - w0.double()
+        w1 = (r1 * 2048.0).half()
+        r2 = r1 - w1.double() / 2048.0
+        w2 = (r2 * 4194304.0).half()
+        tail = torch.tensor([2.0 ** -e], dtype=torch.float32, device=w.device).view(torch.float16)
+        t = torch.cat([w0.flatten(), w1.flatten(), w2.flatten(), tail]).contiguous()
+        _cache(conv)[mode] = (key, t, bias)
+        return t, bias
     if mode != "f32":
         t = t.half()
     _cache(conv)[mode] = (key, t, bias)
@@ -236,6 +253,9 @@ class Pair:
 # post-InstanceNorm / ReLU activations and the random-init plain tower stay well inside; e4m3's relative precision,
 # 2^-4, does not depend on the scale)
 FP8_ACT_SCALE = 8.0
+# fp32 towers: 3x3 / 7x7 layers at fp32 accuracy on the f16 matrix cores (conv_x3_kernel) instead of the f32 MFMA's direct
+# kernel; False: the exact-product f32 MFMA everywhere (tests compare the two)
+X3 = os.environ.get("RAMP_CONV_X3", "1") != "0"      # env: 0 = the fp32 towers on the f32 MFMA (exact products)
 
 
 def _conv_mode(x, half, direct=False):
@@ -262,11 +282,15 @@ def conv2d(x, conv, pre=None, res=None, relu=False, want_stats=False, out_scale=
         pre, x = (x.scale, x.shift), x.raw
     H, W, Cin = x.shape
     mode, code, odt = _conv_mode(x, half, direct)
-    wpk, bias = pack_conv_weight(conv, mode)
     cout, _, kh, kw = conv.weight.shape
     stride = conv.stride[0]
+    if mode == "f32" and X3 and kh == kw and lib().ramp_conv2d_stats_blocks(H, W, Cin, cout, kh, stride,
+                                                                           RAMP_F32 | _lib.RAMP_CONV_X3) > 0:
+        mode, code = "x3", RAMP_F32 | _lib.RAMP_CONV_X3      # the layer shapes conv_x3_kernel covers (the towers' 3x3 / 7x7 layers)
+    wpk, bias = pack_conv_weight(conv, mode)
     kc = 32 if mode == "f16" else 16
-    assert Cin == wpk.shape[1] * kc and conv.padding[0] == kh // 2 and x.is_contiguous()
+    assert (mode == "x3" and Cin == (conv.weight.shape[1] + 15) // 16 * 16) or (mode != "x3" and Cin == wpk.shape[1] * kc)
+    assert conv.padding[0] == kh // 2 and x.is_contiguous()
     assert res is None or (res.is_contiguous() and res.dtype == odt)
     OH = (H + 2 * (kh // 2) - kh) // stride + 1
     OW = (W + 2 * (kw // 2) - kw) // stride + 1

@@ -662,10 +662,12 @@ static __device__ __forceinline__ void corr_edge_rows(const CorrParams &prm, con
           // load s, quarter q <-> channels [4 PER s + PER q, + PER) (fp16: = chunk 4 s + q of the [h][C/8][w][8] layout)
 #if CORR_KPLANE == 32
           // [h][4][w][32]: K step s of a window row is one run of 64 bytes per pixel (18.8 vs 15.7 TB/s from the vector
-          // L1 for the 10-wide windows, tools/mb/gather_patterns.hip P5 / P2)
-          const T *pp = CHUNKED ? f2 + (((size_t)cy * 4) * W2 + cx) * 32 + 8 * q
+          // L1 for the 10-wide windows, tools/mb/gather_patterns.hip P5 / P2).  fp32 features: [h][8][w][16] -- the same 64
+          // bytes per pixel and load (load s of quarter q <-> channels 16 s + 4 q .. + 3), eight planes
+          constexpr int KP = 4 * PER;                       // channels per plane: 32 (fp16), 16 (fp32)
+          const T *pp = CHUNKED ? f2 + (((size_t)cy * (C / KP)) * W2 + cx) * KP + PER * q
                                 : f2 + ((size_t)cy * W2 + cx) * C + PER * q;
-          const size_t sstride = CHUNKED ? (size_t)W2 * 32 : 4 * PER;
+          const size_t sstride = CHUNKED ? (size_t)W2 * KP : 4 * PER;
 #else
           const T *pp = CHUNKED ? f2 + (((size_t)cy * (C / 8) + q) * W2 + cx) * 8
                                 : f2 + ((size_t)cy * W2 + cx) * C + PER * q;
@@ -845,6 +847,43 @@ __global__ void __launch_bounds__(256) pyramid_pack_kernel(const uint4 *__restri
   }
 }
 
+// fp32 features: NHWC [H][W][128] -> level 1 as [H][8][W][16] (one plane per 16-byte-per-lane load of corr_mfma_kernel<float>:
+// a load's 64 lanes read 16 neighbouring window pixels x 64 bytes = one or two contiguous runs instead of 16 pieces 512 bytes
+// apart -- with plain NHWC the window loads were 61 % of that kernel's cycles, tools/corr_trace.py) and level 4 = the 4x4
+// mean as [H/4][8][W/4][16]: the window summed in (ky, kx) order, then x 1/16 -- torch's avg_pool2d to the bit
+// (Ramp_vo.py:378-381).  Thread = one float4 of the output.
+__global__ void __launch_bounds__(256) pyramid_pack_f32_kernel(const float4 *__restrict__ in, float4 *__restrict__ out1,
+                                                               float4 *__restrict__ out4, int H, int W) {
+  const long n1 = (long)H * W * 32, n4 = (long)(H / 4) * (W / 4) * 32;
+  const long o = (long)blockIdx.x * 256 + threadIdx.x;
+  if (o < n1) {
+    // out1 index: ((y * 8 + g) * W + x) * 4 + qq
+    const int qq = (int)(o & 3);
+    const long r = o >> 2;
+    const int x = (int)(r % W);
+    const long r2 = r / W;
+    const int g = (int)(r2 & 7);
+    const long y = r2 >> 3;
+    out1[o] = in[(y * W + x) * 32 + g * 4 + qq];
+  } else if (o < n1 + n4) {
+    const long o4 = o - n1;
+    const int W4 = W / 4;
+    const int qq = (int)(o4 & 3);
+    const long r = o4 >> 2;
+    const int X = (int)(r % W4);
+    const long r2 = r / W4;
+    const int g = (int)(r2 & 7);
+    const long Y = r2 >> 3;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int ky = 0; ky < 4; ky++)
+      for (int kx = 0; kx < 4; kx++) {
+        const float4 v = in[((Y * 4 + ky) * W + X * 4 + kx) * 32 + g * 4 + qq];
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+      }
+    out4[o4] = make_float4(a.x * 0.0625f, a.y * 0.0625f, a.z * 0.0625f, a.w * 0.0625f);
+  }
+}
+
 extern "C" {
 
 #ifdef CORR_TRACE
@@ -857,9 +896,15 @@ int ramp_corr_kplane(void) { return CORR_KPLANE; }
 int ramp_pyramid_pack(const void *fmap, void *level1, void *level4, int H, int W, int C, int dtype,
                       void *stream) {
   if (!fmap || !level1 || !level4 || H <= 0 || W <= 0) return RAMP_EINVAL;
-  if (C != 128 || dtype != RAMP_F16 || (W % 16) || (H % 4)) return RAMP_EUNSUPPORTED;
-  hipLaunchKernelGGL(pyramid_pack_kernel, dim3(W / 16, H / 4), dim3(256), 0, (hipStream_t)stream,
-                     (const uint4 *)fmap, (uint4 *)level1, (uint4 *)level4, H, W);
+  if (C != 128 || (dtype != RAMP_F16 && dtype != RAMP_F32) || (W % 16) || (H % 4)) return RAMP_EUNSUPPORTED;
+  if (dtype == RAMP_F32) {
+    const long n = (long)H * W * 32 + (long)(H / 4) * (W / 4) * 32;
+    hipLaunchKernelGGL(pyramid_pack_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4 *)fmap, (float4 *)level1, (float4 *)level4, H, W);
+  } else {
+    hipLaunchKernelGGL(pyramid_pack_kernel, dim3(W / 16, H / 4), dim3(256), 0, (hipStream_t)stream,
+                       (const uint4 *)fmap, (uint4 *)level1, (uint4 *)level4, H, W);
+  }
   RAMP_CHECK_LAUNCH();
   return RAMP_OK;
 }
@@ -953,6 +998,8 @@ int ramp_i_corr_fwd(const void *fmap1, const ramp_corr_level *levels, int nlevel
   dtype &= ~RAMP_CORR_MFMA32;
   if (dtype == RAMP_F32 && layout == RAMP_NHWC && fast32)
     hipLaunchKernelGGL((corr_mfma_kernel<float, false>), grid, dim3(64), 0, st, prm);
+  else if (dtype == RAMP_F32 && layout == RAMP_NHWC32 && fast32)        // target maps as [h][8][w][16] (ramp_pyramid_pack, fp32)
+    hipLaunchKernelGGL((corr_mfma_kernel<float, true>), grid, dim3(64), 0, st, prm);
   else if (dtype == RAMP_F32 && layout == RAMP_NHWC)
     hipLaunchKernelGGL((corr_kernel<float, RAMP_NHWC>), grid, dim3(64), 0, st, prm);
   else if (dtype == RAMP_F32 && layout == RAMP_NCHW)

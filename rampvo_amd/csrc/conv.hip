@@ -728,6 +728,181 @@ __global__ void __launch_bounds__(256) conv_tile_f16_kernel(const ConvMulti pm) 
 #endif
 }
 
+// fp32 towers on the f16 matrix cores with EXACT-class products (round 6): the fp32 towers ran on v_mfma_f32_16x16x4_f32 through
+// the direct kernel at the top of this file -- one global round trip per tap, 40 us per 3x3 layer -- and the front end's 1.0 ms
+// next to a 1.7 ms step cost the step 25 % by contention.  Here every fp32 operand is split into THREE fp16 numbers,
+//     x = x0 + x1 2^-11 + x2 2^-22,   x0 = fp16(x),  x1 = fp16((x - x0) 2^11),  x2 = fp16((x - x0 - x1 2^-11) 2^22)
+// (33 significant bits; every part has the magnitude of x, so no subnormal operand arises from the split), and a product is
+// the six MFMA products of order <= 2 into three fp32 accumulators, one per order:
+//     acc0 += x0 w0;   acc1 += x0 w1 + x1 w0;   acc2 += x0 w2 + x1 w1 + x2 w0;   result = acc0 + 2^-11 acc1 + 2^-22 acc2
+// (dropped: order 3 and above, 2^-33).  The two-part split of csrc/update_x3.hip (22-bit operands, three products) measures
+// the same against fp64 but is NOT the reference's arithmetic closely enough here: its free-running trajectory sits 7e-6
+// instead of 7e-7 from the reference's own run and two of 2,880 depths leave the 1e-4 bound (tools/traj_fp32_conv_cmp.py) --
+// the reference multiplies exactly and rounds only sums, and so does this kernel.
+// A workgroup owns an 8 x 16 output tile of ALL output channels:
+//   * the fp32 halo tile is loaded once, relu(x scale + shift) applied once per value, the three parts parked in LDS as three
+//     planes (pixel stride CIN 2 + 16 bytes: conflict-free ds_read_b128 A fragments);
+//   * weights are packed per layer as fp16 fragments of the three parts of W 2^s (s: max |W| 2^s in [2^12, 2^13)), plus the
+//     exact inverse 2^-s behind the pack (rampvo_amd/conv_hip.py::pack_conv_weight mode "x3");
+//   * a wave owns one 16-channel tile of the output and 8 (COUT = 64) or 4 (COUT = 32) of the tile's rows, so every weight
+//     fragment is fetched from L2 once per workgroup and the A fragments come from LDS;
+//   * bias, InstanceNorm partial sums (sum, sum of squares of the raw output over the tile's valid pixels -> stats[C][2][nblk],
+//     the direct kernel's contract), ReLU, residual + ReLU, out_scale on the accumulators.
+template <int K, int S, int CIN, int COUT>
+__global__ void __launch_bounds__(256) conv_x3_kernel(const ConvParams p) {
+  constexpr int PAD = K / 2, TH = 8, TW = 16;
+  constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
+  constexpr int KC = CIN >= 32 ? 32 : 16, NCH = CIN / KC, CPL = KC / 4;   // channels per MFMA step, steps per tap, halfs per lane
+  constexpr int PSTR = CIN * 2 + 16;                                    // LDS bytes per tile pixel and plane
+  constexpr int PLANE = IH * IW * PSTR;
+  constexpr int NT = COUT / 16, WPN = 4 / NT, MTW = TH / WPN;           // waves per channel tile, rows (m-tiles) per wave
+  constexpr int CH4 = CIN / 4, NITEM = IH * IW * CH4;
+  static_assert(NT == 2 || NT == 4, "32 or 64 output channels");
+  static_assert(256 % CH4 == 0, "a thread keeps one channel slot");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ float s_stat[4][16][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, j = lane & 15;
+  const int tiles_x = (p.OW + TW - 1) / TW;
+  const int ty0 = blockIdx.x / tiles_x, tx0 = blockIdx.x - ty0 * tiles_x;
+  const int oy0 = ty0 * TH, ox0 = tx0 * TW;
+  const int nt = wave % NT, rg = wave / NT;
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+  // ---- 1. the halo tile: fp32 -> three fp16 planes in LDS, in batches of 8 sixteen-byte loads per thread
+  const float *x = reinterpret_cast<const float *>(p.x);
+  const int cslot = tid % CH4;
+  float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool pre = p.pre_scale != nullptr;
+  if (pre) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) { sc[c] = p.pre_scale[cslot * 4 + c]; sh[c] = p.pre_shift[cslot * 4 + c]; }
+  }
+  constexpr int BATCH = 8;
+  for (int n0 = 0; n0 < NITEM; n0 += 256 * BATCH) {
+    f32x4 v[BATCH];
+    bool ok[BATCH];
+#pragma unroll
+    for (int b = 0; b < BATCH; b++) {
+      const int i = n0 + b * 256 + tid;
+      const int pix = i / CH4, ty = pix / IW, tx = pix - ty * IW;
+      const int gy = oy0 * S + ty - PAD, gx = ox0 * S + tx - PAD;
+      ok[b] = i < NITEM && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+      v[b] = *reinterpret_cast<const f32x4 *>(x + ((size_t)(ok[b] ? gy : 0) * p.W + (ok[b] ? gx : 0)) * CIN + cslot * 4);
+    }
+#pragma unroll
+    for (int b = 0; b < BATCH; b++) {
+      const int i = n0 + b * 256 + tid;
+      if (i >= NITEM) continue;
+      const int pix = i / CH4;
+      h4 h0, h1, h2;
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        float t = pre ? fmaxf(v[b][c] * sc[c] + sh[c], 0.f) : v[b][c];
+        t = ok[b] ? t : 0.f;
+        _Float16 a0 = (_Float16)t;
+        if (fabsf(t) < 6.103515625e-05f) a0 = (_Float16)0.f;            // (no subnormal operand is relied on)
+        const float r1 = t - (float)a0;                                  // exact
+        const _Float16 a1 = (_Float16)(r1 * 2048.0f);
+        const float r2 = r1 - (float)a1 * 0.00048828125f;                // exact
+        h0[c] = a0; h1[c] = a1; h2[c] = (_Float16)(r2 * 4194304.0f);
+      }
+      *reinterpret_cast<h4 *>(smem + pix * PSTR + cslot * 8) = h0;
+      *reinterpret_cast<h4 *>(smem + PLANE + pix * PSTR + cslot * 8) = h1;
+      *reinterpret_cast<h4 *>(smem + 2 * PLANE + pix * PSTR + cslot * 8) = h2;
+    }
+  }
+  __syncthreads();
+
+  // ---- 2. six MFMAs per product from LDS (A) and L2 (this wave's weight fragments)
+  f32x4 acc0[MTW], acc1[MTW], acc2[MTW];
+#pragma unroll
+  for (int a = 0; a < MTW; a++) { acc0[a] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[a] = acc0[a]; acc2[a] = acc0[a]; }
+  const _Float16 *wph = reinterpret_cast<const _Float16 *>(p.wpk);
+  constexpr size_t WTOT = (size_t)K * K * NCH * NT * 64 * CPL;         // halfs per plane of the pack
+  const float descale = *reinterpret_cast<const float *>(wph + 3 * WTOT);
+  const int a_off = ((rg * MTW) * S * IW + j * S) * PSTR + q * CPL * 2;
+  // (one flat loop over (tap, chunk), two steps per trip: fully unrolled the compiler hoists every weight load of the layer --
+  // 256 VGPRs, one wave per SIMD)
+  const int nsteps = K * K * NCH + (p.Cin - CIN);      // (= K K NCH; not a compile-time constant: no full unrolling)
+#pragma unroll 2
+  for (int step = 0; step < nsteps; step++) {
+    const int tap = step / NCH, ch = step - tap * NCH;
+    const int ky = tap / K, kx = tap - ky * K;
+    const size_t wo = (((size_t)step * NT + nt) * 64 + lane) * CPL;
+    const int o0 = a_off + (ky * IW + kx) * PSTR + ch * KC * 2;
+    if constexpr (KC == 32) {
+      const f16x8 w0 = *reinterpret_cast<const f16x8 *>(wph + wo), w1 = *reinterpret_cast<const f16x8 *>(wph + WTOT + wo),
+                  w2 = *reinterpret_cast<const f16x8 *>(wph + 2 * WTOT + wo);
+#pragma unroll
+      for (int mt = 0; mt < MTW; mt++) {
+        const int o = o0 + mt * S * IW * PSTR;
+        const f16x8 a0 = *reinterpret_cast<const f16x8 *>(smem + o), a1 = *reinterpret_cast<const f16x8 *>(smem + PLANE + o),
+                    a2 = *reinterpret_cast<const f16x8 *>(smem + 2 * PLANE + o);
+        acc0[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, w0, acc0[mt], 0, 0, 0);
+        acc1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, w1, acc1[mt], 0, 0, 0);
+        acc1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, w0, acc1[mt], 0, 0, 0);
+        acc2[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, w2, acc2[mt], 0, 0, 0);
+        acc2[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, w1, acc2[mt], 0, 0, 0);
+        acc2[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, w0, acc2[mt], 0, 0, 0);
+      }
+    } else {
+      const f16x4 w0 = *reinterpret_cast<const f16x4 *>(wph + wo), w1 = *reinterpret_cast<const f16x4 *>(wph + WTOT + wo),
+                  w2 = *reinterpret_cast<const f16x4 *>(wph + 2 * WTOT + wo);
+#pragma unroll
+      for (int mt = 0; mt < MTW; mt++) {
+        const int o = o0 + mt * S * IW * PSTR;
+        const f16x4 a0 = *reinterpret_cast<const f16x4 *>(smem + o), a1 = *reinterpret_cast<const f16x4 *>(smem + PLANE + o),
+                    a2 = *reinterpret_cast<const f16x4 *>(smem + 2 * PLANE + o);
+        acc0[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a0, w0, acc0[mt], 0, 0, 0);
+        acc1[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a0, w1, acc1[mt], 0, 0, 0);
+        acc1[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a1, w0, acc1[mt], 0, 0, 0);
+        acc2[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a0, w2, acc2[mt], 0, 0, 0);
+        acc2[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a1, w1, acc2[mt], 0, 0, 0);
+        acc2[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a2, w0, acc2[mt], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- 3. epilogue on the accumulators: lane (q, j) holds pixels x = 4q .. 4q+3 of row rg MTW + mt, channel 16 nt + j
+  const int c = nt * 16 + j;
+  const float bv = p.bias ? p.bias[c] : 0.0f;
+  float *y = reinterpret_cast<float *>(p.y);
+  const float *res = reinterpret_cast<const float *>(p.res);
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int mt = 0; mt < MTW; mt++) {
+    const int oy = oy0 + rg * MTW + mt;
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) {
+      const int ox = ox0 + 4 * q + rr;
+      if (oy < p.OH && ox < p.OW) {
+        const float lo = acc1[mt][rr] + acc2[mt][rr] * 0.00048828125f;                  // (small terms first)
+        float v = (acc0[mt][rr] + lo * 0.00048828125f) * descale + bv;
+        s1 += v;
+        s2 += v * v;
+        if (p.relu) v = fmaxf(v, 0.f);
+        const size_t go = ((size_t)oy * p.OW + ox) * COUT + c;
+        if (res) v = fmaxf(v + res[go], 0.f);
+        y[go] = v * p.out_scale;
+      }
+    }
+  }
+  if (p.stats) {
+    s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+    if (q == 0) { s_stat[wave][j][0] = s1; s_stat[wave][j][1] = s2; }
+    __syncthreads();
+    if (tid < COUT * 2) {
+      const int cc = tid >> 1, k = tid & 1, t = cc >> 4, jj = cc & 15;
+      float v = s_stat[t][jj][k];                         // the waves of channel tile t: t, t + NT, ... in this order
+#pragma unroll
+      for (int w = 1; w < WPN; w++) v += s_stat[t + w * NT][jj][k];
+      p.stats[((size_t)cc * 2 + k) * gridDim.x + blockIdx.x] = v;   // [C][2][nblk]
+    }
+  }
+}
+constexpr int conv_x3_lds_bytes(int K, int S, int CIN) { return 3 * ((8 - 1) * S + K) * ((16 - 1) * S + K) * (CIN * 2 + 16); }
+
 // First layer of BOTH towers in one workgroup (7x7 stride 2, 16 fp32 input channels -> 32 channels per tower): the two
 // towers read the same super-state, so the halo tile is staged once and feeds four 16-channel output tiles.  Unlike
 // the generic tiled kernel the weight fragments are not parked in LDS (49 taps x 4 tiles = 100 KB) but streamed from
@@ -1754,7 +1929,8 @@ int ramp_conv2d_nhwc(const void *x, const void *wpk, const float *bias, const fl
   // dtype: RAMP_F32 = fp32 in/out (exact fp32 MFMA); RAMP_F16 = half in/out;
   //        RAMP_F16 | 0x10 = fp32 in, half out (first layer of the mixed-precision tower)
   const bool f16 = (dtype & 0xf) == RAMP_F16, in_f32 = f16 && (dtype & 0x10);
-  if (!f16 && dtype != RAMP_F32) return RAMP_EINVAL;
+  const bool x3 = dtype == (RAMP_F32 | RAMP_CONV_X3);
+  if (!f16 && dtype != RAMP_F32 && !x3) return RAMP_EINVAL;
   if (f16 && !in_f32 && Cin % 32) return RAMP_EUNSUPPORTED;
   if (in_f32 && Cin != 16) return RAMP_EUNSUPPORTED;
   ConvParams p;
@@ -1771,6 +1947,26 @@ int ramp_conv2d_nhwc(const void *x, const void *wpk, const float *bias, const fl
   const int M = p.OH * p.OW;
   dim3 grid(ramp_cdiv(M, 128), Cout / 32), block(256);
   hipStream_t st = (hipStream_t)stream;
+  if (x3) {
+    // fp32 in / out at fp32 accuracy on the f16 matrix cores (conv_x3_kernel; wpk = pack_conv_weight mode "x3")
+    const dim3 tg(ramp_cdiv(p.OH, 8) * ramp_cdiv(p.OW, 16), 1);
+#define X3_CASE(K, S, CIN, COUT)                                                                      \
+  if (KH == K && stride == S && Cin == CIN && Cout == COUT) {                                         \
+    constexpr int lds_ = conv_x3_lds_bytes(K, S, CIN);                                                \
+    if (conv_tile_attr(conv_x3_kernel<K, S, CIN, COUT>, lds_) != RAMP_OK) return RAMP_ELAUNCH;        \
+    hipLaunchKernelGGL((conv_x3_kernel<K, S, CIN, COUT>), tg, block, lds_, st, p);                    \
+    RAMP_CHECK_LAUNCH();                                                                              \
+    return RAMP_OK;                                                                                   \
+  }
+    X3_CASE(3, 1, 32, 32)
+    X3_CASE(3, 1, 64, 64)
+    X3_CASE(3, 1, 32, 64)
+    X3_CASE(3, 2, 32, 64)
+    X3_CASE(3, 1, 64, 32)
+    X3_CASE(7, 2, 16, 32)
+#undef X3_CASE
+    return RAMP_EUNSUPPORTED;
+  }
   // fp16: LDS-tiled kernel for the layer shapes of the towers (RAMP_CONV_DIRECT forces the direct one)
   if (f16 && !(dtype & RAMP_CONV_DIRECT)) {
     const dim3 tg(ramp_cdiv(p.OH, 8) * ramp_cdiv(p.OW, 16), 1);
@@ -1948,6 +2144,11 @@ int ramp_conv2d_stats_blocks(int H, int W, int Cin, int Cout, int KH, int stride
   const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KH) / stride + 1;
   if (OH <= 0 || OW <= 0) return RAMP_EINVAL;
   const bool f16 = (dtype & 0xf) == RAMP_F16, in_f32 = f16 && (dtype & RAMP_IN_F32);
+  if (dtype == (RAMP_F32 | RAMP_CONV_X3)) {
+    const bool ok = (KH == 3 && stride == 1 && ((Cin == 32 && (Cout == 32 || Cout == 64)) || (Cin == 64 && (Cout == 64 || Cout == 32)))) ||
+                    (KH == 3 && stride == 2 && Cin == 32 && Cout == 64) || (KH == 7 && stride == 2 && Cin == 16 && Cout == 32);
+    return ok ? ramp_cdiv(OH, 8) * ramp_cdiv(OW, 16) : RAMP_EUNSUPPORTED;
+  }
   bool tiled = false;
   if (f16 && !(dtype & RAMP_CONV_DIRECT)) {
     tiled = (KH == 7 && stride == 2 && in_f32 && Cin == 16 && Cout % 32 == 0) ||

@@ -563,7 +563,7 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
     TRK_PROBE(0);
     if (t->feat_fp32)
       TRK_DO(ramp_i_corr_fwd(t->gmap, lv, 2, t->coords, kk, jj, t->ij_order, t->corr, 896, (long)t->M * t->mem, t->mem, Eb,
-                             t->mem * t->M, t->mem, 128, t->P, 3, f32_code, RAMP_NHWC, dyn, st, nullptr, nullptr, nullptr, nullptr,
+                             t->mem * t->M, t->mem, 128, t->P, 3, f32_code, t->feat_plain ? RAMP_NHWC : RAMP_NHWC32, dyn, st, nullptr, nullptr, nullptr, nullptr,
                              t->fmap1_slot));
     else
       TRK_DO(ramp_i_corr_fwd(t->gmap, lv, 2, t->coords, kk, jj, t->ij_order, t->corr, 896, (long)t->M * t->mem, t->mem, Eb,
@@ -622,7 +622,7 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
   } while (0)
       TRK_GATE32(5);
       TRK_DO(ramp_i_corr_fwd(t->gmap, lv, 2, t->coords, kk, jj, t->ij_order, t->corr, 896, (long)t->M * t->mem, t->mem, Eb,
-                             t->mem * t->M, t->mem, 128, t->P, 3, f32_code, RAMP_NHWC, dyn, st, nullptr, nullptr, nullptr,
+                             t->mem * t->M, t->mem, 128, t->P, 3, f32_code, t->feat_plain ? RAMP_NHWC : RAMP_NHWC32, dyn, st, nullptr, nullptr, nullptr,
                              nullptr, t->fmap1_slot));
       TRK_PROBE(1);
       TRK_GATE32(4);

@@ -141,6 +141,9 @@ class Patchifier(nn.Module):
         self.use_graph = os.environ.get("RAMP_NO_GRAPH", "0") != "1"
         self._graphs = {}
         self._graph_warm = 0
+        # fp32 features: the tracker's pyramid planes chunked as [h][8][w][16] for corr_mfma_kernel<float> (off with
+        # RAMP_CORR_F32_MFMA=0: corr_kernel<float>, the reference kernel's summation order, reads plain NHWC planes)
+        self.pack_f32 = os.environ.get("RAMP_CORR_F32_MFMA", "1") != "0"
         self._plist = None
         self._extra = None
         self._index = None
@@ -293,7 +296,8 @@ class Patchifier(nn.Module):
             clr = cl.view(b, -1, 3)
             if self._index is None or self._index.shape[0] != patches_per_image or self._index.device != fmap.device:
                 self._index = torch.zeros(patches_per_image, dtype=torch.long, device=fmap.device)
-            chunked = (fmap.dtype == torch.float16 and ops.pyramid_pack_supported(h, w))
+            chunked = ((fmap.dtype == torch.float16 or (fmap.dtype == torch.float32 and self.pack_f32))
+                       and ops.pyramid_pack_supported(h, w))
             if chunked:
                 f1, f2 = ops.pyramid_pack(f_nhwc[0])
             else:
@@ -318,8 +322,8 @@ class Patchifier(nn.Module):
             # extras for the tracker's one-launch state store (channels-last sources, the 1/4 pyramid
             # level and the uint8 BGR colours of Ramp_vo.py:353-354, 381), produced inside the graph
             col = ((clr[0].flip(-1) + 0.5) * (255.0 / 2)).to(torch.uint8)       # BGR, no host index tensor
-            chunked = (fmap.dtype == torch.float16 and ops.pyramid_pack_supported(h, w)
-                       and f_nhwc[0].is_contiguous())
+            chunked = ((fmap.dtype == torch.float16 or (fmap.dtype == torch.float32 and self.pack_f32))
+                       and ops.pyramid_pack_supported(h, w) and f_nhwc[0].is_contiguous())
             if chunked:
                 # both correlation levels in the MFMA kernel's [h][C/32][w][32] target layout
                 f1, f2 = ops.pyramid_pack(f_nhwc[0])

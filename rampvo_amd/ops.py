@@ -12,7 +12,7 @@ import torch
 from . import _lib
 from ._lib import RAMP_CORR_MFMA32 as _LIB_CORR_MFMA32
 from ._lib import workspace as _lib_workspace
-from ._lib import KPLANE, RAMP_NHWC32, RAMP_NCHW, RAMP_NHWC, CorrLevel, check, dtype_code, lib, ptr, require_cuda, stream
+from ._lib import KPLANE, RAMP_NHWC32, RAMP_NCHW, RAMP_NHWC, CorrLevel, check, dtype_code, kplane, lib, ptr, require_cuda, stream
 
 
 # ------------------------------------------------------------------- altcorr
@@ -77,9 +77,10 @@ def corr(fmap1, fmaps2, coords, ii, jj, radius=3, coord_divs=(1.0,), layout=RAMP
         N1, C, P, _ = fmap1.shape
     else:
         N1, P, _, C = fmap1.shape
-    if layout == RAMP_NHWC32:     # fp16 target maps [N2][H][C/32][W][32] (pyramid_pack); fmap1 stays NHWC
-        assert fmap1.dtype == torch.float16 and all(f.dim() == 5 and f.shape[2] * KPLANE == C and f.shape[4] == KPLANE
-                                                    for f in fmaps2)
+    if layout == RAMP_NHWC32:     # target maps [N2][H][C/32][W][32] (fp16) / [N2][H][C/16][W][16] (fp32) (pyramid_pack); fmap1 stays NHWC
+        kp = kplane(fmap1.dtype)
+        assert fmap1.dtype in (torch.float16, torch.float32) and all(f.dim() == 5 and f.shape[2] * kp == C and f.shape[4] == kp
+                                                                     for f in fmaps2)
     E = coords.shape[0]
     L = len(fmaps2)
     levels = (CorrLevel * L)()
@@ -102,8 +103,10 @@ def corr(fmap1, fmaps2, coords, ii, jj, radius=3, coord_divs=(1.0,), layout=RAMP
     code = dtype_code(fmap1)
     if fast_f32 is None:
         fast_f32 = os.environ.get("RAMP_CORR_F32_MFMA", "0") == "1"
-    if fast_f32 and fmap1.dtype == torch.float32 and layout == RAMP_NHWC:
+    if fast_f32 and fmap1.dtype == torch.float32 and layout in (RAMP_NHWC, RAMP_NHWC32):
         code |= _LIB_CORR_MFMA32         # opt-in: MFMA accumulation order instead of the reference's fmaf chain
+    assert not (fmap1.dtype == torch.float32 and layout == RAMP_NHWC32 and not fast_f32), \
+        "chunked fp32 target maps are read by corr_mfma_kernel<float> only (fast_f32)"
     check(lib().ramp_corr_fwd_ordered(ptr(fmap1), levels, L, ptr(coords), ptr(ii), ptr(jj),
                                       ptr(order) if order is not None else None, ptr(out), int(row_elems), int(mod_ii),
                                       int(mod_jj), E,
@@ -168,15 +171,17 @@ def event_topk_supported(events, k, nms_kernel_size):
 
 
 def pyramid_pack(fmap, out1=None, out4=None):
-    """fp16 NHWC map [H,W,128] -> (level1 [H,4,W,32], level4 [H/4,4,W/4,32]) in the correlation
-    kernel's packed target layout (RAMP_NHWC32: one plane per MFMA K step); level4 is the 4x4 mean (Ramp_vo.py:378-381)"""
+    """NHWC map [H,W,128] -> (level1 [H,4,W,32], level4 [H/4,4,W/4,32]) (fp16) or ([H,8,W,16], [H/4,8,W/4,16]) (fp32) in the
+    correlation kernel's packed target layout (RAMP_NHWC32: 64 bytes per pixel and plane); level4 is the 4x4 mean
+    (Ramp_vo.py:378-381; fp32: torch's avg_pool2d to the bit)"""
     require_cuda(fmap)
     H, W, C = fmap.shape
-    assert fmap.dtype == torch.float16 and fmap.is_contiguous()
+    assert fmap.dtype in (torch.float16, torch.float32) and fmap.is_contiguous()
+    kp = kplane(fmap.dtype)
     if out1 is None:
-        out1 = torch.empty((H, C // KPLANE, W, KPLANE), dtype=fmap.dtype, device=fmap.device)
+        out1 = torch.empty((H, C // kp, W, kp), dtype=fmap.dtype, device=fmap.device)
     if out4 is None:
-        out4 = torch.empty((H // 4, C // KPLANE, W // 4, KPLANE), dtype=fmap.dtype, device=fmap.device)
+        out4 = torch.empty((H // 4, C // kp, W // 4, kp), dtype=fmap.dtype, device=fmap.device)
     check(lib().ramp_pyramid_pack(ptr(fmap), ptr(out1), ptr(out4), H, W, C, dtype_code(fmap), stream()),
           "ramp_pyramid_pack")
     return out1, out4

@@ -92,10 +92,8 @@ def supported(slam):
     csrc/update_x3.hip's fused chains), P = 3, DIM = 384, any PATCHES_PER_FRAME up to 303, DAMPED_LINEAR motion model, an
     optimisation window of at most 32 poses"""
     cfg = slam.cfg
-    # (fp16 features: the chunked pyramid layout, or plain NHWC planes where the feature plane's shape does not fit it; fp32
-    # features: plain NHWC planes)
-    layout_ok = slam.dtype == torch.half or (slam.dtype == torch.float and not slam._chunked)
-    return (layout_ok and slam._lazy_net and slam.P == 3 and slam.DIM == 384
+    # (the chunked pyramid layout, or plain NHWC planes where the feature plane's shape does not fit it)
+    return (slam.dtype in (torch.half, torch.float) and slam._lazy_net and slam.P == 3 and slam.DIM == 384
             and 3 * slam.M * 9 <= 8192 and cfg.MOTION_MODEL in ("DAMPED_LINEAR",)
             and cfg.PATCH_LIFETIME <= cfg.REMOVAL_WINDOW + 1 and cfg.KEYFRAME_INDEX >= 2
             and 6 * cfg.OPTIMIZATION_WINDOW <= 192)
@@ -172,7 +170,7 @@ class DeviceTrack:
         self._keep = []
         t = self.t = Track()
         assert ctypes.sizeof(Track) == lib.ramp_track_sizeof(), "ramp_track mirror out of date"
-        # ring slots: [mem, h, 4, w, 32] (fp16, chunked) or [mem, h, w, 128] (fp32)
+        # ring slots: [mem, h, 4, w, 32] (fp16) / [mem, h, 8, w, 16] (fp32) chunked, or [mem, h, w, 128]
         h, w = slam.fmap1_.shape[1], (slam.fmap1_.shape[3] if slam._chunked else slam.fmap1_.shape[2])
         for name, val in dict(M=M, P=slam.P, mem=slam.mem, n_rows=slam.N, patch_lifetime=r, removal_window=R,
                               opt_window=cfg.OPTIMIZATION_WINDOW, keyframe_index=cfg.KEYFRAME_INDEX, motion_model=1,
@@ -182,7 +180,7 @@ class DeviceTrack:
         t.motion_damping = float(cfg.MOTION_DAMPING)
         t.keyframe_thresh = float(cfg.KEYFRAME_THRESH)
         t.feat_fp32 = 1 if self.fp32 else 0
-        t.feat_plain = 1 if (not self.fp32 and not slam._chunked) else 0
+        t.feat_plain = 0 if slam._chunked else 1
         P = lambda x: x.data_ptr()
         for name, ten in dict(dyn=self.dyn, poses=slam.poses_, patches=slam.patches_, intrinsics=slam.intrinsics_,
                               points=slam.points_, tstamps=slam.tstamps_, index_map=slam.index_map_, ixm=self.ixm,

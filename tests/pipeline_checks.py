@@ -177,7 +177,7 @@ def check_update_step(device, mixed=False):
         assert np.array_equal(np.array(sorted(slam.delta.keys())), g[f"{tag}_delta_keys"])
         kf[tag + "_poses"] = float(np.abs(slam.poses_[:m_].cpu().numpy() - g[f"{tag}_poses"]).max())
         kf[tag + "_imap"] = maxrel(slam.imap_.float().sum((1, 2)).cpu().numpy(), g[f"{tag}_imap_sum"])
-        kf[tag + "_fmap1"] = maxrel(slam.fmap1_.float().sum((1, 2, 3)).cpu().numpy(), g[f"{tag}_fmap1_sum"])
+        kf[tag + "_fmap1"] = maxrel(slam.fmap1_.float().flatten(1).sum(1).cpu().numpy(), g[f"{tag}_fmap1_sum"])   # (any plane layout)
         kf[tag + "_gmap"] = maxrel(slam.gmap_.float().sum((1, 2, 3, 4)).cpu().numpy(), g[f"{tag}_gmap_sum"])
         assert slam.net.shape[1] == len(slam._ii)
     assert int(g["kfb_n"]) == int(g["kfa_n"]) - 1 or int(g["kfa_n"]) == n - 1   # the removal branch was exercised
@@ -255,6 +255,28 @@ def run_trajectory(tag, device, mixed=False, pipelined=False, **cfg_extra):
     return slam, rec, traj, ts
 
 
+def perturbed_images(eps):
+    """context manager: every synthetic frame's image multiplied by (1 + eps u), u uniform in [-1, 1] (seeded per frame) -- a
+    rounding-level change of the INPUT for eps = 2^-22"""
+    import contextlib
+    import rampvo_amd.synthetic as syn
+
+    @contextlib.contextmanager
+    def ctx():
+        orig = syn.SyntheticStream.frame
+
+        def frame(self, t):
+            image, events, K, mask = orig(self, t)
+            gen = torch.Generator().manual_seed(1000 + t)
+            return image * (1.0 + eps * (2.0 * torch.rand(image.shape, generator=gen).to(image.device) - 1.0)), events, K, mask
+        syn.SyntheticStream.frame = frame
+        try:
+            yield
+        finally:
+            syn.SyntheticStream.frame = orig
+    return ctx()
+
+
 def check_trajectory(tag, device, mixed=False, pipelined=False, **cfg_extra):
     """N-frame free run (damped weight profile) against the reference's own run of the same stream: structure
     exact, every float within the returned errors.  ``rel`` = max abs trajectory difference / max(1, largest
@@ -276,5 +298,7 @@ def check_trajectory(tag, device, mixed=False, pipelined=False, **cfg_extra):
                 poses=float(np.abs(slam.poses_[:n].cpu().numpy() - g["final_poses"]).max()),
                 depths_rel=float((np.abs(d_got - d_ref) / np.maximum(np.abs(d_ref), 1.0)).max()),
                 depths_p99=float(np.percentile(np.abs(d_got - d_ref) / np.maximum(np.abs(d_ref), 1.0), 99)),
+                depths_p999=float(np.percentile(np.abs(d_got - d_ref) / np.maximum(np.abs(d_ref), 1.0), 99.9)),
+                depths_beyond=set(map(int, np.nonzero((np.abs(d_got - d_ref) / np.maximum(np.abs(d_ref), 1.0)).ravel() > 1e-4)[0])),
                 ate_rmse=float(ate_rmse(traj[:, :3], g["traj"][:, :3])),
                 path_length=float(np.linalg.norm(np.diff(g["traj"][:, :3], axis=0), axis=1).sum()))

@@ -55,6 +55,57 @@ def test_conv_mfma_matches_torch(cin, cout, k, stride, hw):
         assert float((conv_hip.materialize(p) - refn).abs().max()) <= 2e-3
 
 
+@pytest.mark.parametrize("cin,cout,k,stride,hw", [(32, 32, 3, 1, (24, 40)), (32, 64, 3, 2, (24, 40)), (64, 64, 3, 1, (25, 33)),
+                                                  (16, 32, 7, 2, (48, 64)), (64, 64, 3, 1, (120, 160)), (16, 32, 7, 2, (97, 131))])
+def test_conv_x3_against_fp64_and_the_exact_product_kernel(cin, cout, k, stride, hw):
+    """fp32 towers, round 6: csrc/conv.hip::conv_x3_kernel -- every operand split into three fp16 numbers (33 bits), the six
+    f16 MFMA products of order <= 2 into three fp32 accumulators: exact-class products, only sums are rounded, as in the
+    reference -- against a float64 convolution (error relative to sum |x||w|, the scale of the rounding: <= 2e-6 and no
+    worse than 1.5x the exact-product f32 MFMA kernel it replaces) and against that kernel; the InstanceNorm statistics it
+    emits; prologue affine + ReLU, bias, ReLU, residual, out_scale; inputs with entries below the fp16 normal range and large
+    ones"""
+    from rampvo_amd import conv_hip
+    from rampvo_amd._lib import RAMP_F32, RAMP_CONV_X3, lib
+    torch.manual_seed(5)
+    H, W = hw
+    conv = nn.Conv2d(cin, cout, k, stride, k // 2).cuda()
+    x = torch.randn(H, W, cin, device="cuda")
+    x[::3, ::5] *= 1e-6                                           # below the fp16 normal range
+    x[1::4, 2::7] *= 300.0
+    sc = torch.rand(cin, device="cuda") + 0.5
+    sh = torch.randn(cin, device="cuda") * 0.2
+    OH, OW = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+    res = torch.randn(OH, OW, cout, device="cuda")
+    assert lib().ramp_conv2d_stats_blocks(H, W, cin, cout, k, stride, RAMP_F32 | RAMP_CONV_X3) > 0
+    out = {}
+    with torch.no_grad():
+        for x3 in (True, False):
+            conv_hip.X3 = x3
+            try:
+                y = conv_hip.conv2d(x, conv, pre=(sc, sh), res=res, relu=True, out_scale=0.25)
+                pend = conv_hip.conv2d(x, conv, want_stats=True)
+                out[x3] = (y, pend.raw, pend.scale, pend.shift)
+            finally:
+                conv_hip.X3 = True
+        xd = x.double().permute(2, 0, 1)[None]
+        w, b = conv.weight.double(), conv.bias.double()
+        raw = F.conv2d(xd, w, b, stride, k // 2)[0].permute(1, 2, 0)
+        mag = F.conv2d(xd.abs(), w.abs(), b.abs(), stride, k // 2)[0].permute(1, 2, 0)
+        e3 = float(((out[True][1].double() - raw).abs() / mag).max())
+        e1 = float(((out[False][1].double() - raw).abs() / mag).max())
+        print("max error / sum |x||w|: split %.2e, exact products %.2e" % (e3, e1))
+        assert e3 <= 2e-6 and e1 <= 2e-6 and e3 <= 1.5 * e1 + 1e-8, (e3, e1)
+        xa = torch.relu(x.double() * sc.double() + sh.double()).permute(2, 0, 1)[None]
+        full = torch.relu(torch.relu(F.conv2d(xa, w, b, stride, k // 2)[0].permute(1, 2, 0)) + res.double()) * 0.25
+        magf = F.conv2d(xa.abs(), w.abs(), b.abs(), stride, k // 2)[0].permute(1, 2, 0) * 0.25 + res.double().abs() * 0.25
+        assert float(((out[True][0].double() - full).abs() / magf).max()) <= 2e-6
+        assert (out[True][0] - out[False][0]).abs().max() <= 1e-5 * float(out[False][0].abs().max())
+        # InstanceNorm statistics of the raw output (scale = rsqrt(var + eps), shift = -mean scale)
+        mean, var = raw.mean((0, 1)), raw.var((0, 1), unbiased=False)
+        assert torch.allclose(out[True][2].double(), 1.0 / torch.sqrt(var + 1e-5), rtol=1e-4)
+        assert torch.allclose(out[True][3].double(), -mean / torch.sqrt(var + 1e-5), rtol=1e-4, atol=1e-5)
+
+
 @pytest.mark.parametrize("cin,cout,k,stride,hw,first", [(16, 32, 7, 2, (48, 64), True), (32, 32, 3, 1, (37, 53), False),
                                                          (32, 64, 3, 2, (40, 56), False), (64, 64, 3, 1, (20, 28), False),
                                                          (32, 64, 1, 2, (40, 56), False), (64, 384, 1, 1, (21, 29), False)])

@@ -233,6 +233,41 @@ def test_pyramid_pack_and_chunked_corr():
     assert a.float().abs().max() > 0
 
 
+def test_pyramid_pack_fp32_and_chunked_fp32_corr():
+    """fp32 features (round 6): ramp_pyramid_pack -> [H][8][W][16] planes, level 1 a pure re-layout, level 4 torch's
+    avg_pool2d TO THE BIT ((ky, kx)-ordered sum x 1/16); corr_mfma_kernel<float> over the chunked planes is bit-identical to
+    the same kernel over plain NHWC planes (the layout changes which bytes a load fetches together, never a value)"""
+    import torch.nn.functional as F
+    from rampvo_amd import ops
+    from rampvo_amd._lib import RAMP_NHWC, RAMP_NHWC32, kplane
+    g = torch.Generator().manual_seed(6)
+    N2, H, W, C = 3, 24, 32, 128
+    kp = kplane(torch.float32)
+    assert kp == 16
+    maps = (torch.randn(N2, H, W, C, generator=g) * 0.5).cuda()
+    l1 = torch.empty(N2, H, C // kp, W, kp, device="cuda")
+    l4 = torch.empty(N2, H // 4, C // kp, W // 4, kp, device="cuda")
+    for n in range(N2):
+        ops.pyramid_pack(maps[n], l1[n], l4[n])
+    unchunk = lambda t: t.permute(0, 1, 3, 2, 4).reshape(t.shape[0], t.shape[1], t.shape[3], C)
+    assert torch.equal(unchunk(l1), maps)
+    pooled = F.avg_pool2d(maps.permute(0, 3, 1, 2), 4, 4).permute(0, 2, 3, 1).contiguous()
+    assert torch.equal(unchunk(l4), pooled)
+    rng = np.random.default_rng(4)
+    E, M = 61, 12
+    fmap1 = (torch.randn(M, 3, 3, C, generator=g) * 0.5).cuda()
+    coords = np.stack([rng.uniform(-6, W + 6, (E, 3, 3)), rng.uniform(-6, H + 6, (E, 3, 3))], 1).astype(np.float32)
+    coords[:20] = coords[:20, :, :1, :1] + np.arange(3, dtype=np.float32)[None, None, None, :]   # compact windows
+    ii = torch.from_numpy(rng.integers(0, M, E)).cuda()
+    jj = torch.from_numpy(rng.integers(0, N2, E)).cuda()
+    a = ops.corr(fmap1, [maps, pooled], cu(coords), ii, jj, 3, (1.0, 4.0), RAMP_NHWC, fast_f32=True)
+    b = ops.corr(fmap1, [l1, l4], cu(coords), ii, jj, 3, (1.0, 4.0), RAMP_NHWC32, fast_f32=True)
+    assert torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0))
+    ref = ops.corr(fmap1, [maps, pooled], cu(coords), ii, jj, 3, (1.0, 4.0), RAMP_NHWC, fast_f32=False)   # the fmaf chain
+    assert (torch.nan_to_num(b) - torch.nan_to_num(ref)).abs().max() <= 1e-5 * max(1.0, float(torch.nan_to_num(ref).abs().max()))
+    assert a.abs().max() > 0
+
+
 def test_corr_matches_reference_call_site_golden():
     """G3 (tests/golden/corr.npz): what the reference's altcorr.corr python call site returned for both pyramid
     levels, stacked as Ramp_vo.corr stacks them (ramp/Ramp_vo.py:175-182)"""

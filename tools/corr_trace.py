@@ -10,7 +10,8 @@ from rampvo_amd.config import make_cfg
 from rampvo_amd.Ramp_vo import Ramp_vo
 from rampvo_amd.synthetic import SyntheticStream, make_network
 so = ctypes.CDLL(_lib.LIB_PATH)
-slam = Ramp_vo(make_cfg("default", PATCHES_PER_FRAME=96, MIXED_PRECISION=True), make_network("SingleScale"), {"event_bias": True})
+MIXED = os.environ.get("CT_MIXED", "1") == "1"
+slam = Ramp_vo(make_cfg("default", PATCHES_PER_FRAME=96, MIXED_PRECISION=MIXED), make_network("SingleScale"), {"event_bias": True})
 slam.device_steps = False
 st = SyntheticStream(480, 640, 60, seed=1234, device="cuda")
 for t in range(60):

@@ -3,9 +3,9 @@
 the main stream's wait for the front end's "done" event (RAMP_FE_WAIT_PROBE=1): the first completes when the previous
 frame's plan has, the second when the front end has too.  usage: tools/fe_wait.py [SingleScale|MultiScale] [frames]"""
 import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rampvo_amd.Ramp_vo as _rv
 _rv._FE_WAIT_PROBE = True
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from rampvo_amd.config import make_cfg
 from rampvo_amd.Ramp_vo import Ramp_vo
