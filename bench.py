@@ -221,8 +221,12 @@ class CorrTimer:
         per_edge, src, src_edges = self.pmc_traffic_per_edge(elem_bytes, segment)
         traffic = int(per_edge * E) if per_edge else None
         flops = E * 2 * CORR_FLOP_PER_EDGE_LEVEL
-        peak_tf = MFMA_F16_PEAK_TFLOPS if elem_bytes == 2 else MFMA_F32_PEAK_TFLOPS
-        f32_kernel = "corr_mfma_kernel<float>" if os.environ.get("RAMP_CORR_F32_MFMA", "1") != "0" else "corr_kernel<float>"
+        from rampvo_amd._lib import corr_f32_mode
+        f32_mode = corr_f32_mode()            # 2: split fp16 parts, three f16 MFMA products per dot product (3x the flops below)
+        peak_tf = MFMA_F16_PEAK_TFLOPS if (elem_bytes == 2 or f32_mode == 2) else MFMA_F32_PEAK_TFLOPS
+        if elem_bytes != 2 and f32_mode == 2:
+            flops *= 3
+        f32_kernel = ("corr_kernel<float>", "corr_mfma_kernel<float>", "corr_mfma_kernel<CorrX2> (fp32 features as split fp16 parts)")[f32_mode]
         out = dict(kernel="corr_mfma_kernel<half>" if elem_bytes == 2 else f32_kernel, bound="hbm",
                    achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, launches=int(big.sum()),
@@ -1027,7 +1031,7 @@ def main():
                                                if fp32_dev else "",
                                                ", device-resident steps (the operator's Linear layers: split-fp16 operands on the "
                                                "f16 matrix cores, fp32 accumulate -- csrc/update_x3.hip; correlation: "
-                                               "corr_mfma_kernel<float>)"
+                                               "the same split on the target planes, corr_mfma_kernel<CorrX2>)"
                                                if (not args.mixed and device_step and not fp32_dev) else "",
                                                ", frame pipelining off" if not args.pipeline else "",
                                                ", host-driven steps (RAMP_DEVICE_STEP=0)"

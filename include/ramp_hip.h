@@ -42,11 +42,21 @@ extern "C" {
 /* ramp_corr_fwd*, fp32 + RAMP_NHWC only: OR into `dtype` to use the fp32 MFMA kernel (2.1x faster; results
  * within 1e-5 of the default kernel, which keeps the reference's channel-ordered fmaf accumulation)      */
 #define RAMP_CORR_MFMA32 0x40
+/* fp32 features as split fp16 pairs, "x2" (round 6): every value x = xh + xl 2^-11 (xh = fp16(x), xl = fp16((x - xh) 2^11): 22
+ * significant bits), a dot product = three v_mfma_f32_16x16x32_f16 products (ah bh; ah bl + al bh) into two fp32 accumulators:
+ * fp32-class accuracy (<= 1e-5 of the default kernel like RAMP_CORR_MFMA32, whose fp32 MFMAs cost >= 240 us per launch at
+ * 41k factors) at the fp16 kernel's speed for twice the window bytes.  OR into `dtype` (RAMP_F32) of
+ *   ramp_pyramid_pack: the planes are written as [H][4][2][W][32] fp16 (per row and 32-channel step a [W][32] plane of high
+ *     parts, then one of low parts; 512 bytes per pixel like the fp32 planes) -- level 4 is pooled in fp32, then split;
+ *   ramp_corr_fwd* with RAMP_NHWC32: the target maps are such planes (fmap1 stays fp32 RAMP_NHWC rows, split while loading;
+ *     the output stays fp32).  Any other layout / dtype with this bit: RAMP_EINVAL.                                      */
+#define RAMP_CORR_X2 0x80
 
 #define RAMP_NCHW 0
 #define RAMP_NHWC 1
-#define RAMP_NHWC32 2  /* [H][C/32][W][32] (fp16) / [H][C/16][W][16] (fp32: with RAMP_CORR_MFMA32 only): correlation target maps
-                          (ramp_pyramid_pack); 64 bytes per pixel and plane = one 16-byte load of every lane quarter */
+#define RAMP_NHWC32 2  /* [H][C/32][W][32] (fp16) / [H][C/16][W][16] (fp32: with RAMP_CORR_MFMA32 only) / [H][4][2][W][32] fp16
+                          parts (fp32 with RAMP_CORR_X2): correlation target maps (ramp_pyramid_pack); 64 bytes per pixel and
+                          plane = one 16-byte load of every lane quarter */
 
 /* library / build identification: returns a static string */
 const char *ramp_version(void);
@@ -119,6 +129,7 @@ int ramp_corr_fwd_ordered(const void *fmap1, const ramp_corr_level *levels_host,
  * RAMP_NHWC32 target maps of ramp_corr_fwd (fmap1 stays RAMP_NHWC).  fp32 features
  * (dtype RAMP_F32): planes of 16 channels, [H][8][W][16] and [H/4][8][W/4][16]; the
  * mean is the window summed in (ky, kx) order times 1/16 = torch's avg_pool2d.
+ * dtype RAMP_F32 | RAMP_CORR_X2: the same fp32 input, planes of split fp16 pairs (see RAMP_CORR_X2; same byte counts).
  * C == 128, W % 16 == 0, H % 4 == 0, else RAMP_EUNSUPPORTED.                 */
 int ramp_pyramid_pack(const void *fmap, void *level1, void *level4, int H, int W, int C, int dtype,
                       void *stream);
@@ -749,7 +760,9 @@ typedef struct ramp_track {
                                        * bound): picks the gru launch's tile (64 / 80 rows per workgroup)                    */
   uint32_t gate_seq;                  /* with gate_flag: the value the update operator's last launch (gru) stores into it  */
   int32_t feat_fp32;                  /* 0: fp16 features (imap / gmap / fmap rows of 2-byte elements, chunked [h][C/32][w][32] pyramid
-                                       * planes, corr [E_cap][896] fp16); 1: fp32 features, planes chunked as [h][C/16][w][16]
+                                       * planes, corr [E_cap][896] fp16); 2: fp32 features, chunked planes of split fp16 pairs
+                                       * (RAMP_CORR_X2: corr_mfma_kernel<CorrX2>; feat_plain must be 0), everything else as 1;
+                                       * 1: fp32 features, planes chunked as [h][C/16][w][16]
                                        * (feat_plain = 0) or plain NHWC, corr [E_cap][896] fp32 by corr_mfma_kernel<float>
                                        * (RAMP_CORR_F32_MFMA=0: corr_kernel<float>, the reference kernel's summation order, plain
                                        * planes only), operator csrc/update_x3.hip                                          */

@@ -140,8 +140,10 @@ class Ramp_vo:
         self.imap_ = torch.zeros(self.mem, self.M, DIM, **kwargs)
         self.gmap_ = torch.zeros(self.mem, self.M, self.P, self.P, 128, **kwargs)
         # pyramid on the GPU: [h][C/32][w][32] (fp16) / [h][C/16][w][16] (fp32) slots (csrc/altcorr.hip, the MFMA kernels' target
-        # layout: 64 bytes per pixel and plane); otherwise plain channels-last
+        # layout: 64 bytes per pixel and plane); otherwise plain channels-last.  fp32 features, default: the float32 slots
+        # hold split fp16 parts [h][4][2][w][32] (self._split; corr_mfma_kernel<CorrX2>, include/ramp_hip.h RAMP_CORR_X2)
         self._chunked, self._lazy_net = self._layout_flags(h, w)
+        self._split = bool(self._chunked and self.dtype == torch.float and self._f32_mode == 2)
         self._kp = KP = kplane(self.dtype)
         if self._chunked:
             self.fmap1_ = torch.zeros(self.mem, h, 128 // KP, w, KP, **kwargs)
@@ -227,8 +229,10 @@ class Ramp_vo:
         state is re-indexed, not copied, when the graph changes)"""
         # (fp32 features: chunked planes are read by corr_mfma_kernel<float> only -- RAMP_CORR_F32_MFMA=0 keeps plain planes for
         # corr_kernel<float>, the reference kernel's summation order)
-        can = self.dtype == torch.half or (self.dtype == torch.float and os.environ.get("RAMP_CORR_F32_MFMA", "1") != "0"
-                                           and getattr(self.network.patchify, "pack_f32", False))
+        # (the patchifier packs the planes inside the front end's graph: its mode -- _lib.corr_f32_mode() when it was built --
+        # is the one that counts)
+        self._f32_mode = int(getattr(self.network.patchify, "pack_f32", 0)) if self.dtype == torch.float else 0
+        can = self.dtype == torch.half or (self.dtype == torch.float and self._f32_mode != 0)
         chunked = can and ops.pyramid_pack_supported(h, w) and (h // 4) > 0 and (w // 4) > 0
         if self.dtype == torch.half and not chunked:
             # a performance cliff, not an error: say so once (VERDICT r3 #14)
@@ -394,6 +398,9 @@ class Ramp_vo:
             delta={k: (v[0], c(v[1].data)) for k, v in self.delta.items()})
 
     def _fmap_nchw(self, buf):
+        if self._split:                                                # pairs -> values (22 significant bits), [mem, 128, h, w]
+            hi, lo = ops.unpack_split(buf)
+            return (hi.float() + lo.float() * 2.0 ** -11).permute(0, 3, 1, 2)
         if self._chunked:                                              # [mem, h, 128 / kp, w, kp] -> [mem, 128, h, w]
             return buf.permute(0, 2, 4, 1, 3).reshape(buf.shape[0], 128, buf.shape[1], buf.shape[3])
         return buf.permute(0, 3, 1, 2)
@@ -417,6 +424,9 @@ class Ramp_vo:
         self.gmap_.copy_(sd["gmap"].to(dev).permute(0, 1, 3, 4, 2))
         for buf, key in ((self.fmap1_, "fmap1"), (self.fmap2_, "fmap2")):
             src = sd[key].to(dev)                                      # [mem, 128, h, w]
+            if self._split:
+                buf.copy_(ops.pack_split(src.to(self.dtype).permute(0, 2, 3, 1)))
+                continue
             if self._chunked:
                 src = src.reshape(src.shape[0], 128 // self._kp, self._kp, src.shape[2], src.shape[3]).permute(0, 3, 1, 4, 2)
             else:
@@ -467,7 +477,7 @@ class Ramp_vo:
         return altcorr.corr_pyramid(self.gmap_.view(-1, 3, 3, 128), self.pyramid, coords[0], ii, jj, 3, (1, 4),
                                     RAMP_NHWC32 if self._chunked else RAMP_NHWC, order=order, row_elems=CORR_ROW,
                                     mod_ii=self.M * self.mem, mod_jj=self.mem,
-                                    fast_f32=os.environ.get("RAMP_CORR_F32_MFMA", "1") != "0")
+                                    fast_f32=(2 if self._split else 1) if self._f32_mode != 0 else 0)
 
     def _corr_launch(self, coords, ii, jj, order):
         """ramp_corr_fwd_ordered on the tracker's own buffers (fp16 chunked pyramid, padded rows)"""
@@ -1192,7 +1202,7 @@ class Ramp_vo:
             f = fmap[0]                                                  # [1,128,h,w], channels-last storage
             if self._chunked:
                 ops.pyramid_pack(f[0].permute(1, 2, 0).to(self.dtype).contiguous(), self.fmap1_[slot],
-                                 self.fmap2_[slot])
+                                 self.fmap2_[slot], split=self._split)
             else:
                 self.fmap1_[slot] = f[0].permute(1, 2, 0).to(self.dtype)
                 self.fmap2_[slot] = F.avg_pool2d(f, 4, 4)[0].permute(1, 2, 0).to(self.dtype)

@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("RAMP_HIP_LIB") or os.path.join(CSRC, "libramp_hip.so"
 RAMP_F32, RAMP_F16 = 0, 1
 RAMP_EUNSUPPORTED = -4
 RAMP_CONV_FP8 = 0x40
-RAMP_IN_F32, RAMP_CONV_DIRECT, RAMP_CORR_MFMA32 = 0x10, 0x20, 0x40
+RAMP_IN_F32, RAMP_CONV_DIRECT, RAMP_CORR_MFMA32, RAMP_CORR_X2 = 0x10, 0x20, 0x40, 0x80
 RAMP_CONV_X3 = 0x80
 RAMP_NCHW, RAMP_NHWC, RAMP_NHWC32 = 0, 1, 2
 KPLANE = 32            # channels per plane of the packed correlation target maps: [h][128 / KPLANE][w][KPLANE]
@@ -26,9 +26,22 @@ KPLANE = 32            # channels per plane of the packed correlation target map
 
 def kplane(dtype):
     """channels per plane of the packed correlation target maps for a feature dtype: 64 bytes per pixel and plane
-    ([h][4][w][32] fp16, [h][8][w][16] fp32)"""
+    ([h][4][w][32] fp16, [h][8][w][16] fp32).  fp32 features in the split form (corr_f32_mode() == 2) keep the fp32 CONTAINER
+    [h][8][w][16] float32 -- the same 512 bytes per pixel -- whose bytes are [h][4][2][w][32] fp16 parts (RAMP_CORR_X2)"""
     import torch
     return KPLANE if dtype == torch.float16 else KPLANE // 2
+
+
+def corr_f32_mode():
+    """how the tracker computes the correlation volume of fp32 features (RAMP_CORR_F32_MFMA): 2 (default) split fp16 pairs on
+    the f16 matrix cores (corr_mfma_kernel<CorrX2>, chunked planes of pairs); 1 the fp32 matrix cores
+    (corr_mfma_kernel<float>, chunked fp32 planes); 0 corr_kernel<float>, the reference kernel's summation order, plain planes"""
+    import os
+    try:
+        m = int(os.environ.get("RAMP_CORR_F32_MFMA", "2"))
+    except ValueError:
+        m = 2
+    return m if m in (0, 1, 2) else 2
 
 _ERR = {-1: "RAMP_EINVAL (bad argument)", -2: "RAMP_ELAUNCH (HIP launch/runtime error)",
         -3: "RAMP_EWORKSPACE (workspace too small)", -4: "RAMP_EUNSUPPORTED (size/shape not supported)"}

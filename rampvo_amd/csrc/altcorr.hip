@@ -447,8 +447,19 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 template <typename T> struct CorrMma;
 template <> struct CorrMma<_Float16> {
   typedef f16x8_t frag;
-  static constexpr int STEPS = 4, PER = 8, PGB = CORR_PGB, WAVES = CORR_WAVES;
+  typedef frag afrag_t;
+  typedef frag bfrag_t;
+  typedef f32x4_t acc_t;
+  typedef _Float16 plane_t;                           // element of the target planes ...
+  typedef _Float16 out_t;                             // ... and of the output rows
+  static constexpr int STEPS = 4, PER = 8, PGB = CORR_PGB, WAVES = CORR_WAVES, FE = 1;
   static __device__ __forceinline__ frag zero() { return (frag){0, 0, 0, 0, 0, 0, 0, 0}; }
+  static __device__ __forceinline__ afrag_t load_a(const void *fmap1, size_t off) {
+    return *reinterpret_cast<const frag *>(reinterpret_cast<const _Float16 *>(fmap1) + off);
+  }
+  static __device__ __forceinline__ bfrag_t load_b(const plane_t *p, size_t) { return *reinterpret_cast<const frag *>(p); }
+  static __device__ __forceinline__ acc_t acc_zero() { return (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+  static __device__ __forceinline__ float val(const acc_t &acc, int r) { return acc[r]; }
   static __device__ __forceinline__ f32x4_t mma(const frag &a, const frag &b, f32x4_t acc) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
   }
@@ -465,11 +476,78 @@ template <> struct CorrMma<_Float16> {
 };
 template <> struct CorrMma<float> {
   typedef f32x4_t frag;
-  static constexpr int STEPS = 8, PER = 4, PGB = 2, WAVES = 3;
+  typedef frag afrag_t;
+  typedef frag bfrag_t;
+  typedef f32x4_t acc_t;
+  typedef float plane_t;
+  typedef float out_t;
+  static constexpr int STEPS = 8, PER = 4, PGB = 2, WAVES = 3, FE = 1;
   static __device__ __forceinline__ frag zero() { return (frag){0.f, 0.f, 0.f, 0.f}; }
+  static __device__ __forceinline__ afrag_t load_a(const void *fmap1, size_t off) {
+    return *reinterpret_cast<const frag *>(reinterpret_cast<const float *>(fmap1) + off);
+  }
+  static __device__ __forceinline__ bfrag_t load_b(const plane_t *p, size_t) { return *reinterpret_cast<const frag *>(p); }
+  static __device__ __forceinline__ acc_t acc_zero() { return (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+  static __device__ __forceinline__ float val(const acc_t &acc, int r) { return acc[r]; }
   static __device__ __forceinline__ f32x4_t mma(const frag &a, const frag &b, f32x4_t acc) {
 #pragma unroll
     for (int t4 = 0; t4 < 4; t4++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t4], b[t4], acc, 0, 0, 0);
+    return acc;
+  }
+  static __device__ __forceinline__ void st(float *p, float v) { *p = v; }
+  static __device__ __forceinline__ void st2(float *p, float a, float b) { *reinterpret_cast<float2 *>(p) = make_float2(a, b); }
+};
+
+// fp32 features on the f16 matrix cores, "x2" (round 6, dtype RAMP_F32 | RAMP_CORR_X2, chunked planes only): gfx950 multiplies
+// fp32 operands at the vector rate (v_mfma_f32_16x16x4_f32: the fp32 volume's 37.6 GFLOP at E = 41k are >= 240 us of the
+// matrix pipe), fp16 operands 16x faster.  Every feature is kept as two fp16 numbers,
+//     x = xh + xl 2^-11,   xh = fp16(x),   xl = fp16((x - xh) 2^11)      (22 significant bits; corr_split2 below),
+// and a dot product is three f16 MFMA products into two fp32 accumulators,
+//     acc0 += ah bh;   acc1 += ah bl + al bh;   result = acc0 + 2^-11 acc1      (dropped: al bl, 2^-22 of |a||b|),
+// the scheme of csrc/update_x3.hip's Linear layers.  The target planes hold the parts as [h][4][2][w][32] fp16 -- per row
+// and K step a plane of high parts, then one of low parts, each the fp16 kernel's [w][32] run (ramp_pyramid_pack with
+// RAMP_CORR_X2; 512 bytes per pixel like the fp32 planes they replace, so the tracker's ring buffers and copies do not
+// change) -- and the
+// patch features stay fp32 rows that the wave splits once while loading its A fragments.  The kernel is the fp16 kernel
+// with twice the window bytes: bound by the vector L1 like it, not by the matrix pipe.
+static __device__ __forceinline__ void corr_split2(const float x, _Float16 &h, _Float16 &l) {
+  // (below the fp16 normal range the value goes into the scaled low part whole: no subnormal operand is relied on)
+  const float xh = fabsf(x) < 6.103515625e-5f ? 0.0f : (float)(_Float16)x;
+  h = (_Float16)xh;
+  l = (_Float16)((x - xh) * 2048.0f);
+}
+#ifndef CORR_X2_PGB
+#define CORR_X2_PGB 2     // pixel groups in flight (16 sixteen-byte loads per lane, as the fp16 kernel's four)
+#define CORR_X2_WAVES 3   // waves per SIMD of the register budget (132 VGPRs)
+#endif
+struct CorrX2 {};
+template <> struct CorrMma<CorrX2> {
+  typedef f16x8_t frag;
+  struct afrag_t { f16x8_t h, l; };
+  typedef afrag_t bfrag_t;
+  struct acc_t { f32x4_t a0, a1; };
+  typedef _Float16 plane_t;
+  typedef float out_t;
+  static constexpr int STEPS = 4, PER = 8, PGB = CORR_X2_PGB, WAVES = CORR_X2_WAVES, FE = 2;
+  static __device__ __forceinline__ afrag_t zero() { return (afrag_t){(frag){0, 0, 0, 0, 0, 0, 0, 0}, (frag){0, 0, 0, 0, 0, 0, 0, 0}}; }
+  static __device__ __forceinline__ afrag_t load_a(const void *fmap1, size_t off) {
+    const float4 *p = reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(fmap1) + off);
+    const float4 u = p[0], v = p[1];
+    const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+    afrag_t a;
+#pragma unroll
+    for (int c = 0; c < 8; c++) { _Float16 h, l; corr_split2(x[c], h, l); a.h[c] = h; a.l[c] = l; }
+    return a;
+  }
+  static __device__ __forceinline__ bfrag_t load_b(const plane_t *p, size_t part) {       // part: elements from a high to its low part
+    return (bfrag_t){*reinterpret_cast<const frag *>(p), *reinterpret_cast<const frag *>(p + part)};
+  }
+  static __device__ __forceinline__ acc_t acc_zero() { return (acc_t){(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}}; }
+  static __device__ __forceinline__ float val(const acc_t &acc, int r) { return acc.a0[r] + acc.a1[r] * 0x1p-11f; }
+  static __device__ __forceinline__ acc_t mma(const afrag_t &a, const bfrag_t &b, acc_t acc) {
+    acc.a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, b.h, acc.a0, 0, 0, 0);
+    acc.a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, b.l, acc.a1, 0, 0, 0);
+    acc.a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.l, b.h, acc.a1, 0, 0, 0);
     return acc;
   }
   static __device__ __forceinline__ void st(float *p, float v) { *p = v; }
@@ -505,8 +583,12 @@ template <typename T, bool CHUNKED, bool MULTI>
 static __device__ __forceinline__ void corr_edge_rows(const CorrParams &prm, const int e, const int lane, float *__restrict__ Cs,
                                                       float *__restrict__ outs, float (&res)[CORR_MAXLEV][7]) {
   typedef CorrMma<T> M;
-  typedef typename M::frag frag_t;
+  typedef typename M::afrag_t afrag_t;
+  typedef typename M::bfrag_t bfrag_t;
+  typedef typename M::plane_t PT;
   constexpr int STEPS = M::STEPS, PER = M::PER;   // MFMA-operand loads per pixel, channels per lane and load
+  constexpr int FE = M::FE;                       // plane elements per channel (2: high and low parts, CorrMma<CorrX2>)
+  static_assert(FE == 1 || CHUNKED, "split planes exist in the chunked layout only");
   constexpr int C = 128, PP = 9, R = 3, D = 8, d = 7;
   constexpr int KOUT = d;                    // 7 per lane (lanes 0..62), held until both levels are done
   constexpr int PGB = M::PGB;                     // pixel groups whose loads are in flight together
@@ -578,12 +660,12 @@ static __device__ __forceinline__ void corr_edge_rows(const CorrParams &prm, con
   bool any_live = false;
 #pragma unroll
   for (int lvl = 0; lvl < CORR_MAXLEV; lvl++) any_live |= g_lm_[lvl] != 0;
-  frag_t afrag[STEPS];
+  afrag_t afrag[STEPS];
   {
-    const T *src = reinterpret_cast<const T *>(prm.fmap1) + (size_t)i1 * C * PP;
+    const size_t src = (size_t)i1 * C * PP;
 #pragma unroll
     for (int s = 0; s < STEPS; s++) {
-      if (j < PP && any_live) afrag[s] = *reinterpret_cast<const frag_t *>(src + j * C + 4 * PER * s + PER * q);
+      if (j < PP && any_live) afrag[s] = M::load_a(prm.fmap1, src + j * C + 4 * PER * s + PER * q);
       else afrag[s] = M::zero();
     }
   }
@@ -594,7 +676,7 @@ static __device__ __forceinline__ void corr_edge_rows(const CorrParams &prm, con
     if (lvl >= L) break;
     CTS(ct_l0);
     const int H2 = prm.H2[lvl], W2 = prm.W2[lvl];
-    const T *f2 = reinterpret_cast<const T *>(prm.fmap2[lvl]) + (size_t)((lvl == 0 && prm.slot0) ? (long)prm.slot0[j2] : j2) * C * H2 * W2;
+    const PT *f2 = reinterpret_cast<const PT *>(prm.fmap2[lvl]) + (size_t)((lvl == 0 && prm.slot0) ? (long)prm.slot0[j2] : j2) * (C * FE) * H2 * W2;
     const int my_ox = g_ox_[lvl], my_oy = g_oy_[lvl];
     const float my_dx = g_dx_[lvl], my_dy = g_dy_[lvl];
     const unsigned lmask = g_lm_[lvl];
@@ -650,7 +732,7 @@ static __device__ __forceinline__ void corr_edge_rows(const CorrParams &prm, con
         CTS(ct_b0);
         // all PGB x 4 sixteen-byte loads of the batch are issued before the first MFMA waits on
         // one: the address is always a valid pixel, out-of-window lanes are zeroed afterwards
-        frag_t bfr[PGB][STEPS];
+        bfrag_t bfr[PGB][STEPS];
         bool inb[PGB];
 #pragma unroll
         for (int u = 0; u < PGB; u++) {
@@ -664,17 +746,23 @@ static __device__ __forceinline__ void corr_edge_rows(const CorrParams &prm, con
           // [h][4][w][32]: K step s of a window row is one run of 64 bytes per pixel (18.8 vs 15.7 TB/s from the vector
           // L1 for the 10-wide windows, tools/mb/gather_patterns.hip P5 / P2).  fp32 features: [h][8][w][16] -- the same 64
           // bytes per pixel and load (load s of quarter q <-> channels 16 s + 4 q .. + 3), eight planes
-          constexpr int KP = 4 * PER;                       // channels per plane: 32 (fp16), 16 (fp32)
-          const T *pp = CHUNKED ? f2 + (((size_t)cy * (C / KP)) * W2 + cx) * KP + PER * q
-                                : f2 + ((size_t)cy * W2 + cx) * C + PER * q;
-          const size_t sstride = CHUNKED ? (size_t)W2 * KP : 4 * PER;
+          // split fp32 features (FE = 2): [h][4][2][w][32] fp16 -- per K step a plane of high parts, then one of low parts, so
+          // that every load instruction reads the fp16 kernel's contiguous 64-byte-per-pixel runs (pairs side by side,
+          // [h][4][w][2][32], touch 16 half-used lines per instruction: 334 us against the fp32 kernel's 336)
+          constexpr int KP = 4 * PER;                       // channels per plane: 32 (fp16, split fp32), 16 (fp32)
+          const PT *pp = CHUNKED ? f2 + (((size_t)cy * (C / KP) * FE) * W2 + cx) * KP + PER * q
+                                 : f2 + ((size_t)cy * W2 + cx) * C + PER * q;
+          const size_t sstride = CHUNKED ? (size_t)W2 * (KP * FE) : 4 * PER;
+          const size_t part = (size_t)W2 * KP;
 #else
-          const T *pp = CHUNKED ? f2 + (((size_t)cy * (C / 8) + q) * W2 + cx) * 8
-                                : f2 + ((size_t)cy * W2 + cx) * C + PER * q;
+          static_assert(FE == 1, "CORR_KPLANE=8 builds have no split planes");
+          const PT *pp = CHUNKED ? f2 + (((size_t)cy * (C / 8) + q) * W2 + cx) * 8
+                                 : f2 + ((size_t)cy * W2 + cx) * C + PER * q;
           const size_t sstride = CHUNKED ? (size_t)4 * W2 * 8 : 4 * PER;
+          const size_t part = 0;
 #endif
 #pragma unroll
-          for (int s = 0; s < STEPS; s++) bfr[u][s] = *reinterpret_cast<const frag_t *>(pp + s * sstride);
+          for (int s = 0; s < STEPS; s++) bfr[u][s] = M::load_b(pp + s * sstride, part);
         }
 #ifdef CORR_TRACE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -684,7 +772,7 @@ static __device__ __forceinline__ void corr_edge_rows(const CorrParams &prm, con
 #pragma unroll
         for (int u = 0; u < PGB; u++) {
           const int t = (pg0 + u) * 16 + j;
-          f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+          typename M::acc_t acc = M::acc_zero();
 #pragma unroll
           for (int s = 0; s < STEPS; s++) acc = M::mma(afrag[s], bfr[u][s], acc);
           // D: rows 4q..4q+3 = patch pixels, column j = union pixel t; an out-of-map pixel
@@ -693,7 +781,7 @@ static __device__ __forceinline__ void corr_edge_rows(const CorrParams &prm, con
 #pragma unroll
             for (int r = 0; r < 4; r++) {
               const int p = 4 * q + r;
-              if (p < PP) Cs[p * CORR_TM + t] = inb[u] ? acc[r] : 0.0f;
+              if (p < PP) Cs[p * CORR_TM + t] = inb[u] ? M::val(acc, r) : 0.0f;
             }
           }
         }
@@ -775,7 +863,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CorrMma
   float res[CORR_MAXLEV][KOUT];
   corr_edge_rows<T, CHUNKED, false>(prm, e, lane, Cs, outs, res);
   // out[e][o][lvl]: with two levels a lane's pair is one 4-byte store, consecutive over lanes
-  T *op = reinterpret_cast<T *>(prm.out) + (size_t)e * prm.row_elems;
+  typedef typename M::out_t OT;
+  OT *op = reinterpret_cast<OT *>(prm.out) + (size_t)e * prm.row_elems;
   for (int q = NOUT * L + lane; q < prm.row_elems; q += 64) M::st(op + q, 0.0f);   // row padding
   if (lane < 63) {
     if (L == 2) {
@@ -884,6 +973,60 @@ __global__ void __launch_bounds__(256) pyramid_pack_f32_kernel(const float4 *__r
   }
 }
 
+// fp32 features as split fp16 pairs (CorrMma<CorrX2>): NHWC [H][W][128] -> level 1 as [H][4][2][W][32] fp16, level 4 = the
+// 4x4 mean (summed in (ky, kx) order, x 1/16: torch's avg_pool2d to the bit, as above) split the same way.  Thread = 8
+// channels of one pixel and K step: one 16-byte piece of high parts, one of low parts a [W][32] plane behind it.
+__global__ void __launch_bounds__(256) pyramid_pack_x2_kernel(const float4 *__restrict__ in, uint4 *__restrict__ out1,
+                                                              uint4 *__restrict__ out4, int H, int W) {
+  const long n1 = (long)H * W * 16, n4 = (long)(H / 4) * (W / 4) * 16;
+  const long o = (long)blockIdx.x * 256 + threadIdx.x;
+  float4 a, b;
+  uint4 *dst;
+  long lo_off;
+  if (o < n1) {
+    // o = ((y * 4 + s) * W + x) * 4 + qq: channels 32 s + 8 qq .. + 7
+    const int qq = (int)(o & 3);
+    const long r = o >> 2;
+    const int x = (int)(r % W);
+    const long r2 = r / W;
+    const int s = (int)(r2 & 3);
+    const long y = r2 >> 2;
+    const float4 *src = in + (y * W + x) * 32 + s * 8 + qq * 2;
+    a = src[0]; b = src[1];
+    dst = out1 + ((r2 * 2) * W + x) * 4 + qq;
+    lo_off = (long)W * 4;
+  } else if (o < n1 + n4) {
+    const long o4 = o - n1;
+    const int W4 = W / 4;
+    const int qq = (int)(o4 & 3);
+    const long r = o4 >> 2;
+    const int X = (int)(r % W4);
+    const long r2 = r / W4;
+    const int s = (int)(r2 & 3);
+    const long Y = r2 >> 2;
+    a = make_float4(0.f, 0.f, 0.f, 0.f); b = a;
+    for (int ky = 0; ky < 4; ky++)
+      for (int kx = 0; kx < 4; kx++) {
+        const float4 *src = in + ((Y * 4 + ky) * W + X * 4 + kx) * 32 + s * 8 + qq * 2;
+        const float4 u = src[0], v = src[1];
+        a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+        b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+      }
+    a = make_float4(a.x * 0.0625f, a.y * 0.0625f, a.z * 0.0625f, a.w * 0.0625f);
+    b = make_float4(b.x * 0.0625f, b.y * 0.0625f, b.z * 0.0625f, b.w * 0.0625f);
+    dst = out4 + ((r2 * 2) * W4 + X) * 4 + qq;
+    lo_off = (long)W4 * 4;
+  } else {
+    return;
+  }
+  const float x8[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  f16x8_t hi, lo;
+#pragma unroll
+  for (int c = 0; c < 8; c++) { _Float16 h, l; corr_split2(x8[c], h, l); hi[c] = h; lo[c] = l; }
+  dst[0] = __builtin_bit_cast(uint4, hi);
+  dst[lo_off] = __builtin_bit_cast(uint4, lo);
+}
+
 extern "C" {
 
 #ifdef CORR_TRACE
@@ -896,8 +1039,14 @@ int ramp_corr_kplane(void) { return CORR_KPLANE; }
 int ramp_pyramid_pack(const void *fmap, void *level1, void *level4, int H, int W, int C, int dtype,
                       void *stream) {
   if (!fmap || !level1 || !level4 || H <= 0 || W <= 0) return RAMP_EINVAL;
+  const bool x2 = dtype == (RAMP_F32 | RAMP_CORR_X2);      // fp32 map -> split fp16 pairs (CorrMma<CorrX2>'s planes)
+  if (x2) dtype = RAMP_F32;
   if (C != 128 || (dtype != RAMP_F16 && dtype != RAMP_F32) || (W % 16) || (H % 4)) return RAMP_EUNSUPPORTED;
-  if (dtype == RAMP_F32) {
+  if (x2) {
+    const long n = (long)H * W * 16 + (long)(H / 4) * (W / 4) * 16;
+    hipLaunchKernelGGL(pyramid_pack_x2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4 *)fmap, (uint4 *)level1, (uint4 *)level4, H, W);
+  } else if (dtype == RAMP_F32) {
     const long n = (long)H * W * 32 + (long)(H / 4) * (W / 4) * 32;
     hipLaunchKernelGGL(pyramid_pack_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const float4 *)fmap, (float4 *)level1, (float4 *)level4, H, W);
@@ -961,7 +1110,7 @@ int ramp_i_corr_fwd(const void *fmap1, const ramp_corr_level *levels, int nlevel
                     const int32_t *slot0) {
   if (E < 0 || nlevels < 1 || nlevels > CORR_MAXLEV || !levels) return RAMP_EINVAL;
   if (slot0 && mod_jj <= 0) return RAMP_EINVAL;
-  if (tf_poses && (!tf_patches || !tf_intr || !tf_src || (dtype & ~RAMP_CORR_MFMA32) != RAMP_F16 || layout == RAMP_NCHW)) return RAMP_EINVAL;
+  if (tf_poses && (!tf_patches || !tf_intr || !tf_src || (dtype & ~(RAMP_CORR_MFMA32 | RAMP_CORR_X2)) != RAMP_F16 || layout == RAMP_NCHW)) return RAMP_EINVAL;
   if (C != 128 || P != 3 || radius != 3) return RAMP_EUNSUPPORTED;
   if (E == 0) return RAMP_OK;
   if (!fmap1 || !coords || !ii || !jj || !out) return RAMP_EINVAL;
@@ -994,9 +1143,13 @@ int ramp_i_corr_fwd(const void *fmap1, const ramp_corr_level *levels, int nlevel
   prm.slot0 = slot0;
   const dim3 grid(prm.chunk * CORR_XCDS);
   hipStream_t st = (hipStream_t)stream;
-  const bool fast32 = (dtype & RAMP_CORR_MFMA32) != 0;
-  dtype &= ~RAMP_CORR_MFMA32;
-  if (dtype == RAMP_F32 && layout == RAMP_NHWC && fast32)
+  const bool x2 = (dtype & RAMP_CORR_X2) != 0;             // chunked planes hold split fp16 pairs (ramp_pyramid_pack, x2)
+  const bool fast32 = (dtype & (RAMP_CORR_MFMA32 | RAMP_CORR_X2)) != 0;
+  dtype &= ~(RAMP_CORR_MFMA32 | RAMP_CORR_X2);
+  if (x2 && (dtype != RAMP_F32 || layout != RAMP_NHWC32)) return RAMP_EINVAL;
+  if (x2)
+    hipLaunchKernelGGL((corr_mfma_kernel<CorrX2, true>), grid, dim3(64), 0, st, prm);
+  else if (dtype == RAMP_F32 && layout == RAMP_NHWC && fast32)
     hipLaunchKernelGGL((corr_mfma_kernel<float, false>), grid, dim3(64), 0, st, prm);
   else if (dtype == RAMP_F32 && layout == RAMP_NHWC32 && fast32)        // target maps as [h][8][w][16] (ramp_pyramid_pack, fp32)
     hipLaunchKernelGGL((corr_mfma_kernel<float, true>), grid, dim3(64), 0, st, prm);

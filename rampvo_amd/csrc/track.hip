@@ -548,12 +548,14 @@ int ramp_track_step(const ramp_track *t, int cur, int64_t counter, int flags, in
                                    mod, dyn, (t->median && t->keyframe_index >= 4) ? t->median : nullptr, t->dyn + RAMP_DYN_STATUS, (Eb < Ec && folded) ? Eb : 0, t->n_rows, st,
                                    t->fmap1_slot, 3, nullptr, 0));
   }
-  // fp32 features: the correlation launch is corr_mfma_kernel<float> (RAMP_CORR_F32_MFMA=0: corr_kernel<float>, the reference
+  // fp32 features: the correlation launch is corr_mfma_kernel<CorrX2> on planes of split fp16 pairs (feat_fp32 == 2: the
+  // caller packed them so, RAMP_CORR_X2) or corr_mfma_kernel<float> (RAMP_CORR_F32_MFMA=0: corr_kernel<float>, the reference
   // kernel's summation order) with rows padded to 896 floats, the operator csrc/update_x3.hip's chains; PRE / POST around a
   // caller-run operator remain (RAMP_X3=0: library GEMMs)
   static int corr32_fast = -1;
   if (corr32_fast < 0) { const char *e = getenv("RAMP_CORR_F32_MFMA"); corr32_fast = e ? atoi(e) : 1; }
-  const int f32_code = RAMP_F32 | (corr32_fast ? RAMP_CORR_MFMA32 : 0);
+  if (t->feat_fp32 == 2 && t->feat_plain) return RAMP_EINVAL;
+  const int f32_code = RAMP_F32 | (t->feat_fp32 == 2 ? RAMP_CORR_X2 : corr32_fast ? RAMP_CORR_MFMA32 : 0);
   if (flags & RAMP_TRACK_UPDATE_PRE) {
     if (!t->coords || !t->corr) return RAMP_EINVAL;
     TRK_DO(ramp_i_transform_dyn(t->poses, t->patches, t->intrinsics, ii, jj, kk, t->coords, Eb, dyn, st));

@@ -141,9 +141,11 @@ class Patchifier(nn.Module):
         self.use_graph = os.environ.get("RAMP_NO_GRAPH", "0") != "1"
         self._graphs = {}
         self._graph_warm = 0
-        # fp32 features: the tracker's pyramid planes chunked as [h][8][w][16] for corr_mfma_kernel<float> (off with
-        # RAMP_CORR_F32_MFMA=0: corr_kernel<float>, the reference kernel's summation order, reads plain NHWC planes)
-        self.pack_f32 = os.environ.get("RAMP_CORR_F32_MFMA", "1") != "0"
+        # fp32 features: the tracker's pyramid planes chunked for the MFMA correlation kernels -- 2 (default): split fp16
+        # parts [h][4][2][w][32] for corr_mfma_kernel<CorrX2>; 1: [h][8][w][16] fp32 for corr_mfma_kernel<float>; 0
+        # (RAMP_CORR_F32_MFMA=0): plain NHWC planes for corr_kernel<float>, the reference kernel's summation order
+        from ._lib import corr_f32_mode
+        self.pack_f32 = corr_f32_mode()
         self._plist = None
         self._extra = None
         self._index = None
@@ -299,7 +301,7 @@ class Patchifier(nn.Module):
             chunked = ((fmap.dtype == torch.float16 or (fmap.dtype == torch.float32 and self.pack_f32))
                        and ops.pyramid_pack_supported(h, w))
             if chunked:
-                f1, f2 = ops.pyramid_pack(f_nhwc[0])
+                f1, f2 = ops.pyramid_pack(f_nhwc[0], split=int(self.pack_f32) == 2)
             else:
                 import torch.nn.functional as F
                 f1 = f_nhwc[0]
@@ -326,7 +328,7 @@ class Patchifier(nn.Module):
                        and ops.pyramid_pack_supported(h, w) and f_nhwc[0].is_contiguous())
             if chunked:
                 # both correlation levels in the MFMA kernel's [h][C/32][w][32] target layout
-                f1, f2 = ops.pyramid_pack(f_nhwc[0])
+                f1, f2 = ops.pyramid_pack(f_nhwc[0], split=int(self.pack_f32) == 2)
             else:
                 import torch.nn.functional as F
                 f1 = f_nhwc[0]

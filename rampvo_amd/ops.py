@@ -11,6 +11,7 @@ import torch
 
 from . import _lib
 from ._lib import RAMP_CORR_MFMA32 as _LIB_CORR_MFMA32
+from ._lib import RAMP_CORR_X2 as _LIB_CORR_X2
 from ._lib import workspace as _lib_workspace
 from ._lib import KPLANE, RAMP_NHWC32, RAMP_NCHW, RAMP_NHWC, CorrLevel, check, dtype_code, kplane, lib, ptr, require_cuda, stream
 
@@ -104,9 +105,11 @@ def corr(fmap1, fmaps2, coords, ii, jj, radius=3, coord_divs=(1.0,), layout=RAMP
     if fast_f32 is None:
         fast_f32 = os.environ.get("RAMP_CORR_F32_MFMA", "0") == "1"
     if fast_f32 and fmap1.dtype == torch.float32 and layout in (RAMP_NHWC, RAMP_NHWC32):
-        code |= _LIB_CORR_MFMA32         # opt-in: MFMA accumulation order instead of the reference's fmaf chain
+        # opt-in: MFMA accumulation order instead of the reference's fmaf chain.  fast_f32 = 2 with RAMP_NHWC32: the target
+        # maps are planes of split fp16 pairs (pyramid_pack(split=True)) -> corr_mfma_kernel<CorrX2>
+        code |= _LIB_CORR_X2 if (int(fast_f32) == 2 and layout == RAMP_NHWC32) else _LIB_CORR_MFMA32
     assert not (fmap1.dtype == torch.float32 and layout == RAMP_NHWC32 and not fast_f32), \
-        "chunked fp32 target maps are read by corr_mfma_kernel<float> only (fast_f32)"
+        "chunked fp32 target maps are read by the MFMA kernels only (fast_f32)"
     check(lib().ramp_corr_fwd_ordered(ptr(fmap1), levels, L, ptr(coords), ptr(ii), ptr(jj),
                                       ptr(order) if order is not None else None, ptr(out), int(row_elems), int(mod_ii),
                                       int(mod_jj), E,
@@ -170,21 +173,50 @@ def event_topk_supported(events, k, nms_kernel_size):
             and k <= (events.shape[1] // 4) * (events.shape[2] // 4) and (nms_kernel_size == 0 or (nms_kernel_size % 2 == 1 and nms_kernel_size <= 17)))
 
 
-def pyramid_pack(fmap, out1=None, out4=None):
+def pyramid_pack(fmap, out1=None, out4=None, split=None):
     """NHWC map [H,W,128] -> (level1 [H,4,W,32], level4 [H/4,4,W/4,32]) (fp16) or ([H,8,W,16], [H/4,8,W/4,16]) (fp32) in the
     correlation kernel's packed target layout (RAMP_NHWC32: 64 bytes per pixel and plane); level4 is the 4x4 mean
-    (Ramp_vo.py:378-381; fp32: torch's avg_pool2d to the bit)"""
+    (Ramp_vo.py:378-381; fp32: torch's avg_pool2d to the bit).  fp32 with ``split`` (default: corr_f32_mode() == 2): the two
+    float32 containers hold split fp16 parts [H,4,2,W,32] (x = hi + lo 2^-11; unpack_split() decodes them) for
+    corr(..., fast_f32=2)"""
     require_cuda(fmap)
     H, W, C = fmap.shape
     assert fmap.dtype in (torch.float16, torch.float32) and fmap.is_contiguous()
+    if split is None:
+        split = _lib.corr_f32_mode() == 2
+    split = bool(split) and fmap.dtype == torch.float32
     kp = kplane(fmap.dtype)
     if out1 is None:
         out1 = torch.empty((H, C // kp, W, kp), dtype=fmap.dtype, device=fmap.device)
     if out4 is None:
         out4 = torch.empty((H // 4, C // kp, W // 4, kp), dtype=fmap.dtype, device=fmap.device)
-    check(lib().ramp_pyramid_pack(ptr(fmap), ptr(out1), ptr(out4), H, W, C, dtype_code(fmap), stream()),
-          "ramp_pyramid_pack")
+    check(lib().ramp_pyramid_pack(ptr(fmap), ptr(out1), ptr(out4), H, W, C,
+                                  dtype_code(fmap) | (_LIB_CORR_X2 if split else 0), stream()), "ramp_pyramid_pack")
     return out1, out4
+
+
+def pack_split(rows):
+    """float32 rows [..., H, W, 128] -> the float32 container [..., H, 8, W, 16] of split fp16 pairs, in torch (the
+    arithmetic of csrc/altcorr.hip::corr_split2: load_state_dict, tests); pyramid_pack(split=True) is the kernel"""
+    assert rows.dtype == torch.float32 and rows.shape[-1] == 128
+    lead, (H, W) = rows.shape[:-3], rows.shape[-3:-1]
+    hi = torch.where(rows.abs() < 6.103515625e-5, torch.zeros_like(rows), rows.half().float())
+    lo = ((rows - hi) * 2048.0).half()
+    v = torch.stack((hi.half(), lo), -2)                                  # [.., H, W, 2, 128]
+    n = len(lead)
+    v = v.view(*lead, H, W, 2, 4, 32).permute(*range(n), n, n + 3, n + 2, n + 1, n + 4).contiguous()   # [.., H, 4, 2, W, 32]
+    return v.view(torch.float32).view(*lead, H, 8, W, 16)
+
+
+def unpack_split(planes):
+    """float32 container [..., H, 8, W, 16] of split fp16 pairs (pyramid_pack(split=True)) -> (hi, lo) fp16 tensors
+    [..., H, W, 128]: the value is hi + lo * 2**-11 (tests, debugging)"""
+    lead, (H, _, W, _) = planes.shape[:-4], planes.shape[-4:]
+    v = planes.contiguous().view(torch.float16).view(*lead, H, 4, 2, W, 32)
+    n = len(lead)
+    perm = tuple(range(n)) + (n + 2, n, n + 3, n + 1, n + 4)          # [.., 2, H, W, 4, 32]
+    v = v.permute(*perm).reshape(*lead, 2, H, W, 128)
+    return v.select(n, 0), v.select(n, 1)
 
 
 def pyramid_pack_supported(H, W, C=128):

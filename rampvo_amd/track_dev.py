@@ -179,7 +179,7 @@ class DeviceTrack:
             setattr(t, name, int(val))
         t.motion_damping = float(cfg.MOTION_DAMPING)
         t.keyframe_thresh = float(cfg.KEYFRAME_THRESH)
-        t.feat_fp32 = 1 if self.fp32 else 0
+        t.feat_fp32 = (2 if slam._split else 1) if self.fp32 else 0      # (2: planes of split fp16 pairs, RAMP_CORR_X2)
         t.feat_plain = 0 if slam._chunked else 1
         P = lambda x: x.data_ptr()
         for name, ten in dict(dyn=self.dyn, poses=slam.poses_, patches=slam.patches_, intrinsics=slam.intrinsics_,

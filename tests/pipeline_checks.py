@@ -177,7 +177,7 @@ def check_update_step(device, mixed=False):
         assert np.array_equal(np.array(sorted(slam.delta.keys())), g[f"{tag}_delta_keys"])
         kf[tag + "_poses"] = float(np.abs(slam.poses_[:m_].cpu().numpy() - g[f"{tag}_poses"]).max())
         kf[tag + "_imap"] = maxrel(slam.imap_.float().sum((1, 2)).cpu().numpy(), g[f"{tag}_imap_sum"])
-        kf[tag + "_fmap1"] = maxrel(slam.fmap1_.float().flatten(1).sum(1).cpu().numpy(), g[f"{tag}_fmap1_sum"])   # (any plane layout)
+        kf[tag + "_fmap1"] = maxrel(slam._fmap_nchw(slam.fmap1_).float().flatten(1).sum(1).cpu().numpy(), g[f"{tag}_fmap1_sum"])   # (any plane layout)
         kf[tag + "_gmap"] = maxrel(slam.gmap_.float().sum((1, 2, 3, 4)).cpu().numpy(), g[f"{tag}_gmap_sum"])
         assert slam.net.shape[1] == len(slam._ii)
     assert int(g["kfb_n"]) == int(g["kfa_n"]) - 1 or int(g["kfa_n"]) == n - 1   # the removal branch was exercised

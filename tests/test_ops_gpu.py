@@ -248,7 +248,7 @@ def test_pyramid_pack_fp32_and_chunked_fp32_corr():
     l1 = torch.empty(N2, H, C // kp, W, kp, device="cuda")
     l4 = torch.empty(N2, H // 4, C // kp, W // 4, kp, device="cuda")
     for n in range(N2):
-        ops.pyramid_pack(maps[n], l1[n], l4[n])
+        ops.pyramid_pack(maps[n], l1[n], l4[n], split=False)
     unchunk = lambda t: t.permute(0, 1, 3, 2, 4).reshape(t.shape[0], t.shape[1], t.shape[3], C)
     assert torch.equal(unchunk(l1), maps)
     pooled = F.avg_pool2d(maps.permute(0, 3, 1, 2), 4, 4).permute(0, 2, 3, 1).contiguous()
@@ -266,6 +266,60 @@ def test_pyramid_pack_fp32_and_chunked_fp32_corr():
     ref = ops.corr(fmap1, [maps, pooled], cu(coords), ii, jj, 3, (1.0, 4.0), RAMP_NHWC, fast_f32=False)   # the fmaf chain
     assert (torch.nan_to_num(b) - torch.nan_to_num(ref)).abs().max() <= 1e-5 * max(1.0, float(torch.nan_to_num(ref).abs().max()))
     assert a.abs().max() > 0
+
+
+def test_pyramid_pack_split_and_x2_corr_against_oracle():
+    """fp32 features as split fp16 pairs (round 6, RAMP_CORR_X2; the tracker's default for MIXED_PRECISION off): the pack
+    kernel writes exactly ops.pack_split's pairs (level 1 of the map, level 4 of torch's avg_pool2d), hi + lo 2^-11 is the
+    value to 2^-22; corr_mfma_kernel<CorrX2> -- three f16 MFMA products per dot product -- agrees with the C oracle (the
+    reference kernel's fmaf chain) and with corr_kernel<float> to 1e-5 of the volume's scale, as close as the fp32 MFMA
+    kernel does (both errors printed), NaN pattern included; tiny, huge-ish and zero features included"""
+    import torch.nn.functional as F
+    from rampvo_amd import ops
+    from rampvo_amd._lib import RAMP_NHWC, RAMP_NHWC32
+    fmap1, fmap2, coords, ii, jj = corr_case(seed=11, E=96, N2=5, H=32, W=48, wide=True)
+    fmap2[0, 0, :, :4, :4] *= 1e-5                  # below the fp16 normal range: carried by the low parts
+    fmap2[0, 1, :, 8:12, 8:12] *= 200.0
+    fmap2[0, 2, :64, 16:20] = 0.0
+    fmap1[0, :4] *= 3e-5
+    maps = cu(np.ascontiguousarray(fmap2[0].transpose(0, 2, 3, 1)))                   # [N2, H, W, C]
+    N2, H, W, C = maps.shape
+    l1 = torch.empty(N2, H, 8, W, 16, device="cuda")
+    l4 = torch.empty(N2, H // 4, 8, W // 4, 16, device="cuda")
+    for n in range(N2):
+        ops.pyramid_pack(maps[n], l1[n], l4[n], split=True)
+    pooled = F.avg_pool2d(maps.permute(0, 3, 1, 2), 4, 4).permute(0, 2, 3, 1).contiguous()
+    assert torch.equal(l1.view(torch.int32), ops.pack_split(maps).view(torch.int32))
+    assert torch.equal(l4.view(torch.int32), ops.pack_split(pooled).view(torch.int32))
+    hi, lo = ops.unpack_split(l1)
+    back = hi.double() + lo.double() * 2.0 ** -11
+    assert float((back - maps.double()).abs().max() / maps.abs().max()) <= 2.0 ** -22
+    # (below the fp16 normal range, 6.1e-5, a value is carried by its low part alone: 11 bits, <= 1.5e-8 absolute)
+    assert float(((back - maps.double()).abs() - maps.double().abs() * 2.0 ** -22).max()) <= 1.5e-8
+    f1 = cu(np.ascontiguousarray(fmap1[0].transpose(0, 2, 3, 1)))
+    args = (cu(coords[0]), cu(ii), cu(jj), 3, (1.0, 4.0))
+    x2 = ops.corr(f1, [l1, l4], *args, RAMP_NHWC32, fast_f32=2).cpu().numpy()
+    chain = ops.corr(f1, [maps, pooled], *args, RAMP_NHWC, fast_f32=False).cpu().numpy()
+    mf = ops.corr(f1, [maps, pooled], *args, RAMP_NHWC, fast_f32=True).cpu().numpy()
+    pooled_nchw = pooled.permute(0, 3, 1, 2).cpu().numpy()[None]
+    ref0 = orc.corr(fmap1, fmap2, coords / 1, ii, jj, 3)[0]
+    ref1 = orc.corr(fmap1, pooled_nchw, coords / 4, ii, jj, 3)[0]
+    assert x2.shape == (coords.shape[1], 7, 7, 3, 3, 2)
+    for lvl, ref in ((0, ref0), (1, ref1)):
+        scale = max(1.0, float(np.nanmax(np.abs(ref))))
+        assert np.array_equal(np.isnan(x2[..., lvl]), np.isnan(ref))
+        e_x2 = float(np.nanmax(np.abs(x2[..., lvl] - ref))) / scale
+        e_mf = float(np.nanmax(np.abs(mf[..., lvl] - ref))) / scale
+        print("level %d: x2 %.2e, fp32 MFMA %.2e of the scale %.1f from the oracle's fmaf chain" % (lvl, e_x2, e_mf, scale))
+        assert e_x2 <= 1e-5, (lvl, e_x2)
+    assert np.nanmax(np.abs(x2 - chain)) <= 1e-5 * max(1.0, float(np.nanmax(np.abs(chain))))
+    assert np.nanmax(np.abs(x2)) > 0
+    # padded rows + ring-buffer slots + a schedule, as the tracker calls it
+    order = torch.argsort(cu(jj), stable=True).int()
+    padded = ops.corr(f1, [l1, l4], *args, RAMP_NHWC32, fast_f32=2, order=order, row_elems=896)
+    assert padded.shape == (coords.shape[1], 896) and float(padded[:, 882:].abs().max()) == 0.0
+    assert torch.equal(torch.nan_to_num(padded[:, :882], nan=-7.0),
+                       torch.nan_to_num(torch.from_numpy(x2).cuda().reshape(-1, 882), nan=-7.0))
 
 
 def test_corr_matches_reference_call_site_golden():
