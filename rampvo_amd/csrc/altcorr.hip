@@ -656,6 +656,9 @@ static __device__ __forceinline__ void corr_edge_rows(const CorrParams &prm, con
     }
     g_lm_[lvl] = (unsigned)__ballot(live);
   }
+#ifdef CORR_TRACE
+  const unsigned long long ct_geo = __builtin_readcyclecounter();   // indices + coordinates have arrived (the ballots used them)
+#endif
   // (a factor with nothing in any plane needs no patch features)
   bool any_live = false;
 #pragma unroll
@@ -846,6 +849,7 @@ static __device__ __forceinline__ void corr_edge_rows(const CorrParams &prm, con
   {
     CTS(ct_end);
     CTACC(0, 1); CTACC(1, ct_end - ct_start); CTACC(2, ct_setup); CTACC(3, ct_load); CTACC(4, ct_mma); CTACC(5, ct_blend);
+    CTACC(6, ct_geo - ct_start); CTACC(7, any_live ? 1 : 0);
   }
 #endif
 }

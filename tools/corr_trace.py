@@ -39,3 +39,10 @@ names = ["waves", "total", "setup (coords, union)", "window loads (issue + wait)
 for k in range(1, 6):
     print("  %-28s %8.0f cycles / edge  (%4.1f %%)" % (names[k], v[k] / v[0], 100 * v[k] / v[1]))
 print("  other (A fragments, barriers, output stores) %8.0f cycles / edge" % ((v[1] - v[2:6].sum()) / v[0]))
+live = rows[:, 7] == 1
+print("  of which: indices + coordinates until the window geometry is known %8.0f cycles / edge" % (v[6] / v[0]))
+for name, sel in (("live", live), ("dead (nothing in any plane)", ~live)):
+    if sel.any():
+        r = rows[sel]
+        print("  %-28s %6d waves: total %8.0f cycles, preamble %6.0f, loads %6.0f, MFMA %6.0f, blend %6.0f, setup %6.0f" % (
+            name, sel.sum(), r[:, 1].mean(), r[:, 6].mean(), r[:, 3].mean(), r[:, 4].mean(), r[:, 5].mean(), r[:, 2].mean()))
