@@ -21,6 +21,7 @@
 //     and the residual-block tail relu(skip' + relu(norm(y))).
 #include "ramp_device.h"
 #include <stdlib.h>
+#include <type_traits>
 
 // ------------------------------------------------------------------ any != 0
 #define ANY_MAXB 1024          // workgroups of any_nonzero_kernel (per-workgroup results: flags [2][ANY_MAXB])
@@ -748,6 +749,9 @@ __global__ void __launch_bounds__(256) conv_tile_f16_kernel(const ConvMulti pm) 
 //     fragment is fetched from L2 once per workgroup and the A fragments come from LDS;
 //   * bias, InstanceNorm partial sums (sum, sum of squares of the raw output over the tile's valid pixels -> stats[C][2][nblk],
 //     the direct kernel's contract), ReLU, residual + ReLU, out_scale on the accumulators.
+#ifndef CONV_X3_PF
+#define CONV_X3_PF 1      // weight fragments one trip (two steps) ahead
+#endif
 template <int K, int S, int CIN, int COUT>
 __global__ void __launch_bounds__(256) conv_x3_kernel(const ConvParams p) {
   constexpr int PAD = K / 2, TH = 8, TW = 16;
@@ -821,47 +825,57 @@ __global__ void __launch_bounds__(256) conv_x3_kernel(const ConvParams p) {
   constexpr size_t WTOT = (size_t)K * K * NCH * NT * 64 * CPL;         // halfs per plane of the pack
   const float descale = *reinterpret_cast<const float *>(wph + 3 * WTOT);
   const int a_off = ((rg * MTW) * S * IW + j * S) * PSTR + q * CPL * 2;
-  // (one flat loop over (tap, chunk), two steps per trip: fully unrolled the compiler hoists every weight load of the layer --
-  // 256 VGPRs, one wave per SIMD)
+  // One flat loop over (tap, chunk), two steps per trip (fully unrolled the compiler hoists every weight load of the layer --
+  // 256 VGPRs).  The weight fragments of the NEXT trip are requested before this trip's MFMAs are issued (CONV_X3_PF, round 6):
+  // with one wave per SIMD nothing else covers the L2 round trip of a trip's fragments, and a workgroup's life was the sum
+  // of its trips' latencies -- 25 trips for the 7x7 layer
+  typedef typename std::conditional<KC == 32, f16x8, f16x4>::type wv_t;
+  struct WStep { wv_t w0, w1, w2; };
   const int nsteps = K * K * NCH + (p.Cin - CIN);      // (= K K NCH; not a compile-time constant: no full unrolling)
-#pragma unroll 2
-  for (int step = 0; step < nsteps; step++) {
+  auto ldw = [&](int step) -> WStep {
+    const int sc_ = step < nsteps ? step : nsteps - 1;                   // (past the end: a valid address, never used)
+    const size_t wo = (((size_t)sc_ * NT + nt) * 64 + lane) * CPL;
+    return WStep{*reinterpret_cast<const wv_t *>(wph + wo), *reinterpret_cast<const wv_t *>(wph + WTOT + wo),
+                 *reinterpret_cast<const wv_t *>(wph + 2 * WTOT + wo)};
+  };
+  auto run = [&](int step, const WStep &w) {
     const int tap = step / NCH, ch = step - tap * NCH;
     const int ky = tap / K, kx = tap - ky * K;
-    const size_t wo = (((size_t)step * NT + nt) * 64 + lane) * CPL;
     const int o0 = a_off + (ky * IW + kx) * PSTR + ch * KC * 2;
-    if constexpr (KC == 32) {
-      const f16x8 w0 = *reinterpret_cast<const f16x8 *>(wph + wo), w1 = *reinterpret_cast<const f16x8 *>(wph + WTOT + wo),
-                  w2 = *reinterpret_cast<const f16x8 *>(wph + 2 * WTOT + wo);
 #pragma unroll
-      for (int mt = 0; mt < MTW; mt++) {
-        const int o = o0 + mt * S * IW * PSTR;
-        const f16x8 a0 = *reinterpret_cast<const f16x8 *>(smem + o), a1 = *reinterpret_cast<const f16x8 *>(smem + PLANE + o),
-                    a2 = *reinterpret_cast<const f16x8 *>(smem + 2 * PLANE + o);
-        acc0[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, w0, acc0[mt], 0, 0, 0);
-        acc1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, w1, acc1[mt], 0, 0, 0);
-        acc1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, w0, acc1[mt], 0, 0, 0);
-        acc2[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, w2, acc2[mt], 0, 0, 0);
-        acc2[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, w1, acc2[mt], 0, 0, 0);
-        acc2[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, w0, acc2[mt], 0, 0, 0);
-      }
-    } else {
-      const f16x4 w0 = *reinterpret_cast<const f16x4 *>(wph + wo), w1 = *reinterpret_cast<const f16x4 *>(wph + WTOT + wo),
-                  w2 = *reinterpret_cast<const f16x4 *>(wph + 2 * WTOT + wo);
-#pragma unroll
-      for (int mt = 0; mt < MTW; mt++) {
-        const int o = o0 + mt * S * IW * PSTR;
-        const f16x4 a0 = *reinterpret_cast<const f16x4 *>(smem + o), a1 = *reinterpret_cast<const f16x4 *>(smem + PLANE + o),
-                    a2 = *reinterpret_cast<const f16x4 *>(smem + 2 * PLANE + o);
-        acc0[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a0, w0, acc0[mt], 0, 0, 0);
-        acc1[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a0, w1, acc1[mt], 0, 0, 0);
-        acc1[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a1, w0, acc1[mt], 0, 0, 0);
-        acc2[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a0, w2, acc2[mt], 0, 0, 0);
-        acc2[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a1, w1, acc2[mt], 0, 0, 0);
-        acc2[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a2, w0, acc2[mt], 0, 0, 0);
+    for (int mt = 0; mt < MTW; mt++) {
+      const int o = o0 + mt * S * IW * PSTR;
+      const wv_t a0 = *reinterpret_cast<const wv_t *>(smem + o), a1 = *reinterpret_cast<const wv_t *>(smem + PLANE + o),
+                 a2 = *reinterpret_cast<const wv_t *>(smem + 2 * PLANE + o);
+      if constexpr (KC == 32) {
+        acc0[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, w.w0, acc0[mt], 0, 0, 0);
+        acc1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, w.w1, acc1[mt], 0, 0, 0);
+        acc1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, w.w0, acc1[mt], 0, 0, 0);
+        acc2[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, w.w2, acc2[mt], 0, 0, 0);
+        acc2[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, w.w1, acc2[mt], 0, 0, 0);
+        acc2[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, w.w0, acc2[mt], 0, 0, 0);
+      } else {
+        acc0[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a0, w.w0, acc0[mt], 0, 0, 0);
+        acc1[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a0, w.w1, acc1[mt], 0, 0, 0);
+        acc1[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a1, w.w0, acc1[mt], 0, 0, 0);
+        acc2[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a0, w.w2, acc2[mt], 0, 0, 0);
+        acc2[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a1, w.w1, acc2[mt], 0, 0, 0);
+        acc2[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a2, w.w0, acc2[mt], 0, 0, 0);
       }
     }
+  };
+#if CONV_X3_PF
+  WStep wa = ldw(0), wb = ldw(1);
+  for (int step = 0; step < nsteps; step += 2) {
+    const WStep na = ldw(step + 2), nb = ldw(step + 3);
+    run(step, wa);
+    if (step + 1 < nsteps) run(step + 1, wb);
+    wa = na; wb = nb;
   }
+#else
+#pragma unroll 2
+  for (int step = 0; step < nsteps; step++) run(step, ldw(step));
+#endif
 
   // ---- 3. epilogue on the accumulators: lane (q, j) holds pixels x = 4q .. 4q+3 of row rg MTW + mt, channel 16 nt + j
   const int c = nt * 16 + j;
