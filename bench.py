@@ -179,10 +179,10 @@ class CorrTimer:
         round 5 the passes run the bench's own command line to its steady state (profiles/pmc/r05_corr_traffic.json,
         tools/r05_pmc_corr.sh): ``segment`` picks the launches of the timed region or of the all-live legs, and the
         source's own edges per launch ride along (the scaling is then a few per cent, not 23k -> 42k factors)."""
-        if elem_bytes != 2:
-            return None, None, None
         import glob
-        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc", "r*_corr_traffic.json")))
+        # (fp32 features: the passes of `MIXED=0 tools/r05_pmc_corr.sh` over corr_mfma_kernel<CorrX2>, round 6)
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc", "r*_corr_traffic.json" if elem_bytes == 2 else
+                                              "r*_corr_traffic_fp32.json")))
         for f in reversed(files):
             try:
                 with open(f) as fh:

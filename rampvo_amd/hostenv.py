@@ -50,7 +50,8 @@ def cpu_quota():
 
 
 def fit_host_threads(force=False):
-    """once per process: torch's intra-op pool down to HALF the CPU quota when it is larger than that (half: the pool's
+    """once per process: torch's intra-op pool down to HALF the CPU quota (this rank's share of it: quota / LOCAL_WORLD_SIZE
+    under torchrun) when it is larger than that (half: the pool's
     threads spin after every parallel region, next to the launching thread and the runtime's own threads).  A pool that
     fits is left alone; ``RAMP_HOST_THREADS=0`` leaves any pool alone, ``RAMP_HOST_THREADS=n`` sets n.  Returns the
     pool size in effect."""
@@ -61,6 +62,10 @@ def fit_host_threads(force=False):
     if env == "0":
         return torch.get_num_threads()
     have, quota = torch.get_num_threads(), cpu_quota()
+    try:        # one process per GPU on a node (torchrun): the ranks share the container's quota
+        quota = max(1, quota // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))
+    except ValueError:
+        pass
     want = int(env) if env else max(1, quota // 2)
     if env or have > quota:
         torch.set_num_threads(want)

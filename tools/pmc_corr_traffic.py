@@ -19,18 +19,20 @@ def values(path, counter):
 def main():
     fetch_csv, write_csv, K, W, L, I, out, cmd = (sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]),
                                                   int(sys.argv[6]), sys.argv[7], sys.argv[8])
+    row_bytes = float(sys.argv[9]) if len(sys.argv) > 9 else 1792.0          # one output row per factor: 896 halfs (fp32: 3584)
+    kname = sys.argv[10] if len(sys.argv) > 10 else "corr_mfma_kernel<_Float16, true>"
     f, w = values(fetch_csv, "FETCH_SIZE"), values(write_csv, "WRITE_SIZE")
     assert len(f) == len(w) and len(f) >= K + W + I + 4 + 2 * L, (len(f), len(w))
     seg = {"live_wrapped": slice(len(f) - L + 2, len(f)), "live_compact": slice(len(f) - 2 * L + 2, len(f) - L),
            "timed": slice(len(f) - 2 * L - 4 - I - K, len(f) - 2 * L - 4 - I)}
-    res = {"kernel": "corr_mfma_kernel<_Float16, true>", "command": cmd,
+    res = {"kernel": kname, "command": cmd,
            "source": "tools/r05_pmc_corr.sh -> tools/pmc_corr_traffic.py; counters collected for the correlation launches only "
                      "(--kernel-include-regex), one counter per pass, the tracker's cross-stream signal words replaced by "
                      "events under counter collection (rampvo_amd/Ramp_vo.py::_kernels_are_serialised)",
            "fetch_correction": 2.0, "dispatches": len(f)}
     for name, s in seg.items():
         fs, ws = f[s], w[s]
-        E = [x * 1024.0 / 1792.0 for x in ws]
+        E = [x * 1024.0 / row_bytes for x in ws]
         per = [(2.0 * a + b) * 1024.0 / e for a, b, e in zip(fs, ws, E)]
         res[name] = {"launches": len(fs), "fetch_size_kb_per_launch": round(sum(fs) / len(fs), 1),
                      "write_size_kb_per_launch": round(sum(ws) / len(ws), 1), "edges_per_launch": int(round(sum(E) / len(E))),

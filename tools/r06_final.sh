@@ -29,4 +29,5 @@ bash tools/converged_repeats.sh 3 > $O/converged_repeats.txt 2>&1; cat $O/conver
 timeout 900 python bench.py --preset precise --patches 300 --cpu-steps 0 --parity 0 --steps 60 --prime 90 --clock-warm-max 60 --inst-steps 30 --np-steps 10 --live-steps 0 --fp32-leg 0 2>$O/bench_precise300.err | grep "^{" > $O/bench_precise_300_patches.json
 bash tools/pmc_x3.sh $O/pmc_x3 > /dev/null 2>&1
 bash tools/r05_pmc_corr.sh > $O/pmc_corr.log 2>&1; cp gpurun_out/r05pmc/corr_traffic.json $O/corr_traffic.json 2>/dev/null
+MIXED=0 bash tools/r05_pmc_corr.sh > $O/pmc_corr_fp32.log 2>&1; cp gpurun_out/r05pmc/corr_traffic_fp32.json $O/corr_traffic_fp32.json 2>/dev/null
 bash tools/r04_profiles.sh $TAG
