@@ -60,6 +60,17 @@ if __name__ == "__main__":
     fn = lambda: ops.corr(f1, [l1, l4], coords, kk, jj, 3, (1.0, 4.0), RAMP_NHWC32, **kw)
     out = fn()
     print("corr: %.1f us per call" % timed(fn))
+    # schedule experiment (round 6): the same factors, the launch's positions ordered by (target frame, band of window rows)
+    # instead of (target frame, list order) -- does L2 locality of the windows buy launch time?  (scheduling only: same values)
+    for bands in [int(b) for b in os.environ.get("CORR_BANDS", "").split(",") if b]:
+        cy = coords[:, 1, 1, 1].clamp(0, 119.999)
+        key = jj * 1000 + (cy / (120.0 / bands)).long() if bands > 0 else jj * 1000 + torch.randint(0, 1000, jj.shape, device="cuda")
+        order_b = torch.argsort(key, stable=True).int()
+        kwb = dict(kw, order=order_b)
+        fnb = lambda: ops.corr(f1, [l1, l4], coords, kk, jj, 3, (1.0, 4.0), RAMP_NHWC32, **kwb)
+        ob = fnb()
+        same = torch.equal(torch.nan_to_num(ob.float(), nan=-7.0), torch.nan_to_num(out.float(), nan=-7.0))
+        print("  %3d bands of window rows per target frame: %.1f us per call (same values: %s)" % (bands, timed(fnb), same))
     ref = os.environ.get("CORR_REF_OUT")
     if ref and os.path.exists(ref):
         base = torch.load(ref)
