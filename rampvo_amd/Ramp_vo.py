@@ -197,6 +197,7 @@ class Ramp_vo:
         self.patches_models = None
         self._ba_info = torch.zeros(1, dtype=torch.int32, device=dev)
         self._last_K = self._last_K_raw = None     # last intrinsics written to a row of intrinsics_, and which row
+        self._k_cuda, self._k_cuda_for = None, -1  # device-side intrinsics rows of CUDA `intrinsics` arguments (_cuda_intrinsics)
         self._last_K_row = -1
 
     def close(self):
@@ -794,6 +795,13 @@ class Ramp_vo:
         values, None when it can be copied from row n-1 (the usual case: same values as the previous frame, recognised
         without building new arrays)"""
         k_dev = None
+        if torch.is_tensor(intrinsics) and intrinsics.is_cuda:
+            # The reference's evaluate.py hands `intrinsics.cuda()` -- a device tensor produced on the caller's stream right
+            # before the call.  Reading it back would stall the host behind everything queued (and, with the tracker on its
+            # own streams, race the producer): the row is written from a device-side conversion instead, every frame, on a
+            # stream that is ordered behind the caller's (_cuda_intrinsics); the host keeps no copy to compare with.
+            self._K_raw_now = None
+            return None, self._cuda_intrinsics(intrinsics)
         raw = self._last_K_raw
         # the row copy (intrinsics_[n] = intrinsics_[n-1]) is only right while row n-1 is the row that holds
         # _last_K: not after a frame that wrote a new K to row n and was then rejected by the motion probe
@@ -807,6 +815,25 @@ class Ramp_vo:
             if accepts and not (row_ok and self._last_K is not None and np.array_equal(kq, self._last_K)):
                 k_dev = self._upload(kq.astype(np.float32))
         return kq, k_dev
+
+    def _cuda_intrinsics(self, intrinsics, stream=None):
+        """device [4] fp32 = intrinsics / RES for a CUDA ``intrinsics`` (cached per call: the pipelined device-resident frame
+        converts it ahead, on its front-end stream).  Two buffers by frame parity: a frame's commit launch has read its row
+        before the front end of the frame after the next one may start."""
+        if self._k_cuda_for == self.counter:
+            return self._k_cuda[self.counter & 1]
+        if self._k_cuda is None:
+            self._k_cuda = [torch.zeros(4, dtype=torch.float32, device=self.device) for _ in range(2)]
+        cur = self._cur()
+        st = stream if stream is not None else cur
+        if stream is None and getattr(self, "_in_event_pending", False):
+            cur.wait_event(self._ev_in)                 # (a host-driven frame behind a front end that ran on its own stream)
+        buf = self._k_cuda[self.counter & 1]
+        with torch.cuda.stream(st):
+            torch.div(intrinsics.detach().reshape(4).to(torch.float32), float(self.RES), out=buf)
+        intrinsics.record_stream(st)
+        self._k_cuda_for = self.counter
+        return buf
 
     def _gate_signal(self):
         """the signal word of the gate, or None (RAMP_GATE_FLAG=0, no signal memory, or 2^31 frames behind us: the event
@@ -887,6 +914,8 @@ class Ramp_vo:
             ahead = _gru_tile_rows(dv.factor_estimate(), self.device) == 80
             if getattr(self, "_in_event_pending", False):
                 fe.wait_event(self._ev_in)              # inputs_ready = "stream": the caller's stream up to the call
+            if accepts and torch.is_tensor(intrinsics) and intrinsics.is_cuda:
+                self._cuda_intrinsics(intrinsics, stream=fe)   # (behind the caller's stream, ahead of this frame's "done")
             if not ahead:
                 self._gate_wait(fe)
             with torch.cuda.stream(fe):
@@ -922,8 +951,13 @@ class Ramp_vo:
         if not dv.fp32 or dv.x3:
             dv.bind_weights(self.network.update.fused(self.dtype))
         kq, k_dev = self._intrinsics_row(intrinsics, True)
+        k_new = None
         if k_dev is not None:
-            dv.k_new.copy_(k_dev)
+            if kq is None:
+                k_new = k_dev                           # a CUDA `intrinsics`: converted on the device (_cuda_intrinsics)
+            else:
+                dv.k_new.copy_(k_dev)
+                k_new = dv.k_new
             self._last_K, self._last_K_raw = kq, self._K_raw_now
         self.tlist.append(tstamp)
         if dv.fp32 and not dv.x3:
@@ -931,7 +965,7 @@ class Ramp_vo:
             # halves of the step -- on the launch bound's rows, sizes never read back (csrc/track.hip RAMP_TRACK_UPDATE_PRE /
             # _POST); everything else as in the fp16 step
             Eb = dv.factor_bound(self.counter)
-            dv.step(self.counter, track_dev.COMMIT | track_dev.UPDATE_PRE, k_new=dv.k_new if k_dev is not None else None,
+            dv.step(self.counter, track_dev.COMMIT | track_dev.UPDATE_PRE, k_new=k_new,
                     E_bound=Eb)
             # the GEMMs take their row count from the host: wait (polling pinned memory, no device call) for the sizes the
             # previous frame's plan wrote -- the GPU is busy with the correlation launch enqueued above meanwhile
@@ -947,7 +981,7 @@ class Ramp_vo:
         if sig is not None:
             self._gate_seq += 1
         dv.step(self.counter, track_dev.COMMIT | track_dev.UPDATE | track_dev.KEYFRAME | self._extra_step_flags,
-                k_new=dv.k_new if k_dev is not None else None,
+                k_new=k_new,
                 gate_event=self._ev_gate.cuda_event if (self.inputs_ready and sig is None) else None,
                 gate_flag=sig.ptr if sig is not None else None, gate_seq=self._gate_seq)
         self._gate_armed, self._gate_by_flag = self.inputs_ready, sig is not None

@@ -488,10 +488,16 @@ def test_device_resident_steps_and_frame_pipelining_do_not_change_results():
                 # inputs_ready = "stream": the frame's tensors are produced on the caller's stream right before the call
                 # (the reference's evaluate.py loop) and overwritten right behind it -- the tracker orders itself behind
                 # the first and the caller's stream behind the front end's copy, on its own streams in between
+                # Two frames of three hand the intrinsics as the reference's loop does (evaluate.py:162: `intrinsics.cuda()`, a
+                # device tensor produced on the caller's stream right before the call): converted on the device behind
+                # the caller's stream, never read back -- and clobbered behind the call like the other inputs.
                 ev2, im2 = ev * 1.0, im * 1.0
-                slam(t, input_tensor=(ev2, im2, mask), intrinsics=K)
+                K2 = K.cuda() * 1.0 if t % 3 else K
+                slam(t, input_tensor=(ev2, im2, mask), intrinsics=K2)
                 ev2.fill_(float("nan")); im2.fill_(float("nan"))
-                del ev2, im2
+                if K2.is_cuda:
+                    K2.fill_(float("nan"))
+                del ev2, im2, K2
             else:
                 slam(t, input_tensor=(ev, im, mask), intrinsics=K)
             resident += slam._dev is not None and slam._dev.active
