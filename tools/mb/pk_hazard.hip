@@ -183,6 +183,7 @@ int main(int argc, char **argv) {
   std::vector<float> ref((size_t)E * 18), got((size_t)E * 18);
   CK(hipMemcpy(ref.data(), d_ref, ref.size() * 4, hipMemcpyDeviceToHost));
   int bad_launches = 0; long bad_words = 0;
+  long by_quarter[4] = {0, 0, 0, 0}, bad_edges = 0, edges_all18 = 0;   // wrong words by 16-lane quarter of the wave (round 6)
   for (int r = 0; r < rounds; r++) {
     if (mode == 1 || mode == 3 || mode == 4 || mode == 6) CK(hipGraphLaunch(gexec, sb));
     else if (mode == 2 || mode == 5 || mode == 7) launch_b(sb);
@@ -197,9 +198,17 @@ int main(int argc, char **argv) {
             printf("    edge %6zu (block %4zu, lane %2zu of wave %zu) word %2zu: got %-14.8g expected %-14.8g\n", q / 18, q / 18 / 256,
                    (q / 18) % 64, ((q / 18) % 256) / 64, q % 18, got[q], ref[q]);
           w++;
+          by_quarter[((q / 18) % 64) / 16]++;
         }
       }
-      if (w) { bad_launches++; bad_words += w; }
+      if (w) {
+        bad_launches++; bad_words += w;
+        for (size_t e2 = 0; e2 < (size_t)E; e2++) {            // how many of an affected edge's 18 outputs are wrong
+          int c = 0;
+          for (int k2 = 0; k2 < 18; k2++) c += memcmp(&got[e2 * 18 + k2], &ref[e2 * 18 + k2], 4) != 0;
+          bad_edges += c > 0; edges_all18 += c == 18;
+        }
+      }
     }
     CK(hipStreamSynchronize(sb));
   }
@@ -208,5 +217,7 @@ int main(int argc, char **argv) {
                          "libramp conv 1x1 64->384, hipGraph", "libramp conv 1x1 64->384, plain"};
   printf("stream B: %-32s  %d of %d launches of the kernel under test differ from its first run (%ld words)\n", names[mode],
          bad_launches, rounds * 4, bad_words);
+  printf("  wrong words by 16-lane quarter of the wave (lanes 0-15 / 16-31 / 32-47 / 48-63): %ld / %ld / %ld / %ld; affected edges (= lanes) %ld, of which all 18 outputs wrong %ld\n",
+         by_quarter[0], by_quarter[1], by_quarter[2], by_quarter[3], bad_edges, edges_all18);
   return 0;
 }
