@@ -7,6 +7,9 @@
 //   mode 4 / 5: K = 16 MFMA with AGPR accumulators (conv_tile_f16_kernel's form), hipGraph / plain launches
 // build (hazard expected):   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I include -o /tmp/pk_slp tools/mb/pk_hazard.hip
 // build (control):           ... -fno-slp-vectorize -o /tmp/pk_noslp ...
+#ifndef VICTIM
+#define VICTIM 0
+#endif
 #include "../../rampvo_amd/csrc/ramp_device.h"
 #include <cstdio>
 #include <cstdlib>
@@ -28,9 +31,26 @@ __global__ void __launch_bounds__(256)
   float Ti[7], Tj[7], Tinv[7], G[7];
 #pragma unroll
   for (int c = 0; c < 7; c++) { Ti[c] = poses[7 * i + c]; Tj[c] = poses[7 * j + c]; }
+  // -DVICTIM=1: the relative pose only (quaternion algebra: multiplications and additions), stored into the first 7 words;
+  // -DVICTIM=2: no pose algebra (G = Tj), projection loop only (divisions)  -- round 6's bisect of the victim
+#if VICTIM == 2
+#pragma unroll
+  for (int c = 0; c < 7; c++) { G[c] = Tj[c]; Tinv[c] = Ti[c]; }
+#else
   lt_inv(Ti, Tinv);
   lt_mul(Tj, Tinv, G);
+#endif
   if (tonly) { G[3] = 0; G[4] = 0; G[5] = 0; G[6] = 1; }
+#if VICTIM == 1
+  {
+    float *o1 = out + (size_t)e * 2 * P * P;
+#pragma unroll
+    for (int c = 0; c < 7; c++) o1[c] = G[c];
+#pragma unroll
+    for (int c = 7; c < 18; c++) o1[c] = Tinv[c % 7];
+    return;
+  }
+#endif
   float t[3], q[4];
   lt_load(G, t, q);
   const float fxi = intr[4 * i + 0], fyi = intr[4 * i + 1], cxi = intr[4 * i + 2], cyi = intr[4 * i + 3];
