@@ -664,7 +664,8 @@ def fp32_leg(args, traj_fp32):
                                 % (d["steps"], time.perf_counter() - tic),
                         "edges": d["config"].get("edges"), "frame_pipelining": d["config"].get("frame_pipelining"),
                         "roofline": {k: d.get("roofline", {}).get(k) for k in ("kernel", "mean_launch_us", "achieved", "frac",
-                                                                               "edges_per_launch")},
+                                                                               "edges_per_launch", "bytes_per_launch", "traffic",
+                                                                               "traffic_source")},
                         "roofline_update": {k: (d.get("roofline_update") or {}).get(k)
                                             for k in ("kernel", "mean_call_us", "achieved", "peak", "frac", "edges")},
                         "roofline_encoder_mean_front_end_us": (d.get("roofline_encoder") or {}).get("mean_front_end_us"),
