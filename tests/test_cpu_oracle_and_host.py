@@ -413,3 +413,29 @@ def test_oracle_corr_against_reference_call_site_golden():
     c2 = orc.corr(f1, g["fmap2_l1"].astype(np.float32), coords / 4, ii, jj, 3)
     out = np.stack([c1, c2], -1).reshape(1, len(ii), -1)
     assert out.shape == g["out"].shape and np.array_equal(out, g["out"])
+
+
+def test_split_fp16_planes_host_restatement():
+    """fp32 features as two fp16 parts (RAMP_CORR_X2; csrc/altcorr.hip::corr_split2): the torch restatement the GPU test checks
+    the pack kernel against (ops.pack_split) -- layout [H][4][2][W][32] inside the float32 container, hi = fp16(x) (0 below the
+    fp16 normal range), lo = fp16((x - hi) 2^11), hi + lo 2^-11 within 2^-22 |x| (11 bits of x for the tiny values), and a
+    re-split of the decoded value is the same value (load_state_dict(state_dict()) keeps the planes' values)"""
+    import torch
+    from rampvo_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 8, 16, 128, generator=g) * 0.7
+    x[0, 0, 0, :6] = torch.tensor([1e-6, -3e-5, 6.2e-5, 0.0, 65000.0, -1e-9])
+    c = ops.pack_split(x)
+    assert c.shape == (2, 8, 8, 16, 16) and c.dtype == torch.float32
+    v = c.view(torch.float16).view(2, 8, 4, 2, 16, 32)                       # [n][y][K step][part][x][channel]
+    hi_ref = torch.where(x.abs() < 6.103515625e-5, torch.zeros_like(x), x.half().float())
+    assert float(v[1, 5, 2, 0, 7, 9]) == float(hi_ref[1, 5, 7, 64 + 9])
+    assert float(v[1, 5, 2, 1, 7, 9]) == float(((x - hi_ref) * 2048.0).half()[1, 5, 7, 64 + 9])
+    hi, lo = ops.unpack_split(c)
+    assert torch.equal(hi.float(), hi_ref)
+    back = hi.double() + lo.double() * 2.0 ** -11
+    err = (back - x.double()).abs()
+    assert bool((err <= x.double().abs() * 2.0 ** -22 + 1.5e-8).all())
+    assert float(hi[0, 0, 0, 0]) == 0.0 and float(hi[0, 0, 0, 1]) == 0.0 and float(hi[0, 0, 0, 2]) != 0.0     # the normal-range rule
+    hi2, lo2 = ops.unpack_split(ops.pack_split(back.float()))
+    assert torch.equal(hi2.double() + lo2.double() * 2.0 ** -11, back)
