@@ -752,12 +752,16 @@ __global__ void __launch_bounds__(256) conv_tile_f16_kernel(const ConvMulti pm) 
 #ifndef CONV_X3_PF
 #define CONV_X3_PF 1      // weight fragments one trip (two steps) ahead
 #endif
+#ifndef CONV_X3_PAD
+#define CONV_X3_PAD 0     // bytes of padding per tile pixel and plane: 16 spreads the A-fragment reads over the banks, 0 lets more
+                          // workgroups share a CU (7x7 layer 112 -> 75 KB) -- front end alone 672 -> 643 us (profiles/r06_convpad_ab.txt)
+#endif
 template <int K, int S, int CIN, int COUT>
 __global__ void __launch_bounds__(256) conv_x3_kernel(const ConvParams p) {
   constexpr int PAD = K / 2, TH = 8, TW = 16;
   constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
   constexpr int KC = CIN >= 32 ? 32 : 16, NCH = CIN / KC, CPL = KC / 4;   // channels per MFMA step, steps per tap, halfs per lane
-  constexpr int PSTR = CIN * 2 + 16;                                    // LDS bytes per tile pixel and plane
+  constexpr int PSTR = CIN * 2 + CONV_X3_PAD;                           // LDS bytes per tile pixel and plane
   constexpr int PLANE = IH * IW * PSTR;
   constexpr int NT = COUT / 16, WPN = 4 / NT, MTW = TH / WPN;           // waves per channel tile, rows (m-tiles) per wave
   constexpr int CH4 = CIN / 4, NITEM = IH * IW * CH4;
@@ -915,7 +919,7 @@ __global__ void __launch_bounds__(256) conv_x3_kernel(const ConvParams p) {
     }
   }
 }
-constexpr int conv_x3_lds_bytes(int K, int S, int CIN) { return 3 * ((8 - 1) * S + K) * ((16 - 1) * S + K) * (CIN * 2 + 16); }
+constexpr int conv_x3_lds_bytes(int K, int S, int CIN) { return 3 * ((8 - 1) * S + K) * ((16 - 1) * S + K) * (CIN * 2 + CONV_X3_PAD); }
 
 // First layer of BOTH towers in one workgroup (7x7 stride 2, 16 fp32 input channels -> 32 channels per tower): the two
 // towers read the same super-state, so the halo tile is staged once and feeds four 16-channel output tiles.  Unlike
