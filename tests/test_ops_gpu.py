@@ -322,6 +322,96 @@ def test_pyramid_pack_split_and_x2_corr_against_oracle():
                        torch.nan_to_num(torch.from_numpy(x2).cuda().reshape(-1, 882), nan=-7.0))
 
 
+@pytest.mark.parametrize("mode", ["f16", "x2", "f32"])
+def test_correlation_at_the_benchmark_size_by_properties(mode):
+    """The tracker's correlation launch at BASELINE configs[1]'s OWN size -- 40,000 factors, 36 ring slots of 120 x 160 x 128
+    planes (+ the 4x4-mean level), 3 x 36 x 96 patch rows, padded output rows, ring-buffer modulo, a target-frame-major
+    schedule -- where the oracle cannot follow factor by factor in seconds, through what does not depend on the size:
+      * a random sample of 320 factors against the C oracle's restatement of the reference kernel (both levels);
+      * the schedule (none, target-frame major, a random permutation) changes no bit;
+      * features scaled by a power of two scale the volume by exactly that power (fp32 paths and the fp16 path's normal range);
+      * permuting the factors permutes the rows; factors that see nothing of either plane give zero rows.
+    mode: the three instantiations the tracker launches -- fp16 features (the shipped precision), fp32 features as two fp16
+    parts (`x2`, the fp32 default), fp32 features on the fp32 matrix cores."""
+    from rampvo_amd import ops
+    from rampvo_amd._lib import RAMP_NHWC32
+    rng = np.random.default_rng(17)
+    g = torch.Generator(device="cuda").manual_seed(17)
+    E, M, slots, H, W = 40000, 96, 36, 120, 160
+    f1 = torch.randn(3 * slots * M, 3, 3, 128, generator=g, device="cuda") * 0.5
+    maps = torch.randn(slots, H, W, 128, generator=g, device="cuda") * 0.5
+    # (no feature within a factor 64 of the fp16 normal-range limit: below it an operand changes class -- fp16 subnormal, or
+    # the split's "low part only" rule -- and a scaled copy would not be the same operand scaled)
+    keep = lambda t: torch.where(t.abs() < 2.0 ** -8, torch.full_like(t, 2.0 ** -8).copysign(t), t)
+    f1, maps = keep(f1), keep(maps)
+    jj = np.sort(rng.integers(100, 100 + 31, E)).astype(np.int64)
+    kk = rng.integers(0, 9 * slots * M, E).astype(np.int64)                    # (taken modulo 3 slots M inside the kernel)
+    cx, cy = rng.uniform(-4, W + 4, E), rng.uniform(-4, H + 4, E)
+    sc = rng.choice([0.8, 1.0, 1.2, 1.45, 1.9, 6.0], E, p=[0.05, 0.53, 0.28, 0.10, 0.02, 0.02])
+    d = np.arange(-1, 2, dtype=np.float64)
+    x = cx[:, None, None] + sc[:, None, None] * d[None, None, :] + rng.normal(0, 0.05, (E, 3, 3))
+    y = cy[:, None, None] + sc[:, None, None] * d[None, :, None] + rng.normal(0, 0.05, (E, 3, 3))
+    coords_np = np.stack([x, y], 1).astype(np.float32)
+    far = rng.random(E) < 0.3
+    coords_np[far] += 5000.0                                                 # nothing in either plane
+    coords = cu(coords_np)
+    kkc, jjc = cu(kk), cu(jj)
+    if mode == "f16":
+        f1m, mm = f1.half(), maps.half()
+    else:
+        f1m, mm = f1, maps
+    l1 = torch.empty(slots, H, 128 // (32 if mode == "f16" else 16), W, 32 if mode == "f16" else 16, dtype=mm.dtype, device="cuda")
+    l4 = torch.empty(slots, H // 4, l1.shape[2], W // 4, l1.shape[4], dtype=mm.dtype, device="cuda")
+    for n in range(slots):
+        ops.pyramid_pack(mm[n], l1[n], l4[n], split=(mode == "x2"))
+    fast = {"f16": None, "x2": 2, "f32": 1}[mode]
+    kw = dict(row_elems=896, mod_ii=3 * slots * M, mod_jj=slots, fast_f32=fast)
+    run = lambda a=f1m, c=coords, i=kkc, j=jjc, **k: ops.corr(a, [l1, l4], c, i, j, 3, (1.0, 4.0), RAMP_NHWC32, **dict(kw, **k))
+    byjj = torch.argsort(jjc, stable=True).int()
+    base = run(order=byjj)
+    assert base.shape == (E, 896) and float(base[:, 882:].abs().max()) == 0.0
+    same = lambda a, b: torch.equal(torch.nan_to_num(a.float(), nan=-7.0), torch.nan_to_num(b.float(), nan=-7.0))
+    # --- schedule
+    perm = torch.from_numpy(rng.permutation(E).astype(np.int32)).cuda()
+    assert same(run(), base) and same(run(order=perm), base)
+    # --- dead factors
+    assert float(base[cu(far)].abs().max()) == 0.0 and float(base[cu(~far)].abs().max()) > 0
+    # --- permuting the factors permutes the rows
+    p2 = torch.from_numpy(rng.permutation(E)).cuda()
+    assert same(run(c=coords[p2], i=kkc[p2], j=jjc[p2]), base[p2])
+    # --- scaling by powers of two (the split of the x2 path and every rounding commute with it; fp16 outputs: normal range)
+    for s_ in (4.0, 0.25):
+        scaled = run(a=f1m * s_, order=byjj).float()
+        want = base.float() * s_
+        if mode == "f16":
+            ok = (want.abs() >= 2.0 ** -12) & (want.abs() < 3.0e4) | (want == 0)
+            assert torch.equal(scaled[ok], want[ok]) and float(ok.float().mean()) > 0.9
+        else:
+            assert torch.equal(scaled, want)
+    # --- a sample against the oracle (the pooled level restated with torch's avg_pool2d, checked to the bit elsewhere)
+    import torch.nn.functional as F
+    pick = np.sort(rng.choice(np.nonzero(~far)[0], 320, replace=False))
+    used = np.unique(jj[pick] % slots)
+    remap = {int(u): k for k, u in enumerate(used)}
+    m_used = mm[torch.from_numpy(used).cuda()].float()
+    fm2 = m_used.permute(0, 3, 1, 2).contiguous()
+    fm4 = F.avg_pool2d(fm2, 4, 4) if mode != "f16" else F.avg_pool2d(fm2, 4, 4).half().float()
+    rows = (kk[pick] % (3 * slots * M)).astype(np.int64)
+    f1s = f1m[torch.from_numpy(rows).cuda()].float().permute(0, 3, 1, 2).contiguous().cpu().numpy()[None]
+    ii_s = np.arange(320, dtype=np.int64)
+    jj_s = np.array([remap[int(v % slots)] for v in jj[pick]], dtype=np.int64)
+    c_s = coords_np[pick][None]
+    ref0 = orc.corr(f1s, fm2.cpu().numpy()[None], c_s, ii_s, jj_s, 3)[0]
+    ref1 = orc.corr(f1s, fm4.cpu().numpy()[None], c_s / 4, ii_s, jj_s, 3)[0]
+    got = base[torch.from_numpy(pick).cuda(), :882].float().cpu().numpy().reshape(320, 7, 7, 3, 3, 2)
+    tol = 1.5e-3 if mode == "f16" else 1e-5
+    for lvl, ref in ((0, ref0), (1, ref1)):
+        assert np.array_equal(np.isnan(got[..., lvl]), np.isnan(ref))
+        err = float(np.nanmax(np.abs(got[..., lvl] - ref))) / max(1.0, float(np.nanmax(np.abs(ref))))
+        print("%s level %d: %.2e of the scale from the oracle on 320 sampled factors" % (mode, lvl, err))
+        assert err <= tol, (mode, lvl, err)
+
+
 def test_corr_matches_reference_call_site_golden():
     """G3 (tests/golden/corr.npz): what the reference's altcorr.corr python call site returned for both pyramid
     levels, stacked as Ramp_vo.corr stacks them (ramp/Ramp_vo.py:175-182)"""
