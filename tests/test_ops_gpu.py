@@ -633,6 +633,61 @@ def test_ba_matches_oracle(case):
     assert np.array_equal(pt[:, :2], s["patches"][:, :2])
 
 
+def test_ba_at_the_benchmark_size_by_properties():
+    """fastba.BA at BASELINE configs[1]'s graph size -- 23 keyframes x 96 patches, lifetime 13: ~42k factors, a 10-pose
+    optimisation window, two Gauss-Newton steps -- through what does not depend on the size (the step itself is checked
+    against the oracle at this size by test_full_size_update_step_against_cpu_oracle; here the solver's invariants):
+      * a fixed point: with the targets on the solver's own reprojection (cuda_ba.reproject) and unit confidence the
+        residuals are zero and poses / depths stay where they are;
+      * poses outside [t0, t1) and the patches' pixel coordinates are never written, the run is bit-reproducible;
+      * the factor list's order is bookkeeping: a permuted list gives the same step to fp32 summation accuracy;
+      * a second call continues from the first one's state: 2 + 2 steps = 4 steps bit for bit."""
+    from rampvo_amd import ops
+    s = ba_scene(seed=31, n_frames=23, M=96, lifetime=13, n_total_frames=36)
+    E, nf = len(s["ii"]), s["n_frames"]
+    assert E > 40000
+    t0, t1 = nf - 10, nf
+    dev = lambda: (cu(s["poses"]), cu(s["patches"]))
+    args = lambda tg, w, perm=None: (cu(s["intr"]), tg if perm is None else tg[perm], w if perm is None else w[perm], cu(s["lmbda"]),
+                                     *(cu(s[k]) if perm is None else cu(s[k])[perm] for k in ("ii", "jj", "kk")))
+    target, weight = cu(s["target"]), cu(s["weight"])
+    # --- fixed point
+    poses, patches = dev()
+    proj = ops.reproject(poses, patches, cu(s["intr"]), cu(s["ii"]), cu(s["jj"]), cu(s["kk"]))[0, :, :, 1, 1].contiguous()
+    ops.ba(poses, patches, *args(proj, torch.ones_like(weight)), t0, t1, 2)
+    dp = float((poses - cu(s["poses"])).abs().max()); dd = float((patches - cu(s["patches"])).abs().max())
+    print("zero-residual problem: poses move %.2e, depths %.2e" % (dp, dd))
+    assert dp <= 1e-6 and dd <= 1e-6
+    # --- a real step: untouched state, reproducibility
+    runs = []
+    for _ in range(2):
+        poses, patches = dev()
+        info = torch.zeros(1, dtype=torch.int32, device="cuda")
+        ops.ba(poses, patches, *args(target, weight), t0, t1, 2, info)
+        assert int(info.item()) == 0
+        runs.append((poses.clone(), patches.clone()))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    p, pt = runs[0]
+    assert torch.equal(p[:t0], cu(s["poses"])[:t0]) and torch.equal(p[t1:], cu(s["poses"])[t1:])
+    assert torch.equal(pt[:, :2], cu(s["patches"])[:, :2])
+    step = float((p - cu(s["poses"])).abs().max())
+    assert step > 1e-4                                        # the problem is not degenerate
+    # --- the order of the factor list
+    perm = torch.from_numpy(np.random.default_rng(5).permutation(E)).cuda()
+    poses, patches = dev()
+    ops.ba(poses, patches, *args(target, weight, perm), t0, t1, 2)
+    ep = float((poses - p).abs().max()) / max(1.0, float(p.abs().max())); ed = float((patches[:, 2] - pt[:, 2]).abs().max())
+    print("permuted factor list: poses %.2e, depths %.2e from the listed order (GN step %.2e)" % (ep, ed, step))
+    assert ep <= 1e-5 and ed <= 1e-4 * max(1.0, float(pt[:, 2].abs().max()))
+    # --- 2 + 2 iterations = 4 iterations
+    a_p, a_pt = dev()
+    ops.ba(a_p, a_pt, *args(target, weight), t0, t1, 4)
+    b_p, b_pt = dev()
+    ops.ba(b_p, b_pt, *args(target, weight), t0, t1, 2)
+    ops.ba(b_p, b_pt, *args(target, weight), t0, t1, 2)
+    assert torch.equal(a_p, b_p) and torch.equal(a_pt, b_pt)
+
+
 def test_ba_is_deterministic():
     from rampvo_amd import ops
     s = ba_scene(seed=12, n_frames=9, M=14, lifetime=4, n_total_frames=16, far=True)
